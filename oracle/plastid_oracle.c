@@ -1,0 +1,355 @@
+/*
+ * plastid_oracle.c -- TEST INFRASTRUCTURE ONLY (the parity oracle).
+ *
+ * A plain, single-threaded C restatement of the reference's per-position read
+ * counting path, written to be *obviously the same algorithm* as the reference,
+ * not to be fast.  It operates on the packed alignment arrays that the product
+ * stages to HBM, materialises `read.positions` for every read exactly as the
+ * reference consumes it, and then follows the reference line by line.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  Nothing under plastid_amd/ links, imports or calls it.
+ *
+ * Parity pinning: this file is checked against golden vectors generated in the
+ * build container by the reference's own Cython/Python code
+ * (tests/golden/make_golden.py -> tests/golden/ npz fixtures), including the closed-form
+ * known-answer vectors of plastid/test/unit/genomics/test_map_factories.py:29-49.
+ *
+ * Reference files followed (relative to /root/reference):
+ *   plastid/genomics/map_factories.pyx:200-265   CenterMapFactory.__call__
+ *   plastid/genomics/map_factories.pyx:308-367   FivePrimeMapFactory.__call__
+ *   plastid/genomics/map_factories.pyx:407-466   ThreePrimeMapFactory.__call__
+ *   plastid/genomics/map_factories.pyx:585-650   VariableFivePrimeMapFactory.__call__
+ *   plastid/genomics/map_factories.pyx:724-780   StratifiedVariableFivePrimeMapFactory.__call__
+ *   plastid/genomics/map_factories.pyx:837-839   SizeFilterFactory.__call__
+ *   plastid/genomics/genome_array.py:800-823     fetch -> strand filter -> filters -> map_fn
+ * Third-party semantics not under /root/reference (pysam 0.19.0 / htslib):
+ *   AlignedSegment.positions = reference coordinates of CIGAR M/=/X bases (SAM spec);
+ *   AlignmentFile.fetch(reference,start,end) yields, in file order, records with
+ *   pos < end && endpos > start, endpos = pos+1 for records without aligned bases
+ *   (readable in the vendored kent/src/htslib/sam.c:329-341, hts.c:1952-1954).
+ *
+ * Packed alignment layout (same as include/plastid_counts.h):
+ *   records are in reference fetch order: file-major, then (tid,pos) ascending
+ *   (BAM order) within a file.
+ *   tid[i], pos[i]          reference id / leftmost aligned coordinate
+ *   alen[i]                 L = len(read.positions)
+ *   flags[i] bit0           read.is_reverse
+ *   nblk[i]                 number of maximal runs of contiguous aligned
+ *                           reference positions (0 when L == 0)
+ *   file_id[i]              which BAM file (NULL => all 0)
+ *   blk_start/blk_len       the runs of every record with nblk >= 2, record
+ *                           after record (a record with nblk == 1 has the single
+ *                           implicit run [pos, pos+L))
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PO_FIVE 0
+#define PO_THREE 1
+#define PO_CENTER 2
+#define PO_VAR5 3
+#define PO_STRAT5 4
+
+#define PO_STRAND_FWD 1 /* plastid/genomics/c_common.pxd:1-6 */
+#define PO_STRAND_REV 2
+#define PO_STRAND_UNS 3
+
+#define PO_TABLE_LEN 10000 /* map_factories.pxd:10-12 */
+
+#define PO_OK 0
+#define PO_ERR_ARG -1
+#define PO_ERR_UNDEFINED -2 /* reference behaviour undefined (out-of-bounds table/list index) */
+#define PO_ERR_NOMEM -3
+
+typedef struct {
+    int64_t n;
+    const int32_t *tid, *pos;
+    const uint16_t *alen;
+    const uint8_t *flags, *nblk, *file_id;
+    const int32_t *blk_start, *blk_len;
+    int64_t *blk_off; /* derived: first run of record i in blk_* (valid if nblk>=2) */
+    int64_t *ref_end; /* derived: htslib bam_endpos */
+} po_aln;
+
+typedef struct {
+    int kind;
+    int param;           /* offset (FIVE/THREE) or nibble (CENTER) */
+    const int32_t *fw;   /* forward_offsets[PO_TABLE_LEN] */
+    const int32_t *rc;   /* reverse_offsets[PO_TABLE_LEN] */
+    int min_len, max_len; /* STRAT5 */
+    int filt_on, filt_min, filt_max; /* SizeFilterFactory */
+} po_map;
+
+static int po_prepare(po_aln *a) {
+    a->blk_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(a->n + 1));
+    a->ref_end = (int64_t *)malloc(sizeof(int64_t) * (size_t)(a->n + 1));
+    if (!a->blk_off || !a->ref_end) return PO_ERR_NOMEM;
+    int64_t off = 0;
+    for (int64_t i = 0; i < a->n; ++i) {
+        a->blk_off[i] = off;
+        if (a->nblk[i] >= 2) {
+            int64_t last = off + a->nblk[i] - 1;
+            a->ref_end[i] = (int64_t)a->blk_start[last] + a->blk_len[last];
+            off += a->nblk[i];
+        } else if (a->alen[i] > 0) {
+            a->ref_end[i] = (int64_t)a->pos[i] + a->alen[i];
+        } else {
+            a->ref_end[i] = (int64_t)a->pos[i] + 1; /* htslib: no aligned bases */
+        }
+    }
+    return PO_OK;
+}
+
+static void po_release(po_aln *a) {
+    free(a->blk_off);
+    free(a->ref_end);
+    a->blk_off = a->ref_end = NULL;
+}
+
+/* read.positions (pysam get_reference_positions): every aligned reference coordinate, ascending */
+static int po_positions(const po_aln *a, int64_t i, int32_t *P) {
+    int L = 0;
+    if (a->nblk[i] >= 2) {
+        for (int b = 0; b < a->nblk[i]; ++b) {
+            int32_t s = a->blk_start[a->blk_off[i] + b];
+            int32_t n = a->blk_len[a->blk_off[i] + b];
+            for (int32_t x = 0; x < n; ++x) P[L++] = s + x;
+        }
+    } else {
+        for (int32_t x = 0; x < (int32_t)a->alen[i]; ++x) P[L++] = a->pos[i] + x;
+    }
+    return L;
+}
+
+/* Python list indexing with negative wrap-around; *err set when the reference would read out of bounds */
+static int64_t po_pyindex(const int32_t *P, int L, int k, int *err) {
+    if (k < 0) k += L;
+    if (k < 0 || k >= L) {
+        *err = 1;
+        return 0;
+    }
+    return P[k];
+}
+
+/* SizeFilterFactory.__call__, map_factories.pyx:837-839 */
+static int po_size_filter(const po_map *m, int L) {
+    if (!m->filt_on) return 1;
+    return L >= m->filt_min && (L <= m->filt_max || m->filt_max == -1);
+}
+
+/*
+ * One BAMGenomeArray.get_reads_and_counts() call up to and including map_fn
+ * (genome_array.py:800-823) for ONE segment.
+ *   out      : rows*seg_len elements, int64 (point maps) or double (CENTER),
+ *              zero-initialised here like numpy.zeros in the reference
+ *   mapped   : optional n bytes; mapped[i]=1 iff record i is in `reads_out`
+ *   warn     : set to 1 iff the reference would emit its DataWarning
+ */
+static int po_segment(const po_aln *a, const po_map *m, const int64_t *rng_lo, const int64_t *rng_hi,
+                      int64_t nrng, const int32_t *rng_tid, int64_t max_span, int32_t seg_tid,
+                      int64_t seg_start, int64_t seg_end, int seg_strand, void *out, uint8_t *mapped,
+                      uint8_t *warn, int32_t *P) {
+    const int64_t seg_len = seg_end - seg_start;
+    const int rows = (m->kind == PO_STRAT5) ? (m->max_len - m->min_len + 1) : 1;
+    int64_t *icount = (int64_t *)out;
+    double *dcount = (double *)out;
+    int do_warn = 0;
+    int err = 0;
+
+    if (m->kind == PO_CENTER)
+        memset(dcount, 0, sizeof(double) * (size_t)seg_len);
+    else
+        memset(icount, 0, sizeof(int64_t) * (size_t)(rows * seg_len));
+
+    /* which offset table / index rule: chosen by the SEGMENT's strand (Q2) */
+    int read_offset = m->param;
+    const int32_t *offsets = m->fw;
+    if (m->kind == PO_FIVE) {
+        if (seg_strand == PO_STRAND_REV) read_offset = -read_offset - 1; /* :345-346 */
+    } else if (m->kind == PO_THREE) {
+        if (seg_strand != PO_STRAND_REV) read_offset = -read_offset - 1; /* :444-445 */
+    } else if (m->kind == PO_VAR5 || m->kind == PO_STRAT5) {
+        if (seg_strand == PO_STRAND_REV) offsets = m->rc; /* :625-626, :765-766 */
+    }
+
+    /* itertools.chain over bamfiles: file-major (genome_array.py:800-809).  Ranges are
+     * (file, tid) runs of the record array, already in file-major order. */
+    for (int64_t r = 0; r < nrng; ++r) {
+        if (rng_tid[r] != seg_tid) continue;
+        /* first record that could still overlap: pos > seg_start - max_span */
+        int64_t lo = rng_lo[r], hi = rng_hi[r];
+        int64_t want = seg_start - max_span;
+        int64_t l = lo, h = hi;
+        while (l < h) {
+            int64_t mid = l + (h - l) / 2;
+            if ((int64_t)a->pos[mid] <= want) l = mid + 1; else h = mid;
+        }
+        for (int64_t i = l; i < hi; ++i) {
+            if ((int64_t)a->pos[i] >= seg_end) break;          /* fetch: pos < end        */
+            if (!(a->ref_end[i] > seg_start)) continue;         /* fetch: endpos > start   */
+            const int is_reverse = a->flags[i] & 1;
+            if (seg_strand == PO_STRAND_FWD && is_reverse) continue;  /* genome_array.py:812-813 */
+            if (seg_strand == PO_STRAND_REV && !is_reverse) continue; /* genome_array.py:814-815 */
+            const int L = po_positions(a, i, P);
+            if (!po_size_filter(m, L)) continue;                /* genome_array.py:819-820 */
+
+            switch (m->kind) {
+            case PO_FIVE:
+            case PO_THREE: {
+                if (m->param >= L) { do_warn = 1; continue; }   /* :351-353 / :450-452 */
+                int64_t p = po_pyindex(P, L, read_offset, &err);
+                if (p >= seg_start && p < seg_end) {            /* :356-358 */
+                    if (mapped) mapped[i] = 1;
+                    icount[p - seg_start] += 1;
+                }
+            } break;
+            case PO_CENTER: {
+                const int nibble = m->param;
+                const int map_length = L - 2 * nibble;          /* :245 */
+                if (map_length < 0) { do_warn = 1; continue; }  /* :246-248 */
+                if (map_length > 0) {
+                    const double val = 1.0 / (double)map_length; /* :250 */
+                    for (int k = nibble; k < L - nibble; ++k) {  /* :251-254 */
+                        int64_t coord = (int64_t)P[k] - seg_start;
+                        if (coord >= 0 && coord < seg_len) dcount[coord] += val;
+                    }
+                    if (mapped) mapped[i] = 1;                  /* :256, even if nothing landed */
+                }
+            } break;
+            case PO_VAR5: {
+                if (L >= PO_TABLE_LEN) return PO_ERR_UNDEFINED;
+                const int off = offsets[L];                     /* :631 */
+                if (off == -1) { do_warn = 1; continue; }       /* :633-636 */
+                int64_t p = po_pyindex(P, L, off, &err);
+                if (p >= seg_start && p < seg_end) {            /* :639-641 */
+                    if (mapped) mapped[i] = 1;
+                    icount[p - seg_start] += 1;
+                }
+            } break;
+            case PO_STRAT5: {
+                if (L >= m->min_len && L <= m->max_len) {       /* :771 */
+                    if (L >= PO_TABLE_LEN) return PO_ERR_UNDEFINED;
+                    const int off = offsets[L];                 /* :773, no -1 check (Q7) */
+                    int64_t p = po_pyindex(P, L, off, &err);    /* :774, python wrap */
+                    if (err) return PO_ERR_UNDEFINED;
+                    if (p >= seg_start && p < seg_end) {        /* :776-778 */
+                        if (mapped) mapped[i] = 1;
+                        icount[(int64_t)(L - m->min_len) * seg_len + (p - seg_start)] += 1;
+                    }
+                }
+            } break;
+            default:
+                return PO_ERR_ARG;
+            }
+            if (err) return PO_ERR_UNDEFINED;
+        }
+    }
+    if (m->kind == PO_STRAT5) do_warn = 0; /* never warns (Q15) */
+    if (warn) *warn = (uint8_t)do_warn;
+    return PO_OK;
+}
+
+/*
+ * Batch entry point: every segment is an independent reference call.
+ * Segment s writes rows*len(s) elements at out + out_off[s] (element offset),
+ * row-major [rows][len].  `mapped` (optional) is nseg*n bytes.
+ */
+int po_count_segments(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
+                      const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
+                      const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
+                      const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
+                      int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
+                      const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
+                      const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped) {
+    po_aln a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.tid = tid; a.pos = pos; a.alen = alen; a.flags = flags; a.nblk = nblk;
+    a.file_id = file_id; a.blk_start = blk_start; a.blk_len = blk_len;
+    po_map m;
+    memset(&m, 0, sizeof(m));
+    m.kind = kind; m.param = param; m.fw = fw; m.rc = rc; m.min_len = min_len; m.max_len = max_len;
+    m.filt_on = filt_on; m.filt_min = filt_min; m.filt_max = filt_max;
+    if (kind < PO_FIVE || kind > PO_STRAT5) return PO_ERR_ARG;
+    if ((kind == PO_VAR5 || kind == PO_STRAT5) && (!fw || !rc)) return PO_ERR_ARG;
+    if (kind == PO_STRAT5 && max_len < min_len) return PO_ERR_ARG;
+
+    int rcode = po_prepare(&a);
+    if (rcode != PO_OK) { po_release(&a); return rcode; }
+
+    /* (file, tid) runs + the longest reference span, for the fetch emulation */
+    int64_t nrng = 0, cap = 64;
+    int64_t *rng_lo = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+    int64_t *rng_hi = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+    int32_t *rng_tid = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+    int64_t max_span = 1;
+    int maxL = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int newrun = (i == 0) || tid[i] != tid[i - 1] ||
+                     (file_id && file_id[i] != file_id[i - 1]);
+        if (newrun) {
+            if (nrng == cap) {
+                cap *= 2;
+                rng_lo = (int64_t *)realloc(rng_lo, sizeof(int64_t) * (size_t)cap);
+                rng_hi = (int64_t *)realloc(rng_hi, sizeof(int64_t) * (size_t)cap);
+                rng_tid = (int32_t *)realloc(rng_tid, sizeof(int32_t) * (size_t)cap);
+            }
+            if (nrng > 0) rng_hi[nrng - 1] = i;
+            rng_lo[nrng] = i; rng_tid[nrng] = tid[i]; ++nrng;
+        } else if (pos[i] < pos[i - 1]) {
+            free(rng_lo); free(rng_hi); free(rng_tid); po_release(&a);
+            return PO_ERR_ARG; /* not coordinate sorted: pysam.fetch would raise */
+        }
+        if (a.ref_end[i] - pos[i] > max_span) max_span = a.ref_end[i] - pos[i];
+        if (alen[i] > maxL) maxL = alen[i];
+    }
+    if (nrng > 0) rng_hi[nrng - 1] = n;
+
+    int32_t *P = (int32_t *)malloc(sizeof(int32_t) * (size_t)(maxL + 1));
+    for (int64_t s = 0; s < nseg && rcode == PO_OK; ++s) {
+        const int64_t len = seg_end[s] - seg_start[s];
+        if (len < 0) { rcode = PO_ERR_ARG; break; }
+        char *dst = (char *)out + (size_t)out_off[s] * 8u; /* int64 and double are both 8 bytes */
+        rcode = po_segment(&a, &m, rng_lo, rng_hi, nrng, rng_tid, max_span, seg_tid[s], seg_start[s],
+                           seg_end[s], seg_strand[s], dst, mapped ? mapped + (size_t)s * (size_t)n : NULL,
+                           warn ? warn + s : NULL, P);
+    }
+    free(P); free(rng_lo); free(rng_hi); free(rng_tid);
+    po_release(&a);
+    return rcode;
+}
+
+/* The CIGAR -> aligned-run step restated from the SAM spec (what pysam's
+ * get_reference_positions() yields, grouped into maximal contiguous runs).
+ * ops: BAM op codes 0..8 = MIDNSHP=X.  Returns number of runs, or -1. */
+int po_cigar_to_runs(int32_t pos, int ncig, const uint8_t *op, const int32_t *oplen, int maxruns,
+                     int32_t *run_start, int32_t *run_len, int32_t *aligned_len) {
+    int nrun = 0;
+    int32_t ref = pos, L = 0;
+    int open = 0;
+    for (int c = 0; c < ncig; ++c) {
+        switch (op[c]) {
+        case 0: case 7: case 8: /* M = X : consume query+reference, emit positions */
+            if (oplen[c] > 0) {
+                if (open && run_start[nrun - 1] + run_len[nrun - 1] == ref) {
+                    run_len[nrun - 1] += oplen[c];
+                } else {
+                    if (nrun == maxruns) return -1;
+                    run_start[nrun] = ref; run_len[nrun] = oplen[c]; ++nrun; open = 1;
+                }
+                ref += oplen[c]; L += oplen[c];
+            }
+            break;
+        case 2: case 3: /* D N : consume reference only */
+            ref += oplen[c];
+            break;
+        case 1: case 4: case 5: case 6: /* I S H P : nothing on the reference */
+            break;
+        default:
+            return -1;
+        }
+    }
+    if (aligned_len) *aligned_len = L;
+    return nrun;
+}

@@ -1,0 +1,423 @@
+"""Packed alignment records: the host-side staging format of the counting engine.
+
+The reference consumes, per read, ``read.positions`` (pysam
+``get_reference_positions()``: ascending reference coordinates of the CIGAR
+M/=/X bases) and ``read.is_reverse`` (plastid/genomics/map_factories.pyx:243,
+349, 448, 629, 769, 838; plastid/genomics/genome_array.py:812-815).  A
+:class:`PackedAlignments` holds exactly that information for a whole
+coordinate-sorted BAM file as flat numpy arrays (structure of arrays), which is
+what gets bulk-staged to HBM:
+
+==============  ========  ====================================================
+``tid``         int32     reference (contig) index
+``pos``         int32     leftmost aligned reference coordinate (0-based)
+``alen``        uint16    ``L = len(read.positions)`` ("read length" in plastid)
+``flags``       uint8     bit0 = ``read.is_reverse``; bit7 = excluded by a
+                          host-side (arbitrary Python) read filter
+``nblk``        uint8     number of maximal runs of contiguous aligned
+                          reference positions (0 iff ``L == 0``)
+``blk_start``   int32     runs of every record with ``nblk >= 2``, record after
+``blk_len``     int32     record (a ``nblk == 1`` record has the single implicit
+                          run ``[pos, pos + L)``)
+==============  ========  ====================================================
+
+Records must be in BAM order: sorted by ``(tid, pos)``, ties in file order.
+
+A :class:`PackedAlignments` also duck-types the small part of
+``pysam.AlignmentFile`` that ``BAMGenomeArray`` uses (``fetch``, ``references``,
+``lengths``, ``mapped``, ``close`` -- genome_array.py:669, 679, 690, 802-807), so
+it can be handed to anything that expects an open alignment file.
+"""
+import numpy as np
+
+FLAG_REVERSE = 0x01
+FLAG_EXCLUDED = 0x80
+
+MAX_ALIGNED_LEN = 65535
+MAX_RUNS = 255
+
+# BAM CIGAR op codes (SAM spec section 4.2): MIDNSHP=X
+_CIGAR_CHARS = "MIDNSHP=X"
+_OP_CODE = {c: i for i, c in enumerate(_CIGAR_CHARS)}
+
+
+def positions_to_runs(positions):
+    """Group an ascending list of reference positions into maximal contiguous
+    runs ``[(start, length), ...]``."""
+    runs = []
+    start = prev = None
+    for p in positions:
+        p = int(p)
+        if start is None:
+            start = prev = p
+        elif p == prev + 1:
+            prev = p
+        else:
+            runs.append((start, prev - start + 1))
+            start = prev = p
+    if start is not None:
+        runs.append((start, prev - start + 1))
+    return runs
+
+
+def parse_cigar_string(cigar):
+    """``"10M2D5M"`` -> ``[(0, 10), (2, 2), (0, 5)]`` (BAM op codes)."""
+    out = []
+    num = ""
+    for ch in cigar:
+        if ch.isdigit():
+            num += ch
+        else:
+            if ch not in _OP_CODE or not num:
+                raise ValueError("Malformed CIGAR string '%s'" % cigar)
+            out.append((_OP_CODE[ch], int(num)))
+            num = ""
+    if num:
+        raise ValueError("Malformed CIGAR string '%s'" % cigar)
+    return out
+
+
+def cigar_to_runs(pos, cigartuples):
+    """Aligned reference runs of one alignment (SAM spec: M/=/X consume query and
+    reference and yield aligned positions; D/N advance the reference only;
+    I/S/H/P touch nothing on the reference).
+
+    Returns ``(runs, aligned_len)`` with ``runs = [(start, length), ...]``.
+    """
+    runs = []
+    ref = int(pos)
+    L = 0
+    for op, n in cigartuples:
+        n = int(n)
+        if op in (0, 7, 8):
+            if n > 0:
+                if runs and runs[-1][0] + runs[-1][1] == ref:
+                    runs[-1] = (runs[-1][0], runs[-1][1] + n)
+                else:
+                    runs.append((ref, n))
+                ref += n
+                L += n
+        elif op in (2, 3):
+            ref += n
+        elif op in (1, 4, 5, 6):
+            pass
+        else:
+            raise ValueError("Unknown CIGAR op code %r" % (op,))
+    return runs, L
+
+
+class PackedRead(object):
+    """Minimal read object yielded by :meth:`PackedAlignments.fetch`: carries
+    what the reference's mapping functions and filters consume."""
+
+    __slots__ = ("source", "index", "reference_id", "reference_start", "is_reverse", "_runs")
+
+    def __init__(self, source, index, tid, pos, is_reverse, runs):
+        self.source = source
+        self.index = index
+        self.reference_id = tid
+        self.reference_start = pos
+        self.is_reverse = is_reverse
+        self._runs = runs
+
+    @property
+    def positions(self):
+        out = []
+        for s, n in self._runs:
+            out.extend(range(s, s + n))
+        return out
+
+    def get_reference_positions(self):
+        return self.positions
+
+    @property
+    def reference_end(self):
+        if not self._runs:
+            return None
+        s, n = self._runs[-1]
+        return s + n
+
+    def __repr__(self):
+        return "<PackedRead #%d tid=%d pos=%d %s runs=%r>" % (
+            self.index, self.reference_id, self.reference_start,
+            "-" if self.is_reverse else "+", self._runs)
+
+
+class PackedAlignments(object):
+    """One coordinate-sorted alignment file as flat arrays (see module doc)."""
+
+    def __init__(self, tid, pos, alen, flags, nblk, blk_start=None, blk_len=None,
+                 references=None, lengths=None, mapped=None, read_objects=None, validate=True):
+        self.tid = np.ascontiguousarray(tid, dtype=np.int32)
+        self.pos = np.ascontiguousarray(pos, dtype=np.int32)
+        self.alen = np.ascontiguousarray(alen, dtype=np.uint16)
+        self.flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self.nblk = np.ascontiguousarray(nblk, dtype=np.uint8)
+        self.blk_start = np.ascontiguousarray(
+            np.zeros(0, np.int32) if blk_start is None else blk_start, dtype=np.int32)
+        self.blk_len = np.ascontiguousarray(
+            np.zeros(0, np.int32) if blk_len is None else blk_len, dtype=np.int32)
+        n = len(self.tid)
+        if references is None:
+            ntid = int(self.tid.max()) + 1 if n else 1
+            references = ["chr%d" % i for i in range(ntid)]
+        self.references = tuple(references)
+        if lengths is None:
+            lengths = [0] * len(self.references)
+        self.lengths = tuple(int(x) for x in lengths)
+        self.mapped = int(n if mapped is None else mapped)
+        self._read_objects = read_objects
+        self._blk_off = None
+        self._tid_bounds = None
+        self._max_span = None
+        if validate:
+            self.validate()
+
+    # ------------------------------------------------------------------ basic
+    def __len__(self):
+        return len(self.tid)
+
+    @property
+    def n(self):
+        return len(self.tid)
+
+    def validate(self):
+        n = self.n
+        for name in ("pos", "alen", "flags", "nblk"):
+            if len(getattr(self, name)) != n:
+                raise ValueError("PackedAlignments: array '%s' has wrong length" % name)
+        if n:
+            if self.tid.min() < 0 or self.tid.max() >= len(self.references):
+                raise ValueError("PackedAlignments: tid out of range of `references`")
+            key = (self.tid.astype(np.int64) << 32) | self.pos.astype(np.int64)
+            if np.any(key[1:] < key[:-1]):
+                raise ValueError(
+                    "PackedAlignments: records are not sorted by (tid, pos); "
+                    "alignment files must be coordinate sorted")
+            if self.pos.min() < 0:
+                raise ValueError("PackedAlignments: negative alignment start")
+        multi = self.nblk >= 2
+        if int(self.nblk[multi].astype(np.int64).sum()) != len(self.blk_start) or \
+                len(self.blk_start) != len(self.blk_len):
+            raise ValueError("PackedAlignments: run arrays do not match `nblk`")
+        single = self.nblk == 1
+        if np.any(self.alen[single] == 0) or np.any((self.nblk == 0) != (self.alen == 0)):
+            raise ValueError("PackedAlignments: nblk/alen mismatch")
+        if len(self.blk_start):
+            off = self.block_offsets()
+            idx = np.nonzero(multi)[0]
+            # first run starts at pos; runs ascending and non-adjacent; lengths sum to alen
+            if np.any(self.blk_start[off[idx]] != self.pos[idx]):
+                raise ValueError("PackedAlignments: first run of a record must start at pos")
+            if np.any(self.blk_len <= 0):
+                raise ValueError("PackedAlignments: empty run")
+            sums = np.add.reduceat(self.blk_len.astype(np.int64), off[idx])
+            if np.any(sums != self.alen[idx]):
+                raise ValueError("PackedAlignments: run lengths do not sum to alen")
+            ends = self.blk_start.astype(np.int64) + self.blk_len
+            inner = np.ones(len(self.blk_start), bool)
+            inner[off[idx]] = False  # first run of each record has no predecessor
+            if np.any(self.blk_start[inner] <= ends[np.nonzero(inner)[0] - 1]):
+                raise ValueError("PackedAlignments: runs must be ascending and non-adjacent")
+
+    def block_offsets(self):
+        """``off[i]`` = index of record ``i``'s first run in ``blk_*`` (meaningful
+        for ``nblk >= 2`` records)."""
+        if self._blk_off is None:
+            cnt = np.where(self.nblk >= 2, self.nblk, 0).astype(np.int64)
+            off = np.zeros(self.n + 1, np.int64)
+            np.cumsum(cnt, out=off[1:])
+            self._blk_off = off
+        return self._blk_off
+
+    def tid_bounds(self):
+        """``b[t]:b[t+1]`` = record range of contig ``t``."""
+        if self._tid_bounds is None:
+            self._tid_bounds = np.searchsorted(
+                self.tid, np.arange(len(self.references) + 1), side="left").astype(np.int64)
+        return self._tid_bounds
+
+    def ref_end(self):
+        """htslib ``bam_endpos``: one past the last aligned reference position
+        (``pos + 1`` for records without aligned bases)."""
+        end = self.pos.astype(np.int64) + np.maximum(self.alen.astype(np.int64), 1)
+        multi = np.nonzero(self.nblk >= 2)[0]
+        if len(multi):
+            off = self.block_offsets()
+            last = off[multi] + self.nblk[multi] - 1
+            end[multi] = self.blk_start[last].astype(np.int64) + self.blk_len[last]
+        return end
+
+    def runs_of(self, i):
+        if self.nblk[i] >= 2:
+            o = int(self.block_offsets()[i])
+            return [(int(self.blk_start[o + b]), int(self.blk_len[o + b]))
+                    for b in range(int(self.nblk[i]))]
+        if self.alen[i] == 0:
+            return []
+        return [(int(self.pos[i]), int(self.alen[i]))]
+
+    def read(self, i):
+        """Read object for record ``i`` (the original object if this file was
+        packed from read objects, else a :class:`PackedRead`)."""
+        if self._read_objects is not None:
+            return self._read_objects[i]
+        return PackedRead(self, int(i), int(self.tid[i]), int(self.pos[i]),
+                          bool(self.flags[i] & FLAG_REVERSE), self.runs_of(i))
+
+    # ------------------------------------------- pysam.AlignmentFile duck type
+    def fetch(self, reference=None, start=None, end=None, **kwargs):
+        """Records overlapping ``reference:start-end`` in file order (htslib rule:
+        ``pos < end and endpos > start``)."""
+        for i in self.fetch_indices(reference, start, end):
+            yield self.read(i)
+
+    def fetch_indices(self, reference=None, start=None, end=None):
+        if reference is None:
+            return np.arange(self.n)
+        try:
+            t = self.references.index(reference)
+        except ValueError:
+            raise ValueError("invalid reference `%s`" % reference)
+        b = self.tid_bounds()
+        lo, hi = int(b[t]), int(b[t + 1])
+        if start is None:
+            start = 0
+        if end is None:
+            end = np.iinfo(np.int64).max
+        hi = lo + int(np.searchsorted(self.pos[lo:hi], end, side="left"))
+        if self._max_span is None:
+            self._max_span = int((self.ref_end() - self.pos).max()) if self.n else 1
+        lo2 = lo + int(np.searchsorted(self.pos[lo:hi], start - self._max_span, side="right"))
+        idx = np.arange(lo2, hi)
+        if len(idx):
+            idx = idx[self.ref_end()[lo2:hi] > start]
+        return idx
+
+    def close(self):
+        pass
+
+    # ------------------------------------------------------------ constructors
+    @classmethod
+    def from_runs(cls, tids, is_reverse, runs_per_read, references=None, lengths=None,
+                  mapped=None, read_objects=None, sort=False):
+        """Build from per-read lists of aligned runs ``[(start, len), ...]``."""
+        n = len(runs_per_read)
+        tid = np.asarray(tids, dtype=np.int32) if np.ndim(tids) else np.full(n, tids, np.int32)
+        pos = np.zeros(n, np.int32)
+        alen = np.zeros(n, np.int64)
+        nblk = np.zeros(n, np.int64)
+        flags = np.zeros(n, np.uint8)
+        flags[np.asarray(is_reverse, dtype=bool)] = FLAG_REVERSE
+        order = None
+        for i, runs in enumerate(runs_per_read):
+            nblk[i] = len(runs)
+            if runs:
+                pos[i] = runs[0][0]
+                alen[i] = sum(r[1] for r in runs)
+        if alen.max(initial=0) > MAX_ALIGNED_LEN:
+            raise ValueError("alignments with more than %d aligned positions are not supported"
+                             % MAX_ALIGNED_LEN)
+        if nblk.max(initial=0) > MAX_RUNS:
+            raise ValueError("alignments with more than %d aligned runs are not supported" % MAX_RUNS)
+        if sort and n:
+            key = (tid.astype(np.int64) << 32) | pos.astype(np.int64)
+            order = np.argsort(key, kind="stable")
+            tid, pos, alen, nblk, flags = tid[order], pos[order], alen[order], nblk[order], flags[order]
+            runs_per_read = [runs_per_read[j] for j in order]
+            if read_objects is not None:
+                read_objects = [read_objects[j] for j in order]
+        bs, bl = [], []
+        for runs in runs_per_read:
+            if len(runs) >= 2:
+                for s, ln in runs:
+                    bs.append(s)
+                    bl.append(ln)
+        out = cls(tid, pos, alen.astype(np.uint16), flags, nblk.astype(np.uint8), bs, bl,
+                  references=references, lengths=lengths, mapped=mapped, read_objects=read_objects)
+        out.sort_order = order
+        return out
+
+    @classmethod
+    def from_reads(cls, reads, tids=None, **kwargs):
+        """Build from read objects exposing ``positions`` and ``is_reverse`` (and
+        ``reference_id`` unless `tids` is given) -- e.g. ``pysam.AlignedSegment``."""
+        reads = list(reads)
+        runs = [positions_to_runs(r.positions) for r in reads]
+        rev = [bool(r.is_reverse) for r in reads]
+        if tids is None:
+            tids = [int(getattr(r, "reference_id", 0)) for r in reads]
+            tids = [t if t >= 0 else 0 for t in tids]
+        return cls.from_runs(tids, rev, runs, read_objects=reads, **kwargs)
+
+    @classmethod
+    def from_cigars(cls, tids, pos, cigars, is_reverse, **kwargs):
+        """Build from ``(pos, CIGAR)`` pairs; `cigars` are strings or lists of
+        ``(op, length)`` tuples in BAM op codes."""
+        runs = []
+        for p, cg in zip(pos, cigars):
+            if isinstance(cg, str):
+                cg = parse_cigar_string(cg)
+            r, _ = cigar_to_runs(p, cg)
+            if not r:
+                # no aligned bases: keep the placement so fetch() semantics survive
+                runs.append([])
+            else:
+                runs.append(r)
+        out = cls.from_runs(tids, is_reverse, runs, **kwargs)
+        # records without aligned bases keep their stated position
+        if any(len(r) == 0 for r in runs):
+            order = getattr(out, "sort_order", None)
+            p_arr = np.asarray(pos, dtype=np.int32)
+            if order is not None:
+                p_arr = p_arr[order]
+            empty = out.nblk == 0
+            out.pos[empty] = p_arr[empty]
+            out.validate()
+        return out
+
+    @classmethod
+    def from_ungapped(cls, tid, pos, alen, is_reverse, **kwargs):
+        """Fast path: every read is a single ``<L>M`` run (arrays in, no Python loop)."""
+        pos = np.asarray(pos, dtype=np.int32)
+        alen = np.asarray(alen)
+        n = len(pos)
+        tid = np.asarray(tid, dtype=np.int32) if np.ndim(tid) else np.full(n, tid, np.int32)
+        flags = np.where(np.asarray(is_reverse, dtype=bool), FLAG_REVERSE, 0).astype(np.uint8)
+        nblk = (alen > 0).astype(np.uint8)
+        return cls(tid, pos, alen.astype(np.uint16), flags, nblk, **kwargs)
+
+    def subset(self, mask_or_index):
+        """New :class:`PackedAlignments` with the selected records (order kept)."""
+        idx = np.asarray(mask_or_index)
+        if idx.dtype == bool:
+            idx = np.nonzero(idx)[0]
+        off = self.block_offsets()
+        multi = idx[self.nblk[idx] >= 2]
+        if len(multi):
+            sel = np.concatenate([np.arange(off[i], off[i] + self.nblk[i]) for i in multi])
+        else:
+            sel = np.zeros(0, np.int64)
+        ro = None if self._read_objects is None else [self._read_objects[i] for i in idx]
+        return PackedAlignments(self.tid[idx], self.pos[idx], self.alen[idx], self.flags[idx],
+                                self.nblk[idx], self.blk_start[sel], self.blk_len[sel],
+                                references=self.references, lengths=self.lengths,
+                                mapped=len(idx), read_objects=ro)
+
+
+def concat_file_major(files):
+    """Concatenate packed files into the single file-major record list the
+    reference iterates (``itertools.chain`` over ``bamfile.fetch``,
+    genome_array.py:800-809).  Returns a dict of arrays incl. ``file_id``."""
+    if not files:
+        raise ValueError("no alignment files")
+    return {
+        "tid": np.concatenate([f.tid for f in files]),
+        "pos": np.concatenate([f.pos for f in files]),
+        "alen": np.concatenate([f.alen for f in files]),
+        "flags": np.concatenate([f.flags for f in files]),
+        "nblk": np.concatenate([f.nblk for f in files]),
+        "file_id": np.concatenate([np.full(f.n, k, np.uint8) for k, f in enumerate(files)]),
+        "blk_start": np.concatenate([f.blk_start for f in files]),
+        "blk_len": np.concatenate([f.blk_len for f in files]),
+    }

@@ -1,0 +1,568 @@
+#!/usr/bin/env python
+"""Generate golden input/output vectors from the REFERENCE ITSELF.
+
+Run only in the build container (needs /root/reference):
+
+    bash tests/golden/build_scratch_reference.sh /tmp/oracle      # ~1 min
+    PYTHONPATH=/tmp/oracle:/tmp/oracle/stubs:. python tests/golden/make_golden.py
+
+``build_scratch_reference.sh`` copies the reference's ``plastid`` package to a
+scratch directory and patches type aliases only (numpy-2/Cython-3 names, the
+pysam ``cimport``); every arithmetic line of ``map_factories.pyx``,
+``roitools.pyx`` and ``genome_array.py`` runs unmodified (SURVEY.md section 8c,
+Appendix B).  pysam is absent from the image, so reads are stub objects that
+carry ``positions`` and ``is_reverse`` -- exactly what the hot path consumes --
+served by a duck-typed alignment source (``fetch/references/lengths/mapped``).
+
+What is written to ``tests/golden/*.npz`` is DATA ONLY: packed input arrays,
+query intervals, mapping parameters and the arrays/flags the reference returned.
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import pysam  # the stub from build_scratch_reference.sh
+from plastid.genomics.genome_array import BAMGenomeArray
+from plastid.genomics.map_factories import (CenterMapFactory, FivePrimeMapFactory,
+                                            SizeFilterFactory,
+                                            StratifiedVariableFivePrimeMapFactory,
+                                            ThreePrimeMapFactory, VariableFivePrimeMapFactory)
+from plastid.genomics.roitools import GenomicSegment, SegmentChain
+from plastid.util.services import exceptions as pl_exc
+
+from plastid_amd.packing import PackedAlignments, concat_file_major, positions_to_runs
+
+assert getattr(pysam, "__version__", "") == "0.19.0" and not hasattr(pysam, "AlignmentHeader"), \
+    "expected the scratch pysam stub"
+
+
+# ------------------------------------------------------------------ helpers
+class FakeBAM(object):
+    """Duck-typed ``pysam.AlignmentFile`` over stub reads."""
+
+    def __init__(self, packed):
+        self.packed = packed
+        self.references = packed.references
+        self.lengths = packed.lengths
+        self.mapped = packed.mapped
+        self.reads = []
+        for i in range(packed.n):
+            r = pysam.AlignedSegment(packed.read(i).positions, bool(packed.flags[i] & 1))
+            r.index = i
+            r.file = self
+            self.reads.append(r)
+        self.end = packed.ref_end()
+
+    def fetch(self, reference=None, start=None, end=None):
+        t = self.references.index(reference)
+        for i, r in enumerate(self.reads):
+            if self.packed.tid[i] == t and self.packed.pos[i] < end and self.end[i] > start:
+                yield r
+
+    def close(self):
+        pass
+
+
+def make_factory(spec):
+    k = spec["kind"]
+    if k == "fiveprime":
+        return FivePrimeMapFactory(spec["param"])
+    if k == "threeprime":
+        return ThreePrimeMapFactory(spec["param"])
+    if k == "center":
+        return CenterMapFactory(spec["param"])
+    od = spec.get("offset_dict")
+    if od is not None:
+        od = {(kk if kk == "default" else int(kk)): v for kk, v in od.items()}
+    if k == "variable":
+        return VariableFivePrimeMapFactory(od)
+    if k == "stratified":
+        return StratifiedVariableFivePrimeMapFactory(od, spec["min_len"], spec["max_len"])
+    raise ValueError(k)
+
+
+def call_with_warnings(fn, *args, **kwargs):
+    pl_exc.pl_once_registry.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = fn(*args, **kwargs)
+    return out, [(x.category.__name__, str(x.message)) for x in w]
+
+
+class Group(object):
+    """Collects cases; each case = alignments + mapping + queries with expectations."""
+
+    def __init__(self, name):
+        self.name = name
+        self.arrays = {}
+        self.cases = []
+
+    def put(self, key, arr):
+        self.arrays[key] = np.asarray(arr)
+        return key
+
+    def add_alignments(self, files):
+        cache = self.__dict__.setdefault("_aln_cache", {})
+        ckey = tuple(id(f) for f in files)
+        if ckey in cache:
+            pfx = cache[ckey]
+        else:
+            pfx = "aln%d" % len(cache)
+            cache[ckey] = pfx
+            for k, v in concat_file_major(files).items():
+                self.put("%s_%s" % (pfx, k), v)
+        return {"prefix": pfx, "references": list(files[0].references),
+                "lengths": list(files[0].lengths), "mapped": [f.mapped for f in files],
+                "nfiles": len(files)}
+
+    def save(self):
+        path = os.path.join(HERE, self.name + ".npz")
+        np.savez_compressed(path, manifest=np.array(json.dumps(self.cases)), **self.arrays)
+        print("wrote %s: %d cases, %d arrays, %.1f kB" % (
+            path, len(self.cases), len(self.arrays), os.path.getsize(path) / 1e3))
+
+
+def jsonable_spec(spec):
+    out = dict(spec)
+    if out.get("offset_dict") is not None:
+        out["offset_dict"] = {str(k): int(v) for k, v in out["offset_dict"].items()}
+    return out
+
+
+def ga_case(group, files, spec, queries, size_filter=None, normalize=None, set_sum=None, note=""):
+    """Drive the reference's BAMGenomeArray over `files` and record results.
+
+    queries: list of dicts
+       {"type":"segment","chrom","start","end","strand","roi_order"}
+       {"type":"chain","chrom","strand","segments":[(s,e)..],"masks":[(s,e)..]|None,"stranded":bool}
+    """
+    aln = group.add_alignments(files)
+    fakes = [FakeBAM(f) for f in files]
+    ga = BAMGenomeArray(fakes, mapping=make_factory(spec))
+    if size_filter is not None:
+        ga.add_filter("size", SizeFilterFactory(min=size_filter[0], max=size_filter[1]))
+    if set_sum is not None:
+        ga.set_sum(set_sum)
+    if normalize:
+        ga.set_normalize(True)
+    case = {"kind": "ga", "aln": aln, "spec": jsonable_spec(spec), "size_filter": size_filter,
+            "normalize": bool(normalize), "sum": ga.sum(), "note": note, "queries": []}
+    cid = len(group.cases)
+    offs = np.cumsum([0] + [f.n for f in files])
+    for qi, q in enumerate(queries):
+        rec = dict(q)
+        key = "c%d_q%d" % (cid, qi)
+        if q["type"] == "segment":
+            seg = GenomicSegment(q["chrom"], q["start"], q["end"], q["strand"])
+            (reads, arr), warns = call_with_warnings(ga.get_reads_and_counts, seg,
+                                                     roi_order=q.get("roi_order", True))
+            rec["expected"] = group.put(key + "_exp", arr)
+            rec["reads_out"] = group.put(
+                key + "_reads", np.array([offs[fakes.index(r.file)] + r.index for r in reads], np.int64))
+            rec["warned"] = len(warns) > 0
+            rec["warn_categories"] = sorted(set(c for c, _ in warns))
+            # __getitem__ / get agree with get_reads_and_counts
+            arr2 = ga.get(seg, roi_order=q.get("roi_order", True))
+            assert arr2.dtype == arr.dtype and np.array_equal(arr2, arr)
+            if q.get("roi_order", True):
+                assert np.array_equal(ga[seg], arr)
+        elif q["type"] == "chain":
+            segs = [GenomicSegment(q["chrom"], s, e, q["strand"]) for s, e in q["segments"]]
+            chain = SegmentChain(*segs)
+            rec["merged_segments"] = [(s.start, s.end) for s in chain]
+            rec["length"] = chain.length
+            if q.get("masks"):
+                chain.add_masks(*[GenomicSegment(q["chrom"], s, e, q["strand"]) for s, e in q["masks"]])
+                rec["masked_length"] = chain.masked_length
+                rec["mask_segments"] = [(s.start, s.end) for s in chain.mask_segments]
+            try:
+                (arr), warns = call_with_warnings(chain.get_counts, ga, stranded=q.get("stranded", True))
+            except ValueError as e:
+                rec["raises"] = "ValueError"
+                case["queries"].append(rec)
+                continue
+            rec["expected"] = group.put(key + "_exp", arr)
+            rec["warned"] = len(warns) > 0
+            if q.get("stranded", True):
+                assert np.array_equal(ga[chain], arr) and np.array_equal(ga.get(chain), arr)
+            marr = chain.get_masked_counts(ga)
+            rec["masked_data"] = group.put(key + "_mdata", np.ma.getdata(marr))
+            rec["masked_mask"] = group.put(key + "_mmask", np.ma.getmaskarray(marr))
+            rec["position_list"] = group.put(key + "_plist", np.array(chain.get_position_list(), np.int64))
+            rec["masked_position_set"] = group.put(
+                key + "_mpset", np.array(sorted(chain.get_masked_position_set()), np.int64))
+            assert sorted(chain.get_position_set()) == chain.get_position_list()
+        else:
+            raise ValueError(q["type"])
+        case["queries"].append(rec)
+    group.cases.append(case)
+    return case
+
+
+def mapfn_case(group, packed, spec, chrom, start, end, strand, note=""):
+    """Call the reference's map factory DIRECTLY on a read list (plugin API)."""
+    aln = group.add_alignments([packed])
+    fake = FakeBAM(packed)
+    fn = make_factory(spec)
+    seg = GenomicSegment(chrom, start, end, strand)
+    (reads, arr), warns = call_with_warnings(fn, list(fake.reads), seg)
+    cid = len(group.cases)
+    case = {"kind": "mapfn", "aln": aln, "spec": jsonable_spec(spec), "note": note,
+            "chrom": chrom, "start": start, "end": end, "strand": strand,
+            "expected": group.put("c%d_exp" % cid, arr),
+            "reads_out": group.put("c%d_reads" % cid, np.array([r.index for r in reads], np.int64)),
+            "warned": len(warns) > 0, "warn_categories": sorted(set(c for c, _ in warns))}
+    if hasattr(fn, "shape"):
+        case["shape"] = list(fn.shape)
+        case["row_keys"] = [int(x) for x in fn.row_keys]
+    group.cases.append(case)
+    return case, reads, arr
+
+
+def random_packed(rng, n, references, lengths, lmin=20, lmax=40, gapped_frac=0.0, rev_frac=0.5,
+                  max_intron=60):
+    """Random coordinate-sorted reads; a fraction carry D / N / I / S operations."""
+    tids = rng.integers(0, len(references), n)
+    cigs, poss, revs = [], [], []
+    for i in range(n):
+        L = int(rng.integers(lmin, lmax + 1))
+        glen = lengths[tids[i]]
+        pos = int(rng.integers(0, glen - 3 * lmax - 2 * max_intron))
+        if rng.random() < gapped_frac:
+            kind = rng.integers(0, 5)
+            a = int(rng.integers(1, L - 1))
+            if kind == 0:
+                cg = "%dM%dN%dM" % (a, int(rng.integers(5, max_intron)), L - a)
+            elif kind == 1:
+                cg = "%dM%dD%dM" % (a, int(rng.integers(1, 4)), L - a)
+            elif kind == 2:
+                cg = "%dM%dI%dM" % (a, int(rng.integers(1, 4)), L - a)
+            elif kind == 3:
+                cg = "%dS%dM%dS" % (int(rng.integers(1, 6)), L, int(rng.integers(1, 6)))
+            else:
+                b = int(rng.integers(1, max(2, L - a)))
+                c = L - a - b
+                if c <= 0:
+                    cg = "%dM%dN%dM" % (a, 7, L - a)
+                else:
+                    cg = "%dM%dN%dM%dD%dM" % (a, int(rng.integers(5, max_intron)), b, 2, c)
+        else:
+            cg = "%dM" % L
+        cigs.append(cg)
+        poss.append(pos)
+        revs.append(bool(rng.random() < rev_frac))
+    return PackedAlignments.from_cigars(tids, poss, cigs, revs, references=references,
+                                        lengths=lengths, sort=True)
+
+
+# ------------------------------------------------------------------- groups
+def group_kat():
+    """Closed-form known-answer vectors of the reference's own unit test
+    (plastid/test/unit/genomics/test_map_factories.py:17-200)."""
+    g = Group("kat_map_factories")
+    min_, max_ = 25, 40
+    expected = {}
+    for mapping in ("fiveprime", "threeprime", "center"):
+        for param in (0, 10):
+            for strand in "+-":
+                expected[(mapping, param, strand)] = np.zeros(2000)
+    expected[("fiveprime", 0, "+")][0] = max_ - min_
+    expected[("fiveprime", 10, "+")][10] = max_ - min_
+    expected[("fiveprime", 0, "-")][min_ - 1:max_ - 1] = 1
+    expected[("fiveprime", 10, "-")][min_ - 11:max_ - 11] = 1
+    expected[("threeprime", 0, "-")][0] = max_ - min_
+    expected[("threeprime", 10, "-")][10] = max_ - min_
+    expected[("threeprime", 0, "+")][min_ - 1:max_ - 1] = 1
+    expected[("threeprime", 10, "+")][min_ - 11:max_ - 11] = 1
+    for my_len in range(min_, max_):
+        for strand in "+-":
+            expected[("center", 0, strand)][:my_len] += 1.0 / my_len
+            expected[("center", 10, strand)][10:my_len - 10] += 1.0 / (my_len - 20)
+
+    packed = {}
+    for strand in "+-":
+        packed[strand] = PackedAlignments.from_ungapped(
+            0, np.zeros(max_ - min_, np.int32), np.arange(min_, max_), np.full(max_ - min_, strand == "-"),
+            references=["mock"], lengths=[2000])
+
+    for (mapping, param, strand), exp in sorted(expected.items()):
+        case, reads, arr = mapfn_case(g, packed[strand], {"kind": mapping, "param": param},
+                                      "mock", 0, 2000, strand, note="test_map_factories.py:84-88")
+        assert (arr == exp).all(), (mapping, param, strand)          # the reference's own assertion
+        assert len(reads) == 15
+
+    # variable: default only == fiveprime 0; fancy {L: L//2} (test_map_factories.py:90-111)
+    fancy = {X: X // 2 for X in range(25, 40)}
+    for strand in "+-":
+        case, reads, arr = mapfn_case(g, packed[strand], {"kind": "variable", "offset_dict": {"default": 0}},
+                                      "mock", 0, 2000, strand, note="test_map_factories.py:101-102")
+        assert (arr == expected[("fiveprime", 0, strand)]).all()
+        case, reads, arr = mapfn_case(g, packed[strand], {"kind": "variable", "offset_dict": fancy},
+                                      "mock", 0, 2000, strand, note="test_map_factories.py:103-104")
+        exp = np.zeros(2000)
+        for L in range(25, 40):
+            exp[(L // 2) if strand == "+" else (L - 1 - L // 2)] += 1
+        assert (arr == exp).all()
+
+    # unmappable reads (test_map_factories.py:163-200)
+    params = {"fiveprime": {"kind": "fiveprime", "param": 30},
+              "threeprime": {"kind": "threeprime", "param": 30},
+              "center": {"kind": "center", "param": 15},
+              "variable": {"kind": "variable", "offset_dict": {25: 10, "default": 28}}}
+    nexp = {"fiveprime": 9, "threeprime": 9, "center": 9, "variable": 12}
+    for name, spec in sorted(params.items()):
+        for strand in "+-":
+            case, reads, arr = mapfn_case(g, packed[strand], spec, "mock", 0, 2000, strand,
+                                          note="test_map_factories.py:163-200")
+            assert len(reads) == nexp[name] and round(arr.sum(), 9) == nexp[name], (name, len(reads), arr.sum())
+            assert case["warned"]
+    g.save()
+
+
+def offset_grid(L_values):
+    return [0, 12, 15, min(L_values) - 1, min(L_values), max(L_values) - 1, max(L_values)]
+
+
+def group_random():
+    """Random ungapped + gapped reads through BAMGenomeArray, all five factories,
+    strands + - ., interesting offsets, roi_order on/off."""
+    g = Group("random_reads")
+    rng = np.random.default_rng(20240501)
+    refs, lens = ["chrA", "chrB"], [3000, 1800]
+    ung = random_packed(rng, 900, refs, lens, 22, 36, gapped_frac=0.0)
+    gap = random_packed(rng, 700, refs, lens, 22, 36, gapped_frac=0.5)
+    vdict = {26: 12, 27: 12, 28: 13, 29: 13, 30: 14, 31: 13, "default": 13}
+
+    def queries(strands="+-."):
+        qs = []
+        for strand in strands:
+            qs.append({"type": "segment", "chrom": "chrA", "start": 0, "end": 3000, "strand": strand,
+                       "roi_order": False})
+            qs.append({"type": "segment", "chrom": "chrA", "start": 517, "end": 1201, "strand": strand,
+                       "roi_order": True})
+            qs.append({"type": "segment", "chrom": "chrB", "start": 1000, "end": 1800, "strand": strand,
+                       "roi_order": True})
+        qs.append({"type": "segment", "chrom": "chrB", "start": 300, "end": 300, "strand": "+",
+                   "roi_order": True})  # zero-length segment
+        qs.append({"type": "segment", "chrom": "chrA", "start": 2990, "end": 3300, "strand": "-",
+                   "roi_order": True})  # runs past the contig end
+        return qs
+
+    for name, packed in (("ungapped", ung), ("gapped", gap)):
+        for off in offset_grid(range(22, 37)):
+            ga_case(g, [packed], {"kind": "fiveprime", "param": off}, queries(), note=name)
+            ga_case(g, [packed], {"kind": "threeprime", "param": off}, queries(), note=name)
+        for nib in (0, 5, 11, 12, 18):
+            ga_case(g, [packed], {"kind": "center", "param": nib}, queries(), note=name)
+        ga_case(g, [packed], {"kind": "variable", "offset_dict": vdict}, queries(), note=name)
+        ga_case(g, [packed], {"kind": "variable", "offset_dict": {"default": 30}}, queries(), note=name)
+        ga_case(g, [packed], {"kind": "variable", "offset_dict": {25: 3, 30: 29, 33: 0}}, queries(), note=name)
+        ga_case(g, [packed], {"kind": "stratified", "offset_dict": vdict, "min_len": 25, "max_len": 35},
+                queries(), note=name)
+        ga_case(g, [packed], {"kind": "stratified", "offset_dict": {26: 6, 27: 22, 28: 13, 29: 4, 30: 5},
+                              "min_len": 26, "max_len": 30}, queries("+-"), note=name + " (no default: P[-1])")
+        ga_case(g, [packed], {"kind": "stratified", "offset_dict": None, "min_len": 20, "max_len": 40},
+                queries("+"), note=name + " offset_dict None")
+    g.save()
+
+
+def group_quirks():
+    """SURVEY Appendix A quirks + hand-checked gapped reads."""
+    g = Group("quirks")
+    refs, lens = ["chrQ"], [500]
+    # hand-written reads: (pos, cigar, reverse)
+    reads = [
+        (10, "30M", False),
+        (10, "30M", True),
+        (12, "10M5N20M", False),           # spliced
+        (12, "10M5N20M", True),
+        (20, "5S10M2D15M3S", False),       # soft clips + deletion
+        (25, "12M3I13M", True),            # insertion: one contiguous run of 25
+        (30, "8M100N8M50N9M", False),      # two introns
+        (40, "25M", False),
+        (40, "25M", True),
+        (41, "10=5X10M", False),           # = and X count as aligned, merge into one run
+        (50, "3M1D3M1D19M", True),
+        (60, "40M", False),
+        (70, "5H20M", True),
+        (90, "1M", False),                 # length-1 read
+        (95, "28M", True),
+        (95, "28M", False),
+    ]
+    packed = PackedAlignments.from_cigars([0] * len(reads), [r[0] for r in reads], [r[1] for r in reads],
+                                          [r[2] for r in reads], references=refs, lengths=lens)
+    # hand-checked positions for the gapped reads (SAM spec), independent of the packer
+    hand = {
+        2: list(range(12, 22)) + list(range(27, 47)),
+        4: list(range(20, 30)) + list(range(32, 47)),
+        5: list(range(25, 50)),
+        6: list(range(30, 38)) + list(range(138, 146)) + list(range(196, 205)),
+        9: list(range(41, 66)),
+        10: list(range(50, 53)) + list(range(54, 57)) + list(range(58, 77)),
+        12: list(range(70, 90)),
+    }
+    for i, pos in hand.items():
+        assert packed.read(i).positions == pos, (i, packed.read(i).positions)
+        assert positions_to_runs(pos) == packed.runs_of(i)
+    g.put("hand_indices", np.array(sorted(hand), np.int64))
+    for i, pos in hand.items():
+        g.put("hand_positions_%d" % i, np.array(pos, np.int64))
+    g.put("hand_pos", np.array([r[0] for r in reads], np.int64))
+    g.cases.append({"kind": "hand_cigars", "cigars": [r[1] for r in reads],
+                    "reverse": [r[2] for r in reads]})
+
+    segq = [{"type": "segment", "chrom": "chrQ", "start": 0, "end": 500, "strand": s, "roi_order": ro}
+            for s in "+-." for ro in (False, True)]
+    segq += [{"type": "segment", "chrom": "chrQ", "start": 27, "end": 60, "strand": s, "roi_order": True}
+             for s in "+-."]
+    segq += [{"type": "segment", "chrom": "chrQ", "start": 140, "end": 200, "strand": s, "roi_order": False}
+             for s in "+-."]
+    # Q2 ('.' uses the forward rule for all reads), Q3 (offset == L-1 / L), Q4/Q5 center
+    for off in (0, 1, 12, 24, 25, 27, 28, 29, 30, 39, 40):
+        ga_case(g, [packed], {"kind": "fiveprime", "param": off}, segq, note="Q2/Q3")
+        ga_case(g, [packed], {"kind": "threeprime", "param": off}, segq, note="Q2/Q3")
+    for nib in (0, 1, 12, 13, 14, 15, 20):
+        ga_case(g, [packed], {"kind": "center", "param": nib}, segq, note="Q4 (m==0 silently dropped; m<0 warns)")
+    # Q6 variable table rules
+    for od in ({"default": 0}, {"default": 13}, {25: 30, "default": 12}, {25: 30, 28: 27, "default": 26},
+               {30: 5}, {28: 0, 30: 29, 40: 39}, {25: 24, 1: 0, "default": 39}):
+        ga_case(g, [packed], {"kind": "variable", "offset_dict": od}, segq, note="Q6")
+    # Q7 stratified: no -1 check -> P[-1]; never warns
+    for od, mn, mx in (({26: 6}, 25, 30), ({"default": 13}, 1, 40), ({25: 30, "default": 12}, 20, 30),
+                       (None, 25, 26), ({28: 27, 30: 0}, 28, 30)):
+        ga_case(g, [packed], {"kind": "stratified", "offset_dict": od, "min_len": mn, "max_len": mx},
+                segq, note="Q7")
+    # Q9 unknown chromosome
+    unk = [{"type": "segment", "chrom": "nope", "start": 5, "end": 50, "strand": "+", "roi_order": True}]
+    ga_case(g, [packed], {"kind": "fiveprime", "param": 0}, unk, note="Q9")
+    ga_case(g, [packed], {"kind": "center", "param": 0}, unk, note="Q9")
+    ga_case(g, [packed], {"kind": "stratified", "offset_dict": None, "min_len": 25, "max_len": 30},
+            unk + [{"type": "chain", "chrom": "nope", "strand": "+", "segments": [(5, 50)]}], note="Q9")
+    ga_case(g, [packed], {"kind": "fiveprime", "param": 0},
+            [{"type": "chain", "chrom": "nope", "strand": "-", "segments": [(5, 50), (70, 90)]}], note="Q9 broadcast")
+    # Q8/Q10 normalisation, set_sum, size filter (CLI default 25-100) and odd filters
+    for spec in ({"kind": "fiveprime", "param": 12}, {"kind": "center", "param": 0},
+                 {"kind": "stratified", "offset_dict": {"default": 3}, "min_len": 25, "max_len": 30}):
+        ga_case(g, [packed], spec, segq[:6], normalize=True, note="Q8/Q10 normalize, sum = mapped")
+        ga_case(g, [packed], spec, segq[:6], normalize=True, set_sum=12345.5, note="Q8/Q10 set_sum")
+        ga_case(g, [packed], spec, segq[:6], size_filter=(25, 100), note="A6 size filter")
+        ga_case(g, [packed], spec, segq[:6], size_filter=(26, 29), note="A6 size filter")
+        ga_case(g, [packed], spec, segq[:6], size_filter=(28, -1), note="A6 size filter no max")
+    # Q11 two files: file-major concatenation (matters for center order)
+    rng = np.random.default_rng(7)
+    f1 = random_packed(rng, 300, refs, lens, 24, 33, gapped_frac=0.2, max_intron=20)
+    f2 = random_packed(rng, 250, refs, lens, 24, 33, gapped_frac=0.2, max_intron=20)
+    for spec in ({"kind": "center", "param": 0}, {"kind": "center", "param": 3}, {"kind": "fiveprime", "param": 2}):
+        ga_case(g, [f1, f2], spec, segq[:9], note="Q11 two files")
+        ga_case(g, [f2, f1], spec, segq[:9], note="Q11 two files swapped")
+        ga_case(g, [f1, f1], spec, segq[:3], note="same file twice (test_genome_array.py:1499-1511)")
+    g.save()
+
+
+def group_chains():
+    """SegmentChain.get_counts / get_masked_counts / position sets (A9-A12)."""
+    g = Group("chains")
+    rng = np.random.default_rng(99)
+    refs, lens = ["chrA", "chrB"], [4000, 2500]
+    packed = random_packed(rng, 1500, refs, lens, 24, 34, gapped_frac=0.25, max_intron=80)
+    chains = [
+        {"chrom": "chrA", "strand": "+", "segments": [(100, 400)]},
+        {"chrom": "chrA", "strand": "-", "segments": [(100, 400)]},
+        {"chrom": "chrA", "strand": ".", "segments": [(100, 400), (500, 610)]},
+        {"chrom": "chrA", "strand": "+", "segments": [(50, 200), (260, 300), (1000, 1400), (1500, 1501), (2000, 2600)]},
+        {"chrom": "chrA", "strand": "-", "segments": [(50, 200), (260, 300), (1000, 1400), (1500, 1501), (2000, 2600)]},
+        {"chrom": "chrB", "strand": "-", "segments": [(0, 90), (90, 120), (300, 340)]},     # adjacent -> merged (Q14)
+        {"chrom": "chrB", "strand": "+", "segments": [(700, 900), (850, 1000), (1200, 1210)]},  # overlapping -> merged
+        {"chrom": "chrB", "strand": "+", "segments": [(1200, 1210), (10, 20)]},              # unsorted input
+        {"chrom": "chrB", "strand": "-", "segments": [(2400, 2500)]},
+    ]
+    queries = []
+    for c in chains:
+        q = dict(c, type="chain")
+        queries.append(q)
+        queries.append(dict(q, stranded=False))
+    masks = [
+        dict(chains[3], type="chain", masks=[(60, 80), (290, 1010), (2590, 2700)]),
+        dict(chains[4], type="chain", masks=[(60, 80), (290, 1010), (2590, 2700)]),
+        dict(chains[4], type="chain", masks=[(0, 5000)]),
+        dict(chains[5], type="chain", masks=[(100, 310), (10, 12)]),
+        dict(chains[0], type="chain", masks=[(1000, 1100)]),          # mask outside chain
+    ]
+    vdict = {26: 12, 27: 12, 28: 13, 29: 13, 30: 14, 31: 13, "default": 13}
+    for spec in ({"kind": "fiveprime", "param": 0}, {"kind": "fiveprime", "param": 12},
+                 {"kind": "threeprime", "param": 3}, {"kind": "center", "param": 0}, {"kind": "center", "param": 4},
+                 {"kind": "variable", "offset_dict": vdict},
+                 {"kind": "stratified", "offset_dict": vdict, "min_len": 25, "max_len": 35}):
+        ga_case(g, [packed], spec, queries + masks, note="chains")
+        ga_case(g, [packed], spec, queries[:8] + masks[:2], normalize=True, note="chains normalized")
+        ga_case(g, [packed], spec, queries[:8], size_filter=(25, 100), note="chains + CLI size filter")
+    # zero-length chain (roitools.pyx:3248-3253)
+    chain = SegmentChain()
+    ga = BAMGenomeArray([FakeBAM(packed)], mapping=FivePrimeMapFactory(0))
+    arr, warns = call_with_warnings(chain.get_counts, ga)
+    assert arr.shape == (0,) and arr.dtype == np.float64 and len(warns) == 1
+    g.cases.append({"kind": "empty_chain", "warned": True, "dtype": str(arr.dtype), "shape": list(arr.shape)})
+    g.save()
+
+
+def group_tables():
+    """Offset tables of VariableFivePrimeMapFactory probed behaviourally: for every
+    length L, where does a single L-mer at position 0 land (forward / reverse table)?"""
+    g = Group("offset_tables")
+    dicts = [{"default": 0}, {"default": 13}, {26: 12, 27: 12, 28: 13, 29: 13, 30: 14, 31: 13, "default": 13},
+             {25: 30, "default": 12}, {25: 30, 28: 27, "default": 26}, {30: 5}, {28: 0, 30: 29, 40: 39},
+             {25: 24, 1: 0, "default": 39}, {5: 7, "default": 6}, {5: 7, "default": 3}]
+    maxL = 60
+    for od in dicts:
+        fn = VariableFivePrimeMapFactory(od)
+        fw = np.full(maxL + 1, -1, np.int64)
+        rc = np.full(maxL + 1, -1, np.int64)
+        for L in range(1, maxL + 1):
+            read = pysam.AlignedSegment(range(0, L), False)
+            for strand, tab in (("+", fw), ("-", rc)):
+                (reads, arr), _ = call_with_warnings(fn, [read], GenomicSegment("c", 0, maxL + 5, strand))
+                if len(reads):
+                    tab[L] = int(arr.nonzero()[0][0])
+        cid = len(g.cases)
+        g.cases.append({"kind": "table", "offset_dict": {str(k): v for k, v in od.items()},
+                        "fw": g.put("c%d_fw" % cid, fw), "rc": g.put("c%d_rc" % cid, rc)})
+    # the offset-file grammar's expected dict (test_argparsers.py:75-83)
+    g.cases.append({"kind": "offset_file",
+                    "text": "length\tp_offset\n26\t12\n27\t12\n28\t13\n29\t13\n30\t14\n31\t13\ndefault\t13\n",
+                    "expected": {"26": 12, "27": 12, "28": 13, "29": 13, "30": 14, "31": 13, "default": 13}})
+    import io
+    fn = VariableFivePrimeMapFactory.from_file(io.StringIO(g.cases[-1]["text"]))
+    # ctor error conventions (Q16, A5, A6)
+    errs = {}
+    for name, ctor in (("FivePrime(-1)", lambda: FivePrimeMapFactory(-1)),
+                       ("ThreePrime(-1)", lambda: ThreePrimeMapFactory(-1)),
+                       ("Center(-1)", lambda: CenterMapFactory(-1)),
+                       ("Strat(min==max)", lambda: StratifiedVariableFivePrimeMapFactory({}, 25, 25)),
+                       ("Strat(max<min)", lambda: StratifiedVariableFivePrimeMapFactory({}, 30, 25)),
+                       ("SizeFilter(max<min)", lambda: SizeFilterFactory(30, 25)),
+                       ("SizeFilter(min<1)", lambda: SizeFilterFactory(0, 25)),
+                       ("Variable(bad,no default)", lambda: VariableFivePrimeMapFactory({25: 30})),
+                       ("Segment(end<start)", lambda: GenomicSegment("c", 10, 5, "+")),
+                       ("Chain(mixed strands)", lambda: SegmentChain(GenomicSegment("c", 0, 5, "+"),
+                                                                     GenomicSegment("c", 10, 15, "-")))):
+        try:
+            ctor()
+            errs[name] = None
+        except Exception as e:  # noqa
+            errs[name] = type(e).__name__
+    g.cases.append({"kind": "ctor_errors", "errors": errs})
+    g.save()
+
+
+if __name__ == "__main__":
+    group_kat()
+    group_tables()
+    group_quirks()
+    group_random()
+    group_chains()
