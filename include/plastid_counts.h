@@ -1,0 +1,175 @@
+/*
+ * plastid_counts.h -- C ABI of the MI355X per-position read-counting engine.
+ *
+ * This is the drop-in boundary for ONE hot path of plastid (reference paths are
+ * relative to the reference checkout):
+ *
+ *   plastid/genomics/genome_array.py:760-832   BAMGenomeArray.get_reads_and_counts
+ *   plastid/genomics/genome_array.py:861-928   BAMGenomeArray.__getitem__ / get
+ *   plastid/genomics/map_factories.pyx:167-839 the five BAM mapping functions + SizeFilterFactory
+ *   plastid/genomics/roitools.pyx:3221-3315    SegmentChain.get_counts / get_masked_counts
+ *
+ * The reference has no FFI on this path (it is Cython calling pysam); the entry
+ * points below are what a binding for the path would bind.  Each one cites the
+ * reference interface it replaces.  INTEGRATION.md shows the reference-side
+ * ctypes stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PC_ERR_* code on failure;
+ *     pc_last_error() returns a message for the calling thread's last failure;
+ *   - no exceptions cross the ABI, no torch types, plain pointers and sizes;
+ *   - host buffers are caller-owned, C-contiguous; device buffers are
+ *     engine-owned behind the opaque handles;
+ *   - one engine per GPU; an engine and its plans are not thread-safe;
+ *   - there is NO CPU fallback: without a usable HIP device pc_create() fails.
+ */
+#ifndef PLASTID_COUNTS_H
+#define PLASTID_COUNTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PC_ABI_VERSION 1
+
+typedef struct pc_engine pc_engine;
+typedef struct pc_plan pc_plan;
+
+/* error codes */
+#define PC_OK 0
+#define PC_ERR_ARG (-1)        /* invalid argument (ValueError in the Python shim)   */
+#define PC_ERR_HIP (-2)        /* HIP runtime failure                                */
+#define PC_ERR_NOMEM (-3)
+#define PC_ERR_UNSORTED (-4)   /* records not coordinate sorted (pysam.fetch raises) */
+#define PC_ERR_STATE (-5)      /* e.g. counting before alignments / mapping are set  */
+
+/* mapping rules: plastid/genomics/map_factories.pyx */
+#define PC_MAP_FIVE 0    /* FivePrimeMapFactory                    :278-374 */
+#define PC_MAP_THREE 1   /* ThreePrimeMapFactory                   :377-474 */
+#define PC_MAP_CENTER 2  /* CenterMapFactory                       :167-276 */
+#define PC_MAP_VAR5 3    /* VariableFivePrimeMapFactory            :477-650 */
+#define PC_MAP_STRAT5 4  /* StratifiedVariableFivePrimeMapFactory  :653-791 */
+
+/* strand codes: plastid/genomics/c_common.pxd:1-6 */
+#define PC_STRAND_UNDEF 0
+#define PC_STRAND_FWD 1
+#define PC_STRAND_REV 2
+#define PC_STRAND_UNS 3
+/* OR-ed into a segment's strand byte: do not strand-filter reads (semantics of
+ * calling a map factory directly on a read list, map_factories.pyx:308, instead
+ * of going through BAMGenomeArray, genome_array.py:812-815) */
+#define PC_STRAND_NOFILTER 0x10
+
+/* record flag bits (the `flags` array of pc_add_alignment_file) */
+#define PC_FLAG_REVERSE 0x01   /* pysam AlignedSegment.is_reverse                       */
+#define PC_FLAG_EXCLUDED 0x80  /* dropped by a host-side read filter (genome_array.py:819-820) */
+
+#define PC_OUT_INT64 0
+#define PC_OUT_FLOAT64 1
+
+#define PC_OFFSET_TABLE_LEN 10000 /* map_factories.pxd:10-12 */
+#define PC_MAX_ALIGNED_LEN 65535
+
+const char *pc_last_error(void);
+int pc_abi_version(void);
+/* number of HIP devices visible; never initialises more than the runtime needs */
+int pc_device_count(void);
+
+/* ---- engine ------------------------------------------------------------- */
+int pc_create(int device, pc_engine **out);
+int pc_destroy(pc_engine *e);
+
+/* ---- alignments: replaces pysam AlignmentFile.fetch + AlignedSegment.positions /
+ * .is_reverse as consumed at genome_array.py:800-815 and map_factories.pyx:243,
+ * 349, 448, 629, 769, 838.  One call per BAM file, in the order the files were
+ * given to BAMGenomeArray (file-major order matters, genome_array.py:800-809).
+ *
+ *   n          records, sorted by (tid, pos), ties in file order
+ *   tid,pos    reference index (0 <= tid < ntid) and leftmost aligned coordinate
+ *   alen       L = len(read.positions): aligned reference positions (M/=/X)
+ *   flags      PC_FLAG_* bits
+ *   nblk       number of maximal runs of contiguous aligned positions (0 iff L==0)
+ *   nrun,blk_* runs (start,len) of every record with nblk >= 2, record after
+ *              record; a record with nblk == 1 is the implicit run [pos, pos+L)
+ */
+int pc_clear_alignments(pc_engine *e);
+int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
+                          const int32_t *pos, const uint16_t *alen, const uint8_t *flags,
+                          const uint8_t *nblk, int64_t nrun, const int32_t *blk_start,
+                          const int32_t *blk_len);
+/* replace the flags of one staged file (host-side filters changed) */
+int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags);
+int pc_num_files(pc_engine *e);
+int64_t pc_num_records(pc_engine *e, int file);
+
+/* ---- mapping rule: replaces BAMGenomeArray.set_mapping (genome_array.py:935-963)
+ * with one of the five factories.  `param` = offset (FIVE/THREE) or nibble
+ * (CENTER).  fw/rc = forward_offsets/reverse_offsets[table_len] built on the
+ * host by the restated __cinit__ rules (map_factories.pyx:494-543); entries are
+ * -1 (no usable offset) or 0 <= off < L.  min_len/max_len: STRAT5 rows. */
+int pc_set_mapping(pc_engine *e, int kind, int param, const int32_t *fw, const int32_t *rc,
+                   int table_len, int min_len, int max_len);
+/* SizeFilterFactory(min,max) (map_factories.pyx:794-839); max == -1: no maximum */
+int pc_set_size_filter(pc_engine *e, int enabled, int min_len, int max_len);
+/* set_normalize/set_sum (genome_array.py:482-520): out = count / sum * 1e6 */
+int pc_set_normalize(pc_engine *e, int enabled, double sum);
+int pc_mapping_rows(pc_engine *e);
+
+/* ---- query plan: a batch of GenomicSegments and where their count vectors go.
+ * Replaces the per-segment loop of SegmentChain.get_counts (roitools.pyx:3259-3271)
+ * and BAMGenomeArray.get (genome_array.py:891-928).  For segment s, genomic
+ * position start[s]+i (0 <= i < end[s]-start[s]), row r is written to
+ *     out[out_off[s] + out_step[s]*i + r*row_stride[s]]
+ * so a '-' chain is laid out 5'->3' by giving its segments out_step = -1
+ * (roitools.pyx:3270-3271, genome_array.py:829-830).  tid < 0 or >= ntid means
+ * "chromosome not in the array": the slice is zero (genome_array.py:795-798).
+ * A plan depends only on the intervals; it can be reused across alignment sets,
+ * mapping rules and normalisation settings with the same number of rows.
+ */
+int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t *start,
+                   const int64_t *end, const uint8_t *strand, const int64_t *out_off,
+                   const int8_t *out_step, const int64_t *row_stride, int64_t out_elems, int rows,
+                   pc_plan **out);
+int pc_plan_destroy(pc_plan *p);
+int64_t pc_plan_positions(pc_plan *p); /* distinct (strand-mode, position) pairs counted */
+int64_t pc_plan_tiles(pc_plan *p);
+
+/* ---- counting: map_fn(list(reads), roi) for every segment of the plan
+ * (genome_array.py:823), then normalisation/strand layout.  pc_count launches
+ * asynchronously on the engine's stream; results stay in HBM until read. */
+int pc_count(pc_engine *e, pc_plan *p, int out_dtype);
+int pc_sync(pc_engine *e);
+int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems);
+/* device pointer/stream of the last pc_count output (for zero-copy consumers) */
+void *pc_counts_device_ptr(pc_plan *p);
+void *pc_stream(pc_engine *e);
+
+/* per-segment "the reference would emit its DataWarning" flags
+ * (map_factories.pyx:258-263, 360-365, 459-464, 643-648) for the last pc_count */
+int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags);
+
+/* Sum over all output elements of the last pc_count, left in HBM for an RCCL
+ * all-reduce (int64 for PC_OUT_INT64, fixed-order float64 otherwise);
+ * host_out8 (8 bytes) may be NULL. */
+int pc_total(pc_engine *e, pc_plan *p, void *host_out8);
+void *pc_total_device_ptr(pc_plan *p);
+
+/* reads_out of map_fn for ONE segment over records [rec_lo, rec_hi) of `file`
+ * (genome_array.py:800-823): mask[i - rec_lo] = 1 iff the record is fetched
+ * (htslib overlap), passes strand + filters and is mapped into the segment. */
+int pc_mapped_reads(pc_engine *e, int file, int64_t rec_lo, int64_t rec_hi, int32_t tid,
+                    int64_t start, int64_t end, uint8_t strand, uint8_t *mask);
+
+/* last pc_count: milliseconds per phase, measured with HIP events on the
+ * engine's stream: [0] total, [1] work-list, [2] histogram/center, [3] long
+ * reads, [4] gather, [5] zero-fill.  Returns number of entries written. */
+int pc_last_timing(pc_engine *e, double *ms, int n);
+/* algorithmic bytes of the last pc_count (SURVEY.md section 8d formula) */
+int64_t pc_last_algorithmic_bytes(pc_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLASTID_COUNTS_H */

@@ -1,0 +1,48 @@
+"""Build the HIP shared library in-tree (gfx950 only)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "plastid_counts.hip")
+HDRS = [os.path.join(HERE, "csrc", "pc_kernels.hip.h"), os.path.join(ROOT, "include", "plastid_counts.h")]
+LIB = os.path.join(HERE, "libplastid_counts.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # float64 center counts must be the reference's left-to-right IEEE sums
+    "-fno-fast-math", "-ffp-contract=off",
+    "-Wall", "-Wno-unused-result",
+]
+
+
+def find_hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; cannot build the counting engine")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in [SRC] + HDRS)
+
+
+def build_library(force=False, verbose=False, extra_flags=()):
+    """Compile ``csrc/plastid_counts.hip`` -> ``plastid_amd/libplastid_counts.so``."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [find_hipcc()] + HIPCC_FLAGS + list(extra_flags) + [
+        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), SRC, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True))

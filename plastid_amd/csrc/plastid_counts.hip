@@ -1,0 +1,901 @@
+// plastid_counts.hip -- host side of the C ABI declared in include/plastid_counts.h.
+//
+// Owns device memory, builds the interval plan (islands -> genome tiles ->
+// pieces), launches the kernels of pc_kernels.hip.h on the engine's stream and
+// times them with HIP events.  There is no CPU counting path in this file: every
+// count comes out of a HIP kernel.
+#include "pc_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "plastid_counts.h"
+
+using namespace pc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t err__ = (expr);                                                                 \
+        if (err__ != hipSuccess)                                                                   \
+            return fail(err__ == hipErrorOutOfMemory ? PC_ERR_NOMEM : PC_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(err__), __FILE__, __LINE__);                      \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    int reserve(size_t n) {
+        if (n <= cap) return PC_OK;
+        release();
+        if (n == 0) return PC_OK;
+        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+        cap = n;
+        return PC_OK;
+    }
+    int upload(const std::vector<T> &v, hipStream_t s) {
+        int rc = reserve(v.size());
+        if (rc != PC_OK) return rc;
+        if (!v.empty()) HIP_TRY(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        return PC_OK;
+    }
+};
+
+struct StagedFile {
+    int64_t n = 0, nrun = 0, nlong = 0;
+    int W = 1;               // max reference span of the records scanned by the window kernels
+    int64_t max_span = 1;    // over all records (long ones too)
+    DevBuf<uint2> rec;
+    DevBuf<uint32_t> blk_off;
+    DevBuf<int2> blk;
+    DevBuf<int64_t> tid_bounds;
+    DevBuf<uint32_t> long_idx;
+    DevBuf<int32_t> long_tid;
+    DevBuf<int32_t> long_pmax;
+    DevBuf<int64_t> long_tid_bounds;
+    std::vector<int64_t> len_hist; // records per aligned length (host), for cheap warn pre-checks
+    FileView view() const {
+        FileView v;
+        v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
+        v.long_idx = long_idx.p; v.long_tid = long_tid.p; v.long_pmax = long_pmax.p;
+        v.long_tid_bounds = long_tid_bounds.p; v.n = n; v.nlong = nlong;
+        return v;
+    }
+};
+
+} // namespace
+
+struct pc_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    std::vector<StagedFile *> files;
+    int ntid = 0;
+    DevBuf<FileView> d_files;
+    bool files_dirty = true;
+    // mapping
+    bool have_map = false;
+    int kind = PC_MAP_CENTER, param = 0, min_len = 25, max_len = 35, rows = 1, table_len = 0;
+    std::vector<int32_t> h_fw, h_rc;
+    DevBuf<int32_t> d_fw, d_rc;
+    int filt_on = 0, filt_min = 0, filt_max = -1;
+    int norm_on = 0;
+    double norm_sum = 1.0;
+    DevBuf<double> d_inv; // 1.0/m, m = 0..65535 (host-computed IEEE quotients)
+    // scratch for counting
+    DevBuf<WorkItem> d_work;
+    DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
+    DevBuf<double> d_partial;
+    DevBuf<Unmappable> d_unmap;
+    double last_ms[6] = {0, 0, 0, 0, 0, 0};
+    bool timing_valid = false;
+    int64_t last_alg_bytes = 0;
+
+    MapParams params() const {
+        MapParams mp;
+        mp.kind = kind; mp.param = param; mp.min_len = min_len; mp.max_len = max_len; mp.rows = rows;
+        mp.filt_on = filt_on; mp.filt_min = filt_min; mp.filt_max = filt_max;
+        mp.table_len = table_len; mp.fw = d_fw.p; mp.rc = d_rc.p;
+        return mp;
+    }
+    int W() const {
+        int w = 1;
+        for (auto *f : files) w = std::max(w, f->W);
+        return w;
+    }
+};
+
+struct pc_plan {
+    pc_engine *e = nullptr;
+    int64_t nseg = 0, out_elems = 0, covered = 0;
+    int rows = 1, G = 4096;
+    uint32_t modes = 0;
+    int max_slots = 1;
+    int64_t npos = 0; // island positions (hist row length)
+    std::vector<Tile> tiles;
+    std::vector<Piece> pieces;
+    std::vector<CenterChunk> cchunks;
+    std::vector<GatherSeg> gsegs;
+    std::vector<GatherChunk> gchunks;
+    // host copies for warn evaluation
+    std::vector<int32_t> h_tid;
+    std::vector<int64_t> h_start, h_end;
+    std::vector<uint8_t> h_strand;
+    DevBuf<Tile> d_tiles;
+    DevBuf<Piece> d_pieces;
+    DevBuf<CenterChunk> d_cchunks;
+    DevBuf<GatherSeg> d_gsegs;
+    DevBuf<GatherChunk> d_gchunks;
+    DevBuf<uint32_t> d_tile_items;
+    DevBuf<uint8_t> d_hist; // uint32 or double
+    DevBuf<uint8_t> d_out;  // int64 or double
+    DevBuf<uint8_t> d_total;
+    int last_dtype = -1;
+    bool counted = false;
+};
+
+namespace {
+
+int mode_of(uint8_t strand) {
+    const bool nofilter = strand & PC_STRAND_NOFILTER;
+    const int s = strand & 3;
+    if (s == PC_STRAND_REV) return nofilter ? 3 : 1;
+    if (s == PC_STRAND_FWD) return nofilter ? 2 : 0;
+    return 2; // '.' and undefined: all reads, forward rule
+}
+
+int refresh_file_views(pc_engine *e) {
+    if (!e->files_dirty) return PC_OK;
+    std::vector<FileView> v;
+    for (auto *f : e->files) v.push_back(f->view());
+    int rc = e->d_files.upload(v, e->stream);
+    if (rc != PC_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->files_dirty = false;
+    return PC_OK;
+}
+
+// ------------------------------------------------------------------ counting
+template <typename HistT, typename OutT>
+void launch_gather(pc_engine *e, pc_plan *p, const HistT *hist, OutT *outp) {
+    const unsigned grid = (unsigned)p->gchunks.size();
+    if (!grid) return;
+    if (e->norm_on)
+        hipLaunchKernelGGL((k_gather<HistT, OutT, true>), dim3(grid), dim3(kWG), 0, e->stream, p->d_gsegs.p, p->d_gchunks.p,
+                           hist, p->npos, p->rows, e->norm_sum, outp);
+    else
+        hipLaunchKernelGGL((k_gather<HistT, OutT, false>), dim3(grid), dim3(kWG), 0, e->stream, p->d_gsegs.p, p->d_gchunks.p,
+                           hist, p->npos, p->rows, e->norm_sum, outp);
+}
+
+
+} // namespace
+
+extern "C" {
+
+const char *pc_last_error(void) { return g_err.c_str(); }
+int pc_abi_version(void) { return PC_ABI_VERSION; }
+
+int pc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pc_create(int device, pc_engine **out) {
+    if (!out) return fail(PC_ERR_ARG, "pc_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev <= 0)
+        return fail(PC_ERR_HIP, "pc_create: no HIP device available (%s); this engine has no CPU fallback",
+                    err == hipSuccess ? "device count is 0" : hipGetErrorString(err));
+    if (device < 0 || device >= ndev) return fail(PC_ERR_ARG, "pc_create: device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    pc_engine *e = new pc_engine();
+    e->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+    std::vector<double> inv(65536);
+    inv[0] = 0.0;
+    for (int m = 1; m < 65536; ++m) inv[m] = 1.0 / (double)m; // the reference's `1.0 / map_length`
+    int rc = e->d_inv.upload(inv, e->stream);
+    if (rc == PC_OK) rc = e->d_counters.reserve(4);
+    if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: sync failed");
+    if (rc != PC_OK) {
+        pc_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return PC_OK;
+}
+
+int pc_destroy(pc_engine *e) {
+    if (!e) return PC_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto *f : e->files) delete f;
+    e->files.clear();
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return PC_OK;
+}
+
+int pc_clear_alignments(pc_engine *e) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (auto *f : e->files) delete f;
+    e->files.clear();
+    e->ntid = 0;
+    e->files_dirty = true;
+    return PC_OK;
+}
+
+int pc_num_files(pc_engine *e) { return e ? (int)e->files.size() : 0; }
+int64_t pc_num_records(pc_engine *e, int file) {
+    if (!e || file < 0 || file >= (int)e->files.size()) return -1;
+    return e->files[file]->n;
+}
+
+int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
+                          const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
+                          const int32_t *blk_start, const int32_t *blk_len) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    if (n < 0 || ntid <= 0 || nrun < 0) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad sizes");
+    if (n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL array");
+    if (nrun > 0 && (!blk_start || !blk_len)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL run array");
+    if (n >= (int64_t)0xffffffffu || nrun >= (int64_t)0xffffffffu)
+        return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^32-2 records per file are not supported");
+    if (!e->files.empty() && ntid != e->ntid)
+        return fail(PC_ERR_ARG, "pc_add_alignment_file: all files must use the same reference list (ntid %d vs %d)", ntid, e->ntid);
+    HIP_TRY(hipSetDevice(e->device));
+
+    // ---- host pass: validation, per-tid bounds, spans, packed records
+    std::vector<int64_t> tid_bounds((size_t)ntid + 1, 0);
+    std::vector<uint2> rec((size_t)n);
+    std::vector<uint32_t> blk_off;
+    if (nrun > 0) blk_off.assign((size_t)n, 0u);
+    std::vector<int32_t> span((size_t)n);
+    std::vector<int64_t> span_hist(1026, 0); // spans 0..1024, [1025] = larger
+    std::vector<int64_t> len_hist(65536, 0);
+    int64_t run_cursor = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (tid[i] < 0 || tid[i] >= ntid) return fail(PC_ERR_ARG, "record %lld: tid %d out of range", (long long)i, tid[i]);
+        if (pos[i] < 0) return fail(PC_ERR_ARG, "record %lld: negative position", (long long)i);
+        if (i > 0 && (tid[i] < tid[i - 1] || (tid[i] == tid[i - 1] && pos[i] < pos[i - 1])))
+            return fail(PC_ERR_UNSORTED, "records are not sorted by (tid, pos) at record %lld; alignment files must be coordinate sorted", (long long)i);
+        tid_bounds[(size_t)tid[i] + 1] += 1;
+        const int L = alen[i];
+        int64_t end;
+        if (nblk[i] >= 2) {
+            if (run_cursor + nblk[i] > nrun) return fail(PC_ERR_ARG, "run arrays shorter than sum of nblk");
+            blk_off[(size_t)i] = (uint32_t)run_cursor;
+            int64_t sum = 0, prev_end = -1;
+            for (int b = 0; b < nblk[i]; ++b) {
+                const int64_t s = blk_start[run_cursor + b], ln = blk_len[run_cursor + b];
+                if (ln <= 0 || (b > 0 && s <= prev_end))
+                    return fail(PC_ERR_ARG, "record %lld: aligned runs must be non-empty, ascending and non-adjacent", (long long)i);
+                if (b == 0 && s != pos[i]) return fail(PC_ERR_ARG, "record %lld: first run must start at pos", (long long)i);
+                sum += ln;
+                prev_end = s + ln;
+            }
+            if (sum != L) return fail(PC_ERR_ARG, "record %lld: run lengths do not sum to alen", (long long)i);
+            end = prev_end;
+            run_cursor += nblk[i];
+        } else {
+            if ((nblk[i] == 0) != (L == 0)) return fail(PC_ERR_ARG, "record %lld: nblk/alen mismatch", (long long)i);
+            end = (int64_t)pos[i] + (L > 0 ? L : 1);
+        }
+        if (end > 0x7fffffffLL) return fail(PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", (long long)i);
+        const int64_t sp = end - pos[i];
+        span[(size_t)i] = (int32_t)sp;
+        span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
+        len_hist[(size_t)L] += 1;
+        rec[(size_t)i] = make_uint2((uint32_t)pos[i], (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) |
+                                                          ((uint32_t)nblk[i] << 24));
+    }
+    if (run_cursor != nrun) return fail(PC_ERR_ARG, "run arrays longer than sum of nblk (%lld vs %lld)", (long long)run_cursor, (long long)nrun);
+    for (int t = 0; t < ntid; ++t) tid_bounds[(size_t)t + 1] += tid_bounds[(size_t)t];
+
+    // ---- choose the window halo W: the smallest span bound (>= 64, <= 1024) that covers
+    // >= 99.5% of the records; longer (spliced) reads go through the long-read path.
+    int wcap = 64;
+    {
+        int64_t cum = 0;
+        const int64_t need = n - n / 200;
+        int s = 0;
+        for (; s <= 1024; ++s) {
+            cum += span_hist[(size_t)s];
+            if (cum >= need) break;
+        }
+        wcap = std::max(64, std::min(s, 1024));
+    }
+    StagedFile *sf = new StagedFile();
+    sf->n = n;
+    sf->nrun = nrun;
+    sf->len_hist.swap(len_hist);
+    std::vector<uint32_t> long_idx;
+    std::vector<int32_t> long_tid, long_pmax;
+    std::vector<int64_t> long_bounds((size_t)ntid + 1, 0);
+    int W = 1;
+    int64_t max_span = 1;
+    {
+        int cur_tid = -1;
+        int32_t pm = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t sp = span[(size_t)i];
+            max_span = std::max<int64_t>(max_span, sp);
+            if (sp > wcap) {
+                rec[(size_t)i].y |= (kFlagLong << 16);
+                if (tid[i] != cur_tid) { cur_tid = tid[i]; pm = 0; }
+                pm = std::max(pm, pos[i] + sp);
+                long_idx.push_back((uint32_t)i);
+                long_tid.push_back(tid[i]);
+                long_pmax.push_back(pm);
+                long_bounds[(size_t)tid[i] + 1] += 1;
+            } else {
+                W = std::max(W, (int)sp);
+            }
+        }
+        for (int t = 0; t < ntid; ++t) long_bounds[(size_t)t + 1] += long_bounds[(size_t)t];
+    }
+    sf->W = W;
+    sf->max_span = max_span;
+    sf->nlong = (int64_t)long_idx.size();
+
+    // ---- bulk stage to HBM
+    int rc = sf->rec.upload(rec, e->stream);
+    if (rc == PC_OK && nrun > 0) {
+        rc = sf->blk_off.upload(blk_off, e->stream);
+        std::vector<int2> blk((size_t)nrun);
+        for (int64_t j = 0; j < nrun; ++j) blk[(size_t)j] = make_int2(blk_start[j], blk_len[j]);
+        if (rc == PC_OK) rc = sf->blk.upload(blk, e->stream);
+        if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
+    }
+    if (rc == PC_OK) rc = sf->tid_bounds.upload(tid_bounds, e->stream);
+    if (rc == PC_OK) rc = sf->long_idx.upload(long_idx, e->stream);
+    if (rc == PC_OK) rc = sf->long_tid.upload(long_tid, e->stream);
+    if (rc == PC_OK) rc = sf->long_pmax.upload(long_pmax, e->stream);
+    if (rc == PC_OK) rc = sf->long_tid_bounds.upload(long_bounds, e->stream);
+    if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
+    if (rc != PC_OK) {
+        delete sf;
+        return rc;
+    }
+    e->files.push_back(sf);
+    e->ntid = ntid;
+    e->files_dirty = true;
+    return PC_OK;
+}
+
+int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
+    if (!e || file < 0 || file >= (int)e->files.size()) return fail(PC_ERR_ARG, "pc_update_flags: bad file index");
+    StagedFile *sf = e->files[file];
+    if (n != sf->n || (n > 0 && !flags)) return fail(PC_ERR_ARG, "pc_update_flags: wrong record count");
+    HIP_TRY(hipSetDevice(e->device));
+    std::vector<uint2> rec((size_t)n);
+    HIP_TRY(hipMemcpy(rec.data(), sf->rec.p, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
+    const uint32_t keep = ~(((uint32_t)(PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16);
+    for (int64_t i = 0; i < n; ++i)
+        rec[(size_t)i].y = (rec[(size_t)i].y & keep) | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16);
+    HIP_TRY(hipMemcpy(sf->rec.p, rec.data(), (size_t)n * sizeof(uint2), hipMemcpyHostToDevice));
+    return PC_OK;
+}
+
+int pc_set_mapping(pc_engine *e, int kind, int param, const int32_t *fw, const int32_t *rc, int table_len,
+                   int min_len, int max_len) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    if (kind < PC_MAP_FIVE || kind > PC_MAP_STRAT5) return fail(PC_ERR_ARG, "pc_set_mapping: unknown kind %d", kind);
+    if ((kind == PC_MAP_FIVE || kind == PC_MAP_THREE || kind == PC_MAP_CENTER) && param < 0)
+        return fail(PC_ERR_ARG, "pc_set_mapping: offset/nibble must be >= 0, got %d", param);
+    int rows = 1;
+    if (kind == PC_MAP_VAR5 || kind == PC_MAP_STRAT5) {
+        if (!fw || !rc || table_len <= 0 || table_len > 65536) return fail(PC_ERR_ARG, "pc_set_mapping: offset tables required");
+        for (int L = 0; L < table_len; ++L) {
+            if (fw[L] < -1 || rc[L] < -1 || (fw[L] >= 0 && fw[L] >= std::max(L, 1)) || (rc[L] >= 0 && rc[L] >= std::max(L, 1)))
+                return fail(PC_ERR_ARG, "pc_set_mapping: table entry for length %d out of range (the reference would index read.positions out of bounds)", L);
+            if ((fw[L] < 0) != (rc[L] < 0)) return fail(PC_ERR_ARG, "pc_set_mapping: forward/reverse tables disagree on length %d", L);
+        }
+    }
+    if (kind == PC_MAP_STRAT5) {
+        if (max_len <= min_len) return fail(PC_ERR_ARG, "pc_set_mapping: max length must be > min length"); // :716-717
+        if (max_len >= table_len) return fail(PC_ERR_ARG, "pc_set_mapping: max length beyond offset table");
+        rows = max_len - min_len + 1;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->kind = kind; e->param = param; e->min_len = min_len; e->max_len = max_len; e->rows = rows;
+    e->table_len = 0;
+    e->h_fw.clear(); e->h_rc.clear();
+    if (kind == PC_MAP_VAR5 || kind == PC_MAP_STRAT5) {
+        e->h_fw.assign(fw, fw + table_len);
+        e->h_rc.assign(rc, rc + table_len);
+        int r = e->d_fw.upload(e->h_fw, e->stream);
+        if (r == PC_OK) r = e->d_rc.upload(e->h_rc, e->stream);
+        if (r != PC_OK) return r;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->table_len = table_len;
+    }
+    e->have_map = true;
+    return PC_OK;
+}
+
+int pc_set_size_filter(pc_engine *e, int enabled, int min_len, int max_len) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    if (enabled) {
+        if (max_len != -1 && max_len < min_len) return fail(PC_ERR_ARG, "Alignment size filter: max read length must be >= min read length");
+        if (min_len < 1) return fail(PC_ERR_ARG, "Alignment size filter: min read length must be >= 1. Got %d", min_len);
+    }
+    e->filt_on = enabled ? 1 : 0;
+    e->filt_min = min_len;
+    e->filt_max = max_len;
+    return PC_OK;
+}
+
+int pc_set_normalize(pc_engine *e, int enabled, double sum) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    e->norm_on = enabled ? 1 : 0;
+    e->norm_sum = sum;
+    return PC_OK;
+}
+
+int pc_mapping_rows(pc_engine *e) { return e ? e->rows : 0; }
+
+// ------------------------------------------------------------------ plan
+int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t *start, const int64_t *end,
+                   const uint8_t *strand, const int64_t *out_off, const int8_t *out_step,
+                   const int64_t *row_stride, int64_t out_elems, int rows, pc_plan **out) {
+    if (!e || !out) return fail(PC_ERR_ARG, "pc_plan_create: NULL argument");
+    *out = nullptr;
+    if (nseg < 0 || out_elems < 0 || rows < 1) return fail(PC_ERR_ARG, "pc_plan_create: bad sizes");
+    if (nseg > 0 && (!tid || !start || !end || !strand || !out_off || !out_step || !row_stride))
+        return fail(PC_ERR_ARG, "pc_plan_create: NULL array");
+    if (nseg >= (int64_t)0x7fffffff) return fail(PC_ERR_ARG, "pc_plan_create: too many segments");
+    HIP_TRY(hipSetDevice(e->device));
+    const int ntid = e->ntid;
+
+    struct Iv { int32_t tid; int32_t mode; int64_t s, e; };
+    std::vector<Iv> ivs;
+    ivs.reserve((size_t)nseg);
+    pc_plan *p = new pc_plan();
+    p->e = e;
+    p->nseg = nseg;
+    p->out_elems = out_elems;
+    p->rows = rows;
+    p->gsegs.resize((size_t)nseg);
+    p->h_tid.assign(tid, tid + nseg);
+    p->h_start.assign(start, start + nseg);
+    p->h_end.assign(end, end + nseg);
+    p->h_strand.assign(strand, strand + nseg);
+    const int64_t kMaxPos = 0x7fffffffLL;
+    uint32_t modes = 0;
+    for (int64_t s = 0; s < nseg; ++s) {
+        const int64_t len = end[s] - start[s];
+        if (len < 0) { delete p; return fail(PC_ERR_ARG, "segment %lld: end < start", (long long)s); }
+        if (out_step[s] != 1 && out_step[s] != -1) { delete p; return fail(PC_ERR_ARG, "segment %lld: out_step must be +1 or -1", (long long)s); }
+        // output bounds
+        if (len > 0) {
+            const int64_t first = out_off[s], last = out_off[s] + (int64_t)out_step[s] * (len - 1);
+            const int64_t lo = std::min(first, last), hi = std::max(first, last) + (int64_t)(rows - 1) * row_stride[s];
+            if (lo < 0 || hi >= out_elems || row_stride[s] < 0) {
+                delete p;
+                return fail(PC_ERR_ARG, "segment %lld: output slice [%lld,%lld] outside buffer of %lld elements", (long long)s, (long long)lo, (long long)hi, (long long)out_elems);
+            }
+        }
+        GatherSeg &g = p->gsegs[(size_t)s];
+        g.out_off = out_off[s]; g.row_stride = row_stride[s]; g.len = len; g.step = out_step[s]; g.pad = 0;
+        g.hist_off = -1; g.clip_lo = 0; g.clip_hi = 0;
+        p->covered += len * rows;
+        if (tid[s] < 0 || tid[s] >= ntid || len == 0) continue; // unknown chromosome: zeros (genome_array.py:795-798)
+        const int64_t cs = std::max<int64_t>(start[s], 0), ce = std::min<int64_t>(end[s], kMaxPos);
+        if (ce <= cs) continue;
+        g.clip_lo = cs - start[s];
+        g.clip_hi = ce - start[s];
+        const int m = mode_of(strand[s]);
+        modes |= 1u << m;
+        ivs.push_back({tid[s], m, cs, ce});
+    }
+    p->modes = modes;
+    int nmodes = 0;
+    for (int m = 0; m < kModes; ++m) nmodes += (modes >> m) & 1;
+    if (nmodes == 0) nmodes = 1;
+    // window size: LDS budget of 64 KiB for bins (uint32 per mode x row x position)
+    {
+        int64_t g = (64 * 1024) / (4LL * nmodes * rows);
+        int G = 256;
+        while (G * 2 <= g && G < 4096) G *= 2;
+        if ((int64_t)4 * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
+        p->G = G;
+    }
+    const int G = p->G;
+
+    // ---- islands: union of the queried intervals per (tid, mode)
+    std::sort(ivs.begin(), ivs.end(), [](const Iv &a, const Iv &b) {
+        if (a.tid != b.tid) return a.tid < b.tid;
+        if (a.mode != b.mode) return a.mode < b.mode;
+        if (a.s != b.s) return a.s < b.s;
+        return a.e < b.e;
+    });
+    struct Island { int32_t tid, mode; int64_t s, e, off; };
+    std::vector<Island> islands;
+    for (const Iv &iv : ivs) {
+        if (!islands.empty() && islands.back().tid == iv.tid && islands.back().mode == iv.mode && iv.s <= islands.back().e)
+            islands.back().e = std::max(islands.back().e, iv.e);
+        else
+            islands.push_back({iv.tid, iv.mode, iv.s, iv.e, 0});
+    }
+    int64_t npos = 0;
+    for (Island &is : islands) { is.off = npos; npos += is.e - is.s; }
+    p->npos = npos;
+
+    // ---- every segment -> its island (binary search)
+    for (int64_t s = 0; s < nseg; ++s) {
+        GatherSeg &g = p->gsegs[(size_t)s];
+        if (g.clip_hi <= g.clip_lo) continue;
+        const int64_t cs = start[s] + g.clip_lo;
+        const int m = mode_of(strand[s]);
+        size_t lo = 0, hi = islands.size();
+        while (lo < hi) { // last island with (tid,mode,s) <= (tid,m,cs)
+            size_t mid = (lo + hi) / 2;
+            const Island &is = islands[mid];
+            bool le = is.tid < tid[s] || (is.tid == tid[s] && (is.mode < m || (is.mode == m && is.s <= cs)));
+            if (le) lo = mid + 1; else hi = mid;
+        }
+        const Island &is = islands[lo - 1];
+        g.hist_off = is.off + (cs - is.s);
+    }
+
+    // ---- pieces: islands cut at the fixed genome grid of G positions; tiles: grid windows
+    struct RawPiece { int32_t tid; int64_t win; Piece pc_; };
+    std::vector<RawPiece> raw;
+    for (const Island &is : islands) {
+        for (int64_t a = is.s; a < is.e;) {
+            const int64_t win = (a / G) * G;
+            const int64_t b = std::min<int64_t>(is.e, win + G);
+            Piece pc_;
+            pc_.hist_off = is.off + (a - is.s); pc_.start = (int32_t)a; pc_.len = (int32_t)(b - a); pc_.mode = is.mode; pc_.pad = 0;
+            raw.push_back({is.tid, win, pc_});
+            a = b;
+        }
+    }
+    std::sort(raw.begin(), raw.end(), [](const RawPiece &a, const RawPiece &b) {
+        if (a.tid != b.tid) return a.tid < b.tid;
+        if (a.win != b.win) return a.win < b.win;
+        if (a.pc_.mode != b.pc_.mode) return a.pc_.mode < b.pc_.mode;
+        return a.pc_.start < b.pc_.start;
+    });
+    p->pieces.reserve(raw.size());
+    int max_slots = 1;
+    for (size_t i = 0; i < raw.size(); ++i) {
+        if (p->tiles.empty() || p->tiles.back().tid != raw[i].tid || p->tiles.back().win_start != (int32_t)raw[i].win) {
+            Tile t;
+            t.tid = raw[i].tid; t.win_start = (int32_t)raw[i].win; t.piece_begin = (uint32_t)i; t.piece_end = (uint32_t)i; t.mode_mask = 0; t.pad = 0;
+            p->tiles.push_back(t);
+        }
+        Tile &t = p->tiles.back();
+        t.piece_end = (uint32_t)i + 1;
+        t.mode_mask |= 1u << raw[i].pc_.mode;
+        p->pieces.push_back(raw[i].pc_);
+        // 64-position chunks for the ordered center replay (one wave each)
+        for (int32_t a = 0; a < raw[i].pc_.len; a += kWave) {
+            CenterChunk c;
+            c.hist_off = raw[i].pc_.hist_off + a; c.tid = raw[i].tid; c.start = raw[i].pc_.start + a;
+            c.len = std::min<int32_t>(kWave, raw[i].pc_.len - a); c.mode = raw[i].pc_.mode;
+            p->cchunks.push_back(c);
+        }
+    }
+    for (const Tile &t : p->tiles) max_slots = std::max(max_slots, __builtin_popcount(t.mode_mask));
+    p->max_slots = max_slots;
+
+    // ---- gather work list
+    for (int64_t s = 0; s < nseg; ++s) {
+        const int64_t len = p->gsegs[(size_t)s].len;
+        for (int64_t c = 0; c * kGatherChunk < len; ++c) p->gchunks.push_back({(uint32_t)s, (uint32_t)c});
+    }
+
+    int rc = p->d_tiles.upload(p->tiles, e->stream);
+    if (rc == PC_OK) rc = p->d_pieces.upload(p->pieces, e->stream);
+    if (rc == PC_OK) rc = p->d_cchunks.upload(p->cchunks, e->stream);
+    if (rc == PC_OK) rc = p->d_gsegs.upload(p->gsegs, e->stream);
+    if (rc == PC_OK) rc = p->d_gchunks.upload(p->gchunks, e->stream);
+    if (rc == PC_OK) rc = p->d_tile_items.reserve(p->tiles.size() + 1);
+    if (rc == PC_OK) rc = p->d_total.reserve(8);
+    if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: sync failed");
+    if (rc != PC_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return PC_OK;
+}
+
+int pc_plan_destroy(pc_plan *p) {
+    if (!p) return PC_OK;
+    if (p->e) {
+        (void)hipSetDevice(p->e->device);
+        (void)hipStreamSynchronize(p->e->stream);
+    }
+    delete p;
+    return PC_OK;
+}
+
+int64_t pc_plan_positions(pc_plan *p) { return p ? p->npos : -1; }
+int64_t pc_plan_tiles(pc_plan *p) { return p ? (int64_t)p->tiles.size() : -1; }
+
+int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
+    if (!e || !p || p->e != e) return fail(PC_ERR_ARG, "pc_count: bad engine/plan");
+    if (!e->have_map) return fail(PC_ERR_STATE, "pc_count: no mapping rule set (pc_set_mapping)");
+    if (e->files.empty()) return fail(PC_ERR_STATE, "pc_count: no alignments staged (pc_add_alignment_file)");
+    if (out_dtype != PC_OUT_INT64 && out_dtype != PC_OUT_FLOAT64) return fail(PC_ERR_ARG, "pc_count: bad out_dtype");
+    if (p->rows != e->rows) return fail(PC_ERR_ARG, "pc_count: plan built for %d rows, mapping rule has %d", p->rows, e->rows);
+    const bool center = e->kind == PC_MAP_CENTER;
+    if ((center || e->norm_on) && out_dtype != PC_OUT_FLOAT64)
+        return fail(PC_ERR_ARG, "pc_count: center mapping / normalisation produce float64 (map_factories.pyx:230, genome_array.py:826-827)");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = refresh_file_views(e);
+    if (rc != PC_OK) return rc;
+
+    const size_t hist_elem = center ? sizeof(double) : sizeof(uint32_t);
+    const size_t hist_bytes = (size_t)p->npos * p->rows * hist_elem;
+    rc = p->d_hist.reserve(std::max<size_t>(hist_bytes, 8));
+    if (rc == PC_OK) rc = p->d_out.reserve(std::max<size_t>((size_t)p->out_elems * 8, 8));
+    if (rc != PC_OK) return rc;
+
+    const int nfiles = (int)e->files.size();
+    const int W = e->W();
+    const int G = p->G;
+    const int64_t R = 65536;
+    const MapParams mp = e->params();
+    const int ntiles = (int)p->tiles.size();
+    hipStream_t st = e->stream;
+    int64_t nrec = 0, nextra = 0;
+    for (auto *f : e->files) { nrec += f->n; nextra += f->nrun; }
+
+    HIP_TRY(hipEventRecord(e->ev[0], st));
+    // zero-fill: histogram (tiles without reads, atomically merged tiles) and output gaps
+    if (!center && hist_bytes) HIP_TRY(hipMemsetAsync(p->d_hist.p, 0, hist_bytes, st));
+    // slices may leave gaps in the output buffer; gaps read as zero
+    if (p->covered != p->out_elems && p->out_elems) HIP_TRY(hipMemsetAsync(p->d_out.p, 0, (size_t)p->out_elems * 8, st));
+    HIP_TRY(hipEventRecord(e->ev[1], st));
+
+    if (!center) {
+        if (ntiles > 0) {
+            // work list capacity: every record lies in at most 1 + ceil(W/G) scan windows
+            const int64_t cap64 = (int64_t)ntiles * nfiles + ((1 + (W + G - 1) / G) * nrec) / R + nfiles + 16;
+            if (cap64 >= (int64_t)0xffffffffu) return fail(PC_ERR_ARG, "pc_count: work list too large");
+            rc = e->d_work.reserve((size_t)cap64);
+            if (rc != PC_OK) return rc;
+            HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
+            const int64_t nthreads = (int64_t)ntiles * nfiles;
+            hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kWG - 1) / kWG)), dim3(kWG), 0, st, p->d_tiles.p, ntiles,
+                               e->d_files.p, nfiles, G, W, R, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64);
+            HIP_TRY(hipEventRecord(e->ev[2], st));
+            const size_t lds = (size_t)p->max_slots * p->rows * G * sizeof(uint32_t);
+            hipLaunchKernelGGL(k_hist_point, dim3((unsigned)cap64), dim3(kWG), lds, st, p->d_tiles.p, p->d_pieces.p, e->d_files.p,
+                               e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, (uint32_t *)p->d_hist.p, p->npos);
+            HIP_TRY(hipEventRecord(e->ev[3], st));
+            for (auto *f : e->files) {
+                if (!f->nlong) continue;
+                hipLaunchKernelGGL(k_long_point, dim3((unsigned)((f->nlong + kWG - 1) / kWG)), dim3(kWG), 0, st, p->d_tiles.p, ntiles,
+                                   p->d_pieces.p, f->view(), mp, G, p->modes, (uint32_t *)p->d_hist.p, p->npos);
+            }
+        } else {
+            HIP_TRY(hipEventRecord(e->ev[2], st));
+            HIP_TRY(hipEventRecord(e->ev[3], st));
+        }
+        HIP_TRY(hipEventRecord(e->ev[4], st));
+        if (out_dtype == PC_OUT_INT64)
+            launch_gather<uint32_t, int64_t>(e, p, (const uint32_t *)p->d_hist.p, (int64_t *)p->d_out.p);
+        else
+            launch_gather<uint32_t, double>(e, p, (const uint32_t *)p->d_hist.p, (double *)p->d_out.p);
+    } else {
+        HIP_TRY(hipEventRecord(e->ev[2], st));
+        const int64_t nchunks = (int64_t)p->cchunks.size();
+        if (nchunks > 0)
+            hipLaunchKernelGGL(k_center, dim3((unsigned)((nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p,
+                               nfiles, mp, W, e->d_inv.p, (double *)p->d_hist.p);
+        HIP_TRY(hipEventRecord(e->ev[3], st));
+        HIP_TRY(hipEventRecord(e->ev[4], st));
+        launch_gather<double, double>(e, p, (const double *)p->d_hist.p, (double *)p->d_out.p);
+    }
+    HIP_TRY(hipEventRecord(e->ev[5], st));
+    HIP_TRY(hipGetLastError());
+    p->last_dtype = out_dtype;
+    p->counted = true;
+    e->timing_valid = true;
+    // records once (8 B) + extra runs (8 B) + segments (24 B) + outputs once (8 B)
+    e->last_alg_bytes = nrec * 8 + (nextra > 0 ? (nextra - 0) * 8 : 0) + p->nseg * 24 + p->covered * 8;
+    return PC_OK;
+}
+
+int pc_sync(pc_engine *e) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return PC_OK;
+}
+
+int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems) {
+    if (!e || !p || p->e != e || !p->counted) return fail(PC_ERR_STATE, "pc_read_counts: nothing counted yet");
+    if (out_elems != p->out_elems || (out_elems > 0 && !host_out)) return fail(PC_ERR_ARG, "pc_read_counts: buffer size mismatch");
+    HIP_TRY(hipSetDevice(e->device));
+    if (out_elems > 0) HIP_TRY(hipMemcpyAsync(host_out, p->d_out.p, (size_t)out_elems * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return PC_OK;
+}
+
+void *pc_counts_device_ptr(pc_plan *p) { return p ? (void *)p->d_out.p : nullptr; }
+void *pc_stream(pc_engine *e) { return e ? (void *)e->stream : nullptr; }
+void *pc_total_device_ptr(pc_plan *p) { return p ? (void *)p->d_total.p : nullptr; }
+
+int pc_total(pc_engine *e, pc_plan *p, void *host_out8) {
+    if (!e || !p || p->e != e || !p->counted) return fail(PC_ERR_STATE, "pc_total: nothing counted yet");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemsetAsync(p->d_total.p, 0, 8, st));
+    if (p->out_elems > 0) {
+        if (p->last_dtype == PC_OUT_INT64) {
+            hipLaunchKernelGGL(k_total_i64, dim3(1024), dim3(kWG), 0, st, (const int64_t *)p->d_out.p, p->out_elems, (int64_t *)p->d_total.p);
+        } else {
+            const int nb = 1024;
+            int rc = e->d_partial.reserve(nb);
+            if (rc != PC_OK) return rc;
+            hipLaunchKernelGGL(k_total_f64_partial, dim3(nb), dim3(kWG), 0, st, (const double *)p->d_out.p, p->out_elems, e->d_partial.p);
+            hipLaunchKernelGGL(k_total_f64_final, dim3(1), dim3(64), 0, st, e->d_partial.p, nb, (double *)p->d_total.p);
+        }
+    }
+    if (host_out8) HIP_TRY(hipMemcpyAsync(host_out8, p->d_total.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PC_OK;
+}
+
+int pc_last_timing(pc_engine *e, double *ms, int n) {
+    if (!e || !ms || n <= 0) return fail(PC_ERR_ARG, "pc_last_timing: bad arguments");
+    if (!e->timing_valid) return fail(PC_ERR_STATE, "pc_last_timing: nothing counted yet");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev[5]));
+    float t;
+    HIP_TRY(hipEventElapsedTime(&t, e->ev[0], e->ev[5])); e->last_ms[0] = t;
+    HIP_TRY(hipEventElapsedTime(&t, e->ev[1], e->ev[2])); e->last_ms[1] = t;
+    HIP_TRY(hipEventElapsedTime(&t, e->ev[2], e->ev[3])); e->last_ms[2] = t;
+    HIP_TRY(hipEventElapsedTime(&t, e->ev[3], e->ev[4])); e->last_ms[3] = t;
+    HIP_TRY(hipEventElapsedTime(&t, e->ev[4], e->ev[5])); e->last_ms[4] = t;
+    HIP_TRY(hipEventElapsedTime(&t, e->ev[0], e->ev[1])); e->last_ms[5] = t;
+    const int k = std::min(n, 6);
+    for (int i = 0; i < k; ++i) ms[i] = e->last_ms[i];
+    return k;
+}
+
+int64_t pc_last_algorithmic_bytes(pc_engine *e) { return e ? e->last_alg_bytes : -1; }
+
+// ------------------------------------------------------------------ warnings
+int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
+    if (!e || !p || p->e != e || (p->nseg > 0 && !flags)) return fail(PC_ERR_ARG, "pc_warn_flags: bad arguments");
+    if (!e->have_map) return fail(PC_ERR_STATE, "pc_warn_flags: no mapping rule set");
+    std::memset(flags, 0, (size_t)p->nseg);
+    if (e->kind == PC_MAP_STRAT5) return PC_OK; // never warns
+    // cheap pre-check on the per-length record histogram (ignores filters: conservative)
+    bool any = false;
+    for (auto *f : e->files) {
+        for (int L = 0; L < 65536 && !any; ++L) {
+            if (!f->len_hist[(size_t)L]) continue;
+            bool bad;
+            switch (e->kind) {
+            case PC_MAP_FIVE: case PC_MAP_THREE: bad = e->param >= L; break;
+            case PC_MAP_CENTER: bad = L - 2 * e->param < 0; break;
+            default: bad = L >= e->table_len || e->h_fw[(size_t)L] < 0;
+            }
+            any |= bad;
+        }
+    }
+    if (!any) return PC_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = refresh_file_views(e);
+    if (rc != PC_OK) return rc;
+    const MapParams mp = e->params();
+    std::vector<Unmappable> all;
+    for (auto *f : e->files) {
+        if (!f->n) continue;
+        uint32_t cap = 1u << 16;
+        for (;;) {
+            rc = e->d_unmap.reserve(cap);
+            if (rc != PC_OK) return rc;
+            HIP_TRY(hipMemsetAsync(e->d_counters.p + 1, 0, sizeof(uint32_t), e->stream));
+            hipLaunchKernelGGL(k_unmappable, dim3((unsigned)((f->n + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, f->view(), mp, e->ntid,
+                               e->d_unmap.p, cap, e->d_counters.p + 1);
+            uint32_t cnt = 0;
+            HIP_TRY(hipMemcpyAsync(&cnt, e->d_counters.p + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (cnt <= cap) {
+                const size_t base = all.size();
+                all.resize(base + cnt);
+                if (cnt) HIP_TRY(hipMemcpy(all.data() + base, e->d_unmap.p, (size_t)cnt * sizeof(Unmappable), hipMemcpyDeviceToHost));
+                break;
+            }
+            cap = cnt;
+        }
+    }
+    if (all.empty()) return PC_OK;
+    // host: does any unmappable record of the right strand overlap the segment (htslib rule)?
+    std::sort(all.begin(), all.end(), [](const Unmappable &a, const Unmappable &b) {
+        if (a.tid != b.tid) return a.tid < b.tid;
+        return a.pos < b.pos;
+    });
+    const size_t n = all.size();
+    std::vector<int32_t> pmax_f(n), pmax_r(n);
+    for (size_t i = 0; i < n; ++i) {
+        const bool fresh = i == 0 || all[i].tid != all[i - 1].tid;
+        int32_t pf = fresh ? INT32_MIN : pmax_f[i - 1], pr = fresh ? INT32_MIN : pmax_r[i - 1];
+        if (all[i].rev) pr = std::max(pr, all[i].end); else pf = std::max(pf, all[i].end);
+        pmax_f[i] = pf;
+        pmax_r[i] = pr;
+    }
+    for (int64_t s = 0; s < p->nseg; ++s) {
+        const int32_t t = p->h_tid[(size_t)s];
+        if (t < 0 || t >= e->ntid) continue;
+        const int64_t st = p->h_start[(size_t)s], en = p->h_end[(size_t)s];
+        // last record of tid t with pos < en
+        size_t lo = 0, hi = n;
+        while (lo < hi) {
+            size_t mid = (lo + hi) / 2;
+            if (all[mid].tid < t || (all[mid].tid == t && (int64_t)all[mid].pos < en)) lo = mid + 1; else hi = mid;
+        }
+        if (lo == 0 || all[lo - 1].tid != t) continue;
+        const int mode = mode_of(p->h_strand[(size_t)s]);
+        int64_t best;
+        if (mode == 0) best = pmax_f[lo - 1];
+        else if (mode == 1) best = pmax_r[lo - 1];
+        else best = std::max(pmax_f[lo - 1], pmax_r[lo - 1]);
+        if (best > st) flags[s] = 1;
+    }
+    return PC_OK;
+}
+
+int pc_mapped_reads(pc_engine *e, int file, int64_t rec_lo, int64_t rec_hi, int32_t tid, int64_t start, int64_t end,
+                    uint8_t strand, uint8_t *mask) {
+    if (!e || file < 0 || file >= (int)e->files.size()) return fail(PC_ERR_ARG, "pc_mapped_reads: bad file index");
+    if (!e->have_map) return fail(PC_ERR_STATE, "pc_mapped_reads: no mapping rule set");
+    StagedFile *f = e->files[file];
+    if (rec_lo < 0 || rec_hi > f->n || rec_hi < rec_lo || (rec_hi > rec_lo && !mask)) return fail(PC_ERR_ARG, "pc_mapped_reads: bad record range");
+    (void)tid;
+    if (rec_hi == rec_lo) return PC_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    const int64_t n = rec_hi - rec_lo;
+    DevBuf<uint8_t> d_mask;
+    int rc = d_mask.reserve((size_t)n);
+    if (rc != PC_OK) return rc;
+    hipLaunchKernelGGL(k_mapped_reads, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, f->view(), e->params(), rec_lo, rec_hi,
+                       start, end, mode_of(strand), !(strand & PC_STRAND_NOFILTER), d_mask.p);
+    HIP_TRY(hipMemcpyAsync(mask, d_mask.p, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return PC_OK;
+}
+
+} // extern "C"

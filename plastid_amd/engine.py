@@ -1,0 +1,243 @@
+"""Thin Python wrapper over the C ABI (``include/plastid_counts.h``).
+
+:class:`Engine` owns one GPU's staged alignments and mapping state;
+:class:`Plan` is a batch of genomic intervals plus the layout of their count
+vectors.  All counting happens in HIP kernels; this module only moves numpy
+arrays across the ABI.
+"""
+import ctypes
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import (MAP_CENTER, MAP_FIVE, MAP_STRAT5, MAP_THREE, MAP_VAR5, OUT_FLOAT64, OUT_INT64,
+                   check)
+
+STRAND_CODE = {"\x00": 0, "+": 1, "-": 2, ".": 3}  # plastid/genomics/c_common.pxd:1-6
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Engine(object):
+    """One GPU's counting engine (``pc_engine``)."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self._lib.pc_create(int(device), ctypes.byref(h)), "pc_create")
+        self._h = h
+        self.device = int(device)
+        self._finalizer = weakref.finalize(self, self._lib.pc_destroy, h)
+        self.rows = 1
+        self.kind = None
+        self.nfiles = 0
+        self.ntid = 0
+
+    def close(self):
+        self._finalizer()
+
+    # ------------------------------------------------------------ alignments
+    def clear_alignments(self):
+        check(self._lib.pc_clear_alignments(self._h))
+        self.nfiles = 0
+
+    def add_alignment_file(self, packed, ntid=None):
+        """Stage one :class:`~plastid_amd.packing.PackedAlignments` to HBM."""
+        ntid = len(packed.references) if ntid is None else int(ntid)
+        check(self._lib.pc_add_alignment_file(
+            self._h, packed.n, ntid, _ptr(packed.tid), _ptr(packed.pos), _ptr(packed.alen),
+            _ptr(packed.flags), _ptr(packed.nblk), len(packed.blk_start), _ptr(packed.blk_start),
+            _ptr(packed.blk_len)))
+        self.nfiles += 1
+        self.ntid = ntid
+
+    def set_alignments(self, files, ntid=None):
+        self.clear_alignments()
+        for f in files:
+            self.add_alignment_file(f, ntid)
+
+    def update_flags(self, file_index, flags):
+        flags = _c(flags, np.uint8)
+        check(self._lib.pc_update_flags(self._h, int(file_index), len(flags), _ptr(flags)))
+
+    # --------------------------------------------------------------- mapping
+    def set_mapping(self, kind, param=0, fw=None, rc=None, min_len=25, max_len=35):
+        if kind in (MAP_VAR5, MAP_STRAT5):
+            fw = _c(fw, np.int32)
+            rc = _c(rc, np.int32)
+            n = len(fw)
+        else:
+            fw = rc = None
+            n = 0
+        check(self._lib.pc_set_mapping(self._h, int(kind), int(param), _ptr(fw), _ptr(rc), n,
+                                       int(min_len), int(max_len)))
+        self.kind = int(kind)
+        self.rows = self._lib.pc_mapping_rows(self._h)
+
+    def set_size_filter(self, min_len=None, max_len=-1):
+        if min_len is None:
+            check(self._lib.pc_set_size_filter(self._h, 0, 0, -1))
+        else:
+            check(self._lib.pc_set_size_filter(self._h, 1, int(min_len), int(max_len)))
+
+    def set_normalize(self, enabled, total=1.0):
+        check(self._lib.pc_set_normalize(self._h, 1 if enabled else 0, float(total)))
+
+    # ----------------------------------------------------------------- plans
+    def plan(self, tid, start, end, strand, out_off, out_step, row_stride, out_elems, rows=None):
+        return Plan(self, tid, start, end, strand, out_off, out_step, row_stride, out_elems,
+                    self.rows if rows is None else rows)
+
+    def mapped_reads(self, file_index, rec_lo, rec_hi, tid, start, end, strand_code):
+        """``reads_out`` mask of the current mapping rule for one segment over
+        records ``[rec_lo, rec_hi)`` of one staged file."""
+        n = int(rec_hi) - int(rec_lo)
+        mask = np.zeros(max(n, 0), np.uint8)
+        if n > 0:
+            check(self._lib.pc_mapped_reads(self._h, int(file_index), int(rec_lo), int(rec_hi), int(tid),
+                                            int(start), int(end), int(strand_code), _ptr(mask)))
+        return mask
+
+    def sync(self):
+        check(self._lib.pc_sync(self._h))
+
+    def last_timing(self):
+        """ms per phase of the last count: dict(total, worklist, hist, long, gather, zero)."""
+        ms = np.zeros(6, np.float64)
+        k = self._lib.pc_last_timing(self._h, _ptr(ms), 6)
+        if k < 0:
+            check(k)
+        names = ("total", "worklist", "hist", "long", "gather", "zero")
+        return dict(zip(names, ms.tolist()))
+
+    def last_algorithmic_bytes(self):
+        return int(self._lib.pc_last_algorithmic_bytes(self._h))
+
+    @property
+    def stream(self):
+        return self._lib.pc_stream(self._h)
+
+
+class Plan(object):
+    """A batch of GenomicSegments and the layout of their count vectors (``pc_plan``)."""
+
+    def __init__(self, engine, tid, start, end, strand, out_off, out_step, row_stride, out_elems, rows):
+        self.engine = engine
+        self._lib = engine._lib
+        self.tid = _c(tid, np.int32)
+        self.start = _c(start, np.int64)
+        self.end = _c(end, np.int64)
+        self.strand = _c(strand, np.uint8)
+        self.out_off = _c(out_off, np.int64)
+        self.out_step = _c(out_step, np.int8)
+        self.row_stride = _c(row_stride, np.int64)
+        self.nseg = len(self.tid)
+        self.out_elems = int(out_elems)
+        self.rows = int(rows)
+        h = ctypes.c_void_p()
+        check(self._lib.pc_plan_create(
+            engine._h, self.nseg, _ptr(self.tid), _ptr(self.start), _ptr(self.end), _ptr(self.strand),
+            _ptr(self.out_off), _ptr(self.out_step), _ptr(self.row_stride), self.out_elems, self.rows,
+            ctypes.byref(h)))
+        self._h = h
+        # the plan must die before its engine
+        self._finalizer = weakref.finalize(self, Plan._destroy, self._lib, h, engine)
+
+    @staticmethod
+    def _destroy(lib, h, engine):
+        lib.pc_plan_destroy(h)
+
+    def close(self):
+        self._finalizer()
+
+    @property
+    def positions(self):
+        return int(self._lib.pc_plan_positions(self._h))
+
+    @property
+    def tiles(self):
+        return int(self._lib.pc_plan_tiles(self._h))
+
+    def launch(self, dtype):
+        """Asynchronously run the counting kernels; results stay in HBM."""
+        code = OUT_FLOAT64 if np.dtype(dtype) == np.float64 else OUT_INT64
+        check(self._lib.pc_count(self.engine._h, self._h, code))
+        self._dtype = np.dtype(np.float64 if code == OUT_FLOAT64 else np.int64)
+
+    def read(self, out=None):
+        if out is None:
+            out = np.empty(self.out_elems, self._dtype)
+        assert out.dtype == self._dtype and out.size == self.out_elems and out.flags.c_contiguous
+        check(self._lib.pc_read_counts(self.engine._h, self._h, _ptr(out), self.out_elems))
+        return out
+
+    def count(self, dtype, out=None):
+        self.launch(dtype)
+        return self.read(out)
+
+    def warn_flags(self):
+        flags = np.zeros(self.nseg, np.uint8)
+        check(self._lib.pc_warn_flags(self.engine._h, self._h, _ptr(flags)))
+        return flags
+
+    def total(self):
+        buf = np.zeros(1, self._dtype)
+        check(self._lib.pc_total(self.engine._h, self._h, _ptr(buf)))
+        return buf[0]
+
+    @property
+    def device_ptr(self):
+        return self._lib.pc_counts_device_ptr(self._h)
+
+    @property
+    def total_device_ptr(self):
+        return self._lib.pc_total_device_ptr(self._h)
+
+
+_default_engines = {}
+
+
+def default_engine(device=0):
+    """Process-wide engine used when map factories are called directly on read lists."""
+    if device not in _default_engines:
+        _default_engines[device] = Engine(device)
+    return _default_engines[device]
+
+
+def chain_layout(chains_segments, chain_strands, rows=1, stranded=True):
+    """Output layout of a batch of chains, mirroring ``SegmentChain.get_counts``
+    (roitools.pyx:3259-3271): each chain is a ``[rows, chain_length]`` block; its
+    segments sit at their spliced offsets; '-' chains are stored 5'->3'.
+
+    `chains_segments`: list (per chain) of ``[(start, end), ...]`` sorted, merged.
+    Returns ``(seg_chain, out_off, out_step, row_stride, chain_base, chain_len, total)``.
+    """
+    seg_chain, out_off, out_step, row_stride = [], [], [], []
+    chain_base, chain_len = [], []
+    base = 0
+    for ci, (segs, strand) in enumerate(zip(chains_segments, chain_strands)):
+        length = sum(e - s for s, e in segs)
+        chain_base.append(base)
+        chain_len.append(length)
+        rev = stranded and strand == "-"
+        off = 0
+        for s, e in segs:
+            seg_chain.append(ci)
+            if rev:
+                out_off.append(base + length - 1 - off)
+                out_step.append(-1)
+            else:
+                out_off.append(base + off)
+                out_step.append(1)
+            row_stride.append(length)
+            off += e - s
+        base += rows * length
+    return (np.array(seg_chain, np.int64), np.array(out_off, np.int64), np.array(out_step, np.int8),
+            np.array(row_stride, np.int64), np.array(chain_base, np.int64), np.array(chain_len, np.int64), base)

@@ -9,9 +9,30 @@ the warning once per call, which plain :func:`warnings.warn` does.
 import warnings
 
 
-class DataWarning(Warning):
+class DataWarning(UserWarning):
     """Raised when data has attributes that are unexpected, but that may not
-    be cause for alarm (e.g. read alignments too short for a mapping rule)."""
+    be cause for alarm (e.g. read alignments too short for a mapping rule).
+
+    The reference declares ``DataWarning(Warning)`` but its mapping functions call
+    ``warn_onceperfamily(msg, DataWarning)`` with the class in the *pattern*
+    slot (map_factories.pyx:259-263; signature exceptions.py:203), so what users
+    actually receive there is a ``UserWarning`` [observed on the scratch build].
+    Deriving from ``UserWarning`` satisfies filters written against either."""
+
+
+class MalformedFileError(Exception):
+    """A file cannot be parsed as expected (plastid/util/services/exceptions.py)."""
+
+    def __init__(self, filename, message, line_num=None):
+        self.filename = filename
+        self.msg = message
+        self.line_num = line_num
+        Exception.__init__(self, filename, message, line_num)
+
+    def __str__(self):
+        if self.line_num is None:
+            return "Error opening file '%s': %s" % (self.filename, self.msg)
+        return "Error opening file '%s' at line %s: %s" % (self.filename, self.line_num, self.msg)
 
 
 class ArgumentWarning(Warning):

@@ -1,0 +1,445 @@
+"""|BAMGenomeArray| -- the drop-in boundary of the counting path.
+
+Host-side mirror of ``plastid/genomics/genome_array.py:582-1111`` (same method
+names, argument meaning and error behaviour).  The per-segment work of the
+reference's ``get_reads_and_counts`` (:760-832) -- fetch, strand filter, read
+filters, ``map_fn``, normalisation, strand flip -- runs on the GPU through the C
+ABI in ``include/plastid_counts.h``:
+
+* alignment files are packed once (:mod:`plastid_amd.packing`) and staged to HBM;
+* ``get(segment)`` / ``__getitem__`` count one interval;
+* ``get(chain)`` / ``chain.get_counts(ga)`` count a whole |SegmentChain| in one
+  launch; :meth:`BAMGenomeArray.get_counts_batch` counts thousands of chains in
+  one launch (what the counting scripts of the reference do in a Python loop,
+  e.g. ``bin/counts_in_region.py:113-124``).
+
+Arbitrary Python callables keep working exactly as in the reference: a custom
+*mapping function* is simply called (``map_fn(list(reads), roi)``,
+genome_array.py:823) on the reads fetched from the packed records; a custom
+*filter* is evaluated once per read on the host and staged as an exclusion bit so
+the HIP kernels honour it.  Only the five built-in factories and
+``SizeFilterFactory`` are computed on the GPU -- and they are *always* computed
+there (no CPU fallback).
+"""
+import itertools
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from .engine import STRAND_CODE, Engine, chain_layout
+from .exceptions import DataWarning, warn
+from .map_factories import CenterMapFactory, SizeFilterFactory, _EngineMapFactory
+from .packing import FLAG_EXCLUDED, PackedAlignments
+from .roitools import GenomicSegment, SegmentChain
+
+
+def _open_alignment_source(src):
+    """Filenames are read with the package's own BAM reader; objects are used as
+    given (``multiopen`` passes non-str objects through, util/io/openers.py:90-94)."""
+    if isinstance(src, PackedAlignments):
+        return src
+    if isinstance(src, str):
+        from .bam import read_bam
+        return read_bam(src)
+    return src
+
+
+def _pack_source(src, chroms, chrom_index):
+    """Pack any alignment source into a :class:`PackedAlignments` whose ``tid``
+    indexes `chroms` (the array's sorted chromosome list)."""
+    if isinstance(src, PackedAlignments):
+        remap = np.array([chrom_index[r] for r in src.references], np.int32)
+        if len(remap) == len(chroms) and np.array_equal(remap, np.arange(len(chroms))):
+            return src
+        tid = remap[src.tid] if src.n else src.tid
+        if src.n and np.any(np.diff(tid) < 0):
+            order = np.argsort(tid, kind="stable")  # keep BAM order within a contig
+            sub = src.subset(order)
+            tid = tid[order]
+        else:
+            sub = src
+        return PackedAlignments(tid, sub.pos, sub.alen, sub.flags, sub.nblk, sub.blk_start, sub.blk_len,
+                                references=chroms, lengths=[0] * len(chroms), mapped=src.mapped,
+                                read_objects=sub._read_objects)
+    # duck-typed pysam.AlignmentFile: walk every contig in coordinate order
+    reads, tids = [], []
+    for ref, length in zip(src.references, src.lengths):
+        for r in src.fetch(reference=ref, start=0, end=max(int(length), 1) + 2**29):
+            reads.append(r)
+            tids.append(chrom_index[ref])
+    order = np.argsort(np.asarray(tids, np.int64), kind="stable") if reads else []
+    reads = [reads[i] for i in order]
+    tids = [tids[i] for i in order]
+    return PackedAlignments.from_reads(reads, tids=tids, references=chroms, lengths=[0] * len(chroms),
+                                       mapped=getattr(src, "mapped", len(reads)))
+
+
+class BAMGenomeArray(object):
+    """BAMGenomeArray(*bamfiles, mapping=CenterMapFactory())
+
+    A GenomeArray for read alignments in BAM files (genome_array.py:582-1111).
+    `bamfiles`: filenames, :class:`~plastid_amd.packing.PackedAlignments`, or any
+    object with ``fetch/references/lengths/mapped/close``; or one list of those.
+
+    Extra keyword: ``device`` (GPU index, default 0).
+    """
+
+    def __init__(self, *bamfiles, **kwargs):
+        if len(bamfiles) == 1 and isinstance(bamfiles[0], list):  # :657-658
+            bamfiles = bamfiles[0]
+        self.bamfiles = [_open_alignment_source(x) for x in bamfiles]
+        self._strands = ("+", "-", ".")
+        self._normalize = False
+        self._sum = None
+        self._chr_lengths = {}
+        for bamfile in self.bamfiles:  # :667-670
+            for k, v in zip(bamfile.references, bamfile.lengths):
+                self._chr_lengths[k] = max(self._chr_lengths.get(k, 0), v)
+        self._chroms = sorted(list(self._chr_lengths.keys()))  # :672
+        # engine contig order: the files' own order when they all agree (no re-sorting of
+        # records), else the sorted union
+        ref_lists = [tuple(b.references) for b in self.bamfiles]
+        if ref_lists and all(r == ref_lists[0] for r in ref_lists):
+            self._tid_names = list(ref_lists[0])
+        else:
+            self._tid_names = list(self._chroms)
+        self._chrom_index = {c: i for i, c in enumerate(self._tid_names)}
+        self._filters = OrderedDict()
+        self._engine = Engine(kwargs.get("device", 0))
+        self._packed = [_pack_source(x, self._tid_names, self._chrom_index) for x in self.bamfiles]
+        self._engine.set_alignments(self._packed, ntid=max(len(self._tid_names), 1))
+        self._base_flags = [p.flags.copy() for p in self._packed]
+        self._filters_dirty = False
+        self._file_offsets = np.cumsum([0] + [p.n for p in self._packed])
+        self.map_fn = None
+        self.set_mapping(kwargs.get("mapping", CenterMapFactory()))  # :663
+
+    def __del__(self):  # :677-679
+        for bamfile in getattr(self, "bamfiles", []):
+            try:
+                bamfile.close()
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------ bookkeeping
+    def reset_sum(self):
+        """Sum = total mapped reads of all files; filters are not applied (:681-690)."""
+        self._sum = sum([X.mapped for X in self.bamfiles])
+
+    def _update(self):
+        self.reset_sum()
+
+    def set_sum(self, val):
+        self._sum = val
+
+    def sum(self):
+        if self._sum is None:
+            self.reset_sum()
+        return self._sum
+
+    def set_normalize(self, value=True):
+        assert value in (True, False)
+        self._normalize = value
+
+    def chroms(self):
+        return self._chroms
+
+    def strands(self):
+        return self._strands
+
+    def lengths(self):
+        return self._chr_lengths
+
+    def __contains__(self, chrom):
+        return chrom in self._chr_lengths
+
+    def __len__(self):
+        return len(self._strands) * sum(self.lengths().values())
+
+    def __repr__(self):
+        return "<%s len=%s sum=%s chroms=%s strands=%s>" % (
+            self.__class__.__name__, len(self), self.sum(), ",".join(self.chroms()), ",".join(self.strands()))
+
+    __str__ = __repr__
+
+    def add_filter(self, name, func):
+        """Filter reads before mapping and counting (:697-722)."""
+        self._filters[name] = func
+        self._filters_dirty = True
+
+    def remove_filter(self, name):
+        retval = self._filters.pop(name)
+        self._filters_dirty = True
+        return retval
+
+    def get_mapping(self):
+        return self.map_fn.__doc__
+
+    def set_mapping(self, mapping_function):
+        """Change the mapping rule (:935-963)."""
+        self.map_fn = mapping_function
+        self._update()
+
+    # ------------------------------------------------------- engine plumbing
+    def _native(self):
+        return isinstance(self.map_fn, _EngineMapFactory)
+
+    def _sync_engine(self):
+        """Push mapping rule, filters and normalisation to the engine."""
+        self.map_fn._configure(self._engine)
+        if self._filters_dirty or not hasattr(self, "_size_filter_state"):
+            size = None
+            custom = []
+            for f in self._filters.values():
+                if isinstance(f, SizeFilterFactory) and size is None:
+                    size = f
+                else:
+                    custom.append(f)
+            # arbitrary callables (and any further size filters): evaluate per read on the host,
+            # stage the verdicts as exclusion bits
+            for fi, packed in enumerate(self._packed):
+                flags = self._base_flags[fi].copy()
+                if custom and packed.n:
+                    keep = np.ones(packed.n, bool)
+                    for i in range(packed.n):
+                        read = packed.read(i)
+                        for f in custom:
+                            if not f(read):
+                                keep[i] = False
+                                break
+                    flags[~keep] |= FLAG_EXCLUDED
+                if not np.array_equal(flags, packed.flags):
+                    packed.flags = flags
+                    self._engine.update_flags(fi, flags)
+            self._size_filter_state = size
+            self._filters_dirty = False
+        size = self._size_filter_state
+        if size is None:
+            self._engine.set_size_filter(None)
+        else:
+            self._engine.set_size_filter(size.min_, size.max_)
+        if self._normalize is True:
+            self._engine.set_normalize(True, float(self.sum()))  # count / float(sum) * 1e6, :826-827
+        else:
+            self._engine.set_normalize(False)
+
+    def _out_dtype(self):
+        if self._normalize is True or self.map_fn._kind == _lib.MAP_CENTER:
+            return np.float64
+        return np.int64
+
+    def _warn_if_unmappable(self, plan):
+        if self.map_fn._kind == _lib.MAP_STRAT5:
+            return
+        if plan.warn_flags().any():
+            msg = self.map_fn._warn_message()
+            warn(msg, DataWarning, stacklevel=4)
+
+    # --------------------------------------------------------------- queries
+    def _fetch_filtered(self, roi):
+        """Host-side read objects for `roi`: fetch, strand filter, filters (:800-820)."""
+        reads = itertools.chain.from_iterable(
+            (X.fetch(reference=roi.chrom, start=roi.start, end=roi.end) for X in self._packed_sources()))
+        if roi.strand == "+":
+            reads = filter(lambda x: x.is_reverse is False, reads)
+        elif roi.strand == "-":
+            reads = filter(lambda x: x.is_reverse is True, reads)
+        for my_filter in self._filters.values():
+            reads = filter(my_filter, reads)
+        return list(reads)
+
+    def _packed_sources(self):
+        return self._packed
+
+    def get_reads_and_counts(self, roi, roi_order=True):
+        """Reads covering a |GenomicSegment| and the count vector under the current
+        mapping rule (genome_array.py:760-832)."""
+        chrom, strand = roi.chrom, roi.strand
+        if chrom not in self._chr_lengths:  # :795-798
+            shape = [1] + getattr(self.map_fn, "shape", [])
+            return [], np.zeros(shape)
+
+        if not self._native():
+            # plugin mapping function: same call as the reference (:823)
+            reads, count_array = self.map_fn(self._fetch_filtered(roi), roi)
+            if self._normalize is True:
+                count_array = count_array / float(self.sum()) * 1e6
+            if roi_order is True and strand == "-":
+                count_array = count_array[..., ::-1]
+            return reads, count_array
+
+        count_array, plan = self._count_segments([roi], roi_order=roi_order, keep_plan=True)
+        tid = self._chrom_index[chrom]
+        code = roi.c_strand
+        reads = []
+        for fi, packed in enumerate(self._packed):
+            idx = packed.fetch_indices(chrom, roi.start, roi.end)
+            if len(idx) == 0:
+                continue
+            lo, hi = int(idx[0]), int(idx[-1]) + 1
+            mask = self._engine.mapped_reads(fi, lo, hi, tid, roi.start, roi.end, code)
+            reads.extend(packed.read(i) for i in (lo + np.nonzero(mask)[0]))
+        self._warn_if_unmappable(plan)
+        plan.close()
+        rows = self._engine.rows
+        if self.map_fn._kind == _lib.MAP_STRAT5:
+            count_array = count_array.reshape(rows, len(roi))
+        return reads, count_array
+
+    def get_reads(self, roi):
+        reads, _ = self.get_reads_and_counts(roi)
+        return reads
+
+    def __getitem__(self, roi):
+        return self.get(roi, roi_order=True)
+
+    def get(self, roi, roi_order=True):
+        """Count vector over a |GenomicSegment| or |SegmentChain| (:891-928)."""
+        if isinstance(roi, SegmentChain):
+            return roi.get_counts(self)
+        if not self._native() or roi.chrom not in self._chr_lengths:
+            _, count_array = self.get_reads_and_counts(roi, roi_order=roi_order)
+            return count_array
+        count_array, plan = self._count_segments([roi], roi_order=roi_order, keep_plan=True)
+        self._warn_if_unmappable(plan)
+        plan.close()
+        if self.map_fn._kind == _lib.MAP_STRAT5:
+            count_array = count_array.reshape(self._engine.rows, len(roi))
+        return count_array
+
+    def _count_segments(self, segs, roi_order, keep_plan=False):
+        """One launch over independent segments, each laid out like ``get(seg, roi_order)``."""
+        self._sync_engine()
+        rows = self._engine.rows
+        tid = [self._chrom_index.get(s.chrom, -1) for s in segs]
+        start = [s.start for s in segs]
+        end = [s.end for s in segs]
+        strand = [s.c_strand for s in segs]
+        out_off, out_step, row_stride = [], [], []
+        base = 0
+        for s in segs:
+            n = len(s)
+            if roi_order is True and s.strand == "-":  # :829-830
+                out_off.append(base + n - 1)
+                out_step.append(-1)
+            else:
+                out_off.append(base)
+                out_step.append(1)
+            row_stride.append(n)
+            base += rows * n
+        plan = self._engine.plan(tid, start, end, strand, out_off, out_step, row_stride, base, rows)
+        out = plan.count(self._out_dtype())
+        if keep_plan:
+            return out, plan
+        plan.close()
+        return out
+
+    def _get_chain_counts(self, chain, stranded=True):
+        """``SegmentChain.get_counts`` for this array: one launch for the whole chain
+        (roitools.pyx:3259-3271 semantics, float64 result)."""
+        if not self._native():
+            return _generic_chain_counts(self, chain, stranded)
+        if chain.chrom not in self._chr_lengths:
+            # unknown chromosome: every segment yields zeros([1]+shape), which broadcasts
+            # into a 1-D chain vector and cannot into a stratified one (Q9)
+            return _generic_chain_counts(self, chain, stranded)
+        out = self.get_counts_batch([chain], stranded=stranded)
+        return out[0]
+
+    def get_counts_batch(self, chains, stranded=True):
+        """Count many |SegmentChains| in ONE launch.  Returns a list of float64
+        arrays, each what ``chain.get_counts(self, stranded)`` returns."""
+        if not self._native():
+            return [c.get_counts(self, stranded) for c in chains]
+        self._sync_engine()
+        rows = self._engine.rows
+        segs, strands = [], []
+        for c in chains:
+            segs.append([(s.start, s.end) for s in c])
+            strands.append(c.strand)
+        seg_chain, out_off, out_step, row_stride, chain_base, chain_len, total = chain_layout(
+            segs, strands, rows=rows, stranded=stranded is True)
+        tid = np.array([self._chrom_index.get(chains[ci].chrom, -1) for ci in seg_chain], np.int32)
+        flat = [se for chain_segs in segs for se in chain_segs]
+        start = np.array([s for s, _ in flat], np.int64)
+        end = np.array([e for _, e in flat], np.int64)
+        strand = np.array([chains[ci].c_strand for ci in seg_chain], np.uint8)
+        plan = self._engine.plan(tid, start, end, strand, out_off, out_step, row_stride, total, rows)
+        out = plan.count(np.float64)  # SegmentChain.get_counts always returns float (roitools.pyx:3262)
+        self._warn_if_unmappable(plan)
+        plan.close()
+        results = []
+        strat = self.map_fn._kind == _lib.MAP_STRAT5
+        for ci, c in enumerate(chains):
+            if len(c) == 0:
+                results.append(c.get_counts(self, stranded))
+                continue
+            block = out[chain_base[ci]:chain_base[ci] + rows * chain_len[ci]]
+            results.append(block.reshape(rows, chain_len[ci]) if strat else block)
+        return results
+
+    # ---------------------------------------------------------------- export
+    def to_bedgraph(self, fh, trackname, strand, window_size=100000, printer=None, **kwargs):
+        """Write a bedGraph under the current mapping rule (:1041-1111)."""
+        assert strand in self.strands()
+        assert window_size > 0
+        fh.write("track type=bedGraph name=%s" % trackname)
+        for k, v in sorted(kwargs.items(), key=lambda x: x[0]):
+            fh.write(" %s=%s" % (k, v))
+        fh.write("\n")
+        for chrom in sorted(self.chroms()):
+            if printer is not None:
+                printer.write("Writing chromosome %s..." % chrom)
+            my_size = self.lengths()[chrom]
+            for my_start in range(0, my_size, window_size):
+                my_end = min(my_start + window_size, my_size)
+                my_counts = self.get(GenomicSegment(chrom, my_start, my_end, strand), roi_order=False)
+                if my_counts.sum() > 0:
+                    genomic_start_x = my_start
+                    last_val = my_counts[0]
+                    change = np.nonzero(my_counts[1:] != my_counts[:-1])[0]
+                    for x in change:
+                        genomic_end_x = 1 + int(x) + my_start
+                        if last_val > 0:
+                            fh.write("%s\t%s\t%s\t%s\n" % (chrom, genomic_start_x, genomic_end_x, last_val))
+                        last_val = my_counts[x + 1]
+                        genomic_start_x = genomic_end_x
+                    if last_val > 0:
+                        fh.write("%s\t%s\t%s\t%s\n" % (chrom, genomic_start_x, my_end, last_val))
+
+    def to_variable_step(self, fh, trackname, strand, window_size=100000, printer=None, **kwargs):
+        """Write a variableStep wiggle under the current mapping rule (:990-1039)."""
+        assert strand in self.strands()
+        fh.write("track type=wiggle_0 name=%s" % trackname)
+        for k, v in sorted(kwargs.items(), key=lambda x: x[0]):
+            fh.write(" %s=%s" % (k, v))
+        fh.write("\n")
+        for chrom in sorted(self.chroms()):
+            my_size = self.lengths()[chrom]
+            if printer is not None:
+                printer.write("Writing chromosome %s..." % chrom)
+            fh.write("variableStep chrom=%s span=1\n" % chrom)
+            for my_start in range(0, my_size, window_size):
+                my_end = min(my_start + window_size, my_size)
+                my_counts = self.get(GenomicSegment(chrom, my_start, my_end, strand), roi_order=False)
+                if my_counts.sum() > 0:
+                    for idx in my_counts.nonzero()[0]:
+                        fh.write("%s\t%s\n" % (my_start + idx + 1, my_counts[idx]))
+
+
+def _generic_chain_counts(ga, chain, stranded):
+    """The reference's per-segment loop (roitools.pyx:3259-3271) for array objects
+    or situations the batched path does not cover."""
+    count_arrays = [ga.get(X, roi_order=False) for X in chain]
+    dims = list(count_arrays[0].shape)
+    dims[-1] = chain.length
+    count_array = np.empty(dims, dtype=float)
+    i = 0
+    for n, seg in enumerate(chain):
+        j = i + len(seg)
+        count_array[..., i:j] = count_arrays[n]
+        i = j
+    if chain.c_strand == 2 and stranded is True:
+        count_array = count_array[..., ::-1]
+    return count_array

@@ -1,0 +1,370 @@
+"""Seeded synthetic workloads of the BASELINE configs.
+
+Everything is generated with ``numpy.random.default_rng(seed)`` (PCG64) and
+vectorised so that 10^8 records can be produced on the host in about a minute.
+Used by ``bench.py`` and by the parity tests; contains no counting logic.
+
+* genomes: yeast-scale (17 contigs, sacCer3-like lengths, 12.16 Mb) and
+  human-scale (25 contigs, hg38-like lengths, 3.1 Gb);
+* transcripts: log-normal spliced lengths, uniform placement, overlaps allowed;
+* reads: 90 % drawn inside transcripts (5' end uniform in spliced coordinates,
+  projected to the genome, so junction-spanning reads get N gaps), 10 % uniform
+  background; footprint-like aligned lengths 25..34; 1 % of the records carry a
+  1-nt deletion; records sorted by (tid, pos), stable.
+"""
+import numpy as np
+
+from .packing import FLAG_REVERSE, PackedAlignments
+
+YEAST = (
+    ["chrI", "chrII", "chrIII", "chrIV", "chrV", "chrVI", "chrVII", "chrVIII", "chrIX", "chrX", "chrXI",
+     "chrXII", "chrXIII", "chrXIV", "chrXV", "chrXVI", "chrM"],
+    [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 439888, 745751, 666816, 1078177,
+     924431, 784333, 1091291, 948066, 85779])
+
+HUMAN = (
+    ["chr%s" % x for x in list(range(1, 23)) + ["X", "Y", "M"]],
+    [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+     133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
+     58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569])
+
+FOOTPRINT_LENGTHS = np.arange(25, 35)
+FOOTPRINT_PMF = np.array([1, 2, 4, 10, 20, 22, 18, 10, 6, 3], float)
+FOOTPRINT_PMF /= FOOTPRINT_PMF.sum()
+
+#: the reference's own expected offset table (test_argparsers.py:75-83)
+VARIABLE_OFFSETS = {26: 12, 27: 12, 28: 13, 29: 13, 30: 14, 31: 13, "default": 13}
+
+
+class Transcripts(object):
+    """CSR table of transcripts: exons ``ex_start/ex_end`` (genomic, ascending) of
+    transcript ``t`` are ``ex_off[t]:ex_off[t+1]``."""
+
+    def __init__(self, names, lengths, tid, strand, ex_off, ex_start, ex_end):
+        self.references = list(names)
+        self.ref_lengths = list(lengths)
+        self.tid = np.asarray(tid, np.int32)
+        self.strand = np.asarray(strand, np.uint8)  # 1 '+', 2 '-'
+        self.ex_off = np.asarray(ex_off, np.int64)
+        self.ex_start = np.asarray(ex_start, np.int64)
+        self.ex_end = np.asarray(ex_end, np.int64)
+        self.n = len(self.tid)
+        ex_len = self.ex_end - self.ex_start
+        self.ex_cum = np.zeros(len(ex_len) + 1, np.int64)  # spliced offset of each exon (global running sum)
+        np.cumsum(ex_len, out=self.ex_cum[1:])
+        self.length = self.ex_cum[self.ex_off[1:]] - self.ex_cum[self.ex_off[:-1]]
+        self.ex_tx = np.repeat(np.arange(self.n), np.diff(self.ex_off))
+
+    @property
+    def n_segments(self):
+        return len(self.ex_start)
+
+    @property
+    def n_positions(self):
+        return int(self.length.sum())
+
+    def subset(self, idx):
+        idx = np.asarray(idx)
+        cnt = np.diff(self.ex_off)[idx]
+        sel = np.concatenate([np.arange(self.ex_off[i], self.ex_off[i + 1]) for i in idx]) if len(idx) else \
+            np.zeros(0, np.int64)
+        off = np.zeros(len(idx) + 1, np.int64)
+        np.cumsum(cnt, out=off[1:])
+        return Transcripts(self.references, self.ref_lengths, self.tid[idx], self.strand[idx], off,
+                           self.ex_start[sel], self.ex_end[sel])
+
+    def plan_arrays(self, rows=1, stranded=True):
+        """Segment table + output layout of ``chain.get_counts`` for every transcript
+        (each chain a ``[rows, length]`` block, '-' chains 5'->3')."""
+        seg_tx = self.ex_tx
+        seg_len = self.ex_end - self.ex_start
+        # spliced offset of each exon within its transcript
+        off_in_tx = self.ex_cum[:-1] - self.ex_cum[self.ex_off[:-1]][seg_tx]
+        chain_base = np.zeros(self.n + 1, np.int64)
+        np.cumsum(self.length * rows, out=chain_base[1:])
+        tx_len = self.length[seg_tx]
+        rev = (self.strand[seg_tx] == 2) & bool(stranded)
+        out_off = np.where(rev, chain_base[:-1][seg_tx] + tx_len - 1 - off_in_tx,
+                           chain_base[:-1][seg_tx] + off_in_tx)
+        out_step = np.where(rev, -1, 1).astype(np.int8)
+        return dict(tid=self.tid[seg_tx].astype(np.int32), start=self.ex_start.copy(), end=self.ex_end.copy(),
+                    strand=self.strand[seg_tx].astype(np.uint8), out_off=out_off.astype(np.int64),
+                    out_step=out_step, row_stride=tx_len.astype(np.int64), out_elems=int(chain_base[-1]),
+                    chain_base=chain_base, seg_len=seg_len)
+
+    def chains(self, limit=None):
+        """|SegmentChain| objects (Python objects: use for small sets only)."""
+        from .roitools import GenomicSegment, SegmentChain
+        out = []
+        for t in range(self.n if limit is None else min(limit, self.n)):
+            s = "+" if self.strand[t] == 1 else "-"
+            segs = [GenomicSegment(self.references[self.tid[t]], int(self.ex_start[j]), int(self.ex_end[j]), s)
+                    for j in range(self.ex_off[t], self.ex_off[t + 1])]
+            c = SegmentChain()
+            c._set_segments(segs)
+            out.append(c)
+        return out
+
+
+def _place(rng, lengths, span):
+    """Uniform placement of features with genomic `span` on contigs chosen in
+    proportion to the room they offer."""
+    lengths = np.asarray(lengths, np.int64)
+    n = len(span)
+    tid = np.empty(n, np.int64)
+    start = np.empty(n, np.int64)
+    todo = np.arange(n)
+    p = lengths / lengths.sum()
+    while len(todo):
+        t = rng.choice(len(lengths), size=len(todo), p=p)
+        room = lengths[t] - span[todo]
+        ok = room > 0
+        tid[todo[ok]] = t[ok]
+        start[todo[ok]] = (rng.random(ok.sum()) * room[ok]).astype(np.int64)
+        todo = todo[~ok]
+    return tid, start
+
+
+def make_transcripts(genome, n, seed, style="yeast"):
+    """Synthetic annotation.  `style` = ``"yeast"`` (log-normal
+    spliced length, 5 % two-exon) or ``"human"`` (geometric exon counts)."""
+    names, lengths = genome
+    rng = np.random.default_rng(seed)
+    if style == "yeast":
+        tx_len = np.clip(np.exp(rng.normal(np.log(1400.0), 0.6, n)), 200, 15000).astype(np.int64)
+        two = rng.random(n) < 0.05
+        nex = np.where(two, 2, 1).astype(np.int64)
+        ex_off = np.zeros(n + 1, np.int64)
+        np.cumsum(nex, out=ex_off[1:])
+        cut = (rng.random(n) * (tx_len - 60)).astype(np.int64) + 30
+        intron = rng.integers(100, 501, n)
+        ex_len = np.empty(ex_off[-1], np.int64)
+        gap = np.zeros(ex_off[-1], np.int64)  # intron before this exon
+        first = ex_off[:-1]
+        ex_len[first] = np.where(two, cut, tx_len)
+        second = first[two] + 1
+        ex_len[second] = (tx_len - cut)[two]
+        gap[second] = intron[two]
+    elif style == "human":
+        nex = np.minimum(rng.geometric(1.0 / 8.0, n), 60).astype(np.int64)
+        ex_off = np.zeros(n + 1, np.int64)
+        np.cumsum(nex, out=ex_off[1:])
+        m = int(ex_off[-1])
+        ex_len = np.clip(np.exp(rng.normal(np.log(150.0), 0.7, m)), 30, 5000).astype(np.int64)
+        gap = np.clip(np.exp(rng.normal(np.log(1500.0), 1.2, m)), 70, 200000).astype(np.int64)
+        gap[ex_off[:-1]] = 0
+    else:
+        raise ValueError(style)
+    # genomic offsets of exons relative to the transcript start
+    rel_end = np.cumsum(ex_len + gap)
+    rel_end_tx0 = np.concatenate([[0], rel_end])[ex_off[:-1]]
+    ex_tx = np.repeat(np.arange(n), np.diff(ex_off))
+    rel_e = rel_end - rel_end_tx0[ex_tx]
+    rel_s = rel_e - ex_len
+    span = rel_e[ex_off[1:] - 1]
+    tid, start = _place(rng, lengths, span)
+    strand = np.where(rng.random(n) < 0.5, 1, 2)
+    return Transcripts(names, lengths, tid, strand, ex_off, start[ex_tx] + rel_s, start[ex_tx] + rel_e)
+
+
+def _project(tx, t, x, L):
+    """Project spliced intervals ``[x, x+L)`` of transcripts `t` onto the genome.
+    Returns CSR aligned runs ``(nblk, run_start, run_len)`` in genome order."""
+    n = len(t)
+    gx = tx.ex_cum[tx.ex_off[t]] + x                      # global spliced coordinate
+    e = np.searchsorted(tx.ex_cum, gx, side="right") - 1  # exon holding the first base
+    starts, lens, owner = [], [], []
+    nblk = np.zeros(n, np.int64)
+    active = np.arange(n)
+    cur_e = e.copy()
+    cur_g = gx.copy()
+    remaining = L.astype(np.int64).copy()
+    while len(active):
+        room = tx.ex_cum[cur_e[active] + 1] - cur_g[active]
+        take = np.minimum(room, remaining[active])
+        starts.append(tx.ex_start[cur_e[active]] + (cur_g[active] - tx.ex_cum[cur_e[active]]))
+        lens.append(take)
+        owner.append(active)
+        nblk[active] += 1
+        remaining[active] -= take
+        cur_g[active] += take
+        cur_e[active] += 1
+        active = active[remaining[active] > 0]
+    owner = np.concatenate(owner)
+    starts = np.concatenate(starts)
+    lens = np.concatenate(lens)
+    order = np.lexsort((starts, owner))                   # by read, then left to right
+    owner, starts, lens = owner[order], starts[order], lens[order]
+    # merge runs that are adjacent on the genome (abutting exons)
+    same = (owner[1:] == owner[:-1]) & (starts[1:] == starts[:-1] + lens[:-1])
+    if same.any():
+        grp = np.concatenate([[0], np.cumsum(~same)])
+        first = np.concatenate([[True], ~same])
+        lens = np.bincount(grp, weights=lens).astype(np.int64)
+        starts = starts[first]
+        owner = owner[first]
+        nblk = np.bincount(owner, minlength=n).astype(np.int64)
+    return nblk, owner, starts, lens
+
+
+def make_reads(genome, tx, n, seed, paired=False, length_pmf=None, in_tx_frac=0.9, del_frac=0.01,
+               expr_sigma=1.5):
+    """Synthetic coordinate-sorted alignment records as a
+    :class:`PackedAlignments`.  `paired`: two mates per fragment (fragment length
+    N(180,30) >= 60, mate length U[25,50], mate 2 on the opposite strand); the
+    reference treats mates as independent records."""
+    names, lengths = genome
+    lengths = np.asarray(lengths, np.int64)
+    rng = np.random.default_rng(seed)
+    nfrag = n // 2 if paired else n
+    n_in = int(round(nfrag * in_tx_frac)) if tx is not None and tx.n else 0
+    n_bg = nfrag - n_in
+
+    rec_tid, rec_rev, rec_nblk = [], [], []
+    run_owner, run_start, run_len = [], [], []
+    base = 0
+
+    def add(tid, rev, nblk, owner, starts, lens):
+        nonlocal base
+        rec_tid.append(tid.astype(np.int64))
+        rec_rev.append(rev.astype(bool))
+        rec_nblk.append(nblk.astype(np.int64))
+        run_owner.append(owner + base)
+        run_start.append(starts.astype(np.int64))
+        run_len.append(lens.astype(np.int64))
+        base += len(tid)
+
+    def draw_len(k):
+        if paired:
+            return rng.integers(25, 51, k)
+        pmf = FOOTPRINT_PMF if length_pmf is None else np.asarray(length_pmf[1], float)
+        vals = FOOTPRINT_LENGTHS if length_pmf is None else np.asarray(length_pmf[0])
+        return rng.choice(vals, size=k, p=pmf / pmf.sum())
+
+    if n_in:
+        w = np.exp(rng.normal(0.0, expr_sigma, tx.n))
+        cdf = np.cumsum(w)
+        t = np.searchsorted(cdf, rng.random(n_in) * cdf[-1], side="right").clip(0, tx.n - 1)
+        tlen = tx.length[t]
+        fwd_tx = tx.strand[t] == 1
+        if not paired:
+            L = np.minimum(draw_len(n_in), tlen)
+            x = (rng.random(n_in) * (tlen - L + 1)).astype(np.int64)
+            nb, ow, st, ln = _project(tx, t, x, L)
+            add(tx.tid[t], ~fwd_tx, nb, ow, st, ln)
+        else:
+            frag = np.minimum(np.maximum(rng.normal(180.0, 30.0, n_in), 60).astype(np.int64), tlen)
+            fx = (rng.random(n_in) * (tlen - frag + 1)).astype(np.int64)
+            L1 = np.minimum(draw_len(n_in), frag)
+            L2 = np.minimum(draw_len(n_in), frag)
+            # mate 1 at the fragment's 5' end (transcript orientation), mate 2 at its 3' end
+            x1 = np.where(fwd_tx, fx, fx + frag - L1)
+            x2 = np.where(fwd_tx, fx + frag - L2, fx)
+            nb, ow, st, ln = _project(tx, t, x1, L1)
+            add(tx.tid[t], ~fwd_tx, nb, ow, st, ln)
+            nb, ow, st, ln = _project(tx, t, x2, L2)
+            add(tx.tid[t], fwd_tx, nb, ow, st, ln)
+    if n_bg:
+        k = n_bg * (2 if paired else 1)
+        L = draw_len(k)
+        tid, start = _place(rng, lengths, L.astype(np.int64))
+        add(tid, rng.random(k) < 0.5, np.ones(k, np.int64), np.arange(k), start, L)
+
+    tid = np.concatenate(rec_tid)
+    rev = np.concatenate(rec_rev)
+    nblk = np.concatenate(rec_nblk)
+    owner = np.concatenate(run_owner)
+    rstart = np.concatenate(run_start)
+    rlen = np.concatenate(run_len)
+    nrec = len(tid)
+    o = np.argsort(owner, kind="stable")
+    owner, rstart, rlen = owner[o], rstart[o], rlen[o]
+    run_off = np.zeros(nrec + 1, np.int64)
+    np.cumsum(nblk, out=run_off[1:])
+
+    # 1-nt deletions: split the first run of a random 1 % of records (needs >= 2 bases there)
+    if del_frac > 0 and nrec:
+        cand = np.nonzero((rng.random(nrec) < del_frac) & (rlen[run_off[:-1]] >= 4))[0]
+        if len(cand):
+            first = run_off[cand]
+            cutat = 1 + (rng.random(len(cand)) * (rlen[first] - 2)).astype(np.int64)
+            # room: the deleted base pushes the rest right by one; keep inside the contig and
+            # away from the next run of the same read
+            next_ok = np.ones(len(cand), bool)
+            multi = nblk[cand] > 1
+            next_ok[multi] = rstart[first[multi] + 1] > rstart[first[multi]] + rlen[first[multi]] + 1
+            fits = rstart[first] + rlen[first] + 1 <= lengths[tid[cand]]
+            keep = next_ok & fits
+            cand, first, cutat = cand[keep], first[keep], cutat[keep]
+            new_start = rstart[first] + cutat + 1
+            new_len = rlen[first] - cutat
+            rlen[first] = cutat
+            # later runs of the same read do not move (they are anchored on the genome)
+            ins_at = first + 1
+            owner = np.insert(owner, ins_at, cand)
+            rstart = np.insert(rstart, ins_at, new_start)
+            rlen = np.insert(rlen, ins_at, new_len)
+            nblk[cand] += 1
+            np.cumsum(nblk, out=run_off[1:])
+
+    pos = rstart[run_off[:-1]]
+    alen = np.bincount(owner, weights=rlen, minlength=nrec).astype(np.int64)
+    key = (tid << 32) | pos
+    order = np.argsort(key, kind="stable")
+    tid, pos, alen, rev, nblk = tid[order], pos[order], alen[order], rev[order], nblk[order]
+    # gather the runs of multi-run records in the new record order
+    multi = nblk >= 2
+    src_off = run_off[:-1][order][multi]
+    cnt = nblk[multi]
+    if len(cnt):
+        tot = int(cnt.sum())
+        dst_off = np.zeros(len(cnt) + 1, np.int64)
+        np.cumsum(cnt, out=dst_off[1:])
+        idx = np.repeat(src_off - dst_off[:-1], cnt) + np.arange(tot)
+        blk_start, blk_len = rstart[idx], rlen[idx]
+    else:
+        blk_start = blk_len = np.zeros(0, np.int64)
+    flags = np.where(rev, FLAG_REVERSE, 0).astype(np.uint8)
+    return PackedAlignments(tid.astype(np.int32), pos.astype(np.int32), alen.astype(np.uint16), flags,
+                            nblk.astype(np.uint8), blk_start.astype(np.int32), blk_len.astype(np.int32),
+                            references=names, lengths=[int(x) for x in lengths], mapped=nrec,
+                            validate=nrec <= 5_000_000)
+
+
+CONFIGS = {
+    # name: (genome, tx style, n_tx, tx seed, n_reads, read seed, paired, mapping)
+    "C1": ("yeast", "yeast", 200, 2001, 1_000_000, 1001, False, ("fiveprime", 0)),
+    "C2": ("yeast", "yeast", 20_000, 2001, 100_000_000, 1002, False, ("fiveprime", 12)),
+    "C3": ("yeast", "yeast", 20_000, 2001, 100_000_000, 1003, False, ("center", 0)),
+    "C4": ("human", "human", 60_000, 2004, 500_000_000, 1004, False, ("variable", VARIABLE_OFFSETS)),
+    "C5": ("human", "human", 60_000, 2004, 1_000_000_000, 1005, True, ("stratified", VARIABLE_OFFSETS, 25, 35)),
+}
+
+
+def make_config(name, scale=1.0, tx_scale=None, seed_shift=0):
+    """Build ``(genome, transcripts, packed reads, mapping)`` for BASELINE config
+    `name`; `scale` shrinks the read count (and `tx_scale` the transcript count)."""
+    gname, style, n_tx, tx_seed, n_reads, r_seed, paired, mapping = CONFIGS[name]
+    genome = YEAST if gname == "yeast" else HUMAN
+    n_tx = max(1, int(round(n_tx * (scale if tx_scale is None else tx_scale))))
+    n_reads = max(2, int(round(n_reads * scale)))
+    tx = make_transcripts(genome, n_tx, tx_seed, style)
+    reads = make_reads(genome, tx, n_reads, r_seed + seed_shift, paired=paired)
+    return genome, tx, reads, mapping
+
+
+def mapping_factory(mapping):
+    """``("fiveprime", 12)`` -> the map factory instance."""
+    from . import map_factories as mf
+    kind = mapping[0]
+    if kind == "fiveprime":
+        return mf.FivePrimeMapFactory(mapping[1])
+    if kind == "threeprime":
+        return mf.ThreePrimeMapFactory(mapping[1])
+    if kind == "center":
+        return mf.CenterMapFactory(mapping[1])
+    if kind == "variable":
+        return mf.VariableFivePrimeMapFactory(mapping[1])
+    if kind == "stratified":
+        return mf.StratifiedVariableFivePrimeMapFactory(mapping[1], mapping[2], mapping[3])
+    raise ValueError(kind)

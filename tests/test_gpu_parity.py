@@ -1,0 +1,300 @@
+"""Parity of the HIP path against (a) golden vectors from the reference and (b) the
+oracle on seeded random inputs.  Needs a real MI355X: ``pytest -m gpu``."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import golden_util as gu  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import plastid_amd
+    return plastid_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    o.lib()
+    return o
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+
+
+def files_of(pa, g, case):
+    """Split a fixture's file-major arrays back into PackedAlignments files."""
+    aln = g.aln(case)
+    refs, lens = case["aln"]["references"], case["aln"]["lengths"]
+    files = []
+    off = np.cumsum(np.where(aln["nblk"] >= 2, aln["nblk"], 0).astype(np.int64))
+    off = np.concatenate([[0], off])
+    for k in range(case["aln"]["nfiles"]):
+        idx = np.nonzero(aln["file_id"] == k)[0]
+        lo, hi = (idx[0], idx[-1] + 1) if len(idx) else (0, 0)
+        files.append(pa.PackedAlignments(
+            aln["tid"][lo:hi], aln["pos"][lo:hi], aln["alen"][lo:hi], aln["flags"][lo:hi], aln["nblk"][lo:hi],
+            aln["blk_start"][off[lo]:off[hi]], aln["blk_len"][off[lo]:off[hi]], references=refs, lengths=lens,
+            mapped=case["aln"]["mapped"][k]))
+    return files
+
+
+def factory_of(pa, spec):
+    k = spec["kind"]
+    od = gu.offset_dict_of(spec)
+    if k == "fiveprime":
+        return pa.FivePrimeMapFactory(spec["param"])
+    if k == "threeprime":
+        return pa.ThreePrimeMapFactory(spec["param"])
+    if k == "center":
+        return pa.CenterMapFactory(spec["param"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if k == "variable":
+            return pa.VariableFivePrimeMapFactory(od)
+        return pa.StratifiedVariableFivePrimeMapFactory(od, spec["min_len"], spec["max_len"])
+
+
+def call_with_warnings(fn, *a, **k):
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = fn(*a, **k)
+    return out, [x for x in w if issubclass(x.category, UserWarning)]
+
+
+# ------------------------------------------------------------------ golden
+def test_kat_direct_factory_calls(pa):
+    """The reference's own closed-form unit-test vectors, through the plugin API
+    ``factory(reads, segment)`` (test_map_factories.py:17-200)."""
+    g = gu.load("kat_map_factories")
+    for case in g.cases:
+        packed = files_of(pa, g, case)[0]
+        reads = [packed.read(i) for i in range(packed.n)]
+        fn = factory_of(pa, case["spec"])
+        seg = pa.GenomicSegment(case["chrom"], case["start"], case["end"], case["strand"])
+        (reads_out, arr), warns = call_with_warnings(fn, reads, seg)
+        assert same(arr, g[case["expected"]]), case["spec"]
+        assert [r.index for r in reads_out] == list(g[case["reads_out"]]), case["spec"]
+        assert (len(warns) > 0) == case["warned"], case["spec"]
+
+
+@pytest.mark.parametrize("group", ["quirks", "random_reads", "chains"])
+def test_golden_bamgenomearray(pa, group):
+    g = gu.load(group)
+    nq = 0
+    for case in g.cases:
+        if case["kind"] != "ga":
+            continue
+        files = files_of(pa, g, case)
+        ga = pa.BAMGenomeArray(files, mapping=factory_of(pa, case["spec"]))
+        if case.get("size_filter"):
+            ga.add_filter("size", pa.SizeFilterFactory(min=case["size_filter"][0], max=case["size_filter"][1]))
+        if case["normalize"]:
+            ga.set_sum(case["sum"])
+            ga.set_normalize(True)
+        assert ga.sum() == case["sum"]
+        offs = np.cumsum([0] + [f.n for f in files])
+        for q in case["queries"]:
+            nq += 1
+            if q["type"] == "segment":
+                seg = pa.GenomicSegment(q["chrom"], q["start"], q["end"], q["strand"])
+                (reads, arr), warns = call_with_warnings(ga.get_reads_and_counts, seg, roi_order=q["roi_order"])
+                assert same(arr, g[q["expected"]]), (case["spec"], q, case["note"])
+                got = [offs[files.index(r.source)] + r.index for r in reads]
+                assert got == list(g[q["reads_out"]]), (case["spec"], q)
+                assert (len(warns) > 0) == q["warned"], (case["spec"], q)
+                assert same(ga.get(seg, roi_order=q["roi_order"]), g[q["expected"]])
+                if q["roi_order"]:
+                    assert same(ga[seg], g[q["expected"]])
+            else:
+                segs = [pa.GenomicSegment(q["chrom"], s, e, q["strand"]) for s, e in q["segments"]]
+                chain = pa.SegmentChain(*segs)
+                assert [(s.start, s.end) for s in chain] == [tuple(x) for x in q["merged_segments"]]
+                assert chain.length == q["length"]
+                if q.get("masks"):
+                    chain.add_masks(*[pa.GenomicSegment(q["chrom"], s, e, q["strand"]) for s, e in q["masks"]])
+                    assert chain.masked_length == q["masked_length"]
+                    assert [(s.start, s.end) for s in chain.mask_segments] == [tuple(x) for x in q["mask_segments"]]
+                if q.get("raises"):
+                    with pytest.raises(ValueError):
+                        chain.get_counts(ga)
+                    continue
+                arr = chain.get_counts(ga, stranded=q.get("stranded", True))
+                assert same(arr, g[q["expected"]]), (case["spec"], q)
+                if q.get("stranded", True):
+                    assert same(ga[chain], arr) and same(ga.get(chain), arr)
+                m = chain.get_masked_counts(ga)
+                assert same(np.ma.getdata(m), g[q["masked_data"]])
+                assert same(np.ma.getmaskarray(m), g[q["masked_mask"]])
+                assert chain.get_position_list() == list(g[q["position_list"]])
+                assert sorted(chain.get_masked_position_set()) == list(g[q["masked_position_set"]])
+    assert nq > 100
+
+
+# ------------------------------------------------------------------ oracle, seeded random, through the C ABI
+def aln_dict(files):
+    from plastid_amd.packing import concat_file_major
+    return concat_file_major(files)
+
+
+def spec_for(oracle, mapping, size_filter=None):
+    kind = mapping[0]
+    if kind in ("fiveprime", "threeprime", "center"):
+        return oracle.mapping_spec(kind, mapping[1], size_filter=size_filter)
+    if kind == "variable":
+        return oracle.mapping_spec(kind, 0, mapping[1], size_filter=size_filter)
+    return oracle.mapping_spec(kind, 0, mapping[1], mapping[2], mapping[3], size_filter=size_filter)
+
+
+def engine_for(pa, files, mapping, size_filter=None):
+    from plastid_amd.engine import Engine
+    from plastid_amd import synth
+    eng = Engine(0)
+    eng.set_alignments(files)
+    synth.mapping_factory(mapping)._configure(eng)
+    if size_filter:
+        eng.set_size_filter(*size_filter)
+    return eng
+
+
+def oracle_chain_outputs(oracle, files, spec, tx, plan_arrays, rows, dtype):
+    """Oracle counts for every segment, scattered into the plan's output layout."""
+    aln = aln_dict(files)
+    arrays, warn = oracle.count_segments(aln, spec, plan_arrays["tid"], plan_arrays["start"], plan_arrays["end"],
+                                         plan_arrays["strand"])
+    out = np.zeros(plan_arrays["out_elems"], dtype)
+    for s, arr in enumerate(arrays):
+        n = arr.shape[-1]
+        idx = plan_arrays["out_off"][s] + plan_arrays["out_step"][s].astype(np.int64) * np.arange(n)
+        a2 = arr.reshape(rows, n)
+        for r in range(rows):
+            out[idx + r * plan_arrays["row_stride"][s]] = a2[r]
+    return out, warn
+
+
+MAPPINGS = [
+    ("fiveprime", 0), ("fiveprime", 12), ("fiveprime", 27), ("threeprime", 0), ("threeprime", 14),
+    ("center", 0), ("center", 5), ("center", 13),
+    ("variable", {26: 12, 27: 12, 28: 13, 29: 13, 30: 14, 31: 13, "default": 13}),
+    ("variable", {28: 5, 30: 29}),
+    ("stratified", {26: 12, 27: 12, 28: 13, 29: 13, 30: 14, 31: 13, "default": 13}, 25, 35),
+    ("stratified", {28: 5}, 27, 30),
+]
+
+
+@pytest.mark.parametrize("config,scale,tx_scale", [("C2", 0.001, 0.01), ("C4", 0.0002, 0.005), ("C5", 0.0001, 0.005)])
+@pytest.mark.parametrize("mapping", MAPPINGS, ids=lambda m: "%s-%s" % (m[0], str(m[1])[:12]))
+def test_random_vs_oracle(pa, oracle, config, scale, tx_scale, mapping):
+    """Seeded synthetic reads (incl. spliced + deleted bases) x transcripts: every
+    output element equals the oracle's, int64 and float64 layouts."""
+    from plastid_amd import synth
+    genome, tx, reads, _ = synth.make_config(config, scale=scale, tx_scale=tx_scale)
+    eng = engine_for(pa, [reads], mapping)
+    rows = eng.rows
+    parr = tx.plan_arrays(rows=rows)
+    plan = eng.plan(parr["tid"], parr["start"], parr["end"], parr["strand"], parr["out_off"], parr["out_step"],
+                    parr["row_stride"], parr["out_elems"], rows)
+    spec = spec_for(oracle, mapping)
+    center = mapping[0] == "center"
+    exp, warn = oracle_chain_outputs(oracle, [reads], spec, tx, parr, rows, np.float64 if center else np.int64)
+    got64 = plan.count(np.float64)
+    assert np.array_equal(got64, exp.astype(np.float64))
+    if not center:
+        got = plan.count(np.int64)
+        assert got.dtype == np.int64 and np.array_equal(got, exp)
+        assert plan.total() == exp.sum()
+    assert np.array_equal(plan.warn_flags(), warn)
+    # normalisation: count / float(sum) * 1e6 (genome_array.py:826-827)
+    eng.set_normalize(True, 123457.0)
+    assert np.array_equal(plan.count(np.float64), exp / float(123457.0) * 1e6)
+    plan.close()
+    eng.close()
+
+
+def test_pileup_and_multifile(pa, oracle):
+    """A pile-up (> one work item per tile, merged with global atomics), two files
+    (file-major center order), '.' segments, size filter, overlapping segments."""
+    from plastid_amd import synth
+    from plastid_amd.engine import Engine
+    rng = np.random.default_rng(5)
+    names, lens = ["a", "b"], [50000, 20000]
+    n = 300000
+    pos = np.sort(np.concatenate([rng.integers(1000, 1040, n - 20000), rng.integers(0, 19000, 20000)]))
+    tid = np.zeros(n, np.int32)
+    alen = rng.integers(20, 40, n)
+    rev = rng.random(n) < 0.5
+    f1 = pa.PackedAlignments.from_ungapped(tid, pos, alen, rev, references=names, lengths=lens)
+    _, _, f2, _ = synth.make_config("C2", scale=0.0005, tx_scale=0.001)
+    f2 = pa.PackedAlignments(np.zeros(f2.n, np.int32), np.sort(f2.pos % 40000), f2.alen, f2.flags,
+                             np.minimum(f2.nblk, 1), references=names, lengths=lens)
+    seg_start = np.array([0, 900, 1000, 1010, 1030, 0, 5000, 1000, 0], np.int64)
+    seg_end = np.array([50000, 1100, 1001, 1500, 1031, 2000, 5000, 1040, 20000], np.int64)
+    seg_tid = np.array([0, 0, 0, 0, 0, 0, 0, 0, 1], np.int32)
+    seg_strand = np.array([1, 2, 3, 3, 1, 2, 1, 3, 3], np.uint8)
+    lens_ = seg_end - seg_start
+    for mapping in [("fiveprime", 3), ("center", 2), ("threeprime", 0)]:
+        for sf in (None, (25, 33)):
+            eng = engine_for(pa, [f1, f2], mapping, sf)
+            out_off = np.concatenate([[0], np.cumsum(lens_)[:-1]])
+            plan = eng.plan(seg_tid, seg_start, seg_end, seg_strand, out_off, np.ones(len(lens_), np.int8), lens_,
+                            int(lens_.sum()), 1)
+            spec = spec_for(oracle, mapping, sf)
+            arrays, warn = oracle.count_segments(aln_dict([f1, f2]), spec, seg_tid, seg_start, seg_end, seg_strand)
+            exp = np.concatenate(arrays)
+            got = plan.count(exp.dtype)
+            assert np.array_equal(got, exp), (mapping, sf)
+            assert np.array_equal(plan.warn_flags(), warn)
+            plan.close()
+            eng.close()
+
+
+def test_inverse_table_is_ieee(pa):
+    """1.0/m used by the center kernel is the host's correctly rounded quotient;
+    a lone read of aligned length m contributes exactly 1.0/m at each position."""
+    for m in (1, 3, 7, 25, 29, 33, 49, 97, 1001):
+        packed = pa.PackedAlignments.from_ungapped(0, [10], [m], [False], references=["c"], lengths=[5000])
+        ga = pa.BAMGenomeArray(packed, mapping=pa.CenterMapFactory(0))
+        arr = ga.get(pa.GenomicSegment("c", 0, 2000, "+"))
+        assert arr.dtype == np.float64
+        exp = np.zeros(2000)
+        exp[10:10 + m] = 1.0 / m
+        assert np.array_equal(arr, exp)
+
+
+def test_errors_and_edges(pa):
+    packed = pa.PackedAlignments.from_ungapped(0, [5, 9], [30, 31], [False, True], references=["c"], lengths=[100])
+    ga = pa.BAMGenomeArray(packed, mapping=pa.FivePrimeMapFactory(0))
+    # unknown chromosome: zeros([1]) float64 (genome_array.py:795-798)
+    arr = ga[pa.GenomicSegment("nope", 0, 50, "+")]
+    assert arr.shape == (1,) and arr.dtype == np.float64
+    # empty segment, segment beyond the contig end
+    assert ga[pa.GenomicSegment("c", 7, 7, "+")].shape == (0,)
+    assert ga[pa.GenomicSegment("c", 90, 400, "+")].sum() == 0
+    # unsorted input is rejected like an unindexed BAM (ValueError)
+    with pytest.raises(ValueError):
+        pa.PackedAlignments.from_ungapped(0, [9, 5], [30, 30], [False, False], references=["c"], lengths=[100])
+    # custom (plugin) mapping function and custom filter keep the reference's contract
+    def my_map(reads, seg):
+        out = np.zeros(len(seg), int)
+        for r in reads:
+            out[r.positions[0] - seg.start] += 2
+        return reads, out
+    ga.set_mapping(my_map)
+    assert ga[pa.GenomicSegment("c", 0, 50, "+")][5] == 2
+    ga.set_mapping(pa.FivePrimeMapFactory(0))
+    ga.add_filter("only31", lambda r: len(r.positions) == 31)
+    assert ga[pa.GenomicSegment("c", 0, 50, ".")].sum() == 1
+    assert ga.remove_filter("only31") is not None
+    assert ga[pa.GenomicSegment("c", 0, 50, ".")].sum() == 2
+    # empty read list through the plugin API
+    reads_out, arr = pa.FivePrimeMapFactory(0)([], pa.GenomicSegment("c", 0, 10, "+"))
+    assert reads_out == [] and arr.shape == (10,) and arr.dtype == np.int64 and arr.sum() == 0

@@ -1,0 +1,255 @@
+"""CPU-only tests: host logic (intervals, factories' parameter handling, packing,
+synthetic generators) and the C ABI surface.  No compute calls (no GPU here)."""
+import ctypes
+import io
+import os
+import re
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import plastid_amd as pa  # noqa: E402
+from plastid_amd import _lib, map_factories as mf, packing, synth  # noqa: E402
+from plastid_amd.build import build_library  # noqa: E402
+from tests import golden_util as gu  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------- C ABI
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    build_library()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "plastid_counts.h")).read()
+    declared = set(re.findall(r"\b(pc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().pc_abi_version() == 1
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present")
+    from plastid_amd.engine import Engine
+    with pytest.raises(pa.EngineError) as e:
+        Engine(0)
+    assert "no CPU fallback" in str(e.value)
+    with pytest.raises(pa.EngineError):
+        pa.FivePrimeMapFactory(0)([], pa.GenomicSegment("c", 0, 10, "+"))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "plastid_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").lower() or f == "__none__", \
+                    "%s mentions the oracle" % f
+
+
+# -------------------------------------------------------------- factories
+def test_ctor_errors_match_reference():
+    g = gu.load("offset_tables")
+    errs = [c for c in g.cases if c["kind"] == "ctor_errors"][0]["errors"]
+    ctors = {
+        "FivePrime(-1)": lambda: pa.FivePrimeMapFactory(-1),
+        "ThreePrime(-1)": lambda: pa.ThreePrimeMapFactory(-1),
+        "Center(-1)": lambda: pa.CenterMapFactory(-1),
+        "Strat(min==max)": lambda: pa.StratifiedVariableFivePrimeMapFactory({}, 25, 25),
+        "Strat(max<min)": lambda: pa.StratifiedVariableFivePrimeMapFactory({}, 30, 25),
+        "SizeFilter(max<min)": lambda: pa.SizeFilterFactory(30, 25),
+        "SizeFilter(min<1)": lambda: pa.SizeFilterFactory(0, 25),
+        "Variable(bad,no default)": lambda: pa.VariableFivePrimeMapFactory({25: 30}),
+        "Segment(end<start)": lambda: pa.GenomicSegment("c", 10, 5, "+"),
+        "Chain(mixed strands)": lambda: pa.SegmentChain(pa.GenomicSegment("c", 0, 5, "+"),
+                                                        pa.GenomicSegment("c", 10, 15, "-")),
+    }
+    assert set(ctors) == set(errs)
+    for name, ctor in ctors.items():
+        if errs[name] is None:
+            ctor()
+        else:
+            with pytest.raises(Exception) as e:
+                ctor()
+            assert type(e.value).__name__ == errs[name], (name, type(e.value).__name__, errs[name])
+
+
+def test_offset_tables_match_reference_behaviour():
+    g = gu.load("offset_tables")
+    n = 0
+    for case in g.cases:
+        if case["kind"] != "table":
+            continue
+        od = {(k if k == "default" else int(k)): v for k, v in case["offset_dict"].items()}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fn = pa.VariableFivePrimeMapFactory(od)
+        efw, erc = g[case["fw"]], g[case["rc"]]
+        m = len(efw)
+        assert np.array_equal(fn.forward_offsets[1:m], efw[1:]), od
+        assert np.array_equal(fn.reverse_offsets[1:m], erc[1:]), od
+        assert (fn.forward_offsets == -1).tolist() == (fn.reverse_offsets == -1).tolist()
+        n += 1
+    assert n >= 8
+
+
+def test_offset_file_grammar():
+    g = gu.load("offset_tables")
+    case = [c for c in g.cases if c["kind"] == "offset_file"][0]
+    d = mf._parse_variable_offset_file(io.StringIO(case["text"]))
+    assert {str(k): v for k, v in d.items()} == case["expected"]
+    fn = pa.VariableFivePrimeMapFactory.from_file(io.StringIO("# comment\n" + case["text"]))
+    assert fn.forward_offsets[28] == 13 and fn.forward_offsets[40] == 13 and fn.reverse_offsets[30] == 15
+    for bad in ("28\t12\t1\n", "x\t3\n", "28\tq\n", "28\t1\n28\t2\n"):
+        with pytest.raises(pa.MalformedFileError):
+            mf._parse_variable_offset_file(io.StringIO(bad))
+
+
+def test_factory_properties():
+    f = pa.FivePrimeMapFactory(3)
+    assert f.offset == 3
+    f.offset = 5
+    assert f.offset == 5
+    c = pa.CenterMapFactory()
+    assert c.nibble == 0
+    c.nibble = 4
+    assert c.nibble == 4
+    with pytest.raises(OverflowError):
+        c.nibble = -2
+    s = pa.StratifiedVariableFivePrimeMapFactory(None, 25, 35)
+    assert s.shape == [11] and list(s.row_keys) == list(range(25, 36))
+    sf = pa.SizeFilterFactory(25, 30)
+
+    class R(object):
+        positions = list(range(27))
+    assert sf(R()) is True
+    R.positions = list(range(31))
+    assert sf(R()) is False
+    assert pa.SizeFilterFactory(25)(R()) is True
+    with pytest.raises(TypeError):
+        pa.FivePrimeMapFactory(1.5)
+    with pytest.raises(TypeError):
+        pa.FivePrimeMapFactory(0)(None, pa.GenomicSegment("c", 0, 1, "+"))
+
+
+# ---------------------------------------------------------------- intervals
+def test_genomic_segment():
+    a = pa.GenomicSegment("chrI", 10, 20, "+")
+    assert len(a) == 10 and str(a) == "chrI:10-20(+)" and a.c_strand == 1
+    assert pa.GenomicSegment.from_str(str(a)) == a and hash(pa.GenomicSegment.from_str(str(a))) == hash(a)
+    b = pa.GenomicSegment("chrI", 15, 30, "+")
+    assert a.overlaps(b) and not a.contains(b) and a < b
+    assert pa.GenomicSegment("chrI", 12, 18, "+") in a
+    assert not a.overlaps(pa.GenomicSegment("chrI", 15, 30, "-"))
+    with pytest.raises(ValueError):
+        pa.GenomicSegment("chrI", 10, 20, "x")
+    assert sorted([b, a]) == [a, b]
+
+
+def test_segment_chain_structure_and_masks():
+    S = pa.GenomicSegment
+    chain = pa.SegmentChain(S("c", 300, 340, "-"), S("c", 0, 90, "-"), S("c", 90, 120, "-"), S("c", 100, 130, "-"))
+    assert [(s.start, s.end) for s in chain] == [(0, 130), (300, 340)]   # adjacent + overlapping merged (Q14)
+    assert chain.length == 170 and len(chain) == 2 and chain.strand == "-" and chain.chrom == "c"
+    assert str(chain) == "c:0-130^300-340(-)" and pa.SegmentChain.from_str(str(chain)) == chain
+    assert chain.get_position_list() == list(range(0, 130)) + list(range(300, 340))
+    assert chain.get_position_set() == set(chain.get_position_list())
+    chain.add_masks(S("c", 120, 310, "-"), S("c", 5, 6, "-"))
+    assert [(s.start, s.end) for s in chain.mask_segments] == [(5, 6), (120, 130), (300, 310)]
+    assert chain.masked_length == 170 - 21
+    chain.add_masks(S("c", 4, 7, "-"))
+    assert [(s.start, s.end) for s in chain.mask_segments] == [(4, 7), (120, 130), (300, 310)]
+    assert 5 not in chain.get_masked_position_set() and 8 in chain.get_masked_position_set()
+    assert chain.get_segmentchain_coordinate(0, stranded=False) == 0
+    assert chain.get_segmentchain_coordinate(0) == 169 and chain.get_segmentchain_coordinate(339) == 0
+    with pytest.raises(KeyError):
+        chain.get_segmentchain_coordinate(200)
+    chain.reset_masks()
+    assert chain.masked_length == 170 and chain.mask_segments == []
+    with pytest.raises(ValueError):
+        chain.add_masks(S("c", 4, 7, "+"))
+    assert len(pa.SegmentChain()) == 0 and str(pa.SegmentChain()) == "na"
+
+
+def test_get_counts_duck_typed_array():
+    """SegmentChain.get_counts works on ANY object with .get(seg, roi_order=False)
+    (the reference's tests pass a GenomeArray there, test_roitools.py:1275-1291)."""
+    class FakeGA(object):
+        def get(self, seg, roi_order=True):
+            return np.arange(seg.start, seg.end, dtype=np.int64)
+    S = pa.GenomicSegment
+    plus = pa.SegmentChain(S("c", 10, 13, "+"), S("c", 20, 22, "+"))
+    minus = pa.SegmentChain(S("c", 10, 13, "-"), S("c", 20, 22, "-"))
+    ga = FakeGA()
+    assert plus.get_counts(ga).tolist() == [10, 11, 12, 20, 21] and plus.get_counts(ga).dtype == np.float64
+    assert minus.get_counts(ga).tolist() == [21, 20, 12, 11, 10]
+    assert minus.get_counts(ga, stranded=False).tolist() == [10, 11, 12, 20, 21]
+    minus.add_masks(S("c", 10, 11, "-"))
+    m = minus.get_masked_counts(ga)
+    assert np.ma.getmaskarray(m).tolist() == [False, False, False, False, True]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert pa.SegmentChain().get_counts(ga).shape == (0,)
+    assert len(w) == 1 and issubclass(w[0].category, pa.DataWarning)
+
+
+# ------------------------------------------------------------------ packing
+def test_cigar_to_runs_hand_checked():
+    g = gu.load("quirks")
+    case = [c for c in g.cases if c["kind"] == "hand_cigars"][0]
+    for i in g["hand_indices"]:
+        runs, L = packing.cigar_to_runs(int(g["hand_pos"][i]), packing.parse_cigar_string(case["cigars"][i]))
+        pos = [p for s, n in runs for p in range(s, s + n)]
+        assert pos == list(g["hand_positions_%d" % i]) and L == len(pos)
+        assert packing.positions_to_runs(pos) == runs
+    with pytest.raises(ValueError):
+        packing.parse_cigar_string("10M5")
+
+
+def test_packed_alignments_roundtrip_and_fetch():
+    p = pa.PackedAlignments.from_cigars([0, 0, 1, 0], [5, 50, 7, 20], ["10M", "5M100N5M", "3S8M", "4M1D4M"],
+                                        [False, True, False, True], references=["a", "b"], lengths=[500, 100],
+                                        sort=True)
+    assert p.tid.tolist() == [0, 0, 0, 1] and p.pos.tolist() == [5, 20, 50, 7]
+    assert p.alen.tolist() == [10, 8, 10, 8] and p.nblk.tolist() == [1, 2, 2, 1]
+    assert p.blk_start.tolist() == [20, 25, 50, 155] and p.blk_len.tolist() == [4, 4, 5, 5]
+    assert p.ref_end().tolist() == [15, 29, 160, 15]
+    assert p.read(2).positions == list(range(50, 55)) + list(range(155, 160))
+    assert [r.index for r in p.fetch("a", 100, 120)] == [2]        # spans the window through its intron
+    assert [r.index for r in p.fetch("a", 15, 20)] == []
+    assert [r.index for r in p.fetch("a", 14, 21)] == [0, 1]
+    assert [r.index for r in p.fetch("b", 0, 100)] == [3]
+    with pytest.raises(ValueError):
+        p.fetch_indices("zzz", 0, 1)
+    sub = p.subset([1, 3])
+    assert sub.blk_start.tolist() == [20, 25] and sub.n == 2
+    from_reads = pa.PackedAlignments.from_reads([p.read(i) for i in range(p.n)], references=["a", "b"],
+                                                lengths=[500, 100])
+    for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
+        assert np.array_equal(getattr(from_reads, k), getattr(p, k)), k
+
+
+def test_synthetic_configs_are_seeded_and_valid():
+    for name, scale, txs in (("C1", 0.01, 0.5), ("C2", 0.0002, 0.005), ("C4", 0.00004, 0.002), ("C5", 0.00002, 0.002)):
+        g, tx, reads, mapping = synth.make_config(name, scale=scale, tx_scale=txs)
+        g2, tx2, reads2, _ = synth.make_config(name, scale=scale, tx_scale=txs)
+        reads.validate()
+        assert np.array_equal(reads.pos, reads2.pos) and np.array_equal(tx.ex_start, tx2.ex_start)
+        assert np.all(tx.ex_end > tx.ex_start)
+        ends = reads.ref_end()
+        assert np.all(ends <= np.asarray(g[1])[reads.tid])
+        p = tx.plan_arrays(rows=1)
+        assert p["out_elems"] == tx.n_positions
+        # every output element is addressed exactly once
+        hit = np.zeros(p["out_elems"], np.int32)
+        for s in range(len(p["tid"])):
+            n = p["end"][s] - p["start"][s]
+            hit[p["out_off"][s] + p["out_step"][s].astype(np.int64) * np.arange(n)] += 1
+        assert hit.min() == 1 and hit.max() == 1
+    assert synth.mapping_factory(("stratified", synth.VARIABLE_OFFSETS, 25, 35)).shape == [11]
