@@ -169,23 +169,35 @@ def make_transcripts(genome, n, seed, style="yeast"):
 
 def _project(tx, t, x, L):
     """Project spliced intervals ``[x, x+L)`` of transcripts `t` onto the genome.
-    Returns CSR aligned runs ``(nblk, run_start, run_len)`` in genome order."""
-    n = len(t)
-    gx = tx.ex_cum[tx.ex_off[t]] + x                      # global spliced coordinate
-    e = np.searchsorted(tx.ex_cum, gx, side="right") - 1  # exon holding the first base
+
+    Returns ``(pos, multi_idx, nblk, run_start, run_len)``: `pos` = genomic start of
+    every read; reads listed in `multi_idx` cross exon junctions and have their
+    ``nblk`` (>= 2) aligned runs in ``run_start/run_len`` (CSR, read after read)."""
+    t = t.astype(np.int64)
+    gx = tx.ex_cum[tx.ex_off[t]] + x                       # global spliced coordinate
+    e = tx.ex_off[t].copy()
+    m = np.nonzero((tx.ex_off[t + 1] - tx.ex_off[t]) > 1)[0]
+    if len(m):
+        e[m] = np.searchsorted(tx.ex_cum, gx[m], side="right") - 1  # exon holding the first base
+    room = tx.ex_cum[e + 1] - gx
+    pos = tx.ex_start[e] + (gx - tx.ex_cum[e])
+    multi = np.nonzero(room < L)[0]
+    if not len(multi):
+        z = np.zeros(0, np.int64)
+        return pos, multi, z, z, z
+    # general walk, only for the junction-spanning reads
+    k = len(multi)
     starts, lens, owner = [], [], []
-    nblk = np.zeros(n, np.int64)
-    active = np.arange(n)
-    cur_e = e.copy()
-    cur_g = gx.copy()
-    remaining = L.astype(np.int64).copy()
+    active = np.arange(k)
+    cur_e = e[multi]
+    cur_g = gx[multi]
+    remaining = L[multi].astype(np.int64)
     while len(active):
-        room = tx.ex_cum[cur_e[active] + 1] - cur_g[active]
-        take = np.minimum(room, remaining[active])
+        room_a = tx.ex_cum[cur_e[active] + 1] - cur_g[active]
+        take = np.minimum(room_a, remaining[active])
         starts.append(tx.ex_start[cur_e[active]] + (cur_g[active] - tx.ex_cum[cur_e[active]]))
         lens.append(take)
         owner.append(active)
-        nblk[active] += 1
         remaining[active] -= take
         cur_g[active] += take
         cur_e[active] += 1
@@ -193,7 +205,7 @@ def _project(tx, t, x, L):
     owner = np.concatenate(owner)
     starts = np.concatenate(starts)
     lens = np.concatenate(lens)
-    order = np.lexsort((starts, owner))                   # by read, then left to right
+    order = np.lexsort((starts, owner))                    # by read, then left to right
     owner, starts, lens = owner[order], starts[order], lens[order]
     # merge runs that are adjacent on the genome (abutting exons)
     same = (owner[1:] == owner[:-1]) & (starts[1:] == starts[:-1] + lens[:-1])
@@ -203,12 +215,21 @@ def _project(tx, t, x, L):
         lens = np.bincount(grp, weights=lens).astype(np.int64)
         starts = starts[first]
         owner = owner[first]
-        nblk = np.bincount(owner, minlength=n).astype(np.int64)
-    return nblk, owner, starts, lens
+    nblk = np.bincount(owner, minlength=k).astype(np.int64)
+    still = nblk >= 2
+    if not still.all():                                    # fully merged: a plain single-run read
+        keep = still[owner]
+        owner, starts, lens = owner[keep], starts[keep], lens[keep]
+        multi = multi[still]
+        nblk = nblk[still]
+    return pos, multi, nblk, starts, lens
 
 
-def make_reads(genome, tx, n, seed, paired=False, length_pmf=None, in_tx_frac=0.9, del_frac=0.01,
-               expr_sigma=1.5):
+#: footprint-like aligned lengths 25..34 peaked at 28-30: 96-entry inverse-cdf lookup table
+_FOOTPRINT_TABLE = np.repeat(FOOTPRINT_LENGTHS, [1, 2, 4, 10, 20, 22, 18, 10, 6, 3]).astype(np.int64)
+
+
+def make_reads(genome, tx, n, seed, paired=False, in_tx_frac=0.9, del_frac=0.01, expr_sigma=1.5):
     """Synthetic coordinate-sorted alignment records as a
     :class:`PackedAlignments`.  `paired`: two mates per fragment (fragment length
     N(180,30) >= 60, mate length U[25,50], mate 2 on the opposite strand); the
@@ -220,115 +241,115 @@ def make_reads(genome, tx, n, seed, paired=False, length_pmf=None, in_tx_frac=0.
     n_in = int(round(nfrag * in_tx_frac)) if tx is not None and tx.n else 0
     n_bg = nfrag - n_in
 
-    rec_tid, rec_rev, rec_nblk = [], [], []
-    run_owner, run_start, run_len = [], [], []
-    base = 0
+    # single-run records accumulate as (tid, pos, L, rev); multi-run records keep CSR runs
+    s_tid, s_pos, s_len, s_rev = [], [], [], []
+    m_tid, m_rev, m_nblk, m_start, m_len = [], [], [], [], []
 
-    def add(tid, rev, nblk, owner, starts, lens):
-        nonlocal base
-        rec_tid.append(tid.astype(np.int64))
-        rec_rev.append(rev.astype(bool))
-        rec_nblk.append(nblk.astype(np.int64))
-        run_owner.append(owner + base)
-        run_start.append(starts.astype(np.int64))
-        run_len.append(lens.astype(np.int64))
-        base += len(tid)
+    def add(tid, rev, L, pos, multi, nblk, starts, lens):
+        single = np.ones(len(tid), bool)
+        single[multi] = False
+        s_tid.append(tid[single]); s_pos.append(pos[single]); s_len.append(L[single]); s_rev.append(rev[single])
+        if len(multi):
+            m_tid.append(tid[multi]); m_rev.append(rev[multi]); m_nblk.append(nblk)
+            m_start.append(starts); m_len.append(lens)
 
     def draw_len(k):
         if paired:
             return rng.integers(25, 51, k)
-        pmf = FOOTPRINT_PMF if length_pmf is None else np.asarray(length_pmf[1], float)
-        vals = FOOTPRINT_LENGTHS if length_pmf is None else np.asarray(length_pmf[0])
-        return rng.choice(vals, size=k, p=pmf / pmf.sum())
+        return _FOOTPRINT_TABLE[rng.integers(0, len(_FOOTPRINT_TABLE), k)]
 
     if n_in:
         w = np.exp(rng.normal(0.0, expr_sigma, tx.n))
-        cdf = np.cumsum(w)
-        t = np.searchsorted(cdf, rng.random(n_in) * cdf[-1], side="right").clip(0, tx.n - 1)
+        counts = rng.multinomial(n_in, w / w.sum())
+        t = np.repeat(np.arange(tx.n, dtype=np.int64), counts)   # grouped by transcript; sorted later anyway
         tlen = tx.length[t]
-        fwd_tx = tx.strand[t] == 1
+        rev_tx = tx.strand[t] == 2
+        ttid = tx.tid[t].astype(np.int64)
         if not paired:
             L = np.minimum(draw_len(n_in), tlen)
             x = (rng.random(n_in) * (tlen - L + 1)).astype(np.int64)
-            nb, ow, st, ln = _project(tx, t, x, L)
-            add(tx.tid[t], ~fwd_tx, nb, ow, st, ln)
+            add(ttid, rev_tx, L, *_project(tx, t, x, L))
         else:
             frag = np.minimum(np.maximum(rng.normal(180.0, 30.0, n_in), 60).astype(np.int64), tlen)
             fx = (rng.random(n_in) * (tlen - frag + 1)).astype(np.int64)
             L1 = np.minimum(draw_len(n_in), frag)
             L2 = np.minimum(draw_len(n_in), frag)
             # mate 1 at the fragment's 5' end (transcript orientation), mate 2 at its 3' end
-            x1 = np.where(fwd_tx, fx, fx + frag - L1)
-            x2 = np.where(fwd_tx, fx + frag - L2, fx)
-            nb, ow, st, ln = _project(tx, t, x1, L1)
-            add(tx.tid[t], ~fwd_tx, nb, ow, st, ln)
-            nb, ow, st, ln = _project(tx, t, x2, L2)
-            add(tx.tid[t], fwd_tx, nb, ow, st, ln)
+            x1 = np.where(rev_tx, fx + frag - L1, fx)
+            x2 = np.where(rev_tx, fx, fx + frag - L2)
+            add(ttid, rev_tx, L1, *_project(tx, t, x1, L1))
+            add(ttid, ~rev_tx, L2, *_project(tx, t, x2, L2))
     if n_bg:
         k = n_bg * (2 if paired else 1)
         L = draw_len(k)
         tid, start = _place(rng, lengths, L.astype(np.int64))
-        add(tid, rng.random(k) < 0.5, np.ones(k, np.int64), np.arange(k), start, L)
+        z = np.zeros(0, np.int64)
+        add(tid, rng.random(k) < 0.5, L, start, z, z, z, z)
 
-    tid = np.concatenate(rec_tid)
-    rev = np.concatenate(rec_rev)
-    nblk = np.concatenate(rec_nblk)
-    owner = np.concatenate(run_owner)
-    rstart = np.concatenate(run_start)
-    rlen = np.concatenate(run_len)
-    nrec = len(tid)
-    o = np.argsort(owner, kind="stable")
-    owner, rstart, rlen = owner[o], rstart[o], rlen[o]
-    run_off = np.zeros(nrec + 1, np.int64)
-    np.cumsum(nblk, out=run_off[1:])
+    tid = np.concatenate(s_tid); pos = np.concatenate(s_pos); L = np.concatenate(s_len); rev = np.concatenate(s_rev)
+    del s_tid, s_pos, s_len, s_rev
 
-    # 1-nt deletions: split the first run of a random 1 % of records (needs >= 2 bases there)
-    if del_frac > 0 and nrec:
-        cand = np.nonzero((rng.random(nrec) < del_frac) & (rlen[run_off[:-1]] >= 4))[0]
+    # 1-nt deletions in a random 1 % of the single-run records: they become two-run records
+    if del_frac > 0 and len(tid):
+        cand = np.nonzero((rng.random(len(tid)) < del_frac) & (L >= 4) & (pos + L + 1 <= lengths[tid]))[0]
         if len(cand):
-            first = run_off[cand]
-            cutat = 1 + (rng.random(len(cand)) * (rlen[first] - 2)).astype(np.int64)
-            # room: the deleted base pushes the rest right by one; keep inside the contig and
-            # away from the next run of the same read
-            next_ok = np.ones(len(cand), bool)
-            multi = nblk[cand] > 1
-            next_ok[multi] = rstart[first[multi] + 1] > rstart[first[multi]] + rlen[first[multi]] + 1
-            fits = rstart[first] + rlen[first] + 1 <= lengths[tid[cand]]
-            keep = next_ok & fits
-            cand, first, cutat = cand[keep], first[keep], cutat[keep]
-            new_start = rstart[first] + cutat + 1
-            new_len = rlen[first] - cutat
-            rlen[first] = cutat
-            # later runs of the same read do not move (they are anchored on the genome)
-            ins_at = first + 1
-            owner = np.insert(owner, ins_at, cand)
-            rstart = np.insert(rstart, ins_at, new_start)
-            rlen = np.insert(rlen, ins_at, new_len)
-            nblk[cand] += 1
-            np.cumsum(nblk, out=run_off[1:])
+            cut = 1 + (rng.random(len(cand)) * (L[cand] - 2)).astype(np.int64)
+            m_tid.append(tid[cand]); m_rev.append(rev[cand]); m_nblk.append(np.full(len(cand), 2, np.int64))
+            st = np.empty(2 * len(cand), np.int64); ln = np.empty(2 * len(cand), np.int64)
+            st[0::2] = pos[cand]; st[1::2] = pos[cand] + cut + 1
+            ln[0::2] = cut; ln[1::2] = L[cand] - cut
+            m_start.append(st); m_len.append(ln)
+            keep = np.ones(len(tid), bool)
+            keep[cand] = False
+            tid, pos, L, rev = tid[keep], pos[keep], L[keep], rev[keep]
 
-    pos = rstart[run_off[:-1]]
-    alen = np.bincount(owner, weights=rlen, minlength=nrec).astype(np.int64)
-    key = (tid << 32) | pos
-    order = np.argsort(key, kind="stable")
-    tid, pos, alen, rev, nblk = tid[order], pos[order], alen[order], rev[order], nblk[order]
-    # gather the runs of multi-run records in the new record order
-    multi = nblk >= 2
-    src_off = run_off[:-1][order][multi]
-    cnt = nblk[multi]
-    if len(cnt):
-        tot = int(cnt.sum())
-        dst_off = np.zeros(len(cnt) + 1, np.int64)
-        np.cumsum(cnt, out=dst_off[1:])
-        idx = np.repeat(src_off - dst_off[:-1], cnt) + np.arange(tot)
-        blk_start, blk_len = rstart[idx], rlen[idx]
+    # ---- sort the single-run records: everything fits one 64-bit key, so a value sort suffices
+    key = (tid << 40) | (pos << 9) | (L << 1) | rev
+    del tid, pos, L, rev
+    key.sort()
+    ns = len(key)
+
+    # ---- multi-run records: argsort (they are few), then merge the two sorted streams
+    if m_tid:
+        mt = np.concatenate(m_tid); mr = np.concatenate(m_rev); mn = np.concatenate(m_nblk)
+        ms = np.concatenate(m_start); ml = np.concatenate(m_len)
+        moff = np.zeros(len(mt) + 1, np.int64)
+        np.cumsum(mn, out=moff[1:])
+        mpos = ms[moff[:-1]]
+        malen = np.add.reduceat(ml, moff[:-1])
+        mkey = (mt << 40) | (mpos << 9)
+        o = np.argsort(mkey, kind="stable")
+        mt, mr, mn, mpos, malen, mkey = mt[o], mr[o], mn[o], mpos[o], malen[o], mkey[o]
+        tot = int(mn.sum())
+        dst = np.zeros(len(mn) + 1, np.int64)
+        np.cumsum(mn, out=dst[1:])
+        idx = np.repeat(moff[:-1][o] - dst[:-1], mn) + np.arange(tot)
+        blk_start, blk_len = ms[idx], ml[idx]
+        ins = np.searchsorted(key >> 9, mkey >> 9, side="left")  # a multi-run read goes before equal-pos singles
+        m_dest = ins + np.arange(len(mt))
+        nm = len(mt)
     else:
+        nm = 0
         blk_start = blk_len = np.zeros(0, np.int64)
-    flags = np.where(rev, FLAG_REVERSE, 0).astype(np.uint8)
-    return PackedAlignments(tid.astype(np.int32), pos.astype(np.int32), alen.astype(np.uint16), flags,
-                            nblk.astype(np.uint8), blk_start.astype(np.int32), blk_len.astype(np.int32),
-                            references=names, lengths=[int(x) for x in lengths], mapped=nrec,
-                            validate=nrec <= 5_000_000)
+    nrec = ns + nm
+    out_tid = np.empty(nrec, np.int32); out_pos = np.empty(nrec, np.int32)
+    out_len = np.empty(nrec, np.uint16); out_flags = np.empty(nrec, np.uint8); out_nblk = np.ones(nrec, np.uint8)
+    if nm:
+        is_m = np.zeros(nrec, bool)
+        is_m[m_dest] = True
+        s_dest = np.nonzero(~is_m)[0]
+    else:
+        s_dest = slice(None)
+    out_tid[s_dest] = key >> 40
+    out_pos[s_dest] = (key >> 9) & 0x7fffffff
+    out_len[s_dest] = (key >> 1) & 0xff
+    out_flags[s_dest] = (key & 1) * FLAG_REVERSE
+    if nm:
+        out_tid[m_dest] = mt; out_pos[m_dest] = mpos; out_len[m_dest] = malen
+        out_flags[m_dest] = np.where(mr, FLAG_REVERSE, 0); out_nblk[m_dest] = mn
+    return PackedAlignments(out_tid, out_pos, out_len, out_flags, out_nblk, blk_start.astype(np.int32),
+                            blk_len.astype(np.int32), references=names, lengths=[int(x) for x in lengths],
+                            mapped=nrec, validate=nrec <= 5_000_000)
 
 
 CONFIGS = {
