@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -529,7 +530,9 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     {
         int64_t g = (64 * 1024) / (4LL * nmodes * rows);
         int G = 256;
-        while (G * 2 <= g && G < 4096) G *= 2;
+        int gmax = 4096;
+        if (const char *env = getenv("PC_TILE_G")) gmax = std::max(256, atoi(env)); // tuning knob
+        while (G * 2 <= g && G * 2 <= gmax) G *= 2;
         if ((int64_t)4 * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
         p->G = G;
     }
@@ -670,7 +673,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     const int nfiles = (int)e->files.size();
     const int W = e->W();
     const int G = p->G;
-    const int64_t R = 65536;
+    int64_t R = 65536;
+    if (const char *env = getenv("PC_WORK_R")) R = std::max(1024, atoi(env)); // tuning knob
     const MapParams mp = e->params();
     const int ntiles = (int)p->tiles.size();
     hipStream_t st = e->stream;
