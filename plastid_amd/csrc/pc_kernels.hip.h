@@ -51,9 +51,56 @@ struct FileView {
     const int32_t *long_tid;
     const int32_t *long_pmax;       // prefix max of ref_end within a tid
     const int64_t *long_tid_bounds; // ntid+1
+    const uint4 *gap_rec;           // short-span gapped records {pos, meta, blk_off, rec_idx}, record order
+    const int64_t *gap_tid_bounds;  // ntid+1
     int64_t n;
     int64_t nlong;
+    int64_t ngap;
 };
+
+// Pointers that come out of a FileView are loaded from memory, so the compiler only knows
+// them as generic ("flat") pointers: flat loads count on both vmcnt and lgkmcnt and cannot be
+// scalarised.  GFile re-types them as global (address space 1) once per kernel.
+#define PC_GLOBAL __attribute__((address_space(1)))
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+struct GFile {
+    const u32x2 PC_GLOBAL *rec;
+    const u32x4 PC_GLOBAL *rec4;
+    const uint32_t PC_GLOBAL *blk_off;
+    const i32x2 PC_GLOBAL *blk;
+    const int64_t PC_GLOBAL *tid_bounds;
+    const uint32_t PC_GLOBAL *long_idx;
+    const int32_t PC_GLOBAL *long_tid;
+    const int32_t PC_GLOBAL *long_pmax;
+    const int64_t PC_GLOBAL *long_tid_bounds;
+    const u32x4 PC_GLOBAL *gap_rec;
+    const int64_t PC_GLOBAL *gap_tid_bounds;
+    int64_t n;
+    int64_t nlong;
+    int64_t ngap;
+};
+
+__device__ __forceinline__ GFile gfile(const FileView &v) {
+    GFile g;
+    g.rec = (const u32x2 PC_GLOBAL *)v.rec;
+    g.rec4 = (const u32x4 PC_GLOBAL *)v.rec;
+    g.blk_off = (const uint32_t PC_GLOBAL *)v.blk_off;
+    g.blk = (const i32x2 PC_GLOBAL *)v.blk;
+    g.tid_bounds = (const int64_t PC_GLOBAL *)v.tid_bounds;
+    g.long_idx = (const uint32_t PC_GLOBAL *)v.long_idx;
+    g.long_tid = (const int32_t PC_GLOBAL *)v.long_tid;
+    g.long_pmax = (const int32_t PC_GLOBAL *)v.long_pmax;
+    g.long_tid_bounds = (const int64_t PC_GLOBAL *)v.long_tid_bounds;
+    g.gap_rec = (const u32x4 PC_GLOBAL *)v.gap_rec;
+    g.gap_tid_bounds = (const int64_t PC_GLOBAL *)v.gap_tid_bounds;
+    g.n = v.n;
+    g.nlong = v.nlong;
+    g.ngap = v.ngap;
+    return g;
+}
 
 struct MapParams {
     int kind;
@@ -84,7 +131,8 @@ struct Piece {
 };
 
 struct WorkItem {
-    int64_t lo, hi;
+    int64_t lo, hi;   // record range of the packed stream
+    int64_t glo, ghi; // range of the gapped-record list (first work item of a tile only)
     uint32_t tile;
     uint32_t file;
 };
@@ -132,7 +180,7 @@ __device__ __forceinline__ bool strand_ok(int mode, bool rev) {
 }
 
 // first index in [lo,hi) whose pos >= key
-__device__ __forceinline__ int64_t lower_bound_pos(const uint2 *rec, int64_t lo, int64_t hi, int64_t key) {
+__device__ __forceinline__ int64_t lower_bound_pos(const u32x2 PC_GLOBAL *rec, int64_t lo, int64_t hi, int64_t key) {
     while (lo < hi) {
         int64_t mid = lo + ((hi - lo) >> 1);
         if ((int64_t)(int32_t)rec[mid].x < key) lo = mid + 1; else hi = mid;
@@ -142,47 +190,56 @@ __device__ __forceinline__ int64_t lower_bound_pos(const uint2 *rec, int64_t lo,
 
 // Index (counted from the left end of read.positions) the rule selects, or -1 when
 // the read is not mapped.  `row` = output row (stratified).
+template <int KIND>
 __device__ __forceinline__ int map_kleft(const MapParams &mp, int L, bool rev_rule, int &row) {
     row = 0;
-    switch (mp.kind) {
-    case 0: // FivePrimeMapFactory.__call__ :343-355
+    if (KIND == 0) { // FivePrimeMapFactory.__call__ :343-355
         if (mp.param >= L) return -1;
         return rev_rule ? L - 1 - mp.param : mp.param;
-    case 1: // ThreePrimeMapFactory.__call__ :442-454
+    } else if (KIND == 1) { // ThreePrimeMapFactory.__call__ :442-454
         if (mp.param >= L) return -1;
         return rev_rule ? mp.param : L - 1 - mp.param;
-    case 3: { // VariableFivePrimeMapFactory.__call__ :625-638
+    } else if (KIND == 3) { // VariableFivePrimeMapFactory.__call__ :625-638
         if (L >= mp.table_len) return -1;
-        return (rev_rule ? mp.rc : mp.fw)[L]; // -1 == _BAD_OFFSET
-    }
-    case 4: { // StratifiedVariableFivePrimeMapFactory.__call__ :765-778
+        const int32_t PC_GLOBAL *tab = (const int32_t PC_GLOBAL *)(rev_rule ? mp.rc : mp.fw);
+        return tab[L]; // -1 == _BAD_OFFSET
+    } else if (KIND == 4) { // StratifiedVariableFivePrimeMapFactory.__call__ :765-778
         if (L < mp.min_len || L > mp.max_len || L < 1 || L >= mp.table_len) return -1;
-        int off = (rev_rule ? mp.rc : mp.fw)[L];
+        const int32_t PC_GLOBAL *tab = (const int32_t PC_GLOBAL *)(rev_rule ? mp.rc : mp.fw);
+        const int off = tab[L];
         row = L - mp.min_len;
         return off < 0 ? L - 1 : off; // no _BAD_OFFSET check: read_positions[-1]
     }
-    default:
-        return -1;
+    return -1;
+}
+
+__device__ __forceinline__ int map_kleft_dyn(const MapParams &mp, int L, bool rev_rule, int &row) {
+    switch (mp.kind) {
+    case 0: return map_kleft<0>(mp, L, rev_rule, row);
+    case 1: return map_kleft<1>(mp, L, rev_rule, row);
+    case 3: return map_kleft<3>(mp, L, rev_rule, row);
+    case 4: return map_kleft<4>(mp, L, rev_rule, row);
+    default: row = 0; return -1;
     }
 }
 
 // read.positions[k] for a record with aligned runs
-__device__ __forceinline__ int32_t walk_runs(const FileView &fv, int64_t i, int nblk, int k) {
-    const int2 *b = fv.blk + fv.blk_off[i];
+__device__ __forceinline__ int32_t walk_runs(const GFile &fv, int64_t i, int nblk, int k) {
+    const i32x2 PC_GLOBAL *b = fv.blk + fv.blk_off[i];
     int32_t p = 0;
     for (int j = 0; j < nblk; ++j) {
-        int2 r = b[j];
+        i32x2 r = b[j];
         if (k < r.y) { p = r.x + k; break; }
         k -= r.y;
     }
     return p;
 }
 
-__device__ __forceinline__ int32_t rec_end(const FileView &fv, int64_t i, int32_t pos, uint32_t meta) {
+__device__ __forceinline__ int32_t rec_end(const GFile &fv, int64_t i, int32_t pos, uint32_t meta) {
     // htslib bam_endpos
     int nb = rec_nblk(meta);
     if (nb >= 2) {
-        int2 r = fv.blk[fv.blk_off[i] + nb - 1];
+        i32x2 r = fv.blk[fv.blk_off[i] + nb - 1];
         return r.x + r.y;
     }
     int L = rec_len(meta);
@@ -190,8 +247,17 @@ __device__ __forceinline__ int32_t rec_end(const FileView &fv, int64_t i, int32_
 }
 
 // ---------------------------------------------------------------- k_tile_ranges
-// One thread per (tile, file): the record range a tile has to scan, cut into work
-// items of at most `R` records (load balance for pile-ups).
+// One thread per (tile, file): the record range a tile has to scan (fetch emulation),
+// cut into work items of at most `R` records (load balance for pile-ups), plus the range
+// of the file's gapped-record list that can reach the tile.
+__device__ __forceinline__ int64_t lower_bound_gap(const u32x4 PC_GLOBAL *rec, int64_t lo, int64_t hi, int64_t key) {
+    while (lo < hi) {
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)(int32_t)rec[mid].x < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(kWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
                                                      const FileView *__restrict__ files, int nfiles,
                                                      int G, int W, int64_t R, WorkItem *work,
@@ -201,13 +267,20 @@ __global__ __launch_bounds__(kWG) void k_tile_ranges(const Tile *__restrict__ ti
     if (idx >= (int64_t)ntiles * nfiles) return;
     int t = (int)(idx / nfiles), f = (int)(idx % nfiles);
     Tile tl = tiles[t];
-    const FileView &fv = files[f];
+    const GFile fv = gfile(files[f]);
+    const int64_t key_lo = (int64_t)tl.win_start - W + 1, key_hi = (int64_t)tl.win_start + G;
     int64_t b0 = fv.tid_bounds[tl.tid], b1 = fv.tid_bounds[tl.tid + 1];
-    int64_t lo = lower_bound_pos(fv.rec, b0, b1, (int64_t)tl.win_start - W + 1);
-    int64_t hi = lower_bound_pos(fv.rec, lo, b1, (int64_t)tl.win_start + G);
+    int64_t lo = lower_bound_pos(fv.rec, b0, b1, key_lo);
+    int64_t hi = lower_bound_pos(fv.rec, lo, b1, key_hi);
+    int64_t glo = 0, ghi = 0;
+    if (fv.ngap) {
+        const int64_t g0 = fv.gap_tid_bounds[tl.tid], g1 = fv.gap_tid_bounds[tl.tid + 1];
+        glo = lower_bound_gap(fv.gap_rec, g0, g1, key_lo);
+        ghi = lower_bound_gap(fv.gap_rec, glo, g1, key_hi);
+    }
     int64_t n = hi - lo;
-    if (n <= 0) return;
-    uint32_t items = (uint32_t)((n + R - 1) / R);
+    if (n <= 0 && ghi <= glo) return;
+    uint32_t items = n > 0 ? (uint32_t)((n + R - 1) / R) : 1u;
     uint32_t base = atomicAdd(nwork, items);
     atomicAdd(&tile_items[t], items);
     for (uint32_t k = 0; k < items; ++k) {
@@ -215,6 +288,8 @@ __global__ __launch_bounds__(kWG) void k_tile_ranges(const Tile *__restrict__ ti
         WorkItem w;
         w.lo = lo + (int64_t)k * R;
         w.hi = (w.lo + R < hi) ? w.lo + R : hi;
+        w.glo = k == 0 ? glo : 0;
+        w.ghi = k == 0 ? ghi : 0;
         w.tile = (uint32_t)t;
         w.file = (uint32_t)f;
         work[base + k] = w;
@@ -227,38 +302,77 @@ __global__ __launch_bounds__(kWG) void k_tile_ranges(const Tile *__restrict__ ti
 // genome positions per strand mode, then writes the island pieces of the window
 // to the compact histogram (plain coalesced stores when the tile has a single
 // work item, global atomics otherwise).
-__device__ __forceinline__ void hist_one(const FileView &fv, const MapParams &mp, int64_t i, uint2 r,
-                                         const int *slot, int32_t win_start, int G, uint32_t *bins) {
-    const uint32_t meta = r.y;
-    const uint32_t fl = rec_flags(meta);
-    if (fl & (kFlagExcluded | kFlagLong)) return;
-    const int L = rec_len(meta);
-    if (!size_ok(mp, L)) return;
-    const bool rev = fl & kFlagReverse;
-    const int nb = rec_nblk(meta);
-    const int32_t pos = (int32_t)r.x;
-    int row_f, row_r;
-    const int kf = map_kleft(mp, L, false, row_f);
-    const int kr = map_kleft(mp, L, true, row_r);
-    int32_t pf = 0, pr = 0;
-    if (nb >= 2) {
-        if (kf >= 0) pf = walk_runs(fv, i, nb, kf);
-        if (kr >= 0) pr = walk_runs(fv, i, nb, kr);
-    } else {
-        pf = pos + kf;
-        pr = pos + kr;
-    }
+// One record -> at most one LDS atomic per strand mode of the tile.  Predicated code, no
+// divergent branches; `sbase[m]` is the wave-uniform LDS word offset of mode m's bins, or
+// -1 when the tile has no such mode.  `pf`/`pr` = the position the forward / reverse index
+// rule selects (valid when kf / kr >= 0).
+// AGG: reads arrive sorted by position, so neighbouring lanes often hit the same bin
+// (ribosome-profiling pile-ups).  With AGG each maximal run of lanes with the same target
+// bin is collapsed into ONE ds_add of the run length (ballot + one ds_bpermute).
+template <int KIND, bool AGG>
+__device__ __forceinline__ void hist_bin(const MapParams &mp, bool ok, bool rev, int kf, int kr, int32_t pf,
+                                         int32_t pr, int row_f, int row_r, const int (&sbase)[kModes],
+                                         int32_t win_start, uint32_t G, uint32_t *bins, int lane) {
 #pragma unroll
     for (int m = 0; m < kModes; ++m) {
-        if (slot[m] < 0 || !strand_ok(m, rev)) continue;
+        if (sbase[m] < 0) continue; // wave-uniform
         const bool rr = (m == 1 || m == 3);
         const int k = rr ? kr : kf;
-        if (k < 0) continue;
         const uint32_t d = (uint32_t)((rr ? pr : pf) - win_start);
-        if (d < (uint32_t)G) atomicAdd(&bins[(size_t)(slot[m] * mp.rows + (rr ? row_r : row_f)) * G + d], 1u);
+        const bool hit = ok && strand_ok(m, rev) && k >= 0 && d < G;
+        const uint32_t addr = (uint32_t)sbase[m] + (KIND == 4 ? (uint32_t)(rr ? row_r : row_f) * G : 0u) + d;
+        if (!AGG) {
+            if (hit) atomicAdd(&bins[addr], 1u);
+        } else {
+            const unsigned long long V = __ballot(hit);
+            if (V == 0) continue; // wave-uniform
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long below = V & lt;
+            const int prev = below ? 63 - __clzll(below) : lane;
+            const uint32_t pkey = (uint32_t)__shfl((int)addr, prev, 64);
+            const bool head = hit && (below == 0 || pkey != addr);
+            const unsigned long long H = __ballot(head);
+            if (head) {
+                const unsigned long long above = H & ~(lt | (1ull << lane));
+                const unsigned long long upto = above ? ((above & (0 - above)) - 1ull) : ~0ull; // lanes below the next head
+                atomicAdd(&bins[addr], (uint32_t)__popcll(V & upto & ~lt));
+            }
+        }
     }
 }
 
+// ungapped record of the packed stream (gapped ones come from the gapped list, long ones
+// from k_long_point)
+template <int KIND, bool AGG>
+__device__ __forceinline__ void hist_rec(const MapParams &mp, uint32_t rx, uint32_t meta, bool inrange,
+                                         const int (&sbase)[kModes], int32_t win_start, uint32_t G,
+                                         uint32_t *bins, int lane) {
+    const uint32_t fl = rec_flags(meta);
+    const int L = rec_len(meta);
+    const bool ok = inrange && !(fl & (kFlagExcluded | kFlagLong)) && rec_nblk(meta) < 2 && size_ok(mp, L);
+    int row_f, row_r;
+    const int kf = map_kleft<KIND>(mp, L, false, row_f);
+    const int kr = map_kleft<KIND>(mp, L, true, row_r);
+    hist_bin<KIND, AGG>(mp, ok, fl & kFlagReverse, kf, kr, (int32_t)rx + kf, (int32_t)rx + kr, row_f, row_r, sbase,
+                        win_start, G, bins, lane);
+}
+
+// position of read.positions[k] given the first two runs in registers
+__device__ __forceinline__ int32_t walk_from(const GFile &fv, uint32_t off, int nblk, int k, i32x2 b0, i32x2 b1) {
+    if (k < b0.y) return b0.x + k;
+    k -= b0.y;
+    if (k < b1.y) return b1.x + k;
+    k -= b1.y;
+    int32_t p = 0;
+    for (int j = 2; j < nblk; ++j) {
+        const i32x2 r = fv.blk[off + j];
+        if (k < r.y) { p = r.x + k; break; }
+        k -= r.y;
+    }
+    return p;
+}
+
+template <int KIND, bool AGG>
 __global__ __launch_bounds__(kWG) void k_hist_point(const Tile *__restrict__ tiles,
                                                     const Piece *__restrict__ pieces,
                                                     const FileView *__restrict__ files,
@@ -270,35 +384,72 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Tile *__restrict__ til
     if (blockIdx.x >= *nwork) return;
     const WorkItem w = work[blockIdx.x];
     const Tile tl = tiles[w.tile];
-    const FileView &fv = files[w.file];
-    int slot[kModes];
+    const GFile fv = gfile(files[w.file]);
+    const int lane = threadIdx.x & 63;
+    int sbase[kModes];
     int nslots = 0;
 #pragma unroll
-    for (int m = 0; m < kModes; ++m) slot[m] = ((tl.mode_mask >> m) & 1u) ? nslots++ : -1;
+    for (int m = 0; m < kModes; ++m) sbase[m] = ((tl.mode_mask >> m) & 1u) ? (nslots++) * mp.rows * G : -1;
     const int nbins = nslots * mp.rows * G;
     for (int i = threadIdx.x; i < nbins; i += kWG) bins[i] = 0;
     __syncthreads();
 
+    // ---- the packed record stream.  16-byte pairs: one global_load_dwordx4 per lane = 1 KiB
+    // per wave instruction, U per lane in flight, and the next batch is requested before the
+    // current one is consumed (register double buffer) so HBM latency overlaps the LDS atomics.
+    // No dependent loads in this loop.
     constexpr int U = 4;
-    for (int64_t base = w.lo; base < w.hi; base += (int64_t)kWG * U) {
-        uint2 r[U];
+    const int64_t pair_lo = w.lo >> 1, pair_hi = (w.hi + 1) >> 1;
+    const u32x4 none = {0u, kFlagExcluded << 16, 0u, kFlagExcluded << 16};
+    u32x4 cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t j = pair_lo + u * kWG + threadIdx.x;
+        cur[u] = (j < pair_hi) ? fv.rec4[j] : none;
+    }
+    for (int64_t base = pair_lo; base < pair_hi; base += (int64_t)kWG * U) {
+        const int64_t nbase = base + (int64_t)kWG * U;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            int64_t i = base + u * kWG + threadIdx.x;
-            r[u] = (i < w.hi) ? fv.rec[i] : make_uint2(0u, kFlagExcluded << 16);
+            const int64_t j = nbase + u * kWG + threadIdx.x;
+            nxt[u] = (j < pair_hi) ? fv.rec4[j] : none;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) hist_one(fv, mp, base + u * kWG + threadIdx.x, r[u], slot, tl.win_start, G, bins);
+        for (int u = 0; u < U; ++u) {
+            const int64_t i0 = (base + u * kWG + threadIdx.x) * 2;
+            hist_rec<KIND, AGG>(mp, cur[u].x, cur[u].y, i0 >= w.lo && i0 < w.hi, sbase, tl.win_start, (uint32_t)G, bins, lane);
+            hist_rec<KIND, AGG>(mp, cur[u].z, cur[u].w, i0 + 1 >= w.lo && i0 + 1 < w.hi, sbase, tl.win_start, (uint32_t)G, bins, lane);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+
+    // ---- gapped records (deletions, short introns): their aligned runs live in a side
+    // array; consecutive list entries own consecutive runs, so these gathers stay coalesced.
+    for (int64_t base = w.glo; base < w.ghi; base += kWG) {
+        const int64_t j = base + threadIdx.x;
+        const bool in = j < w.ghi;
+        const u32x4 g = in ? fv.gap_rec[j] : none;
+        const uint32_t meta = g.y, fl = rec_flags(meta);
+        const int L = rec_len(meta), nb = rec_nblk(meta);
+        const bool ok = in && !(fl & kFlagExcluded) && size_ok(mp, L);
+        i32x2 b0 = {0, 1}, b1 = {0, 1};
+        if (in) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
+        int row_f, row_r;
+        const int kf = map_kleft<KIND>(mp, L, false, row_f);
+        const int kr = map_kleft<KIND>(mp, L, true, row_r);
+        const int32_t pf = (ok && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
+        const int32_t pr = (ok && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
+        hist_bin<KIND, AGG>(mp, ok, fl & kFlagReverse, kf, kr, pf, pr, row_f, row_r, sbase, tl.win_start, (uint32_t)G, bins, lane);
     }
     __syncthreads();
 
     const bool single = tile_items[w.tile] == 1u;
     for (uint32_t pi = tl.piece_begin; pi < tl.piece_end; ++pi) {
         const Piece pc_ = pieces[pi];
-        const int s = slot[pc_.mode];
         const int rel = pc_.start - tl.win_start;
         for (int r = 0; r < mp.rows; ++r) {
-            const uint32_t *src = bins + (size_t)(s * mp.rows + r) * G + rel;
+            const uint32_t *src = bins + sbase[pc_.mode] + r * G + rel;
             uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
             if (single) {
                 for (int i = threadIdx.x; i < pc_.len; i += kWG) dst[i] = src[i];
@@ -329,13 +480,14 @@ __device__ __forceinline__ int64_t find_tile(const Tile *tiles, int ntiles, int3
 }
 
 __global__ __launch_bounds__(kWG) void k_long_point(const Tile *__restrict__ tiles, int ntiles,
-                                                    const Piece *__restrict__ pieces, FileView fv,
+                                                    const Piece *__restrict__ pieces, FileView fview,
                                                     MapParams mp, int G, uint32_t plan_modes,
                                                     uint32_t *hist, int64_t hist_row_stride) {
+    const GFile fv = gfile(fview);
     int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (j >= fv.nlong) return;
     const int64_t i = fv.long_idx[j];
-    const uint2 r = fv.rec[i];
+    const u32x2 r = fv.rec[i];
     const uint32_t meta = r.y;
     const uint32_t fl = rec_flags(meta);
     if (fl & kFlagExcluded) return;
@@ -347,7 +499,7 @@ __global__ __launch_bounds__(kWG) void k_long_point(const Tile *__restrict__ til
     for (int m = 0; m < kModes; ++m) {
         if (!((plan_modes >> m) & 1u) || !strand_ok(m, rev)) continue;
         int row;
-        const int k = map_kleft(mp, L, m == 1 || m == 3, row);
+        const int k = map_kleft_dyn(mp, L, m == 1 || m == 3, row);
         if (k < 0) continue;
         const int32_t p = nb >= 2 ? walk_runs(fv, i, nb, k) : (int32_t)r.x + k;
         const int64_t t = find_tile(tiles, ntiles, tid, (int32_t)(((int64_t)p / G) * G));
@@ -371,9 +523,9 @@ __global__ __launch_bounds__(kWG) void k_long_point(const Tile *__restrict__ til
 // there are no atomics: one lane owns one output position and replays, in record
 // order, every read that can cover it.  One wave per 64 positions; the candidate
 // loop is wave-uniform (scalar loads), the coverage test is per lane.
-__device__ __forceinline__ void center_one(const FileView &fv, const MapParams &mp, int64_t i, int mode,
-                                           const double *__restrict__ inv, int32_t p, double &acc) {
-    const uint2 r = fv.rec[i];
+__device__ __forceinline__ void center_one(const GFile &fv, const MapParams &mp, int64_t i, int mode,
+                                           const double PC_GLOBAL *inv, int32_t p, double &acc) {
+    const u32x2 r = fv.rec[i];
     const uint32_t meta = r.y;
     const uint32_t fl = rec_flags(meta);
     if (fl & kFlagExcluded) return;
@@ -391,10 +543,10 @@ __device__ __forceinline__ void center_one(const FileView &fv, const MapParams &
         hit = p >= s && p < s + m;
     } else {
         hit = false;
-        const int2 *b = fv.blk + fv.blk_off[i];
+        const i32x2 PC_GLOBAL *b = fv.blk + fv.blk_off[i];
         int cum = 0;
         for (int j = 0; j < nb; ++j) {
-            const int2 run = b[j];
+            const i32x2 run = b[j];
             const int idx = cum + (p - run.x);
             hit |= (p >= run.x) && (p < run.x + run.y) && (idx >= nib) && (idx < L - nib);
             cum += run.y;
@@ -405,8 +557,9 @@ __device__ __forceinline__ void center_one(const FileView &fv, const MapParams &
 
 __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                 const FileView *__restrict__ files, int nfiles,
-                                                MapParams mp, int W, const double *__restrict__ inv,
+                                                MapParams mp, int W, const double *__restrict__ inv_,
                                                 double *hist) {
+    const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
     const int64_t c = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
     if (c >= nchunks) return;
     const int lane = threadIdx.x & 63;
@@ -414,7 +567,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     const int32_t p = ck.start + lane;
     double acc = 0.0;
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
-        const FileView &fv = files[f];
+        const GFile fv = gfile(files[f]);
         const int64_t b0 = fv.tid_bounds[ck.tid], b1 = fv.tid_bounds[ck.tid + 1];
         const int64_t near_key = (int64_t)ck.start - W + 1;
         if (fv.nlong) {
@@ -504,12 +657,13 @@ __global__ void k_total_f64_final(const double *__restrict__ partial, int nb, do
 
 // ---------------------------------------------------------------- k_mapped_reads
 // reads_out of the map functions for ONE segment (genome_array.py:800-823).
-__global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fv, MapParams mp, int64_t rec_lo, int64_t rec_hi,
+__global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fview, MapParams mp, int64_t rec_lo, int64_t rec_hi,
                                                       int64_t start, int64_t end, int mode, bool strand_filter,
                                                       uint8_t *mask) {
+    const GFile fv = gfile(fview);
     int64_t i = rec_lo + (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (i >= rec_hi) return;
-    const uint2 r = fv.rec[i];
+    const u32x2 r = fv.rec[i];
     const uint32_t meta = r.y;
     const uint32_t fl = rec_flags(meta);
     const int32_t pos = (int32_t)r.x;
@@ -523,7 +677,7 @@ __global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fv, MapParams mp,
             out = (L - 2 * mp.param) > 0; // CenterMapFactory :249-256: appended even if nothing landed
         } else {
             int row;
-            const int k = map_kleft(mp, L, mode == 1 || mode == 3, row);
+            const int k = map_kleft_dyn(mp, L, mode == 1 || mode == 3, row);
             if (k >= 0) {
                 const int64_t p = nb >= 2 ? walk_runs(fv, i, nb, k) : pos + k;
                 out = p >= start && p < end;
@@ -536,11 +690,12 @@ __global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fv, MapParams mp,
 // ---------------------------------------------------------------- k_unmappable
 // Records for which the reference sets its warning flag (:246-248, :351-353,
 // :450-452, :633-636); compacted for the host-side per-segment overlap test.
-__global__ __launch_bounds__(kWG) void k_unmappable(FileView fv, MapParams mp, int ntid, Unmappable *list,
+__global__ __launch_bounds__(kWG) void k_unmappable(FileView fview, MapParams mp, int ntid, Unmappable *list,
                                                     uint32_t cap, uint32_t *count) {
+    const GFile fv = gfile(fview);
     int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (i >= fv.n) return;
-    const uint2 r = fv.rec[i];
+    const u32x2 r = fv.rec[i];
     const uint32_t meta = r.y;
     const uint32_t fl = rec_flags(meta);
     const int L = rec_len(meta);

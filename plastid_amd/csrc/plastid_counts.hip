@@ -77,12 +77,16 @@ struct StagedFile {
     DevBuf<int32_t> long_tid;
     DevBuf<int32_t> long_pmax;
     DevBuf<int64_t> long_tid_bounds;
+    int64_t ngap = 0;
+    DevBuf<uint4> gap_rec;
+    DevBuf<int64_t> gap_tid_bounds;
     std::vector<int64_t> len_hist; // records per aligned length (host), for cheap warn pre-checks
     FileView view() const {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
         v.long_idx = long_idx.p; v.long_tid = long_tid.p; v.long_pmax = long_pmax.p;
         v.long_tid_bounds = long_tid_bounds.p; v.n = n; v.nlong = nlong;
+        v.gap_rec = gap_rec.p; v.gap_tid_bounds = gap_tid_bounds.p; v.ngap = ngap;
         return v;
     }
 };
@@ -279,7 +283,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
 
     // ---- host pass: validation, per-tid bounds, spans, packed records
     std::vector<int64_t> tid_bounds((size_t)ntid + 1, 0);
-    std::vector<uint2> rec((size_t)n);
+    std::vector<uint2> rec((size_t)n + 2, make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16)); // +pad: 16-byte pair loads
     std::vector<uint32_t> blk_off;
     if (nrun > 0) blk_off.assign((size_t)n, 0u);
     std::vector<int32_t> span((size_t)n);
@@ -344,6 +348,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     std::vector<uint32_t> long_idx;
     std::vector<int32_t> long_tid, long_pmax;
     std::vector<int64_t> long_bounds((size_t)ntid + 1, 0);
+    std::vector<uint4> gap_rec;                                  // short-span gapped records
+    std::vector<int64_t> gap_bounds((size_t)ntid + 1, 0);
     int W = 1;
     int64_t max_span = 1;
     {
@@ -362,13 +368,19 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 long_bounds[(size_t)tid[i] + 1] += 1;
             } else {
                 W = std::max(W, (int)sp);
+                if (nblk[i] >= 2) {
+                    gap_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, blk_off[(size_t)i], (uint32_t)i));
+                    gap_bounds[(size_t)tid[i] + 1] += 1;
+                }
             }
         }
         for (int t = 0; t < ntid; ++t) long_bounds[(size_t)t + 1] += long_bounds[(size_t)t];
+        for (int t = 0; t < ntid; ++t) gap_bounds[(size_t)t + 1] += gap_bounds[(size_t)t];
     }
     sf->W = W;
     sf->max_span = max_span;
     sf->nlong = (int64_t)long_idx.size();
+    sf->ngap = (int64_t)gap_rec.size();
 
     // ---- bulk stage to HBM
     int rc = sf->rec.upload(rec, e->stream);
@@ -384,6 +396,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc == PC_OK) rc = sf->long_tid.upload(long_tid, e->stream);
     if (rc == PC_OK) rc = sf->long_pmax.upload(long_pmax, e->stream);
     if (rc == PC_OK) rc = sf->long_tid_bounds.upload(long_bounds, e->stream);
+    if (rc == PC_OK) rc = sf->gap_rec.upload(gap_rec, e->stream);
+    if (rc == PC_OK) rc = sf->gap_tid_bounds.upload(gap_bounds, e->stream);
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
     if (rc != PC_OK) {
         delete sf;
@@ -406,6 +420,12 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     for (int64_t i = 0; i < n; ++i)
         rec[(size_t)i].y = (rec[(size_t)i].y & keep) | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16);
     HIP_TRY(hipMemcpy(sf->rec.p, rec.data(), (size_t)n * sizeof(uint2), hipMemcpyHostToDevice));
+    if (sf->ngap) { // the gapped-record list carries a copy of the header
+        std::vector<uint4> g((size_t)sf->ngap);
+        HIP_TRY(hipMemcpy(g.data(), sf->gap_rec.p, g.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+        for (auto &x : g) x.y = rec[(size_t)x.w].y;
+        HIP_TRY(hipMemcpy(sf->gap_rec.p, g.data(), g.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     return PC_OK;
 }
 
@@ -673,7 +693,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     const int nfiles = (int)e->files.size();
     const int W = e->W();
     const int G = p->G;
-    int64_t R = 65536;
+    int64_t R = 16384;
     if (const char *env = getenv("PC_WORK_R")) R = std::max(1024, atoi(env)); // tuning knob
     const MapParams mp = e->params();
     const int ntiles = (int)p->tiles.size();
@@ -702,8 +722,22 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                                e->d_files.p, nfiles, G, W, R, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64);
             HIP_TRY(hipEventRecord(e->ev[2], st));
             const size_t lds = (size_t)p->max_slots * p->rows * G * sizeof(uint32_t);
-            hipLaunchKernelGGL(k_hist_point, dim3((unsigned)cap64), dim3(kWG), lds, st, p->d_tiles.p, p->d_pieces.p, e->d_files.p,
-                               e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, (uint32_t *)p->d_hist.p, p->npos);
+#define PC_LAUNCH_HIST(K, A)                                                                                          \
+    hipLaunchKernelGGL((k_hist_point<K, A>), dim3((unsigned)cap64), dim3(kWG), lds, st, p->d_tiles.p, p->d_pieces.p,    \
+                       e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, (uint32_t *)p->d_hist.p, p->npos)
+            bool agg = false;
+            if (const char *env = getenv("PC_HIST_AGG")) agg = atoi(env) != 0; // tuning knob
+            switch (e->kind * 2 + (agg ? 1 : 0)) {
+            case PC_MAP_FIVE * 2: PC_LAUNCH_HIST(0, false); break;
+            case PC_MAP_FIVE * 2 + 1: PC_LAUNCH_HIST(0, true); break;
+            case PC_MAP_THREE * 2: PC_LAUNCH_HIST(1, false); break;
+            case PC_MAP_THREE * 2 + 1: PC_LAUNCH_HIST(1, true); break;
+            case PC_MAP_VAR5 * 2: PC_LAUNCH_HIST(3, false); break;
+            case PC_MAP_VAR5 * 2 + 1: PC_LAUNCH_HIST(3, true); break;
+            case PC_MAP_STRAT5 * 2: PC_LAUNCH_HIST(4, false); break;
+            default: PC_LAUNCH_HIST(4, true); break;
+            }
+#undef PC_LAUNCH_HIST
             HIP_TRY(hipEventRecord(e->ev[3], st));
             for (auto *f : e->files) {
                 if (!f->nlong) continue;

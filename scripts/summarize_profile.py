@@ -35,7 +35,7 @@ for f in find("trace/**/*kernel_stats.csv"):
     print("== rocprofv3 --stats:", os.path.relpath(f, out))
     print(open(f).read()[:3000])
 
-for sub in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcc"):
+for sub in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write", "pmc_tcc"):
     for f in find(sub + "/**/*counter_collection.csv"):
         d = defaultdict(lambda: defaultdict(list))
         for row in csv.DictReader(open(f)):
