@@ -34,6 +34,7 @@ constexpr uint32_t kFlagReverse = 0x01;
 constexpr uint32_t kFlagLong = 0x40;      // engine-internal: span > W, handled by the long-read path
 constexpr uint32_t kFlagExcluded = 0x80;
 constexpr int kGatherChunk = 1024;
+constexpr int kLinShift = 7;              // linear-index bucket = 128 genome positions
 
 // strand modes of a query interval
 //   0: '+'  keeps forward reads, forward index rule
@@ -53,6 +54,11 @@ struct FileView {
     const int64_t *long_tid_bounds; // ntid+1
     const uint4 *gap_rec;           // short-span gapped records {pos, meta, blk_off, rec_idx}, record order
     const int64_t *gap_tid_bounds;  // ntid+1
+    // linear index (cf. the BAI linear index): first record at or after every kLinShift-bit
+    // genome bucket, per contig; lin_off[t] = start of contig t's buckets (nb_t + 1 entries)
+    const uint32_t *lin_tab;
+    const uint32_t *glin_tab;       // same for the gapped-record list
+    const int64_t *lin_off;         // ntid+1 (shared by both tables)
     int64_t n;
     int64_t nlong;
     int64_t ngap;
@@ -78,6 +84,9 @@ struct GFile {
     const int64_t PC_GLOBAL *long_tid_bounds;
     const u32x4 PC_GLOBAL *gap_rec;
     const int64_t PC_GLOBAL *gap_tid_bounds;
+    const uint32_t PC_GLOBAL *lin_tab;
+    const uint32_t PC_GLOBAL *glin_tab;
+    const int64_t PC_GLOBAL *lin_off;
     int64_t n;
     int64_t nlong;
     int64_t ngap;
@@ -96,6 +105,9 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.long_tid_bounds = (const int64_t PC_GLOBAL *)v.long_tid_bounds;
     g.gap_rec = (const u32x4 PC_GLOBAL *)v.gap_rec;
     g.gap_tid_bounds = (const int64_t PC_GLOBAL *)v.gap_tid_bounds;
+    g.lin_tab = (const uint32_t PC_GLOBAL *)v.lin_tab;
+    g.glin_tab = (const uint32_t PC_GLOBAL *)v.glin_tab;
+    g.lin_off = (const int64_t PC_GLOBAL *)v.lin_off;
     g.n = v.n;
     g.nlong = v.nlong;
     g.ngap = v.ngap;
@@ -135,7 +147,12 @@ struct WorkItem {
     int64_t glo, ghi; // range of the gapped-record list (first work item of a tile only)
     uint32_t tile;
     uint32_t file;
+    int32_t win_start; // copied from the tile: saves the histogram kernel a dependent load
+    uint32_t mode_mask;
+    uint32_t piece_begin, piece_end;
 };
+
+
 
 struct CenterChunk {
     int64_t hist_off;
@@ -247,43 +264,91 @@ __device__ __forceinline__ int32_t rec_end(const GFile &fv, int64_t i, int32_t p
 }
 
 // ---------------------------------------------------------------- k_tile_ranges
-// One thread per (tile, file): the record range a tile has to scan (fetch emulation),
-// cut into work items of at most `R` records (load balance for pile-ups), plus the range
-// of the file's gapped-record list that can reach the tile.
-__device__ __forceinline__ int64_t lower_bound_gap(const u32x4 PC_GLOBAL *rec, int64_t lo, int64_t hi, int64_t key) {
-    while (lo < hi) {
-        int64_t mid = lo + ((hi - lo) >> 1);
-        if ((int64_t)(int32_t)rec[mid].x < key) lo = mid + 1; else hi = mid;
+// One WAVE per (tile, file): the record range a tile has to scan (fetch emulation), cut
+// into work items of at most `R` records (load balance for pile-ups), plus the range of
+// the file's gapped-record list that can reach the tile.  Each search starts from the
+// linear index (one lookup narrows it to a 128-nt bucket) and finishes 64-ary: every step
+// probes 64 evenly spaced records of the bucket at once (ballot), so a search costs about
+// three dependent loads instead of the ~27 of a binary search over the whole contig.
+template <int STRIDE> // dwords between consecutive records: 2 (packed stream) or 4 (gapped list)
+__device__ __forceinline__ int64_t wave_lower_bound(const uint32_t PC_GLOBAL *pos, int64_t lo, int64_t hi, int64_t key,
+                                                    int lane) {
+    while (hi - lo > 64) {
+        const int64_t step = (hi - lo + 63) >> 6;
+        int64_t idx = lo + (int64_t)(lane + 1) * step - 1;
+        if (idx >= hi) idx = hi - 1;
+        const bool less = (int64_t)(int32_t)pos[idx * STRIDE] < key;
+        const int c = __popcll(__ballot(less)); // probes are monotone: the first c are < key
+        const int64_t nlo = c == 0 ? lo : lo + (int64_t)c * step;          // one past probe c-1
+        const int64_t nhi = c == 64 ? hi : lo + (int64_t)(c + 1) * step - 1; // probe c
+        lo = nlo < hi ? nlo : hi;
+        hi = nhi < hi ? nhi : hi;
+        if (hi < lo) hi = lo;
     }
-    return lo;
+    const int64_t idx = lo + lane;
+    const bool less = idx < hi && (int64_t)(int32_t)pos[idx * STRIDE] < key;
+    return lo + __popcll(__ballot(less));
 }
 
-__global__ __launch_bounds__(kWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
-                                                     const FileView *__restrict__ files, int nfiles,
-                                                     int G, int W, int64_t R, WorkItem *work,
-                                                     uint32_t *nwork, uint32_t *tile_items,
-                                                     uint32_t work_cap) {
-    int64_t idx = (int64_t)blockIdx.x * kWG + threadIdx.x;
-    if (idx >= (int64_t)ntiles * nfiles) return;
-    int t = (int)(idx / nfiles), f = (int)(idx % nfiles);
-    Tile tl = tiles[t];
-    const GFile fv = gfile(files[f]);
-    const int64_t key_lo = (int64_t)tl.win_start - W + 1, key_hi = (int64_t)tl.win_start + G;
-    int64_t b0 = fv.tid_bounds[tl.tid], b1 = fv.tid_bounds[tl.tid + 1];
-    int64_t lo = lower_bound_pos(fv.rec, b0, b1, key_lo);
-    int64_t hi = lower_bound_pos(fv.rec, lo, b1, key_hi);
-    int64_t glo = 0, ghi = 0;
-    if (fv.ngap) {
-        const int64_t g0 = fv.gap_tid_bounds[tl.tid], g1 = fv.gap_tid_bounds[tl.tid + 1];
-        glo = lower_bound_gap(fv.gap_rec, g0, g1, key_lo);
-        ghi = lower_bound_gap(fv.gap_rec, glo, g1, key_hi);
+template <int STRIDE>
+__device__ __forceinline__ int64_t indexed_lower_bound(const uint32_t PC_GLOBAL *pos, const uint32_t PC_GLOBAL *lin,
+                                                       int64_t lin0, int64_t nb, int64_t key, int lane) {
+    // lin[lin0 + b] = first record with pos >= b << kLinShift, b = 0..nb (entry nb = contig end)
+    int64_t b = key <= 0 ? 0 : (key >> kLinShift);
+    if (b > nb) b = nb;
+    const int64_t b1 = b + 1 > nb ? nb : b + 1;
+    const int64_t lo = lin[lin0 + b], hi = lin[lin0 + b1];
+    return wave_lower_bound<STRIDE>(pos, lo, hi, key, lane);
+}
+
+constexpr int kRangesWG = 1024; // 16 waves = 16 (tile, file) pairs per workgroup
+
+__global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
+                                                           const FileView *__restrict__ files, int nfiles,
+                                                           int G, int W, int64_t R, WorkItem *work,
+                                                           uint32_t *nwork, uint32_t *tile_items,
+                                                           uint32_t work_cap) {
+    __shared__ uint32_t s_items[kRangesWG / 64];
+    __shared__ uint32_t s_base;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * (kRangesWG / 64) + wv;
+    const bool live = idx < (int64_t)ntiles * nfiles;
+    int t = 0, f = 0;
+    Tile tl = {};
+    int64_t lo = 0, hi = 0, glo = 0, ghi = 0;
+    uint32_t items = 0;
+    if (live) {
+        t = (int)(idx / nfiles);
+        f = (int)(idx % nfiles);
+        tl = tiles[t];
+        const GFile fv = gfile(files[f]);
+        const int64_t key_lo = (int64_t)tl.win_start - W + 1, key_hi = (int64_t)tl.win_start + G;
+        const int64_t l0 = fv.lin_off[tl.tid], nb = fv.lin_off[tl.tid + 1] - l0 - 1;
+        const uint32_t PC_GLOBAL *rpos = (const uint32_t PC_GLOBAL *)fv.rec;
+        lo = indexed_lower_bound<2>(rpos, fv.lin_tab, l0, nb, key_lo, lane);
+        hi = indexed_lower_bound<2>(rpos, fv.lin_tab, l0, nb, key_hi, lane);
+        if (fv.ngap) {
+            const uint32_t PC_GLOBAL *gpos = (const uint32_t PC_GLOBAL *)fv.gap_rec;
+            glo = indexed_lower_bound<4>(gpos, fv.glin_tab, l0, nb, key_lo, lane);
+            ghi = indexed_lower_bound<4>(gpos, fv.glin_tab, l0, nb, key_hi, lane);
+        }
+        const int64_t n = hi - lo;
+        if (n > 0) items = (uint32_t)((n + R - 1) / R);
+        else if (ghi > glo) items = 1u;
     }
-    int64_t n = hi - lo;
-    if (n <= 0 && ghi <= glo) return;
-    uint32_t items = n > 0 ? (uint32_t)((n + R - 1) / R) : 1u;
-    uint32_t base = atomicAdd(nwork, items);
-    atomicAdd(&tile_items[t], items);
-    for (uint32_t k = 0; k < items; ++k) {
+    // one returning atomic per workgroup (a single hot counter saturates near 90 atomics/us)
+    if (lane == 0) s_items[wv] = items;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < kRangesWG / 64; ++i) { const uint32_t v = s_items[i]; s_items[i] = tot; tot += v; }
+        s_base = tot ? atomicAdd(nwork, tot) : 0u;
+    }
+    __syncthreads();
+    if (!items) return;
+    const uint32_t base = s_base + s_items[wv];
+    if (lane == 0) atomicAdd(&tile_items[t], items);
+    for (uint32_t k = lane; k < items; k += 64) {
         if (base + k >= work_cap) break; // cannot happen (capacity is an upper bound); defensive
         WorkItem w;
         w.lo = lo + (int64_t)k * R;
@@ -292,6 +357,10 @@ __global__ __launch_bounds__(kWG) void k_tile_ranges(const Tile *__restrict__ ti
         w.ghi = k == 0 ? ghi : 0;
         w.tile = (uint32_t)t;
         w.file = (uint32_t)f;
+        w.win_start = tl.win_start;
+        w.mode_mask = tl.mode_mask;
+        w.piece_begin = tl.piece_begin;
+        w.piece_end = tl.piece_end;
         work[base + k] = w;
     }
 }
@@ -302,59 +371,78 @@ __global__ __launch_bounds__(kWG) void k_tile_ranges(const Tile *__restrict__ ti
 // genome positions per strand mode, then writes the island pieces of the window
 // to the compact histogram (plain coalesced stores when the tile has a single
 // work item, global atomics otherwise).
-// One record -> at most one LDS atomic per strand mode of the tile.  Predicated code, no
-// divergent branches; `sbase[m]` is the wave-uniform LDS word offset of mode m's bins, or
-// -1 when the tile has no such mode.  `pf`/`pr` = the position the forward / reverse index
-// rule selects (valid when kf / kr >= 0).
-// AGG: reads arrive sorted by position, so neighbouring lanes often hit the same bin
-// (ribosome-profiling pile-ups).  With AGG each maximal run of lanes with the same target
-// bin is collapsed into ONE ds_add of the run length (ballot + one ds_bpermute).
-template <int KIND, bool AGG>
-__device__ __forceinline__ void hist_bin(const MapParams &mp, bool ok, bool rev, int kf, int kr, int32_t pf,
-                                         int32_t pr, int row_f, int row_r, const int (&sbase)[kModes],
-                                         int32_t win_start, uint32_t G, uint32_t *bins, int lane) {
-#pragma unroll
-    for (int m = 0; m < kModes; ++m) {
-        if (sbase[m] < 0) continue; // wave-uniform
-        const bool rr = (m == 1 || m == 3);
-        const int k = rr ? kr : kf;
-        const uint32_t d = (uint32_t)((rr ? pr : pf) - win_start);
-        const bool hit = ok && strand_ok(m, rev) && k >= 0 && d < G;
-        const uint32_t addr = (uint32_t)sbase[m] + (KIND == 4 ? (uint32_t)(rr ? row_r : row_f) * G : 0u) + d;
-        if (!AGG) {
-            if (hit) atomicAdd(&bins[addr], 1u);
-        } else {
-            const unsigned long long V = __ballot(hit);
-            if (V == 0) continue; // wave-uniform
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const unsigned long long below = V & lt;
-            const int prev = below ? 63 - __clzll(below) : lane;
-            const uint32_t pkey = (uint32_t)__shfl((int)addr, prev, 64);
-            const bool head = hit && (below == 0 || pkey != addr);
-            const unsigned long long H = __ballot(head);
-            if (head) {
-                const unsigned long long above = H & ~(lt | (1ull << lane));
-                const unsigned long long upto = above ? ((above & (0 - above)) - 1ull) : ~0ull; // lanes below the next head
-                atomicAdd(&bins[addr], (uint32_t)__popcll(V & upto & ~lt));
-            }
+// Per-work-item constants of the histogram kernel (all wave-uniform -> SGPRs).
+struct HistCfg {
+    int32_t win_start;
+    uint32_t G;
+    int base[kModes];      // LDS word offset of each strand mode's bins, -1 = mode absent
+    uint32_t fmin, frange; // size filter as one unsigned compare: (L - fmin) <= frange
+    int tab_lo;            // offset tables staged in LDS for aligned lengths [tab_lo, tab_lo + tab_n)
+    uint32_t tab_n;
+};
+
+// Index from the left end of read.positions under the forward / reverse rule (-1: read not
+// mapped) and the LDS row offset (stratified).  Offset tables come from LDS as one packed
+// word per length: low half = forward_offsets[L], high half = reverse_offsets[L], 0xffff = none.
+template <int KIND>
+__device__ __forceinline__ void map_both(const MapParams &mp, const HistCfg &c, const uint32_t *ltab, int L, int &kf,
+                                         int &kr, uint32_t &rowoff) {
+    rowoff = 0;
+    if (KIND == 0 || KIND == 1) { // :343-355 / :442-454
+        const bool ok = mp.param < L;
+        const int a = mp.param, z = L - 1 - mp.param;
+        kf = ok ? (KIND == 0 ? a : z) : -1;
+        kr = ok ? (KIND == 0 ? z : a) : -1;
+    } else {
+        const uint32_t t = (uint32_t)(L - c.tab_lo);
+        const uint32_t e = t < c.tab_n ? ltab[t] : 0xffffffffu;
+        const int f = (e & 0xffffu) == 0xffffu ? -1 : (int)(e & 0xffffu);
+        const int r = (e >> 16) == 0xffffu ? -1 : (int)(e >> 16);
+        if (KIND == 3) { // :625-638
+            kf = t < c.tab_n ? f : -1;
+            kr = t < c.tab_n ? r : -1;
+        } else { // :765-778: no bad-offset check, read_positions[-1]
+            const bool in = (L >= mp.min_len) & (L <= mp.max_len) & (L >= 1) & (t < c.tab_n);
+            kf = in ? (f < 0 ? L - 1 : f) : -1;
+            kr = in ? (r < 0 ? L - 1 : r) : -1;
+            rowoff = (uint32_t)(L - mp.min_len) * c.G;
         }
     }
 }
 
-// ungapped record of the packed stream (gapped ones come from the gapped list, long ones
-// from k_long_point)
-template <int KIND, bool AGG>
-__device__ __forceinline__ void hist_rec(const MapParams &mp, uint32_t rx, uint32_t meta, bool inrange,
-                                         const int (&sbase)[kModes], int32_t win_start, uint32_t G,
-                                         uint32_t *bins, int lane) {
-    const uint32_t fl = rec_flags(meta);
-    const int L = rec_len(meta);
-    const bool ok = inrange && !(fl & (kFlagExcluded | kFlagLong)) && rec_nblk(meta) < 2 && size_ok(mp, L);
-    int row_f, row_r;
-    const int kf = map_kleft<KIND>(mp, L, false, row_f);
-    const int kr = map_kleft<KIND>(mp, L, true, row_r);
-    hist_bin<KIND, AGG>(mp, ok, fl & kFlagReverse, kf, kr, (int32_t)rx + kf, (int32_t)rx + kr, row_f, row_r, sbase,
-                        win_start, G, bins, lane);
+// Bin one read.  `pf`/`pr` = window-relative position under the forward / reverse rule.
+// Modes 0 ('+') and 1 ('-') are mutually exclusive per read (strand filter), so they share
+// one predicated ds_add; '.' (mode 2) and the unfiltered reverse rule (mode 3) add their own.
+__device__ __forceinline__ void hist_bin(const HistCfg &c, bool valid, bool rev, int kf, int kr, uint32_t df,
+                                         uint32_t dr, uint32_t rowoff, uint32_t *bins) {
+    if ((c.base[0] & c.base[1]) != -1) { // uniform: the tile has a '+' and/or a '-' island
+        const int k = rev ? kr : kf;
+        const int b = rev ? c.base[1] : c.base[0];
+        const uint32_t d = rev ? dr : df;
+        if (valid & (k >= 0) & (b >= 0) & (d < c.G)) atomicAdd(&bins[(uint32_t)b + rowoff + d], 1u);
+    }
+    if (c.base[2] >= 0) {
+        if (valid & (kf >= 0) & (df < c.G)) atomicAdd(&bins[(uint32_t)c.base[2] + rowoff + df], 1u);
+    }
+    if (c.base[3] >= 0) {
+        if (valid & (kr >= 0) & (dr < c.G)) atomicAdd(&bins[(uint32_t)c.base[3] + rowoff + dr], 1u);
+    }
+}
+
+// ungapped record of the packed stream (gapped ones come from the gapped list, long-span
+// ones from k_long_point)
+template <int KIND>
+__device__ __forceinline__ void hist_rec(const MapParams &mp, const HistCfg &c, const uint32_t *ltab, uint32_t rx,
+                                         uint32_t meta, bool inrange, uint32_t *bins) {
+    const int L = (int)(meta & 0xffffu);
+    const uint32_t hi = meta >> 16;                   // flags | nblk << 8
+    const uint32_t bad = (hi & (kFlagExcluded | kFlagLong)) | (hi >> 9); // excluded, long or nblk >= 2
+    const bool valid = inrange & (bad == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
+    int kf, kr;
+    uint32_t rowoff;
+    map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
+    const int32_t rel = (int32_t)rx - c.win_start;
+    hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(rel + kf), (uint32_t)(rel + kr), rowoff, bins);
 }
 
 // position of read.positions[k] given the first two runs in registers
@@ -372,53 +460,81 @@ __device__ __forceinline__ int32_t walk_from(const GFile &fv, uint32_t off, int 
     return p;
 }
 
-template <int KIND, bool AGG>
-__global__ __launch_bounds__(kWG) void k_hist_point(const Tile *__restrict__ tiles,
-                                                    const Piece *__restrict__ pieces,
+// One workgroup per work item.  The work-item descriptor carries the tile's window and
+// piece range, and up to two staged files travel as kernel arguments, so the first record
+// batch is requested after a single dependent load; the LDS set-up runs under that latency.
+template <int KIND>
+__global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pieces, FileView file0, FileView file1,
                                                     const FileView *__restrict__ files,
                                                     const WorkItem *__restrict__ work,
                                                     const uint32_t *__restrict__ nwork,
                                                     const uint32_t *__restrict__ tile_items, MapParams mp,
-                                                    int G, uint32_t *hist, int64_t hist_row_stride) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t bins[];
-    if (blockIdx.x >= *nwork) return;
+                                                    int G, int tab_lo, int tab_n, uint32_t *hist,
+                                                    int64_t hist_row_stride, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const WorkItem w = work[blockIdx.x];
-    const Tile tl = tiles[w.tile];
-    const GFile fv = gfile(files[w.file]);
-    const int lane = threadIdx.x & 63;
-    int sbase[kModes];
-    int nslots = 0;
-#pragma unroll
-    for (int m = 0; m < kModes; ++m) sbase[m] = ((tl.mode_mask >> m) & 1u) ? (nslots++) * mp.rows * G : -1;
-    const int nbins = nslots * mp.rows * G;
-    for (int i = threadIdx.x; i < nbins; i += kWG) bins[i] = 0;
-    __syncthreads();
+    if (blockIdx.x >= *nwork) return;
+    const GFile fv = w.file == 0 ? gfile(file0) : (w.file == 1 ? gfile(file1) : gfile(files[w.file]));
 
-    // ---- the packed record stream.  16-byte pairs: one global_load_dwordx4 per lane = 1 KiB
-    // per wave instruction, U per lane in flight, and the next batch is requested before the
-    // current one is consumed (register double buffer) so HBM latency overlaps the LDS atomics.
-    // No dependent loads in this loop.
+    // ---- first batch of the record stream (and the first gapped records): 16-byte pairs,
+    // one global_load_dwordx4 per lane = 1 KiB per wave instruction, U per lane in flight
     constexpr int U = 4;
-    const int64_t pair_lo = w.lo >> 1, pair_hi = (w.hi + 1) >> 1;
+    const int64_t pair_lo = w.lo >> 1;
+    const int npairs = (int)(((w.hi + 1) >> 1) - pair_lo);
+    const int lo_odd = (int)(w.lo & 1), hi_odd = (int)(w.hi & 1);
+    const u32x4 PC_GLOBAL *src = fv.rec4 + pair_lo;
     const u32x4 none = {0u, kFlagExcluded << 16, 0u, kFlagExcluded << 16};
-    u32x4 cur[U], nxt[U];
+    u32x4 cur[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int64_t j = pair_lo + u * kWG + threadIdx.x;
-        cur[u] = (j < pair_hi) ? fv.rec4[j] : none;
+        const int j = u * kWG + (int)threadIdx.x;
+        cur[u] = (j < npairs) ? src[j] : none;
     }
-    for (int64_t base = pair_lo; base < pair_hi; base += (int64_t)kWG * U) {
-        const int64_t nbase = base + (int64_t)kWG * U;
+    const int64_t gj0 = w.glo + threadIdx.x;
+    const u32x4 gfirst = (gj0 < w.ghi) ? fv.gap_rec[gj0] : none;
+
+    HistCfg c;
+    c.win_start = w.win_start;
+    c.G = (uint32_t)G;
+    int nslots = 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t j = nbase + u * kWG + threadIdx.x;
-            nxt[u] = (j < pair_hi) ? fv.rec4[j] : none;
+    for (int m = 0; m < kModes; ++m) c.base[m] = ((w.mode_mask >> m) & 1u) ? (nslots++) * mp.rows * G : -1;
+    c.fmin = mp.filt_on ? (uint32_t)mp.filt_min : 0u;
+    c.frange = (mp.filt_on && mp.filt_max != -1) ? (uint32_t)(mp.filt_max - mp.filt_min) : 0xffffu - c.fmin;
+    c.tab_lo = tab_lo;
+    c.tab_n = (uint32_t)tab_n;
+    const int nbins = nslots * mp.rows * G;
+    uint32_t *ltab = smem;                      // packed offset tables first (variable / stratified rules) ...
+    uint32_t *bins = smem + ((tab_n + 3) & ~3); // ... then the bins
+    for (int i = threadIdx.x; i < nbins; i += kWG) bins[i] = 0;
+    if (KIND >= 3) {
+        const int32_t PC_GLOBAL *fw = (const int32_t PC_GLOBAL *)mp.fw, *rc = (const int32_t PC_GLOBAL *)mp.rc;
+        for (int i = threadIdx.x; i < tab_n; i += kWG) {
+            const int f = fw[tab_lo + i], r = rc[tab_lo + i];
+            ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
+    }
+    __syncthreads();
+
+    // ---- the packed record stream: no dependent global loads in this loop
+    uint32_t dbg_acc = 0;
+    for (int base = 0; base < npairs; base += kWG * U) {
+        u32x4 nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t i0 = (base + u * kWG + threadIdx.x) * 2;
-            hist_rec<KIND, AGG>(mp, cur[u].x, cur[u].y, i0 >= w.lo && i0 < w.hi, sbase, tl.win_start, (uint32_t)G, bins, lane);
-            hist_rec<KIND, AGG>(mp, cur[u].z, cur[u].w, i0 + 1 >= w.lo && i0 + 1 < w.hi, sbase, tl.win_start, (uint32_t)G, bins, lane);
+            const int j = base + kWG * U + u * kWG + (int)threadIdx.x;
+            nxt[u] = (j < npairs) ? src[j] : none;
+        }
+        if (dbg & 1) { // DEBUG: stream only
+#pragma unroll
+            for (int u = 0; u < U; ++u) dbg_acc ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
+        } else
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base + u * kWG + (int)threadIdx.x;
+            const bool in = j < npairs;
+            hist_rec<KIND>(mp, c, ltab, cur[u].x, cur[u].y, in & !((j == 0) & (lo_odd != 0)), bins);
+            hist_rec<KIND>(mp, c, ltab, cur[u].z, cur[u].w, in & !((j == npairs - 1) & (hi_odd != 0)), bins);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
@@ -429,33 +545,36 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Tile *__restrict__ til
     for (int64_t base = w.glo; base < w.ghi; base += kWG) {
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.ghi;
-        const u32x4 g = in ? fv.gap_rec[j] : none;
-        const uint32_t meta = g.y, fl = rec_flags(meta);
-        const int L = rec_len(meta), nb = rec_nblk(meta);
-        const bool ok = in && !(fl & kFlagExcluded) && size_ok(mp, L);
+        const u32x4 g = base == w.glo ? gfirst : (in ? fv.gap_rec[j] : none);
+        const uint32_t meta = g.y, hi = meta >> 16;
+        const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
+        const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
         i32x2 b0 = {0, 1}, b1 = {0, 1};
         if (in) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
-        int row_f, row_r;
-        const int kf = map_kleft<KIND>(mp, L, false, row_f);
-        const int kr = map_kleft<KIND>(mp, L, true, row_r);
-        const int32_t pf = (ok && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
-        const int32_t pr = (ok && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
-        hist_bin<KIND, AGG>(mp, ok, fl & kFlagReverse, kf, kr, pf, pr, row_f, row_r, sbase, tl.win_start, (uint32_t)G, bins, lane);
+        int kf, kr;
+        uint32_t rowoff;
+        map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
+        const int32_t pf = (valid && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
+        const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
+        hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
     }
     __syncthreads();
+    if (dbg_acc == 0x12345u) hist[0] = dbg_acc;
+    if (dbg & 2) return; // DEBUG: no flush
 
+    // ---- flush: island pieces of the window -> compact histogram
     const bool single = tile_items[w.tile] == 1u;
-    for (uint32_t pi = tl.piece_begin; pi < tl.piece_end; ++pi) {
+    for (uint32_t pi = w.piece_begin; pi < w.piece_end; ++pi) {
         const Piece pc_ = pieces[pi];
-        const int rel = pc_.start - tl.win_start;
+        const int rel = pc_.start - w.win_start;
         for (int r = 0; r < mp.rows; ++r) {
-            const uint32_t *src = bins + sbase[pc_.mode] + r * G + rel;
+            const uint32_t *srcb = bins + c.base[pc_.mode] + r * G + rel;
             uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
             if (single) {
-                for (int i = threadIdx.x; i < pc_.len; i += kWG) dst[i] = src[i];
+                for (int i = threadIdx.x; i < pc_.len; i += kWG) dst[i] = srcb[i];
             } else {
                 for (int i = threadIdx.x; i < pc_.len; i += kWG) {
-                    uint32_t v = src[i];
+                    uint32_t v = srcb[i];
                     if (v) atomicAdd(&dst[i], v);
                 }
             }

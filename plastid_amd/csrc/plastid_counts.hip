@@ -80,6 +80,8 @@ struct StagedFile {
     int64_t ngap = 0;
     DevBuf<uint4> gap_rec;
     DevBuf<int64_t> gap_tid_bounds;
+    DevBuf<uint32_t> lin_tab, glin_tab;
+    DevBuf<int64_t> lin_off;
     std::vector<int64_t> len_hist; // records per aligned length (host), for cheap warn pre-checks
     FileView view() const {
         FileView v;
@@ -87,6 +89,7 @@ struct StagedFile {
         v.long_idx = long_idx.p; v.long_tid = long_tid.p; v.long_pmax = long_pmax.p;
         v.long_tid_bounds = long_tid_bounds.p; v.n = n; v.nlong = nlong;
         v.gap_rec = gap_rec.p; v.gap_tid_bounds = gap_tid_bounds.p; v.ngap = ngap;
+        v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.lin_off = lin_off.p;
         return v;
     }
 };
@@ -382,6 +385,36 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     sf->nlong = (int64_t)long_idx.size();
     sf->ngap = (int64_t)gap_rec.size();
 
+    // ---- linear index: first record at/after every 2^kLinShift-position bucket of each contig
+    std::vector<int64_t> lin_off((size_t)ntid + 1, 0);
+    for (int t = 0; t < ntid; ++t) {
+        const int64_t b = tid_bounds[(size_t)t], en = tid_bounds[(size_t)t + 1];
+        const int64_t nb = en > b ? ((int64_t)pos[en - 1] >> kLinShift) + 1 : 0;
+        lin_off[(size_t)t + 1] = lin_off[(size_t)t] + nb + 1;
+    }
+    std::vector<uint32_t> lin_tab((size_t)lin_off[(size_t)ntid]), glin_tab((size_t)lin_off[(size_t)ntid]);
+    for (int t = 0; t < ntid; ++t) {
+        const int64_t l0 = lin_off[(size_t)t], nb = lin_off[(size_t)t + 1] - l0 - 1;
+        {
+            const int64_t b = tid_bounds[(size_t)t], en = tid_bounds[(size_t)t + 1];
+            int64_t i = b;
+            for (int64_t k = 0; k <= nb; ++k) {
+                const int64_t edge = k << kLinShift;
+                while (i < en && k < nb && (int64_t)pos[i] < edge) ++i;
+                lin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? i : en);
+            }
+        }
+        {
+            const int64_t b = gap_bounds[(size_t)t], en = gap_bounds[(size_t)t + 1];
+            int64_t i = b;
+            for (int64_t k = 0; k <= nb; ++k) {
+                const int64_t edge = k << kLinShift;
+                while (i < en && k < nb && (int64_t)(int32_t)gap_rec[(size_t)i].x < edge) ++i;
+                glin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? i : en);
+            }
+        }
+    }
+
     // ---- bulk stage to HBM
     int rc = sf->rec.upload(rec, e->stream);
     if (rc == PC_OK && nrun > 0) {
@@ -398,6 +431,9 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc == PC_OK) rc = sf->long_tid_bounds.upload(long_bounds, e->stream);
     if (rc == PC_OK) rc = sf->gap_rec.upload(gap_rec, e->stream);
     if (rc == PC_OK) rc = sf->gap_tid_bounds.upload(gap_bounds, e->stream);
+    if (rc == PC_OK) rc = sf->lin_tab.upload(lin_tab, e->stream);
+    if (rc == PC_OK) rc = sf->glin_tab.upload(glin_tab, e->stream);
+    if (rc == PC_OK) rc = sf->lin_off.upload(lin_off, e->stream);
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
     if (rc != PC_OK) {
         delete sf;
@@ -548,9 +584,9 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     if (nmodes == 0) nmodes = 1;
     // window size: LDS budget of 64 KiB for bins (uint32 per mode x row x position)
     {
-        int64_t g = (64 * 1024) / (4LL * nmodes * rows);
+        int64_t g = (48 * 1024) / (4LL * nmodes * rows);
         int G = 256;
-        int gmax = 4096;
+        int gmax = 2048;
         if (const char *env = getenv("PC_TILE_G")) gmax = std::max(256, atoi(env)); // tuning knob
         while (G * 2 <= g && G * 2 <= gmax) G *= 2;
         if ((int64_t)4 * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
@@ -717,25 +753,35 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (rc != PC_OK) return rc;
             HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
             HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
-            const int64_t nthreads = (int64_t)ntiles * nfiles;
-            hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kWG - 1) / kWG)), dim3(kWG), 0, st, p->d_tiles.p, ntiles,
+            const int64_t nthreads = (int64_t)ntiles * nfiles * kWave; // one wave per (tile, file)
+            hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
                                e->d_files.p, nfiles, G, W, R, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64);
             HIP_TRY(hipEventRecord(e->ev[2], st));
-            const size_t lds = (size_t)p->max_slots * p->rows * G * sizeof(uint32_t);
-#define PC_LAUNCH_HIST(K, A)                                                                                          \
-    hipLaunchKernelGGL((k_hist_point<K, A>), dim3((unsigned)cap64), dim3(kWG), lds, st, p->d_tiles.p, p->d_pieces.p,    \
-                       e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, (uint32_t *)p->d_hist.p, p->npos)
-            bool agg = false;
-            if (const char *env = getenv("PC_HIST_AGG")) agg = atoi(env) != 0; // tuning knob
-            switch (e->kind * 2 + (agg ? 1 : 0)) {
-            case PC_MAP_FIVE * 2: PC_LAUNCH_HIST(0, false); break;
-            case PC_MAP_FIVE * 2 + 1: PC_LAUNCH_HIST(0, true); break;
-            case PC_MAP_THREE * 2: PC_LAUNCH_HIST(1, false); break;
-            case PC_MAP_THREE * 2 + 1: PC_LAUNCH_HIST(1, true); break;
-            case PC_MAP_VAR5 * 2: PC_LAUNCH_HIST(3, false); break;
-            case PC_MAP_VAR5 * 2 + 1: PC_LAUNCH_HIST(3, true); break;
-            case PC_MAP_STRAT5 * 2: PC_LAUNCH_HIST(4, false); break;
-            default: PC_LAUNCH_HIST(4, true); break;
+            // offset tables are staged in LDS for the aligned lengths that occur in the data
+            int tab_lo = 0, tab_n = 0;
+            if (e->kind == PC_MAP_VAR5 || e->kind == PC_MAP_STRAT5) {
+                int lmin = e->table_len, lmax = -1;
+                for (auto *f : e->files)
+                    for (int L = 0; L < e->table_len; ++L)
+                        if (f->len_hist[(size_t)L]) { lmin = std::min(lmin, L); lmax = std::max(lmax, L); }
+                if (lmax >= lmin) { tab_lo = lmin; tab_n = lmax - lmin + 1; }
+            }
+            const size_t lds = ((size_t)p->max_slots * p->rows * G + (size_t)((tab_n + 3) & ~3)) * sizeof(uint32_t);
+            if (lds > 64 * 1024) return fail(PC_ERR_ARG, "pc_count: LDS budget exceeded (%zu bytes)", lds);
+#define PC_LAUNCH_HIST(K)                                                                                             \
+    hipLaunchKernelGGL((k_hist_point<K>), dim3(grid), dim3(kWG), lds, st, p->d_pieces.p, fv0, fv1, e->d_files.p,        \
+                       e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, tab_lo, tab_n, (uint32_t *)p->d_hist.p,   \
+                       p->npos, dbg)
+            const FileView fv0 = e->files[0]->view();
+            const FileView fv1 = nfiles > 1 ? e->files[1]->view() : fv0;
+            const unsigned grid = (unsigned)cap64;
+            int dbg = 0;
+            if (const char *env = getenv("PC_DEBUG_HIST")) dbg = atoi(env); // profiling experiments only
+            switch (e->kind) {
+            case PC_MAP_FIVE: PC_LAUNCH_HIST(0); break;
+            case PC_MAP_THREE: PC_LAUNCH_HIST(1); break;
+            case PC_MAP_VAR5: PC_LAUNCH_HIST(3); break;
+            default: PC_LAUNCH_HIST(4); break;
             }
 #undef PC_LAUNCH_HIST
             HIP_TRY(hipEventRecord(e->ev[3], st));

@@ -8,12 +8,15 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int U>
+template <int MODE, int U, int SCRAMBLE = 0>
 __global__ __launch_bounds__(256) void probe(const u32x4* __restrict__ rec4, int64_t npairs, int64_t chunk_pairs, int G, unsigned* out) {
     extern __shared__ unsigned bins[];
     for (int i = threadIdx.x; i < 2 * G; i += 256) bins[i] = 0;
     __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * chunk_pairs;
+    const unsigned nchunks = (unsigned)((npairs + chunk_pairs - 1) / chunk_pairs);
+    if (SCRAMBLE && blockIdx.x >= nchunks) return;
+    const unsigned cid = SCRAMBLE ? (unsigned)(((unsigned long long)blockIdx.x * 2654435761ull) % nchunks) : blockIdx.x;
+    const int64_t lo = (int64_t)cid * chunk_pairs;
     const int64_t hi = lo + chunk_pairs < npairs ? lo + chunk_pairs : npairs;
     unsigned acc = 0;
     const unsigned win = rec4[lo < npairs ? lo : 0].x;
@@ -68,6 +71,9 @@ int main(int argc, char** argv) {
             run("stream + ds_write U=4", probe<2, 4>, chunk, G);
         }
     }
+    run("scrambled stream only", probe<0, 4, 1>, 16384, 2048);
+    run("scrambled stream+ds_add", probe<1, 4, 1>, 16384, 2048);
+    run("scrambled stream only 8k", probe<0, 4, 1>, 8192, 2048);
     run("stream only U=8", probe<0, 8>, 16384, 2048);
     run("stream + ds_add U=8", probe<1, 8>, 16384, 2048);
     run("stream only U=2", probe<0, 2>, 16384, 2048);
