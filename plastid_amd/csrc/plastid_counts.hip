@@ -586,7 +586,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     {
         int64_t g = (48 * 1024) / (4LL * nmodes * rows);
         int G = 256;
-        int gmax = 2048;
+        int gmax = 4096;
         if (const char *env = getenv("PC_TILE_G")) gmax = std::max(256, atoi(env)); // tuning knob
         while (G * 2 <= g && G * 2 <= gmax) G *= 2;
         if ((int64_t)4 * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
