@@ -106,9 +106,8 @@ def main():
     ap.add_argument("--out-dtype", default="int64", choices=["int64", "float64"])
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from plastid_amd import multigpu
+    rank, local_rank, world = multigpu.env_rank()
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
@@ -146,10 +145,8 @@ def main():
     # ---------------------------------------------------------------- GPU
     import torch
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    multigpu.init("nccl", device=torch.device("cuda", local_rank))  # RCCL
     from plastid_amd.engine import Engine
     eng = Engine(local_rank)
     t0 = time.perf_counter()
@@ -161,9 +158,7 @@ def main():
                     p["out_elems"], rows)
     plan_s = time.perf_counter() - t0
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = multigpu.barrier
 
     for _ in range(max(args.warmup, 1)):
         plan.launch(out_dtype)
@@ -193,18 +188,13 @@ def main():
     eng.sync()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = multigpu.max_over_ranks(time.perf_counter() - t0, device="cuda")
 
     # summary totals: the only collective (RCCL all-reduce over xGMI)
-    tot = torch.tensor([int(reads.n), int(total_counts) if not center else 0, int(p["out_elems"])],
-                       dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    n_records_all, counts_all, positions_all = [int(x) for x in tot.tolist()]
+    n_records_all, counts_all, positions_all = multigpu.allreduce_int_totals(
+        [int(reads.n), int(total_counts) if not center else 0, int(p["out_elems"])], device="cuda")
+    if center:
+        counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device="cuda")[0]
 
     # ---------------------------------------------------------------- per-kernel timing (HIP events on the engine's stream)
     phases = {"total": 0.0, "worklist": 0.0, "hist": 0.0, "long": 0.0, "gather": 0.0, "zero": 0.0}
