@@ -16,7 +16,7 @@
 // Kernels (one reference function each; reference = plastid/genomics/map_factories.pyx)
 //   k_tile_ranges   fetch emulation: record range of every genome tile    (genome_array.py:800-809)
 //   k_hist_point    FivePrime/ThreePrime/Variable/Stratified              (:308-367,:407-466,:585-650,:724-780)
-//   k_long_point    same rules for the few long-span (spliced) reads
+//   k_gather_split  lays out tiles that were split into several work items
 //   k_center        CenterMapFactory, ordered float64 replay              (:200-265)
 //   k_gather        SegmentChain.get_counts layout + normalisation        (roitools.pyx:3259-3271,
 //                                                                          genome_array.py:826-830)
@@ -52,6 +52,7 @@ struct FileView {
     const int32_t *long_tid;
     const int32_t *long_pmax;       // prefix max of ref_end within a tid
     const int64_t *long_tid_bounds; // ntid+1
+    const uint4 *long_rec;          // long-span records {pos, meta, blk_off, rec_idx}, record order
     const uint4 *gap_rec;           // short-span gapped records {pos, meta, blk_off, rec_idx}, record order
     const int64_t *gap_tid_bounds;  // ntid+1
     // linear index (cf. the BAI linear index): first record at or after every kLinShift-bit
@@ -82,6 +83,7 @@ struct GFile {
     const int32_t PC_GLOBAL *long_tid;
     const int32_t PC_GLOBAL *long_pmax;
     const int64_t PC_GLOBAL *long_tid_bounds;
+    const u32x4 PC_GLOBAL *long_rec;
     const u32x4 PC_GLOBAL *gap_rec;
     const int64_t PC_GLOBAL *gap_tid_bounds;
     const uint32_t PC_GLOBAL *lin_tab;
@@ -103,6 +105,7 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.long_tid = (const int32_t PC_GLOBAL *)v.long_tid;
     g.long_pmax = (const int32_t PC_GLOBAL *)v.long_pmax;
     g.long_tid_bounds = (const int64_t PC_GLOBAL *)v.long_tid_bounds;
+    g.long_rec = (const u32x4 PC_GLOBAL *)v.long_rec;
     g.gap_rec = (const u32x4 PC_GLOBAL *)v.gap_rec;
     g.gap_tid_bounds = (const int64_t PC_GLOBAL *)v.gap_tid_bounds;
     g.lin_tab = (const uint32_t PC_GLOBAL *)v.lin_tab;
@@ -128,10 +131,24 @@ struct MapParams {
 struct Tile {
     int32_t tid;
     int32_t win_start;
-    uint32_t piece_begin;
+    uint32_t piece_begin; // island pieces (histogram coordinates)
     uint32_t piece_end;
     uint32_t mode_mask;
+    uint32_t op_begin;    // output pieces (segment slices in the caller's layout)
+    uint32_t op_end;
     uint32_t pad;
+};
+
+// A queried segment cut at the tile grid, with its place in the caller's output buffer:
+// position start+i, row r  ->  out[out_off + step*i + r*row_stride]
+struct OutPiece {
+    int64_t out_off;
+    int64_t row_stride;
+    int64_t hist_off; // same positions in the compact histogram (used when a tile is split)
+    int32_t start;
+    int32_t len;
+    int32_t mode;
+    int32_t step;
 };
 
 struct Piece {
@@ -145,11 +162,16 @@ struct Piece {
 struct WorkItem {
     int64_t lo, hi;   // record range of the packed stream
     int64_t glo, ghi; // range of the gapped-record list (first work item of a tile only)
+    int64_t llo, lhi; // candidate range of the long-span list (first work item only)
     uint32_t tile;
     uint32_t file;
     int32_t win_start; // copied from the tile: saves the histogram kernel a dependent load
     uint32_t mode_mask;
     uint32_t piece_begin, piece_end;
+    uint32_t op_begin, op_end;
+    int32_t sub_lo, sub_hi; // the part of the window this item owns (window-relative positions)
+    uint32_t merge;         // 1: several items share the window (pile-up / several files) -> merge via hist
+    uint32_t pad;
 };
 
 
@@ -302,7 +324,22 @@ __device__ __forceinline__ int64_t indexed_lower_bound(const uint32_t PC_GLOBAL 
 }
 
 constexpr int kRangesWG = 1024; // 16 waves = 16 (tile, file) pairs per workgroup
+constexpr int kMaxSub = 32;     // a dense window is cut into up to 32 sub-windows (>= 128 positions each)
 
+// linear-index lookup: first record at/after the bucket holding `key` (conservative: rounds down)
+__device__ __forceinline__ int64_t lin_floor(const uint32_t PC_GLOBAL *lin, int64_t lin0, int64_t nb, int64_t key) {
+    int64_t b = key <= 0 ? 0 : (key >> kLinShift);
+    if (b > nb) b = nb;
+    return lin[lin0 + b];
+}
+
+// One WAVE per (tile, file): which records the tile must scan (fetch emulation,
+// genome_array.py:800-809).  Window edges are multiples of the 128-nt linear-index bucket, so
+// the upper ends are exact table lookups and the lower ends are rounded down to a bucket (a
+// few extra records are streamed; they fall outside the bins).  A dense window is cut into
+// sub-windows, each an independent work item that owns its slice of the output -- no merging.
+// Only when a sub-window alone holds a pile-up (> 4R records), or several files feed one
+// window, the window falls back to record slices merged through the compact histogram.
 __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
                                                            const FileView *__restrict__ files, int nfiles,
                                                            int G, int W, int64_t R, WorkItem *work,
@@ -315,26 +352,51 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     const bool live = idx < (int64_t)ntiles * nfiles;
     int t = 0, f = 0;
     Tile tl = {};
-    int64_t lo = 0, hi = 0, glo = 0, ghi = 0;
+    int64_t lo = 0, hi = 0, glo = 0, ghi = 0, llo = 0, lhi = 0; // per lane: this lane's sub-window
+    int64_t wlo = 0, whi = 0, wglo = 0, wghi = 0;                // whole window
     uint32_t items = 0;
+    int S = 1;
+    bool merge = false;
     if (live) {
         t = (int)(idx / nfiles);
         f = (int)(idx % nfiles);
         tl = tiles[t];
         const GFile fv = gfile(files[f]);
-        const int64_t key_lo = (int64_t)tl.win_start - W + 1, key_hi = (int64_t)tl.win_start + G;
+        const int64_t ws = tl.win_start;
         const int64_t l0 = fv.lin_off[tl.tid], nb = fv.lin_off[tl.tid + 1] - l0 - 1;
-        const uint32_t PC_GLOBAL *rpos = (const uint32_t PC_GLOBAL *)fv.rec;
-        lo = indexed_lower_bound<2>(rpos, fv.lin_tab, l0, nb, key_lo, lane);
-        hi = indexed_lower_bound<2>(rpos, fv.lin_tab, l0, nb, key_hi, lane);
+        wlo = lin_floor(fv.lin_tab, l0, nb, ws - W + 1);
+        whi = lin_floor(fv.lin_tab, l0, nb, ws + G);
         if (fv.ngap) {
-            const uint32_t PC_GLOBAL *gpos = (const uint32_t PC_GLOBAL *)fv.gap_rec;
-            glo = indexed_lower_bound<4>(gpos, fv.glin_tab, l0, nb, key_lo, lane);
-            ghi = indexed_lower_bound<4>(gpos, fv.glin_tab, l0, nb, key_hi, lane);
+            wglo = lin_floor(fv.glin_tab, l0, nb, ws - W + 1);
+            wghi = lin_floor(fv.glin_tab, l0, nb, ws + G);
         }
-        const int64_t n = hi - lo;
-        if (n > 0) items = (uint32_t)((n + R - 1) / R);
-        else if (ghi > glo) items = 1u;
+        if (fv.nlong) {
+            // long-span reads that can reach the window: they start before its end, and the
+            // running maximum of the ends (monotone) has passed its start
+            const int64_t q0 = fv.long_tid_bounds[tl.tid], q1 = fv.long_tid_bounds[tl.tid + 1];
+            lhi = wave_lower_bound<4>((const uint32_t PC_GLOBAL *)fv.long_rec, q0, q1, ws + G, lane);
+            llo = wave_lower_bound<1>((const uint32_t PC_GLOBAL *)fv.long_pmax, q0, lhi, ws + 1, lane);
+        }
+        const int64_t n = whi - wlo;
+        merge = nfiles > 1;
+        if (!merge) {
+            while (S < kMaxSub && (G / (S * 2)) >= (1 << kLinShift) && n > R * S) S <<= 1;
+            const int sub = G / S;
+            const int k = lane < S ? lane : S - 1;
+            const int64_t a = ws + (int64_t)k * sub;
+            lo = lin_floor(fv.lin_tab, l0, nb, a - W + 1);
+            hi = lin_floor(fv.lin_tab, l0, nb, a + sub);
+            if (fv.ngap) {
+                glo = lin_floor(fv.glin_tab, l0, nb, a - W + 1);
+                ghi = lin_floor(fv.glin_tab, l0, nb, a + sub);
+            }
+            merge = __ballot(lane < S && hi - lo > 4 * R) != 0ull; // a pile-up inside one sub-window
+            items = (uint32_t)S;
+        }
+        if (merge) {
+            S = 1;
+            items = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || f == 0) ? 1u : 0u);
+        }
     }
     // one returning atomic per workgroup (a single hot counter saturates near 90 atomics/us)
     if (lane == 0) s_items[wv] = items;
@@ -347,14 +409,29 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     __syncthreads();
     if (!items) return;
     const uint32_t base = s_base + s_items[wv];
-    if (lane == 0) atomicAdd(&tile_items[t], items);
+    if (lane == 0 && merge) atomicAdd(&tile_items[t], items); // > 0 marks the tile for k_gather_split
     for (uint32_t k = lane; k < items; k += 64) {
         if (base + k >= work_cap) break; // cannot happen (capacity is an upper bound); defensive
         WorkItem w;
-        w.lo = lo + (int64_t)k * R;
-        w.hi = (w.lo + R < hi) ? w.lo + R : hi;
-        w.glo = k == 0 ? glo : 0;
-        w.ghi = k == 0 ? ghi : 0;
+        if (merge) {
+            w.lo = wlo + (int64_t)k * R;
+            w.hi = (w.lo + R < whi) ? w.lo + R : whi;
+            w.glo = k == 0 ? wglo : 0;
+            w.ghi = k == 0 ? wghi : 0;
+            w.llo = k == 0 ? llo : 0;
+            w.lhi = k == 0 ? lhi : 0;
+            w.sub_lo = 0;
+            w.sub_hi = G;
+        } else {
+            w.lo = lo; w.hi = hi; w.glo = glo; w.ghi = ghi;
+            w.llo = llo; w.lhi = lhi; // every sub-window checks the (few) long-span candidates
+            w.sub_lo = (int32_t)k * (G / S);
+            w.sub_hi = w.sub_lo + G / S;
+        }
+        w.merge = merge ? 1u : 0u;
+        w.pad = 0;
+        w.op_begin = tl.op_begin;
+        w.op_end = tl.op_end;
         w.tile = (uint32_t)t;
         w.file = (uint32_t)f;
         w.win_start = tl.win_start;
@@ -430,7 +507,7 @@ __device__ __forceinline__ void hist_bin(const HistCfg &c, bool valid, bool rev,
 }
 
 // ungapped record of the packed stream (gapped ones come from the gapped list, long-span
-// ones from k_long_point)
+// ones from the long-span list)
 template <int KIND>
 __device__ __forceinline__ void hist_rec(const MapParams &mp, const HistCfg &c, const uint32_t *ltab, uint32_t rx,
                                          uint32_t meta, bool inrange, uint32_t *bins) {
@@ -463,14 +540,28 @@ __device__ __forceinline__ int32_t walk_from(const GFile &fv, uint32_t off, int 
 // One workgroup per work item.  The work-item descriptor carries the tile's window and
 // piece range, and up to two staged files travel as kernel arguments, so the first record
 // batch is requested after a single dependent load; the LDS set-up runs under that latency.
-template <int KIND>
-__global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pieces, FileView file0, FileView file1,
-                                                    const FileView *__restrict__ files,
+// OUTMODE: 0 = int64 counts, 1 = float64 counts, 2 = float64 reads-per-million
+// (count / sum * 1e6 in that order, genome_array.py:826-827)
+template <int OUTMODE> struct OutT_ { typedef int64_t type; };
+template <> struct OutT_<1> { typedef double type; };
+template <> struct OutT_<2> { typedef double type; };
+template <int OUTMODE>
+__device__ __forceinline__ typename OutT_<OUTMODE>::type out_conv(uint32_t v, double norm_sum) {
+    if (OUTMODE == 0) return (typename OutT_<OUTMODE>::type)v;
+    if (OUTMODE == 1) return (typename OutT_<OUTMODE>::type)(double)v;
+    return (typename OutT_<OUTMODE>::type)((double)v / norm_sum * 1e6);
+}
+
+template <int KIND, int OUTMODE>
+__global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pieces,
+                                                    const OutPiece *__restrict__ opieces, FileView file0,
+                                                    FileView file1, const FileView *__restrict__ files,
                                                     const WorkItem *__restrict__ work,
                                                     const uint32_t *__restrict__ nwork,
                                                     const uint32_t *__restrict__ tile_items, MapParams mp,
                                                     int G, int tab_lo, int tab_n, uint32_t *hist,
-                                                    int64_t hist_row_stride, int dbg) {
+                                                    int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
+                                                    double norm_sum, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const WorkItem w = work[blockIdx.x];
     if (blockIdx.x >= *nwork) return;
@@ -558,23 +649,55 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
         const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
         hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
     }
+
+    // ---- long-span (spliced) reads that can reach this window: same binning, every run walked
+    for (int64_t base = w.llo; base < w.lhi; base += kWG) {
+        const int64_t j = base + threadIdx.x;
+        const bool in = j < w.lhi;
+        const u32x4 g = in ? fv.long_rec[j] : none;
+        const uint32_t meta = g.y, hi = meta >> 16;
+        const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
+        const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
+        i32x2 b0 = {0, 1}, b1 = {0, 1};
+        if (in) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
+        int kf, kr;
+        uint32_t rowoff;
+        map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
+        const int32_t pf = (valid && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
+        const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
+        hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
+    }
     __syncthreads();
     if (dbg_acc == 0x12345u) hist[0] = dbg_acc;
     if (dbg & 2) return; // DEBUG: no flush
 
-    // ---- flush: island pieces of the window -> compact histogram
-    const bool single = tile_items[w.tile] == 1u;
-    for (uint32_t pi = w.piece_begin; pi < w.piece_end; ++pi) {
-        const Piece pc_ = pieces[pi];
-        const int rel = pc_.start - w.win_start;
-        for (int r = 0; r < mp.rows; ++r) {
-            const uint32_t *srcb = bins + c.base[pc_.mode] + r * G + rel;
-            uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
-            if (single) {
-                for (int i = threadIdx.x; i < pc_.len; i += kWG) dst[i] = srcb[i];
-            } else {
+    if (!w.merge) {
+        // ---- this workgroup owns [sub_lo, sub_hi) of the window and its bins are complete:
+        // write every queried segment slice straight into the caller's layout (chain offset,
+        // 5'->3' reversal, int64/float64, normalisation) -- SegmentChain.get_counts,
+        // roitools.pyx:3259-3271
+        for (uint32_t oi = w.op_begin; oi < w.op_end; ++oi) {
+            const OutPiece o = opieces[oi];
+            const int rel = o.start - w.win_start;
+            const int i0 = w.sub_lo > rel ? w.sub_lo - rel : 0;
+            const int i1 = (w.sub_hi - rel) < o.len ? (w.sub_hi - rel) : o.len;
+            for (int r = 0; r < mp.rows; ++r) {
+                const uint32_t *srcb = bins + c.base[o.mode] + r * G + rel;
+                typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
+                for (int i = i0 + (int)threadIdx.x; i < i1; i += kWG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(srcb[i], norm_sum);
+            }
+        }
+    } else {
+        // ---- split tile (pile-up or several files): merge into the zeroed compact histogram;
+        // k_gather_split lays it out afterwards
+        for (uint32_t pi = w.piece_begin; pi < w.piece_end; ++pi) {
+            const Piece pc_ = pieces[pi];
+            const int rel = pc_.start - w.win_start;
+            for (int r = 0; r < mp.rows; ++r) {
+                const uint32_t *srcb = bins + c.base[pc_.mode] + r * G + rel;
+                uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
                 for (int i = threadIdx.x; i < pc_.len; i += kWG) {
-                    uint32_t v = srcb[i];
+                    const uint32_t v = srcb[i];
                     if (v) atomicAdd(&dst[i], v);
                 }
             }
@@ -582,55 +705,32 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
     }
 }
 
-// ---------------------------------------------------------------- k_long_point
-// Long-span (spliced) reads are skipped by the window scan; one thread per such
-// read computes its mapped position, finds the island piece holding it and adds
-// with a global atomic.
-__device__ __forceinline__ int64_t find_tile(const Tile *tiles, int ntiles, int32_t tid, int32_t win_start) {
-    int64_t lo = 0, hi = ntiles;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        Tile t = tiles[mid];
-        bool less = t.tid < tid || (t.tid == tid && t.win_start < win_start);
-        if (less) lo = mid + 1; else hi = mid;
+// ---------------------------------------------------------------- k_gather_split
+// Split tiles only: lay out their segment slices from the merged histogram, then clear the
+// tile's histogram region so the next call starts from zeros again.
+template <int OUTMODE>
+__global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ tiles,
+                                                      const Piece *__restrict__ pieces,
+                                                      const OutPiece *__restrict__ opieces,
+                                                      const uint32_t *__restrict__ tile_items, int rows,
+                                                      uint32_t *hist, int64_t hist_row_stride,
+                                                      typename OutT_<OUTMODE>::type *out, double norm_sum) {
+    if (tile_items[blockIdx.x] == 0u) return; // only windows that were merged through the histogram
+    const Tile tl = tiles[blockIdx.x];
+    for (uint32_t oi = tl.op_begin; oi < tl.op_end; ++oi) {
+        const OutPiece o = opieces[oi];
+        for (int r = 0; r < rows; ++r) {
+            const uint32_t *src = hist + (size_t)r * hist_row_stride + o.hist_off;
+            typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
+            for (int i = threadIdx.x; i < o.len; i += kWG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(src[i], norm_sum);
+        }
     }
-    if (lo < ntiles && tiles[lo].tid == tid && tiles[lo].win_start == win_start) return lo;
-    return -1;
-}
-
-__global__ __launch_bounds__(kWG) void k_long_point(const Tile *__restrict__ tiles, int ntiles,
-                                                    const Piece *__restrict__ pieces, FileView fview,
-                                                    MapParams mp, int G, uint32_t plan_modes,
-                                                    uint32_t *hist, int64_t hist_row_stride) {
-    const GFile fv = gfile(fview);
-    int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
-    if (j >= fv.nlong) return;
-    const int64_t i = fv.long_idx[j];
-    const u32x2 r = fv.rec[i];
-    const uint32_t meta = r.y;
-    const uint32_t fl = rec_flags(meta);
-    if (fl & kFlagExcluded) return;
-    const int L = rec_len(meta);
-    if (!size_ok(mp, L)) return;
-    const bool rev = fl & kFlagReverse;
-    const int nb = rec_nblk(meta);
-    const int32_t tid = fv.long_tid[j];
-    for (int m = 0; m < kModes; ++m) {
-        if (!((plan_modes >> m) & 1u) || !strand_ok(m, rev)) continue;
-        int row;
-        const int k = map_kleft_dyn(mp, L, m == 1 || m == 3, row);
-        if (k < 0) continue;
-        const int32_t p = nb >= 2 ? walk_runs(fv, i, nb, k) : (int32_t)r.x + k;
-        const int64_t t = find_tile(tiles, ntiles, tid, (int32_t)(((int64_t)p / G) * G));
-        if (t < 0) continue;
-        const Tile tl = tiles[t];
-        if (!((tl.mode_mask >> m) & 1u)) continue;
-        for (uint32_t pi = tl.piece_begin; pi < tl.piece_end; ++pi) {
-            const Piece pc_ = pieces[pi];
-            if (pc_.mode == m && p >= pc_.start && p < pc_.start + pc_.len) {
-                atomicAdd(&hist[(size_t)row * hist_row_stride + pc_.hist_off + (p - pc_.start)], 1u);
-                break;
-            }
+    __syncthreads();
+    for (uint32_t pi = tl.piece_begin; pi < tl.piece_end; ++pi) {
+        const Piece pc_ = pieces[pi];
+        for (int r = 0; r < rows; ++r) {
+            uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
+            for (int i = threadIdx.x; i < pc_.len; i += kWG) dst[i] = 0u;
         }
     }
 }

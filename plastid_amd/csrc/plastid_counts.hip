@@ -77,6 +77,7 @@ struct StagedFile {
     DevBuf<int32_t> long_tid;
     DevBuf<int32_t> long_pmax;
     DevBuf<int64_t> long_tid_bounds;
+    DevBuf<uint4> long_rec;
     int64_t ngap = 0;
     DevBuf<uint4> gap_rec;
     DevBuf<int64_t> gap_tid_bounds;
@@ -87,7 +88,7 @@ struct StagedFile {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
         v.long_idx = long_idx.p; v.long_tid = long_tid.p; v.long_pmax = long_pmax.p;
-        v.long_tid_bounds = long_tid_bounds.p; v.n = n; v.nlong = nlong;
+        v.long_tid_bounds = long_tid_bounds.p; v.long_rec = long_rec.p; v.n = n; v.nlong = nlong;
         v.gap_rec = gap_rec.p; v.gap_tid_bounds = gap_tid_bounds.p; v.ngap = ngap;
         v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.lin_off = lin_off.p;
         return v;
@@ -145,6 +146,10 @@ struct pc_plan {
     int64_t npos = 0; // island positions (hist row length)
     std::vector<Tile> tiles;
     std::vector<Piece> pieces;
+    std::vector<OutPiece> opieces;
+    bool out_needs_zero = false; // some queried positions lie outside every tile (unknown contig, clipped)
+    bool hist_clean = false;     // compact histogram known to be all zero (point-rule invariant)
+    int hist_kind = -1;          // 0 uint32 (point rules), 1 float64 (center)
     std::vector<CenterChunk> cchunks;
     std::vector<GatherSeg> gsegs;
     std::vector<GatherChunk> gchunks;
@@ -154,6 +159,7 @@ struct pc_plan {
     std::vector<uint8_t> h_strand;
     DevBuf<Tile> d_tiles;
     DevBuf<Piece> d_pieces;
+    DevBuf<OutPiece> d_opieces;
     DevBuf<CenterChunk> d_cchunks;
     DevBuf<GatherSeg> d_gsegs;
     DevBuf<GatherChunk> d_gchunks;
@@ -349,6 +355,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     sf->nrun = nrun;
     sf->len_hist.swap(len_hist);
     std::vector<uint32_t> long_idx;
+    std::vector<uint4> long_rec;
     std::vector<int32_t> long_tid, long_pmax;
     std::vector<int64_t> long_bounds((size_t)ntid + 1, 0);
     std::vector<uint4> gap_rec;                                  // short-span gapped records
@@ -366,6 +373,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 if (tid[i] != cur_tid) { cur_tid = tid[i]; pm = 0; }
                 pm = std::max(pm, pos[i] + sp);
                 long_idx.push_back((uint32_t)i);
+                long_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, nblk[i] >= 2 ? blk_off[(size_t)i] : 0u, (uint32_t)i));
                 long_tid.push_back(tid[i]);
                 long_pmax.push_back(pm);
                 long_bounds[(size_t)tid[i] + 1] += 1;
@@ -429,6 +437,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc == PC_OK) rc = sf->long_tid.upload(long_tid, e->stream);
     if (rc == PC_OK) rc = sf->long_pmax.upload(long_pmax, e->stream);
     if (rc == PC_OK) rc = sf->long_tid_bounds.upload(long_bounds, e->stream);
+    if (rc == PC_OK) rc = sf->long_rec.upload(long_rec, e->stream);
     if (rc == PC_OK) rc = sf->gap_rec.upload(gap_rec, e->stream);
     if (rc == PC_OK) rc = sf->gap_tid_bounds.upload(gap_bounds, e->stream);
     if (rc == PC_OK) rc = sf->lin_tab.upload(lin_tab, e->stream);
@@ -456,6 +465,12 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     for (int64_t i = 0; i < n; ++i)
         rec[(size_t)i].y = (rec[(size_t)i].y & keep) | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16);
     HIP_TRY(hipMemcpy(sf->rec.p, rec.data(), (size_t)n * sizeof(uint2), hipMemcpyHostToDevice));
+    if (sf->nlong) {
+        std::vector<uint4> g((size_t)sf->nlong);
+        HIP_TRY(hipMemcpy(g.data(), sf->long_rec.p, g.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+        for (auto &x : g) x.y = rec[(size_t)x.w].y;
+        HIP_TRY(hipMemcpy(sf->long_rec.p, g.data(), g.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     if (sf->ngap) { // the gapped-record list carries a copy of the header
         std::vector<uint4> g((size_t)sf->ngap);
         HIP_TRY(hipMemcpy(g.data(), sf->gap_rec.p, g.size() * sizeof(uint4), hipMemcpyDeviceToHost));
@@ -655,6 +670,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         if (p->tiles.empty() || p->tiles.back().tid != raw[i].tid || p->tiles.back().win_start != (int32_t)raw[i].win) {
             Tile t;
             t.tid = raw[i].tid; t.win_start = (int32_t)raw[i].win; t.piece_begin = (uint32_t)i; t.piece_end = (uint32_t)i; t.mode_mask = 0; t.pad = 0;
+            t.op_begin = t.op_end = 0;
             p->tiles.push_back(t);
         }
         Tile &t = p->tiles.back();
@@ -672,7 +688,46 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     for (const Tile &t : p->tiles) max_slots = std::max(max_slots, __builtin_popcount(t.mode_mask));
     p->max_slots = max_slots;
 
-    // ---- gather work list
+    // ---- output pieces: every queried segment cut at the tile grid, in the caller's layout
+    {
+        struct RawOut { uint32_t tile; OutPiece o; };
+        std::vector<RawOut> ro;
+        for (int64_t s = 0; s < nseg; ++s) {
+            const GatherSeg &g = p->gsegs[(size_t)s];
+            if (g.len > 0 && (g.hist_off < 0 || g.clip_lo > 0 || g.clip_hi < g.len)) p->out_needs_zero = true;
+            if (g.hist_off < 0 || g.clip_hi <= g.clip_lo) continue;
+            const int m = mode_of(strand[s]);
+            const int64_t cs = start[s] + g.clip_lo, ce = start[s] + g.clip_hi;
+            for (int64_t a = cs; a < ce;) {
+                const int64_t win = (a / G) * G;
+                const int64_t b = std::min<int64_t>(ce, win + G);
+                // tile of (tid, win)
+                size_t lo = 0, hi = p->tiles.size();
+                while (lo < hi) {
+                    size_t mid = (lo + hi) / 2;
+                    const Tile &t = p->tiles[mid];
+                    if (t.tid < tid[s] || (t.tid == tid[s] && (int64_t)t.win_start < win)) lo = mid + 1; else hi = mid;
+                }
+                OutPiece o;
+                o.out_off = g.out_off + (int64_t)g.step * (a - start[s]);
+                o.row_stride = g.row_stride;
+                o.hist_off = g.hist_off + (a - cs);
+                o.start = (int32_t)a; o.len = (int32_t)(b - a); o.mode = m; o.step = g.step;
+                ro.push_back({(uint32_t)lo, o});
+                a = b;
+            }
+        }
+        std::stable_sort(ro.begin(), ro.end(), [](const RawOut &a, const RawOut &b) { return a.tile < b.tile; });
+        p->opieces.reserve(ro.size());
+        for (size_t i = 0; i < ro.size(); ++i) {
+            Tile &t = p->tiles[ro[i].tile];
+            if (t.op_end == 0 && t.op_begin == 0) t.op_begin = (uint32_t)i;
+            t.op_end = (uint32_t)i + 1;
+            p->opieces.push_back(ro[i].o);
+        }
+    }
+
+    // ---- gather work list (center rule)
     for (int64_t s = 0; s < nseg; ++s) {
         const int64_t len = p->gsegs[(size_t)s].len;
         for (int64_t c = 0; c * kGatherChunk < len; ++c) p->gchunks.push_back({(uint32_t)s, (uint32_t)c});
@@ -680,6 +735,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
 
     int rc = p->d_tiles.upload(p->tiles, e->stream);
     if (rc == PC_OK) rc = p->d_pieces.upload(p->pieces, e->stream);
+    if (rc == PC_OK) rc = p->d_opieces.upload(p->opieces, e->stream);
     if (rc == PC_OK) rc = p->d_cchunks.upload(p->cchunks, e->stream);
     if (rc == PC_OK) rc = p->d_gsegs.upload(p->gsegs, e->stream);
     if (rc == PC_OK) rc = p->d_gchunks.upload(p->gchunks, e->stream);
@@ -722,7 +778,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
 
     const size_t hist_elem = center ? sizeof(double) : sizeof(uint32_t);
     const size_t hist_bytes = (size_t)p->npos * p->rows * hist_elem;
-    rc = p->d_hist.reserve(std::max<size_t>(hist_bytes, 8));
+    rc = p->d_hist.reserve(std::max<size_t>((size_t)p->npos * p->rows * sizeof(double), 8));
     if (rc == PC_OK) rc = p->d_out.reserve(std::max<size_t>((size_t)p->out_elems * 8, 8));
     if (rc != PC_OK) return rc;
 
@@ -738,16 +794,25 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     for (auto *f : e->files) { nrec += f->n; nextra += f->nrun; }
 
     HIP_TRY(hipEventRecord(e->ev[0], st));
-    // zero-fill: histogram (tiles without reads, atomically merged tiles) and output gaps
-    if (!center && hist_bytes) HIP_TRY(hipMemsetAsync(p->d_hist.p, 0, hist_bytes, st));
-    // slices may leave gaps in the output buffer; gaps read as zero
-    if (p->covered != p->out_elems && p->out_elems) HIP_TRY(hipMemsetAsync(p->d_out.p, 0, (size_t)p->out_elems * 8, st));
+    // Outputs are written exactly once by the tile kernels.  Only positions that belong to no
+    // tile (unknown contig, clipped coordinates) or gaps the caller left between slices need a
+    // zero fill; the compact histogram of the point rules is kept all-zero between calls.
+    if ((p->out_needs_zero || p->covered != p->out_elems) && p->out_elems)
+        HIP_TRY(hipMemsetAsync(p->d_out.p, 0, (size_t)p->out_elems * 8, st));
+    if (!center && hist_bytes && !(p->hist_clean && p->hist_kind == 0)) {
+        HIP_TRY(hipMemsetAsync(p->d_hist.p, 0, hist_bytes, st));
+    }
     HIP_TRY(hipEventRecord(e->ev[1], st));
 
     if (!center) {
+        p->hist_kind = 0;
+        p->hist_clean = true; // k_gather_split clears what the split tiles merged
         if (ntiles > 0) {
             // work list capacity: every record lies in at most 1 + ceil(W/G) scan windows
-            const int64_t cap64 = (int64_t)ntiles * nfiles + ((1 + (W + G - 1) / G) * nrec) / R + nfiles + 16;
+            // work-list capacity (an upper bound): a window scanning n records yields at most
+            // max(1, 2n/R) items, and every record is scanned by at most 1 + (W+127)/G windows
+            const double windows_per_record = 1.0 + (double)(W + 127) / (double)G;
+            const int64_t cap64 = (int64_t)ntiles * nfiles + (int64_t)(2.0 * windows_per_record * (double)nrec / (double)R) + nfiles + 64;
             if (cap64 >= (int64_t)0xffffffffu) return fail(PC_ERR_ARG, "pc_count: work list too large");
             rc = e->d_work.reserve((size_t)cap64);
             if (rc != PC_OK) return rc;
@@ -768,38 +833,50 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             }
             const size_t lds = ((size_t)p->max_slots * p->rows * G + (size_t)((tab_n + 3) & ~3)) * sizeof(uint32_t);
             if (lds > 64 * 1024) return fail(PC_ERR_ARG, "pc_count: LDS budget exceeded (%zu bytes)", lds);
-#define PC_LAUNCH_HIST(K)                                                                                             \
-    hipLaunchKernelGGL((k_hist_point<K>), dim3(grid), dim3(kWG), lds, st, p->d_pieces.p, fv0, fv1, e->d_files.p,        \
-                       e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, tab_lo, tab_n, (uint32_t *)p->d_hist.p,   \
-                       p->npos, dbg)
             const FileView fv0 = e->files[0]->view();
             const FileView fv1 = nfiles > 1 ? e->files[1]->view() : fv0;
             const unsigned grid = (unsigned)cap64;
             int dbg = 0;
             if (const char *env = getenv("PC_DEBUG_HIST")) dbg = atoi(env); // profiling experiments only
+            const int outmode = e->norm_on ? 2 : (out_dtype == PC_OUT_FLOAT64 ? 1 : 0);
+#define PC_LAUNCH_HIST(K, O)                                                                                          \
+    hipLaunchKernelGGL((k_hist_point<K, O>), dim3(grid), dim3(kWG), lds, st, p->d_pieces.p, p->d_opieces.p, fv0, fv1,   \
+                       e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, tab_lo, tab_n,             \
+                       (uint32_t *)p->d_hist.p, p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, dbg)
+#define PC_LAUNCH_HIST_O(K)                                                                                           \
+    do {                                                                                                              \
+        if (outmode == 0) PC_LAUNCH_HIST(K, 0);                                                                       \
+        else if (outmode == 1) PC_LAUNCH_HIST(K, 1);                                                                  \
+        else PC_LAUNCH_HIST(K, 2);                                                                                    \
+    } while (0)
             switch (e->kind) {
-            case PC_MAP_FIVE: PC_LAUNCH_HIST(0); break;
-            case PC_MAP_THREE: PC_LAUNCH_HIST(1); break;
-            case PC_MAP_VAR5: PC_LAUNCH_HIST(3); break;
-            default: PC_LAUNCH_HIST(4); break;
+            case PC_MAP_FIVE: PC_LAUNCH_HIST_O(0); break;
+            case PC_MAP_THREE: PC_LAUNCH_HIST_O(1); break;
+            case PC_MAP_VAR5: PC_LAUNCH_HIST_O(3); break;
+            default: PC_LAUNCH_HIST_O(4); break;
             }
+#undef PC_LAUNCH_HIST_O
 #undef PC_LAUNCH_HIST
             HIP_TRY(hipEventRecord(e->ev[3], st));
-            for (auto *f : e->files) {
-                if (!f->nlong) continue;
-                hipLaunchKernelGGL(k_long_point, dim3((unsigned)((f->nlong + kWG - 1) / kWG)), dim3(kWG), 0, st, p->d_tiles.p, ntiles,
-                                   p->d_pieces.p, f->view(), mp, G, p->modes, (uint32_t *)p->d_hist.p, p->npos);
-            }
+            HIP_TRY(hipEventRecord(e->ev[4], st));
+            // tiles that were split into several work items: lay out from the merged histogram
+#define PC_LAUNCH_SPLIT(O)                                                                                            \
+    hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)ntiles), dim3(kWG), 0, st, p->d_tiles.p, p->d_pieces.p,      \
+                       p->d_opieces.p, p->d_tile_items.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,                    \
+                       (OutT_<O>::type *)p->d_out.p, e->norm_sum)
+            if (outmode == 0) PC_LAUNCH_SPLIT(0);
+            else if (outmode == 1) PC_LAUNCH_SPLIT(1);
+            else PC_LAUNCH_SPLIT(2);
+#undef PC_LAUNCH_SPLIT
         } else {
             HIP_TRY(hipEventRecord(e->ev[2], st));
             HIP_TRY(hipEventRecord(e->ev[3], st));
+            HIP_TRY(hipEventRecord(e->ev[4], st));
         }
-        HIP_TRY(hipEventRecord(e->ev[4], st));
-        if (out_dtype == PC_OUT_INT64)
-            launch_gather<uint32_t, int64_t>(e, p, (const uint32_t *)p->d_hist.p, (int64_t *)p->d_out.p);
-        else
-            launch_gather<uint32_t, double>(e, p, (const uint32_t *)p->d_hist.p, (double *)p->d_out.p);
     } else {
+        p->hist_kind = 1;
+        p->hist_clean = false;
+        // the center gather writes whole slices, including zeros outside the tiles
         HIP_TRY(hipEventRecord(e->ev[2], st));
         const int64_t nchunks = (int64_t)p->cchunks.size();
         if (nchunks > 0)
