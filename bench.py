@@ -208,10 +208,14 @@ def main():
 
     if rank == 0:
         n_extra_runs = int(len(reads.blk_start))
-        hist_bytes = plan.positions * rows * (8 if center else 4)
-        # dominant kernel = k_hist_point (k_center for the center rule): it streams every packed
-        # record once (8 B) + the runs of gapped records (8 B each) and writes the island histogram once
-        kern_alg_bytes = reads.n * 8 + n_extra_runs * 8 + hist_bytes
+        if center:
+            # k_center streams the candidate records and writes the float64 island histogram
+            kern_alg_bytes = reads.n * 8 + n_extra_runs * 8 + plan.positions * 8
+        else:
+            # dominant kernel = k_hist_point (fused): streams every packed record once (8 B) + the
+            # runs of gapped records (8 B each) + the segment table (24 B each) and writes every
+            # output position once (8 B) -- exactly SURVEY section 8(d)'s B_alg for the step
+            kern_alg_bytes = reads.n * 8 + n_extra_runs * 8 + tx.n_segments * 24 + int(p["out_elems"]) * 8
         kern_ms = phases["hist"]
         achieved = kern_alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = None
