@@ -1,0 +1,77 @@
+"""BAM files -> :class:`~plastid_amd.packing.PackedAlignments` with the package's own
+native reader (``csrc/bam_stager.cpp``: BGZF inflate on a thread pool + BAM record parse).
+
+Replaces what the reference gets from pysam on this path (``pysam.AlignmentFile(X, "rb")``,
+``.references/.lengths/.mapped``, ``read.positions``, ``read.is_reverse`` --
+plastid/genomics/genome_array.py:660-690, 800-815).  The file must be coordinate sorted
+(as for pysam ``fetch``); no index file is needed because the whole file is staged.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .build import BAM_LIB, build_bam_library
+from .packing import PackedAlignments
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(BAM_LIB):
+            build_bam_library()
+        L = ctypes.CDLL(BAM_LIB)
+        vp = ctypes.c_void_p
+        L.pb_last_error.restype = ctypes.c_char_p
+        L.pb_open.restype = vp
+        L.pb_open.argtypes = [ctypes.c_char_p]
+        L.pb_close.argtypes = [vp]
+        L.pb_load.argtypes = [vp, ctypes.c_int]
+        L.pb_nref.argtypes = [vp]
+        L.pb_ref_name.restype = ctypes.c_char_p
+        L.pb_ref_name.argtypes = [vp, ctypes.c_int]
+        L.pb_ref_length.restype = ctypes.c_int32
+        L.pb_ref_length.argtypes = [vp, ctypes.c_int]
+        L.pb_counts.argtypes = [vp, vp]
+        L.pb_fill.argtypes = [vp] * 8
+        _lib = L
+    return _lib
+
+
+def read_bam(path, threads=0):
+    """Read a coordinate-sorted BAM file into a :class:`PackedAlignments`.
+
+    ``mapped`` is the number of records with flag 0x4 unset (what ``pysam
+    AlignmentFile.mapped`` reports from the index); unplaced reads are not staged
+    (``fetch`` never returns them).  Raises ``ValueError`` for unsorted input, as pysam does."""
+    L = _load()
+    h = L.pb_open(os.fsencode(path))
+    if not h:
+        raise IOError(L.pb_last_error().decode())
+    try:
+        if L.pb_load(h, int(threads)) != 0:
+            msg = L.pb_last_error().decode()
+            raise ValueError(msg)
+        counts = np.zeros(4, np.int64)
+        L.pb_counts(h, counts.ctypes.data_as(ctypes.c_void_p))
+        n, nrun, mapped = int(counts[0]), int(counts[1]), int(counts[2])
+        nref = L.pb_nref(h)
+        refs = [L.pb_ref_name(h, i).decode() for i in range(nref)]
+        lens = [int(L.pb_ref_length(h, i)) for i in range(nref)]
+        tid = np.empty(n, np.int32)
+        pos = np.empty(n, np.int32)
+        alen = np.empty(n, np.uint16)
+        flags = np.empty(n, np.uint8)
+        nblk = np.empty(n, np.uint8)
+        bs = np.empty(nrun, np.int32)
+        bl = np.empty(nrun, np.int32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        L.pb_fill(h, p(tid), p(pos), p(alen), p(flags), p(nblk), p(bs), p(bl))
+    finally:
+        L.pb_close(h)
+    out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
+                           validate=n <= 5_000_000)
+    out.filename = path
+    return out

@@ -24,6 +24,22 @@ def find_hipcc():
     raise RuntimeError("hipcc not found; cannot build the counting engine")
 
 
+BAM_SRC = os.path.join(HERE, "csrc", "bam_stager.cpp")
+BAM_LIB = os.path.join(HERE, "libplastid_bam.so")
+
+
+def build_bam_library(force=False, verbose=False):
+    """Compile the native BAM -> packed-array stager (host C++, zlib; no GPU code)."""
+    if not force and os.path.exists(BAM_LIB) and os.path.getmtime(BAM_LIB) >= os.path.getmtime(BAM_SRC):
+        return BAM_LIB
+    cxx = shutil.which("g++") or shutil.which("c++") or find_hipcc()
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", BAM_SRC, "-o", BAM_LIB, "-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return BAM_LIB
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -46,3 +62,4 @@ def build_library(force=False, verbose=False, extra_flags=()):
 if __name__ == "__main__":
     import sys
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_bam_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,55 @@
+"""BED -> interval table and SegmentChain.from_bed (CPU only)."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import plastid_amd as pa  # noqa: E402
+from plastid_amd.annotation import IntervalTable, read_bed  # noqa: E402
+
+BED = """track name=test
+# a comment
+chrA\t100\t1100\ttx1\t0\t+\t200\t900\t0,0,0\t3\t100,200,300\t0,400,700
+chrB\t50\t80\ttx2\t5\t-
+chrA\t10\t20
+browser position chrA:1-100
+chrZ\t5\t50\ttx4\t0\t-\t5\t5\t0\t2\t10,10\t0,35
+"""
+
+
+def test_from_bed_line_and_reader():
+    chains = read_bed(io.StringIO(BED))
+    assert len(chains) == 4
+    c = chains[0]
+    assert [(s.start, s.end) for s in c] == [(100, 200), (500, 700), (800, 1100)]
+    assert c.strand == "+" and c.chrom == "chrA" and c.length == 600 and c.attr["ID"] == "tx1"
+    assert c.attr["thickstart"] == 200 and c.attr["thickend"] == 900
+    assert chains[1].strand == "-" and chains[1].attr["score"] == 5.0
+    assert chains[2].strand == "." and chains[2].get_name() == "chrA:10-20(.)"
+    assert pa.SegmentChain.from_bed("chrA\t10\t20\tx\t0\t-") == pa.SegmentChain(pa.GenomicSegment("chrA", 10, 20, "-"))
+    with pytest.raises(ValueError):
+        pa.SegmentChain.from_bed("chrA\t10")
+
+
+def test_interval_table_layout_matches_chains():
+    refs = ["chrA", "chrB"]
+    tab = IntervalTable.from_bed(io.StringIO(BED), refs)
+    assert tab.n == 4 and tab.n_segments == 7 and tab.tid.tolist() == [0, 1, 0, -1]
+    assert tab.length.tolist() == [600, 30, 10, 20] and tab.ids[3] == "tx4"
+    tab2 = IntervalTable.from_chains(read_bed(io.StringIO(BED)), refs)
+    for k in ("tid", "strand", "ex_off", "ex_start", "ex_end"):
+        assert np.array_equal(getattr(tab, k), getattr(tab2, k)), k
+    p = tab.plan_arrays(rows=2)
+    assert p["out_elems"] == 2 * 660
+    # '-' chains are laid out 5'->3': the last genomic position of chain 1 is output element 0 of its block
+    base = p["chain_base"][1]
+    seg = 3  # the single exon of tx2
+    assert p["out_step"][seg] == -1 and p["out_off"][seg] == base + 29 and p["row_stride"][seg] == 30
+    flat = np.arange(p["out_elems"])
+    views = tab.split_counts(flat, rows=2)
+    assert views[0].shape == (2, 600) and views[1].shape == (2, 30) and views[1][0, 0] == base
+    chains = tab.chains()
+    assert str(chains[0]) == "chrA:100-200^500-700^800-1100(+)"
