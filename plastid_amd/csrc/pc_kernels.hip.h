@@ -338,15 +338,15 @@ __device__ __forceinline__ int64_t lin_floor(const uint32_t PC_GLOBAL *lin, int6
 // the upper ends are exact table lookups and the lower ends are rounded down to a bucket (a
 // few extra records are streamed; they fall outside the bins).  A dense window is cut into
 // sub-windows, each an independent work item that owns its slice of the output -- no merging.
-// Only when a sub-window alone holds a pile-up (> 4R records), or several files feed one
+// Only when a sub-window alone holds a pile-up (> `pile` records), or several files feed one
 // window, the window falls back to record slices merged through the compact histogram.
 __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
                                                            const FileView *__restrict__ files, int nfiles,
-                                                           int G, int W, int64_t R, WorkItem *work,
+                                                           int G, int W, int64_t R, int64_t pile, WorkItem *work,
                                                            uint32_t *nwork, uint32_t *tile_items,
                                                            uint32_t work_cap) {
-    __shared__ uint32_t s_items[kRangesWG / 64];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_items[kRangesWG / 64], s_items2[kRangesWG / 64];
+    __shared__ uint32_t s_base, s_base2;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t idx = (int64_t)blockIdx.x * (kRangesWG / 64) + wv;
     const bool live = idx < (int64_t)ntiles * nfiles;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
                 glo = lin_floor(fv.glin_tab, l0, nb, a - W + 1);
                 ghi = lin_floor(fv.glin_tab, l0, nb, a + sub);
             }
-            merge = __ballot(lane < S && hi - lo > 4 * R) != 0ull; // a pile-up inside one sub-window
+            merge = __ballot(lane < S && hi - lo > pile) != 0ull; // a pile-up inside one sub-window
             items = (uint32_t)S;
         }
         if (merge) {
@@ -398,21 +398,33 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             items = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || f == 0) ? 1u : 0u);
         }
     }
-    // one returning atomic per workgroup (a single hot counter saturates near 90 atomics/us)
-    if (lane == 0) s_items[wv] = items;
+    // Work-list slots.  Items that scan more than R records ("heavy": dense sub-windows below
+    // the pile-up threshold) are queued from the FRONT of the list, all others from the BACK;
+    // the histogram kernel dispatches front first, so the long items start at t = 0 and the
+    // short ones fill the tail (longest-processing-time-first, in two classes).
+    // One returning atomic per class per workgroup: a single hot counter saturates near 90/us.
+    const bool heavy_lane = live && !merge && lane < (int)items && (hi - lo) > R;
+    const unsigned long long hmask = __ballot(heavy_lane);
+    const uint32_t n_heavy = (uint32_t)__popcll(hmask), n_light = items - n_heavy;
+    if (lane == 0) { s_items[wv] = n_heavy; s_items2[wv] = n_light; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int i = 0; i < kRangesWG / 64; ++i) { const uint32_t v = s_items[i]; s_items[i] = tot; tot += v; }
-        s_base = tot ? atomicAdd(nwork, tot) : 0u;
+        uint32_t th = 0, tlt = 0;
+        for (int i = 0; i < kRangesWG / 64; ++i) {
+            const uint32_t a = s_items[i], b = s_items2[i];
+            s_items[i] = th; s_items2[i] = tlt;
+            th += a; tlt += b;
+        }
+        s_base = th ? atomicAdd(&nwork[0], th) : 0u;
+        s_base2 = tlt ? atomicAdd(&nwork[1], tlt) : 0u;
     }
     __syncthreads();
     if (!items) return;
-    const uint32_t base = s_base + s_items[wv];
+    const uint32_t base_h = s_base + s_items[wv], base_l = s_base2 + s_items2[wv];
     if (lane == 0 && merge) atomicAdd(&tile_items[t], items); // > 0 marks the tile for k_gather_split
     for (uint32_t k = lane; k < items; k += 64) {
-        if (base + k >= work_cap) break; // cannot happen (capacity is an upper bound); defensive
         WorkItem w;
+        uint32_t slot;
         if (merge) {
             w.lo = wlo + (int64_t)k * R;
             w.hi = (w.lo + R < whi) ? w.lo + R : whi;
@@ -422,12 +434,17 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             w.lhi = k == 0 ? lhi : 0;
             w.sub_lo = 0;
             w.sub_hi = G;
+            slot = work_cap - 1u - (base_l + k);
         } else {
             w.lo = lo; w.hi = hi; w.glo = glo; w.ghi = ghi;
             w.llo = llo; w.lhi = lhi; // every sub-window checks the (few) long-span candidates
             w.sub_lo = (int32_t)k * (G / S);
             w.sub_hi = w.sub_lo + G / S;
+            const unsigned long long below = (1ull << k) - 1ull; // k == lane here (items <= 64)
+            slot = heavy_lane ? base_h + (uint32_t)__popcll(hmask & below)
+                              : work_cap - 1u - (base_l + (k - (uint32_t)__popcll(hmask & below)));
         }
+        if (slot >= work_cap) continue; // cannot happen (capacity is an upper bound); defensive
         w.merge = merge ? 1u : 0u;
         w.pad = 0;
         w.op_begin = tl.op_begin;
@@ -438,7 +455,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         w.mode_mask = tl.mode_mask;
         w.piece_begin = tl.piece_begin;
         w.piece_end = tl.piece_end;
-        work[base + k] = w;
+        work[slot] = w;
     }
 }
 
@@ -561,10 +578,12 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
                                                     const uint32_t *__restrict__ tile_items, MapParams mp,
                                                     int G, int tab_lo, int tab_n, uint32_t *hist,
                                                     int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
-                                                    double norm_sum, int dbg) {
+                                                    double norm_sum, uint32_t work_cap, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const WorkItem w = work[blockIdx.x];
-    if (blockIdx.x >= *nwork) return;
+    // heavy items sit at the front of the list, light ones at the back (see k_tile_ranges)
+    const uint32_t n_heavy = nwork[0], n_light = nwork[1];
+    if (blockIdx.x >= n_heavy + n_light) return;
+    const WorkItem w = work[blockIdx.x < n_heavy ? blockIdx.x : work_cap - 1u - (blockIdx.x - n_heavy)];
     const GFile fv = w.file == 0 ? gfile(file0) : (w.file == 1 ? gfile(file1) : gfile(files[w.file]));
 
     // ---- first batch of the record stream (and the first gapped records): 16-byte pairs,

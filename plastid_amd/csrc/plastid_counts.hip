@@ -787,6 +787,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     const int G = p->G;
     int64_t R = 16384;
     if (const char *env = getenv("PC_WORK_R")) R = std::max(1024, atoi(env)); // tuning knob
+    int64_t pile = 16 * R; // a 128-nt sub-window with more records than this is merged through the histogram
+    if (const char *env = getenv("PC_PILE")) pile = std::max<int64_t>(R, atoll(env)); // tuning knob
     const MapParams mp = e->params();
     const int ntiles = (int)p->tiles.size();
     hipStream_t st = e->stream;
@@ -820,7 +822,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
             const int64_t nthreads = (int64_t)ntiles * nfiles * kWave; // one wave per (tile, file)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
-                               e->d_files.p, nfiles, G, W, R, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64);
+                               e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64);
             HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
             int tab_lo = 0, tab_n = 0;
@@ -842,7 +844,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
 #define PC_LAUNCH_HIST(K, O)                                                                                          \
     hipLaunchKernelGGL((k_hist_point<K, O>), dim3(grid), dim3(kWG), lds, st, p->d_pieces.p, p->d_opieces.p, fv0, fv1,   \
                        e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, tab_lo, tab_n,             \
-                       (uint32_t *)p->d_hist.p, p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, dbg)
+                       (uint32_t *)p->d_hist.p, p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap64, dbg)
 #define PC_LAUNCH_HIST_O(K)                                                                                           \
     do {                                                                                                              \
         if (outmode == 0) PC_LAUNCH_HIST(K, 0);                                                                       \
