@@ -107,7 +107,9 @@ def cpu_baseline_all_cores(oracle, aln, spec, p, tx, n_records, chains_done):
     """The same oracle on every host core: one process per core over disjoint chain shards
     (the reference itself is single-threaded; this is the most favourable honest scaling)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    # every worker re-derives the oracle's per-record arrays (16 B/record), so the process count
+    # is bounded by memory, not only by cores: at most 16 workers
+    cores = min(os.cpu_count() or 1, 16)
     if cores < 2 or len(chains_done) < cores:
         return None
     _MP.update(oracle=oracle, aln=aln, spec=spec, p=p)

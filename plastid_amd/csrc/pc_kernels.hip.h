@@ -793,6 +793,14 @@ __device__ __forceinline__ void center_one(const GFile &fv, const MapParams &mp,
     if (hit) acc += val;                    // :254, one IEEE add per covering read, in order
 }
 
+// wave-uniform value of lane `j` of a per-lane register (j uniform)
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
+__device__ __forceinline__ double lane_f64(double v, int j) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = lane_u32((uint32_t)b, j), hi = lane_u32((uint32_t)(b >> 32), j);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                 const FileView *__restrict__ files, int nfiles,
                                                 MapParams mp, int W, const double *__restrict__ inv_,
@@ -803,18 +811,20 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     const int lane = threadIdx.x & 63;
     const CenterChunk ck = chunks[c];
     const int32_t p = ck.start + lane;
+    const int32_t cend = ck.start + ck.len;
+    const int nib = mp.param;
     double acc = 0.0;
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
-        const int64_t b0 = fv.tid_bounds[ck.tid], b1 = fv.tid_bounds[ck.tid + 1];
         const int64_t near_key = (int64_t)ck.start - W + 1;
         if (fv.nlong) {
-            // long-span reads that start before the near window but may reach into it
+            // long-span reads that start before the near window but may reach into it (rare:
+            // wave-uniform scalar replay)
             const int64_t l0 = fv.long_tid_bounds[ck.tid], l1 = fv.long_tid_bounds[ck.tid + 1];
             int64_t lo = l0, hi = l1;
             while (lo < hi) { // first long read with pos >= near_key
                 int64_t mid = lo + ((hi - lo) >> 1);
-                if ((int64_t)(int32_t)fv.rec[fv.long_idx[mid]].x < near_key) lo = mid + 1; else hi = mid;
+                if ((int64_t)(int32_t)fv.long_rec[mid].x < near_key) lo = mid + 1; else hi = mid;
             }
             const int64_t jhi = lo;
             lo = l0; hi = jhi;
@@ -824,9 +834,53 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
             }
             for (int64_t j = lo; j < jhi; ++j) center_one(fv, mp, fv.long_idx[j], ck.mode, inv, p, acc);
         }
-        const int64_t lo = lower_bound_pos(fv.rec, b0, b1, near_key);
-        const int64_t hi = lower_bound_pos(fv.rec, lo, b1, (int64_t)ck.start + ck.len);
-        for (int64_t i = lo; i < hi; ++i) center_one(fv, mp, i, ck.mode, inv, p, acc);
+        // near window: every record whose start lies in the 128-nt buckets covering
+        // (start - W, end).  A batch of 64 candidate records is fetched with ONE coalesced
+        // vector load, then replayed in record order out of registers (readlane), so the
+        // ordered float64 accumulation never waits on memory.
+        const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
+        const int64_t lo = lin_floor(fv.lin_tab, q0, nb, near_key);
+        const int64_t hi = lin_floor(fv.lin_tab, q0, nb, (int64_t)cend + (1 << kLinShift) - 1);
+        for (int64_t base = lo; base < hi; base += 64) {
+            const int64_t i = base + lane;
+            const bool in = i < hi;
+            const u32x2 r = in ? fv.rec[i] : (u32x2){0u, kFlagExcluded << 16};
+            const uint32_t meta = r.y, fl = rec_flags(meta);
+            const int32_t pos = (int32_t)r.x;
+            const int L = rec_len(meta), nbk = rec_nblk(meta);
+            const int m = L - 2 * nib;                       // map_length, :245
+            bool ok = in && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse) && size_ok(mp, L) && (m > 0);
+            ok &= !((fl & kFlagLong) && (int64_t)pos < near_key); // those were replayed above
+            // can the read touch this chunk at all?  (gapped: decided per run below)
+            const int32_t s = pos + nib;
+            ok &= (pos < cend) & ((nbk >= 2) | (s + m > ck.start));
+            const double val = ok ? inv[m] : 0.0;            // 1.0 / map_length, :250
+            unsigned long long todo = __ballot(ok);
+            while (todo) {                                   // record order
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t meta_j = lane_u32(meta, j);
+                const int32_t pos_j = (int32_t)lane_u32((uint32_t)pos, j);
+                const double val_j = lane_f64(val, j);
+                const int L_j = rec_len(meta_j), nb_j = rec_nblk(meta_j);
+                bool hit;
+                if (nb_j < 2) {
+                    const int32_t s_j = pos_j + nib;
+                    hit = (p >= s_j) & (p < s_j + (L_j - 2 * nib));
+                } else {
+                    hit = false;
+                    const i32x2 PC_GLOBAL *bl = fv.blk + fv.blk_off[base + j];
+                    int cum = 0;
+                    for (int q = 0; q < nb_j; ++q) {
+                        const i32x2 run = bl[q];
+                        const int idx = cum + (p - run.x);
+                        hit |= (p >= run.x) & (p < run.x + run.y) & (idx >= nib) & (idx < L_j - nib);
+                        cum += run.y;
+                    }
+                }
+                if (hit) acc += val_j;                       // :254, one IEEE add per covering read, in order
+            }
+        }
     }
     if (lane < ck.len) hist[ck.hist_off + lane] = acc;
 }
