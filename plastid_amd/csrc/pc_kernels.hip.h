@@ -59,6 +59,8 @@ struct FileView {
     // genome bucket, per contig; lin_off[t] = start of contig t's buckets (nb_t + 1 entries)
     const uint32_t *lin_tab;
     const uint32_t *glin_tab;       // same for the gapped-record list
+    const uint32_t *llin_tab;       // same for the long-span list (first long read at/after the bucket)
+    const uint32_t *plin_tab;       // first long read whose running max end exceeds the bucket start
     const int64_t *lin_off;         // ntid+1 (shared by both tables)
     int64_t n;
     int64_t nlong;
@@ -88,6 +90,8 @@ struct GFile {
     const int64_t PC_GLOBAL *gap_tid_bounds;
     const uint32_t PC_GLOBAL *lin_tab;
     const uint32_t PC_GLOBAL *glin_tab;
+    const uint32_t PC_GLOBAL *llin_tab;
+    const uint32_t PC_GLOBAL *plin_tab;
     const int64_t PC_GLOBAL *lin_off;
     int64_t n;
     int64_t nlong;
@@ -110,6 +114,8 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.gap_tid_bounds = (const int64_t PC_GLOBAL *)v.gap_tid_bounds;
     g.lin_tab = (const uint32_t PC_GLOBAL *)v.lin_tab;
     g.glin_tab = (const uint32_t PC_GLOBAL *)v.glin_tab;
+    g.llin_tab = (const uint32_t PC_GLOBAL *)v.llin_tab;
+    g.plin_tab = (const uint32_t PC_GLOBAL *)v.plin_tab;
     g.lin_off = (const int64_t PC_GLOBAL *)v.lin_off;
     g.n = v.n;
     g.nlong = v.nlong;
@@ -136,7 +142,8 @@ struct Tile {
     uint32_t mode_mask;
     uint32_t op_begin;    // output pieces (segment slices in the caller's layout)
     uint32_t op_end;
-    uint32_t pad;
+    uint16_t span_lo;     // queried positions of the window all lie in [span_lo, span_hi) (window-relative)
+    uint16_t span_hi;
 };
 
 // A queried segment cut at the tile grid, with its place in the caller's output buffer:
@@ -171,7 +178,7 @@ struct WorkItem {
     uint32_t op_begin, op_end;
     int32_t sub_lo, sub_hi; // the part of the window this item owns (window-relative positions)
     uint32_t merge;         // 1: several items share the window (pile-up / several files) -> merge via hist
-    uint32_t pad;
+    uint16_t span_lo, span_hi; // bins that can ever be read back (see Tile)
 };
 
 
@@ -323,7 +330,7 @@ __device__ __forceinline__ int64_t indexed_lower_bound(const uint32_t PC_GLOBAL 
     return wave_lower_bound<STRIDE>(pos, lo, hi, key, lane);
 }
 
-constexpr int kRangesWG = 1024; // 16 waves = 16 (tile, file) pairs per workgroup
+constexpr int kRangesWG = 256;
 constexpr int kMaxSub = 32;     // a dense window is cut into up to 32 sub-windows (>= 128 positions each)
 
 // linear-index lookup: first record at/after the bucket holding `key` (conservative: rounds down)
@@ -333,129 +340,178 @@ __device__ __forceinline__ int64_t lin_floor(const uint32_t PC_GLOBAL *lin, int6
     return lin[lin0 + b];
 }
 
-// One WAVE per (tile, file): which records the tile must scan (fetch emulation,
+// exclusive prefix sum of one value per thread over a kRangesWG-thread block
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kRangesWG / 64; ++i) {
+        const uint32_t t = s_wave[i];
+        if (i < wv) base += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+// first index in [lo,hi) of a stride-`STRIDE` dword array whose value >= key (per-thread bisection)
+template <int STRIDE>
+__device__ __forceinline__ int64_t lower_bound_i32(const uint32_t PC_GLOBAL *v, int64_t lo, int64_t hi, int64_t key) {
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)(int32_t)v[mid * STRIDE] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One THREAD per (tile, file): which records the tile must scan (fetch emulation,
 // genome_array.py:800-809).  Window edges are multiples of the 128-nt linear-index bucket, so
 // the upper ends are exact table lookups and the lower ends are rounded down to a bucket (a
-// few extra records are streamed; they fall outside the bins).  A dense window is cut into
-// sub-windows, each an independent work item that owns its slice of the output -- no merging.
-// Only when a sub-window alone holds a pile-up (> `pile` records), or several files feed one
-// window, the window falls back to record slices merged through the compact histogram.
+// few extra records are streamed; they fall outside the bins) -- no searching at all for the
+// packed stream.  A dense window is cut into sub-windows, each an independent work item that
+// owns its slice of the output -- no merging.  Only when a sub-window alone holds a pile-up
+// (> `pile` records), or several files feed one window, the window falls back to record slices
+// merged through the compact histogram.
+//
+// Work-list slots, three classes:
+//   heavy  items that scan more than R records (dense sub-windows): queued from the FRONT of the
+//          list -- the histogram kernel dispatches front first, so the long items start at t = 0
+//          and the short ones fill the tail (longest-processing-time-first, in two classes);
+//   light  everything else, queued from the BACK;
+//   small  sparse windows (all queried positions within `small_g`, few records): their own list,
+//          served by single-wave workgroups with a small LDS footprint -- a sparse annotation is
+//          latency-bound, so what matters is how many windows are in flight per CU.
+// One returning atomic per class per workgroup: a single hot counter saturates near 90/us.
 __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
                                                            const FileView *__restrict__ files, int nfiles,
                                                            int G, int W, int64_t R, int64_t pile, WorkItem *work,
                                                            uint32_t *nwork, uint32_t *tile_items,
-                                                           uint32_t work_cap) {
-    __shared__ uint32_t s_items[kRangesWG / 64], s_items2[kRangesWG / 64];
-    __shared__ uint32_t s_base, s_base2;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t idx = (int64_t)blockIdx.x * (kRangesWG / 64) + wv;
+                                                           uint32_t work_cap, WorkItem *work_small, int small_g,
+                                                           int64_t small_n) {
+    __shared__ uint32_t s_wave[kRangesWG / 64];
+    __shared__ uint32_t s_base[3];
+    const int64_t idx = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
     const bool live = idx < (int64_t)ntiles * nfiles;
-    int t = 0, f = 0;
+    int t = 0, f = 0, S = 1;
     Tile tl = {};
-    int64_t lo = 0, hi = 0, glo = 0, ghi = 0, llo = 0, lhi = 0; // per lane: this lane's sub-window
-    int64_t wlo = 0, whi = 0, wglo = 0, wghi = 0;                // whole window
-    uint32_t items = 0;
-    int S = 1;
+    GFile fv = {};
+    int64_t l0 = 0, nb = 0, ws = 0;
+    int64_t wlo = 0, whi = 0, wglo = 0, wghi = 0, llo = 0, lhi = 0;
+    uint32_t n_heavy = 0, n_light = 0, n_small = 0;
     bool merge = false;
     if (live) {
         t = (int)(idx / nfiles);
         f = (int)(idx % nfiles);
         tl = tiles[t];
-        const GFile fv = gfile(files[f]);
-        const int64_t ws = tl.win_start;
-        const int64_t l0 = fv.lin_off[tl.tid], nb = fv.lin_off[tl.tid + 1] - l0 - 1;
-        wlo = lin_floor(fv.lin_tab, l0, nb, ws - W + 1);
-        whi = lin_floor(fv.lin_tab, l0, nb, ws + G);
+        fv = gfile(files[f]);
+        ws = tl.win_start;
+        l0 = fv.lin_off[tl.tid];
+        nb = fv.lin_off[tl.tid + 1] - l0 - 1;
+        // only reads that can land on a queried position matter: a sparse annotation (one
+        // 150-nt exon in a 4096-nt window) scans the exon's neighbourhood, not the whole window
+        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1;
+        wlo = lin_floor(fv.lin_tab, l0, nb, s_lo - W + 1);
+        whi = lin_floor(fv.lin_tab, l0, nb, s_hi);
         if (fv.ngap) {
-            wglo = lin_floor(fv.glin_tab, l0, nb, ws - W + 1);
-            wghi = lin_floor(fv.glin_tab, l0, nb, ws + G);
+            wglo = lin_floor(fv.glin_tab, l0, nb, s_lo - W + 1);
+            wghi = lin_floor(fv.glin_tab, l0, nb, s_hi);
         }
         if (fv.nlong) {
-            // long-span reads that can reach the window: they start before its end, and the
+            // long-span reads that can reach the queried span: they start before its end, and the
             // running maximum of the ends (monotone) has passed its start
-            const int64_t q0 = fv.long_tid_bounds[tl.tid], q1 = fv.long_tid_bounds[tl.tid + 1];
-            lhi = wave_lower_bound<4>((const uint32_t PC_GLOBAL *)fv.long_rec, q0, q1, ws + G, lane);
-            llo = wave_lower_bound<1>((const uint32_t PC_GLOBAL *)fv.long_pmax, q0, lhi, ws + 1, lane);
+            // (two table lookups, both rounded outwards to a 128-nt bucket)
+            lhi = lin_floor(fv.llin_tab, l0, nb, s_hi);
+            llo = lin_floor(fv.plin_tab, l0, nb, s_lo);
+            if (llo > lhi) llo = lhi;
         }
         const int64_t n = whi - wlo;
         merge = nfiles > 1;
         if (!merge) {
             while (S < kMaxSub && (G / (S * 2)) >= (1 << kLinShift) && n > R * S) S <<= 1;
-            const int sub = G / S;
-            const int k = lane < S ? lane : S - 1;
-            const int64_t a = ws + (int64_t)k * sub;
-            lo = lin_floor(fv.lin_tab, l0, nb, a - W + 1);
-            hi = lin_floor(fv.lin_tab, l0, nb, a + sub);
-            if (fv.ngap) {
-                glo = lin_floor(fv.glin_tab, l0, nb, a - W + 1);
-                ghi = lin_floor(fv.glin_tab, l0, nb, a + sub);
+            if (S == 1) {
+                const bool small = small_g > 0 && (int)tl.span_hi - (int)tl.span_lo <= small_g && n <= small_n &&
+                                   (wghi - wglo) <= small_n && (lhi - llo) <= small_n;
+                if (small) n_small = 1; else if (n > R) n_heavy = 1; else n_light = 1;
+            } else {
+                const int sub = G / S;
+                for (int k = 0; k < S; ++k) {
+                    const int64_t a = ws + (int64_t)k * sub;
+                    const int64_t nk = lin_floor(fv.lin_tab, l0, nb, a + sub) - lin_floor(fv.lin_tab, l0, nb, a - W + 1);
+                    if (nk > pile) merge = true; // a pile-up inside one sub-window
+                    if (nk > R) ++n_heavy; else ++n_light;
+                }
             }
-            merge = __ballot(lane < S && hi - lo > pile) != 0ull; // a pile-up inside one sub-window
-            items = (uint32_t)S;
         }
         if (merge) {
             S = 1;
-            items = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || f == 0) ? 1u : 0u);
+            n_heavy = 0;
+            n_light = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || f == 0) ? 1u : 0u);
         }
     }
-    // Work-list slots.  Items that scan more than R records ("heavy": dense sub-windows below
-    // the pile-up threshold) are queued from the FRONT of the list, all others from the BACK;
-    // the histogram kernel dispatches front first, so the long items start at t = 0 and the
-    // short ones fill the tail (longest-processing-time-first, in two classes).
-    // One returning atomic per class per workgroup: a single hot counter saturates near 90/us.
-    const bool heavy_lane = live && !merge && lane < (int)items && (hi - lo) > R;
-    const unsigned long long hmask = __ballot(heavy_lane);
-    const uint32_t n_heavy = (uint32_t)__popcll(hmask), n_light = items - n_heavy;
-    if (lane == 0) { s_items[wv] = n_heavy; s_items2[wv] = n_light; }
-    __syncthreads();
+    uint32_t tot_h, tot_l, tot_s;
+    const uint32_t off_h = block_scan_excl(n_heavy, s_wave, tot_h);
+    const uint32_t off_l = block_scan_excl(n_light, s_wave, tot_l);
+    const uint32_t off_s = block_scan_excl(n_small, s_wave, tot_s);
     if (threadIdx.x == 0) {
-        uint32_t th = 0, tlt = 0;
-        for (int i = 0; i < kRangesWG / 64; ++i) {
-            const uint32_t a = s_items[i], b = s_items2[i];
-            s_items[i] = th; s_items2[i] = tlt;
-            th += a; tlt += b;
-        }
-        s_base = th ? atomicAdd(&nwork[0], th) : 0u;
-        s_base2 = tlt ? atomicAdd(&nwork[1], tlt) : 0u;
+        s_base[0] = tot_h ? atomicAdd(&nwork[0], tot_h) : 0u;
+        s_base[1] = tot_l ? atomicAdd(&nwork[1], tot_l) : 0u;
+        s_base[2] = tot_s ? atomicAdd(&nwork[2], tot_s) : 0u;
     }
     __syncthreads();
-    if (!items) return;
-    const uint32_t base_h = s_base + s_items[wv], base_l = s_base2 + s_items2[wv];
-    if (lane == 0 && merge) atomicAdd(&tile_items[t], items); // > 0 marks the tile for k_gather_split
-    for (uint32_t k = lane; k < items; k += 64) {
-        WorkItem w;
-        uint32_t slot;
-        if (merge) {
+    if (!(n_heavy + n_light + n_small)) return;
+    WorkItem w;
+    w.tile = (uint32_t)t;
+    w.file = (uint32_t)f;
+    w.mode_mask = tl.mode_mask;
+    w.piece_begin = tl.piece_begin; w.piece_end = tl.piece_end;
+    w.op_begin = tl.op_begin; w.op_end = tl.op_end;
+    w.win_start = tl.win_start;
+    w.span_lo = tl.span_lo; w.span_hi = tl.span_hi;
+    w.merge = merge ? 1u : 0u;
+    if (n_small) {
+        w.lo = wlo; w.hi = whi; w.glo = wglo; w.ghi = wghi; w.llo = llo; w.lhi = lhi;
+        w.win_start = tl.win_start + (int32_t)tl.span_lo; // a small window that starts at the first queried position
+        w.sub_lo = 0; w.sub_hi = small_g;
+        w.span_lo = 0; w.span_hi = (uint16_t)(tl.span_hi - tl.span_lo);
+        work_small[s_base[2] + off_s] = w;
+        return;
+    }
+    uint32_t ih = s_base[0] + off_h, il = s_base[1] + off_l;
+    if (merge) {
+        atomicAdd(&tile_items[t], n_light); // > 0 marks the tile for k_gather_split
+        for (uint32_t k = 0; k < n_light; ++k) {
             w.lo = wlo + (int64_t)k * R;
             w.hi = (w.lo + R < whi) ? w.lo + R : whi;
-            w.glo = k == 0 ? wglo : 0;
-            w.ghi = k == 0 ? wghi : 0;
-            w.llo = k == 0 ? llo : 0;
-            w.lhi = k == 0 ? lhi : 0;
-            w.sub_lo = 0;
-            w.sub_hi = G;
-            slot = work_cap - 1u - (base_l + k);
-        } else {
-            w.lo = lo; w.hi = hi; w.glo = glo; w.ghi = ghi;
-            w.llo = llo; w.lhi = lhi; // every sub-window checks the (few) long-span candidates
-            w.sub_lo = (int32_t)k * (G / S);
-            w.sub_hi = w.sub_lo + G / S;
-            const unsigned long long below = (1ull << k) - 1ull; // k == lane here (items <= 64)
-            slot = heavy_lane ? base_h + (uint32_t)__popcll(hmask & below)
-                              : work_cap - 1u - (base_l + (k - (uint32_t)__popcll(hmask & below)));
+            w.glo = k == 0 ? wglo : 0; w.ghi = k == 0 ? wghi : 0;
+            w.llo = k == 0 ? llo : 0;  w.lhi = k == 0 ? lhi : 0;
+            w.sub_lo = 0; w.sub_hi = G;
+            const uint32_t slot = work_cap - 1u - (il + k);
+            if (slot < work_cap) work[slot] = w;
         }
-        if (slot >= work_cap) continue; // cannot happen (capacity is an upper bound); defensive
-        w.merge = merge ? 1u : 0u;
-        w.pad = 0;
-        w.op_begin = tl.op_begin;
-        w.op_end = tl.op_end;
-        w.tile = (uint32_t)t;
-        w.file = (uint32_t)f;
-        w.win_start = tl.win_start;
-        w.mode_mask = tl.mode_mask;
-        w.piece_begin = tl.piece_begin;
-        w.piece_end = tl.piece_end;
-        work[slot] = w;
+        return;
+    }
+    const int sub = G / S;
+    for (int k = 0; k < S; ++k) {
+        const int64_t a = S == 1 ? ws + tl.span_lo : ws + (int64_t)k * sub;
+        const int64_t e = S == 1 ? ws + tl.span_hi + (1 << kLinShift) - 1 : a + sub;
+        w.lo = lin_floor(fv.lin_tab, l0, nb, a - W + 1);
+        w.hi = lin_floor(fv.lin_tab, l0, nb, e);
+        w.glo = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, a - W + 1) : 0;
+        w.ghi = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, e) : 0;
+        w.llo = llo; w.lhi = lhi; // every sub-window checks the (few) long-span candidates
+        w.sub_lo = S == 1 ? 0 : k * sub;
+        w.sub_hi = S == 1 ? G : w.sub_lo + sub;
+        const uint32_t slot = (w.hi - w.lo) > R ? ih++ : work_cap - 1u - (il++);
+        if (slot < work_cap) work[slot] = w; // capacity is an upper bound; the test is defensive
     }
 }
 
@@ -569,8 +625,8 @@ __device__ __forceinline__ typename OutT_<OUTMODE>::type out_conv(uint32_t v, do
     return (typename OutT_<OUTMODE>::type)((double)v / norm_sum * 1e6);
 }
 
-template <int KIND, int OUTMODE>
-__global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pieces,
+template <int KIND, int OUTMODE, int WG, bool SMALL>
+__global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pieces,
                                                     const OutPiece *__restrict__ opieces, FileView file0,
                                                     FileView file1, const FileView *__restrict__ files,
                                                     const WorkItem *__restrict__ work,
@@ -580,8 +636,9 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
                                                     int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
                                                     double norm_sum, uint32_t work_cap, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    // heavy items sit at the front of the list, light ones at the back (see k_tile_ranges)
-    const uint32_t n_heavy = nwork[0], n_light = nwork[1];
+    // heavy items sit at the front of the list, light ones at the back (see k_tile_ranges);
+    // the sparse-window list is a plain array of its own
+    const uint32_t n_heavy = SMALL ? nwork[2] : nwork[0], n_light = SMALL ? 0u : nwork[1];
     if (blockIdx.x >= n_heavy + n_light) return;
     const WorkItem w = work[blockIdx.x < n_heavy ? blockIdx.x : work_cap - 1u - (blockIdx.x - n_heavy)];
     const GFile fv = w.file == 0 ? gfile(file0) : (w.file == 1 ? gfile(file1) : gfile(files[w.file]));
@@ -597,7 +654,7 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
     u32x4 cur[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int j = u * kWG + (int)threadIdx.x;
+        const int j = u * WG + (int)threadIdx.x;
         cur[u] = (j < npairs) ? src[j] : none;
     }
     const int64_t gj0 = w.glo + threadIdx.x;
@@ -613,13 +670,15 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
     c.frange = (mp.filt_on && mp.filt_max != -1) ? (uint32_t)(mp.filt_max - mp.filt_min) : 0xffffu - c.fmin;
     c.tab_lo = tab_lo;
     c.tab_n = (uint32_t)tab_n;
-    const int nbins = nslots * mp.rows * G;
     uint32_t *ltab = smem;                      // packed offset tables first (variable / stratified rules) ...
     uint32_t *bins = smem + ((tab_n + 3) & ~3); // ... then the bins
-    for (int i = threadIdx.x; i < nbins; i += kWG) bins[i] = 0;
+    {   // only bins in [span_lo, span_hi) are ever read back: clear just those
+        const int span = (int)w.span_hi - (int)w.span_lo, nrow = nslots * mp.rows;
+        for (int i = threadIdx.x; i < nrow * span; i += WG) bins[(i / span) * G + w.span_lo + (i % span)] = 0;
+    }
     if (KIND >= 3) {
         const int32_t PC_GLOBAL *fw = (const int32_t PC_GLOBAL *)mp.fw, *rc = (const int32_t PC_GLOBAL *)mp.rc;
-        for (int i = threadIdx.x; i < tab_n; i += kWG) {
+        for (int i = threadIdx.x; i < tab_n; i += WG) {
             const int f = fw[tab_lo + i], r = rc[tab_lo + i];
             ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
@@ -628,11 +687,11 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
 
     // ---- the packed record stream: no dependent global loads in this loop
     uint32_t dbg_acc = 0;
-    for (int base = 0; base < npairs; base += kWG * U) {
+    for (int base = 0; base < npairs; base += WG * U) {
         u32x4 nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = base + kWG * U + u * kWG + (int)threadIdx.x;
+            const int j = base + WG * U + u * WG + (int)threadIdx.x;
             nxt[u] = (j < npairs) ? src[j] : none;
         }
         if (dbg & 1) { // DEBUG: stream only
@@ -641,7 +700,7 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
         } else
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = base + u * kWG + (int)threadIdx.x;
+            const int j = base + u * WG + (int)threadIdx.x;
             const bool in = j < npairs;
             hist_rec<KIND>(mp, c, ltab, cur[u].x, cur[u].y, in & !((j == 0) & (lo_odd != 0)), bins);
             hist_rec<KIND>(mp, c, ltab, cur[u].z, cur[u].w, in & !((j == npairs - 1) & (hi_odd != 0)), bins);
@@ -652,7 +711,7 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
 
     // ---- gapped records (deletions, short introns): their aligned runs live in a side
     // array; consecutive list entries own consecutive runs, so these gathers stay coalesced.
-    for (int64_t base = w.glo; base < w.ghi; base += kWG) {
+    for (int64_t base = w.glo; base < w.ghi; base += WG) {
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.ghi;
         const u32x4 g = base == w.glo ? gfirst : (in ? fv.gap_rec[j] : none);
@@ -670,7 +729,7 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
     }
 
     // ---- long-span (spliced) reads that can reach this window: same binning, every run walked
-    for (int64_t base = w.llo; base < w.lhi; base += kWG) {
+    for (int64_t base = w.llo; base < w.lhi; base += WG) {
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.lhi;
         const u32x4 g = in ? fv.long_rec[j] : none;
@@ -703,7 +762,7 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
             for (int r = 0; r < mp.rows; ++r) {
                 const uint32_t *srcb = bins + c.base[o.mode] + r * G + rel;
                 typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
-                for (int i = i0 + (int)threadIdx.x; i < i1; i += kWG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(srcb[i], norm_sum);
+                for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(srcb[i], norm_sum);
             }
         }
     } else {
@@ -715,7 +774,7 @@ __global__ __launch_bounds__(kWG) void k_hist_point(const Piece *__restrict__ pi
             for (int r = 0; r < mp.rows; ++r) {
                 const uint32_t *srcb = bins + c.base[pc_.mode] + r * G + rel;
                 uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
-                for (int i = threadIdx.x; i < pc_.len; i += kWG) {
+                for (int i = threadIdx.x; i < pc_.len; i += WG) {
                     const uint32_t v = srcb[i];
                     if (v) atomicAdd(&dst[i], v);
                 }

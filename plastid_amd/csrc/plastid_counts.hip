@@ -81,7 +81,7 @@ struct StagedFile {
     int64_t ngap = 0;
     DevBuf<uint4> gap_rec;
     DevBuf<int64_t> gap_tid_bounds;
-    DevBuf<uint32_t> lin_tab, glin_tab;
+    DevBuf<uint32_t> lin_tab, glin_tab, llin_tab, plin_tab;
     DevBuf<int64_t> lin_off;
     std::vector<int64_t> len_hist; // records per aligned length (host), for cheap warn pre-checks
     FileView view() const {
@@ -90,7 +90,7 @@ struct StagedFile {
         v.long_idx = long_idx.p; v.long_tid = long_tid.p; v.long_pmax = long_pmax.p;
         v.long_tid_bounds = long_tid_bounds.p; v.long_rec = long_rec.p; v.n = n; v.nlong = nlong;
         v.gap_rec = gap_rec.p; v.gap_tid_bounds = gap_tid_bounds.p; v.ngap = ngap;
-        v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.lin_off = lin_off.p;
+        v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.llin_tab = llin_tab.p; v.plin_tab = plin_tab.p; v.lin_off = lin_off.p;
         return v;
     }
 };
@@ -115,7 +115,7 @@ struct pc_engine {
     double norm_sum = 1.0;
     DevBuf<double> d_inv; // 1.0/m, m = 0..65535 (host-computed IEEE quotients)
     // scratch for counting
-    DevBuf<WorkItem> d_work;
+    DevBuf<WorkItem> d_work, d_work_small;
     DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
     DevBuf<double> d_partial;
     DevBuf<Unmappable> d_unmap;
@@ -401,6 +401,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         lin_off[(size_t)t + 1] = lin_off[(size_t)t] + nb + 1;
     }
     std::vector<uint32_t> lin_tab((size_t)lin_off[(size_t)ntid]), glin_tab((size_t)lin_off[(size_t)ntid]);
+    std::vector<uint32_t> llin_tab((size_t)lin_off[(size_t)ntid]), plin_tab((size_t)lin_off[(size_t)ntid]);
     for (int t = 0; t < ntid; ++t) {
         const int64_t l0 = lin_off[(size_t)t], nb = lin_off[(size_t)t + 1] - l0 - 1;
         {
@@ -419,6 +420,17 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 const int64_t edge = k << kLinShift;
                 while (i < en && k < nb && (int64_t)(int32_t)gap_rec[(size_t)i].x < edge) ++i;
                 glin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? i : en);
+            }
+        }
+        {   // long-span list: by start, and by running maximum end (both monotone)
+            const int64_t b = long_bounds[(size_t)t], en = long_bounds[(size_t)t + 1];
+            int64_t i = b, j = b;
+            for (int64_t k = 0; k <= nb; ++k) {
+                const int64_t edge = k << kLinShift;
+                while (i < en && k < nb && (int64_t)(int32_t)long_rec[(size_t)i].x < edge) ++i;
+                while (j < en && k < nb && (int64_t)long_pmax[(size_t)j] <= edge) ++j;
+                llin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? i : en);
+                plin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? j : en);
             }
         }
     }
@@ -442,6 +454,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc == PC_OK) rc = sf->gap_tid_bounds.upload(gap_bounds, e->stream);
     if (rc == PC_OK) rc = sf->lin_tab.upload(lin_tab, e->stream);
     if (rc == PC_OK) rc = sf->glin_tab.upload(glin_tab, e->stream);
+    if (rc == PC_OK) rc = sf->llin_tab.upload(llin_tab, e->stream);
+    if (rc == PC_OK) rc = sf->plin_tab.upload(plin_tab, e->stream);
     if (rc == PC_OK) rc = sf->lin_off.upload(lin_off, e->stream);
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
     if (rc != PC_OK) {
@@ -669,13 +683,16 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     for (size_t i = 0; i < raw.size(); ++i) {
         if (p->tiles.empty() || p->tiles.back().tid != raw[i].tid || p->tiles.back().win_start != (int32_t)raw[i].win) {
             Tile t;
-            t.tid = raw[i].tid; t.win_start = (int32_t)raw[i].win; t.piece_begin = (uint32_t)i; t.piece_end = (uint32_t)i; t.mode_mask = 0; t.pad = 0;
+            t.tid = raw[i].tid; t.win_start = (int32_t)raw[i].win; t.piece_begin = (uint32_t)i; t.piece_end = (uint32_t)i; t.mode_mask = 0;
             t.op_begin = t.op_end = 0;
+            t.span_lo = 0xffff; t.span_hi = 0;
             p->tiles.push_back(t);
         }
         Tile &t = p->tiles.back();
         t.piece_end = (uint32_t)i + 1;
         t.mode_mask |= 1u << raw[i].pc_.mode;
+        t.span_lo = std::min<uint16_t>(t.span_lo, (uint16_t)(raw[i].pc_.start - t.win_start));
+        t.span_hi = std::max<uint16_t>(t.span_hi, (uint16_t)(raw[i].pc_.start - t.win_start + raw[i].pc_.len));
         p->pieces.push_back(raw[i].pc_);
         // 64-position chunks for the ordered center replay (one wave each)
         for (int32_t a = 0; a < raw[i].pc_.len; a += kWave) {
@@ -818,11 +835,20 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (cap64 >= (int64_t)0xffffffffu) return fail(PC_ERR_ARG, "pc_count: work list too large");
             rc = e->d_work.reserve((size_t)cap64);
             if (rc != PC_OK) return rc;
+            // sparse windows: single-wave workgroups with a small LDS window (rows == 1 only)
+            // (skipped for dense annotations, where queried positions fill most of every window)
+            const bool sparse_plan = (double)p->npos < 0.25 * (double)ntiles * (double)G;
+            const int small_g = (p->rows == 1 && sparse_plan && !getenv("PC_NO_SMALL")) ? std::min(512, G) : 0;
+            const int64_t small_n = 2048;
+            const int64_t cap_small = small_g ? (int64_t)ntiles * nfiles : 0;
+            rc = e->d_work_small.reserve((size_t)std::max<int64_t>(cap_small, 1));
+            if (rc != PC_OK) return rc;
             HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
             HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
-            const int64_t nthreads = (int64_t)ntiles * nfiles * kWave; // one wave per (tile, file)
+            const int64_t nthreads = (int64_t)ntiles * nfiles; // one thread per (tile, file)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
-                               e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64);
+                               e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
+                               e->d_work_small.p, small_g, small_n);
             HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
             int tab_lo = 0, tab_n = 0;
@@ -842,15 +868,24 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (const char *env = getenv("PC_DEBUG_HIST")) dbg = atoi(env); // profiling experiments only
             const int outmode = e->norm_on ? 2 : (out_dtype == PC_OUT_FLOAT64 ? 1 : 0);
 #define PC_LAUNCH_HIST(K, O)                                                                                          \
-    hipLaunchKernelGGL((k_hist_point<K, O>), dim3(grid), dim3(kWG), lds, st, p->d_pieces.p, p->d_opieces.p, fv0, fv1,   \
-                       e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, G, tab_lo, tab_n,             \
-                       (uint32_t *)p->d_hist.p, p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap64, dbg)
+    do {                                                                                                              \
+        hipLaunchKernelGGL((k_hist_point<K, O, kWG, false>), dim3(grid), dim3(kWG), lds, st, p->d_pieces.p,             \
+                           p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, \
+                           G, tab_lo, tab_n, (uint32_t *)p->d_hist.p, p->npos, (OutT_<O>::type *)p->d_out.p,            \
+                           e->norm_sum, (uint32_t)cap64, dbg);                                                          \
+        if (cap_small)                                                                                                \
+            hipLaunchKernelGGL((k_hist_point<K, O, 64, true>), dim3((unsigned)cap_small), dim3(64), lds_small, st,      \
+                               p->d_pieces.p, p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work_small.p,                \
+                               e->d_counters.p, p->d_tile_items.p, mp, small_g, tab_lo, tab_n, (uint32_t *)p->d_hist.p, \
+                               p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small, dbg);           \
+    } while (0)
 #define PC_LAUNCH_HIST_O(K)                                                                                           \
     do {                                                                                                              \
         if (outmode == 0) PC_LAUNCH_HIST(K, 0);                                                                       \
         else if (outmode == 1) PC_LAUNCH_HIST(K, 1);                                                                  \
         else PC_LAUNCH_HIST(K, 2);                                                                                    \
     } while (0)
+            const size_t lds_small = ((size_t)p->max_slots * p->rows * std::max(small_g, 1) + (size_t)((tab_n + 3) & ~3)) * sizeof(uint32_t);
             switch (e->kind) {
             case PC_MAP_FIVE: PC_LAUNCH_HIST_O(0); break;
             case PC_MAP_THREE: PC_LAUNCH_HIST_O(1); break;
