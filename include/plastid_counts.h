@@ -123,7 +123,10 @@ int pc_mapping_rows(pc_engine *e);
  * position start[s]+i (0 <= i < end[s]-start[s]), row r is written to
  *     out[out_off[s] + out_step[s]*i + r*row_stride[s]]
  * so a '-' chain is laid out 5'->3' by giving its segments out_step = -1
- * (roitools.pyx:3270-3271, genome_array.py:829-830).  tid < 0 or >= ntid means
+ * (roitools.pyx:3270-3271, genome_array.py:829-830).  out_step = 0 SUMS the slice instead:
+ *     out[out_off[s] + r*row_stride[s]] += sum_i count(start[s]+i, r)
+ * (fused region statistics, numpy.nansum(chain.get_masked_counts(ga)) of
+ * bin/counts_in_region.py:120; integer rules without normalisation only).  tid < 0 or >= ntid means
  * "chromosome not in the array": the slice is zero (genome_array.py:795-798).
  * A plan depends only on the intervals; it can be reused across alignment sets,
  * mapping rules and normalisation settings with the same number of rows.

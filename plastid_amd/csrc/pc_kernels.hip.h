@@ -625,6 +625,18 @@ __device__ __forceinline__ typename OutT_<OUTMODE>::type out_conv(uint32_t v, do
     return (typename OutT_<OUTMODE>::type)((double)v / norm_sum * 1e6);
 }
 
+// out_step == 0: the slice is not laid out but SUMMED into one element per row (region
+// statistics: numpy.nansum(chain.get_masked_counts(ga)), bin/counts_in_region.py:120).  Integer
+// counts, so the atomic adds are exact and order-independent (int64, or float64 below 2^53).
+template <int OUTMODE>
+__device__ __forceinline__ void out_add(typename OutT_<OUTMODE>::type *dst, unsigned long long partial) {
+    for (int o = 32; o > 0; o >>= 1) partial += __shfl_down(partial, o, 64);
+    if ((threadIdx.x & 63) == 0 && partial) {
+        if (OUTMODE == 0) atomicAdd((unsigned long long *)dst, partial);
+        else atomicAdd((double *)dst, (double)partial);
+    }
+}
+
 template <int KIND, int OUTMODE, int WG, bool SMALL>
 __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pieces,
                                                     const OutPiece *__restrict__ opieces, FileView file0,
@@ -762,7 +774,13 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
             for (int r = 0; r < mp.rows; ++r) {
                 const uint32_t *srcb = bins + c.base[o.mode] + r * G + rel;
                 typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
-                for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(srcb[i], norm_sum);
+                if (o.step != 0) {
+                    for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(srcb[i], norm_sum);
+                } else {
+                    unsigned long long part = 0;
+                    for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) part += srcb[i];
+                    out_add<OUTMODE>(dst, part);
+                }
             }
         }
     } else {
@@ -800,7 +818,13 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
         for (int r = 0; r < rows; ++r) {
             const uint32_t *src = hist + (size_t)r * hist_row_stride + o.hist_off;
             typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
-            for (int i = threadIdx.x; i < o.len; i += kWG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(src[i], norm_sum);
+            if (o.step != 0) {
+                for (int i = threadIdx.x; i < o.len; i += kWG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(src[i], norm_sum);
+            } else {
+                unsigned long long part = 0;
+                for (int i = threadIdx.x; i < o.len; i += kWG) part += src[i];
+                out_add<OUTMODE>(dst, part);
+            }
         }
     }
     __syncthreads();

@@ -147,6 +147,7 @@ struct pc_plan {
     std::vector<Tile> tiles;
     std::vector<Piece> pieces;
     std::vector<OutPiece> opieces;
+    bool has_sums = false;       // some slices are summed (out_step 0): the output is an accumulator
     bool out_needs_zero = false; // some queried positions lie outside every tile (unknown contig, clipped)
     bool hist_clean = false;     // compact histogram known to be all zero (point-rule invariant)
     int hist_kind = -1;          // 0 uint32 (point rules), 1 float64 (center)
@@ -584,7 +585,8 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     for (int64_t s = 0; s < nseg; ++s) {
         const int64_t len = end[s] - start[s];
         if (len < 0) { delete p; return fail(PC_ERR_ARG, "segment %lld: end < start", (long long)s); }
-        if (out_step[s] != 1 && out_step[s] != -1) { delete p; return fail(PC_ERR_ARG, "segment %lld: out_step must be +1 or -1", (long long)s); }
+        if (out_step[s] != 1 && out_step[s] != -1 && out_step[s] != 0) { delete p; return fail(PC_ERR_ARG, "segment %lld: out_step must be +1, -1 or 0 (sum)", (long long)s); }
+        if (out_step[s] == 0) p->has_sums = true;
         // output bounds
         if (len > 0) {
             const int64_t first = out_off[s], last = out_off[s] + (int64_t)out_step[s] * (len - 1);
@@ -597,7 +599,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         GatherSeg &g = p->gsegs[(size_t)s];
         g.out_off = out_off[s]; g.row_stride = row_stride[s]; g.len = len; g.step = out_step[s]; g.pad = 0;
         g.hist_off = -1; g.clip_lo = 0; g.clip_hi = 0;
-        p->covered += len * rows;
+        p->covered += (out_step[s] == 0 ? (len > 0 ? 1 : 0) : len) * rows;
         if (tid[s] < 0 || tid[s] >= ntid || len == 0) continue; // unknown chromosome: zeros (genome_array.py:795-798)
         const int64_t cs = std::max<int64_t>(start[s], 0), ce = std::min<int64_t>(end[s], kMaxPos);
         if (ce <= cs) continue;
@@ -816,7 +818,9 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     // Outputs are written exactly once by the tile kernels.  Only positions that belong to no
     // tile (unknown contig, clipped coordinates) or gaps the caller left between slices need a
     // zero fill; the compact histogram of the point rules is kept all-zero between calls.
-    if ((p->out_needs_zero || p->covered != p->out_elems) && p->out_elems)
+    if (p->has_sums && (center || e->norm_on))
+        return fail(PC_ERR_ARG, "pc_count: summed slices (out_step 0) need an integer mapping rule without normalisation");
+    if ((p->has_sums || p->out_needs_zero || p->covered != p->out_elems) && p->out_elems)
         HIP_TRY(hipMemsetAsync(p->d_out.p, 0, (size_t)p->out_elems * 8, st));
     if (!center && hist_bytes && !(p->hist_clean && p->hist_kind == 0)) {
         HIP_TRY(hipMemsetAsync(p->d_hist.p, 0, hist_bytes, st));

@@ -338,3 +338,35 @@ def test_bam_file_end_to_end(pa, oracle, tmp_path):
         chrom, s, e, v = line.split("\t")
         total += (int(e) - int(s)) * int(v)
     assert total == int(((reads.flags & 1) == 0).sum())
+
+
+def test_fused_region_statistics(pa, oracle):
+    """count_in_regions == numpy.nansum(chain.get_masked_counts(ga)) per chain (counts_in_region.py:113-124)."""
+    from plastid_amd import synth
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.003)
+    ga = pa.BAMGenomeArray(reads, mapping=pa.VariableFivePrimeMapFactory(synth.VARIABLE_OFFSETS))
+    ga.add_filter("size", pa.SizeFilterFactory(25, 100))
+    chains = tx.chains(limit=60)
+    rng = np.random.default_rng(3)
+    for c in chains[::2]:   # mask a random stretch of every other chain
+        span = c.spanning_segment
+        a = int(rng.integers(span.start, span.end))
+        c.add_masks(pa.GenomicSegment(c.chrom, a, min(span.end, a + 200), c.strand))
+    chains.append(pa.SegmentChain(pa.GenomicSegment("nope", 5, 50, "+")))   # unknown contig -> 0
+    stats = ga.count_in_regions(chains)
+    for i, c in enumerate(chains):
+        exp = np.nansum(c.get_masked_counts(ga))
+        assert stats["counts"][i] == exp, i
+        assert stats["length"][i] == c.masked_length
+        if c.masked_length:
+            assert stats["counts_per_nucleotide"][i] == float(exp) / c.masked_length
+            assert stats["rpkm"][i] == float(exp) / c.masked_length * (1000.0 * 1e6 / ga.sum())
+    # stratified: one sum per read length
+    ga.set_mapping(pa.StratifiedVariableFivePrimeMapFactory(synth.VARIABLE_OFFSETS, 25, 35))
+    st2 = ga.count_in_regions(chains[:10])
+    assert st2["counts"].shape == (10, 11)
+    for i, c in enumerate(chains[:10]):
+        assert np.array_equal(st2["counts"][i], np.nansum(c.get_masked_counts(ga), axis=-1))
+    ga.set_mapping(pa.CenterMapFactory())
+    with pytest.raises(TypeError):
+        ga.count_in_regions(chains[:2])
