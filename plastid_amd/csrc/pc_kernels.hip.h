@@ -884,11 +884,16 @@ __device__ __forceinline__ double lane_f64(double v, int j) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+constexpr int kInvLds = 1024; // 1/m table kept in LDS for m < kInvLds
+
 __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                 const FileView *__restrict__ files, int nfiles,
                                                 MapParams mp, int W, const double *__restrict__ inv_,
                                                 double *hist) {
+    __shared__ double s_inv[kInvLds];
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
+    for (int i = threadIdx.x; i < kInvLds; i += kWG) s_inv[i] = inv[i]; // host-computed IEEE quotients 1.0/m
+    __syncthreads();
     const int64_t c = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
     if (c >= nchunks) return;
     const int lane = threadIdx.x & 63;
@@ -900,44 +905,40 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
         const int64_t near_key = (int64_t)ck.start - W + 1;
+        const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
         if (fv.nlong) {
             // long-span reads that start before the near window but may reach into it (rare:
-            // wave-uniform scalar replay)
-            const int64_t l0 = fv.long_tid_bounds[ck.tid], l1 = fv.long_tid_bounds[ck.tid + 1];
-            int64_t lo = l0, hi = l1;
-            while (lo < hi) { // first long read with pos >= near_key
-                int64_t mid = lo + ((hi - lo) >> 1);
-                if ((int64_t)(int32_t)fv.long_rec[mid].x < near_key) lo = mid + 1; else hi = mid;
+            // wave-uniform scalar replay).  Candidates from the linear index of the long list:
+            // they start before near_key, and the running maximum of the ends has passed the chunk
+            // start (both bounds rounded outwards to a bucket; the tests below are exact).
+            int64_t jlo = lin_floor(fv.plin_tab, q0, nb, ck.start);
+            const int64_t jhi = lin_floor(fv.llin_tab, q0, nb, near_key + (1 << kLinShift) - 1);
+            for (int64_t j = jlo; j < jhi; ++j) {
+                if ((int64_t)(int32_t)fv.long_rec[j].x >= near_key) break; // met in the near window instead
+                center_one(fv, mp, fv.long_idx[j], ck.mode, inv, p, acc);
             }
-            const int64_t jhi = lo;
-            lo = l0; hi = jhi;
-            while (lo < hi) { // first long read whose running max end reaches past the chunk start
-                int64_t mid = lo + ((hi - lo) >> 1);
-                if (fv.long_pmax[mid] <= ck.start) lo = mid + 1; else hi = mid;
-            }
-            for (int64_t j = lo; j < jhi; ++j) center_one(fv, mp, fv.long_idx[j], ck.mode, inv, p, acc);
         }
-        // near window: every record whose start lies in the 128-nt buckets covering
-        // (start - W, end).  A batch of 64 candidate records is fetched with ONE coalesced
-        // vector load, then replayed in record order out of registers (readlane), so the
-        // ordered float64 accumulation never waits on memory.
-        const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
-        const int64_t lo = lin_floor(fv.lin_tab, q0, nb, near_key);
+        // near window: the records that start in (start - W, end).  A batch of 64 candidates is
+        // fetched with ONE coalesced vector load (the next batch is requested before this one is
+        // used), then replayed in record order out of registers (readlane), so the ordered
+        // float64 accumulation never waits on memory.
+        const int64_t lo = indexed_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, q0, nb, near_key, lane);
         const int64_t hi = lin_floor(fv.lin_tab, q0, nb, (int64_t)cend + (1 << kLinShift) - 1);
+        const u32x2 none = {0x7fffffffu, kFlagExcluded << 16};
+        u32x2 nxt = (lo + lane < hi) ? fv.rec[lo + lane] : none;
         for (int64_t base = lo; base < hi; base += 64) {
-            const int64_t i = base + lane;
-            const bool in = i < hi;
-            const u32x2 r = in ? fv.rec[i] : (u32x2){0u, kFlagExcluded << 16};
+            const u32x2 r = nxt;
+            nxt = (base + 64 + lane < hi) ? fv.rec[base + 64 + lane] : none;
+            if ((int32_t)lane_u32(r.x, 0) >= cend) break; // sorted by start: nothing further can reach the chunk
             const uint32_t meta = r.y, fl = rec_flags(meta);
             const int32_t pos = (int32_t)r.x;
             const int L = rec_len(meta), nbk = rec_nblk(meta);
             const int m = L - 2 * nib;                       // map_length, :245
-            bool ok = in && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse) && size_ok(mp, L) && (m > 0);
-            ok &= !((fl & kFlagLong) && (int64_t)pos < near_key); // those were replayed above
+            bool ok = !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse) && size_ok(mp, L) && (m > 0);
             // can the read touch this chunk at all?  (gapped: decided per run below)
             const int32_t s = pos + nib;
             ok &= (pos < cend) & ((nbk >= 2) | (s + m > ck.start));
-            const double val = ok ? inv[m] : 0.0;            // 1.0 / map_length, :250
+            const double val = ok ? (m < kInvLds ? s_inv[m] : inv[m]) : 0.0; // 1.0 / map_length, :250
             unsigned long long todo = __ballot(ok);
             while (todo) {                                   // record order
                 const int j = __ffsll((long long)todo) - 1;
@@ -948,8 +949,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
                 const int L_j = rec_len(meta_j), nb_j = rec_nblk(meta_j);
                 bool hit;
                 if (nb_j < 2) {
-                    const int32_t s_j = pos_j + nib;
-                    hit = (p >= s_j) & (p < s_j + (L_j - 2 * nib));
+                    hit = (uint32_t)(p - (pos_j + nib)) < (uint32_t)(L_j - 2 * nib);
                 } else {
                     hit = false;
                     const i32x2 PC_GLOBAL *bl = fv.blk + fv.blk_off[base + j];
