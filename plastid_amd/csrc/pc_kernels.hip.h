@@ -886,18 +886,53 @@ __device__ __forceinline__ double lane_f64(double v, int j) {
 
 constexpr int kInvLds = 1024; // 1/m table kept in LDS for m < kInvLds
 
+// Dispatch order of the center chunks: a chunk's replay time is proportional to the reads
+// that overlap it, and expression is heavy-tailed, so chunks over a pile-up are queued first
+// (two-class longest-first, same scheme as the histogram work list): order[0..nheavy) heavy,
+// order[n-1 .. n-nlight] light.
+__global__ __launch_bounds__(kRangesWG) void k_center_order(const CenterChunk *__restrict__ chunks, int64_t nchunks,
+                                                            const FileView *__restrict__ files, int nfiles, int W,
+                                                            int64_t heavy_thr, uint32_t *order, uint32_t *counters) {
+    __shared__ uint32_t s_wave[kRangesWG / 64];
+    __shared__ uint32_t s_base[2];
+    const int64_t c = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
+    const bool live = c < nchunks;
+    int64_t cand = 0;
+    if (live) {
+        const CenterChunk ck = chunks[c];
+        for (int f = 0; f < nfiles; ++f) {
+            const GFile fv = gfile(files[f]);
+            const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
+            cand += lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start + ck.len + (1 << kLinShift) - 1) -
+                    lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start - W + 1);
+        }
+    }
+    const bool heavy = live && cand > heavy_thr;
+    uint32_t th, tl;
+    const uint32_t oh = block_scan_excl(heavy ? 1u : 0u, s_wave, th);
+    const uint32_t ol = block_scan_excl((live && !heavy) ? 1u : 0u, s_wave, tl);
+    if (threadIdx.x == 0) {
+        s_base[0] = th ? atomicAdd(&counters[0], th) : 0u;
+        s_base[1] = tl ? atomicAdd(&counters[1], tl) : 0u;
+    }
+    __syncthreads();
+    if (!live) return;
+    if (heavy) order[s_base[0] + oh] = (uint32_t)c;
+    else order[(uint32_t)nchunks - 1u - (s_base[1] + ol)] = (uint32_t)c;
+}
+
 __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                 const FileView *__restrict__ files, int nfiles,
                                                 MapParams mp, int W, const double *__restrict__ inv_,
-                                                double *hist) {
+                                                const uint32_t *__restrict__ order, double *hist) {
     __shared__ double s_inv[kInvLds];
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
     for (int i = threadIdx.x; i < kInvLds; i += kWG) s_inv[i] = inv[i]; // host-computed IEEE quotients 1.0/m
     __syncthreads();
-    const int64_t c = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
-    if (c >= nchunks) return;
+    const int64_t slot = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
+    if (slot >= nchunks) return;
     const int lane = threadIdx.x & 63;
-    const CenterChunk ck = chunks[c];
+    const CenterChunk ck = chunks[order[slot]];
     const int32_t p = ck.start + lane;
     const int32_t cend = ck.start + ck.len;
     const int nib = mp.param;

@@ -162,6 +162,7 @@ struct pc_plan {
     DevBuf<Piece> d_pieces;
     DevBuf<OutPiece> d_opieces;
     DevBuf<CenterChunk> d_cchunks;
+    DevBuf<uint32_t> d_corder;
     DevBuf<GatherSeg> d_gsegs;
     DevBuf<GatherChunk> d_gchunks;
     DevBuf<uint32_t> d_tile_items;
@@ -920,9 +921,16 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         // the center gather writes whole slices, including zeros outside the tiles
         HIP_TRY(hipEventRecord(e->ev[2], st));
         const int64_t nchunks = (int64_t)p->cchunks.size();
-        if (nchunks > 0)
+        if (nchunks > 0) {
+            rc = p->d_corder.reserve((size_t)nchunks);
+            if (rc != PC_OK) return rc;
+            HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
+            const int64_t heavy_thr = std::max<int64_t>(2048, 8 * nrec / std::max<int64_t>(nchunks, 1));
+            hipLaunchKernelGGL(k_center_order, dim3((unsigned)((nchunks + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st,
+                               p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W, heavy_thr, p->d_corder.p, e->d_counters.p);
             hipLaunchKernelGGL(k_center, dim3((unsigned)((nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p,
-                               nfiles, mp, W, e->d_inv.p, (double *)p->d_hist.p);
+                               nfiles, mp, W, e->d_inv.p, p->d_corder.p, (double *)p->d_hist.p);
+        }
         HIP_TRY(hipEventRecord(e->ev[3], st));
         HIP_TRY(hipEventRecord(e->ev[4], st));
         launch_gather<double, double>(e, p, (const double *)p->d_hist.p, (double *)p->d_out.p);
