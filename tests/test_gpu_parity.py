@@ -370,3 +370,60 @@ def test_fused_region_statistics(pa, oracle):
     ga.set_mapping(pa.CenterMapFactory())
     with pytest.raises(TypeError):
         ga.count_in_regions(chains[:2])
+
+
+@pytest.mark.parametrize("knobs", [
+    {},                                                   # defaults
+    {"PC_WORK_R": "1024", "PC_PILE": "1000000"},          # every dense window cut into sub-windows
+    {"PC_WORK_R": "1024", "PC_PILE": "1024"},             # pile-up fallback: record slices merged via hist
+    {"PC_TILE_G": "512", "PC_WORK_R": "2048"},            # small windows
+    {"PC_NO_SMALL": "1"},                                 # no single-wave class
+])
+def test_work_list_paths_vs_oracle(pa, oracle, knobs, monkeypatch):
+    """Every scheduling path of the tile kernel (sub-windows, heavy/light/small classes, merged
+    windows, 3 files -> FileView array path) gives the oracle's counts: dense pile-up + sparse
+    annotation + whole-contig and '.' segments + gapped/long reads, all five... integer rules."""
+    from plastid_amd import synth
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(11)
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.003, tx_scale=0.01)      # 300 k reads, 200 tx
+    # a second, sparse file with spliced reads on the same contigs and a third tiny one
+    _, tx4, r4, _ = synth.make_config("C4", scale=0.0001, tx_scale=0.002)
+    names, lens = list(reads.references), list(reads.lengths)
+    sparse = pa.PackedAlignments(r4.tid % len(names), r4.pos % 200000, r4.alen, r4.flags, r4.nblk,
+                                 r4.blk_start, r4.blk_len, references=names, lengths=lens, validate=False)
+    # rebuild runs consistently after the modulo: simplest is to drop gapped structure there
+    order = np.lexsort((sparse.pos, sparse.tid))
+    sparse = pa.PackedAlignments(sparse.tid[order], sparse.pos[order], sparse.alen[order], sparse.flags[order],
+                                 np.minimum(sparse.nblk[order], 1), references=names, lengths=lens)
+    third = reads.subset(np.arange(0, reads.n, 97))
+    # segments: the transcripts, plus whole contigs on '.', plus tiny exons far apart
+    p = tx.plan_arrays(rows=1)
+    extra_tid = np.array([0, 1, 2, 3, 3], np.int32)
+    extra_start = np.array([0, 0, 1000, 50000, 50300], np.int64)
+    extra_end = np.array([lens[0], lens[1], 300000, 50030, 50310], np.int64)
+    extra_strand = np.array([3, 3, 1, 2, 2], np.uint8)
+    for files in ([reads], [reads, sparse, third]):
+        for mapping in [("fiveprime", 12), ("threeprime", 3), ("variable", synth.VARIABLE_OFFSETS),
+                        ("stratified", synth.VARIABLE_OFFSETS, 27, 31)]:
+            eng = engine_for(pa, files, mapping)
+            rows = eng.rows
+            pp = tx.plan_arrays(rows=rows)
+            base = pp["out_elems"]
+            elen = extra_end - extra_start
+            eoff = base + np.concatenate([[0], np.cumsum(elen * rows)[:-1]])
+            tid = np.concatenate([pp["tid"], extra_tid]); start = np.concatenate([pp["start"], extra_start])
+            end = np.concatenate([pp["end"], extra_end]); strand = np.concatenate([pp["strand"], extra_strand])
+            out_off = np.concatenate([pp["out_off"], eoff]); step = np.concatenate([pp["out_step"], np.ones(5, np.int8)])
+            rstride = np.concatenate([pp["row_stride"], elen])
+            total = int(base + (elen * rows).sum())
+            plan = eng.plan(tid, start, end, strand, out_off, step, rstride, total, rows)
+            got = plan.count(np.int64)
+            full = dict(tid=tid, start=start, end=end, strand=strand, out_off=out_off, out_step=step,
+                        row_stride=rstride, out_elems=total)
+            exp, warn = oracle_chain_outputs(oracle, files, spec_for(oracle, mapping), None, full, rows, np.int64)
+            assert np.array_equal(got, exp), (knobs, len(files), mapping)
+            assert np.array_equal(plan.warn_flags(), warn)
+            plan.close()
+            eng.close()
