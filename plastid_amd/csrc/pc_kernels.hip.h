@@ -646,7 +646,7 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
                                                     const uint32_t *__restrict__ tile_items, MapParams mp,
                                                     int G, int tab_lo, int tab_n, uint32_t *hist,
                                                     int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
-                                                    double norm_sum, uint32_t work_cap, int dbg) {
+                                                    double norm_sum, uint32_t work_cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // heavy items sit at the front of the list, light ones at the back (see k_tile_ranges);
     // the sparse-window list is a plain array of its own
@@ -698,7 +698,6 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     __syncthreads();
 
     // ---- the packed record stream: no dependent global loads in this loop
-    uint32_t dbg_acc = 0;
     for (int base = 0; base < npairs; base += WG * U) {
         u32x4 nxt[U];
 #pragma unroll
@@ -706,10 +705,6 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
             const int j = base + WG * U + u * WG + (int)threadIdx.x;
             nxt[u] = (j < npairs) ? src[j] : none;
         }
-        if (dbg & 1) { // DEBUG: stream only
-#pragma unroll
-            for (int u = 0; u < U; ++u) dbg_acc ^= cur[u].x ^ cur[u].y ^ cur[u].z ^ cur[u].w;
-        } else
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = base + u * WG + (int)threadIdx.x;
@@ -758,8 +753,6 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
         hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
     }
     __syncthreads();
-    if (dbg_acc == 0x12345u) hist[0] = dbg_acc;
-    if (dbg & 2) return; // DEBUG: no flush
 
     if (!w.merge) {
         // ---- this workgroup owns [sub_lo, sub_hi) of the window and its bins are complete:

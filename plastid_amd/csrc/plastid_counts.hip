@@ -869,20 +869,18 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const FileView fv0 = e->files[0]->view();
             const FileView fv1 = nfiles > 1 ? e->files[1]->view() : fv0;
             const unsigned grid = (unsigned)cap64;
-            int dbg = 0;
-            if (const char *env = getenv("PC_DEBUG_HIST")) dbg = atoi(env); // profiling experiments only
             const int outmode = e->norm_on ? 2 : (out_dtype == PC_OUT_FLOAT64 ? 1 : 0);
 #define PC_LAUNCH_HIST(K, O)                                                                                          \
     do {                                                                                                              \
         hipLaunchKernelGGL((k_hist_point<K, O, kWG, false>), dim3(grid), dim3(kWG), lds, st, p->d_pieces.p,             \
                            p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, \
                            G, tab_lo, tab_n, (uint32_t *)p->d_hist.p, p->npos, (OutT_<O>::type *)p->d_out.p,            \
-                           e->norm_sum, (uint32_t)cap64, dbg);                                                          \
+                           e->norm_sum, (uint32_t)cap64);                                                               \
         if (cap_small)                                                                                                \
             hipLaunchKernelGGL((k_hist_point<K, O, 64, true>), dim3((unsigned)cap_small), dim3(64), lds_small, st,      \
                                p->d_pieces.p, p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work_small.p,                \
                                e->d_counters.p, p->d_tile_items.p, mp, small_g, tab_lo, tab_n, (uint32_t *)p->d_hist.p, \
-                               p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small, dbg);           \
+                               p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small);                \
     } while (0)
 #define PC_LAUNCH_HIST_O(K)                                                                                           \
     do {                                                                                                              \
