@@ -8,6 +8,8 @@ plan for the whole annotation.  :class:`IntervalTable` is that table; it can be 
 BED text, from ``SegmentChain`` objects, or directly from arrays, and hands back per-chain
 views of the batched result.
 """
+import re
+
 import numpy as np
 
 from .exceptions import DataWarning, warn
@@ -86,6 +88,112 @@ def read_bed(path_or_stream, cls=None):
     return [bed_line_to_chain(l, cls) for l in iter_bed_lines(path_or_stream)]
 
 
+_GTF2_EXON_LIKE = ("exon", "5UTR", "3UTR", "CDS", "start_codon", "stop_codon")
+_GTF2_CDS_LIKE = ("CDS", "start_codon", "stop_codon")
+_GTF2_TOKEN = re.compile(r'\s*([^\s";]+)\s+(?:"((?:[^"\\]|\\.)*)"|([^\s;]+))\s*(?:;|$)')
+
+
+def _gtf2_attributes(text):
+    """Ninth GTF2 column -> dict (``parse_GTF2_tokens``, readers/gff_tokens.py:537-600):
+    ``key "value";`` pairs, values may hold semicolons inside the quotes, repeated keys
+    are joined with a comma."""
+    out = {}
+    for m in _GTF2_TOKEN.finditer(text.strip()):
+        key = m.group(1)
+        val = m.group(2) if m.group(2) is not None else m.group(3)
+        out[key] = "%s,%s" % (out[key], val) if key in out else val
+    return out
+
+
+def iter_gtf2_features(stream):
+    """(chrom, type, start, end, strand, attr) of every data line; coordinates converted
+    from GTF2's 1-based closed to 0-based half-open (readers/gff.py:305-340)."""
+    for line in stream:
+        if not line.strip() or line.startswith("#"):
+            continue
+        items = line.rstrip("\n").split("\t")
+        if len(items) < 9:
+            raise ValueError("GTF2 format requires 9 columns. Found only %s.\n\t    %s" % (len(items), items))
+        yield (items[0], items[2], int(items[3]) - 1, int(items[4]), items[6],
+               _gtf2_attributes(items[8]))
+
+
+def _assemble_gtf2(stream):
+    """Group exon-like features by ``transcript_id`` (``GTF2_TranscriptAssembler``,
+    readers/gff.py:1089-1206): ``exon``/UTR/CDS/codon features build the exon chain (CDS
+    features alone imply the exons), blocks are sorted and overlapping/adjacent ones merged as
+    the ``Transcript`` constructor does (roitools.pyx:1450-1498), transcripts with blocks on
+    several chromosomes or strands are rejected with a ``DataWarning``, and the result is
+    sorted the way |SegmentChains| compare (roitools.pyx:835-853).
+
+    Returns a list of ``(chrom, strand, [(start, end), ...], attr)``."""
+    exons, cds, attrs = {}, {}, {}
+    for chrom, ftype, start, end, strand, attr in stream:
+        if ftype not in _GTF2_EXON_LIKE:
+            continue
+        tname = attr.get("transcript_id")
+        exons.setdefault(tname, []).append((chrom, start, end, strand))
+        if ftype in _GTF2_CDS_LIKE:
+            cds.setdefault(tname, []).append((start, end))
+        common = attrs.get(tname)
+        if common is None:
+            attrs[tname] = dict(attr)
+        else:  # keep what every component agrees on (get_identical_attributes, gff.py:1008-1045)
+            for k in [k for k in common if attr.get(k, None) != common[k]]:
+                del common[k]
+    out = []
+    for tname, blocks in exons.items():
+        if len(set((b[0], b[3]) for b in blocks)) > 1:
+            warn("Rejecting transcript '%s' because it contains exons on multiple chromosomes or strands."
+                 % tname, DataWarning)
+            continue
+        merged = []
+        for _, s, e, _ in sorted(blocks):
+            if merged and s <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], e)
+            else:
+                merged.append([s, e])
+        attr = attrs[tname]
+        attr["type"] = "mRNA"
+        if tname in cds:
+            attr["cds_genome_start"] = min(c[0] for c in cds[tname])
+            attr["cds_genome_end"] = max(c[1] for c in cds[tname])
+        out.append((blocks[0][0], blocks[0][3], [tuple(m) for m in merged], attr))
+    out.sort(key=lambda t: (t[0], t[2][0][0], t[2][-1][1], STRAND_CODE.get(t[1], 3),
+                            sum(e - s for s, e in t[2]), str(t[3].get("transcript_id"))))
+    return out
+
+
+def _open_text(path_or_stream):
+    if isinstance(path_or_stream, str):
+        if path_or_stream.endswith(".gz"):
+            import gzip
+            return gzip.open(path_or_stream, "rt"), True
+        return open(path_or_stream), True
+    return path_or_stream, False
+
+
+def read_gtf2(path_or_stream, cls=None):
+    """Transcripts of a GTF2 file as |SegmentChains| named by ``transcript_id``, in the order
+    ``GTF2_TranscriptAssembler`` returns them for an unsorted file (readers/gff.py:1150-1206)."""
+    from .roitools import GenomicSegment, SegmentChain
+    cls = SegmentChain if cls is None else cls
+    fh, opened = _open_text(path_or_stream)
+    try:
+        rows = _assemble_gtf2(iter_gtf2_features(fh))
+    finally:
+        if opened:
+            fh.close()
+    chains = []
+    for chrom, strand, blocks, attr in rows:
+        chain = cls()
+        chain._set_segments([GenomicSegment(chrom, s, e, strand) for s, e in blocks])
+        chain.attr.update(attr)
+        chain.attr.setdefault("ID", attr.get("transcript_id"))
+        chains.append(chain)
+    return chains
+
+
 class IntervalTable(object):
     """CSR table of chains: exons ``ex_start/ex_end`` (genomic, ascending, non-overlapping) of
     chain ``c`` are ``ex_off[c]:ex_off[c+1]``; ``tid`` indexes ``references``;
@@ -145,6 +253,28 @@ class IntervalTable(object):
         finally:
             if opened:
                 fh.close()
+        return cls(references, None, tid, strand, ex_off, s, e, ids=ids)
+
+    @classmethod
+    def from_gtf2(cls, path_or_stream, references):
+        """Straight from GTF2 text: exon-like features grouped by ``transcript_id`` and merged
+        (see :func:`_assemble_gtf2`), no per-transcript Python objects."""
+        index = {r: i for i, r in enumerate(references)}
+        fh, opened = _open_text(path_or_stream)
+        try:
+            rows = _assemble_gtf2(iter_gtf2_features(fh))
+        finally:
+            if opened:
+                fh.close()
+        tid, strand, ex_off, s, e, ids = [], [], [0], [], [], []
+        for chrom, st, blocks, attr in rows:
+            tid.append(index.get(chrom, -1))
+            strand.append(STRAND_CODE.get(st, 3))
+            for a, b in blocks:
+                s.append(a)
+                e.append(b)
+            ex_off.append(len(s))
+            ids.append(attr.get("transcript_id"))
         return cls(references, None, tid, strand, ex_off, s, e, ids=ids)
 
     # ------------------------------------------------------------------ views

@@ -53,3 +53,43 @@ def test_interval_table_layout_matches_chains():
     assert views[0].shape == (2, 600) and views[1].shape == (2, 30) and views[1][0, 0] == base
     chains = tab.chains()
     assert str(chains[0]) == "chrA:100-200^500-700^800-1100(+)"
+
+
+# ---------------------------------------------------------------------------- GTF2
+def _gtf2_golden():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gtf2_transcripts.json")) as fh:
+        return json.load(fh)
+
+
+def test_gtf2_assembly_matches_reference_golden():
+    """Transcripts, exon structure, CDS bounds, rejected ids and ORDER as the reference's
+    GTF2_TranscriptAssembler gave them (fixture: tests/golden/make_gtf2_golden.py)."""
+    import warnings
+    from plastid_amd.annotation import read_gtf2
+    gold = _gtf2_golden()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        chains = read_gtf2(io.StringIO(gold["gtf2"]))
+    rejected = sorted(str(x.message).split("'")[1] for x in w if "Rejecting" in str(x.message))
+    assert rejected == gold["rejected"]
+    assert all(issubclass(x.category, pa.DataWarning) for x in w)
+    got = [[c.get_name(), str(c), c.attr.get("cds_genome_start"), c.attr.get("cds_genome_end"),
+            c.attr.get("gene_id")] for c in chains]
+    assert got == gold["transcripts"]
+    assert all(c.attr["tag"] == "a;b" for c in chains if c.attr.get("gene_id", "").startswith("g"))
+
+
+def test_interval_table_from_gtf2():
+    gold = _gtf2_golden()
+    import warnings
+    refs = ["chrI", "chrII", "chrM"]  # '2-micron' is not in the array -> tid -1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tab = IntervalTable.from_gtf2(io.StringIO(gold["gtf2"]), refs)
+    assert tab.n == len(gold["transcripts"]) and tab.ids == [r[0] for r in gold["transcripts"]]
+    for c, row in zip(tab.chains(), gold["transcripts"]):
+        if not row[1].startswith("2-micron"):
+            assert str(c) == row[1]
+    assert (tab.tid == -1).sum() == sum(r[1].startswith("2-micron") for r in gold["transcripts"])
+    assert (np.diff(tab.ex_start) > 0)[tab.ex_tx[1:] == tab.ex_tx[:-1]].all()
