@@ -230,8 +230,12 @@ def main():
         counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device="cuda")[0]
 
     # ---------------------------------------------------------------- per-kernel timing (HIP events on the engine's stream)
+    # The timed region above runs the product default (no events: each hipEventRecord costs a few
+    # microseconds of stream time).  The same launches are repeated here with the engine's phase
+    # events switched on; the dominant kernel's average duration feeds the roofline object.
     phases = {"total": 0.0, "worklist": 0.0, "hist": 0.0, "long": 0.0, "gather": 0.0, "zero": 0.0}
-    m = max(3, min(args.steps, 10))
+    m = max(3, min(args.steps, 20))
+    eng.set_profiling(2)
     for _ in range(m):
         plan.launch(out_dtype)
         eng.sync()

@@ -165,9 +165,13 @@ void *pc_total_device_ptr(pc_plan *p);
 int pc_mapped_reads(pc_engine *e, int file, int64_t rec_lo, int64_t rec_hi, int32_t tid,
                     int64_t start, int64_t end, uint8_t strand, uint8_t *mask);
 
-/* last pc_count: milliseconds per phase, measured with HIP events on the
- * engine's stream: [0] total, [1] work-list, [2] histogram/center, [3] long
- * reads, [4] gather, [5] zero-fill.  Returns number of entries written. */
+/* HIP-event timing of pc_count on the engine's stream.  level 0 (default): no events are
+ * recorded; 1: the whole call and the histogram / center kernel; 2: every phase.  Each
+ * recorded event costs a few microseconds of stream time, which is why it is opt-in. */
+int pc_set_profiling(pc_engine *e, int level);
+/* last timed pc_count, milliseconds: [0] total, [1] work-list, [2] histogram/center kernel,
+ * [3] long reads, [4] gather, [5] zero-fill ([1],[3],[4],[5] are 0 below level 2).
+ * Returns number of entries written. */
 int pc_last_timing(pc_engine *e, double *ms, int n);
 /* algorithmic bytes of the last pc_count (SURVEY.md section 8d formula) */
 int64_t pc_last_algorithmic_bytes(pc_engine *e);

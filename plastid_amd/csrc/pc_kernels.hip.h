@@ -29,6 +29,16 @@
 namespace pc {
 
 constexpr int kWG = 256;          // 4 waves of 64
+#ifndef PC_HIST_WG
+#define PC_HIST_WG 256            // workgroup size of the histogram kernel
+#endif
+#ifndef PC_HIST_U
+#define PC_HIST_U 4               // 16-byte loads in flight per lane (x2: register double buffer)
+#endif
+#ifndef PC_LANE_CONTIG
+#define PC_LANE_CONTIG 1          // 1: a lane loads U consecutive 16-byte pairs (64 B); 0: wave-coalesced pairs
+#endif
+constexpr int kHistWG = PC_HIST_WG;
 constexpr int kWave = 64;
 constexpr uint32_t kFlagReverse = 0x01;
 constexpr uint32_t kFlagLong = 0x40;      // engine-internal: span > W, handled by the long-read path
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         const int64_t n = whi - wlo;
         merge = nfiles > 1;
         if (!merge) {
-            while (S < kMaxSub && (G / (S * 2)) >= (1 << kLinShift) && n > R * S) S <<= 1;
+            while (S < kMaxSub && G % (S * 2 << kLinShift) == 0 && n > R * S) S <<= 1; // sub-windows end on index buckets
             if (S == 1) {
                 const bool small = small_g > 0 && (int)tl.span_hi - (int)tl.span_lo <= small_g && n <= small_n &&
                                    (wghi - wglo) <= small_n && (lhi - llo) <= small_n;
@@ -545,14 +555,20 @@ __device__ __forceinline__ void map_both(const MapParams &mp, const HistCfg &c, 
         kr = ok ? (KIND == 0 ? z : a) : -1;
     } else {
         const uint32_t t = (uint32_t)(L - c.tab_lo);
-        const uint32_t e = t < c.tab_n ? ltab[t] : 0xffffffffu;
+        uint32_t e = 0xffffffffu;
+        const bool known = (uint32_t)L < (uint32_t)mp.table_len;
+        if (t < c.tab_n) e = ltab[t];
+        else if (known) { // rare: an aligned length outside the LDS-staged slice of the tables
+            const int gf = ((const int32_t PC_GLOBAL *)mp.fw)[L], gr = ((const int32_t PC_GLOBAL *)mp.rc)[L];
+            e = (uint32_t)(gf < 0 ? 0xffff : gf) | ((uint32_t)(gr < 0 ? 0xffff : gr) << 16);
+        }
         const int f = (e & 0xffffu) == 0xffffu ? -1 : (int)(e & 0xffffu);
         const int r = (e >> 16) == 0xffffu ? -1 : (int)(e >> 16);
         if (KIND == 3) { // :625-638
-            kf = t < c.tab_n ? f : -1;
-            kr = t < c.tab_n ? r : -1;
+            kf = known ? f : -1;
+            kr = known ? r : -1;
         } else { // :765-778: no bad-offset check, read_positions[-1]
-            const bool in = (L >= mp.min_len) & (L <= mp.max_len) & (L >= 1) & (t < c.tab_n);
+            const bool in = (L >= mp.min_len) & (L <= mp.max_len) & (L >= 1) & known;
             kf = in ? (f < 0 ? L - 1 : f) : -1;
             kr = in ? (r < 0 ? L - 1 : r) : -1;
             rowoff = (uint32_t)(L - mp.min_len) * c.G;
@@ -593,6 +609,111 @@ __device__ __forceinline__ void hist_rec(const MapParams &mp, const HistCfg &c, 
     map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
     const int32_t rel = (int32_t)rx - c.win_start;
     hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(rel + kf), (uint32_t)(rel + kr), rowoff, bins);
+}
+
+// ---- table-driven binning (the common case: every aligned length that occurs fits a small
+// LDS table).  Everything that depends only on (aligned length, strand mode) -- the index rule
+// of the mapping function, the size filter, whether the tile has bins for the mode, the
+// stratified row, the window origin -- is folded once per work item into an 8-byte entry
+//     ftab[L*4 + mode] = { k - win_start  (0x40000000: no bin for this pair),  LDS byte offset of the mode's bins }
+// so that binning an ungapped record is: one ds_read_b64, add, and-or, compare, ds_add.
+constexpr uint32_t kBadMask = ((kFlagExcluded | kFlagLong) << 16) | 0xfe000000u; // excluded, long-span or nblk >= 2
+constexpr uint32_t kNoBin = 0x40000000u;
+constexpr int kOpStage = 32;    // output pieces of a window staged in LDS ahead of the epilogue
+constexpr int kFastMaxLen = 447; // table of (kFastMaxLen+1) x 32 B = 14 KiB
+
+template <int KIND>
+__device__ __forceinline__ void fast_table_init(const MapParams &mp, const HistCfg &c, uint32_t mode_mask, int lo, int hi,
+                                                u32x2 *ftab, uint32_t bins_byte, int tid, int nthreads) {
+    for (int i = tid; i < (hi - lo + 1) * kModes; i += nthreads) {
+        const int L = lo + (i >> 2), m = i & 3;
+        int row;
+        const int k = map_kleft<KIND>(mp, L, (m & 1) != 0, row); // modes 1 and 3 use the reverse rule
+        const bool have = (mode_mask >> m) & 1u;
+        const int slot = __popc(mode_mask & ((1u << m) - 1u));
+        const bool ok = have & (k >= 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
+        u32x2 e;
+        e.x = ok ? (uint32_t)(k - c.win_start) : kNoBin;
+        e.y = ok ? bins_byte + (uint32_t)(slot * mp.rows + row) * c.G * 4u : 0u;
+        ftab[L * kModes + m] = e;
+    }
+}
+
+// Bin N ungapped records (x = pos, y = meta).  All table reads of a strand-mode pass are issued
+// before its first ds_add: the compiler cannot move an LDS read across an LDS atomic on its own
+// (table and bins share the LDS), and one read-wait-add chain per record would serialise on
+// the LDS latency.  e.y is the byte address of the mode's first bin.
+template <int N>
+__device__ __forceinline__ void fast_bin(const u32x2 *ftab, uint32_t mode_mask, uint32_t G, const uint32_t (&x)[N],
+                                         const uint32_t (&y)[N], uint32_t *smem) {
+    const char *tab = (const char *)ftab;
+    uint32_t a[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = (y[i] & 0xffffu) << 5; // 32 B of entries per aligned length
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        // pass 0: '+' / '-' (mutually exclusive per read: entry picked by the read's strand);
+        // pass 1: '.' (all reads, forward rule); pass 2: all reads, reverse rule
+        if (!(mode_mask & (pass == 0 ? 3u : (pass == 1 ? 4u : 8u)))) continue;
+        u32x2 e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            e[i] = *(const u32x2 *)(tab + (pass == 0 ? (a[i] | ((y[i] >> 13) & 8u)) : a[i] + (pass == 1 ? 16u : 24u)));
+        // byte address of every record's bin (~0: none), then one ds_add per run of equal
+        // addresses: the records of a lane are consecutive in the coordinate-sorted stream, so
+        // the reads piled on one position collapse into a single LDS atomic per lane
+        uint32_t addr[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const uint32_t d = x[i] + e[i].x;
+            addr[i] = ((d | (y[i] & kBadMask)) < G) ? e[i].y + (d << 2) : ~0u;
+        }
+        uint32_t cnt = 1;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const bool last = (i == N - 1) || (addr[i + 1 < N ? i + 1 : i] != addr[i]);
+            if (last & (addr[i] != ~0u)) atomicAdd((uint32_t *)((char *)smem + addr[i]), cnt);
+            cnt = last ? 1u : cnt + 1u;
+        }
+    }
+}
+
+// The packed record stream of one work item: 16-byte pairs, every wave owns 4 KiB per batch
+// (U x 64 lanes x 16 B, the U loads of a lane 1 KiB apart -> one address register and immediate
+// offsets), register double buffer.  Batches that lie wholly inside the range are loaded
+// without per-lane predicates; lanes past the end of the last batch hold an excluded record.
+template <int KIND, int WG, bool FAST, int U>
+__device__ __forceinline__ void stream_packed(const u32x4 PC_GLOBAL *src, int npairs, u32x4 (&cur)[U], const u32x4 none,
+                                              const MapParams &mp, const HistCfg &c, const uint32_t *ltab,
+                                              const u32x2 *ftab, uint32_t mode_mask, uint32_t *smem, uint32_t *bins) {
+    const int lane_j = PC_LANE_CONTIG ? (int)threadIdx.x * U : (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
+    constexpr int US = PC_LANE_CONTIG ? 1 : 64; // pairs between the U loads of a lane
+    for (int base = 0; base < npairs; base += WG * U) {
+        u32x4 nxt[U];
+        const int nb = base + WG * U;
+        const u32x4 PC_GLOBAL *q = src + nb + lane_j;
+        if (nb + WG * U <= npairs) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = q[u * US];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = (nb + lane_j + u * US < npairs) ? q[u * US] : none;
+        }
+        if (FAST) {
+            uint32_t x[2 * U], y[2 * U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { x[2 * u] = cur[u].x; y[2 * u] = cur[u].y; x[2 * u + 1] = cur[u].z; y[2 * u + 1] = cur[u].w; }
+            fast_bin<2 * U>(ftab, mode_mask, c.G, x, y, smem);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                hist_rec<KIND>(mp, c, ltab, cur[u].x, cur[u].y, true, bins);
+                hist_rec<KIND>(mp, c, ltab, cur[u].z, cur[u].w, true, bins);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
 }
 
 // position of read.positions[k] given the first two runs in registers
@@ -644,7 +765,8 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
                                                     const WorkItem *__restrict__ work,
                                                     const uint32_t *__restrict__ nwork,
                                                     const uint32_t *__restrict__ tile_items, MapParams mp,
-                                                    int G, int tab_lo, int tab_n, uint32_t *hist,
+                                                    int G, int max_slots, int tab_lo, int tab_n, int fast_lo,
+                                                    int fast_hi, uint32_t *hist,
                                                     int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
                                                     double norm_sum, uint32_t work_cap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -655,20 +777,30 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     const WorkItem w = work[blockIdx.x < n_heavy ? blockIdx.x : work_cap - 1u - (blockIdx.x - n_heavy)];
     const GFile fv = w.file == 0 ? gfile(file0) : (w.file == 1 ? gfile(file1) : gfile(files[w.file]));
 
-    // ---- first batch of the record stream (and the first gapped records): 16-byte pairs,
-    // one global_load_dwordx4 per lane = 1 KiB per wave instruction, U per lane in flight
-    constexpr int U = 4;
+    // ---- first batch of the record stream (and the first gapped records).  The stream is read
+    // as 16-byte record pairs; a range that starts or ends on an odd record has its outer half
+    // pair handled apart: the leading one is masked below, the trailing one is a single record.
+    constexpr int U = PC_HIST_U;
     const int64_t pair_lo = w.lo >> 1;
-    const int npairs = (int)(((w.hi + 1) >> 1) - pair_lo);
-    const int lo_odd = (int)(w.lo & 1), hi_odd = (int)(w.hi & 1);
+    const int lo_odd = (int)(w.lo & 1);
+    const bool has_tail = (w.hi & 1) && (w.hi - 1 >= w.lo);
+    const int npairs = (int)((w.hi >> 1) - pair_lo); // whole pairs [pair_lo, hi/2)
     const u32x4 PC_GLOBAL *src = fv.rec4 + pair_lo;
     const u32x4 none = {0u, kFlagExcluded << 16, 0u, kFlagExcluded << 16};
     u32x4 cur[U];
+    {
+        const int lane_j = PC_LANE_CONTIG ? (int)threadIdx.x * U : (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
+        constexpr int US = PC_LANE_CONTIG ? 1 : 64;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int j = u * WG + (int)threadIdx.x;
-        cur[u] = (j < npairs) ? src[j] : none;
+        for (int u = 0; u < U; ++u) cur[u] = (lane_j + u * US < npairs) ? src[lane_j + u * US] : none;
     }
+    u32x2 tail = {0u, kFlagExcluded << 16};
+    if (has_tail && threadIdx.x == 0) tail = fv.rec[w.hi - 1];
+    // the window's output pieces (48 B each) are fetched now and parked in LDS, so that the
+    // epilogue does not start with a chain of dependent global loads
+    const int nstage = w.merge ? 0 : (int)min(w.op_end - w.op_begin, (uint32_t)kOpStage);
+    u32x4 opq = {0u, 0u, 0u, 0u};
+    if ((int)threadIdx.x < nstage * 3) opq = ((const u32x4 PC_GLOBAL *)(opieces + w.op_begin))[threadIdx.x];
     const int64_t gj0 = w.glo + threadIdx.x;
     const u32x4 gfirst = (gj0 < w.ghi) ? fv.gap_rec[gj0] : none;
 
@@ -682,8 +814,14 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     c.frange = (mp.filt_on && mp.filt_max != -1) ? (uint32_t)(mp.filt_max - mp.filt_min) : 0xffffu - c.fmin;
     c.tab_lo = tab_lo;
     c.tab_n = (uint32_t)tab_n;
-    uint32_t *ltab = smem;                      // packed offset tables first (variable / stratified rules) ...
-    uint32_t *bins = smem + ((tab_n + 3) & ~3); // ... then the bins
+    // LDS: [table-driven entries, indexed by aligned length from 0][packed offset tables][bins]
+    const bool fast = fast_hi >= 0;
+    const int fwords = fast ? (fast_hi + 1) * kModes * 2 : 0;
+    u32x2 *ftab = (u32x2 *)smem;
+    uint32_t *ltab = smem + fwords;                      // variable / stratified rules: gapped and long-span reads
+    uint32_t *bins = smem + fwords + ((tab_n + 3) & ~3);
+    OutPiece *s_op = (OutPiece *)(bins + (size_t)max_slots * mp.rows * G); // 16-byte aligned: every part is a multiple of 4 words
+    if ((int)threadIdx.x < nstage * 3) ((u32x4 *)s_op)[threadIdx.x] = opq;
     {   // only bins in [span_lo, span_hi) are ever read back: clear just those
         const int span = (int)w.span_hi - (int)w.span_lo, nrow = nslots * mp.rows;
         for (int i = threadIdx.x; i < nrow * span; i += WG) bins[(i / span) * G + w.span_lo + (i % span)] = 0;
@@ -695,25 +833,18 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
             ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
     }
+    if (fast) fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)((char *)bins - (char *)smem), (int)threadIdx.x, WG);
+    if (lo_odd && threadIdx.x == 0) cur[0].y = kFlagExcluded << 16; // record lo-1 shares the first pair
     __syncthreads();
 
     // ---- the packed record stream: no dependent global loads in this loop
-    for (int base = 0; base < npairs; base += WG * U) {
-        u32x4 nxt[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = base + WG * U + u * WG + (int)threadIdx.x;
-            nxt[u] = (j < npairs) ? src[j] : none;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = base + u * WG + (int)threadIdx.x;
-            const bool in = j < npairs;
-            hist_rec<KIND>(mp, c, ltab, cur[u].x, cur[u].y, in & !((j == 0) & (lo_odd != 0)), bins);
-            hist_rec<KIND>(mp, c, ltab, cur[u].z, cur[u].w, in & !((j == npairs - 1) & (hi_odd != 0)), bins);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    if (fast) {
+        stream_packed<KIND, WG, true, U>(src, npairs, cur, none, mp, c, ltab, ftab, w.mode_mask, smem, bins);
+        const uint32_t tx[1] = {tail.x}, ty[1] = {tail.y};
+        fast_bin<1>(ftab, w.mode_mask, c.G, tx, ty, smem);
+    } else {
+        stream_packed<KIND, WG, false, U>(src, npairs, cur, none, mp, c, ltab, ftab, w.mode_mask, smem, bins);
+        hist_rec<KIND>(mp, c, ltab, tail.x, tail.y, true, bins);
     }
 
     // ---- gapped records (deletions, short introns): their aligned runs live in a side
@@ -743,8 +874,8 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
         const uint32_t meta = g.y, hi = meta >> 16;
         const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
         const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-        i32x2 b0 = {0, 1}, b1 = {0, 1};
-        if (in) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
+        i32x2 b0 = {(int32_t)g.x, L}, b1 = {0, 0}; // an ungapped read longer than the halo has no stored runs
+        if (in && nb >= 2) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
         int kf, kr;
         uint32_t rowoff;
         map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
@@ -760,15 +891,25 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
         // 5'->3' reversal, int64/float64, normalisation) -- SegmentChain.get_counts,
         // roitools.pyx:3259-3271
         for (uint32_t oi = w.op_begin; oi < w.op_end; ++oi) {
-            const OutPiece o = opieces[oi];
+            const uint32_t k = oi - w.op_begin;
+            const OutPiece o = k < (uint32_t)kOpStage ? s_op[k] : opieces[oi];
             const int rel = o.start - w.win_start;
             const int i0 = w.sub_lo > rel ? w.sub_lo - rel : 0;
             const int i1 = (w.sub_hi - rel) < o.len ? (w.sub_hi - rel) : o.len;
+            const int slot = __popc(w.mode_mask & ((1u << o.mode) - 1u));
             for (int r = 0; r < mp.rows; ++r) {
-                const uint32_t *srcb = bins + c.base[o.mode] + r * G + rel;
+                const uint32_t *srcb = bins + (slot * mp.rows + r) * G + rel;
                 typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
                 if (o.step != 0) {
-                    for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(srcb[i], norm_sum);
+                    int i = i0 + (int)threadIdx.x;
+                    for (; i + 3 * WG < i1; i += 4 * WG) { // four LDS reads in flight per lane
+                        const uint32_t v0 = srcb[i], v1 = srcb[i + WG], v2 = srcb[i + 2 * WG], v3 = srcb[i + 3 * WG];
+                        dst[(int64_t)o.step * i] = out_conv<OUTMODE>(v0, norm_sum);
+                        dst[(int64_t)o.step * (i + WG)] = out_conv<OUTMODE>(v1, norm_sum);
+                        dst[(int64_t)o.step * (i + 2 * WG)] = out_conv<OUTMODE>(v2, norm_sum);
+                        dst[(int64_t)o.step * (i + 3 * WG)] = out_conv<OUTMODE>(v3, norm_sum);
+                    }
+                    for (; i < i1; i += WG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>(srcb[i], norm_sum);
                 } else {
                     unsigned long long part = 0;
                     for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) part += srcb[i];

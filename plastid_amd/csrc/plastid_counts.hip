@@ -84,6 +84,7 @@ struct StagedFile {
     DevBuf<uint32_t> lin_tab, glin_tab, llin_tab, plin_tab;
     DevBuf<int64_t> lin_off;
     std::vector<int64_t> len_hist; // records per aligned length (host), for cheap warn pre-checks
+    int len_min = 65536, len_max = -1; // aligned lengths present
     FileView view() const {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
@@ -121,6 +122,8 @@ struct pc_engine {
     DevBuf<Unmappable> d_unmap;
     double last_ms[6] = {0, 0, 0, 0, 0, 0};
     bool timing_valid = false;
+    int prof_level = 0;      // pc_set_profiling: 0 no events, 1 whole call + histogram/center kernel, 2 every phase
+    int timed_level = 0;     // level the last pc_count was recorded with
     int64_t last_alg_bytes = 0;
 
     MapParams params() const {
@@ -356,6 +359,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     sf->n = n;
     sf->nrun = nrun;
     sf->len_hist.swap(len_hist);
+    for (int L = 0; L < 65536; ++L)
+        if (sf->len_hist[(size_t)L]) { sf->len_min = std::min(sf->len_min, L); sf->len_max = std::max(sf->len_max, L); }
     std::vector<uint32_t> long_idx;
     std::vector<uint4> long_rec;
     std::vector<int32_t> long_tid, long_pmax;
@@ -399,7 +404,12 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     std::vector<int64_t> lin_off((size_t)ntid + 1, 0);
     for (int t = 0; t < ntid; ++t) {
         const int64_t b = tid_bounds[(size_t)t], en = tid_bounds[(size_t)t + 1];
-        const int64_t nb = en > b ? ((int64_t)pos[en - 1] >> kLinShift) + 1 : 0;
+        // buckets up to the last record start -- and up to the furthest end of a long-span read,
+        // which can reach windows that lie beyond every record start
+        int64_t last = en > b ? (int64_t)pos[en - 1] : -1;
+        const int64_t lb = long_bounds[(size_t)t], le = long_bounds[(size_t)t + 1];
+        if (le > lb) last = std::max<int64_t>(last, (int64_t)long_pmax[(size_t)le - 1] - 1);
+        const int64_t nb = last >= 0 ? (last >> kLinShift) + 1 : 0;
         lin_off[(size_t)t + 1] = lin_off[(size_t)t] + nb + 1;
     }
     std::vector<uint32_t> lin_tab((size_t)lin_off[(size_t)ntid]), glin_tab((size_t)lin_off[(size_t)ntid]);
@@ -619,8 +629,11 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         int64_t g = (48 * 1024) / (4LL * nmodes * rows);
         int G = 256;
         int gmax = 4096;
-        if (const char *env = getenv("PC_TILE_G")) gmax = std::max(256, atoi(env)); // tuning knob
         while (G * 2 <= g && G * 2 <= gmax) G *= 2;
+        if (const char *env = getenv("PC_TILE_G")) { // tuning knob: any multiple of 256 within the budget
+            const int want = std::max(256, atoi(env) / 256 * 256);
+            if (want <= g) G = want;
+        }
         if ((int64_t)4 * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
         p->G = G;
     }
@@ -815,7 +828,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     int64_t nrec = 0, nextra = 0;
     for (auto *f : e->files) { nrec += f->n; nextra += f->nrun; }
 
-    HIP_TRY(hipEventRecord(e->ev[0], st));
+    if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[0], st));
     // Outputs are written exactly once by the tile kernels.  Only positions that belong to no
     // tile (unknown contig, clipped coordinates) or gaps the caller left between slices need a
     // zero fill; the compact histogram of the point rules is kept all-zero between calls.
@@ -826,7 +839,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     if (!center && hist_bytes && !(p->hist_clean && p->hist_kind == 0)) {
         HIP_TRY(hipMemsetAsync(p->d_hist.p, 0, hist_bytes, st));
     }
-    HIP_TRY(hipEventRecord(e->ev[1], st));
+    if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[1], st));
 
     if (!center) {
         p->hist_kind = 0;
@@ -854,17 +867,27 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
                                e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
                                e->d_work_small.p, small_g, small_n);
-            HIP_TRY(hipEventRecord(e->ev[2], st));
+            if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
+            int lmin = 65536, lmax = -1;
+            for (auto *f : e->files) { lmin = std::min(lmin, f->len_min); lmax = std::max(lmax, f->len_max); }
             int tab_lo = 0, tab_n = 0;
-            if (e->kind == PC_MAP_VAR5 || e->kind == PC_MAP_STRAT5) {
-                int lmin = e->table_len, lmax = -1;
-                for (auto *f : e->files)
-                    for (int L = 0; L < e->table_len; ++L)
-                        if (f->len_hist[(size_t)L]) { lmin = std::min(lmin, L); lmax = std::max(lmax, L); }
-                if (lmax >= lmin) { tab_lo = lmin; tab_n = lmax - lmin + 1; }
+            if ((e->kind == PC_MAP_VAR5 || e->kind == PC_MAP_STRAT5) && lmax >= lmin) {
+                tab_lo = lmin;
+                tab_n = std::min(lmax, e->table_len - 1) - lmin + 1;
+                tab_n = std::max(0, std::min(tab_n, 1024)); // longer reads look the tables up in HBM
             }
-            const size_t lds = ((size_t)p->max_slots * p->rows * G + (size_t)((tab_n + 3) & ~3)) * sizeof(uint32_t);
+            const size_t stage_words = (size_t)kOpStage * sizeof(OutPiece) / sizeof(uint32_t); // output pieces parked in LDS
+            const size_t bins_words = (size_t)p->max_slots * p->rows * G + (size_t)((tab_n + 3) & ~3) + stage_words;
+            // table-driven binning when every aligned length present fits the LDS table
+            int fast_lo = 0, fast_hi = -1;
+            if (lmax >= lmin && lmax <= kFastMaxLen && !getenv("PC_NO_FAST") &&
+                (bins_words + (size_t)(lmax + 1) * kModes * 2) * sizeof(uint32_t) <= 64 * 1024) {
+                fast_lo = lmin;
+                fast_hi = lmax;
+            }
+            const size_t fwords = fast_hi >= 0 ? (size_t)(fast_hi + 1) * kModes * 2 : 0;
+            const size_t lds = (bins_words + fwords) * sizeof(uint32_t);
             if (lds > 64 * 1024) return fail(PC_ERR_ARG, "pc_count: LDS budget exceeded (%zu bytes)", lds);
             const FileView fv0 = e->files[0]->view();
             const FileView fv1 = nfiles > 1 ? e->files[1]->view() : fv0;
@@ -872,14 +895,16 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const int outmode = e->norm_on ? 2 : (out_dtype == PC_OUT_FLOAT64 ? 1 : 0);
 #define PC_LAUNCH_HIST(K, O)                                                                                          \
     do {                                                                                                              \
-        hipLaunchKernelGGL((k_hist_point<K, O, kWG, false>), dim3(grid), dim3(kWG), lds, st, p->d_pieces.p,             \
+        hipLaunchKernelGGL((k_hist_point<K, O, kHistWG, false>), dim3(grid), dim3(kHistWG), lds, st, p->d_pieces.p,             \
                            p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, \
-                           G, tab_lo, tab_n, (uint32_t *)p->d_hist.p, p->npos, (OutT_<O>::type *)p->d_out.p,            \
+                           G, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, (uint32_t *)p->d_hist.p, p->npos,                        \
+                           (OutT_<O>::type *)p->d_out.p,                                                                \
                            e->norm_sum, (uint32_t)cap64);                                                               \
         if (cap_small)                                                                                                \
             hipLaunchKernelGGL((k_hist_point<K, O, 64, true>), dim3((unsigned)cap_small), dim3(64), lds_small, st,      \
                                p->d_pieces.p, p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work_small.p,                \
-                               e->d_counters.p, p->d_tile_items.p, mp, small_g, tab_lo, tab_n, (uint32_t *)p->d_hist.p, \
+                               e->d_counters.p, p->d_tile_items.p, mp, small_g, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, \
+                               (uint32_t *)p->d_hist.p,                                                                 \
                                p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small);                \
     } while (0)
 #define PC_LAUNCH_HIST_O(K)                                                                                           \
@@ -888,7 +913,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         else if (outmode == 1) PC_LAUNCH_HIST(K, 1);                                                                  \
         else PC_LAUNCH_HIST(K, 2);                                                                                    \
     } while (0)
-            const size_t lds_small = ((size_t)p->max_slots * p->rows * std::max(small_g, 1) + (size_t)((tab_n + 3) & ~3)) * sizeof(uint32_t);
+            const size_t lds_small = ((size_t)p->max_slots * p->rows * std::max(small_g, 1) + (size_t)((tab_n + 3) & ~3) + fwords + stage_words) * sizeof(uint32_t);
             switch (e->kind) {
             case PC_MAP_FIVE: PC_LAUNCH_HIST_O(0); break;
             case PC_MAP_THREE: PC_LAUNCH_HIST_O(1); break;
@@ -897,8 +922,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             }
 #undef PC_LAUNCH_HIST_O
 #undef PC_LAUNCH_HIST
-            HIP_TRY(hipEventRecord(e->ev[3], st));
-            HIP_TRY(hipEventRecord(e->ev[4], st));
+            if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
+            if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
             // tiles that were split into several work items: lay out from the merged histogram
 #define PC_LAUNCH_SPLIT(O)                                                                                            \
     hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)ntiles), dim3(kWG), 0, st, p->d_tiles.p, p->d_pieces.p,      \
@@ -909,15 +934,15 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             else PC_LAUNCH_SPLIT(2);
 #undef PC_LAUNCH_SPLIT
         } else {
-            HIP_TRY(hipEventRecord(e->ev[2], st));
-            HIP_TRY(hipEventRecord(e->ev[3], st));
-            HIP_TRY(hipEventRecord(e->ev[4], st));
+            if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
+            if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
+            if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
         }
     } else {
         p->hist_kind = 1;
         p->hist_clean = false;
         // the center gather writes whole slices, including zeros outside the tiles
-        HIP_TRY(hipEventRecord(e->ev[2], st));
+        if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
         const int64_t nchunks = (int64_t)p->cchunks.size();
         if (nchunks > 0) {
             rc = p->d_corder.reserve((size_t)nchunks);
@@ -929,15 +954,16 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             hipLaunchKernelGGL(k_center, dim3((unsigned)((nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p,
                                nfiles, mp, W, e->d_inv.p, p->d_corder.p, (double *)p->d_hist.p);
         }
-        HIP_TRY(hipEventRecord(e->ev[3], st));
-        HIP_TRY(hipEventRecord(e->ev[4], st));
+        if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
+        if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
         launch_gather<double, double>(e, p, (const double *)p->d_hist.p, (double *)p->d_out.p);
     }
-    HIP_TRY(hipEventRecord(e->ev[5], st));
+    if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[5], st));
     HIP_TRY(hipGetLastError());
     p->last_dtype = out_dtype;
     p->counted = true;
-    e->timing_valid = true;
+    e->timing_valid = e->prof_level > 0;
+    e->timed_level = e->prof_level;
     // records once (8 B) + extra runs (8 B) + segments (24 B) + outputs once (8 B)
     e->last_alg_bytes = nrec * 8 + (nextra > 0 ? (nextra - 0) * 8 : 0) + p->nseg * 24 + p->covered * 8;
     return PC_OK;
@@ -984,18 +1010,29 @@ int pc_total(pc_engine *e, pc_plan *p, void *host_out8) {
     return PC_OK;
 }
 
+int pc_set_profiling(pc_engine *e, int level) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    if (level < 0 || level > 2) return fail(PC_ERR_ARG, "pc_set_profiling: level must be 0, 1 or 2");
+    e->prof_level = level;
+    e->timing_valid = false;
+    return PC_OK;
+}
+
 int pc_last_timing(pc_engine *e, double *ms, int n) {
     if (!e || !ms || n <= 0) return fail(PC_ERR_ARG, "pc_last_timing: bad arguments");
-    if (!e->timing_valid) return fail(PC_ERR_STATE, "pc_last_timing: nothing counted yet");
+    if (!e->timing_valid) return fail(PC_ERR_STATE, "pc_last_timing: no timed pc_count yet (see pc_set_profiling)");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventSynchronize(e->ev[5]));
     float t;
+    for (double &v : e->last_ms) v = 0.0;
     HIP_TRY(hipEventElapsedTime(&t, e->ev[0], e->ev[5])); e->last_ms[0] = t;
-    HIP_TRY(hipEventElapsedTime(&t, e->ev[1], e->ev[2])); e->last_ms[1] = t;
     HIP_TRY(hipEventElapsedTime(&t, e->ev[2], e->ev[3])); e->last_ms[2] = t;
-    HIP_TRY(hipEventElapsedTime(&t, e->ev[3], e->ev[4])); e->last_ms[3] = t;
-    HIP_TRY(hipEventElapsedTime(&t, e->ev[4], e->ev[5])); e->last_ms[4] = t;
-    HIP_TRY(hipEventElapsedTime(&t, e->ev[0], e->ev[1])); e->last_ms[5] = t;
+    if (e->timed_level >= 2) {
+        HIP_TRY(hipEventElapsedTime(&t, e->ev[1], e->ev[2])); e->last_ms[1] = t;
+        HIP_TRY(hipEventElapsedTime(&t, e->ev[3], e->ev[4])); e->last_ms[3] = t;
+        HIP_TRY(hipEventElapsedTime(&t, e->ev[4], e->ev[5])); e->last_ms[4] = t;
+        HIP_TRY(hipEventElapsedTime(&t, e->ev[0], e->ev[1])); e->last_ms[5] = t;
+    }
     const int k = std::min(n, 6);
     for (int i = 0; i < k; ++i) ms[i] = e->last_ms[i];
     return k;

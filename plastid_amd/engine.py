@@ -108,8 +108,12 @@ class Engine(object):
     def sync(self):
         check(self._lib.pc_sync(self._h))
 
+    def set_profiling(self, level):
+        """HIP-event timing of every count: 0 off (default), 1 total + main kernel, 2 all phases."""
+        check(self._lib.pc_set_profiling(self._h, int(level)))
+
     def last_timing(self):
-        """ms per phase of the last count: dict(total, worklist, hist, long, gather, zero)."""
+        """ms per phase of the last timed count: dict(total, worklist, hist, long, gather, zero)."""
         ms = np.zeros(6, np.float64)
         k = self._lib.pc_last_timing(self._h, _ptr(ms), 6)
         if k < 0:

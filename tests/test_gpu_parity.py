@@ -257,6 +257,55 @@ def test_pileup_and_multifile(pa, oracle):
             eng.close()
 
 
+def test_long_aligned_lengths(pa, oracle):
+    """Aligned lengths beyond the LDS entry table (L > 447) switch the tile kernel to its
+    arithmetic binning path; short-only data uses the table.  Both must match the oracle,
+    including the nofilter/'.' strand modes and odd record ranges."""
+    rng = np.random.default_rng(23)
+    names, lens = ["a", "b"], [60000, 9000]
+    for lmax in (40, 3000):
+        n = 50001
+        tid = np.sort((rng.random(n) < 0.1).astype(np.int32))
+        alen = np.where(rng.random(n) < 0.02, rng.integers(1, lmax + 1, n), rng.integers(18, 41, n))
+        pos = np.empty(n, np.int64)
+        for t in (0, 1):
+            m = tid == t
+            pos[m] = np.sort(rng.integers(0, lens[t] - 3100, int(m.sum())))
+        rev = rng.random(n) < 0.5
+        f1 = pa.PackedAlignments.from_ungapped(tid, pos, alen, rev, references=names, lengths=lens)
+        f_allrev = pa.PackedAlignments.from_ungapped(tid, pos, alen, np.ones(n, bool), references=names, lengths=lens)
+        seg_tid = np.array([0, 0, 0, 1, 0, 0], np.int32)
+        seg_start = np.array([0, 100, 20000, 0, 31000, 7], np.int64)
+        seg_end = np.array([60000, 30000, 20001, 9000, 33333, 4100], np.int64)
+        seg_strand = np.array([1, 2, 3, 3, 2 | 0x10, 1 | 0x10], np.uint8)
+        lens_ = seg_end - seg_start
+        out_off = np.concatenate([[0], np.cumsum(lens_)[:-1]])
+        voff = {26: 12, 27: 12, 28: 13, 29: 13, 30: 14, 31: 13, 600: 300, "default": 13}
+        for mapping in [("fiveprime", 12), ("threeprime", 30), ("variable", voff), ("stratified", voff, 20, 32)]:
+            for sf in (None, (20, 500)):
+                eng = engine_for(pa, [f1], mapping, sf)
+                rows = eng.rows
+                plan = eng.plan(seg_tid, seg_start, seg_end, seg_strand, out_off * rows, np.ones(len(lens_), np.int8),
+                                lens_, int(lens_.sum()) * rows, rows)
+                spec = spec_for(oracle, mapping, sf)
+                # the oracle has no "unfiltered" strand code: all reads under the forward rule is what
+                # '.' does, all reads under the reverse rule is a '-' query over reads all flagged reverse
+                ostrand = np.where(seg_strand == (1 | 0x10), 3, seg_strand & 3).astype(np.uint8)
+                arrays, warn = oracle.count_segments(aln_dict([f1]), spec, seg_tid, seg_start, seg_end, ostrand)
+                nf = np.nonzero(seg_strand == (2 | 0x10))[0]
+                arr2, warn2 = oracle.count_segments(aln_dict([f_allrev]), spec, seg_tid[nf], seg_start[nf], seg_end[nf],
+                                                    ostrand[nf])
+                for k, s_ in enumerate(nf):
+                    arrays[s_] = arr2[k]
+                    warn[s_] = warn2[k]
+                exp = np.concatenate([a.reshape(-1) for a in arrays])
+                got = plan.count(np.int64)
+                assert np.array_equal(got, exp), (lmax, mapping, sf)
+                assert np.array_equal(plan.warn_flags(), warn)
+                plan.close()
+                eng.close()
+
+
 def test_inverse_table_is_ieee(pa):
     """1.0/m used by the center kernel is the host's correctly rounded quotient;
     a lone read of aligned length m contributes exactly 1.0/m at each position."""
@@ -378,6 +427,9 @@ def test_fused_region_statistics(pa, oracle):
     {"PC_WORK_R": "1024", "PC_PILE": "1024"},             # pile-up fallback: record slices merged via hist
     {"PC_TILE_G": "512", "PC_WORK_R": "2048"},            # small windows
     {"PC_NO_SMALL": "1"},                                 # no single-wave class
+    {"PC_NO_FAST": "1"},                                  # arithmetic binning instead of the LDS entry table
+    {"PC_NO_FAST": "1", "PC_WORK_R": "1024", "PC_PILE": "1024"},
+    {"PC_TILE_G": "768", "PC_WORK_R": "512", "PC_PILE": "100000"},  # odd window size, odd/even record ranges
 ])
 def test_work_list_paths_vs_oracle(pa, oracle, knobs, monkeypatch):
     """Every scheduling path of the tile kernel (sub-windows, heavy/light/small classes, merged
