@@ -823,8 +823,13 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     OutPiece *s_op = (OutPiece *)(bins + (size_t)max_slots * mp.rows * G); // 16-byte aligned: every part is a multiple of 4 words
     if ((int)threadIdx.x < nstage * 3) ((u32x4 *)s_op)[threadIdx.x] = opq;
     {   // only bins in [span_lo, span_hi) are ever read back: clear just those
-        const int span = (int)w.span_hi - (int)w.span_lo, nrow = nslots * mp.rows;
-        for (int i = threadIdx.x; i < nrow * span; i += WG) bins[(i / span) * G + w.span_lo + (i % span)] = 0;
+        // (16-byte stores over the span rounded out to 4 words; no per-element division)
+        const int lo4 = (int)w.span_lo >> 2, hi4 = ((int)w.span_hi + 3) >> 2, nrow = nslots * mp.rows;
+        const u32x4 zero4 = {0u, 0u, 0u, 0u};
+        for (int r = 0; r < nrow; ++r) {
+            u32x4 *row4 = (u32x4 *)(bins + r * G);
+            for (int i = lo4 + (int)threadIdx.x; i < hi4; i += WG) row4[i] = zero4;
+        }
     }
     if (KIND >= 3) {
         const int32_t PC_GLOBAL *fw = (const int32_t PC_GLOBAL *)mp.fw, *rc = (const int32_t PC_GLOBAL *)mp.rc;

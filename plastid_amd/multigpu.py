@@ -75,3 +75,160 @@ def barrier():
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+class GenomePartition(object):
+    """Cut one job into `world` contiguous genome ranges balanced by record count.
+
+    Rank ``r`` gets (a) from every file the records that start inside its range, extended to the
+    left by the largest reference span of any record (read-only duplication: a read that starts
+    before the cut can still map inside the range), and (b) every queried segment *cut at the
+    range borders*.  Cutting is exact for all five mapping rules: a read is counted at a position
+    it aligns to, so whenever it counts inside a piece it also overlaps that piece, i.e. the
+    reference's ``fetch`` would have returned it for the piece (genome_array.py:800-823), and
+    records keep their relative order inside a rank (center sums stay bit-identical).
+    No count vector crosses ranks; per-chain statistics are completed with one small all-reduce
+    (:func:`allreduce_chain_sums`).
+
+    `segments` is a dict with ``tid, start, end, strand, out_off, out_step, row_stride`` (the
+    arguments of ``pc_plan_create``, e.g. ``IntervalTable.plan_arrays()``).
+    """
+
+    def __init__(self, files, segments, world, sample=1 << 20):
+        self.files = list(files)
+        self.world = int(world)
+        seg = {k: np.asarray(v) for k, v in segments.items() if k in
+               ("tid", "start", "end", "strand", "out_off", "out_step", "row_stride")}
+        self.seg = seg
+        ntid = len(self.files[0].references) if self.files else 0
+        self.ntid = ntid
+        # linear genome coordinate: contigs laid end to end, each as long as anything that touches it
+        span_max = 1
+        extent = np.zeros(ntid, np.int64)
+        for f in self.files:
+            if f.lengths is not None:
+                extent = np.maximum(extent, np.asarray(f.lengths, np.int64)[:ntid])
+            if f.n:
+                end = f.ref_end()
+                span_max = max(span_max, int((end - f.pos).max()))
+                np.maximum.at(extent, f.tid, end)
+        known = (seg["tid"] >= 0) & (seg["tid"] < ntid)
+        if known.any():
+            np.maximum.at(extent, seg["tid"][known], seg["end"][known].astype(np.int64))
+        self.halo = span_max
+        self.tid_off = np.zeros(ntid + 1, np.int64)
+        np.cumsum(extent + 1, out=self.tid_off[1:])
+        self._keys = [self.tid_off[f.tid] + f.pos for f in self.files]
+        # cut points at record-count quantiles (of a sample of every file's keys)
+        parts = []
+        for k in self._keys:
+            step = max(1, len(k) // sample)
+            parts.append(k[::step])
+        allk = np.sort(np.concatenate(parts)) if parts and sum(len(x) for x in parts) else np.zeros(0, np.int64)
+        if len(allk) and self.world > 1:
+            q = (np.arange(1, self.world) * len(allk)) // self.world
+            self.cuts = allk[q].astype(np.int64)
+        else:
+            self.cuts = np.full(max(self.world - 1, 0), self.tid_off[-1], np.int64)
+        self._build_pieces(known)
+
+    def cut_coordinates(self):
+        """The cut points as ``(tid, pos)`` pairs."""
+        t = np.searchsorted(self.tid_off, self.cuts, side="right") - 1
+        t = np.clip(t, 0, max(self.ntid - 1, 0))
+        return [(int(a), int(c - self.tid_off[a])) for a, c in zip(t, self.cuts)]
+
+    def _build_pieces(self, known):
+        seg, cuts = self.seg, self.cuts
+        nseg = len(seg["tid"])
+        ks = np.zeros(nseg, np.int64)
+        ke = np.zeros(nseg, np.int64)
+        ks[known] = self.tid_off[seg["tid"][known]] + seg["start"][known]
+        ke[known] = self.tid_off[seg["tid"][known]] + seg["end"][known]
+        r0 = np.searchsorted(cuts, ks, side="right")
+        r1 = np.where(ke > ks, np.searchsorted(cuts, ke, side="left"), r0)
+        r0[~known] = 0   # segments on contigs the files do not have are all-zero: rank 0 keeps them whole
+        r1[~known] = 0
+        npiece = (r1 - r0 + 1).astype(np.int64)
+        owner = np.repeat(np.arange(nseg), npiece)
+        first = np.zeros(nseg + 1, np.int64)
+        np.cumsum(npiece, out=first[1:])
+        rank = r0[owner] + (np.arange(len(owner)) - first[:-1][owner])
+        lo_cut = np.where(rank > 0, cuts[np.clip(rank - 1, 0, max(len(cuts) - 1, 0))] if len(cuts) else 0, np.iinfo(np.int64).min)
+        hi_cut = np.where(rank < self.world - 1, cuts[np.clip(rank, 0, max(len(cuts) - 1, 0))] if len(cuts) else 0,
+                          np.iinfo(np.int64).max)
+        a = np.maximum(ks[owner], lo_cut)
+        b = np.minimum(ke[owner], hi_cut)
+        kn = known[owner]
+        delta = np.where(kn, a - ks[owner], 0)
+        start = seg["start"][owner].astype(np.int64) + delta
+        end = np.where(kn, start + (b - a), seg["end"][owner].astype(np.int64))
+        step = seg["out_step"][owner].astype(np.int64)
+        self.piece = dict(
+            rank=rank.astype(np.int64), owner=owner, tid=seg["tid"][owner].astype(np.int32), start=start, end=end,
+            strand=seg["strand"][owner].astype(np.uint8), out_off=seg["out_off"][owner].astype(np.int64) + step * delta,
+            out_step=seg["out_step"][owner].astype(np.int8), row_stride=seg["row_stride"][owner].astype(np.int64))
+
+    # ------------------------------------------------------------------ per rank
+    def record_ranges(self, rank):
+        """``[(i0, i1), ...]`` per file: the records rank `rank` stages."""
+        out = []
+        for k in self._keys:
+            lo = 0 if rank == 0 else int(np.searchsorted(k, self.cuts[rank - 1] - self.halo, side="left"))
+            hi = len(k) if rank == self.world - 1 else int(np.searchsorted(k, self.cuts[rank], side="left"))
+            out.append((lo, max(hi, lo)))
+        return out
+
+    def records(self, rank):
+        return [f.slice(i0, i1) for f, (i0, i1) in zip(self.files, self.record_ranges(rank))]
+
+    def segments(self, rank, layout="global"):
+        """Segment pieces of `rank` as ``pc_plan_create`` arrays.  ``layout="global"`` keeps the
+        caller's output coordinates (every rank fills its part of one global layout: right for
+        summed slices); ``"local"`` packs the pieces into a rank-local buffer (forward order, one
+        block of ``rows x len`` per piece) -- see :meth:`scatter_local`."""
+        m = np.nonzero(self.piece["rank"] == rank)[0]
+        out = {k: self.piece[k][m] for k in ("tid", "start", "end", "strand", "out_off", "out_step", "row_stride")}
+        out["piece_index"] = m
+        if layout == "local":
+            ln = out["end"] - out["start"]
+            out["local_len"] = ln
+        return out
+
+    def local_plan_arrays(self, rank, rows=1):
+        """Rank-local layout: pieces back to back, ``[rows, len]`` each, genome order inside."""
+        sg = self.segments(rank, "local")
+        ln = sg["local_len"]
+        off = np.zeros(len(ln) + 1, np.int64)
+        np.cumsum(ln * rows, out=off[1:])
+        return dict(tid=sg["tid"], start=sg["start"], end=sg["end"], strand=sg["strand"], out_off=off[:-1].copy(),
+                    out_step=np.ones(len(ln), np.int8), row_stride=ln.astype(np.int64), out_elems=int(off[-1]),
+                    piece_index=sg["piece_index"])
+
+    def scatter_local(self, global_out, rank, local_out, rows=1):
+        """Place a rank-local result (see :meth:`local_plan_arrays`) into the caller's global layout
+        (host-side assembly of chains whose exons straddle a cut)."""
+        lp = self.local_plan_arrays(rank, rows)
+        for j, pi in enumerate(lp["piece_index"]):
+            n = int(lp["end"][j] - lp["start"][j])
+            if n <= 0:
+                continue
+            g0, st, rs = int(self.piece["out_off"][pi]), int(self.piece["out_step"][pi]), int(self.piece["row_stride"][pi])
+            src = local_out[lp["out_off"][j]:lp["out_off"][j] + n * rows].reshape(rows, n)
+            for r in range(rows):
+                if st == 0:
+                    global_out[g0 + r * rs] += src[r].sum()
+                else:
+                    global_out[g0 + r * rs + st * np.arange(n)] = src[r]
+        return global_out
+
+
+def allreduce_chain_sums(values, device="cpu"):
+    """Complete per-chain statistics whose chains straddle a range border: one all-reduce (RCCL
+    ``ncclSum`` over xGMI on GPUs) of an int64 vector with one slot per chain."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.array(values, dtype=np.int64, copy=True)).to(device)  # never aliases the caller's array
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()

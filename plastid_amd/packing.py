@@ -405,6 +405,19 @@ class PackedAlignments(object):
                                 mapped=len(idx), read_objects=ro)
 
 
+    def slice(self, i0, i1):
+        """Records ``[i0, i1)`` as a new :class:`PackedAlignments` (views, no Python loop): a genome
+        range of a coordinate-sorted file is a contiguous record range."""
+        i0, i1 = int(i0), int(i1)
+        off = self.block_offsets()
+        b0, b1 = int(off[i0]), int(off[i1])
+        ro = None if self._read_objects is None else self._read_objects[i0:i1]
+        return PackedAlignments(self.tid[i0:i1], self.pos[i0:i1], self.alen[i0:i1], self.flags[i0:i1],
+                                self.nblk[i0:i1], self.blk_start[b0:b1], self.blk_len[b0:b1],
+                                references=self.references, lengths=self.lengths, mapped=i1 - i0,
+                                read_objects=ro, validate=False)
+
+
 def concat_file_major(files):
     """Concatenate packed files into the single file-major record list the
     reference iterates (``itertools.chain`` over ``bamfile.fetch``,

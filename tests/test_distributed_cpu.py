@@ -61,3 +61,98 @@ def test_two_rank_sharding_and_total_reduction(tmp_path):
     # shards are disjoint and cover all chains
     ids = np.concatenate([multigpu.shard_chains(tx.n, r, world) for r in range(world)])
     assert np.array_equal(ids, np.arange(tx.n))
+
+
+# ---------------------------------------------------------------------------- genome-range partition
+def _oracle_global(oracle, files, spec, p, rows, dtype):
+    from plastid_amd.packing import concat_file_major
+    arrays, _ = oracle.count_segments(concat_file_major(files), spec, p["tid"], p["start"], p["end"], p["strand"])
+    out = np.zeros(p["out_elems"], dtype)
+    for s, a in enumerate(arrays):
+        a2 = a.reshape(rows, -1)
+        for r in range(rows):
+            out[p["out_off"][s] + r * p["row_stride"][s] + p["out_step"][s].astype(np.int64) * np.arange(a2.shape[1])] = a2[r]
+    return out
+
+
+def test_genome_partition_is_exact_for_every_rule():
+    """Cutting records and segments at record-count quantiles of the genome and counting every
+    range on its own reproduces the unpartitioned result bit for bit (center float sums included),
+    for spliced human-scale reads whose halo spans introns."""
+    from oracle import oracle
+    from plastid_amd import multigpu, synth
+    from plastid_amd.packing import concat_file_major
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.003)
+    second = reads.subset(np.arange(0, reads.n, 7))
+    files = [reads, second]
+    for kind, args, rows in (("fiveprime", (12,), 1), ("center", (3,), 1),
+                             ("stratified", (0, synth.VARIABLE_OFFSETS, 27, 31), 5)):
+        spec = oracle.mapping_spec(kind, *args)
+        dtype = np.float64 if kind == "center" else np.int64
+        p = tx.plan_arrays(rows=rows)
+        want = _oracle_global(oracle, files, spec, p, rows, dtype)
+        for world in (2, 5):
+            part = multigpu.GenomePartition(files, p, world)
+            assert len(part.cut_coordinates()) == world - 1
+            got = np.zeros(p["out_elems"], dtype)
+            staged = 0
+            for r in range(world):
+                mine = part.records(r)
+                staged += sum(f.n for f in mine)
+                lp = part.local_plan_arrays(r, rows)
+                arr, _ = oracle.count_segments(concat_file_major(mine), spec, lp["tid"], lp["start"], lp["end"], lp["strand"])
+                loc = np.concatenate([a.reshape(-1) for a in arr]) if len(arr) else np.zeros(0, dtype)
+                assert len(loc) == lp["out_elems"]
+                part.scatter_local(got, r, loc, rows)
+            assert np.array_equal(got, want), (kind, world)
+            assert staged >= sum(f.n for f in files)                      # halo duplicates, never drops
+            # pieces tile every segment exactly once
+            ln = np.zeros(len(p["tid"]), np.int64)
+            np.add.at(ln, part.piece["owner"], part.piece["end"] - part.piece["start"])
+            assert np.array_equal(ln, p["end"] - p["start"])
+
+
+def _partition_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    from plastid_amd import multigpu, synth
+    from plastid_amd.packing import concat_file_major
+    multigpu.init("gloo")
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.003)
+    # per-chain sums (out_step 0: the fused region statistics layout), chains straddle the cut
+    p = tx.plan_arrays(rows=1)
+    seg = dict(p, out_off=tx.ex_tx.astype(np.int64), out_step=np.zeros(len(p["tid"]), np.int8),
+               row_stride=np.ones(len(p["tid"]), np.int64))
+    part = multigpu.GenomePartition([reads], seg, world)
+    sg = part.segments(rank)
+    arr, _ = oracle.count_segments(concat_file_major(part.records(rank)), oracle.mapping_spec("threeprime", 0),
+                                   sg["tid"], sg["start"], sg["end"], sg["strand"])
+    sums = np.zeros(tx.n, np.int64)
+    for j, a in enumerate(arr):
+        sums[sg["out_off"][j]] += a.sum()
+    total = multigpu.allreduce_chain_sums(sums)
+    np.save(os.path.join(out_dir, "sums%d.npy" % rank), total)
+    np.save(os.path.join(out_dir, "part%d.npy" % rank), sums)
+
+
+def test_two_rank_genome_partition_chain_sums(tmp_path):
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_partition_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    tot = [np.load(os.path.join(str(tmp_path), "sums%d.npy" % r)) for r in range(world)]
+    par = [np.load(os.path.join(str(tmp_path), "part%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(tot[0], tot[1]) and np.array_equal(tot[0], par[0] + par[1])
+    assert ((par[0] > 0) & (par[1] > 0)).any()        # at least one chain really straddles the cut
+    from oracle import oracle
+    from plastid_amd import synth
+    from plastid_amd.packing import concat_file_major
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.003)
+    p = tx.plan_arrays(rows=1)
+    arr, _ = oracle.count_segments(concat_file_major([reads]), oracle.mapping_spec("threeprime", 0), p["tid"],
+                                   p["start"], p["end"], p["strand"])
+    want = np.zeros(tx.n, np.int64)
+    for s, a in enumerate(arr):
+        want[tx.ex_tx[s]] += a.sum()
+    assert np.array_equal(tot[0], want)

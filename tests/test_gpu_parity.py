@@ -306,6 +306,56 @@ def test_long_aligned_lengths(pa, oracle):
                 eng.close()
 
 
+def test_genome_partition_through_the_engine(pa, oracle):
+    """every genome range counted by its own engine instance (what one rank per GPU does)
+    and assembled on the host equals the single-engine result; per-chain sums complete by addition."""
+    from plastid_amd import multigpu, synth
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0005, tx_scale=0.005)
+    for mapping, rows in ((("fiveprime", 12), 1), (("center", 2), 1), (("stratified", synth.VARIABLE_OFFSETS, 27, 31), 5)):
+        center = mapping[0] == "center"
+        dtype = np.float64 if center else np.int64
+        p = tx.plan_arrays(rows=rows)
+        eng = engine_for(pa, [reads], mapping)
+        plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"],
+                        p["out_elems"], rows)
+        want = plan.count(dtype)
+        plan.close()
+        eng.close()
+        world = 4
+        part = multigpu.GenomePartition([reads], p, world)
+        got = np.zeros(p["out_elems"], dtype)
+        for r in range(world):
+            lp = part.local_plan_arrays(r, rows)
+            eng = engine_for(pa, part.records(r), mapping)
+            plan = eng.plan(lp["tid"], lp["start"], lp["end"], lp["strand"], lp["out_off"], lp["out_step"],
+                            lp["row_stride"], lp["out_elems"], rows)
+            part.scatter_local(got, r, plan.count(dtype), rows)
+            plan.close()
+            eng.close()
+        assert np.array_equal(got, want), mapping
+    # fused per-chain sums: each rank fills its share of one [n_chains] vector; the all-reduce is a sum
+    p = tx.plan_arrays(rows=1)
+    seg = dict(p, out_off=tx.ex_tx.astype(np.int64), out_step=np.zeros(len(p["tid"]), np.int8),
+               row_stride=np.ones(len(p["tid"]), np.int64))
+    eng = engine_for(pa, [reads], ("threeprime", 0))
+    plan = eng.plan(seg["tid"], seg["start"], seg["end"], seg["strand"], seg["out_off"], seg["out_step"],
+                    seg["row_stride"], tx.n, 1)
+    want = plan.count(np.int64)
+    plan.close()
+    eng.close()
+    part = multigpu.GenomePartition([reads], seg, 3)
+    acc = np.zeros(tx.n, np.int64)
+    for r in range(3):
+        sg = part.segments(r)
+        eng = engine_for(pa, part.records(r), ("threeprime", 0))
+        plan = eng.plan(sg["tid"], sg["start"], sg["end"], sg["strand"], sg["out_off"], sg["out_step"],
+                        sg["row_stride"], tx.n, 1)
+        acc += plan.count(np.int64)
+        plan.close()
+        eng.close()
+    assert np.array_equal(acc, want)
+
+
 def test_inverse_table_is_ieee(pa):
     """1.0/m used by the center kernel is the host's correctly rounded quotient;
     a lone read of aligned length m contributes exactly 1.0/m at each position."""
