@@ -19,6 +19,7 @@ echo 'def colored(s,*a,**k): return s' > stubs/termcolor/__init__.py
 printf 'class SeqRecord(object):\n    def __init__(self,*a,**k): pass\n' > stubs/Bio/SeqRecord.py
 echo 'class TwoBitFile(object): pass' > stubs/twobitreader/__init__.py
 echo 'class BigWigReader(object): pass' > plastid/readers/bigwig.py      # real one needs the Kent C library
+echo 'class BigBedReader(object): pass' > plastid/readers/bigbed.py      # idem (only needed to import bin/psite.py)
 # numpy-2 / Cython-3 type aliases only (no arithmetic touched)
 sed -i -e 's/^INT    = numpy.int$/INT = numpy.int_/' -e 's/^FLOAT  = numpy.float$/FLOAT = numpy.float64/' -e 's/^LONG   = numpy.long$/LONG = numpy.int64/' \
   -e 's/^ctypedef numpy.int_t    INT_t/ctypedef long INT_t/' -e 's/^ctypedef numpy.float_t  FLOAT_t/ctypedef double FLOAT_t/' \
