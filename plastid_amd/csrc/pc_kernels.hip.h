@@ -947,9 +947,12 @@ template <int OUTMODE>
 __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ tiles,
                                                       const Piece *__restrict__ pieces,
                                                       const OutPiece *__restrict__ opieces,
-                                                      const uint32_t *__restrict__ tile_items, int rows,
+                                                      uint32_t *tile_items, uint32_t *counters, int rows,
                                                       uint32_t *hist, int64_t hist_row_stride,
                                                       typename OutT_<OUTMODE>::type *out, double norm_sum) {
+    // last kernel of a call: leave the work-list counters and the per-tile item counts zeroed,
+    // so that the next call needs no memset launches in front of k_tile_ranges
+    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
     if (tile_items[blockIdx.x] == 0u) return; // only windows that were merged through the histogram
     const Tile tl = tiles[blockIdx.x];
     for (uint32_t oi = tl.op_begin; oi < tl.op_end; ++oi) {
@@ -974,6 +977,7 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
             for (int i = threadIdx.x; i < pc_.len; i += kWG) dst[i] = 0u;
         }
     }
+    if (threadIdx.x == 0) tile_items[blockIdx.x] = 0u;
 }
 
 // ---------------------------------------------------------------- k_center

@@ -118,6 +118,7 @@ struct pc_engine {
     // scratch for counting
     DevBuf<WorkItem> d_work, d_work_small;
     DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
+    bool counters_zero = false; // left zeroed by the last kernel of a point-rule count
     DevBuf<double> d_partial;
     DevBuf<Unmappable> d_unmap;
     double last_ms[6] = {0, 0, 0, 0, 0, 0};
@@ -169,6 +170,7 @@ struct pc_plan {
     DevBuf<GatherSeg> d_gsegs;
     DevBuf<GatherChunk> d_gchunks;
     DevBuf<uint32_t> d_tile_items;
+    bool tile_items_zero = false;
     DevBuf<uint8_t> d_hist; // uint32 or double
     DevBuf<uint8_t> d_out;  // int64 or double
     DevBuf<uint8_t> d_total;
@@ -861,8 +863,11 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const int64_t cap_small = small_g ? (int64_t)ntiles * nfiles : 0;
             rc = e->d_work_small.reserve((size_t)std::max<int64_t>(cap_small, 1));
             if (rc != PC_OK) return rc;
-            HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
-            HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
+            // both are left zeroed by k_gather_split, the last kernel of the previous call
+            if (!e->counters_zero) HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
+            if (!p->tile_items_zero) HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
+            e->counters_zero = false;
+            p->tile_items_zero = false;
             const int64_t nthreads = (int64_t)ntiles * nfiles; // one thread per (tile, file)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
                                e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
@@ -927,12 +932,14 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // tiles that were split into several work items: lay out from the merged histogram
 #define PC_LAUNCH_SPLIT(O)                                                                                            \
     hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)ntiles), dim3(kWG), 0, st, p->d_tiles.p, p->d_pieces.p,      \
-                       p->d_opieces.p, p->d_tile_items.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,                    \
+                       p->d_opieces.p, p->d_tile_items.p, e->d_counters.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,   \
                        (OutT_<O>::type *)p->d_out.p, e->norm_sum)
             if (outmode == 0) PC_LAUNCH_SPLIT(0);
             else if (outmode == 1) PC_LAUNCH_SPLIT(1);
             else PC_LAUNCH_SPLIT(2);
 #undef PC_LAUNCH_SPLIT
+            e->counters_zero = true;
+            p->tile_items_zero = true;
         } else {
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
@@ -948,6 +955,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             rc = p->d_corder.reserve((size_t)nchunks);
             if (rc != PC_OK) return rc;
             HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
+            e->counters_zero = false;
             const int64_t heavy_thr = std::max<int64_t>(2048, 8 * nrec / std::max<int64_t>(nchunks, 1));
             hipLaunchKernelGGL(k_center_order, dim3((unsigned)((nchunks + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st,
                                p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W, heavy_thr, p->d_corder.p, e->d_counters.p);
@@ -1073,6 +1081,7 @@ int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
             rc = e->d_unmap.reserve(cap);
             if (rc != PC_OK) return rc;
             HIP_TRY(hipMemsetAsync(e->d_counters.p + 1, 0, sizeof(uint32_t), e->stream));
+            e->counters_zero = false;
             hipLaunchKernelGGL(k_unmappable, dim3((unsigned)((f->n + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, f->view(), mp, e->ntid,
                                e->d_unmap.p, cap, e->d_counters.p + 1);
             uint32_t cnt = 0;
