@@ -178,10 +178,15 @@ def main():
     # ---------------------------------------------------------------- GPU
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    multigpu.init("nccl", device=torch.device("cuda", local_rank))  # RCCL
+    # one rank per GPU over RCCL.  PC_BENCH_BACKEND=gloo is a rehearsal aid only: it lets the
+    # multi-rank flow run on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("PC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    tdev = "cuda" if backend == "nccl" else "cpu"
+    torch.cuda.set_device(dev_index)
+    multigpu.init(backend, device=torch.device("cuda", dev_index))  # "nccl" is RCCL on ROCm
     from plastid_amd.engine import Engine
-    eng = Engine(local_rank)
+    eng = Engine(dev_index)
     t0 = time.perf_counter()
     eng.set_alignments([reads])
     stage_s = time.perf_counter() - t0
@@ -221,13 +226,13 @@ def main():
     eng.sync()
     torch.cuda.synchronize()
     barrier()
-    elapsed = multigpu.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    elapsed = multigpu.max_over_ranks(time.perf_counter() - t0, device=tdev)
 
     # summary totals: the only collective (RCCL all-reduce over xGMI)
     n_records_all, counts_all, positions_all = multigpu.allreduce_int_totals(
-        [int(reads.n), int(total_counts) if not center else 0, int(p["out_elems"])], device="cuda")
+        [int(reads.n), int(total_counts) if not center else 0, int(p["out_elems"])], device=tdev)
     if center:
-        counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device="cuda")[0]
+        counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device=tdev)[0]
 
     # ---------------------------------------------------------------- per-kernel timing (HIP events on the engine's stream)
     # The timed region above runs the product default (no events: each hipEventRecord costs a few

@@ -253,3 +253,23 @@ def test_synthetic_configs_are_seeded_and_valid():
             hit[p["out_off"][s] + p["out_step"][s].astype(np.int64) * np.arange(n)] += 1
         assert hit.min() == 1 and hit.max() == 1
     assert synth.mapping_factory(("stratified", synth.VARIABLE_OFFSETS, 25, 35)).shape == [11]
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/plastid_counts.h is the drop-in boundary: it must compile as C99 and as C++ on
+    its own (no torch / HIP types), and declare exactly the symbols the ctypes shim binds."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "plastid_counts.h")
+    src = tmp_path / "use.c"
+    src.write_text('#include "plastid_counts.h"\nint main(void) { return pc_abi_version() == PC_ABI_VERSION ? 0 : 1; }\n')
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        if shutil.which(cc) is None:
+            pytest.skip("no %s" % cc)
+        lang = ["-x", "c"] if cc == "gcc" else ["-x", "c++"]
+        subprocess.check_call([cc, std, "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.dirname(hdr)] + lang + [str(src)])
+    from plastid_amd import _lib
+    declared = set(re.findall(r"\b(pc_[a-z_0-9]+)\s*\(", open(hdr).read()))
+    assert declared == set(_lib.SIGNATURES)
