@@ -269,6 +269,21 @@ __device__ __forceinline__ int map_kleft(const MapParams &mp, int L, bool rev_ru
     return -1;
 }
 
+// same, with the offset-table entry of (L, rule) already in a register (`tabval`)
+template <int KIND>
+__device__ __forceinline__ int map_kleft_val(const MapParams &mp, int L, bool rev_rule, int &row, int tabval) {
+    if (KIND == 3) {
+        row = 0;
+        return L >= mp.table_len ? -1 : tabval;
+    } else if (KIND == 4) {
+        row = 0;
+        if (L < mp.min_len || L > mp.max_len || L < 1 || L >= mp.table_len) return -1;
+        row = L - mp.min_len;
+        return tabval < 0 ? L - 1 : tabval;
+    }
+    return map_kleft<KIND>(mp, L, rev_rule, row);
+}
+
 __device__ __forceinline__ int map_kleft_dyn(const MapParams &mp, int L, bool rev_rule, int &row) {
     switch (mp.kind) {
     case 0: return map_kleft<0>(mp, L, rev_rule, row);
@@ -624,11 +639,14 @@ constexpr int kFastMaxLen = 447; // table of (kFastMaxLen+1) x 32 B = 14 KiB
 
 template <int KIND>
 __device__ __forceinline__ void fast_table_init(const MapParams &mp, const HistCfg &c, uint32_t mode_mask, int lo, int hi,
-                                                u32x2 *ftab, uint32_t bins_byte, int tid, int nthreads) {
+                                                u32x2 *ftab, uint32_t bins_byte, int tid, int nthreads, int pre_f,
+                                                int pre_r) {
     for (int i = tid; i < (hi - lo + 1) * kModes; i += nthreads) {
         const int L = lo + (i >> 2), m = i & 3;
         int row;
-        const int k = map_kleft<KIND>(mp, L, (m & 1) != 0, row); // modes 1 and 3 use the reverse rule
+        // modes 1 and 3 use the reverse rule; the first round's table values were fetched at kernel start
+        const int k = i == tid ? map_kleft_val<KIND>(mp, L, (m & 1) != 0, row, (m & 1) ? pre_r : pre_f)
+                               : map_kleft<KIND>(mp, L, (m & 1) != 0, row);
         const bool have = (mode_mask >> m) & 1u;
         const int slot = __popc(mode_mask & ((1u << m) - 1u));
         const bool ok = have & (k >= 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
@@ -772,9 +790,21 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // heavy items sit at the front of the list, light ones at the back (see k_tile_ranges);
     // the sparse-window list is a plain array of its own
+    // The grid spans the whole list capacity and block b serves slot b (heavy slots [0, n_heavy),
+    // light slots [cap - n_light, cap), nothing in between), so the item is requested together with
+    // the counters instead of after them: one dependent round trip less per workgroup.
     const uint32_t n_heavy = SMALL ? nwork[2] : nwork[0], n_light = SMALL ? 0u : nwork[1];
-    if (blockIdx.x >= n_heavy + n_light) return;
-    const WorkItem w = work[blockIdx.x < n_heavy ? blockIdx.x : work_cap - 1u - (blockIdx.x - n_heavy)];
+    const WorkItem w = work[blockIdx.x];
+    // offset-table values this thread needs for the LDS tables (variable / stratified rules): they
+    // depend on kernel arguments only and travel together with the work item
+    int pre_f = -1, pre_r = -1, lt_f = -1, lt_r = -1;
+    if (KIND >= 3) {
+        const int32_t PC_GLOBAL *fw = (const int32_t PC_GLOBAL *)mp.fw, *rc = (const int32_t PC_GLOBAL *)mp.rc;
+        if ((int)threadIdx.x < tab_n) { lt_f = fw[tab_lo + threadIdx.x]; lt_r = rc[tab_lo + threadIdx.x]; }
+        const int Lp = fast_lo + (int)(threadIdx.x >> 2);
+        if (Lp <= fast_hi && Lp < mp.table_len) { pre_f = fw[Lp]; pre_r = rc[Lp]; }
+    }
+    if (!(blockIdx.x < n_heavy || blockIdx.x >= work_cap - n_light)) return;
     const GFile fv = w.file == 0 ? gfile(file0) : (w.file == 1 ? gfile(file1) : gfile(files[w.file]));
 
     // ---- first batch of the record stream (and the first gapped records).  The stream is read
@@ -834,11 +864,12 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     if (KIND >= 3) {
         const int32_t PC_GLOBAL *fw = (const int32_t PC_GLOBAL *)mp.fw, *rc = (const int32_t PC_GLOBAL *)mp.rc;
         for (int i = threadIdx.x; i < tab_n; i += WG) {
-            const int f = fw[tab_lo + i], r = rc[tab_lo + i];
+            const bool first = i == (int)threadIdx.x;
+            const int f = first ? lt_f : fw[tab_lo + i], r = first ? lt_r : rc[tab_lo + i];
             ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
     }
-    if (fast) fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)((char *)bins - (char *)smem), (int)threadIdx.x, WG);
+    if (fast) fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)((char *)bins - (char *)smem), (int)threadIdx.x, WG, pre_f, pre_r);
     if (lo_odd && threadIdx.x == 0) cur[0].y = kFlagExcluded << 16; // record lo-1 shares the first pair
     __syncthreads();
 
