@@ -45,6 +45,21 @@ constexpr uint32_t kFlagLong = 0x40;      // engine-internal: span > W, handled 
 constexpr uint32_t kFlagExcluded = 0x80;
 constexpr int kGatherChunk = 1024;
 constexpr int kLinShift = 7;              // linear-index bucket = 128 genome positions
+constexpr int kStreamMaxLen = 255;        // aligned lengths the 4-byte record stream can carry
+
+// The record stream the tile kernel reads is 4 bytes per record:
+//   bits 0-15  low half of pos (the high half is implied by the window: every record a window
+//              scans lies within +-32 K positions of its start)
+//   bits 16-23 aligned length L (<= kStreamMaxLen)
+//   bit  24    reverse strand
+//   bit  31    skip: excluded by a host-side filter, or binned from a side list instead (gapped,
+//              long-span, or longer than kStreamMaxLen)
+constexpr uint32_t kStreamSkip = 0x80000000u;
+__host__ __device__ inline uint32_t stream_word(uint32_t pos, uint32_t meta) {
+    const uint32_t L = meta & 0xffffu, fl = (meta >> 16) & 0xffu, nb = meta >> 24;
+    const bool skip = (fl & (kFlagExcluded | kFlagLong)) != 0u || nb >= 2u || L > (uint32_t)kStreamMaxLen;
+    return (pos & 0xffffu) | (skip ? kStreamSkip : (L << 16)) | ((fl & kFlagReverse) << 24);
+}
 
 // strand modes of a query interval
 //   0: '+'  keeps forward reads, forward index rule
@@ -55,6 +70,7 @@ constexpr int kModes = 4;
 
 struct FileView {
     const uint2 *rec;
+    const uint32_t *stream;         // 4-byte record stream (see stream_word), padded to a multiple of 4 with skip words
     const uint32_t *blk_off;
     const int2 *blk;
     const int64_t *tid_bounds;      // ntid+1
@@ -87,7 +103,7 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 struct GFile {
     const u32x2 PC_GLOBAL *rec;
-    const u32x4 PC_GLOBAL *rec4;
+    const u32x4 PC_GLOBAL *stream4; // the 4-byte record stream, four records per 16-byte load
     const uint32_t PC_GLOBAL *blk_off;
     const i32x2 PC_GLOBAL *blk;
     const int64_t PC_GLOBAL *tid_bounds;
@@ -111,7 +127,7 @@ struct GFile {
 __device__ __forceinline__ GFile gfile(const FileView &v) {
     GFile g;
     g.rec = (const u32x2 PC_GLOBAL *)v.rec;
-    g.rec4 = (const u32x4 PC_GLOBAL *)v.rec;
+    g.stream4 = (const u32x4 PC_GLOBAL *)v.stream;
     g.blk_off = (const uint32_t PC_GLOBAL *)v.blk_off;
     g.blk = (const i32x2 PC_GLOBAL *)v.blk;
     g.tid_bounds = (const int64_t PC_GLOBAL *)v.tid_bounds;
@@ -610,32 +626,16 @@ __device__ __forceinline__ void hist_bin(const HistCfg &c, bool valid, bool rev,
     }
 }
 
-// ungapped record of the packed stream (gapped ones come from the gapped list, long-span
-// ones from the long-span list)
-template <int KIND>
-__device__ __forceinline__ void hist_rec(const MapParams &mp, const HistCfg &c, const uint32_t *ltab, uint32_t rx,
-                                         uint32_t meta, bool inrange, uint32_t *bins) {
-    const int L = (int)(meta & 0xffffu);
-    const uint32_t hi = meta >> 16;                   // flags | nblk << 8
-    const uint32_t bad = (hi & (kFlagExcluded | kFlagLong)) | (hi >> 9); // excluded, long or nblk >= 2
-    const bool valid = inrange & (bad == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-    int kf, kr;
-    uint32_t rowoff;
-    map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
-    const int32_t rel = (int32_t)rx - c.win_start;
-    hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(rel + kf), (uint32_t)(rel + kr), rowoff, bins);
-}
-
-// ---- table-driven binning (the common case: every aligned length that occurs fits a small
-// LDS table).  Everything that depends only on (aligned length, strand mode) -- the index rule
-// of the mapping function, the size filter, whether the tile has bins for the mode, the
-// stratified row, the window origin -- is folded once per work item into an 8-byte entry
-//     ftab[L*4 + mode] = { k - win_start  (0x40000000: no bin for this pair),  LDS byte offset of the mode's bins }
-// so that binning an ungapped record is: one ds_read_b64, add, and-or, compare, ds_add.
-constexpr uint32_t kBadMask = ((kFlagExcluded | kFlagLong) << 16) | 0xfe000000u; // excluded, long-span or nblk >= 2
+// ---- table-driven binning of the record stream.  Everything that depends only on (aligned
+// length, strand mode) -- the index rule of the mapping function, the size filter, whether the
+// tile has bins for the mode, the stratified row -- is folded once per work item into an 8-byte
+// LDS entry
+//     ftab[L*4 + mode] = { k - 32768  (0x40000000: no bin for this pair),  LDS byte offset of the mode's bins }
+// so that binning a stream record is: one ds_read_b64, a 16-bit subtract that recovers the
+// window-relative position from the stored low half, add, and-or, compare, ds_add.
+constexpr uint32_t kBadMask = 0xfe000000u; // stream word: skip bit (and the unused flag bits)
 constexpr uint32_t kNoBin = 0x40000000u;
 constexpr int kOpStage = 32;    // output pieces of a window staged in LDS ahead of the epilogue
-constexpr int kFastMaxLen = 447; // table of (kFastMaxLen+1) x 32 B = 14 KiB
 
 template <int KIND>
 __device__ __forceinline__ void fast_table_init(const MapParams &mp, const HistCfg &c, uint32_t mode_mask, int lo, int hi,
@@ -651,23 +651,25 @@ __device__ __forceinline__ void fast_table_init(const MapParams &mp, const HistC
         const int slot = __popc(mode_mask & ((1u << m) - 1u));
         const bool ok = have & (k >= 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
         u32x2 e;
-        e.x = ok ? (uint32_t)(k - c.win_start) : kNoBin;
+        e.x = ok ? (uint32_t)(k - 32768) : kNoBin;
         e.y = ok ? bins_byte + (uint32_t)(slot * mp.rows + row) * c.G * 4u : 0u;
         ftab[L * kModes + m] = e;
     }
 }
 
-// Bin N ungapped records (x = pos, y = meta).  All table reads of a strand-mode pass are issued
-// before its first ds_add: the compiler cannot move an LDS read across an LDS atomic on its own
-// (table and bins share the LDS), and one read-wait-add chain per record would serialise on
-// the LDS latency.  e.y is the byte address of the mode's first bin.
+// Bin N records of the 4-byte stream.  `b16` = low half of (win_start - 32768): the 16-bit
+// difference `word.lo16 - b16` is the window-relative position + 32768 of every record the window
+// can scan (they all lie within +-32 K of its start).  All table reads of a strand-mode pass are
+// issued before its first ds_add: the compiler cannot move an LDS read across an LDS atomic on
+// its own (table and bins share the LDS), and one read-wait-add chain per record would serialise
+// on the LDS latency.  e.y is the byte address of the mode's first bin.
 template <int N>
-__device__ __forceinline__ void fast_bin(const u32x2 *ftab, uint32_t mode_mask, uint32_t G, const uint32_t (&x)[N],
-                                         const uint32_t (&y)[N], uint32_t *smem) {
+__device__ __forceinline__ void fast_bin(const u32x2 *ftab, uint32_t mode_mask, uint32_t G, uint32_t b16,
+                                         const uint32_t (&w)[N], uint32_t *smem) {
     const char *tab = (const char *)ftab;
     uint32_t a[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) a[i] = (y[i] & 0xffffu) << 5; // 32 B of entries per aligned length
+    for (int i = 0; i < N; ++i) a[i] = (w[i] >> 11) & 0x1fe0u; // L * 32: 32 B of entries per aligned length
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         // pass 0: '+' / '-' (mutually exclusive per read: entry picked by the read's strand);
@@ -676,15 +678,15 @@ __device__ __forceinline__ void fast_bin(const u32x2 *ftab, uint32_t mode_mask, 
         u32x2 e[N];
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            e[i] = *(const u32x2 *)(tab + (pass == 0 ? (a[i] | ((y[i] >> 13) & 8u)) : a[i] + (pass == 1 ? 16u : 24u)));
+            e[i] = *(const u32x2 *)(tab + (pass == 0 ? (a[i] | ((w[i] >> 21) & 8u)) : a[i] + (pass == 1 ? 16u : 24u)));
         // byte address of every record's bin (~0: none), then one ds_add per run of equal
-        // addresses: the records of a lane are consecutive in the coordinate-sorted stream, so
+        // addresses: neighbouring stream records are neighbours in the coordinate-sorted file, so
         // the reads piled on one position collapse into a single LDS atomic per lane
         uint32_t addr[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const uint32_t d = x[i] + e[i].x;
-            addr[i] = ((d | (y[i] & kBadMask)) < G) ? e[i].y + (d << 2) : ~0u;
+            const uint32_t d = ((w[i] - b16) & 0xffffu) + e[i].x;
+            addr[i] = ((d | (w[i] & kBadMask)) < G) ? e[i].y + (d << 2) : ~0u;
         }
         uint32_t cnt = 1;
 #pragma unroll
@@ -696,38 +698,31 @@ __device__ __forceinline__ void fast_bin(const u32x2 *ftab, uint32_t mode_mask, 
     }
 }
 
-// The packed record stream of one work item: 16-byte pairs, every wave owns 4 KiB per batch
-// (U x 64 lanes x 16 B, the U loads of a lane 1 KiB apart -> one address register and immediate
-// offsets), register double buffer.  Batches that lie wholly inside the range are loaded
-// without per-lane predicates; lanes past the end of the last batch hold an excluded record.
-template <int KIND, int WG, bool FAST, int U>
-__device__ __forceinline__ void stream_packed(const u32x4 PC_GLOBAL *src, int npairs, u32x4 (&cur)[U], const u32x4 none,
-                                              const MapParams &mp, const HistCfg &c, const uint32_t *ltab,
-                                              const u32x2 *ftab, uint32_t mode_mask, uint32_t *smem, uint32_t *bins) {
-    const int lane_j = PC_LANE_CONTIG ? (int)threadIdx.x * U : (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
-    constexpr int US = PC_LANE_CONTIG ? 1 : 64; // pairs between the U loads of a lane
-    for (int base = 0; base < npairs; base += WG * U) {
+// The record stream of one work item: 16-byte loads of four 4-byte records, every wave owns
+// 4 KiB per batch (U x 64 lanes x 16 B, the U loads of a lane 1 KiB apart -> one address register
+// and immediate offsets), register double buffer.  Batches that lie wholly inside the range are
+// loaded without per-lane predicates; lanes past the end of the last batch hold skip words.
+template <int WG, int U>
+__device__ __forceinline__ void stream_records(const u32x4 PC_GLOBAL *src, int nquads, u32x4 (&cur)[U], const u32x4 none,
+                                               const u32x2 *ftab, uint32_t mode_mask, uint32_t G, uint32_t b16,
+                                               uint32_t *smem) {
+    const int lane_j = (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
+    for (int base = 0; base < nquads; base += WG * U) {
         u32x4 nxt[U];
         const int nb = base + WG * U;
         const u32x4 PC_GLOBAL *q = src + nb + lane_j;
-        if (nb + WG * U <= npairs) {
+        if (nb + WG * U <= nquads) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = q[u * US];
+            for (int u = 0; u < U; ++u) nxt[u] = q[u * 64];
         } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = (nb + lane_j + u * US < npairs) ? q[u * US] : none;
+            for (int u = 0; u < U; ++u) nxt[u] = (nb + lane_j + u * 64 < nquads) ? q[u * 64] : none;
         }
-        if (FAST) {
-            uint32_t x[2 * U], y[2 * U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { x[2 * u] = cur[u].x; y[2 * u] = cur[u].y; x[2 * u + 1] = cur[u].z; y[2 * u + 1] = cur[u].w; }
-            fast_bin<2 * U>(ftab, mode_mask, c.G, x, y, smem);
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                hist_rec<KIND>(mp, c, ltab, cur[u].x, cur[u].y, true, bins);
-                hist_rec<KIND>(mp, c, ltab, cur[u].z, cur[u].w, true, bins);
-            }
+        for (int u = 0; u < U; u += 2) { // eight records (two neighbouring quads of the lane's slice) per call
+            const uint32_t w8[8] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w,
+                                    cur[u + 1].x, cur[u + 1].y, cur[u + 1].z, cur[u + 1].w};
+            fast_bin<8>(ftab, mode_mask, G, b16, w8, smem);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
@@ -808,31 +803,30 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     const GFile fv = w.file == 0 ? gfile(file0) : (w.file == 1 ? gfile(file1) : gfile(files[w.file]));
 
     // ---- first batch of the record stream (and the first gapped records).  The stream is read
-    // as 16-byte record pairs; a range that starts or ends on an odd record has its outer half
-    // pair handled apart: the leading one is masked below, the trailing one is a single record.
+    // as quads of 4-byte records; the records of the first quad that precede `lo` are masked
+    // below, and a last quad that `hi` cuts is handled apart (by thread 0, masked on both sides).
     constexpr int U = PC_HIST_U;
-    const int64_t pair_lo = w.lo >> 1;
-    const int lo_odd = (int)(w.lo & 1);
-    const bool has_tail = (w.hi & 1) && (w.hi - 1 >= w.lo);
-    const int npairs = (int)((w.hi >> 1) - pair_lo); // whole pairs [pair_lo, hi/2)
-    const u32x4 PC_GLOBAL *src = fv.rec4 + pair_lo;
-    const u32x4 none = {0u, kFlagExcluded << 16, 0u, kFlagExcluded << 16};
+    static_assert(U % 2 == 0, "PC_HIST_U must be even");
+    const int64_t quad_lo = w.lo >> 2;
+    const int nquads = (int)((w.hi >> 2) - quad_lo); // quads wholly below hi (may be 0, never negative)
+    const u32x4 PC_GLOBAL *src = fv.stream4 + quad_lo;
+    const u32x4 none = {kStreamSkip, kStreamSkip, kStreamSkip, kStreamSkip};
     u32x4 cur[U];
     {
-        const int lane_j = PC_LANE_CONTIG ? (int)threadIdx.x * U : (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
-        constexpr int US = PC_LANE_CONTIG ? 1 : 64;
+        const int lane_j = (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = (lane_j + u * US < npairs) ? src[lane_j + u * US] : none;
+        for (int u = 0; u < U; ++u) cur[u] = (lane_j + u * 64 < nquads) ? src[lane_j + u * 64] : none;
     }
-    u32x2 tail = {0u, kFlagExcluded << 16};
-    if (has_tail && threadIdx.x == 0) tail = fv.rec[w.hi - 1];
+    u32x4 tail = none;
+    if ((w.hi & 3) && threadIdx.x == 0) tail = fv.stream4[w.hi >> 2];
     // the window's output pieces (48 B each) are fetched now and parked in LDS, so that the
     // epilogue does not start with a chain of dependent global loads
     const int nstage = w.merge ? 0 : (int)min(w.op_end - w.op_begin, (uint32_t)kOpStage);
     u32x4 opq = {0u, 0u, 0u, 0u};
     if ((int)threadIdx.x < nstage * 3) opq = ((const u32x4 PC_GLOBAL *)(opieces + w.op_begin))[threadIdx.x];
     const int64_t gj0 = w.glo + threadIdx.x;
-    const u32x4 gfirst = (gj0 < w.ghi) ? fv.gap_rec[gj0] : none;
+    const u32x4 gnone = {0u, kFlagExcluded << 16, 0u, 0u};
+    const u32x4 gfirst = (gj0 < w.ghi) ? fv.gap_rec[gj0] : gnone;
 
     HistCfg c;
     c.win_start = w.win_start;
@@ -845,8 +839,7 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     c.tab_lo = tab_lo;
     c.tab_n = (uint32_t)tab_n;
     // LDS: [table-driven entries, indexed by aligned length from 0][packed offset tables][bins]
-    const bool fast = fast_hi >= 0;
-    const int fwords = fast ? (fast_hi + 1) * kModes * 2 : 0;
+    const int fwords = (fast_hi + 1) * kModes * 2;
     u32x2 *ftab = (u32x2 *)smem;
     uint32_t *ltab = smem + fwords;                      // variable / stratified rules: gapped and long-span reads
     uint32_t *bins = smem + fwords + ((tab_n + 3) & ~3);
@@ -869,18 +862,29 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
             ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
     }
-    if (fast) fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)((char *)bins - (char *)smem), (int)threadIdx.x, WG, pre_f, pre_r);
-    if (lo_odd && threadIdx.x == 0) cur[0].y = kFlagExcluded << 16; // record lo-1 shares the first pair
+    fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)((char *)bins - (char *)smem), (int)threadIdx.x, WG, pre_f, pre_r);
+    if (threadIdx.x == 0) {
+        // records of the first quad before `lo`, of the cut last quad outside [lo, hi)
+        const int lead = (int)(w.lo & 3), keep = (int)(w.hi & 3);
+        if (nquads > 0) {
+            if (lead > 0) cur[0].x = kStreamSkip;
+            if (lead > 1) cur[0].y = kStreamSkip;
+            if (lead > 2) cur[0].z = kStreamSkip;
+        }
+        const int tlead = nquads == 0 ? lead : 0; // lo and hi inside the same quad
+        if (keep <= 0 || tlead > 0) tail.x = kStreamSkip;
+        if (keep <= 1 || tlead > 1) tail.y = kStreamSkip;
+        if (keep <= 2 || tlead > 2) tail.z = kStreamSkip;
+        tail.w = kStreamSkip;
+    }
     __syncthreads();
 
-    // ---- the packed record stream: no dependent global loads in this loop
-    if (fast) {
-        stream_packed<KIND, WG, true, U>(src, npairs, cur, none, mp, c, ltab, ftab, w.mode_mask, smem, bins);
-        const uint32_t tx[1] = {tail.x}, ty[1] = {tail.y};
-        fast_bin<1>(ftab, w.mode_mask, c.G, tx, ty, smem);
-    } else {
-        stream_packed<KIND, WG, false, U>(src, npairs, cur, none, mp, c, ltab, ftab, w.mode_mask, smem, bins);
-        hist_rec<KIND>(mp, c, ltab, tail.x, tail.y, true, bins);
+    // ---- the record stream: no dependent global loads in this loop
+    const uint32_t b16 = (uint32_t)(w.win_start - 32768) & 0xffffu;
+    stream_records<WG, U>(src, nquads, cur, none, ftab, w.mode_mask, c.G, b16, smem);
+    {
+        const uint32_t w4[4] = {tail.x, tail.y, tail.z, tail.w};
+        fast_bin<4>(ftab, w.mode_mask, c.G, b16, w4, smem);
     }
 
     // ---- gapped records (deletions, short introns): their aligned runs live in a side
@@ -888,12 +892,12 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     for (int64_t base = w.glo; base < w.ghi; base += WG) {
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.ghi;
-        const u32x4 g = base == w.glo ? gfirst : (in ? fv.gap_rec[j] : none);
+        const u32x4 g = base == w.glo ? gfirst : (in ? fv.gap_rec[j] : gnone);
         const uint32_t meta = g.y, hi = meta >> 16;
         const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
         const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-        i32x2 b0 = {0, 1}, b1 = {0, 1};
-        if (in) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
+        i32x2 b0 = {(int32_t)g.x, L}, b1 = {0, 0}; // one run: an ungapped read too long for the stream
+        if (in && nb >= 2) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
         int kf, kr;
         uint32_t rowoff;
         map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     for (int64_t base = w.llo; base < w.lhi; base += WG) {
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.lhi;
-        const u32x4 g = in ? fv.long_rec[j] : none;
+        const u32x4 g = in ? fv.long_rec[j] : gnone;
         const uint32_t meta = g.y, hi = meta >> 16;
         const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
         const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);

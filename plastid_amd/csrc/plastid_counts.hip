@@ -85,9 +85,12 @@ struct StagedFile {
     DevBuf<int64_t> lin_off;
     std::vector<int64_t> len_hist; // records per aligned length (host), for cheap warn pre-checks
     int len_min = 65536, len_max = -1; // aligned lengths present
+    int slen_min = 0, slen_max = 0;    // ... among the records the 4-byte stream carries
+    DevBuf<uint32_t> stream;           // 4-byte record stream (pc::stream_word), padded with skip words
     FileView view() const {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
+        v.stream = stream.p;
         v.long_idx = long_idx.p; v.long_tid = long_tid.p; v.long_pmax = long_pmax.p;
         v.long_tid_bounds = long_tid_bounds.p; v.long_rec = long_rec.p; v.n = n; v.nlong = nlong;
         v.gap_rec = gap_rec.p; v.gap_tid_bounds = gap_tid_bounds.p; v.ngap = ngap;
@@ -388,8 +391,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 long_bounds[(size_t)tid[i] + 1] += 1;
             } else {
                 W = std::max(W, (int)sp);
-                if (nblk[i] >= 2) {
-                    gap_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, blk_off[(size_t)i], (uint32_t)i));
+                if (nblk[i] >= 2 || alen[i] > kStreamMaxLen) { // binned from the side list, not from the stream
+                    gap_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, nblk[i] >= 2 ? blk_off[(size_t)i] : 0u, (uint32_t)i));
                     gap_bounds[(size_t)tid[i] + 1] += 1;
                 }
             }
@@ -399,6 +402,20 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     }
     sf->W = W;
     sf->max_span = max_span;
+    std::vector<uint32_t> stream((size_t)n + 8, kStreamSkip); // +pad: whole quads can always be loaded
+    {
+        int smin = 65536, smax = -1;
+        for (int64_t i = 0; i < n; ++i) {
+            const uint32_t wd = stream_word(rec[(size_t)i].x, rec[(size_t)i].y & ~((uint32_t)kFlagExcluded << 16));
+            if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
+                const int L = (int)((wd >> 16) & 0xffu);
+                smin = std::min(smin, L); smax = std::max(smax, L);
+            }
+            stream[(size_t)i] = stream_word(rec[(size_t)i].x, rec[(size_t)i].y);
+        }
+        sf->slen_min = smax >= smin ? smin : 0;
+        sf->slen_max = smax >= smin ? smax : 0;
+    }
     sf->nlong = (int64_t)long_idx.size();
     sf->ngap = (int64_t)gap_rec.size();
 
@@ -451,6 +468,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
 
     // ---- bulk stage to HBM
     int rc = sf->rec.upload(rec, e->stream);
+    if (rc == PC_OK) rc = sf->stream.upload(stream, e->stream);
     if (rc == PC_OK && nrun > 0) {
         rc = sf->blk_off.upload(blk_off, e->stream);
         std::vector<int2> blk((size_t)nrun);
@@ -493,6 +511,11 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     for (int64_t i = 0; i < n; ++i)
         rec[(size_t)i].y = (rec[(size_t)i].y & keep) | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16);
     HIP_TRY(hipMemcpy(sf->rec.p, rec.data(), (size_t)n * sizeof(uint2), hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> stream((size_t)n);
+        for (int64_t i = 0; i < n; ++i) stream[(size_t)i] = stream_word(rec[(size_t)i].x, rec[(size_t)i].y);
+        if (n) HIP_TRY(hipMemcpy(sf->stream.p, stream.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (sf->nlong) {
         std::vector<uint4> g((size_t)sf->nlong);
         HIP_TRY(hipMemcpy(g.data(), sf->long_rec.p, g.size() * sizeof(uint4), hipMemcpyDeviceToHost));
@@ -884,14 +907,11 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             }
             const size_t stage_words = (size_t)kOpStage * sizeof(OutPiece) / sizeof(uint32_t); // output pieces parked in LDS
             const size_t bins_words = (size_t)p->max_slots * p->rows * G + (size_t)((tab_n + 3) & ~3) + stage_words;
-            // table-driven binning when every aligned length present fits the LDS table
-            int fast_lo = 0, fast_hi = -1;
-            if (lmax >= lmin && lmax <= kFastMaxLen && !getenv("PC_NO_FAST") &&
-                (bins_words + (size_t)(lmax + 1) * kModes * 2) * sizeof(uint32_t) <= 64 * 1024) {
-                fast_lo = lmin;
-                fast_hi = lmax;
-            }
-            const size_t fwords = fast_hi >= 0 ? (size_t)(fast_hi + 1) * kModes * 2 : 0;
+            // LDS entry table of the record stream: the aligned lengths the stream carries
+            int fast_lo = kStreamMaxLen, fast_hi = 0;
+            for (auto *f : e->files) { fast_lo = std::min(fast_lo, f->slen_min); fast_hi = std::max(fast_hi, f->slen_max); }
+            fast_lo = std::min(fast_lo, fast_hi);
+            const size_t fwords = (size_t)(fast_hi + 1) * kModes * 2;
             const size_t lds = (bins_words + fwords) * sizeof(uint32_t);
             if (lds > 64 * 1024) return fail(PC_ERR_ARG, "pc_count: LDS budget exceeded (%zu bytes)", lds);
             const FileView fv0 = e->files[0]->view();

@@ -258,9 +258,10 @@ def test_pileup_and_multifile(pa, oracle):
 
 
 def test_long_aligned_lengths(pa, oracle):
-    """Aligned lengths beyond the LDS entry table (L > 447) switch the tile kernel to its
-    arithmetic binning path; short-only data uses the table.  Both must match the oracle,
-    including the nofilter/'.' strand modes and odd record ranges."""
+    """Ungapped reads too long for the 4-byte record stream (L > 255) are binned from the side
+    list, and those longer than the window halo through the long-span path; short-only data stays
+    in the stream.  All must match the oracle, including the nofilter/'.' strand modes and odd
+    record ranges."""
     rng = np.random.default_rng(23)
     names, lens = ["a", "b"], [60000, 9000]
     for lmax in (40, 3000):
@@ -477,8 +478,6 @@ def test_fused_region_statistics(pa, oracle):
     {"PC_WORK_R": "1024", "PC_PILE": "1024"},             # pile-up fallback: record slices merged via hist
     {"PC_TILE_G": "512", "PC_WORK_R": "2048"},            # small windows
     {"PC_NO_SMALL": "1"},                                 # no single-wave class
-    {"PC_NO_FAST": "1"},                                  # arithmetic binning instead of the LDS entry table
-    {"PC_NO_FAST": "1", "PC_WORK_R": "1024", "PC_PILE": "1024"},
     {"PC_TILE_G": "768", "PC_WORK_R": "512", "PC_PILE": "100000"},  # odd window size, odd/even record ranges
 ])
 def test_work_list_paths_vs_oracle(pa, oracle, knobs, monkeypatch):
