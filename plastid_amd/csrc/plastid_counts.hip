@@ -843,9 +843,9 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     const int nfiles = (int)e->files.size();
     const int W = e->W();
     const int G = p->G;
-    int64_t R = 32768;
+    int64_t R = 49152; // records per work item (192 KiB of the 4-byte stream)
     if (const char *env = getenv("PC_WORK_R")) R = std::max(1024, atoi(env)); // tuning knob
-    int64_t pile = 16 * R; // a 128-nt sub-window with more records than this is merged through the histogram
+    int64_t pile = 12 * R; // a 128-nt sub-window with more records than this is merged through the histogram
     if (const char *env = getenv("PC_PILE")) pile = std::max<int64_t>(R, atoll(env)); // tuning knob
     const MapParams mp = e->params();
     const int ntiles = (int)p->tiles.size();

@@ -11,7 +11,6 @@ for sigma in [float(x) for x in os.environ.get("SIGMAS", "1.5,0.0").split(",")]:
     reads = synth.make_reads(synth.YEAST, tx, n, 1002, expr_sigma=sigma)
     eng = Engine(0)
     eng.set_profiling(2)
-eng.set_profiling(2)
     eng.set_alignments([reads])
     synth.mapping_factory(("fiveprime", 12))._configure(eng)
     p = tx.plan_arrays(rows=1)
