@@ -297,6 +297,7 @@ def main():
                 "host_generate_s": round(gen_s, 2), "host_stage_s": round(stage_s, 2),
                 "plan_build_ms_once_per_annotation": round(plan_s * 1e3, 2),
                 "algorithmic_bytes_per_step": int(alg_bytes_step),
+                "staged_stream_bytes_per_record": 4,  # what the tile kernel reads; the algorithmic record is 8 B
                 "step_GBps_algorithmic": alg_bytes_step / (ms_per_step * 1e-3) / 1e9,
                 "kernel_ms": {k: round(v, 4) for k, v in phases.items()},
             },
