@@ -48,18 +48,21 @@ constexpr int kLinShift = 7;              // linear-index bucket = 128 genome po
 constexpr int kStreamMaxLen = 255;        // aligned lengths the 4-byte record stream can carry
 
 // The record stream the tile kernel reads is 4 bytes per record:
-//   bits 0-15  low half of pos (the high half is implied by the window: every record a window
-//              scans lies within +-32 K positions of its start)
-//   bits 16-23 aligned length L (<= kStreamMaxLen)
-//   bit  24    reverse strand
-//   bit  31    skip: excluded by a host-side filter, or binned from a side list instead (gapped,
-//              long-span, or longer than kStreamMaxLen)
-constexpr uint32_t kStreamSkip = 0x80000000u;
+//   bit  0      skip: excluded by a host-side filter, or binned from a side list instead (gapped,
+//               long-span, or longer than kStreamMaxLen)
+//   bit  2      reverse strand
+//   bits 4-11   aligned length L (<= kStreamMaxLen)
+//   bits 16-31  low half of pos (the high half is implied by the window: every record a window
+//               scans lies within +-32 K positions of its start)
+// The fields sit where the kernel wants them: `word & 0xff4` is the byte offset of the record's
+// (length, strand) entry in the LDS table, `(word + entry) >> 16` its window-relative position.
+constexpr uint32_t kStreamSkip = 1u;
 __host__ __device__ inline uint32_t stream_word(uint32_t pos, uint32_t meta) {
     const uint32_t L = meta & 0xffffu, fl = (meta >> 16) & 0xffu, nb = meta >> 24;
     const bool skip = (fl & (kFlagExcluded | kFlagLong)) != 0u || nb >= 2u || L > (uint32_t)kStreamMaxLen;
-    return (pos & 0xffffu) | (skip ? kStreamSkip : (L << 16)) | ((fl & kFlagReverse) << 24);
+    return (pos << 16) | (skip ? kStreamSkip : (L << 4)) | ((fl & kFlagReverse) << 2);
 }
+__host__ __device__ inline uint32_t stream_len(uint32_t word) { return (word >> 4) & 0xffu; }
 
 // strand modes of a query interval
 //   0: '+'  keeps forward reads, forward index rule
@@ -628,18 +631,18 @@ __device__ __forceinline__ void hist_bin(const HistCfg &c, bool valid, bool rev,
 
 // ---- table-driven binning of the record stream.  Everything that depends only on (aligned
 // length, strand mode) -- the index rule of the mapping function, the size filter, whether the
-// tile has bins for the mode, the stratified row -- is folded once per work item into an 8-byte
-// LDS entry
-//     ftab[L*4 + mode] = { k - 32768  (0x40000000: no bin for this pair),  LDS byte offset of the mode's bins }
-// so that binning a stream record is: one ds_read_b64, a 16-bit subtract that recovers the
-// window-relative position from the stored low half, add, and-or, compare, ds_add.
-constexpr uint32_t kBadMask = 0xfe000000u; // stream word: skip bit (and the unused flag bits)
-constexpr uint32_t kNoBin = 0x40000000u;
+// tile has bins for the mode, the stratified row, the window origin -- is folded once per work
+// item into a 4-byte LDS entry
+//     ftab[L*4 + mode] = ((k - win_start) & 0xffff) << 16  |  LDS word offset of the mode's bins
+// (an offset of 32768 - win_start marks "no bin for this pair": it lands outside every window).
+// Adding the entry to the stream word puts the window-relative position in the high half (the
+// low halves never carry: 0xff5 + 0x3fff < 2^16), so binning a stream record is: one ds_read_b32,
+// add, shift, shift-or (the skip bit poisons the position), compare, and, add-shift, ds_add.
 constexpr int kOpStage = 32;    // output pieces of a window staged in LDS ahead of the epilogue
 
 template <int KIND>
 __device__ __forceinline__ void fast_table_init(const MapParams &mp, const HistCfg &c, uint32_t mode_mask, int lo, int hi,
-                                                u32x2 *ftab, uint32_t bins_byte, int tid, int nthreads, int pre_f,
+                                                uint32_t *ftab, uint32_t bins_word, int tid, int nthreads, int pre_f,
                                                 int pre_r) {
     for (int i = tid; i < (hi - lo + 1) * kModes; i += nthreads) {
         const int L = lo + (i >> 2), m = i & 3;
@@ -650,49 +653,44 @@ __device__ __forceinline__ void fast_table_init(const MapParams &mp, const HistC
         const bool have = (mode_mask >> m) & 1u;
         const int slot = __popc(mode_mask & ((1u << m) - 1u));
         const bool ok = have & (k >= 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-        u32x2 e;
-        e.x = ok ? (uint32_t)(k - 32768) : kNoBin;
-        e.y = ok ? bins_byte + (uint32_t)(slot * mp.rows + row) * c.G * 4u : 0u;
-        ftab[L * kModes + m] = e;
+        const uint32_t off = (uint32_t)((ok ? k : 32768) - c.win_start) & 0xffffu;
+        const uint32_t base = ok ? bins_word + (uint32_t)(slot * mp.rows + row) * c.G : 0u;
+        ftab[L * kModes + m] = (off << 16) | base;
     }
 }
 
-// Bin N records of the 4-byte stream.  `b16` = low half of (win_start - 32768): the 16-bit
-// difference `word.lo16 - b16` is the window-relative position + 32768 of every record the window
-// can scan (they all lie within +-32 K of its start).  All table reads of a strand-mode pass are
-// issued before its first ds_add: the compiler cannot move an LDS read across an LDS atomic on
-// its own (table and bins share the LDS), and one read-wait-add chain per record would serialise
-// on the LDS latency.  e.y is the byte address of the mode's first bin.
+// Bin N records of the 4-byte stream.  All table reads of a strand-mode pass are issued before
+// its first ds_add: the compiler cannot move an LDS read across an LDS atomic on its own (table and
+// bins share the LDS), and one read-wait-add chain per record would serialise on the LDS latency.
+// A record without a bin (outside the window, skipped, unmapped length) is sent to the lane's own
+// dump word instead of being branched around.
 template <int N>
-__device__ __forceinline__ void fast_bin(const u32x2 *ftab, uint32_t mode_mask, uint32_t G, uint32_t b16,
+__device__ __forceinline__ void fast_bin(const uint32_t *ftab, uint32_t mode_mask, uint32_t G, uint32_t dump,
                                          const uint32_t (&w)[N], uint32_t *smem) {
     const char *tab = (const char *)ftab;
-    uint32_t a[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) a[i] = (w[i] >> 11) & 0x1fe0u; // L * 32: 32 B of entries per aligned length
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
         // pass 0: '+' / '-' (mutually exclusive per read: entry picked by the read's strand);
         // pass 1: '.' (all reads, forward rule); pass 2: all reads, reverse rule
         if (!(mode_mask & (pass == 0 ? 3u : (pass == 1 ? 4u : 8u)))) continue;
-        u32x2 e[N];
+        uint32_t e[N];
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            e[i] = *(const u32x2 *)(tab + (pass == 0 ? (a[i] | ((w[i] >> 21) & 8u)) : a[i] + (pass == 1 ? 16u : 24u)));
-        // byte address of every record's bin (~0: none), then one ds_add per run of equal
-        // addresses: neighbouring stream records are neighbours in the coordinate-sorted file, so
-        // the reads piled on one position collapse into a single LDS atomic per lane
+            e[i] = *(const uint32_t *)(tab + (pass == 0 ? (w[i] & 0xff4u) : (w[i] & 0xff0u) + (pass == 1 ? 8u : 12u)));
+        // byte address of every record's bin, then one ds_add per run of equal addresses:
+        // neighbouring stream records are neighbours in the coordinate-sorted file, so the reads
+        // piled on one position collapse into a single LDS atomic per lane
         uint32_t addr[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const uint32_t d = ((w[i] - b16) & 0xffffu) + e[i].x;
-            addr[i] = ((d | (w[i] & kBadMask)) < G) ? e[i].y + (d << 2) : ~0u;
+            const uint32_t d = (w[i] + e[i]) >> 16;
+            addr[i] = (((w[i] << 31) | d) < G) ? ((e[i] & 0xffffu) + d) << 2 : dump;
         }
         uint32_t cnt = 1;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const bool last = (i == N - 1) || (addr[i + 1 < N ? i + 1 : i] != addr[i]);
-            if (last & (addr[i] != ~0u)) atomicAdd((uint32_t *)((char *)smem + addr[i]), cnt);
+            if (last) atomicAdd((uint32_t *)((char *)smem + addr[i]), cnt);
             cnt = last ? 1u : cnt + 1u;
         }
     }
@@ -704,7 +702,7 @@ __device__ __forceinline__ void fast_bin(const u32x2 *ftab, uint32_t mode_mask, 
 // loaded without per-lane predicates; lanes past the end of the last batch hold skip words.
 template <int WG, int U>
 __device__ __forceinline__ void stream_records(const u32x4 PC_GLOBAL *src, int nquads, u32x4 (&cur)[U], const u32x4 none,
-                                               const u32x2 *ftab, uint32_t mode_mask, uint32_t G, uint32_t b16,
+                                               const uint32_t *ftab, uint32_t mode_mask, uint32_t G, uint32_t dump,
                                                uint32_t *smem) {
     const int lane_j = (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
     for (int base = 0; base < nquads; base += WG * U) {
@@ -722,7 +720,7 @@ __device__ __forceinline__ void stream_records(const u32x4 PC_GLOBAL *src, int n
         for (int u = 0; u < U; u += 2) { // eight records (two neighbouring quads of the lane's slice) per call
             const uint32_t w8[8] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w,
                                     cur[u + 1].x, cur[u + 1].y, cur[u + 1].z, cur[u + 1].w};
-            fast_bin<8>(ftab, mode_mask, G, b16, w8, smem);
+            fast_bin<8>(ftab, mode_mask, G, dump, w8, smem);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
@@ -839,11 +837,12 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     c.tab_lo = tab_lo;
     c.tab_n = (uint32_t)tab_n;
     // LDS: [table-driven entries, indexed by aligned length from 0][packed offset tables][bins]
-    const int fwords = (fast_hi + 1) * kModes * 2;
-    u32x2 *ftab = (u32x2 *)smem;
+    const int fwords = (fast_hi + 1) * kModes;
+    uint32_t *ftab = smem;
     uint32_t *ltab = smem + fwords;                      // variable / stratified rules: gapped and long-span reads
     uint32_t *bins = smem + fwords + ((tab_n + 3) & ~3);
     OutPiece *s_op = (OutPiece *)(bins + (size_t)max_slots * mp.rows * G); // 16-byte aligned: every part is a multiple of 4 words
+    const uint32_t dump = (uint32_t)((char *)(s_op + kOpStage) - (char *)smem) + (threadIdx.x & 63u) * 4u; // the lane's dump word
     if ((int)threadIdx.x < nstage * 3) ((u32x4 *)s_op)[threadIdx.x] = opq;
     {   // only bins in [span_lo, span_hi) are ever read back: clear just those
         // (16-byte stores over the span rounded out to 4 words; no per-element division)
@@ -862,7 +861,7 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
             ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
     }
-    fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)((char *)bins - (char *)smem), (int)threadIdx.x, WG, pre_f, pre_r);
+    fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)(bins - smem), (int)threadIdx.x, WG, pre_f, pre_r);
     if (threadIdx.x == 0) {
         // records of the first quad before `lo`, of the cut last quad outside [lo, hi)
         const int lead = (int)(w.lo & 3), keep = (int)(w.hi & 3);
@@ -880,11 +879,10 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     __syncthreads();
 
     // ---- the record stream: no dependent global loads in this loop
-    const uint32_t b16 = (uint32_t)(w.win_start - 32768) & 0xffffu;
-    stream_records<WG, U>(src, nquads, cur, none, ftab, w.mode_mask, c.G, b16, smem);
+    stream_records<WG, U>(src, nquads, cur, none, ftab, w.mode_mask, c.G, dump, smem);
     {
         const uint32_t w4[4] = {tail.x, tail.y, tail.z, tail.w};
-        fast_bin<4>(ftab, w.mode_mask, c.G, b16, w4, smem);
+        fast_bin<4>(ftab, w.mode_mask, c.G, dump, w4, smem);
     }
 
     // ---- gapped records (deletions, short introns): their aligned runs live in a side

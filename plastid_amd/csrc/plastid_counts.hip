@@ -408,7 +408,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         for (int64_t i = 0; i < n; ++i) {
             const uint32_t wd = stream_word(rec[(size_t)i].x, rec[(size_t)i].y & ~((uint32_t)kFlagExcluded << 16));
             if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
-                const int L = (int)((wd >> 16) & 0xffu);
+                const int L = (int)stream_len(wd);
                 smin = std::min(smin, L); smax = std::max(smax, L);
             }
             stream[(size_t)i] = stream_word(rec[(size_t)i].x, rec[(size_t)i].y);
@@ -911,7 +911,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             int fast_lo = kStreamMaxLen, fast_hi = 0;
             for (auto *f : e->files) { fast_lo = std::min(fast_lo, f->slen_min); fast_hi = std::max(fast_hi, f->slen_max); }
             fast_lo = std::min(fast_lo, fast_hi);
-            const size_t fwords = (size_t)(fast_hi + 1) * kModes * 2;
+            const size_t fwords = (size_t)(fast_hi + 1) * kModes + 64; // entry table + one dump word per lane (after the staged pieces)
             const size_t lds = (bins_words + fwords) * sizeof(uint32_t);
             if (lds > 64 * 1024) return fail(PC_ERR_ARG, "pc_count: LDS budget exceeded (%zu bytes)", lds);
             const FileView fv0 = e->files[0]->view();
