@@ -716,8 +716,10 @@ __device__ __forceinline__ void stream_records(const u32x4 PC_GLOBAL *src, int n
 #pragma unroll
             for (int u = 0; u < U; ++u) nxt[u] = (nb + lane_j + u * 64 < nquads) ? q[u * 64] : none;
         }
+        const int wave_q = base + (int)(threadIdx.x >> 6) * (64 * U); // first quad of this wave's slice of the batch
 #pragma unroll
-        for (int u = 0; u < U; u += 2) { // eight records (two neighbouring quads of the lane's slice) per call
+        for (int u = 0; u < U; u += 2) { // eight records (two quads of the lane's slice) per call
+            if (wave_q + u * 64 >= nquads) break; // wave-uniform: nothing but padding from here on (sparse windows)
             const uint32_t w8[8] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w,
                                     cur[u + 1].x, cur[u + 1].y, cur[u + 1].z, cur[u + 1].w};
             fast_bin<8>(ftab, mode_mask, G, dump, w8, smem);
@@ -880,7 +882,7 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
 
     // ---- the record stream: no dependent global loads in this loop
     stream_records<WG, U>(src, nquads, cur, none, ftab, w.mode_mask, c.G, dump, smem);
-    {
+    if ((w.hi & 3) && threadIdx.x < 64) { // the cut last quad lives in lane 0 of the first wave
         const uint32_t w4[4] = {tail.x, tail.y, tail.z, tail.w};
         fast_bin<4>(ftab, w.mode_mask, c.G, dump, w4, smem);
     }
