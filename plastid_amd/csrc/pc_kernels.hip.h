@@ -35,9 +35,6 @@ constexpr int kWG = 256;          // 4 waves of 64
 #ifndef PC_HIST_U
 #define PC_HIST_U 4               // 16-byte loads in flight per lane (x2: register double buffer)
 #endif
-#ifndef PC_LANE_CONTIG
-#define PC_LANE_CONTIG 1          // 1: a lane loads U consecutive 16-byte pairs (64 B); 0: wave-coalesced pairs
-#endif
 constexpr int kHistWG = PC_HIST_WG;
 constexpr int kWave = 64;
 constexpr uint32_t kFlagReverse = 0x01;
@@ -977,19 +974,17 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
 
 // ---------------------------------------------------------------- k_gather_split
 // Split tiles only: lay out their segment slices from the merged histogram, then clear the
-// tile's histogram region so the next call starts from zeros again.
+// tile's histogram region so the next call starts from zeros again.  Last kernel of a call: it
+// also leaves the work-list counters and the per-tile item counts zeroed, so that the next call
+// needs no memset launches in front of k_tile_ranges.
+// `per_wg` tiles are looked at by one workgroup: 1 when every window is merged (several BAM
+// files), 256 otherwise -- merged windows are then the exception (pile-ups), and a sparse
+// annotation has hundreds of thousands of windows that would each cost an empty workgroup.
 template <int OUTMODE>
-__global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ tiles,
-                                                      const Piece *__restrict__ pieces,
-                                                      const OutPiece *__restrict__ opieces,
-                                                      uint32_t *tile_items, uint32_t *counters, int rows,
-                                                      uint32_t *hist, int64_t hist_row_stride,
-                                                      typename OutT_<OUTMODE>::type *out, double norm_sum) {
-    // last kernel of a call: leave the work-list counters and the per-tile item counts zeroed,
-    // so that the next call needs no memset launches in front of k_tile_ranges
-    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
-    if (tile_items[blockIdx.x] == 0u) return; // only windows that were merged through the histogram
-    const Tile tl = tiles[blockIdx.x];
+__device__ __forceinline__ void gather_tile(const Tile &tl, const Piece *__restrict__ pieces,
+                                            const OutPiece *__restrict__ opieces, int rows, uint32_t *hist,
+                                            int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
+                                            double norm_sum) {
     for (uint32_t oi = tl.op_begin; oi < tl.op_end; ++oi) {
         const OutPiece o = opieces[oi];
         for (int r = 0; r < rows; ++r) {
@@ -1012,7 +1007,37 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
             for (int i = threadIdx.x; i < pc_.len; i += kWG) dst[i] = 0u;
         }
     }
-    if (threadIdx.x == 0) tile_items[blockIdx.x] = 0u;
+}
+
+template <int OUTMODE>
+__global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ tiles, int ntiles, int per_wg,
+                                                      const Piece *__restrict__ pieces,
+                                                      const OutPiece *__restrict__ opieces,
+                                                      uint32_t *tile_items, uint32_t *counters, int rows,
+                                                      uint32_t *hist, int64_t hist_row_stride,
+                                                      typename OutT_<OUTMODE>::type *out, double norm_sum) {
+    __shared__ uint32_t s_list[kWG];
+    __shared__ uint32_t s_n;
+    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
+    if (per_wg == 1) {
+        if (tile_items[blockIdx.x] == 0u) return; // only windows that were merged through the histogram
+        gather_tile<OUTMODE>(tiles[blockIdx.x], pieces, opieces, rows, hist, hist_row_stride, out, norm_sum);
+        if (threadIdx.x == 0) tile_items[blockIdx.x] = 0u;
+        return;
+    }
+    const int t = (int)blockIdx.x * kWG + (int)threadIdx.x;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    if (t < ntiles && tile_items[t] != 0u) {
+        s_list[atomicAdd(&s_n, 1u)] = (uint32_t)t;
+        tile_items[t] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    for (uint32_t k = 0; k < n; ++k) { // rare; the whole workgroup lays each of them out in turn
+        gather_tile<OUTMODE>(tiles[s_list[k]], pieces, opieces, rows, hist, hist_row_stride, out, norm_sum);
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------- k_center

@@ -950,8 +950,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
             if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
             // tiles that were split into several work items: lay out from the merged histogram
+            const int split_per_wg = nfiles > 1 ? 1 : kWG; // several files: every window is merged
 #define PC_LAUNCH_SPLIT(O)                                                                                            \
-    hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)ntiles), dim3(kWG), 0, st, p->d_tiles.p, p->d_pieces.p,      \
+    hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)((ntiles + split_per_wg - 1) / split_per_wg)), dim3(kWG), 0, st, \
+                       p->d_tiles.p, ntiles, split_per_wg, p->d_pieces.p,                                               \
                        p->d_opieces.p, p->d_tile_items.p, e->d_counters.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,   \
                        (OutT_<O>::type *)p->d_out.p, e->norm_sum)
             if (outmode == 0) PC_LAUNCH_SPLIT(0);
