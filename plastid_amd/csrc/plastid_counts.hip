@@ -649,15 +649,16 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     int nmodes = 0;
     for (int m = 0; m < kModes; ++m) nmodes += (modes >> m) & 1;
     if (nmodes == 0) nmodes = 1;
-    // window size: LDS budget of 64 KiB for bins (uint32 per mode x row x position)
+    // window size: 24 KiB of LDS bins (uint32 per mode x row x position) -- small enough for six
+    // workgroups per CU; the per-call hard limit is checked in pc_count
     {
-        int64_t g = (48 * 1024) / (4LL * nmodes * rows);
+        int64_t g = (24 * 1024) / (4LL * nmodes * rows);
         int G = 256;
         int gmax = 4096;
         while (G * 2 <= g && G * 2 <= gmax) G *= 2;
         if (const char *env = getenv("PC_TILE_G")) { // tuning knob: any multiple of 256 within the budget
             const int want = std::max(256, atoi(env) / 256 * 256);
-            if (want <= g) G = want;
+            if (want <= 2 * g) G = want;
         }
         if ((int64_t)4 * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
         p->G = G;
