@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "plastid_counts.h"
@@ -57,13 +59,46 @@ template <typename T> struct DevBuf {
         cap = n;
         return PC_OK;
     }
-    int upload(const std::vector<T> &v, hipStream_t s) {
-        int rc = reserve(v.size());
+    int upload(const T *src, size_t n, hipStream_t s) {
+        int rc = reserve(n);
         if (rc != PC_OK) return rc;
-        if (!v.empty()) HIP_TRY(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        if (n) HIP_TRY(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
         return PC_OK;
     }
+    int upload(const std::vector<T> &v, hipStream_t s) { return upload(v.data(), v.size(), s); }
 };
+
+// Host staging buffer that is NOT value-initialised: the worker threads of the staging pass are the
+// first to touch their slice (page faults spread over the threads instead of one memset).
+template <typename T> struct HostBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    explicit HostBuf(size_t count) : p((T *)malloc(std::max<size_t>(count, 1) * sizeof(T))), n(count) {}
+    ~HostBuf() { free(p); }
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
+// fn(thread index, begin, end) over [0, n) cut into `nthreads` contiguous chunks
+template <typename F> static void parallel_chunks(int64_t n, int nthreads, F fn) {
+    if (nthreads <= 1 || n <= 0) { fn(0, (int64_t)0, n); return; }
+    const int64_t chunk = (n + nthreads - 1) / nthreads;
+    std::vector<std::thread> th;
+    th.reserve((size_t)nthreads);
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t b = std::min<int64_t>(n, (int64_t)t * chunk), e_ = std::min<int64_t>(n, b + chunk);
+        th.emplace_back(fn, t, b, e_);
+    }
+    for (auto &x : th) x.join();
+}
+
+static int stage_threads(int64_t n) {
+    int t = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    if (const char *env = getenv("PC_STAGE_THREADS")) t = std::max(1, atoi(env));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(t, n / (1 << 20) + 1)); // a thread is not worth < 1 M records
+}
 
 struct StagedFile {
     int64_t n = 0, nrun = 0, nlong = 0;
@@ -287,6 +322,20 @@ int64_t pc_num_records(pc_engine *e, int file) {
     return e->files[file]->n;
 }
 
+namespace {
+// PC_STAGE_TIMING=1: print where pc_add_alignment_file spends its time (stderr)
+struct StageClock {
+    bool on = getenv("PC_STAGE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[stage] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+} // namespace
+
 int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
                           const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
                           const int32_t *blk_start, const int32_t *blk_len) {
@@ -300,51 +349,102 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         return fail(PC_ERR_ARG, "pc_add_alignment_file: all files must use the same reference list (ntid %d vs %d)", ntid, e->ntid);
     HIP_TRY(hipSetDevice(e->device));
 
-    // ---- host pass: validation, per-tid bounds, spans, packed records
+    StageClock clk;
+    // ---- host pass: validation, per-tid bounds, spans, packed records.  Threaded over contiguous
+    // record chunks; every per-chunk result is merged in chunk order, and the error reported is the
+    // one of the lowest record index, so the outcome does not depend on the thread count.
+    const int T = stage_threads(n);
+    struct ChunkErr { int64_t idx = INT64_MAX; int code = PC_OK; char msg[200] = {0}; };
+    struct Chunk1 {
+        ChunkErr err;
+        std::vector<int64_t> tid_count, span_hist, len_hist;
+        int64_t runs = 0, cursor = 0;
+    };
+    std::vector<Chunk1> c1((size_t)T);
     std::vector<int64_t> tid_bounds((size_t)ntid + 1, 0);
-    std::vector<uint2> rec((size_t)n + 2, make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16)); // +pad: 16-byte pair loads
-    std::vector<uint32_t> blk_off;
-    if (nrun > 0) blk_off.assign((size_t)n, 0u);
-    std::vector<int32_t> span((size_t)n);
-    std::vector<int64_t> span_hist(1026, 0); // spans 0..1024, [1025] = larger
-    std::vector<int64_t> len_hist(65536, 0);
-    int64_t run_cursor = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        if (tid[i] < 0 || tid[i] >= ntid) return fail(PC_ERR_ARG, "record %lld: tid %d out of range", (long long)i, tid[i]);
-        if (pos[i] < 0) return fail(PC_ERR_ARG, "record %lld: negative position", (long long)i);
-        if (i > 0 && (tid[i] < tid[i - 1] || (tid[i] == tid[i - 1] && pos[i] < pos[i - 1])))
-            return fail(PC_ERR_UNSORTED, "records are not sorted by (tid, pos) at record %lld; alignment files must be coordinate sorted", (long long)i);
-        tid_bounds[(size_t)tid[i] + 1] += 1;
-        const int L = alen[i];
-        int64_t end;
-        if (nblk[i] >= 2) {
-            if (run_cursor + nblk[i] > nrun) return fail(PC_ERR_ARG, "run arrays shorter than sum of nblk");
-            blk_off[(size_t)i] = (uint32_t)run_cursor;
-            int64_t sum = 0, prev_end = -1;
-            for (int b = 0; b < nblk[i]; ++b) {
-                const int64_t s = blk_start[run_cursor + b], ln = blk_len[run_cursor + b];
-                if (ln <= 0 || (b > 0 && s <= prev_end))
-                    return fail(PC_ERR_ARG, "record %lld: aligned runs must be non-empty, ascending and non-adjacent", (long long)i);
-                if (b == 0 && s != pos[i]) return fail(PC_ERR_ARG, "record %lld: first run must start at pos", (long long)i);
-                sum += ln;
-                prev_end = s + ln;
-            }
-            if (sum != L) return fail(PC_ERR_ARG, "record %lld: run lengths do not sum to alen", (long long)i);
-            end = prev_end;
-            run_cursor += nblk[i];
-        } else {
-            if ((nblk[i] == 0) != (L == 0)) return fail(PC_ERR_ARG, "record %lld: nblk/alen mismatch", (long long)i);
-            end = (int64_t)pos[i] + (L > 0 ? L : 1);
-        }
-        if (end > 0x7fffffffLL) return fail(PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", (long long)i);
-        const int64_t sp = end - pos[i];
-        span[(size_t)i] = (int32_t)sp;
-        span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
-        len_hist[(size_t)L] += 1;
-        rec[(size_t)i] = make_uint2((uint32_t)pos[i], (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) |
-                                                          ((uint32_t)nblk[i] << 24));
+    HostBuf<uint2> rec((size_t)n + 2);
+    HostBuf<uint32_t> blk_off(nrun > 0 ? (size_t)n : 0);
+    HostBuf<int32_t> span((size_t)n);
+    if (!rec.p || !blk_off.p || !span.p) return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
+    rec[(size_t)n] = rec[(size_t)n + 1] = make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16);
+    // runs owned by each chunk (records with >= 2 runs keep theirs in blk_*), so that a chunk knows
+    // where its first run sits
+    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
+        int64_t r = 0;
+        for (int64_t i = b; i < en; ++i) r += nblk[i] >= 2 ? nblk[i] : 0;
+        c1[(size_t)t].runs = r;
+    });
+    {
+        int64_t cur = 0;
+        for (auto &c : c1) { c.cursor = cur; cur += c.runs; }
+        if (cur != nrun)
+            return fail(PC_ERR_ARG, cur > nrun ? "run arrays shorter than sum of nblk" : "run arrays longer than sum of nblk (%lld vs %lld)",
+                        (long long)cur, (long long)nrun);
     }
-    if (run_cursor != nrun) return fail(PC_ERR_ARG, "run arrays longer than sum of nblk (%lld vs %lld)", (long long)run_cursor, (long long)nrun);
+    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
+        Chunk1 &c = c1[(size_t)t];
+        c.tid_count.assign((size_t)ntid + 1, 0);
+        c.span_hist.assign(1026, 0); // spans 0..1024, [1025] = larger
+        c.len_hist.assign(65536, 0);
+        int64_t run_cursor = c.cursor;
+        auto bad = [&](int64_t i, int code, const char *fmt, long long a1, long long a2) {
+            c.err.idx = i; c.err.code = code;
+            snprintf(c.err.msg, sizeof(c.err.msg), fmt, a1, a2);
+        };
+        for (int64_t i = b; i < en; ++i) {
+            if (tid[i] < 0 || tid[i] >= ntid) { bad(i, PC_ERR_ARG, "record %lld: tid %lld out of range", i, tid[i]); return; }
+            if (pos[i] < 0) { bad(i, PC_ERR_ARG, "record %lld: negative position", i, 0); return; }
+            if (i > 0 && (tid[i] < tid[i - 1] || (tid[i] == tid[i - 1] && pos[i] < pos[i - 1]))) {
+                bad(i, PC_ERR_UNSORTED, "records are not sorted by (tid, pos) at record %lld; alignment files must be coordinate sorted", i, 0);
+                return;
+            }
+            c.tid_count[(size_t)tid[i] + 1] += 1;
+            const int L = alen[i];
+            int64_t end;
+            if (nblk[i] >= 2) {
+                blk_off[(size_t)i] = (uint32_t)run_cursor;
+                int64_t sum = 0, prev_end = -1;
+                for (int k = 0; k < nblk[i]; ++k) {
+                    const int64_t s0 = blk_start[run_cursor + k], ln = blk_len[run_cursor + k];
+                    if (ln <= 0 || (k > 0 && s0 <= prev_end)) {
+                        bad(i, PC_ERR_ARG, "record %lld: aligned runs must be non-empty, ascending and non-adjacent", i, 0);
+                        return;
+                    }
+                    if (k == 0 && s0 != pos[i]) { bad(i, PC_ERR_ARG, "record %lld: first run must start at pos", i, 0); return; }
+                    sum += ln;
+                    prev_end = s0 + ln;
+                }
+                if (sum != L) { bad(i, PC_ERR_ARG, "record %lld: run lengths do not sum to alen", i, 0); return; }
+                end = prev_end;
+                run_cursor += nblk[i];
+            } else {
+                if (nrun > 0) blk_off[(size_t)i] = 0u;
+                if ((nblk[i] == 0) != (L == 0)) { bad(i, PC_ERR_ARG, "record %lld: nblk/alen mismatch", i, 0); return; }
+                end = (int64_t)pos[i] + (L > 0 ? L : 1);
+            }
+            if (end > 0x7fffffffLL) { bad(i, PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", i, 0); return; }
+            const int64_t sp = end - pos[i];
+            span[(size_t)i] = (int32_t)sp;
+            c.span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
+            c.len_hist[(size_t)L] += 1;
+            rec[(size_t)i] = make_uint2((uint32_t)pos[i], (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) |
+                                                              ((uint32_t)nblk[i] << 24));
+        }
+    });
+    std::vector<int64_t> span_hist(1026, 0), len_hist(65536, 0);
+    {
+        const ChunkErr *first = nullptr;
+        for (const auto &c : c1)
+            if (c.err.code != PC_OK && (!first || c.err.idx < first->idx)) first = &c.err;
+        if (first) return fail(first->code, "%s", first->msg);
+        for (const auto &c : c1) {
+            if (c.tid_count.empty()) continue;
+            for (int t = 0; t <= ntid; ++t) tid_bounds[(size_t)t] += c.tid_count[(size_t)t];
+            for (size_t k = 0; k < span_hist.size(); ++k) span_hist[k] += c.span_hist[k];
+            for (size_t k = 0; k < len_hist.size(); ++k) len_hist[k] += c.len_hist[k];
+        }
+    }
+    clk.lap("validate + pack");
     for (int t = 0; t < ntid; ++t) tid_bounds[(size_t)t + 1] += tid_bounds[(size_t)t];
 
     // ---- choose the window halo W: the smallest span bound (>= 64, <= 1024) that covers
@@ -353,12 +453,12 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     {
         int64_t cum = 0;
         const int64_t need = n - n / 200;
-        int s = 0;
-        for (; s <= 1024; ++s) {
-            cum += span_hist[(size_t)s];
+        int s0 = 0;
+        for (; s0 <= 1024; ++s0) {
+            cum += span_hist[(size_t)s0];
             if (cum >= need) break;
         }
-        wcap = std::max(64, std::min(s, 1024));
+        wcap = std::max(64, std::min(s0, 1024));
     }
     StagedFile *sf = new StagedFile();
     sf->n = n;
@@ -366,56 +466,75 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     sf->len_hist.swap(len_hist);
     for (int L = 0; L < 65536; ++L)
         if (sf->len_hist[(size_t)L]) { sf->len_min = std::min(sf->len_min, L); sf->len_max = std::max(sf->len_max, L); }
+    // ---- side lists (long-span and gapped / over-long records, both rare), the long flag, and
+    // the 4-byte record stream: per chunk, then concatenated in chunk order
+    struct Chunk2 {
+        std::vector<uint32_t> long_idx;
+        std::vector<uint4> gap_rec;
+        int W = 1, smin = 65536, smax = -1;
+        int64_t max_span = 1;
+    };
+    std::vector<Chunk2> c2((size_t)T);
+    HostBuf<uint32_t> stream((size_t)n + 8);
+    if (!stream.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
+    for (int k = 0; k < 8; ++k) stream[(size_t)n + k] = kStreamSkip; // pad: whole quads can always be loaded
+    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
+        Chunk2 &c = c2[(size_t)t];
+        for (int64_t i = b; i < en; ++i) {
+            const int32_t sp = span[(size_t)i];
+            c.max_span = std::max<int64_t>(c.max_span, sp);
+            if (sp > wcap) {
+                rec[(size_t)i].y |= (kFlagLong << 16);
+                c.long_idx.push_back((uint32_t)i);
+            } else {
+                c.W = std::max(c.W, (int)sp);
+                if (nblk[i] >= 2 || alen[i] > kStreamMaxLen) // binned from the side list, not from the stream
+                    c.gap_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, nblk[i] >= 2 ? blk_off[(size_t)i] : 0u, (uint32_t)i));
+            }
+            const uint32_t wd = stream_word(rec[(size_t)i].x, rec[(size_t)i].y & ~((uint32_t)kFlagExcluded << 16));
+            if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
+                const int L = (int)stream_len(wd);
+                c.smin = std::min(c.smin, L); c.smax = std::max(c.smax, L);
+            }
+            stream[(size_t)i] = stream_word(rec[(size_t)i].x, rec[(size_t)i].y);
+        }
+    });
     std::vector<uint32_t> long_idx;
     std::vector<uint4> long_rec;
     std::vector<int32_t> long_tid, long_pmax;
     std::vector<int64_t> long_bounds((size_t)ntid + 1, 0);
-    std::vector<uint4> gap_rec;                                  // short-span gapped records
+    std::vector<uint4> gap_rec;
     std::vector<int64_t> gap_bounds((size_t)ntid + 1, 0);
     int W = 1;
     int64_t max_span = 1;
     {
+        int smin = 65536, smax = -1;
+        for (const auto &c : c2) {
+            W = std::max(W, c.W);
+            max_span = std::max(max_span, c.max_span);
+            smin = std::min(smin, c.smin); smax = std::max(smax, c.smax);
+            long_idx.insert(long_idx.end(), c.long_idx.begin(), c.long_idx.end());
+            gap_rec.insert(gap_rec.end(), c.gap_rec.begin(), c.gap_rec.end());
+        }
+        sf->slen_min = smax >= smin ? smin : 0;
+        sf->slen_max = smax >= smin ? smax : 0;
         int cur_tid = -1;
         int32_t pm = 0;
-        for (int64_t i = 0; i < n; ++i) {
-            const int32_t sp = span[(size_t)i];
-            max_span = std::max<int64_t>(max_span, sp);
-            if (sp > wcap) {
-                rec[(size_t)i].y |= (kFlagLong << 16);
-                if (tid[i] != cur_tid) { cur_tid = tid[i]; pm = 0; }
-                pm = std::max(pm, pos[i] + sp);
-                long_idx.push_back((uint32_t)i);
-                long_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, nblk[i] >= 2 ? blk_off[(size_t)i] : 0u, (uint32_t)i));
-                long_tid.push_back(tid[i]);
-                long_pmax.push_back(pm);
-                long_bounds[(size_t)tid[i] + 1] += 1;
-            } else {
-                W = std::max(W, (int)sp);
-                if (nblk[i] >= 2 || alen[i] > kStreamMaxLen) { // binned from the side list, not from the stream
-                    gap_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, nblk[i] >= 2 ? blk_off[(size_t)i] : 0u, (uint32_t)i));
-                    gap_bounds[(size_t)tid[i] + 1] += 1;
-                }
-            }
+        for (const uint32_t i : long_idx) { // running maximum of the ends, per contig
+            if (tid[i] != cur_tid) { cur_tid = tid[i]; pm = 0; }
+            pm = std::max(pm, pos[i] + span[(size_t)i]);
+            long_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, nblk[i] >= 2 ? blk_off[(size_t)i] : 0u, i));
+            long_tid.push_back(tid[i]);
+            long_pmax.push_back(pm);
+            long_bounds[(size_t)tid[i] + 1] += 1;
         }
+        for (const uint4 &g : gap_rec) gap_bounds[(size_t)tid[g.w] + 1] += 1;
         for (int t = 0; t < ntid; ++t) long_bounds[(size_t)t + 1] += long_bounds[(size_t)t];
         for (int t = 0; t < ntid; ++t) gap_bounds[(size_t)t + 1] += gap_bounds[(size_t)t];
     }
     sf->W = W;
     sf->max_span = max_span;
-    std::vector<uint32_t> stream((size_t)n + 8, kStreamSkip); // +pad: whole quads can always be loaded
-    {
-        int smin = 65536, smax = -1;
-        for (int64_t i = 0; i < n; ++i) {
-            const uint32_t wd = stream_word(rec[(size_t)i].x, rec[(size_t)i].y & ~((uint32_t)kFlagExcluded << 16));
-            if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
-                const int L = (int)stream_len(wd);
-                smin = std::min(smin, L); smax = std::max(smax, L);
-            }
-            stream[(size_t)i] = stream_word(rec[(size_t)i].x, rec[(size_t)i].y);
-        }
-        sf->slen_min = smax >= smin ? smin : 0;
-        sf->slen_max = smax >= smin ? smax : 0;
-    }
+    clk.lap("side lists + record stream");
     sf->nlong = (int64_t)long_idx.size();
     sf->ngap = (int64_t)gap_rec.size();
 
@@ -466,11 +585,12 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         }
     }
 
+    clk.lap("linear index");
     // ---- bulk stage to HBM
-    int rc = sf->rec.upload(rec, e->stream);
-    if (rc == PC_OK) rc = sf->stream.upload(stream, e->stream);
+    int rc = sf->rec.upload(rec.p, rec.n, e->stream);
+    if (rc == PC_OK) rc = sf->stream.upload(stream.p, stream.n, e->stream);
     if (rc == PC_OK && nrun > 0) {
-        rc = sf->blk_off.upload(blk_off, e->stream);
+        rc = sf->blk_off.upload(blk_off.p, blk_off.n, e->stream);
         std::vector<int2> blk((size_t)nrun);
         for (int64_t j = 0; j < nrun; ++j) blk[(size_t)j] = make_int2(blk_start[j], blk_len[j]);
         if (rc == PC_OK) rc = sf->blk.upload(blk, e->stream);
@@ -494,6 +614,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         delete sf;
         return rc;
     }
+    clk.lap("upload");
     e->files.push_back(sf);
     e->ntid = ntid;
     e->files_dirty = true;
