@@ -357,6 +357,44 @@ def test_genome_partition_through_the_engine(pa, oracle):
     assert np.array_equal(acc, want)
 
 
+def test_threaded_staging_is_deterministic(pa, monkeypatch):
+    """pc_add_alignment_file runs its host pass on several threads for large files: the staged
+    result (hence every count) and the reported error must not depend on the thread count."""
+    from plastid_amd import synth
+    from plastid_amd.engine import Engine
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.005, tx_scale=0.01)      # 2.5 M reads, spliced
+    p = tx.plan_arrays(rows=1)
+    outs = []
+    for threads in ("1", "5"):
+        monkeypatch.setenv("PC_STAGE_THREADS", threads)
+        eng = engine_for(pa, [reads], ("threeprime", 3))
+        plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"],
+                        p["out_elems"], 1)
+        outs.append(plan.count(np.int64))
+        plan.close()
+        eng.close()
+    assert np.array_equal(outs[0], outs[1]) and outs[0].sum() > 0
+    # two defects in different thread chunks: the one with the lower record index is reported
+    bad_pos = reads.pos.copy()
+    i_lo, i_hi = reads.n // 3, (2 * reads.n) // 3
+    for i in (i_lo, i_hi):
+        j = i
+        while reads.tid[j] != reads.tid[j - 1] or reads.nblk[j] >= 2 or reads.nblk[j - 1] >= 2:
+            j += 1
+        bad_pos[j] = bad_pos[j - 1] - 1 if bad_pos[j - 1] > 0 else bad_pos[j]
+        if i == i_lo:
+            first = j
+    broken = pa.PackedAlignments(reads.tid, bad_pos, reads.alen, reads.flags, reads.nblk, reads.blk_start, reads.blk_len,
+                                 references=reads.references, lengths=reads.lengths, validate=False)
+    for threads in ("1", "5"):
+        monkeypatch.setenv("PC_STAGE_THREADS", threads)
+        eng = Engine(0)
+        with pytest.raises(ValueError) as ei:
+            eng.set_alignments([broken])
+        assert "record %d" % first in str(ei.value), str(ei.value)
+        eng.close()
+
+
 def test_inverse_table_is_ieee(pa):
     """1.0/m used by the center kernel is the host's correctly rounded quotient;
     a lone read of aligned length m contributes exactly 1.0/m at each position."""
