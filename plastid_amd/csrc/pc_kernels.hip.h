@@ -1089,53 +1089,100 @@ __device__ __forceinline__ double lane_f64(double v, int j) {
 
 constexpr int kInvLds = 1024; // 1/m table kept in LDS for m < kInvLds
 
-// Dispatch order of the center chunks: a chunk's replay time is proportional to the reads
-// that overlap it, and expression is heavy-tailed, so chunks over a pile-up are queued first
-// (two-class longest-first, same scheme as the histogram work list): order[0..nheavy) heavy,
-// order[n-1 .. n-nlight] light.
-__global__ __launch_bounds__(kRangesWG) void k_center_order(const CenterChunk *__restrict__ chunks, int64_t nchunks,
+// Dispatch list of the center kernel.  A chunk's replay is sequential in the reads that overlap
+// it (the order is the contract), so its time is proportional to that count, and expression is
+// heavy-tailed: the kernel would wait for the chunks over the deepest pile-up.  Two measures:
+//   * chunks with many candidates are CUT into 4 or 8 sub-chunks of 16 / 8 positions, one wave
+//     each: a wave then replays the reads over (8 + L) instead of (64 + L) positions -- the
+//     critical path shrinks 2-2.5x for idle lanes in a few waves;
+//   * those entries are queued first (longest-first in two classes, as for the histogram work
+//     list): list[0 .. nheavy) heavy, list[cap-1 .. cap-nlight] light, cap = 2 * nchunks.
+// Thresholds are relative to the mean candidate count (pass 1 sums it), so by Markov's
+// inequality fewer than nchunks/8 chunks are cut and the heavy entries fit in nchunks slots.
+// Entry = chunk index | code << 27: 0 whole chunk, 1..4 quarter, 5..12 eighth.
+constexpr int kSubShift = 27;
+__device__ __forceinline__ int64_t center_candidates(const CenterChunk &ck, const FileView *__restrict__ files, int nfiles, int W) {
+    int64_t cand = 0;
+    for (int f = 0; f < nfiles; ++f) {
+        const GFile fv = gfile(files[f]);
+        const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
+        cand += lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start + ck.len + (1 << kLinShift) - 1) -
+                lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start - W + 1);
+    }
+    return cand;
+}
+
+// pass 1: candidate count per chunk, and their sum (counters[2..3] as one 64-bit value)
+__global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                             const FileView *__restrict__ files, int nfiles, int W,
-                                                            int64_t heavy_thr, uint32_t *order, uint32_t *counters) {
+                                                            uint32_t *cand_out, unsigned long long *total) {
+    const int64_t c = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
+    unsigned long long cand = 0;
+    if (c < nchunks) {
+        cand = (unsigned long long)center_candidates(chunks[c], files, nfiles, W);
+        cand_out[c] = (uint32_t)(cand > 0xffffffffull ? 0xffffffffull : cand);
+    }
+    for (int o = 32; o > 0; o >>= 1) cand += __shfl_down(cand, o, 64);
+    if ((threadIdx.x & 63) == 0 && cand) atomicAdd(total, cand);
+}
+
+// pass 2: cut and queue
+__global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__restrict__ cand_in, int64_t nchunks,
+                                                            const unsigned long long *__restrict__ total,
+                                                            int64_t floor_thr, uint32_t *order, uint32_t *counters) {
     __shared__ uint32_t s_wave[kRangesWG / 64];
     __shared__ uint32_t s_base[2];
     const int64_t c = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
     const bool live = c < nchunks;
-    int64_t cand = 0;
-    if (live) {
-        const CenterChunk ck = chunks[c];
-        for (int f = 0; f < nfiles; ++f) {
-            const GFile fv = gfile(files[f]);
-            const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
-            cand += lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start + ck.len + (1 << kLinShift) - 1) -
-                    lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start - W + 1);
-        }
-    }
-    const bool heavy = live && cand > heavy_thr;
+    const int64_t mean = (int64_t)(*total / (unsigned long long)(nchunks > 0 ? nchunks : 1));
+    const int64_t t1 = 8 * mean > floor_thr ? 8 * mean : floor_thr, t2 = 4 * t1;
+    const int64_t cand = live ? (int64_t)cand_in[c] : 0;
+    const uint32_t nsub = !live ? 0u : (cand > t2 ? 8u : (cand > t1 ? 4u : 0u)); // 0: not cut
     uint32_t th, tl;
-    const uint32_t oh = block_scan_excl(heavy ? 1u : 0u, s_wave, th);
-    const uint32_t ol = block_scan_excl((live && !heavy) ? 1u : 0u, s_wave, tl);
+    const uint32_t oh = block_scan_excl(nsub, s_wave, th);
+    const uint32_t ol = block_scan_excl((live && nsub == 0u) ? 1u : 0u, s_wave, tl);
     if (threadIdx.x == 0) {
         s_base[0] = th ? atomicAdd(&counters[0], th) : 0u;
         s_base[1] = tl ? atomicAdd(&counters[1], tl) : 0u;
     }
     __syncthreads();
     if (!live) return;
-    if (heavy) order[s_base[0] + oh] = (uint32_t)c;
-    else order[(uint32_t)nchunks - 1u - (s_base[1] + ol)] = (uint32_t)c;
+    const uint32_t cap = 2u * (uint32_t)nchunks;
+    if (nsub == 0u) {
+        order[cap - 1u - (s_base[1] + ol)] = (uint32_t)c;
+    } else {
+        const uint32_t first_code = nsub == 4u ? 1u : 5u;
+        for (uint32_t k = 0; k < nsub; ++k) order[s_base[0] + oh + k] = (uint32_t)c | ((first_code + k) << kSubShift);
+    }
 }
 
 __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                 const FileView *__restrict__ files, int nfiles,
                                                 MapParams mp, int W, const double *__restrict__ inv_,
-                                                const uint32_t *__restrict__ order, double *hist) {
+                                                const uint32_t *__restrict__ order,
+                                                const uint32_t *__restrict__ counters, double *hist) {
     __shared__ double s_inv[kInvLds];
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
     for (int i = threadIdx.x; i < kInvLds; i += kWG) s_inv[i] = inv[i]; // host-computed IEEE quotients 1.0/m
     __syncthreads();
-    const int64_t slot = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
-    if (slot >= nchunks) return;
+    // the grid spans the list capacity: heavy entries at the front, light ones at the back
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
+    const uint32_t cap = 2u * (uint32_t)nchunks;
+    if (slot >= cap) return;
+    const uint32_t n_heavy = counters[0], n_light = counters[1];
+    const uint32_t entry = order[slot];
+    if (!(slot < n_heavy || slot >= cap - n_light)) return;
     const int lane = threadIdx.x & 63;
-    const CenterChunk ck = chunks[order[slot]];
+    CenterChunk ck = chunks[entry & ((1u << kSubShift) - 1u)];
+    {   // a sub-chunk is a chunk of its own: narrow the descriptor
+        const uint32_t code = entry >> kSubShift;
+        const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
+        const int sub_len = code == 0u ? 64 : (code <= 4u ? 16 : 8);
+        if (sub_off >= ck.len) return;
+        ck.len = ck.len - sub_off < sub_len ? ck.len - sub_off : sub_len;
+        ck.start += sub_off;
+        ck.hist_off += sub_off;
+    }
     const int32_t p = ck.start + lane;
     const int32_t cend = ck.start + ck.len;
     const int nib = mp.param;
