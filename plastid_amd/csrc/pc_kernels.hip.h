@@ -1101,25 +1101,36 @@ constexpr int kInvLds = 1024; // 1/m table kept in LDS for m < kInvLds
 // inequality fewer than nchunks/8 chunks are cut and the heavy entries fit in nchunks slots.
 // Entry = chunk index | code << 27: 0 whole chunk, 1..4 quarter, 5..12 eighth.
 constexpr int kSubShift = 27;
-__device__ __forceinline__ int64_t center_candidates(const CenterChunk &ck, const FileView *__restrict__ files, int nfiles, int W) {
-    int64_t cand = 0;
-    for (int f = 0; f < nfiles; ++f) {
-        const GFile fv = gfile(files[f]);
-        const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
-        cand += lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start + ck.len + (1 << kLinShift) - 1) -
-                lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start - W + 1);
-    }
-    return cand;
-}
-
-// pass 1: candidate count per chunk, and their sum (counters[2..3] as one 64-bit value)
+struct __attribute__((aligned(16))) CenterEntry { int32_t s; int32_t m; double val; };
+// pass 1 (one THREAD per chunk): the record range and the long-span candidate range every file
+// offers the chunk -- all the dependent index lookups happen here, once, instead of at the head of
+// every wave of k_center -- plus the candidate count and its sum (counters[2..3] as one 64-bit value).
+// Ranges are rounded outwards to index buckets and cover every sub-chunk of the chunk; k_center's own
+// tests are exact.
 __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                             const FileView *__restrict__ files, int nfiles, int W,
-                                                            uint32_t *cand_out, unsigned long long *total) {
+                                                            uint32_t *cand_out, u32x4 *ranges, unsigned long long *total) {
     const int64_t c = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
     unsigned long long cand = 0;
     if (c < nchunks) {
-        cand = (unsigned long long)center_candidates(chunks[c], files, nfiles, W);
+        const CenterChunk ck = chunks[c];
+        for (int f = 0; f < nfiles; ++f) {
+            const GFile fv = gfile(files[f]);
+            const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
+            const int64_t cend = (int64_t)ck.start + ck.len;
+            u32x4 rg;
+            rg.x = (uint32_t)lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start - W + 1);
+            rg.y = (uint32_t)lin_floor(fv.lin_tab, q0, nb, cend + (1 << kLinShift) - 1);
+            rg.z = rg.w = 0u;
+            if (fv.nlong) { // they start before the near window of some position of the chunk, and the
+                            // running maximum of the ends has passed the chunk start
+                rg.z = (uint32_t)lin_floor(fv.plin_tab, q0, nb, ck.start);
+                rg.w = (uint32_t)lin_floor(fv.llin_tab, q0, nb, cend - W + (1 << kLinShift) - 1);
+                if (rg.z > rg.w) rg.z = rg.w;
+            }
+            ranges[c * nfiles + f] = rg;
+            cand += rg.y - rg.x;
+        }
         cand_out[c] = (uint32_t)(cand > 0xffffffffull ? 0xffffffffull : cand);
     }
     for (int o = 32; o > 0; o >>= 1) cand += __shfl_down(cand, o, 64);
@@ -1160,8 +1171,10 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
                                                 const FileView *__restrict__ files, int nfiles,
                                                 MapParams mp, int W, const double *__restrict__ inv_,
                                                 const uint32_t *__restrict__ order,
-                                                const uint32_t *__restrict__ counters, double *hist) {
+                                                const uint32_t *__restrict__ counters,
+                                                const u32x4 *__restrict__ ranges, double *hist) {
     __shared__ double s_inv[kInvLds];
+    __shared__ CenterEntry s_list[kWG];                       // 64 compacted candidates per wave
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
     for (int i = threadIdx.x; i < kInvLds; i += kWG) s_inv[i] = inv[i]; // host-computed IEEE quotients 1.0/m
     __syncthreads();
@@ -1173,9 +1186,9 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     const uint32_t entry = order[slot];
     if (!(slot < n_heavy || slot >= cap - n_light)) return;
     const int lane = threadIdx.x & 63;
-    CenterChunk ck = chunks[entry & ((1u << kSubShift) - 1u)];
+    const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
+    CenterChunk ck = chunks[cidx];
     {   // a sub-chunk is a chunk of its own: narrow the descriptor
-        const uint32_t code = entry >> kSubShift;
         const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
         const int sub_len = code == 0u ? 64 : (code <= 4u ? 16 : 8);
         if (sub_off >= ck.len) return;
@@ -1190,27 +1203,30 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
         const int64_t near_key = (int64_t)ck.start - W + 1;
-        const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
-        if (fv.nlong) {
+        const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[(int64_t)cidx * nfiles + f]; // from k_center_weigh
+        if (rg.w > rg.z) {
             // long-span reads that start before the near window but may reach into it (rare:
-            // wave-uniform scalar replay).  Candidates from the linear index of the long list:
-            // they start before near_key, and the running maximum of the ends has passed the chunk
-            // start (both bounds rounded outwards to a bucket; the tests below are exact).
-            int64_t jlo = lin_floor(fv.plin_tab, q0, nb, ck.start);
-            const int64_t jhi = lin_floor(fv.llin_tab, q0, nb, near_key + (1 << kLinShift) - 1);
-            for (int64_t j = jlo; j < jhi; ++j) {
+            // wave-uniform scalar replay); the tests below are exact
+            for (int64_t j = rg.z; j < (int64_t)rg.w; ++j) {
                 if ((int64_t)(int32_t)fv.long_rec[j].x >= near_key) break; // met in the near window instead
                 center_one(fv, mp, fv.long_idx[j], ck.mode, inv, p, acc);
             }
         }
         // near window: the records that start in (start - W, end).  A batch of 64 candidates is
         // fetched with ONE coalesced vector load (the next batch is requested before this one is
-        // used), then replayed in record order out of registers (readlane), so the ordered
-        // float64 accumulation never waits on memory.
-        const int64_t lo = indexed_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, q0, nb, near_key, lane);
-        const int64_t hi = lin_floor(fv.lin_tab, q0, nb, (int64_t)cend + (1 << kLinShift) - 1);
+        // used).  The candidates that can touch the chunk are compacted, in record order, into the
+        // wave's LDS list {first covered position, covered length, 1/m}; then every lane walks the
+        // list with broadcast LDS reads -- the ordered float64 accumulation is a plain dependent
+        // v_add_f64 chain, no scalar extraction per read.  `acc += hit ? val : 0.0` equals the
+        // reference's conditional add bit for bit (x + 0.0 == x for every x this sum can hold).
+        // whole chunks start at the bucket edge (a few surplus candidates, filtered below); the waves of
+        // a cut chunk each search their exact start, or they would all scan the whole pile-up
+        const int64_t lo = code == 0u ? (int64_t)rg.x
+                                      : wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
+        const int64_t hi = rg.y;
         const u32x2 none = {0x7fffffffu, kFlagExcluded << 16};
         u32x2 nxt = (lo + lane < hi) ? fv.rec[lo + lane] : none;
+        CenterEntry *list = s_list + (threadIdx.x >> 6) * 64;
         for (int64_t base = lo; base < hi; base += 64) {
             const u32x2 r = nxt;
             nxt = (base + 64 + lane < hi) ? fv.rec[base + 64 + lane] : none;
@@ -1222,20 +1238,39 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
             bool ok = !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse) && size_ok(mp, L) && (m > 0);
             // can the read touch this chunk at all?  (gapped: decided per run below)
             const int32_t s = pos + nib;
-            ok &= (pos < cend) & ((nbk >= 2) | (s + m > ck.start));
+            ok &= (pos < cend) & (pos >= near_key) & ((nbk >= 2) | (s + m > ck.start)); // before near_key: long-span loop above
             const double val = ok ? (m < kInvLds ? s_inv[m] : inv[m]) : 0.0; // 1.0 / map_length, :250
-            unsigned long long todo = __ballot(ok);
-            while (todo) {                                   // record order
-                const int j = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const uint32_t meta_j = lane_u32(meta, j);
-                const int32_t pos_j = (int32_t)lane_u32((uint32_t)pos, j);
-                const double val_j = lane_f64(val, j);
-                const int L_j = rec_len(meta_j), nb_j = rec_nblk(meta_j);
+            const unsigned long long okmask = __ballot(ok);
+            const int nok = __popcll(okmask);
+            if (ok) {
+                const int k = __popcll(okmask & ((1ull << lane) - 1ull)); // rank in record order
+                CenterEntry e;
+                e.s = nbk >= 2 ? lane : s;                    // gapped: which lane holds the record
+                e.m = nbk >= 2 ? -1 : m;
+                e.val = val;
+                list[k] = e;
+            }
+            // (same wave wrote and reads the list: program order + s_waitcnt, no barrier needed)
+            int k = 0;
+            const bool plain = !__any(ok && nbk >= 2);        // no gapped read in this batch (the usual case)
+            if (plain) {
+                for (; k + 4 <= nok; k += 4) {               // four list entries in flight; adds stay in order
+                    const CenterEntry e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
+                    acc += ((uint32_t)(p - e0.s) < (uint32_t)e0.m) ? e0.val : 0.0;
+                    acc += ((uint32_t)(p - e1.s) < (uint32_t)e1.m) ? e1.val : 0.0;
+                    acc += ((uint32_t)(p - e2.s) < (uint32_t)e2.m) ? e2.val : 0.0;
+                    acc += ((uint32_t)(p - e3.s) < (uint32_t)e3.m) ? e3.val : 0.0;
+                }
+            }
+            for (; k < nok; ++k) {                           // record order; wave-uniform trip count
+                const CenterEntry e = list[k];
                 bool hit;
-                if (nb_j < 2) {
-                    hit = (uint32_t)(p - (pos_j + nib)) < (uint32_t)(L_j - 2 * nib);
-                } else {
+                if (e.m >= 0) {
+                    hit = (uint32_t)(p - e.s) < (uint32_t)e.m;
+                } else {                                     // gapped read: walk its aligned runs
+                    const int j = e.s;
+                    const uint32_t meta_j = lane_u32(meta, j);
+                    const int L_j = rec_len(meta_j), nb_j = rec_nblk(meta_j);
                     hit = false;
                     const i32x2 PC_GLOBAL *bl = fv.blk + fv.blk_off[base + j];
                     int cum = 0;
@@ -1246,7 +1281,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
                         cum += run.y;
                     }
                 }
-                if (hit) acc += val_j;                       // :254, one IEEE add per covering read, in order
+                acc += hit ? e.val : 0.0;                    // :254, one IEEE add per covering read, in order
             }
         }
     }

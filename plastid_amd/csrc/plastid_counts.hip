@@ -206,6 +206,7 @@ struct pc_plan {
     DevBuf<CenterChunk> d_cchunks;
     DevBuf<uint32_t> d_corder;
     DevBuf<uint32_t> d_ccand;   // candidate records per center chunk
+    DevBuf<u32x4> d_cranges;    // per (chunk, file): record range and long-span candidate range
     DevBuf<GatherSeg> d_gsegs;
     DevBuf<GatherChunk> d_gchunks;
     DevBuf<uint32_t> d_tile_items;
@@ -1100,17 +1101,19 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (nchunks >= (int64_t)1 << (kSubShift - 1)) return fail(PC_ERR_ARG, "pc_count: too many positions for the center rule");
             rc = p->d_corder.reserve((size_t)(2 * nchunks));   // dispatch list: heavy entries front, light back
             if (rc == PC_OK) rc = p->d_ccand.reserve((size_t)nchunks);
+            if (rc == PC_OK) rc = p->d_cranges.reserve((size_t)nchunks * (size_t)nfiles);
             if (rc != PC_OK) return rc;
             HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
             e->counters_zero = false;
             unsigned long long *total = (unsigned long long *)(e->d_counters.p + 2); // counters[2..3]
             const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
             hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
-                               p->d_ccand.p, total);
+                               p->d_ccand.p, p->d_cranges.p, total);
             hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, (int64_t)2048,
                                p->d_corder.p, e->d_counters.p);
             hipLaunchKernelGGL(k_center, dim3((unsigned)((2 * nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks,
-                               e->d_files.p, nfiles, mp, W, e->d_inv.p, p->d_corder.p, e->d_counters.p, (double *)p->d_hist.p);
+                               e->d_files.p, nfiles, mp, W, e->d_inv.p, p->d_corder.p, e->d_counters.p, p->d_cranges.p,
+                               (double *)p->d_hist.p);
         }
         if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
         if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
