@@ -16,7 +16,8 @@ def find(pattern):
 
 def short(name):
     name = name.split("(")[0]
-    for k in ("k_hist_point", "k_tile_ranges", "k_long_point", "k_center", "k_gather", "k_total", "k_unmappable", "k_mapped"):
+    for k in ("k_hist_point", "k_tile_ranges", "k_long_point", "k_center_weigh", "k_center_order", "k_center", "k_gather", "k_total",
+              "k_unmappable", "k_mapped"):
         if k in name:
             return k + ("<%s>" % name.split("<")[1].split(">")[0] if "<" in name and k == "k_gather" else "")
     return name[:60]
