@@ -404,6 +404,28 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_wave
     return base + x - v;
 }
 
+__device__ __forceinline__ unsigned long long block_scan_excl64(unsigned long long v, unsigned long long *s_wave,
+                                                               unsigned long long &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kRangesWG / 64; ++i) {
+        const unsigned long long t = s_wave[i];
+        if (i < wv) base += t;
+        tot += t;
+    }
+    total = tot;
+    return base + x - v;
+}
+
 // first index in [lo,hi) of a stride-`STRIDE` dword array whose value >= key (per-thread bisection)
 template <int STRIDE>
 __device__ __forceinline__ int64_t lower_bound_i32(const uint32_t PC_GLOBAL *v, int64_t lo, int64_t hi, int64_t key) {
@@ -433,12 +455,12 @@ __device__ __forceinline__ int64_t lower_bound_i32(const uint32_t PC_GLOBAL *v, 
 //          latency-bound, so what matters is how many windows are in flight per CU.
 // One returning atomic per class per workgroup: a single hot counter saturates near 90/us.
 __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
-                                                           const FileView *__restrict__ files, int nfiles,
-                                                           int G, int W, int64_t R, int64_t pile, WorkItem *work,
-                                                           uint32_t *nwork, uint32_t *tile_items,
+                                                           FileView file0, const FileView *__restrict__ files,
+                                                           int nfiles, int G, int W, int64_t R, int64_t pile,
+                                                           WorkItem *work, uint32_t *nwork, uint32_t *tile_items,
                                                            uint32_t work_cap, WorkItem *work_small, int small_g,
                                                            int64_t small_n) {
-    __shared__ uint32_t s_wave[kRangesWG / 64];
+    __shared__ unsigned long long s_wave64[kRangesWG / 64];
     __shared__ uint32_t s_base[3];
     const int64_t idx = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
     const bool live = idx < (int64_t)ntiles * nfiles;
@@ -453,7 +475,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         t = (int)(idx / nfiles);
         f = (int)(idx % nfiles);
         tl = tiles[t];
-        fv = gfile(files[f]);
+        fv = f == 0 ? gfile(file0) : gfile(files[f]); // the first file's view travels as a kernel argument
         ws = tl.win_start;
         l0 = fv.lin_off[tl.tid];
         nb = fv.lin_off[tl.tid + 1] - l0 - 1;
@@ -498,10 +520,13 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             n_light = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || f == 0) ? 1u : 0u);
         }
     }
-    uint32_t tot_h, tot_l, tot_s;
-    const uint32_t off_h = block_scan_excl(n_heavy, s_wave, tot_h);
-    const uint32_t off_l = block_scan_excl(n_light, s_wave, tot_l);
-    const uint32_t off_s = block_scan_excl(n_small, s_wave, tot_s);
+    // one scan for the three classes: 21 bits each (a block queues far fewer than 2 M items)
+    unsigned long long tot3;
+    const unsigned long long off3 = block_scan_excl64((unsigned long long)n_heavy | ((unsigned long long)n_light << 21) |
+                                                      ((unsigned long long)n_small << 42), s_wave64, tot3);
+    const uint32_t m21 = (1u << 21) - 1u;
+    const uint32_t tot_h = (uint32_t)tot3 & m21, tot_l = (uint32_t)(tot3 >> 21) & m21, tot_s = (uint32_t)(tot3 >> 42) & m21;
+    const uint32_t off_h = (uint32_t)off3 & m21, off_l = (uint32_t)(off3 >> 21) & m21, off_s = (uint32_t)(off3 >> 42) & m21;
     if (threadIdx.x == 0) {
         s_base[0] = tot_h ? atomicAdd(&nwork[0], tot_h) : 0u;
         s_base[1] = tot_l ? atomicAdd(&nwork[1], tot_l) : 0u;

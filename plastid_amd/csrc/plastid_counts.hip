@@ -1017,7 +1017,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             p->tile_items_zero = false;
             const int64_t nthreads = (int64_t)ntiles * nfiles; // one thread per (tile, file)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
-                               e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
+                               e->files[0]->view(), e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
                                e->d_work_small.p, small_g, small_n);
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
