@@ -157,6 +157,7 @@ struct pc_engine {
     DevBuf<WorkItem> d_work, d_work_small;
     DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
     bool counters_zero = false; // left zeroed by the last kernel of a point-rule count
+    size_t max_lds = 64 * 1024; // LDS a workgroup may use (160 KiB on gfx950)
     DevBuf<double> d_partial;
     DevBuf<Unmappable> d_unmap;
     double last_ms[6] = {0, 0, 0, 0, 0, 0};
@@ -279,6 +280,11 @@ int pc_create(int device, pc_engine **out) {
     pc_engine *e = new pc_engine();
     e->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    {
+        int lds_attr = 0;
+        if (hipDeviceGetAttribute(&lds_attr, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds_attr > 0)
+            e->max_lds = (size_t)lds_attr;
+    }
     for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     std::vector<double> inv(65536);
     inv[0] = 0.0;
@@ -1037,7 +1043,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             fast_lo = std::min(fast_lo, fast_hi);
             const size_t fwords = (size_t)(fast_hi + 1) * kModes + 64; // entry table + one dump word per lane (after the staged pieces)
             const size_t lds = (bins_words + fwords) * sizeof(uint32_t);
-            if (lds > 64 * 1024) return fail(PC_ERR_ARG, "pc_count: LDS budget exceeded (%zu bytes)", lds);
+            if (lds > e->max_lds)
+                return fail(PC_ERR_ARG, "pc_count: the window needs %zu bytes of LDS, the device offers %zu per workgroup (too many rows)", lds, e->max_lds);
             const FileView fv0 = e->files[0]->view();
             const FileView fv1 = nfiles > 1 ? e->files[1]->view() : fv0;
             const unsigned grid = (unsigned)cap64;

@@ -395,6 +395,24 @@ def test_threaded_staging_is_deterministic(pa, monkeypatch):
         eng.close()
 
 
+def test_stratified_with_many_rows(pa, oracle):
+    """36 length rows x both strands need more than 64 KiB of LDS bins per window: gfx950 lets a
+    workgroup have it."""
+    from plastid_amd import synth
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.002, tx_scale=0.004)
+    mapping = ("stratified", {"default": 12, 30: 15}, 15, 50)
+    eng = engine_for(pa, [reads], mapping)
+    rows = eng.rows
+    assert rows == 36
+    parr = tx.plan_arrays(rows=rows)
+    plan = eng.plan(parr["tid"], parr["start"], parr["end"], parr["strand"], parr["out_off"], parr["out_step"],
+                    parr["row_stride"], parr["out_elems"], rows)
+    exp, _ = oracle_chain_outputs(oracle, [reads], spec_for(oracle, mapping), tx, parr, rows, np.int64)
+    assert np.array_equal(plan.count(np.int64), exp) and exp.sum() > 0
+    plan.close()
+    eng.close()
+
+
 def test_inverse_table_is_ieee(pa):
     """1.0/m used by the center kernel is the host's correctly rounded quotient;
     a lone read of aligned length m contributes exactly 1.0/m at each position."""
