@@ -1043,7 +1043,10 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
                                                       typename OutT_<OUTMODE>::type *out, double norm_sum) {
     __shared__ uint32_t s_list[kWG];
     __shared__ uint32_t s_n;
-    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 4) {
+        counters[4 + threadIdx.x] = counters[threadIdx.x]; // kept for diagnostics (PC_DEBUG_WORK)
+        counters[threadIdx.x] = 0u;
+    }
     if (per_wg == 1) {
         if (tile_items[blockIdx.x] == 0u) return; // only windows that were merged through the histogram
         gather_tile<OUTMODE>(tiles[blockIdx.x], pieces, opieces, rows, hist, hist_row_stride, out, norm_sum);

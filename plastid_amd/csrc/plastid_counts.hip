@@ -290,7 +290,7 @@ int pc_create(int device, pc_engine **out) {
     inv[0] = 0.0;
     for (int m = 1; m < 65536; ++m) inv[m] = 1.0 / (double)m; // the reference's `1.0 / map_length`
     int rc = e->d_inv.upload(inv, e->stream);
-    if (rc == PC_OK) rc = e->d_counters.reserve(4);
+    if (rc == PC_OK) rc = e->d_counters.reserve(8);
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: sync failed");
     if (rc != PC_OK) {
         pc_destroy(e);
@@ -1011,8 +1011,11 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // sparse windows: single-wave workgroups with a small LDS window (rows == 1 only)
             // (skipped for dense annotations, where queried positions fill most of every window)
             const bool sparse_plan = (double)p->npos < 0.25 * (double)ntiles * (double)G;
-            const int small_g = (p->rows == 1 && sparse_plan && !getenv("PC_NO_SMALL")) ? std::min(512, G) : 0;
-            const int64_t small_n = 2048;
+            int small_span = 512;                                          // tuning knobs
+            if (const char *env = getenv("PC_SMALL_G")) small_span = std::max(64, atoi(env) / 64 * 64);
+            const int small_g = (p->rows == 1 && sparse_plan && !getenv("PC_NO_SMALL")) ? std::min(small_span, G) : 0;
+            int64_t small_n = 2048;
+            if (const char *env = getenv("PC_SMALL_N")) small_n = std::max(64, atoi(env));
             const int64_t cap_small = small_g ? (int64_t)ntiles * nfiles : 0;
             rc = e->d_work_small.reserve((size_t)std::max<int64_t>(cap_small, 1));
             if (rc != PC_OK) return rc;
@@ -1093,6 +1096,13 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
 #undef PC_LAUNCH_SPLIT
             e->counters_zero = true;
             p->tile_items_zero = true;
+            if (getenv("PC_DEBUG_WORK")) { // diagnostics: how many work items of each class this call queued
+                uint32_t c4[4] = {0, 0, 0, 0};
+                HIP_TRY(hipMemcpyAsync(c4, e->d_counters.p + 4, sizeof(c4), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                fprintf(stderr, "[work] tiles %d: heavy %u light %u small %u (capacity %lld, G %d, R %lld)\n", ntiles, c4[0], c4[1], c4[2],
+                        (long long)cap64, G, (long long)R);
+            }
         } else {
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
