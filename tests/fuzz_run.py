@@ -1,7 +1,8 @@
-"""Long-running randomised differential run (GPU box): python scripts/fuzz.py [seconds] [first_seed] [size]"""
+"""Long-running randomised differential run (GPU box; test infrastructure, not collected by pytest):
+    python tests/fuzz_run.py [seconds] [first_seed] [size]"""
 import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import plastid_amd as pa
 from oracle import oracle
 import fuzz_cases, test_gpu_parity as T
