@@ -1129,7 +1129,10 @@ constexpr int kInvLds = 1024; // 1/m table kept in LDS for m < kInvLds
 // inequality fewer than nchunks/8 chunks are cut and the heavy entries fit in nchunks slots.
 // Entry = chunk index | code << 27: 0 whole chunk, 1..4 quarter, 5..12 eighth.
 constexpr int kSubShift = 27;
-struct __attribute__((aligned(16))) CenterEntry { int32_t s; int32_t m; double val; };
+// One candidate read of the center kernel, ready to replay: the (at most two) runs of covered
+// positions [a0, a0+m0) and [a1, a1+m1) after trimming `nibble` from both ends, and 1/m.
+// m0 < 0: a read with three or more aligned runs -- `a0` names the lane that holds its header.
+struct __attribute__((aligned(16))) CenterEntry { int32_t a0, m0, a1, m1; double val; int32_t pad0, pad1; };
 // pass 1 (one THREAD per chunk): the record range and the long-span candidate range every file
 // offers the chunk -- all the dependent index lookups happen here, once, instead of at the head of
 // every wave of k_center -- plus the candidate count and its sum (counters[2..3] as one 64-bit value).
@@ -1195,6 +1198,75 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
     }
 }
 
+// One batch of up to 64 candidate reads (lane j holds candidate j's header, in record order):
+// filter, fetch the first two aligned runs of the gapped ones (all lanes at once -- not one
+// dependent load chain per read), compact the reads that can touch the chunk into the wave's LDS
+// list, then let every lane walk the list with broadcast reads, four entries in flight.  The
+// ordered float64 accumulation is a plain dependent v_add_f64 chain; `acc += hit ? val : 0.0`
+// equals the reference's conditional add bit for bit (x + 0.0 == x for every x this sum can hold).
+__device__ __forceinline__ void center_batch(const GFile &fv, const MapParams &mp, const CenterChunk &ck, int32_t cend,
+                                             bool in, int32_t pos, uint32_t meta, uint32_t boff, const double *s_inv,
+                                             const double PC_GLOBAL *inv, CenterEntry *list, int lane, int32_t p,
+                                             double &acc) {
+    const int nib = mp.param;
+    const uint32_t fl = rec_flags(meta);
+    const int L = rec_len(meta), nbk = rec_nblk(meta);
+    const int m = L - 2 * nib;                               // map_length, :245
+    bool ok = in && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse) && size_ok(mp, L) && (m > 0) &&
+              (pos < cend);
+    CenterEntry e;
+    e.a0 = pos + nib; e.m0 = m; e.a1 = 0; e.m1 = 0; e.pad0 = e.pad1 = 0;
+    if (ok && nbk >= 2) {
+        const i32x2 b0 = fv.blk[boff], b1 = fv.blk[boff + 1];
+        if (nbk == 2) {                                      // positions with index in [nib, L - nib)
+            const int hi0 = b0.y < L - nib ? b0.y : L - nib;
+            e.a0 = b0.x + nib; e.m0 = hi0 > nib ? hi0 - nib : 0;
+            const int lo1 = nib > b0.y ? nib : b0.y;
+            e.a1 = b1.x + (lo1 - b0.y); e.m1 = L - nib > lo1 ? L - nib - lo1 : 0;
+        } else {
+            e.a0 = lane; e.m0 = -1;                          // walked run by run below
+        }
+    }
+    // can the read touch this chunk at all?
+    if (e.m0 >= 0)
+        ok &= ((e.a0 < cend) & (e.a0 + e.m0 > ck.start)) | ((e.m1 > 0) & (e.a1 < cend) & (e.a1 + e.m1 > ck.start));
+    e.val = ok ? (m < kInvLds ? s_inv[m] : inv[m]) : 0.0;    // 1.0 / map_length, :250
+    const unsigned long long okmask = __ballot(ok);
+    const int nok = __popcll(okmask);
+    if (ok) list[__popcll(okmask & ((1ull << lane) - 1ull))] = e; // rank in record order
+    // (same wave wrote and reads the list: program order, no barrier needed)
+    int k = 0;
+    if (!__any(ok && e.m0 < 0)) {                            // no read with > 2 runs in this batch (the usual case)
+        for (; k + 4 <= nok; k += 4) {                       // four list entries in flight; adds stay in order
+            const CenterEntry e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
+            acc += (((uint32_t)(p - e0.a0) < (uint32_t)e0.m0) | ((uint32_t)(p - e0.a1) < (uint32_t)e0.m1)) ? e0.val : 0.0;
+            acc += (((uint32_t)(p - e1.a0) < (uint32_t)e1.m0) | ((uint32_t)(p - e1.a1) < (uint32_t)e1.m1)) ? e1.val : 0.0;
+            acc += (((uint32_t)(p - e2.a0) < (uint32_t)e2.m0) | ((uint32_t)(p - e2.a1) < (uint32_t)e2.m1)) ? e2.val : 0.0;
+            acc += (((uint32_t)(p - e3.a0) < (uint32_t)e3.m0) | ((uint32_t)(p - e3.a1) < (uint32_t)e3.m1)) ? e3.val : 0.0;
+        }
+    }
+    for (; k < nok; ++k) {                                   // record order; wave-uniform trip count
+        const CenterEntry c = list[k];
+        bool hit;
+        if (c.m0 >= 0) {
+            hit = ((uint32_t)(p - c.a0) < (uint32_t)c.m0) | ((uint32_t)(p - c.a1) < (uint32_t)c.m1);
+        } else {                                             // three or more runs: walk them
+            const int j = c.a0;
+            const uint32_t meta_j = lane_u32(meta, j), boff_j = lane_u32(boff, j);
+            const int L_j = rec_len(meta_j), nb_j = rec_nblk(meta_j);
+            hit = false;
+            int cum = 0;
+            for (int q = 0; q < nb_j; ++q) {
+                const i32x2 run = fv.blk[boff_j + q];
+                const int idx = cum + (p - run.x);
+                hit |= (p >= run.x) & (p < run.x + run.y) & (idx >= nib) & (idx < L_j - nib);
+                cum += run.y;
+            }
+        }
+        acc += hit ? c.val : 0.0;                            // :254, one IEEE add per covering read, in order
+    }
+}
+
 __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                 const FileView *__restrict__ files, int nfiles,
                                                 MapParams mp, int W, const double *__restrict__ inv_,
@@ -1232,85 +1304,38 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
         const GFile fv = gfile(files[f]);
         const int64_t near_key = (int64_t)ck.start - W + 1;
         const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[(int64_t)cidx * nfiles + f]; // from k_center_weigh
-        if (rg.w > rg.z) {
-            // long-span reads that start before the near window but may reach into it (rare:
-            // wave-uniform scalar replay); the tests below are exact
-            for (int64_t j = rg.z; j < (int64_t)rg.w; ++j) {
-                if ((int64_t)(int32_t)fv.long_rec[j].x >= near_key) break; // met in the near window instead
-                center_one(fv, mp, fv.long_idx[j], ck.mode, inv, p, acc);
-            }
+        CenterEntry *list = s_list + (threadIdx.x >> 6) * 64;
+        // long-span reads that start before the near window but may reach into it: they precede every
+        // near-window record in the file, so they are replayed first (64 list entries at a time)
+        for (int64_t base = rg.z; base < (int64_t)rg.w; base += 64) {
+            const bool in = base + lane < (int64_t)rg.w;
+            const u32x4 g = in ? fv.long_rec[base + lane] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
+            if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_key) break; // sorted by start: the rest is met in the near window
+            center_batch(fv, mp, ck, cend, in & ((int64_t)(int32_t)g.x < near_key), (int32_t)g.x, g.y, g.z, s_inv, inv, list,
+                         lane, p, acc);
         }
-        // near window: the records that start in (start - W, end).  A batch of 64 candidates is
-        // fetched with ONE coalesced vector load (the next batch is requested before this one is
-        // used).  The candidates that can touch the chunk are compacted, in record order, into the
-        // wave's LDS list {first covered position, covered length, 1/m}; then every lane walks the
-        // list with broadcast LDS reads -- the ordered float64 accumulation is a plain dependent
-        // v_add_f64 chain, no scalar extraction per read.  `acc += hit ? val : 0.0` equals the
-        // reference's conditional add bit for bit (x + 0.0 == x for every x this sum can hold).
-        // whole chunks start at the bucket edge (a few surplus candidates, filtered below); the waves of
-        // a cut chunk each search their exact start, or they would all scan the whole pile-up
+        // near window: the records that start in [start - W + 1, end).  A batch of 64 candidates is
+        // fetched with ONE coalesced vector load, four batches in flight (a wave walks its range
+        // alone).  Whole chunks start at the bucket edge (a few surplus candidates, filtered out); the
+        // waves of a cut chunk each search their exact start, or they would all scan the whole pile-up.
         const int64_t lo = code == 0u ? (int64_t)rg.x
                                       : wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
         const int64_t hi = rg.y;
         const u32x2 none = {0x7fffffffu, kFlagExcluded << 16};
-        u32x2 nxt = (lo + lane < hi) ? fv.rec[lo + lane] : none;
-        CenterEntry *list = s_list + (threadIdx.x >> 6) * 64;
+        u32x2 q0 = (lo + lane < hi) ? fv.rec[lo + lane] : none;
+        u32x2 q1 = (lo + 64 + lane < hi) ? fv.rec[lo + 64 + lane] : none;
+        u32x2 q2 = (lo + 128 + lane < hi) ? fv.rec[lo + 128 + lane] : none;
+        u32x2 q3 = (lo + 192 + lane < hi) ? fv.rec[lo + 192 + lane] : none;
         for (int64_t base = lo; base < hi; base += 64) {
-            const u32x2 r = nxt;
-            nxt = (base + 64 + lane < hi) ? fv.rec[base + 64 + lane] : none;
+            const u32x2 r = q0;
+            q0 = q1; q1 = q2; q2 = q3;
+            q3 = (base + 256 + lane < hi) ? fv.rec[base + 256 + lane] : none;
             if ((int32_t)lane_u32(r.x, 0) >= cend) break; // sorted by start: nothing further can reach the chunk
-            const uint32_t meta = r.y, fl = rec_flags(meta);
             const int32_t pos = (int32_t)r.x;
-            const int L = rec_len(meta), nbk = rec_nblk(meta);
-            const int m = L - 2 * nib;                       // map_length, :245
-            bool ok = !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse) && size_ok(mp, L) && (m > 0);
-            // can the read touch this chunk at all?  (gapped: decided per run below)
-            const int32_t s = pos + nib;
-            ok &= (pos < cend) & (pos >= near_key) & ((nbk >= 2) | (s + m > ck.start)); // before near_key: long-span loop above
-            const double val = ok ? (m < kInvLds ? s_inv[m] : inv[m]) : 0.0; // 1.0 / map_length, :250
-            const unsigned long long okmask = __ballot(ok);
-            const int nok = __popcll(okmask);
-            if (ok) {
-                const int k = __popcll(okmask & ((1ull << lane) - 1ull)); // rank in record order
-                CenterEntry e;
-                e.s = nbk >= 2 ? lane : s;                    // gapped: which lane holds the record
-                e.m = nbk >= 2 ? -1 : m;
-                e.val = val;
-                list[k] = e;
-            }
-            // (same wave wrote and reads the list: program order + s_waitcnt, no barrier needed)
-            int k = 0;
-            const bool plain = !__any(ok && nbk >= 2);        // no gapped read in this batch (the usual case)
-            if (plain) {
-                for (; k + 4 <= nok; k += 4) {               // four list entries in flight; adds stay in order
-                    const CenterEntry e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
-                    acc += ((uint32_t)(p - e0.s) < (uint32_t)e0.m) ? e0.val : 0.0;
-                    acc += ((uint32_t)(p - e1.s) < (uint32_t)e1.m) ? e1.val : 0.0;
-                    acc += ((uint32_t)(p - e2.s) < (uint32_t)e2.m) ? e2.val : 0.0;
-                    acc += ((uint32_t)(p - e3.s) < (uint32_t)e3.m) ? e3.val : 0.0;
-                }
-            }
-            for (; k < nok; ++k) {                           // record order; wave-uniform trip count
-                const CenterEntry e = list[k];
-                bool hit;
-                if (e.m >= 0) {
-                    hit = (uint32_t)(p - e.s) < (uint32_t)e.m;
-                } else {                                     // gapped read: walk its aligned runs
-                    const int j = e.s;
-                    const uint32_t meta_j = lane_u32(meta, j);
-                    const int L_j = rec_len(meta_j), nb_j = rec_nblk(meta_j);
-                    hit = false;
-                    const i32x2 PC_GLOBAL *bl = fv.blk + fv.blk_off[base + j];
-                    int cum = 0;
-                    for (int q = 0; q < nb_j; ++q) {
-                        const i32x2 run = bl[q];
-                        const int idx = cum + (p - run.x);
-                        hit |= (p >= run.x) & (p < run.x + run.y) & (idx >= nib) & (idx < L_j - nib);
-                        cum += run.y;
-                    }
-                }
-                acc += hit ? e.val : 0.0;                    // :254, one IEEE add per covering read, in order
-            }
+            // records before near_key belong to the long-span loop above (or cannot reach the chunk)
+            const bool in = (base + lane < hi) & ((int64_t)pos >= near_key);
+            const uint32_t boff = (in && rec_nblk(r.y) >= 2) ? fv.blk_off[base + lane] : 0u;
+            center_batch(fv, mp, ck, cend, in, pos, r.y, boff, s_inv, inv, list, lane, p, acc);
         }
     }
     if (lane < ck.len) hist[ck.hist_off + lane] = acc;
