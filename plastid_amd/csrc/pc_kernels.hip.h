@@ -1133,6 +1133,7 @@ constexpr int kSubShift = 27;
 // positions [a0, a0+m0) and [a1, a1+m1) after trimming `nibble` from both ends, and 1/m.
 // m0 < 0: a read with three or more aligned runs -- `a0` names the lane that holds its header.
 struct __attribute__((aligned(16))) CenterEntry { int32_t a0, m0, a1, m1; double val; int32_t pad0, pad1; };
+struct __attribute__((aligned(16))) CenterPlain { int32_t a0, m0; double val; }; // single-run reads only
 // pass 1 (one THREAD per chunk): the record range and the long-span candidate range every file
 // offers the chunk -- all the dependent index lookups happen here, once, instead of at the head of
 // every wave of k_center -- plus the candidate count and its sum (counters[2..3] as one 64-bit value).
@@ -1204,6 +1205,11 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
 // list, then let every lane walk the list with broadcast reads, four entries in flight.  The
 // ordered float64 accumulation is a plain dependent v_add_f64 chain; `acc += hit ? val : 0.0`
 // equals the reference's conditional add bit for bit (x + 0.0 == x for every x this sum can hold).
+// PLAIN = no candidate of the batch has several aligned runs or a map length beyond the LDS table:
+// that instantiation contains no global load at all.  (A load anywhere in the routine, even one
+// skipped at run time, makes the compiler wait for *all* outstanding loads -- the record
+// prefetches included -- wherever its destination register is used.)
+template <bool PLAIN>
 __device__ __forceinline__ void center_batch(const GFile &fv, const MapParams &mp, const CenterChunk &ck, int32_t cend,
                                              bool in, int32_t pos, uint32_t meta, uint32_t boff, const double *s_inv,
                                              const double PC_GLOBAL *inv, CenterEntry *list, int lane, int32_t p,
@@ -1216,7 +1222,7 @@ __device__ __forceinline__ void center_batch(const GFile &fv, const MapParams &m
               (pos < cend);
     CenterEntry e;
     e.a0 = pos + nib; e.m0 = m; e.a1 = 0; e.m1 = 0; e.pad0 = e.pad1 = 0;
-    if (ok && nbk >= 2) {
+    if (!PLAIN) if (ok && nbk >= 2) {
         const i32x2 b0 = fv.blk[boff], b1 = fv.blk[boff + 1];
         if (nbk == 2) {                                      // positions with index in [nib, L - nib)
             const int hi0 = b0.y < L - nib ? b0.y : L - nib;
@@ -1230,13 +1236,33 @@ __device__ __forceinline__ void center_batch(const GFile &fv, const MapParams &m
     // can the read touch this chunk at all?
     if (e.m0 >= 0)
         ok &= ((e.a0 < cend) & (e.a0 + e.m0 > ck.start)) | ((e.m1 > 0) & (e.a1 < cend) & (e.a1 + e.m1 > ck.start));
-    e.val = ok ? (m < kInvLds ? s_inv[m] : inv[m]) : 0.0;    // 1.0 / map_length, :250
+    e.val = (ok && m < kInvLds) ? s_inv[m] : 0.0;            // 1.0 / map_length, :250
+    if (!PLAIN) if (ok && m >= kInvLds) e.val = inv[m];
     const unsigned long long okmask = __ballot(ok);
     const int nok = __popcll(okmask);
+    if (PLAIN) {
+        // every read of the batch is one run: 16-byte entries {start, length, 1/m}, five instructions
+        // per entry and position (a wave over a pile-up runs alone: its replay is issue-bound)
+        CenterPlain *plist = (CenterPlain *)list;
+        if (ok) plist[__popcll(okmask & ((1ull << lane) - 1ull))] = CenterPlain{e.a0, e.m0, e.val};
+        int k = 0;
+        for (; k + 4 <= nok; k += 4) {                       // four list entries in flight; adds stay in order
+            const CenterPlain e0 = plist[k], e1 = plist[k + 1], e2 = plist[k + 2], e3 = plist[k + 3];
+            acc += ((uint32_t)(p - e0.a0) < (uint32_t)e0.m0) ? e0.val : 0.0;
+            acc += ((uint32_t)(p - e1.a0) < (uint32_t)e1.m0) ? e1.val : 0.0;
+            acc += ((uint32_t)(p - e2.a0) < (uint32_t)e2.m0) ? e2.val : 0.0;
+            acc += ((uint32_t)(p - e3.a0) < (uint32_t)e3.m0) ? e3.val : 0.0;
+        }
+        for (; k < nok; ++k) {
+            const CenterPlain c = plist[k];
+            acc += ((uint32_t)(p - c.a0) < (uint32_t)c.m0) ? c.val : 0.0;
+        }
+        return;
+    }
     if (ok) list[__popcll(okmask & ((1ull << lane) - 1ull))] = e; // rank in record order
     // (same wave wrote and reads the list: program order, no barrier needed)
     int k = 0;
-    if (!__any(ok && e.m0 < 0)) {                            // no read with > 2 runs in this batch (the usual case)
+    if (!__any(ok && e.m0 < 0)) {                            // no read with > 2 runs in this batch
         for (; k + 4 <= nok; k += 4) {                       // four list entries in flight; adds stay in order
             const CenterEntry e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
             acc += (((uint32_t)(p - e0.a0) < (uint32_t)e0.m0) | ((uint32_t)(p - e0.a1) < (uint32_t)e0.m1)) ? e0.val : 0.0;
@@ -1311,8 +1337,8 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
             const bool in = base + lane < (int64_t)rg.w;
             const u32x4 g = in ? fv.long_rec[base + lane] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
             if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_key) break; // sorted by start: the rest is met in the near window
-            center_batch(fv, mp, ck, cend, in & ((int64_t)(int32_t)g.x < near_key), (int32_t)g.x, g.y, g.z, s_inv, inv, list,
-                         lane, p, acc);
+            center_batch<false>(fv, mp, ck, cend, in & ((int64_t)(int32_t)g.x < near_key), (int32_t)g.x, g.y, g.z, s_inv, inv,
+                                list, lane, p, acc);
         }
         // near window: the records that start in [start - W + 1, end).  A batch of 64 candidates is
         // fetched with ONE coalesced vector load, four batches in flight (a wave walks its range
@@ -1321,21 +1347,43 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
         const int64_t lo = code == 0u ? (int64_t)rg.x
                                       : wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
         const int64_t hi = rg.y;
-        const u32x2 none = {0x7fffffffu, kFlagExcluded << 16};
-        u32x2 q0 = (lo + lane < hi) ? fv.rec[lo + lane] : none;
-        u32x2 q1 = (lo + 64 + lane < hi) ? fv.rec[lo + 64 + lane] : none;
-        u32x2 q2 = (lo + 128 + lane < hi) ? fv.rec[lo + 128 + lane] : none;
-        u32x2 q3 = (lo + 192 + lane < hi) ? fv.rec[lo + 192 + lane] : none;
-        for (int64_t base = lo; base < hi; base += 64) {
-            const u32x2 r = q0;
-            q0 = q1; q1 = q2; q2 = q3;
-            q3 = (base + 256 + lane < hi) ? fv.rec[base + 256 + lane] : none;
-            if ((int32_t)lane_u32(r.x, 0) >= cend) break; // sorted by start: nothing further can reach the chunk
+        // (the loads are unconditional, with the index clamped into the range: a load under a lane
+        // predicate would keep the compiler from counting how many are outstanding, and it would
+        // wait for all of them at every batch)
+        const int64_t last = hi - 1;
+        u32x2 q0 = {0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
+        if (hi > lo) {
+            q0 = fv.rec[lo + lane < last ? lo + lane : last];
+            q1 = fv.rec[lo + 64 + lane < last ? lo + 64 + lane : last];
+            q2 = fv.rec[lo + 128 + lane < last ? lo + 128 + lane : last];
+            q3 = fv.rec[lo + 192 + lane < last ? lo + 192 + lane : last];
+        }
+        // one batch: take its records out of register `q`, refill `q` with the batch four ahead (the
+        // loop is unrolled over the four registers: rotating them with moves would make every batch
+        // wait for all loads), then filter / compact / replay.  Returns false when the scan is over.
+        auto step = [&](u32x2 &q, int64_t base) -> bool {
+            if (base >= hi) return false;
+            const u32x2 r = q;
+            q = fv.rec[base + 256 + lane < last ? base + 256 + lane : last];
+            if ((int32_t)lane_u32(r.x, 0) >= cend) return false; // sorted by start: nothing further can reach the chunk
             const int32_t pos = (int32_t)r.x;
             // records before near_key belong to the long-span loop above (or cannot reach the chunk)
             const bool in = (base + lane < hi) & ((int64_t)pos >= near_key);
-            const uint32_t boff = (in && rec_nblk(r.y) >= 2) ? fv.blk_off[base + lane] : 0u;
-            center_batch(fv, mp, ck, cend, in, pos, r.y, boff, s_inv, inv, list, lane, p, acc);
+            const bool odd = in && (rec_nblk(r.y) >= 2 || rec_len(r.y) - 2 * mp.param >= kInvLds);
+            if (__any(odd)) {                                // gapped reads / very long reads in the batch
+                uint32_t boff = 0u;
+                if (in && rec_nblk(r.y) >= 2) boff = fv.blk_off[base + lane];
+                center_batch<false>(fv, mp, ck, cend, in, pos, r.y, boff, s_inv, inv, list, lane, p, acc);
+            } else {
+                center_batch<true>(fv, mp, ck, cend, in, pos, r.y, 0u, s_inv, inv, list, lane, p, acc);
+            }
+            return true;
+        };
+        for (int64_t base = lo; base < hi; base += 256) {
+            if (!step(q0, base)) break;
+            if (!step(q1, base + 64)) break;
+            if (!step(q2, base + 128)) break;
+            if (!step(q3, base + 192)) break;
         }
     }
     if (lane < ck.len) hist[ck.hist_off + lane] = acc;
