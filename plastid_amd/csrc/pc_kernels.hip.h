@@ -1073,39 +1073,7 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
 // 1/(L-2*nibble) over the reads whose trimmed positions contain p.  The order is
 // part of the contract (the reference's own test demands exact equality), so
 // there are no atomics: one lane owns one output position and replays, in record
-// order, every read that can cover it.  One wave per 64 positions; the candidate
-// loop is wave-uniform (scalar loads), the coverage test is per lane.
-__device__ __forceinline__ void center_one(const GFile &fv, const MapParams &mp, int64_t i, int mode,
-                                           const double PC_GLOBAL *inv, int32_t p, double &acc) {
-    const u32x2 r = fv.rec[i];
-    const uint32_t meta = r.y;
-    const uint32_t fl = rec_flags(meta);
-    if (fl & kFlagExcluded) return;
-    if (!strand_ok(mode, fl & kFlagReverse)) return;
-    const int L = rec_len(meta);
-    if (!size_ok(mp, L)) return;
-    const int nib = mp.param;
-    const int m = L - 2 * nib;              // map_length, :245
-    if (m <= 0) return;                     // :246-249
-    const double val = inv[m];              // 1.0 / map_length, :250 (host-computed IEEE quotient)
-    const int nb = rec_nblk(meta);
-    bool hit;
-    if (nb < 2) {
-        const int32_t s = (int32_t)r.x + nib;
-        hit = p >= s && p < s + m;
-    } else {
-        hit = false;
-        const i32x2 PC_GLOBAL *b = fv.blk + fv.blk_off[i];
-        int cum = 0;
-        for (int j = 0; j < nb; ++j) {
-            const i32x2 run = b[j];
-            const int idx = cum + (p - run.x);
-            hit |= (p >= run.x) && (p < run.x + run.y) && (idx >= nib) && (idx < L - nib);
-            cum += run.y;
-        }
-    }
-    if (hit) acc += val;                    // :254, one IEEE add per covering read, in order
-}
+// order, every read that can cover it.  One wave per chunk of <= 64 positions.
 
 // wave-uniform value of lane `j` of a per-lane register (j uniform)
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
