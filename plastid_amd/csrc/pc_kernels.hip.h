@@ -80,6 +80,8 @@ struct FileView {
     const int64_t *long_tid_bounds; // ntid+1
     const uint4 *long_rec;          // long-span records {pos, meta, blk_off, rec_idx}, record order
     const uint4 *gap_rec;           // short-span gapped records {pos, meta, blk_off, rec_idx}, record order
+    const int4 *gap_runs;           // their first two aligned runs {start0, len0, start1, len1} (no dependent load)
+    const int4 *long_runs;          // same for the long-span list
     const int64_t *gap_tid_bounds;  // ntid+1
     // linear index (cf. the BAI linear index): first record at or after every kLinShift-bit
     // genome bucket, per contig; lin_off[t] = start of contig t's buckets (nb_t + 1 entries)
@@ -100,6 +102,7 @@ struct FileView {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct GFile {
     const u32x2 PC_GLOBAL *rec;
@@ -113,6 +116,8 @@ struct GFile {
     const int64_t PC_GLOBAL *long_tid_bounds;
     const u32x4 PC_GLOBAL *long_rec;
     const u32x4 PC_GLOBAL *gap_rec;
+    const i32x4 PC_GLOBAL *gap_runs;
+    const i32x4 PC_GLOBAL *long_runs;
     const int64_t PC_GLOBAL *gap_tid_bounds;
     const uint32_t PC_GLOBAL *lin_tab;
     const uint32_t PC_GLOBAL *glin_tab;
@@ -137,6 +142,8 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.long_tid_bounds = (const int64_t PC_GLOBAL *)v.long_tid_bounds;
     g.long_rec = (const u32x4 PC_GLOBAL *)v.long_rec;
     g.gap_rec = (const u32x4 PC_GLOBAL *)v.gap_rec;
+    g.gap_runs = (const i32x4 PC_GLOBAL *)v.gap_runs;
+    g.long_runs = (const i32x4 PC_GLOBAL *)v.long_runs;
     g.gap_tid_bounds = (const int64_t PC_GLOBAL *)v.gap_tid_bounds;
     g.lin_tab = (const uint32_t PC_GLOBAL *)v.lin_tab;
     g.glin_tab = (const uint32_t PC_GLOBAL *)v.glin_tab;
@@ -849,6 +856,7 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     const int64_t gj0 = w.glo + threadIdx.x;
     const u32x4 gnone = {0u, kFlagExcluded << 16, 0u, 0u};
     const u32x4 gfirst = (gj0 < w.ghi) ? fv.gap_rec[gj0] : gnone;
+    const i32x4 gfirst_runs = (gj0 < w.ghi) ? fv.gap_runs[gj0] : i32x4{0, 1, 0, 0};
 
     HistCfg c;
     c.win_start = w.win_start;
@@ -915,11 +923,11 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.ghi;
         const u32x4 g = base == w.glo ? gfirst : (in ? fv.gap_rec[j] : gnone);
+        const i32x4 gr = base == w.glo ? gfirst_runs : (in ? fv.gap_runs[j] : i32x4{0, 1, 0, 0});
         const uint32_t meta = g.y, hi = meta >> 16;
         const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
         const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-        i32x2 b0 = {(int32_t)g.x, L}, b1 = {0, 0}; // one run: an ungapped read too long for the stream
-        if (in && nb >= 2) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
+        const i32x2 b0 = {gr.x, gr.y}, b1 = {gr.z, gr.w}; // first two runs travel with the list entry
         int kf, kr;
         uint32_t rowoff;
         map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
@@ -933,11 +941,11 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.lhi;
         const u32x4 g = in ? fv.long_rec[j] : gnone;
+        const i32x4 gr = in ? fv.long_runs[j] : i32x4{0, 1, 0, 0};
         const uint32_t meta = g.y, hi = meta >> 16;
         const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
         const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-        i32x2 b0 = {(int32_t)g.x, L}, b1 = {0, 0}; // an ungapped read longer than the halo has no stored runs
-        if (in && nb >= 2) { b0 = fv.blk[g.z]; b1 = fv.blk[g.z + 1]; }
+        const i32x2 b0 = {gr.x, gr.y}, b1 = {gr.z, gr.w};
         int kf, kr;
         uint32_t rowoff;
         map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);

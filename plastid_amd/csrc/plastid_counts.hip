@@ -115,6 +115,7 @@ struct StagedFile {
     DevBuf<uint4> long_rec;
     int64_t ngap = 0;
     DevBuf<uint4> gap_rec;
+    DevBuf<int4> gap_runs, long_runs; // first two aligned runs of every side-list record
     DevBuf<int64_t> gap_tid_bounds;
     DevBuf<uint32_t> lin_tab, glin_tab, llin_tab, plin_tab;
     DevBuf<int64_t> lin_off;
@@ -129,6 +130,7 @@ struct StagedFile {
         v.long_idx = long_idx.p; v.long_tid = long_tid.p; v.long_pmax = long_pmax.p;
         v.long_tid_bounds = long_tid_bounds.p; v.long_rec = long_rec.p; v.n = n; v.nlong = nlong;
         v.gap_rec = gap_rec.p; v.gap_tid_bounds = gap_tid_bounds.p; v.ngap = ngap;
+        v.gap_runs = gap_runs.p; v.long_runs = long_runs.p;
         v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.llin_tab = llin_tab.p; v.plin_tab = plin_tab.p; v.lin_off = lin_off.p;
         return v;
     }
@@ -545,6 +547,19 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     clk.lap("side lists + record stream");
     sf->nlong = (int64_t)long_idx.size();
     sf->ngap = (int64_t)gap_rec.size();
+    // the first two aligned runs of every side-list record, next to its header: the kernels then
+    // need the run array only for reads with three or more runs
+    auto first_runs = [&](const std::vector<uint4> &list) {
+        std::vector<int4> out(list.size());
+        for (size_t k = 0; k < list.size(); ++k) {
+            const uint4 &g = list[k];
+            const uint32_t i = g.w;
+            if (nblk[i] >= 2) out[k] = make_int4(blk_start[g.z], blk_len[g.z], blk_start[g.z + 1], blk_len[g.z + 1]);
+            else out[k] = make_int4(pos[i], (int)alen[i], 0, 0);
+        }
+        return out;
+    };
+    const std::vector<int4> gap_runs = first_runs(gap_rec), long_runs = first_runs(long_rec);
 
     // ---- linear index: first record at/after every 2^kLinShift-position bucket of each contig
     std::vector<int64_t> lin_off((size_t)ntid + 1, 0);
@@ -611,6 +626,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc == PC_OK) rc = sf->long_tid_bounds.upload(long_bounds, e->stream);
     if (rc == PC_OK) rc = sf->long_rec.upload(long_rec, e->stream);
     if (rc == PC_OK) rc = sf->gap_rec.upload(gap_rec, e->stream);
+    if (rc == PC_OK) rc = sf->gap_runs.upload(gap_runs, e->stream);
+    if (rc == PC_OK) rc = sf->long_runs.upload(long_runs, e->stream);
     if (rc == PC_OK) rc = sf->gap_tid_bounds.upload(gap_bounds, e->stream);
     if (rc == PC_OK) rc = sf->lin_tab.upload(lin_tab, e->stream);
     if (rc == PC_OK) rc = sf->glin_tab.upload(glin_tab, e->stream);
