@@ -152,13 +152,21 @@ def run_case(pa, oracle, case, spec_for, engine_for):
     os.environ.update(case["knobs"])
     try:
         mapping, sf = case["mapping"], case["size_filter"]
+        rng = np.random.default_rng(case["step_seed"])
+        late_flags = bool(rng.random() < 0.4)     # exclusion bits arrive after staging (pc_update_flags)
+        files = case["files"]
+        if late_flags:
+            files = [pa.PackedAlignments(f.tid, f.pos, f.alen, f.flags & 0x7f, f.nblk, f.blk_start, f.blk_len,
+                                         references=f.references, lengths=f.lengths, validate=False) for f in files]
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")  # offset-dictionary DataWarnings of the factory constructors
-            eng = engine_for(pa, case["files"], mapping, sf)
+            eng = engine_for(pa, files, mapping, sf)
+        if late_flags:
+            for fi, f in enumerate(case["files"]):
+                eng.update_flags(fi, f.flags)
         rows = eng.rows
         lens_ = case["seg_end"] - case["seg_start"]
         nseg = len(lens_)
-        rng = np.random.default_rng(case["step_seed"])
         layout = case["layout"]
         if layout == "sums":
             step = np.zeros(nseg, np.int8)
@@ -196,6 +204,10 @@ def run_case(pa, oracle, case, spec_for, engine_for):
             got = plan.count(np.float64)
             assert np.array_equal(got, exp.astype(np.float64)), tag
         assert np.array_equal(plan.warn_flags(), warn), tag
+        if layout != "sums" and rng.random() < 0.5:   # count / float(sum) * 1e6, genome_array.py:826-827
+            total = float(rng.integers(1, 10 ** 9))
+            eng.set_normalize(True, total)
+            assert np.array_equal(plan.count(np.float64), exp.astype(np.float64) / total * 1e6), tag
         plan.close()
         eng.close()
     finally:
