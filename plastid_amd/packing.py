@@ -300,8 +300,9 @@ class PackedAlignments(object):
     # ------------------------------------------------------------ constructors
     @classmethod
     def from_runs(cls, tids, is_reverse, runs_per_read, references=None, lengths=None,
-                  mapped=None, read_objects=None, sort=False):
-        """Build from per-read lists of aligned runs ``[(start, len), ...]``."""
+                  mapped=None, read_objects=None, sort=False, positions=None):
+        """Build from per-read lists of aligned runs ``[(start, len), ...]``.  `positions`
+        (optional) places the records that have no aligned base at all."""
         n = len(runs_per_read)
         tid = np.asarray(tids, dtype=np.int32) if np.ndim(tids) else np.full(n, tids, np.int32)
         pos = np.zeros(n, np.int32)
@@ -315,6 +316,8 @@ class PackedAlignments(object):
             if runs:
                 pos[i] = runs[0][0]
                 alen[i] = sum(r[1] for r in runs)
+            elif positions is not None:
+                pos[i] = positions[i]
         if alen.max(initial=0) > MAX_ALIGNED_LEN:
             raise ValueError("alignments with more than %d aligned positions are not supported"
                              % MAX_ALIGNED_LEN)
@@ -364,17 +367,8 @@ class PackedAlignments(object):
                 runs.append([])
             else:
                 runs.append(r)
-        out = cls.from_runs(tids, is_reverse, runs, **kwargs)
         # records without aligned bases keep their stated position
-        if any(len(r) == 0 for r in runs):
-            order = getattr(out, "sort_order", None)
-            p_arr = np.asarray(pos, dtype=np.int32)
-            if order is not None:
-                p_arr = p_arr[order]
-            empty = out.nblk == 0
-            out.pos[empty] = p_arr[empty]
-            out.validate()
-        return out
+        return cls.from_runs(tids, is_reverse, runs, positions=pos, **kwargs)
 
     @classmethod
     def from_ungapped(cls, tid, pos, alen, is_reverse, **kwargs):
