@@ -11,6 +11,6 @@ from .roitools import GenomicSegment, SegmentChain  # noqa: F401
 from .map_factories import (CenterMapFactory, FivePrimeMapFactory, SizeFilterFactory,  # noqa: F401
                             StratifiedVariableFivePrimeMapFactory, ThreePrimeMapFactory,
                             VariableFivePrimeMapFactory)
-from .genome_array import BAMGenomeArray  # noqa: F401
+from .genome_array import BAMGenomeArray, DenseGenomeArray  # noqa: F401
 
 __version__ = "0.1.0"

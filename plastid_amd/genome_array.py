@@ -441,6 +441,19 @@ class BAMGenomeArray(object):
             counts, rpnt, rpkm = counts[:, 0], rpnt[:, 0], rpkm[:, 0]
         return {"counts": counts, "length": length, "counts_per_nucleotide": rpnt, "rpkm": rpkm}
 
+    def to_genome_array(self, array_type=None):
+        """Dense per-chromosome arrays under the current mapping rule (genome_array.py:965-988): one
+        whole-contig launch per chromosome and strand.  As in the reference the query stops one
+        position short of the contig end (``lengths()[chrom] - 1`` as the half-open end)."""
+        if array_type is None:
+            array_type = DenseGenomeArray
+        ga = array_type(chr_lengths=self.lengths(), strands=self.strands())
+        for chrom in self.chroms():
+            for strand in self.strands():
+                seg = GenomicSegment(chrom, 0, self.lengths()[chrom] - 1, strand)
+                ga[seg] = self[seg]
+        return ga
+
     # ---------------------------------------------------------------- export
     def to_bedgraph(self, fh, trackname, strand, window_size=100000, printer=None, **kwargs):
         """Write a bedGraph under the current mapping rule (:1041-1111)."""
@@ -488,6 +501,63 @@ class BAMGenomeArray(object):
                 if my_counts.sum() > 0:
                     for idx in my_counts.nonzero()[0]:
                         fh.write("%s\t%s\n" % (my_start + idx + 1, my_counts[idx]))
+
+
+class DenseGenomeArray(object):
+    """Read-mostly dense array, the part of the reference's |GenomeArray| that
+    ``BAMGenomeArray.to_genome_array`` produces and ``SegmentChain.get_counts`` consumes
+    (genome_array.py:1323-1800, hot subset): one float vector per chromosome and strand."""
+
+    def __init__(self, chr_lengths=None, strands=("+", "-")):
+        self._chr_lengths = OrderedDict(chr_lengths or {})
+        self._strands = tuple(strands)
+        self._chroms = {c: {st: np.zeros(int(n)) for st in self._strands} for c, n in self._chr_lengths.items()}
+        self._normalize = False
+        self._sum = None
+
+    def chroms(self):
+        return list(self._chr_lengths.keys())
+
+    def strands(self):
+        return self._strands
+
+    def lengths(self):
+        return self._chr_lengths
+
+    def sum(self):
+        if self._sum is None:
+            self._sum = float(sum(v.sum() for d in self._chroms.values() for v in d.values()))
+        return self._sum
+
+    def set_normalize(self, value=True):
+        assert value in (True, False)
+        self._normalize = value
+
+    def __setitem__(self, seg, val):
+        """``ga[seg] = val`` with `val` 5'->3' relative to `seg` (genome_array.py:1655-1700)."""
+        val = np.asarray(val, float)
+        if seg.strand == "-":
+            val = val[::-1]
+        self._chroms[seg.chrom][seg.strand][seg.start:seg.end] = val
+        self._sum = None
+
+    def get(self, roi, roi_order=True):
+        if isinstance(roi, SegmentChain):
+            return roi.get_counts(self)
+        out = np.zeros(len(roi))
+        vec = self._chroms.get(roi.chrom, {}).get(roi.strand)
+        if vec is not None:
+            a, b = max(roi.start, 0), min(roi.end, len(vec))
+            if b > a:
+                out[a - roi.start:b - roi.start] = vec[a:b]
+        if self._normalize is True:
+            out = out / float(self.sum()) * 1e6
+        if roi_order is True and roi.strand == "-":
+            out = out[::-1]
+        return out
+
+    def __getitem__(self, roi):
+        return self.get(roi, roi_order=True)
 
 
 def _generic_chain_counts(ga, chain, stranded):

@@ -413,6 +413,31 @@ def test_stratified_with_many_rows(pa, oracle):
     eng.close()
 
 
+def test_to_genome_array(pa):
+    """BAMGenomeArray.to_genome_array (genome_array.py:965-988): the dense copy answers segment and
+    chain queries like the BAM-backed array (last nucleotide of every contig excepted, as in the
+    reference)."""
+    from plastid_amd import synth
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.001, tx_scale=0.002)
+    small = reads.subset(np.nonzero(reads.tid < 2)[0])          # two contigs are enough
+    ga = pa.BAMGenomeArray(small, mapping=pa.FivePrimeMapFactory(offset=12))
+    dense = ga.to_genome_array()
+    assert sorted(dense.chroms()) == sorted(ga.chroms()) and tuple(dense.strands()) == tuple(ga.strands())
+    rng = np.random.default_rng(3)
+    names = list(ga.chroms())[:2]
+    for _ in range(20):
+        chrom = names[int(rng.integers(0, 2))]
+        a = int(rng.integers(0, ga.lengths()[chrom] - 2000))
+        seg = pa.GenomicSegment(chrom, a, a + int(rng.integers(1, 1500)), "+-."[int(rng.integers(0, 3))])
+        assert np.array_equal(dense[seg], ga[seg].astype(float))
+        assert np.array_equal(dense.get(seg, roi_order=False), ga.get(seg, roi_order=False).astype(float))
+    chains = [c for c in tx.chains() if c.chrom in names][:10]
+    for c in chains:
+        assert np.array_equal(c.get_counts(dense), c.get_counts(ga))
+    total = sum(float(ga[pa.GenomicSegment(ch, 0, ga.lengths()[ch] - 1, st)].sum()) for ch in ga.chroms() for st in ga.strands())
+    assert dense.sum() == total
+
+
 def test_inverse_table_is_ieee(pa):
     """1.0/m used by the center kernel is the host's correctly rounded quotient;
     a lone read of aligned length m contributes exactly 1.0/m at each position."""
