@@ -149,6 +149,15 @@ int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems);
 void *pc_counts_device_ptr(pc_plan *p);
 void *pc_stream(pc_engine *e);
 
+/* ---- export: run-length encoding of the last pc_count output on the GPU, so that only the runs
+ * cross PCIe (BAMGenomeArray.to_bedgraph / to_variable_step, genome_array.py:990-1111).  A run
+ * starts at element 0, wherever the 8-byte value differs from its predecessor, and at every multiple
+ * of `period` elements (0: no such cut; the reference cuts its runs at window borders; 1 lists
+ * every element).  pc_read_rle returns, for run k, its first element and its value (int64 or
+ * float64 as counted); run k ends where run k+1 starts, the last one at out_elems. */
+int pc_rle(pc_engine *e, pc_plan *p, int64_t period, int64_t *n_runs);
+int pc_read_rle(pc_engine *e, pc_plan *p, int64_t *starts, void *values, int64_t n_runs);
+
 /* per-segment "the reference would emit its DataWarning" flags
  * (map_factories.pyx:258-263, 360-365, 459-464, 643-648) for the last pc_count */
 int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags);

@@ -51,6 +51,8 @@ SIGNATURES = {
     "pc_read_counts": (_int, [_vp, _vp, _vp, _i64]),
     "pc_counts_device_ptr": (_vp, [_vp]),
     "pc_stream": (_vp, [_vp]),
+    "pc_rle": (_int, [_vp, _vp, _i64, ctypes.POINTER(_i64)]),
+    "pc_read_rle": (_int, [_vp, _vp, _vp, _vp, _i64]),
     "pc_warn_flags": (_int, [_vp, _vp, _vp]),
     "pc_total": (_int, [_vp, _vp, _vp]),
     "pc_total_device_ptr": (_vp, [_vp]),

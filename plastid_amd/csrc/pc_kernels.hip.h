@@ -1427,6 +1427,84 @@ __global__ void k_total_f64_final(const double *__restrict__ partial, int nb, do
     }
 }
 
+// ---------------------------------------------------------------- run-length encoding
+// Export side (genome_array.py:1041-1111, to_bedgraph / to_variable_step): the per-position
+// vector of a whole chromosome is reduced on the GPU to its runs -- a run starts at element 0,
+// where the value changes, and at every multiple of `period` (the scripts cut their runs at
+// window borders; period 1 lists every element) -- so that only the runs cross PCIe.
+// 64-bit patterns are compared (int64 counts or float64 values).  Two passes over `kRleChunk`
+// elements per workgroup: count the heads, scan the counts, write {start, value}.
+constexpr int kRleChunk = 2048;
+__device__ __forceinline__ bool rle_head(const unsigned long long PC_GLOBAL *v, int64_t i, int64_t period) {
+    return i == 0 || v[i] != v[i - 1] || (period > 0 && i % period == 0);
+}
+
+__global__ __launch_bounds__(kWG) void k_rle_count(const unsigned long long *__restrict__ v_, int64_t n, int64_t period,
+                                                   uint32_t *wg_count) {
+    const unsigned long long PC_GLOBAL *v = (const unsigned long long PC_GLOBAL *)v_;
+    __shared__ uint32_t s_wave[kWG / 64];
+    const int64_t base = (int64_t)blockIdx.x * kRleChunk;
+    uint32_t c = 0;
+    for (int k = 0; k < kRleChunk / kWG; ++k) {
+        const int64_t i = base + k * kWG + threadIdx.x;
+        if (i < n && rle_head(v, i, period)) ++c;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kWG / 64; ++w) t += s_wave[w];
+        wg_count[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of the per-workgroup counts by ONE workgroup (a few thousand entries per Mb)
+__global__ __launch_bounds__(kWG) void k_rle_scan(const uint32_t *__restrict__ wg_count, int64_t nwg, int64_t *wg_base,
+                                                  int64_t *total) {
+    __shared__ int64_t s_part[kWG];
+    const int64_t per = (nwg + kWG - 1) / kWG;
+    const int64_t b = (int64_t)threadIdx.x * per, e = b + per < nwg ? b + per : nwg;
+    int64_t sum = 0;
+    for (int64_t i = b; i < e; ++i) sum += wg_count[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int t = 0; t < kWG; ++t) { const int64_t x = s_part[t]; s_part[t] = run; run += x; }
+        *total = run;
+    }
+    __syncthreads();
+    int64_t run = s_part[threadIdx.x];
+    for (int64_t i = b; i < e; ++i) { wg_base[i] = run; run += wg_count[i]; }
+}
+
+__global__ __launch_bounds__(kWG) void k_rle_write(const unsigned long long *__restrict__ v_, int64_t n, int64_t period,
+                                                   const int64_t *__restrict__ wg_base, int64_t *starts,
+                                                   unsigned long long *values) {
+    const unsigned long long PC_GLOBAL *v = (const unsigned long long PC_GLOBAL *)v_;
+    __shared__ uint32_t s_wave[kWG / 64];
+    const int64_t base = (int64_t)blockIdx.x * kRleChunk;
+    int64_t out = wg_base[blockIdx.x];
+    for (int k = 0; k < kRleChunk / kWG; ++k) { // element order == run order
+        const int64_t i = base + k * kWG + threadIdx.x;
+        const bool head = i < n && rle_head(v, i, period);
+        const unsigned long long m = __ballot(head);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, tot = 0;
+        for (int w = 0; w < kWG / 64; ++w) { const uint32_t t = s_wave[w]; if (w < wv) before += t; tot += t; }
+        if (head) {
+            const int64_t slot = out + before + __popcll(m & ((1ull << lane) - 1ull));
+            starts[slot] = i;
+            values[slot] = v[i];
+        }
+        out += tot;
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- k_mapped_reads
 // reads_out of the map functions for ONE segment (genome_array.py:800-823).
 __global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fview, MapParams mp, int64_t rec_lo, int64_t rec_hi,

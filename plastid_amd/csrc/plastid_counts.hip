@@ -209,6 +209,11 @@ struct pc_plan {
     DevBuf<CenterChunk> d_cchunks;
     DevBuf<uint32_t> d_corder;
     DevBuf<uint32_t> d_ccand;   // candidate records per center chunk
+    DevBuf<uint32_t> d_rle_cnt; // run-length encoding of the output: heads per workgroup, their scan,
+    DevBuf<int64_t> d_rle_base; // [nwg] bases + [1] total
+    DevBuf<int64_t> d_rle_starts;
+    DevBuf<unsigned long long> d_rle_values;
+    int64_t rle_runs = -1;
     DevBuf<u32x4> d_cranges;    // per (chunk, file): record range and long-span candidate range
     DevBuf<GatherSeg> d_gsegs;
     DevBuf<GatherChunk> d_gchunks;
@@ -1157,6 +1162,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     HIP_TRY(hipGetLastError());
     p->last_dtype = out_dtype;
     p->counted = true;
+    p->rle_runs = -1;
     e->timing_valid = e->prof_level > 0;
     e->timed_level = e->prof_level;
     // records once (8 B) + extra runs (8 B) + segments (24 B) + outputs once (8 B)
@@ -1202,6 +1208,51 @@ int pc_total(pc_engine *e, pc_plan *p, void *host_out8) {
     }
     if (host_out8) HIP_TRY(hipMemcpyAsync(host_out8, p->d_total.p, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return PC_OK;
+}
+
+// ------------------------------------------------------------------ export: run-length encoding
+int pc_rle(pc_engine *e, pc_plan *p, int64_t period, int64_t *n_runs) {
+    if (!e || !p || p->e != e || !n_runs) return fail(PC_ERR_ARG, "pc_rle: bad arguments");
+    if (!p->counted) return fail(PC_ERR_STATE, "pc_rle: nothing counted yet");
+    if (period < 0) return fail(PC_ERR_ARG, "pc_rle: period must be >= 0");
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    const int64_t n = p->out_elems;
+    p->rle_runs = 0;
+    *n_runs = 0;
+    if (n == 0) return PC_OK;
+    const int64_t nwg = (n + kRleChunk - 1) / kRleChunk;
+    int rc = p->d_rle_cnt.reserve((size_t)nwg);
+    if (rc == PC_OK) rc = p->d_rle_base.reserve((size_t)nwg + 1);
+    if (rc != PC_OK) return rc;
+    const unsigned long long *v = (const unsigned long long *)p->d_out.p;
+    hipLaunchKernelGGL(k_rle_count, dim3((unsigned)nwg), dim3(kWG), 0, st, v, n, period, p->d_rle_cnt.p);
+    hipLaunchKernelGGL(k_rle_scan, dim3(1), dim3(kWG), 0, st, p->d_rle_cnt.p, nwg, p->d_rle_base.p, p->d_rle_base.p + nwg);
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, p->d_rle_base.p + nwg, sizeof(total), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    rc = p->d_rle_starts.reserve((size_t)std::max<int64_t>(total, 1));
+    if (rc == PC_OK) rc = p->d_rle_values.reserve((size_t)std::max<int64_t>(total, 1));
+    if (rc != PC_OK) return rc;
+    hipLaunchKernelGGL(k_rle_write, dim3((unsigned)nwg), dim3(kWG), 0, st, v, n, period, p->d_rle_base.p, p->d_rle_starts.p,
+                       p->d_rle_values.p);
+    HIP_TRY(hipGetLastError());
+    p->rle_runs = total;
+    *n_runs = total;
+    return PC_OK;
+}
+
+int pc_read_rle(pc_engine *e, pc_plan *p, int64_t *starts, void *values, int64_t n_runs) {
+    if (!e || !p || p->e != e) return fail(PC_ERR_ARG, "pc_read_rle: bad arguments");
+    if (p->rle_runs < 0) return fail(PC_ERR_STATE, "pc_read_rle: pc_rle has not run");
+    if (n_runs != p->rle_runs || (n_runs > 0 && (!starts || !values))) return fail(PC_ERR_ARG, "pc_read_rle: expected %lld runs", (long long)p->rle_runs);
+    HIP_TRY(hipSetDevice(e->device));
+    if (n_runs > 0) {
+        HIP_TRY(hipMemcpyAsync(starts, p->d_rle_starts.p, (size_t)n_runs * 8, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(values, p->d_rle_values.p, (size_t)n_runs * 8, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return PC_OK;
 }
 

@@ -191,6 +191,18 @@ class Plan(object):
         check(self._lib.pc_warn_flags(self.engine._h, self._h, _ptr(flags)))
         return flags
 
+    def rle(self, period=0):
+        """Run-length encode the last count on the GPU: ``(starts, values)``; run k covers
+        ``[starts[k], starts[k+1])`` (the last one ends at ``out_elems``).  Runs are also cut at
+        every multiple of `period` (0: never)."""
+        import ctypes
+        n = ctypes.c_int64(0)
+        check(self._lib.pc_rle(self.engine._h, self._h, int(period), ctypes.byref(n)))
+        starts = np.zeros(n.value, np.int64)
+        values = np.zeros(n.value, self._dtype)
+        check(self._lib.pc_read_rle(self.engine._h, self._h, _ptr(starts), _ptr(values), n.value))
+        return starts, values
+
     def total(self):
         buf = np.zeros(1, self._dtype)
         check(self._lib.pc_total(self.engine._h, self._h, _ptr(buf)))

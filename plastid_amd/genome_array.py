@@ -455,8 +455,28 @@ class BAMGenomeArray(object):
         return ga
 
     # ---------------------------------------------------------------- export
+    def _chromosome_runs(self, chrom, strand, period):
+        """Runs of the whole-chromosome vector (genome order) under the current mapping rule: one
+        count launch + the GPU run-length encoder; only the runs come back.  Returns
+        ``(starts, ends, values)``; runs are also cut at every multiple of `period`."""
+        size = self.lengths()[chrom]
+        self._sync_engine()
+        rows = self._engine.rows
+        if rows != 1:
+            raise TypeError("export needs a mapping rule that returns one row per position")
+        plan = self._engine.plan([self._chrom_index[chrom]], [0], [size], [STRAND_CODE[strand]], [0], np.ones(1, np.int8),
+                                 [size], size, 1)
+        plan.launch(self._out_dtype())
+        starts, values = plan.rle(period)
+        self._warn_if_unmappable(plan)
+        plan.close()
+        ends = np.append(starts[1:], size)
+        return starts, ends, values
+
     def to_bedgraph(self, fh, trackname, strand, window_size=100000, printer=None, **kwargs):
-        """Write a bedGraph under the current mapping rule (:1041-1111)."""
+        """Write a bedGraph under the current mapping rule (:1041-1111).  Same lines as the
+        reference's window loop writes (its runs restart at every window border, windows and runs
+        without counts are skipped), from one launch per chromosome."""
         assert strand in self.strands()
         assert window_size > 0
         fh.write("track type=bedGraph name=%s" % trackname)
@@ -466,41 +486,31 @@ class BAMGenomeArray(object):
         for chrom in sorted(self.chroms()):
             if printer is not None:
                 printer.write("Writing chromosome %s..." % chrom)
-            my_size = self.lengths()[chrom]
-            for my_start in range(0, my_size, window_size):
-                my_end = min(my_start + window_size, my_size)
-                my_counts = self.get(GenomicSegment(chrom, my_start, my_end, strand), roi_order=False)
-                if my_counts.sum() > 0:
-                    genomic_start_x = my_start
-                    last_val = my_counts[0]
-                    change = np.nonzero(my_counts[1:] != my_counts[:-1])[0]
-                    for x in change:
-                        genomic_end_x = 1 + int(x) + my_start
-                        if last_val > 0:
-                            fh.write("%s\t%s\t%s\t%s\n" % (chrom, genomic_start_x, genomic_end_x, last_val))
-                        last_val = my_counts[x + 1]
-                        genomic_start_x = genomic_end_x
-                    if last_val > 0:
-                        fh.write("%s\t%s\t%s\t%s\n" % (chrom, genomic_start_x, my_end, last_val))
+            if self.lengths()[chrom] <= 0:
+                continue
+            starts, ends, values = self._chromosome_runs(chrom, strand, window_size)
+            keep = values > 0
+            for a, b, v in zip(starts[keep], ends[keep], values[keep]):
+                fh.write("%s\t%s\t%s\t%s\n" % (chrom, a, b, v))
 
     def to_variable_step(self, fh, trackname, strand, window_size=100000, printer=None, **kwargs):
-        """Write a variableStep wiggle under the current mapping rule (:990-1039)."""
+        """Write a variableStep wiggle under the current mapping rule (:990-1039): every position
+        with a non-zero count, 1-based."""
         assert strand in self.strands()
         fh.write("track type=wiggle_0 name=%s" % trackname)
         for k, v in sorted(kwargs.items(), key=lambda x: x[0]):
             fh.write(" %s=%s" % (k, v))
         fh.write("\n")
         for chrom in sorted(self.chroms()):
-            my_size = self.lengths()[chrom]
             if printer is not None:
                 printer.write("Writing chromosome %s..." % chrom)
             fh.write("variableStep chrom=%s span=1\n" % chrom)
-            for my_start in range(0, my_size, window_size):
-                my_end = min(my_start + window_size, my_size)
-                my_counts = self.get(GenomicSegment(chrom, my_start, my_end, strand), roi_order=False)
-                if my_counts.sum() > 0:
-                    for idx in my_counts.nonzero()[0]:
-                        fh.write("%s\t%s\n" % (my_start + idx + 1, my_counts[idx]))
+            if self.lengths()[chrom] <= 0:
+                continue
+            starts, ends, values = self._chromosome_runs(chrom, strand, 1)
+            keep = values != 0
+            for a, v in zip(starts[keep], values[keep]):
+                fh.write("%s\t%s\n" % (a + 1, v))
 
 
 class DenseGenomeArray(object):

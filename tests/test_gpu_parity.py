@@ -521,6 +521,88 @@ def test_bam_file_end_to_end(pa, oracle, tmp_path):
     assert total == int(((reads.flags & 1) == 0).sum())
 
 
+def _window_loop_bedgraph(ga, pa, fh, trackname, strand, window_size):
+    """The reference's own export loop (genome_array.py:1041-1111), over ``ga.get``."""
+    fh.write("track type=bedGraph name=%s\n" % trackname)
+    for chrom in sorted(ga.chroms()):
+        my_size = ga.lengths()[chrom]
+        for my_start in range(0, my_size, window_size):
+            my_end = min(my_start + window_size, my_size)
+            my_counts = ga.get(pa.GenomicSegment(chrom, my_start, my_end, strand), roi_order=False)
+            if my_counts.sum() > 0:
+                genomic_start_x = my_start
+                last_val = my_counts[0]
+                for x in np.nonzero(my_counts[1:] != my_counts[:-1])[0]:
+                    genomic_end_x = 1 + int(x) + my_start
+                    if last_val > 0:
+                        fh.write("%s\t%s\t%s\t%s\n" % (chrom, genomic_start_x, genomic_end_x, last_val))
+                    last_val = my_counts[x + 1]
+                    genomic_start_x = genomic_end_x
+                if last_val > 0:
+                    fh.write("%s\t%s\t%s\t%s\n" % (chrom, genomic_start_x, my_end, last_val))
+
+
+def _window_loop_variable_step(ga, pa, fh, trackname, strand, window_size):
+    """genome_array.py:990-1039"""
+    fh.write("track type=wiggle_0 name=%s\n" % trackname)
+    for chrom in sorted(ga.chroms()):
+        my_size = ga.lengths()[chrom]
+        fh.write("variableStep chrom=%s span=1\n" % chrom)
+        for my_start in range(0, my_size, window_size):
+            my_end = min(my_start + window_size, my_size)
+            my_counts = ga.get(pa.GenomicSegment(chrom, my_start, my_end, strand), roi_order=False)
+            if my_counts.sum() > 0:
+                for idx in my_counts.nonzero()[0]:
+                    fh.write("%s\t%s\n" % (my_start + idx + 1, my_counts[idx]))
+
+
+def test_export_is_the_reference_window_loop(pa):
+    """to_bedgraph / to_variable_step (one launch + GPU run-length encoding per chromosome) write,
+    byte for byte, what the reference's window loop writes -- runs cut at window borders, int and
+    float formatting -- for integer, normalised and center mappings and every strand."""
+    import io
+    from plastid_amd import synth
+    from plastid_amd.engine import Engine
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.002, tx_scale=0.002)
+    small = reads.subset(np.nonzero(reads.tid < 3)[0])
+    names = list(small.references)
+    lens = list(small.lengths)
+    # shrink the unused contigs so the reference-style loop stays quick
+    for t in range(3, len(lens)):
+        lens[t] = 1000
+    small = pa.PackedAlignments(small.tid, small.pos, small.alen, small.flags, small.nblk, small.blk_start, small.blk_len,
+                                references=names, lengths=lens)
+    for mapping, norm in ((pa.FivePrimeMapFactory(12), False), (pa.ThreePrimeMapFactory(0), True), (pa.CenterMapFactory(3), False)):
+        ga = pa.BAMGenomeArray(small, mapping=mapping)
+        ga.set_normalize(norm)
+        for strand in ("+", "-", "."):
+            for window in (100000, 7777):
+                got, want = io.StringIO(), io.StringIO()
+                ga.to_bedgraph(got, "t", strand, window_size=window)
+                _window_loop_bedgraph(ga, pa, want, "t", strand, window)
+                assert got.getvalue() == want.getvalue(), (mapping, norm, strand, window)
+            got, want = io.StringIO(), io.StringIO()
+            ga.to_variable_step(got, "t", strand)
+            _window_loop_variable_step(ga, pa, want, "t", strand, 100000)
+            assert got.getvalue() == want.getvalue(), (mapping, norm, strand)
+    # the encoder itself against numpy, with and without a period
+    eng = Engine(0)
+    eng.set_alignments([small])
+    pa.FivePrimeMapFactory(0)._configure(eng)
+    size = lens[0]
+    plan = eng.plan([0], [0], [size], [3], [0], np.ones(1, np.int8), [size], size, 1)
+    vec = plan.count(np.int64)
+    for period in (0, 1, 4096, 1000):
+        starts, values = plan.rle(period)
+        head = np.ones(size, bool)
+        head[1:] = vec[1:] != vec[:-1]
+        if period:
+            head[::period] = True
+        assert np.array_equal(starts, np.nonzero(head)[0]) and np.array_equal(values, vec[head]), period
+    plan.close()
+    eng.close()
+
+
 def test_fused_region_statistics(pa, oracle):
     """count_in_regions == numpy.nansum(chain.get_masked_counts(ga)) per chain (counts_in_region.py:113-124)."""
     from plastid_amd import synth
