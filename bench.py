@@ -203,7 +203,9 @@ def main():
     eng.sync()
 
     # parity gate: bit-exact vs the oracle on the sampled chains
+    t0 = time.perf_counter()
     got = plan.read()
+    read_s = time.perf_counter() - t0   # D2H of every output position (t_staged of SURVEY 8d = stage + step + this)
     exp = scatter_expected(check_arrays, p, check_sel, rows, out_dtype, p["out_elems"])
     touched = np.zeros(p["out_elems"], bool)
     for s in check_sel:
@@ -294,7 +296,7 @@ def main():
                 "positions_per_sec": positions_all * args.steps / elapsed,
                 "parity": "bit-exact vs oracle on %d output positions (seeded sample of chains)" % n_checked,
                 "sum_of_counts_all_ranks": counts_all,
-                "host_generate_s": round(gen_s, 2), "host_stage_s": round(stage_s, 2),
+                "host_generate_s": round(gen_s, 2), "host_stage_s": round(stage_s, 2), "host_read_outputs_s": round(read_s, 3),
                 "plan_build_ms_once_per_annotation": round(plan_s * 1e3, 2),
                 "algorithmic_bytes_per_step": int(alg_bytes_step),
                 "staged_stream_bytes_per_record": 4,  # what the tile kernel reads; the algorithmic record is 8 B
