@@ -3,23 +3,27 @@
 // gfx950 only (wave64, 256 CUs in 8 XCDs, 160 KiB LDS/CU, HBM3E).  This path is
 // integer/byte scatter-reduce work bound by HBM bandwidth: no MFMA anywhere.
 //
-// Data layout in HBM
-//   rec[i]      uint2 {pos:int32, meta:uint32}, meta = L | flags<<16 | nblk<<24   (8 B / record,
-//               BAM order; the only array the histogram kernel streams)
-//   blk_off[i]  uint32, first run of record i (read only for the rare nblk>=2 records)
-//   blk[j]      int2 {start,len}  aligned runs of the nblk>=2 records
-//   hist        compact coverage over the *union* of queried intervals per strand
-//               mode ("islands"): uint32 (point maps) or float64 (center);
-//               rows x npos, row-major
+// Data layout in HBM (per staged file, BAM order; DESIGN.md section 3 has the full table)
+//   stream[i]   uint32 4-byte record the tile kernel streams: low half of pos | L | strand | skip
+//   rec[i]      uint2 {pos:int32, meta:uint32}, meta = L | flags<<16 | nblk<<24   (center /
+//               reads_out / warning kernels)
+//   gap_rec, long_rec (+ *_runs)   side lists: gapped / over-long and long-span records with their
+//               first two aligned runs; blk_off[i], blk[j] int2 {start,len}: all runs of nblk>=2 records
+//   lin_tab, glin_tab, llin_tab, plin_tab   linear index (first record at/after every 128-nt bucket)
+//   hist        compact coverage over the *union* of queried intervals per strand mode
+//               ("islands"): uint32 (merged windows of the point rules) or float64 (center)
 //   out         the caller-visible int64/float64 vectors (every chain 5'->3')
 //
-// Kernels (one reference function each; reference = plastid/genomics/map_factories.pyx)
-//   k_tile_ranges   fetch emulation: record range of every genome tile    (genome_array.py:800-809)
-//   k_hist_point    FivePrime/ThreePrime/Variable/Stratified              (:308-367,:407-466,:585-650,:724-780)
-//   k_gather_split  lays out tiles that were split into several work items
-//   k_center        CenterMapFactory, ordered float64 replay              (:200-265)
-//   k_gather        SegmentChain.get_counts layout + normalisation        (roitools.pyx:3259-3271,
-//                                                                          genome_array.py:826-830)
+// Kernels (reference = plastid/genomics/map_factories.pyx unless noted)
+//   k_tile_ranges   fetch emulation: record range of every genome window  (genome_array.py:800-809)
+//   k_hist_point    FivePrime/ThreePrime/Variable/Stratified + filters + get_counts layout
+//                                                                         (:308-367,:407-466,:585-650,:724-780)
+//   k_gather_split  lays out windows that were split into several work items
+//   k_center_weigh / k_center_order / k_center   CenterMapFactory, ordered float64 replay (:200-265)
+//   k_gather        SegmentChain.get_counts layout + normalisation for the center rule
+//                                                                         (roitools.pyx:3259-3271, genome_array.py:826-830)
+//   k_rle_*         run-length encoding of an output vector (export, genome_array.py:990-1111)
+//   k_total_*       sum of an output vector (multi-GPU summary totals)
 //   k_mapped_reads  reads_out of the map functions for one segment
 //   k_unmappable    records that make the reference emit its DataWarning
 #pragma once
