@@ -1431,6 +1431,28 @@ __global__ void k_total_f64_final(const double *__restrict__ partial, int nb, do
     }
 }
 
+// ---------------------------------------------------------------- k_update_flags
+// Host-side read filters changed (genome_array.py:697-722, 819-820): rewrite the strand / excluded
+// bits of every staged copy of the record headers -- packed record, 4-byte stream word, side lists.
+__global__ __launch_bounds__(kWG) void k_update_flags(uint2 *rec, uint32_t *stream, const uint8_t *__restrict__ flags,
+                                                      int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t keep = ~((kFlagReverse | kFlagExcluded) << 16);
+    uint2 r = rec[i];
+    r.y = (r.y & keep) | ((uint32_t)(flags[i] & (kFlagReverse | kFlagExcluded)) << 16);
+    rec[i] = r;
+    stream[i] = stream_word(r.x, r.y);
+}
+
+__global__ __launch_bounds__(kWG) void k_update_side_flags(uint4 *list, int64_t n, const uint2 *__restrict__ rec) {
+    const int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (j >= n) return;
+    uint4 g = list[j];
+    g.y = rec[g.w].y; // the side lists carry a copy of the header
+    list[j] = g;
+}
+
 // ---------------------------------------------------------------- run-length encoding
 // Export side (genome_array.py:1041-1111, to_bedgraph / to_variable_step): the per-position
 // vector of a whole chromosome is reduced on the GPU to its runs -- a run starts at element 0,

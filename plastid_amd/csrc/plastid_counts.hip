@@ -158,6 +158,7 @@ struct pc_engine {
     // scratch for counting
     DevBuf<WorkItem> d_work, d_work_small;
     DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
+    DevBuf<uint8_t> d_flags;     // staging buffer of pc_update_flags
     bool counters_zero = false; // left zeroed by the last kernel of a point-rule count
     size_t max_lds = 64 * 1024; // LDS a workgroup may use (160 KiB on gfx950)
     DevBuf<double> d_partial;
@@ -656,29 +657,22 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     StagedFile *sf = e->files[file];
     if (n != sf->n || (n > 0 && !flags)) return fail(PC_ERR_ARG, "pc_update_flags: wrong record count");
     HIP_TRY(hipSetDevice(e->device));
-    std::vector<uint2> rec((size_t)n);
-    HIP_TRY(hipMemcpy(rec.data(), sf->rec.p, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost));
-    const uint32_t keep = ~(((uint32_t)(PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16);
-    for (int64_t i = 0; i < n; ++i)
-        rec[(size_t)i].y = (rec[(size_t)i].y & keep) | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16);
-    HIP_TRY(hipMemcpy(sf->rec.p, rec.data(), (size_t)n * sizeof(uint2), hipMemcpyHostToDevice));
-    {
-        std::vector<uint32_t> stream((size_t)n);
-        for (int64_t i = 0; i < n; ++i) stream[(size_t)i] = stream_word(rec[(size_t)i].x, rec[(size_t)i].y);
-        if (n) HIP_TRY(hipMemcpy(sf->stream.p, stream.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    if (sf->nlong) {
-        std::vector<uint4> g((size_t)sf->nlong);
-        HIP_TRY(hipMemcpy(g.data(), sf->long_rec.p, g.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-        for (auto &x : g) x.y = rec[(size_t)x.w].y;
-        HIP_TRY(hipMemcpy(sf->long_rec.p, g.data(), g.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    }
-    if (sf->ngap) { // the gapped-record list carries a copy of the header
-        std::vector<uint4> g((size_t)sf->ngap);
-        HIP_TRY(hipMemcpy(g.data(), sf->gap_rec.p, g.size() * sizeof(uint4), hipMemcpyDeviceToHost));
-        for (auto &x : g) x.y = rec[(size_t)x.w].y;
-        HIP_TRY(hipMemcpy(sf->gap_rec.p, g.data(), g.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    }
+    if (n == 0) return PC_OK;
+    // the flags go up (1 byte per record); every staged copy of the headers is patched in HBM
+    int rc = e->d_flags.reserve((size_t)n);
+    if (rc != PC_OK) return rc;
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemcpyAsync(e->d_flags.p, flags, (size_t)n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_update_flags, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, sf->stream.p,
+                       e->d_flags.p, n);
+    if (sf->nlong)
+        hipLaunchKernelGGL(k_update_side_flags, dim3((unsigned)((sf->nlong + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->long_rec.p,
+                           sf->nlong, sf->rec.p);
+    if (sf->ngap)
+        hipLaunchKernelGGL(k_update_side_flags, dim3((unsigned)((sf->ngap + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->gap_rec.p,
+                           sf->ngap, sf->rec.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
     return PC_OK;
 }
 
