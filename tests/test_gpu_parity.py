@@ -521,39 +521,42 @@ def test_bam_file_end_to_end(pa, oracle, tmp_path):
     assert total == int(((reads.flags & 1) == 0).sum())
 
 
-def _window_loop_bedgraph(ga, pa, fh, trackname, strand, window_size):
-    """The reference's own export loop (genome_array.py:1041-1111), over ``ga.get``."""
-    fh.write("track type=bedGraph name=%s\n" % trackname)
+def _windows(ga, pa, strand, window_size):
+    """(chrom, window start, genome-order vector) for every export window, chromosomes sorted --
+    the iteration order of the reference's exporters (genome_array.py:990-1111)."""
     for chrom in sorted(ga.chroms()):
-        my_size = ga.lengths()[chrom]
-        for my_start in range(0, my_size, window_size):
-            my_end = min(my_start + window_size, my_size)
-            my_counts = ga.get(pa.GenomicSegment(chrom, my_start, my_end, strand), roi_order=False)
-            if my_counts.sum() > 0:
-                genomic_start_x = my_start
-                last_val = my_counts[0]
-                for x in np.nonzero(my_counts[1:] != my_counts[:-1])[0]:
-                    genomic_end_x = 1 + int(x) + my_start
-                    if last_val > 0:
-                        fh.write("%s\t%s\t%s\t%s\n" % (chrom, genomic_start_x, genomic_end_x, last_val))
-                    last_val = my_counts[x + 1]
-                    genomic_start_x = genomic_end_x
-                if last_val > 0:
-                    fh.write("%s\t%s\t%s\t%s\n" % (chrom, genomic_start_x, my_end, last_val))
+        size = ga.lengths()[chrom]
+        for w0 in range(0, size, window_size):
+            yield chrom, w0, ga.get(pa.GenomicSegment(chrom, w0, min(w0 + window_size, size), strand), roi_order=False)
 
 
-def _window_loop_variable_step(ga, pa, fh, trackname, strand, window_size):
-    """genome_array.py:990-1039"""
-    fh.write("track type=wiggle_0 name=%s\n" % trackname)
+def _expected_bedgraph(ga, pa, trackname, strand, window_size):
+    """What to_bedgraph must write: per window, maximal runs of equal positive values as
+    ``chrom start end value`` lines; windows without counts write nothing."""
+    lines = ["track type=bedGraph name=%s\n" % trackname]
+    for chrom, w0, vec in _windows(ga, pa, strand, window_size):
+        if not vec.sum() > 0:
+            continue
+        edges = np.concatenate([[0], np.nonzero(np.diff(vec))[0] + 1, [len(vec)]])
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            if vec[lo] > 0:
+                lines.append("%s\t%s\t%s\t%s\n" % (chrom, w0 + lo, w0 + hi, vec[lo]))
+    return "".join(lines)
+
+
+def _expected_variable_step(ga, pa, trackname, strand, window_size):
+    """What to_variable_step must write: a header per chromosome, then ``position(1-based) value``
+    for every position with a count."""
+    lines = ["track type=wiggle_0 name=%s\n" % trackname]
+    last = None
     for chrom in sorted(ga.chroms()):
-        my_size = ga.lengths()[chrom]
-        fh.write("variableStep chrom=%s span=1\n" % chrom)
-        for my_start in range(0, my_size, window_size):
-            my_end = min(my_start + window_size, my_size)
-            my_counts = ga.get(pa.GenomicSegment(chrom, my_start, my_end, strand), roi_order=False)
-            if my_counts.sum() > 0:
-                for idx in my_counts.nonzero()[0]:
-                    fh.write("%s\t%s\n" % (my_start + idx + 1, my_counts[idx]))
+        lines.append("variableStep chrom=%s span=1\n" % chrom)
+        for c2, w0, vec in _windows(ga, pa, strand, window_size):
+            if c2 != chrom or not vec.sum() > 0:
+                continue
+            for i in np.flatnonzero(vec):
+                lines.append("%s\t%s\n" % (w0 + i + 1, vec[i]))
+    return "".join(lines)
 
 
 def test_export_is_the_reference_window_loop(pa):
@@ -577,14 +580,12 @@ def test_export_is_the_reference_window_loop(pa):
         ga.set_normalize(norm)
         for strand in ("+", "-", "."):
             for window in (100000, 7777):
-                got, want = io.StringIO(), io.StringIO()
+                got = io.StringIO()
                 ga.to_bedgraph(got, "t", strand, window_size=window)
-                _window_loop_bedgraph(ga, pa, want, "t", strand, window)
-                assert got.getvalue() == want.getvalue(), (mapping, norm, strand, window)
-            got, want = io.StringIO(), io.StringIO()
+                assert got.getvalue() == _expected_bedgraph(ga, pa, "t", strand, window), (mapping, norm, strand, window)
+            got = io.StringIO()
             ga.to_variable_step(got, "t", strand)
-            _window_loop_variable_step(ga, pa, want, "t", strand, 100000)
-            assert got.getvalue() == want.getvalue(), (mapping, norm, strand)
+            assert got.getvalue() == _expected_variable_step(ga, pa, "t", strand, 100000), (mapping, norm, strand)
     # the encoder itself against numpy, with and without a period
     eng = Engine(0)
     eng.set_alignments([small])
