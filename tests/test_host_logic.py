@@ -273,3 +273,33 @@ def test_header_is_plain_c_and_cxx(tmp_path):
     from plastid_amd import _lib
     declared = set(re.findall(r"\b(pc_[a-z_0-9]+)\s*\(", open(hdr).read()))
     assert declared == set(_lib.SIGNATURES)
+
+
+def _build_c_client(tmp_path):
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from plastid_amd import build
+    build.build_library()
+    exe = str(tmp_path / "c_client")
+    libdir = os.path.join(root, "plastid_amd")
+    subprocess.check_call([shutil.which("gcc") or "gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_client.c"), "-L", libdir, "-lplastid_counts",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_c_client_links_against_the_abi(tmp_path):
+    """examples/c_client.c -- a client that knows only the header -- compiles and links (C99)."""
+    assert os.path.exists(_build_c_client(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_client_runs(tmp_path):
+    import subprocess
+    out = subprocess.check_output([_build_c_client(tmp_path)]).decode()
+    want = [0] * 30
+    for p in (102, 102, 105, 107):
+        want[p - 95] += 1
+    assert out.splitlines()[0] == "counts[95..125) = " + " ".join(str(v) for v in want)
+    assert out.splitlines()[1].startswith("total = 4 ")
