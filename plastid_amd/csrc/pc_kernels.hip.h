@@ -1152,13 +1152,14 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
 // pass 2: cut and queue
 __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__restrict__ cand_in, int64_t nchunks,
                                                             const unsigned long long *__restrict__ total,
-                                                            int64_t floor_thr, uint32_t *order, uint32_t *counters) {
+                                                            int64_t floor_thr, int k1, int k2, uint32_t *order,
+                                                            uint32_t *counters) {
     __shared__ uint32_t s_wave[kRangesWG / 64];
     __shared__ uint32_t s_base[2];
     const int64_t c = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
     const bool live = c < nchunks;
     const int64_t mean = (int64_t)(*total / (unsigned long long)(nchunks > 0 ? nchunks : 1));
-    const int64_t t1 = 8 * mean > floor_thr ? 8 * mean : floor_thr, t2 = 4 * t1;
+    const int64_t t1 = k1 * mean > floor_thr ? k1 * mean : floor_thr, t2 = k2 * t1; // k1 >= 8 (capacity, see above)
     const int64_t cand = live ? (int64_t)cand_in[c] : 0;
     const uint32_t nsub = !live ? 0u : (cand > t2 ? 8u : (cand > t1 ? 4u : 0u)); // 0: not cut
     uint32_t th, tl;

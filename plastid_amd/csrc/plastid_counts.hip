@@ -1142,7 +1142,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
             hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
                                p->d_ccand.p, p->d_cranges.p, total);
-            hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, (int64_t)2048,
+            int ck1 = 8, ck2 = 4; // cut thresholds, in multiples of the mean candidate count (tuning knobs)
+            if (const char *env = getenv("PC_CENTER_T1")) ck1 = std::max(8, atoi(env));
+            if (const char *env = getenv("PC_CENTER_T2")) ck2 = std::max(1, atoi(env));
+            hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, (int64_t)2048, ck1, ck2,
                                p->d_corder.p, e->d_counters.p);
             hipLaunchKernelGGL(k_center, dim3((unsigned)((2 * nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks,
                                e->d_files.p, nfiles, mp, W, e->d_inv.p, p->d_corder.p, e->d_counters.p, p->d_cranges.p,
