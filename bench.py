@@ -103,6 +103,16 @@ def _mp_worker(sel):
     return time.perf_counter() - t0
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline_all_cores(oracle, aln, spec, p, tx, n_records, chains_done):
     """The same oracle on every host core: one process per core over disjoint chain shards
     (the reference itself is single-threaded; this is the most favourable honest scaling)."""
@@ -167,6 +177,8 @@ def main():
         cpu, check_sel, check_arrays, chains_done = cpu_baseline(oracle, aln, spec, p, tx, reads.n, args.cpu_budget,
                                                                  np.random.default_rng(7))
         cpu["all_cores"] = cpu_baseline_all_cores(oracle, aln, spec, p, tx, reads.n, chains_done)
+        cpu["cpu_model"] = cpu_model()
+        cpu["host_cores"] = os.cpu_count()
     else:
         # parity gate only: a small seeded sample of chains
         order = np.random.default_rng(7 + rank).permutation(tx.n)[:min(tx.n, 100)]
