@@ -122,3 +122,48 @@ def test_random_cigars_roundtrip(tmp_path, seed):
     assert got.n == len(recs)
     for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
         assert np.array_equal(getattr(got, k), getattr(exp, k)), k
+
+
+def test_corrupt_bam_is_rejected_not_crashed(tmp_path):
+    """Damaged files -- flipped bytes, truncation, absurd length fields, both in the BGZF container
+    and inside well-formed BGZF blocks -- either load or raise; they never take the process down
+    (the same loop ran clean under AddressSanitizer / UBSan during development)."""
+    import struct
+    from plastid_amd.exceptions import MalformedFileError
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00001, tx_scale=0.001)
+    recs = bam_writer.packed_to_records(reads)
+    refs, lens = list(reads.references), list(reads.lengths)
+    text = b"@HD\\tVN:1.6\\tSO:coordinate\\n"
+    head = b"BAM\\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(refs))
+    for nm, ln in zip(refs, lens):
+        nmb = nm.encode() + b"\\x00"
+        head += struct.pack("<I", len(nmb)) + nmb + struct.pack("<I", ln)
+    good = head + b"".join(bam_writer.encode_record(t, p, c, f) for t, p, c, f in recs)
+    rng = np.random.default_rng(5)
+    path = str(tmp_path / "damaged.bam")
+    outcomes = {"ok": 0, "rejected": 0}
+    for it in range(150):
+        b = bytearray(good)
+        mode = int(rng.integers(0, 4))
+        lo = 0 if rng.random() < 0.2 else len(head)
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(lo, len(b)))] = int(rng.integers(0, 256))
+        elif mode == 1:
+            b = b[:int(rng.integers(lo, len(b)))]
+        else:
+            i = int(rng.integers(lo, len(b) - 4))
+            b[i:i + 4] = struct.pack("<I", int(rng.choice([0, 1, 0x7fffffff, 0xffffffff, 0x80000000, 65536])))
+        blob = b"".join(bam_writer.bgzf_block(bytes(b[o:o + 3000])) for o in range(0, len(b), 3000)) + bam_writer.BGZF_EOF
+        if mode == 3:   # damage the container itself
+            blob = bytearray(blob)
+            blob[int(rng.integers(0, len(blob)))] ^= 0x5a
+            blob = bytes(blob[:int(rng.integers(len(blob) // 2, len(blob) + 1))])
+        with open(path, "wb") as fh:
+            fh.write(blob)
+        try:
+            read_bam(path, threads=int(rng.integers(1, 3)))
+            outcomes["ok"] += 1
+        except (ValueError, MalformedFileError, OSError):
+            outcomes["rejected"] += 1
+    assert outcomes["rejected"] > 30 and outcomes["ok"] + outcomes["rejected"] == 150
