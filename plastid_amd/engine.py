@@ -51,6 +51,12 @@ class Engine(object):
     def add_alignment_file(self, packed, ntid=None):
         """Stage one :class:`~plastid_amd.packing.PackedAlignments` to HBM."""
         ntid = len(packed.references) if ntid is None else int(ntid)
+        # the C side trusts the sizes it is given: the array lengths are checked here, always
+        for name in ("pos", "alen", "flags", "nblk"):
+            if len(getattr(packed, name)) != packed.n:
+                raise ValueError("alignment array '%s' has %d entries, expected %d" % (name, len(getattr(packed, name)), packed.n))
+        if len(packed.blk_start) != len(packed.blk_len):
+            raise ValueError("run arrays blk_start / blk_len differ in length")
         check(self._lib.pc_add_alignment_file(
             self._h, packed.n, ntid, _ptr(packed.tid), _ptr(packed.pos), _ptr(packed.alen),
             _ptr(packed.flags), _ptr(packed.nblk), len(packed.blk_start), _ptr(packed.blk_start),
