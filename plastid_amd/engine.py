@@ -149,6 +149,9 @@ class Plan(object):
         self.out_step = _c(out_step, np.int8)
         self.row_stride = _c(row_stride, np.int64)
         self.nseg = len(self.tid)
+        for name in ("start", "end", "strand", "out_off", "out_step", "row_stride"):
+            if len(getattr(self, name)) != self.nseg:
+                raise ValueError("plan array '%s' has %d entries, expected %d" % (name, len(getattr(self, name)), self.nseg))
         self.out_elems = int(out_elems)
         self.rows = int(rows)
         h = ctypes.c_void_p()
