@@ -738,27 +738,34 @@ __device__ __forceinline__ void stream_records(const u32x4 PC_GLOBAL *src, int n
                                                const uint32_t *ftab, uint32_t mode_mask, uint32_t G, uint32_t dump,
                                                uint32_t *smem) {
     const int lane_j = (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
-    for (int base = 0; base < nquads; base += WG * U) {
-        u32x4 nxt[U];
-        const int nb = base + WG * U;
+    // two register sets used alternately (the loop body is written out twice): handing the next
+    // batch over with register moves would make every iteration wait for all of its loads
+    auto load = [&](u32x4 (&d)[U], int nb) {
         const u32x4 PC_GLOBAL *q = src + nb + lane_j;
         if (nb + WG * U <= nquads) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = q[u * 64];
+            for (int u = 0; u < U; ++u) d[u] = q[u * 64];
         } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = (nb + lane_j + u * 64 < nquads) ? q[u * 64] : none;
+            for (int u = 0; u < U; ++u) d[u] = (nb + lane_j + u * 64 < nquads) ? q[u * 64] : none;
         }
+    };
+    auto bin = [&](const u32x4 (&c)[U], int base) {
         const int wave_q = base + (int)(threadIdx.x >> 6) * (64 * U); // first quad of this wave's slice of the batch
 #pragma unroll
         for (int u = 0; u < U; u += 2) { // eight records (two quads of the lane's slice) per call
             if (wave_q + u * 64 >= nquads) break; // wave-uniform: nothing but padding from here on (sparse windows)
-            const uint32_t w8[8] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w,
-                                    cur[u + 1].x, cur[u + 1].y, cur[u + 1].z, cur[u + 1].w};
+            const uint32_t w8[8] = {c[u].x, c[u].y, c[u].z, c[u].w, c[u + 1].x, c[u + 1].y, c[u + 1].z, c[u + 1].w};
             fast_bin<8>(ftab, mode_mask, G, dump, w8, smem);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    };
+    u32x4 alt[U];
+    for (int base = 0; base < nquads; base += 2 * WG * U) {
+        load(alt, base + WG * U);
+        bin(cur, base);
+        if (base + WG * U >= nquads) break;
+        load(cur, base + 2 * WG * U);
+        bin(alt, base + WG * U);
     }
 }
 
