@@ -141,6 +141,8 @@ struct StagedFile {
 struct pc_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // the single-wave kernel of sparse windows runs beside the main one
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev[8] = {};
     std::vector<StagedFile *> files;
     int ntid = 0;
@@ -288,6 +290,9 @@ int pc_create(int device, pc_engine **out) {
     pc_engine *e = new pc_engine();
     e->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     {
         int lds_attr = 0;
         if (hipDeviceGetAttribute(&lds_attr, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds_attr > 0)
@@ -316,6 +321,9 @@ int pc_destroy(pc_engine *e) {
     e->files.clear();
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return PC_OK;
@@ -1076,7 +1084,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                            (OutT_<O>::type *)p->d_out.p,                                                                \
                            e->norm_sum, (uint32_t)cap64);                                                               \
         if (cap_small)                                                                                                \
-            hipLaunchKernelGGL((k_hist_point<K, O, 64, true>), dim3((unsigned)cap_small), dim3(64), lds_small, st,      \
+            hipLaunchKernelGGL((k_hist_point<K, O, 64, true>), dim3((unsigned)cap_small), dim3(64), lds_small, st_small, \
                                p->d_pieces.p, p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work_small.p,                \
                                e->d_counters.p, p->d_tile_items.p, mp, small_g, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, \
                                (uint32_t *)p->d_hist.p,                                                                 \
@@ -1089,6 +1097,15 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         else PC_LAUNCH_HIST(K, 2);                                                                                    \
     } while (0)
             const size_t lds_small = ((size_t)p->max_slots * p->rows * std::max(small_g, 1) + (size_t)((tab_n + 3) & ~3) + fwords + stage_words) * sizeof(uint32_t);
+            // sparse windows (single-wave workgroups) and dense ones are two independent launches over
+            // disjoint windows: they run side by side on two streams, forked after the work lists exist
+            // and joined before the last kernel of the call
+            hipStream_t st_small = st;
+            if (cap_small) {
+                st_small = e->side_stream;
+                HIP_TRY(hipEventRecord(e->ev_fork, st));
+                HIP_TRY(hipStreamWaitEvent(st_small, e->ev_fork, 0));
+            }
             switch (e->kind) {
             case PC_MAP_FIVE: PC_LAUNCH_HIST_O(0); break;
             case PC_MAP_THREE: PC_LAUNCH_HIST_O(1); break;
@@ -1097,6 +1114,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             }
 #undef PC_LAUNCH_HIST_O
 #undef PC_LAUNCH_HIST
+            if (cap_small) {
+                HIP_TRY(hipEventRecord(e->ev_join, st_small));
+                HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+            }
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
             if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
             // tiles that were split into several work items: lay out from the merged histogram
