@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
                                                            int nfiles, int G, int W, int64_t R, int64_t pile,
                                                            WorkItem *work, uint32_t *nwork, uint32_t *tile_items,
                                                            uint32_t work_cap, WorkItem *work_small, int small_g,
-                                                           int64_t small_n) {
+                                                           int64_t small_n, int diag) {
     __shared__ unsigned long long s_wave64[kRangesWG / 64];
     __shared__ uint32_t s_base[3];
     const int64_t idx = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
@@ -531,6 +531,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             n_light = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || f == 0) ? 1u : 0u);
         }
     }
+    if (diag && live && f == 0 && lhi > llo) atomicAdd(&nwork[3], (uint32_t)(lhi - llo)); // PC_DEBUG_WORK: long-span candidates
     // one scan for the three classes: 21 bits each (a block queues far fewer than 2 M items)
     unsigned long long tot3;
     const unsigned long long off3 = block_scan_excl64((unsigned long long)n_heavy | ((unsigned long long)n_light << 21) |

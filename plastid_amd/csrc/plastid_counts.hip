@@ -1051,7 +1051,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const int64_t nthreads = (int64_t)ntiles * nfiles; // one thread per (tile, file)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
                                e->files[0]->view(), e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
-                               e->d_work_small.p, small_g, small_n);
+                               e->d_work_small.p, small_g, small_n, getenv("PC_DEBUG_WORK") ? 1 : 0);
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
             int lmin = 65536, lmax = -1;
@@ -1137,8 +1137,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 uint32_t c4[4] = {0, 0, 0, 0};
                 HIP_TRY(hipMemcpyAsync(c4, e->d_counters.p + 4, sizeof(c4), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                fprintf(stderr, "[work] tiles %d: heavy %u light %u small %u (capacity %lld, G %d, R %lld)\n", ntiles, c4[0], c4[1], c4[2],
-                        (long long)cap64, G, (long long)R);
+                fprintf(stderr, "[work] tiles %d: heavy %u light %u small %u, long-span candidates %u (capacity %lld, G %d, R %lld)\n", ntiles,
+                        c4[0], c4[1], c4[2], c4[3], (long long)cap64, G, (long long)R);
             }
         } else {
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
