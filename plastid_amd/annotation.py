@@ -156,12 +156,165 @@ def _assemble_gtf2(stream):
         attr = attrs[tname]
         attr["type"] = "mRNA"
         if tname in cds:
-            attr["cds_genome_start"] = min(c[0] for c in cds[tname])
-            attr["cds_genome_end"] = max(c[1] for c in cds[tname])
+            ordered = sorted(cds[tname])   # first start / last end of the sorted CDS features (gff.py:1175-1178)
+            attr["cds_genome_start"], attr["cds_genome_end"] = ordered[0][0], ordered[-1][1]
         out.append((blocks[0][0], blocks[0][3], [tuple(m) for m in merged], attr))
     out.sort(key=lambda t: (t[0], t[2][0][0], t[2][-1][1], STRAND_CODE.get(t[1], 3),
                             sum(e - s for s, e in t[2]), str(t[3].get("transcript_id"))))
     return out
+
+
+# ---------------------------------------------------------------------------- GFF3
+# feature types of the reference's default schema (Sequence Ontology 2.5.3 subset, readers/gff.py:203-345)
+def _load_terms(name):
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", name)
+    with open(path) as fh:
+        return frozenset(line.strip() for line in fh if line.strip() and not line.startswith("#"))
+
+
+GFF3_TRANSCRIPT_TYPES = _load_terms("gff3_transcript_types.txt")
+GFF3_EXON_TYPES = frozenset(["exon", "coding_exon", "noncoding_exon", "exon_of_single_exon_gene", "interior_exon",
+                             "interior_coding_exon", "five_prime_coding_exon",
+                             "three_prime_coding_exonfive_prime_noncoding_exon",   # (sic: the reference's list lacks a comma)
+                             "three_prime_noncoding_exon", "pseudogenic_exon"])
+GFF3_CDS_TYPES = frozenset(["CDS", "CDS_fragment", "CDS_indpendently_known", "CDS_predicted"])
+_GFF3_LIST_KEYS = ("Parent", "Alias", "Note", "Dbxref", "Ontology_term", "dbxref")
+
+
+def _gff3_unescape(text):
+    from urllib.parse import unquote
+    return unquote(text)
+
+
+def _gff3_attributes(text):
+    """Ninth GFF3 column -> dict (``parse_GFF3_tokens``, readers/gff_tokens.py:460-535): ``key=value``
+    pairs, URL-unescaped; Parent / Alias / Note / Dbxref / Ontology_term are comma-separated lists."""
+    out = {}
+    for item in text.strip("\n").strip(";").split(";"):
+        if not item:
+            continue
+        key, val = item.split("=")
+        key = _gff3_unescape(key.strip(" "))
+        if key in _GFF3_LIST_KEYS:
+            val = [_gff3_unescape(x) for x in val.strip(" ").split(",")]
+        else:
+            val = _gff3_unescape(val.strip(" "))
+        if key in out:
+            val = "%s,%s" % (out[key], val)
+        out[key] = val
+    return out
+
+
+def _gff3_batches(stream):
+    """Lists of (chrom, type, start, end, strand, attr) between ``###`` lines (the signal that
+    everything read so far may be assembled, readers/gff.py:925-988); ``##FASTA`` ends the features."""
+    batch = []
+    for line in stream:
+        if line.startswith("##FASTA") or line.startswith("###FASTA"):
+            break
+        if line.startswith("###"):
+            yield batch
+            batch = []
+            continue
+        if not line.strip() or line.startswith("#"):
+            continue
+        items = line.rstrip("\n").split("\t")
+        if len(items) < 9:
+            raise ValueError("GFF3 format requires 9 columns. Found only %s.\n\t    %s" % (len(items), items))
+        attr = _gff3_attributes(items[8])
+        batch.append((items[0], items[2], int(items[3]) - 1, int(items[4]), items[6], attr))
+    yield batch
+
+
+def _identical_attributes(dicts):
+    out = None
+    for d in dicts:
+        if out is None:
+            out = dict(d)
+        else:
+            for k in [k for k in out if d.get(k, None) != out[k]]:
+                del out[k]
+    return out or {}
+
+
+def _assemble_gff3(features, transcript_types=GFF3_TRANSCRIPT_TYPES, exon_types=GFF3_EXON_TYPES,
+                   cds_types=GFF3_CDS_TYPES):
+    """One batch of ``GFF3_TranscriptAssembler`` (readers/gff.py:1417-1565): exon- and CDS-type
+    features are grouped under every ``Parent`` they name (or, lacking one, under their shared ``ID``);
+    a group becomes a transcript whose blocks are the merged exon and CDS spans; its attributes come
+    from the transcript-type feature of that ID when there is one, else from what all components
+    agree on.  Transcript features without exon/CDS children yield nothing, groups on several
+    chromosomes or strands are rejected with a ``DataWarning``.  Sorted like |SegmentChains|."""
+    tx_features, comp, cds_of = {}, {}, {}
+    for chrom, ftype, start, end, strand, attr in features:
+        name = attr.get("ID", attr.get("Name", attr.get("name", "%s:%s-%s(%s)" % (chrom, start, end, strand))))
+        if ftype in transcript_types:
+            tx_features.setdefault(name, []).append(dict(attr, type=ftype))
+        elif ftype in exon_types or ftype in cds_types:
+            parents = attr.get("Parent")
+            if parents is None:
+                if "ID" not in attr:
+                    warn("Found %s at %s:%s-%s(%s) with no `Parent` or `ID`. Ignoring." % (ftype, chrom, start, end, strand),
+                         DataWarning)
+                    continue
+                parents = [attr["ID"]]
+            full = dict(attr, type=ftype)
+            for tname in parents:
+                comp.setdefault(tname, []).append((chrom, start, end, strand, full))
+                if ftype in cds_types:
+                    cds_of.setdefault(tname, []).append((chrom, start, end, STRAND_CODE.get(strand, 3)))
+    out = []
+    for tname, blocks in comp.items():
+        if tname in tx_features:
+            attr = dict(tx_features[tname][0])
+            attr["gene_id"] = ",".join(sorted(attr.get("Parent", [tname])))
+        else:
+            attr = _identical_attributes([b[4] for b in blocks])
+            attr["type"] = "mRNA"
+        attr["ID"] = attr["transcript_id"] = tname
+        if tname in cds_of:
+            ordered = sorted(cds_of[tname])
+            attr["cds_genome_start"], attr["cds_genome_end"] = ordered[0][1], ordered[-1][2]
+        if len(set((b[0], b[3]) for b in blocks)) > 1:
+            warn("Rejecting transcript '%s' because it contains exons  on multiple strands." % tname, DataWarning)
+            continue
+        merged = []
+        for _, s, e, _, _ in sorted(blocks, key=lambda b: (b[1], b[2])):
+            if merged and s <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], e)
+            else:
+                merged.append([s, e])
+        out.append((blocks[0][0], blocks[0][3], [tuple(m) for m in merged], attr))
+    out.sort(key=lambda t: (t[0], t[2][0][0], t[2][-1][1], STRAND_CODE.get(t[1], 3),
+                            sum(e - s for s, e in t[2]), str(t[3]["transcript_id"])))
+    return out
+
+
+def _gff3_rows(path_or_stream, **types):
+    fh, opened = _open_text(path_or_stream)
+    try:
+        rows = []
+        for batch in _gff3_batches(fh):
+            rows.extend(_assemble_gff3(batch, **types))
+        return rows
+    finally:
+        if opened:
+            fh.close()
+
+
+def read_gff3(path_or_stream, cls=None, **types):
+    """Transcripts of a GFF3 file as |SegmentChains|, in the order ``GFF3_TranscriptAssembler``
+    yields them (every ``###``-delimited batch sorted)."""
+    from .roitools import GenomicSegment, SegmentChain
+    cls = SegmentChain if cls is None else cls
+    chains = []
+    for chrom, strand, blocks, attr in _gff3_rows(path_or_stream, **types):
+        chain = cls()
+        chain._set_segments([GenomicSegment(chrom, s, e, strand) for s, e in blocks])
+        chain.attr.update(attr)
+        chains.append(chain)
+    return chains
 
 
 def _open_text(path_or_stream):
@@ -275,6 +428,21 @@ class IntervalTable(object):
                 e.append(b)
             ex_off.append(len(s))
             ids.append(attr.get("transcript_id"))
+        return cls(references, None, tid, strand, ex_off, s, e, ids=ids)
+
+    @classmethod
+    def from_gff3(cls, path_or_stream, references, **types):
+        """Straight from GFF3 text (see :func:`_assemble_gff3`), no per-transcript Python objects."""
+        index = {r: i for i, r in enumerate(references)}
+        tid, strand, ex_off, s, e, ids = [], [], [0], [], [], []
+        for chrom, st, blocks, attr in _gff3_rows(path_or_stream, **types):
+            tid.append(index.get(chrom, -1))
+            strand.append(STRAND_CODE.get(st, 3))
+            for a, b in blocks:
+                s.append(a)
+                e.append(b)
+            ex_off.append(len(s))
+            ids.append(attr["transcript_id"])
         return cls(references, None, tid, strand, ex_off, s, e, ids=ids)
 
     # ------------------------------------------------------------------ views

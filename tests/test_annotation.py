@@ -93,3 +93,37 @@ def test_interval_table_from_gtf2():
             assert str(c) == row[1]
     assert (tab.tid == -1).sum() == sum(r[1].startswith("2-micron") for r in gold["transcripts"])
     assert (np.diff(tab.ex_start) > 0)[tab.ex_tx[1:] == tab.ex_tx[:-1]].all()
+
+
+# ---------------------------------------------------------------------------- GFF3
+def _gff3_golden():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gff3_transcripts.json")) as fh:
+        return json.load(fh)
+
+
+def test_gff3_assembly_matches_reference_golden():
+    """Transcripts (Parent-linked, shared-ID, implied by a non-transcript parent, exons with several
+    parents), CDS bounds, gene ids, types, rejected ids and ORDER (``###`` batches, each sorted) as the
+    reference's GFF3_TranscriptAssembler gave them (fixture: tests/golden/make_gff3_golden.py)."""
+    import warnings
+    from plastid_amd.annotation import read_gff3
+    gold = _gff3_golden()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        chains = read_gff3(io.StringIO(gold["gff3"]))
+    rejected = sorted(str(x.message).split("'")[1] for x in w if "Rejecting" in str(x.message))
+    assert rejected == gold["rejected"]
+    got = [[c.attr["transcript_id"], str(c), c.attr.get("cds_genome_start"), c.attr.get("cds_genome_end"),
+            c.attr.get("gene_id"), c.attr.get("type")] for c in chains]
+    assert got == gold["transcripts"]
+
+
+def test_interval_table_from_gff3():
+    import warnings
+    gold = _gff3_golden()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tab = IntervalTable.from_gff3(io.StringIO(gold["gff3"]), ["chrI", "chrII", "chrM"])
+    assert tab.ids == [r[0] for r in gold["transcripts"]]
+    assert [str(c) for c in tab.chains()] == [r[1] for r in gold["transcripts"]]
