@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -42,19 +43,75 @@ int fail(int code, const char *fmt, ...) {
                         #expr, hipGetErrorString(err__), __FILE__, __LINE__);                      \
     } while (0)
 
+// Per-engine cache of small device blocks.  A plan of one short segment is otherwise dominated by
+// hipMalloc / hipFree (the latter synchronises the device): blocks up to 32 MiB are kept by
+// power-of-two size class when a plan lets go of them and handed to the next one.  Every user of
+// one pool enqueues on the same engine stream, so a recycled block is ordered after its last use.
+struct DevPool {
+    static constexpr int kMinShift = 8, kClasses = 18;   // 256 B .. 32 MiB
+    static constexpr size_t kMaxCached = (size_t)512 << 20;
+    std::mutex m;
+    std::vector<void *> bins[kClasses];
+    size_t cached = 0;
+    static int size_class(size_t bytes) {
+        int c = 0;
+        while (c < kClasses && ((size_t)1 << (kMinShift + c)) < bytes) ++c;
+        return c;   // kClasses: too large to pool
+    }
+    static size_t class_bytes(int c) { return (size_t)1 << (kMinShift + c); }
+    void *take(int c) {
+        std::lock_guard<std::mutex> g(m);
+        if (bins[c].empty()) return nullptr;
+        void *p = bins[c].back();
+        bins[c].pop_back();
+        cached -= class_bytes(c);
+        return p;
+    }
+    bool give(void *p, int c) {
+        std::lock_guard<std::mutex> g(m);
+        if (cached + class_bytes(c) > kMaxCached) return false;
+        bins[c].push_back(p);
+        cached += class_bytes(c);
+        return true;
+    }
+    void drain() {
+        std::lock_guard<std::mutex> g(m);
+        for (auto &b : bins) {
+            for (void *p : b) (void)hipFree(p);
+            b.clear();
+        }
+        cached = 0;
+    }
+    ~DevPool() { drain(); }
+};
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
+    DevPool *pool = nullptr;   // set: blocks come from / return to this pool
+    int pool_class = -1;       // size class of the current block, -1: plain hipMalloc
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !(pool_class >= 0 && pool && pool->give(p, pool_class))) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        pool_class = -1;
     }
     int reserve(size_t n) {
         if (n <= cap) return PC_OK;
         release();
         if (n == 0) return PC_OK;
+        if (pool) {
+            const int c = DevPool::size_class(n * sizeof(T));
+            if (c < DevPool::kClasses) {
+                void *q = pool->take(c);
+                if (!q) HIP_TRY(hipMalloc(&q, DevPool::class_bytes(c)));
+                p = (T *)q;
+                cap = DevPool::class_bytes(c) / sizeof(T);
+                pool_class = c;
+                return PC_OK;
+            }
+        }
         HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
         cap = n;
         return PC_OK;
@@ -66,6 +123,27 @@ template <typename T> struct DevBuf {
         return PC_OK;
     }
     int upload(const std::vector<T> &v, hipStream_t s) { return upload(v.data(), v.size(), s); }
+};
+
+// Page-locked host buffer that only grows.
+struct PinnedBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    int reserve(size_t n) {
+        if (n <= cap) return PC_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = std::max<size_t>(n + n / 2, 64 * 1024);
+        HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+        cap = want;
+        return PC_OK;
+    }
+};
+
+// A typed window into a block some DevBuf owns (the tables of a plan share one block and one upload).
+template <typename T> struct DevView {
+    T *p = nullptr;
 };
 
 // Host staging buffer that is NOT value-initialised: the worker threads of the staging pass are the
@@ -139,10 +217,12 @@ struct StagedFile {
 } // namespace
 
 struct pc_engine {
+    DevPool pool;   // first member: outlives every buffer of the engine
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // the single-wave kernel of sparse windows runs beside the main one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_pinned = nullptr;      // end of the last copy out of `pinned`
     hipEvent_t ev[8] = {};
     std::vector<StagedFile *> files;
     int ntid = 0;
@@ -161,6 +241,8 @@ struct pc_engine {
     DevBuf<WorkItem> d_work, d_work_small;
     DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
     DevBuf<uint8_t> d_flags;     // staging buffer of pc_update_flags
+    bool pinned_busy = false;
+    PinnedBuf pinned;            // host side of the plan-table upload (reused: ev_pinned is waited for before it is rewritten)
     bool counters_zero = false; // left zeroed by the last kernel of a point-rule count
     size_t max_lds = 64 * 1024; // LDS a workgroup may use (160 KiB on gfx950)
     DevBuf<double> d_partial;
@@ -206,10 +288,11 @@ struct pc_plan {
     std::vector<int32_t> h_tid;
     std::vector<int64_t> h_start, h_end;
     std::vector<uint8_t> h_strand;
-    DevBuf<Tile> d_tiles;
-    DevBuf<Piece> d_pieces;
-    DevBuf<OutPiece> d_opieces;
-    DevBuf<CenterChunk> d_cchunks;
+    DevBuf<uint8_t> d_tables;   // one block: tiles, pieces, output pieces, chunks, segments, per-tile counters, total
+    DevView<Tile> d_tiles;
+    DevView<Piece> d_pieces;
+    DevView<OutPiece> d_opieces;
+    DevView<CenterChunk> d_cchunks;
     DevBuf<uint32_t> d_corder;
     DevBuf<uint32_t> d_ccand;   // candidate records per center chunk
     DevBuf<uint32_t> d_rle_cnt; // run-length encoding of the output: heads per workgroup, their scan,
@@ -218,15 +301,22 @@ struct pc_plan {
     DevBuf<unsigned long long> d_rle_values;
     int64_t rle_runs = -1;
     DevBuf<u32x4> d_cranges;    // per (chunk, file): record range and long-span candidate range
-    DevBuf<GatherSeg> d_gsegs;
-    DevBuf<GatherChunk> d_gchunks;
-    DevBuf<uint32_t> d_tile_items;
+    DevView<GatherSeg> d_gsegs;
+    DevView<GatherChunk> d_gchunks;
+    DevView<uint32_t> d_tile_items;
     bool tile_items_zero = false;
     DevBuf<uint8_t> d_hist; // uint32 or double
     DevBuf<uint8_t> d_out;  // int64 or double
-    DevBuf<uint8_t> d_total;
+    DevView<uint8_t> d_total;
     int last_dtype = -1;
     bool counted = false;
+
+    explicit pc_plan(pc_engine *eng) : e(eng) {
+        DevPool *pl = &eng->pool;
+        d_tables.pool = pl; d_corder.pool = pl;
+        d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
+        d_cranges.pool = pl; d_hist.pool = pl; d_out.pool = pl;
+    }
 };
 
 namespace {
@@ -292,6 +382,7 @@ int pc_create(int device, pc_engine **out) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_pinned, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     {
         int lds_attr = 0;
@@ -323,6 +414,7 @@ int pc_destroy(pc_engine *e) {
         if (ev) (void)hipEventDestroy(ev);
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_pinned) (void)hipEventDestroy(e->ev_pinned);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -759,8 +851,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     struct Iv { int32_t tid; int32_t mode; int64_t s, e; };
     std::vector<Iv> ivs;
     ivs.reserve((size_t)nseg);
-    pc_plan *p = new pc_plan();
-    p->e = e;
+    pc_plan *p = new pc_plan(e);
     p->nseg = nseg;
     p->out_elems = out_elems;
     p->rows = rows;
@@ -945,15 +1036,36 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         for (int64_t c = 0; c * kGatherChunk < len; ++c) p->gchunks.push_back({(uint32_t)s, (uint32_t)c});
     }
 
-    int rc = p->d_tiles.upload(p->tiles, e->stream);
-    if (rc == PC_OK) rc = p->d_pieces.upload(p->pieces, e->stream);
-    if (rc == PC_OK) rc = p->d_opieces.upload(p->opieces, e->stream);
-    if (rc == PC_OK) rc = p->d_cchunks.upload(p->cchunks, e->stream);
-    if (rc == PC_OK) rc = p->d_gsegs.upload(p->gsegs, e->stream);
-    if (rc == PC_OK) rc = p->d_gchunks.upload(p->gchunks, e->stream);
-    if (rc == PC_OK) rc = p->d_tile_items.reserve(p->tiles.size() + 1);
-    if (rc == PC_OK) rc = p->d_total.reserve(8);
-    if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: sync failed");
+    // ---- one device block and one upload for all tables (a plan of one short segment is otherwise
+    // dominated by the per-copy cost); the per-tile item counters arrive zeroed with it
+    size_t bytes = 0;
+    auto place = [&bytes](size_t n) { const size_t at = bytes; bytes += (n + 255) & ~(size_t)255; return at; };
+    const size_t at_tiles = place(p->tiles.size() * sizeof(Tile)), at_pieces = place(p->pieces.size() * sizeof(Piece)),
+                 at_opieces = place(p->opieces.size() * sizeof(OutPiece)), at_cchunks = place(p->cchunks.size() * sizeof(CenterChunk)),
+                 at_gsegs = place(p->gsegs.size() * sizeof(GatherSeg)), at_gchunks = place(p->gchunks.size() * sizeof(GatherChunk)),
+                 at_items = place((p->tiles.size() + 1) * sizeof(uint32_t)), at_total = place(64);
+    int rc = p->d_tables.reserve(bytes);
+    if (rc == PC_OK && e->pinned_busy && hipEventSynchronize(e->ev_pinned) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: wait failed");
+    if (rc == PC_OK) rc = e->pinned.reserve(bytes);
+    if (rc == PC_OK) {
+        uint8_t *h = e->pinned.p, *d = p->d_tables.p;
+        auto put = [h](size_t at, const void *src, size_t n) { if (n) memcpy(h + at, src, n); };
+        put(at_tiles, p->tiles.data(), p->tiles.size() * sizeof(Tile));
+        put(at_pieces, p->pieces.data(), p->pieces.size() * sizeof(Piece));
+        put(at_opieces, p->opieces.data(), p->opieces.size() * sizeof(OutPiece));
+        put(at_cchunks, p->cchunks.data(), p->cchunks.size() * sizeof(CenterChunk));
+        put(at_gsegs, p->gsegs.data(), p->gsegs.size() * sizeof(GatherSeg));
+        put(at_gchunks, p->gchunks.data(), p->gchunks.size() * sizeof(GatherChunk));
+        memset(h + at_items, 0, bytes - at_items);
+        p->d_tiles.p = (Tile *)(d + at_tiles); p->d_pieces.p = (Piece *)(d + at_pieces);
+        p->d_opieces.p = (OutPiece *)(d + at_opieces); p->d_cchunks.p = (CenterChunk *)(d + at_cchunks);
+        p->d_gsegs.p = (GatherSeg *)(d + at_gsegs); p->d_gchunks.p = (GatherChunk *)(d + at_gchunks);
+        p->d_tile_items.p = (uint32_t *)(d + at_items); p->d_total.p = d + at_total;
+        p->tile_items_zero = true;
+        if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: upload failed");
+        else if (hipEventRecord(e->ev_pinned, e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: event failed");
+        else e->pinned_busy = true;
+    }
     if (rc != PC_OK) {
         delete p;
         return rc;
