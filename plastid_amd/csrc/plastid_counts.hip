@@ -305,7 +305,8 @@ struct pc_plan {
     DevView<GatherChunk> d_gchunks;
     DevView<uint32_t> d_tile_items;
     bool tile_items_zero = false;
-    DevBuf<uint8_t> d_hist; // uint32 or double
+    DevView<uint8_t> d_hist; // uint32 or double; inside d_tables when short, else d_hist_own
+    DevBuf<uint8_t> d_hist_own;
     DevBuf<uint8_t> d_out;  // int64 or double
     DevView<uint8_t> d_total;
     int last_dtype = -1;
@@ -315,7 +316,7 @@ struct pc_plan {
         DevPool *pl = &eng->pool;
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
-        d_cranges.pool = pl; d_hist.pool = pl; d_out.pool = pl;
+        d_cranges.pool = pl; d_hist_own.pool = pl; d_out.pool = pl;
     }
 };
 
@@ -1044,6 +1045,10 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
                  at_opieces = place(p->opieces.size() * sizeof(OutPiece)), at_cchunks = place(p->cchunks.size() * sizeof(CenterChunk)),
                  at_gsegs = place(p->gsegs.size() * sizeof(GatherSeg)), at_gchunks = place(p->gchunks.size() * sizeof(GatherChunk)),
                  at_items = place((p->tiles.size() + 1) * sizeof(uint32_t)), at_total = place(64);
+    // a short compact histogram rides along, already zeroed (one memset less on the first count)
+    const size_t hist_full = (size_t)p->npos * (size_t)p->rows * sizeof(double);
+    const bool hist_here = hist_full > 0 && hist_full <= 64 * 1024;
+    const size_t at_hist = hist_here ? place(hist_full) : 0;
     int rc = p->d_tables.reserve(bytes);
     if (rc == PC_OK && e->pinned_busy && hipEventSynchronize(e->ev_pinned) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: wait failed");
     if (rc == PC_OK) rc = e->pinned.reserve(bytes);
@@ -1062,6 +1067,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         p->d_gsegs.p = (GatherSeg *)(d + at_gsegs); p->d_gchunks.p = (GatherChunk *)(d + at_gchunks);
         p->d_tile_items.p = (uint32_t *)(d + at_items); p->d_total.p = d + at_total;
         p->tile_items_zero = true;
+        if (hist_here) { p->d_hist.p = d + at_hist; p->hist_kind = 0; p->hist_clean = true; }
         if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: upload failed");
         else if (hipEventRecord(e->ev_pinned, e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: event failed");
         else e->pinned_busy = true;
@@ -1102,7 +1108,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
 
     const size_t hist_elem = center ? sizeof(double) : sizeof(uint32_t);
     const size_t hist_bytes = (size_t)p->npos * p->rows * hist_elem;
-    rc = p->d_hist.reserve(std::max<size_t>((size_t)p->npos * p->rows * sizeof(double), 8));
+    if (!p->d_hist.p) {
+        rc = p->d_hist_own.reserve(std::max<size_t>((size_t)p->npos * p->rows * sizeof(double), 8));
+        p->d_hist.p = p->d_hist_own.p;
+    }
     if (rc == PC_OK) rc = p->d_out.reserve(std::max<size_t>((size_t)p->out_elems * 8, 8));
     if (rc != PC_OK) return rc;
 
@@ -1307,11 +1316,23 @@ int pc_sync(pc_engine *e) {
     return PC_OK;
 }
 
+static constexpr size_t kSmallRead = 256 * 1024;
+
 int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems) {
     if (!e || !p || p->e != e || !p->counted) return fail(PC_ERR_STATE, "pc_read_counts: nothing counted yet");
     if (out_elems != p->out_elems || (out_elems > 0 && !host_out)) return fail(PC_ERR_ARG, "pc_read_counts: buffer size mismatch");
     HIP_TRY(hipSetDevice(e->device));
-    if (out_elems > 0) HIP_TRY(hipMemcpyAsync(host_out, p->d_out.p, (size_t)out_elems * 8, hipMemcpyDeviceToHost, e->stream));
+    const size_t bytes = (size_t)out_elems * 8;
+    if (bytes > 0 && bytes <= kSmallRead && e->pinned.reserve(bytes) == PC_OK) {
+        // short vectors come back through the page-locked buffer (stream order keeps it behind any
+        // plan upload still reading from it): a pageable destination costs an extra staging hop
+        HIP_TRY(hipMemcpyAsync(e->pinned.p, p->d_out.p, bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->pinned_busy = false;
+        memcpy(host_out, e->pinned.p, bytes);
+        return PC_OK;
+    }
+    if (bytes > 0) HIP_TRY(hipMemcpyAsync(host_out, p->d_out.p, bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return PC_OK;
 }
