@@ -1446,7 +1446,7 @@ int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
     // cheap pre-check on the per-length record histogram (ignores filters: conservative)
     bool any = false;
     for (auto *f : e->files) {
-        for (int L = 0; L < 65536 && !any; ++L) {
+        for (int L = f->len_min; L <= f->len_max && !any; ++L) {   // lengths present in the file
             if (!f->len_hist[(size_t)L]) continue;
             bool bad;
             switch (e->kind) {

@@ -18,7 +18,8 @@ STRAND_CODE = {"\x00": 0, "+": 1, "-": 2, ".": 3}  # plastid/genomics/c_common.p
 
 
 def _ptr(a):
-    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    # the address as an int (c_void_p argtypes take it): the caller holds `a` for the (synchronous) call
+    return None if a is None else a.ctypes.data
 
 
 def _c(a, dtype):
@@ -39,6 +40,7 @@ class Engine(object):
         self.kind = None
         self.nfiles = 0
         self.ntid = 0
+        self._state = {}   # last values pushed through the setters (a repeat is not sent again)
 
     def close(self):
         self._finalizer()
@@ -79,22 +81,34 @@ class Engine(object):
             fw = _c(fw, np.int32)
             rc = _c(rc, np.int32)
             n = len(fw)
+            self._state.pop("map", None)
         else:
             fw = rc = None
             n = 0
+            key = (int(kind), int(param))
+            if self._state.get("map") == key:
+                return
         check(self._lib.pc_set_mapping(self._h, int(kind), int(param), _ptr(fw), _ptr(rc), n,
                                        int(min_len), int(max_len)))
         self.kind = int(kind)
         self.rows = self._lib.pc_mapping_rows(self._h)
+        if n == 0:
+            self._state["map"] = key
 
     def set_size_filter(self, min_len=None, max_len=-1):
+        if self._state.get("size") == (min_len, max_len):
+            return
         if min_len is None:
             check(self._lib.pc_set_size_filter(self._h, 0, 0, -1))
         else:
             check(self._lib.pc_set_size_filter(self._h, 1, int(min_len), int(max_len)))
+        self._state["size"] = (min_len, max_len)
 
     def set_normalize(self, enabled, total=1.0):
+        if self._state.get("norm") == (bool(enabled), float(total)):
+            return
         check(self._lib.pc_set_normalize(self._h, 1 if enabled else 0, float(total)))
+        self._state["norm"] = (bool(enabled), float(total))
 
     # ----------------------------------------------------------------- plans
     def plan(self, tid, start, end, strand, out_off, out_step, row_stride, out_elems, rows=None):
