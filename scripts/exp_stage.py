@@ -10,6 +10,9 @@ genome, tx, reads, mapping = synth.make_config(cfg, scale=float(os.environ.get("
 eng = Engine(0)
 for _ in range(2):
     t0 = time.perf_counter()
-    eng.set_alignments([reads])
-    print("set_alignments %.3f s for %d records" % (time.perf_counter() - t0, reads.n), flush=True)
+    eng.clear_alignments()
+    t1 = time.perf_counter()
+    eng.add_alignment_file(reads)
+    t2 = time.perf_counter()
+    print("clear %.3f s, add_alignment_file %.3f s for %d records" % (t1 - t0, t2 - t1, reads.n), flush=True)
 eng.close()
