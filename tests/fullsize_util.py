@@ -79,3 +79,66 @@ def whole_contig_plan(lengths, code):
     return dict(tid=np.arange(len(n), dtype=np.int32), start=np.zeros(len(n), np.int64), end=n.copy(),
                 strand=np.full(len(n), code, np.uint8), out_off=off[:-1].copy(), out_step=np.ones(len(n), np.int8),
                 row_stride=n.copy(), out_elems=int(off[-1]))
+
+
+# ---------------------------------------------------------------- table rules, large genomes
+def offsets_by_length(offset_dict, max_len=65536):
+    """``off[L]`` of a Variable / Stratified offset dict (``'default'`` fills the gaps, -1: none)."""
+    off = np.full(max_len, int(offset_dict.get("default", -1)), np.int64)
+    for k, v in offset_dict.items():
+        if k != "default":
+            off[int(k)] = int(v)
+    return off
+
+
+def mapped_positions_by_table(reads, off_by_len):
+    """Like :func:`mapped_positions` for a per-length 5' offset table (map_factories.pyx:584-600):
+    forward reads map at aligned index ``off[L]``, reverse reads at ``L - 1 - off[L]``."""
+    L = reads.alen.astype(np.int64)
+    o = off_by_len[L]
+    rev = (reads.flags & FLAG_REVERSE) != 0
+    ok = ((reads.flags & FLAG_EXCLUDED) == 0) & (o >= 0) & (o < L)
+    idx = np.where(rev, L - 1 - o, o)
+    pos = reads.pos.astype(np.int64) + idx
+    multi = np.nonzero((reads.nblk >= 2) & ok)[0]
+    if len(multi):
+        off = reads.block_offsets()[multi]
+        left = idx[multi].copy()
+        out = np.full(len(multi), -1, np.int64)
+        for r in range(int(reads.nblk[multi].max())):
+            live = (out < 0) & (reads.nblk[multi] > r)
+            j = off[live] + r
+            blen = reads.blk_len[j].astype(np.int64)
+            here = left[live] < blen
+            li = np.nonzero(live)[0]
+            out[li[here]] = reads.blk_start[j[here]].astype(np.int64) + left[li[here]]
+            left[li[~here]] -= blen[~here]
+        pos[multi] = out
+    return pos, ok
+
+
+def sparse_chain_vectors(tx, reads, pos, sel):
+    """Flat ``get_counts`` layout (rows = 1) of every chain of `tx`, from the mapped positions of the
+    records in boolean `sel`: a sorted (contig, position, strand) key table is sliced per exon, so
+    no dense genome-sized vector is ever built (human-scale genomes)."""
+    clen = np.asarray(reads.lengths, np.int64)
+    base = np.zeros(len(clen) + 1, np.int64)
+    np.cumsum(clen, out=base[1:])
+    span = int(base[-1])
+    rev = (reads.flags & FLAG_REVERSE) != 0
+    inside = sel & (pos >= 0) & (pos < clen[reads.tid])
+    keys = np.where(rev[inside], span, 0) + base[reads.tid[inside]] + pos[inside]
+    ukeys, cnt = np.unique(keys, return_counts=True)
+    # exon table in chain order
+    ex_tx = tx.ex_tx
+    sbase = np.where(tx.strand[ex_tx] == 2, span, 0) + base[tx.tid[ex_tx]]
+    lo = np.searchsorted(ukeys, sbase + tx.ex_start)
+    hi = np.searchsorted(ukeys, sbase + tx.ex_end)
+    p = tx.plan_arrays(rows=1)
+    flat = np.zeros(p["out_elems"], np.int64)
+    n = hi - lo
+    ex_of = np.repeat(np.arange(len(lo)), n)
+    k = np.arange(int(n.sum())) - np.repeat(np.cumsum(n) - n, n) + np.repeat(lo, n)
+    rel = ukeys[k] - (sbase + tx.ex_start)[ex_of]
+    flat[p["out_off"][ex_of] + p["out_step"][ex_of].astype(np.int64) * rel] = cnt[k]
+    return flat

@@ -143,3 +143,80 @@ def test_full_size_center_rule_properties():
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), "center sums differ from the oracle in some bit"
     plan.close()
     eng.close()
+
+
+def _scatter(p, arrays, rows=1):
+    want = np.zeros(p["out_elems"] * rows, np.int64)
+    for s, a in enumerate(arrays):
+        a = a.reshape(rows, -1)
+        o, st, rs = int(p["out_off"][s]), int(p["out_step"][s]), int(p["row_stride"][s])
+        for r in range(rows):
+            want[o + r * rs + st * np.arange(a.shape[1])] = a[r]
+    return want
+
+
+def test_sparse_table_expectation_matches_oracle():
+    """Variable and Stratified rules: the sparse numpy expectation vs the oracle at oracle size."""
+    from oracle import oracle
+    genome, tx, reads, mapping = synth.make_config("C5", scale=0.0002, tx_scale=0.005)
+    aln = concat_file_major([reads])
+    off = fu.offsets_by_length(mapping[1])
+    pos, ok = fu.mapped_positions_by_table(reads, off)
+    p = tx.plan_arrays(rows=1)
+    arrays, _ = oracle.count_segments(aln, oracle.mapping_spec("variable", 0, mapping[1]), p["tid"], p["start"], p["end"], p["strand"])
+    assert np.array_equal(fu.sparse_chain_vectors(tx, reads, pos, ok), _scatter(p, arrays))
+    # stratified: row L - min_len holds the reads of aligned length L, mapped with the same table
+    lo, hi = mapping[2], mapping[3]
+    rows = hi - lo + 1
+    pr = tx.plan_arrays(rows=rows)
+    arrays, _ = oracle.count_segments(aln, oracle.mapping_spec("stratified", 0, mapping[1], lo, hi), pr["tid"], pr["start"], pr["end"], pr["strand"])
+    want = _scatter(pr, arrays, rows)
+    L = reads.alen.astype(np.int64)
+    base = pr["chain_base"]
+    for r in range(rows):
+        flat = fu.sparse_chain_vectors(tx, reads, pos, ok & (L == lo + r))
+        got_r = np.concatenate([want[base[c] + r * tx.length[c]: base[c] + (r + 1) * tx.length[c]] for c in range(tx.n)])
+        assert np.array_equal(flat, got_r), r
+
+
+@pytest.mark.gpu
+def test_large_table_rule_properties():
+    """C4 / C5 at a per-GPU share of the 8-GPU BASELINE sizes (62.5 M reads, Variable; 31 M mate
+    records, Stratified): engine vs the sparse numpy expectation, every chain, every row."""
+    from plastid_amd.engine import Engine
+    scale = float(os.environ.get("PC_FULLSIZE_SCALE", "1.0"))
+    eng = Engine(0)
+    # ---- C4: VariableFivePrimeMapFactory
+    genome, tx, reads, mapping = synth.make_config("C4", scale=0.125 * scale, tx_scale=0.25)
+    off = fu.offsets_by_length(mapping[1])
+    pos, ok = fu.mapped_positions_by_table(reads, off)
+    eng.set_alignments([reads])
+    synth.mapping_factory(mapping)._configure(eng)
+    p = tx.plan_arrays(rows=1)
+    plan = _plan(eng, p)
+    got = plan.count(np.int64)
+    assert np.array_equal(got, fu.sparse_chain_vectors(tx, reads, pos, ok)), "variable-offset chain vectors differ"
+    assert np.array_equal(plan.count(np.int64), got)
+    plan.close()
+    # ---- C5: StratifiedVariableFivePrimeMapFactory, rows = read lengths
+    genome, tx, reads, mapping = synth.make_config("C5", scale=0.03125 * scale, tx_scale=0.05)
+    lo, hi = mapping[2], mapping[3]
+    rows = hi - lo + 1
+    pos, ok = fu.mapped_positions_by_table(reads, fu.offsets_by_length(mapping[1]))
+    eng.set_alignments([reads])
+    synth.mapping_factory(mapping)._configure(eng)
+    pr = tx.plan_arrays(rows=rows)
+    plan = eng.plan(pr["tid"], pr["start"], pr["end"], pr["strand"], pr["out_off"], pr["out_step"], pr["row_stride"],
+                    pr["out_elems"], rows)
+    got = plan.count(np.int64)
+    per_chain = tx.split_counts(got, rows)
+    L = reads.alen.astype(np.int64)
+    total = 0
+    for r in range(rows):
+        want = fu.sparse_chain_vectors(tx, reads, pos, ok & (L == lo + r))
+        have = np.concatenate([m[r] for m in per_chain])
+        assert np.array_equal(have, want), "stratified row %d (length %d) differs" % (r, lo + r)
+        total += int(want.sum())
+    assert int(plan.total()) == total
+    plan.close()
+    eng.close()
