@@ -167,3 +167,46 @@ def test_corrupt_bam_is_rejected_not_crashed(tmp_path):
         except (ValueError, MalformedFileError, OSError):
             outcomes["rejected"] += 1
     assert outcomes["rejected"] > 30 and outcomes["ok"] + outcomes["rejected"] == 150
+
+
+@pytest.mark.parametrize("piece", [1, 2, 7])
+def test_piecewise_decoding_is_the_serial_walk(tmp_path, monkeypatch, piece):
+    """The reader decodes pieces of the record stream in parallel and stitches them; with tiny
+    pieces (PB_PIECE) every cross-piece check is exercised: same arrays as one piece, and the same
+    verdict on files whose defect sits on a piece boundary."""
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00002, tx_scale=0.001)
+    recs = bam_writer.packed_to_records(reads)
+    refs, lens = list(reads.references), list(reads.lengths)
+    path = str(tmp_path / "p.bam")
+    bam_writer.write_bam(path, refs, lens, recs, block_bytes=900)
+    whole = read_bam(path, threads=1)
+    monkeypatch.setenv("PB_PIECE", str(piece))
+    for th in (1, 3):
+        got = read_bam(path, threads=th)
+        for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
+            assert np.array_equal(getattr(got, name), getattr(whole, name)), name
+        assert got.mapped == whole.mapped
+    # defects at every position of a short file: disorder, a placed record after an unplaced one,
+    # a leading deletion that breaks the order of the first aligned positions
+    base = [(0, 100 + 10 * i, [(0, 30)], 0) for i in range(9)]
+    for i in range(1, 9):
+        bad = list(base)
+        bad[i] = (0, 5, [(0, 30)], 0)
+        bam_writer.write_bam(path, ["c"], [5000], bad)
+        with pytest.raises(ValueError, match="sorted"):
+            read_bam(path, threads=2)
+        bad = list(base)
+        bad[i - 1] = (-1, -1, [], 4)
+        bam_writer.write_bam(path, ["c"], [5000], bad)
+        with pytest.raises(ValueError, match="sorted"):
+            read_bam(path, threads=2)
+        bad = list(base)
+        bad[i - 1] = (0, bad[i][1] - 2, [(2, 1), (0, 30)], 0) if i > 1 else bad[i - 1]   # D first: spos = pos + 1
+        bad[i - 1] = (0, bad[i][1] - 1, [(2, 5), (0, 30)], 0)                             # starts after record i
+        bam_writer.write_bam(path, ["c"], [5000], bad)
+        with pytest.raises(ValueError, match="deletion|sorted"):
+            read_bam(path, threads=2)
+    # unplaced reads at the end are fine
+    bam_writer.write_bam(path, ["c"], [5000], base + [(-1, -1, [], 4)] * 3)
+    ok = read_bam(path, threads=2)
+    assert ok.n == 9 and ok.mapped == 9
