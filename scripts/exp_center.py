@@ -12,6 +12,7 @@ for sigma in [float(x) for x in os.environ.get("SIGMAS", "1.5,0.0").split(",")]:
     synth.mapping_factory(("center", 0))._configure(eng)
     p = tx.plan_arrays(rows=1)
     plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    eng.set_profiling(2)
     plan.launch(np.float64); eng.sync()
     acc = {}
     for _ in range(3):
