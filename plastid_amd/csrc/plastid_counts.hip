@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <future>
 #include <mutex>
 #include <sys/mman.h>
 #include <thread>
@@ -164,7 +165,6 @@ template <typename T> struct HostBuf {
     }
     explicit HostBuf(size_t count) : p(grab(count)), n(count) {}
     ~HostBuf() { free(p); }
-    T *detach() { T *q = p; p = nullptr; n = 0; return q; }
     HostBuf(const HostBuf &) = delete;
     HostBuf &operator=(const HostBuf &) = delete;
     T &operator[](size_t i) { return p[i]; }
@@ -264,12 +264,6 @@ struct pc_engine {
     int prof_level = 0;      // pc_set_profiling: 0 no events, 1 whole call + histogram/center kernel, 2 every phase
     int timed_level = 0;     // level the last pc_count was recorded with
     int64_t last_alg_bytes = 0;
-
-    std::thread reaper;   // frees the host staging buffers of the last pc_add_alignment_file
-    void reap(std::vector<void *> dead) {
-        if (reaper.joinable()) reaper.join();
-        reaper = std::thread([dead]() { for (void *q : dead) free(q); });
-    }
 
     MapParams params() const {
         MapParams mp;
@@ -427,7 +421,6 @@ int pc_destroy(pc_engine *e) {
     if (!e) return PC_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->reaper.joinable()) e->reaper.join();
     for (auto *f : e->files) delete f;
     e->files.clear();
     for (auto &ev : e->ev)
@@ -498,11 +491,6 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     };
     std::vector<Chunk1> c1((size_t)T);
     std::vector<int64_t> tid_bounds((size_t)ntid + 1, 0);
-    HostBuf<uint2> rec((size_t)n + 2);
-    HostBuf<uint32_t> blk_off(nrun > 0 ? (size_t)n : 0);
-    HostBuf<int32_t> span((size_t)n);
-    if (!rec.p || !blk_off.p || !span.p) return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
-    rec[(size_t)n] = rec[(size_t)n + 1] = make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16);
     // runs owned by each chunk (records with >= 2 runs keep theirs in blk_*), so that a chunk knows
     // where its first run sits
     parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
@@ -517,6 +505,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             return fail(PC_ERR_ARG, cur > nrun ? "run arrays shorter than sum of nblk" : "run arrays longer than sum of nblk (%lld vs %lld)",
                         (long long)cur, (long long)nrun);
     }
+    // pass A keeps nothing per record: it validates and gathers the statistics that decide the halo
     parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
         Chunk1 &c = c1[(size_t)t];
         c.tid_count.assign((size_t)ntid + 1, 0);
@@ -538,7 +527,6 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             const int L = alen[i];
             int64_t end;
             if (nblk[i] >= 2) {
-                blk_off[(size_t)i] = (uint32_t)run_cursor;
                 int64_t sum = 0, prev_end = -1;
                 for (int k = 0; k < nblk[i]; ++k) {
                     const int64_t s0 = blk_start[run_cursor + k], ln = blk_len[run_cursor + k];
@@ -554,17 +542,13 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 end = prev_end;
                 run_cursor += nblk[i];
             } else {
-                if (nrun > 0) blk_off[(size_t)i] = 0u;
                 if ((nblk[i] == 0) != (L == 0)) { bad(i, PC_ERR_ARG, "record %lld: nblk/alen mismatch", i, 0); return; }
                 end = (int64_t)pos[i] + (L > 0 ? L : 1);
             }
             if (end > 0x7fffffffLL) { bad(i, PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", i, 0); return; }
             const int64_t sp = end - pos[i];
-            span[(size_t)i] = (int32_t)sp;
             c.span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
             c.len_hist[(size_t)L] += 1;
-            rec[(size_t)i] = make_uint2((uint32_t)pos[i], (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) |
-                                                              ((uint32_t)nblk[i] << 24));
         }
     });
     std::vector<int64_t> span_hist(1026, 0), len_hist(65536, 0);
@@ -580,7 +564,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             for (size_t k = 0; k < len_hist.size(); ++k) len_hist[k] += c.len_hist[k];
         }
     }
-    clk.lap("validate + pack");
+    clk.lap("validate + statistics");
     for (int t = 0; t < ntid; ++t) tid_bounds[(size_t)t + 1] += tid_bounds[(size_t)t];
 
     // ---- choose the window halo W: the smallest span bound (>= 64, <= 1024) that covers
@@ -602,39 +586,131 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     sf->len_hist.swap(len_hist);
     for (int L = 0; L < 65536; ++L)
         if (sf->len_hist[(size_t)L]) { sf->len_min = std::min(sf->len_min, L); sf->len_max = std::max(sf->len_max, L); }
-    // ---- side lists (long-span and gapped / over-long records, both rare), the long flag, and
-    // the 4-byte record stream: per chunk, then concatenated in chunk order
-    struct Chunk2 {
-        std::vector<uint32_t> long_idx;
-        std::vector<uint4> gap_rec;
+
+    // ---- pass B: packed records (8 B), record stream (4 B), run offsets and the side lists, produced
+    // slice by slice into two sets of reusable host buffers; a slice crosses PCIe (on a thread of
+    // its own) while the next one is packed, so the host never holds more than two slices and there
+    // is no per-record scratch to fault in or to give back.
+    int64_t S = (int64_t)8 << 20;
+    if (const char *env = getenv("PC_STAGE_SLICE")) S = std::max<int64_t>(1, atoll(env)); // test knob: tiny slices
+    const int64_t nslices = (n + S - 1) / S;
+    struct Unit { // one thread's share of one slice
+        std::vector<uint4> long_rec, gap_rec;
+        std::vector<int32_t> long_span;
         int W = 1, smin = 65536, smax = -1;
-        int64_t max_span = 1;
+        int64_t max_span = 1, cursor = 0;
     };
-    std::vector<Chunk2> c2((size_t)T);
-    HostBuf<uint32_t> stream((size_t)n + 8);
-    if (!stream.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
-    for (int k = 0; k < 8; ++k) stream[(size_t)n + k] = kStreamSkip; // pad: whole quads can always be loaded
-    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
-        Chunk2 &c = c2[(size_t)t];
-        for (int64_t i = b; i < en; ++i) {
-            const int32_t sp = span[(size_t)i];
-            c.max_span = std::max<int64_t>(c.max_span, sp);
-            if (sp > wcap) {
-                rec[(size_t)i].y |= (kFlagLong << 16);
-                c.long_idx.push_back((uint32_t)i);
-            } else {
-                c.W = std::max(c.W, (int)sp);
-                if (nblk[i] >= 2 || alen[i] > kStreamMaxLen) // binned from the side list, not from the stream
-                    c.gap_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, nblk[i] >= 2 ? blk_off[(size_t)i] : 0u, (uint32_t)i));
+    std::vector<Unit> units((size_t)(nslices * T));
+    auto unit_range = [&](int64_t sl, int t, int64_t &b, int64_t &en) {
+        const int64_t s0 = sl * S, s1 = std::min(n, s0 + S), q = (s1 - s0 + T - 1) / T;
+        b = std::min(s1, s0 + (int64_t)t * q);
+        en = std::min(s1, b + q);
+    };
+    if (nrun > 0) { // where every unit's first run sits
+        parallel_chunks(nslices * T, T, [&](int, int64_t ub, int64_t ue) {
+            for (int64_t u = ub; u < ue; ++u) {
+                int64_t b, en, r = 0;
+                unit_range(u / T, (int)(u % T), b, en);
+                for (int64_t i = b; i < en; ++i) r += nblk[i] >= 2 ? nblk[i] : 0;
+                units[(size_t)u].cursor = r;
             }
-            const uint32_t wd = stream_word(rec[(size_t)i].x, rec[(size_t)i].y & ~((uint32_t)kFlagExcluded << 16));
-            if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
-                const int L = (int)stream_len(wd);
-                c.smin = std::min(c.smin, L); c.smax = std::max(c.smax, L);
+        });
+        int64_t cur = 0;
+        for (auto &u : units) { const int64_t r = u.cursor; u.cursor = cur; cur += r; }
+    }
+    int rc = sf->rec.reserve((size_t)n + 2);
+    if (rc == PC_OK) rc = sf->stream.reserve((size_t)n + 8);
+    if (rc == PC_OK && nrun > 0) rc = sf->blk_off.reserve((size_t)n);
+    if (rc != PC_OK) { delete sf; return rc; }
+    struct SliceBuf {
+        HostBuf<uint2> rec;
+        HostBuf<uint32_t> stream, boff;
+        std::future<int> up;
+        SliceBuf(size_t cap, bool runs) : rec(cap), stream(cap), boff(runs ? cap : 0) {}
+    };
+    const size_t slice_cap = (size_t)std::min<int64_t>(S, std::max<int64_t>(n, 1));
+    SliceBuf bufs[2] = {SliceBuf(slice_cap, nrun > 0), SliceBuf(nslices > 1 ? slice_cap : 1, nrun > 0)};
+    if (!bufs[0].rec.p || !bufs[0].stream.p || !bufs[1].rec.p || !bufs[1].stream.p || (nrun > 0 && (!bufs[0].boff.p || !bufs[1].boff.p))) {
+        delete sf;
+        return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
+    }
+    const int device = e->device;
+    hipStream_t up_stream = e->stream;
+    for (int64_t sl = 0; sl < nslices && rc == PC_OK; ++sl) {
+        SliceBuf &sb = bufs[sl & 1];
+        if (sb.up.valid()) rc = sb.up.get();               // the slice that used these buffers has gone up
+        if (rc != PC_OK) break;
+        const int64_t s0 = sl * S, s1 = std::min(n, s0 + S);
+        parallel_chunks((int64_t)T, T, [&](int, int64_t tb, int64_t te) {
+            for (int64_t t = tb; t < te; ++t) {
+                Unit &c = units[(size_t)(sl * T + t)];
+                int64_t b, en;
+                unit_range(sl, (int)t, b, en);
+                int64_t cursor = c.cursor;
+                for (int64_t i = b; i < en; ++i) {
+                    const int L = alen[i], nb = nblk[i];
+                    uint32_t boff = 0u;
+                    int64_t end;
+                    if (nb >= 2) {
+                        boff = (uint32_t)cursor;
+                        end = (int64_t)blk_start[cursor + nb - 1] + blk_len[cursor + nb - 1];
+                        cursor += nb;
+                    } else {
+                        end = (int64_t)pos[i] + (L > 0 ? L : 1);
+                    }
+                    const int32_t sp = (int32_t)(end - pos[i]);
+                    uint32_t meta = (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) | ((uint32_t)nb << 24);
+                    c.max_span = std::max<int64_t>(c.max_span, sp);
+                    if (sp > wcap) {
+                        meta |= (kFlagLong << 16);
+                        c.long_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
+                        c.long_span.push_back(sp);
+                    } else {
+                        c.W = std::max(c.W, (int)sp);
+                        if (nb >= 2 || L > kStreamMaxLen) // binned from the side list, not from the stream
+                            c.gap_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
+                    }
+                    const uint32_t wd = stream_word((uint32_t)pos[i], meta & ~((uint32_t)kFlagExcluded << 16));
+                    if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
+                        const int Ls = (int)stream_len(wd);
+                        c.smin = std::min(c.smin, Ls); c.smax = std::max(c.smax, Ls);
+                    }
+                    const size_t j = (size_t)(i - s0);
+                    sb.rec[j] = make_uint2((uint32_t)pos[i], meta);
+                    sb.stream[j] = stream_word((uint32_t)pos[i], meta);
+                    if (nrun > 0) sb.boff[j] = boff;
+                }
             }
-            stream[(size_t)i] = stream_word(rec[(size_t)i].x, rec[(size_t)i].y);
+        });
+        uint2 *d_rec = sf->rec.p + s0;
+        uint32_t *d_stream = sf->stream.p + s0, *d_boff = nrun > 0 ? sf->blk_off.p + s0 : nullptr;
+        const uint2 *h_rec = sb.rec.p;
+        const uint32_t *h_stream = sb.stream.p, *h_boff = sb.boff.p;
+        const size_t cnt = (size_t)(s1 - s0);
+        sb.up = std::async(std::launch::async, [=]() -> int {
+            if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
+            if (hipMemcpyAsync(d_rec, h_rec, cnt * sizeof(uint2), hipMemcpyHostToDevice, up_stream) != hipSuccess) return PC_ERR_HIP;
+            if (hipMemcpyAsync(d_stream, h_stream, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, up_stream) != hipSuccess) return PC_ERR_HIP;
+            if (d_boff && hipMemcpyAsync(d_boff, h_boff, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, up_stream) != hipSuccess) return PC_ERR_HIP;
+            return hipStreamSynchronize(up_stream) == hipSuccess ? PC_OK : PC_ERR_HIP;
+        });
+    }
+    for (auto &sb : bufs)
+        if (sb.up.valid()) { const int r = sb.up.get(); if (rc == PC_OK) rc = r; }
+    if (rc != PC_OK) { delete sf; return fail(rc, "pc_add_alignment_file: staging a slice failed"); }
+    {   // sentinels behind the last record: two excluded headers, eight skip words (whole quads can always be loaded)
+        const uint2 tail_rec[2] = {make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16), make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16)};
+        uint32_t tail_stream[8];
+        for (int k = 0; k < 8; ++k) tail_stream[k] = kStreamSkip;
+        if (hipMemcpyAsync(sf->rec.p + n, tail_rec, sizeof(tail_rec), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipMemcpyAsync(sf->stream.p + n, tail_stream, sizeof(tail_stream), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess) {
+            delete sf;
+            return fail(PC_ERR_HIP, "pc_add_alignment_file: staging the sentinels failed");
         }
-    });
+    }
+    clk.lap("pack + upload (pipelined)");
+    // side lists in record order (slice-major, then thread order inside a slice)
     std::vector<uint32_t> long_idx;
     std::vector<uint4> long_rec;
     std::vector<int32_t> long_tid, long_pmax;
@@ -645,32 +721,46 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     int64_t max_span = 1;
     {
         int smin = 65536, smax = -1;
-        for (const auto &c : c2) {
+        std::vector<int32_t> long_span;
+        size_t nl = 0, ng = 0;
+        for (const auto &c : units) { nl += c.long_rec.size(); ng += c.gap_rec.size(); }
+        long_rec.reserve(nl); long_span.reserve(nl); gap_rec.reserve(ng);
+        for (const auto &c : units) {
             W = std::max(W, c.W);
             max_span = std::max(max_span, c.max_span);
             smin = std::min(smin, c.smin); smax = std::max(smax, c.smax);
-            long_idx.insert(long_idx.end(), c.long_idx.begin(), c.long_idx.end());
+            long_rec.insert(long_rec.end(), c.long_rec.begin(), c.long_rec.end());
+            long_span.insert(long_span.end(), c.long_span.begin(), c.long_span.end());
             gap_rec.insert(gap_rec.end(), c.gap_rec.begin(), c.gap_rec.end());
         }
         sf->slen_min = smax >= smin ? smin : 0;
         sf->slen_max = smax >= smin ? smax : 0;
-        int cur_tid = -1;
+        // (the contig of a list entry comes from tid_bounds, walked along with the list: the lists
+        // are in record order, and a look-up in the caller's tid[] would miss the cache every time)
+        int cur_tid = -1, t_of = 0;
         int32_t pm = 0;
-        for (const uint32_t i : long_idx) { // running maximum of the ends, per contig
-            if (tid[i] != cur_tid) { cur_tid = tid[i]; pm = 0; }
-            pm = std::max(pm, pos[i] + span[(size_t)i]);
-            long_rec.push_back(make_uint4(rec[(size_t)i].x, rec[(size_t)i].y, nblk[i] >= 2 ? blk_off[(size_t)i] : 0u, i));
-            long_tid.push_back(tid[i]);
+        long_idx.reserve(long_rec.size()); long_tid.reserve(long_rec.size()); long_pmax.reserve(long_rec.size());
+        for (size_t k = 0; k < long_rec.size(); ++k) { // running maximum of the ends, per contig
+            const uint32_t i = long_rec[k].w;
+            while ((int64_t)i >= tid_bounds[(size_t)t_of + 1]) ++t_of;
+            if (t_of != cur_tid) { cur_tid = t_of; pm = 0; }
+            pm = std::max(pm, (int32_t)long_rec[k].x + long_span[k]);
+            long_idx.push_back(i);
+            long_tid.push_back(t_of);
             long_pmax.push_back(pm);
-            long_bounds[(size_t)tid[i] + 1] += 1;
+            long_bounds[(size_t)t_of + 1] += 1;
         }
-        for (const uint4 &g : gap_rec) gap_bounds[(size_t)tid[g.w] + 1] += 1;
+        t_of = 0;
+        for (const uint4 &g : gap_rec) {
+            while ((int64_t)g.w >= tid_bounds[(size_t)t_of + 1]) ++t_of;
+            gap_bounds[(size_t)t_of + 1] += 1;
+        }
         for (int t = 0; t < ntid; ++t) long_bounds[(size_t)t + 1] += long_bounds[(size_t)t];
         for (int t = 0; t < ntid; ++t) gap_bounds[(size_t)t + 1] += gap_bounds[(size_t)t];
     }
     sf->W = W;
     sf->max_span = max_span;
-    clk.lap("side lists + record stream");
+    clk.lap("side lists");
     sf->nlong = (int64_t)long_idx.size();
     sf->ngap = (int64_t)gap_rec.size();
     // the first two aligned runs of every side-list record, next to its header: the kernels then
@@ -678,10 +768,9 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     auto first_runs = [&](const std::vector<uint4> &list) {
         std::vector<int4> out(list.size());
         for (size_t k = 0; k < list.size(); ++k) {
-            const uint4 &g = list[k];
-            const uint32_t i = g.w;
-            if (nblk[i] >= 2) out[k] = make_int4(blk_start[g.z], blk_len[g.z], blk_start[g.z + 1], blk_len[g.z + 1]);
-            else out[k] = make_int4(pos[i], (int)alen[i], 0, 0);
+            const uint4 &g = list[k];                       // {pos, aligned length | flags << 16 | runs << 24, first run, record}
+            if ((g.y >> 24) >= 2u) out[k] = make_int4(blk_start[g.z], blk_len[g.z], blk_start[g.z + 1], blk_len[g.z + 1]);
+            else out[k] = make_int4((int32_t)g.x, (int)(g.y & 0xffffu), 0, 0);
         }
         return out;
     };
@@ -699,47 +788,48 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         const int64_t nb = last >= 0 ? (last >> kLinShift) + 1 : 0;
         lin_off[(size_t)t + 1] = lin_off[(size_t)t] + nb + 1;
     }
-    std::vector<uint32_t> lin_tab((size_t)lin_off[(size_t)ntid]), glin_tab((size_t)lin_off[(size_t)ntid]);
-    std::vector<uint32_t> llin_tab((size_t)lin_off[(size_t)ntid]), plin_tab((size_t)lin_off[(size_t)ntid]);
-    for (int t = 0; t < ntid; ++t) {
-        const int64_t l0 = lin_off[(size_t)t], nb = lin_off[(size_t)t + 1] - l0 - 1;
-        {
-            const int64_t b = tid_bounds[(size_t)t], en = tid_bounds[(size_t)t + 1];
-            int64_t i = b;
-            for (int64_t k = 0; k <= nb; ++k) {
+    // (not value-initialised: a human-scale genome has 2.4e7 buckets per table, and the threads that
+    // fill them are the first to touch their part)
+    const size_t nlin = (size_t)lin_off[(size_t)ntid];
+    HostBuf<uint32_t> lin_tab(nlin), glin_tab(nlin), llin_tab(nlin), plin_tab(nlin);
+    if (!lin_tab.p || !glin_tab.p || !llin_tab.p || !plin_tab.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
+    // every table entry is "first list index whose key is not before the bucket edge": the entries are
+    // dealt to the threads in contiguous ranges; a thread finds its first index by bisection and
+    // walks on from there (the keys are monotone inside a contig)
+    auto fill_lin = [&](HostBuf<uint32_t> &tab, const std::vector<int64_t> &bounds, auto before) {
+        parallel_chunks(lin_off[(size_t)ntid], T, [&](int, int64_t g0, int64_t g1) {
+            if (g0 >= g1) return;
+            int t = (int)(std::upper_bound(lin_off.begin(), lin_off.end(), g0) - lin_off.begin()) - 1;
+            int64_t i = -1;
+            for (int64_t g = g0; g < g1; ++g) {
+                while (g >= lin_off[(size_t)t + 1]) { ++t; i = -1; }
+                const int64_t l0 = lin_off[(size_t)t], nb = lin_off[(size_t)t + 1] - l0 - 1, k = g - l0;
+                const int64_t b = bounds[(size_t)t], en = bounds[(size_t)t + 1];
+                if (k >= nb) { tab[(size_t)g] = (uint32_t)en; continue; }
                 const int64_t edge = k << kLinShift;
-                while (i < en && k < nb && (int64_t)pos[i] < edge) ++i;
-                lin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? i : en);
+                if (i < 0) {
+                    int64_t lo = b, hi = en;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (before(mid, edge)) lo = mid + 1; else hi = mid;
+                    }
+                    i = lo;
+                } else {
+                    while (i < en && before(i, edge)) ++i;
+                }
+                tab[(size_t)g] = (uint32_t)i;
             }
-        }
-        {
-            const int64_t b = gap_bounds[(size_t)t], en = gap_bounds[(size_t)t + 1];
-            int64_t i = b;
-            for (int64_t k = 0; k <= nb; ++k) {
-                const int64_t edge = k << kLinShift;
-                while (i < en && k < nb && (int64_t)(int32_t)gap_rec[(size_t)i].x < edge) ++i;
-                glin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? i : en);
-            }
-        }
-        {   // long-span list: by start, and by running maximum end (both monotone)
-            const int64_t b = long_bounds[(size_t)t], en = long_bounds[(size_t)t + 1];
-            int64_t i = b, j = b;
-            for (int64_t k = 0; k <= nb; ++k) {
-                const int64_t edge = k << kLinShift;
-                while (i < en && k < nb && (int64_t)(int32_t)long_rec[(size_t)i].x < edge) ++i;
-                while (j < en && k < nb && (int64_t)long_pmax[(size_t)j] <= edge) ++j;
-                llin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? i : en);
-                plin_tab[(size_t)(l0 + k)] = (uint32_t)(k < nb ? j : en);
-            }
-        }
-    }
+        });
+    };
+    fill_lin(lin_tab, tid_bounds, [&](int64_t i, int64_t edge) { return (int64_t)pos[i] < edge; });
+    fill_lin(glin_tab, gap_bounds, [&](int64_t i, int64_t edge) { return (int64_t)(int32_t)gap_rec[(size_t)i].x < edge; });
+    // long-span list: by start, and by running maximum end (both monotone)
+    fill_lin(llin_tab, long_bounds, [&](int64_t i, int64_t edge) { return (int64_t)(int32_t)long_rec[(size_t)i].x < edge; });
+    fill_lin(plin_tab, long_bounds, [&](int64_t i, int64_t edge) { return (int64_t)long_pmax[(size_t)i] <= edge; });
 
     clk.lap("linear index");
     // ---- bulk stage to HBM
-    int rc = sf->rec.upload(rec.p, rec.n, e->stream);
-    if (rc == PC_OK) rc = sf->stream.upload(stream.p, stream.n, e->stream);
     if (rc == PC_OK && nrun > 0) {
-        rc = sf->blk_off.upload(blk_off.p, blk_off.n, e->stream);
         std::vector<int2> blk((size_t)nrun);
         for (int64_t j = 0; j < nrun; ++j) blk[(size_t)j] = make_int2(blk_start[j], blk_len[j]);
         if (rc == PC_OK) rc = sf->blk.upload(blk, e->stream);
@@ -755,20 +845,17 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc == PC_OK) rc = sf->gap_runs.upload(gap_runs, e->stream);
     if (rc == PC_OK) rc = sf->long_runs.upload(long_runs, e->stream);
     if (rc == PC_OK) rc = sf->gap_tid_bounds.upload(gap_bounds, e->stream);
-    if (rc == PC_OK) rc = sf->lin_tab.upload(lin_tab, e->stream);
-    if (rc == PC_OK) rc = sf->glin_tab.upload(glin_tab, e->stream);
-    if (rc == PC_OK) rc = sf->llin_tab.upload(llin_tab, e->stream);
-    if (rc == PC_OK) rc = sf->plin_tab.upload(plin_tab, e->stream);
+    if (rc == PC_OK) rc = sf->lin_tab.upload(lin_tab.p, nlin, e->stream);
+    if (rc == PC_OK) rc = sf->glin_tab.upload(glin_tab.p, nlin, e->stream);
+    if (rc == PC_OK) rc = sf->llin_tab.upload(llin_tab.p, nlin, e->stream);
+    if (rc == PC_OK) rc = sf->plin_tab.upload(plin_tab.p, nlin, e->stream);
     if (rc == PC_OK) rc = sf->lin_off.upload(lin_off, e->stream);
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
     if (rc != PC_OK) {
         delete sf;
         return rc;
     }
-    clk.lap("upload");
-    // Giving ~16 bytes per record back to the OS takes as long as the upload: it happens beside
-    // the caller, on a thread the engine joins before the next staging pass and at shutdown.
-    if (n >= ((int64_t)1 << 22)) e->reap({rec.detach(), span.detach(), stream.detach(), blk_off.detach()});
+    clk.lap("upload of the side tables");
     e->files.push_back(sf);
     e->ntid = ntid;
     e->files_dirty = true;

@@ -365,15 +365,20 @@ def test_threaded_staging_is_deterministic(pa, monkeypatch):
     genome, tx, reads, _ = synth.make_config("C4", scale=0.005, tx_scale=0.01)      # 2.5 M reads, spliced
     p = tx.plan_arrays(rows=1)
     outs = []
-    for threads in ("1", "5"):
+    for threads, slice_records in (("1", None), ("5", None), ("5", "300000"), ("2", "77777")):
         monkeypatch.setenv("PC_STAGE_THREADS", threads)
+        if slice_records is None:
+            monkeypatch.delenv("PC_STAGE_SLICE", raising=False)
+        else:
+            monkeypatch.setenv("PC_STAGE_SLICE", slice_records)    # several slices through the two host buffers
         eng = engine_for(pa, [reads], ("threeprime", 3))
         plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"],
                         p["out_elems"], 1)
         outs.append(plan.count(np.int64))
         plan.close()
         eng.close()
-    assert np.array_equal(outs[0], outs[1]) and outs[0].sum() > 0
+    assert all(np.array_equal(outs[0], o) for o in outs[1:]) and outs[0].sum() > 0
+    monkeypatch.delenv("PC_STAGE_SLICE", raising=False)
     # two defects in different thread chunks: the one with the lower record index is reported
     bad_pos = reads.pos.copy()
     i_lo, i_hi = reads.n // 3, (2 * reads.n) // 3
