@@ -710,49 +710,76 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         }
     }
     clk.lap("pack + upload (pipelined)");
-    // side lists in record order (slice-major, then thread order inside a slice)
-    std::vector<uint32_t> long_idx;
-    std::vector<uint4> long_rec;
-    std::vector<int32_t> long_tid, long_pmax;
-    std::vector<int64_t> long_bounds((size_t)ntid + 1, 0);
-    std::vector<uint4> gap_rec;
-    std::vector<int64_t> gap_bounds((size_t)ntid + 1, 0);
+    // side lists in record order (slice-major, then thread order inside a slice): every unit copies
+    // its entries to their final place; only the running maximum of the ends is a serial walk
+    std::vector<int64_t> long_bounds((size_t)ntid + 1, 0), gap_bounds((size_t)ntid + 1, 0);
     int W = 1;
     int64_t max_span = 1;
+    std::vector<size_t> lo_of(units.size() + 1, 0), go_of(units.size() + 1, 0);
     {
         int smin = 65536, smax = -1;
-        std::vector<int32_t> long_span;
-        size_t nl = 0, ng = 0;
-        for (const auto &c : units) { nl += c.long_rec.size(); ng += c.gap_rec.size(); }
-        long_rec.reserve(nl); long_span.reserve(nl); gap_rec.reserve(ng);
-        for (const auto &c : units) {
+        for (size_t u = 0; u < units.size(); ++u) {
+            const Unit &c = units[u];
             W = std::max(W, c.W);
             max_span = std::max(max_span, c.max_span);
             smin = std::min(smin, c.smin); smax = std::max(smax, c.smax);
-            long_rec.insert(long_rec.end(), c.long_rec.begin(), c.long_rec.end());
-            long_span.insert(long_span.end(), c.long_span.begin(), c.long_span.end());
-            gap_rec.insert(gap_rec.end(), c.gap_rec.begin(), c.gap_rec.end());
+            lo_of[u + 1] = lo_of[u] + c.long_rec.size();
+            go_of[u + 1] = go_of[u] + c.gap_rec.size();
         }
         sf->slen_min = smax >= smin ? smin : 0;
         sf->slen_max = smax >= smin ? smax : 0;
-        // (the contig of a list entry comes from tid_bounds, walked along with the list: the lists
-        // are in record order, and a look-up in the caller's tid[] would miss the cache every time)
-        int cur_tid = -1, t_of = 0;
+    }
+    const size_t nlong = lo_of[units.size()], ngap = go_of[units.size()];
+    HostBuf<uint4> long_rec(nlong), gap_rec(ngap);
+    HostBuf<uint32_t> long_idx(nlong);
+    HostBuf<int32_t> long_tid(nlong), long_pmax(nlong);
+    HostBuf<int4> long_runs(nlong), gap_runs(ngap);
+    if (!long_rec.p || !gap_rec.p || !long_idx.p || !long_tid.p || !long_pmax.p || !long_runs.p || !gap_runs.p) {
+        delete sf;
+        return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
+    }
+    // the first two aligned runs of every side-list record travel next to its header: the kernels then
+    // need the run array only for reads with three or more runs
+    auto first_two = [&](const uint4 &g) { // {pos, aligned length | flags << 16 | runs << 24, first run, record}
+        return (g.y >> 24) >= 2u ? make_int4(blk_start[g.z], blk_len[g.z], blk_start[g.z + 1], blk_len[g.z + 1])
+                                 : make_int4((int32_t)g.x, (int)(g.y & 0xffffu), 0, 0);
+    };
+    parallel_chunks((int64_t)units.size(), T, [&](int, int64_t ub, int64_t ue) {
+        int t_of = 0;
+        for (int64_t u = ub; u < ue; ++u) {
+            const Unit &c = units[(size_t)u];
+            size_t at = lo_of[(size_t)u];
+            for (size_t k = 0; k < c.long_rec.size(); ++k, ++at) {
+                const uint4 g = c.long_rec[k];
+                // (the contig comes from tid_bounds, walked along with the list: a look-up in the
+                // caller's tid[] would miss the cache every time)
+                while ((int64_t)g.w >= tid_bounds[(size_t)t_of + 1]) ++t_of;
+                long_rec[at] = g;
+                long_idx[at] = g.w;
+                long_tid[at] = t_of;
+                long_pmax[at] = (int32_t)g.x + c.long_span[k];   // the read's own end; made a running maximum below
+                long_runs[at] = first_two(g);
+            }
+            at = go_of[(size_t)u];
+            for (size_t k = 0; k < c.gap_rec.size(); ++k, ++at) {
+                gap_rec[at] = c.gap_rec[k];
+                gap_runs[at] = first_two(c.gap_rec[k]);
+            }
+        }
+    });
+    {
+        int cur_tid = -1;
         int32_t pm = 0;
-        long_idx.reserve(long_rec.size()); long_tid.reserve(long_rec.size()); long_pmax.reserve(long_rec.size());
-        for (size_t k = 0; k < long_rec.size(); ++k) { // running maximum of the ends, per contig
-            const uint32_t i = long_rec[k].w;
-            while ((int64_t)i >= tid_bounds[(size_t)t_of + 1]) ++t_of;
+        for (size_t k = 0; k < nlong; ++k) { // running maximum of the ends, per contig
+            const int t_of = long_tid[k];
             if (t_of != cur_tid) { cur_tid = t_of; pm = 0; }
-            pm = std::max(pm, (int32_t)long_rec[k].x + long_span[k]);
-            long_idx.push_back(i);
-            long_tid.push_back(t_of);
-            long_pmax.push_back(pm);
+            pm = std::max(pm, long_pmax[k]);
+            long_pmax[k] = pm;
             long_bounds[(size_t)t_of + 1] += 1;
         }
-        t_of = 0;
-        for (const uint4 &g : gap_rec) {
-            while ((int64_t)g.w >= tid_bounds[(size_t)t_of + 1]) ++t_of;
+        int t_of = 0;
+        for (size_t k = 0; k < ngap; ++k) {
+            while ((int64_t)gap_rec[k].w >= tid_bounds[(size_t)t_of + 1]) ++t_of;
             gap_bounds[(size_t)t_of + 1] += 1;
         }
         for (int t = 0; t < ntid; ++t) long_bounds[(size_t)t + 1] += long_bounds[(size_t)t];
@@ -760,21 +787,32 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     }
     sf->W = W;
     sf->max_span = max_span;
+    sf->nlong = (int64_t)nlong;
+    sf->ngap = (int64_t)ngap;
+    units.clear();
+    units.shrink_to_fit();
     clk.lap("side lists");
-    sf->nlong = (int64_t)long_idx.size();
-    sf->ngap = (int64_t)gap_rec.size();
-    // the first two aligned runs of every side-list record, next to its header: the kernels then
-    // need the run array only for reads with three or more runs
-    auto first_runs = [&](const std::vector<uint4> &list) {
-        std::vector<int4> out(list.size());
-        for (size_t k = 0; k < list.size(); ++k) {
-            const uint4 &g = list[k];                       // {pos, aligned length | flags << 16 | runs << 24, first run, record}
-            if ((g.y >> 24) >= 2u) out[k] = make_int4(blk_start[g.z], blk_len[g.z], blk_start[g.z + 1], blk_len[g.z + 1]);
-            else out[k] = make_int4((int32_t)g.x, (int)(g.y & 0xffffu), 0, 0);
-        }
-        return out;
-    };
-    const std::vector<int4> gap_runs = first_runs(gap_rec), long_runs = first_runs(long_rec);
+    // they go up while the index tables are built
+    std::future<int> side_up;
+    {
+        StagedFile *f = sf;
+        const uint4 *h_lr = long_rec.p, *h_gr = gap_rec.p;
+        const uint32_t *h_li = long_idx.p;
+        const int32_t *h_lt = long_tid.p, *h_lp = long_pmax.p;
+        const int4 *h_lru = long_runs.p, *h_gru = gap_runs.p;
+        side_up = std::async(std::launch::async, [=]() -> int {
+            if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
+            int r = f->long_idx.upload(h_li, nlong, up_stream);
+            if (r == PC_OK) r = f->long_tid.upload(h_lt, nlong, up_stream);
+            if (r == PC_OK) r = f->long_pmax.upload(h_lp, nlong, up_stream);
+            if (r == PC_OK) r = f->long_rec.upload(h_lr, nlong, up_stream);
+            if (r == PC_OK) r = f->gap_rec.upload(h_gr, ngap, up_stream);
+            if (r == PC_OK) r = f->gap_runs.upload(h_gru, ngap, up_stream);
+            if (r == PC_OK) r = f->long_runs.upload(h_lru, nlong, up_stream);
+            if (r == PC_OK && hipStreamSynchronize(up_stream) != hipSuccess) r = PC_ERR_HIP;
+            return r;
+        });
+    }
 
     // ---- linear index: first record at/after every 2^kLinShift-position bucket of each contig
     std::vector<int64_t> lin_off((size_t)ntid + 1, 0);
@@ -792,7 +830,11 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     // fill them are the first to touch their part)
     const size_t nlin = (size_t)lin_off[(size_t)ntid];
     HostBuf<uint32_t> lin_tab(nlin), glin_tab(nlin), llin_tab(nlin), plin_tab(nlin);
-    if (!lin_tab.p || !glin_tab.p || !llin_tab.p || !plin_tab.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
+    if (!lin_tab.p || !glin_tab.p || !llin_tab.p || !plin_tab.p) {
+        (void)side_up.get();
+        delete sf;
+        return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
+    }
     // every table entry is "first list index whose key is not before the bucket edge": the entries are
     // dealt to the threads in contiguous ranges; a thread finds its first index by bisection and
     // walks on from there (the keys are monotone inside a contig)
@@ -828,22 +870,19 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     fill_lin(plin_tab, long_bounds, [&](int64_t i, int64_t edge) { return (int64_t)long_pmax[(size_t)i] <= edge; });
 
     clk.lap("linear index");
-    // ---- bulk stage to HBM
+    // ---- the remaining tables
+    { const int r = side_up.get(); if (rc == PC_OK && r != PC_OK) rc = fail(r, "pc_add_alignment_file: staging the side lists failed"); }
     if (rc == PC_OK && nrun > 0) {
-        std::vector<int2> blk((size_t)nrun);
-        for (int64_t j = 0; j < nrun; ++j) blk[(size_t)j] = make_int2(blk_start[j], blk_len[j]);
-        if (rc == PC_OK) rc = sf->blk.upload(blk, e->stream);
+        HostBuf<int2> blk((size_t)nrun);
+        if (!blk.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
+        parallel_chunks(nrun, T, [&](int, int64_t jb, int64_t je) {
+            for (int64_t j = jb; j < je; ++j) blk[(size_t)j] = make_int2(blk_start[j], blk_len[j]);
+        });
+        rc = sf->blk.upload(blk.p, (size_t)nrun, e->stream);
         if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
     }
     if (rc == PC_OK) rc = sf->tid_bounds.upload(tid_bounds, e->stream);
-    if (rc == PC_OK) rc = sf->long_idx.upload(long_idx, e->stream);
-    if (rc == PC_OK) rc = sf->long_tid.upload(long_tid, e->stream);
-    if (rc == PC_OK) rc = sf->long_pmax.upload(long_pmax, e->stream);
     if (rc == PC_OK) rc = sf->long_tid_bounds.upload(long_bounds, e->stream);
-    if (rc == PC_OK) rc = sf->long_rec.upload(long_rec, e->stream);
-    if (rc == PC_OK) rc = sf->gap_rec.upload(gap_rec, e->stream);
-    if (rc == PC_OK) rc = sf->gap_runs.upload(gap_runs, e->stream);
-    if (rc == PC_OK) rc = sf->long_runs.upload(long_runs, e->stream);
     if (rc == PC_OK) rc = sf->gap_tid_bounds.upload(gap_bounds, e->stream);
     if (rc == PC_OK) rc = sf->lin_tab.upload(lin_tab.p, nlin, e->stream);
     if (rc == PC_OK) rc = sf->glin_tab.upload(glin_tab.p, nlin, e->stream);
