@@ -997,6 +997,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     HIP_TRY(hipSetDevice(e->device));
     const int ntid = e->ntid;
 
+    StageClock pclk;
     struct Iv { int32_t tid; int32_t mode; int64_t s, e; };
     std::vector<Iv> ivs;
     ivs.reserve((size_t)nseg);
@@ -1058,6 +1059,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     }
     const int G = p->G;
 
+    pclk.lap("plan: segments");
     // ---- islands: union of the queried intervals per (tid, mode)
     std::sort(ivs.begin(), ivs.end(), [](const Iv &a, const Iv &b) {
         if (a.tid != b.tid) return a.tid < b.tid;
@@ -1077,8 +1079,11 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     for (Island &is : islands) { is.off = npos; npos += is.e - is.s; }
     p->npos = npos;
 
+    pclk.lap("plan: islands");
     // ---- every segment -> its island (binary search)
-    for (int64_t s = 0; s < nseg; ++s) {
+    const int PT = nseg >= (1 << 16) ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u) : 1;
+    parallel_chunks(nseg, PT, [&](int, int64_t sb, int64_t se) {
+    for (int64_t s = sb; s < se; ++s) {
         GatherSeg &g = p->gsegs[(size_t)s];
         if (g.clip_hi <= g.clip_lo) continue;
         const int64_t cs = start[s] + g.clip_lo;
@@ -1093,7 +1098,9 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         const Island &is = islands[lo - 1];
         g.hist_off = is.off + (cs - is.s);
     }
+    });
 
+    pclk.lap("plan: segment->island");
     // ---- pieces: islands cut at the fixed genome grid of G positions; tiles: grid windows
     struct RawPiece { int32_t tid; int64_t win; Piece pc_; };
     std::vector<RawPiece> raw;
@@ -1114,6 +1121,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         return a.pc_.start < b.pc_.start;
     });
     p->pieces.reserve(raw.size());
+    p->cchunks.reserve((size_t)(npos / kWave) + raw.size());
     int max_slots = 1;
     for (size_t i = 0; i < raw.size(); ++i) {
         if (p->tiles.empty() || p->tiles.back().tid != raw[i].tid || p->tiles.back().win_start != (int32_t)raw[i].win) {
@@ -1140,51 +1148,62 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     for (const Tile &t : p->tiles) max_slots = std::max(max_slots, __builtin_popcount(t.mode_mask));
     p->max_slots = max_slots;
 
+    pclk.lap("plan: pieces+tiles+chunks");
     // ---- output pieces: every queried segment cut at the tile grid, in the caller's layout
     {
         struct RawOut { uint32_t tile; OutPiece o; };
-        std::vector<RawOut> ro;
-        for (int64_t s = 0; s < nseg; ++s) {
-            const GatherSeg &g = p->gsegs[(size_t)s];
-            if (g.len > 0 && (g.hist_off < 0 || g.clip_lo > 0 || g.clip_hi < g.len)) p->out_needs_zero = true;
-            if (g.hist_off < 0 || g.clip_hi <= g.clip_lo) continue;
-            const int m = mode_of(strand[s]);
-            const int64_t cs = start[s] + g.clip_lo, ce = start[s] + g.clip_hi;
-            for (int64_t a = cs; a < ce;) {
-                const int64_t win = (a / G) * G;
-                const int64_t b = std::min<int64_t>(ce, win + G);
-                // tile of (tid, win)
-                size_t lo = 0, hi = p->tiles.size();
-                while (lo < hi) {
-                    size_t mid = (lo + hi) / 2;
-                    const Tile &t = p->tiles[mid];
-                    if (t.tid < tid[s] || (t.tid == tid[s] && (int64_t)t.win_start < win)) lo = mid + 1; else hi = mid;
+        std::vector<std::vector<RawOut>> part((size_t)PT);
+        std::vector<uint8_t> part_zero((size_t)PT, 0);
+        parallel_chunks(nseg, PT, [&](int th, int64_t sb, int64_t se) {
+            std::vector<RawOut> &mine = part[(size_t)th];
+            for (int64_t s = sb; s < se; ++s) {
+                const GatherSeg &g = p->gsegs[(size_t)s];
+                if (g.len > 0 && (g.hist_off < 0 || g.clip_lo > 0 || g.clip_hi < g.len)) part_zero[(size_t)th] = 1;
+                if (g.hist_off < 0 || g.clip_hi <= g.clip_lo) continue;
+                const int m = mode_of(strand[s]);
+                const int64_t cs = start[s] + g.clip_lo, ce = start[s] + g.clip_hi;
+                for (int64_t a = cs; a < ce;) {
+                    const int64_t win = (a / G) * G;
+                    const int64_t b = std::min<int64_t>(ce, win + G);
+                    // tile of (tid, win)
+                    size_t lo = 0, hi = p->tiles.size();
+                    while (lo < hi) {
+                        size_t mid = (lo + hi) / 2;
+                        const Tile &t = p->tiles[mid];
+                        if (t.tid < tid[s] || (t.tid == tid[s] && (int64_t)t.win_start < win)) lo = mid + 1; else hi = mid;
+                    }
+                    OutPiece o;
+                    o.out_off = g.out_off + (int64_t)g.step * (a - start[s]);
+                    o.row_stride = g.row_stride;
+                    o.hist_off = g.hist_off + (a - cs);
+                    o.start = (int32_t)a; o.len = (int32_t)(b - a); o.mode = m; o.step = g.step;
+                    mine.push_back({(uint32_t)lo, o});
+                    a = b;
                 }
-                OutPiece o;
-                o.out_off = g.out_off + (int64_t)g.step * (a - start[s]);
-                o.row_stride = g.row_stride;
-                o.hist_off = g.hist_off + (a - cs);
-                o.start = (int32_t)a; o.len = (int32_t)(b - a); o.mode = m; o.step = g.step;
-                ro.push_back({(uint32_t)lo, o});
-                a = b;
             }
+        });
+        for (uint8_t z : part_zero) if (z) p->out_needs_zero = true;
+        // stable counting sort by tile (the thread lists are in segment order, taken in thread order)
+        const size_t ntl = p->tiles.size();
+        std::vector<uint32_t> at(ntl + 1, 0);
+        for (const auto &v : part) for (const RawOut &r : v) at[(size_t)r.tile + 1] += 1;
+        for (size_t t = 0; t < ntl; ++t) {
+            p->tiles[t].op_begin = at[t];
+            at[t + 1] += at[t];
+            p->tiles[t].op_end = at[t + 1];
         }
-        std::stable_sort(ro.begin(), ro.end(), [](const RawOut &a, const RawOut &b) { return a.tile < b.tile; });
-        p->opieces.reserve(ro.size());
-        for (size_t i = 0; i < ro.size(); ++i) {
-            Tile &t = p->tiles[ro[i].tile];
-            if (t.op_end == 0 && t.op_begin == 0) t.op_begin = (uint32_t)i;
-            t.op_end = (uint32_t)i + 1;
-            p->opieces.push_back(ro[i].o);
-        }
+        p->opieces.resize(at[ntl]);
+        for (const auto &v : part) for (const RawOut &r : v) p->opieces[at[r.tile]++] = r.o;
     }
 
+    pclk.lap("plan: output pieces");
     // ---- gather work list (center rule)
     for (int64_t s = 0; s < nseg; ++s) {
         const int64_t len = p->gsegs[(size_t)s].len;
         for (int64_t c = 0; c * kGatherChunk < len; ++c) p->gchunks.push_back({(uint32_t)s, (uint32_t)c});
     }
 
+    pclk.lap("plan: gather list");
     // ---- one device block and one upload for all tables (a plan of one short segment is otherwise
     // dominated by the per-copy cost); the per-tile item counters arrive zeroed with it
     size_t bytes = 0;
@@ -1197,30 +1216,43 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     const size_t hist_full = (size_t)p->npos * (size_t)p->rows * sizeof(double);
     const bool hist_here = hist_full > 0 && hist_full <= 64 * 1024;
     const size_t at_hist = hist_here ? place(hist_full) : 0;
+    // (a large annotation's tables -- tens of MB -- go up table by table from where they are: a
+    // page-locked buffer of that size costs more to create than it saves)
+    const bool through_pinned = bytes <= ((size_t)4 << 20);
     int rc = p->d_tables.reserve(bytes);
-    if (rc == PC_OK && e->pinned_busy && hipEventSynchronize(e->ev_pinned) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: wait failed");
-    if (rc == PC_OK) rc = e->pinned.reserve(bytes);
+    if (rc == PC_OK && through_pinned && e->pinned_busy && hipEventSynchronize(e->ev_pinned) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: wait failed");
+    if (rc == PC_OK && through_pinned) rc = e->pinned.reserve(bytes);
     if (rc == PC_OK) {
-        uint8_t *h = e->pinned.p, *d = p->d_tables.p;
-        auto put = [h](size_t at, const void *src, size_t n) { if (n) memcpy(h + at, src, n); };
+        uint8_t *h = through_pinned ? e->pinned.p : nullptr, *d = p->d_tables.p;
+        bool copy_failed = false;
+        auto put = [&](size_t at, const void *src, size_t n) {
+            if (!n) return;
+            if (through_pinned) memcpy(h + at, src, n);
+            else if (hipMemcpyAsync(d + at, src, n, hipMemcpyHostToDevice, e->stream) != hipSuccess) copy_failed = true;
+        };
         put(at_tiles, p->tiles.data(), p->tiles.size() * sizeof(Tile));
         put(at_pieces, p->pieces.data(), p->pieces.size() * sizeof(Piece));
         put(at_opieces, p->opieces.data(), p->opieces.size() * sizeof(OutPiece));
         put(at_cchunks, p->cchunks.data(), p->cchunks.size() * sizeof(CenterChunk));
         put(at_gsegs, p->gsegs.data(), p->gsegs.size() * sizeof(GatherSeg));
         put(at_gchunks, p->gchunks.data(), p->gchunks.size() * sizeof(GatherChunk));
-        memset(h + at_items, 0, bytes - at_items);
+        if (through_pinned) memset(h + at_items, 0, bytes - at_items);
+        else if (hipMemsetAsync(d + at_items, 0, bytes - at_items, e->stream) != hipSuccess) copy_failed = true;
         p->d_tiles.p = (Tile *)(d + at_tiles); p->d_pieces.p = (Piece *)(d + at_pieces);
         p->d_opieces.p = (OutPiece *)(d + at_opieces); p->d_cchunks.p = (CenterChunk *)(d + at_cchunks);
         p->d_gsegs.p = (GatherSeg *)(d + at_gsegs); p->d_gchunks.p = (GatherChunk *)(d + at_gchunks);
         p->d_tile_items.p = (uint32_t *)(d + at_items); p->d_total.p = d + at_total;
         p->tile_items_zero = true;
         if (hist_here) { p->d_hist.p = d + at_hist; p->hist_kind = 0; p->hist_clean = true; }
-        if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: upload failed");
+        if (!through_pinned) {   // the copies read the plan's own vectors, which live as long as the plan
+            if (copy_failed) rc = fail(PC_ERR_HIP, "pc_plan_create: upload failed");
+        } else if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: upload failed");
         else if (hipEventRecord(e->ev_pinned, e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_plan_create: event failed");
         else e->pinned_busy = true;
     }
+    pclk.lap("plan: upload");
     if (rc != PC_OK) {
+        (void)hipStreamSynchronize(e->stream);   // copies out of the plan's vectors may be in flight
         delete p;
         return rc;
     }
