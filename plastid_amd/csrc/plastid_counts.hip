@@ -4,6 +4,18 @@
 // pieces), launches the kernels of pc_kernels.hip.h on the engine's stream and
 // times them with HIP events.  There is no CPU counting path in this file: every
 // count comes out of a HIP kernel.
+//
+// Host-side structure, in file order:
+//   DevPool / DevBuf / PinnedBuf   device blocks recycled per engine, one page-locked buffer: a plan of
+//                                  one short segment costs API calls, not bytes
+//   pc_add_alignment_file          staging: pass A validates and fixes the halo W; pass B packs the
+//                                  records slice by slice while the previous slice crosses PCIe; side
+//                                  lists and linear-index tables on the same threads
+//   pc_plan_create                 segments -> islands -> windows -> output pieces, all tables of a
+//                                  plan in one device block
+//   pc_count                       k_tile_ranges -> k_hist_point (two classes, two streams) ->
+//                                  k_gather_split, or the three center kernels + k_gather
+//   pc_rle / pc_total / pc_mapped_reads / pc_warn_flags   consumers of a finished count
 #include "pc_kernels.hip.h"
 
 #include <algorithm>
