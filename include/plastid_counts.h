@@ -79,6 +79,7 @@ int pc_device_count(void);
 
 /* ---- engine ------------------------------------------------------------- */
 int pc_create(int device, pc_engine **out);
+/* Every plan of the engine must have been destroyed first (plans return their device blocks to it). */
 int pc_destroy(pc_engine *e);
 
 /* ---- alignments: replaces pysam AlignmentFile.fetch + AlignedSegment.positions /

@@ -148,7 +148,7 @@ struct PinnedBuf {
         if (n <= cap) return PC_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
-        const size_t want = std::max<size_t>(n + n / 2, 64 * 1024);
+        const size_t want = std::max<size_t>(n + n / 2, 512 * 1024);   // covers every short read-back (kSmallRead) from the start
         HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
         cap = want;
         return PC_OK;
@@ -1515,6 +1515,8 @@ int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems) 
     if (out_elems != p->out_elems || (out_elems > 0 && !host_out)) return fail(PC_ERR_ARG, "pc_read_counts: buffer size mismatch");
     HIP_TRY(hipSetDevice(e->device));
     const size_t bytes = (size_t)out_elems * 8;
+    // (growing the buffer frees the old one: not while a plan upload may still be reading from it)
+    if (bytes > e->pinned.cap && e->pinned_busy) { HIP_TRY(hipEventSynchronize(e->ev_pinned)); e->pinned_busy = false; }
     if (bytes > 0 && bytes <= kSmallRead && e->pinned.reserve(bytes) == PC_OK) {
         // short vectors come back through the page-locked buffer (stream order keeps it behind any
         // plan upload still reading from it): a pageable destination costs an extra staging hop
