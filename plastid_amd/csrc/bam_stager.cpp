@@ -145,83 +145,38 @@ struct Lap {
     }
 };
 
-int decode(Bam &bam, int nthreads) {
-    Lap lap;
-    std::vector<uint8_t> file;
-    if (!read_file(bam.path, file)) return fail("cannot read " + bam.path);
-    std::vector<Block> blocks;
-    size_t total_u = 0;
-    if (scan_blocks(file, blocks, total_u) != 0) return -1;
-    lap("read + index members");
-    // the inflated stream: not value-initialised (the inflate threads are the first to touch their
-    // members' pages) and on transparent huge pages when large
-    struct Raw {
-        uint8_t *p = nullptr;
-        size_t n = 0;
-        explicit Raw(size_t bytes) : n(bytes) {
-            const size_t huge = (size_t)2 << 20, want = std::max<size_t>(bytes, 1);
-            if (want >= 4 * huge) {
-                void *q = nullptr;
-                if (posix_memalign(&q, huge, (want + huge - 1) / huge * huge) == 0) {
-                    (void)madvise(q, (want + huge - 1) / huge * huge, MADV_HUGEPAGE);
-                    p = (uint8_t *)q;
-                }
-            } else {
-                p = (uint8_t *)malloc(want);
-            }
-        }
-        ~Raw() { free(p); }
-        uint8_t *data() { return p; }
-        size_t size() const { return n; }
-    } data(total_u);
-    if (!data.p) return fail("out of memory inflating " + bam.path);
-    lap("allocate");
-    // inflate all members in parallel
-    std::atomic<size_t> next(0);
-    std::atomic<int> bad(0);
-    if (nthreads < 1) nthreads = 1;
-    nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(blocks.size(), 1));
-    auto worker = [&]() {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= blocks.size()) return;
-            const int rc = inflate_block(file, blocks[i], data.data() + blocks[i].uoff);
-            if (rc != 0) bad.store(rc);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-    worker();
-    for (auto &t : pool) t.join();
-    if (bad.load() == -2) return fail("BGZF CRC mismatch in " + bam.path);
-    if (bad.load() != 0) return fail("BGZF inflate failed in " + bam.path);
-    file.clear();
-    file.shrink_to_fit();
-    lap("inflate");
-
-    // ---- BAM header
-    const uint8_t *p = data.data(), *end = data.data() + data.size();
-    if (end - p < 12 || std::memcmp(p, "BAM\1", 4) != 0) return fail("not a BAM file (bad magic)");
+// BAM header (magic, text, reference list) at `p`; leaves `p` at the first alignment record.
+// need_more (optional): set when the buffer ends inside the header (a caller that inflates lazily
+// fetches more and retries) instead of reporting truncation.
+int parse_header(Bam &bam, const uint8_t *&p, const uint8_t *end, uint32_t &n_ref_out, bool *need_more = nullptr) {
+    auto trunc = [&](const char *what) { if (need_more) { *need_more = true; return -1; } return fail(what); };
+    if (end - p < 12) return trunc("not a BAM file (bad magic)");
+    if (std::memcmp(p, "BAM\1", 4) != 0) return fail("not a BAM file (bad magic)");
     const uint32_t l_text = rd32(p + 4);
     p += 8;
-    if ((size_t)(end - p) < (size_t)l_text + 4) return fail("truncated BAM header");
+    if ((size_t)(end - p) < (size_t)l_text + 4) return trunc("truncated BAM header");
     p += l_text;
     const uint32_t n_ref = rd32(p);
     p += 4;
     bam.ref_names.clear();
     bam.ref_lengths.clear();
     for (uint32_t r = 0; r < n_ref; ++r) {
-        if (end - p < 4) return fail("truncated BAM reference list");
+        if (end - p < 4) return trunc("truncated BAM reference list");
         const uint32_t l_name = rd32(p);
         p += 4;
-        if ((size_t)(end - p) < (size_t)l_name + 4) return fail("truncated BAM reference list");
+        if ((size_t)(end - p) < (size_t)l_name + 4) return trunc("truncated BAM reference list");
         bam.ref_names.emplace_back(reinterpret_cast<const char *>(p), l_name ? l_name - 1 : 0);
         p += l_name;
         bam.ref_lengths.push_back((int32_t)rd32(p));
         p += 4;
     }
+    n_ref_out = n_ref;
+    return 0;
+}
 
-    // ---- alignment records.  A serial walk over the length prefixes cuts the stream into pieces of
+// Alignment records in [p, end) -> bam.parts (file order), with every order / format check.
+int decode_records(Bam &bam, const uint8_t *p, const uint8_t *end, uint32_t n_ref, int nthreads, Lap &lap) {
+    // A serial walk over the length prefixes cuts the stream into pieces of
     // kPiece records; the pieces are decoded by the thread pool; the stitching pass then applies the
     // checks that span two pieces.  The defect reported is the one of the lowest record index, as
     // in a serial walk (where one record fails two checks, the serial order of the checks decides).
@@ -374,6 +329,344 @@ int decode(Bam &bam, int nthreads) {
         bam.threads = nthreads;
     }
     lap("stitch");
+    return 0;
+}
+
+int decode(Bam &bam, int nthreads) {
+    Lap lap;
+    std::vector<uint8_t> file;
+    if (!read_file(bam.path, file)) return fail("cannot read " + bam.path);
+    std::vector<Block> blocks;
+    size_t total_u = 0;
+    if (scan_blocks(file, blocks, total_u) != 0) return -1;
+    lap("read + index members");
+    // the inflated stream: not value-initialised (the inflate threads are the first to touch their
+    // members' pages) and on transparent huge pages when large
+    struct Raw {
+        uint8_t *p = nullptr;
+        size_t n = 0;
+        explicit Raw(size_t bytes) : n(bytes) {
+            const size_t huge = (size_t)2 << 20, want = std::max<size_t>(bytes, 1);
+            if (want >= 4 * huge) {
+                void *q = nullptr;
+                if (posix_memalign(&q, huge, (want + huge - 1) / huge * huge) == 0) {
+                    (void)madvise(q, (want + huge - 1) / huge * huge, MADV_HUGEPAGE);
+                    p = (uint8_t *)q;
+                }
+            } else {
+                p = (uint8_t *)malloc(want);
+            }
+        }
+        ~Raw() { free(p); }
+        uint8_t *data() { return p; }
+        size_t size() const { return n; }
+    } data(total_u);
+    if (!data.p) return fail("out of memory inflating " + bam.path);
+    lap("allocate");
+    // inflate all members in parallel
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    if (nthreads < 1) nthreads = 1;
+    nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(blocks.size(), 1));
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= blocks.size()) return;
+            const int rc = inflate_block(file, blocks[i], data.data() + blocks[i].uoff);
+            if (rc != 0) bad.store(rc);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    if (bad.load() == -2) return fail("BGZF CRC mismatch in " + bam.path);
+    if (bad.load() != 0) return fail("BGZF inflate failed in " + bam.path);
+    file.clear();
+    file.shrink_to_fit();
+    lap("inflate");
+
+    // ---- BAM header, then the alignment records
+    const uint8_t *p = data.data(), *end = data.data() + data.size();
+    uint32_t n_ref = 0;
+    if (parse_header(bam, p, end, n_ref) != 0) return -1;
+    if (decode_records(bam, p, end, n_ref, nthreads, lap) != 0) return -1;
+    bam.loaded = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------- region-limited loading (BAI)
+// The reference fetches per region through the BAM index (genome_array.py:800-809 via pysam; bin /
+// chunk / linear-index scheme of the SAM specification, section 5).  Here the regions of a whole
+// query set are resolved at once: bins -> chunks of virtual offsets, clipped by the linear index,
+// merged; only the BGZF members those chunks touch are read and inflated; the records then go
+// through the same decoder as a whole file and are filtered by htslib's overlap test
+// (pos < end && endpos > start).  `mapped` comes from the index's per-reference counts, as
+// pysam's AlignmentFile.mapped does.
+struct BaiRef {
+    std::vector<uint32_t> bin_id;
+    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> chunks;
+    std::vector<uint64_t> linear;
+    uint64_t n_mapped = 0, n_unmapped = 0;
+    bool has_meta = false;
+};
+
+int load_bai(const std::string &bam_path, std::vector<BaiRef> &refs) {
+    std::vector<uint8_t> buf;
+    std::string ipath = bam_path + ".bai";
+    if (!read_file(ipath, buf)) {
+        ipath = bam_path.size() > 4 ? bam_path.substr(0, bam_path.size() - 4) + ".bai" : ipath;
+        if (!read_file(ipath, buf)) return fail("cannot read the index of " + bam_path + " (.bam.bai / .bai)");
+    }
+    const uint8_t *p = buf.data(), *end = p + buf.size();
+    auto need = [&](size_t n) { return (size_t)(end - p) >= n; };
+    if (!need(8) || std::memcmp(p, "BAI\1", 4) != 0) return fail("not a BAI index: " + ipath);
+    const uint32_t n_ref = rd32(p + 4);
+    p += 8;
+    if (n_ref > (1u << 24)) return fail("corrupt BAI index (reference count): " + ipath);
+    refs.assign(n_ref, BaiRef());
+    auto rd64 = [](const uint8_t *q) { return (uint64_t)rd32(q) | ((uint64_t)rd32(q + 4) << 32); };
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        BaiRef &br = refs[r];
+        if (!need(4)) return fail("truncated BAI index: " + ipath);
+        const uint32_t n_bin = rd32(p);
+        p += 4;
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            if (!need(8)) return fail("truncated BAI index: " + ipath);
+            const uint32_t bin = rd32(p), n_chunk = rd32(p + 4);
+            p += 8;
+            if (!need((size_t)n_chunk * 16) || n_chunk > (1u << 28)) return fail("truncated BAI index: " + ipath);
+            if (bin == 37450u) { // samtools' metadata pseudo-bin: (file range), (mapped, unmapped)
+                if (n_chunk >= 2) { br.n_mapped = rd64(p + 16); br.n_unmapped = rd64(p + 24); br.has_meta = true; }
+            } else {
+                br.bin_id.push_back(bin);
+                br.chunks.emplace_back();
+                auto &v = br.chunks.back();
+                v.reserve(n_chunk);
+                for (uint32_t c = 0; c < n_chunk; ++c) v.emplace_back(rd64(p + 16 * (size_t)c), rd64(p + 16 * (size_t)c + 8));
+            }
+            p += (size_t)n_chunk * 16;
+        }
+        if (!need(4)) return fail("truncated BAI index: " + ipath);
+        const uint32_t n_intv = rd32(p);
+        p += 4;
+        if (!need((size_t)n_intv * 8) || n_intv > (1u << 28)) return fail("truncated BAI index: " + ipath);
+        br.linear.resize(n_intv);
+        for (uint32_t i = 0; i < n_intv; ++i) br.linear[i] = rd64(p + 8 * (size_t)i);
+        p += (size_t)n_intv * 8;
+    }
+    return 0;
+}
+
+// the BGZF member at file offset `coff`, inflated and appended to `out`; returns its compressed
+// length, 0 at end of file, -1 on a damaged member
+long read_member(FILE *f, uint64_t coff, std::vector<uint8_t> &out) {
+    uint8_t h[18];
+    if (fseeko(f, (off_t)coff, SEEK_SET) != 0) return -1;
+    const size_t got = fread(h, 1, 18, f);
+    if (got == 0) return 0;
+    if (got < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return -1;
+    const uint16_t xlen = rd16(h + 10);
+    std::vector<uint8_t> member((size_t)12 + xlen);
+    std::memcpy(member.data(), h, std::min<size_t>(18, member.size()));
+    if (member.size() > 18 && fread(member.data() + 18, 1, member.size() - 18, f) != member.size() - 18) return -1;
+    int bsize = -1;
+    for (size_t x = 0; x + 4 <= xlen;) {
+        const uint8_t *sf = member.data() + 12 + x;
+        const uint16_t slen = rd16(sf + 2);
+        if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = rd16(sf + 4);
+        x += 4 + (size_t)slen;
+    }
+    if (bsize < 0) return -1;
+    const size_t clen = (size_t)bsize + 1, hdr = (size_t)12 + xlen;
+    if (clen < hdr + 8) return -1;
+    std::vector<uint8_t> rest(clen - hdr);
+    // (the header bytes beyond 12 + xlen that were read with the first 18 belong to the payload)
+    if (fseeko(f, (off_t)(coff + hdr), SEEK_SET) != 0 || fread(rest.data(), 1, rest.size(), f) != rest.size()) return -1;
+    const uint32_t isize = rd32(rest.data() + rest.size() - 4), crc = rd32(rest.data() + rest.size() - 8);
+    if (isize > (1u << 16)) return -1;
+    const size_t at = out.size();
+    out.resize(at + isize);
+    if (isize) {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) return -1;
+        zs.next_in = rest.data();
+        zs.avail_in = (uInt)(rest.size() - 8);
+        zs.next_out = out.data() + at;
+        zs.avail_out = isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) return -1;
+        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out.data() + at, isize) != crc) return -1;
+    }
+    return (long)clen;
+}
+
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &bins) {
+    --end;
+    bins.push_back(0);
+    for (int64_t k = 1 + (beg >> 26); k <= 1 + (end >> 26); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 9 + (beg >> 23); k <= 9 + (end >> 23); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 73 + (beg >> 20); k <= 73 + (end >> 20); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 585 + (beg >> 17); k <= 585 + (end >> 17); ++k) bins.push_back((uint32_t)k);
+    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (end >> 14); ++k) bins.push_back((uint32_t)k);
+}
+
+int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, const int64_t *rstart, const int64_t *rend) {
+    Lap lap;
+    FILE *f = fopen(bam.path.c_str(), "rb");
+    if (!f) return fail("cannot read " + bam.path);
+    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{f};
+    // ---- header: inflate members from the start of the file until it is complete
+    uint32_t n_ref = 0;
+    {
+        std::vector<uint8_t> hbuf;
+        uint64_t coff = 0;
+        for (;;) {
+            const long cl = read_member(f, coff, hbuf);
+            if (cl <= 0) return fail(cl == 0 ? "truncated BAM header" : "not a BGZF file (bad gzip member header)");
+            coff += (uint64_t)cl;
+            const uint8_t *p = hbuf.data();
+            bool more = false;
+            if (parse_header(bam, p, hbuf.data() + hbuf.size(), n_ref, &more) == 0) break;
+            if (!more) return -1;
+        }
+    }
+    std::vector<BaiRef> refs;
+    if (load_bai(bam.path, refs) != 0) return -1;
+    if (refs.size() != (size_t)n_ref) return fail("the index does not belong to this BAM file (reference count differs): " + bam.path);
+    lap("header + index");
+    // ---- regions: by reference id, sorted, overlapping / adjacent ones merged
+    struct Reg { int32_t tid; int64_t s, e; };
+    std::vector<Reg> regs;
+    for (int i = 0; i < nreg; ++i) {
+        int32_t tid = -1;
+        for (uint32_t r = 0; r < n_ref; ++r)
+            if (bam.ref_names[r] == rname[i]) { tid = (int32_t)r; break; }
+        if (tid < 0) continue;                           // unknown chromosome: fetch() finds nothing there
+        const int64_t s = std::max<int64_t>(rstart[i], 0), e = std::min<int64_t>(rend[i], (int64_t)1 << 29);
+        if (e > s) regs.push_back({tid, s, e});
+    }
+    std::sort(regs.begin(), regs.end(), [](const Reg &a, const Reg &b) { return a.tid != b.tid ? a.tid < b.tid : (a.s != b.s ? a.s < b.s : a.e < b.e); });
+    std::vector<Reg> merged;
+    for (const Reg &r : regs) {
+        if (!merged.empty() && merged.back().tid == r.tid && r.s <= merged.back().e) merged.back().e = std::max(merged.back().e, r.e);
+        else merged.push_back(r);
+    }
+    // ---- chunks of virtual offsets
+    std::vector<std::pair<uint64_t, uint64_t>> ch;
+    std::vector<uint32_t> bins;
+    for (const Reg &r : merged) {
+        const BaiRef &br = refs[(size_t)r.tid];
+        const size_t w = (size_t)(r.s >> 14);
+        if (br.linear.empty()) continue;
+        const uint64_t min_off = w < br.linear.size() ? br.linear[w] : br.linear.back();
+        bins.clear();
+        reg2bins(r.s, r.e, bins);
+        std::sort(bins.begin(), bins.end());
+        for (size_t b = 0; b < br.bin_id.size(); ++b) {
+            if (!std::binary_search(bins.begin(), bins.end(), br.bin_id[b])) continue;
+            for (const auto &c : br.chunks[b])
+                if (c.second > min_off && c.second > c.first) ch.push_back(c);
+        }
+    }
+    std::sort(ch.begin(), ch.end());
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    for (const auto &c : ch) {
+        if (!chunks.empty() && c.first <= chunks.back().second) chunks.back().second = std::max(chunks.back().second, c.second);
+        else chunks.push_back(c);
+    }
+    // ---- read and inflate what the chunks touch (threads over chunks, one file handle each)
+    std::vector<std::vector<uint8_t>> bytes(chunks.size());
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto worker = [&]() {
+        FILE *g = fopen(bam.path.c_str(), "rb");
+        if (!g) { bad.store(1); return; }
+        std::vector<uint8_t> buf;
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= chunks.size()) break;
+            const uint64_t vb = chunks[k].first, ve = chunks[k].second;
+            const uint64_t cb = vb >> 16, ce = ve >> 16;
+            const size_t ub = (size_t)(vb & 0xffff), ue = (size_t)(ve & 0xffff);
+            buf.clear();
+            uint64_t cur = cb;
+            size_t stop = (size_t)-1;
+            bool ok = true;
+            while (cur < ce || (cur == ce && ue > 0)) {
+                const size_t before = buf.size();
+                const long cl = read_member(g, cur, buf);
+                if (cl <= 0) { ok = false; break; }
+                if (cur == ce) { stop = before + ue; break; }
+                cur += (uint64_t)cl;
+            }
+            if (stop == (size_t)-1) stop = buf.size();
+            if (!ok || ub > stop || stop > buf.size()) { bad.store(2); continue; }
+            bytes[k].assign(buf.begin() + (long)ub, buf.begin() + (long)stop);
+        }
+        fclose(g);
+    };
+    {
+        std::vector<std::thread> pool;
+        const int nt = (int)std::min<size_t>((size_t)std::max(nthreads, 1), std::max<size_t>(chunks.size(), 1));
+        for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+    }
+    if (bad.load() != 0) return fail("damaged BGZF member or index out of step with " + bam.path);
+    size_t total = 0;
+    for (const auto &b : bytes) total += b.size();
+    std::vector<uint8_t> data;
+    data.reserve(total);
+    for (const auto &b : bytes) data.insert(data.end(), b.begin(), b.end());
+    bytes.clear();
+    lap("read + inflate chunks");
+    if (decode_records(bam, data.data(), data.data() + data.size(), n_ref, nthreads, lap) != 0) return -1;
+    // ---- keep what overlaps a requested region (htslib: pos < end && endpos > start)
+    std::vector<size_t> first_reg((size_t)n_ref + 1, merged.size());
+    for (size_t i = merged.size(); i-- > 0;) first_reg[(size_t)merged[i].tid] = i;
+    auto overlaps = [&](int32_t tid, int64_t pos, int64_t endpos) {
+        size_t lo = first_reg[(size_t)tid], hi = lo;
+        while (hi < merged.size() && merged[hi].tid == tid) ++hi;
+        // first region of this reference whose end lies beyond pos
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (merged[mid].e <= pos) lo = mid + 1; else hi = mid;
+        }
+        return lo < merged.size() && merged[lo].tid == tid && merged[lo].s < endpos;
+    };
+    for (Part &pt : bam.parts) {
+        size_t w = 0, rw = 0, rr = 0;
+        for (size_t i = 0; i < pt.tid.size(); ++i) {
+            const int nb = pt.nblk[i];
+            const size_t runs = nb >= 2 ? (size_t)nb : 0;
+            const int64_t endpos = nb >= 2 ? (int64_t)pt.blk_start[rr + runs - 1] + pt.blk_len[rr + runs - 1]
+                                           : (int64_t)pt.pos[i] + std::max<int64_t>(pt.alen[i], 1);
+            if (overlaps(pt.tid[i], pt.pos[i], endpos)) {
+                pt.tid[w] = pt.tid[i]; pt.pos[w] = pt.pos[i]; pt.alen[w] = pt.alen[i]; pt.flags[w] = pt.flags[i]; pt.nblk[w] = pt.nblk[i];
+                for (size_t k = 0; k < runs; ++k) { pt.blk_start[rw + k] = pt.blk_start[rr + k]; pt.blk_len[rw + k] = pt.blk_len[rr + k]; }
+                ++w;
+                rw += runs;
+            }
+            rr += runs;
+        }
+        pt.tid.resize(w); pt.pos.resize(w); pt.alen.resize(w); pt.flags.resize(w); pt.nblk.resize(w);
+        pt.blk_start.resize(rw); pt.blk_len.resize(rw);
+    }
+    for (size_t k = 0; k < bam.parts.size(); ++k) {
+        bam.rec_off[k + 1] = bam.rec_off[k] + bam.parts[k].tid.size();
+        bam.run_off[k + 1] = bam.run_off[k] + bam.parts[k].blk_start.size();
+    }
+    bam.nrec = bam.parts.empty() ? 0 : bam.rec_off[bam.parts.size()];
+    bam.nrun = bam.parts.empty() ? 0 : bam.run_off[bam.parts.size()];
+    // `mapped` as pysam reports it: from the index, for the whole file
+    bool any_meta = false;
+    int64_t mapped = 0;
+    for (const BaiRef &br : refs) { any_meta |= br.has_meta; mapped += (int64_t)br.n_mapped; }
+    bam.mapped = any_meta ? mapped : -1;
+    lap("filter");
     bam.loaded = true;
     return 0;
 }
@@ -409,6 +702,17 @@ int pb_load(void *h, int nthreads) {
     if (b->loaded) return 0;
     if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
     return decode(*b, nthreads);
+}
+
+// region-limited load through the BAI index: only records that overlap one of the `nreg` regions
+// (reference name, 0-based half-open) are staged; counts[2] (`mapped`) then comes from the index (-1 if
+// the index carries no per-reference counts)
+int pb_load_regions(void *h, int nthreads, int nreg, const char *const *names, const int64_t *start, const int64_t *end) {
+    Bam *b = static_cast<Bam *>(h);
+    if (!b || nreg < 0 || (nreg > 0 && (!names || !start || !end))) return fail("pb_load_regions: bad arguments");
+    if (b->loaded) return fail("pb_load_regions: file already loaded");
+    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    return decode_regions(*b, nthreads, nreg, names, start, end);
 }
 
 int pb_nref(void *h) { return h ? (int)static_cast<Bam *>(h)->ref_names.size() : -1; }

@@ -34,14 +34,15 @@ from .packing import FLAG_EXCLUDED, PackedAlignments
 from .roitools import GenomicSegment, SegmentChain
 
 
-def _open_alignment_source(src):
+def _open_alignment_source(src, regions=None):
     """Filenames are read with the package's own BAM reader; objects are used as
-    given (``multiopen`` passes non-str objects through, util/io/openers.py:90-94)."""
+    given (``multiopen`` passes non-str objects through, util/io/openers.py:90-94).
+    `regions`: stage only the alignments that overlap them (through the BAI index)."""
     if isinstance(src, PackedAlignments):
         return src
     if isinstance(src, str):
         from .bam import read_bam
-        return read_bam(src)
+        return read_bam(src, regions=regions)
     return src
 
 
@@ -88,7 +89,9 @@ class BAMGenomeArray(object):
     def __init__(self, *bamfiles, **kwargs):
         if len(bamfiles) == 1 and isinstance(bamfiles[0], list):  # :657-658
             bamfiles = bamfiles[0]
-        self.bamfiles = [_open_alignment_source(x) for x in bamfiles]
+        # (extension) regions=[(chrom, start, end) | GenomicSegment, ...]: files named by path are staged
+        # only where they overlap the regions, via their BAI index -- for a few loci of a large file
+        self.bamfiles = [_open_alignment_source(x, kwargs.get("regions")) for x in bamfiles]
         self._strands = ("+", "-", ".")
         self._normalize = False
         self._sum = None

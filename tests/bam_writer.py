@@ -41,8 +41,9 @@ def encode_record(tid, pos, cigartuples, flag, name=b"r", seq_len=None, mapq=30)
     return struct.pack("<I", len(body)) + body
 
 
-def write_bam(path, references, lengths, records, block_bytes=60000, header_text="@HD\tVN:1.6\tSO:coordinate\n"):
-    """records: iterable of (tid, pos, cigartuples, flag)."""
+def write_bam(path, references, lengths, records, block_bytes=60000, header_text="@HD\tVN:1.6\tSO:coordinate\n", index=False):
+    """records: sequence of (tid, pos, cigartuples, flag); `index`: also write ``path + ".bai"``."""
+    records = list(records)
     text = header_text.encode()
     out = b"BAM\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(references))
     for nm, ln in zip(references, lengths):
@@ -52,10 +53,70 @@ def write_bam(path, references, lengths, records, block_bytes=60000, header_text
     for i, (tid, pos, cig, flag) in enumerate(records):
         chunks.append(encode_record(tid, pos, cig, flag, name=("r%d" % i).encode()))
     data = b"".join(chunks)
+    block_coff = []
+    coff = 0
     with open(path, "wb") as fh:
         for off in range(0, len(data), block_bytes):
-            fh.write(bgzf_block(data[off:off + block_bytes]))
+            blk = bgzf_block(data[off:off + block_bytes])
+            block_coff.append(coff)
+            coff += len(blk)
+            fh.write(blk)
+        block_coff.append(coff)          # the EOF block: virtual offset of "end of data"
         fh.write(BGZF_EOF)
+    if not index:
+        return
+    # ---- BAI (SAM spec section 5.2): bins -> chunks of virtual offsets, 16 kb linear index, and the
+    # samtools metadata pseudo-bin 37450 with the mapped / unmapped record counts
+    def voff(u):
+        if u >= len(data):
+            return block_coff[-1] << 16
+        return (block_coff[u // block_bytes] << 16) | (u % block_bytes)
+    u = len(chunks[0])
+    nref = len(references)
+    bins = [dict() for _ in range(nref)]
+    linear = [dict() for _ in range(nref)]
+    meta = [[None, None, 0, 0] for _ in range(nref)]
+    n_no_coor = 0
+    last = (None, None)
+    for (tid, pos, cig, flag), raw in zip(records, chunks[1:]):
+        beg, endv = voff(u), voff(u + len(raw))
+        u += len(raw)
+        if tid < 0:
+            n_no_coor += 1
+            continue
+        ref_len = sum(n for op, n in cig if op in (0, 2, 3, 7, 8))
+        end = pos + max(ref_len, 1)
+        b = reg2bin(pos, end)
+        lst = bins[tid].setdefault(b, [])
+        if last == (tid, b) and lst and lst[-1][1] == beg:
+            lst[-1][1] = endv
+        else:
+            lst.append([beg, endv])
+        last = (tid, b)
+        for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+            linear[tid].setdefault(w, beg)
+        m = meta[tid]
+        m[0] = beg if m[0] is None else m[0]
+        m[1] = endv
+        m[2 if not (flag & 4) else 3] += 1
+    with open(path + ".bai", "wb") as fh:
+        fh.write(b"BAI\x01" + struct.pack("<i", nref))
+        for t in range(nref):
+            nb = len(bins[t]) + (1 if meta[t][0] is not None else 0)
+            fh.write(struct.pack("<i", nb))
+            for b in sorted(bins[t]):
+                fh.write(struct.pack("<Ii", b, len(bins[t][b])))
+                for cb, ce in bins[t][b]:
+                    fh.write(struct.pack("<QQ", cb, ce))
+            if meta[t][0] is not None:
+                fh.write(struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", meta[t][0], meta[t][1], meta[t][2], meta[t][3]))
+            nint = (max(linear[t]) + 1) if linear[t] else 0
+            fh.write(struct.pack("<i", nint))
+            prev = 0
+            for w in range(nint):
+                prev = linear[t].get(w, prev)   # empty windows repeat the previous offset, as samtools writes them
+                fh.write(struct.pack("<Q", prev))
+        fh.write(struct.pack("<Q", n_no_coor))
 
 
 def packed_to_records(packed):

@@ -210,3 +210,89 @@ def test_piecewise_decoding_is_the_serial_walk(tmp_path, monkeypatch, piece):
     bam_writer.write_bam(path, ["c"], [5000], base + [(-1, -1, [], 4)] * 3)
     ok = read_bam(path, threads=2)
     assert ok.n == 9 and ok.mapped == 9
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_region_loading_through_the_index(tmp_path, monkeypatch, seed):
+    """``read_bam(path, regions=...)`` walks the BAI index (bins, chunks, linear index) and must return
+    exactly the alignments htslib's fetch would: those with ``pos < end and endpos > start`` for
+    some region, once each, in file order; ``mapped`` comes from the index."""
+    rng = np.random.default_rng(100 + seed)
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00004, tx_scale=0.002, seed_shift=seed)   # spliced, human-scale contigs
+    recs = bam_writer.packed_to_records(reads)
+    path = str(tmp_path / "r.bam")
+    bam_writer.write_bam(path, list(reads.references), list(reads.lengths), recs + [(-1, -1, [], 4)] * 2,
+                         block_bytes=int(rng.choice([300, 4000, 60000])), index=True)
+    whole = read_bam(path, threads=1)
+    assert whole.n == reads.n
+    end = whole.pos.astype(np.int64) + np.maximum(whole.alen, 1)
+    multi = np.nonzero(whole.nblk >= 2)[0]
+    off = whole.block_offsets()
+    last = off[multi] + whole.nblk[multi] - 1
+    end[multi] = whole.blk_start[last].astype(np.int64) + whole.blk_len[last]
+    if seed == 1:
+        monkeypatch.setenv("PB_PIECE", "3")
+    for trial in range(12):
+        regs = []
+        for _ in range(int(rng.integers(1, 6))):
+            if rng.random() < 0.7 and reads.n:                      # around a read
+                i = int(rng.integers(0, reads.n))
+                t, c = int(whole.tid[i]), int(whole.pos[i]) + int(rng.integers(-2000, 2000))
+            else:
+                t = int(rng.integers(0, len(reads.references)))
+                c = int(rng.integers(0, reads.lengths[t]))
+            s = max(0, c)
+            regs.append((reads.references[t], s, s + int(rng.choice([1, 50, 5000, 300000]))))
+        if trial == 0:
+            regs.append(("not_a_contig", 0, 1000))
+        keep = np.zeros(whole.n, bool)
+        for chrom, s, e in regs:
+            if chrom in reads.references:
+                t = reads.references.index(chrom)
+                keep |= (whole.tid == t) & (whole.pos < e) & (end > s)
+        got = read_bam(path, threads=int(rng.integers(1, 4)), regions=regs)
+        idx = np.nonzero(keep)[0]
+        assert got.n == len(idx), (regs, got.n, len(idx))
+        for name in ("tid", "pos", "alen", "flags", "nblk"):
+            assert np.array_equal(getattr(got, name), getattr(whole, name)[idx]), name
+        runs = np.concatenate([np.arange(off[i], off[i + 1]) for i in idx]) if len(idx) else np.zeros(0, np.int64)
+        assert np.array_equal(got.blk_start, whole.blk_start[runs]) and np.array_equal(got.blk_len, whole.blk_len[runs])
+        assert got.mapped == whole.mapped
+    # no index: a clear error
+    os.remove(path + ".bai")
+    with pytest.raises(ValueError, match="index"):
+        read_bam(path, regions=[(reads.references[0], 0, 10)])
+
+
+def test_damaged_index_is_rejected_not_crashed(tmp_path):
+    """A BAI file with flipped bytes, absurd counts or a cut end either still resolves or raises;
+    virtual offsets that point nowhere are caught when the members are read."""
+    import struct
+    rng = np.random.default_rng(9)
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00002, tx_scale=0.001)
+    path = str(tmp_path / "d.bam")
+    bam_writer.write_bam(path, list(reads.references), list(reads.lengths), bam_writer.packed_to_records(reads),
+                         block_bytes=2000, index=True)
+    good = open(path + ".bai", "rb").read()
+    regs = [(reads.references[int(reads.tid[i])], max(0, int(reads.pos[i]) - 100), int(reads.pos[i]) + 100)
+            for i in rng.integers(0, reads.n, 8)]
+    outcomes = {"ok": 0, "rejected": 0}
+    for it in range(120):
+        b = bytearray(good)
+        mode = it % 3
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif mode == 1:
+            b = b[:int(rng.integers(0, len(b)))]
+        else:
+            i = int(rng.integers(4, len(b) - 8))
+            b[i:i + 8] = struct.pack("<Q", [0, 1, 2 ** 63, 2 ** 64 - 1, 2 ** 40, 70000 << 16][int(rng.integers(0, 6))])
+        with open(path + ".bai", "wb") as fh:
+            fh.write(bytes(b))
+        try:
+            read_bam(path, threads=2, regions=regs)
+            outcomes["ok"] += 1
+        except (ValueError, OSError):
+            outcomes["rejected"] += 1
+    assert outcomes["rejected"] > 20 and outcomes["ok"] + outcomes["rejected"] == 120

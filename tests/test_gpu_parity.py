@@ -526,6 +526,29 @@ def test_bam_file_end_to_end(pa, oracle, tmp_path):
     assert total == int(((reads.flags & 1) == 0).sum())
 
 
+def test_region_limited_staging_counts_like_the_whole_file(pa, tmp_path):
+    """``BAMGenomeArray(path, regions=...)`` stages only what the BAI index says overlaps the regions;
+    every count inside the regions equals the whole-file count (all five rules see the same reads
+    there, htslib fetch semantics), and ``sum()`` is the whole file's, from the index."""
+    from plastid_amd import synth
+    from tests import bam_writer
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.002)      # 100 k reads, spliced
+    path = str(tmp_path / "reads.bam")
+    bam_writer.write_bam(path, list(reads.references), list(reads.lengths), bam_writer.packed_to_records(reads),
+                         block_bytes=20000, index=True)
+    chains = tx.chains(limit=40)
+    regions = [seg for c in chains for seg in c]
+    for mapping in (pa.FivePrimeMapFactory(12), pa.CenterMapFactory(2), pa.VariableFivePrimeMapFactory(synth.VARIABLE_OFFSETS)):
+        whole = pa.BAMGenomeArray(path, mapping=mapping)
+        part = pa.BAMGenomeArray(path, mapping=mapping, regions=regions)
+        assert part._packed[0].n < whole._packed[0].n and part.sum() == whole.sum()
+        a, b = whole.get_counts_batch(chains), part.get_counts_batch(chains)
+        assert sum(x.sum() for x in a) > 0
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+        assert np.array_equal(whole[chains[0][0]], part[chains[0][0]])
+
+
 def _windows(ga, pa, strand, window_size):
     """(chrom, window start, genome-order vector) for every export window, chromosomes sorted --
     the iteration order of the reference's exporters (genome_array.py:990-1111)."""
