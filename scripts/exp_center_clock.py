@@ -10,14 +10,23 @@ genome, tx, reads, mapping = synth.make_config("C3", scale=float(os.environ.get(
 eng = Engine(0); eng.set_alignments([reads]); synth.mapping_factory(mapping)._configure(eng)
 # one segment per (contig, strand) so that output index == island position
 names = reads.references
-p = tx.plan_arrays(rows=1)
-plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+# one '+' segment per contig, laid out left to right: output index == genome position, so the lanes of a
+# wave sit next to each other in the result
+lens = np.asarray(reads.lengths, np.int64)
+off = np.zeros(len(lens) + 1, np.int64); np.cumsum(lens, out=off[1:])
+plan = eng.plan(np.arange(len(lens), dtype=np.int32), np.zeros(len(lens), np.int64), lens, np.full(len(lens), 1, np.uint8),
+                off[:-1], np.ones(len(lens), np.int8), lens, int(off[-1]), 1)
 out = plan.count(np.float64)
-cyc = out[(out > 1000) & (out < 9e8)]      # lane-0 values (cycle counts); real center counts stay far below 1000 here
-print("kernel-clock experiment"); print("waves seen", len(cyc), "sum cycles %.3g" % cyc.sum(), "max %.3g" % cyc.max(), "p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f" % tuple(np.percentile(cyc, [50, 90, 99, 99.9])))
+w = np.nonzero(out[6:] >= 7e15)[0]; w = w[(w - np.searchsorted(off, w, side='right') * 0) >= 0]                       # lane 6 marks a reporting wave; lanes 0..5 sit before it
+tot, nb, wait, filt, rep, ent = (out[w + k] for k in range(6))
+code = out[w + 6] - 7e15
+for name, sel in (("all reporting waves", code >= 0), ("whole chunks (code 0)", code == 0), ("cut chunks (code > 0)", code > 0)):
+    if not sel.any():
+        continue
+    T, B = tot[sel].sum(), nb[sel].sum()
+    print("%-24s waves %d  cycles %.3g (max %.3g)  batches %.3g  entries %.3g" % (name, sel.sum(), T, tot[sel].max(), B, ent[sel].sum()))
+    print("    share of wave cycles: wait for records %.1f%%, filter+compact %.1f%%, replay %.1f%%, rest (start-up, index look-ups, loop) %.1f%%" % (
+        100 * wait[sel].sum() / T, 100 * filt[sel].sum() / T, 100 * rep[sel].sum() / T, 100 * (T - wait[sel].sum() - filt[sel].sum() - rep[sel].sum()) / T))
+    print("    per batch: wait %.0f, filter %.0f, replay %.0f cycles; %.1f entries per batch, %.0f replay cycles per entry" % (
+        wait[sel].sum() / B, filt[sel].sum() / B, rep[sel].sum() / B, ent[sel].sum() / B, rep[sel].sum() / max(ent[sel].sum(), 1)))
 eng.set_profiling(2); plan.launch(np.float64); eng.sync(); print(eng.last_timing())
-idx = np.nonzero(out > 1000)[0]
-idx = idx[out[idx] < 9e8]
-order = idx[np.argsort(out[idx])[-12:]]
-for i in order:
-    print("cycles %.0f  batches(long*1e6+near) %.0f  code %.0f" % (out[i], out[i + 1] - 1e9, out[i + 2] - 2e9))
