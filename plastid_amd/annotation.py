@@ -98,7 +98,31 @@ def _gtf2_attributes(text):
     ``key "value";`` pairs, values may hold semicolons inside the quotes, repeated keys
     are joined with a comma."""
     out = {}
-    for m in _GTF2_TOKEN.finditer(text.strip()):
+    text = text.strip()
+    if "\\" not in text:
+        # fast path (no escapes): split at the semicolons; a token with an odd number of quotes means a
+        # semicolon sat inside a quoted value -- then the general tokenizer below takes over
+        ok = True
+        for tok in text.split(";"):
+            tok = tok.strip()
+            if not tok:
+                continue
+            if tok.count('"') & 1:
+                ok = False
+                break
+            key, sep, val = tok.partition(" ")
+            val = val.strip()
+            if not sep or not val or (val[0] == '"') != (val[-1] == '"') or (val[0] != '"' and (" " in val or "\t" in val)) \
+                    or '"' in key or "\t" in key or (val[0] == '"' and ('"' in val[1:-1] or len(val) < 2)):
+                ok = False
+                break
+            if val[0] == '"':
+                val = val[1:-1]
+            out[key] = "%s,%s" % (out[key], val) if key in out else val
+        if ok:
+            return out
+        out = {}
+    for m in _GTF2_TOKEN.finditer(text):
         key = m.group(1)
         val = m.group(2) if m.group(2) is not None else m.group(3)
         out[key] = "%s,%s" % (out[key], val) if key in out else val
