@@ -127,3 +127,40 @@ def test_interval_table_from_gff3():
         tab = IntervalTable.from_gff3(io.StringIO(gold["gff3"]), ["chrI", "chrII", "chrM"])
     assert tab.ids == [r[0] for r in gold["transcripts"]]
     assert [str(c) for c in tab.chains()] == [r[1] for r in gold["transcripts"]]
+
+
+def test_gtf2_attribute_fast_path_equals_the_tokenizer():
+    """The split-based fast path of the ninth GTF2 column must agree with the general tokenizer
+    (quoted semicolons, escapes, bare numbers, empty values, repeated keys) on random strings."""
+    import random
+    from plastid_amd import annotation as A
+
+    def tokenizer_only(text):
+        out = {}
+        for m in A._GTF2_TOKEN.finditer(text.strip()):
+            key = m.group(1)
+            val = m.group(2) if m.group(2) is not None else m.group(3)
+            out[key] = "%s,%s" % (out[key], val) if key in out else val
+        return out
+
+    rng = random.Random(11)
+    keys = ["gene_id", "transcript_id", "exon_number", "gene_name", "tag", "note", "level"]
+
+    def rand_val():
+        r = rng.random()
+        if r < 0.5:
+            return '"%s"' % "".join(rng.choice("abcXYZ012._-") for _ in range(rng.randint(0, 8)))
+        if r < 0.6:
+            return '"a;b c"'
+        if r < 0.7:
+            return '"with \\\\"esc\\\\" quote"'
+        if r < 0.8:
+            return str(rng.randint(0, 99))
+        if r < 0.9:
+            return '"two words"'
+        return '""'
+
+    for _ in range(5000):
+        parts = ["%s%s%s" % (rng.choice(keys), rng.choice([" ", "  ", "\\t"]), rand_val()) for _ in range(rng.randint(0, 6))]
+        text = rng.choice(["; ", ";", " ; ", ";  "]).join(parts) + rng.choice(["", ";", "; "])
+        assert A._gtf2_attributes(text) == tokenizer_only(text), text
