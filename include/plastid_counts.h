@@ -81,6 +81,9 @@ int pc_device_count(void);
 int pc_create(int device, pc_engine **out);
 /* Every plan of the engine must have been destroyed first (plans return their device blocks to it). */
 int pc_destroy(pc_engine *e);
+/* The PC_* tuning/diagnostic environment knobs are read once, by pc_create;
+ * this re-reads them (tests and experiments only -- no reference counterpart). */
+int pc_reload_knobs(pc_engine *e);
 
 /* ---- alignments: replaces pysam AlignmentFile.fetch + AlignedSegment.positions /
  * .is_reverse as consumed at genome_array.py:800-815 and map_factories.pyx:243,

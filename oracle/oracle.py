@@ -54,6 +54,8 @@ def lib():
             i64, vp, vp, vp, vp, vp, vp, vp, vp,          # alignments
             i32, i32, vp, vp, i32, i32, i32, i32, i32,    # mapping + filter
             i64, vp, vp, vp, vp, vp, vp, vp, vp]          # segments + outputs
+        L.po_count_segments_mt.restype = ctypes.c_int
+        L.po_count_segments_mt.argtypes = L.po_count_segments.argtypes + [i32]
         L.po_cigar_to_runs.restype = ctypes.c_int
         L.po_cigar_to_runs.argtypes = [ctypes.c_int32, i32, vp, vp, i32, vp, vp, vp]
         _lib = L
@@ -107,14 +109,15 @@ def rows_of(spec):
 
 
 # ------------------------------------------------------------- segment level
-def count_segments(aln, spec, seg_tid, seg_start, seg_end, seg_strand, want_mapped=False):
+def count_segments(aln, spec, seg_tid, seg_start, seg_end, seg_strand, want_mapped=False, threads=1):
     """Run the C oracle: one independent reference ``map_fn`` call per segment.
 
     `aln` is a dict of packed arrays (``tid,pos,alen,flags,nblk,blk_start,blk_len``
     and optionally ``file_id``; file-major order).  Returns
     ``(arrays, warn_flags[, mapped])`` where ``arrays[s]`` has shape ``(len,)`` or
     ``(rows, len)`` and dtype int64 (point maps) / float64 (center) -- exactly what
-    the reference's map function returns for segment ``s``."""
+    the reference's map function returns for segment ``s``.  `threads` > 1 deals the segments
+    to that many POSIX threads (same results; the all-cores CPU baseline of bench.py)."""
     L = lib()
     seg_tid = np.ascontiguousarray(seg_tid, np.int32)
     seg_start = np.ascontiguousarray(seg_start, np.int64)
@@ -135,14 +138,14 @@ def count_segments(aln, spec, seg_tid, seg_start, seg_end, seg_strand, want_mapp
     assert a["alen"].dtype == np.uint16 and a["flags"].dtype == np.uint8 and a["nblk"].dtype == np.uint8
     assert a["blk_start"].dtype == np.int32 and a["blk_len"].dtype == np.int32
     sf = spec.get("size_filter")
-    rcode = L.po_count_segments(
+    rcode = L.po_count_segments_mt(
         n, _ptr(a["tid"]), _ptr(a["pos"]), _ptr(a["alen"]), _ptr(a["flags"]), _ptr(a["nblk"]),
         _ptr(a.get("file_id")), _ptr(a["blk_start"]), _ptr(a["blk_len"]),
         spec["kind"], spec["param"], _ptr(spec["fw"]), _ptr(spec["rc"]),
         spec["min_len"], spec["max_len"],
         0 if sf is None else 1, 0 if sf is None else int(sf[0]), 0 if sf is None else int(sf[1]),
         nseg, _ptr(seg_tid), _ptr(seg_start), _ptr(seg_end), _ptr(seg_strand),
-        _ptr(out_off), _ptr(out), _ptr(warn), _ptr(mapped))
+        _ptr(out_off), _ptr(out), _ptr(warn), _ptr(mapped), int(threads))
     if rcode != 0:
         raise RuntimeError("oracle: po_count_segments failed with code %d" % rcode)
     arrays = []

@@ -1,8 +1,9 @@
 /*
  * plastid_oracle.c -- TEST INFRASTRUCTURE ONLY (the parity oracle).
  *
- * A plain, single-threaded C restatement of the reference's per-position read
- * counting path, written to be *obviously the same algorithm* as the reference,
+ * A plain C restatement of the reference's per-position read counting path
+ * (every segment is one sequential reference call; po_count_segments_mt only deals
+ * whole segments to threads), written to be *obviously the same algorithm* as the reference,
  * not to be fast.  It operates on the packed alignment arrays that the product
  * stages to HBM, materialises `read.positions` for every read exactly as the
  * reference consumes it, and then follows the reference line by line.
@@ -42,6 +43,7 @@
  *                           after record (a record with nblk == 1 has the single
  *                           implicit run [pos, pos+L))
  */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -255,14 +257,56 @@ static int po_segment(const po_aln *a, const po_map *m, const int64_t *rng_lo, c
  * Batch entry point: every segment is an independent reference call.
  * Segment s writes rows*len(s) elements at out + out_off[s] (element offset),
  * row-major [rows][len].  `mapped` (optional) is nseg*n bytes.
+ *
+ * po_count_segments_mt: the same, with the segments dealt to `nthreads` POSIX threads (the
+ * reference itself is single-threaded; this is the "every host core" CPU baseline of bench.py:
+ * the per-record arrays are derived ONCE and shared, every segment is still one independent,
+ * sequential reference call, so the results are those of the single-threaded run bit for bit).
  */
-int po_count_segments(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
-                      const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
-                      const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
-                      const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
-                      int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
-                      const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
-                      const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped) {
+typedef struct {
+    const po_aln *a; const po_map *m;
+    const int64_t *rng_lo, *rng_hi; int64_t nrng; const int32_t *rng_tid; int64_t max_span; int maxL;
+    int64_t nseg; const int32_t *seg_tid; const int64_t *seg_start, *seg_end; const uint8_t *seg_strand;
+    const int64_t *out_off; void *out; uint8_t *warn; uint8_t *mapped;
+    int64_t next;          /* next unclaimed block of segments (atomic) */
+    int rcode;
+} po_job;
+
+#define PO_SEG_BLOCK 16
+
+static void *po_worker(void *arg) {
+    po_job *j = (po_job *)arg;
+    int32_t *P = (int32_t *)malloc(sizeof(int32_t) * (size_t)(j->maxL + 1));
+    if (!P) { __atomic_store_n(&j->rcode, PO_ERR_NOMEM, __ATOMIC_RELAXED); return NULL; }
+    for (;;) {
+        const int64_t s0 = __atomic_fetch_add(&j->next, (int64_t)PO_SEG_BLOCK, __ATOMIC_RELAXED);
+        if (s0 >= j->nseg || __atomic_load_n(&j->rcode, __ATOMIC_RELAXED) != PO_OK) break;
+        const int64_t s1 = s0 + PO_SEG_BLOCK < j->nseg ? s0 + PO_SEG_BLOCK : j->nseg;
+        for (int64_t s = s0; s < s1; ++s) {
+            const int64_t len = j->seg_end[s] - j->seg_start[s];
+            int rc = PO_OK;
+            if (len < 0) rc = PO_ERR_ARG;
+            else {
+                char *dst = (char *)j->out + (size_t)j->out_off[s] * 8u; /* int64 and double are both 8 bytes */
+                rc = po_segment(j->a, j->m, j->rng_lo, j->rng_hi, j->nrng, j->rng_tid, j->max_span, j->seg_tid[s],
+                                j->seg_start[s], j->seg_end[s], j->seg_strand[s], dst,
+                                j->mapped ? j->mapped + (size_t)s * (size_t)j->a->n : NULL,
+                                j->warn ? j->warn + s : NULL, P);
+            }
+            if (rc != PO_OK) { __atomic_store_n(&j->rcode, rc, __ATOMIC_RELAXED); break; }
+        }
+    }
+    free(P);
+    return NULL;
+}
+
+int po_count_segments_mt(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
+                         const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
+                         const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
+                         const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
+                         int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
+                         const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
+                         const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped, int nthreads) {
     po_aln a;
     memset(&a, 0, sizeof(a));
     a.n = n; a.tid = tid; a.pos = pos; a.alen = alen; a.flags = flags; a.nblk = nblk;
@@ -306,18 +350,39 @@ int po_count_segments(int64_t n, const int32_t *tid, const int32_t *pos, const u
     }
     if (nrng > 0) rng_hi[nrng - 1] = n;
 
-    int32_t *P = (int32_t *)malloc(sizeof(int32_t) * (size_t)(maxL + 1));
-    for (int64_t s = 0; s < nseg && rcode == PO_OK; ++s) {
-        const int64_t len = seg_end[s] - seg_start[s];
-        if (len < 0) { rcode = PO_ERR_ARG; break; }
-        char *dst = (char *)out + (size_t)out_off[s] * 8u; /* int64 and double are both 8 bytes */
-        rcode = po_segment(&a, &m, rng_lo, rng_hi, nrng, rng_tid, max_span, seg_tid[s], seg_start[s],
-                           seg_end[s], seg_strand[s], dst, mapped ? mapped + (size_t)s * (size_t)n : NULL,
-                           warn ? warn + s : NULL, P);
+    po_job job;
+    memset(&job, 0, sizeof(job));
+    job.a = &a; job.m = &m; job.rng_lo = rng_lo; job.rng_hi = rng_hi; job.nrng = nrng; job.rng_tid = rng_tid;
+    job.max_span = max_span; job.maxL = maxL; job.nseg = nseg; job.seg_tid = seg_tid; job.seg_start = seg_start;
+    job.seg_end = seg_end; job.seg_strand = seg_strand; job.out_off = out_off; job.out = out; job.warn = warn;
+    job.mapped = mapped; job.next = 0; job.rcode = PO_OK;
+    if (nthreads <= 1) {
+        po_worker(&job);
+    } else {
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+        int started = 0;
+        for (int t = 0; th && t < nthreads; ++t)
+            if (pthread_create(&th[t], NULL, po_worker, &job) == 0) ++started; else break;
+        if (started == 0) po_worker(&job);
+        for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+        free(th);
     }
-    free(P); free(rng_lo); free(rng_hi); free(rng_tid);
+    rcode = job.rcode;
+    free(rng_lo); free(rng_hi); free(rng_tid);
     po_release(&a);
     return rcode;
+}
+
+int po_count_segments(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
+                      const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
+                      const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
+                      const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
+                      int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
+                      const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
+                      const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped) {
+    return po_count_segments_mt(n, tid, pos, alen, flags, nblk, file_id, blk_start, blk_len, kind, param, fw, rc,
+                                min_len, max_len, filt_on, filt_min, filt_max, nseg, seg_tid, seg_start, seg_end,
+                                seg_strand, out_off, out, warn, mapped, 1);
 }
 
 /* The CIGAR -> aligned-run step restated from the SAM spec (what pysam's

@@ -9,7 +9,9 @@ import os
 from .exceptions import EngineError
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libplastid_counts.so")
+#: the product library; ``PLASTID_AMD_LIB`` points experiments at a variant built elsewhere
+#: (``build_library(out=...)``) so that they never overwrite the product build
+LIB_PATH = os.environ.get("PLASTID_AMD_LIB") or os.path.join(HERE, "libplastid_counts.so")
 
 PC_OK = 0
 PC_ERR_ARG = -1
@@ -33,6 +35,7 @@ SIGNATURES = {
     "pc_device_count": (_int, []),
     "pc_create": (_int, [_int, _pp]),
     "pc_destroy": (_int, [_vp]),
+    "pc_reload_knobs": (_int, [_vp]),
     "pc_clear_alignments": (_int, [_vp]),
     "pc_add_alignment_file": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "pc_update_flags": (_int, [_vp, _int, _i64, _vp]),

@@ -47,16 +47,23 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in [SRC] + HDRS)
 
 
-def build_library(force=False, verbose=False, extra_flags=()):
-    """Compile ``csrc/plastid_counts.hip`` -> ``plastid_amd/libplastid_counts.so``."""
-    if not force and not needs_build():
+def build_library(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile ``csrc/plastid_counts.hip`` -> ``plastid_amd/libplastid_counts.so``.
+
+    Experiment variants (``extra_flags``) must name their own output file (``out``) and be loaded
+    through ``PLASTID_AMD_LIB``: the product library is only ever built with the default flags."""
+    if extra_flags and out is None:
+        raise ValueError("a build with extra flags needs its own output path (out=...); "
+                         "it must not replace the product library")
+    target = out or LIB
+    if out is None and not force and not needs_build():
         return LIB
     cmd = [find_hipcc()] + HIPCC_FLAGS + list(extra_flags) + [
-        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), SRC, "-o", LIB]
+        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), SRC, "-o", target]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

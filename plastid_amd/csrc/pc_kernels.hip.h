@@ -1117,6 +1117,7 @@ constexpr int kInvLds = 1024; // 1/m table kept in LDS for m < kInvLds
 // inequality fewer than nchunks/8 chunks are cut and the heavy entries fit in nchunks slots.
 // Entry = chunk index | code << 27: 0 whole chunk, 1..4 quarter, 5..12 eighth.
 constexpr int kSubShift = 27;
+constexpr int64_t kCenterSearchFrom = 1024; // candidate count from which a whole chunk searches its exact first record
 // One candidate read of the center kernel, ready to replay: the (at most two) runs of covered
 // positions [a0, a0+m0) and [a1, a1+m1) after trimming `nibble` from both ends, and 1/m.
 // m0 < 0: a read with three or more aligned runs -- `a0` names the lane that holds its header.
@@ -1188,14 +1189,6 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
     }
 }
 
-#ifdef PC_EXP_CENTER_CLOCK   // experiment build (scripts/exp_center_clock.py): per-wave cycle accounting
-#define PC_EXP_PARAMS , long long &exp_filter, long long &exp_replay, long long &exp_entries
-#define PC_EXP_ARGS , exp_filter, exp_replay, exp_entries
-#else
-#define PC_EXP_PARAMS
-#define PC_EXP_ARGS
-#endif
-
 // One batch of up to 64 candidate reads (lane j holds candidate j's header, in record order):
 // filter, fetch the first two aligned runs of the gapped ones (all lanes at once -- not one
 // dependent load chain per read), compact the reads that can touch the chunk into the wave's LDS
@@ -1210,10 +1203,7 @@ template <bool PLAIN>
 __device__ __forceinline__ void center_batch(const GFile &fv, const MapParams &mp, const CenterChunk &ck, int32_t cend,
                                              bool in, int32_t pos, uint32_t meta, uint32_t boff, const double *s_inv,
                                              const double PC_GLOBAL *inv, CenterEntry *list, int lane, int32_t p,
-                                             double &acc PC_EXP_PARAMS) {
-#ifdef PC_EXP_CENTER_CLOCK
-    const long long exp_ta = __builtin_readcyclecounter();
-#endif
+                                             double &acc) {
     const int nib = mp.param;
     const uint32_t fl = rec_flags(meta);
     const int L = rec_len(meta), nbk = rec_nblk(meta);
@@ -1240,12 +1230,6 @@ __device__ __forceinline__ void center_batch(const GFile &fv, const MapParams &m
     if (!PLAIN) if (ok && m >= kInvLds) e.val = inv[m];
     const unsigned long long okmask = __ballot(ok);
     const int nok = __popcll(okmask);
-#ifdef PC_EXP_CENTER_CLOCK
-    const long long exp_tb = __builtin_readcyclecounter();
-    exp_filter += exp_tb - exp_ta;
-    exp_entries += nok;
-    struct ExpDone { long long &r; long long t; __device__ ~ExpDone() { r += __builtin_readcyclecounter() - t; } } exp_done{exp_replay, exp_tb};
-#endif
     if (PLAIN) {
         // every read of the batch is one run: 16-byte entries {start, length, 1/m}, five instructions
         // per entry and position (a wave over a pile-up runs alone: its replay is issue-bound)
@@ -1332,10 +1316,6 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     const int32_t cend = ck.start + ck.len;
     const int nib = mp.param;
     double acc = 0.0;
-#ifdef PC_EXP_CENTER_CLOCK
-    const long long exp_t0 = __builtin_readcyclecounter();
-    long long exp_batches = 0, exp_wait = 0, exp_filter = 0, exp_replay = 0, exp_entries = 0;
-#endif
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
         const int64_t near_key = (int64_t)ck.start - W + 1;
@@ -1348,14 +1328,18 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
             const u32x4 g = in ? fv.long_rec[base + lane] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
             if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_key) break; // sorted by start: the rest is met in the near window
             center_batch<false>(fv, mp, ck, cend, in & ((int64_t)(int32_t)g.x < near_key), (int32_t)g.x, g.y, g.z, s_inv, inv,
-                                list, lane, p, acc PC_EXP_ARGS);
+                                list, lane, p, acc);
         }
         // near window: the records that start in [start - W + 1, end).  A batch of 64 candidates is
         // fetched with ONE coalesced vector load, four batches in flight (a wave walks its range
         // alone).  Whole chunks start at the bucket edge (a few surplus candidates, filtered out); the
         // waves of a cut chunk each search their exact start, or they would all scan the whole pile-up.
-        const int64_t lo = code == 0u ? (int64_t)rg.x
-                                      : wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
+        // (a whole chunk over a dense region searches too: the bucket edge lies 64 positions before
+        // near_key on average, and every surplus batch costs a filter pass; three dependent loads pay
+        // for themselves from about a thousand candidates on)
+        const int64_t lo = (code == 0u && (int64_t)rg.y - (int64_t)rg.x < kCenterSearchFrom)
+                               ? (int64_t)rg.x
+                               : wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
         const int64_t hi = rg.y;
         // (the loads are unconditional, with the index clamped into the range: a load under a lane
         // predicate would keep the compiler from counting how many are outstanding, and it would
@@ -1373,16 +1357,9 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
         // wait for all loads), then filter / compact / replay.  Returns false when the scan is over.
         auto step = [&](u32x2 &q, int64_t base) -> bool {
             if (base >= hi) return false;
-#ifdef PC_EXP_CENTER_CLOCK
-            exp_batches += 1;
-            const long long exp_tw = __builtin_readcyclecounter();
-#endif
             const u32x2 r = q;
             q = fv.rec[base + 256 + lane < last ? base + 256 + lane : last];
             if ((int32_t)lane_u32(r.x, 0) >= cend) return false; // sorted by start: nothing further can reach the chunk
-#ifdef PC_EXP_CENTER_CLOCK
-            exp_wait += __builtin_readcyclecounter() - exp_tw;   // the readlane needed the batch: the wait is over
-#endif
             const int32_t pos = (int32_t)r.x;
             // records before near_key belong to the long-span loop above (or cannot reach the chunk)
             const bool in = (base + lane < hi) & ((int64_t)pos >= near_key);
@@ -1390,9 +1367,9 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
             if (__any(odd)) {                                // gapped reads / very long reads in the batch
                 uint32_t boff = 0u;
                 if (in && rec_nblk(r.y) >= 2) boff = fv.blk_off[base + lane];
-                center_batch<false>(fv, mp, ck, cend, in, pos, r.y, boff, s_inv, inv, list, lane, p, acc PC_EXP_ARGS);
+                center_batch<false>(fv, mp, ck, cend, in, pos, r.y, boff, s_inv, inv, list, lane, p, acc);
             } else {
-                center_batch<true>(fv, mp, ck, cend, in, pos, r.y, 0u, s_inv, inv, list, lane, p, acc PC_EXP_ARGS);
+                center_batch<true>(fv, mp, ck, cend, in, pos, r.y, 0u, s_inv, inv, list, lane, p, acc);
             }
             return true;
         };
@@ -1403,15 +1380,6 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
             if (!step(q3, base + 192)) break;
         }
     }
-#ifdef PC_EXP_CENTER_CLOCK   // lanes 0..6 report (whole chunks of 64 positions only are read back)
-    if (lane == 0) acc = (double)(__builtin_readcyclecounter() - exp_t0);
-    if (lane == 1) acc = (double)exp_batches;
-    if (lane == 2) acc = (double)exp_wait;
-    if (lane == 3) acc = (double)exp_filter;
-    if (lane == 4) acc = (double)exp_replay;
-    if (lane == 5) acc = (double)exp_entries;
-    if (lane == 6) acc = 7e15 + (double)code;
-#endif
     if (lane < ck.len) hist[ck.hist_off + lane] = acc;
 }
 

@@ -240,8 +240,36 @@ struct StagedFile {
 
 } // namespace
 
+// Tuning and diagnostic knobs (environment).  Read ONCE, at pc_create -- the query path is
+// advertised at tens of microseconds per call and does not look at the environment;
+// pc_reload_knobs() re-reads them (tests and experiments drive the scheduling paths with them).
+struct Knobs {
+    int tile_g = 0;            // PC_TILE_G: window size (0: chosen from the LDS budget)
+    int64_t work_r = 49152;    // PC_WORK_R: records per work item (192 KiB of the 4-byte stream)
+    int64_t pile = 0;          // PC_PILE: records of a 128-nt sub-window beyond which it is merged through the histogram (0: 12 R)
+    int no_small = 0;          // PC_NO_SMALL: no single-wave class for sparse windows
+    int small_g = 512;         // PC_SMALL_G: queried span a single-wave window may have
+    int64_t small_n = 2048;    // PC_SMALL_N: records a single-wave window may scan
+    int debug_work = 0;        // PC_DEBUG_WORK: print the queued work items per class (stderr; synchronises)
+    int center_t1 = 8;         // PC_CENTER_T1 / PC_CENTER_T2: center chunks with more than T1 x (T1*T2 x) the mean candidate
+    int center_t2 = 4;         //   count are cut into 4 (8) sub-chunks
+    void load() {
+        *this = Knobs();
+        if (const char *env = getenv("PC_TILE_G")) tile_g = std::max(256, atoi(env) / 256 * 256);
+        if (const char *env = getenv("PC_WORK_R")) work_r = std::max(1024, atoi(env));
+        if (const char *env = getenv("PC_PILE")) pile = std::max<int64_t>(work_r, atoll(env));
+        no_small = getenv("PC_NO_SMALL") ? 1 : 0;
+        if (const char *env = getenv("PC_SMALL_G")) small_g = std::max(64, atoi(env) / 64 * 64);
+        if (const char *env = getenv("PC_SMALL_N")) small_n = std::max(64, atoi(env));
+        debug_work = getenv("PC_DEBUG_WORK") ? 1 : 0;
+        if (const char *env = getenv("PC_CENTER_T1")) center_t1 = std::max(8, atoi(env));
+        if (const char *env = getenv("PC_CENTER_T2")) center_t2 = std::max(1, atoi(env));
+    }
+};
+
 struct pc_engine {
     DevPool pool;   // first member: outlives every buffer of the engine
+    Knobs knobs;
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // the single-wave kernel of sparse windows runs beside the main one
@@ -404,6 +432,7 @@ int pc_create(int device, pc_engine **out) {
     HIP_TRY(hipSetDevice(device));
     pc_engine *e = new pc_engine();
     e->device = device;
+    e->knobs.load();
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -443,6 +472,12 @@ int pc_destroy(pc_engine *e) {
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+    return PC_OK;
+}
+
+int pc_reload_knobs(pc_engine *e) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    e->knobs.load();
     return PC_OK;
 }
 
@@ -1062,10 +1097,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         int G = 256;
         int gmax = 4096;
         while (G * 2 <= g && G * 2 <= gmax) G *= 2;
-        if (const char *env = getenv("PC_TILE_G")) { // tuning knob: any multiple of 256 within the budget
-            const int want = std::max(256, atoi(env) / 256 * 256);
-            if (want <= 2 * g) G = want;
-        }
+        if (e->knobs.tile_g && e->knobs.tile_g <= 2 * g) G = e->knobs.tile_g; // tuning knob: any multiple of 256 within the budget
         if ((int64_t)4 * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
         p->G = G;
     }
@@ -1310,10 +1342,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     const int nfiles = (int)e->files.size();
     const int W = e->W();
     const int G = p->G;
-    int64_t R = 49152; // records per work item (192 KiB of the 4-byte stream)
-    if (const char *env = getenv("PC_WORK_R")) R = std::max(1024, atoi(env)); // tuning knob
-    int64_t pile = 12 * R; // a 128-nt sub-window with more records than this is merged through the histogram
-    if (const char *env = getenv("PC_PILE")) pile = std::max<int64_t>(R, atoll(env)); // tuning knob
+    const int64_t R = e->knobs.work_r;                             // records per work item
+    const int64_t pile = e->knobs.pile ? e->knobs.pile : 12 * R;   // a 128-nt sub-window with more records than this is merged through the histogram
     const MapParams mp = e->params();
     const int ntiles = (int)p->tiles.size();
     hipStream_t st = e->stream;
@@ -1348,11 +1378,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // sparse windows: single-wave workgroups with a small LDS window (rows == 1 only)
             // (skipped for dense annotations, where queried positions fill most of every window)
             const bool sparse_plan = (double)p->npos < 0.25 * (double)ntiles * (double)G;
-            int small_span = 512;                                          // tuning knobs
-            if (const char *env = getenv("PC_SMALL_G")) small_span = std::max(64, atoi(env) / 64 * 64);
-            const int small_g = (p->rows == 1 && sparse_plan && !getenv("PC_NO_SMALL")) ? std::min(small_span, G) : 0;
-            int64_t small_n = 2048;
-            if (const char *env = getenv("PC_SMALL_N")) small_n = std::max(64, atoi(env));
+            const int small_g = (p->rows == 1 && sparse_plan && !e->knobs.no_small) ? std::min(e->knobs.small_g, G) : 0;
+            const int64_t small_n = e->knobs.small_n;
             const int64_t cap_small = small_g ? (int64_t)ntiles * nfiles : 0;
             rc = e->d_work_small.reserve((size_t)std::max<int64_t>(cap_small, 1));
             if (rc != PC_OK) return rc;
@@ -1364,7 +1391,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const int64_t nthreads = (int64_t)ntiles * nfiles; // one thread per (tile, file)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
                                e->files[0]->view(), e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
-                               e->d_work_small.p, small_g, small_n, getenv("PC_DEBUG_WORK") ? 1 : 0);
+                               e->d_work_small.p, small_g, small_n, e->knobs.debug_work);
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
             int lmin = 65536, lmax = -1;
@@ -1446,7 +1473,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
 #undef PC_LAUNCH_SPLIT
             e->counters_zero = true;
             p->tile_items_zero = true;
-            if (getenv("PC_DEBUG_WORK")) { // diagnostics: how many work items of each class this call queued
+            if (e->knobs.debug_work) { // diagnostics: how many work items of each class this call queued
                 uint32_t c4[4] = {0, 0, 0, 0};
                 HIP_TRY(hipMemcpyAsync(c4, e->d_counters.p + 4, sizeof(c4), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
@@ -1476,9 +1503,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
             hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
                                p->d_ccand.p, p->d_cranges.p, total);
-            int ck1 = 8, ck2 = 4; // cut thresholds, in multiples of the mean candidate count (tuning knobs)
-            if (const char *env = getenv("PC_CENTER_T1")) ck1 = std::max(8, atoi(env));
-            if (const char *env = getenv("PC_CENTER_T2")) ck2 = std::max(1, atoi(env));
+            const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2; // cut thresholds, in multiples of the mean candidate count
             hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, (int64_t)2048, ck1, ck2,
                                p->d_corder.p, e->d_counters.p);
             hipLaunchKernelGGL(k_center, dim3((unsigned)((2 * nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks,
