@@ -8,21 +8,32 @@ A *step* is one pass of the hot path over one batch: every alignment record of
 the synthetic BAM (already packed and resident in HBM) is counted under the
 mapping rule into the per-position vectors of ALL transcripts of the annotation
 (int64, every chain laid out 5'->3') -- what ``for chain in transcripts:
-chain.get_counts(ga)`` does in the reference.  Default workload = BASELINE.json
+chain.get_counts(ga)`` does in the reference.  Headline workload = BASELINE.json
 ``configs[1]`` (C2): 100 M single-end reads, FivePrimeMapFactory(offset=12),
 20 k yeast-scale transcripts, one MI355X.
 
-At N > 1 every rank owns an independent shard of the same shape (its own
-records and the same annotation: weak scaling, no data-path collective); the
-only collective is an RCCL all-reduce of the summary totals.
+N = 1 (default): after the headline, the same process runs the other GPU configs
+of BASELINE.json -- C3 (center rule), whole C4 and whole C5 (they fit one GPU) --
+each parity-gated against the oracle on a seeded sample of chains; their numbers
+go to ``config.other_configs`` (``--other-configs none`` skips them).
+
+N > 1: ONE job over N GPUs (``--partition genome``, strong scaling): the genome
+is cut at record-count quantiles (``multigpu.GenomePartition``), every
+rank stages its record range plus halo and counts its segment pieces -- no
+data-path collective; per-chain sums are completed by one RCCL all-reduce of the
+engine's device buffer, timed separately.  ``--partition replicas`` gives every
+rank an independent shard of the same shape instead (weak scaling).
 
 Before anything is timed the GPU output is compared bit-for-bit with the oracle
-(``oracle/``) on a seeded sample of chains; a mismatch aborts the run.
+(``oracle/``) on a seeded sample of chains, and again after the timed steps; a
+mismatch aborts the run.
 """
 import argparse
+import gc
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,6 +44,7 @@ sys.path.insert(0, ROOT)
 from plastid_amd import synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SIZE_FILTER = (25, 100)  # the CLI default SizeFilterFactory (argparsers.py:355-380, 678-679)
 
 WORKLOAD_TEXT = {
     "C1": "C1: 1 M synthetic reads, FivePrimeMapFactory(offset=0), 200 yeast-scale SegmentChains",
@@ -43,38 +55,57 @@ WORKLOAD_TEXT = {
 }
 
 
-def oracle_spec(oracle, mapping):
+def oracle_spec(oracle, mapping, size_filter=None):
     kind = mapping[0]
     if kind in ("fiveprime", "threeprime", "center"):
-        return oracle.mapping_spec(kind, mapping[1])
+        return oracle.mapping_spec(kind, mapping[1], size_filter=size_filter)
     if kind == "variable":
-        return oracle.mapping_spec(kind, 0, mapping[1])
-    return oracle.mapping_spec(kind, 0, mapping[1], mapping[2], mapping[3])
+        return oracle.mapping_spec(kind, 0, mapping[1], size_filter=size_filter)
+    return oracle.mapping_spec(kind, 0, mapping[1], mapping[2], mapping[3], size_filter=size_filter)
 
 
-def scatter_expected(arrays, p, sel, rows, dtype, out_elems):
-    """Oracle per-segment arrays -> the plan's output layout (only segments `sel`)."""
-    out = np.zeros(out_elems, dtype)
+def sparse_expected(arrays, p, sel, rows):
+    """Oracle per-segment arrays -> (sorted element indices of the plan's output layout, values)."""
+    idxs, vals = [], []
     for arr, s in zip(arrays, sel):
         n = arr.shape[-1]
         idx = p["out_off"][s] + p["out_step"][s].astype(np.int64) * np.arange(n)
         a2 = arr.reshape(rows, n)
         for r in range(rows):
-            out[idx + r * p["row_stride"][s]] = a2[r]
-    return out
+            idxs.append(idx + r * p["row_stride"][s])
+            vals.append(a2[r])
+    if not idxs:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    idx = np.concatenate(idxs)
+    val = np.concatenate(vals)
+    o = np.argsort(idx, kind="stable")
+    return idx[o], val[o]
+
+
+def segments_of_chains(tx, chains):
+    return np.concatenate([np.arange(tx.ex_off[c], tx.ex_off[c + 1]) for c in chains]) if len(chains) else np.zeros(0, np.int64)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(oracle, aln, spec, p, tx, n_records, budget_s, rng):
-    """Time the oracle (single-threaded C port of the reference algorithm) on a
-    bounded, seeded sample of chains; report whole-job-equivalent reads/s."""
+    """Time the oracle (C port of the reference algorithm, one thread) on a bounded, seeded sample
+    of chains; report whole-job-equivalent reads/s.  Returns the sampled segments and their oracle
+    arrays too (they are the parity gate of the GPU run)."""
     order = rng.permutation(tx.n)
-    seg_of_chain = [np.arange(tx.ex_off[c], tx.ex_off[c + 1]) for c in order]
-    # pilot to size the sample
     done, t_used, results = 0, 0.0, []
     batch = 50
     while done < tx.n and t_used < budget_s:
         chains = order[done:done + batch]
-        sel = np.concatenate([seg_of_chain[k] for k in range(done, done + len(chains))])
+        sel = segments_of_chains(tx, chains)
         t0 = time.perf_counter()
         arrays, _ = oracle.count_segments(aln, spec, p["tid"][sel], p["start"][sel], p["end"][sel], p["strand"][sel])
         t_used += time.perf_counter() - t0
@@ -93,46 +124,328 @@ def cpu_baseline(oracle, aln, spec, p, tx, n_records, budget_s, rng):
                       "sampled fraction / time" % (done, tx.n, n_records, t_used)}, sel_all, arrays_all, order[:done]
 
 
-_MP = {}
-
-
-def _mp_worker(sel):
+def cpu_baseline_all_cores(oracle, aln, spec, p, tx, n_records, budget_s, rng, one_core_value):
+    """The same oracle on EVERY host core: the per-record arrays are derived once and shared, the
+    segments are dealt to one POSIX thread per core (the reference itself is single-threaded; whole
+    segments per thread is the most favourable honest scaling).  The sample is sized from the
+    one-core rate so that it takes about `budget_s` seconds of wall time."""
+    cores = os.cpu_count() or 1
+    if cores < 2:
+        return None
+    per_chain_s = (n_records / max(one_core_value, 1.0)) / tx.n          # one-core seconds per chain
+    nch = int(min(tx.n, max(4 * cores, budget_s * cores * 0.7 / max(per_chain_s, 1e-9))))
+    chains = rng.permutation(tx.n)[:nch]
+    sel = segments_of_chains(tx, chains)
+    none = sel[:0]
+    t0 = time.perf_counter()       # the once-per-file preparation (end coordinates, contig ranges), single-threaded
+    oracle.count_segments(aln, spec, p["tid"][none], p["start"][none], p["end"][none], p["strand"][none])
+    prep = time.perf_counter() - t0
     t0 = time.perf_counter()
-    _MP["oracle"].count_segments(_MP["aln"], _MP["spec"], _MP["p"]["tid"][sel], _MP["p"]["start"][sel],
-                                 _MP["p"]["end"][sel], _MP["p"]["strand"][sel])
-    return time.perf_counter() - t0
+    oracle.count_segments(aln, spec, p["tid"][sel], p["start"][sel], p["end"][sel], p["strand"][sel], threads=cores)
+    wall = time.perf_counter() - t0
+    work = max(wall - prep, 1e-6)
+    return {"value": n_records * (nch / float(tx.n)) / work, "unit": "reads/s", "cores": cores,
+            "sample": "%d of %d transcripts dealt to %d threads of one process (per-record arrays derived once and shared): "
+                      "%.2f s wall, of which %.2f s is that single-threaded once-per-file preparation (excluded from the rate)"
+                      % (nch, tx.n, cores, wall, prep)}
 
 
-def cpu_model():
+def load_traffic(config, n_records):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+        tj = json.load(open(tpath))
+    except Exception:
+        return None, None
+    for entry in ([tj] + list(tj.get("configs", {}).values())) if isinstance(tj, dict) else []:
+        if entry.get("config") == config and int(entry.get("n_records", -1)) == n_records:
+            return entry.get("hbm_bytes_per_launch"), entry
+    return None, None
+
+
+def run_workload(name, args, ctx, headline):
+    """One BASELINE config through the hot path.  Returns the result dict of that config."""
+    from oracle import oracle
+    from plastid_amd import multigpu
+    from plastid_amd.engine import Engine
+    from plastid_amd.packing import concat_file_major
+    rank, world = ctx["rank"], ctx["world"]
+    partition = ctx["partition"] if world > 1 else "none"
+    steps = args.steps if headline else max(3, min(args.steps, 10))
+    warmup = max(args.warmup, 1) if headline else 2
+    scale = args.scale
+    tx_scale = args.tx_scale
+
+    # ---------------------------------------------------------------- inputs (host)
+    t0 = time.perf_counter()
+    genome, tx, reads, mapping = synth.make_config(name, scale=scale, tx_scale=tx_scale,
+                                                   seed_shift=rank if partition == "replicas" else 0)
+    gen_s = time.perf_counter() - t0
+    center = mapping[0] == "center"
+    out_dtype = np.float64 if (center or args.out_dtype == "float64") else np.int64
+    factory = synth.mapping_factory(mapping)
+    rows = getattr(factory, "_numlengths", 1)
+    p = tx.plan_arrays(rows=rows)
+    n_job = int(reads.n)                      # records of the whole job this rank belongs to
+
+    # ---------------------------------------------------------------- oracle: CPU baseline and parity sample
+    cpu = None
+    aln = concat_file_major([reads])
+    spec = oracle_spec(oracle, mapping)
+    rng = np.random.default_rng(7 + (rank if partition == "replicas" else 0))
+    if headline and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, check_sel, check_arrays, _ = cpu_baseline(oracle, aln, spec, p, tx, reads.n, args.cpu_budget, rng)
+        cpu["all_cores"] = cpu_baseline_all_cores(oracle, aln, spec, p, tx, reads.n, min(args.cpu_budget, 10.0),
+                                                  np.random.default_rng(8), cpu["value"])
+        cpu["cpu_model"] = cpu_model()
+        cpu["host_cores"] = os.cpu_count()
+    else:
+        chains = rng.permutation(tx.n)[:min(tx.n, args.parity_chains)]
+        check_sel = segments_of_chains(tx, chains)
+        check_arrays, _ = oracle.count_segments(aln, spec, p["tid"][check_sel], p["start"][check_sel],
+                                                p["end"][check_sel], p["strand"][check_sel])
+    # the SizeFilterFactory(25,100) variant is gated on a small sample of its own
+    sf_chains = np.random.default_rng(9).permutation(tx.n)[:min(tx.n, 40)]
+    sf_sel = segments_of_chains(tx, sf_chains)
+    sf_arrays, _ = oracle.count_segments(aln, oracle_spec(oracle, mapping, SIZE_FILTER), p["tid"][sf_sel], p["start"][sf_sel],
+                                         p["end"][sf_sel], p["strand"][sf_sel])
+    del aln
+    exp = sparse_expected(check_arrays, p, check_sel, rows)        # (element indices, values) of the sampled chains
+    sf_exp = sparse_expected(sf_arrays, p, sf_sel, rows)
+    seg_sums = {int(s): a.reshape(rows, -1).sum(axis=1) for a, s in zip(check_arrays, check_sel)}  # for the chain-sum check
+    del check_arrays, sf_arrays
+
+    # ---------------------------------------------------------------- partition (N > 1, one job)
+    gp = None
+    my_reads, lp = reads, p
+    balance = None
+    if partition == "genome":
+        gp = multigpu.GenomePartition([reads], p, world)
+        my_reads = gp.records(rank)[0]
+        lp = gp.local_plan_arrays(rank, rows)
+
+    # ---------------------------------------------------------------- GPU
+    import torch
+    eng = Engine(ctx["dev_index"])
+    t0 = time.perf_counter()
+    eng.set_alignments([my_reads])
+    stage_s = time.perf_counter() - t0
+    factory._configure(eng)
+    t0 = time.perf_counter()
+    plan = eng.plan(lp["tid"], lp["start"], lp["end"], lp["strand"], lp["out_off"], lp["out_step"], lp["row_stride"],
+                    lp["out_elems"], rows)
+    plan_s = time.perf_counter() - t0
+
+    out_buf = np.zeros(lp["out_elems"], out_dtype)   # host side of the read-back, touched once
+
+    # where the sampled elements live in THIS rank's output: (local element index, global element index)
+    own = None if gp is None else gp.owned_elements(rank, rows, np.concatenate([check_sel, sf_sel]))
+
+    def gate(expected, what):
+        """Bit-exact comparison of the sampled elements this rank owns with the oracle."""
+        got = plan.read(out_buf)
+        e_idx, e_val = expected
+        if own is None:
+            ok, n = np.array_equal(got[e_idx], e_val.astype(got.dtype)), len(e_idx)
+        else:
+            li_, gi_ = own
+            pos = np.searchsorted(e_idx, gi_)
+            pos[pos >= len(e_idx)] = 0
+            hit = (e_idx[pos] == gi_) if len(e_idx) else np.zeros(len(gi_), bool)
+            ok, n = np.array_equal(got[li_[hit]], e_val[pos[hit]].astype(got.dtype)), int(hit.sum())
+        if not ok:
+            raise SystemExit("PARITY FAILURE (%s, %s): HIP counts differ from the oracle on the sampled chains" % (name, what))
+        return n
+
+    for _ in range(warmup):
+        plan.launch(out_dtype)
+    eng.sync()
+    t0 = time.perf_counter()
+    plan.read(out_buf)
+    read_s = time.perf_counter() - t0   # D2H of every output position
+    n_checked = gate(exp, "before timing")
+    total_counts = plan.total()
+
+    # ---------------------------------------------------------------- timed region
+    multigpu.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.launch(out_dtype)
+    eng.sync()
+    torch.cuda.synchronize()
+    multigpu.barrier()
+    elapsed = multigpu.max_over_ranks(time.perf_counter() - t0, device=ctx["tdev"])
+    gate(exp, "output of the last timed step")
+
+    # ---------------------------------------------------------------- per-kernel timing (HIP events on the engine's stream)
+    # The timed region above runs the product default (no events: each hipEventRecord costs a few
+    # microseconds of stream time).  The same launches are repeated here with the engine's phase
+    # events switched on; the dominant kernel's average duration feeds the roofline object.
+    phases = {"total": 0.0, "worklist": 0.0, "hist": 0.0, "long": 0.0, "gather": 0.0, "zero": 0.0}
+    m = max(3, min(steps, 20))
+    eng.set_profiling(2)
+    for _ in range(m):
+        plan.launch(out_dtype)
+        eng.sync()
+        for k, v in eng.last_timing().items():
+            phases[k] += v / m
+    eng.set_profiling(0)
+    alg_bytes_step = eng.last_algorithmic_bytes()
+
+    # ---------------------------------------------------------------- the CLI-default size filter (one extra run per config)
+    eng.set_size_filter(*SIZE_FILTER)
+    plan.launch(out_dtype)
+    eng.sync()
+    n_sf = gate(sf_exp, "SizeFilterFactory(25,100)")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.launch(out_dtype)
+    eng.sync()
+    sf_elapsed = multigpu.max_over_ranks(time.perf_counter() - t0, device=ctx["tdev"])
+    eng.set_size_filter(None)
+
+    # ---------------------------------------------------------------- collectives
+    n_records_all, counts_all, positions_all = multigpu.allreduce_int_totals(
+        [int(my_reads.n) if partition != "genome" else (int(reads.n) if rank == 0 else 0),
+         int(total_counts) if not center else 0, int(lp["out_elems"])], device=ctx["tdev"])
+    if center:
+        counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device=ctx["tdev"])[0]
+    allreduce = None
+    if gp is not None:
+        balance = multigpu.allreduce_int_totals([int(my_reads.n) if r == rank else 0 for r in range(world)], device=ctx["tdev"])
+        if not center:
+            # per-chain sums: every rank sums its pieces into one slot per (chain, row); ONE all-reduce
+            # of the engine's device buffer completes the chains that straddle a cut
+            seg_chain = np.repeat(np.arange(tx.n, dtype=np.int64), np.diff(tx.ex_off))
+            sp = gp.chain_sum_plan_arrays(rank, seg_chain, tx.n, rows)
+            splan = eng.plan(sp["tid"], sp["start"], sp["end"], sp["strand"], sp["out_off"], sp["out_step"], sp["row_stride"],
+                             sp["out_elems"], rows)
+            exp_sums = {}
+            for c in np.unique(seg_chain[check_sel]):
+                segs = np.arange(tx.ex_off[c], tx.ex_off[c + 1])
+                if all(int(s_) in seg_sums for s_ in segs):
+                    exp_sums[int(c)] = sum(seg_sums[int(s_)] for s_ in segs).astype(np.int64)
+            times = []
+            for it in range(4):
+                splan.launch(np.int64)
+                eng.sync()
+                torch.cuda.synchronize()
+                multigpu.barrier()
+                t0 = time.perf_counter()
+                if ctx["backend"] == "nccl":
+                    t = multigpu.allreduce_device_sums(splan.device_ptr, tx.n * rows, "int64")
+                    torch.cuda.synchronize()
+                    sums = None
+                else:   # rehearsal on CPU ranks (gloo): through the host
+                    sums = multigpu.allreduce_chain_sums(splan.read(), device="cpu")
+                times.append(time.perf_counter() - t0)
+            if sums is None:
+                sums = t.cpu().numpy()
+            for c, acc in exp_sums.items():
+                if not np.array_equal(sums[c * rows:(c + 1) * rows], acc):
+                    raise SystemExit("PARITY FAILURE (%s): all-reduced chain sums differ from the oracle" % name)
+            allreduce = {"what": "per-chain sums, int64[%d], RCCL all-reduce of the engine's device buffer" % (tx.n * rows),
+                         "ms": min(times[1:]) * 1e3, "chains_checked_vs_oracle": len(exp_sums)}
+            splan.close()
+
+    # ---------------------------------------------------------------- result of this config
+    n_extra_runs = int(len(my_reads.blk_start))
+    n_seg_local = int(len(lp["tid"]))
+    if center:
+        # k_center streams the candidate records and writes the float64 island histogram
+        kern_alg_bytes = my_reads.n * 8 + n_extra_runs * 8 + plan.positions * 8
+        kernel_name = "k_center"
+    else:
+        # dominant kernel = k_hist_point (fused): streams every packed record once (8 B) + the runs of
+        # gapped records (8 B each) + the segment table (24 B each) and writes every output position
+        # once (8 B) -- exactly SURVEY section 8(d)'s B_alg for the step
+        kern_alg_bytes = my_reads.n * 8 + n_extra_runs * 8 + n_seg_local * 24 + int(lp["out_elems"]) * 8
+        kernel_name = "k_hist_point"
+    kern_ms = phases["hist"]
+    achieved = kern_alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic, _ = load_traffic(name, int(my_reads.n)) if world == 1 else (None, None)
+    ms_per_step = elapsed / steps * 1e3
+    value = n_records_all * steps / elapsed
+    res = {
+        "workload": WORKLOAD_TEXT[name] + ("" if scale == 1.0 else " [scaled x%g]" % scale),
+        "value": value, "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
+        "dtype": "float64" if out_dtype == np.float64 else "int64",
+        "records_per_gpu": int(my_reads.n), "records_total": int(n_records_all),
+        "chains": int(tx.n), "segments": int(tx.n_segments), "output_positions_per_gpu": int(lp["out_elems"]),
+        "island_positions": int(plan.positions), "tiles": int(plan.tiles), "rows": rows,
+        "mapping": [str(x) for x in mapping], "read_seed": synth.CONFIGS[name][5], "transcript_seed": synth.CONFIGS[name][3],
+        "positions_per_sec": positions_all * steps / elapsed,
+        "parity": "bit-exact vs oracle on %d output positions (seeded sample of chains), before the timed steps and on "
+                  "the output of the last one" % n_checked,
+        "sum_of_counts_all_ranks": counts_all,
+        "host_generate_s": round(gen_s, 2), "host_stage_s": round(stage_s, 3), "host_read_outputs_s": round(read_s, 4),
+        "plan_build_ms_once_per_annotation": round(plan_s * 1e3, 2),
+        "algorithmic_bytes_per_step": int(alg_bytes_step),
+        "step_GBps_algorithmic": alg_bytes_step / (ms_per_step * 1e-3) / 1e9,
+        "kernel_ms": {k: round(v, 4) for k, v in phases.items()},
+        "size_filter_variant": {"filter": "SizeFilterFactory(25,100)", "ms_per_step": sf_elapsed / steps * 1e3,
+                                "reads_per_s": n_records_all * steps / sf_elapsed,
+                                "parity": "bit-exact vs oracle on %d positions" % n_sf},
+        # SURVEY 8(d): kernel scope = `value`; staged = + H2D staging of the packed arrays and D2H of every
+        # output; both from host buffers of the job (PCIe inclusive, never the headline value)
+        "scopes": {"kernel_reads_per_s": value,
+                   "staged_reads_per_s": my_reads.n / (stage_s + ms_per_step * 1e-3 + read_s) * (world if partition != "none" else 1)},
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_ms > 0) else None,
+                     "algorithmic_bytes_per_launch": int(kern_alg_bytes), "avg_launch_ms": kern_ms},
+        "cpu_baseline": cpu,
+    }
+    if gp is not None:
+        res["partition"] = {"mode": "genome ranges at record-count quantiles (multigpu.GenomePartition)",
+                            "records_per_rank": balance, "halo_positions": int(gp.halo), "allreduce": allreduce}
+    ctx["last_engine_objects"] = (eng, plan, my_reads)
+    return res
+
+
+def e2e_scope(args, ctx, name):
+    """SURVEY 8(d) t_e2e on a bounded sample: a BAM file written once (untimed) is decoded by the
+    native reader, staged, counted and read back."""
+    from plastid_amd.bam import read_bam
+    from plastid_amd.engine import Engine
+    from tests import bam_writer
+    n = int(args.e2e_records)
+    genome, tx, reads, mapping = synth.make_config(name, scale=n / float(synth.CONFIGS[name][4]), tx_scale=args.tx_scale)
+    factory = synth.mapping_factory(mapping)
+    rows = getattr(factory, "_numlengths", 1)
+    p = tx.plan_arrays(rows=rows)
+    tmp = tempfile.mkdtemp(prefix="pc_bench_")
+    path = os.path.join(tmp, "sample.bam")
+    nbytes = bam_writer.write_bam_packed(path, reads, threads=min(16, os.cpu_count() or 1))
+    fsize = os.path.getsize(path)
+    eng = Engine(ctx["dev_index"])
+    factory._configure(eng)
+    read_bam(path)                                   # page cache + library warm-up
+    t0 = time.perf_counter()
+    packed = read_bam(path)
+    t_decode = time.perf_counter() - t0
+    eng.set_alignments([packed])
+    t_stage = time.perf_counter() - t0 - t_decode
+    plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
+    got = plan.count(np.float64 if mapping[0] == "center" else np.int64)
+    t_all = time.perf_counter() - t0
+    ok = all(np.array_equal(getattr(packed, k), getattr(reads, k)) for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"))
+    plan.close()
+    eng.close()
+    try:
+        os.remove(path)
+        os.rmdir(tmp)
     except OSError:
         pass
-    return "unknown"
-
-
-def cpu_baseline_all_cores(oracle, aln, spec, p, tx, n_records, chains_done):
-    """The same oracle on every host core: one process per core over disjoint chain shards
-    (the reference itself is single-threaded; this is the most favourable honest scaling)."""
-    import multiprocessing as mp
-    # every worker re-derives the oracle's per-record arrays (16 B/record), so the process count
-    # is bounded by memory, not only by cores: at most 16 workers
-    cores = min(os.cpu_count() or 1, 16)
-    if cores < 2 or len(chains_done) < cores:
-        return None
-    _MP.update(oracle=oracle, aln=aln, spec=spec, p=p)
-    shards = np.array_split(np.asarray(chains_done), cores)
-    sels = [np.concatenate([np.arange(tx.ex_off[c], tx.ex_off[c + 1]) for c in sh]) for sh in shards]
-    ctx = mp.get_context("fork")  # before the GPU is initialised; children only run the C oracle
-    with ctx.Pool(cores) as pool:
-        t0 = time.perf_counter()
-        pool.map(_mp_worker, sels)
-        wall = time.perf_counter() - t0
-    frac = len(chains_done) / float(tx.n)
-    return {"value": n_records * frac / wall, "unit": "reads/s", "cores": cores,
-            "sample": "%d transcripts in %d forked processes: %.2f s wall" % (len(chains_done), cores, wall)}
+    if not ok:
+        raise SystemExit("e2e scope: the decoded BAM differs from the records it was written from")
+    del got
+    return {"e2e_reads_per_s": reads.n / t_all,
+            "e2e_sample": "%d records of %s written once (untimed) as a BGZF-compressed BAM of %.0f MB (%.0f MB inflated); timed: native "
+                          "decode %.3f s + staging %.3f s + plan, count and read-back %.3f s" %
+                          (reads.n, name, fsize / 1e6, nbytes / 1e6, t_decode, t_stage, t_all - t_decode - t_stage)}
 
 
 def main():
@@ -143,10 +456,19 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOAD_TEXT))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the read count (testing only)")
     ap.add_argument("--tx-scale", type=float, default=1.0)
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-dtype", default="int64", choices=["int64", "float64"])
+    ap.add_argument("--other-configs", default="auto",
+                    help="comma list of further configs run after the headline (auto: C3,C4,C5 at N=1 with the default "
+                         "headline, none otherwise)")
+    ap.add_argument("--partition", default="auto", choices=["auto", "genome", "replicas"],
+                    help="N > 1: one job cut into genome ranges (strong scaling, default) or independent replicas (weak)")
+    ap.add_argument("--parity-chains", type=int, default=200, help="chains of the parity sample when no CPU baseline is timed")
+    ap.add_argument("--time-budget", type=float, default=1200.0, help="seconds after which no further config is started")
+    ap.add_argument("--e2e-records", type=float, default=5e6, help="records of the BAM sample of the e2e scope (0: skip)")
     args = ap.parse_args()
+    t_start = time.perf_counter()
 
     from plastid_amd import multigpu
     rank, local_rank, world = multigpu.env_rank()
@@ -154,178 +476,113 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    partition = "genome" if args.partition == "auto" else args.partition
 
-    # ---------------------------------------------------------------- inputs (host)
-    t0 = time.perf_counter()
-    genome, tx, reads, mapping = synth.make_config(args.config, scale=args.scale, tx_scale=args.tx_scale,
-                                                   seed_shift=rank)
-    gen_s = time.perf_counter() - t0
-    center = mapping[0] == "center"
-    out_dtype = np.float64 if (center or args.out_dtype == "float64") else np.int64
-    factory = synth.mapping_factory(mapping)
-    rows = getattr(factory, "_numlengths", 1)
-    p = tx.plan_arrays(rows=rows)
-
-    # ---------------------------------------------------------------- CPU baseline (before the GPU is touched)
-    cpu = None
-    check_sel = check_arrays = None
-    from oracle import oracle
-    from plastid_amd.packing import concat_file_major
-    aln = concat_file_major([reads])
-    spec = oracle_spec(oracle, mapping)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, check_sel, check_arrays, chains_done = cpu_baseline(oracle, aln, spec, p, tx, reads.n, args.cpu_budget,
-                                                                 np.random.default_rng(7))
-        cpu["all_cores"] = cpu_baseline_all_cores(oracle, aln, spec, p, tx, reads.n, chains_done)
-        cpu["cpu_model"] = cpu_model()
-        cpu["host_cores"] = os.cpu_count()
-    else:
-        # parity gate only: a small seeded sample of chains
-        order = np.random.default_rng(7 + rank).permutation(tx.n)[:min(tx.n, 100)]
-        check_sel = np.concatenate([np.arange(tx.ex_off[c], tx.ex_off[c + 1]) for c in order])
-        check_arrays, _ = oracle.count_segments(aln, spec, p["tid"][check_sel], p["start"][check_sel],
-                                                p["end"][check_sel], p["strand"][check_sel])
-    del aln
-
-    # ---------------------------------------------------------------- GPU
     import torch
     import torch.distributed as dist
     # one rank per GPU over RCCL.  PC_BENCH_BACKEND=gloo is a rehearsal aid only: it lets the
     # multi-rank flow run on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("PC_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
-    tdev = "cuda" if backend == "nccl" else "cpu"
+    ctx = {"rank": rank, "world": world, "partition": partition, "backend": backend, "dev_index": dev_index,
+           "tdev": "cuda" if backend == "nccl" else "cpu"}
+
+    # The CPU baseline of the headline runs before this process initialises the GPU only in the
+    # sense that it never touches it; run_workload does oracle work first, then creates the engine.
     torch.cuda.set_device(dev_index)
     multigpu.init(backend, device=torch.device("cuda", dev_index))  # "nccl" is RCCL on ROCm
-    from plastid_amd.engine import Engine
-    eng = Engine(dev_index)
-    t0 = time.perf_counter()
-    eng.set_alignments([reads])
-    stage_s = time.perf_counter() - t0
-    factory._configure(eng)
-    t0 = time.perf_counter()
-    plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"],
-                    p["out_elems"], rows)
-    plan_s = time.perf_counter() - t0
 
-    barrier = multigpu.barrier
+    head = run_workload(args.config, args, ctx, headline=True)
+    eng, plan, _reads = ctx.pop("last_engine_objects")
+    stream_peak = None
+    if rank == 0:
+        try:
+            rd, wr = eng.stream_probe(1 << 30, 5)
+            stream_peak = {"read_GBps": rd, "write_GBps": wr,
+                           "what": "pc_stream_probe: 16-byte contiguous loads / 8-byte contiguous stores per lane over 1 GiB, "
+                                   "measured in this process"}
+        except Exception as e:  # a probe failure must not cost the bench line
+            stream_peak = {"error": str(e)}
+    plan.close()
+    eng.close()
+    del eng, plan, _reads
+    gc.collect()
 
-    for _ in range(max(args.warmup, 1)):
-        plan.launch(out_dtype)
-    eng.sync()
+    others = {}
+    want = args.other_configs
+    if want == "auto":
+        want = "C3,C4,C5" if (world == 1 and args.config == "C2" and args.scale == 1.0) else "none"
+    names = [c for c in want.split(",") if c and c != "none" and c != args.config]
+    for c in names:
+        if time.perf_counter() - t_start > args.time_budget:
+            others[c] = {"skipped": "time budget of %.0f s used up before this config" % args.time_budget}
+            continue
+        r = run_workload(c, args, ctx, headline=False)
+        e2, p2, _r2 = ctx.pop("last_engine_objects")
+        p2.close()
+        e2.close()
+        del e2, p2, _r2
+        gc.collect()
+        others[c] = {"workload": r["workload"], "ms_per_step": r["ms_per_step"], "reads_per_s": r["value"],
+                     "positions_per_sec": r["positions_per_sec"], "steps": r["steps"], "dtype": r["dtype"],
+                     "records": r["records_total"], "chains": r["chains"], "segments": r["segments"], "rows": r["rows"],
+                     "output_positions": r["output_positions_per_gpu"], "tiles": r["tiles"], "parity": r["parity"],
+                     "kernel_ms": r["kernel_ms"], "roofline": r["roofline"], "size_filter_variant": r["size_filter_variant"],
+                     "scopes": r["scopes"], "host_generate_s": r["host_generate_s"], "host_stage_s": r["host_stage_s"],
+                     "host_read_outputs_s": r["host_read_outputs_s"],
+                     "plan_build_ms_once_per_annotation": r["plan_build_ms_once_per_annotation"]}
+        if "partition" in r:
+            others[c]["partition"] = r["partition"]
 
-    # parity gate: bit-exact vs the oracle on the sampled chains
-    t0 = time.perf_counter()
-    got = plan.read()
-    read_s = time.perf_counter() - t0   # D2H of every output position (t_staged of SURVEY 8d = stage + step + this)
-    exp = scatter_expected(check_arrays, p, check_sel, rows, out_dtype, p["out_elems"])
-    touched = np.zeros(p["out_elems"], bool)
-    for s in check_sel:
-        n = p["end"][s] - p["start"][s]
-        idx = p["out_off"][s] + p["out_step"][s].astype(np.int64) * np.arange(n)
-        for r in range(rows):
-            touched[idx + r * p["row_stride"][s]] = True
-    if not np.array_equal(got[touched], exp[touched]):
-        raise SystemExit("PARITY FAILURE: HIP counts differ from the oracle on the sampled chains")
-    n_checked = int(touched.sum())
-    total_counts = plan.total()
-    del got, exp, touched
-
-    # ---------------------------------------------------------------- timed region
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        plan.launch(out_dtype)
-    eng.sync()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = multigpu.max_over_ranks(time.perf_counter() - t0, device=tdev)
-
-    # summary totals: the only collective (RCCL all-reduce over xGMI)
-    n_records_all, counts_all, positions_all = multigpu.allreduce_int_totals(
-        [int(reads.n), int(total_counts) if not center else 0, int(p["out_elems"])], device=tdev)
-    if center:
-        counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device=tdev)[0]
-
-    # ---------------------------------------------------------------- per-kernel timing (HIP events on the engine's stream)
-    # The timed region above runs the product default (no events: each hipEventRecord costs a few
-    # microseconds of stream time).  The same launches are repeated here with the engine's phase
-    # events switched on; the dominant kernel's average duration feeds the roofline object.
-    phases = {"total": 0.0, "worklist": 0.0, "hist": 0.0, "long": 0.0, "gather": 0.0, "zero": 0.0}
-    m = max(3, min(args.steps, 20))
-    eng.set_profiling(2)
-    for _ in range(m):
-        plan.launch(out_dtype)
-        eng.sync()
-        for k, v in eng.last_timing().items():
-            phases[k] += v / m
-    alg_bytes_step = eng.last_algorithmic_bytes()
+    e2e = None
+    if rank == 0 and world == 1 and args.e2e_records > 0 and time.perf_counter() - t_start <= args.time_budget:
+        try:
+            e2e = e2e_scope(args, ctx, args.config)
+        except SystemExit:
+            raise
+        except Exception as e:
+            e2e = {"error": str(e)}
 
     if rank == 0:
-        n_extra_runs = int(len(reads.blk_start))
-        if center:
-            # k_center streams the candidate records and writes the float64 island histogram
-            kern_alg_bytes = reads.n * 8 + n_extra_runs * 8 + plan.positions * 8
-        else:
-            # dominant kernel = k_hist_point (fused): streams every packed record once (8 B) + the
-            # runs of gapped records (8 B each) + the segment table (24 B each) and writes every
-            # output position once (8 B) -- exactly SURVEY section 8(d)'s B_alg for the step
-            kern_alg_bytes = reads.n * 8 + n_extra_runs * 8 + tx.n_segments * 24 + int(p["out_elems"]) * 8
-        kern_ms = phases["hist"]
-        achieved = kern_alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("config") == args.config and int(tj.get("n_records", -1)) == reads.n:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_records_all * args.steps / elapsed
+        roof = dict(head["roofline"])
+        if stream_peak and "read_GBps" in stream_peak:
+            roof["stream_peak_measured"] = stream_peak
+            roof["frac_of_measured_stream"] = roof["achieved"] / stream_peak["read_GBps"]
+            if roof.get("traffic"):
+                roof["frac_traffic_of_measured_stream"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / stream_peak["read_GBps"]
+        scopes = dict(head["scopes"])
+        if e2e:
+            scopes.update(e2e)
+        config = {k: head[k] for k in (
+            "workload", "records_per_gpu", "records_total", "chains", "segments", "output_positions_per_gpu", "island_positions",
+            "tiles", "rows", "mapping", "read_seed", "transcript_seed", "positions_per_sec", "parity", "sum_of_counts_all_ranks",
+            "host_generate_s", "host_stage_s", "host_read_outputs_s", "plan_build_ms_once_per_annotation",
+            "algorithmic_bytes_per_step", "step_GBps_algorithmic", "kernel_ms", "size_filter_variant")}
+        config["staged_stream_bytes_per_record"] = 4  # what the tile kernel reads; the algorithmic record is 8 B
+        config["scopes"] = scopes
+        if "partition" in head:
+            config["partition"] = head["partition"]
+        if others:
+            config["other_configs"] = others
+        config["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
         result = {
             "metric": "mapped_reads_per_sec",
-            "value": value,
+            "value": head["value"],
             "unit": "reads/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if (world == 1 or partition == "replicas") else "strong",
             "vs_baseline": None,
-            "dtype": "float64" if out_dtype == np.float64 else "int64",
+            "dtype": head["dtype"],
             "data": "synthetic",
-            "config": {
-                "workload": WORKLOAD_TEXT[args.config] + ("" if args.scale == 1.0 else " [scaled x%g]" % args.scale),
-                "records_per_gpu": int(reads.n), "records_total": n_records_all,
-                "chains": int(tx.n), "segments": int(tx.n_segments), "output_positions_per_gpu": int(p["out_elems"]),
-                "island_positions": int(plan.positions), "tiles": int(plan.tiles), "rows": rows,
-                "mapping": [str(x) for x in mapping], "read_seed": synth.CONFIGS[args.config][5],
-                "transcript_seed": synth.CONFIGS[args.config][3],
-                "positions_per_sec": positions_all * args.steps / elapsed,
-                "parity": "bit-exact vs oracle on %d output positions (seeded sample of chains)" % n_checked,
-                "sum_of_counts_all_ranks": counts_all,
-                "host_generate_s": round(gen_s, 2), "host_stage_s": round(stage_s, 2), "host_read_outputs_s": round(read_s, 3),
-                "plan_build_ms_once_per_annotation": round(plan_s * 1e3, 2),
-                "algorithmic_bytes_per_step": int(alg_bytes_step),
-                "staged_stream_bytes_per_record": 4,  # what the tile kernel reads; the algorithmic record is 8 B
-                "step_GBps_algorithmic": alg_bytes_step / (ms_per_step * 1e-3) / 1e9,
-                "kernel_ms": {k: round(v, 4) for k, v in phases.items()},
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_center" if center else "k_hist_point",
-                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(kern_alg_bytes), "avg_launch_ms": kern_ms,
-            },
-            "cpu_baseline": cpu,
+            "config": config,
+            "roofline": roof,
+            "cpu_baseline": head["cpu_baseline"],
         }
         print(json.dumps(result))
-    plan.close()
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
 

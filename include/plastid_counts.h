@@ -90,7 +90,9 @@ int pc_reload_knobs(pc_engine *e);
  * 349, 448, 629, 769, 838.  One call per BAM file, in the order the files were
  * given to BAMGenomeArray (file-major order matters, genome_array.py:800-809).
  *
- *   n          records, sorted by (tid, pos), ties in file order
+ *   n          records, sorted by (tid, pos), ties in file order; at most 2^32 - 2 per file (and as
+ *              many runs): record indices and window bins are 32-bit (PC_ERR_ARG beyond that --
+ *              split larger inputs into several files, which are counted as one)
  *   tid,pos    reference index (0 <= tid < ntid) and leftmost aligned coordinate
  *   alen       L = len(read.positions): aligned reference positions (M/=/X)
  *   flags      PC_FLAG_* bits
@@ -188,6 +190,11 @@ int pc_set_profiling(pc_engine *e, int level);
 int pc_last_timing(pc_engine *e, double *ms, int n);
 /* algorithmic bytes of the last pc_count (SURVEY.md section 8d formula) */
 int64_t pc_last_algorithmic_bytes(pc_engine *e);
+/* Measured streaming rates of this GPU (GB/s) for the access patterns of the tile kernel: 16-byte
+ * contiguous loads per lane and 8-byte contiguous stores per lane over a buffer of `bytes` bytes
+ * (>= 1 MiB; use several hundred MB to get past the 256 MiB Infinity Cache).  The second roofline
+ * denominator of SURVEY.md 8(d); no reference counterpart. */
+int pc_stream_probe(pc_engine *e, int64_t bytes, int iters, double *read_gbps, double *write_gbps);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pc_set_profiling": (_int, [_vp, _int]),
     "pc_last_timing": (_int, [_vp, _vp, _int]),
     "pc_last_algorithmic_bytes": (_i64, [_vp]),
+    "pc_stream_probe": (_int, [_vp, _i64, _int, _vp, _vp]),
 }
 
 _lib = None

@@ -1545,6 +1545,34 @@ __global__ __launch_bounds__(kWG) void k_rle_write(const unsigned long long *__r
     }
 }
 
+// ---------------------------------------------------------------- streaming probes
+// Measurement helpers (pc_stream_probe): what this GPU sustains for the two access patterns of the
+// tile kernel -- 16-byte-per-lane contiguous loads (one contiguous chunk per workgroup, four loads
+// in flight per lane) and 8-byte-per-lane contiguous stores.  The measured read rate is the second
+// roofline denominator of bench.py; the store kernel is also the known byte count on
+// which the WRITE_SIZE counter is calibrated (profiles/traffic.json).
+constexpr int kProbeChunk = 16384;   // 16-byte vectors per workgroup (256 KiB)
+__global__ __launch_bounds__(kWG) void k_probe_read(const u32x4 *__restrict__ src_, int64_t nvec, uint32_t *sink) {
+    const u32x4 PC_GLOBAL *src = (const u32x4 PC_GLOBAL *)src_;
+    const int64_t lo = (int64_t)blockIdx.x * kProbeChunk;
+    const int64_t hi = lo + kProbeChunk < nvec ? lo + kProbeChunk : nvec;
+    uint32_t acc = 0;
+    for (int64_t b = lo + threadIdx.x; b < hi; b += 4 * kWG) {
+        u32x4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = b + u * kWG < hi ? src[b + u * kWG] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= r[u].x ^ r[u].y ^ r[u].z ^ r[u].w;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;   // never true for the probe's fill pattern; keeps the loads alive
+}
+
+__global__ __launch_bounds__(kWG) void k_probe_write(unsigned long long *dst, int64_t n) {
+    const int64_t lo = (int64_t)blockIdx.x * (2 * kProbeChunk);
+    const int64_t hi = lo + 2 * kProbeChunk < n ? lo + 2 * kProbeChunk : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kWG) dst[i] = (unsigned long long)i;
+}
+
 // ---------------------------------------------------------------- k_mapped_reads
 // reads_out of the map functions for ONE segment (genome_array.py:800-823).
 __global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fview, MapParams mp, int64_t rec_lo, int64_t rec_hi,

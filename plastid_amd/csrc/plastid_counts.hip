@@ -1656,6 +1656,34 @@ int pc_last_timing(pc_engine *e, double *ms, int n) {
 
 int64_t pc_last_algorithmic_bytes(pc_engine *e) { return e ? e->last_alg_bytes : -1; }
 
+int pc_stream_probe(pc_engine *e, int64_t bytes, int iters, double *read_gbps, double *write_gbps) {
+    if (!e || bytes < (1 << 20) || iters < 1) return fail(PC_ERR_ARG, "pc_stream_probe: bad arguments");
+    HIP_TRY(hipSetDevice(e->device));
+    DevBuf<uint8_t> buf;
+    int rc = buf.reserve((size_t)bytes);
+    if (rc != PC_OK) return rc;
+    hipStream_t st = e->stream;
+    const int64_t nvec = bytes / 16, n8 = bytes / 8;
+    const unsigned grid_r = (unsigned)((nvec + kProbeChunk - 1) / kProbeChunk), grid_w = (unsigned)((n8 + 2 * kProbeChunk - 1) / (2 * kProbeChunk));
+    uint32_t *sink = e->d_counters.p + 7;   // a word no kernel of the counting path reads
+    float ms = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {   // pass 0: stores (also fills the buffer), pass 1: loads
+        for (int it = -1; it < iters; ++it) {   // one untimed launch first
+            if (it == 0) HIP_TRY(hipEventRecord(e->ev[6], st));
+            if (pass == 0) hipLaunchKernelGGL(k_probe_write, dim3(grid_w), dim3(kWG), 0, st, (unsigned long long *)buf.p, n8);
+            else hipLaunchKernelGGL(k_probe_read, dim3(grid_r), dim3(kWG), 0, st, (const u32x4 *)buf.p, nvec, sink);
+        }
+        HIP_TRY(hipEventRecord(e->ev[7], st));
+        HIP_TRY(hipEventSynchronize(e->ev[7]));
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev[6], e->ev[7]));
+        const double gbps = (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
+        if (pass == 0 && write_gbps) *write_gbps = gbps;
+        if (pass == 1 && read_gbps) *read_gbps = gbps;
+    }
+    HIP_TRY(hipGetLastError());
+    return PC_OK;
+}
+
 // ------------------------------------------------------------------ warnings
 int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
     if (!e || !p || p->e != e || (p->nseg > 0 && !flags)) return fail(PC_ERR_ARG, "pc_warn_flags: bad arguments");

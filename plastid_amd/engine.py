@@ -141,6 +141,16 @@ class Engine(object):
         names = ("total", "worklist", "hist", "long", "gather", "zero")
         return dict(zip(names, ms.tolist()))
 
+    def stream_probe(self, nbytes=1 << 30, iters=5):
+        """Measured streaming rates of this GPU in GB/s: ``(16-byte loads, 8-byte stores)``."""
+        r = np.zeros(2, np.float64)
+        check(self._lib.pc_stream_probe(self._h, int(nbytes), int(iters), r.ctypes.data, r.ctypes.data + 8))
+        return float(r[0]), float(r[1])
+
+    def reload_knobs(self):
+        """Re-read the PC_* environment knobs (they are read once, when the engine is created)."""
+        check(self._lib.pc_reload_knobs(self._h))
+
     def last_algorithmic_bytes(self):
         return int(self._lib.pc_last_algorithmic_bytes(self._h))
 

@@ -205,6 +205,42 @@ class GenomePartition(object):
                     out_step=np.ones(len(ln), np.int8), row_stride=ln.astype(np.int64), out_elems=int(off[-1]),
                     piece_index=sg["piece_index"])
 
+    def owned_elements(self, rank, rows=1, segments=None):
+        """Where rank `rank`'s local output (see :meth:`local_plan_arrays`) sits in the caller's global
+        layout: ``(local_index, global_index)`` element arrays, optionally only for the pieces of the
+        given segment indices.  Summed slices (``out_step`` 0) are not covered."""
+        lp = self.local_plan_arrays(rank, rows)
+        want = None
+        if segments is not None:
+            want = np.zeros(len(self.seg["tid"]), bool)
+            want[np.asarray(segments, np.int64)] = True
+        pc = self.piece
+        li, gi = [], []
+        for j, pi in enumerate(lp["piece_index"]):
+            if want is not None and not want[pc["owner"][pi]]:
+                continue
+            n = int(lp["end"][j] - lp["start"][j])
+            if n <= 0:
+                continue
+            g0, st, rs = int(pc["out_off"][pi]), int(pc["out_step"][pi]), int(pc["row_stride"][pi])
+            for r in range(rows):
+                li.append(lp["out_off"][j] + r * n + np.arange(n))
+                gi.append(g0 + r * rs + st * np.arange(n))
+        z = np.zeros(0, np.int64)
+        return (np.concatenate(li) if li else z, np.concatenate(gi) if gi else z)
+
+    def chain_sum_plan_arrays(self, rank, seg_chain, n_chains, rows=1):
+        """``pc_plan_create`` arrays that make rank `rank` SUM each of its pieces into slot
+        ``chain * rows + row`` of an ``int64[n_chains * rows]`` buffer (``out_step`` 0); one
+        all-reduce of that buffer over the ranks completes the chains that straddle a cut
+        (:func:`allreduce_device_sums`).  `seg_chain[s]` = chain of segment ``s``."""
+        sg = self.segments(rank)
+        owner = self.piece["owner"][sg["piece_index"]]
+        k = len(owner)
+        return dict(tid=sg["tid"], start=sg["start"], end=sg["end"], strand=sg["strand"],
+                    out_off=np.asarray(seg_chain, np.int64)[owner] * rows, out_step=np.zeros(k, np.int8),
+                    row_stride=np.ones(k, np.int64), out_elems=int(n_chains) * rows)
+
     def scatter_local(self, global_out, rank, local_out, rows=1):
         """Place a rank-local result (see :meth:`local_plan_arrays`) into the caller's global layout
         (host-side assembly of chains whose exons straddle a cut)."""
@@ -232,3 +268,29 @@ def allreduce_chain_sums(values, device="cpu"):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+class _DevicePointer(object):
+    """``__cuda_array_interface__`` view of memory some engine owns (no copy, no ownership)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, n, dtype="int64"):
+    """A ``torch`` tensor over `n` elements at device address `ptr` (e.g. ``Plan.device_ptr``): lets
+    RCCL reduce the engine's output in place, without a host round trip."""
+    import torch
+    typestr = {"int64": "<i8", "float64": "<f8"}[dtype]
+    return torch.as_tensor(_DevicePointer(ptr, n, typestr), device="cuda")
+
+
+def allreduce_device_sums(ptr, n, dtype="int64"):
+    """In-place all-reduce (RCCL ``ncclSum`` over xGMI) of `n` int64 / float64 values at device
+    address `ptr`.  The caller synchronises the engine's stream first: RCCL runs on torch's stream.
+    Returns the tensor view."""
+    import torch.distributed as dist
+    t = device_tensor(ptr, n, dtype)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t

@@ -132,3 +132,94 @@ def packed_to_records(packed):
         flag = 16 if packed.flags[i] & 1 else 0
         recs.append((int(packed.tid[i]), int(packed.pos[i]), cig, flag))
     return recs
+
+
+def reg2bin_array(beg, end):
+    """Vectorised :func:`reg2bin`."""
+    beg = np.asarray(beg, np.int64)
+    end = np.asarray(end, np.int64) - 1
+    out = np.zeros(len(beg), np.int64)
+    done = np.zeros(len(beg), bool)
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        hit = ~done & ((beg >> shift) == (end >> shift))
+        out[hit] = off + (beg[hit] >> shift)
+        done |= hit
+    return out
+
+
+def write_bam_packed(path, packed, block_bytes=60000, level=1, threads=8):
+    """Vectorised writer for a whole :class:`PackedAlignments` (millions of records): every record
+    becomes ``<run>M`` ops joined by ``N`` gaps, name ``r``, no sequence (``l_seq`` 0).  BGZF members
+    are deflated on a thread pool.  Same format as :func:`write_bam`, no index."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = packed.n
+    text = b"@HD\tVN:1.6\tSO:coordinate\n"
+    head = b"BAM\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(packed.references))
+    for nm, ln in zip(packed.references, packed.lengths):
+        nmb = nm.encode() + b"\x00"
+        head += struct.pack("<I", len(nmb)) + nmb + struct.pack("<I", int(ln))
+    nblk = np.maximum(packed.nblk.astype(np.int64), 0)
+    ncig = np.where(nblk >= 1, 2 * nblk - 1, 0)
+    size = 38 + 4 * ncig                                   # block_size field included
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(size, out=off[1:])
+    buf = np.zeros(int(off[-1]), np.uint8)
+    rec0 = off[:-1]
+
+    def put(rel, width, values):
+        v = np.asarray(values, np.int64)
+        for k in range(width):
+            buf[rec0 + rel + k] = (v >> (8 * k)) & 0xff
+
+    end = packed.ref_end().astype(np.int64)
+    put(0, 4, size - 4)
+    put(4, 4, packed.tid)
+    put(8, 4, packed.pos)
+    put(12, 1, np.full(n, 2))                              # l_read_name ("r\0")
+    put(13, 1, np.full(n, 30))
+    put(14, 2, reg2bin_array(packed.pos, end))
+    put(16, 2, ncig)
+    put(18, 2, np.where(packed.flags & 1, 16, 0))
+    put(20, 4, np.zeros(n, np.int64))                      # l_seq
+    put(24, 4, np.full(n, -1) & 0xffffffff)
+    put(28, 4, np.full(n, -1) & 0xffffffff)
+    put(32, 4, np.zeros(n, np.int64))
+    buf[rec0 + 36] = ord("r")
+    # CIGAR: single-run records <L>M; multi-run records M N M ...
+    single = nblk == 1
+    v = (packed.alen[single].astype(np.int64) << 4) | 0
+    base = rec0[single] + 38
+    for k in range(4):
+        buf[base + k] = (v >> (8 * k)) & 0xff
+    multi = np.nonzero(nblk >= 2)[0]
+    if len(multi):
+        boff = packed.block_offsets()
+        owner = np.repeat(multi, nblk[multi])
+        j = np.arange(len(owner)) - np.repeat(np.cumsum(nblk[multi]) - nblk[multi], nblk[multi])   # run index in its record
+        run = boff[owner] + j
+        st, ln = packed.blk_start[run].astype(np.int64), packed.blk_len[run].astype(np.int64)
+        mbase = rec0[owner] + 38 + 8 * j
+        mv = (ln << 4) | 0
+        for k in range(4):
+            buf[mbase + k] = (mv >> (8 * k)) & 0xff
+        gap = j > 0
+        prev_end = np.zeros(len(owner), np.int64)
+        prev_end[1:] = (st + ln)[:-1]
+        gv = ((st - prev_end)[gap] << 4) | 3
+        gbase = mbase[gap] - 4
+        for k in range(4):
+            buf[gbase + k] = (gv >> (8 * k)) & 0xff
+    data = head + buf.tobytes()
+
+    def member(i):
+        raw = data[i:i + block_bytes]
+        comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cdata = comp.compress(raw) + comp.flush()
+        return (struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(cdata) + 25) + cdata +
+                struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw)))
+
+    with ThreadPoolExecutor(max(1, threads)) as pool, open(path, "wb") as fh:
+        for blk in pool.map(member, range(0, len(data), block_bytes)):
+            fh.write(blk)
+        fh.write(BGZF_EOF)
+    return len(data)

@@ -156,3 +156,72 @@ def test_two_rank_genome_partition_chain_sums(tmp_path):
     for s, a in enumerate(arr):
         want[tx.ex_tx[s]] += a.sum()
     assert np.array_equal(tot[0], want)
+
+
+# ---------------------------------------------------------------------------- the bench's one-job mode
+def _bench_partition_worker(rank, world, port, out_dir):
+    """What ``bench.py --gpus N --partition genome`` does per rank, with the oracle standing in for the
+    engine: stage the rank's records, count its pieces in the rank-local layout, check the sampled
+    elements it owns against the global expectation (``owned_elements``), sum its pieces per chain
+    (``chain_sum_plan_arrays``) and complete the sums with one all-reduce."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    from plastid_amd import multigpu, synth
+    from plastid_amd.packing import concat_file_major
+    multigpu.init("gloo")
+    rows = 5
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.003)
+    spec = oracle.mapping_spec("stratified", 0, synth.VARIABLE_OFFSETS, 27, 31)
+    p = tx.plan_arrays(rows=rows)
+    part = multigpu.GenomePartition([reads], p, world)
+    lp = part.local_plan_arrays(rank, rows)
+    mine = concat_file_major(part.records(rank))
+    arr, _ = oracle.count_segments(mine, spec, lp["tid"], lp["start"], lp["end"], lp["strand"])
+    local = np.concatenate([a.reshape(-1) for a in arr]) if len(arr) else np.zeros(0, np.int64)
+    sample = np.arange(0, len(p["tid"]), 3)
+    li, gi = part.owned_elements(rank, rows, sample)
+    np.save(os.path.join(out_dir, "own%d.npy" % rank), np.stack([gi, local[li]]))
+    seg_chain = tx.ex_tx.astype(np.int64)
+    sp = part.chain_sum_plan_arrays(rank, seg_chain, tx.n, rows)
+    arr2, _ = oracle.count_segments(mine, spec, sp["tid"], sp["start"], sp["end"], sp["strand"])
+    sums = np.zeros(sp["out_elems"], np.int64)
+    for j, a in enumerate(arr2):
+        for r in range(rows):
+            sums[sp["out_off"][j] + r * sp["row_stride"][j]] += a.reshape(rows, -1)[r].sum()
+    np.save(os.path.join(out_dir, "bsum%d.npy" % rank), multigpu.allreduce_chain_sums(sums))
+
+
+def test_two_rank_bench_partition_path(tmp_path):
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_bench_partition_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle
+    from plastid_amd import synth
+    from plastid_amd.packing import concat_file_major
+    rows = 5
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.003)
+    spec = oracle.mapping_spec("stratified", 0, synth.VARIABLE_OFFSETS, 27, 31)
+    p = tx.plan_arrays(rows=rows)
+    want = _oracle_global(oracle, [reads], spec, p, rows, np.int64)
+    covered = np.zeros(p["out_elems"], bool)
+    for r in range(world):
+        gi, val = np.load(os.path.join(str(tmp_path), "own%d.npy" % r))
+        assert np.array_equal(want[gi], val)             # every owned element equals the unpartitioned job's
+        assert not covered[gi].any()                     # and is owned by exactly one rank
+        covered[gi] = True
+    sample = np.arange(0, len(p["tid"]), 3)
+    expect = np.zeros(p["out_elems"], bool)
+    for s in sample:
+        n = int(p["end"][s] - p["start"][s])
+        for r in range(rows):
+            expect[p["out_off"][s] + r * p["row_stride"][s] + p["out_step"][s].astype(np.int64) * np.arange(n)] = True
+    assert np.array_equal(covered, expect)               # the ranks' pieces tile the sampled segments
+    sums = [np.load(os.path.join(str(tmp_path), "bsum%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(sums[0], sums[1])
+    chain_want = np.zeros(tx.n * rows, np.int64)
+    arr, _ = oracle.count_segments(concat_file_major([reads]), spec, p["tid"], p["start"], p["end"], p["strand"])
+    for s, a in enumerate(arr):
+        chain_want[tx.ex_tx[s] * rows:(tx.ex_tx[s] + 1) * rows] += a.reshape(rows, -1).sum(axis=1)
+    assert np.array_equal(sums[0], chain_want)

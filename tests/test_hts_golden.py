@@ -1,0 +1,158 @@
+"""The CIGAR -> positions step, the BAM / BGZF / BAI reader and the fetch emulations against
+fixtures produced by the REFERENCE-HELD htslib itself (``tests/golden/hts_fixture.npz``, made in the
+build container by ``tests/golden/make_hts_golden.py`` from htslib 1.3 as vendored under
+``/root/reference/kent/src/htslib``: ``sam_write1`` / ``sam_index_build`` wrote the bytes,
+``bam_endpos``, a ``bam_cigar_type``-driven CIGAR walk and ``sam_itr_queryi`` produced the
+expectations).  pysam delegates exactly these steps to htslib (genome_array.py:800-809,
+map_factories.pyx:243), so this pins what SURVEY 8(c) lists as unpinned by runnable reference tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from plastid_amd import packing  # noqa: E402
+from plastid_amd.bam import read_bam  # noqa: E402
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hts_fixture.npz")
+
+
+@pytest.fixture(scope="module")
+def hts():
+    return np.load(FIX)
+
+
+@pytest.fixture(scope="module")
+def bam_path(hts, tmp_path_factory):
+    d = tmp_path_factory.mktemp("hts")
+    path = str(d / "htslib.bam")
+    open(path, "wb").write(hts["bam"].tobytes())
+    open(path + ".bai", "wb").write(hts["bai"].tobytes())
+    return path
+
+
+def _placed(hts):
+    return np.nonzero(hts["tid"] >= 0)[0]
+
+
+def _htslib_runs(hts, i):
+    """Maximal runs of the aligned reference positions htslib reports for record i."""
+    p = hts["positions"][hts["positions_off"][i]:hts["positions_off"][i + 1]]
+    return packing.positions_to_runs(p), len(p)
+
+
+def test_fixture_covers_every_cigar_operation(hts):
+    assert set(np.unique(hts["cigar_op"])) == set(range(9))                 # M I D N S H P = X
+    n_ops = np.diff(hts["cigar_off"])
+    assert (n_ops == 0).sum() >= 5 and n_ops.max() >= 8                     # CIGAR-less placed reads, long CIGARs
+    assert (hts["flag"] & 0x4).any() and (hts["flag"] & 0x100).any() and (hts["flag"] & 0x400).any()
+    assert (hts["tid"] < 0).sum() == int(hts["n_no_coor"]) == 2
+
+
+def test_cigar_to_runs_python_and_oracle_match_htslib(hts):
+    """packing.cigar_to_runs (product) and po_cigar_to_runs (oracle) give htslib's positions, and the
+    reference end they imply is bam_endpos (sam.c:329-341)."""
+    from oracle import oracle
+    for i in _placed(hts):
+        ops = hts["cigar_op"][hts["cigar_off"][i]:hts["cigar_off"][i + 1]]
+        lens = hts["cigar_len"][hts["cigar_off"][i]:hts["cigar_off"][i + 1]]
+        cig = [(int(o), int(n)) for o, n in zip(ops, lens)]
+        want_runs, want_len = _htslib_runs(hts, i)
+        runs, L = packing.cigar_to_runs(int(hts["pos"][i]), cig)
+        assert runs == want_runs and L == want_len, i
+        oruns, oL = oracle.cigar_to_runs(int(hts["pos"][i]), cig) if cig else ([], 0)
+        assert oruns == want_runs and oL == want_len, i
+        # end coordinate: htslib's bam_endpos counts every reference-consuming op, pos + 1 without any
+        ref_len = sum(n for o, n in cig if o in (0, 2, 3, 7, 8))
+        assert int(hts["endpos"][i]) == int(hts["pos"][i]) + (ref_len if ref_len > 0 else 1)
+
+
+def test_native_reader_decodes_the_htslib_written_bam(hts, bam_path):
+    """bam_stager.cpp on bytes written by htslib: records, aligned runs, strand bit, mapped count."""
+    for threads in (1, 4):
+        got = read_bam(bam_path, threads=threads)
+        keep = _placed(hts)                                                  # unplaced reads are never fetched
+        assert got.n == len(keep)
+        assert list(got.references) == [str(x) for x in hts["references"]]
+        assert list(got.lengths) == [int(x) for x in hts["lengths"]]
+        assert np.array_equal(got.tid, hts["tid"][keep]) and np.array_equal(got.pos, hts["pos"][keep])
+        assert np.array_equal(got.flags & 1, (hts["flag"][keep] >> 4) & 1)   # FLAG 0x10 -> is_reverse
+        assert got.mapped == int(hts["index_stat"][:, 1].sum())             # pysam AlignmentFile.mapped
+        assert got.mapped == int(((hts["flag"][keep] & 0x4) == 0).sum())
+        for j, i in enumerate(keep):
+            runs, L = _htslib_runs(hts, i)
+            assert int(got.alen[j]) == L, i
+            assert got.runs_of(j) == (runs if L else []), i
+        # reference end as the fetch emulation uses it == bam_endpos
+        assert np.array_equal(got.ref_end(), hts["endpos"][keep])
+
+
+def test_region_reads_through_the_bai_match_hts_itr_query(hts, bam_path):
+    """read_bam(regions=...) (BAI bins + linear index + overlap test) returns exactly the records
+    htslib's iterator yields (hts.c:1924-1960), for every seeded region; so do the pure-Python fetch of
+    PackedAlignments and the oracle's fetch emulation."""
+    from oracle import oracle
+    from plastid_amd.packing import concat_file_major
+    whole = read_bam(bam_path)
+    keep = _placed(hts)
+    rec_of = {int(i): j for j, i in enumerate(keep)}
+    refs = [str(x) for x in hts["references"]]
+    aln = concat_file_major([whole])
+    spec = oracle.mapping_spec("center", 0)      # reads_out of the center rule = every fetched read with L > 0
+    for q, (tid, beg, end) in enumerate(hts["regions"]):
+        want = hts["region_records"][hts["region_off"][q]:hts["region_off"][q + 1]]
+        want_j = np.array([rec_of[int(i)] for i in want], np.int64)
+        # the Python duck type of AlignmentFile.fetch
+        got_idx = whole.fetch_indices(refs[tid], int(beg), int(end))
+        assert np.array_equal(got_idx, want_j), (q, tid, beg, end)
+        # the native reader through the index
+        part = read_bam(bam_path, regions=[(refs[tid], int(beg), int(end))])
+        assert part.n == len(want_j), (q, tid, beg, end)
+        assert np.array_equal(part.pos, whole.pos[want_j]) and np.array_equal(part.alen, whole.alen[want_j])
+        assert np.array_equal(part.flags, whole.flags[want_j])
+        # the oracle's fetch emulation (what po_segment hands to the map function)
+        if q % 8 == 0:
+            _, _, mapped = oracle.count_segments(aln, spec, [tid], [int(beg)], [int(end)], [3], want_mapped=True)
+            assert np.array_equal(np.nonzero(mapped[0])[0], want_j[whole.alen[want_j] > 0]), (q, tid, beg, end)
+
+
+@pytest.mark.gpu
+def test_htslib_bam_end_to_end_on_the_gpu(hts, bam_path):
+    """The htslib-written BAM staged by the native reader and counted by the HIP kernels equals the
+    oracle run on htslib's own positions -- all five rules, whole contigs and short segments."""
+    from oracle import oracle
+    import plastid_amd as pa
+    from plastid_amd import synth
+    keep = _placed(hts)
+    runs = [_htslib_runs(hts, i)[0] for i in keep]
+    ref = pa.PackedAlignments.from_runs([int(t) for t in hts["tid"][keep]], [bool(f & 16) for f in hts["flag"][keep]], runs,
+                                        references=[str(x) for x in hts["references"]], lengths=[int(x) for x in hts["lengths"]],
+                                        positions=[int(p) for p in hts["pos"][keep]])
+    aln = pa.packing.concat_file_major([ref])
+    lens = [int(x) for x in hts["lengths"]]
+    seg_tid = np.array([0, 0, 1, 1, 2, 0, 0], np.int32)
+    seg_start = np.array([0, 0, 0, 1000, 0, 20000, 150000], np.int64)
+    seg_end = np.array([lens[0], lens[0], lens[1], 30000, lens[2], 20300, 190000], np.int64)
+    seg_strand = np.array([1, 2, 3, 2, 1, 3, 1], np.uint8)
+    ga_bam = read_bam(bam_path)
+    eng = pa.engine.Engine(0)
+    eng.set_alignments([ga_bam])
+    for mapping in (("fiveprime", 3), ("threeprime", 0), ("center", 1), ("variable", synth.VARIABLE_OFFSETS),
+                    ("stratified", synth.VARIABLE_OFFSETS, 20, 40)):
+        synth.mapping_factory(mapping)._configure(eng)
+        rows = eng.rows
+        ln = seg_end - seg_start
+        off = np.zeros(len(ln) + 1, np.int64)
+        np.cumsum(ln * rows, out=off[1:])
+        plan = eng.plan(seg_tid, seg_start, seg_end, seg_strand, off[:-1], np.ones(len(ln), np.int8), ln, int(off[-1]), rows)
+        got = plan.count(np.float64)
+        kind = mapping[0]
+        spec = oracle.mapping_spec(kind, mapping[1] if kind in ("fiveprime", "threeprime", "center") else 0,
+                                   mapping[1] if kind in ("variable", "stratified") else None,
+                                   *(mapping[2:4] if kind == "stratified" else (25, 35)))
+        arrays, _ = oracle.count_segments(aln, spec, seg_tid, seg_start, seg_end, seg_strand)
+        exp = np.concatenate([a.astype(np.float64).reshape(-1) for a in arrays])
+        assert np.array_equal(got, exp), mapping
+        plan.close()
+    eng.close()
