@@ -142,6 +142,10 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
                    const int8_t *out_step, const int64_t *row_stride, int64_t out_elems, int rows,
                    pc_plan **out);
 int pc_plan_destroy(pc_plan *p);
+/* SegmentChain.get_position_list / _get_position_hash (roitools.pyx:1450-1484, 2059-2080) for the whole
+ * batch: host_out[k] = genomic coordinate of output element k of the plan's layout (-1 where no segment
+ * writes; every row of a multi-row layout gets the coordinates; summed slices have none). */
+int pc_plan_coordinates(pc_engine *e, pc_plan *p, int64_t *host_out, int64_t out_elems);
 int64_t pc_plan_positions(pc_plan *p); /* distinct (strand-mode, position) pairs counted */
 int64_t pc_plan_tiles(pc_plan *p);
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pc_plan_create": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _pp]),
     "pc_plan_destroy": (_int, [_vp]),
     "pc_plan_positions": (_i64, [_vp]),
+    "pc_plan_coordinates": (_int, [_vp, _vp, _vp, _i64]),
     "pc_plan_tiles": (_i64, [_vp]),
     "pc_count": (_int, [_vp, _vp, _int]),
     "pc_sync": (_int, [_vp]),

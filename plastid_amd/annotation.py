@@ -507,6 +507,55 @@ class IntervalTable(object):
                     out_step=out_step, row_stride=tx_len.astype(np.int64), out_elems=int(chain_base[-1]),
                     chain_base=chain_base, seg_len=seg_len)
 
+    # -------------------------------------------------------------- positions
+    def position_arrays(self, engine=None):
+        """``SegmentChain.get_position_list`` for EVERY chain at once (roitools.pyx:1450-1484, 2059-2080):
+        ``(positions, chain_off)`` -- the genomic coordinate of every chain position, ascending within a
+        chain regardless of strand, chains back to back; chain ``c`` owns
+        ``positions[chain_off[c]:chain_off[c+1]]``.  With an :class:`~plastid_amd.engine.Engine` the array
+        is filled by one HIP kernel over the plan's segments (``pc_plan_coordinates``); without one, by a
+        single vectorised numpy pass.  Both give the same array."""
+        chain_off = np.zeros(self.n + 1, np.int64)
+        np.cumsum(self.length, out=chain_off[1:])
+        if engine is not None:
+            p = self.plan_arrays(rows=1, stranded=False)        # ascending layout: the position hash
+            plan = engine.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"],
+                               p["out_elems"], 1)
+            try:
+                return plan.coordinates(), chain_off
+            finally:
+                plan.close()
+        ex_len = self.ex_end - self.ex_start
+        total = int(self.ex_cum[-1])
+        pos = np.repeat(self.ex_start - self.ex_cum[:-1], ex_len) + np.arange(total, dtype=np.int64)
+        return pos, chain_off
+
+    def masked_position_arrays(self, masks, engine=None):
+        """``SegmentChain.get_masked_position_set`` for every chain (roitools.pyx:2117-2135, masks as
+        ``add_masks`` defines them, :2213-2256): the chain positions NOT covered by a mask segment of the
+        same chain.  `masks` is an :class:`IntervalTable` with one (possibly empty) chain of mask segments
+        per chain of `self` -- mask segments may overlap each other and need not lie inside the chain.
+        Returns ``(positions, chain_off)`` like :meth:`position_arrays`."""
+        if masks.n != self.n:
+            raise ValueError("mask table has %d chains, expected %d" % (masks.n, self.n))
+        pos, off = self.position_arrays(engine)
+        chain_of = np.repeat(np.arange(self.n, dtype=np.int64), self.length)
+        keep = np.ones(len(pos), bool)
+        if masks.n_segments:
+            # a position is masked iff it lies in [start, end) of some mask segment of its chain:
+            # count starts <= x minus ends <= x over the chain's (sorted) mask edges
+            shift = np.int64(1) << 40
+            mchain = masks.ex_tx.astype(np.int64)
+            ks = np.sort(mchain * shift + masks.ex_start)
+            ke = np.sort(mchain * shift + masks.ex_end)
+            kx = chain_of * shift + pos
+            opened = np.searchsorted(ks, kx, side="right") - np.searchsorted(ks, chain_of * shift, side="left")
+            closed = np.searchsorted(ke, kx, side="right") - np.searchsorted(ke, chain_of * shift, side="left")
+            keep = opened == closed
+        moff = np.zeros(self.n + 1, np.int64)
+        np.cumsum(np.bincount(chain_of[keep], minlength=self.n), out=moff[1:])
+        return pos[keep], moff
+
     def split_counts(self, flat, rows=1):
         """Per-chain views (``[length]`` or ``[rows, length]``) of a batched result."""
         base = np.zeros(self.n + 1, np.int64)
@@ -519,6 +568,7 @@ class IntervalTable(object):
         """|SegmentChain| objects (Python objects: use for small sets only)."""
         from .roitools import GenomicSegment, SegmentChain
         out = []
+        flat, off = self.position_arrays()
         for t in range(self.n if limit is None else min(limit, self.n)):
             s = STRAND_CHAR[int(self.strand[t])]
             chrom = self.references[self.tid[t]] if self.tid[t] >= 0 else "?"
@@ -526,6 +576,7 @@ class IntervalTable(object):
                     for j in range(self.ex_off[t], self.ex_off[t + 1])]
             c = SegmentChain()
             c._set_segments(segs)
+            c._position_hash = flat[off[t]:off[t + 1]]    # get_position_list / get_position_set: views of the batch array
             if self.ids is not None:
                 c.attr["ID"] = self.ids[t]
             out.append(c)

@@ -234,6 +234,7 @@ struct GatherSeg {
     int64_t hist_off; // hist index of position (start + clip_lo); -1: all zero
     int64_t len;
     int64_t clip_lo, clip_hi;
+    int64_t start;    // genomic coordinate of the segment's first position
     int32_t step;
     int32_t pad;
 };
@@ -1408,6 +1409,23 @@ __global__ __launch_bounds__(kWG) void k_gather(const GatherSeg *__restrict__ se
             else o = (OutT)v;
             dst[(int64_t)sg.step * idx] = o;
         }
+    }
+}
+
+// ---------------------------------------------------------------- k_coordinates
+// SegmentChain._get_position_hash / get_position_list (roitools.pyx:1450-1484, 2059-2080) for a whole
+// batch of chains: the genomic coordinate of every element of the plan's output layout (with the
+// ascending layout of IntervalTable.position_arrays this is the flat position hash of every chain).
+__global__ __launch_bounds__(kWG) void k_coordinates(const GatherSeg *__restrict__ segs,
+                                                     const GatherChunk *__restrict__ chunks, int rows, int64_t *out) {
+    const GatherChunk gc = chunks[blockIdx.x];
+    const GatherSeg sg = segs[gc.seg];
+    if (sg.step == 0) return;   // a summed slice has no per-position elements
+    const int64_t base = (int64_t)gc.chunk * kGatherChunk;
+    const int64_t n = (sg.len - base < kGatherChunk) ? sg.len - base : kGatherChunk;
+    for (int r = 0; r < rows; ++r) {
+        int64_t *dst = out + sg.out_off + (int64_t)r * sg.row_stride;
+        for (int64_t i = threadIdx.x; i < n; i += kWG) dst[(int64_t)sg.step * (base + i)] = sg.start + base + i;
     }
 }
 

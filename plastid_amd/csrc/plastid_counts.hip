@@ -1075,7 +1075,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         }
         GatherSeg &g = p->gsegs[(size_t)s];
         g.out_off = out_off[s]; g.row_stride = row_stride[s]; g.len = len; g.step = out_step[s]; g.pad = 0;
-        g.hist_off = -1; g.clip_lo = 0; g.clip_hi = 0;
+        g.hist_off = -1; g.clip_lo = 0; g.clip_hi = 0; g.start = start[s];
         p->covered += (out_step[s] == 0 ? (len > 0 ? 1 : 0) : len) * rows;
         if (tid[s] < 0 || tid[s] >= ntid || len == 0) continue; // unknown chromosome: zeros (genome_array.py:795-798)
         const int64_t cs = std::max<int64_t>(start[s], 0), ce = std::min<int64_t>(end[s], kMaxPos);
@@ -1553,6 +1553,25 @@ int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems) 
     }
     if (bytes > 0) HIP_TRY(hipMemcpyAsync(host_out, p->d_out.p, bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return PC_OK;
+}
+
+int pc_plan_coordinates(pc_engine *e, pc_plan *p, int64_t *host_out, int64_t out_elems) {
+    if (!e || !p || p->e != e) return fail(PC_ERR_ARG, "pc_plan_coordinates: bad engine/plan");
+    if (out_elems != p->out_elems || (out_elems > 0 && !host_out)) return fail(PC_ERR_ARG, "pc_plan_coordinates: buffer size mismatch");
+    HIP_TRY(hipSetDevice(e->device));
+    if (out_elems == 0) return PC_OK;
+    DevBuf<int64_t> d;
+    d.pool = &e->pool;
+    int rc = d.reserve((size_t)out_elems);
+    if (rc != PC_OK) return rc;
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemsetAsync(d.p, 0xff, (size_t)out_elems * 8, st));   // -1: elements no segment covers
+    const unsigned grid = (unsigned)p->gchunks.size();
+    if (grid) hipLaunchKernelGGL(k_coordinates, dim3(grid), dim3(kWG), 0, st, p->d_gsegs.p, p->d_gchunks.p, p->rows, d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_out, d.p, (size_t)out_elems * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return PC_OK;
 }
 

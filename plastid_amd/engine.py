@@ -202,6 +202,12 @@ class Plan(object):
     def tiles(self):
         return int(self._lib.pc_plan_tiles(self._h))
 
+    def coordinates(self):
+        """Genomic coordinate of every output element of the plan's layout (``-1``: not covered)."""
+        out = np.empty(self.out_elems, np.int64)
+        check(self._lib.pc_plan_coordinates(self.engine._h, self._h, _ptr(out), self.out_elems))
+        return out
+
     def launch(self, dtype):
         """Asynchronously run the counting kernels; results stay in HBM."""
         code = OUT_FLOAT64 if np.dtype(dtype) == np.float64 else OUT_INT64

@@ -444,6 +444,21 @@ class BAMGenomeArray(object):
             counts, rpnt, rpkm = counts[:, 0], rpnt[:, 0], rpkm[:, 0]
         return {"counts": counts, "length": length, "counts_per_nucleotide": rpnt, "rpkm": rpkm}
 
+    @staticmethod
+    def counts_in_region_lines(chains, stats, names=None):
+        """The per-region lines ``bin/counts_in_region.py:113-124`` writes, from the result of
+        :meth:`count_in_regions` (one row per chain): name, region, counts, counts per nucleotide,
+        RPKM (``%.8e``) and masked length.  A fully masked region prints ``nan`` for all three numbers:
+        ``numpy.nansum`` of the reference's all-masked array is ``masked``, which formats as nan."""
+        lines = []
+        for i, c in enumerate(chains):
+            length = int(stats["length"][i])
+            counts = float("nan") if length == 0 else float(stats["counts"][i])
+            name = names[i] if names is not None else c.get_name()
+            lines.append("\t".join([name, str(c), "%.8e" % counts, "%.8e" % float(stats["counts_per_nucleotide"][i]),
+                                    "%.8e" % float(stats["rpkm"][i]), "%d" % length]))
+        return lines
+
     def to_genome_array(self, array_type=None):
         """Dense per-chromosome arrays under the current mapping rule (genome_array.py:965-988): one
         whole-contig launch per chromosome and strand.  As in the reference the query stops one

