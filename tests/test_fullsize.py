@@ -181,13 +181,15 @@ def test_sparse_table_expectation_matches_oracle():
 
 @pytest.mark.gpu
 def test_large_table_rule_properties():
-    """C4 / C5 at a per-GPU share of the 8-GPU BASELINE sizes (62.5 M reads, Variable; 31 M mate
-    records, Stratified): engine vs the sparse numpy expectation, every chain, every row."""
+    """C4 at its BASELINE size on ONE GPU (500 M reads, Variable, 60 k human-scale transcripts) and C5 at
+    a per-GPU share of its reads over the WHOLE annotation (125 M mate records, Stratified, 60 k
+    transcripts x 11 rows = 1.7e9 outputs): engine vs the sparse numpy expectation, every chain, every
+    row."""
     from plastid_amd.engine import Engine
     scale = float(os.environ.get("PC_FULLSIZE_SCALE", "1.0"))
     eng = Engine(0)
     # ---- C4: VariableFivePrimeMapFactory
-    genome, tx, reads, mapping = synth.make_config("C4", scale=0.125 * scale, tx_scale=0.25)
+    genome, tx, reads, mapping = synth.make_config("C4", scale=scale, tx_scale=1.0 if scale >= 0.5 else 0.25)
     off = fu.offsets_by_length(mapping[1])
     pos, ok = fu.mapped_positions_by_table(reads, off)
     eng.set_alignments([reads])
@@ -199,7 +201,8 @@ def test_large_table_rule_properties():
     assert np.array_equal(plan.count(np.int64), got)
     plan.close()
     # ---- C5: StratifiedVariableFivePrimeMapFactory, rows = read lengths
-    genome, tx, reads, mapping = synth.make_config("C5", scale=0.03125 * scale, tx_scale=0.05)
+    del reads, pos, ok, got
+    genome, tx, reads, mapping = synth.make_config("C5", scale=0.125 * scale, tx_scale=1.0 if scale >= 0.5 else 0.05)
     lo, hi = mapping[2], mapping[3]
     rows = hi - lo + 1
     pos, ok = fu.mapped_positions_by_table(reads, fu.offsets_by_length(mapping[1]))
@@ -220,3 +223,37 @@ def test_large_table_rule_properties():
     assert int(plan.total()) == total
     plan.close()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_c1_workload_fully_vs_oracle():
+    """BASELINE configs[0] (C1: 1 M reads, FivePrimeMapFactory(offset=0), 200 SegmentChains -- the
+    reference's own CPU-runnable shape; the real test BAM is not in the container) through
+    the HIP path, EVERY output position against the oracle; plus the CLI size filter and the batch
+    API of the Python mirror."""
+    from oracle import oracle
+    import plastid_amd as pa
+    from plastid_amd.engine import Engine
+    genome, tx, reads, mapping = synth.make_config("C1")
+    assert mapping == ("fiveprime", 0) and reads.n == 1_000_000 and tx.n == 200
+    aln = concat_file_major([reads])
+    p = tx.plan_arrays(rows=1)
+    eng = Engine(0)
+    eng.set_alignments([reads])
+    synth.mapping_factory(mapping)._configure(eng)
+    plan = _plan(eng, p)
+    for sf in (None, (25, 100)):
+        eng.set_size_filter(*(sf if sf else (None,)))
+        got = plan.count(np.int64)
+        arrays, _ = oracle.count_segments(aln, oracle.mapping_spec("fiveprime", 0, size_filter=sf), p["tid"], p["start"], p["end"], p["strand"])
+        assert np.array_equal(got, _scatter(p, arrays)), sf
+    eng.set_size_filter(None)
+    plan.close()
+    eng.close()
+    # the same through the drop-in classes: ga.get_counts_batch / chain.get_counts on a few chains
+    ga = pa.BAMGenomeArray(reads, mapping=pa.FivePrimeMapFactory(0))
+    chains = tx.chains(limit=20)
+    arrays, _ = oracle.count_segments(aln, oracle.mapping_spec("fiveprime", 0), p["tid"], p["start"], p["end"], p["strand"])
+    want = tx.split_counts(_scatter(p, arrays).astype(np.float64))
+    for c, chain in enumerate(chains):
+        assert np.array_equal(chain.get_counts(ga), want[c])
