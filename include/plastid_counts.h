@@ -171,6 +171,10 @@ int pc_read_rle(pc_engine *e, pc_plan *p, int64_t *starts, void *values, int64_t
 /* per-segment "the reference would emit its DataWarning" flags
  * (map_factories.pyx:258-263, 360-365, 459-464, 643-648) for the last pc_count */
 int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags);
+/* the same, plus (last_len, may be NULL) the aligned length of the LAST such read in fetch order per
+ * flagged segment, -1 otherwise: the length VariableFivePrimeMapFactory names in its warning
+ * (`no_offset_length`, map_factories.pyx:633-648) */
+int pc_warn_details(pc_engine *e, pc_plan *p, uint8_t *flags, int32_t *last_len);
 
 /* Sum over all output elements of the last pc_count, left in HBM for an RCCL
  * all-reduce (int64 for PC_OUT_INT64, fixed-order float64 otherwise);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "pc_rle": (_int, [_vp, _vp, _i64, ctypes.POINTER(_i64)]),
     "pc_read_rle": (_int, [_vp, _vp, _vp, _vp, _i64]),
     "pc_warn_flags": (_int, [_vp, _vp, _vp]),
+    "pc_warn_details": (_int, [_vp, _vp, _vp, _vp]),
     "pc_total": (_int, [_vp, _vp, _vp]),
     "pc_total_device_ptr": (_vp, [_vp]),
     "pc_mapped_reads": (_int, [_vp, _int, _i64, _i64, _i32, _i64, _i64, ctypes.c_uint8, _vp]),

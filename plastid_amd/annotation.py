@@ -12,7 +12,7 @@ import re
 
 import numpy as np
 
-from .exceptions import DataWarning, warn
+from .exceptions import DataWarning, FileFormatWarning, warn
 
 STRAND_CODE = {"\x00": 0, "+": 1, "-": 2, ".": 3}
 STRAND_CHAR = {0: "\x00", 1: "+", 2: "-", 3: "."}
@@ -99,10 +99,12 @@ def _gtf2_attributes(text):
     are joined with a comma."""
     out = {}
     text = text.strip()
+    pairs = None
     if "\\" not in text:
-        # fast path (no escapes): split at the semicolons; a token with an odd number of quotes means a
+        # fast path (no backslashes): split at the semicolons; a token with an odd number of quotes means a
         # semicolon sat inside a quoted value -- then the general tokenizer below takes over
         ok = True
+        pairs = []
         for tok in text.split(";"):
             tok = tok.strip()
             if not tok:
@@ -118,14 +120,23 @@ def _gtf2_attributes(text):
                 break
             if val[0] == '"':
                 val = val[1:-1]
-            out[key] = "%s,%s" % (out[key], val) if key in out else val
-        if ok:
-            return out
-        out = {}
-    for m in _GTF2_TOKEN.finditer(text):
-        key = m.group(1)
-        val = m.group(2) if m.group(2) is not None else m.group(3)
-        out[key] = "%s,%s" % (out[key], val) if key in out else val
+            pairs.append((key, val))
+        if not ok:
+            pairs = None
+    if pairs is None:
+        pairs = []
+        for m in _GTF2_TOKEN.finditer(text):
+            pairs.append((m.group(1), m.group(2) if m.group(2) is not None else m.group(3)))
+    esc = "%" in text
+    for key, val in pairs:
+        if esc:   # unescape_GTF2 on keys and values (gff_tokens.py:582-599)
+            key, val = _unescape(key, True), _unescape(val, True)
+        if key in out:
+            warn("Found duplicate attribute key '%s' in GTF2 line. Catenating value with previous value for key in attr dict:\n    %s"
+                 % (key, text), FileFormatWarning)
+            out[key] = "%s,%s" % (out[key], val)
+        else:
+            out[key] = val
     return out
 
 
@@ -206,9 +217,26 @@ GFF3_CDS_TYPES = frozenset(["CDS", "CDS_fragment", "CDS_indpendently_known", "CD
 _GFF3_LIST_KEYS = ("Parent", "Alias", "Note", "Dbxref", "Ontology_term", "dbxref")
 
 
+# percent escapes the reference undoes (readers/gff_tokens.py:44-125): "%;,=&", the control characters
+# 0x00-0x1f, 0x7f and 0x80-0x9f -- upper-case hex only -- and, in GTF2, the double quote.  Every other
+# "%XX" stays as it is ("%25" -> "%" is applied last there and nothing is rescanned, so one pass equals it).
+_ESCAPED_CODES = frozenset("%%%02X" % c for c in ([ord(x) for x in "%;,=&"] + list(range(0x20)) + [0x7f] + list(range(0x80, 0xa0))))
+_ESCAPE_RE = re.compile(r"%[0-9A-F]{2}")
+
+
+def _unescape(text, gtf2=False):
+    if "%" not in text:
+        return text
+    def repl(m):
+        code = m.group(0)
+        if code in _ESCAPED_CODES or (gtf2 and code == "%22"):
+            return chr(int(code[1:], 16))
+        return code
+    return _ESCAPE_RE.sub(repl, text)
+
+
 def _gff3_unescape(text):
-    from urllib.parse import unquote
-    return unquote(text)
+    return _unescape(text)
 
 
 def _gff3_attributes(text):

@@ -246,6 +246,8 @@ struct GatherChunk {
 
 struct Unmappable {
     int32_t tid, pos, end, rev;
+    int32_t len;      // aligned length (the reference names it in the Variable rule's warning, :633-648)
+    uint32_t rec;     // record index in its file (fetch order: file-major, then record order)
 };
 
 // ---------------------------------------------------------------- helpers
@@ -449,7 +451,11 @@ __device__ __forceinline__ int64_t lower_bound_i32(const uint32_t PC_GLOBAL *v, 
 }
 
 // One THREAD per (tile, file): which records the tile must scan (fetch emulation,
-// genome_array.py:800-809).  Window edges are multiples of the 128-nt linear-index bucket, so
+// genome_array.py:800-809).  Two halos: the 4-byte stream only carries single-run reads, which reach
+// at most `Ws` (their longest aligned length) positions to the right of their start, so the stream
+// scan starts Ws before the first queried position; gapped reads with a short span come from the side
+// list, whose scan starts `W` (their longest span) before it.  On spliced data W is ~30x Ws, and a
+// stream scan with the wide halo would read every record several times over.  Window edges are multiples of the 128-nt linear-index bucket, so
 // the upper ends are exact table lookups and the lower ends are rounded down to a bucket (a
 // few extra records are streamed; they fall outside the bins) -- no searching at all for the
 // packed stream.  A dense window is cut into sub-windows, each an independent work item that
@@ -468,7 +474,7 @@ __device__ __forceinline__ int64_t lower_bound_i32(const uint32_t PC_GLOBAL *v, 
 // One returning atomic per class per workgroup: a single hot counter saturates near 90/us.
 __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
                                                            FileView file0, const FileView *__restrict__ files,
-                                                           int nfiles, int G, int W, int64_t R, int64_t pile,
+                                                           int nfiles, int G, int W, int Ws, int64_t R, int64_t pile,
                                                            WorkItem *work, uint32_t *nwork, uint32_t *tile_items,
                                                            uint32_t work_cap, WorkItem *work_small, int small_g,
                                                            int64_t small_n, int diag) {
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         // only reads that can land on a queried position matter: a sparse annotation (one
         // 150-nt exon in a 4096-nt window) scans the exon's neighbourhood, not the whole window
         const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1;
-        wlo = lin_floor(fv.lin_tab, l0, nb, s_lo - W + 1);
+        wlo = lin_floor(fv.lin_tab, l0, nb, s_lo - Ws + 1);
         whi = lin_floor(fv.lin_tab, l0, nb, s_hi);
         if (fv.ngap) {
             wglo = lin_floor(fv.glin_tab, l0, nb, s_lo - W + 1);
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
                 const int sub = G / S;
                 for (int k = 0; k < S; ++k) {
                     const int64_t a = ws + (int64_t)k * sub;
-                    const int64_t nk = lin_floor(fv.lin_tab, l0, nb, a + sub) - lin_floor(fv.lin_tab, l0, nb, a - W + 1);
+                    const int64_t nk = lin_floor(fv.lin_tab, l0, nb, a + sub) - lin_floor(fv.lin_tab, l0, nb, a - Ws + 1);
                     if (nk > pile) merge = true; // a pile-up inside one sub-window
                     if (nk > R) ++n_heavy; else ++n_light;
                 }
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     for (int k = 0; k < S; ++k) {
         const int64_t a = S == 1 ? ws + tl.span_lo : ws + (int64_t)k * sub;
         const int64_t e = S == 1 ? ws + tl.span_hi + (1 << kLinShift) - 1 : a + sub;
-        w.lo = lin_floor(fv.lin_tab, l0, nb, a - W + 1);
+        w.lo = lin_floor(fv.lin_tab, l0, nb, a - Ws + 1);
         w.hi = lin_floor(fv.lin_tab, l0, nb, e);
         w.glo = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, a - W + 1) : 0;
         w.ghi = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, e) : 0;
@@ -893,9 +899,16 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
         // (16-byte stores over the span rounded out to 4 words; no per-element division)
         const int lo4 = (int)w.span_lo >> 2, hi4 = ((int)w.span_hi + 3) >> 2, nrow = nslots * mp.rows;
         const u32x4 zero4 = {0u, 0u, 0u, 0u};
-        for (int r = 0; r < nrow; ++r) {
-            u32x4 *row4 = (u32x4 *)(bins + r * G);
-            for (int i = lo4 + (int)threadIdx.x; i < hi4; i += WG) row4[i] = zero4;
+        if (nrow > 2 && (hi4 - lo4) * 2 > (G >> 2)) {
+            // many rows and a span that covers most of the window: clear all rows in one flat sweep
+            // (a row-by-row loop costs one mostly idle pass per row)
+            u32x4 *all4 = (u32x4 *)bins;
+            for (int i = (int)threadIdx.x; i < nrow * (G >> 2); i += WG) all4[i] = zero4;
+        } else {
+            for (int r = 0; r < nrow; ++r) {
+                u32x4 *row4 = (u32x4 *)(bins + r * G);
+                for (int i = lo4 + (int)threadIdx.x; i < hi4; i += WG) row4[i] = zero4;
+            }
         }
     }
     if (KIND >= 3) {
@@ -980,6 +993,21 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
             const int i0 = w.sub_lo > rel ? w.sub_lo - rel : 0;
             const int i1 = (w.sub_hi - rel) < o.len ? (w.sub_hi - rel) : o.len;
             const int slot = __popc(w.mode_mask & ((1u << o.mode) - 1u));
+            if (mp.rows > 1 && o.step != 0) {
+                // several rows (stratified rule): a lane keeps its position and walks down the rows with two
+                // pointer increments per element -- a row-major loop pays the 64-bit address set-up of a row
+                // for 1.2 KB of output (a 150-nt exon), eleven times per piece
+                for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) {
+                    const uint32_t *srcp = bins + slot * mp.rows * G + rel + i;
+                    typename OutT_<OUTMODE>::type *dstp = out + o.out_off + (int64_t)o.step * i;
+                    for (int r = 0; r < mp.rows; ++r) {
+                        *dstp = out_conv<OUTMODE>(*srcp, norm_sum);
+                        srcp += G;
+                        dstp += o.row_stride;
+                    }
+                }
+                continue;
+            }
             for (int r = 0; r < mp.rows; ++r) {
                 const uint32_t *srcb = bins + (slot * mp.rows + r) * G + rel;
                 typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
@@ -1007,7 +1035,10 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
             const Piece pc_ = pieces[pi];
             const int rel = pc_.start - w.win_start;
             for (int r = 0; r < mp.rows; ++r) {
-                const uint32_t *srcb = bins + c.base[pc_.mode] + r * G + rel;
+                // (not c.base[pc_.mode]: a run-time index into that array would put the whole struct into
+                // scratch memory -- 44 bytes per lane written to HBM by every work item)
+                const int mode_base = __popc(w.mode_mask & ((1u << pc_.mode) - 1u)) * mp.rows * G;
+                const uint32_t *srcb = bins + mode_base + r * G + rel;
                 uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
                 for (int i = threadIdx.x; i < pc_.len; i += WG) {
                     const uint32_t v = srcb[i];
@@ -1113,11 +1144,12 @@ constexpr int kInvLds = 1024; // 1/m table kept in LDS for m < kInvLds
 //     each: a wave then replays the reads over (8 + L) instead of (64 + L) positions -- the
 //     critical path shrinks 2-2.5x for idle lanes in a few waves;
 //   * those entries are queued first (longest-first in two classes, as for the histogram work
-//     list): list[0 .. nheavy) heavy, list[cap-1 .. cap-nlight] light, cap = 2 * nchunks.
+//     list): list[0 .. nheavy) heavy, list[cap-1 .. cap-nlight] light, cap = kCenterCap * nchunks.
 // Thresholds are relative to the mean candidate count (pass 1 sums it), so by Markov's
 // inequality fewer than nchunks/8 chunks are cut and the heavy entries fit in nchunks slots.
 // Entry = chunk index | code << 27: 0 whole chunk, 1..4 quarter, 5..12 eighth.
 constexpr int kSubShift = 27;
+constexpr uint32_t kCenterCap = 3u;   // dispatch-list slots per chunk: front entries < (8/k1 + 1/8) x chunks by Markov, the rest from the back
 constexpr int64_t kCenterSearchFrom = 1024; // candidate count from which a whole chunk searches its exact first record
 // One candidate read of the center kernel, ready to replay: the (at most two) runs of covered
 // positions [a0, a0+m0) and [a1, a1+m1) after trimming `nibble` from both ends, and 1/m.
@@ -1170,8 +1202,13 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
     const bool live = c < nchunks;
     const int64_t mean = (int64_t)(*total / (unsigned long long)(nchunks > 0 ? nchunks : 1));
     const int64_t t1 = k1 * mean > floor_thr ? k1 * mean : floor_thr, t2 = k2 * t1; // k1 >= 8 (capacity, see above)
+    const int64_t th_whole = 8 * mean > floor_thr ? 8 * mean : floor_thr;           // starts early, but stays whole
     const int64_t cand = live ? (int64_t)cand_in[c] : 0;
-    const uint32_t nsub = !live ? 0u : (cand > t2 ? 8u : (cand > t1 ? 4u : 0u)); // 0: not cut
+    // entries a chunk puts at the FRONT of the list: 8 / 4 sub-chunks, 1 = the whole chunk (heavy but
+    // below the cut threshold: cutting multiplies the work -- eight sub-chunks scan 8 x (8 + L)
+    // positions' worth of reads instead of 64 + L -- so only the deepest pile-ups, whose sequential
+    // replay would otherwise outlast the rest of the launch, are cut); 0 = light, queued from the back
+    const uint32_t nsub = !live ? 0u : (cand > t2 ? 8u : (cand > t1 ? 4u : (cand > th_whole ? 1u : 0u)));
     uint32_t th, tl;
     const uint32_t oh = block_scan_excl(nsub, s_wave, th);
     const uint32_t ol = block_scan_excl((live && nsub == 0u) ? 1u : 0u, s_wave, tl);
@@ -1181,9 +1218,11 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
     }
     __syncthreads();
     if (!live) return;
-    const uint32_t cap = 2u * (uint32_t)nchunks;
+    const uint32_t cap = kCenterCap * (uint32_t)nchunks;
     if (nsub == 0u) {
         order[cap - 1u - (s_base[1] + ol)] = (uint32_t)c;
+    } else if (nsub == 1u) {
+        order[s_base[0] + oh] = (uint32_t)c;
     } else {
         const uint32_t first_code = nsub == 4u ? 1u : 5u;
         for (uint32_t k = 0; k < nsub; ++k) order[s_base[0] + oh + k] = (uint32_t)c | ((first_code + k) << kSubShift);
@@ -1297,7 +1336,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     __syncthreads();
     // the grid spans the list capacity: heavy entries at the front, light ones at the back
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
-    const uint32_t cap = 2u * (uint32_t)nchunks;
+    const uint32_t cap = kCenterCap * (uint32_t)nchunks;
     if (slot >= cap) return;
     const uint32_t n_heavy = counters[0], n_light = counters[1];
     const uint32_t entry = order[slot];
@@ -1657,6 +1696,8 @@ __global__ __launch_bounds__(kWG) void k_unmappable(FileView fview, MapParams mp
     u.pos = (int32_t)r.x;
     u.end = rec_end(fv, i, (int32_t)r.x, meta);
     u.rev = (fl & kFlagReverse) ? 1 : 0;
+    u.len = L;
+    u.rec = (uint32_t)i;
     list[slot] = u;
 }
 

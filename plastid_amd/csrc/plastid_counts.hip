@@ -317,6 +317,11 @@ struct pc_engine {
         for (auto *f : files) w = std::max(w, f->W);
         return w;
     }
+    int Ws() const {   // halo of the 4-byte record stream: the longest aligned length it carries
+        int w = 1;
+        for (auto *f : files) w = std::max(w, f->slen_max);
+        return w;
+    }
 };
 
 struct pc_plan {
@@ -1390,7 +1395,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             p->tile_items_zero = false;
             const int64_t nthreads = (int64_t)ntiles * nfiles; // one thread per (tile, file)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
-                               e->files[0]->view(), e->d_files.p, nfiles, G, W, R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
+                               e->files[0]->view(), e->d_files.p, nfiles, G, W, e->Ws(), R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
                                e->d_work_small.p, small_g, small_n, e->knobs.debug_work);
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
@@ -1492,8 +1497,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
         const int64_t nchunks = (int64_t)p->cchunks.size();
         if (nchunks > 0) {
-            if (nchunks >= (int64_t)1 << (kSubShift - 1)) return fail(PC_ERR_ARG, "pc_count: too many positions for the center rule");
-            rc = p->d_corder.reserve((size_t)(2 * nchunks));   // dispatch list: heavy entries front, light back
+            if (kCenterCap * nchunks >= (int64_t)1 << kSubShift) return fail(PC_ERR_ARG, "pc_count: too many positions for the center rule");
+            rc = p->d_corder.reserve((size_t)(kCenterCap * nchunks));   // dispatch list: heavy entries front, light back
             if (rc == PC_OK) rc = p->d_ccand.reserve((size_t)nchunks);
             if (rc == PC_OK) rc = p->d_cranges.reserve((size_t)nchunks * (size_t)nfiles);
             if (rc != PC_OK) return rc;
@@ -1506,7 +1511,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2; // cut thresholds, in multiples of the mean candidate count
             hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, (int64_t)2048, ck1, ck2,
                                p->d_corder.p, e->d_counters.p);
-            hipLaunchKernelGGL(k_center, dim3((unsigned)((2 * nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks,
+            hipLaunchKernelGGL(k_center, dim3((unsigned)((kCenterCap * nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks,
                                e->d_files.p, nfiles, mp, W, e->d_inv.p, p->d_corder.p, e->d_counters.p, p->d_cranges.p,
                                (double *)p->d_hist.p);
         }
@@ -1704,10 +1709,13 @@ int pc_stream_probe(pc_engine *e, int64_t bytes, int iters, double *read_gbps, d
 }
 
 // ------------------------------------------------------------------ warnings
-int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
+int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) { return pc_warn_details(e, p, flags, nullptr); }
+
+int pc_warn_details(pc_engine *e, pc_plan *p, uint8_t *flags, int32_t *last_len) {
     if (!e || !p || p->e != e || (p->nseg > 0 && !flags)) return fail(PC_ERR_ARG, "pc_warn_flags: bad arguments");
     if (!e->have_map) return fail(PC_ERR_STATE, "pc_warn_flags: no mapping rule set");
     std::memset(flags, 0, (size_t)p->nseg);
+    if (last_len) std::fill(last_len, last_len + p->nseg, (int32_t)-1);
     if (e->kind == PC_MAP_STRAT5) return PC_OK; // never warns
     // cheap pre-check on the per-length record histogram (ignores filters: conservative)
     bool any = false;
@@ -1729,7 +1737,10 @@ int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
     if (rc != PC_OK) return rc;
     const MapParams mp = e->params();
     std::vector<Unmappable> all;
+    std::vector<uint32_t> file_of;   // staged file of every entry of `all` (parallel array, permuted with it)
+    int file_index = -1;
     for (auto *f : e->files) {
+        ++file_index;
         if (!f->n) continue;
         uint32_t cap = 1u << 16;
         for (;;) {
@@ -1746,6 +1757,7 @@ int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
                 const size_t base = all.size();
                 all.resize(base + cnt);
                 if (cnt) HIP_TRY(hipMemcpy(all.data() + base, e->d_unmap.p, (size_t)cnt * sizeof(Unmappable), hipMemcpyDeviceToHost));
+                file_of.resize(base + cnt, (uint32_t)file_index);
                 break;
             }
             cap = cnt;
@@ -1753,10 +1765,19 @@ int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
     }
     if (all.empty()) return PC_OK;
     // host: does any unmappable record of the right strand overlap the segment (htslib rule)?
-    std::sort(all.begin(), all.end(), [](const Unmappable &a, const Unmappable &b) {
-        if (a.tid != b.tid) return a.tid < b.tid;
-        return a.pos < b.pos;
-    });
+    {   // sort by (tid, pos), carrying the file index along
+        std::vector<size_t> perm(all.size());
+        for (size_t i = 0; i < perm.size(); ++i) perm[i] = i;
+        std::sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
+            if (all[a].tid != all[b].tid) return all[a].tid < all[b].tid;
+            return all[a].pos < all[b].pos;
+        });
+        std::vector<Unmappable> a2(all.size());
+        std::vector<uint32_t> f2(all.size());
+        for (size_t i = 0; i < perm.size(); ++i) { a2[i] = all[perm[i]]; f2[i] = file_of[perm[i]]; }
+        all.swap(a2);
+        file_of.swap(f2);
+    }
     const size_t n = all.size();
     std::vector<int32_t> pmax_f(n), pmax_r(n);
     for (size_t i = 0; i < n; ++i) {
@@ -1783,6 +1804,20 @@ int pc_warn_flags(pc_engine *e, pc_plan *p, uint8_t *flags) {
         else if (mode == 1) best = pmax_r[lo - 1];
         else best = std::max(pmax_f[lo - 1], pmax_r[lo - 1]);
         if (best > st) flags[s] = 1;
+        if (best > st && last_len) {
+            // the LAST offending read in fetch order (file-major, then record order) among those fetch
+            // returns for the segment: walk back while some earlier read of the strand can still reach it
+            uint64_t best_key = 0;
+            bool have = false;
+            for (size_t i = lo; i-- > 0 && all[i].tid == t;) {
+                const int64_t reach = mode == 0 ? pmax_f[i] : (mode == 1 ? pmax_r[i] : std::max(pmax_f[i], pmax_r[i]));
+                if (reach <= st) break;
+                const bool strand_ok = mode == 0 ? !all[i].rev : (mode == 1 ? all[i].rev != 0 : true);
+                if (!strand_ok || (int64_t)all[i].end <= st) continue;
+                const uint64_t key = ((uint64_t)file_of[i] << 32) | all[i].rec;
+                if (!have || key > best_key) { best_key = key; last_len[s] = all[i].len; have = true; }
+            }
+        }
     }
     return PC_OK;
 }

@@ -230,6 +230,14 @@ class Plan(object):
         check(self._lib.pc_warn_flags(self.engine._h, self._h, _ptr(flags)))
         return flags
 
+    def warn_details(self):
+        """``(flags, last_len)``: per segment whether the reference would warn, and the aligned
+        length of the last offending read in fetch order (-1: none)."""
+        flags = np.zeros(self.nseg, np.uint8)
+        lens = np.full(self.nseg, -1, np.int32)
+        check(self._lib.pc_warn_details(self.engine._h, self._h, _ptr(flags), _ptr(lens)))
+        return flags, lens
+
     def rle(self, period=0):
         """Run-length encode the last count on the GPU: ``(starts, values)``; run k covers
         ``[starts[k], starts[k+1])`` (the last one ends at ``out_elems``).  Runs are also cut at

@@ -35,6 +35,11 @@ class MalformedFileError(Exception):
         return "Error opening file '%s' at line %s: %s" % (self.filename, self.line_num, self.msg)
 
 
+class FileFormatWarning(Warning):
+    """A file is not formatted as expected but can still be read
+    (plastid/util/services/exceptions.py:119), e.g. a repeated attribute key in a GTF2 line."""
+
+
 class ArgumentWarning(Warning):
     """Raised when arguments are nonsensical but recoverable."""
 

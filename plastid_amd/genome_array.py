@@ -188,8 +188,14 @@ class BAMGenomeArray(object):
     def _native(self):
         return isinstance(self.map_fn, _EngineMapFactory)
 
-    def _sync_engine(self):
-        """Push mapping rule, filters and normalisation to the engine."""
+    def _sync_engine(self, queries=None):
+        """Push mapping rule, filters and normalisation to the engine.
+
+        `queries`: the ``(chrom, start, end, strand)`` regions about to be counted.  Arbitrary filter
+        callables are evaluated lazily, as the reference does (genome_array.py:800-820): only on the
+        reads ``fetch`` returns for those regions, only on the strand the region keeps, each read at
+        most once (verdicts are cached until the filter set changes); ``None`` evaluates every read
+        of every file (whole-annotation batch calls)."""
         self.map_fn._configure(self._engine)
         if self._filters_dirty or not hasattr(self, "_size_filter_state"):
             size = None
@@ -199,24 +205,17 @@ class BAMGenomeArray(object):
                     size = f
                 else:
                     custom.append(f)
-            # arbitrary callables (and any further size filters): evaluate per read on the host,
-            # stage the verdicts as exclusion bits
+            self._custom_filters = custom
+            # verdicts of the callables per record: -1 not asked yet, 0 dropped, 1 kept
+            self._verdict = [np.full(packed.n, -1, np.int8) for packed in self._packed]
             for fi, packed in enumerate(self._packed):
-                flags = self._base_flags[fi].copy()
-                if custom and packed.n:
-                    keep = np.ones(packed.n, bool)
-                    for i in range(packed.n):
-                        read = packed.read(i)
-                        for f in custom:
-                            if not f(read):
-                                keep[i] = False
-                                break
-                    flags[~keep] |= FLAG_EXCLUDED
-                if not np.array_equal(flags, packed.flags):
-                    packed.flags = flags
-                    self._engine.update_flags(fi, flags)
+                if not np.array_equal(self._base_flags[fi], packed.flags):
+                    packed.flags = self._base_flags[fi].copy()
+                    self._engine.update_flags(fi, packed.flags)
             self._size_filter_state = size
             self._filters_dirty = False
+        if self._custom_filters:
+            self._evaluate_custom_filters(queries)
         size = self._size_filter_state
         if size is None:
             self._engine.set_size_filter(None)
@@ -227,6 +226,46 @@ class BAMGenomeArray(object):
         else:
             self._engine.set_normalize(False)
 
+    def _evaluate_custom_filters(self, queries):
+        """Arbitrary callables (and any size filter beyond the first): evaluated per read on the host,
+        staged as exclusion bits the kernels honour."""
+        for fi, packed in enumerate(self._packed):
+            if not packed.n:
+                continue
+            verdict = self._verdict[fi]
+            if queries is None:
+                todo = np.nonzero(verdict < 0)[0]
+            else:
+                sel = np.zeros(packed.n, bool)
+                rev = (self._base_flags[fi] & 1) != 0
+                for chrom, start, end, strand in queries:
+                    if chrom not in self._chrom_index or chrom not in packed.references:
+                        continue
+                    idx = packed.fetch_indices(chrom, start, end)
+                    if strand == "+":
+                        idx = idx[~rev[idx]]
+                    elif strand == "-":
+                        idx = idx[rev[idx]]
+                    sel[idx] = True
+                todo = np.nonzero(sel & (verdict < 0))[0]
+            if not len(todo):
+                continue
+            dropped = False
+            for i in todo:
+                read = packed.read(int(i))
+                keep = True
+                for f in self._custom_filters:
+                    if not f(read):
+                        keep = False
+                        break
+                verdict[i] = 1 if keep else 0
+                dropped |= not keep
+            if dropped:
+                flags = self._base_flags[fi].copy()
+                flags[verdict == 0] |= FLAG_EXCLUDED
+                packed.flags = flags
+                self._engine.update_flags(fi, flags)
+
     def _out_dtype(self):
         if self._normalize is True or self.map_fn._kind == _lib.MAP_CENTER:
             return np.float64
@@ -234,6 +273,13 @@ class BAMGenomeArray(object):
 
     def _warn_if_unmappable(self, plan):
         if self.map_fn._kind == _lib.MAP_STRAT5:
+            return
+        if self.map_fn._kind == _lib.MAP_VAR5:
+            # the reference names the length of the last offending read of the (last warning) call (:633-648)
+            flags, lens = plan.warn_details()
+            hit = np.nonzero(flags)[0]
+            if len(hit):
+                warn(self.map_fn._warn_message(int(lens[hit[-1]])), DataWarning, stacklevel=4)
             return
         if plan.warn_flags().any():
             msg = self.map_fn._warn_message()
@@ -313,7 +359,7 @@ class BAMGenomeArray(object):
 
     def _count_segments(self, segs, roi_order, keep_plan=False):
         """One launch over independent segments, each laid out like ``get(seg, roi_order)``."""
-        self._sync_engine()
+        self._sync_engine([(s.chrom, s.start, s.end, s.strand) for s in segs])
         rows = self._engine.rows
         tid = [self._chrom_index.get(s.chrom, -1) for s in segs]
         start = [s.start for s in segs]
@@ -355,7 +401,7 @@ class BAMGenomeArray(object):
         arrays, each what ``chain.get_counts(self, stranded)`` returns."""
         if not self._native():
             return [c.get_counts(self, stranded) for c in chains]
-        self._sync_engine()
+        self._sync_engine([(c.chrom, s.start, s.end, c.strand) for c in chains for s in c])
         rows = self._engine.rows
         segs, strands = [], []
         for c in chains:
@@ -414,7 +460,7 @@ class BAMGenomeArray(object):
         norm = self._normalize
         self._normalize = False
         try:
-            self._sync_engine()
+            self._sync_engine([(c.chrom, s.start, s.end, c.strand) for c in chains for s in list(c) + list(c.mask_segments)])
         finally:
             self._normalize = norm
         rows = self._engine.rows
@@ -478,7 +524,7 @@ class BAMGenomeArray(object):
         count launch + the GPU run-length encoder; only the runs come back.  Returns
         ``(starts, ends, values)``; runs are also cut at every multiple of `period`."""
         size = self.lengths()[chrom]
-        self._sync_engine()
+        self._sync_engine([(chrom, 0, size, strand)])
         rows = self._engine.rows
         if rows != 1:
             raise TypeError("export needs a mapping rule that returns one row per position")

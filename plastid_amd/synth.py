@@ -12,6 +12,8 @@ Used by ``bench.py`` and by the parity tests; contains no counting logic.
   background; footprint-like aligned lengths 25..34; 1 % of the records carry a
   1-nt deletion; records sorted by (tid, pos), stable.
 """
+import os
+
 import numpy as np
 
 from .packing import FLAG_REVERSE, PackedAlignments
@@ -307,7 +309,21 @@ def make_config(name, scale=1.0, tx_scale=None, seed_shift=0):
     n_tx = max(1, int(round(n_tx * (scale if tx_scale is None else tx_scale))))
     n_reads = max(2, int(round(n_reads * scale)))
     tx = make_transcripts(genome, n_tx, tx_seed, style)
+    cache = os.environ.get("PC_SYNTH_CACHE")   # profiling aid: several rocprofv3 passes over the same large config
+    path = None
+    if cache:
+        path = os.path.join(cache, "%s_%d_%d_%d.npz" % (name, n_reads, n_tx, r_seed + seed_shift))
+        if os.path.exists(path):
+            z = np.load(path)
+            reads = PackedAlignments(z["tid"], z["pos"], z["alen"], z["flags"], z["nblk"], z["blk_start"], z["blk_len"],
+                                     references=genome[0], lengths=[int(x) for x in genome[1]], mapped=len(z["tid"]),
+                                     validate=False)
+            return genome, tx, reads, mapping
     reads = make_reads(genome, tx, n_reads, r_seed + seed_shift, paired=paired)
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        np.savez(path, tid=reads.tid, pos=reads.pos, alen=reads.alen, flags=reads.flags, nblk=reads.nblk,
+                 blk_start=reads.blk_start, blk_len=reads.blk_len)
     return genome, tx, reads, mapping
 
 

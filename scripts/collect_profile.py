@@ -1,19 +1,37 @@
 #!/usr/bin/env python3
-"""Condense a scripts/profile.sh output directory into the files kept under profiles/<round>/:
+"""Condense a scripts/profile.sh output directory into the files kept under profiles/<round>/<config>/:
 kernel_stats.csv (rocprofv3 --stats), pmc_<pass>_per_kernel.csv (kernel, counter, launches, mean per
-launch), rocprofv3_summary.txt, and profiles/traffic.json (HBM bytes per launch of the tile kernel:
-FETCH_SIZE x2 + WRITE_SIZE, in KB as rocprofv3 reports them -- MI355X_MICROARCH.md, HBM section).
-usage: python scripts/collect_profile.py gpurun_out/prof_<tag> profiles/r01 [bench_line.json]"""
-import csv, glob, json, os, shutil, sys
+launch), rocprofv3_summary.txt, bench_line.json, and an entry of profiles/traffic.json (HBM bytes per
+launch of the dominant kernel).
+
+Counter units and corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are reported
+in KB; on gfx950 FETCH_SIZE tallies a wide coalesced read at half its bytes and WRITE_SIZE is
+uncalibrated, so both are calibrated on a known byte count in the kernel's own access pattern: the
+streaming probes bench.py runs in the same process (pc_stream_probe: k_probe_read = 16-byte loads per
+lane, k_probe_write = 8-byte stores per lane, 1 GiB each).  traffic = FETCH x f_read + WRITE x f_write.
+
+usage: python scripts/collect_profile.py gpurun_out/prof_<tag> profiles/r02/<config> <config>"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
 from collections import defaultdict
 
-src, dst = sys.argv[1], sys.argv[2]
+src, dst, config = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "summary.txt")):
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, "rocprofv3_summary.txt"))
+line = None
+if os.path.exists(os.path.join(src, "bench_line.json")):
+    rows = [l for l in open(os.path.join(src, "bench_line.json")).read().splitlines() if l.startswith("{")]
+    if rows:
+        line = json.loads(rows[-1])
+        json.dump(line, open(os.path.join(dst, "bench_line.json"), "w"), indent=1)
 means = {}
 for sub in ("sq1", "sq2", "fetch", "write", "tcc"):
     files = glob.glob(os.path.join(src, "pmc_" + sub, "**", "*counter_collection.csv"), recursive=True)
@@ -27,16 +45,52 @@ for sub in ("sq1", "sq2", "fetch", "write", "tcc"):
         for (k, c), v in sorted(d.items()):
             fh.write('"%s",%s,%d,%.6g\n' % (k, c, len(v), sum(v) / len(v)))
             means[(k, c)] = sum(v) / len(v)
-hist = [k for (k, c) in means if "k_hist_point" in k and c == "FETCH_SIZE"]
-if hist:
-    k = hist[0]
-    fetch_kb, write_kb = means[(k, "FETCH_SIZE")], means.get((k, "WRITE_SIZE"), 0.0)
-    tpath = os.path.join(os.path.dirname(os.path.abspath(dst)), "traffic.json")
-    t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    t.update({"FETCH_SIZE_KB_per_launch": round(fetch_kb, 1), "WRITE_SIZE_KB_per_launch": round(write_kb, 1),
-              "hbm_bytes_per_launch": int(round((2.0 * fetch_kb + write_kb) * 1024))})
-    json.dump(t, open(tpath, "w"), indent=1)
-    print("traffic: FETCH %.1f KB x2 + WRITE %.1f KB = %d bytes per launch" % (fetch_kb, write_kb, t["hbm_bytes_per_launch"]))
-if len(sys.argv) > 3:
-    line = [l for l in open(sys.argv[3]).read().splitlines() if l.startswith("{")][-1]
-    json.dump(json.loads(line), open(os.path.join(dst, "bench_line.json"), "w"), indent=1)
+
+
+def kernel_with(sub, counter):
+    # the instantiation with the largest counter value (C4 / C5 run a 256-thread and a single-wave class)
+    best = None
+    for (k, c), v in means.items():
+        if sub in k and c == counter and (best is None or v > means[(best, counter)]):
+            best = k
+    return best
+
+
+probe_bytes = float(1 << 30)
+cal = {}
+kr, kw = kernel_with("k_probe_read", "FETCH_SIZE"), kernel_with("k_probe_write", "WRITE_SIZE")
+if kr:
+    cal["f_read"] = probe_bytes / (means[(kr, "FETCH_SIZE")] * 1024.0)
+    cal["probe_read_FETCH_SIZE_KB"] = means[(kr, "FETCH_SIZE")]
+if kw:
+    cal["f_write"] = probe_bytes / (means[(kw, "WRITE_SIZE")] * 1024.0)
+    cal["probe_write_WRITE_SIZE_KB"] = means[(kw, "WRITE_SIZE")]
+dominant = "k_center" if config == "C3" else "k_hist_point"
+entry = {"config": config, "round": 2, "dominant_kernel": dominant, "calibration": cal,
+         "source": "%s/pmc_fetch_per_kernel.csv, pmc_write_per_kernel.csv (separate rocprofv3 --pmc passes, scripts/profile.sh)" % dst}
+if line is not None:
+    entry["n_records"] = line["config"]["records_per_gpu"]
+    entry["algorithmic_bytes_per_launch"] = line["roofline"]["algorithmic_bytes_per_launch"]
+fetch = write = 0.0
+per_kernel = {}
+for (k, c), v in means.items():
+    if dominant in k and "weigh" not in k and "order" not in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+        per_kernel.setdefault(k, {})[c] = v
+        if c == "FETCH_SIZE":
+            fetch += v
+        else:
+            write += v
+if per_kernel:
+    f_read, f_write = cal.get("f_read", 2.0), cal.get("f_write", 1.0)
+    entry.update({"FETCH_SIZE_KB_per_launch": round(fetch, 1), "WRITE_SIZE_KB_per_launch": round(write, 1),
+                  "per_instantiation_KB": per_kernel,
+                  "hbm_bytes_per_launch": int(round((f_read * fetch + f_write * write) * 1024)),
+                  "correction": "FETCH_SIZE x %.3f, WRITE_SIZE x %.3f: factors measured in the same runs on the 1 GiB streaming "
+                                "probes (16 B/lane loads, 8 B/lane stores); the guide's nominal factor for wide reads is 2" % (f_read, f_write)})
+tpath = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(dst))), "traffic.json")
+t = json.load(open(tpath)) if os.path.exists(tpath) else {}
+if "configs" not in t:
+    t = {"note": "HBM bytes per launch of the dominant kernel per config; round-1 C2 entry kept under r01", "r01": t, "configs": {}}
+t["configs"][config] = entry
+json.dump(t, open(tpath, "w"), indent=1)
+print(json.dumps(entry, indent=1))

@@ -167,6 +167,7 @@ def ga_case(group, files, spec, queries, size_filter=None, normalize=None, set_s
                 key + "_reads", np.array([offs[fakes.index(r.file)] + r.index for r in reads], np.int64))
             rec["warned"] = len(warns) > 0
             rec["warn_categories"] = sorted(set(c for c, _ in warns))
+            rec["warn_messages"] = [m for _, m in warns]
             # __getitem__ / get agree with get_reads_and_counts
             arr2 = ga.get(seg, roi_order=q.get("roi_order", True))
             assert arr2.dtype == arr.dtype and np.array_equal(arr2, arr)

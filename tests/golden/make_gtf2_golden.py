@@ -67,6 +67,12 @@ def synth_gtf2(seed=7, ngenes=60):
     for nm in ("tie.b", "tie.a"):
         lines.append("\t".join(["chrI", "synth", "exon", "5000", "5100", ".", "+", ".",
                                 'gene_id "tie"; transcript_id "%s"' % nm]))
+    # percent escapes (unescape_GTF2, gff_tokens.py:582-599) in ids, a repeated key (joined with a comma, with
+    # a FileFormatWarning), a lower-case escape and one outside the reference's table (both stay literal)
+    for s, e in ((7000, 7100), (7200, 7300)):
+        lines.append("\t".join(["chrI", "synth", "exon", str(s), str(e), ".", "+", ".",
+                                'gene_id "esc%2Cg"; transcript_id "esc%3B1"; note "q%22uoted%25"; note "second";']))
+    lines.append("\t".join(["chrI", "synth", "exon", "8000", "8100", ".", "+", ".", 'gene_id "low"; transcript_id "low%3b%41"']))
     return "\n".join(lines) + "\n"
 
 
@@ -78,9 +84,11 @@ def main():
     rejected = sorted(str(x.message).split("'")[1] for x in w if "Rejecting" in str(x.message))
     rows = [[t.get_name(), str(t), t.attr.get("cds_genome_start"), t.attr.get("cds_genome_end"),
              t.attr.get("gene_id")] for t in txs]
+    notes = {t.get_name(): t.attr.get("note") for t in txs if t.attr.get("note") is not None}
+    n_dup = sum(1 for x in w if "duplicate attribute key" in str(x.message))
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gtf2_transcripts.json")
     with open(out, "w") as fh:
-        json.dump({"gtf2": text, "transcripts": rows, "rejected": rejected}, fh)
+        json.dump({"gtf2": text, "transcripts": rows, "rejected": rejected, "notes": notes, "duplicate_key_warnings": n_dup}, fh)
     print(len(rows), "transcripts,", len(rejected), "rejected ->", out)
 
 

@@ -112,6 +112,8 @@ def test_golden_bamgenomearray(pa, group):
                 got = [offs[files.index(r.source)] + r.index for r in reads]
                 assert got == list(g[q["reads_out"]]), (case["spec"], q)
                 assert (len(warns) > 0) == q["warned"], (case["spec"], q)
+                if "warn_messages" in q:   # the text too, incl. the read length the Variable rule names (:633-648)
+                    assert [str(w.message) for w in warns] == q["warn_messages"], (case["spec"], q)
                 assert same(ga.get(seg, roi_order=q["roi_order"]), g[q["expected"]])
                 if q["roi_order"]:
                     assert same(ga[seg], g[q["expected"]])
@@ -792,3 +794,45 @@ def test_region_statistics_equal_reference_output(pa):
                 assert float(st["counts"][i]) == row["counts"]
                 assert st["counts_per_nucleotide"][i] == row["rpnt"] and st["rpkm"][i] == row["rpkm"]
             assert lines[i] == row["line"], (tab["spec"], i)
+
+
+def test_custom_filters_are_evaluated_like_the_reference(pa, oracle):
+    """An arbitrary filter callable sees what the reference would pass to it (genome_array.py:800-820):
+    only reads ``fetch`` returns for the queried region, only the strand the region keeps, and -- here --
+    each read at most once; the counts equal the oracle's on the reads the filter keeps."""
+    from plastid_amd import synth
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.0005, tx_scale=0.005)
+    ga = pa.BAMGenomeArray(reads, mapping=pa.FivePrimeMapFactory(5))
+    seen = []
+
+    def keep_even_starts(read):
+        seen.append((read.index, read.is_reverse))
+        return read.positions[0] % 2 == 0
+    ga.add_filter("even", keep_even_starts)
+    chrom = reads.references[3]
+    seg = pa.GenomicSegment(chrom, 1000, 9000, "+")
+    got = ga[seg]
+    fetched = reads.fetch_indices(chrom, 1000, 9000)
+    fwd = fetched[(reads.flags[fetched] & 1) == 0]
+    assert sorted(i for i, _ in seen) == list(fwd) and not any(rev for _, rev in seen)   # fetched, forward only, once each
+    n_first = len(seen)
+    assert np.array_equal(ga[seg], got) and len(seen) == n_first                          # cached verdicts
+    # expected: the oracle on the records the filter keeps
+    keep = np.ones(reads.n, bool)
+    keep[reads.pos % 2 == 1] = False
+    sub = reads.subset(np.nonzero(keep)[0])
+    aln = aln_dict([sub])
+    arrays, _ = oracle.count_segments(aln, oracle.mapping_spec("fiveprime", 5), [3], [1000], [9000], [1])
+    assert np.array_equal(got, arrays[0])
+    # an overlapping '-' query asks about the reverse reads only, and only the new ones
+    seg2 = pa.GenomicSegment(chrom, 5000, 12000, "-")
+    got2 = ga.get(seg2, roi_order=False)
+    new = seen[n_first:]
+    f2 = reads.fetch_indices(chrom, 5000, 12000)
+    assert sorted(i for i, _ in new) == list(f2[(reads.flags[f2] & 1) == 1]) and all(rev for _, rev in new)
+    arrays, _ = oracle.count_segments(aln, oracle.mapping_spec("fiveprime", 5), [3], [5000], [12000], [2])
+    assert np.array_equal(got2, arrays[0])
+    # removing the filter restores every read
+    ga.remove_filter("even")
+    arrays, _ = oracle.count_segments(aln_dict([reads]), oracle.mapping_spec("fiveprime", 5), [3], [1000], [9000], [1])
+    assert np.array_equal(ga[seg], arrays[0])

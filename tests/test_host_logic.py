@@ -303,3 +303,30 @@ def test_c_client_runs(tmp_path):
         want[p - 95] += 1
     assert out.splitlines()[0] == "counts[95..125) = " + " ".join(str(v) for v in want)
     assert out.splitlines()[1].startswith("total = 4 ")
+
+
+def test_no_kernel_uses_scratch_memory(tmp_path):
+    """Every kernel of the built gfx950 code object has ``private_segment_fixed_size`` 0.  A run-time
+    index into a small per-thread array (round 1: ``HistCfg::base[mode]``) silently moves the whole
+    struct to scratch: 44 bytes per lane that every work item wrote to HBM -- 2 GB per step on C4 and
+    8 GB on C5 (profiles/r02: WRITE_SIZE 2-3.7x the output bytes)."""
+    import shutil
+    import subprocess
+    from plastid_amd import build
+    lib = build.build_library()
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not available")
+    work = tmp_path / "co"
+    work.mkdir()
+    copy = str(work / "lib.so")
+    shutil.copy(lib, copy)
+    subprocess.check_call([objdump, "--offloading", copy], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(work))
+    objs = [f for f in os.listdir(str(work)) if "gfx950" in f]
+    assert objs, "no gfx950 code object found in %s" % lib
+    notes = subprocess.check_output([readelf, "--notes", str(work / objs[0])]).decode()
+    sizes = [int(line.split(":")[1]) for line in notes.splitlines() if ".private_segment_fixed_size" in line]
+    names = [line.split(":")[1].strip() for line in notes.splitlines() if line.strip().startswith(".name:")]
+    assert len(sizes) >= 30 and len(sizes) == len(names)
+    bad = [n for n, s in zip(names, sizes) if s != 0]
+    assert not bad, "kernels using scratch memory: %s" % bad
