@@ -42,6 +42,7 @@ constexpr int kWG = 256;          // 4 waves of 64
 constexpr int kHistWG = PC_HIST_WG;
 constexpr int kWave = 64;
 constexpr uint32_t kFlagReverse = 0x01;
+constexpr uint32_t kFlagRuns = 0x20;      // engine-internal: every aligned run of the record is in the run stream
 constexpr uint32_t kFlagLong = 0x40;      // engine-internal: span > W, handled by the long-read path
 constexpr uint32_t kFlagExcluded = 0x80;
 constexpr int kGatherChunk = 1024;
@@ -94,9 +95,20 @@ struct FileView {
     const uint32_t *llin_tab;       // same for the long-span list (first long read at/after the bucket)
     const uint32_t *plin_tab;       // first long read whose running max end exceeds the bucket start
     const int64_t *lin_off;         // ntid+1 (shared by both tables)
+    // run stream: one 8-byte record per aligned run of every multi-run read with L <= kStreamMaxLen, sorted
+    // by (contig, run start) -- what the point rules scan instead of the gapped / long-span lists
+    const uint2 *run_rec;           // {run start, run length | read index of the run's first base << 8 | L << 16 | flags << 24}
+    const uint32_t *rlin_tab;       // first run at/after every bucket
+    // long-span reads that are NOT in the run stream (aligned length > kStreamMaxLen): the point rules' own list
+    const uint4 *xlong_rec;
+    const int4 *xlong_runs;
+    const uint32_t *xllin_tab;
+    const uint32_t *xplin_tab;
     int64_t n;
     int64_t nlong;
     int64_t ngap;
+    int64_t nrunrec;
+    int64_t nxlong;
 };
 
 // Pointers that come out of a FileView are loaded from memory, so the compiler only knows
@@ -128,9 +140,17 @@ struct GFile {
     const uint32_t PC_GLOBAL *llin_tab;
     const uint32_t PC_GLOBAL *plin_tab;
     const int64_t PC_GLOBAL *lin_off;
+    const u32x2 PC_GLOBAL *run_rec;
+    const uint32_t PC_GLOBAL *rlin_tab;
+    const u32x4 PC_GLOBAL *xlong_rec;
+    const i32x4 PC_GLOBAL *xlong_runs;
+    const uint32_t PC_GLOBAL *xllin_tab;
+    const uint32_t PC_GLOBAL *xplin_tab;
     int64_t n;
     int64_t nlong;
     int64_t ngap;
+    int64_t nrunrec;
+    int64_t nxlong;
 };
 
 __device__ __forceinline__ GFile gfile(const FileView &v) {
@@ -154,9 +174,17 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.llin_tab = (const uint32_t PC_GLOBAL *)v.llin_tab;
     g.plin_tab = (const uint32_t PC_GLOBAL *)v.plin_tab;
     g.lin_off = (const int64_t PC_GLOBAL *)v.lin_off;
+    g.run_rec = (const u32x2 PC_GLOBAL *)v.run_rec;
+    g.rlin_tab = (const uint32_t PC_GLOBAL *)v.rlin_tab;
+    g.xlong_rec = (const u32x4 PC_GLOBAL *)v.xlong_rec;
+    g.xlong_runs = (const i32x4 PC_GLOBAL *)v.xlong_runs;
+    g.xllin_tab = (const uint32_t PC_GLOBAL *)v.xllin_tab;
+    g.xplin_tab = (const uint32_t PC_GLOBAL *)v.xplin_tab;
     g.n = v.n;
     g.nlong = v.nlong;
     g.ngap = v.ngap;
+    g.nrunrec = v.nrunrec;
+    g.nxlong = v.nxlong;
     return g;
 }
 
@@ -207,6 +235,7 @@ struct WorkItem {
     int64_t lo, hi;   // record range of the packed stream
     int64_t glo, ghi; // range of the gapped-record list (first work item of a tile only)
     int64_t llo, lhi; // candidate range of the long-span list (first work item only)
+    uint32_t rlo, rhi; // range of the run stream
     uint32_t tile;
     uint32_t file;
     int32_t win_start; // copied from the tile: saves the histogram kernel a dependent load
@@ -474,7 +503,7 @@ __device__ __forceinline__ int64_t lower_bound_i32(const uint32_t PC_GLOBAL *v, 
 // One returning atomic per class per workgroup: a single hot counter saturates near 90/us.
 __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
                                                            FileView file0, const FileView *__restrict__ files,
-                                                           int nfiles, int G, int W, int Ws, int64_t R, int64_t pile,
+                                                           int nfiles, int G, int W, int Ws, int Wr, int64_t R, int64_t pile,
                                                            WorkItem *work, uint32_t *nwork, uint32_t *tile_items,
                                                            uint32_t work_cap, WorkItem *work_small, int small_g,
                                                            int64_t small_n, int diag) {
@@ -486,7 +515,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     Tile tl = {};
     GFile fv = {};
     int64_t l0 = 0, nb = 0, ws = 0;
-    int64_t wlo = 0, whi = 0, wglo = 0, wghi = 0, llo = 0, lhi = 0;
+    int64_t wlo = 0, whi = 0, wglo = 0, wghi = 0, llo = 0, lhi = 0, wrlo = 0, wrhi = 0;
     uint32_t n_heavy = 0, n_light = 0, n_small = 0;
     bool merge = false;
     if (live) {
@@ -506,12 +535,16 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             wglo = lin_floor(fv.glin_tab, l0, nb, s_lo - W + 1);
             wghi = lin_floor(fv.glin_tab, l0, nb, s_hi);
         }
-        if (fv.nlong) {
-            // long-span reads that can reach the queried span: they start before its end, and the
-            // running maximum of the ends (monotone) has passed its start
+        if (fv.nrunrec) { // aligned runs (of gapped and spliced reads) that start up to Wr before the span
+            wrlo = lin_floor(fv.rlin_tab, l0, nb, s_lo - Wr + 1);
+            wrhi = lin_floor(fv.rlin_tab, l0, nb, s_hi);
+        }
+        if (fv.nxlong) {
+            // long-span reads outside the run stream that can reach the queried span: they start before
+            // its end, and the running maximum of the ends (monotone) has passed its start
             // (two table lookups, both rounded outwards to a 128-nt bucket)
-            lhi = lin_floor(fv.llin_tab, l0, nb, s_hi);
-            llo = lin_floor(fv.plin_tab, l0, nb, s_lo);
+            lhi = lin_floor(fv.xllin_tab, l0, nb, s_hi);
+            llo = lin_floor(fv.xplin_tab, l0, nb, s_lo);
             if (llo > lhi) llo = lhi;
         }
         const int64_t n = whi - wlo;
@@ -520,7 +553,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             while (S < kMaxSub && G % (S * 2 << kLinShift) == 0 && n > R * S) S <<= 1; // sub-windows end on index buckets
             if (S == 1) {
                 const bool small = small_g > 0 && (int)tl.span_hi - (int)tl.span_lo <= small_g && n <= small_n &&
-                                   (wghi - wglo) <= small_n && (lhi - llo) <= small_n;
+                                   (wghi - wglo) <= small_n && (lhi - llo) <= small_n && (wrhi - wrlo) <= small_n;
                 if (small) n_small = 1; else if (n > R) n_heavy = 1; else n_light = 1;
             } else {
                 const int sub = G / S;
@@ -535,7 +568,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         if (merge) {
             S = 1;
             n_heavy = 0;
-            n_light = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || f == 0) ? 1u : 0u);
+            n_light = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || wrhi > wrlo || f == 0) ? 1u : 0u);
         }
     }
     if (diag && live && f == 0 && lhi > llo) atomicAdd(&nwork[3], (uint32_t)(lhi - llo)); // PC_DEBUG_WORK: long-span candidates
@@ -564,6 +597,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     w.merge = merge ? 1u : 0u;
     if (n_small) {
         w.lo = wlo; w.hi = whi; w.glo = wglo; w.ghi = wghi; w.llo = llo; w.lhi = lhi;
+        w.rlo = (uint32_t)wrlo; w.rhi = (uint32_t)wrhi;
         w.win_start = tl.win_start + (int32_t)tl.span_lo; // a small window that starts at the first queried position
         w.sub_lo = 0; w.sub_hi = small_g;
         w.span_lo = 0; w.span_hi = (uint16_t)(tl.span_hi - tl.span_lo);
@@ -578,6 +612,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             w.hi = (w.lo + R < whi) ? w.lo + R : whi;
             w.glo = k == 0 ? wglo : 0; w.ghi = k == 0 ? wghi : 0;
             w.llo = k == 0 ? llo : 0;  w.lhi = k == 0 ? lhi : 0;
+            w.rlo = k == 0 ? (uint32_t)wrlo : 0u; w.rhi = k == 0 ? (uint32_t)wrhi : 0u;
             w.sub_lo = 0; w.sub_hi = G;
             const uint32_t slot = work_cap - 1u - (il + k);
             if (slot < work_cap) work[slot] = w;
@@ -592,6 +627,8 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         w.hi = lin_floor(fv.lin_tab, l0, nb, e);
         w.glo = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, a - W + 1) : 0;
         w.ghi = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, e) : 0;
+        w.rlo = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, a - Wr + 1) : 0u;
+        w.rhi = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, e) : 0u;
         w.llo = llo; w.lhi = lhi; // every sub-window checks the (few) long-span candidates
         w.sub_lo = S == 1 ? 0 : k * sub;
         w.sub_hi = S == 1 ? G : w.sub_lo + sub;
@@ -876,6 +913,9 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     const u32x4 gnone = {0u, kFlagExcluded << 16, 0u, 0u};
     const u32x4 gfirst = (gj0 < w.ghi) ? fv.gap_rec[gj0] : gnone;
     const i32x4 gfirst_runs = (gj0 < w.ghi) ? fv.gap_runs[gj0] : i32x4{0, 1, 0, 0};
+    const u32x2 rnone = {0u, kFlagExcluded << 24};
+    const uint32_t rj0 = w.rlo + threadIdx.x;
+    const u32x2 rfirst = (rj0 < w.rhi) ? fv.run_rec[rj0] : rnone;
 
     HistCfg c;
     c.win_start = w.win_start;
@@ -943,7 +983,28 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
         fast_bin<4>(ftab, w.mode_mask, c.G, dump, w4, smem);
     }
 
-    // ---- gapped records (deletions, short introns): their aligned runs live in a side
+    // ---- run stream: the aligned runs of gapped and spliced reads (aligned length <= kStreamMaxLen), one
+    // 8-byte record per run, sorted by run start.  A rule picks ONE index k of read.positions; the run
+    // whose read indices [cum, cum + len) contain k holds the mapped position start + (k - cum), and that
+    // run starts at most `len` before it -- so a window scans the runs that start up to Wr before its
+    // first queried position: no dependent loads, no introns to look across, every run read once.
+    for (uint32_t base = w.rlo; base < w.rhi; base += WG) {
+        const uint32_t j = base + threadIdx.x;
+        const bool in = j < w.rhi;
+        const u32x2 rr = base == w.rlo ? rfirst : (in ? fv.run_rec[j] : rnone);
+        const int len = (int)(rr.y & 0xffu), cum = (int)((rr.y >> 8) & 0xffu), L = (int)((rr.y >> 16) & 0xffu);
+        const uint32_t fl = rr.y >> 24;
+        const bool valid = in & ((fl & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
+        int kf, kr;
+        uint32_t rowoff;
+        map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
+        const bool hf = (uint32_t)(kf - cum) < (uint32_t)len, hr = (uint32_t)(kr - cum) < (uint32_t)len; // the index lies in this run
+        const int32_t pf = (int32_t)rr.x + (kf - cum), pr = (int32_t)rr.x + (kr - cum);
+        hist_bin(c, valid, fl & kFlagReverse, hf ? kf : -1, hr ? kr : -1, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start),
+                 rowoff, bins);
+    }
+
+    // ---- gapped records outside the run stream (aligned length > kStreamMaxLen): their aligned runs live in a side
     // array; consecutive list entries own consecutive runs, so these gathers stay coalesced.
     for (int64_t base = w.glo; base < w.ghi; base += WG) {
         const int64_t j = base + threadIdx.x;
@@ -966,8 +1027,8 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
     for (int64_t base = w.llo; base < w.lhi; base += WG) {
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.lhi;
-        const u32x4 g = in ? fv.long_rec[j] : gnone;
-        const i32x4 gr = in ? fv.long_runs[j] : i32x4{0, 1, 0, 0};
+        const u32x4 g = in ? fv.xlong_rec[j] : gnone;
+        const i32x4 gr = in ? fv.xlong_runs[j] : i32x4{0, 1, 0, 0};
         const uint32_t meta = g.y, hi = meta >> 16;
         const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
         const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
@@ -1514,6 +1575,50 @@ __global__ __launch_bounds__(kWG) void k_update_flags(uint2 *rec, uint32_t *stre
     r.y = (r.y & keep) | ((uint32_t)(flags[i] & (kFlagReverse | kFlagExcluded)) << 16);
     rec[i] = r;
     stream[i] = stream_word(r.x, r.y);
+}
+
+__global__ __launch_bounds__(kWG) void k_update_run_flags(uint2 *runs, const uint32_t *__restrict__ run_recidx, int64_t n,
+                                                          const uint2 *__restrict__ rec) {
+    const int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (j >= n) return;
+    uint2 r = runs[j];
+    const uint32_t fl = (rec[run_recidx[j]].y >> 16) & (kFlagReverse | kFlagExcluded);
+    r.y = (r.y & ~((kFlagReverse | kFlagExcluded) << 24)) | (fl << 24);
+    runs[j] = r;
+}
+
+// ---------------------------------------------------------------- run stream construction (staging time)
+// 64-bit sort key of every run: contig << 32 | run start; the payload is permuted with the sorted indices.
+__global__ __launch_bounds__(kWG) void k_run_gather(const uint32_t *__restrict__ order, const uint2 *__restrict__ val_in,
+                                                    const uint32_t *__restrict__ idx_in, int64_t n, uint2 *val_out,
+                                                    uint32_t *idx_out) {
+    const int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t o = order[j];
+    val_out[j] = val_in[o];
+    idx_out[j] = idx_in[o];
+}
+
+// rlin_tab[g] = first sorted run whose (contig, start) is not before bucket g's edge (entry nb of a contig =
+// its end), from the sorted 64-bit keys: one bisection per table entry
+__global__ __launch_bounds__(kWG) void k_run_lin(const unsigned long long *__restrict__ keys, int64_t n,
+                                                 const int64_t *__restrict__ lin_off, int ntid, int64_t nlin, uint32_t *rlin) {
+    const int64_t g = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (g >= nlin) return;
+    int lo_t = 0, hi_t = ntid;             // contig of table entry g
+    while (lo_t < hi_t) {
+        const int mid = (lo_t + hi_t) >> 1;
+        if (lin_off[mid + 1] <= g) lo_t = mid + 1; else hi_t = mid;
+    }
+    const int t = lo_t;
+    const int64_t k = g - lin_off[t], nb = lin_off[t + 1] - lin_off[t] - 1;
+    const unsigned long long key = k >= nb ? ((unsigned long long)(t + 1) << 32) : (((unsigned long long)t << 32) | (unsigned long long)(k << kLinShift));
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    rlin[g] = (uint32_t)lo;
 }
 
 __global__ __launch_bounds__(kWG) void k_update_side_flags(uint4 *list, int64_t n, const uint2 *__restrict__ rec) {

@@ -18,6 +18,8 @@
 //   pc_rle / pc_total / pc_mapped_reads / pc_warn_flags   consumers of a finished count
 #include "pc_kernels.hip.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -225,6 +227,18 @@ struct StagedFile {
     int len_min = 65536, len_max = -1; // aligned lengths present
     int slen_min = 0, slen_max = 0;    // ... among the records the 4-byte stream carries
     DevBuf<uint32_t> stream;           // 4-byte record stream (pc::stream_word), padded with skip words
+    // run stream (aligned runs of multi-run reads with L <= kStreamMaxLen, sorted by contig and run start)
+    int64_t nrunrec = 0;
+    int Wr = 1;                        // longest run it carries
+    DevBuf<uint2> run_rec;
+    DevBuf<uint32_t> run_recidx;       // record of every run (for pc_update_flags)
+    DevBuf<uint32_t> rlin_tab;
+    // long-span reads outside the run stream: the point rules' own long list
+    int64_t nxlong = 0;
+    int Wg = 1;                        // longest span in the gapped-record list
+    DevBuf<uint4> xlong_rec;
+    DevBuf<int4> xlong_runs;
+    DevBuf<uint32_t> xllin_tab, xplin_tab;
     FileView view() const {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
@@ -234,6 +248,8 @@ struct StagedFile {
         v.gap_rec = gap_rec.p; v.gap_tid_bounds = gap_tid_bounds.p; v.ngap = ngap;
         v.gap_runs = gap_runs.p; v.long_runs = long_runs.p;
         v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.llin_tab = llin_tab.p; v.plin_tab = plin_tab.p; v.lin_off = lin_off.p;
+        v.run_rec = run_rec.p; v.rlin_tab = rlin_tab.p; v.nrunrec = nrunrec;
+        v.xlong_rec = xlong_rec.p; v.xlong_runs = xlong_runs.p; v.xllin_tab = xllin_tab.p; v.xplin_tab = xplin_tab.p; v.nxlong = nxlong;
         return v;
     }
 };
@@ -315,6 +331,16 @@ struct pc_engine {
     int W() const {
         int w = 1;
         for (auto *f : files) w = std::max(w, f->W);
+        return w;
+    }
+    int Wg() const {   // halo of the gapped-record list
+        int w = 1;
+        for (auto *f : files) w = std::max(w, f->Wg);
+        return w;
+    }
+    int Wr() const {   // halo of the run stream: its longest run
+        int w = 1;
+        for (auto *f : files) w = std::max(w, f->Wr);
         return w;
     }
     int Ws() const {   // halo of the 4-byte record stream: the longest aligned length it carries
@@ -538,7 +564,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     struct ChunkErr { int64_t idx = INT64_MAX; int code = PC_OK; char msg[200] = {0}; };
     struct Chunk1 {
         ChunkErr err;
-        std::vector<int64_t> tid_count, span_hist, len_hist;
+        std::vector<int64_t> tid_count, span_hist, len_hist, tid_end;
         int64_t runs = 0, cursor = 0;
     };
     std::vector<Chunk1> c1((size_t)T);
@@ -563,6 +589,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         c.tid_count.assign((size_t)ntid + 1, 0);
         c.span_hist.assign(1026, 0); // spans 0..1024, [1025] = larger
         c.len_hist.assign(65536, 0);
+        c.tid_end.assign((size_t)ntid, 0);
         int64_t run_cursor = c.cursor;
         auto bad = [&](int64_t i, int code, const char *fmt, long long a1, long long a2) {
             c.err.idx = i; c.err.code = code;
@@ -599,11 +626,12 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             }
             if (end > 0x7fffffffLL) { bad(i, PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", i, 0); return; }
             const int64_t sp = end - pos[i];
+            c.tid_end[(size_t)tid[i]] = std::max(c.tid_end[(size_t)tid[i]], end);
             c.span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
             c.len_hist[(size_t)L] += 1;
         }
     });
-    std::vector<int64_t> span_hist(1026, 0), len_hist(65536, 0);
+    std::vector<int64_t> span_hist(1026, 0), len_hist(65536, 0), tid_end((size_t)ntid, 0);
     {
         const ChunkErr *first = nullptr;
         for (const auto &c : c1)
@@ -612,6 +640,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         for (const auto &c : c1) {
             if (c.tid_count.empty()) continue;
             for (int t = 0; t <= ntid; ++t) tid_bounds[(size_t)t] += c.tid_count[(size_t)t];
+            for (int t = 0; t < ntid; ++t) tid_end[(size_t)t] = std::max(tid_end[(size_t)t], c.tid_end[(size_t)t]);
             for (size_t k = 0; k < span_hist.size(); ++k) span_hist[k] += c.span_hist[k];
             for (size_t k = 0; k < len_hist.size(); ++k) len_hist[k] += c.len_hist[k];
         }
@@ -647,9 +676,12 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (const char *env = getenv("PC_STAGE_SLICE")) S = std::max<int64_t>(1, atoll(env)); // test knob: tiny slices
     const int64_t nslices = (n + S - 1) / S;
     struct Unit { // one thread's share of one slice
-        std::vector<uint4> long_rec, gap_rec;
-        std::vector<int32_t> long_span;
-        int W = 1, smin = 65536, smax = -1;
+        std::vector<uint4> long_rec, gap_rec, xlong_rec;
+        std::vector<int32_t> long_span, xlong_span;
+        std::vector<unsigned long long> run_key;   // contig << 32 | run start
+        std::vector<uint2> run_val;                // {run start, len | cum << 8 | L << 16 | flags << 24}
+        std::vector<uint32_t> run_idx;             // record index
+        int W = 1, Wg = 1, Wr = 1, smin = 65536, smax = -1;
         int64_t max_span = 1, cursor = 0;
     };
     std::vector<Unit> units((size_t)(nslices * T));
@@ -713,14 +745,36 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                     const int32_t sp = (int32_t)(end - pos[i]);
                     uint32_t meta = (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) | ((uint32_t)nb << 24);
                     c.max_span = std::max<int64_t>(c.max_span, sp);
+                    // multi-run reads of ordinary length: every aligned run goes to the run stream (what the
+                    // point rules scan); only longer reads keep to the gapped / long-span side lists there
+                    const bool in_runs = nb >= 2 && L <= kStreamMaxLen;
+                    if (in_runs) {
+                        meta |= (kFlagRuns << 16);
+                        uint32_t cum = 0;
+                        for (int k = 0; k < nb; ++k) {
+                            const uint32_t rs = (uint32_t)blk_start[boff + k], rl = (uint32_t)blk_len[boff + k];
+                            c.run_key.push_back(((unsigned long long)(uint32_t)tid[i] << 32) | rs);
+                            c.run_val.push_back(make_uint2(rs, rl | (cum << 8) | ((uint32_t)L << 16) |
+                                                               ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 24)));
+                            c.run_idx.push_back((uint32_t)i);
+                            c.Wr = std::max(c.Wr, (int)rl);
+                            cum += rl;
+                        }
+                    }
                     if (sp > wcap) {
                         meta |= (kFlagLong << 16);
                         c.long_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
                         c.long_span.push_back(sp);
+                        if (!in_runs) {
+                            c.xlong_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
+                            c.xlong_span.push_back(sp);
+                        }
                     } else {
                         c.W = std::max(c.W, (int)sp);
-                        if (nb >= 2 || L > kStreamMaxLen) // binned from the side list, not from the stream
+                        if ((nb >= 2 || L > kStreamMaxLen) && !in_runs) { // binned from the side list, not from a stream
                             c.gap_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
+                            c.Wg = std::max(c.Wg, (int)sp);
+                        }
                     }
                     const uint32_t wd = stream_word((uint32_t)pos[i], meta & ~((uint32_t)kFlagExcluded << 16));
                     if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
@@ -764,15 +818,20 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     clk.lap("pack + upload (pipelined)");
     // side lists in record order (slice-major, then thread order inside a slice): every unit copies
     // its entries to their final place; only the running maximum of the ends is a serial walk
-    std::vector<int64_t> long_bounds((size_t)ntid + 1, 0), gap_bounds((size_t)ntid + 1, 0);
+    std::vector<int64_t> long_bounds((size_t)ntid + 1, 0), gap_bounds((size_t)ntid + 1, 0), xlong_bounds((size_t)ntid + 1, 0);
     int W = 1;
     int64_t max_span = 1;
-    std::vector<size_t> lo_of(units.size() + 1, 0), go_of(units.size() + 1, 0);
+    std::vector<size_t> lo_of(units.size() + 1, 0), go_of(units.size() + 1, 0), xo_of(units.size() + 1, 0), ro_of(units.size() + 1, 0);
+    int Wg = 1, Wr = 1;
     {
         int smin = 65536, smax = -1;
         for (size_t u = 0; u < units.size(); ++u) {
             const Unit &c = units[u];
             W = std::max(W, c.W);
+            Wg = std::max(Wg, c.Wg);
+            Wr = std::max(Wr, c.Wr);
+            xo_of[u + 1] = xo_of[u] + c.xlong_rec.size();
+            ro_of[u + 1] = ro_of[u] + c.run_key.size();
             max_span = std::max(max_span, c.max_span);
             smin = std::min(smin, c.smin); smax = std::max(smax, c.smax);
             lo_of[u + 1] = lo_of[u] + c.long_rec.size();
@@ -781,12 +840,17 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         sf->slen_min = smax >= smin ? smin : 0;
         sf->slen_max = smax >= smin ? smax : 0;
     }
-    const size_t nlong = lo_of[units.size()], ngap = go_of[units.size()];
-    HostBuf<uint4> long_rec(nlong), gap_rec(ngap);
+    const size_t nlong = lo_of[units.size()], ngap = go_of[units.size()], nxlong = xo_of[units.size()], nrunrec = ro_of[units.size()];
+    if (nrunrec >= (size_t)0x7fffffffu) { delete sf; return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 aligned runs of multi-run reads per file are not supported"); }
+    HostBuf<uint4> long_rec(nlong), gap_rec(ngap), xlong_rec(nxlong);
     HostBuf<uint32_t> long_idx(nlong);
-    HostBuf<int32_t> long_tid(nlong), long_pmax(nlong);
-    HostBuf<int4> long_runs(nlong), gap_runs(ngap);
-    if (!long_rec.p || !gap_rec.p || !long_idx.p || !long_tid.p || !long_pmax.p || !long_runs.p || !gap_runs.p) {
+    HostBuf<int32_t> long_tid(nlong), long_pmax(nlong), xlong_tid(nxlong), xlong_pmax(nxlong);
+    HostBuf<int4> long_runs(nlong), gap_runs(ngap), xlong_runs(nxlong);
+    HostBuf<unsigned long long> run_key(nrunrec);
+    HostBuf<uint2> run_val(nrunrec);
+    HostBuf<uint32_t> run_idx(nrunrec);
+    if (!long_rec.p || !gap_rec.p || !long_idx.p || !long_tid.p || !long_pmax.p || !long_runs.p || !gap_runs.p || !xlong_rec.p ||
+        !xlong_tid.p || !xlong_pmax.p || !xlong_runs.p || !run_key.p || !run_val.p || !run_idx.p) {
         delete sf;
         return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
     }
@@ -817,6 +881,22 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 gap_rec[at] = c.gap_rec[k];
                 gap_runs[at] = first_two(c.gap_rec[k]);
             }
+            at = xo_of[(size_t)u];
+            int t_x = 0;
+            for (size_t k = 0; k < c.xlong_rec.size(); ++k, ++at) {
+                const uint4 g = c.xlong_rec[k];
+                while ((int64_t)g.w >= tid_bounds[(size_t)t_x + 1]) ++t_x;
+                xlong_rec[at] = g;
+                xlong_tid[at] = t_x;
+                xlong_pmax[at] = (int32_t)g.x + c.xlong_span[k];
+                xlong_runs[at] = first_two(g);
+            }
+            at = ro_of[(size_t)u];
+            if (!c.run_key.empty()) {
+                memcpy(run_key.p + at, c.run_key.data(), c.run_key.size() * sizeof(unsigned long long));
+                memcpy(run_val.p + at, c.run_val.data(), c.run_val.size() * sizeof(uint2));
+                memcpy(run_idx.p + at, c.run_idx.data(), c.run_idx.size() * sizeof(uint32_t));
+            }
         }
     });
     {
@@ -836,11 +916,24 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         }
         for (int t = 0; t < ntid; ++t) long_bounds[(size_t)t + 1] += long_bounds[(size_t)t];
         for (int t = 0; t < ntid; ++t) gap_bounds[(size_t)t + 1] += gap_bounds[(size_t)t];
+        cur_tid = -1; pm = 0;
+        for (size_t k = 0; k < nxlong; ++k) { // the same for the long-span reads outside the run stream
+            const int t_x = xlong_tid[k];
+            if (t_x != cur_tid) { cur_tid = t_x; pm = 0; }
+            pm = std::max(pm, xlong_pmax[k]);
+            xlong_pmax[k] = pm;
+            xlong_bounds[(size_t)t_x + 1] += 1;
+        }
+        for (int t = 0; t < ntid; ++t) xlong_bounds[(size_t)t + 1] += xlong_bounds[(size_t)t];
     }
     sf->W = W;
+    sf->Wg = Wg;
+    sf->Wr = Wr;
     sf->max_span = max_span;
     sf->nlong = (int64_t)nlong;
     sf->ngap = (int64_t)ngap;
+    sf->nxlong = (int64_t)nxlong;
+    sf->nrunrec = (int64_t)nrunrec;
     units.clear();
     units.shrink_to_fit();
     clk.lap("side lists");
@@ -851,10 +944,13 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         const uint4 *h_lr = long_rec.p, *h_gr = gap_rec.p;
         const uint32_t *h_li = long_idx.p;
         const int32_t *h_lt = long_tid.p, *h_lp = long_pmax.p;
-        const int4 *h_lru = long_runs.p, *h_gru = gap_runs.p;
+        const int4 *h_lru = long_runs.p, *h_gru = gap_runs.p, *h_xru = xlong_runs.p;
+        const uint4 *h_xr = xlong_rec.p;
         side_up = std::async(std::launch::async, [=]() -> int {
             if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
             int r = f->long_idx.upload(h_li, nlong, up_stream);
+            if (r == PC_OK) r = f->xlong_rec.upload(h_xr, nxlong, up_stream);
+            if (r == PC_OK) r = f->xlong_runs.upload(h_xru, nxlong, up_stream);
             if (r == PC_OK) r = f->long_tid.upload(h_lt, nlong, up_stream);
             if (r == PC_OK) r = f->long_pmax.upload(h_lp, nlong, up_stream);
             if (r == PC_OK) r = f->long_rec.upload(h_lr, nlong, up_stream);
@@ -875,6 +971,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         int64_t last = en > b ? (int64_t)pos[en - 1] : -1;
         const int64_t lb = long_bounds[(size_t)t], le = long_bounds[(size_t)t + 1];
         if (le > lb) last = std::max<int64_t>(last, (int64_t)long_pmax[(size_t)le - 1] - 1);
+        if (en > b) last = std::max<int64_t>(last, tid_end[(size_t)t] - 1);   // later runs of gapped reads start beyond every record start
         const int64_t nb = last >= 0 ? (last >> kLinShift) + 1 : 0;
         lin_off[(size_t)t + 1] = lin_off[(size_t)t] + nb + 1;
     }
@@ -920,6 +1017,12 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     // long-span list: by start, and by running maximum end (both monotone)
     fill_lin(llin_tab, long_bounds, [&](int64_t i, int64_t edge) { return (int64_t)(int32_t)long_rec[(size_t)i].x < edge; });
     fill_lin(plin_tab, long_bounds, [&](int64_t i, int64_t edge) { return (int64_t)long_pmax[(size_t)i] <= edge; });
+    HostBuf<uint32_t> xllin_tab(nxlong ? nlin : 0), xplin_tab(nxlong ? nlin : 0);
+    if (nxlong) {
+        if (!xllin_tab.p || !xplin_tab.p) { (void)side_up.get(); delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
+        fill_lin(xllin_tab, xlong_bounds, [&](int64_t i, int64_t edge) { return (int64_t)(int32_t)xlong_rec[(size_t)i].x < edge; });
+        fill_lin(xplin_tab, xlong_bounds, [&](int64_t i, int64_t edge) { return (int64_t)xlong_pmax[(size_t)i] <= edge; });
+    }
 
     clk.lap("linear index");
     // ---- the remaining tables
@@ -940,8 +1043,57 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc == PC_OK) rc = sf->glin_tab.upload(glin_tab.p, nlin, e->stream);
     if (rc == PC_OK) rc = sf->llin_tab.upload(llin_tab.p, nlin, e->stream);
     if (rc == PC_OK) rc = sf->plin_tab.upload(plin_tab.p, nlin, e->stream);
+    if (rc == PC_OK && nxlong) rc = sf->xllin_tab.upload(xllin_tab.p, nlin, e->stream);
+    if (rc == PC_OK && nxlong) rc = sf->xplin_tab.upload(xplin_tab.p, nlin, e->stream);
     if (rc == PC_OK) rc = sf->lin_off.upload(lin_off, e->stream);
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
+    // ---- run stream: sorted by (contig, run start) on the GPU (radix sort of the 64-bit keys, the 8-byte
+    // records and their record indices permuted along), then its linear index by one bisection per bucket
+    if (rc == PC_OK && nrunrec) {
+        DevBuf<unsigned long long> d_key, d_key_sorted;
+        DevBuf<uint32_t> d_ord, d_ord_sorted, d_idx_in;
+        DevBuf<uint2> d_val_in;
+        DevBuf<uint8_t> d_tmp;
+        rc = d_key.upload(run_key.p, nrunrec, e->stream);
+        if (rc == PC_OK) rc = d_val_in.upload(run_val.p, nrunrec, e->stream);
+        if (rc == PC_OK) rc = d_idx_in.upload(run_idx.p, nrunrec, e->stream);
+        if (rc == PC_OK) rc = d_key_sorted.reserve(nrunrec);
+        if (rc == PC_OK) rc = d_ord_sorted.reserve(nrunrec);
+        if (rc == PC_OK) rc = sf->run_rec.reserve(nrunrec + 1);
+        if (rc == PC_OK) rc = sf->run_recidx.reserve(nrunrec);
+        if (rc == PC_OK) rc = sf->rlin_tab.reserve(nlin);
+        if (rc == PC_OK) {   // identity permutation (filled on the host: it is one more upload, not a kernel of its own)
+            HostBuf<uint32_t> ident(nrunrec);
+            if (!ident.p) rc = fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
+            else {
+                parallel_chunks((int64_t)nrunrec, T, [&](int, int64_t jb, int64_t je) { for (int64_t j = jb; j < je; ++j) ident[(size_t)j] = (uint32_t)j; });
+                rc = d_ord.upload(ident.p, nrunrec, e->stream);
+                if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
+            }
+        }
+        if (rc == PC_OK) {
+            size_t tmp_bytes = 0;
+            const int end_bit = 32 + (ntid > 1 ? 32 - __builtin_clz((unsigned)(ntid - 1)) : 1);
+            hipError_t he = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key.p, d_key_sorted.p, d_ord.p, d_ord_sorted.p,
+                                                               (int)nrunrec, 0, end_bit, e->stream);
+            if (he == hipSuccess) rc = d_tmp.reserve(tmp_bytes);
+            if (he == hipSuccess && rc == PC_OK)
+                he = hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_key.p, d_key_sorted.p, d_ord.p, d_ord_sorted.p, (int)nrunrec,
+                                                        0, end_bit, e->stream);   // stable: equal starts keep record order
+            if (he != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sorting the run stream failed: %s", hipGetErrorString(he));
+        }
+        if (rc == PC_OK) {
+            const unsigned grid = (unsigned)((nrunrec + kWG - 1) / kWG);
+            hipLaunchKernelGGL(k_run_gather, dim3(grid), dim3(kWG), 0, e->stream, d_ord_sorted.p, d_val_in.p, d_idx_in.p, (int64_t)nrunrec,
+                               sf->run_rec.p, sf->run_recidx.p);
+            hipLaunchKernelGGL(k_run_lin, dim3((unsigned)((nlin + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, d_key_sorted.p, (int64_t)nrunrec,
+                               sf->lin_off.p, ntid, (int64_t)nlin, sf->rlin_tab.p);
+            const uint2 tail_run = make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 24);
+            if (hipMemcpyAsync(sf->run_rec.p + nrunrec, &tail_run, sizeof(tail_run), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+                hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+                rc = fail(PC_ERR_HIP, "stage: building the run stream failed");
+        }
+    }
     if (rc != PC_OK) {
         delete sf;
         return rc;
@@ -972,6 +1124,12 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     if (sf->ngap)
         hipLaunchKernelGGL(k_update_side_flags, dim3((unsigned)((sf->ngap + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->gap_rec.p,
                            sf->ngap, sf->rec.p);
+    if (sf->nxlong)
+        hipLaunchKernelGGL(k_update_side_flags, dim3((unsigned)((sf->nxlong + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->xlong_rec.p,
+                           sf->nxlong, sf->rec.p);
+    if (sf->nrunrec)
+        hipLaunchKernelGGL(k_update_run_flags, dim3((unsigned)((sf->nrunrec + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->run_rec.p,
+                           sf->run_recidx.p, sf->nrunrec, sf->rec.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
     return PC_OK;
@@ -1395,7 +1553,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             p->tile_items_zero = false;
             const int64_t nthreads = (int64_t)ntiles * nfiles; // one thread per (tile, file)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
-                               e->files[0]->view(), e->d_files.p, nfiles, G, W, e->Ws(), R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
+                               e->files[0]->view(), e->d_files.p, nfiles, G, e->Wg(), e->Ws(), e->Wr(), R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
                                e->d_work_small.p, small_g, small_n, e->knobs.debug_work);
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
