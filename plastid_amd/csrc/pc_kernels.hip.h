@@ -866,15 +866,18 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
                                                     int G, int max_slots, int tab_lo, int tab_n, int fast_lo,
                                                     int fast_hi, uint32_t *hist,
                                                     int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
-                                                    double norm_sum, uint32_t work_cap) {
+                                                    double norm_sum, uint32_t work_cap, uint32_t grid_front) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // heavy items sit at the front of the list, light ones at the back (see k_tile_ranges);
     // the sparse-window list is a plain array of its own
     // The grid spans the whole list capacity and block b serves slot b (heavy slots [0, n_heavy),
     // light slots [cap - n_light, cap), nothing in between), so the item is requested together with
     // the counters instead of after them: one dependent round trip less per workgroup.
+    // (the first `grid_front` blocks serve the front of the list, the others its back: the host launches
+    // the whole capacity the first time and exactly the queued counts once it has seen them)
+    const uint32_t slot = blockIdx.x < grid_front ? blockIdx.x : work_cap - (gridDim.x - blockIdx.x);
     const uint32_t n_heavy = SMALL ? nwork[2] : nwork[0], n_light = SMALL ? 0u : nwork[1];
-    const WorkItem w = work[blockIdx.x];
+    const WorkItem w = work[slot];
     // offset-table values this thread needs for the LDS tables (variable / stratified rules): they
     // depend on kernel arguments only and travel together with the work item
     int pre_f = -1, pre_r = -1, lt_f = -1, lt_r = -1;
@@ -884,7 +887,7 @@ __global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pie
         const int Lp = fast_lo + (int)(threadIdx.x >> 2);
         if (Lp <= fast_hi && Lp < mp.table_len) { pre_f = fw[Lp]; pre_r = rc[Lp]; }
     }
-    if (!(blockIdx.x < n_heavy || blockIdx.x >= work_cap - n_light)) return;
+    if (!(slot < n_heavy || slot >= work_cap - n_light)) return;
     const GFile fv = w.file == 0 ? gfile(file0) : (w.file == 1 ? gfile(file1) : gfile(files[w.file]));
 
     // ---- first batch of the record stream (and the first gapped records).  The stream is read

@@ -312,6 +312,7 @@ struct pc_engine {
     bool pinned_busy = false;
     PinnedBuf pinned;            // host side of the plan-table upload (reused: ev_pinned is waited for before it is rewritten)
     bool counters_zero = false; // left zeroed by the last kernel of a point-rule count
+    uint64_t work_generation = 1; // bumped by whatever changes the work list of a plan (alignment files, knobs)
     size_t max_lds = 64 * 1024; // LDS a workgroup may use (160 KiB on gfx950)
     DevBuf<double> d_partial;
     DevBuf<Unmappable> d_unmap;
@@ -394,6 +395,15 @@ struct pc_plan {
     DevView<uint8_t> d_total;
     int last_dtype = -1;
     bool counted = false;
+    // queued work items per class as the last count of this plan left them (a large plan launches exactly
+    // that many workgroups next time instead of the whole list capacity)
+    uint32_t *h_work_counts = nullptr;   // page-locked [4]: heavy, light, small, -
+    hipEvent_t ev_work_counts = nullptr;
+    uint64_t work_counts_generation = 0; // engine work_generation the read-back belongs to (0: none in flight)
+    ~pc_plan() {
+        if (ev_work_counts) (void)hipEventDestroy(ev_work_counts);
+        if (h_work_counts) (void)hipHostFree(h_work_counts);
+    }
 
     explicit pc_plan(pc_engine *eng) : e(eng) {
         DevPool *pl = &eng->pool;
@@ -509,6 +519,7 @@ int pc_destroy(pc_engine *e) {
 int pc_reload_knobs(pc_engine *e) {
     if (!e) return fail(PC_ERR_ARG, "engine is NULL");
     e->knobs.load();
+    e->work_generation += 1;
     return PC_OK;
 }
 
@@ -520,6 +531,7 @@ int pc_clear_alignments(pc_engine *e) {
     e->files.clear();
     e->ntid = 0;
     e->files_dirty = true;
+    e->work_generation += 1;
     return PC_OK;
 }
 
@@ -1102,6 +1114,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     e->files.push_back(sf);
     e->ntid = ntid;
     e->files_dirty = true;
+    e->work_generation += 1;
     return PC_OK;
 }
 
@@ -1577,7 +1590,20 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 return fail(PC_ERR_ARG, "pc_count: the window needs %zu bytes of LDS, the device offers %zu per workgroup (too many rows)", lds, e->max_lds);
             const FileView fv0 = e->files[0]->view();
             const FileView fv1 = nfiles > 1 ? e->files[1]->view() : fv0;
-            const unsigned grid = (unsigned)cap64;
+            // grids: the whole list capacity, or -- once a count of this plan has shown how many items each
+            // class queues (same alignments, same knobs) -- exactly those: a sparse annotation leaves most
+            // of the capacity empty, and an empty workgroup still costs a dispatch slot
+            unsigned grid = (unsigned)cap64, grid_front = (unsigned)cap64, grid_small = (unsigned)cap_small;
+            const bool track_counts = ntiles >= 4096;
+            if (track_counts && p->work_counts_generation == e->work_generation && p->h_work_counts &&
+                hipEventQuery(p->ev_work_counts) == hipSuccess) {
+                const uint32_t nh = p->h_work_counts[0], nl = p->h_work_counts[1], ns = p->h_work_counts[2];
+                if ((uint64_t)nh + nl <= (uint64_t)cap64 && (int64_t)ns <= cap_small) {
+                    grid_front = nh;
+                    grid = std::max(1u, nh + nl);
+                    grid_small = ns;
+                }
+            }
             const int outmode = e->norm_on ? 2 : (out_dtype == PC_OUT_FLOAT64 ? 1 : 0);
 #define PC_LAUNCH_HIST(K, O)                                                                                          \
     do {                                                                                                              \
@@ -1585,13 +1611,13 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                            p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, \
                            G, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, (uint32_t *)p->d_hist.p, p->npos,                        \
                            (OutT_<O>::type *)p->d_out.p,                                                                \
-                           e->norm_sum, (uint32_t)cap64);                                                               \
-        if (cap_small)                                                                                                \
-            hipLaunchKernelGGL((k_hist_point<K, O, 64, true>), dim3((unsigned)cap_small), dim3(64), lds_small, st_small, \
+                           e->norm_sum, (uint32_t)cap64, grid_front);                                                   \
+        if (cap_small && grid_small)                                                                                  \
+            hipLaunchKernelGGL((k_hist_point<K, O, 64, true>), dim3(grid_small), dim3(64), lds_small, st_small, \
                                p->d_pieces.p, p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work_small.p,                \
                                e->d_counters.p, p->d_tile_items.p, mp, small_g, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, \
                                (uint32_t *)p->d_hist.p,                                                                 \
-                               p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small);                \
+                               p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small, grid_small);    \
     } while (0)
 #define PC_LAUNCH_HIST_O(K)                                                                                           \
     do {                                                                                                              \
@@ -1636,6 +1662,17 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
 #undef PC_LAUNCH_SPLIT
             e->counters_zero = true;
             p->tile_items_zero = true;
+            if (track_counts) {   // how many items each class queued (k_gather_split keeps a copy): sizes the next launch
+                if (!p->h_work_counts) {
+                    HIP_TRY(hipHostMalloc((void **)&p->h_work_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
+                    HIP_TRY(hipEventCreateWithFlags(&p->ev_work_counts, hipEventDisableTiming));
+                }
+                if (p->work_counts_generation != e->work_generation || hipEventQuery(p->ev_work_counts) == hipSuccess) {
+                    HIP_TRY(hipMemcpyAsync(p->h_work_counts, e->d_counters.p + 4, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipEventRecord(p->ev_work_counts, st));
+                    p->work_counts_generation = e->work_generation;
+                }
+            }
             if (e->knobs.debug_work) { // diagnostics: how many work items of each class this call queued
                 uint32_t c4[4] = {0, 0, 0, 0};
                 HIP_TRY(hipMemcpyAsync(c4, e->d_counters.p + 4, sizeof(c4), hipMemcpyDeviceToHost, st));
