@@ -400,6 +400,8 @@ struct pc_plan {
     uint32_t *h_work_counts = nullptr;   // page-locked [4]: heavy, light, small, -
     hipEvent_t ev_work_counts = nullptr;
     uint64_t work_counts_generation = 0; // engine work_generation the read-back belongs to (0: none in flight)
+    bool work_counts_known = false;      // the read-back has arrived: work_counts holds it
+    uint32_t work_counts[3] = {0, 0, 0};
     ~pc_plan() {
         if (ev_work_counts) (void)hipEventDestroy(ev_work_counts);
         if (h_work_counts) (void)hipHostFree(h_work_counts);
@@ -1595,9 +1597,13 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // of the capacity empty, and an empty workgroup still costs a dispatch slot
             unsigned grid = (unsigned)cap64, grid_front = (unsigned)cap64, grid_small = (unsigned)cap_small;
             const bool track_counts = ntiles >= 4096;
-            if (track_counts && p->work_counts_generation == e->work_generation && p->h_work_counts &&
+            if (track_counts && p->work_counts_generation == e->work_generation && p->h_work_counts && !p->work_counts_known &&
                 hipEventQuery(p->ev_work_counts) == hipSuccess) {
-                const uint32_t nh = p->h_work_counts[0], nl = p->h_work_counts[1], ns = p->h_work_counts[2];
+                for (int k = 0; k < 3; ++k) p->work_counts[k] = p->h_work_counts[k];
+                p->work_counts_known = true;   // deterministic for this plan while the generation stands: no further read-backs
+            }
+            if (track_counts && p->work_counts_known && p->work_counts_generation == e->work_generation) {
+                const uint32_t nh = p->work_counts[0], nl = p->work_counts[1], ns = p->work_counts[2];
                 if ((uint64_t)nh + nl <= (uint64_t)cap64 && (int64_t)ns <= cap_small) {
                     grid_front = nh;
                     grid = std::max(1u, nh + nl);
@@ -1667,7 +1673,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                     HIP_TRY(hipHostMalloc((void **)&p->h_work_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
                     HIP_TRY(hipEventCreateWithFlags(&p->ev_work_counts, hipEventDisableTiming));
                 }
-                if (p->work_counts_generation != e->work_generation || hipEventQuery(p->ev_work_counts) == hipSuccess) {
+                if (p->work_counts_generation != e->work_generation) {   // one read-back per (plan, generation)
+                    p->work_counts_known = false;
                     HIP_TRY(hipMemcpyAsync(p->h_work_counts, e->d_counters.p + 4, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipEventRecord(p->ev_work_counts, st));
                     p->work_counts_generation = e->work_generation;
