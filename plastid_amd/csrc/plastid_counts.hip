@@ -239,6 +239,13 @@ struct StagedFile {
     DevBuf<uint4> xlong_rec;
     DevBuf<int4> xlong_runs;
     DevBuf<uint32_t> xllin_tab, xplin_tab;
+    // strand-split copies of rec / blk_off ([0] forward, [1] reverse) with their own linear index: the
+    // center kernel of a stranded region walks only its strand's reads
+    int64_t sn[2] = {0, 0};
+    int64_t nlin = 0;
+    DevBuf<uint2> srec[2];
+    DevBuf<uint32_t> sblk_off[2], sidx[2], slin_tab[2];
+    DevBuf<int64_t> stid_bounds[2];
     FileView view() const {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
@@ -250,6 +257,7 @@ struct StagedFile {
         v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.llin_tab = llin_tab.p; v.plin_tab = plin_tab.p; v.lin_off = lin_off.p;
         v.run_rec = run_rec.p; v.rlin_tab = rlin_tab.p; v.nrunrec = nrunrec;
         v.xlong_rec = xlong_rec.p; v.xlong_runs = xlong_runs.p; v.xllin_tab = xllin_tab.p; v.xplin_tab = xplin_tab.p; v.nxlong = nxlong;
+        for (int k = 0; k < 2; ++k) { v.srec[k] = srec[k].p; v.sblk_off[k] = sblk_off[k].p; v.slin_tab[k] = slin_tab[k].p; }
         return v;
     }
 };
@@ -449,6 +457,53 @@ void launch_gather(pc_engine *e, pc_plan *p, const HistT *hist, OutT *outp) {
                            hist, p->npos, p->rows, e->norm_sum, outp);
 }
 
+
+// Strand-split record streams of one staged file (built at staging and again whenever the strand /
+// exclusion bits change): stable partition of rec (+ blk_off) by the reverse bit, contig bounds and a
+// linear index per strand.  All on the GPU; one small read-back (the number of forward records).
+int build_strand_streams(pc_engine *e, StagedFile *sf, int ntid) {
+    const int64_t n = sf->n;
+    hipStream_t st = e->stream;
+    sf->sn[0] = sf->sn[1] = 0;
+    if (n == 0 || sf->nlin == 0) return PC_OK;
+    const int64_t nwg = (n + kStrandBlock - 1) / kStrandBlock;
+    DevBuf<uint32_t> cnt;
+    DevBuf<int64_t> base;
+    int rc = cnt.reserve((size_t)nwg);
+    if (rc == PC_OK) rc = base.reserve((size_t)nwg + 1);
+    if (rc != PC_OK) return rc;
+    hipLaunchKernelGGL(k_strand_count, dim3((unsigned)nwg), dim3(kWG), 0, st, sf->rec.p, n, cnt.p);
+    hipLaunchKernelGGL(k_rle_scan, dim3(1), dim3(kWG), 0, st, cnt.p, nwg, base.p, base.p + nwg);
+    int64_t nf = 0;
+    HIP_TRY(hipMemcpyAsync(&nf, base.p + nwg, sizeof(nf), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int64_t ns[2] = {nf, n - nf};
+    const bool runs = sf->blk_off.p != nullptr;
+    for (int k = 0; k < 2 && rc == PC_OK; ++k) {
+        rc = sf->srec[k].reserve((size_t)ns[k] + 2);
+        if (rc == PC_OK) rc = sf->sidx[k].reserve((size_t)std::max<int64_t>(ns[k], 1));
+        if (rc == PC_OK && runs) rc = sf->sblk_off[k].reserve((size_t)std::max<int64_t>(ns[k], 1));
+        if (rc == PC_OK) rc = sf->stid_bounds[k].reserve((size_t)ntid + 1);
+        if (rc == PC_OK) rc = sf->slin_tab[k].reserve((size_t)sf->nlin);
+    }
+    if (rc != PC_OK) return rc;
+    hipLaunchKernelGGL(k_strand_write, dim3((unsigned)nwg), dim3(kWG), 0, st, sf->rec.p, runs ? sf->blk_off.p : nullptr, n, base.p,
+                       sf->srec[0].p, sf->srec[1].p, runs ? sf->sblk_off[0].p : nullptr, runs ? sf->sblk_off[1].p : nullptr,
+                       sf->sidx[0].p, sf->sidx[1].p);
+    const uint2 tail_rec[2] = {make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16), make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16)};
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMemcpyAsync(sf->srec[k].p + ns[k], tail_rec, sizeof(tail_rec), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_strand_tid_bounds, dim3((unsigned)((ntid + 1 + 63) / 64)), dim3(64), 0, st, sf->sidx[k].p, ns[k], sf->tid_bounds.p,
+                           ntid, sf->stid_bounds[k].p);
+        hipLaunchKernelGGL(k_strand_lin, dim3((unsigned)((sf->nlin + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->srec[k].p, sf->stid_bounds[k].p,
+                           sf->lin_off.p, ntid, sf->nlin, sf->slin_tab[k].p);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // tail_rec lives on this stack frame
+    sf->sn[0] = ns[0];
+    sf->sn[1] = ns[1];
+    return PC_OK;
+}
 
 } // namespace
 
@@ -1108,6 +1163,10 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 rc = fail(PC_ERR_HIP, "stage: building the run stream failed");
         }
     }
+    if (rc == PC_OK) {
+        sf->nlin = (int64_t)nlin;
+        rc = build_strand_streams(e, sf, ntid);
+    }
     if (rc != PC_OK) {
         delete sf;
         return rc;
@@ -1147,6 +1206,9 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
                            sf->run_recidx.p, sf->nrunrec, sf->rec.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
+    rc = build_strand_streams(e, sf, e->ntid);   // strand or exclusion bits may have changed
+    if (rc != PC_OK) return rc;
+    e->files_dirty = true;                       // the view's pointers may have moved
     return PC_OK;
 }
 
