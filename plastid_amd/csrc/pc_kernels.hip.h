@@ -104,11 +104,6 @@ struct FileView {
     const int4 *xlong_runs;
     const uint32_t *xllin_tab;
     const uint32_t *xplin_tab;
-    // strand-split copies of rec / blk_off with their own linear index ([0] forward, [1] reverse reads, file
-    // order kept): the center kernel of a '+' or '-' region walks only the reads its strand filter keeps
-    const uint2 *srec[2];
-    const uint32_t *sblk_off[2];
-    const uint32_t *slin_tab[2];
     int64_t n;
     int64_t nlong;
     int64_t ngap;
@@ -151,9 +146,6 @@ struct GFile {
     const i32x4 PC_GLOBAL *xlong_runs;
     const uint32_t PC_GLOBAL *xllin_tab;
     const uint32_t PC_GLOBAL *xplin_tab;
-    const u32x2 PC_GLOBAL *srec[2];
-    const uint32_t PC_GLOBAL *sblk_off[2];
-    const uint32_t PC_GLOBAL *slin_tab[2];
     int64_t n;
     int64_t nlong;
     int64_t ngap;
@@ -188,9 +180,6 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.xlong_runs = (const i32x4 PC_GLOBAL *)v.xlong_runs;
     g.xllin_tab = (const uint32_t PC_GLOBAL *)v.xllin_tab;
     g.xplin_tab = (const uint32_t PC_GLOBAL *)v.xplin_tab;
-    g.srec[0] = (const u32x2 PC_GLOBAL *)v.srec[0]; g.srec[1] = (const u32x2 PC_GLOBAL *)v.srec[1];
-    g.sblk_off[0] = (const uint32_t PC_GLOBAL *)v.sblk_off[0]; g.sblk_off[1] = (const uint32_t PC_GLOBAL *)v.sblk_off[1];
-    g.slin_tab[0] = (const uint32_t PC_GLOBAL *)v.slin_tab[0]; g.slin_tab[1] = (const uint32_t PC_GLOBAL *)v.slin_tab[1];
     g.n = v.n;
     g.nlong = v.nlong;
     g.ngap = v.ngap;
@@ -1248,10 +1237,8 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
             const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
             const int64_t cend = (int64_t)ck.start + ck.len;
             u32x4 rg;
-            // '+' / '-' regions walk the strand's own record stream, '.' regions the whole file
-            const uint32_t PC_GLOBAL *lin = ck.mode == 0 ? fv.slin_tab[0] : (ck.mode == 1 ? fv.slin_tab[1] : fv.lin_tab);
-            rg.x = lin ? (uint32_t)lin_floor(lin, q0, nb, (int64_t)ck.start - W + 1) : 0u;
-            rg.y = lin ? (uint32_t)lin_floor(lin, q0, nb, cend + (1 << kLinShift) - 1) : 0u;
+            rg.x = (uint32_t)lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start - W + 1);
+            rg.y = (uint32_t)lin_floor(fv.lin_tab, q0, nb, cend + (1 << kLinShift) - 1);
             rg.z = rg.w = 0u;
             if (fv.nlong) { // they start before the near window of some position of the chunk, and the
                             // running maximum of the ends has passed the chunk start
@@ -1435,8 +1422,6 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     double acc = 0.0;
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
-        const u32x2 PC_GLOBAL *recs = ck.mode == 0 ? fv.srec[0] : (ck.mode == 1 ? fv.srec[1] : fv.rec);
-        const uint32_t PC_GLOBAL *boffs = ck.mode == 0 ? fv.sblk_off[0] : (ck.mode == 1 ? fv.sblk_off[1] : fv.blk_off);
         const int64_t near_key = (int64_t)ck.start - W + 1;
         const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[(int64_t)cidx * nfiles + f]; // from k_center_weigh
         CenterEntry *list = s_list + (threadIdx.x >> 6) * 64;
@@ -1458,7 +1443,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
         // for themselves from about a thousand candidates on)
         const int64_t lo = (code == 0u && (int64_t)rg.y - (int64_t)rg.x < kCenterSearchFrom)
                                ? (int64_t)rg.x
-                               : wave_lower_bound<2>((const uint32_t PC_GLOBAL *)recs, rg.x, rg.y, near_key, lane);
+                               : wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
         const int64_t hi = rg.y;
         // (the loads are unconditional, with the index clamped into the range: a load under a lane
         // predicate would keep the compiler from counting how many are outstanding, and it would
@@ -1466,10 +1451,10 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
         const int64_t last = hi - 1;
         u32x2 q0 = {0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
         if (hi > lo) {
-            q0 = recs[lo + lane < last ? lo + lane : last];
-            q1 = recs[lo + 64 + lane < last ? lo + 64 + lane : last];
-            q2 = recs[lo + 128 + lane < last ? lo + 128 + lane : last];
-            q3 = recs[lo + 192 + lane < last ? lo + 192 + lane : last];
+            q0 = fv.rec[lo + lane < last ? lo + lane : last];
+            q1 = fv.rec[lo + 64 + lane < last ? lo + 64 + lane : last];
+            q2 = fv.rec[lo + 128 + lane < last ? lo + 128 + lane : last];
+            q3 = fv.rec[lo + 192 + lane < last ? lo + 192 + lane : last];
         }
         // one batch: take its records out of register `q`, refill `q` with the batch four ahead (the
         // loop is unrolled over the four registers: rotating them with moves would make every batch
@@ -1477,7 +1462,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
         auto step = [&](u32x2 &q, int64_t base) -> bool {
             if (base >= hi) return false;
             const u32x2 r = q;
-            q = recs[base + 256 + lane < last ? base + 256 + lane : last];
+            q = fv.rec[base + 256 + lane < last ? base + 256 + lane : last];
             if ((int32_t)lane_u32(r.x, 0) >= cend) return false; // sorted by start: nothing further can reach the chunk
             const int32_t pos = (int32_t)r.x;
             // records before near_key belong to the long-span loop above (or cannot reach the chunk)
@@ -1485,7 +1470,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
             const bool odd = in && (rec_nblk(r.y) >= 2 || rec_len(r.y) - 2 * mp.param >= kInvLds);
             if (__any(odd)) {                                // gapped reads / very long reads in the batch
                 uint32_t boff = 0u;
-                if (in && rec_nblk(r.y) >= 2) boff = boffs[base + lane];
+                if (in && rec_nblk(r.y) >= 2) boff = fv.blk_off[base + lane];
                 center_batch<false>(fv, mp, ck, cend, in, pos, r.y, boff, s_inv, inv, list, lane, p, acc);
             } else {
                 center_batch<true>(fv, mp, ck, cend, in, pos, r.y, 0u, s_inv, inv, list, lane, p, acc);
@@ -1605,114 +1590,23 @@ __global__ __launch_bounds__(kWG) void k_update_run_flags(uint2 *runs, const uin
     runs[j] = r;
 }
 
-// ---------------------------------------------------------------- strand-split record streams (staging time)
-// Stable partition of rec / blk_off by the reverse-strand bit: count per 1024-record block, scan the block
-// counts (k_rle_scan), write.  sidx keeps the record index of every entry (tid bounds, flag updates).
-constexpr int kStrandBlock = 1024;
-__global__ __launch_bounds__(kWG) void k_strand_count(const uint2 *__restrict__ rec, int64_t n, uint32_t *wg_fwd) {
-    __shared__ uint32_t s_wave[kWG / 64];
-    const int64_t base = (int64_t)blockIdx.x * kStrandBlock;
-    uint32_t c = 0;
-    for (int k = 0; k < kStrandBlock / kWG; ++k) {
-        const int64_t i = base + k * kWG + threadIdx.x;
-        if (i < n && !((rec[i].y >> 16) & kFlagReverse)) ++c;
-    }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < kWG / 64; ++w) t += s_wave[w];
-        wg_fwd[blockIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(kWG) void k_strand_write(const uint2 *__restrict__ rec, const uint32_t *__restrict__ blk_off, int64_t n,
-                                                      const int64_t *__restrict__ wg_base_fwd, uint2 *rec_f, uint2 *rec_r,
-                                                      uint32_t *boff_f, uint32_t *boff_r, uint32_t *idx_f, uint32_t *idx_r) {
-    __shared__ uint32_t s_wave[kWG / 64];
-    const int64_t base = (int64_t)blockIdx.x * kStrandBlock;
-    int64_t out_f = wg_base_fwd[blockIdx.x], out_r = base - out_f;   // every record before this block went to one of the two
-    for (int k = 0; k < kStrandBlock / kWG; ++k) {                    // element order == output order
-        const int64_t i = base + k * kWG + threadIdx.x;
-        const bool in = i < n;
-        const uint2 r = in ? rec[i] : make_uint2(0u, 0u);
-        const bool fwd = in && !((r.y >> 16) & kFlagReverse);
-        const unsigned long long mf = __ballot(fwd), mi = __ballot(in);
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (lane == 0) s_wave[wv] = (uint32_t)__popcll(mf) | ((uint32_t)__popcll(mi) << 16);
-        __syncthreads();
-        uint32_t bf = 0, bi = 0, tf = 0, ti = 0;
-        for (int w = 0; w < kWG / 64; ++w) {
-            const uint32_t t = s_wave[w];
-            if (w < wv) { bf += t & 0xffffu; bi += t >> 16; }
-            tf += t & 0xffffu; ti += t >> 16;
-        }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (in) {
-            const uint32_t rf = bf + (uint32_t)__popcll(mf & below), ri = bi + (uint32_t)__popcll(mi & below);
-            if (fwd) {
-                const int64_t d = out_f + rf;
-                rec_f[d] = r; idx_f[d] = (uint32_t)i;
-                if (blk_off) boff_f[d] = blk_off[i];
-            } else {
-                const int64_t d = out_r + (ri - rf);
-                rec_r[d] = r; idx_r[d] = (uint32_t)i;
-                if (blk_off) boff_r[d] = blk_off[i];
-            }
-        }
-        out_f += tf;
-        out_r += ti - tf;
-        __syncthreads();
-    }
-}
-
-// contig bounds of a strand stream: first entry whose record index is not before the contig's first record
-__global__ void k_strand_tid_bounds(const uint32_t *__restrict__ sidx, int64_t ns, const int64_t *__restrict__ tid_bounds, int ntid,
-                                    int64_t *out) {
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t > ntid) return;
-    const int64_t key = tid_bounds[t];
-    int64_t lo = 0, hi = ns;
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        if ((int64_t)sidx[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    out[t] = lo;
-}
-
-// linear index of a strand stream: one bisection (inside the contig) per table entry
-__global__ __launch_bounds__(kWG) void k_strand_lin(const uint2 *__restrict__ srec, const int64_t *__restrict__ stid_bounds,
-                                                    const int64_t *__restrict__ lin_off, int ntid, int64_t nlin, uint32_t *slin) {
-    const int64_t g = (int64_t)blockIdx.x * kWG + threadIdx.x;
-    if (g >= nlin) return;
-    int lo_t = 0, hi_t = ntid;
-    while (lo_t < hi_t) {
-        const int mid = (lo_t + hi_t) >> 1;
-        if (lin_off[mid + 1] <= g) lo_t = mid + 1; else hi_t = mid;
-    }
-    const int t = lo_t;
-    const int64_t k = g - lin_off[t], nb = lin_off[t + 1] - lin_off[t] - 1;
-    int64_t lo = stid_bounds[t], hi = stid_bounds[t + 1];
-    if (k >= nb) { slin[g] = (uint32_t)hi; return; }
-    const int64_t edge = k << kLinShift;
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        if ((int64_t)(int32_t)srec[mid].x < edge) lo = mid + 1; else hi = mid;
-    }
-    slin[g] = (uint32_t)lo;
-}
-
-// exclusion bits changed: refresh the copies of the headers
-__global__ __launch_bounds__(kWG) void k_strand_refresh(uint2 *srec, const uint32_t *__restrict__ sidx, int64_t ns,
-                                                        const uint2 *__restrict__ rec) {
-    const int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
-    if (j >= ns) return;
-    srec[j] = rec[sidx[j]];
-}
-
 // ---------------------------------------------------------------- run stream construction (staging time)
 // 64-bit sort key of every run: contig << 32 | run start; the payload is permuted with the sorted indices.
+__global__ __launch_bounds__(kWG) void k_run_keys(const uint2 *__restrict__ val, const uint32_t *__restrict__ recidx, int64_t n,
+                                                  const int64_t *__restrict__ tid_bounds, int ntid, unsigned long long *key,
+                                                  uint32_t *order) {
+    const int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (j >= n) return;
+    const int64_t i = recidx[j];
+    int lo = 0, hi = ntid;   // contig of record i
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tid_bounds[mid + 1] <= i) lo = mid + 1; else hi = mid;
+    }
+    key[j] = ((unsigned long long)(uint32_t)lo << 32) | val[j].x;
+    order[j] = (uint32_t)j;
+}
+
 __global__ __launch_bounds__(kWG) void k_run_gather(const uint32_t *__restrict__ order, const uint2 *__restrict__ val_in,
                                                     const uint32_t *__restrict__ idx_in, int64_t n, uint2 *val_out,
                                                     uint32_t *idx_out) {

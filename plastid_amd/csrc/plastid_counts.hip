@@ -239,13 +239,6 @@ struct StagedFile {
     DevBuf<uint4> xlong_rec;
     DevBuf<int4> xlong_runs;
     DevBuf<uint32_t> xllin_tab, xplin_tab;
-    // strand-split copies of rec / blk_off ([0] forward, [1] reverse) with their own linear index: the
-    // center kernel of a stranded region walks only its strand's reads
-    int64_t sn[2] = {0, 0};
-    int64_t nlin = 0;
-    DevBuf<uint2> srec[2];
-    DevBuf<uint32_t> sblk_off[2], sidx[2], slin_tab[2];
-    DevBuf<int64_t> stid_bounds[2];
     FileView view() const {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
@@ -257,7 +250,6 @@ struct StagedFile {
         v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.llin_tab = llin_tab.p; v.plin_tab = plin_tab.p; v.lin_off = lin_off.p;
         v.run_rec = run_rec.p; v.rlin_tab = rlin_tab.p; v.nrunrec = nrunrec;
         v.xlong_rec = xlong_rec.p; v.xlong_runs = xlong_runs.p; v.xllin_tab = xllin_tab.p; v.xplin_tab = xplin_tab.p; v.nxlong = nxlong;
-        for (int k = 0; k < 2; ++k) { v.srec[k] = srec[k].p; v.sblk_off[k] = sblk_off[k].p; v.slin_tab[k] = slin_tab[k].p; }
         return v;
     }
 };
@@ -457,53 +449,6 @@ void launch_gather(pc_engine *e, pc_plan *p, const HistT *hist, OutT *outp) {
                            hist, p->npos, p->rows, e->norm_sum, outp);
 }
 
-
-// Strand-split record streams of one staged file (built at staging and again whenever the strand /
-// exclusion bits change): stable partition of rec (+ blk_off) by the reverse bit, contig bounds and a
-// linear index per strand.  All on the GPU; one small read-back (the number of forward records).
-int build_strand_streams(pc_engine *e, StagedFile *sf, int ntid) {
-    const int64_t n = sf->n;
-    hipStream_t st = e->stream;
-    sf->sn[0] = sf->sn[1] = 0;
-    if (n == 0 || sf->nlin == 0) return PC_OK;
-    const int64_t nwg = (n + kStrandBlock - 1) / kStrandBlock;
-    DevBuf<uint32_t> cnt;
-    DevBuf<int64_t> base;
-    int rc = cnt.reserve((size_t)nwg);
-    if (rc == PC_OK) rc = base.reserve((size_t)nwg + 1);
-    if (rc != PC_OK) return rc;
-    hipLaunchKernelGGL(k_strand_count, dim3((unsigned)nwg), dim3(kWG), 0, st, sf->rec.p, n, cnt.p);
-    hipLaunchKernelGGL(k_rle_scan, dim3(1), dim3(kWG), 0, st, cnt.p, nwg, base.p, base.p + nwg);
-    int64_t nf = 0;
-    HIP_TRY(hipMemcpyAsync(&nf, base.p + nwg, sizeof(nf), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const int64_t ns[2] = {nf, n - nf};
-    const bool runs = sf->blk_off.p != nullptr;
-    for (int k = 0; k < 2 && rc == PC_OK; ++k) {
-        rc = sf->srec[k].reserve((size_t)ns[k] + 2);
-        if (rc == PC_OK) rc = sf->sidx[k].reserve((size_t)std::max<int64_t>(ns[k], 1));
-        if (rc == PC_OK && runs) rc = sf->sblk_off[k].reserve((size_t)std::max<int64_t>(ns[k], 1));
-        if (rc == PC_OK) rc = sf->stid_bounds[k].reserve((size_t)ntid + 1);
-        if (rc == PC_OK) rc = sf->slin_tab[k].reserve((size_t)sf->nlin);
-    }
-    if (rc != PC_OK) return rc;
-    hipLaunchKernelGGL(k_strand_write, dim3((unsigned)nwg), dim3(kWG), 0, st, sf->rec.p, runs ? sf->blk_off.p : nullptr, n, base.p,
-                       sf->srec[0].p, sf->srec[1].p, runs ? sf->sblk_off[0].p : nullptr, runs ? sf->sblk_off[1].p : nullptr,
-                       sf->sidx[0].p, sf->sidx[1].p);
-    const uint2 tail_rec[2] = {make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16), make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16)};
-    for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipMemcpyAsync(sf->srec[k].p + ns[k], tail_rec, sizeof(tail_rec), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_strand_tid_bounds, dim3((unsigned)((ntid + 1 + 63) / 64)), dim3(64), 0, st, sf->sidx[k].p, ns[k], sf->tid_bounds.p,
-                           ntid, sf->stid_bounds[k].p);
-        hipLaunchKernelGGL(k_strand_lin, dim3((unsigned)((sf->nlin + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->srec[k].p, sf->stid_bounds[k].p,
-                           sf->lin_off.p, ntid, sf->nlin, sf->slin_tab[k].p);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));   // tail_rec lives on this stack frame
-    sf->sn[0] = ns[0];
-    sf->sn[1] = ns[1];
-    return PC_OK;
-}
 
 } // namespace
 
@@ -747,13 +692,12 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     struct Unit { // one thread's share of one slice
         std::vector<uint4> long_rec, gap_rec, xlong_rec;
         std::vector<int32_t> long_span, xlong_span;
-        std::vector<unsigned long long> run_key;   // contig << 32 | run start
-        std::vector<uint2> run_val;                // {run start, len | cum << 8 | L << 16 | flags << 24}
-        std::vector<uint32_t> run_idx;             // record index
         int W = 1, Wg = 1, Wr = 1, smin = 65536, smax = -1;
         int64_t max_span = 1, cursor = 0;
+        int64_t run_at = 0;                        // where this unit's run-stream records go
     };
     std::vector<Unit> units((size_t)(nslices * T));
+    int64_t nrunrec_total = 0;
     auto unit_range = [&](int64_t sl, int t, int64_t &b, int64_t &en) {
         const int64_t s0 = sl * S, s1 = std::min(n, s0 + S), q = (s1 - s0 + T - 1) / T;
         b = std::min(s1, s0 + (int64_t)t * q);
@@ -762,15 +706,27 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (nrun > 0) { // where every unit's first run sits
         parallel_chunks(nslices * T, T, [&](int, int64_t ub, int64_t ue) {
             for (int64_t u = ub; u < ue; ++u) {
-                int64_t b, en, r = 0;
+                int64_t b, en, r = 0, rs = 0;
                 unit_range(u / T, (int)(u % T), b, en);
-                for (int64_t i = b; i < en; ++i) r += nblk[i] >= 2 ? nblk[i] : 0;
+                for (int64_t i = b; i < en; ++i) {
+                    r += nblk[i] >= 2 ? nblk[i] : 0;
+                    rs += (nblk[i] >= 2 && alen[i] <= kStreamMaxLen) ? nblk[i] : 0;   // runs that go to the run stream
+                }
                 units[(size_t)u].cursor = r;
+                units[(size_t)u].run_at = rs;
             }
         });
-        int64_t cur = 0;
-        for (auto &u : units) { const int64_t r = u.cursor; u.cursor = cur; cur += r; }
+        int64_t cur = 0, rcur = 0;
+        for (auto &u : units) {
+            const int64_t r = u.cursor; u.cursor = cur; cur += r;
+            const int64_t q = u.run_at; u.run_at = rcur; rcur += q;
+        }
+        nrunrec_total = rcur;
     }
+    if (nrunrec_total >= (int64_t)0x7fffffff) { delete sf; return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 aligned runs of multi-run reads per file are not supported"); }
+    HostBuf<uint2> run_val((size_t)nrunrec_total);      // {run start, len | cum << 8 | L << 16 | flags << 24}, record order
+    HostBuf<uint32_t> run_idx((size_t)nrunrec_total);   // record of every run
+    if (!run_val.p || !run_idx.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
     int rc = sf->rec.reserve((size_t)n + 2);
     if (rc == PC_OK) rc = sf->stream.reserve((size_t)n + 8);
     if (rc == PC_OK && nrun > 0) rc = sf->blk_off.reserve((size_t)n);
@@ -799,7 +755,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 Unit &c = units[(size_t)(sl * T + t)];
                 int64_t b, en;
                 unit_range(sl, (int)t, b, en);
-                int64_t cursor = c.cursor;
+                int64_t cursor = c.cursor, run_at = c.run_at;
                 for (int64_t i = b; i < en; ++i) {
                     const int L = alen[i], nb = nblk[i];
                     uint32_t boff = 0u;
@@ -822,10 +778,10 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                         uint32_t cum = 0;
                         for (int k = 0; k < nb; ++k) {
                             const uint32_t rs = (uint32_t)blk_start[boff + k], rl = (uint32_t)blk_len[boff + k];
-                            c.run_key.push_back(((unsigned long long)(uint32_t)tid[i] << 32) | rs);
-                            c.run_val.push_back(make_uint2(rs, rl | (cum << 8) | ((uint32_t)L << 16) |
-                                                               ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 24)));
-                            c.run_idx.push_back((uint32_t)i);
+                            run_val[(size_t)run_at] = make_uint2(rs, rl | (cum << 8) | ((uint32_t)L << 16) |
+                                                                         ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 24));
+                            run_idx[(size_t)run_at] = (uint32_t)i;
+                            ++run_at;
                             c.Wr = std::max(c.Wr, (int)rl);
                             cum += rl;
                         }
@@ -890,7 +846,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     std::vector<int64_t> long_bounds((size_t)ntid + 1, 0), gap_bounds((size_t)ntid + 1, 0), xlong_bounds((size_t)ntid + 1, 0);
     int W = 1;
     int64_t max_span = 1;
-    std::vector<size_t> lo_of(units.size() + 1, 0), go_of(units.size() + 1, 0), xo_of(units.size() + 1, 0), ro_of(units.size() + 1, 0);
+    std::vector<size_t> lo_of(units.size() + 1, 0), go_of(units.size() + 1, 0), xo_of(units.size() + 1, 0);
     int Wg = 1, Wr = 1;
     {
         int smin = 65536, smax = -1;
@@ -900,7 +856,6 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             Wg = std::max(Wg, c.Wg);
             Wr = std::max(Wr, c.Wr);
             xo_of[u + 1] = xo_of[u] + c.xlong_rec.size();
-            ro_of[u + 1] = ro_of[u] + c.run_key.size();
             max_span = std::max(max_span, c.max_span);
             smin = std::min(smin, c.smin); smax = std::max(smax, c.smax);
             lo_of[u + 1] = lo_of[u] + c.long_rec.size();
@@ -909,17 +864,13 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         sf->slen_min = smax >= smin ? smin : 0;
         sf->slen_max = smax >= smin ? smax : 0;
     }
-    const size_t nlong = lo_of[units.size()], ngap = go_of[units.size()], nxlong = xo_of[units.size()], nrunrec = ro_of[units.size()];
-    if (nrunrec >= (size_t)0x7fffffffu) { delete sf; return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 aligned runs of multi-run reads per file are not supported"); }
+    const size_t nlong = lo_of[units.size()], ngap = go_of[units.size()], nxlong = xo_of[units.size()], nrunrec = (size_t)nrunrec_total;
     HostBuf<uint4> long_rec(nlong), gap_rec(ngap), xlong_rec(nxlong);
     HostBuf<uint32_t> long_idx(nlong);
     HostBuf<int32_t> long_tid(nlong), long_pmax(nlong), xlong_tid(nxlong), xlong_pmax(nxlong);
     HostBuf<int4> long_runs(nlong), gap_runs(ngap), xlong_runs(nxlong);
-    HostBuf<unsigned long long> run_key(nrunrec);
-    HostBuf<uint2> run_val(nrunrec);
-    HostBuf<uint32_t> run_idx(nrunrec);
     if (!long_rec.p || !gap_rec.p || !long_idx.p || !long_tid.p || !long_pmax.p || !long_runs.p || !gap_runs.p || !xlong_rec.p ||
-        !xlong_tid.p || !xlong_pmax.p || !xlong_runs.p || !run_key.p || !run_val.p || !run_idx.p) {
+        !xlong_tid.p || !xlong_pmax.p || !xlong_runs.p) {
         delete sf;
         return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
     }
@@ -959,12 +910,6 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 xlong_tid[at] = t_x;
                 xlong_pmax[at] = (int32_t)g.x + c.xlong_span[k];
                 xlong_runs[at] = first_two(g);
-            }
-            at = ro_of[(size_t)u];
-            if (!c.run_key.empty()) {
-                memcpy(run_key.p + at, c.run_key.data(), c.run_key.size() * sizeof(unsigned long long));
-                memcpy(run_val.p + at, c.run_val.data(), c.run_val.size() * sizeof(uint2));
-                memcpy(run_idx.p + at, c.run_idx.data(), c.run_idx.size() * sizeof(uint32_t));
             }
         }
     });
@@ -1123,7 +1068,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         DevBuf<uint32_t> d_ord, d_ord_sorted, d_idx_in;
         DevBuf<uint2> d_val_in;
         DevBuf<uint8_t> d_tmp;
-        rc = d_key.upload(run_key.p, nrunrec, e->stream);
+        rc = d_key.reserve(nrunrec);
+        if (rc == PC_OK) rc = d_ord.reserve(nrunrec);
         if (rc == PC_OK) rc = d_val_in.upload(run_val.p, nrunrec, e->stream);
         if (rc == PC_OK) rc = d_idx_in.upload(run_idx.p, nrunrec, e->stream);
         if (rc == PC_OK) rc = d_key_sorted.reserve(nrunrec);
@@ -1131,15 +1077,9 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         if (rc == PC_OK) rc = sf->run_rec.reserve(nrunrec + 1);
         if (rc == PC_OK) rc = sf->run_recidx.reserve(nrunrec);
         if (rc == PC_OK) rc = sf->rlin_tab.reserve(nlin);
-        if (rc == PC_OK) {   // identity permutation (filled on the host: it is one more upload, not a kernel of its own)
-            HostBuf<uint32_t> ident(nrunrec);
-            if (!ident.p) rc = fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
-            else {
-                parallel_chunks((int64_t)nrunrec, T, [&](int, int64_t jb, int64_t je) { for (int64_t j = jb; j < je; ++j) ident[(size_t)j] = (uint32_t)j; });
-                rc = d_ord.upload(ident.p, nrunrec, e->stream);
-                if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
-            }
-        }
+        if (rc == PC_OK)   // sort keys (contig << 32 | run start) and the identity permutation, made on the GPU
+            hipLaunchKernelGGL(k_run_keys, dim3((unsigned)((nrunrec + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, d_val_in.p, d_idx_in.p,
+                               (int64_t)nrunrec, sf->tid_bounds.p, ntid, d_key.p, d_ord.p);
         if (rc == PC_OK) {
             size_t tmp_bytes = 0;
             const int end_bit = 32 + (ntid > 1 ? 32 - __builtin_clz((unsigned)(ntid - 1)) : 1);
@@ -1162,10 +1102,6 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
                 rc = fail(PC_ERR_HIP, "stage: building the run stream failed");
         }
-    }
-    if (rc == PC_OK) {
-        sf->nlin = (int64_t)nlin;
-        rc = build_strand_streams(e, sf, ntid);
     }
     if (rc != PC_OK) {
         delete sf;
@@ -1206,9 +1142,6 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
                            sf->run_recidx.p, sf->nrunrec, sf->rec.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
-    rc = build_strand_streams(e, sf, e->ntid);   // strand or exclusion bits may have changed
-    if (rc != PC_OK) return rc;
-    e->files_dirty = true;                       // the view's pointers may have moved
     return PC_OK;
 }
 
