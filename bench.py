@@ -124,12 +124,37 @@ def cpu_baseline(oracle, aln, spec, p, tx, n_records, budget_s, rng):
                       "sampled fraction / time" % (done, tx.n, n_records, t_used)}, sel_all, arrays_all, order[:done]
 
 
+def usable_cpus():
+    """CPUs this process may actually use: hardware threads, affinity mask and the container's CFS
+    quota (cgroup v2 cpu.max / v1 cfs_quota_us), whichever is smallest."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = period = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota, period = int(q), int(per)
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota and period and quota > 0:
+        n = min(n, max(1, -(-quota // period)))
+    return n
+
+
 def cpu_baseline_all_cores(oracle, aln, spec, p, tx, n_records, budget_s, rng, one_core_value):
-    """The same oracle on EVERY host core: the per-record arrays are derived once and shared, the
-    segments are dealt to one POSIX thread per core (the reference itself is single-threaded; whole
-    segments per thread is the most favourable honest scaling).  The sample is sized from the
-    one-core rate so that it takes about `budget_s` seconds of wall time."""
-    cores = os.cpu_count() or 1
+    """The same oracle on EVERY host core this process may use (usable_cpus: the GPU boxes grant a CFS
+    quota well below the 256 hardware threads they show): the per-record arrays are derived once and
+    shared, the segments are dealt to one POSIX thread per core (the reference itself is
+    single-threaded; whole segments per thread is the most favourable honest scaling).  The sample is
+    sized from the one-core rate so that it takes about `budget_s` seconds of wall time."""
+    cores = usable_cpus()
     if cores < 2:
         return None
     per_chain_s = (n_records / max(one_core_value, 1.0)) / tx.n          # one-core seconds per chain
@@ -199,6 +224,7 @@ def run_workload(name, args, ctx, headline):
                                                   np.random.default_rng(8), cpu["value"])
         cpu["cpu_model"] = cpu_model()
         cpu["host_cores"] = os.cpu_count()
+        cpu["usable_cores"] = usable_cpus()
     else:
         chains = rng.permutation(tx.n)[:min(tx.n, args.parity_chains)]
         check_sel = segments_of_chains(tx, chains)
@@ -236,7 +262,11 @@ def run_workload(name, args, ctx, headline):
                     lp["out_elems"], rows)
     plan_s = time.perf_counter() - t0
 
-    out_buf = np.zeros(lp["out_elems"], out_dtype)   # host side of the read-back, touched once
+    # host side of the read-back: page-locked (what a caller that reads repeatedly would hand over), touched once
+    # (above 1 GiB -- the sparse configurations -- ordinary pageable memory)
+    out_pin = torch.zeros(int(lp["out_elems"]), dtype=torch.int64 if out_dtype == np.int64 else torch.float64,
+                          pin_memory=int(lp["out_elems"]) * 8 <= (1 << 30))
+    out_buf = out_pin.numpy()
 
     # where the sampled elements live in THIS rank's output: (local element index, global element index)
     own = None if gp is None else gp.owned_elements(rank, rows, np.concatenate([check_sel, sf_sel]))
@@ -411,28 +441,35 @@ def e2e_scope(args, ctx, name):
     from plastid_amd.bam import read_bam
     from plastid_amd.engine import Engine
     from tests import bam_writer
-    n = int(args.e2e_records)
+    n = min(int(args.e2e_records), int(synth.CONFIGS[name][4] * args.scale))   # default: every record of the configuration
     genome, tx, reads, mapping = synth.make_config(name, scale=n / float(synth.CONFIGS[name][4]), tx_scale=args.tx_scale)
     factory = synth.mapping_factory(mapping)
     rows = getattr(factory, "_numlengths", 1)
     p = tx.plan_arrays(rows=rows)
     tmp = tempfile.mkdtemp(prefix="pc_bench_")
     path = os.path.join(tmp, "sample.bam")
-    nbytes = bam_writer.write_bam_packed(path, reads, threads=min(16, os.cpu_count() or 1))
+    nbytes = bam_writer.write_bam_packed(path, reads, threads=min(16, usable_cpus()))
     fsize = os.path.getsize(path)
     eng = Engine(ctx["dev_index"])
     factory._configure(eng)
     read_bam(path)                                   # page cache + library warm-up
-    t0 = time.perf_counter()
-    packed = read_bam(path)
-    t_decode = time.perf_counter() - t0
-    eng.set_alignments([packed])
-    t_stage = time.perf_counter() - t0 - t_decode
-    plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
-    got = plan.count(np.float64 if mapping[0] == "center" else np.int64)
-    t_all = time.perf_counter() - t0
+    best = None
+    runs = []
+    for _ in range(3):                               # the host cores are shared with other tenants: best of three
+        t0 = time.perf_counter()
+        packed = read_bam(path)
+        t_decode = time.perf_counter() - t0
+        eng.set_alignments([packed])
+        t_stage = time.perf_counter() - t0 - t_decode
+        plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
+        got = plan.count(np.float64 if mapping[0] == "center" else np.int64)
+        t_all = time.perf_counter() - t0
+        runs.append(round(t_all, 4))
+        if best is None or t_all < best[0]:
+            best = (t_all, t_decode, t_stage)
+        plan.close()
+    t_all, t_decode, t_stage = best
     ok = all(np.array_equal(getattr(packed, k), getattr(reads, k)) for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"))
-    plan.close()
     eng.close()
     try:
         os.remove(path)
@@ -443,9 +480,10 @@ def e2e_scope(args, ctx, name):
         raise SystemExit("e2e scope: the decoded BAM differs from the records it was written from")
     del got
     return {"e2e_reads_per_s": reads.n / t_all,
-            "e2e_sample": "%d records of %s written once (untimed) as a BGZF-compressed BAM of %.0f MB (%.0f MB inflated); timed: native "
-                          "decode %.3f s + staging %.3f s + plan, count and read-back %.3f s" %
-                          (reads.n, name, fsize / 1e6, nbytes / 1e6, t_decode, t_stage, t_all - t_decode - t_stage)}
+            "e2e_sample": "%d records of %s written once (untimed) as a BGZF-compressed BAM of %.0f MB (%.0f MB inflated); timed (best of 3 "
+                          "whole passes, %s s): native decode %.3f s + staging %.3f s + plan, count and read-back %.3f s" %
+                          (reads.n, name, fsize / 1e6, nbytes / 1e6, "/".join("%.3f" % r for r in runs), t_decode, t_stage,
+                           t_all - t_decode - t_stage)}
 
 
 def main():
@@ -466,7 +504,7 @@ def main():
                     help="N > 1: one job cut into genome ranges (strong scaling, default) or independent replicas (weak)")
     ap.add_argument("--parity-chains", type=int, default=200, help="chains of the parity sample when no CPU baseline is timed")
     ap.add_argument("--time-budget", type=float, default=1200.0, help="seconds after which no further config is started")
-    ap.add_argument("--e2e-records", type=float, default=5e6, help="records of the BAM sample of the e2e scope (0: skip)")
+    ap.add_argument("--e2e-records", type=float, default=1e8, help="records of the BAM file of the e2e scope, at most the whole configuration (0: skip)")
     args = ap.parse_args()
     t_start = time.perf_counter()
 

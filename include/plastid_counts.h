@@ -90,8 +90,8 @@ int pc_reload_knobs(pc_engine *e);
  * 349, 448, 629, 769, 838.  One call per BAM file, in the order the files were
  * given to BAMGenomeArray (file-major order matters, genome_array.py:800-809).
  *
- *   n          records, sorted by (tid, pos), ties in file order; at most 2^32 - 2 per file (and as
- *              many runs): record indices and window bins are 32-bit (PC_ERR_ARG beyond that --
+ *   n          records, sorted by (tid, pos), ties in file order; at most 2^31 - 2 per file (and
+ *              2^31 - 2 runs of multi-run reads): record indices and window bins are 32-bit (PC_ERR_ARG beyond that --
  *              split larger inputs into several files, which are counted as one)
  *   tid,pos    reference index (0 <= tid < ntid) and leftmost aligned coordinate
  *   alen       L = len(read.positions): aligned reference positions (M/=/X)

@@ -92,6 +92,6 @@ def read_bam(path, threads=0, regions=None):
         warnings.warn("the BAI index of %s carries no mapped-read counts; using the number of alignments read" % path)
         mapped = n
     out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
-                           validate=n <= 5_000_000)
+                           validate=False)   # the native reader has checked every invariant validate() checks
     out.filename = path
     return out

@@ -33,7 +33,7 @@ def build_bam_library(force=False, verbose=False):
     if not force and os.path.exists(BAM_LIB) and os.path.getmtime(BAM_LIB) >= os.path.getmtime(BAM_SRC):
         return BAM_LIB
     cxx = shutil.which("g++") or shutil.which("c++") or find_hipcc()
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", BAM_SRC, "-o", BAM_LIB, "-lz"]
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", BAM_SRC, "-o", BAM_LIB, "-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -7,11 +7,12 @@
 // records) straight into the flat arrays `pc_add_alignment_file` stages to HBM:
 //   tid, pos, alen (= number of M/=/X reference positions), flags (bit0 = reverse strand),
 //   nblk (maximal runs of contiguous aligned positions), runs of the gapped records.
-// BGZF members are independent, so they are inflated by a pool of threads.
+// BGZF members are independent, so they are inflated (and the records in them decoded) by a pool of threads.
 //
 // C ABI (ctypes: plastid_amd/bam.py):
 //   pb_open / pb_close, pb_nref / pb_ref_name / pb_ref_length,
 //   pb_load  (decode the whole file), pb_counts, pb_fill (copy into caller arrays)
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -22,7 +23,11 @@
 #include <string>
 #include <chrono>
 #include <thread>
+#include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -47,8 +52,8 @@ struct Part {
     std::vector<uint16_t> alen;
     std::vector<uint8_t> flags, nblk;
     int64_t mapped = 0, unplaced = 0, total = 0;
-    // first defect found inside the piece: global record index, message; `before_order` marks the
-    // checks the serial walk makes before it looks at the sort order of a record
+    // first defect found inside the piece: record index within the piece, message; `before_order` marks
+    // the checks the serial walk makes before it looks at the sort order of a record
     int64_t err_rec = INT64_MAX;
     bool err_before_order = false;
     std::string err;
@@ -57,6 +62,7 @@ struct Part {
     int64_t first_placed_rec = -1;
     int32_t first_tid = -1, first_pos = -1, first_spos = -1;
     int32_t last_tid = -1, last_pos = -1, last_spos = -1;
+    bool bad_size = false;            // decode_span stopped at a length prefix below the fixed record size
 };
 
 struct Bam {
@@ -87,7 +93,31 @@ inline uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); 
 inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
 // index the BGZF members (RFC 1952 gzip header with the 'BC' extra subfield carrying BSIZE)
-int scan_blocks(const std::vector<uint8_t> &file, std::vector<Block> &blocks, size_t &total_u) {
+// a read-only view of a whole file (mapped: the inflate threads read the page cache directly)
+struct FileMap {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    bool ok = false;
+    explicit FileMap(const std::string &path) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            n = (size_t)st.st_size;
+            if (n == 0) ok = true;
+            else {
+                void *q = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+                if (q != MAP_FAILED) { p = (const uint8_t *)q; ok = true; }
+            }
+        }
+        close(fd);
+    }
+    ~FileMap() { if (p) munmap(const_cast<uint8_t *>(p), n); }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+};
+
+int scan_blocks(const FileMap &file, std::vector<Block> &blocks, size_t &total_u) {
     size_t off = 0;
     total_u = 0;
     while (off < file.size()) {
@@ -107,6 +137,7 @@ int scan_blocks(const std::vector<uint8_t> &file, std::vector<Block> &blocks, si
         const size_t clen = (size_t)bsize + 1;
         if (off + clen > file.size()) return fail("truncated BGZF member");
         const uint32_t isize = rd32(file.data() + off + clen - 4);
+        if (isize > (1u << 16)) return fail("corrupt BGZF member (more than 64 KiB of payload)");
         blocks.push_back({off, (uint32_t)clen, isize, total_u});
         total_u += isize;
         off += clen;
@@ -114,23 +145,65 @@ int scan_blocks(const std::vector<uint8_t> &file, std::vector<Block> &blocks, si
     return 0;
 }
 
-int inflate_block(const std::vector<uint8_t> &file, const Block &b, uint8_t *dst) {
-    if (b.ulen == 0) return 0;
-    const uint8_t *h = file.data() + b.coff;
-    const size_t hdr = 12 + rd16(h + 10);
+// libdeflate, when the host has it (looked up at run time; nothing links against it): its raw-deflate
+// decoder and its carry-less-multiply CRC-32 are several times faster than zlib 1.2's.  PB_ZLIB=1 keeps
+// to zlib.  One decompressor per thread.
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+    LibDeflate() {
+        if (getenv("PB_ZLIB")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = reinterpret_cast<decltype(alloc)>(dlsym(h, "libdeflate_alloc_decompressor"));
+        decompress = reinterpret_cast<decltype(decompress)>(dlsym(h, "libdeflate_deflate_decompress"));
+        release = reinterpret_cast<decltype(release)>(dlsym(h, "libdeflate_free_decompressor"));
+        crc32 = reinterpret_cast<decltype(crc32)>(dlsym(h, "libdeflate_crc32"));
+        ok = alloc && decompress && release && crc32;
+    }
+};
+const LibDeflate &libdeflate() {
+    static const LibDeflate ld;
+    return ld;
+}
+struct ThreadDecompressor {
+    void *d = nullptr;
+    ~ThreadDecompressor() { if (d) libdeflate().release(d); }
+};
+
+// raw deflate stream -> exactly `out_n` bytes with CRC-32 `crc`; 0, -1 (damaged stream) or -2 (CRC)
+int raw_inflate(const uint8_t *in, size_t in_n, uint8_t *out, size_t out_n, uint32_t crc) {
+    const LibDeflate &ld = libdeflate();
+    if (ld.ok) {
+        thread_local ThreadDecompressor td;
+        if (!td.d) td.d = ld.alloc();
+        if (td.d) {
+            if (ld.decompress(td.d, in, in_n, out, out_n, nullptr) != 0) return -1;
+            return ld.crc32(0, out, out_n) == crc ? 0 : -2;
+        }
+    }
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, -15) != Z_OK) return -1;
-    zs.next_in = const_cast<uint8_t *>(h + hdr);
-    zs.avail_in = (uInt)(b.clen - hdr - 8);
-    zs.next_out = dst;
-    zs.avail_out = b.ulen;
+    zs.next_in = const_cast<uint8_t *>(in);
+    zs.avail_in = (uInt)in_n;
+    zs.next_out = out;
+    zs.avail_out = (uInt)out_n;
     const int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
     if (rc != Z_STREAM_END || zs.avail_out != 0) return -1;
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, b.ulen);
-    if (crc != rd32(h + b.clen - 8)) return -2;
-    return 0;
+    return (uint32_t)::crc32(::crc32(0L, Z_NULL, 0), out, (uInt)out_n) == crc ? 0 : -2;
+}
+
+int inflate_block(const FileMap &file, const Block &b, uint8_t *dst) {
+    if (b.ulen == 0) return 0;
+    const uint8_t *h = file.data() + b.coff;
+    const size_t hdr = 12 + rd16(h + 10);
+    if (b.clen < hdr + 8) return -1;
+    return raw_inflate(h + hdr, b.clen - hdr - 8, dst, b.ulen, rd32(h + b.clen - 8));
 }
 
 // PB_TIMING=1: print the phases of a load to stderr
@@ -174,12 +247,137 @@ int parse_header(Bam &bam, const uint8_t *&p, const uint8_t *end, uint32_t &n_re
     return 0;
 }
 
+// Decodes the records that start at `q` and lie wholly inside [q, limit), at most `max_rec` of them, into
+// `pt` with every per-record format check and the order checks inside the piece.  Returns where it
+// stopped: `limit`, the start of the first record that crosses `limit`, or the record whose length
+// prefix is impossible (pt.bad_size).  A defect ends the piece (pt.err, pt.err_rec).
+const uint8_t *decode_span(const Bam &bam, Part &pt, const uint8_t *q, const uint8_t *limit, uint32_t n_ref, int64_t max_rec) {
+    std::vector<std::pair<int32_t, int32_t>> runs;
+    auto bad = [&](int64_t i, bool before_order, const std::string &m) {
+        pt.err_rec = i; pt.err_before_order = before_order; pt.err = m;
+        return q;
+    };
+    for (int64_t i = 0; i < max_rec; ++i) {
+        if (limit - q < 4) return q;
+        const uint32_t block_size = rd32(q);
+        if (block_size < 32) { pt.bad_size = true; return q; }
+        if ((size_t)(limit - q - 4) < block_size) return q;
+        const uint8_t *r = q + 4;
+        q = r + block_size;
+        const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
+        const uint8_t l_read_name = r[8];
+        const uint16_t n_cigar = rd16(r + 12), flag = rd16(r + 14);
+        pt.total += 1;
+        if (!(flag & 0x4)) pt.mapped += 1;
+        if (tid < 0) { // unplaced reads sit at the end of a sorted BAM; fetch() never returns them
+            pt.unplaced += 1;
+            pt.saw_unplaced = true;
+            continue;
+        }
+        if (tid >= (int32_t)n_ref) return bad(i, true, "BAM record with reference id out of range");
+        if (!pt.any_placed) {     // its order against the previous piece is checked when stitching
+            pt.any_placed = true;
+            pt.first_placed_rec = i;
+            pt.first_tid = tid; pt.first_pos = pos;
+            if (pt.saw_unplaced) return bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
+        } else if (pt.saw_unplaced || tid < pt.last_tid || (tid == pt.last_tid && pos < pt.last_pos)) {
+            return bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
+        }
+        const bool first = pt.tid.empty();
+        if ((size_t)32 + l_read_name + (size_t)n_cigar * 4 > block_size) return bad(i, false, "corrupt BAM record (cigar overruns block)");
+        const uint8_t *cig = r + 32 + l_read_name;
+        runs.clear();
+        int64_t ref = pos, L = 0;
+        for (uint16_t c = 0; c < n_cigar; ++c) {
+            const uint32_t v = rd32(cig + 4 * c);
+            const uint32_t op = v & 0xf, len = v >> 4;
+            switch (op) {
+            case 0: case 7: case 8: // M = X : aligned positions
+                if (len) {
+                    if (!runs.empty() && (int64_t)runs.back().first + runs.back().second == ref) runs.back().second += (int32_t)len;
+                    else runs.emplace_back((int32_t)ref, (int32_t)len);
+                    ref += len;
+                    L += len;
+                }
+                break;
+            case 2: case 3: // D N : reference only
+                ref += len;
+                break;
+            case 1: case 4: case 5: case 6: // I S H P
+                break;
+            default:
+                return bad(i, false, "unknown CIGAR operation in " + bam.path);
+            }
+        }
+        if (L > 65535) return bad(i, false, "alignment with more than 65535 aligned positions is not supported");
+        if (runs.size() > 255) return bad(i, false, "alignment with more than 255 aligned runs is not supported");
+        // the packed format keys a record on its first aligned position; a CIGAR that opens with
+        // D/N (not produced by aligners) is accepted only if that keeps the file order
+        const int32_t spos = runs.empty() ? pos : runs[0].first;
+        if (first) pt.first_spos = spos;
+        else if (pt.last_tid == tid && pt.last_spos > spos)
+            return bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
+        pt.last_tid = tid; pt.last_pos = pos; pt.last_spos = spos;
+        pt.tid.push_back(tid);
+        pt.pos.push_back(spos);
+        pt.alen.push_back((uint16_t)L);
+        pt.flags.push_back((flag & 0x10) ? 1 : 0);
+        pt.nblk.push_back((uint8_t)runs.size());
+        if (runs.size() >= 2)
+            for (auto &x : runs) {
+                pt.blk_start.push_back(x.first);
+                pt.blk_len.push_back(x.second);
+            }
+    }
+    return q;
+}
+
+void reserve_part(Part &pt, size_t count) {
+    pt.tid.reserve(count); pt.pos.reserve(count); pt.alen.reserve(count);
+    pt.flags.reserve(count); pt.nblk.reserve(count);
+}
+
+// The checks that span two pieces, and the flat offsets of every piece (bam.parts in file order).  The
+// defect reported is the one of the lowest record index, as in a serial walk (where one record fails
+// two checks, the serial order of the checks decides).
+int stitch_parts(Bam &bam, bool truncated, int nthreads) {
+    const size_t nparts = bam.parts.size();
+    bool seen_unplaced = false, have_prev = false;
+    int32_t prev_tid = -1, prev_pos = -1, prev_spos = -1;
+    bam.rec_off.assign(nparts + 1, 0);
+    bam.run_off.assign(nparts + 1, 0);
+    for (size_t k = 0; k < nparts; ++k) {
+        const Part &pt = bam.parts[k];
+        int64_t at = INT64_MAX;
+        std::string msg;
+        if (pt.any_placed) {
+            const int64_t f = pt.first_placed_rec;
+            if (seen_unplaced || (have_prev && (pt.first_tid < prev_tid || (pt.first_tid == prev_tid && pt.first_pos < prev_pos)))) {
+                at = f; msg = "BAM file is not coordinate sorted: " + bam.path;
+            } else if (have_prev && prev_tid == pt.first_tid && prev_spos > pt.first_spos && pt.err_rec != f) {
+                at = f; msg = "alignment starting with a deletion breaks coordinate order; not supported";
+            }
+        }
+        if (pt.err_rec < at || (pt.err_rec == at && pt.err_before_order)) { at = pt.err_rec; msg = pt.err; }
+        if (at != INT64_MAX) return fail(msg);
+        if (pt.any_placed && !pt.tid.empty()) { have_prev = true; prev_tid = pt.last_tid; prev_pos = pt.last_pos; prev_spos = pt.last_spos; }
+        seen_unplaced |= pt.saw_unplaced;
+        bam.mapped += pt.mapped; bam.unplaced += pt.unplaced; bam.total += pt.total;
+        bam.rec_off[k + 1] = bam.rec_off[k] + pt.tid.size();
+        bam.run_off[k + 1] = bam.run_off[k] + pt.blk_start.size();
+    }
+    if (truncated) return fail("truncated BAM record");
+    bam.nrec = bam.rec_off[nparts];
+    bam.nrun = bam.run_off[nparts];
+    bam.threads = nthreads;
+    return 0;
+}
+
 // Alignment records in [p, end) -> bam.parts (file order), with every order / format check.
 int decode_records(Bam &bam, const uint8_t *p, const uint8_t *end, uint32_t n_ref, int nthreads, Lap &lap) {
-    // A serial walk over the length prefixes cuts the stream into pieces of
-    // kPiece records; the pieces are decoded by the thread pool; the stitching pass then applies the
-    // checks that span two pieces.  The defect reported is the one of the lowest record index, as
-    // in a serial walk (where one record fails two checks, the serial order of the checks decides).
+    // A serial walk over the length prefixes cuts the stream into pieces of kPiece records; the pieces
+    // are decoded by the thread pool and stitched.  (The region loader's path: its buffers are small.
+    // Whole files go through decode(), which needs no serial walk.)
     int64_t kPiece = 1 << 16;
     if (const char *env = getenv("PB_PIECE")) kPiece = std::max(1, atoi(env));   // test knob: tiny pieces exercise the stitching
     std::vector<const uint8_t *> cuts;
@@ -200,94 +398,14 @@ int decode_records(Bam &bam, const uint8_t *p, const uint8_t *end, uint32_t n_re
     lap("walk records");
     const size_t nparts = cuts.size() - 1;
     bam.parts.assign(nparts, Part());
-    auto decode_piece = [&](size_t k) {
-        Part &pt = bam.parts[k];
-        const int64_t base = (int64_t)k * kPiece;
-        const int64_t count = std::min<int64_t>(kPiece, nwalk - base);
-        pt.tid.reserve((size_t)count); pt.pos.reserve((size_t)count); pt.alen.reserve((size_t)count);
-        pt.flags.reserve((size_t)count); pt.nblk.reserve((size_t)count);
-        const uint8_t *q = cuts[k];
-        std::vector<std::pair<int32_t, int32_t>> runs;
-        auto bad = [&](int64_t i, bool before_order, const std::string &m) {
-            pt.err_rec = base + i; pt.err_before_order = before_order; pt.err = m;
-        };
-        for (int64_t i = 0; i < count; ++i) {
-            const uint32_t block_size = rd32(q);
-            const uint8_t *r = q + 4;
-            q = r + block_size;
-            const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
-            const uint8_t l_read_name = r[8];
-            const uint16_t n_cigar = rd16(r + 12), flag = rd16(r + 14);
-            pt.total += 1;
-            if (!(flag & 0x4)) pt.mapped += 1;
-            if (tid < 0) { // unplaced reads sit at the end of a sorted BAM; fetch() never returns them
-                pt.unplaced += 1;
-                pt.saw_unplaced = true;
-                continue;
-            }
-            if (tid >= (int32_t)n_ref) return bad(i, true, "BAM record with reference id out of range");
-            if (!pt.any_placed) {     // its order against the previous piece is checked when stitching
-                pt.any_placed = true;
-                pt.first_placed_rec = base + i;
-                pt.first_tid = tid; pt.first_pos = pos;
-                if (pt.saw_unplaced) return bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
-            } else if (pt.saw_unplaced || tid < pt.last_tid || (tid == pt.last_tid && pos < pt.last_pos)) {
-                return bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
-            }
-            const bool first = pt.tid.empty();
-            if ((size_t)32 + l_read_name + (size_t)n_cigar * 4 > block_size) return bad(i, false, "corrupt BAM record (cigar overruns block)");
-            const uint8_t *cig = r + 32 + l_read_name;
-            runs.clear();
-            int64_t ref = pos, L = 0;
-            for (uint16_t c = 0; c < n_cigar; ++c) {
-                const uint32_t v = rd32(cig + 4 * c);
-                const uint32_t op = v & 0xf, len = v >> 4;
-                switch (op) {
-                case 0: case 7: case 8: // M = X : aligned positions
-                    if (len) {
-                        if (!runs.empty() && (int64_t)runs.back().first + runs.back().second == ref) runs.back().second += (int32_t)len;
-                        else runs.emplace_back((int32_t)ref, (int32_t)len);
-                        ref += len;
-                        L += len;
-                    }
-                    break;
-                case 2: case 3: // D N : reference only
-                    ref += len;
-                    break;
-                case 1: case 4: case 5: case 6: // I S H P
-                    break;
-                default:
-                    return bad(i, false, "unknown CIGAR operation in " + bam.path);
-                }
-            }
-            if (L > 65535) return bad(i, false, "alignment with more than 65535 aligned positions is not supported");
-            if (runs.size() > 255) return bad(i, false, "alignment with more than 255 aligned runs is not supported");
-            // the packed format keys a record on its first aligned position; a CIGAR that opens with
-            // D/N (not produced by aligners) is accepted only if that keeps the file order
-            const int32_t spos = runs.empty() ? pos : runs[0].first;
-            if (first) pt.first_spos = spos;
-            else if (pt.last_tid == tid && pt.last_spos > spos)
-                return bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
-            pt.last_tid = tid; pt.last_pos = pos; pt.last_spos = spos;
-            pt.tid.push_back(tid);
-            pt.pos.push_back(spos);
-            pt.alen.push_back((uint16_t)L);
-            pt.flags.push_back((flag & 0x10) ? 1 : 0);
-            pt.nblk.push_back((uint8_t)runs.size());
-            if (runs.size() >= 2)
-                for (auto &x : runs) {
-                    pt.blk_start.push_back(x.first);
-                    pt.blk_len.push_back(x.second);
-                }
-        }
-    };
     {
         std::atomic<size_t> nextp(0);
         auto pworker = [&]() {
             for (;;) {
                 const size_t k = nextp.fetch_add(1);
                 if (k >= nparts) return;
-                decode_piece(k);
+                reserve_part(bam.parts[k], (size_t)std::min<int64_t>(kPiece, nwalk - (int64_t)k * kPiece));
+                decode_span(bam, bam.parts[k], cuts[k], cuts[k + 1], n_ref, INT64_MAX);
             }
         };
         std::vector<std::thread> ppool;
@@ -297,100 +415,257 @@ int decode_records(Bam &bam, const uint8_t *p, const uint8_t *end, uint32_t n_re
         for (auto &t : ppool) t.join();
     }
     lap("decode records");
-    // ---- stitch
-    {
-        bool seen_unplaced = false, have_prev = false;
-        int32_t prev_tid = -1, prev_pos = -1, prev_spos = -1;
-        bam.rec_off.assign(nparts + 1, 0);
-        bam.run_off.assign(nparts + 1, 0);
-        for (size_t k = 0; k < nparts; ++k) {
-            const Part &pt = bam.parts[k];
-            int64_t at = INT64_MAX;
-            std::string msg;
-            if (pt.any_placed) {
-                const int64_t f = pt.first_placed_rec;
-                if (seen_unplaced || (have_prev && (pt.first_tid < prev_tid || (pt.first_tid == prev_tid && pt.first_pos < prev_pos)))) {
-                    at = f; msg = "BAM file is not coordinate sorted: " + bam.path;
-                } else if (have_prev && prev_tid == pt.first_tid && prev_spos > pt.first_spos && pt.err_rec != f) {
-                    at = f; msg = "alignment starting with a deletion breaks coordinate order; not supported";
-                }
-            }
-            if (pt.err_rec < at || (pt.err_rec == at && pt.err_before_order)) { at = pt.err_rec; msg = pt.err; }
-            if (at != INT64_MAX) return fail(msg);
-            if (pt.any_placed && !pt.tid.empty()) { have_prev = true; prev_tid = pt.last_tid; prev_pos = pt.last_pos; prev_spos = pt.last_spos; }
-            seen_unplaced |= pt.saw_unplaced;
-            bam.mapped += pt.mapped; bam.unplaced += pt.unplaced; bam.total += pt.total;
-            bam.rec_off[k + 1] = bam.rec_off[k] + pt.tid.size();
-            bam.run_off[k + 1] = bam.run_off[k] + pt.blk_start.size();
-        }
-        if (walk_truncated) return fail("truncated BAM record");
-        bam.nrec = bam.rec_off[nparts];
-        bam.nrun = bam.run_off[nparts];
-        bam.threads = nthreads;
-    }
+    const int rc = stitch_parts(bam, walk_truncated, nthreads);
     lap("stitch");
-    return 0;
+    return rc;
 }
 
+// Where a record starts in [lo, hi), for a worker that holds a chunk of the inflated stream but not
+// what precedes it: the first offset from which three records in a row look like BAM records (or
+// fewer, when they reach the end of the chunk).  Only a guess -- decode() keeps what was decoded from
+// it only if the preceding chunk's last record ends exactly there.
+const uint8_t *guess_record_start(const uint8_t *lo, const uint8_t *hi, uint32_t n_ref) {
+    auto plausible = [&](const uint8_t *q, const uint8_t *&next) {
+        if (hi - q < 36) return false;
+        const uint32_t bs = rd32(q);
+        if (bs < 32 || bs > (1u << 26)) return false;
+        const int32_t tid = (int32_t)rd32(q + 4), pos = (int32_t)rd32(q + 8);
+        const uint32_t l_name = q[12], n_cigar = rd16(q + 16);
+        const int32_t l_seq = (int32_t)rd32(q + 20), mtid = (int32_t)rd32(q + 24), mpos = (int32_t)rd32(q + 28);
+        if (tid < -1 || tid >= (int32_t)n_ref || mtid < -1 || mtid >= (int32_t)n_ref || pos < -1 || mpos < -1) return false;
+        if (l_name == 0 || l_seq < 0 || l_seq > (1 << 28)) return false;
+        if ((uint64_t)32 + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > bs) return false;
+        const uint8_t *nul = q + 36 + l_name - 1;
+        if (nul < hi && *nul != 0) return false;
+        next = q + 4 + (size_t)bs;
+        return true;
+    };
+    const uint8_t *stop = hi - lo > (1 << 20) ? lo + (1 << 20) : hi;
+    for (const uint8_t *q = lo; q < stop; ++q) {
+        const uint8_t *a = q, *next = nullptr;
+        int k = 0;
+        while (k < 3 && plausible(a, next)) {
+            ++k;
+            if (next >= hi) { k = 3; break; }
+            a = next;
+        }
+        if (k == 3) return q;
+    }
+    return nullptr;
+}
+
+// Whole file.  The BGZF members are grouped into chunks of about 1 MiB of inflated stream; a worker
+// inflates a chunk into its own scratch buffer and, while it is still in its cache, decodes the
+// records that start in it from a guessed record boundary (guess_record_start).  The inflated stream
+// is never held as a whole: of each chunk only the first bytes and the bytes behind its last whole
+// record are kept.  The serial pass that follows only chains the chunks: it confirms each guess
+// against the end of the preceding chunk's last record (inflating and decoding the chunk again from
+// the right offset where a guess was wrong), and decodes the one record that straddles each chunk
+// boundary.  No pass walks the whole stream on one thread.  Positions are offsets in the inflated
+// stream.
 int decode(Bam &bam, int nthreads) {
     Lap lap;
-    std::vector<uint8_t> file;
-    if (!read_file(bam.path, file)) return fail("cannot read " + bam.path);
+    FileMap file(bam.path);
+    if (!file.ok) return fail("cannot read " + bam.path);
     std::vector<Block> blocks;
     size_t total_u = 0;
     if (scan_blocks(file, blocks, total_u) != 0) return -1;
-    lap("read + index members");
-    // the inflated stream: not value-initialised (the inflate threads are the first to touch their
-    // members' pages) and on transparent huge pages when large
-    struct Raw {
-        uint8_t *p = nullptr;
-        size_t n = 0;
-        explicit Raw(size_t bytes) : n(bytes) {
-            const size_t huge = (size_t)2 << 20, want = std::max<size_t>(bytes, 1);
-            if (want >= 4 * huge) {
-                void *q = nullptr;
-                if (posix_memalign(&q, huge, (want + huge - 1) / huge * huge) == 0) {
-                    (void)madvise(q, (want + huge - 1) / huge * huge, MADV_HUGEPAGE);
-                    p = (uint8_t *)q;
-                }
-            } else {
-                p = (uint8_t *)malloc(want);
-            }
+    lap("map + index members");
+    auto inflate_error = [&](int rc) { return fail(std::string(rc == -2 ? "BGZF CRC mismatch in " : "BGZF inflate failed in ") + bam.path); };
+
+    // ---- BAM header: inflate members from the start until it is complete
+    uint32_t n_ref = 0;
+    size_t pre = 0;                       // members inflated here
+    std::vector<uint8_t> hbuf;
+    size_t first_rec = 0;
+    for (;;) {
+        if (pre < blocks.size()) {
+            hbuf.resize(blocks[pre].uoff + blocks[pre].ulen);
+            const int rc = inflate_block(file, blocks[pre], hbuf.data() + blocks[pre].uoff);
+            if (rc != 0) return inflate_error(rc);
+            ++pre;
         }
-        ~Raw() { free(p); }
-        uint8_t *data() { return p; }
-        size_t size() const { return n; }
-    } data(total_u);
-    if (!data.p) return fail("out of memory inflating " + bam.path);
-    lap("allocate");
-    // inflate all members in parallel
-    std::atomic<size_t> next(0);
+        const uint8_t *p = hbuf.data();
+        bool more = false;
+        if (parse_header(bam, p, hbuf.data() + hbuf.size(), n_ref, pre < blocks.size() ? &more : nullptr) == 0) {
+            first_rec = (size_t)(p - hbuf.data());
+            break;
+        }
+        if (!more) return -1;
+    }
+    lap("header");
+
+    // ---- chunks of members; chunk 0 = what the header pass inflated (its first record is known)
+    size_t chunk_bytes = (size_t)1 << 20;
+    if (const char *env = getenv("PB_CHUNK")) chunk_bytes = (size_t)std::max(1, atoi(env));   // test knob: tiny chunks exercise the chaining
+    const size_t kNone = (size_t)-1;
+    size_t kHead = (size_t)32 << 10;
+    if (const char *env = getenv("PB_HEAD")) kHead = (size_t)std::max(0, atoi(env));            // test knob: records longer than a head
+    struct Chunk {
+        size_t b0, b1;                    // members
+        size_t lo, hi;                    // its bytes of the inflated stream
+        size_t guess, stop;               // where decoding started / stopped
+        std::vector<uint8_t> head, tail;  // stream bytes [lo, lo + head.size()) and [stop, hi)
+        Part part;
+    };
+    std::vector<Chunk> chunks;
+    size_t max_chunk = 0;
+    {
+        Chunk c0;
+        c0.b0 = 0; c0.b1 = pre; c0.lo = 0; c0.hi = hbuf.size();
+        c0.guess = c0.stop = kNone;
+        chunks.push_back(std::move(c0));
+        for (size_t b = pre; b < blocks.size();) {
+            Chunk c;
+            c.b0 = b;
+            size_t bytes = 0;
+            while (b < blocks.size() && (bytes < chunk_bytes || blocks[b].ulen == 0)) bytes += blocks[b++].ulen;
+            c.b1 = b;
+            c.lo = blocks[c.b0].uoff;
+            c.hi = c.lo + bytes;
+            c.guess = c.stop = kNone;
+            max_chunk = std::max(max_chunk, bytes);
+            chunks.push_back(std::move(c));
+        }
+    }
+    // chunk k inflated into buf (resized to its length)
+    auto inflate_chunk = [&](const Chunk &c, std::vector<uint8_t> &buf) {
+        buf.resize(c.hi - c.lo);
+        for (size_t b = c.b0; b < c.b1; ++b) {
+            const int rc = inflate_block(file, blocks[b], buf.data() + (blocks[b].uoff - c.lo));
+            if (rc != 0) return rc;
+        }
+        return 0;
+    };
+    // decode chunk c, held in `base` (= stream offset c.lo), from stream offset `from`; keeps head and tail
+    auto decode_chunk = [&](Chunk &c, const uint8_t *base, size_t from) {
+        const size_t len = c.hi - c.lo;
+        c.part = Part();
+        reserve_part(c.part, (c.hi - from) / 40 + 16);
+        const uint8_t *q = decode_span(bam, c.part, base + (from - c.lo), base + len, n_ref, INT64_MAX);
+        c.guess = from;
+        c.stop = c.lo + (size_t)(q - base);
+        c.head.assign(base, base + std::min(len, kHead));
+        c.tail.assign(q, base + len);
+    };
+    if (first_rec < chunks[0].hi) decode_chunk(chunks[0], hbuf.data(), first_rec);
+    std::atomic<size_t> next(1);
     std::atomic<int> bad(0);
     if (nthreads < 1) nthreads = 1;
-    nthreads = (int)std::min<size_t>((size_t)nthreads, std::max<size_t>(blocks.size(), 1));
+    nthreads = (int)std::min<size_t>((size_t)nthreads, chunks.size());
+    const bool timing = getenv("PB_TIMING") != nullptr;
+    std::atomic<int64_t> ns_inflate(0), ns_decode(0), ns_start(0);
+    const auto t_spawn = std::chrono::steady_clock::now();
     auto worker = [&]() {
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto t0 = now();
+        if (timing) ns_start += std::chrono::duration_cast<std::chrono::nanoseconds>(t0 - t_spawn).count();
+        std::vector<uint8_t> buf;
+        buf.reserve(max_chunk);
         for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= blocks.size()) return;
-            const int rc = inflate_block(file, blocks[i], data.data() + blocks[i].uoff);
-            if (rc != 0) bad.store(rc);
+            const size_t k = next.fetch_add(1);
+            if (k >= chunks.size()) return;
+            Chunk &c = chunks[k];
+            if (timing) t0 = now();
+            const int rc = inflate_chunk(c, buf);
+            if (rc != 0) { bad.store(rc); continue; }
+            if (bad.load() != 0) continue;
+            auto t1 = t0;
+            if (timing) { t1 = now(); ns_inflate += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(); }
+            const uint8_t *g = guess_record_start(buf.data(), buf.data() + buf.size(), n_ref);
+            if (g) decode_chunk(c, buf.data(), c.lo + (size_t)(g - buf.data()));
+            else c.head.assign(buf.data(), buf.data() + std::min(buf.size(), kHead));
+            if (timing) ns_decode += std::chrono::duration_cast<std::chrono::nanoseconds>(now() - t1).count();
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-    worker();
-    for (auto &t : pool) t.join();
-    if (bad.load() == -2) return fail("BGZF CRC mismatch in " + bam.path);
-    if (bad.load() != 0) return fail("BGZF inflate failed in " + bam.path);
-    file.clear();
-    file.shrink_to_fit();
-    lap("inflate");
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+    }
+    if (bad.load() != 0) return inflate_error(bad.load());
+    if (timing)
+        fprintf(stderr, "[bam] %d threads: summed over threads, inflate %.1f ms, decode %.1f ms; mean start delay %.2f ms\n", nthreads,
+                ns_inflate.load() / 1e6, ns_decode.load() / 1e6, ns_start.load() / 1e6 / nthreads);
+    lap("inflate + decode chunks");
 
-    // ---- BAM header, then the alignment records
-    const uint8_t *p = data.data(), *end = data.data() + data.size();
-    uint32_t n_ref = 0;
-    if (parse_header(bam, p, end, n_ref) != 0) return -1;
-    if (decode_records(bam, p, end, n_ref, nthreads, lap) != 0) return -1;
+    // ---- chain the chunks
+    bam.parts.clear();
+    bam.parts.reserve(2 * chunks.size());
+    bool truncated = false;
+    int64_t redone = 0, refetched = 0;
+    size_t expected = first_rec;
+    std::vector<uint8_t> buf, rec;
+    size_t buf_holds = kNone;                                // the chunk `buf` holds inflated
+    for (size_t k = 0; k < chunks.size(); ++k) {
+        Chunk &c = chunks[k];
+        if (expected >= c.hi) continue;                      // a record (or the header) covers the whole chunk
+        if (c.guess != expected) {                           // decode it from where the records really resume
+            if (buf_holds != k) {
+                if (k == 0) buf = hbuf;
+                else if (const int rc = inflate_chunk(c, buf)) return inflate_error(rc);
+                buf_holds = k;
+            }
+            decode_chunk(c, buf.data(), expected);
+            ++redone;
+        }
+        const bool defect = c.part.err_rec != INT64_MAX, bad_size = c.part.bad_size;
+        const size_t q = c.stop;
+        bam.parts.push_back(std::move(c.part));
+        if (defect) break;                                   // stitch_parts reports it
+        if (bad_size) { truncated = true; break; }
+        expected = q;
+        if (q == c.hi) continue;
+        // the record that starts at q and ends in a later chunk: its first bytes are c.tail, the rest
+        // comes from the heads of the following chunks (or, for a record longer than a head, from
+        // inflating them again)
+        rec = c.tail;
+        size_t j = k + 1, used = 0;                          // next unread stream byte: chunk j, offset `used`
+        int pull_rc = 0;
+        auto pull = [&](size_t want) {                       // appends up to `want` further stream bytes to rec
+            while (want > 0 && j < chunks.size()) {
+                const Chunk &d = chunks[j];
+                const size_t len = d.hi - d.lo;
+                if (used >= len) { ++j; used = 0; continue; }
+                const size_t take = std::min(want, len - used);
+                if (used + take <= d.head.size()) {
+                    rec.insert(rec.end(), d.head.begin() + (long)used, d.head.begin() + (long)(used + take));
+                } else {
+                    if (buf_holds != j) {
+                        if (j == 0) buf = hbuf;
+                        else if ((pull_rc = inflate_chunk(d, buf)) != 0) return;
+                        buf_holds = j;
+                        ++refetched;
+                    }
+                    rec.insert(rec.end(), buf.begin() + (long)used, buf.begin() + (long)(used + take));
+                }
+                used += take;
+                want -= take;
+            }
+        };
+        if (rec.size() < 4) pull(4 - rec.size());
+        if (pull_rc != 0) return inflate_error(pull_rc);
+        if (rec.size() < 4) { truncated = true; break; }
+        const uint32_t block_size = rd32(rec.data());
+        const size_t need = 4 + (size_t)block_size;
+        if (block_size < 32 || need > total_u - q) { truncated = true; break; }
+        if (rec.size() < need) pull(need - rec.size());
+        if (pull_rc != 0) return inflate_error(pull_rc);
+        if (rec.size() < need) { truncated = true; break; }
+        Part tail;
+        decode_span(bam, tail, rec.data(), rec.data() + need, n_ref, 1);
+        const bool tail_defect = tail.err_rec != INT64_MAX;
+        bam.parts.push_back(std::move(tail));
+        if (tail_defect) break;
+        expected = q + need;
+    }
+    if (getenv("PB_TIMING"))
+        fprintf(stderr, "[bam] %zu chunks, %lld decoded again serially, %lld inflated again for a long record\n", chunks.size(),
+                (long long)redone, (long long)refetched);
+    lap("chain chunks");
+    if (stitch_parts(bam, truncated, nthreads) != 0) return -1;
+    lap("stitch");
     bam.loaded = true;
     return 0;
 }
@@ -487,19 +762,7 @@ long read_member(FILE *f, uint64_t coff, std::vector<uint8_t> &out) {
     if (isize > (1u << 16)) return -1;
     const size_t at = out.size();
     out.resize(at + isize);
-    if (isize) {
-        z_stream zs;
-        std::memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, -15) != Z_OK) return -1;
-        zs.next_in = rest.data();
-        zs.avail_in = (uInt)(rest.size() - 8);
-        zs.next_out = out.data() + at;
-        zs.avail_out = isize;
-        const int rc = inflate(&zs, Z_FINISH);
-        inflateEnd(&zs);
-        if (rc != Z_STREAM_END || zs.avail_out != 0) return -1;
-        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out.data() + at, isize) != crc) return -1;
-    }
+    if (isize && raw_inflate(rest.data(), rest.size() - 8, out.data() + at, isize, crc) != 0) return -1;
     return (long)clen;
 }
 
@@ -671,6 +934,29 @@ int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, c
     return 0;
 }
 
+// CPUs this process may actually use: the smaller of the hardware threads, the affinity mask and the
+// container's CFS quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  Pools sized beyond the quota only
+// burn it in bursts and are then throttled as a whole.
+static int usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    long long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else {
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    return (int)n;
+}
+
+// one thread per usable CPU, at most 128 (starting hundreds of threads costs more than they return)
+int default_threads() { return std::min(128, usable_cpus()); }
+
 } // namespace
 
 extern "C" {
@@ -700,7 +986,7 @@ int pb_load(void *h, int nthreads) {
     Bam *b = static_cast<Bam *>(h);
     if (!b) return fail("pb_load: NULL handle");
     if (b->loaded) return 0;
-    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (nthreads <= 0) nthreads = default_threads();
     return decode(*b, nthreads);
 }
 
@@ -711,7 +997,7 @@ int pb_load_regions(void *h, int nthreads, int nreg, const char *const *names, c
     Bam *b = static_cast<Bam *>(h);
     if (!b || nreg < 0 || (nreg > 0 && (!names || !start || !end))) return fail("pb_load_regions: bad arguments");
     if (b->loaded) return fail("pb_load_regions: file already loaded");
-    if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (nthreads <= 0) nthreads = default_threads();
     return decode_regions(*b, nthreads, nreg, names, start, end);
 }
 

@@ -1639,6 +1639,16 @@ __global__ __launch_bounds__(kWG) void k_run_lin(const unsigned long long *__res
     rlin[g] = (uint32_t)lo;
 }
 
+// staging: the 4-byte stream word of every record, and (for the following prefix sum) the number of runs a
+// multi-run record keeps in blk -- both functions of the uploaded 8-byte record
+__global__ __launch_bounds__(kWG) void k_stream_from_rec(const uint2 *__restrict__ rec, int64_t n, uint32_t *stream, uint32_t *nruns) {
+    const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= n) return;
+    const uint2 r = rec[i];
+    stream[i] = stream_word(r.x, r.y);
+    if (nruns) { const uint32_t nb = r.y >> 24; nruns[i] = nb >= 2u ? nb : 0u; }
+}
+
 __global__ __launch_bounds__(kWG) void k_update_side_flags(uint4 *list, int64_t n, const uint2 *__restrict__ rec) {
     const int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (j >= n) return;

@@ -29,6 +29,7 @@
 #include <chrono>
 #include <future>
 #include <mutex>
+#include <sched.h>
 #include <sys/mman.h>
 #include <thread>
 #include <vector>
@@ -198,8 +199,28 @@ template <typename F> static void parallel_chunks(int64_t n, int nthreads, F fn)
     for (auto &x : th) x.join();
 }
 
+// CPUs this process may actually use: the smaller of the hardware threads, the affinity mask and the
+// container's CFS quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  Pools sized beyond the quota only
+// burn it in bursts and are then throttled as a whole.
+static int usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    long long quota = -1, period = -1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else {
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    return (int)n;
+}
+
 static int stage_threads(int64_t n) {
-    int t = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    int t = std::min(usable_cpus(), 32);
     if (const char *env = getenv("PC_STAGE_THREADS")) t = std::max(1, atoi(env));
     return (int)std::max<int64_t>(1, std::min<int64_t>(t, n / (1 << 20) + 1)); // a thread is not worth < 1 M records
 }
@@ -564,8 +585,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (n < 0 || ntid <= 0 || nrun < 0) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad sizes");
     if (n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL array");
     if (nrun > 0 && (!blk_start || !blk_len)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL run array");
-    if (n >= (int64_t)0xffffffffu || nrun >= (int64_t)0xffffffffu)
-        return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^32-2 records per file are not supported");
+    if (n >= (int64_t)0x7fffffff || nrun >= (int64_t)0xffffffffu)
+        return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 records per file are not supported");
     if (!e->files.empty() && ntid != e->ntid)
         return fail(PC_ERR_ARG, "pc_add_alignment_file: all files must use the same reference list (ntid %d vs %d)", ntid, e->ntid);
     HIP_TRY(hipSetDevice(e->device));
@@ -731,15 +752,16 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc == PC_OK) rc = sf->stream.reserve((size_t)n + 8);
     if (rc == PC_OK && nrun > 0) rc = sf->blk_off.reserve((size_t)n);
     if (rc != PC_OK) { delete sf; return rc; }
+    // Only the 8-byte records cross PCIe: the 4-byte stream word and the run offset of every record are functions
+    // of the records (stream_word; a prefix sum of the run counts) and are derived on the GPU below.
     struct SliceBuf {
         HostBuf<uint2> rec;
-        HostBuf<uint32_t> stream, boff;
         std::future<int> up;
-        SliceBuf(size_t cap, bool runs) : rec(cap), stream(cap), boff(runs ? cap : 0) {}
+        explicit SliceBuf(size_t cap) : rec(cap) {}
     };
     const size_t slice_cap = (size_t)std::min<int64_t>(S, std::max<int64_t>(n, 1));
-    SliceBuf bufs[2] = {SliceBuf(slice_cap, nrun > 0), SliceBuf(nslices > 1 ? slice_cap : 1, nrun > 0)};
-    if (!bufs[0].rec.p || !bufs[0].stream.p || !bufs[1].rec.p || !bufs[1].stream.p || (nrun > 0 && (!bufs[0].boff.p || !bufs[1].boff.p))) {
+    SliceBuf bufs[2] = {SliceBuf(slice_cap), SliceBuf(nslices > 1 ? slice_cap : 1)};
+    if (!bufs[0].rec.p || !bufs[1].rec.p) {
         delete sf;
         return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
     }
@@ -808,21 +830,15 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                     }
                     const size_t j = (size_t)(i - s0);
                     sb.rec[j] = make_uint2((uint32_t)pos[i], meta);
-                    sb.stream[j] = stream_word((uint32_t)pos[i], meta);
-                    if (nrun > 0) sb.boff[j] = boff;
                 }
             }
         });
         uint2 *d_rec = sf->rec.p + s0;
-        uint32_t *d_stream = sf->stream.p + s0, *d_boff = nrun > 0 ? sf->blk_off.p + s0 : nullptr;
         const uint2 *h_rec = sb.rec.p;
-        const uint32_t *h_stream = sb.stream.p, *h_boff = sb.boff.p;
         const size_t cnt = (size_t)(s1 - s0);
         sb.up = std::async(std::launch::async, [=]() -> int {
             if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
             if (hipMemcpyAsync(d_rec, h_rec, cnt * sizeof(uint2), hipMemcpyHostToDevice, up_stream) != hipSuccess) return PC_ERR_HIP;
-            if (hipMemcpyAsync(d_stream, h_stream, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, up_stream) != hipSuccess) return PC_ERR_HIP;
-            if (d_boff && hipMemcpyAsync(d_boff, h_boff, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, up_stream) != hipSuccess) return PC_ERR_HIP;
             return hipStreamSynchronize(up_stream) == hipSuccess ? PC_OK : PC_ERR_HIP;
         });
     }
@@ -839,6 +855,21 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             delete sf;
             return fail(PC_ERR_HIP, "pc_add_alignment_file: staging the sentinels failed");
         }
+    }
+    if (n > 0) {   // the 4-byte stream, and the run offsets (exclusive sum of the run counts of the multi-run records)
+        const unsigned grid = (unsigned)((n + kWG - 1) / kWG);
+        hipLaunchKernelGGL(k_stream_from_rec, dim3(grid), dim3(kWG), 0, e->stream, sf->rec.p, n, sf->stream.p,
+                           nrun > 0 ? sf->blk_off.p : nullptr);
+        hipError_t he = hipGetLastError();
+        if (he == hipSuccess && nrun > 0) {
+            size_t tmp_bytes = 0;
+            DevBuf<uint8_t> d_tmp;
+            he = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, sf->blk_off.p, sf->blk_off.p, (int)n, e->stream);
+            if (he == hipSuccess && d_tmp.reserve(tmp_bytes) != PC_OK) he = hipErrorOutOfMemory;
+            if (he == hipSuccess) he = hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, sf->blk_off.p, sf->blk_off.p, (int)n, e->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(e->stream);   // d_tmp goes out of scope
+        }
+        if (he != hipSuccess) { delete sf; return fail(PC_ERR_HIP, "pc_add_alignment_file: deriving the record stream failed: %s", hipGetErrorString(he)); }
     }
     clk.lap("pack + upload (pipelined)");
     // side lists in record order (slice-major, then thread order inside a slice): every unit copies
@@ -1298,7 +1329,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
 
     pclk.lap("plan: islands");
     // ---- every segment -> its island (binary search)
-    const int PT = nseg >= (1 << 16) ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u) : 1;
+    const int PT = nseg >= (1 << 16) ? std::min(usable_cpus(), 32) : 1;
     parallel_chunks(nseg, PT, [&](int, int64_t sb, int64_t se) {
     for (int64_t s = sb; s < se; ++s) {
         GatherSeg &g = p->gsegs[(size_t)s];

@@ -161,55 +161,104 @@ def write_bam_packed(path, packed, block_bytes=60000, level=1, threads=8):
     nblk = np.maximum(packed.nblk.astype(np.int64), 0)
     ncig = np.where(nblk >= 1, 2 * nblk - 1, 0)
     size = 38 + 4 * ncig                                   # block_size field included
-    off = np.zeros(n + 1, np.int64)
-    np.cumsum(size, out=off[1:])
-    buf = np.zeros(int(off[-1]), np.uint8)
-    rec0 = off[:-1]
+    H = len(head)
+    if n and bool(np.all(nblk >= 1)):
+        # one 42-byte row per record (fixed part + the first run's <L>M), filled column-wise; the further
+        # ops of the multi-run records (N M pairs) are spliced in behind their rows afterwards
+        rows = np.zeros((n, 42), np.uint8)
 
-    def put(rel, width, values):
-        v = np.asarray(values, np.int64)
-        for k in range(width):
-            buf[rec0 + rel + k] = (v >> (8 * k)) & 0xff
+        def col(rel, width, values, dt):
+            rows[:, rel:rel + width] = np.ascontiguousarray(values, dtype=dt).view(np.uint8).reshape(n, width)
 
-    end = packed.ref_end().astype(np.int64)
-    put(0, 4, size - 4)
-    put(4, 4, packed.tid)
-    put(8, 4, packed.pos)
-    put(12, 1, np.full(n, 2))                              # l_read_name ("r\0")
-    put(13, 1, np.full(n, 30))
-    put(14, 2, reg2bin_array(packed.pos, end))
-    put(16, 2, ncig)
-    put(18, 2, np.where(packed.flags & 1, 16, 0))
-    put(20, 4, np.zeros(n, np.int64))                      # l_seq
-    put(24, 4, np.full(n, -1) & 0xffffffff)
-    put(28, 4, np.full(n, -1) & 0xffffffff)
-    put(32, 4, np.zeros(n, np.int64))
-    buf[rec0 + 36] = ord("r")
-    # CIGAR: single-run records <L>M; multi-run records M N M ...
-    single = nblk == 1
-    v = (packed.alen[single].astype(np.int64) << 4) | 0
-    base = rec0[single] + 38
-    for k in range(4):
-        buf[base + k] = (v >> (8 * k)) & 0xff
-    multi = np.nonzero(nblk >= 2)[0]
-    if len(multi):
-        boff = packed.block_offsets()
-        owner = np.repeat(multi, nblk[multi])
-        j = np.arange(len(owner)) - np.repeat(np.cumsum(nblk[multi]) - nblk[multi], nblk[multi])   # run index in its record
-        run = boff[owner] + j
-        st, ln = packed.blk_start[run].astype(np.int64), packed.blk_len[run].astype(np.int64)
-        mbase = rec0[owner] + 38 + 8 * j
-        mv = (ln << 4) | 0
+        end = packed.ref_end().astype(np.int64)
+        first_len = packed.alen.astype(np.int64)
+        multi = np.nonzero(nblk >= 2)[0]
+        extra = np.zeros(0, np.uint8)
+        at = np.zeros(0, np.int64)
+        if len(multi):
+            boff = packed.block_offsets()
+            first_len[multi] = packed.blk_len[boff[multi]]
+            cnt = nblk[multi] - 1                                  # further runs per record
+            owner = np.repeat(np.arange(len(multi)), cnt)
+            j = 1 + np.arange(len(owner)) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            run = boff[multi][owner] + j
+            st, ln = packed.blk_start[run].astype(np.int64), packed.blk_len[run].astype(np.int64)
+            prev_end = packed.blk_start[run - 1].astype(np.int64) + packed.blk_len[run - 1]
+            ops = np.empty((len(run), 2), "<u4")
+            ops[:, 0] = ((st - prev_end) << 4) | 3
+            ops[:, 1] = ln << 4
+            extra = ops.view(np.uint8).reshape(-1)
+            at = np.repeat((multi + 1) * 42, 8 * cnt)
+        col(0, 4, size - 4, "<u4")
+        col(4, 4, packed.tid, "<i4")
+        col(8, 4, packed.pos, "<i4")
+        rows[:, 12] = 2
+        rows[:, 13] = 30
+        col(14, 2, reg2bin_array(packed.pos, end), "<u2")
+        col(16, 2, ncig, "<u2")
+        col(18, 2, np.where(packed.flags & 1, 16, 0), "<u2")
+        col(24, 4, np.full(n, -1), "<i4")
+        col(28, 4, np.full(n, -1), "<i4")
+        rows[:, 36] = ord("r")
+        col(38, 4, first_len << 4, "<u4")
+        body = rows.reshape(-1)
+        if len(extra):
+            body = np.insert(body.view("<u2"), at[::2] // 2, extra.view("<u2")).view(np.uint8)   # all sizes are even
+        whole = np.empty(H + len(body), np.uint8)
+        whole[H:] = body
+        del rows, body
+    else:
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(size, out=off[1:])
+        whole = np.zeros(H + int(off[-1]), np.uint8)
+        buf = whole[H:]
+        rec0 = off[:-1]
+
+        def put(rel, width, values):
+            v = np.asarray(values, np.int64)
+            for k in range(width):
+                buf[rec0 + rel + k] = (v >> (8 * k)) & 0xff
+
+        end = packed.ref_end().astype(np.int64)
+        put(0, 4, size - 4)
+        put(4, 4, packed.tid)
+        put(8, 4, packed.pos)
+        put(12, 1, np.full(n, 2))                              # l_read_name ("r\0")
+        put(13, 1, np.full(n, 30))
+        put(14, 2, reg2bin_array(packed.pos, end))
+        put(16, 2, ncig)
+        put(18, 2, np.where(packed.flags & 1, 16, 0))
+        put(20, 4, np.zeros(n, np.int64))                      # l_seq
+        put(24, 4, np.full(n, -1) & 0xffffffff)
+        put(28, 4, np.full(n, -1) & 0xffffffff)
+        put(32, 4, np.zeros(n, np.int64))
+        buf[rec0 + 36] = ord("r")
+        # CIGAR: single-run records <L>M; multi-run records M N M ...
+        single = nblk == 1
+        v = (packed.alen[single].astype(np.int64) << 4) | 0
+        base = rec0[single] + 38
         for k in range(4):
-            buf[mbase + k] = (mv >> (8 * k)) & 0xff
-        gap = j > 0
-        prev_end = np.zeros(len(owner), np.int64)
-        prev_end[1:] = (st + ln)[:-1]
-        gv = ((st - prev_end)[gap] << 4) | 3
-        gbase = mbase[gap] - 4
-        for k in range(4):
-            buf[gbase + k] = (gv >> (8 * k)) & 0xff
-    data = head + buf.tobytes()
+            buf[base + k] = (v >> (8 * k)) & 0xff
+        multi = np.nonzero(nblk >= 2)[0]
+        if len(multi):
+            boff = packed.block_offsets()
+            owner = np.repeat(multi, nblk[multi])
+            j = np.arange(len(owner)) - np.repeat(np.cumsum(nblk[multi]) - nblk[multi], nblk[multi])   # run index in its record
+            run = boff[owner] + j
+            st, ln = packed.blk_start[run].astype(np.int64), packed.blk_len[run].astype(np.int64)
+            mbase = rec0[owner] + 38 + 8 * j
+            mv = (ln << 4) | 0
+            for k in range(4):
+                buf[mbase + k] = (mv >> (8 * k)) & 0xff
+            gap = j > 0
+            prev_end = np.zeros(len(owner), np.int64)
+            prev_end[1:] = (st + ln)[:-1]
+            gv = ((st - prev_end)[gap] << 4) | 3
+            gbase = mbase[gap] - 4
+            for k in range(4):
+                buf[gbase + k] = (gv >> (8 * k)) & 0xff
+    whole[:H] = np.frombuffer(head, np.uint8)
+    data = memoryview(whole)
 
     def member(i):
         raw = data[i:i + block_bytes]

@@ -56,6 +56,24 @@ def random_file(rng, pa, names, lens, n, max_len, p_gapped, p_long_gap, pile):
                                references=names, lengths=lens, validate=False)
 
 
+def lengthen_last_runs(rng, pa, f):
+    multi = np.nonzero(f.nblk >= 2)[0]
+    if not len(multi):
+        return f
+    pick = multi[rng.random(len(multi)) < 0.3]
+    if not len(pick):
+        return f
+    off = f.block_offsets()
+    bl = f.blk_len.copy()
+    alen = f.alen.astype(np.int64)
+    for i in pick:
+        extra = int(rng.integers(230, 700))
+        bl[off[i] + int(f.nblk[i]) - 1] += extra
+        alen[i] += extra
+    return pa.PackedAlignments(f.tid, f.pos, alen, f.flags, f.nblk, f.blk_start, bl, references=f.references,
+                               lengths=f.lengths, validate=False)
+
+
 def random_case(seed, pa, size="small"):
     rng = np.random.default_rng(seed)
     ntid = int(rng.integers(1, 5))
@@ -68,6 +86,12 @@ def random_case(seed, pa, size="small"):
         n = int(rng.choice([0, 1, 2, 50, 3000, 20000 if size == "small" else 200000]))
         files.append(random_file(rng, pa, names, lens, n, max_len, float(rng.choice([0.0, 0.05, 0.4])),
                                  float(rng.choice([0.0, 0.1, 0.5])), bool(rng.random() < 0.4)))
+    if seed % 3 == 1:
+        # Multi-run reads longer than the run stream carries (aligned length > 255): they stay on the gapped /
+        # long-span side lists.  Made from the drawn files by lengthening the LAST run of some gapped reads, with
+        # a generator of its own, so that every case of earlier revisions keeps its draws.
+        rng2 = np.random.default_rng(seed + 1000003)
+        files = [lengthen_last_runs(rng2, pa, f) for f in files]
     nseg = int(rng.integers(1, 60))
     seg_tid = rng.integers(-1, ntid + 1, nseg).astype(np.int32)
     seg_start = np.zeros(nseg, np.int64)

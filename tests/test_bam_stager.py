@@ -172,20 +172,30 @@ def test_corrupt_bam_is_rejected_not_crashed(tmp_path):
 @pytest.mark.parametrize("piece", [1, 2, 7])
 def test_piecewise_decoding_is_the_serial_walk(tmp_path, monkeypatch, piece):
     """The reader decodes pieces of the record stream in parallel and stitches them; with tiny
-    pieces (PB_PIECE) every cross-piece check is exercised: same arrays as one piece, and the same
-    verdict on files whose defect sits on a piece boundary."""
+    pieces (PB_PIECE: the region loader's record pieces; PB_CHUNK: the whole-file loader's chunks of
+    BGZF members, here one member each, down to members shorter than a record) every cross-piece
+    check is exercised: same arrays as one piece, and the same verdict on files whose defect sits on
+    a piece boundary."""
     genome, tx, reads, _ = synth.make_config("C4", scale=0.00002, tx_scale=0.001)
     recs = bam_writer.packed_to_records(reads)
     refs, lens = list(reads.references), list(reads.lengths)
     path = str(tmp_path / "p.bam")
     bam_writer.write_bam(path, refs, lens, recs, block_bytes=900)
     whole = read_bam(path, threads=1)
+    exp = PackedAlignments.from_cigars([r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs],
+                                       [bool(r[3] & 16) for r in recs], references=refs, lengths=lens)
+    for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
+        assert np.array_equal(getattr(whole, name), getattr(exp, name)), name
     monkeypatch.setenv("PB_PIECE", str(piece))
-    for th in (1, 3):
-        got = read_bam(path, threads=th)
-        for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
-            assert np.array_equal(getattr(got, name), getattr(whole, name)), name
-        assert got.mapped == whole.mapped
+    monkeypatch.setenv("PB_CHUNK", "1")
+    for block_bytes in (900, 150, 23 * piece):
+        bam_writer.write_bam(path, refs, lens, recs, block_bytes=block_bytes)
+        monkeypatch.setenv("PB_HEAD", "16" if block_bytes == 900 else "32768")   # heads shorter than a record
+        for th in (1, 3):
+            got = read_bam(path, threads=th)
+            for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
+                assert np.array_equal(getattr(got, name), getattr(whole, name)), (name, block_bytes)
+            assert got.mapped == whole.mapped
     # defects at every position of a short file: disorder, a placed record after an unplaced one,
     # a leading deletion that breaks the order of the first aligned positions
     base = [(0, 100 + 10 * i, [(0, 30)], 0) for i in range(9)]
