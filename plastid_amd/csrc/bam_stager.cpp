@@ -22,6 +22,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <fcntl.h>
 #include <sched.h>
@@ -48,9 +49,11 @@ struct Block {
 // Records decoded from one contiguous piece of the inflated stream (the pieces are decoded in
 // parallel and stitched in file order).
 struct Part {
-    std::vector<int32_t> tid, pos, blk_start, blk_len;
-    std::vector<uint16_t> alen;
-    std::vector<uint8_t> flags, nblk;
+    // the columns: n records, nrun runs of the gapped ones, held by the load's Arena
+    int32_t *tid = nullptr, *pos = nullptr, *blk_start = nullptr, *blk_len = nullptr;
+    uint16_t *alen = nullptr;
+    uint8_t *flags = nullptr, *nblk = nullptr;
+    size_t n = 0, nrun = 0;
     int64_t mapped = 0, unplaced = 0, total = 0;
     // first defect found inside the piece: record index within the piece, message; `before_order` marks
     // the checks the serial walk makes before it looks at the sort order of a record
@@ -65,8 +68,93 @@ struct Part {
     bool bad_size = false;            // decode_span stopped at a length prefix below the fixed record size
 };
 
+// Column storage of one load: 64 MiB anonymous mappings (on huge pages where the host grants them), handed
+// out by bumping a pointer.  Thousands of per-piece vectors cost more in mmap/munmap and page faults than
+// the decoding itself.  Regions released by a closed file wait in a process-wide pool (at most PB_POOL_MB,
+// default 2048) for the next load -- several BAM files are the normal case -- which then neither faults
+// them in again nor unmaps them.
+struct RegionPool {
+    static constexpr size_t kRegion = (size_t)64 << 20;
+    std::mutex mu;
+    std::vector<void *> idle;
+    size_t cap = 2048;   // MiB
+    RegionPool() { if (const char *env = getenv("PB_POOL_MB")) cap = (size_t)std::max(0, atoi(env)); }
+    ~RegionPool() { for (void *q : idle) munmap(q, kRegion); }
+    void *get() {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!idle.empty()) { void *q = idle.back(); idle.pop_back(); return q; }
+        }
+        void *q = mmap(nullptr, kRegion, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) return nullptr;
+        (void)madvise(q, kRegion, MADV_HUGEPAGE);
+        return q;
+    }
+    void put(void *q) {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if ((idle.size() + 1) * (kRegion >> 20) <= cap) { idle.push_back(q); return; }
+        }
+        munmap(q, kRegion);
+    }
+};
+RegionPool &region_pool() {
+    static RegionPool pool;
+    return pool;
+}
+
+struct Arena {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> regions;
+    uint8_t *cur = nullptr;
+    size_t left = 0;
+    void *alloc(size_t bytes) {
+        bytes = (bytes + 63) & ~(size_t)63;
+        std::lock_guard<std::mutex> lock(mu);
+        if (bytes > left) {
+            void *q;
+            size_t sz = RegionPool::kRegion;
+            if (bytes <= sz) {
+                q = region_pool().get();
+            } else {                                      // an outsize piece gets a mapping of its own
+                sz = (bytes + 4095) & ~(size_t)4095;
+                q = mmap(nullptr, sz, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+                if (q == MAP_FAILED) q = nullptr;
+            }
+            if (!q) return nullptr;
+            regions.emplace_back(q, sz);
+            cur = (uint8_t *)q;
+            left = sz;
+        }
+        void *r = cur;
+        cur += bytes;
+        left -= bytes;
+        return r;
+    }
+    void clear() {
+        for (auto &r : regions) {
+            if (r.second == RegionPool::kRegion) region_pool().put(r.first);
+            else munmap(r.first, r.second);
+        }
+        regions.clear();
+        cur = nullptr;
+        left = 0;
+    }
+    ~Arena() { clear(); }
+};
+
+// The records of the piece being decoded (scratch: reused from piece to piece, so it stays in cache; the
+// finished columns are copied into the Arena at their exact size).
+struct Cols {
+    std::vector<int32_t> tid, pos, blk_start, blk_len;
+    std::vector<uint16_t> alen;
+    std::vector<uint8_t> flags, nblk;
+    void clear() { tid.clear(); pos.clear(); blk_start.clear(); blk_len.clear(); alen.clear(); flags.clear(); nblk.clear(); }
+};
+
 struct Bam {
     std::string path;
+    Arena arena;
     std::vector<std::string> ref_names;
     std::vector<int32_t> ref_lengths;
     std::vector<Part> parts;          // decoded records, in file order
@@ -251,8 +339,9 @@ int parse_header(Bam &bam, const uint8_t *&p, const uint8_t *end, uint32_t &n_re
 // `pt` with every per-record format check and the order checks inside the piece.  Returns where it
 // stopped: `limit`, the start of the first record that crosses `limit`, or the record whose length
 // prefix is impossible (pt.bad_size).  A defect ends the piece (pt.err, pt.err_rec).
-const uint8_t *decode_span(const Bam &bam, Part &pt, const uint8_t *q, const uint8_t *limit, uint32_t n_ref, int64_t max_rec) {
+const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint8_t *q, const uint8_t *limit, uint32_t n_ref, int64_t max_rec) {
     std::vector<std::pair<int32_t, int32_t>> runs;
+    cols.clear();
     auto bad = [&](int64_t i, bool before_order, const std::string &m) {
         pt.err_rec = i; pt.err_before_order = before_order; pt.err = m;
         return q;
@@ -283,7 +372,7 @@ const uint8_t *decode_span(const Bam &bam, Part &pt, const uint8_t *q, const uin
         } else if (pt.saw_unplaced || tid < pt.last_tid || (tid == pt.last_tid && pos < pt.last_pos)) {
             return bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
         }
-        const bool first = pt.tid.empty();
+        const bool first = cols.tid.empty();
         if ((size_t)32 + l_read_name + (size_t)n_cigar * 4 > block_size) return bad(i, false, "corrupt BAM record (cigar overruns block)");
         const uint8_t *cig = r + 32 + l_read_name;
         runs.clear();
@@ -318,23 +407,44 @@ const uint8_t *decode_span(const Bam &bam, Part &pt, const uint8_t *q, const uin
         else if (pt.last_tid == tid && pt.last_spos > spos)
             return bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
         pt.last_tid = tid; pt.last_pos = pos; pt.last_spos = spos;
-        pt.tid.push_back(tid);
-        pt.pos.push_back(spos);
-        pt.alen.push_back((uint16_t)L);
-        pt.flags.push_back((flag & 0x10) ? 1 : 0);
-        pt.nblk.push_back((uint8_t)runs.size());
+        cols.tid.push_back(tid);
+        cols.pos.push_back(spos);
+        cols.alen.push_back((uint16_t)L);
+        cols.flags.push_back((flag & 0x10) ? 1 : 0);
+        cols.nblk.push_back((uint8_t)runs.size());
         if (runs.size() >= 2)
             for (auto &x : runs) {
-                pt.blk_start.push_back(x.first);
-                pt.blk_len.push_back(x.second);
+                cols.blk_start.push_back(x.first);
+                cols.blk_len.push_back(x.second);
             }
     }
     return q;
 }
 
-void reserve_part(Part &pt, size_t count) {
-    pt.tid.reserve(count); pt.pos.reserve(count); pt.alen.reserve(count);
-    pt.flags.reserve(count); pt.nblk.reserve(count);
+const uint8_t *decode_span(Bam &bam, Part &pt, const uint8_t *q, const uint8_t *limit, uint32_t n_ref, int64_t max_rec) {
+    thread_local Cols cols;
+    const uint8_t *stop = decode_span_cols(bam, pt, cols, q, limit, n_ref, max_rec);
+    // the finished columns, at their exact size, into the load's arena
+    const size_t n = cols.tid.size(), m = cols.blk_start.size();
+    if (n) {
+        uint8_t *mem = (uint8_t *)bam.arena.alloc(n * 12 + 64 * 5 + m * 8 + 64 * 2);
+        if (!mem) {
+            if (pt.err_rec == INT64_MAX) { pt.err_rec = 0; pt.err_before_order = true; pt.err = "out of memory reading " + bam.path; }
+            return stop;
+        }
+        auto take = [&](size_t bytes) { uint8_t *r = mem; mem += (bytes + 63) & ~(size_t)63; return r; };
+        pt.tid = (int32_t *)take(n * 4); pt.pos = (int32_t *)take(n * 4); pt.alen = (uint16_t *)take(n * 2);
+        pt.flags = take(n); pt.nblk = take(n);
+        std::memcpy(pt.tid, cols.tid.data(), n * 4); std::memcpy(pt.pos, cols.pos.data(), n * 4);
+        std::memcpy(pt.alen, cols.alen.data(), n * 2); std::memcpy(pt.flags, cols.flags.data(), n); std::memcpy(pt.nblk, cols.nblk.data(), n);
+        if (m) {
+            pt.blk_start = (int32_t *)take(m * 4); pt.blk_len = (int32_t *)take(m * 4);
+            std::memcpy(pt.blk_start, cols.blk_start.data(), m * 4); std::memcpy(pt.blk_len, cols.blk_len.data(), m * 4);
+        }
+    }
+    pt.n = n;
+    pt.nrun = m;
+    return stop;
 }
 
 // The checks that span two pieces, and the flat offsets of every piece (bam.parts in file order).  The
@@ -360,11 +470,11 @@ int stitch_parts(Bam &bam, bool truncated, int nthreads) {
         }
         if (pt.err_rec < at || (pt.err_rec == at && pt.err_before_order)) { at = pt.err_rec; msg = pt.err; }
         if (at != INT64_MAX) return fail(msg);
-        if (pt.any_placed && !pt.tid.empty()) { have_prev = true; prev_tid = pt.last_tid; prev_pos = pt.last_pos; prev_spos = pt.last_spos; }
+        if (pt.any_placed && pt.n > 0) { have_prev = true; prev_tid = pt.last_tid; prev_pos = pt.last_pos; prev_spos = pt.last_spos; }
         seen_unplaced |= pt.saw_unplaced;
         bam.mapped += pt.mapped; bam.unplaced += pt.unplaced; bam.total += pt.total;
-        bam.rec_off[k + 1] = bam.rec_off[k] + pt.tid.size();
-        bam.run_off[k + 1] = bam.run_off[k] + pt.blk_start.size();
+        bam.rec_off[k + 1] = bam.rec_off[k] + pt.n;
+        bam.run_off[k + 1] = bam.run_off[k] + pt.nrun;
     }
     if (truncated) return fail("truncated BAM record");
     bam.nrec = bam.rec_off[nparts];
@@ -404,7 +514,6 @@ int decode_records(Bam &bam, const uint8_t *p, const uint8_t *end, uint32_t n_re
             for (;;) {
                 const size_t k = nextp.fetch_add(1);
                 if (k >= nparts) return;
-                reserve_part(bam.parts[k], (size_t)std::min<int64_t>(kPiece, nwalk - (int64_t)k * kPiece));
                 decode_span(bam, bam.parts[k], cuts[k], cuts[k + 1], n_ref, INT64_MAX);
             }
         };
@@ -541,7 +650,6 @@ int decode(Bam &bam, int nthreads) {
     auto decode_chunk = [&](Chunk &c, const uint8_t *base, size_t from) {
         const size_t len = c.hi - c.lo;
         c.part = Part();
-        reserve_part(c.part, (c.hi - from) / 40 + 16);
         const uint8_t *q = decode_span(bam, c.part, base + (from - c.lo), base + len, n_ref, INT64_MAX);
         c.guess = from;
         c.stop = c.lo + (size_t)(q - base);
@@ -902,7 +1010,7 @@ int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, c
     };
     for (Part &pt : bam.parts) {
         size_t w = 0, rw = 0, rr = 0;
-        for (size_t i = 0; i < pt.tid.size(); ++i) {
+        for (size_t i = 0; i < pt.n; ++i) {
             const int nb = pt.nblk[i];
             const size_t runs = nb >= 2 ? (size_t)nb : 0;
             const int64_t endpos = nb >= 2 ? (int64_t)pt.blk_start[rr + runs - 1] + pt.blk_len[rr + runs - 1]
@@ -915,12 +1023,12 @@ int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, c
             }
             rr += runs;
         }
-        pt.tid.resize(w); pt.pos.resize(w); pt.alen.resize(w); pt.flags.resize(w); pt.nblk.resize(w);
-        pt.blk_start.resize(rw); pt.blk_len.resize(rw);
+        pt.n = w;
+        pt.nrun = rw;
     }
     for (size_t k = 0; k < bam.parts.size(); ++k) {
-        bam.rec_off[k + 1] = bam.rec_off[k] + bam.parts[k].tid.size();
-        bam.run_off[k + 1] = bam.run_off[k] + bam.parts[k].blk_start.size();
+        bam.rec_off[k + 1] = bam.rec_off[k] + bam.parts[k].n;
+        bam.run_off[k + 1] = bam.run_off[k] + bam.parts[k].nrun;
     }
     bam.nrec = bam.parts.empty() ? 0 : bam.rec_off[bam.parts.size()];
     bam.nrun = bam.parts.empty() ? 0 : bam.run_off[bam.parts.size()];
@@ -1028,22 +1136,22 @@ int pb_fill(void *h, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags,
             const size_t k = next.fetch_add(1);
             if (k >= nparts) return;
             const Part &pt = b->parts[k];
-            const size_t at = b->rec_off[k], n = pt.tid.size(), rat = b->run_off[k], m = pt.blk_start.size();
+            const size_t at = b->rec_off[k], n = pt.n, rat = b->run_off[k], m = pt.nrun;
             if (n) {
-                std::memcpy(tid + at, pt.tid.data(), n * 4);
-                std::memcpy(pos + at, pt.pos.data(), n * 4);
-                std::memcpy(alen + at, pt.alen.data(), n * 2);
-                std::memcpy(flags + at, pt.flags.data(), n);
-                std::memcpy(nblk + at, pt.nblk.data(), n);
+                std::memcpy(tid + at, pt.tid, n * 4);
+                std::memcpy(pos + at, pt.pos, n * 4);
+                std::memcpy(alen + at, pt.alen, n * 2);
+                std::memcpy(flags + at, pt.flags, n);
+                std::memcpy(nblk + at, pt.nblk, n);
             }
             if (m) {
-                std::memcpy(blk_start + rat, pt.blk_start.data(), m * 4);
-                std::memcpy(blk_len + rat, pt.blk_len.data(), m * 4);
+                std::memcpy(blk_start + rat, pt.blk_start, m * 4);
+                std::memcpy(blk_len + rat, pt.blk_len, m * 4);
             }
         }
     };
     std::vector<std::thread> pool;
-    const int nt = (int)std::min<size_t>((size_t)std::max(b->threads, 1), std::max<size_t>(nparts, 1));
+    const int nt = (int)std::min<size_t>((size_t)std::min(std::max(b->threads, 1), 32), std::max<size_t>(nparts, 1));   // a copy: memory-bound
     for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
     worker();
     for (auto &t : pool) t.join();

@@ -754,19 +754,23 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     if (rc != PC_OK) { delete sf; return rc; }
     // Only the 8-byte records cross PCIe: the 4-byte stream word and the run offset of every record are functions
     // of the records (stream_word; a prefix sum of the run counts) and are derived on the GPU below.
+    // (Page-locked slices were measured and bought nothing: on the 16 CPUs a GPU box grants, packing a slice
+    // takes as long as its pageable upload, 31-37 ms per 100 M records either way.)
     struct SliceBuf {
-        HostBuf<uint2> rec;
+        HostBuf<uint2> own;
+        uint2 *rec = nullptr;
         std::future<int> up;
-        explicit SliceBuf(size_t cap) : rec(cap) {}
+        explicit SliceBuf(size_t cap) : own(cap) { rec = own.p; }
     };
     const size_t slice_cap = (size_t)std::min<int64_t>(S, std::max<int64_t>(n, 1));
     SliceBuf bufs[2] = {SliceBuf(slice_cap), SliceBuf(nslices > 1 ? slice_cap : 1)};
-    if (!bufs[0].rec.p || !bufs[1].rec.p) {
+    if (!bufs[0].rec || !bufs[1].rec) {
         delete sf;
         return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
     }
     const int device = e->device;
     hipStream_t up_stream = e->stream;
+    clk.lap("run layout + allocations");
     for (int64_t sl = 0; sl < nslices && rc == PC_OK; ++sl) {
         SliceBuf &sb = bufs[sl & 1];
         if (sb.up.valid()) rc = sb.up.get();               // the slice that used these buffers has gone up
@@ -834,7 +838,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             }
         });
         uint2 *d_rec = sf->rec.p + s0;
-        const uint2 *h_rec = sb.rec.p;
+        const uint2 *h_rec = sb.rec;
         const size_t cnt = (size_t)(s1 - s0);
         sb.up = std::async(std::launch::async, [=]() -> int {
             if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
