@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
                                                 MapParams mp, int W, const double *__restrict__ inv_,
                                                 const uint32_t *__restrict__ order,
                                                 const uint32_t *__restrict__ counters,
-                                                const u32x4 *__restrict__ ranges, double *hist) {
+                                                const u32x4 *__restrict__ ranges, double *hist, unsigned long long *dbg) {
     __shared__ double s_inv[kInvLds];
     __shared__ CenterEntry s_list[kWG];                       // 64 compacted candidates per wave
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
@@ -1420,6 +1420,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     const int32_t cend = ck.start + ck.len;
     const int nib = mp.param;
     double acc = 0.0;
+    const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
         const int64_t near_key = (int64_t)ck.start - W + 1;
@@ -1485,6 +1486,7 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
         }
     }
     if (lane < ck.len) hist[ck.hist_off + lane] = acc;
+    if (dbg && lane == 0) { dbg[2 * (size_t)slot] = wall_clock64() - t_begin; dbg[2 * (size_t)slot + 1] = t_begin; }   // PC_CENTER_DEBUG
 }
 
 // ---------------------------------------------------------------- k_gather

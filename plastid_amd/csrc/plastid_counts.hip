@@ -1740,12 +1740,48 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
             hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
                                p->d_ccand.p, p->d_cranges.p, total);
-            const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2; // cut thresholds, in multiples of the mean candidate count
+            // cut thresholds, in multiples of the mean candidate count
+            const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2;
             hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, (int64_t)2048, ck1, ck2,
                                p->d_corder.p, e->d_counters.p);
+            // PC_CENTER_DEBUG: how long every dispatched wave ran (wall clock ticks), printed after the launch
+            DevBuf<unsigned long long> d_dbg;
+            const bool dbg_on = getenv("PC_CENTER_DEBUG") != nullptr;
+            if (dbg_on) {
+                rc = d_dbg.reserve((size_t)(2 * kCenterCap * nchunks));
+                if (rc != PC_OK) return rc;
+                HIP_TRY(hipMemsetAsync(d_dbg.p, 0, (size_t)(2 * kCenterCap * nchunks) * 8, st));
+            }
+            unsigned long long *dbg = dbg_on ? d_dbg.p : nullptr;
             hipLaunchKernelGGL(k_center, dim3((unsigned)((kCenterCap * nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks,
                                e->d_files.p, nfiles, mp, W, e->d_inv.p, p->d_corder.p, e->d_counters.p, p->d_cranges.p,
-                               (double *)p->d_hist.p);
+                               (double *)p->d_hist.p, dbg);
+            if (dbg_on) {
+                std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks));
+                std::vector<uint32_t> h_order((size_t)(kCenterCap * nchunks)), h_cand((size_t)nchunks);
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(h.data(), d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(h_order.data(), p->d_corder.p, h_order.size() * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(h_cand.data(), p->d_ccand.p, h_cand.size() * 4, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, t1 = 0, sum = 0;
+                size_t nw = 0;
+                std::vector<std::pair<unsigned long long, size_t>> byd;
+                for (size_t i = 0; i < h.size() / 2; ++i)
+                    if (h[2 * i]) {
+                        t0 = std::min(t0, h[2 * i + 1]); t1 = std::max(t1, h[2 * i + 1] + h[2 * i]);
+                        sum += h[2 * i]; ++nw;
+                        byd.emplace_back(h[2 * i], i);
+                    }
+                std::sort(byd.rbegin(), byd.rend());
+                fprintf(stderr, "[center] %zu waves, launch span %llu ticks (100 MHz: %.3f ms), summed wave time %llu ticks = %.1f x the span\n", nw, t1 - t0,
+                        (t1 - t0) / 1e5, sum, (double)sum / (double)std::max<unsigned long long>(t1 - t0, 1));
+                for (size_t k = 0; k < std::min<size_t>(byd.size(), 12); ++k) {
+                    const size_t i = byd[k].second;
+                    const uint32_t en = h_order[i], ci = en & ((1u << kSubShift) - 1u);
+                    fprintf(stderr, "[center]   slot %zu: %.3f ms, started at %.3f ms, chunk %u code %u, candidates %u\n", i, byd[k].first / 1e5,
+                            (h[2 * i + 1] - t0) / 1e5, ci, en >> kSubShift, h_cand[ci]);
+                }
+            }
         }
         if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
         if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
