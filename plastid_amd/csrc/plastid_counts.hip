@@ -1578,7 +1578,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // work list capacity: every record lies in at most 1 + ceil(W/G) scan windows
             // work-list capacity (an upper bound): a window scanning n records yields at most
             // max(1, 2n/R) items, and every record is scanned by at most 1 + (W+127)/G windows
-            const double windows_per_record = 1.0 + (double)(W + 127) / (double)G;
+            const int halo = std::max(std::max(W, e->Ws()), std::max(e->Wg(), e->Wr()));
+            const double windows_per_record = 1.0 + (double)(halo + 127) / (double)G;
             const int64_t cap64 = (int64_t)ntiles * nfiles + (int64_t)(2.0 * windows_per_record * (double)nrec / (double)R) + nfiles + 64;
             if (cap64 >= (int64_t)0xffffffffu) return fail(PC_ERR_ARG, "pc_count: work list too large");
             rc = e->d_work.reserve((size_t)cap64);
@@ -1773,7 +1774,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                         byd.emplace_back(h[2 * i], i);
                     }
                 std::sort(byd.rbegin(), byd.rend());
-                fprintf(stderr, "[center] %zu waves, launch span %llu ticks (100 MHz: %.3f ms), summed wave time %llu ticks = %.1f x the span\n", nw, t1 - t0,
+                fprintf(stderr, "[center] W %d: %zu waves, launch span %llu ticks (100 MHz: %.3f ms), summed wave time %llu ticks = %.1f x the span\n", W, nw, t1 - t0,
                         (t1 - t0) / 1e5, sum, (double)sum / (double)std::max<unsigned long long>(t1 - t0, 1));
                 for (size_t k = 0; k < std::min<size_t>(byd.size(), 12); ++k) {
                     const size_t i = byd[k].second;
