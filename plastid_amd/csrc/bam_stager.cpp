@@ -243,7 +243,6 @@ struct LibDeflate {
     uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
     bool ok = false;
     LibDeflate() {
-        if (getenv("PB_ZLIB")) return;
         void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
         alloc = reinterpret_cast<decltype(alloc)>(dlsym(h, "libdeflate_alloc_decompressor"));
@@ -265,7 +264,7 @@ struct ThreadDecompressor {
 // raw deflate stream -> exactly `out_n` bytes with CRC-32 `crc`; 0, -1 (damaged stream) or -2 (CRC)
 int raw_inflate(const uint8_t *in, size_t in_n, uint8_t *out, size_t out_n, uint32_t crc) {
     const LibDeflate &ld = libdeflate();
-    if (ld.ok) {
+    if (ld.ok && getenv("PB_ZLIB") == nullptr) {
         thread_local ThreadDecompressor td;
         if (!td.d) td.d = ld.alloc();
         if (td.d) {

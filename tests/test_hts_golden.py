@@ -88,6 +88,21 @@ def test_native_reader_decodes_the_htslib_written_bam(hts, bam_path):
         assert np.array_equal(got.ref_end(), hts["endpos"][keep])
 
 
+@pytest.mark.parametrize("knobs", [{"PB_CHUNK": "1"}, {"PB_CHUNK": "700", "PB_HEAD": "24"}, {"PB_CHUNK": "1", "PB_HEAD": "5", "PB_ZLIB": "1"}])
+def test_chunked_decoding_of_the_htslib_written_bam(hts, bam_path, monkeypatch, knobs):
+    """The whole-file reader decodes chunks of BGZF members from guessed record boundaries and chains them;
+    on htslib's own records (names, sequences, qualities, tags -- not the bare records of tests/bam_writer)
+    tiny chunks, heads shorter than a record and the zlib path give the arrays of the default decode."""
+    whole = read_bam(bam_path, threads=1)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for threads in (1, 3):
+        got = read_bam(bam_path, threads=threads)
+        for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
+            assert np.array_equal(getattr(got, name), getattr(whole, name)), (name, knobs)
+        assert got.mapped == whole.mapped
+
+
 def test_region_reads_through_the_bai_match_hts_itr_query(hts, bam_path):
     """read_bam(regions=...) (BAI bins + linear index + overlap test) returns exactly the records
     htslib's iterator yields (hts.c:1924-1960), for every seeded region; so do the pure-Python fetch of
