@@ -857,7 +857,7 @@ __device__ __forceinline__ void out_add(typename OutT_<OUTMODE>::type *dst, unsi
 }
 
 template <int KIND, int OUTMODE, int WG, bool SMALL>
-__global__ __launch_bounds__(WG) void k_hist_point(const Piece *__restrict__ pieces,
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_hist_point(const Piece *__restrict__ pieces,
                                                     const OutPiece *__restrict__ opieces, FileView file0,
                                                     FileView file1, const FileView *__restrict__ files,
                                                     const WorkItem *__restrict__ work,
@@ -1418,7 +1418,6 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     }
     const int32_t p = ck.start + lane;
     const int32_t cend = ck.start + ck.len;
-    const int nib = mp.param;
     double acc = 0.0;
     const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
