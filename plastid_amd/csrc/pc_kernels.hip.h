@@ -36,8 +36,16 @@ constexpr int kWG = 256;          // 4 waves of 64
 #ifndef PC_HIST_WG
 #define PC_HIST_WG 256            // workgroup size of the histogram kernel
 #endif
+// Waves per SIMD the tile kernel is compiled for (register budget 512 / waves), and 16-byte loads in flight per lane
+// (x2: register double buffer).  Sparse windows are latency-bound, so residency beats prefetch depth there: the
+// variable-offset rule gets seven waves and two loads, the others six and four (C2, dense: 0.157 ms with 4 loads,
+// 0.160 with 2; C4: 1.32 -> 1.25 ms; the stratified rule's window holds 11 rows of bins, so its LDS allows six
+// workgroups per CU whatever the registers: C5 5.0 ms with 6 / 4, 5.2 with 7 / 2).
+#ifndef PC_HIST_WAVES
+#define PC_HIST_WAVES(KIND) ((KIND) == 3 ? 7 : 6)
+#endif
 #ifndef PC_HIST_U
-#define PC_HIST_U 4               // 16-byte loads in flight per lane (x2: register double buffer)
+#define PC_HIST_U(KIND) ((KIND) == 3 ? 2 : 4)
 #endif
 constexpr int kHistWG = PC_HIST_WG;
 constexpr int kWave = 64;
@@ -857,7 +865,7 @@ __device__ __forceinline__ void out_add(typename OutT_<OUTMODE>::type *dst, unsi
 }
 
 template <int KIND, int OUTMODE, int WG, bool SMALL>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_hist_point(const Piece *__restrict__ pieces,
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVES(KIND), 8))) void k_hist_point(const Piece *__restrict__ pieces,
                                                     const OutPiece *__restrict__ opieces, FileView file0,
                                                     FileView file1, const FileView *__restrict__ files,
                                                     const WorkItem *__restrict__ work,
@@ -893,7 +901,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // ---- first batch of the record stream (and the first gapped records).  The stream is read
     // as quads of 4-byte records; the records of the first quad that precede `lo` are masked
     // below, and a last quad that `hi` cuts is handled apart (by thread 0, masked on both sides).
-    constexpr int U = PC_HIST_U;
+    constexpr int U = PC_HIST_U(KIND);
     static_assert(U % 2 == 0, "PC_HIST_U must be even");
     const int64_t quad_lo = w.lo >> 2;
     const int nquads = (int)((w.hi >> 2) - quad_lo); // quads wholly below hi (may be 0, never negative)

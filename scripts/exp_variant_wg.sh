@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/variants
-for flags in "-DPC_HIST_WG=128" "-DPC_HIST_WG=128 -DPC_HIST_U=8"; do
+for flags in "-DPC_HIST_WG=128" "-DPC_HIST_WG=128 -DPC_HIST_U(K)=8"; do
   tag=$(echo "$flags" | tr -d ' =-')
   LIBV=$(python - <<PY
 import os
