@@ -37,15 +37,17 @@ constexpr int kWG = 256;          // 4 waves of 64
 #define PC_HIST_WG 256            // workgroup size of the histogram kernel
 #endif
 // Waves per SIMD the tile kernel is compiled for (register budget 512 / waves), and 16-byte loads in flight per lane
-// (x2: register double buffer).  Sparse windows are latency-bound, so residency beats prefetch depth there: the
-// variable-offset rule gets seven waves and two loads, the others six and four (C2, dense: 0.157 ms with 4 loads,
-// 0.160 with 2; C4: 1.32 -> 1.25 ms; the stratified rule's window holds 11 rows of bins, so its LDS allows six
-// workgroups per CU whatever the registers: C5 5.0 ms with 6 / 4, 5.2 with 7 / 2).
+// (x2: register double buffer).  Sparse windows are latency-bound, so residency counts there: every instantiation
+// fits six waves (76 - 77 VGPRs) and, without the first-batch prefetch of the gapped-record list, seven (66 - 69)
+// without scratch; eight spill.  Measured (scripts/exp_hist_occupancy.sh): C4 (variable offsets) 1.51 ms at five
+// waves, 1.36 at six, 1.22 at seven; C2 (dense, HBM-bound) 0.155 at six, 0.158 at seven; C5 (stratified: its
+// 11-row window allows six workgroups per CU by LDS alone) 5.0 at six, 5.1 at seven.  So: seven for the
+// variable-offset rule, six for the others.
 #ifndef PC_HIST_WAVES
 #define PC_HIST_WAVES(KIND) ((KIND) == 3 ? 7 : 6)
 #endif
 #ifndef PC_HIST_U
-#define PC_HIST_U(KIND) ((KIND) == 3 ? 2 : 4)
+#define PC_HIST_U(KIND) 4
 #endif
 constexpr int kHistWG = PC_HIST_WG;
 constexpr int kWave = 64;
@@ -920,10 +922,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVE
     const int nstage = w.merge ? 0 : (int)min(w.op_end - w.op_begin, (uint32_t)kOpStage);
     u32x4 opq = {0u, 0u, 0u, 0u};
     if ((int)threadIdx.x < nstage * 3) opq = ((const u32x4 PC_GLOBAL *)(opieces + w.op_begin))[threadIdx.x];
-    const int64_t gj0 = w.glo + threadIdx.x;
     const u32x4 gnone = {0u, kFlagExcluded << 16, 0u, 0u};
-    const u32x4 gfirst = (gj0 < w.ghi) ? fv.gap_rec[gj0] : gnone;
-    const i32x4 gfirst_runs = (gj0 < w.ghi) ? fv.gap_runs[gj0] : i32x4{0, 1, 0, 0};
+    // first batch of the gapped-record list, requested with everything else -- where the register budget is that of
+    // six waves anyway (eight registers held across the stream loop are what separates six waves from seven)
+    constexpr bool kGapPrefetch = PC_HIST_WAVES(KIND) <= 6;
+    const int64_t gj0 = w.glo + threadIdx.x;
+    u32x4 gfirst = gnone;
+    i32x4 gfirst_runs = {0, 1, 0, 0};
+    if (kGapPrefetch && gj0 < w.ghi) { gfirst = fv.gap_rec[gj0]; gfirst_runs = fv.gap_runs[gj0]; }
     const u32x2 rnone = {0u, kFlagExcluded << 24};
     const uint32_t rj0 = w.rlo + threadIdx.x;
     const u32x2 rfirst = (rj0 < w.rhi) ? fv.run_rec[rj0] : rnone;
@@ -1020,8 +1026,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVE
     for (int64_t base = w.glo; base < w.ghi; base += WG) {
         const int64_t j = base + threadIdx.x;
         const bool in = j < w.ghi;
-        const u32x4 g = base == w.glo ? gfirst : (in ? fv.gap_rec[j] : gnone);
-        const i32x4 gr = base == w.glo ? gfirst_runs : (in ? fv.gap_runs[j] : i32x4{0, 1, 0, 0});
+        const u32x4 g = (kGapPrefetch && base == w.glo) ? gfirst : (in ? fv.gap_rec[j] : gnone);
+        const i32x4 gr = (kGapPrefetch && base == w.glo) ? gfirst_runs : (in ? fv.gap_runs[j] : i32x4{0, 1, 0, 0});
         const uint32_t meta = g.y, hi = meta >> 16;
         const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
         const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
