@@ -1410,13 +1410,18 @@ __global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ 
     __shared__ double s_inv[kInvLds];
     __shared__ CenterEntry s_list[kWG];                       // 64 compacted candidates per wave
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
+    // the grid spans the list capacity: heavy entries at the front, light ones at the back, nothing in between --
+    // two thirds of the workgroups have no slot to serve and leave before they fill the table
+    const uint32_t cap = kCenterCap * (uint32_t)nchunks;
+    const uint32_t n_heavy = counters[0], n_light = counters[1];
+    {
+        const uint32_t first = blockIdx.x * (uint32_t)(kWG / 64), last = first + (uint32_t)(kWG / 64) - 1u;
+        if (first >= cap || !(first < n_heavy || last >= cap - n_light)) return;   // uniform over the workgroup
+    }
     for (int i = threadIdx.x; i < kInvLds; i += kWG) s_inv[i] = inv[i]; // host-computed IEEE quotients 1.0/m
     __syncthreads();
-    // the grid spans the list capacity: heavy entries at the front, light ones at the back
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
-    const uint32_t cap = kCenterCap * (uint32_t)nchunks;
     if (slot >= cap) return;
-    const uint32_t n_heavy = counters[0], n_light = counters[1];
     const uint32_t entry = order[slot];
     if (!(slot < n_heavy || slot >= cap - n_light)) return;
     const int lane = threadIdx.x & 63;
