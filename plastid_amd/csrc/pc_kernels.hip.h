@@ -1213,7 +1213,15 @@ __device__ __forceinline__ double lane_f64(double v, int j) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-constexpr int kInvLds = 1024; // 1/m table kept in LDS for m < kInvLds
+#ifndef PC_CENTER_WG
+#define PC_CENTER_WG 64
+#endif
+// Workgroup of the center kernel: ONE wave.  The waves of a launch are independent (one chunk each) and very
+// unequal; in a four-wave workgroup the LDS and the wave slots of the finished ones stay taken until the last one
+// is done, and a new workgroup needs four free slots at once: PC_CENTER_DEBUG showed ~4 200 of 6 144 possible
+// waves resident through the launch.
+constexpr int kCenterWG = PC_CENTER_WG;
+constexpr int kInvLds = 256; // 1/m table kept in LDS for m < kInvLds (2 KiB per workgroup; longer map lengths read the global table)
 
 // Dispatch list of the center kernel.  A chunk's replay is sequential in the reads that overlap
 // it (the order is the contract), so its time is proportional to that count, and expression is
@@ -1401,26 +1409,26 @@ __device__ __forceinline__ void center_batch(const GFile &fv, const MapParams &m
     }
 }
 
-__global__ __launch_bounds__(kWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
+__global__ __launch_bounds__(kCenterWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                 const FileView *__restrict__ files, int nfiles,
                                                 MapParams mp, int W, const double *__restrict__ inv_,
                                                 const uint32_t *__restrict__ order,
                                                 const uint32_t *__restrict__ counters,
                                                 const u32x4 *__restrict__ ranges, double *hist, unsigned long long *dbg) {
     __shared__ double s_inv[kInvLds];
-    __shared__ CenterEntry s_list[kWG];                       // 64 compacted candidates per wave
+    __shared__ CenterEntry s_list[kCenterWG];                 // 64 compacted candidates per wave
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
     // the grid spans the list capacity: heavy entries at the front, light ones at the back, nothing in between --
     // two thirds of the workgroups have no slot to serve and leave before they fill the table
     const uint32_t cap = kCenterCap * (uint32_t)nchunks;
     const uint32_t n_heavy = counters[0], n_light = counters[1];
     {
-        const uint32_t first = blockIdx.x * (uint32_t)(kWG / 64), last = first + (uint32_t)(kWG / 64) - 1u;
+        const uint32_t first = blockIdx.x * (uint32_t)(kCenterWG / 64), last = first + (uint32_t)(kCenterWG / 64) - 1u;
         if (first >= cap || !(first < n_heavy || last >= cap - n_light)) return;   // uniform over the workgroup
     }
-    for (int i = threadIdx.x; i < kInvLds; i += kWG) s_inv[i] = inv[i]; // host-computed IEEE quotients 1.0/m
+    for (int i = threadIdx.x; i < kInvLds; i += kCenterWG) s_inv[i] = inv[i]; // host-computed IEEE quotients 1.0/m
     __syncthreads();
-    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kWG + threadIdx.x) >> 6));
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kCenterWG + threadIdx.x) >> 6));
     if (slot >= cap) return;
     const uint32_t entry = order[slot];
     if (!(slot < n_heavy || slot >= cap - n_light)) return;

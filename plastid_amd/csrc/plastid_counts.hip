@@ -1754,7 +1754,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 HIP_TRY(hipMemsetAsync(d_dbg.p, 0, (size_t)(2 * kCenterCap * nchunks) * 8, st));
             }
             unsigned long long *dbg = dbg_on ? d_dbg.p : nullptr;
-            hipLaunchKernelGGL(k_center, dim3((unsigned)((kCenterCap * nchunks + 3) / 4)), dim3(kWG), 0, st, p->d_cchunks.p, nchunks,
+            const int64_t cwaves = kCenterWG / 64;
+            hipLaunchKernelGGL(k_center, dim3((unsigned)((kCenterCap * nchunks + cwaves - 1) / cwaves)), dim3(kCenterWG), 0, st, p->d_cchunks.p, nchunks,
                                e->d_files.p, nfiles, mp, W, e->d_inv.p, p->d_corder.p, e->d_counters.p, p->d_cranges.p,
                                (double *)p->d_hist.p, dbg);
             if (dbg_on) {
@@ -1776,6 +1777,19 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 std::sort(byd.rbegin(), byd.rend());
                 fprintf(stderr, "[center] W %d: %zu waves, launch span %llu ticks (100 MHz: %.3f ms), summed wave time %llu ticks = %.1f x the span\n", W, nw, t1 - t0,
                         (t1 - t0) / 1e5, sum, (double)sum / (double)std::max<unsigned long long>(t1 - t0, 1));
+                {   // resident waves over the launch, in twenty slices of its span
+                    const int nb = 20;
+                    std::vector<double> occ(nb, 0.0);
+                    const double span = (double)std::max<unsigned long long>(t1 - t0, 1);
+                    for (size_t i = 0; i < h.size() / 2; ++i)
+                        if (h[2 * i]) {
+                            const double a = (double)(h[2 * i + 1] - t0) / span * nb, b = (double)(h[2 * i + 1] + h[2 * i] - t0) / span * nb;
+                            for (int k = std::max(0, (int)a); k < nb && k < b; ++k) occ[(size_t)k] += std::min(b, k + 1.0) - std::max(a, (double)k);
+                        }
+                    fprintf(stderr, "[center] resident waves per twentieth of the launch:");
+                    for (int k = 0; k < nb; ++k) fprintf(stderr, " %.0f", occ[(size_t)k]);
+                    fprintf(stderr, "\n");
+                }
                 for (size_t k = 0; k < std::min<size_t>(byd.size(), 12); ++k) {
                     const size_t i = byd[k].second;
                     const uint32_t en = h_order[i], ci = en & ((1u << kSubShift) - 1u);
