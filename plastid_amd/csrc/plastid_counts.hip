@@ -631,6 +631,30 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             snprintf(c.err.msg, sizeof(c.err.msg), fmt, a1, a2);
         };
         for (int64_t i = b; i < en; ++i) {
+            if (i + 8 <= en) {   // eight plain records of one contig, in order: nothing to report, fewer branches
+                const int32_t t0 = tid[i];
+                bool ok8 = t0 >= 0 && t0 < ntid && pos[i] >= 0 &&
+                           (i == 0 || tid[i - 1] < t0 || (tid[i - 1] == t0 && pos[i - 1] <= pos[i])) &&
+                           (int64_t)pos[i + 7] + 65535 <= 0x7fffffffLL;
+                int32_t prev = pos[i];
+                for (int k = 0; k < 8; ++k) {
+                    ok8 &= (tid[i + k] == t0) & (nblk[i + k] == 1) & (alen[i + k] > 0) & (pos[i + k] >= prev);
+                    prev = pos[i + k];
+                }
+                if (ok8) {
+                    int64_t emax = 0;
+                    for (int k = 0; k < 8; ++k) {
+                        const int L = alen[i + k];
+                        c.len_hist[(size_t)L] += 1;
+                        c.span_hist[(size_t)std::min(L, 1025)] += 1;
+                        emax = std::max(emax, (int64_t)pos[i + k] + L);
+                    }
+                    c.tid_count[(size_t)t0 + 1] += 8;
+                    c.tid_end[(size_t)t0] = std::max(c.tid_end[(size_t)t0], emax);
+                    i += 7;
+                    continue;
+                }
+            }
             if (tid[i] < 0 || tid[i] >= ntid) { bad(i, PC_ERR_ARG, "record %lld: tid %lld out of range", i, tid[i]); return; }
             if (pos[i] < 0) { bad(i, PC_ERR_ARG, "record %lld: negative position", i, 0); return; }
             if (i > 0 && (tid[i] < tid[i - 1] || (tid[i] == tid[i - 1] && pos[i] < pos[i - 1]))) {
@@ -782,7 +806,29 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 int64_t b, en;
                 unit_range(sl, (int)t, b, en);
                 int64_t cursor = c.cursor, run_at = c.run_at;
+                // Eight records at a time when all eight are plain (one aligned run, ordinary length, span within the
+                // halo): then span = L, nothing goes to a side list or the run stream, and the loop has no branches.
+                const int plain_max = std::min(wcap, kStreamMaxLen);
+                int pl_min = 65536, pl_max = 0;
                 for (int64_t i = b; i < en; ++i) {
+                    if (i + 8 <= en) {
+                        bool plain = true;
+                        int lo8 = 65536, hi8 = 0;
+                        for (int k = 0; k < 8; ++k) {
+                            const int Lk = alen[i + k];
+                            plain &= (nblk[i + k] == 1);
+                            lo8 = std::min(lo8, Lk); hi8 = std::max(hi8, Lk);
+                        }
+                        if (plain && lo8 > 0 && hi8 <= plain_max) {
+                            const size_t j0 = (size_t)(i - s0);
+                            for (int k = 0; k < 8; ++k)
+                                sb.rec[j0 + k] = make_uint2((uint32_t)pos[i + k], (uint32_t)alen[i + k] | (1u << 24) |
+                                                            ((uint32_t)(flags[i + k] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16));
+                            pl_min = std::min(pl_min, lo8); pl_max = std::max(pl_max, hi8);
+                            i += 7;
+                            continue;
+                        }
+                    }
                     const int L = alen[i], nb = nblk[i];
                     uint32_t boff = 0u;
                     int64_t end;
@@ -834,6 +880,11 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                     }
                     const size_t j = (size_t)(i - s0);
                     sb.rec[j] = make_uint2((uint32_t)pos[i], meta);
+                }
+                if (pl_max > 0) {   // what the plain blocks contribute to the unit's statistics
+                    c.max_span = std::max<int64_t>(c.max_span, pl_max);
+                    c.W = std::max(c.W, pl_max);
+                    c.smin = std::min(c.smin, pl_min); c.smax = std::max(c.smax, pl_max);
                 }
             }
         });
