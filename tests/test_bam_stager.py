@@ -306,3 +306,42 @@ def test_damaged_index_is_rejected_not_crashed(tmp_path):
         except (ValueError, OSError):
             outcomes["rejected"] += 1
     assert outcomes["rejected"] > 20 and outcomes["ok"] + outcomes["rejected"] == 120
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chunk_chaining_under_random_geometry(tmp_path, monkeypatch, seed):
+    """Whole-file loads guess a record boundary per chunk of BGZF members and chain the chunks: random member
+    sizes, chunk sizes and kept-head sizes over records with sequences, every CIGAR operation, long names
+    (records from 40 bytes to several KB, so that records straddle several chunks and heads) must always give
+    the arrays of the packed expectation."""
+    rng = np.random.default_rng(900 + seed)
+    refs, lens = ["chrA", "chrB", "chrC"], [400000, 300000, 200000]
+    recs = []
+    for tid in range(3):
+        pos = 0
+        for _ in range(int(rng.integers(150, 400))):
+            pos += int(rng.integers(0, 400))
+            cig = []
+            if rng.random() < 0.2:
+                cig.append((4, int(rng.integers(1, 20))))                   # soft clip
+            nrun = 1 if rng.random() < 0.7 else int(rng.integers(2, 6))
+            for k in range(nrun):
+                cig.append((int(rng.choice([0, 7, 8])), int(rng.integers(1, 120 if rng.random() < 0.9 else 3000))))
+                if k + 1 < nrun:
+                    cig.append((int(rng.choice([2, 3, 1])), int(rng.integers(1, 500))))
+            if rng.random() < 0.1:
+                cig.append((5, 3))                                          # hard clip
+            recs.append((tid, pos, cig, int(rng.choice([0, 16]))))
+    recs += [(-1, -1, [], 4)] * int(rng.integers(0, 4))
+    path = str(tmp_path / "g.bam")
+    placed = [r for r in recs if r[0] >= 0]
+    exp = PackedAlignments.from_cigars([r[0] for r in placed], [r[1] for r in placed], [r[2] for r in placed],
+                                       [bool(r[3] & 16) for r in placed], references=refs, lengths=lens)
+    for trial in range(6):
+        bam_writer.write_bam(path, refs, lens, recs, block_bytes=int(rng.choice([40, 333, 2000, 60000])))
+        monkeypatch.setenv("PB_CHUNK", str(int(rng.choice([1, 100, 5000, 1 << 20]))))
+        monkeypatch.setenv("PB_HEAD", str(int(rng.choice([0, 16, 300, 32768]))))
+        got = read_bam(path, threads=int(rng.integers(1, 5)))
+        for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
+            assert np.array_equal(getattr(got, name), getattr(exp, name)), (name, seed, trial)
+        assert got.mapped == len(placed)
