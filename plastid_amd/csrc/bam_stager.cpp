@@ -149,7 +149,11 @@ struct Cols {
     std::vector<int32_t> tid, pos, blk_start, blk_len;
     std::vector<uint16_t> alen;
     std::vector<uint8_t> flags, nblk;
-    void clear() { tid.clear(); pos.clear(); blk_start.clear(); blk_len.clear(); alen.clear(); flags.clear(); nblk.clear(); }
+    size_t n = 0;   // records held: the five per-record columns are sized for the piece up front and written by index
+    void clear() { n = 0; blk_start.clear(); blk_len.clear(); }
+    void room(size_t records) {
+        if (tid.size() < records) { tid.resize(records); pos.resize(records); alen.resize(records); flags.resize(records); nblk.resize(records); }
+    }
 };
 
 struct Bam {
@@ -341,6 +345,7 @@ int parse_header(Bam &bam, const uint8_t *&p, const uint8_t *end, uint32_t &n_re
 const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint8_t *q, const uint8_t *limit, uint32_t n_ref, int64_t max_rec) {
     std::vector<std::pair<int32_t, int32_t>> runs;
     cols.clear();
+    cols.room(limit > q ? (size_t)(limit - q) / 36 + 1 : 1);   // a record takes at least 36 bytes
     auto bad = [&](int64_t i, bool before_order, const std::string &m) {
         pt.err_rec = i; pt.err_before_order = before_order; pt.err = m;
         return q;
@@ -371,9 +376,25 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         } else if (pt.saw_unplaced || tid < pt.last_tid || (tid == pt.last_tid && pos < pt.last_pos)) {
             return bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
         }
-        const bool first = cols.tid.empty();
+        const bool first = cols.n == 0;
         if ((size_t)32 + l_read_name + (size_t)n_cigar * 4 > block_size) return bad(i, false, "corrupt BAM record (cigar overruns block)");
         const uint8_t *cig = r + 32 + l_read_name;
+        if (n_cigar == 1) {   // the common record: one M / = / X operation (one aligned run starting at pos)
+            const uint32_t v = rd32(cig), op = v & 0xf, len = v >> 4;
+            if ((op == 0 || op == 7 || op == 8) && len > 0 && len <= 65535) {
+                if (first) pt.first_spos = pos;
+                else if (pt.last_tid == tid && pt.last_spos > pos)
+                    return bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
+                pt.last_tid = tid; pt.last_pos = pos; pt.last_spos = pos;
+                const size_t at = cols.n++;
+                cols.tid[at] = tid;
+                cols.pos[at] = pos;
+                cols.alen[at] = (uint16_t)len;
+                cols.flags[at] = (flag & 0x10) ? 1 : 0;
+                cols.nblk[at] = 1;
+                continue;
+            }
+        }
         runs.clear();
         int64_t ref = pos, L = 0;
         for (uint16_t c = 0; c < n_cigar; ++c) {
@@ -406,11 +427,12 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         else if (pt.last_tid == tid && pt.last_spos > spos)
             return bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
         pt.last_tid = tid; pt.last_pos = pos; pt.last_spos = spos;
-        cols.tid.push_back(tid);
-        cols.pos.push_back(spos);
-        cols.alen.push_back((uint16_t)L);
-        cols.flags.push_back((flag & 0x10) ? 1 : 0);
-        cols.nblk.push_back((uint8_t)runs.size());
+        const size_t at = cols.n++;
+        cols.tid[at] = tid;
+        cols.pos[at] = spos;
+        cols.alen[at] = (uint16_t)L;
+        cols.flags[at] = (flag & 0x10) ? 1 : 0;
+        cols.nblk[at] = (uint8_t)runs.size();
         if (runs.size() >= 2)
             for (auto &x : runs) {
                 cols.blk_start.push_back(x.first);
@@ -424,7 +446,7 @@ const uint8_t *decode_span(Bam &bam, Part &pt, const uint8_t *q, const uint8_t *
     thread_local Cols cols;
     const uint8_t *stop = decode_span_cols(bam, pt, cols, q, limit, n_ref, max_rec);
     // the finished columns, at their exact size, into the load's arena
-    const size_t n = cols.tid.size(), m = cols.blk_start.size();
+    const size_t n = cols.n, m = cols.blk_start.size();
     if (n) {
         uint8_t *mem = (uint8_t *)bam.arena.alloc(n * 12 + 64 * 5 + m * 8 + 64 * 2);
         if (!mem) {
