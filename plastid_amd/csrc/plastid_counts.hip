@@ -754,6 +754,11 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 int64_t b, en, r = 0, rs = 0;
                 unit_range(u / T, (int)(u % T), b, en);
                 for (int64_t i = b; i < en; ++i) {
+                    if (i + 8 <= en) {   // eight single-run records hold no run to place
+                        uint64_t eight;
+                        std::memcpy(&eight, nblk + i, 8);
+                        if (((eight & 0xfefefefefefefefeull) == 0)) { i += 7; continue; }   // every count is 0 or 1
+                    }
                     r += nblk[i] >= 2 ? nblk[i] : 0;
                     rs += (nblk[i] >= 2 && alen[i] <= kStreamMaxLen) ? nblk[i] : 0;   // runs that go to the run stream
                 }
