@@ -333,3 +333,13 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
     assert len(own) >= 30
     bad = [n for n, s in own if s != 0]
     assert not bad, "kernels using scratch memory: %s" % bad
+
+
+def test_usable_cpus_respects_the_container_limits():
+    """bench.py sizes its thread pools (and reports `cpu_baseline.usable_cores`) by what the process may use:
+    hardware threads, affinity mask and the cgroup CPU quota -- the GPU boxes show 256 threads and grant 16."""
+    import bench
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
