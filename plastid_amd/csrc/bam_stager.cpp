@@ -346,58 +346,72 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
     std::vector<std::pair<int32_t, int32_t>> runs;
     cols.clear();
     cols.room(limit > q ? (size_t)(limit - q) / 36 + 1 : 1);   // a record takes at least 36 bytes
+    // the state every record touches lives in locals (the columns are int32 / uint8 arrays: through `pt` and `cols`
+    // the compiler has to assume that every store may change them) and is written back on the way out
+    int32_t *const c_tid = cols.tid.data(), *const c_pos = cols.pos.data();
+    uint16_t *const c_alen = cols.alen.data();
+    uint8_t *const c_flags = cols.flags.data(), *const c_nblk = cols.nblk.data();
+    size_t n = 0;
+    int64_t total = pt.total, mapped = pt.mapped, unplaced = pt.unplaced;
+    bool any_placed = pt.any_placed, saw_unplaced = pt.saw_unplaced;
+    int32_t last_tid = pt.last_tid, last_pos = pt.last_pos, last_spos = pt.last_spos;
+    const uint8_t *ret = nullptr;
     auto bad = [&](int64_t i, bool before_order, const std::string &m) {
         pt.err_rec = i; pt.err_before_order = before_order; pt.err = m;
         return q;
     };
     for (int64_t i = 0; i < max_rec; ++i) {
-        if (limit - q < 4) return q;
+        if (limit - q < 4) break;
         const uint32_t block_size = rd32(q);
-        if (block_size < 32) { pt.bad_size = true; return q; }
-        if ((size_t)(limit - q - 4) < block_size) return q;
+        if (block_size < 32) { pt.bad_size = true; break; }
+        if ((size_t)(limit - q - 4) < block_size) break;
         const uint8_t *r = q + 4;
         q = r + block_size;
         const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
         const uint8_t l_read_name = r[8];
         const uint16_t n_cigar = rd16(r + 12), flag = rd16(r + 14);
-        pt.total += 1;
-        if (!(flag & 0x4)) pt.mapped += 1;
+        total += 1;
+        if (!(flag & 0x4)) mapped += 1;
         if (tid < 0) { // unplaced reads sit at the end of a sorted BAM; fetch() never returns them
-            pt.unplaced += 1;
-            pt.saw_unplaced = true;
+            unplaced += 1;
+            saw_unplaced = true;
             continue;
         }
-        if (tid >= (int32_t)n_ref) return bad(i, true, "BAM record with reference id out of range");
-        if (!pt.any_placed) {     // its order against the previous piece is checked when stitching
-            pt.any_placed = true;
+        if (tid >= (int32_t)n_ref) { ret = bad(i, true, "BAM record with reference id out of range"); break; }
+        if (!any_placed) {        // its order against the previous piece is checked when stitching
+            any_placed = true;
             pt.first_placed_rec = i;
             pt.first_tid = tid; pt.first_pos = pos;
-            if (pt.saw_unplaced) return bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
-        } else if (pt.saw_unplaced || tid < pt.last_tid || (tid == pt.last_tid && pos < pt.last_pos)) {
-            return bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
+            if (saw_unplaced) { ret = bad(i, false, "BAM file is not coordinate sorted: " + bam.path); break; }
+        } else if (saw_unplaced || tid < last_tid || (tid == last_tid && pos < last_pos)) {
+            ret = bad(i, false, "BAM file is not coordinate sorted: " + bam.path);
+            break;
         }
-        const bool first = cols.n == 0;
-        if ((size_t)32 + l_read_name + (size_t)n_cigar * 4 > block_size) return bad(i, false, "corrupt BAM record (cigar overruns block)");
+        const bool first = n == 0;
+        if ((size_t)32 + l_read_name + (size_t)n_cigar * 4 > block_size) { ret = bad(i, false, "corrupt BAM record (cigar overruns block)"); break; }
         const uint8_t *cig = r + 32 + l_read_name;
         if (n_cigar == 1) {   // the common record: one M / = / X operation (one aligned run starting at pos)
             const uint32_t v = rd32(cig), op = v & 0xf, len = v >> 4;
             if ((op == 0 || op == 7 || op == 8) && len > 0 && len <= 65535) {
                 if (first) pt.first_spos = pos;
-                else if (pt.last_tid == tid && pt.last_spos > pos)
-                    return bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
-                pt.last_tid = tid; pt.last_pos = pos; pt.last_spos = pos;
-                const size_t at = cols.n++;
-                cols.tid[at] = tid;
-                cols.pos[at] = pos;
-                cols.alen[at] = (uint16_t)len;
-                cols.flags[at] = (flag & 0x10) ? 1 : 0;
-                cols.nblk[at] = 1;
+                else if (last_tid == tid && last_spos > pos) {
+                    ret = bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
+                    break;
+                }
+                last_tid = tid; last_pos = pos; last_spos = pos;
+                c_tid[n] = tid;
+                c_pos[n] = pos;
+                c_alen[n] = (uint16_t)len;
+                c_flags[n] = (flag & 0x10) ? 1 : 0;
+                c_nblk[n] = 1;
+                ++n;
                 continue;
             }
         }
         runs.clear();
         int64_t ref = pos, L = 0;
-        for (uint16_t c = 0; c < n_cigar; ++c) {
+        bool unknown_op = false;
+        for (uint16_t c = 0; c < n_cigar && !unknown_op; ++c) {
             const uint32_t v = rd32(cig + 4 * c);
             const uint32_t op = v & 0xf, len = v >> 4;
             switch (op) {
@@ -415,31 +429,39 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
             case 1: case 4: case 5: case 6: // I S H P
                 break;
             default:
-                return bad(i, false, "unknown CIGAR operation in " + bam.path);
+                unknown_op = true;
+                break;
             }
         }
-        if (L > 65535) return bad(i, false, "alignment with more than 65535 aligned positions is not supported");
-        if (runs.size() > 255) return bad(i, false, "alignment with more than 255 aligned runs is not supported");
+        if (unknown_op) { ret = bad(i, false, "unknown CIGAR operation in " + bam.path); break; }
+        if (L > 65535) { ret = bad(i, false, "alignment with more than 65535 aligned positions is not supported"); break; }
+        if (runs.size() > 255) { ret = bad(i, false, "alignment with more than 255 aligned runs is not supported"); break; }
         // the packed format keys a record on its first aligned position; a CIGAR that opens with
         // D/N (not produced by aligners) is accepted only if that keeps the file order
         const int32_t spos = runs.empty() ? pos : runs[0].first;
         if (first) pt.first_spos = spos;
-        else if (pt.last_tid == tid && pt.last_spos > spos)
-            return bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
-        pt.last_tid = tid; pt.last_pos = pos; pt.last_spos = spos;
-        const size_t at = cols.n++;
-        cols.tid[at] = tid;
-        cols.pos[at] = spos;
-        cols.alen[at] = (uint16_t)L;
-        cols.flags[at] = (flag & 0x10) ? 1 : 0;
-        cols.nblk[at] = (uint8_t)runs.size();
+        else if (last_tid == tid && last_spos > spos) {
+            ret = bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
+            break;
+        }
+        last_tid = tid; last_pos = pos; last_spos = spos;
+        c_tid[n] = tid;
+        c_pos[n] = spos;
+        c_alen[n] = (uint16_t)L;
+        c_flags[n] = (flag & 0x10) ? 1 : 0;
+        c_nblk[n] = (uint8_t)runs.size();
+        ++n;
         if (runs.size() >= 2)
             for (auto &x : runs) {
                 cols.blk_start.push_back(x.first);
                 cols.blk_len.push_back(x.second);
             }
     }
-    return q;
+    cols.n = n;
+    pt.total = total; pt.mapped = mapped; pt.unplaced = unplaced;
+    pt.any_placed = any_placed; pt.saw_unplaced = saw_unplaced;
+    pt.last_tid = last_tid; pt.last_pos = last_pos; pt.last_spos = last_spos;
+    return ret ? ret : q;
 }
 
 const uint8_t *decode_span(Bam &bam, Part &pt, const uint8_t *q, const uint8_t *limit, uint32_t n_ref, int64_t max_rec) {
