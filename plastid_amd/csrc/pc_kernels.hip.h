@@ -19,7 +19,8 @@
 //   k_hist_point    FivePrime/ThreePrime/Variable/Stratified + filters + get_counts layout
 //                                                                         (:308-367,:407-466,:585-650,:724-780)
 //   k_gather_split  lays out windows that were split into several work items
-//   k_center_weigh / k_center_order / k_center   CenterMapFactory, ordered float64 replay (:200-265)
+//   k_cs_count / k_cs_scatter   center streams: the aligned runs of the reads a strand selection keeps, record order
+//   k_center_vals / k_center_weigh / k_center_order / k_center   CenterMapFactory, ordered float64 replay (:200-265)
 //   k_gather        SegmentChain.get_counts layout + normalisation for the center rule
 //                                                                         (roitools.pyx:3259-3271, genome_array.py:826-830)
 //   k_rle_*         run-length encoding of an output vector (export, genome_array.py:990-1111)
@@ -114,6 +115,10 @@ struct FileView {
     const int4 *xlong_runs;
     const uint32_t *xllin_tab;
     const uint32_t *xplin_tab;
+    // center streams (see k_center): entries and entries-before-record per strand selection (forward / reverse / all reads)
+    const uint2 *cs_ent[3];
+    const uint32_t *cs_soff[3];
+    int32_t c_lbase;                // first aligned length of the center rule's SGPR value table
     int64_t n;
     int64_t nlong;
     int64_t ngap;
@@ -156,6 +161,7 @@ struct GFile {
     const i32x4 PC_GLOBAL *xlong_runs;
     const uint32_t PC_GLOBAL *xllin_tab;
     const uint32_t PC_GLOBAL *xplin_tab;
+    int32_t c_lbase;
     int64_t n;
     int64_t nlong;
     int64_t ngap;
@@ -190,6 +196,7 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.xlong_runs = (const i32x4 PC_GLOBAL *)v.xlong_runs;
     g.xllin_tab = (const uint32_t PC_GLOBAL *)v.xllin_tab;
     g.xplin_tab = (const uint32_t PC_GLOBAL *)v.xplin_tab;
+    g.c_lbase = v.c_lbase;   // (the center streams are picked by a run-time index: read from the FileView in memory, cs_stream)
     g.n = v.n;
     g.nlong = v.nlong;
     g.ngap = v.ngap;
@@ -1204,6 +1211,16 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
 // part of the contract (the reference's own test demands exact equality), so
 // there are no atomics: one lane owns one output position and replays, in record
 // order, every read that can cover it.  One wave per chunk of <= 64 positions.
+//
+// Round 3: the candidates come from a CENTER STREAM (below) -- one 8-byte entry per aligned run of every read a
+// strand mode keeps, in record order, host-excluded reads left out -- so a wave never filters or compacts: a batch of
+// 64 entries arrives with one coalesced load (lane j holds entry j), every lane derives the covered interval of its
+// entry, and entry j is then broadcast with two v_readlane.  1/m comes from a 16-entry table held in SGPRs
+// (s_movrels_b64), the covering test of four entries is computed ahead into SGPR pairs (v_cmp), and the ordered
+// accumulation is  s_mov_b64 exec, mask ; v_add_f64 acc, acc, 1/m  -- lanes outside the mask keep their sum, which is
+// the reference's conditional add bit for bit.  No LDS at all (round 2's kernel spent 80 % of the launch on one
+// 16-byte LDS broadcast read per entry and wave), 5 vector + 3 scalar instructions per entry (scripts/ubench/
+// scalar_stream_probe.hip: 23 SIMD-cycles per entry at full occupancy, 45 for a wave that runs alone).
 
 // wave-uniform value of lane `j` of a per-lane register (j uniform)
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
@@ -1213,15 +1230,66 @@ __device__ __forceinline__ double lane_f64(double v, int j) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-#ifndef PC_CENTER_WG
-#define PC_CENTER_WG 64
-#endif
 // Workgroup of the center kernel: ONE wave.  The waves of a launch are independent (one chunk each) and very
-// unequal; in a four-wave workgroup the LDS and the wave slots of the finished ones stay taken until the last one
-// is done, and a new workgroup needs four free slots at once: PC_CENTER_DEBUG showed ~4 200 of 6 144 possible
-// waves resident through the launch.
-constexpr int kCenterWG = PC_CENTER_WG;
-constexpr int kInvLds = 256; // 1/m table kept in LDS for m < kInvLds (2 KiB per workgroup; longer map lengths read the global table)
+// unequal; in a four-wave workgroup the wave slots of the finished ones stay taken until the last one is done.
+constexpr int kCenterWG = 64;
+
+// Center stream of a staged file and a strand selection (0: forward reads, 1: reverse reads, 2: all reads), built
+// on the GPU at the first center-rule count of the file and again when the host-side filters change:
+//   cs_ent[k] = {x, y}: x = first position of an aligned run; y = run length | read index of the run's first base << 8
+//               | aligned length L of the read << 16 | flags << 24.  A read contributes its runs consecutively, reads in
+//               record order; reads the selection drops, host-excluded reads and reads without aligned bases have no
+//               entry.  flags bit 0 (kCsIndirect): the read does not fit the 8-bit fields (L > 255) -- one entry,
+//               x = its record index.
+//   cs_soff[i] = entries before record i (cs_soff[n] = all): turns a record range into an entry range.
+constexpr uint32_t kCsIndirect = 1u;
+constexpr int kCTab = 16;   // aligned lengths [c_lbase, c_lbase + kCTab) have their 1/m in the SGPR table; others take a slower path
+
+__device__ __forceinline__ uint32_t cs_entries_of(uint32_t meta, int sel) {
+    const uint32_t fl = rec_flags(meta);
+    if ((fl & kFlagExcluded) || rec_len(meta) == 0) return 0u;
+    if (sel < 2 && (int)(fl & kFlagReverse) != sel) return 0u;
+    return rec_len(meta) > 255 ? 1u : (uint32_t)(rec_nblk(meta) >= 2 ? rec_nblk(meta) : 1);
+}
+
+__global__ __launch_bounds__(kWG) void k_cs_count(const uint2 *__restrict__ rec, int64_t n, int sel, uint32_t *cnt) {
+    const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (i > n) return;
+    cnt[i] = i < n ? cs_entries_of(rec[i].y, sel) : 0u;   // entry n: the exclusive sum then ends with the total
+}
+
+__global__ __launch_bounds__(kWG) void k_cs_scatter(const uint2 *__restrict__ rec, const uint32_t *__restrict__ blk_off,
+                                                    const int2 *__restrict__ blk, int64_t n, int sel,
+                                                    const uint32_t *__restrict__ soff, uint2 *ent) {
+    const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= n) {   // padding behind the last entry: entries that cover nothing (whole batches can always be loaded)
+        if (i < n + 64) ent[(int64_t)soff[n] + (i - n)] = make_uint2(0x7fffffffu, 0u);
+        return;
+    }
+    const uint2 r = rec[i];
+    const uint32_t k = cs_entries_of(r.y, sel);
+    if (k == 0u) return;
+    uint2 *dst = ent + soff[i];
+    const uint32_t L = (uint32_t)rec_len(r.y);
+    if (L > 255u) { dst[0] = make_uint2((uint32_t)i, kCsIndirect << 24); return; }
+    if (rec_nblk(r.y) < 2) { dst[0] = make_uint2(r.x, L | (L << 16)); return; }
+    const int2 *b = blk + blk_off[i];
+    uint32_t cum = 0;
+    for (uint32_t q = 0; q < k; ++q) {
+        const int2 run = b[q];
+        dst[q] = make_uint2((uint32_t)run.x, (uint32_t)run.y | (cum << 8) | (L << 16));
+        cum += (uint32_t)run.y;
+    }
+}
+
+// 1.0 / map_length for the lengths of every file's SGPR table (0.0 where the read is not counted: size filter,
+// map length <= 0 -- adding +0.0 never changes a sum that starts at +0.0 and only grows)
+__global__ void k_center_vals(const FileView *__restrict__ files, int nfiles, MapParams mp, const double *__restrict__ inv, double *cval) {
+    const int t = (int)threadIdx.x;
+    if (t >= nfiles * kCTab) return;
+    const int L = files[t / kCTab].c_lbase + t % kCTab, m = L - 2 * mp.param;
+    cval[t] = (m > 0 && m < 65536 && size_ok(mp, L)) ? inv[m] : 0.0;
+}
 
 // Dispatch list of the center kernel.  A chunk's replay is sequential in the reads that overlap
 // it (the order is the contract), so its time is proportional to that count, and expression is
@@ -1236,17 +1304,24 @@ constexpr int kInvLds = 256; // 1/m table kept in LDS for m < kInvLds (2 KiB per
 // Entry = chunk index | code << 27: 0 whole chunk, 1..4 quarter, 5..12 eighth.
 constexpr int kSubShift = 27;
 constexpr uint32_t kCenterCap = 3u;   // dispatch-list slots per chunk: front entries < (8/k1 + 1/8) x chunks by Markov, the rest from the back
-constexpr int64_t kCenterSearchFrom = 1024; // candidate count from which a whole chunk searches its exact first record
-// One candidate read of the center kernel, ready to replay: the (at most two) runs of covered
-// positions [a0, a0+m0) and [a1, a1+m1) after trimming `nibble` from both ends, and 1/m.
-// m0 < 0: a read with three or more aligned runs -- `a0` names the lane that holds its header.
-struct __attribute__((aligned(16))) CenterEntry { int32_t a0, m0, a1, m1; double val; int32_t pad0, pad1; };
-struct __attribute__((aligned(16))) CenterPlain { int32_t a0, m0; double val; }; // single-run reads only
-// pass 1 (one THREAD per chunk): the record range and the long-span candidate range every file
-// offers the chunk -- all the dependent index lookups happen here, once, instead of at the head of
-// every wave of k_center -- plus the candidate count and its sum (counters[2..3] as one 64-bit value).
-// Ranges are rounded outwards to index buckets and cover every sub-chunk of the chunk; k_center's own
-// tests are exact.
+
+__device__ __forceinline__ int center_sel(int mode) { return mode < 2 ? mode : 2; }
+// (indexed in memory: a run-time index into a register copy of the view would put that copy into scratch)
+__device__ __forceinline__ const u32x2 PC_GLOBAL *cs_stream(const FileView *f, int sel) { return (const u32x2 PC_GLOBAL *)f->cs_ent[sel]; }
+__device__ __forceinline__ const uint32_t PC_GLOBAL *cs_offsets(const FileView *f, int sel) { return (const uint32_t PC_GLOBAL *)f->cs_soff[sel]; }
+
+// pass 1 (one THREAD per chunk): per file the EXACT record range of the chunk's near window -- first record that
+// starts at or after start - W + 1, first record that starts at or after the chunk's end (index bucket, then a
+// bisection inside it) -- and the candidate range of the long-span list; all the dependent index lookups happen
+// here, once, instead of at the head of every wave of k_center.  The candidate count (stream entries of the near
+// window) and its sum (counters[2..3] as one 64-bit value) feed the dispatch order.
+__device__ __forceinline__ int64_t bucket_lower_bound(const GFile &fv, int64_t q0, int64_t nb, int64_t key) {
+    int64_t b = key <= 0 ? 0 : (key >> kLinShift);
+    if (b > nb) b = nb;
+    const int64_t b1 = b + 1 > nb ? nb : b + 1;
+    return lower_bound_pos(fv.rec, fv.lin_tab[q0 + b], fv.lin_tab[q0 + b1], key);
+}
+
 __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                             const FileView *__restrict__ files, int nfiles, int W,
                                                             uint32_t *cand_out, u32x4 *ranges, unsigned long long *total) {
@@ -1259,8 +1334,9 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
             const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
             const int64_t cend = (int64_t)ck.start + ck.len;
             u32x4 rg;
-            rg.x = (uint32_t)lin_floor(fv.lin_tab, q0, nb, (int64_t)ck.start - W + 1);
-            rg.y = (uint32_t)lin_floor(fv.lin_tab, q0, nb, cend + (1 << kLinShift) - 1);
+            rg.x = (uint32_t)bucket_lower_bound(fv, q0, nb, (int64_t)ck.start - W + 1);
+            rg.y = (uint32_t)bucket_lower_bound(fv, q0, nb, cend);
+            if (rg.y < rg.x) rg.y = rg.x;
             rg.z = rg.w = 0u;
             if (fv.nlong) { // they start before the near window of some position of the chunk, and the
                             // running maximum of the ends has passed the chunk start
@@ -1269,7 +1345,8 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
                 if (rg.z > rg.w) rg.z = rg.w;
             }
             ranges[c * nfiles + f] = rg;
-            cand += rg.y - rg.x;
+            const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, center_sel(ck.mode));
+            cand += soff[rg.y] - soff[rg.x];
         }
         cand_out[c] = (uint32_t)(cand > 0xffffffffull ? 0xffffffffull : cand);
     }
@@ -1280,15 +1357,15 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
 // pass 2: cut and queue
 __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__restrict__ cand_in, int64_t nchunks,
                                                             const unsigned long long *__restrict__ total,
-                                                            int64_t floor_thr, int k1, int k2, uint32_t *order,
-                                                            uint32_t *counters) {
+                                                            int64_t floor_thr, int64_t floor_whole, int k1, int k2,
+                                                            uint32_t *order, uint32_t *counters) {
     __shared__ uint32_t s_wave[kRangesWG / 64];
     __shared__ uint32_t s_base[2];
     const int64_t c = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
     const bool live = c < nchunks;
     const int64_t mean = (int64_t)(*total / (unsigned long long)(nchunks > 0 ? nchunks : 1));
     const int64_t t1 = k1 * mean > floor_thr ? k1 * mean : floor_thr, t2 = k2 * t1; // k1 >= 8 (capacity, see above)
-    const int64_t th_whole = 8 * mean > floor_thr ? 8 * mean : floor_thr;           // starts early, but stays whole
+    const int64_t th_whole = 8 * mean > floor_whole ? 8 * mean : floor_whole;       // starts early, but stays whole
     const int64_t cand = live ? (int64_t)cand_in[c] : 0;
     // entries a chunk puts at the FRONT of the list: 8 / 4 sub-chunks, 1 = the whole chunk (heavy but
     // below the cut threshold: cutting multiplies the work -- eight sub-chunks scan 8 x (8 + L)
@@ -1315,125 +1392,121 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
     }
 }
 
-// One batch of up to 64 candidate reads (lane j holds candidate j's header, in record order):
-// filter, fetch the first two aligned runs of the gapped ones (all lanes at once -- not one
-// dependent load chain per read), compact the reads that can touch the chunk into the wave's LDS
-// list, then let every lane walk the list with broadcast reads, four entries in flight.  The
-// ordered float64 accumulation is a plain dependent v_add_f64 chain; `acc += hit ? val : 0.0`
-// equals the reference's conditional add bit for bit (x + 0.0 == x for every x this sum can hold).
-// PLAIN = no candidate of the batch has several aligned runs or a map length beyond the LDS table:
-// that instantiation contains no global load at all.  (A load anywhere in the routine, even one
-// skipped at run time, makes the compiler wait for *all* outstanding loads -- the record
-// prefetches included -- wherever its destination register is used.)
-template <bool PLAIN>
-__device__ __forceinline__ void center_batch(const GFile &fv, const MapParams &mp, const CenterChunk &ck, int32_t cend,
-                                             bool in, int32_t pos, uint32_t meta, uint32_t boff, const double *s_inv,
-                                             const double PC_GLOBAL *inv, CenterEntry *list, int lane, int32_t p,
-                                             double &acc) {
-    const int nib = mp.param;
-    const uint32_t fl = rec_flags(meta);
-    const int L = rec_len(meta), nbk = rec_nblk(meta);
+// One read replayed from its record header (wave-uniform arguments): reads that come from the long-span list, and
+// reads the 8-bit fields of a stream entry cannot describe.  CenterMapFactory.__call__, map_factories.pyx:242-256.
+__device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp, const double PC_GLOBAL *inv, int32_t pos,
+                                            uint32_t meta, uint32_t boff, int32_t p, double &acc) {
+    const int nib = mp.param, L = rec_len(meta), nbk = rec_nblk(meta);
     const int m = L - 2 * nib;                               // map_length, :245
-    bool ok = in && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse) && size_ok(mp, L) && (m > 0) &&
-              (pos < cend);
-    CenterEntry e;
-    e.a0 = pos + nib; e.m0 = m; e.a1 = 0; e.m1 = 0; e.pad0 = e.pad1 = 0;
-    if (!PLAIN) if (ok && nbk >= 2) {
-        const i32x2 b0 = fv.blk[boff], b1 = fv.blk[boff + 1];
-        if (nbk == 2) {                                      // positions with index in [nib, L - nib)
-            const int hi0 = b0.y < L - nib ? b0.y : L - nib;
-            e.a0 = b0.x + nib; e.m0 = hi0 > nib ? hi0 - nib : 0;
-            const int lo1 = nib > b0.y ? nib : b0.y;
-            e.a1 = b1.x + (lo1 - b0.y); e.m1 = L - nib > lo1 ? L - nib - lo1 : 0;
-        } else {
-            e.a0 = lane; e.m0 = -1;                          // walked run by run below
+    if (m <= 0 || !size_ok(mp, L)) return;
+    const double val = inv[m];                               // 1.0 / map_length, :250
+    bool hit;
+    if (nbk < 2) {
+        hit = (uint32_t)(p - (pos + nib)) < (uint32_t)m;
+    } else {                                                 // positions with read index in [nib, L - nib)
+        hit = false;
+        int cum = 0;
+        for (int q = 0; q < nbk; ++q) {
+            const i32x2 run = fv.blk[boff + q];
+            const int idx = cum + (p - run.x);
+            hit |= (p >= run.x) & (p < run.x + run.y) & (idx >= nib) & (idx < L - nib);
+            cum += run.y;
         }
     }
-    // can the read touch this chunk at all?
-    if (e.m0 >= 0)
-        ok &= ((e.a0 < cend) & (e.a0 + e.m0 > ck.start)) | ((e.m1 > 0) & (e.a1 < cend) & (e.a1 + e.m1 > ck.start));
-    e.val = (ok && m < kInvLds) ? s_inv[m] : 0.0;            // 1.0 / map_length, :250
-    if (!PLAIN) if (ok && m >= kInvLds) e.val = inv[m];
-    const unsigned long long okmask = __ballot(ok);
-    const int nok = __popcll(okmask);
-    if (PLAIN) {
-        // every read of the batch is one run: 16-byte entries {start, length, 1/m}, five instructions
-        // per entry and position (a wave over a pile-up runs alone: its replay is issue-bound)
-        CenterPlain *plist = (CenterPlain *)list;
-        if (ok) plist[__popcll(okmask & ((1ull << lane) - 1ull))] = CenterPlain{e.a0, e.m0, e.val};
-        int k = 0;
-        for (; k + 4 <= nok; k += 4) {                       // four list entries in flight; adds stay in order
-            const CenterPlain e0 = plist[k], e1 = plist[k + 1], e2 = plist[k + 2], e3 = plist[k + 3];
-            acc += ((uint32_t)(p - e0.a0) < (uint32_t)e0.m0) ? e0.val : 0.0;
-            acc += ((uint32_t)(p - e1.a0) < (uint32_t)e1.m0) ? e1.val : 0.0;
-            acc += ((uint32_t)(p - e2.a0) < (uint32_t)e2.m0) ? e2.val : 0.0;
-            acc += ((uint32_t)(p - e3.a0) < (uint32_t)e3.m0) ? e3.val : 0.0;
-        }
-        for (; k < nok; ++k) {
-            const CenterPlain c = plist[k];
-            acc += ((uint32_t)(p - c.a0) < (uint32_t)c.m0) ? c.val : 0.0;
-        }
-        return;
-    }
-    if (ok) list[__popcll(okmask & ((1ull << lane) - 1ull))] = e; // rank in record order
-    // (same wave wrote and reads the list: program order, no barrier needed)
-    int k = 0;
-    if (!__any(ok && e.m0 < 0)) {                            // no read with > 2 runs in this batch
-        for (; k + 4 <= nok; k += 4) {                       // four list entries in flight; adds stay in order
-            const CenterEntry e0 = list[k], e1 = list[k + 1], e2 = list[k + 2], e3 = list[k + 3];
-            acc += (((uint32_t)(p - e0.a0) < (uint32_t)e0.m0) | ((uint32_t)(p - e0.a1) < (uint32_t)e0.m1)) ? e0.val : 0.0;
-            acc += (((uint32_t)(p - e1.a0) < (uint32_t)e1.m0) | ((uint32_t)(p - e1.a1) < (uint32_t)e1.m1)) ? e1.val : 0.0;
-            acc += (((uint32_t)(p - e2.a0) < (uint32_t)e2.m0) | ((uint32_t)(p - e2.a1) < (uint32_t)e2.m1)) ? e2.val : 0.0;
-            acc += (((uint32_t)(p - e3.a0) < (uint32_t)e3.m0) | ((uint32_t)(p - e3.a1) < (uint32_t)e3.m1)) ? e3.val : 0.0;
-        }
-    }
-    for (; k < nok; ++k) {                                   // record order; wave-uniform trip count
-        const CenterEntry c = list[k];
-        bool hit;
-        if (c.m0 >= 0) {
-            hit = ((uint32_t)(p - c.a0) < (uint32_t)c.m0) | ((uint32_t)(p - c.a1) < (uint32_t)c.m1);
-        } else {                                             // three or more runs: walk them
-            const int j = c.a0;
-            const uint32_t meta_j = lane_u32(meta, j), boff_j = lane_u32(boff, j);
-            const int L_j = rec_len(meta_j), nb_j = rec_nblk(meta_j);
-            hit = false;
-            int cum = 0;
-            for (int q = 0; q < nb_j; ++q) {
-                const i32x2 run = fv.blk[boff_j + q];
-                const int idx = cum + (p - run.x);
-                hit |= (p >= run.x) & (p < run.x + run.y) & (idx >= nib) & (idx < L_j - nib);
-                cum += run.y;
-            }
-        }
-        acc += hit ? c.val : 0.0;                            // :254, one IEEE add per covering read, in order
-    }
+    acc += hit ? val : 0.0;                                  // :254, one IEEE add per covering read, in order
 }
 
-__global__ __launch_bounds__(kCenterWG) void k_center(const CenterChunk *__restrict__ chunks, int64_t nchunks,
-                                                const FileView *__restrict__ files, int nfiles,
-                                                MapParams mp, int W, const double *__restrict__ inv_,
-                                                const uint32_t *__restrict__ order,
-                                                const uint32_t *__restrict__ counters,
-                                                const u32x4 *__restrict__ ranges, double *hist, unsigned long long *dbg) {
-    __shared__ double s_inv[kInvLds];
-    __shared__ CenterEntry s_list[kCenterWG];                 // 64 compacted candidates per wave
+// Replay of a batch.  Lanes j of vlo / vhi / vix hold entry j's 64-bit mask of covered lanes and its table index x 2.
+// Per entry: v_readlane of the index and of the two mask halves, s_mov m0 + s_movrels_b64 (1/m out of the SGPR
+// table), then  s_mov_b64 exec, mask ; v_add_f64 acc, acc, 1/m  -- 4 vector + 3 scalar instructions.  Entries go in
+// groups of four, software-pipelined: the twelve v_readlane of group g+1 are issued before the adds of group g and
+// its table look-ups between them, so that a wave that runs alone (the deepest pile-up is the launch's critical
+// path) does not wait for a VALU-written SGPR at every step (scripts/ubench/scalar_stream_probe.hip, forms Ma / Mb /
+// Mc: 57 / 42 / 38 cycles per entry for one wave alone, 19 at full occupancy).
+// Fixed registers: the value table in s[42:73], two sets of four masks in s[74:89] -- k_center is compiled for 48
+// SGPRs (s0 - s41 + the six special ones), so the compiler never allocates them, and the kernel as a whole stays
+// within 96: eight waves per SIMD.
+#define PC_C_RL_IDX(S, J0, J1, J2, J3)                                                                                 \
+    "v_readlane_b32 %[si" #S "0], %[vix], " #J0 "\n\tv_readlane_b32 %[si" #S "1], %[vix], " #J1 "\n\t"                  \
+    "v_readlane_b32 %[si" #S "2], %[vix], " #J2 "\n\tv_readlane_b32 %[si" #S "3], %[vix], " #J3 "\n\t"
+#define PC_C_MASKS_A(J0, J1, J2, J3)                                                                                   \
+    "v_readlane_b32 s74, %[vlo], " #J0 "\n\tv_readlane_b32 s75, %[vhi], " #J0 "\n\t"                                    \
+    "v_readlane_b32 s76, %[vlo], " #J1 "\n\tv_readlane_b32 s77, %[vhi], " #J1 "\n\t"                                    \
+    "v_readlane_b32 s78, %[vlo], " #J2 "\n\tv_readlane_b32 s79, %[vhi], " #J2 "\n\t"                                    \
+    "v_readlane_b32 s80, %[vlo], " #J3 "\n\tv_readlane_b32 s81, %[vhi], " #J3 "\n\t"
+#define PC_C_MASKS_B(J0, J1, J2, J3)                                                                                   \
+    "v_readlane_b32 s82, %[vlo], " #J0 "\n\tv_readlane_b32 s83, %[vhi], " #J0 "\n\t"                                    \
+    "v_readlane_b32 s84, %[vlo], " #J1 "\n\tv_readlane_b32 s85, %[vhi], " #J1 "\n\t"                                    \
+    "v_readlane_b32 s86, %[vlo], " #J2 "\n\tv_readlane_b32 s87, %[vhi], " #J2 "\n\t"                                    \
+    "v_readlane_b32 s88, %[vlo], " #J3 "\n\tv_readlane_b32 s89, %[vhi], " #J3 "\n\t"
+// (an instruction has to sit between a scalar write of m0 and s_movrels)
+#define PC_C_LOOKUP(S, K) "s_mov_b32 m0, %[si" #S #K "]\n\ts_nop 0\n\ts_movrels_b64 %[val" #S #K "], s[42:43]\n\t"
+#define PC_C_ADD(S, K, M) "s_mov_b64 exec, s[" #M "]\n\tv_add_f64 %[acc], %[acc], %[val" #S #K "]\n\t"
+// first group of a block into set A
+#define PC_C_PRO(J0, J1, J2, J3)                                                                                       \
+    PC_C_RL_IDX(a, J0, J1, J2, J3) PC_C_MASKS_A(J0, J1, J2, J3) PC_C_LOOKUP(a, 0) PC_C_LOOKUP(a, 1) PC_C_LOOKUP(a, 2) PC_C_LOOKUP(a, 3)
+// the adds of the group in set A, with group J0..J3 read into set B and looked up in between; and the mirror image
+#define PC_C_STEP_AB(J0, J1, J2, J3)                                                                                   \
+    PC_C_RL_IDX(b, J0, J1, J2, J3) PC_C_MASKS_B(J0, J1, J2, J3)                                                         \
+    "s_mov_b64 exec, s[74:75]\n\tv_add_f64 %[acc], %[acc], %[vala0]\n\ts_mov_b32 m0, %[sib0]\n\t"                        \
+    "s_mov_b64 exec, s[76:77]\n\ts_movrels_b64 %[valb0], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala1]\n\ts_mov_b32 m0, %[sib1]\n\t" \
+    "s_mov_b64 exec, s[78:79]\n\ts_movrels_b64 %[valb1], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala2]\n\ts_mov_b32 m0, %[sib2]\n\t" \
+    "s_mov_b64 exec, s[80:81]\n\ts_movrels_b64 %[valb2], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala3]\n\ts_mov_b32 m0, %[sib3]\n\t" \
+    "s_mov_b64 exec, -1\n\ts_movrels_b64 %[valb3], s[42:43]\n\t"
+#define PC_C_STEP_BA(J0, J1, J2, J3)                                                                                   \
+    PC_C_RL_IDX(a, J0, J1, J2, J3) PC_C_MASKS_A(J0, J1, J2, J3)                                                         \
+    "s_mov_b64 exec, s[82:83]\n\tv_add_f64 %[acc], %[acc], %[valb0]\n\ts_mov_b32 m0, %[sia0]\n\t"                        \
+    "s_mov_b64 exec, s[84:85]\n\ts_movrels_b64 %[vala0], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb1]\n\ts_mov_b32 m0, %[sia1]\n\t" \
+    "s_mov_b64 exec, s[86:87]\n\ts_movrels_b64 %[vala1], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb2]\n\ts_mov_b32 m0, %[sia2]\n\t" \
+    "s_mov_b64 exec, s[88:89]\n\ts_movrels_b64 %[vala2], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb3]\n\ts_mov_b32 m0, %[sia3]\n\t" \
+    "s_mov_b64 exec, -1\n\ts_movrels_b64 %[vala3], s[42:43]\n\t"
+#define PC_C_EPI_A PC_C_ADD(a, 0, 74:75) PC_C_ADD(a, 1, 76:77) PC_C_ADD(a, 2, 78:79) PC_C_ADD(a, 3, 80:81) "s_mov_b64 exec, -1\n\t"
+#define PC_C_EPI_B PC_C_ADD(b, 0, 82:83) PC_C_ADD(b, 1, 84:85) PC_C_ADD(b, 2, 86:87) PC_C_ADD(b, 3, 88:89) "s_mov_b64 exec, -1\n\t"
+#define PC_C_PAIR(B) PC_C_STEP_AB(B + 4, B + 5, B + 6, B + 7) PC_C_STEP_BA(B + 8, B + 9, B + 10, B + 11)
+// sixteen entries (lanes B .. B+15) and a whole batch of 64
+#define PC_C_16(B) PC_C_PRO(B + 0, B + 1, B + 2, B + 3) PC_C_PAIR(B) PC_C_STEP_AB(B + 12, B + 13, B + 14, B + 15) PC_C_EPI_B
+#define PC_C_64                                                                                                        \
+    PC_C_PRO(0, 1, 2, 3) PC_C_PAIR(0) PC_C_PAIR(8) PC_C_PAIR(16) PC_C_PAIR(24) PC_C_PAIR(32) PC_C_PAIR(40) PC_C_PAIR(48)  \
+    PC_C_STEP_AB(60, 61, 62, 63) PC_C_EPI_B
+#define PC_CENTER_TABLE_REGS                                                                                           \
+    "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57",    \
+        "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73"
+#define PC_CENTER_MASK_REGS "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89"
+
+// CODE = PC_C_64 or PC_C_16(B); exec all ones on entry and on exit
+#define PC_CENTER_REPLAY(CODE)                                                                                         \
+    do {                                                                                                               \
+        int sia0_, sia1_, sia2_, sia3_, sib0_, sib1_, sib2_, sib3_, m0_;                                               \
+        double vala0_, vala1_, vala2_, vala3_, valb0_, valb1_, valb2_, valb3_;                                         \
+        asm volatile("s_mov_b32 %[m0s], m0\n\t" CODE "s_mov_b32 m0, %[m0s]\n\t"                                        \
+                     : [acc] "+v"(acc), [sia0] "=&s"(sia0_), [sia1] "=&s"(sia1_), [sia2] "=&s"(sia2_),                 \
+                       [sia3] "=&s"(sia3_), [sib0] "=&s"(sib0_), [sib1] "=&s"(sib1_), [sib2] "=&s"(sib2_),             \
+                       [sib3] "=&s"(sib3_), [vala0] "=&s"(vala0_), [vala1] "=&s"(vala1_), [vala2] "=&s"(vala2_),       \
+                       [vala3] "=&s"(vala3_), [valb0] "=&s"(valb0_), [valb1] "=&s"(valb1_), [valb2] "=&s"(valb2_),     \
+                       [valb3] "=&s"(valb3_), [m0s] "=&s"(m0_)                                                         \
+                     : [vlo] "v"(mlo), [vhi] "v"(mhi), [vix] "v"(vix)                                                  \
+                     : PC_CENTER_MASK_REGS, "scc");                                                                    \
+    } while (0)
+
+// (the table registers are reserved -- that is the point -- so naming them as clobbered draws a warning)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) void k_center(
+    const CenterChunk *__restrict__ chunks, int64_t nchunks, const FileView *__restrict__ files, int nfiles, MapParams mp, int W,
+    const double *__restrict__ inv_, const double *__restrict__ cval, const uint32_t *__restrict__ order,
+    const uint32_t *__restrict__ counters, const u32x4 *__restrict__ ranges, double *hist, unsigned long long *dbg) {
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
-    // the grid spans the list capacity: heavy entries at the front, light ones at the back, nothing in between --
-    // two thirds of the workgroups have no slot to serve and leave before they fill the table
+    // the grid spans the list capacity: heavy entries at the front, light ones at the back, nothing in between
     const uint32_t cap = kCenterCap * (uint32_t)nchunks;
     const uint32_t n_heavy = counters[0], n_light = counters[1];
-    {
-        const uint32_t first = blockIdx.x * (uint32_t)(kCenterWG / 64), last = first + (uint32_t)(kCenterWG / 64) - 1u;
-        if (first >= cap || !(first < n_heavy || last >= cap - n_light)) return;   // uniform over the workgroup
-    }
-    for (int i = threadIdx.x; i < kInvLds; i += kCenterWG) s_inv[i] = inv[i]; // host-computed IEEE quotients 1.0/m
-    __syncthreads();
-    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kCenterWG + threadIdx.x) >> 6));
-    if (slot >= cap) return;
+    const uint32_t slot = blockIdx.x;
+    if (slot >= cap || !(slot < n_heavy || slot >= cap - n_light)) return;
     const uint32_t entry = order[slot];
-    if (!(slot < n_heavy || slot >= cap - n_light)) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
+    // the heavy entries at the front of the list are the launch's critical path: their waves go first when
+    // several waves of a SIMD are ready
+    if (slot < n_heavy) __builtin_amdgcn_s_setprio(3);
     CenterChunk ck = chunks[cidx];
     {   // a sub-chunk is a chunk of its own: narrow the descriptor
         const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
@@ -1445,75 +1518,121 @@ __global__ __launch_bounds__(kCenterWG) void k_center(const CenterChunk *__restr
     }
     const int32_t p = ck.start + lane;
     const int32_t cend = ck.start + ck.len;
+    const int nib = mp.param;
+    const int sel = center_sel(ck.mode);
     double acc = 0.0;
     const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
+    unsigned long long n_slots = 0;   // PC_CENTER_DEBUG: entry slots this wave replayed
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
+        {   // this file's value table into the reserved registers
+            const unsigned long long tp = (unsigned long long)(cval + (size_t)f * kCTab);
+            asm volatile("s_load_dwordx2 s[42:43], %0, 0x0\n\ts_load_dwordx4 s[44:47], %0, 0x8\n\ts_load_dwordx16 s[48:63], %0, 0x18\n\t"
+                         "s_load_dwordx8 s[64:71], %0, 0x58\n\ts_load_dwordx2 s[72:73], %0, 0x78\n\ts_waitcnt lgkmcnt(0)"
+                         :: "s"(tp) : PC_CENTER_TABLE_REGS, "memory");
+        }
+        const int lbase = fv.c_lbase;
         const int64_t near_key = (int64_t)ck.start - W + 1;
         const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[(int64_t)cidx * nfiles + f]; // from k_center_weigh
-        CenterEntry *list = s_list + (threadIdx.x >> 6) * 64;
-        // long-span reads that start before the near window but may reach into it: they precede every
-        // near-window record in the file, so they are replayed first (64 list entries at a time)
-        for (int64_t base = rg.z; base < (int64_t)rg.w; base += 64) {
-            const bool in = base + lane < (int64_t)rg.w;
-            const u32x4 g = in ? fv.long_rec[base + lane] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
-            if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_key) break; // sorted by start: the rest is met in the near window
-            center_batch<false>(fv, mp, ck, cend, in & ((int64_t)(int32_t)g.x < near_key), (int32_t)g.x, g.y, g.z, s_inv, inv,
-                                list, lane, p, acc);
-        }
-        // near window: the records that start in [start - W + 1, end).  A batch of 64 candidates is
-        // fetched with ONE coalesced vector load, four batches in flight (a wave walks its range
-        // alone).  Whole chunks start at the bucket edge (a few surplus candidates, filtered out); the
-        // waves of a cut chunk each search their exact start, or they would all scan the whole pile-up.
-        // (a whole chunk over a dense region searches too: the bucket edge lies 64 positions before
-        // near_key on average, and every surplus batch costs a filter pass; three dependent loads pay
-        // for themselves from about a thousand candidates on)
-        const int64_t lo = (code == 0u && (int64_t)rg.y - (int64_t)rg.x < kCenterSearchFrom)
-                               ? (int64_t)rg.x
-                               : wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
-        const int64_t hi = rg.y;
-        // (the loads are unconditional, with the index clamped into the range: a load under a lane
-        // predicate would keep the compiler from counting how many are outstanding, and it would
-        // wait for all of them at every batch)
-        const int64_t last = hi - 1;
-        u32x2 q0 = {0u, 0u}, q1 = q0, q2 = q0, q3 = q0;
-        if (hi > lo) {
-            q0 = fv.rec[lo + lane < last ? lo + lane : last];
-            q1 = fv.rec[lo + 64 + lane < last ? lo + 64 + lane : last];
-            q2 = fv.rec[lo + 128 + lane < last ? lo + 128 + lane : last];
-            q3 = fv.rec[lo + 192 + lane < last ? lo + 192 + lane : last];
-        }
-        // one batch: take its records out of register `q`, refill `q` with the batch four ahead (the
-        // loop is unrolled over the four registers: rotating them with moves would make every batch
-        // wait for all loads), then filter / compact / replay.  Returns false when the scan is over.
-        auto step = [&](u32x2 &q, int64_t base) -> bool {
-            if (base >= hi) return false;
-            const u32x2 r = q;
-            q = fv.rec[base + 256 + lane < last ? base + 256 + lane : last];
-            if ((int32_t)lane_u32(r.x, 0) >= cend) return false; // sorted by start: nothing further can reach the chunk
-            const int32_t pos = (int32_t)r.x;
-            // records before near_key belong to the long-span loop above (or cannot reach the chunk)
-            const bool in = (base + lane < hi) & ((int64_t)pos >= near_key);
-            const bool odd = in && (rec_nblk(r.y) >= 2 || rec_len(r.y) - 2 * mp.param >= kInvLds);
-            if (__any(odd)) {                                // gapped reads / very long reads in the batch
-                uint32_t boff = 0u;
-                if (in && rec_nblk(r.y) >= 2) boff = fv.blk_off[base + lane];
-                center_batch<false>(fv, mp, ck, cend, in, pos, r.y, boff, s_inv, inv, list, lane, p, acc);
-            } else {
-                center_batch<true>(fv, mp, ck, cend, in, pos, r.y, 0u, s_inv, inv, list, lane, p, acc);
+        // One batch: lane j describes entry j -- aligned run [x, x + len) of a read of aligned length L, the run's
+        // first base being read index `cum` (or `indirect`: a read the 8-bit fields cannot describe, record `recidx`).
+        // Every lane derives what its entry covers after the nibble; then the entries are replayed in lane order.
+        auto replay = [&](bool valid, bool indirect, int32_t x, int len, int cum, int L, uint32_t recidx, int nvalid) {
+            // read indices [nib, L - nib) are counted: the part of this run inside that, as genome positions
+            const int lo_i = cum > nib ? cum : nib, hi_i = cum + len < L - nib ? cum + len : L - nib;
+            const int a0 = x + (lo_i - cum), m = hi_i - lo_i;
+            const bool live = valid && !indirect && m > 0 && a0 < cend && a0 + m > ck.start;
+            const uint32_t tix = (uint32_t)(L - lbase);
+            if (__any(indirect || (live && tix >= (uint32_t)kCTab))) {
+                // a batch with a length outside the table, or a read the entry cannot describe: entry by entry
+                const int mtot = L - 2 * nib;
+                double val = 0.0;
+                if (live && size_ok(mp, L)) val = inv[mtot];    // live implies mtot >= m > 0
+                unsigned long long todo = __ballot(live || indirect);
+                while (todo) {
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    if (lane_u32((uint32_t)indirect, j)) {
+                        const int64_t i = (int64_t)lane_u32(recidx, j);
+                        const u32x2 rr = fv.rec[i];
+                        center_read(fv, mp, inv, (int32_t)rr.x, rr.y, rec_nblk(rr.y) >= 2 ? fv.blk_off[i] : 0u, p, acc);
+                    } else {
+                        const int aj = (int)lane_u32((uint32_t)a0, j), mj = (int)lane_u32((uint32_t)m, j);
+                        const double vj = lane_f64(val, j);
+                        acc += ((uint32_t)(p - aj) < (uint32_t)mj) ? vj : 0.0;
+                    }
+                }
+                return;
             }
-            return true;
+            // the lanes entry j covers, as a 64-bit mask (chunk-relative positions [rlo, rhi))
+            const int rel = a0 - ck.start, rlo = rel > 0 ? rel : 0, rhi = rel + m < 64 ? rel + m : 64, nlanes = rhi - rlo;
+            const unsigned long long mask = (live && nlanes > 0) ? ((nlanes >= 64 ? ~0ull : ((1ull << nlanes) - 1ull)) << rlo) : 0ull;
+            const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32), vix = live ? tix * 2u : 0u;
+            if (nvalid > 32) {
+                n_slots += 64ull;
+                PC_CENTER_REPLAY(PC_C_64);
+            } else {
+                n_slots += (unsigned long long)((nvalid + 15) & ~15);
+                PC_CENTER_REPLAY(PC_C_16(0));
+                if (nvalid > 16) PC_CENTER_REPLAY(PC_C_16(16));
+            }
         };
-        for (int64_t base = lo; base < hi; base += 256) {
-            if (!step(q0, base)) break;
-            if (!step(q1, base + 64)) break;
-            if (!step(q2, base + 128)) break;
-            if (!step(q3, base + 192)) break;
+        // long-span reads that start before the near window but may reach into it: they precede every
+        // near-window record in the file, so they are replayed first -- 32 reads per batch, the first two aligned
+        // runs of read j (they travel next to its header) as entries 2j and 2j + 1; reads with more runs go through
+        // their record
+        for (int64_t base = rg.z; base < (int64_t)rg.w; base += 32) {
+            const int64_t j = base + (lane >> 1);
+            const bool in = j < (int64_t)rg.w;
+            const u32x4 g = in ? fv.long_rec[j] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
+            if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_key) break; // sorted by start: the rest is met in the near window
+            const i32x4 runs = in ? fv.long_runs[j] : i32x4{0, 0, 0, 0};
+            const uint32_t fl = rec_flags(g.y);
+            const int nbk = rec_nblk(g.y), r = lane & 1;
+            const bool ok = in && (int64_t)(int32_t)g.x < near_key && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse);
+            replay(ok && nbk <= 2 && (r == 0 || nbk == 2), ok && nbk > 2 && r == 0, r ? runs.z : runs.x, r ? runs.w : runs.y,
+                   r ? runs.y : 0, rec_len(g.y), g.w, 64);
+        }
+        // near window: the stream entries of the records that start in [start - W + 1, end).  Whole chunks take the
+        // exact record range of the pre-pass; a sub-chunk narrows it to its own positions.
+        int64_t r0 = rg.x, r1 = rg.y;
+        if (code != 0u) {
+            r0 = wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
+            r1 = wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, r0, rg.y, (int64_t)cend, lane);
+        }
+        const u32x2 PC_GLOBAL *ent = cs_stream(files + f, sel);
+        const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, sel);
+        const int64_t lo = soff[r0], hi = soff[r1];
+        // (the loads are unconditional, with the index clamped into the range: the padding behind the last
+        // entry makes every clamped batch readable)
+        const int64_t last = hi - 1;
+        u32x2 q0 = {0u, 0u}, q1 = q0;
+        if (hi > lo) {
+            q0 = ent[lo + lane < last ? lo + lane : last];
+            q1 = ent[lo + 64 + lane < last ? lo + 64 + lane : last];
+        }
+        // one batch of the stream: its entries out of register `q`, `q` refilled with the batch two ahead
+        auto step = [&](u32x2 &q, int64_t base) {
+            const u32x2 r = q;
+            q = ent[base + 128 + lane < last ? base + 128 + lane : last];
+            const int nvalid = hi - base < 64 ? (int)(hi - base) : 64;
+            const bool valid = lane < nvalid;
+            replay(valid, valid && ((r.y >> 24) & kCsIndirect), (int32_t)r.x, (int)(r.y & 0xffu), (int)((r.y >> 8) & 0xffu),
+                   (int)((r.y >> 16) & 0xffu), r.x, nvalid);
+        };
+        for (int64_t base = lo; base < hi; base += 128) {
+            step(q0, base);
+            if (base + 64 >= hi) break;
+            step(q1, base + 64);
         }
     }
     if (lane < ck.len) hist[ck.hist_off + lane] = acc;
-    if (dbg && lane == 0) { dbg[2 * (size_t)slot] = wall_clock64() - t_begin; dbg[2 * (size_t)slot + 1] = t_begin; }   // PC_CENTER_DEBUG
+    if (dbg && lane == 0) {   // PC_CENTER_DEBUG
+        dbg[2 * (size_t)slot] = wall_clock64() - t_begin; dbg[2 * (size_t)slot + 1] = t_begin;
+        dbg[2 * (size_t)cap + slot] = n_slots;
+    }
 }
+#pragma clang diagnostic pop
 
 // ---------------------------------------------------------------- k_gather
 // Lays the per-segment slices out the way SegmentChain.get_counts does: chain

@@ -260,6 +260,11 @@ struct StagedFile {
     DevBuf<uint4> xlong_rec;
     DevBuf<int4> xlong_runs;
     DevBuf<uint32_t> xllin_tab, xplin_tab;
+    // center streams (built at the first center-rule count that needs them; dropped when the host-side filters change)
+    DevBuf<uint2> cs_ent[3];
+    DevBuf<uint32_t> cs_soff[3];
+    int64_t cs_n[3] = {-1, -1, -1};    // entries, -1: not built
+    int c_lbase = 0;                   // the 16 aligned lengths from here on have their 1/m in the center kernel's SGPR table
     FileView view() const {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
@@ -271,6 +276,8 @@ struct StagedFile {
         v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.llin_tab = llin_tab.p; v.plin_tab = plin_tab.p; v.lin_off = lin_off.p;
         v.run_rec = run_rec.p; v.rlin_tab = rlin_tab.p; v.nrunrec = nrunrec;
         v.xlong_rec = xlong_rec.p; v.xlong_runs = xlong_runs.p; v.xllin_tab = xllin_tab.p; v.xplin_tab = xplin_tab.p; v.nxlong = nxlong;
+        for (int k = 0; k < 3; ++k) { v.cs_ent[k] = cs_n[k] >= 0 ? cs_ent[k].p : nullptr; v.cs_soff[k] = cs_n[k] >= 0 ? cs_soff[k].p : nullptr; }
+        v.c_lbase = c_lbase;
         return v;
     }
 };
@@ -290,6 +297,8 @@ struct Knobs {
     int debug_work = 0;        // PC_DEBUG_WORK: print the queued work items per class (stderr; synchronises)
     int center_t1 = 8;         // PC_CENTER_T1 / PC_CENTER_T2: center chunks with more than T1 x (T1*T2 x) the mean candidate
     int center_t2 = 4;         //   count are cut into 4 (8) sub-chunks
+    int64_t center_floor = 32768; // PC_CENTER_FLOOR: stream entries below which a chunk is never cut (a wave alone replays ~50 k per ms)
+    int center_debug = 0;      // PC_CENTER_DEBUG: wall-clock span of every dispatched wave of k_center, printed after the launch (synchronises)
     void load() {
         *this = Knobs();
         if (const char *env = getenv("PC_TILE_G")) tile_g = std::max(256, atoi(env) / 256 * 256);
@@ -301,6 +310,8 @@ struct Knobs {
         debug_work = getenv("PC_DEBUG_WORK") ? 1 : 0;
         if (const char *env = getenv("PC_CENTER_T1")) center_t1 = std::max(8, atoi(env));
         if (const char *env = getenv("PC_CENTER_T2")) center_t2 = std::max(1, atoi(env));
+        if (const char *env = getenv("PC_CENTER_FLOOR")) center_floor = std::max(64, atoi(env));
+        center_debug = getenv("PC_CENTER_DEBUG") ? 1 : 0;
     }
 };
 
@@ -326,6 +337,7 @@ struct pc_engine {
     int norm_on = 0;
     double norm_sum = 1.0;
     DevBuf<double> d_inv; // 1.0/m, m = 0..65535 (host-computed IEEE quotients)
+    DevBuf<double> d_cval; // per file: the 1/m of the center kernel's SGPR table (k_center_vals)
     // scratch for counting
     DevBuf<WorkItem> d_work, d_work_small;
     DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
@@ -454,6 +466,35 @@ int refresh_file_views(pc_engine *e) {
     if (rc != PC_OK) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->files_dirty = false;
+    return PC_OK;
+}
+
+// Center stream `sel` (0 forward reads, 1 reverse reads, 2 all reads) of one staged file: entries per record,
+// exclusive sum, scatter -- three passes over the 8-byte records in HBM (see k_center in pc_kernels.hip.h).
+int build_center_stream(pc_engine *e, StagedFile *sf, int sel) {
+    hipStream_t st = e->stream;
+    const int64_t n = sf->n;
+    int rc = sf->cs_soff[sel].reserve((size_t)n + 1);
+    if (rc != PC_OK) return rc;
+    hipLaunchKernelGGL(k_cs_count, dim3((unsigned)((n + 1 + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, n, sel, sf->cs_soff[sel].p);
+    {
+        size_t tmp_bytes = 0;
+        DevBuf<uint8_t> d_tmp;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, sf->cs_soff[sel].p, sf->cs_soff[sel].p, (int)(n + 1), st));
+        rc = d_tmp.reserve(tmp_bytes);
+        if (rc != PC_OK) return rc;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, sf->cs_soff[sel].p, sf->cs_soff[sel].p, (int)(n + 1), st));
+        HIP_TRY(hipStreamSynchronize(st));   // d_tmp goes out of scope
+    }
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpy(&total, sf->cs_soff[sel].p + n, sizeof(total), hipMemcpyDeviceToHost));
+    rc = sf->cs_ent[sel].reserve((size_t)total + 64);
+    if (rc != PC_OK) return rc;
+    hipLaunchKernelGGL(k_cs_scatter, dim3((unsigned)((n + 64 + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, sf->blk_off.p, sf->blk.p, n,
+                       sel, sf->cs_soff[sel].p, sf->cs_ent[sel].p);
+    HIP_TRY(hipGetLastError());
+    sf->cs_n[sel] = (int64_t)total;
+    e->files_dirty = true;
     return PC_OK;
 }
 
@@ -726,6 +767,14 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     sf->len_hist.swap(len_hist);
     for (int L = 0; L < 65536; ++L)
         if (sf->len_hist[(size_t)L]) { sf->len_min = std::min(sf->len_min, L); sf->len_max = std::max(sf->len_max, L); }
+    {   // the kCTab consecutive aligned lengths (<= 255) that hold the most records: the center kernel's fast table
+        int64_t win = 0, best = -1;
+        for (int L = 1; L <= 255; ++L) {
+            win += sf->len_hist[(size_t)L];
+            if (L - kCTab >= 1) win -= sf->len_hist[(size_t)(L - kCTab)];
+            if (win > best) { best = win; sf->c_lbase = std::max(1, L - kCTab + 1); }
+        }
+    }
 
     // ---- pass B: packed records (8 B), record stream (4 B), run offsets and the side lists, produced
     // slice by slice into two sets of reusable host buffers; a slice crosses PCIe (on a thread of
@@ -1233,6 +1282,8 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
                            sf->run_recidx.p, sf->nrunrec, sf->rec.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
+    for (int k = 0; k < 3; ++k) sf->cs_n[k] = -1;   // the center streams leave excluded reads out: rebuilt at the next center count
+    e->files_dirty = true;
     return PC_OK;
 }
 
@@ -1591,7 +1642,15 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     if ((center || e->norm_on) && out_dtype != PC_OUT_FLOAT64)
         return fail(PC_ERR_ARG, "pc_count: center mapping / normalisation produce float64 (map_factories.pyx:230, genome_array.py:826-827)");
     HIP_TRY(hipSetDevice(e->device));
-    int rc = refresh_file_views(e);
+    int rc = PC_OK;
+    if (center) {   // the center streams of the strand selections this plan queries (built once per file and filter state)
+        const bool need[3] = {(p->modes & 1u) != 0, (p->modes & 2u) != 0, (p->modes & 12u) != 0};
+        for (auto *f : e->files)
+            for (int k = 0; k < 3 && rc == PC_OK; ++k)
+                if (need[k] && f->cs_n[k] < 0) rc = build_center_stream(e, f, k);
+        if (rc != PC_OK) return rc;
+    }
+    rc = refresh_file_views(e);
     if (rc != PC_OK) return rc;
 
     const size_t hist_elem = center ? sizeof(double) : sizeof(uint32_t);
@@ -1795,32 +1854,47 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             e->counters_zero = false;
             unsigned long long *total = (unsigned long long *)(e->d_counters.p + 2); // counters[2..3]
             const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
+            if (nfiles * kCTab > 1024) return fail(PC_ERR_ARG, "pc_count: the center rule takes at most %d alignment files", 1024 / kCTab);
+            rc = e->d_cval.reserve((size_t)nfiles * kCTab);
+            if (rc != PC_OK) return rc;
+            hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(1024), 0, st, e->d_files.p, nfiles, mp, e->d_inv.p, e->d_cval.p);
             hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
                                p->d_ccand.p, p->d_cranges.p, total);
             // cut thresholds, in multiples of the mean candidate count
             const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2;
-            hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, (int64_t)2048, ck1, ck2,
+            hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, e->knobs.center_floor, (int64_t)2048, ck1, ck2,
                                p->d_corder.p, e->d_counters.p);
             // PC_CENTER_DEBUG: how long every dispatched wave ran (wall clock ticks), printed after the launch
             DevBuf<unsigned long long> d_dbg;
-            const bool dbg_on = getenv("PC_CENTER_DEBUG") != nullptr;
+            const bool dbg_on = e->knobs.center_debug != 0;
             if (dbg_on) {
-                rc = d_dbg.reserve((size_t)(2 * kCenterCap * nchunks));
+                rc = d_dbg.reserve((size_t)(2 * kCenterCap * nchunks) + (size_t)kCenterCap * nchunks);
                 if (rc != PC_OK) return rc;
-                HIP_TRY(hipMemsetAsync(d_dbg.p, 0, (size_t)(2 * kCenterCap * nchunks) * 8, st));
+                HIP_TRY(hipMemsetAsync(d_dbg.p, 0, (size_t)(3 * kCenterCap * nchunks) * 8, st));
             }
             unsigned long long *dbg = dbg_on ? d_dbg.p : nullptr;
-            const int64_t cwaves = kCenterWG / 64;
-            hipLaunchKernelGGL(k_center, dim3((unsigned)((kCenterCap * nchunks + cwaves - 1) / cwaves)), dim3(kCenterWG), 0, st, p->d_cchunks.p, nchunks,
-                               e->d_files.p, nfiles, mp, W, e->d_inv.p, p->d_corder.p, e->d_counters.p, p->d_cranges.p,
+            hipLaunchKernelGGL(k_center, dim3((unsigned)(kCenterCap * nchunks)), dim3(kCenterWG), 0, st, p->d_cchunks.p, nchunks,
+                               e->d_files.p, nfiles, mp, W, e->d_inv.p, e->d_cval.p, p->d_corder.p, e->d_counters.p, p->d_cranges.p,
                                (double *)p->d_hist.p, dbg);
             if (dbg_on) {
-                std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks));
+                std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks)), h_slots((size_t)(kCenterCap * nchunks));
                 std::vector<uint32_t> h_order((size_t)(kCenterCap * nchunks)), h_cand((size_t)nchunks);
                 HIP_TRY(hipStreamSynchronize(st));
                 HIP_TRY(hipMemcpy(h.data(), d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(h_slots.data(), d_dbg.p + h.size(), h_slots.size() * 8, hipMemcpyDeviceToHost));
                 HIP_TRY(hipMemcpy(h_order.data(), p->d_corder.p, h_order.size() * 4, hipMemcpyDeviceToHost));
                 HIP_TRY(hipMemcpy(h_cand.data(), p->d_ccand.p, h_cand.size() * 4, hipMemcpyDeviceToHost));
+                {   // replayed entry slots per class of dispatch entry (whole chunk / quarter / eighth)
+                    unsigned long long cls[3] = {0, 0, 0}, ncl[3] = {0, 0, 0};
+                    for (size_t i = 0; i < h_slots.size(); ++i)
+                        if (h[2 * i]) {
+                            const uint32_t code = h_order[i] >> kSubShift;
+                            const int k = code == 0u ? 0 : (code <= 4u ? 1 : 2);
+                            cls[k] += h_slots[i]; ncl[k] += 1;
+                        }
+                    fprintf(stderr, "[center] replayed entry slots: whole chunks %llu in %llu waves, quarters %llu in %llu, eighths %llu in %llu\n", cls[0], ncl[0],
+                            cls[1], ncl[1], cls[2], ncl[2]);
+                }
                 unsigned long long t0 = ~0ull, t1 = 0, sum = 0;
                 size_t nw = 0;
                 std::vector<std::pair<unsigned long long, size_t>> byd;

@@ -13,5 +13,12 @@ factory._configure(eng)
 p = tx.plan_arrays(rows=1)
 plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
 plan.launch(np.float64); eng.sync()
+import time
+eng.set_profiling(2)
+for _ in range(3):
+    plan.launch(np.float64); eng.sync()
+    print("phases ms:", {k: round(v, 4) for k, v in eng.last_timing().items()})
+eng.set_profiling(0)
 os.environ["PC_CENTER_DEBUG"] = "1"
+eng.reload_knobs()   # the knobs are read at pc_create / pc_reload_knobs
 plan.launch(np.float64); eng.sync()
