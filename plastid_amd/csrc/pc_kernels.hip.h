@@ -1232,7 +1232,10 @@ __device__ __forceinline__ double lane_f64(double v, int j) {
 
 // Workgroup of the center kernel: ONE wave.  The waves of a launch are independent (one chunk each) and very
 // unequal; in a four-wave workgroup the wave slots of the finished ones stay taken until the last one is done.
-constexpr int kCenterWG = 64;
+#ifndef PC_CENTER_WG
+#define PC_CENTER_WG 64
+#endif
+constexpr int kCenterWG = PC_CENTER_WG;
 
 // Center stream of a staged file and a strand selection (0: forward reads, 1: reverse reads, 2: all reads), built
 // on the GPU at the first center-rule count of the file and again when the host-side filters change:
@@ -1324,7 +1327,8 @@ __device__ __forceinline__ int64_t bucket_lower_bound(const GFile &fv, int64_t q
 
 __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                             const FileView *__restrict__ files, int nfiles, int W,
-                                                            uint32_t *cand_out, u32x4 *ranges, unsigned long long *total) {
+                                                            uint32_t *cand_out, u32x4 *ranges, u32x2 *rec_ranges,
+                                                            unsigned long long *total) {
     const int64_t c = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
     unsigned long long cand = 0;
     if (c < nchunks) {
@@ -1334,9 +1338,13 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
             const int64_t q0 = fv.lin_off[ck.tid], nb = fv.lin_off[ck.tid + 1] - q0 - 1;
             const int64_t cend = (int64_t)ck.start + ck.len;
             u32x4 rg;
-            rg.x = (uint32_t)bucket_lower_bound(fv, q0, nb, (int64_t)ck.start - W + 1);
-            rg.y = (uint32_t)bucket_lower_bound(fv, q0, nb, cend);
-            if (rg.y < rg.x) rg.y = rg.x;
+            u32x2 rr;   // the near window as a record range (what a sub-chunk narrows) and as the entry range of the chunk's stream
+            rr.x = (uint32_t)bucket_lower_bound(fv, q0, nb, (int64_t)ck.start - W + 1);
+            rr.y = (uint32_t)bucket_lower_bound(fv, q0, nb, cend);
+            if (rr.y < rr.x) rr.y = rr.x;
+            const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, center_sel(ck.mode));
+            rg.x = soff[rr.x];
+            rg.y = soff[rr.y];
             rg.z = rg.w = 0u;
             if (fv.nlong) { // they start before the near window of some position of the chunk, and the
                             // running maximum of the ends has passed the chunk start
@@ -1345,8 +1353,8 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
                 if (rg.z > rg.w) rg.z = rg.w;
             }
             ranges[c * nfiles + f] = rg;
-            const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, center_sel(ck.mode));
-            cand += soff[rg.y] - soff[rg.x];
+            rec_ranges[c * nfiles + f] = rr;
+            cand += rg.y - rg.x;
         }
         cand_out[c] = (uint32_t)(cand > 0xffffffffull ? 0xffffffffull : cand);
     }
@@ -1494,19 +1502,22 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) void k_center(
     const CenterChunk *__restrict__ chunks, int64_t nchunks, const FileView *__restrict__ files, int nfiles, MapParams mp, int W,
     const double *__restrict__ inv_, const double *__restrict__ cval, const uint32_t *__restrict__ order,
-    const uint32_t *__restrict__ counters, const u32x4 *__restrict__ ranges, double *hist, unsigned long long *dbg) {
+    const uint32_t *__restrict__ counters, const u32x4 *__restrict__ ranges, const u32x2 *__restrict__ rec_ranges, double *hist,
+    unsigned long long *dbg) {
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
-    // the grid spans the list capacity: heavy entries at the front, light ones at the back, nothing in between
+    // the list holds the heavy entries at its front and the light ones at its back; workgroup b serves the b-th
+    // entry of the two runs (the grid is their exact number once a count of the plan has shown it, else 2 x chunks,
+    // which bounds it).  One wave per entry: persistent waves that take entries off the list (heavy first, light
+    // ones a few at a time) were measured at 2.3 - 2.4 ms against 1.6 on C3, whatever the grab size.
     const uint32_t cap = kCenterCap * (uint32_t)nchunks;
     const uint32_t n_heavy = counters[0], n_light = counters[1];
-    const uint32_t slot = blockIdx.x;
-    if (slot >= cap || !(slot < n_heavy || slot >= cap - n_light)) return;
+    const uint32_t bidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (uint32_t)kCenterWG + threadIdx.x) >> 6));
+    if (bidx >= n_heavy + n_light) return;
+    const int lane = threadIdx.x & 63;
+    const int nib = mp.param;
+    const uint32_t slot = bidx < n_heavy ? bidx : cap - 1u - (bidx - n_heavy);
     const uint32_t entry = order[slot];
-    const int lane = threadIdx.x;
     const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
-    // the heavy entries at the front of the list are the launch's critical path: their waves go first when
-    // several waves of a SIMD are ready
-    if (slot < n_heavy) __builtin_amdgcn_s_setprio(3);
     CenterChunk ck = chunks[cidx];
     {   // a sub-chunk is a chunk of its own: narrow the descriptor
         const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
@@ -1518,7 +1529,6 @@ __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) voi
     }
     const int32_t p = ck.start + lane;
     const int32_t cend = ck.start + ck.len;
-    const int nib = mp.param;
     const int sel = center_sel(ck.mode);
     double acc = 0.0;
     const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
@@ -1595,14 +1605,16 @@ __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) voi
         }
         // near window: the stream entries of the records that start in [start - W + 1, end).  Whole chunks take the
         // exact record range of the pre-pass; a sub-chunk narrows it to its own positions.
-        int64_t r0 = rg.x, r1 = rg.y;
+        int64_t lo = rg.x, hi = rg.y;
         if (code != 0u) {
-            r0 = wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rg.x, rg.y, near_key, lane);
-            r1 = wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, r0, rg.y, (int64_t)cend, lane);
+            const u32x2 rr = ((const u32x2 PC_GLOBAL *)rec_ranges)[(int64_t)cidx * nfiles + f];
+            const int64_t r0 = wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rr.x, rr.y, near_key, lane);
+            const int64_t r1 = wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, r0, rr.y, (int64_t)cend, lane);
+            const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, sel);
+            lo = soff[r0];
+            hi = soff[r1];
         }
         const u32x2 PC_GLOBAL *ent = cs_stream(files + f, sel);
-        const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, sel);
-        const int64_t lo = soff[r0], hi = soff[r1];
         // (the loads are unconditional, with the index clamped into the range: the padding behind the last
         // entry makes every clamped batch readable)
         const int64_t last = hi - 1;

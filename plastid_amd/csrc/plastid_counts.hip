@@ -298,6 +298,7 @@ struct Knobs {
     int center_t1 = 8;         // PC_CENTER_T1 / PC_CENTER_T2: center chunks with more than T1 x (T1*T2 x) the mean candidate
     int center_t2 = 4;         //   count are cut into 4 (8) sub-chunks
     int64_t center_floor = 32768; // PC_CENTER_FLOOR: stream entries below which a chunk is never cut (a wave alone replays ~50 k per ms)
+    int center_lds = 0;        // PC_CENTER_LDS: bytes of (unused) LDS per k_center workgroup -- an occupancy throttle for experiments
     int center_debug = 0;      // PC_CENTER_DEBUG: wall-clock span of every dispatched wave of k_center, printed after the launch (synchronises)
     void load() {
         *this = Knobs();
@@ -312,6 +313,7 @@ struct Knobs {
         if (const char *env = getenv("PC_CENTER_T2")) center_t2 = std::max(1, atoi(env));
         if (const char *env = getenv("PC_CENTER_FLOOR")) center_floor = std::max(64, atoi(env));
         center_debug = getenv("PC_CENTER_DEBUG") ? 1 : 0;
+        if (const char *env = getenv("PC_CENTER_LDS")) center_lds = std::max(0, atoi(env));
     }
 };
 
@@ -417,7 +419,17 @@ struct pc_plan {
     DevBuf<int64_t> d_rle_starts;
     DevBuf<unsigned long long> d_rle_values;
     int64_t rle_runs = -1;
-    DevBuf<u32x4> d_cranges;    // per (chunk, file): record range and long-span candidate range
+    DevBuf<u32x4> d_cranges;    // per (chunk, file): entry range of the near window and candidate range of the long-span list
+    DevBuf<u32x2> d_crec;       // per (chunk, file): the near window as a record range (sub-chunks narrow it)
+    DevBuf<uint32_t> d_ccounts; // [0] heavy, [1] light entries of the dispatch list, [2..3] sum of the candidate counts
+    // the center pre-passes (ranges, candidate counts, dispatch order) depend on the plan, the staged files and the
+    // knobs only -- not on the mapping rule: kept from count to count while the engine's work generation stands
+    uint64_t center_generation = 0;
+    int center_W = -1;
+    uint32_t *h_center_counts = nullptr;   // page-locked [2]: heavy, light entries of the list (sizes the grid of later counts)
+    hipEvent_t ev_center_counts = nullptr;
+    bool center_counts_known = false;
+    uint32_t center_counts[2] = {0, 0};
     DevView<GatherSeg> d_gsegs;
     DevView<GatherChunk> d_gchunks;
     DevView<uint32_t> d_tile_items;
@@ -438,13 +450,15 @@ struct pc_plan {
     ~pc_plan() {
         if (ev_work_counts) (void)hipEventDestroy(ev_work_counts);
         if (h_work_counts) (void)hipHostFree(h_work_counts);
+        if (ev_center_counts) (void)hipEventDestroy(ev_center_counts);
+        if (h_center_counts) (void)hipHostFree(h_center_counts);
     }
 
     explicit pc_plan(pc_engine *eng) : e(eng) {
         DevPool *pl = &eng->pool;
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
-        d_cranges.pool = pl; d_hist_own.pool = pl; d_out.pool = pl;
+        d_cranges.pool = pl; d_crec.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl;
     }
 };
 
@@ -1284,6 +1298,7 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
     for (int k = 0; k < 3; ++k) sf->cs_n[k] = -1;   // the center streams leave excluded reads out: rebuilt at the next center count
     e->files_dirty = true;
+    e->work_generation += 1;
     return PC_OK;
 }
 
@@ -1849,21 +1864,40 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             rc = p->d_corder.reserve((size_t)(kCenterCap * nchunks));   // dispatch list: heavy entries front, light back
             if (rc == PC_OK) rc = p->d_ccand.reserve((size_t)nchunks);
             if (rc == PC_OK) rc = p->d_cranges.reserve((size_t)nchunks * (size_t)nfiles);
+            if (rc == PC_OK) rc = p->d_crec.reserve((size_t)nchunks * (size_t)nfiles);
+            if (rc == PC_OK) rc = p->d_ccounts.reserve(8);
             if (rc != PC_OK) return rc;
-            HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
-            e->counters_zero = false;
-            unsigned long long *total = (unsigned long long *)(e->d_counters.p + 2); // counters[2..3]
-            const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
             if (nfiles * kCTab > 1024) return fail(PC_ERR_ARG, "pc_count: the center rule takes at most %d alignment files", 1024 / kCTab);
             rc = e->d_cval.reserve((size_t)nfiles * kCTab);
             if (rc != PC_OK) return rc;
             hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(1024), 0, st, e->d_files.p, nfiles, mp, e->d_inv.p, e->d_cval.p);
-            hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
-                               p->d_ccand.p, p->d_cranges.p, total);
-            // cut thresholds, in multiples of the mean candidate count
-            const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2;
-            hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, e->knobs.center_floor, (int64_t)2048, ck1, ck2,
-                               p->d_corder.p, e->d_counters.p);
+            if (p->center_generation != e->work_generation || p->center_W != W) {
+                HIP_TRY(hipMemsetAsync(p->d_ccounts.p, 0, 4 * sizeof(uint32_t), st));
+                unsigned long long *total = (unsigned long long *)(p->d_ccounts.p + 2);
+                const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
+                hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
+                                   p->d_ccand.p, p->d_cranges.p, p->d_crec.p, total);
+                // cut thresholds, in multiples of the mean candidate count
+                const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2;
+                hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, e->knobs.center_floor,
+                                   (int64_t)2048, ck1, ck2, p->d_corder.p, p->d_ccounts.p);
+                p->center_generation = e->work_generation;
+                p->center_W = W;
+                // how many entries the list got: sizes the grid of the later counts of this plan (read back once)
+                if (!p->h_center_counts) {
+                    HIP_TRY(hipHostMalloc((void **)&p->h_center_counts, 2 * sizeof(uint32_t), hipHostMallocDefault));
+                    HIP_TRY(hipEventCreateWithFlags(&p->ev_center_counts, hipEventDisableTiming));
+                }
+                p->center_counts_known = false;
+                HIP_TRY(hipMemcpyAsync(p->h_center_counts, p->d_ccounts.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(p->ev_center_counts, st));
+            } else if (!p->center_counts_known && hipEventQuery(p->ev_center_counts) == hipSuccess) {
+                p->center_counts[0] = p->h_center_counts[0];
+                p->center_counts[1] = p->h_center_counts[1];
+                p->center_counts_known = true;
+            }
+            uint64_t cgrid = 2 * (uint64_t)nchunks;   // bounds heavy + light entries (fewer than an eighth of the chunks are cut, into at most eight)
+            if (p->center_counts_known) cgrid = std::max<uint64_t>(1, (uint64_t)p->center_counts[0] + p->center_counts[1]);
             // PC_CENTER_DEBUG: how long every dispatched wave ran (wall clock ticks), printed after the launch
             DevBuf<unsigned long long> d_dbg;
             const bool dbg_on = e->knobs.center_debug != 0;
@@ -1873,9 +1907,9 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 HIP_TRY(hipMemsetAsync(d_dbg.p, 0, (size_t)(3 * kCenterCap * nchunks) * 8, st));
             }
             unsigned long long *dbg = dbg_on ? d_dbg.p : nullptr;
-            hipLaunchKernelGGL(k_center, dim3((unsigned)(kCenterCap * nchunks)), dim3(kCenterWG), 0, st, p->d_cchunks.p, nchunks,
-                               e->d_files.p, nfiles, mp, W, e->d_inv.p, e->d_cval.p, p->d_corder.p, e->d_counters.p, p->d_cranges.p,
-                               (double *)p->d_hist.p, dbg);
+            hipLaunchKernelGGL(k_center, dim3((unsigned)((cgrid * 64 + kCenterWG - 1) / kCenterWG)), dim3(kCenterWG), (size_t)e->knobs.center_lds, st, p->d_cchunks.p, nchunks,
+                               e->d_files.p, nfiles, mp, W, e->d_inv.p, e->d_cval.p, p->d_corder.p, p->d_ccounts.p, p->d_cranges.p,
+                               p->d_crec.p, (double *)p->d_hist.p, dbg);
             if (dbg_on) {
                 std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks)), h_slots((size_t)(kCenterCap * nchunks));
                 std::vector<uint32_t> h_order((size_t)(kCenterCap * nchunks)), h_cand((size_t)nchunks);

@@ -335,6 +335,52 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
     assert not bad, "kernels using scratch memory: %s" % bad
 
 
+def test_center_kernel_keeps_its_reserved_registers(tmp_path):
+    """k_center keeps the 1/m table in s[42:73] and the lane masks of two entry groups in s[74:89] across its inline
+    assembly blocks; it is compiled for 48 SGPRs so that the compiler never allocates those.  Checked on the built code
+    object: the kernel stays within 96 SGPRs (eight waves per SIMD), and in its disassembly the table registers are only
+    ever written by the s_load that fills them and read by s_movrels, the mask registers only written by v_readlane
+    and read by s_mov_b64 exec."""
+    import re
+    import shutil
+    import subprocess
+    from plastid_amd import build
+    lib = build.build_library()
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not available")
+    work = tmp_path / "co"
+    work.mkdir()
+    copy = str(work / "lib.so")
+    shutil.copy(lib, copy)
+    subprocess.check_call([objdump, "--offloading", copy], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(work))
+    obj = str(work / [f for f in os.listdir(str(work)) if "gfx950" in f][0])
+    notes = subprocess.check_output([readelf, "--notes", obj]).decode()
+    block = [b for b in notes.split("- .agpr_count")[1:] if re.search(r"\.name:\s+_ZN2pc8k_centerE", b)]
+    assert len(block) == 1
+    assert int(re.search(r"\.sgpr_count:\s+(\d+)", block[0]).group(1)) <= 96
+    symbol = re.search(r"\.name:\s+(_ZN2pc8k_centerE\S+)", block[0]).group(1)
+    dis = subprocess.check_output([objdump, "-d", "--disassemble-symbols=" + symbol, obj]).decode()
+    lines = [ln.split("//")[0].strip() for ln in dis.splitlines() if "\t" in ln]
+    assert len(lines) > 500, "k_center not found in the disassembly"
+    sreg = re.compile(r"\bs\[?(\d+)(?::(\d+))?\]?")
+    seen_table = seen_mask = 0
+    for ln in lines:
+        parts = ln.split(None, 1)
+        if len(parts) < 2:
+            continue
+        op, args = parts[0], parts[1]
+        for m in sreg.finditer(args):
+            lo, hi = int(m.group(1)), int(m.group(2) or m.group(1))
+            if hi >= 42 and lo <= 73:
+                assert op.startswith("s_load_dword") or op == "s_movrels_b64", ln
+                seen_table += 1
+            elif hi >= 74 and lo <= 89:
+                assert op == "v_readlane_b32" or (op == "s_mov_b64" and args.startswith("exec")), ln
+                seen_mask += 1
+    assert seen_table > 100 and seen_mask > 100
+
+
 def test_usable_cpus_respects_the_container_limits():
     """bench.py sizes its thread pools (and reports `cpu_baseline.usable_cores`) by what the process may use:
     hardware threads, affinity mask and the cgroup CPU quota -- the GPU boxes show 256 threads and grant 16."""
