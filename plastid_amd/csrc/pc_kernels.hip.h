@@ -1425,8 +1425,9 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 }
 
 // Replay of a batch.  Lanes j of vlo / vhi / vix hold entry j's 64-bit mask of covered lanes and its table index x 2.
-// Per entry: v_readlane of the index and of the two mask halves, s_mov m0 + s_movrels_b64 (1/m out of the SGPR
-// table), then  s_mov_b64 exec, mask ; v_add_f64 acc, acc, 1/m  -- 4 vector + 3 scalar instructions.  Entries go in
+// Per entry: v_readlane of the two mask halves (and, once per four entries, of their packed table indices), s_bfe m0 +
+// s_movrels_b64 (1/m out of the SGPR table), then  s_mov_b64 exec, mask ; v_add_f64 acc, acc, 1/m  -- 3.25 vector + 3
+// scalar instructions.  Entries go in
 // groups of four, software-pipelined: the twelve v_readlane of group g+1 are issued before the adds of group g and
 // its table look-ups between them, so that a wave that runs alone (the deepest pile-up is the launch's critical
 // path) does not wait for a VALU-written SGPR at every step (scripts/ubench/scalar_stream_probe.hip, forms Ma / Mb /
@@ -1434,9 +1435,7 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 // Fixed registers: the value table in s[42:73], two sets of four masks in s[74:89] -- k_center is compiled for 48
 // SGPRs (s0 - s41 + the six special ones), so the compiler never allocates them, and the kernel as a whole stays
 // within 96: eight waves per SIMD.
-#define PC_C_RL_IDX(S, J0, J1, J2, J3)                                                                                 \
-    "v_readlane_b32 %[si" #S "0], %[vix], " #J0 "\n\tv_readlane_b32 %[si" #S "1], %[vix], " #J1 "\n\t"                  \
-    "v_readlane_b32 %[si" #S "2], %[vix], " #J2 "\n\tv_readlane_b32 %[si" #S "3], %[vix], " #J3 "\n\t"
+#define PC_C_RL_IDX(S, J0, J1, J2, J3) "v_readlane_b32 %[si" #S "], %[vix], " #J0 "\n\t"
 #define PC_C_MASKS_A(J0, J1, J2, J3)                                                                                   \
     "v_readlane_b32 s74, %[vlo], " #J0 "\n\tv_readlane_b32 s75, %[vhi], " #J0 "\n\t"                                    \
     "v_readlane_b32 s76, %[vlo], " #J1 "\n\tv_readlane_b32 s77, %[vhi], " #J1 "\n\t"                                    \
@@ -1448,7 +1447,8 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
     "v_readlane_b32 s86, %[vlo], " #J2 "\n\tv_readlane_b32 s87, %[vhi], " #J2 "\n\t"                                    \
     "v_readlane_b32 s88, %[vlo], " #J3 "\n\tv_readlane_b32 s89, %[vhi], " #J3 "\n\t"
 // (an instruction has to sit between a scalar write of m0 and s_movrels)
-#define PC_C_LOOKUP(S, K) "s_mov_b32 m0, %[si" #S #K "]\n\ts_nop 0\n\ts_movrels_b64 %[val" #S #K "], s[42:43]\n\t"
+#define PC_C_M0(S, K) "s_bfe_u32 m0, %[si" #S "], 0x80000 + 8 * " #K "\n\t"   /* byte K of the group's index word: offset 8 K, width 8 */
+#define PC_C_LOOKUP(S, K) PC_C_M0(S, K) "s_nop 0\n\ts_movrels_b64 %[val" #S #K "], s[42:43]\n\t"
 #define PC_C_ADD(S, K, M) "s_mov_b64 exec, s[" #M "]\n\tv_add_f64 %[acc], %[acc], %[val" #S #K "]\n\t"
 // first group of a block into set A
 #define PC_C_PRO(J0, J1, J2, J3)                                                                                       \
@@ -1456,17 +1456,17 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 // the adds of the group in set A, with group J0..J3 read into set B and looked up in between; and the mirror image
 #define PC_C_STEP_AB(J0, J1, J2, J3)                                                                                   \
     PC_C_RL_IDX(b, J0, J1, J2, J3) PC_C_MASKS_B(J0, J1, J2, J3)                                                         \
-    "s_mov_b64 exec, s[74:75]\n\tv_add_f64 %[acc], %[acc], %[vala0]\n\ts_mov_b32 m0, %[sib0]\n\t"                        \
-    "s_mov_b64 exec, s[76:77]\n\ts_movrels_b64 %[valb0], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala1]\n\ts_mov_b32 m0, %[sib1]\n\t" \
-    "s_mov_b64 exec, s[78:79]\n\ts_movrels_b64 %[valb1], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala2]\n\ts_mov_b32 m0, %[sib2]\n\t" \
-    "s_mov_b64 exec, s[80:81]\n\ts_movrels_b64 %[valb2], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala3]\n\ts_mov_b32 m0, %[sib3]\n\t" \
+    "s_mov_b64 exec, s[74:75]\n\tv_add_f64 %[acc], %[acc], %[vala0]\n\t" PC_C_M0(b, 0) ""                        \
+    "s_mov_b64 exec, s[76:77]\n\ts_movrels_b64 %[valb0], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala1]\n\t" PC_C_M0(b, 1) "" \
+    "s_mov_b64 exec, s[78:79]\n\ts_movrels_b64 %[valb1], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala2]\n\t" PC_C_M0(b, 2) "" \
+    "s_mov_b64 exec, s[80:81]\n\ts_movrels_b64 %[valb2], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala3]\n\t" PC_C_M0(b, 3) "" \
     "s_mov_b64 exec, -1\n\ts_movrels_b64 %[valb3], s[42:43]\n\t"
 #define PC_C_STEP_BA(J0, J1, J2, J3)                                                                                   \
     PC_C_RL_IDX(a, J0, J1, J2, J3) PC_C_MASKS_A(J0, J1, J2, J3)                                                         \
-    "s_mov_b64 exec, s[82:83]\n\tv_add_f64 %[acc], %[acc], %[valb0]\n\ts_mov_b32 m0, %[sia0]\n\t"                        \
-    "s_mov_b64 exec, s[84:85]\n\ts_movrels_b64 %[vala0], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb1]\n\ts_mov_b32 m0, %[sia1]\n\t" \
-    "s_mov_b64 exec, s[86:87]\n\ts_movrels_b64 %[vala1], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb2]\n\ts_mov_b32 m0, %[sia2]\n\t" \
-    "s_mov_b64 exec, s[88:89]\n\ts_movrels_b64 %[vala2], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb3]\n\ts_mov_b32 m0, %[sia3]\n\t" \
+    "s_mov_b64 exec, s[82:83]\n\tv_add_f64 %[acc], %[acc], %[valb0]\n\t" PC_C_M0(a, 0) ""                        \
+    "s_mov_b64 exec, s[84:85]\n\ts_movrels_b64 %[vala0], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb1]\n\t" PC_C_M0(a, 1) "" \
+    "s_mov_b64 exec, s[86:87]\n\ts_movrels_b64 %[vala1], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb2]\n\t" PC_C_M0(a, 2) "" \
+    "s_mov_b64 exec, s[88:89]\n\ts_movrels_b64 %[vala2], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb3]\n\t" PC_C_M0(a, 3) "" \
     "s_mov_b64 exec, -1\n\ts_movrels_b64 %[vala3], s[42:43]\n\t"
 #define PC_C_EPI_A PC_C_ADD(a, 0, 74:75) PC_C_ADD(a, 1, 76:77) PC_C_ADD(a, 2, 78:79) PC_C_ADD(a, 3, 80:81) "s_mov_b64 exec, -1\n\t"
 #define PC_C_EPI_B PC_C_ADD(b, 0, 82:83) PC_C_ADD(b, 1, 84:85) PC_C_ADD(b, 2, 86:87) PC_C_ADD(b, 3, 88:89) "s_mov_b64 exec, -1\n\t"
@@ -1484,12 +1484,11 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 // CODE = PC_C_64 or PC_C_16(B); exec all ones on entry and on exit
 #define PC_CENTER_REPLAY(CODE)                                                                                         \
     do {                                                                                                               \
-        int sia0_, sia1_, sia2_, sia3_, sib0_, sib1_, sib2_, sib3_, m0_;                                               \
+        int sia_, sib_, m0_;                                                                                           \
         double vala0_, vala1_, vala2_, vala3_, valb0_, valb1_, valb2_, valb3_;                                         \
         asm volatile("s_mov_b32 %[m0s], m0\n\t" CODE "s_mov_b32 m0, %[m0s]\n\t"                                        \
-                     : [acc] "+v"(acc), [sia0] "=&s"(sia0_), [sia1] "=&s"(sia1_), [sia2] "=&s"(sia2_),                 \
-                       [sia3] "=&s"(sia3_), [sib0] "=&s"(sib0_), [sib1] "=&s"(sib1_), [sib2] "=&s"(sib2_),             \
-                       [sib3] "=&s"(sib3_), [vala0] "=&s"(vala0_), [vala1] "=&s"(vala1_), [vala2] "=&s"(vala2_),       \
+                     : [acc] "+v"(acc), [sia] "=&s"(sia_), [sib] "=&s"(sib_),                                          \
+                       [vala0] "=&s"(vala0_), [vala1] "=&s"(vala1_), [vala2] "=&s"(vala2_),                            \
                        [vala3] "=&s"(vala3_), [valb0] "=&s"(valb0_), [valb1] "=&s"(valb1_), [valb2] "=&s"(valb2_),     \
                        [valb3] "=&s"(valb3_), [m0s] "=&s"(m0_)                                                         \
                      : [vlo] "v"(mlo), [vhi] "v"(mhi), [vix] "v"(vix)                                                  \
@@ -1577,7 +1576,12 @@ __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) voi
             // the lanes entry j covers, as a 64-bit mask (chunk-relative positions [rlo, rhi))
             const int rel = a0 - ck.start, rlo = rel > 0 ? rel : 0, rhi = rel + m < 64 ? rel + m : 64, nlanes = rhi - rlo;
             const unsigned long long mask = (live && nlanes > 0) ? ((nlanes >= 64 ? ~0ull : ((1ull << nlanes) - 1ull)) << rlo) : 0ull;
-            const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32), vix = live ? tix * 2u : 0u;
+            const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+            // table index x 2 of the entry, and in every fourth lane those of the three entries after it (one byte each)
+            const int ix1 = (int)(live ? tix * 2u : 0u);
+            const uint32_t vix = (uint32_t)ix1 | ((uint32_t)__builtin_amdgcn_update_dpp(0, ix1, 0x101, 0xf, 0xf, true) << 8) |
+                                 ((uint32_t)__builtin_amdgcn_update_dpp(0, ix1, 0x102, 0xf, 0xf, true) << 16) |
+                                 ((uint32_t)__builtin_amdgcn_update_dpp(0, ix1, 0x103, 0xf, 0xf, true) << 24);
             if (nvalid > 32) {
                 n_slots += 64ull;
                 PC_CENTER_REPLAY(PC_C_64);
