@@ -2,6 +2,8 @@
 """Headline benchmark: mapped reads/s of the per-position counting hot path.
 
     python bench.py --gpus 1 --steps K --warmup W            (one process)
+    python bench.py --gpus N ...                             (spawns its N ranks itself: torch.distributed.run as a
+                                                              child process, before this process touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A *step* is one pass of the hot path over one batch: every alignment record of
@@ -18,11 +20,14 @@ each parity-gated against the oracle on a seeded sample of chains; their numbers
 go to ``config.other_configs`` (``--other-configs none`` skips them).
 
 N > 1: ONE job over N GPUs (``--partition genome``, strong scaling): the genome
-is cut at record-count quantiles (``multigpu.GenomePartition``), every
-rank stages its record range plus halo and counts its segment pieces -- no
-data-path collective; per-chain sums are completed by one RCCL all-reduce of the
-engine's device buffer, timed separately.  ``--partition replicas`` gives every
-rank an independent shard of the same shape instead (weak scaling).
+is cut at quantiles of the expected record density (``synth.JobLayout.cuts``,
+SURVEY 8e), every rank GENERATES and stages only its own range plus halo
+(``synth.make_reads_blocked``: no rank ever holds the whole job) and counts its
+segment pieces -- no data-path collective; per-chain sums are completed by one
+RCCL all-reduce of the engine's device buffer, timed separately.  The headline
+is followed by C4 and C5, partitioned the same way (``config.other_configs``).
+``--partition replicas`` gives every rank an independent shard of the same
+shape instead (weak scaling).
 
 Before anything is timed the GPU output is compared bit-for-bit with the oracle
 (``oracle/``) on a seeded sample of chains, and again after the timed steps; a
@@ -97,31 +102,40 @@ def cpu_model():
 
 
 def cpu_baseline(oracle, aln, spec, p, tx, n_records, budget_s, rng):
-    """Time the oracle (C port of the reference algorithm, one thread) on a bounded, seeded sample
-    of chains; report whole-job-equivalent reads/s.  Returns the sampled segments and their oracle
-    arrays too (they are the parity gate of the GPU run)."""
+    """Time the oracle (C port of the reference algorithm, one thread) on a bounded, seeded sample of chains and
+    report whole-job-equivalent reads/s.  The oracle derives per-record arrays (end coordinates, contig ranges) once
+    per call: that preparation is timed on its own (a call without segments) and enters the whole-job estimate ONCE,
+    time = preparation + counting time / sampled fraction.  Returns the sampled segments and their oracle arrays too
+    (they are the parity gate of the GPU run)."""
     order = rng.permutation(tx.n)
-    done, t_used, results = 0, 0.0, []
-    batch = 50
-    while done < tx.n and t_used < budget_s:
-        chains = order[done:done + batch]
+    none = np.zeros(0, np.int64)
+
+    def run(chains):
         sel = segments_of_chains(tx, chains)
         t0 = time.perf_counter()
         arrays, _ = oracle.count_segments(aln, spec, p["tid"][sel], p["start"][sel], p["end"][sel], p["strand"][sel])
-        t_used += time.perf_counter() - t0
-        results.append((sel, arrays))
-        done += len(chains)
-        if t_used > 0:
-            rate = done / t_used
-            batch = int(max(50, min(tx.n - done, rate * max(budget_s - t_used, 0.5) * 0.5)))
+        return sel, arrays, time.perf_counter() - t0
+    _, _, t_prep = run(none)
+    n_cal = min(tx.n, 20)
+    sel0, arr0, t_cal = run(order[:n_cal])
+    per_chain = max(t_cal - t_prep, 1e-6) / n_cal
+    n_main = int(min(tx.n - n_cal, max(0, (budget_s - t_prep - t_cal) / per_chain)))
+    results = [(sel0, arr0)]
+    t_work, done = max(t_cal - t_prep, 1e-6), n_cal
+    if n_main > 0:
+        sel1, arr1, t_main = run(order[n_cal:n_cal + n_main])
+        results.append((sel1, arr1))
+        t_work += max(t_main - t_prep, 1e-6)
+        done += n_main
     frac = done / float(tx.n)
-    value = n_records * frac / t_used
     sel_all = np.concatenate([s for s, _ in results])
     arrays_all = [a for _, arrs in results for a in arrs]
-    return {"value": value, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "oracle/plastid_oracle.c (C port of the reference algorithm, 1 thread) over %d of %d "
-                      "transcripts (seeded sample) against all %d records: %.1f s; value = records x "
-                      "sampled fraction / time" % (done, tx.n, n_records, t_used)}, sel_all, arrays_all, order[:done]
+    return {"value": n_records / (t_prep + t_work / frac), "unit": "reads/s", "cores": 1, "kind": "port",
+            "value_excluding_preparation": n_records * frac / t_work,
+            "sample": "oracle/plastid_oracle.c (C port of the reference algorithm, 1 thread) over %d of %d transcripts "
+                      "(seeded sample) against all %d records: %.1f s of counting + %.2f s once-per-file preparation; "
+                      "value = records / (preparation + counting time / sampled fraction)" % (done, tx.n, n_records, t_work, t_prep),
+            "preparation_s": t_prep}, sel_all, arrays_all, order[:done]
 
 
 def usable_cpus():
@@ -148,35 +162,46 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline_all_cores(oracle, aln, spec, p, tx, n_records, budget_s, rng, one_core_value):
+def cpu_baseline_all_cores(oracle, aln, spec, p, tx, n_records, budget_s, rng, one_core):
     """The same oracle on EVERY host core this process may use (usable_cpus: the GPU boxes grant a CFS
     quota well below the 256 hardware threads they show): the per-record arrays are derived once and
     shared, the segments are dealt to one POSIX thread per core (the reference itself is
     single-threaded; whole segments per thread is the most favourable honest scaling).  The sample is
-    sized from the one-core rate so that it takes about `budget_s` seconds of wall time."""
+    sized from the one-core rate so that it takes about `budget_s` seconds of wall time.  The preparation
+    is single-threaded; `value` counts it once for the whole job, as the one-core figure does."""
     cores = usable_cpus()
     if cores < 2:
         return None
-    per_chain_s = (n_records / max(one_core_value, 1.0)) / tx.n          # one-core seconds per chain
-    nch = int(min(tx.n, max(4 * cores, budget_s * cores * 0.7 / max(per_chain_s, 1e-9))))
+    prep = one_core["preparation_s"]
+    per_chain_s = (n_records / max(one_core["value_excluding_preparation"], 1.0)) / tx.n          # one-core seconds per chain
+    nch = int(min(tx.n, max(4 * cores, (budget_s - prep) * cores * 0.7 / max(per_chain_s, 1e-9))))
     chains = rng.permutation(tx.n)[:nch]
     sel = segments_of_chains(tx, chains)
-    none = sel[:0]
-    t0 = time.perf_counter()       # the once-per-file preparation (end coordinates, contig ranges), single-threaded
-    oracle.count_segments(aln, spec, p["tid"][none], p["start"][none], p["end"][none], p["strand"][none])
-    prep = time.perf_counter() - t0
     t0 = time.perf_counter()
     oracle.count_segments(aln, spec, p["tid"][sel], p["start"][sel], p["end"][sel], p["strand"][sel], threads=cores)
     wall = time.perf_counter() - t0
     work = max(wall - prep, 1e-6)
-    return {"value": n_records * (nch / float(tx.n)) / work, "unit": "reads/s", "cores": cores,
+    frac = nch / float(tx.n)
+    return {"value": n_records / (prep + work / frac), "unit": "reads/s", "cores": cores,
+            "value_excluding_preparation": n_records * frac / work,
             "sample": "%d of %d transcripts dealt to %d threads of one process (per-record arrays derived once and shared): "
-                      "%.2f s wall, of which %.2f s is that single-threaded once-per-file preparation (excluded from the rate)"
-                      % (nch, tx.n, cores, wall, prep)}
+                      "%.2f s wall, of which %.2f s is the single-threaded once-per-file preparation; value = records / "
+                      "(preparation + threaded counting time / sampled fraction)" % (nch, tx.n, cores, wall, prep)}
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the kernel sources: what a PMC-derived traffic figure belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("plastid_amd/csrc/pc_kernels.hip.h", "plastid_amd/csrc/plastid_counts.hip"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def load_traffic(config, n_records):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json)."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json) -- only
+    when the entry was measured on THESE kernel sources (`kernel_source_sha16`); a changed kernel reports null."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         tj = json.load(open(tpath))
@@ -184,16 +209,35 @@ def load_traffic(config, n_records):
         return None, None
     for entry in ([tj] + list(tj.get("configs", {}).values())) if isinstance(tj, dict) else []:
         if entry.get("config") == config and int(entry.get("n_records", -1)) == n_records:
+            if entry.get("kernel_source_sha16") != kernel_source_hash():
+                return None, entry
             return entry.get("hbm_bytes_per_launch"), entry
     return None, None
+
+
+def peak_rss_mb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+
+
+def engine_class():
+    """The engine: plastid_amd.engine.Engine (HIP, no CPU path).  PC_BENCH_ENGINE names a stand-in module for
+    REHEARSALS of the multi-rank control flow on a box without GPUs (tests/oracle_engine.py); a line produced that
+    way says so and carries no value."""
+    name = os.environ.get("PC_BENCH_ENGINE")
+    if name:
+        import importlib
+        return importlib.import_module(name).Engine, True
+    from plastid_amd.engine import Engine
+    return Engine, False
 
 
 def run_workload(name, args, ctx, headline):
     """One BASELINE config through the hot path.  Returns the result dict of that config."""
     from oracle import oracle
     from plastid_amd import multigpu
-    from plastid_amd.engine import Engine
     from plastid_amd.packing import concat_file_major
+    Engine, _ = engine_class()
     rank, world = ctx["rank"], ctx["world"]
     partition = ctx["partition"] if world > 1 else "none"
     steps = args.steps if headline else max(3, min(args.steps, 10))
@@ -218,10 +262,12 @@ def run_workload(name, args, ctx, headline):
     aln = concat_file_major([reads])
     spec = oracle_spec(oracle, mapping)
     rng = np.random.default_rng(7 + (rank if partition == "replicas" else 0))
-    if headline and rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, check_sel, check_arrays, _ = cpu_baseline(oracle, aln, spec, p, tx, reads.n, args.cpu_budget, rng)
-        cpu["all_cores"] = cpu_baseline_all_cores(oracle, aln, spec, p, tx, reads.n, min(args.cpu_budget, 10.0),
-                                                  np.random.default_rng(8), cpu["value"])
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # (beside every config: the other configs get ~10 s per figure so that the default run stays within minutes)
+        budget = args.cpu_budget if headline else min(args.cpu_budget, 10.0)
+        cpu, check_sel, check_arrays, _ = cpu_baseline(oracle, aln, spec, p, tx, reads.n, budget, rng)
+        cpu["all_cores"] = cpu_baseline_all_cores(oracle, aln, spec, p, tx, reads.n, min(budget, 10.0),
+                                                  np.random.default_rng(8), cpu)
         cpu["cpu_model"] = cpu_model()
         cpu["host_cores"] = os.cpu_count()
         cpu["usable_cores"] = usable_cpus()
@@ -238,17 +284,9 @@ def run_workload(name, args, ctx, headline):
     del aln
     exp = sparse_expected(check_arrays, p, check_sel, rows)        # (element indices, values) of the sampled chains
     sf_exp = sparse_expected(sf_arrays, p, sf_sel, rows)
-    seg_sums = {int(s): a.reshape(rows, -1).sum(axis=1) for a, s in zip(check_arrays, check_sel)}  # for the chain-sum check
     del check_arrays, sf_arrays
 
-    # ---------------------------------------------------------------- partition (N > 1, one job)
-    gp = None
-    my_reads, lp = reads, p
-    balance = None
-    if partition == "genome":
-        gp = multigpu.GenomePartition([reads], p, world)
-        my_reads = gp.records(rank)[0]
-        lp = gp.local_plan_arrays(rank, rows)
+    my_reads, lp = reads, p     # (N > 1 here means independent replicas; the one-job mode is run_partitioned)
 
     # ---------------------------------------------------------------- GPU
     import torch
@@ -268,24 +306,13 @@ def run_workload(name, args, ctx, headline):
                           pin_memory=int(lp["out_elems"]) * 8 <= (1 << 30))
     out_buf = out_pin.numpy()
 
-    # where the sampled elements live in THIS rank's output: (local element index, global element index)
-    own = None if gp is None else gp.owned_elements(rank, rows, np.concatenate([check_sel, sf_sel]))
-
     def gate(expected, what):
-        """Bit-exact comparison of the sampled elements this rank owns with the oracle."""
+        """Bit-exact comparison of the sampled elements with the oracle."""
         got = plan.read(out_buf)
         e_idx, e_val = expected
-        if own is None:
-            ok, n = np.array_equal(got[e_idx], e_val.astype(got.dtype)), len(e_idx)
-        else:
-            li_, gi_ = own
-            pos = np.searchsorted(e_idx, gi_)
-            pos[pos >= len(e_idx)] = 0
-            hit = (e_idx[pos] == gi_) if len(e_idx) else np.zeros(len(gi_), bool)
-            ok, n = np.array_equal(got[li_[hit]], e_val[pos[hit]].astype(got.dtype)), int(hit.sum())
-        if not ok:
+        if not np.array_equal(got[e_idx], e_val.astype(got.dtype)):
             raise SystemExit("PARITY FAILURE (%s, %s): HIP counts differ from the oracle on the sampled chains" % (name, what))
-        return n
+        return len(e_idx)
 
     for _ in range(warmup):
         plan.launch(out_dtype)
@@ -338,47 +365,9 @@ def run_workload(name, args, ctx, headline):
 
     # ---------------------------------------------------------------- collectives
     n_records_all, counts_all, positions_all = multigpu.allreduce_int_totals(
-        [int(my_reads.n) if partition != "genome" else (int(reads.n) if rank == 0 else 0),
-         int(total_counts) if not center else 0, int(lp["out_elems"])], device=ctx["tdev"])
+        [int(my_reads.n), int(total_counts) if not center else 0, int(lp["out_elems"])], device=ctx["tdev"])
     if center:
         counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device=ctx["tdev"])[0]
-    allreduce = None
-    if gp is not None:
-        balance = multigpu.allreduce_int_totals([int(my_reads.n) if r == rank else 0 for r in range(world)], device=ctx["tdev"])
-        if not center:
-            # per-chain sums: every rank sums its pieces into one slot per (chain, row); ONE all-reduce
-            # of the engine's device buffer completes the chains that straddle a cut
-            seg_chain = np.repeat(np.arange(tx.n, dtype=np.int64), np.diff(tx.ex_off))
-            sp = gp.chain_sum_plan_arrays(rank, seg_chain, tx.n, rows)
-            splan = eng.plan(sp["tid"], sp["start"], sp["end"], sp["strand"], sp["out_off"], sp["out_step"], sp["row_stride"],
-                             sp["out_elems"], rows)
-            exp_sums = {}
-            for c in np.unique(seg_chain[check_sel]):
-                segs = np.arange(tx.ex_off[c], tx.ex_off[c + 1])
-                if all(int(s_) in seg_sums for s_ in segs):
-                    exp_sums[int(c)] = sum(seg_sums[int(s_)] for s_ in segs).astype(np.int64)
-            times = []
-            for it in range(4):
-                splan.launch(np.int64)
-                eng.sync()
-                torch.cuda.synchronize()
-                multigpu.barrier()
-                t0 = time.perf_counter()
-                if ctx["backend"] == "nccl":
-                    t = multigpu.allreduce_device_sums(splan.device_ptr, tx.n * rows, "int64")
-                    torch.cuda.synchronize()
-                    sums = None
-                else:   # rehearsal on CPU ranks (gloo): through the host
-                    sums = multigpu.allreduce_chain_sums(splan.read(), device="cpu")
-                times.append(time.perf_counter() - t0)
-            if sums is None:
-                sums = t.cpu().numpy()
-            for c, acc in exp_sums.items():
-                if not np.array_equal(sums[c * rows:(c + 1) * rows], acc):
-                    raise SystemExit("PARITY FAILURE (%s): all-reduced chain sums differ from the oracle" % name)
-            allreduce = {"what": "per-chain sums, int64[%d], RCCL all-reduce of the engine's device buffer" % (tx.n * rows),
-                         "ms": min(times[1:]) * 1e3, "chains_checked_vs_oracle": len(exp_sums)}
-            splan.close()
 
     # ---------------------------------------------------------------- result of this config
     n_extra_runs = int(len(my_reads.blk_start))
@@ -428,9 +417,206 @@ def run_workload(name, args, ctx, headline):
                      "algorithmic_bytes_per_launch": int(kern_alg_bytes), "avg_launch_ms": kern_ms},
         "cpu_baseline": cpu,
     }
-    if gp is not None:
-        res["partition"] = {"mode": "genome ranges at record-count quantiles (multigpu.GenomePartition)",
-                            "records_per_rank": balance, "halo_positions": int(gp.halo), "allreduce": allreduce}
+    ctx["last_engine_objects"] = (eng, plan, my_reads)
+    return res
+
+
+def run_partitioned(name, args, ctx, headline):
+    """One BASELINE config as ONE job over the ranks (N > 1, ``--partition genome``): every rank generates, stages
+    and counts only its own genome range.  Parity: every rank compares the sampled segment pieces it
+    owns with the oracle run on ITS records (the cut is exact for all rules, tests/test_distributed_cpu.py), the
+    per-chain sums after the device all-reduce with the all-reduced oracle sums."""
+    from oracle import oracle
+    from plastid_amd import multigpu
+    from plastid_amd.packing import concat_file_major
+    Engine, rehearsal = engine_class()
+    rank, world = ctx["rank"], ctx["world"]
+    steps = args.steps if headline else max(3, min(args.steps, 10))
+    warmup = max(args.warmup, 1) if headline else 2
+
+    # ---------------------------------------------------------------- this rank's share of the inputs (host)
+    t0 = time.perf_counter()
+    genome, tx, lay, mapping = synth.job_layout(name, scale=args.scale, tx_scale=args.tx_scale)
+    cuts = lay.cuts(world)
+    lo, hi = lay.rank_range(cuts, rank)
+    my_reads = synth.make_reads_blocked(lay, max(0, lo - lay.halo), hi)
+    gen_s = time.perf_counter() - t0
+    owned = int(((lay.tid_off[my_reads.tid] + my_reads.pos) >= lo).sum())
+    center = mapping[0] == "center"
+    out_dtype = np.float64 if (center or args.out_dtype == "float64") else np.int64
+    factory = synth.mapping_factory(mapping)
+    rows = getattr(factory, "_numlengths", 1)
+    p = tx.plan_arrays(rows=rows)
+    gp = multigpu.GenomePartition.from_cuts(p, world, lay.tid_off, cuts, lay.halo)
+    lp = gp.local_plan_arrays(rank, rows)
+    piece_owner = gp.piece["owner"][lp["piece_index"]]          # global segment of every local piece
+
+    # ---------------------------------------------------------------- oracle on the rank's own records: parity sample
+    aln = concat_file_major([my_reads])
+    spec = oracle_spec(oracle, mapping)
+    chains = np.random.default_rng(7).permutation(tx.n)[:min(tx.n, args.parity_chains)]      # the same chains on every rank
+    sampled = np.zeros(len(p["tid"]), bool)
+    sampled[segments_of_chains(tx, chains)] = True
+
+    def local_expectation(sp, pieces):
+        arrays, _ = oracle.count_segments(aln, sp, lp["tid"][pieces], lp["start"][pieces], lp["end"][pieces], lp["strand"][pieces])
+        idxs, vals = [], []
+        for a, j in zip(arrays, pieces):
+            n = a.shape[-1]
+            idxs.append((lp["out_off"][j] + (np.arange(rows)[:, None] * n + np.arange(n)[None, :])).reshape(-1))   # rank-local layout: [rows, len]
+            vals.append(a.reshape(-1))
+        if not idxs:
+            return np.zeros(0, np.int64), np.zeros(0, out_dtype), arrays
+        return np.concatenate(idxs), np.concatenate(vals), arrays
+    pieces = np.nonzero(sampled[piece_owner])[0]
+    exp_idx, exp_val, piece_arrays = local_expectation(spec, pieces)
+    sf_chains = np.random.default_rng(9).permutation(tx.n)[:min(tx.n, 40)]
+    sf_sampled = np.zeros(len(p["tid"]), bool)
+    sf_sampled[segments_of_chains(tx, sf_chains)] = True
+    sf_idx, sf_val, _ = local_expectation(oracle_spec(oracle, mapping, SIZE_FILTER), np.nonzero(sf_sampled[piece_owner])[0])
+    # the oracle's share of the per-chain sums (completed across the ranks below)
+    seg_chain = np.repeat(np.arange(tx.n, dtype=np.int64), np.diff(tx.ex_off))
+    oracle_part = np.zeros(tx.n * rows, np.int64)
+    if not center:
+        for a, j in zip(piece_arrays, pieces):
+            oracle_part[seg_chain[piece_owner[j]] * rows:(seg_chain[piece_owner[j]] + 1) * rows] += a.reshape(rows, -1).sum(axis=1)
+    del aln, piece_arrays
+
+    # ---------------------------------------------------------------- GPU
+    import torch
+    eng = Engine(ctx["dev_index"])
+    t0 = time.perf_counter()
+    eng.set_alignments([my_reads])
+    stage_s = time.perf_counter() - t0
+    factory._configure(eng)
+    t0 = time.perf_counter()
+    plan = eng.plan(lp["tid"], lp["start"], lp["end"], lp["strand"], lp["out_off"], lp["out_step"], lp["row_stride"],
+                    lp["out_elems"], rows)
+    plan_s = time.perf_counter() - t0
+    out_buf = np.zeros(int(lp["out_elems"]), out_dtype)
+
+    def gate(idx, val, what):
+        got = plan.read(out_buf)
+        if not np.array_equal(got[idx], val.astype(got.dtype)):
+            raise SystemExit("PARITY FAILURE (%s, rank %d, %s): HIP counts differ from the oracle on the sampled pieces" % (name, rank, what))
+        return len(idx)
+    for _ in range(warmup):
+        plan.launch(out_dtype)
+    eng.sync()
+    t0 = time.perf_counter()
+    plan.read(out_buf)
+    read_s = time.perf_counter() - t0
+    n_checked = gate(exp_idx, exp_val, "before timing")
+    total_counts = plan.total()
+
+    # ---------------------------------------------------------------- timed region
+    multigpu.barrier()
+    if not rehearsal:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.launch(out_dtype)
+    eng.sync()
+    if not rehearsal:
+        torch.cuda.synchronize()
+    multigpu.barrier()
+    elapsed = multigpu.max_over_ranks(time.perf_counter() - t0, device=ctx["tdev"])
+    gate(exp_idx, exp_val, "output of the last timed step")
+
+    phases = {"total": 0.0, "worklist": 0.0, "hist": 0.0, "long": 0.0, "gather": 0.0, "zero": 0.0}
+    m = max(3, min(steps, 20))
+    eng.set_profiling(2)
+    for _ in range(m):
+        plan.launch(out_dtype)
+        eng.sync()
+        for k, v in eng.last_timing().items():
+            phases[k] += v / m
+    eng.set_profiling(0)
+    alg_bytes_step = eng.last_algorithmic_bytes()
+
+    eng.set_size_filter(*SIZE_FILTER)
+    plan.launch(out_dtype)
+    eng.sync()
+    n_sf = gate(sf_idx, sf_val, "SizeFilterFactory(25,100)")
+    eng.set_size_filter(None)
+
+    # ---------------------------------------------------------------- collectives
+    tot = multigpu.allreduce_int_totals([owned, int(total_counts) if not center else 0, int(lp["out_elems"]), n_checked, n_sf],
+                                        device=ctx["tdev"])
+    n_records_all, counts_all, positions_all, checked_all, sf_all = tot
+    if n_records_all != lay.n:
+        raise SystemExit("partition (%s): the ranks own %d records, the job has %d" % (name, n_records_all, lay.n))
+    if center:
+        counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device=ctx["tdev"])[0]
+    per_rank = lambda v: multigpu.allreduce_int_totals([int(v) if r == rank else 0 for r in range(world)], device=ctx["tdev"])
+    balance, staged, rss = per_rank(owned), per_rank(my_reads.n), per_rank(peak_rss_mb())
+    gen_all = per_rank(round(gen_s * 1e3))
+    allreduce = None
+    if not center:
+        sp = gp.chain_sum_plan_arrays(rank, seg_chain, tx.n, rows)
+        splan = eng.plan(sp["tid"], sp["start"], sp["end"], sp["strand"], sp["out_off"], sp["out_step"], sp["row_stride"],
+                         sp["out_elems"], rows)
+        want = multigpu.allreduce_chain_sums(oracle_part, device=ctx["tdev"])     # the oracle's sums, completed the same way
+        times = []
+        for it in range(4):
+            splan.launch(np.int64)
+            eng.sync()
+            multigpu.barrier()
+            t0 = time.perf_counter()
+            if ctx["backend"] == "nccl" and not rehearsal:
+                torch.cuda.synchronize()
+                t = multigpu.allreduce_device_sums(splan.device_ptr, tx.n * rows, "int64")
+                torch.cuda.synchronize()
+                sums = t.cpu().numpy() if it == 3 else None
+            else:   # rehearsal on CPU ranks (gloo): through the host
+                sums = multigpu.allreduce_chain_sums(splan.read(), device="cpu")
+            times.append(time.perf_counter() - t0)
+        nchk = 0
+        for c in chains:
+            if not np.array_equal(sums[c * rows:(c + 1) * rows], want[c * rows:(c + 1) * rows]):
+                raise SystemExit("PARITY FAILURE (%s): all-reduced chain sums differ from the oracle" % name)
+            nchk += 1
+        allreduce = {"what": "per-chain sums, int64[%d], RCCL all-reduce of the engine's device buffer" % (tx.n * rows),
+                     "ms": min(times[1:]) * 1e3, "chains_checked_vs_oracle": nchk}
+        splan.close()
+
+    n_extra_runs = int(len(my_reads.blk_start))
+    kern_alg_bytes = (my_reads.n * 8 + n_extra_runs * 8 + (plan.positions * 8 if center else len(lp["tid"]) * 24 + int(lp["out_elems"]) * 8))
+    kern_ms = phases["hist"]
+    achieved = kern_alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    ms_per_step = elapsed / steps * 1e3
+    value = n_records_all * steps / elapsed
+    res = {
+        "workload": WORKLOAD_TEXT[name] + ("" if args.scale == 1.0 else " [scaled x%g]" % args.scale) + " -- one job over %d ranks" % world,
+        "value": None if rehearsal else value, "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
+        "dtype": "float64" if out_dtype == np.float64 else "int64",
+        "records_per_gpu": owned, "records_total": int(n_records_all),
+        "chains": int(tx.n), "segments": int(tx.n_segments), "output_positions_per_gpu": int(lp["out_elems"]),
+        "island_positions": int(plan.positions), "tiles": int(plan.tiles), "rows": rows,
+        "mapping": [str(x) for x in mapping], "read_seed": synth.CONFIGS[name][5], "transcript_seed": synth.CONFIGS[name][3],
+        "positions_per_sec": positions_all * steps / elapsed,
+        "parity": "bit-exact vs oracle on %d output positions over all ranks (every rank: its pieces of a seeded sample of "
+                  "chains against the oracle on its own records), before the timed steps and on the output of the last one" % checked_all,
+        "sum_of_counts_all_ranks": counts_all,
+        "host_generate_s": round(gen_s, 2), "host_stage_s": round(stage_s, 3), "host_read_outputs_s": round(read_s, 4),
+        "plan_build_ms_once_per_annotation": round(plan_s * 1e3, 2),
+        "algorithmic_bytes_per_step": int(alg_bytes_step),
+        "step_GBps_algorithmic": alg_bytes_step / (ms_per_step * 1e-3) / 1e9,
+        "kernel_ms": {k: round(v, 4) for k, v in phases.items()},
+        "size_filter_variant": {"filter": "SizeFilterFactory(25,100)", "parity": "bit-exact vs oracle on %d positions over all ranks" % sf_all},
+        "scopes": {"kernel_reads_per_s": value,
+                   "staged_reads_per_s": lay.n / (multigpu.max_over_ranks(stage_s + read_s, device=ctx["tdev"]) + ms_per_step * 1e-3)},
+        "roofline": {"bound": "hbm", "kernel": "k_center" if center else "k_hist_point", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "what": "rank 0's launch: its records and outputs",
+                     "algorithmic_bytes_per_launch": int(kern_alg_bytes), "avg_launch_ms": kern_ms},
+        "cpu_baseline": None,
+        "partition": {"mode": "genome ranges at quantiles of the expected record density (synth.JobLayout.cuts); every rank generates "
+                              "and stages only its range (synth.make_reads_blocked)",
+                      "records_per_rank": balance, "records_staged_per_rank": staged, "halo_positions": int(lay.halo),
+                      "host_generate_ms_per_rank": gen_all, "peak_host_rss_MB_per_rank": rss, "allreduce": allreduce},
+    }
+    if rehearsal:
+        res["rehearsal"] = "engine stand-in %s: control flow only, no measurement" % os.environ.get("PC_BENCH_ENGINE")
     ctx["last_engine_objects"] = (eng, plan, my_reads)
     return res
 
@@ -508,11 +694,30 @@ def main():
     args = ap.parse_args()
     t_start = time.perf_counter()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: spawn the N ranks (one per GPU) as a child torch.distributed.run and relay its
+        # one JSON line and exit code.  This process has not touched a GPU (no torch import, no HIP call) and never does.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE)
+        line = None
+        for ln in proc.stdout.decode("utf-8", "replace").splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+            elif ln.strip():
+                print(ln, file=sys.stderr)
+        if line:
+            print(line)
+        raise SystemExit(proc.returncode if (proc.returncode or line) else 1)
+
     from plastid_amd import multigpu
     rank, local_rank, world = multigpu.env_rank()
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     partition = "genome" if args.partition == "auto" else args.partition
 
@@ -521,19 +726,23 @@ def main():
     # one rank per GPU over RCCL.  PC_BENCH_BACKEND=gloo is a rehearsal aid only: it lets the
     # multi-rank flow run on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("PC_BENCH_BACKEND", "nccl")
+    rehearsal = engine_class()[1]
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     ctx = {"rank": rank, "world": world, "partition": partition, "backend": backend, "dev_index": dev_index,
            "tdev": "cuda" if backend == "nccl" else "cpu"}
 
     # The CPU baseline of the headline runs before this process initialises the GPU only in the
     # sense that it never touches it; run_workload does oracle work first, then creates the engine.
-    torch.cuda.set_device(dev_index)
-    multigpu.init(backend, device=torch.device("cuda", dev_index))  # "nccl" is RCCL on ROCm
+    if not rehearsal:
+        torch.cuda.set_device(dev_index)
+    multigpu.init(backend, device=None if rehearsal else torch.device("cuda", dev_index))  # "nccl" is RCCL on ROCm
+    one_job = world > 1 and partition == "genome"
+    run_config = run_partitioned if one_job else run_workload
 
-    head = run_workload(args.config, args, ctx, headline=True)
+    head = run_config(args.config, args, ctx, headline=True)
     eng, plan, _reads = ctx.pop("last_engine_objects")
     stream_peak = None
-    if rank == 0:
+    if rank == 0 and not rehearsal:
         try:
             rd, wr = eng.stream_probe(1 << 30, 5)
             stream_peak = {"read_GBps": rd, "write_GBps": wr,
@@ -549,13 +758,14 @@ def main():
     others = {}
     want = args.other_configs
     if want == "auto":
-        want = "C3,C4,C5" if (world == 1 and args.config == "C2" and args.scale == 1.0) else "none"
+        # N = 1: the other single-GPU configs; N > 1: the two configs BASELINE.json labels 8 x MI355X, as one job each
+        want = ("C3,C4,C5" if world == 1 else ("C4,C5" if one_job else "none")) if (args.config == "C2" and args.scale == 1.0) else "none"
     names = [c for c in want.split(",") if c and c != "none" and c != args.config]
     for c in names:
         if time.perf_counter() - t_start > args.time_budget:
             others[c] = {"skipped": "time budget of %.0f s used up before this config" % args.time_budget}
             continue
-        r = run_workload(c, args, ctx, headline=False)
+        r = run_config(c, args, ctx, headline=False)
         e2, p2, _r2 = ctx.pop("last_engine_objects")
         p2.close()
         e2.close()
@@ -568,7 +778,8 @@ def main():
                      "kernel_ms": r["kernel_ms"], "roofline": r["roofline"], "size_filter_variant": r["size_filter_variant"],
                      "scopes": r["scopes"], "host_generate_s": r["host_generate_s"], "host_stage_s": r["host_stage_s"],
                      "host_read_outputs_s": r["host_read_outputs_s"],
-                     "plan_build_ms_once_per_annotation": r["plan_build_ms_once_per_annotation"]}
+                     "plan_build_ms_once_per_annotation": r["plan_build_ms_once_per_annotation"],
+                     "cpu_baseline": r["cpu_baseline"]}
         if "partition" in r:
             others[c]["partition"] = r["partition"]
 
@@ -600,6 +811,8 @@ def main():
         config["scopes"] = scopes
         if "partition" in head:
             config["partition"] = head["partition"]
+        if "rehearsal" in head:
+            config["rehearsal"] = head["rehearsal"]
         if others:
             config["other_configs"] = others
         config["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
@@ -615,7 +828,7 @@ def main():
             "scaling": "weak" if (world == 1 or partition == "replicas") else "strong",
             "vs_baseline": None,
             "dtype": head["dtype"],
-            "data": "synthetic",
+            "data": "synthetic" if not one_job else "synthetic (range-addressable generator: every rank draws its own genome range of the one job)",
             "config": config,
             "roofline": roof,
             "cpu_baseline": head["cpu_baseline"],

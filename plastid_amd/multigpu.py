@@ -132,6 +132,27 @@ class GenomePartition(object):
             self.cuts = np.full(max(self.world - 1, 0), self.tid_off[-1], np.int64)
         self._build_pieces(known)
 
+    @classmethod
+    def from_cuts(cls, segments, world, tid_off, cuts, halo):
+        """The same partition from GIVEN cut points (linear genome coordinates under `tid_off`) and halo, without
+        any alignment file: what a rank builds when it only ever holds its own range of the job
+        (``synth.JobLayout.cuts``; bench.py --gpus N).  Everything that concerns the segments -- pieces, rank-local
+        layouts, owned elements, chain-sum plans -- works as usual; ``records`` / ``record_ranges`` need files."""
+        self = cls.__new__(cls)
+        self.files = []
+        self.world = int(world)
+        self.seg = {k: np.asarray(v) for k, v in segments.items() if k in
+                    ("tid", "start", "end", "strand", "out_off", "out_step", "row_stride")}
+        self.tid_off = np.asarray(tid_off, np.int64)
+        self.ntid = len(self.tid_off) - 1
+        self.halo = int(halo)
+        self._keys = []
+        self.cuts = np.asarray(cuts, np.int64)
+        if len(self.cuts) != max(self.world - 1, 0):
+            raise ValueError("GenomePartition.from_cuts: %d cut points for %d ranks" % (len(self.cuts), self.world))
+        self._build_pieces((self.seg["tid"] >= 0) & (self.seg["tid"] < self.ntid))
+        return self
+
     def cut_coordinates(self):
         """The cut points as ``(tid, pos)`` pairs."""
         t = np.searchsorted(self.tid_off, self.cuts, side="right") - 1

@@ -291,6 +291,283 @@ def make_reads(genome, tx, n, seed, paired=False, in_tx_frac=0.9, del_frac=0.01,
                             mapped=nrec, validate=nrec <= 5_000_000)
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Range-addressable generator (bench.py --gpus N: every rank generates ONLY its genome range of the one job).
+#
+# The job is defined unit by unit -- unit t = the reads of transcript t, unit n_tx + w = the background reads of genome
+# window w -- with record counts that follow deterministically from the seed (largest-remainder apportionment of the
+# read total over the expression weights / window lengths) and one ``default_rng([seed, 1, unit])`` per unit.  A rank
+# draws the units whose reads can fall into its range, in unit order, keeps the records that start inside the range
+# and sorts them by the job's canonical order: (tid, pos), multi-run reads before single-run reads of the same start,
+# single-run reads by (aligned length, strand), multi-run reads by (unit, draw order).  The union of the ranks' owned
+# records IS the job (``make_reads_blocked(layout)`` generates it whole), whatever the number of ranks.
+# Same distributions as ``make_reads``; not the same draws: N = 1 keeps ``make_reads``.
+def _apportion(total, weights):
+    """Largest-remainder apportionment of `total` over `weights` (deterministic, sums to `total`)."""
+    weights = np.asarray(weights, np.float64)
+    if total <= 0 or len(weights) == 0 or weights.sum() <= 0:
+        return np.zeros(len(weights), np.int64)
+    q = total * (weights / weights.sum())
+    base = np.floor(q).astype(np.int64)
+    rem = int(total - base.sum())
+    if rem > 0:
+        order = np.argsort(-(q - base), kind="stable")
+        base[order[:rem]] += 1
+    return base
+
+
+class JobLayout(object):
+    """Record counts per unit, linear genome coordinates and rank cuts of one blocked job."""
+
+    def __init__(self, genome, tx, n, seed, paired=False, in_tx_frac=0.9, del_frac=0.01, expr_sigma=1.5, bg_window=1 << 16):
+        names, lengths = genome
+        self.genome, self.tx, self.n, self.seed, self.paired, self.del_frac = genome, tx, int(n), int(seed), bool(paired), del_frac
+        self.lengths = np.asarray(lengths, np.int64)
+        nfrag = n // 2 if paired else n
+        n_in = int(round(nfrag * in_tx_frac)) if tx is not None and tx.n else 0
+        rng = np.random.default_rng([self.seed, 0])
+        w = np.exp(rng.normal(0.0, expr_sigma, tx.n)) if n_in else np.zeros(0)
+        self.tx_count = _apportion(n_in, w)                                     # fragments per transcript
+        wt, ws = [], []
+        for t, ln in enumerate(self.lengths):
+            s0 = np.arange(0, int(ln), bg_window, dtype=np.int64)
+            wt.append(np.full(len(s0), t, np.int64)); ws.append(s0)
+        self.win_tid = np.concatenate(wt); self.win_start = np.concatenate(ws)
+        self.win_len = np.minimum(bg_window, self.lengths[self.win_tid] - self.win_start)
+        self.win_count = _apportion(nfrag - n_in, self.win_len)                 # fragments per background window
+        self.tid_off = np.zeros(len(self.lengths) + 1, np.int64)
+        np.cumsum(self.lengths + 1, out=self.tid_off[1:])
+        self.max_len = 50 if paired else int(FOOTPRINT_LENGTHS.max())
+        # genomic extent of every transcript, and the largest reference span a record can have: a read that crosses
+        # the longest intron chain of its transcript end to end is bounded by aligned length + deletion + the introns
+        # inside any max_len-long stretch of spliced coordinates -- bounded here by the transcript's own extent
+        self.tx_lo = tx.ex_start[tx.ex_off[:-1]].astype(np.int64) if tx.n else np.zeros(0, np.int64)
+        self.tx_hi = tx.ex_end[tx.ex_off[1:] - 1].astype(np.int64) if tx.n else np.zeros(0, np.int64)
+        gap_max = 0
+        if tx.n:
+            gaps = tx.ex_start[1:] - tx.ex_end[:-1]
+            inner = np.ones(len(gaps), bool)
+            inner[tx.ex_off[1:-1] - 1] = False                                  # not across transcripts
+            # a read of max_len bases crosses at most max_len - 1 junctions; exons are >= 30 nt, so in practice 1 - 2
+            k = max(1, min(3, self.max_len // 25))
+            g = np.where(inner, gaps, 0).astype(np.int64)
+            if len(g):
+                run = g.copy()
+                for j in range(1, k):
+                    run[:-j] += np.where(np.cumsum(~inner)[j:] == np.cumsum(~inner)[:-j], g[j:], 0) if len(g) > j else 0
+                gap_max = int(run.max())
+        self.halo = int(self.max_len + 1 + gap_max)
+
+    @property
+    def n_units(self):
+        return self.tx.n + len(self.win_tid)
+
+    def cuts(self, world, bin_size=4096):
+        """`world - 1` cut points (linear genome coordinates) at quantiles of the EXPECTED record density:
+        a transcript's reads spread evenly over its genomic extent, background reads evenly over their window."""
+        total = int(self.tid_off[-1])
+        nb = total // bin_size + 2
+        dens = np.zeros(nb + 1, np.float64)
+        mult = 2.0 if self.paired else 1.0
+
+        def spread(lo, hi, cnt):
+            lo = np.asarray(lo, np.int64); hi = np.maximum(np.asarray(hi, np.int64), lo + 1)
+            b0, b1 = lo // bin_size, (hi - 1) // bin_size
+            per = cnt * mult / (b1 - b0 + 1)
+            np.add.at(dens, b0, per)
+            np.add.at(dens, b1 + 1, -per)
+        if self.tx.n:
+            spread(self.tid_off[self.tx.tid] + self.tx_lo, self.tid_off[self.tx.tid] + self.tx_hi, self.tx_count.astype(np.float64))
+        spread(self.tid_off[self.win_tid] + self.win_start, self.tid_off[self.win_tid] + self.win_start + self.win_len,
+               self.win_count.astype(np.float64))
+        cum = np.cumsum(np.cumsum(dens)[:nb])
+        if world <= 1 or cum[-1] <= 0:
+            return np.zeros(0, np.int64)
+        q = cum[-1] * np.arange(1, world) / world
+        return (np.searchsorted(cum, q, side="left").astype(np.int64) + 1) * bin_size
+
+    def rank_range(self, cuts, rank):
+        """``(lo, hi)``: rank `rank` OWNS the records whose linear start lies in [lo, hi)."""
+        world = len(cuts) + 1
+        lo = 0 if rank == 0 else int(cuts[rank - 1])
+        hi = int(self.tid_off[-1]) if rank == world - 1 else int(cuts[rank])
+        return lo, hi
+
+
+def _assemble(genome, key, mt, mr, mn, ms, ml):
+    """Sorted single-run keys + multi-run reads (CSR runs, already in canonical order) -> PackedAlignments."""
+    names, lengths = genome
+    ns, nm = len(key), len(mt)
+    if nm:
+        moff = np.zeros(nm + 1, np.int64)
+        np.cumsum(mn, out=moff[1:])
+        mpos = ms[moff[:-1]]
+        malen = np.add.reduceat(ml, moff[:-1])
+        mkey = (mt << 40) | (mpos << 9)
+        ins = np.searchsorted(key >> 9, mkey >> 9, side="left")    # a multi-run read goes before equal-pos singles
+        m_dest = ins + np.arange(nm)
+    nrec = ns + nm
+    out_tid = np.empty(nrec, np.int32); out_pos = np.empty(nrec, np.int32)
+    out_len = np.empty(nrec, np.uint16); out_flags = np.empty(nrec, np.uint8); out_nblk = np.ones(nrec, np.uint8)
+    if nm:
+        is_m = np.zeros(nrec, bool)
+        is_m[m_dest] = True
+        s_dest = np.nonzero(~is_m)[0]
+    else:
+        s_dest = slice(None)
+    out_tid[s_dest] = key >> 40
+    out_pos[s_dest] = (key >> 9) & 0x7fffffff
+    out_len[s_dest] = (key >> 1) & 0xff
+    out_flags[s_dest] = (key & 1) * FLAG_REVERSE
+    if nm:
+        out_tid[m_dest] = mt; out_pos[m_dest] = mpos; out_len[m_dest] = malen
+        out_flags[m_dest] = np.where(mr, FLAG_REVERSE, 0); out_nblk[m_dest] = mn
+    z = np.zeros(0, np.int32)
+    return PackedAlignments(out_tid, out_pos, out_len, out_flags, out_nblk, ms.astype(np.int32) if nm else z,
+                            ml.astype(np.int32) if nm else z, references=names, lengths=[int(x) for x in lengths],
+                            mapped=nrec, validate=nrec <= 5_000_000)
+
+
+def make_reads_blocked(layout, lo=None, hi=None, block_reads=4_000_000):
+    """The records of the blocked job `layout` whose linear start lies in ``[lo, hi)`` (default: the whole job), in
+    the job's canonical order.  Only the units that can reach the range are drawn."""
+    tx, genome, lengths = layout.tx, layout.genome, layout.lengths
+    total = int(layout.tid_off[-1])
+    lo = 0 if lo is None else int(lo)
+    hi = total if hi is None else int(hi)
+    paired, del_frac = layout.paired, layout.del_frac
+    # units that can hold a record starting in [lo, hi)
+    t_sel = np.nonzero((layout.tx_count > 0) & (layout.tid_off[tx.tid] + layout.tx_hi > lo) &
+                       (layout.tid_off[tx.tid] + layout.tx_lo < hi))[0] if tx.n else np.zeros(0, np.int64)
+    w_lin = layout.tid_off[layout.win_tid] + layout.win_start
+    w_sel = np.nonzero((layout.win_count > 0) & (w_lin + layout.win_len > lo) & (w_lin < hi))[0]
+    keys, m_parts = [], []
+
+    def keep(tid, pos):
+        lin = layout.tid_off[tid] + pos
+        return (lin >= lo) & (lin < hi)
+
+    def add_block(tid, rev, L, pos, multi, nblk, starts, lens, u_del, u_cut):
+        """One block of reads in unit / draw order: junction-spanning reads are multi-run already; a random
+        `del_frac` of the others get a 1-nt deletion (two runs).  Filter to the range, queue."""
+        n = len(tid)
+        single = np.ones(n, bool)
+        single[multi] = False
+        dele = single & (u_del < del_frac) & (L >= 4) & (pos + L + 1 <= lengths[tid])
+        single &= ~dele
+        k = keep(tid[single], pos[single])
+        keys.append((tid[single][k] << 40) | (pos[single][k] << 9) | (L[single][k] << 1) | rev[single][k])
+        # multi-run reads of the block, in draw order: junction-spanning and deleted ones interleaved by read index
+        d_idx = np.nonzero(dele)[0]
+        cut = 1 + (u_cut[d_idx] * (L[d_idx] - 2)).astype(np.int64)
+        all_idx = np.concatenate([multi, d_idx])
+        all_n = np.concatenate([nblk, np.full(len(d_idx), 2, np.int64)])
+        st = np.empty(2 * len(d_idx), np.int64); ln = np.empty(2 * len(d_idx), np.int64)
+        st[0::2] = pos[d_idx]; st[1::2] = pos[d_idx] + cut + 1
+        ln[0::2] = cut; ln[1::2] = L[d_idx] - cut
+        all_s = np.concatenate([starts, st]); all_l = np.concatenate([lens, ln])
+        if not len(all_idx):
+            return
+        off = np.zeros(len(all_idx) + 1, np.int64)
+        np.cumsum(all_n, out=off[1:])
+        o = np.argsort(all_idx, kind="stable")
+        kk = keep(tid[all_idx[o]], all_s[off[:-1][o]])
+        o = o[kk]
+        if not len(o):
+            return
+        nn = all_n[o]
+        dst = np.zeros(len(o) + 1, np.int64)
+        np.cumsum(nn, out=dst[1:])
+        idx = np.repeat(off[:-1][o] - dst[:-1], nn) + np.arange(int(dst[-1]))
+        m_parts.append((tid[all_idx[o]], rev[all_idx[o]], nn, all_s[idx], all_l[idx]))
+
+    def draw_len(rng, k):
+        if paired:
+            return rng.integers(25, 51, k)
+        return _FOOTPRINT_TABLE[rng.integers(0, len(_FOOTPRINT_TABLE), k)]
+
+    # ---- transcript units, a block of them at a time (the projection onto the genome is vectorised over the block)
+    b0 = 0
+    while b0 < len(t_sel):
+        b1, acc = b0, 0
+        while b1 < len(t_sel) and (acc == 0 or acc + layout.tx_count[t_sel[b1]] <= block_reads):
+            acc += int(layout.tx_count[t_sel[b1]]); b1 += 1
+        ts, xs, Ls, ud, uc, xs2, Ls2, ud2, uc2 = [], [], [], [], [], [], [], [], []
+        for t in t_sel[b0:b1]:
+            c = int(layout.tx_count[t])
+            rng = np.random.default_rng([layout.seed, 1, int(t)])
+            tlen = int(tx.length[t])
+            if not paired:
+                L = np.minimum(draw_len(rng, c), tlen)
+                x = (rng.random(c) * (tlen - L + 1)).astype(np.int64)
+            else:
+                frag = np.minimum(np.maximum(rng.normal(180.0, 30.0, c), 60).astype(np.int64), tlen)
+                fx = (rng.random(c) * (tlen - frag + 1)).astype(np.int64)
+                L = np.minimum(draw_len(rng, c), frag)
+                L2 = np.minimum(draw_len(rng, c), frag)
+                rv = tx.strand[t] == 2
+                x = fx + frag - L if rv else fx             # mate 1 at the fragment's 5' end (transcript orientation)
+                x2 = fx if rv else fx + frag - L2
+                xs2.append(x2); Ls2.append(L2); ud2.append(rng.random(c)); uc2.append(rng.random(c))
+            ts.append(np.full(c, t, np.int64)); xs.append(x); Ls.append(L); ud.append(rng.random(c)); uc.append(rng.random(c))
+        t_all = np.concatenate(ts)
+        rev_tx = tx.strand[t_all] == 2
+        ttid = tx.tid[t_all].astype(np.int64)
+        L_all = np.concatenate(Ls)
+        add_block(ttid, rev_tx, L_all, *_project(tx, t_all, np.concatenate(xs), L_all), np.concatenate(ud), np.concatenate(uc))
+        if paired:
+            L2_all = np.concatenate(Ls2)
+            add_block(ttid, ~rev_tx, L2_all, *_project(tx, t_all, np.concatenate(xs2), L2_all), np.concatenate(ud2), np.concatenate(uc2))
+        b0 = b1
+    # ---- background units
+    z = np.zeros(0, np.int64)
+    b0 = 0
+    while b0 < len(w_sel):
+        b1, acc = b0, 0
+        while b1 < len(w_sel) and (acc == 0 or acc + layout.win_count[w_sel[b1]] <= block_reads):
+            acc += int(layout.win_count[w_sel[b1]]); b1 += 1
+        tids, poss, Ls, revs, ud, uc = [], [], [], [], [], []
+        for w in w_sel[b0:b1]:
+            c = int(layout.win_count[w]) * (2 if paired else 1)
+            rng = np.random.default_rng([layout.seed, 1, int(tx.n + w)])
+            L = draw_len(rng, c).astype(np.int64)
+            t = int(layout.win_tid[w])
+            start = layout.win_start[w] + (rng.random(c) * layout.win_len[w]).astype(np.int64)
+            start = np.maximum(0, np.minimum(start, lengths[t] - L))
+            tids.append(np.full(c, t, np.int64)); poss.append(start); Ls.append(L); revs.append(rng.random(c) < 0.5)
+            ud.append(rng.random(c)); uc.append(rng.random(c))
+        add_block(np.concatenate(tids), np.concatenate(revs), np.concatenate(Ls), np.concatenate(poss), z, z, z, z,
+                  np.concatenate(ud), np.concatenate(uc))
+        b0 = b1
+    key = np.concatenate(keys) if keys else np.zeros(0, np.int64)
+    del keys
+    key.sort()
+    if m_parts:
+        mt = np.concatenate([p[0] for p in m_parts]); mr = np.concatenate([p[1] for p in m_parts])
+        mn = np.concatenate([p[2] for p in m_parts]); ms = np.concatenate([p[3] for p in m_parts]); ml = np.concatenate([p[4] for p in m_parts])
+        moff = np.zeros(len(mt) + 1, np.int64)
+        np.cumsum(mn, out=moff[1:])
+        o = np.argsort((mt << 40) | (ms[moff[:-1]] << 9), kind="stable")     # ties stay in (unit, draw) order
+        dst = np.zeros(len(o) + 1, np.int64)
+        np.cumsum(mn[o], out=dst[1:])
+        idx = np.repeat(moff[:-1][o] - dst[:-1], mn[o]) + np.arange(int(dst[-1]))
+        mt, mr, mn, ms, ml = mt[o], mr[o], mn[o], ms[idx], ml[idx]
+    else:
+        mt = mr = mn = ms = ml = z
+    return _assemble(genome, key, mt, mr, mn, ms, ml)
+
+
+def job_layout(name, scale=1.0, tx_scale=None):
+    """``(genome, transcripts, JobLayout, mapping)`` of BASELINE config `name` under the blocked generator."""
+    gname, style, n_tx, tx_seed, n_reads, r_seed, paired, mapping = CONFIGS[name]
+    genome = YEAST if gname == "yeast" else HUMAN
+    n_tx = max(1, int(round(n_tx * (scale if tx_scale is None else tx_scale))))
+    n_reads = max(2, int(round(n_reads * scale)))
+    tx = make_transcripts(genome, n_tx, tx_seed, style)
+    return genome, tx, JobLayout(genome, tx, n_reads, r_seed, paired=paired), mapping
+
+
 CONFIGS = {
     # name: (genome, tx style, n_tx, tx seed, n_reads, read seed, paired, mapping)
     "C1": ("yeast", "yeast", 200, 2001, 1_000_000, 1001, False, ("fiveprime", 0)),

@@ -225,3 +225,59 @@ def test_two_rank_bench_partition_path(tmp_path):
     for s, a in enumerate(arr):
         chain_want[tx.ex_tx[s] * rows:(tx.ex_tx[s] + 1) * rows] += a.reshape(rows, -1).sum(axis=1)
     assert np.array_equal(sums[0], chain_want)
+
+
+# ---------------------------------------------------------------------------- bench.py --gpus N, end to end
+def test_range_addressable_generator_rank_slices_are_the_job():
+    """``synth.make_reads_blocked``: the records a rank draws for its range (plus halo) are exactly that slice of the
+    whole job, for any number of ranks; the owned records add up to the job; no record spans more than the halo."""
+    from plastid_amd import synth
+    for name, sc, txs in (("C2", 0.001, 0.01), ("C4", 0.0003, 0.005), ("C5", 0.0001, 0.005)):
+        genome, tx, lay, _ = synth.job_layout(name, scale=sc, tx_scale=txs)
+        whole = synth.make_reads_blocked(lay)
+        assert whole.n == lay.n
+        whole.validate()
+        assert int((whole.ref_end() - whole.pos).max()) <= lay.halo
+        lin = lay.tid_off[whole.tid] + whole.pos
+        for world in (2, 5):
+            cuts = lay.cuts(world)
+            assert len(cuts) == world - 1 and np.all(np.diff(cuts) >= 0)
+            owned = 0
+            for r in range(world):
+                lo, hi = lay.rank_range(cuts, r)
+                mine = synth.make_reads_blocked(lay, max(0, lo - lay.halo), hi, block_reads=20000)
+                i0, i1 = np.searchsorted(lin, max(0, lo - lay.halo), "left"), np.searchsorted(lin, hi, "left")
+                ref = whole.slice(i0, i1)
+                for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
+                    assert np.array_equal(getattr(mine, k), getattr(ref, k)), (name, world, r, k)
+                owned += int(((lay.tid_off[mine.tid] + mine.pos) >= lo).sum())
+            assert owned == lay.n
+
+
+def test_bench_spawns_its_ranks_and_runs_the_one_job_mode(tmp_path):
+    """``python bench.py --gpus 2`` without a torchrun environment: the parent spawns the two ranks and relays ONE JSON
+    line.  Rehearsed here without GPUs (gloo; the oracle-backed stand-in engine of tests/oracle_engine.py counts): every
+    rank generates only its range, passes its parity gates, the chain sums agree after the all-reduce, the records owned
+    by the ranks add up to the job, and C4 / C5 follow the headline as partitioned jobs."""
+    import json
+    import subprocess
+    env = dict(os.environ, PC_BENCH_BACKEND="gloo", PC_BENCH_ENGINE="tests.oracle_engine", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.002", "--tx-scale", "0.01", "--steps", "2",
+           "--warmup", "1", "--other-configs", "C4,C5", "--parity-chains", "60"]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["metric"] == "mapped_reads_per_sec"
+    assert "rehearsal" in d["config"] and d["value"] is None
+    part = d["config"]["partition"]
+    assert sum(part["records_per_rank"]) == d["config"]["records_total"] == 200000
+    assert all(s >= o for s, o in zip(part["records_staged_per_rank"], part["records_per_rank"]))
+    assert len(part["peak_host_rss_MB_per_rank"]) == 2 and part["allreduce"]["chains_checked_vs_oracle"] == 60
+    for c in ("C4", "C5"):
+        oc = d["config"]["other_configs"][c]
+        assert sum(oc["partition"]["records_per_rank"]) == oc["records"]
+        assert oc["partition"]["halo_positions"] > 1000 and "bit-exact" in oc["parity"]
