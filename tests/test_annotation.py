@@ -252,6 +252,10 @@ def test_position_arrays_device_kernel_equals_numpy():
     mp, mo = table.masked_position_arrays(masks)
     dmp, dmo = table.masked_position_arrays(masks, eng)
     assert np.array_equal(dmp, mp) and np.array_equal(dmo, mo)
+    # and the kernel's output against the reference's own lists (golden chains.npz), not only against the host form
+    for c, q in enumerate(queries):
+        assert dpos[doff[c]:doff[c + 1]].tolist() == list(g[q["position_list"]]), q
+        assert dmp[dmo[c]:dmo[c + 1]].tolist() == list(g[q["masked_position_set"]]), q
     tx = synth.make_transcripts(synth.YEAST, 20000, 2001, "yeast")
     pos, off = tx.position_arrays()
     dpos, doff = tx.position_arrays(eng)

@@ -179,6 +179,60 @@ def test_sparse_table_expectation_matches_oracle():
         assert np.array_equal(flat, got_r), r
 
 
+def test_sparse_row_expectation_matches_oracle():
+    """fu.sparse_chain_rows (one pass for all rows) vs the oracle at oracle size, on the blocked generator's records."""
+    from oracle import oracle
+    genome, tx, lay, mapping = synth.job_layout("C5", scale=0.0002, tx_scale=0.005)
+    reads = synth.make_reads_blocked(lay)
+    lo, hi = mapping[2], mapping[3]
+    rows = hi - lo + 1
+    pos, ok = fu.mapped_positions_by_table(reads, fu.offsets_by_length(mapping[1]))
+    pr = tx.plan_arrays(rows=rows)
+    arrays, _ = oracle.count_segments(concat_file_major([reads]), oracle.mapping_spec("stratified", 0, mapping[1], lo, hi), pr["tid"],
+                                      pr["start"], pr["end"], pr["strand"])
+    want = _scatter(pr, arrays, rows)[:pr["out_elems"]]     # (_scatter sizes its buffer for rows = 1 plans)
+    assert np.array_equal(fu.sparse_chain_rows(tx, reads, pos, ok, reads.alen.astype(np.int64) - lo, rows, threads=4), want)
+
+
+@pytest.mark.gpu
+def test_c5_at_its_full_size():
+    """C5 at BASELINE size on ONE GPU: 10^9 mate records (blocked generator, drawn range by range on a thread
+    pool), StratifiedVariableFivePrimeMapFactory(25..35), 60 k human-scale transcripts x 11 rows = 1.0e9 outputs --
+    every output element against the sparse numpy expectation, the total against the mapped records, a second launch
+    bit-identical.  PC_FULLSIZE_SCALE shrinks it."""
+    from concurrent.futures import ThreadPoolExecutor
+    from plastid_amd.engine import Engine
+    from plastid_amd.packing import PackedAlignments
+    scale = float(os.environ.get("PC_FULLSIZE_SCALE", "1.0"))
+    genome, tx, lay, mapping = synth.job_layout("C5", scale=scale, tx_scale=1.0 if scale >= 0.5 else 0.05)
+    nparts = 16
+    cuts = lay.cuts(nparts)
+    with ThreadPoolExecutor(nparts) as pool:
+        parts = list(pool.map(lambda r: synth.make_reads_blocked(lay, *lay.rank_range(cuts, r)), range(nparts)))
+    reads = PackedAlignments(*[np.concatenate([getattr(q, k) for q in parts]) for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len")],
+                             references=genome[0], lengths=[int(x) for x in genome[1]], validate=False)
+    del parts
+    assert reads.n == lay.n
+    lo, hi = mapping[2], mapping[3]
+    rows = hi - lo + 1
+    eng = Engine(0)
+    eng.set_alignments([reads])
+    synth.mapping_factory(mapping)._configure(eng)
+    pr = tx.plan_arrays(rows=rows)
+    plan = eng.plan(pr["tid"], pr["start"], pr["end"], pr["strand"], pr["out_off"], pr["out_step"], pr["row_stride"],
+                    pr["out_elems"], rows)
+    got = plan.count(np.int64)
+    pos, ok = fu.mapped_positions_by_table(reads, fu.offsets_by_length(mapping[1]))
+    want = fu.sparse_chain_rows(tx, reads, pos, ok, reads.alen.astype(np.int64) - lo, rows)
+    assert np.array_equal(got, want), "stratified chain vectors differ at full size"
+    assert int(plan.total()) == int(want.sum())
+    del want
+    again = plan.count(np.int64)
+    assert np.array_equal(again, got)
+    plan.close()
+    eng.close()
+
+
 @pytest.mark.gpu
 def test_large_table_rule_properties():
     """C4 at its BASELINE size on ONE GPU (500 M reads, Variable, 60 k human-scale transcripts) and C5 at
