@@ -222,7 +222,7 @@ int scan_blocks(const FileMap &file, std::vector<Block> &blocks, size_t &total_u
         for (size_t x = 0; x + 4 <= xlen;) {
             const uint8_t *sf = h + 12 + x;
             const uint16_t slen = rd16(sf + 2);
-            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2) bsize = rd16(sf + 4);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = rd16(sf + 4);   // (the two payload bytes lie inside the extra field)
             x += 4 + slen;
         }
         if (bsize < 0) return fail("BGZF member without BC subfield");
@@ -378,6 +378,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
             continue;
         }
         if (tid >= (int32_t)n_ref) { ret = bad(i, true, "BAM record with reference id out of range"); break; }
+        if (pos < 0) { ret = bad(i, true, "placed BAM record with a negative position"); break; }
         if (!any_placed) {        // its order against the previous piece is checked when stitching
             any_placed = true;
             pt.first_placed_rec = i;
@@ -392,7 +393,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         const uint8_t *cig = r + 32 + l_read_name;
         if (n_cigar == 1) {   // the common record: one M / = / X operation (one aligned run starting at pos)
             const uint32_t v = rd32(cig), op = v & 0xf, len = v >> 4;
-            if ((op == 0 || op == 7 || op == 8) && len > 0 && len <= 65535) {
+            if ((op == 0 || op == 7 || op == 8) && len > 0 && len <= 65535 && (int64_t)pos + len <= 0x7fffffffLL) {
                 if (first) pt.first_spos = pos;
                 else if (last_tid == tid && last_spos > pos) {
                     ret = bad(i, false, "alignment starting with a deletion breaks coordinate order; not supported");
@@ -434,6 +435,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
             }
         }
         if (unknown_op) { ret = bad(i, false, "unknown CIGAR operation in " + bam.path); break; }
+        if (ref > 0x7fffffffLL) { ret = bad(i, false, "alignment ends beyond 2^31 - 1"); break; }   // run starts are int32
         if (L > 65535) { ret = bad(i, false, "alignment with more than 65535 aligned positions is not supported"); break; }
         if (runs.size() > 255) { ret = bad(i, false, "alignment with more than 255 aligned runs is not supported"); break; }
         // the packed format keys a record on its first aligned position; a CIGAR that opens with

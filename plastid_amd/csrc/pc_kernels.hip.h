@@ -1177,10 +1177,16 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
                                                       const OutPiece *__restrict__ opieces,
                                                       uint32_t *tile_items, uint32_t *counters, int rows,
                                                       uint32_t *hist, int64_t hist_row_stride,
-                                                      typename OutT_<OUTMODE>::type *out, double norm_sum) {
+                                                      typename OutT_<OUTMODE>::type *out, double norm_sum,
+                                                      uint32_t launched_heavy, uint32_t launched_light, uint32_t launched_small,
+                                                      uint32_t *grid_error) {
     __shared__ uint32_t s_list[kWG];
     __shared__ uint32_t s_n;
     if (blockIdx.x == 0 && threadIdx.x < 4) {
+        // guard of the exact grids: the histogram kernels were launched with the work counts a previous count of
+        // this plan left (0xffffffff: the whole capacity was launched); if this count queued more, items went unserved
+        const uint32_t launched = threadIdx.x == 0 ? launched_heavy : (threadIdx.x == 1 ? launched_light : (threadIdx.x == 2 ? launched_small : 0xffffffffu));
+        if (launched != 0xffffffffu && counters[threadIdx.x] > launched) atomicOr(grid_error, 1u);
         counters[4 + threadIdx.x] = counters[threadIdx.x]; // kept for diagnostics (PC_DEBUG_WORK)
         counters[threadIdx.x] = 0u;
     }

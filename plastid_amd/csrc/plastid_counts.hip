@@ -295,6 +295,7 @@ struct Knobs {
     int small_g = 512;         // PC_SMALL_G: queried span a single-wave window may have
     int64_t small_n = 8192;    // PC_SMALL_N: records a single-wave window may scan (C4: 1.25 ms at 2048, 1.22 at 8192, 1.21 at 32768)
     int debug_work = 0;        // PC_DEBUG_WORK: print the queued work items per class (stderr; synchronises)
+    int test_stale_counts = 0; // PC_TEST_STALE_COUNTS: pretend the cached work counts are one light item short (exercises the exact-grid guard)
     int center_t1 = 8;         // PC_CENTER_T1 / PC_CENTER_T2: center chunks with more than T1 x (T1*T2 x) the mean candidate
     int center_t2 = 4;         //   count are cut into 4 (8) sub-chunks
     int64_t center_floor = 32768; // PC_CENTER_FLOOR: stream entries below which a chunk is never cut (a wave alone replays ~50 k per ms)
@@ -309,6 +310,7 @@ struct Knobs {
         if (const char *env = getenv("PC_SMALL_G")) small_g = std::max(64, atoi(env) / 64 * 64);
         if (const char *env = getenv("PC_SMALL_N")) small_n = std::max(64, atoi(env));
         debug_work = getenv("PC_DEBUG_WORK") ? 1 : 0;
+        test_stale_counts = getenv("PC_TEST_STALE_COUNTS") ? 1 : 0;
         if (const char *env = getenv("PC_CENTER_T1")) center_t1 = std::max(8, atoi(env));
         if (const char *env = getenv("PC_CENTER_T2")) center_t2 = std::max(1, atoi(env));
         if (const char *env = getenv("PC_CENTER_FLOOR")) center_floor = std::max(64, atoi(env));
@@ -447,6 +449,7 @@ struct pc_plan {
     uint64_t work_counts_generation = 0; // engine work_generation the read-back belongs to (0: none in flight)
     bool work_counts_known = false;      // the read-back has arrived: work_counts holds it
     uint32_t work_counts[3] = {0, 0, 0};
+    bool exact_grid_used = false;        // some count of this plan launched exact grids: its results are read back with the guard word
     ~pc_plan() {
         if (ev_work_counts) (void)hipEventDestroy(ev_work_counts);
         if (h_work_counts) (void)hipHostFree(h_work_counts);
@@ -567,7 +570,8 @@ int pc_create(int device, pc_engine **out) {
     inv[0] = 0.0;
     for (int m = 1; m < 65536; ++m) inv[m] = 1.0 / (double)m; // the reference's `1.0 / map_length`
     int rc = e->d_inv.upload(inv, e->stream);
-    if (rc == PC_OK) rc = e->d_counters.reserve(8);
+    if (rc == PC_OK) rc = e->d_counters.reserve(16);   // [0..3] work counts, [4..7] their copy, [12] exact-grid guard
+    if (rc == PC_OK && hipMemsetAsync(e->d_counters.p, 0, 16 * sizeof(uint32_t), e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: memset failed");
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: sync failed");
     if (rc != PC_OK) {
         pc_destroy(e);
@@ -1757,6 +1761,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // class queues (same alignments, same knobs) -- exactly those: a sparse annotation leaves most
             // of the capacity empty, and an empty workgroup still costs a dispatch slot
             unsigned grid = (unsigned)cap64, grid_front = (unsigned)cap64, grid_small = (unsigned)cap_small;
+            uint32_t launched[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};   // exact grids: what k_gather_split checks the queued counts against
             const bool track_counts = ntiles >= 4096;
             if (track_counts && p->work_counts_generation == e->work_generation && p->h_work_counts && !p->work_counts_known &&
                 hipEventQuery(p->ev_work_counts) == hipSuccess) {
@@ -1764,11 +1769,13 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 p->work_counts_known = true;   // deterministic for this plan while the generation stands: no further read-backs
             }
             if (track_counts && p->work_counts_known && p->work_counts_generation == e->work_generation) {
-                const uint32_t nh = p->work_counts[0], nl = p->work_counts[1], ns = p->work_counts[2];
+                const uint32_t nh = p->work_counts[0], nl = p->work_counts[1] - ((e->knobs.test_stale_counts && p->work_counts[1]) ? 1u : 0u), ns = p->work_counts[2];
                 if ((uint64_t)nh + nl <= (uint64_t)cap64 && (int64_t)ns <= cap_small) {
                     grid_front = nh;
                     grid = std::max(1u, nh + nl);
                     grid_small = ns;
+                    launched[0] = nh; launched[1] = nl; launched[2] = ns;
+                    p->exact_grid_used = true;
                 }
             }
             const int outmode = e->norm_on ? 2 : (out_dtype == PC_OUT_FLOAT64 ? 1 : 0);
@@ -1822,7 +1829,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)((ntiles + split_per_wg - 1) / split_per_wg)), dim3(kWG), 0, st, \
                        p->d_tiles.p, ntiles, split_per_wg, p->d_pieces.p,                                               \
                        p->d_opieces.p, p->d_tile_items.p, e->d_counters.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,   \
-                       (OutT_<O>::type *)p->d_out.p, e->norm_sum)
+                       (OutT_<O>::type *)p->d_out.p, e->norm_sum, launched[0], launched[1], launched[2], e->d_counters.p + 12)
             if (outmode == 0) PC_LAUNCH_SPLIT(0);
             else if (outmode == 1) PC_LAUNCH_SPLIT(1);
             else PC_LAUNCH_SPLIT(2);
@@ -1985,12 +1992,30 @@ int pc_sync(pc_engine *e) {
     return PC_OK;
 }
 
+
+// Exact grids (pc_count) rest on the work counts of a plan being a function of (plan, work generation).  The last
+// kernel of a count compares what was queued with what was launched; a mismatch means work items went unserved.
+static int check_grid_guard(pc_engine *e, pc_plan *p) {
+    if (!p->exact_grid_used) return PC_OK;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, e->d_counters.p + 12, sizeof(err), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!err) return PC_OK;
+    HIP_TRY(hipMemsetAsync(e->d_counters.p + 12, 0, sizeof(uint32_t), e->stream));
+    p->work_counts_known = false;
+    p->work_counts_generation = 0;
+    p->exact_grid_used = false;
+    return fail(PC_ERR_STATE, "a count of this plan queued more work items than the cached work counts launched (results incomplete); "
+                              "the cache has been dropped -- count again");
+}
+
 static constexpr size_t kSmallRead = 256 * 1024;
 
 int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems) {
     if (!e || !p || p->e != e || !p->counted) return fail(PC_ERR_STATE, "pc_read_counts: nothing counted yet");
     if (out_elems != p->out_elems || (out_elems > 0 && !host_out)) return fail(PC_ERR_ARG, "pc_read_counts: buffer size mismatch");
     HIP_TRY(hipSetDevice(e->device));
+    { const int grc = check_grid_guard(e, p); if (grc != PC_OK) return grc; }
     const size_t bytes = (size_t)out_elems * 8;
     // (growing the buffer frees the old one: not while a plan upload may still be reading from it)
     if (bytes > e->pinned.cap && e->pinned_busy) { HIP_TRY(hipEventSynchronize(e->ev_pinned)); e->pinned_busy = false; }
@@ -2034,6 +2059,7 @@ void *pc_total_device_ptr(pc_plan *p) { return p ? (void *)p->d_total.p : nullpt
 int pc_total(pc_engine *e, pc_plan *p, void *host_out8) {
     if (!e || !p || p->e != e || !p->counted) return fail(PC_ERR_STATE, "pc_total: nothing counted yet");
     HIP_TRY(hipSetDevice(e->device));
+    { const int grc = check_grid_guard(e, p); if (grc != PC_OK) return grc; }
     hipStream_t st = e->stream;
     HIP_TRY(hipMemsetAsync(p->d_total.p, 0, 8, st));
     if (p->out_elems > 0) {

@@ -272,3 +272,106 @@ def write_bam_packed(path, packed, block_bytes=60000, level=1, threads=8):
             fh.write(blk)
         fh.write(BGZF_EOF)
     return len(data)
+
+
+def write_bam_realistic(path, packed, block_bytes=60000, level=1, threads=8, seed=5):
+    """Like :func:`write_bam_packed`, with records that look like an aligner's: a 23-character read name, the query
+    sequence (``l_seq`` = aligned length, 4-bit packed random bases), base qualities (binned, mostly one value), and
+    the tags ``NH:C:1`` and ``MD:Z:<n>`` -- about 120 bytes per 30-nt read instead of 42.  Aligned runs are joined by
+    ``N`` (gap > 1) or ``D`` (gap of 1) operations.  Returns the number of inflated bytes."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = packed.n
+    rng = np.random.default_rng(seed)
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@PG\tID:synth\n"
+    head = b"BAM\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(packed.references))
+    for nm, ln in zip(packed.references, packed.lengths):
+        nmb = nm.encode() + b"\x00"
+        head += struct.pack("<I", len(nmb)) + nmb + struct.pack("<I", int(ln))
+    H = len(head)
+    L = packed.alen.astype(np.int64)
+    nblk = np.maximum(packed.nblk.astype(np.int64), 1)
+    ncig = 2 * nblk - 1
+    name_len = 24                                              # "SRR0000000.%012d" + NUL
+    md_len = np.where(L >= 100, 3, np.where(L >= 10, 2, 1)) + 4  # "MDZ" digits NUL
+    size = 36 + name_len + 4 * ncig + (L + 1) // 2 + L + 4 + md_len        # block_size field included
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(size, out=off[1:])
+    whole = np.zeros(H + int(off[-1]), np.uint8)
+    whole[:H] = np.frombuffer(head, np.uint8)
+    buf = whole[H:]
+    end = packed.ref_end().astype(np.int64)
+    bins = reg2bin_array(packed.pos, end)
+    digits = np.frombuffer(b"0123456789", np.uint8)
+    boff = packed.block_offsets() if len(packed.blk_start) else None
+    # records of one (aligned length, run count) class share their layout: filled as a 2-D block, scattered by offset
+    cls = L * 256 + nblk
+    order = np.argsort(cls, kind="stable")
+    bounds = np.nonzero(np.diff(cls[order]))[0] + 1
+    for grp in np.split(order, bounds):
+        if not len(grp):
+            continue
+        Lg, nb = int(L[grp[0]]), int(nblk[grp[0]])
+        sz = int(size[grp[0]])
+        k = len(grp)
+        rows = np.zeros((k, sz), np.uint8)
+
+        def col(rel, width, values, dt):
+            rows[:, rel:rel + width] = np.ascontiguousarray(values, dtype=dt).view(np.uint8).reshape(k, width)
+        col(0, 4, np.full(k, sz - 4), "<u4")
+        col(4, 4, packed.tid[grp], "<i4")
+        col(8, 4, packed.pos[grp], "<i4")
+        rows[:, 12] = name_len
+        rows[:, 13] = 255 if False else 30
+        col(14, 2, bins[grp], "<u2")
+        col(16, 2, np.full(k, 2 * nb - 1), "<u2")
+        col(18, 2, np.where(packed.flags[grp] & 1, 16, 0), "<u2")
+        col(20, 4, np.full(k, Lg), "<i4")
+        col(24, 4, np.full(k, -1), "<i4")
+        col(28, 4, np.full(k, -1), "<i4")
+        # name: SRR0000000.<12 digits of the record index>
+        rows[:, 36:47] = np.frombuffer(b"SRR0000000.", np.uint8)
+        idx = grp.astype(np.int64)
+        for d in range(12):
+            rows[:, 47 + 11 - d] = digits[(idx // 10 ** d) % 10]
+        at = 36 + name_len
+        if nb == 1:
+            col(at, 4, np.full(k, Lg << 4), "<u4")
+        else:
+            runs = boff[grp][:, None] + np.arange(nb)[None, :]
+            st, ln = packed.blk_start[runs].astype(np.int64), packed.blk_len[runs].astype(np.int64)
+            for j in range(nb):
+                if j:
+                    gap = st[:, j] - (st[:, j - 1] + ln[:, j - 1])
+                    col(at + 8 * j - 4, 4, (gap << 4) | np.where(gap == 1, 2, 3), "<u4")
+                col(at + 8 * j, 4, ln[:, j] << 4, "<u4")
+        at += 4 * (2 * nb - 1)
+        nseq = (Lg + 1) // 2
+        base = (1 << rng.integers(0, 4, (k, 2 * nseq))).astype(np.uint8)     # A C G T = 1 2 4 8
+        rows[:, at:at + nseq] = (base[:, 0::2] << 4) | base[:, 1::2]
+        if Lg & 1:
+            rows[:, at + nseq - 1] &= 0xf0
+        at += nseq
+        q = np.where(rng.random((k, Lg)) < 0.9, 37, np.where(rng.random((k, Lg)) < 0.7, 25, 11)).astype(np.uint8)
+        rows[:, at:at + Lg] = q
+        at += Lg
+        rows[:, at:at + 4] = np.frombuffer(b"NHC\x01", np.uint8)
+        at += 4
+        md = ("MDZ%d" % Lg).encode() + b"\x00"
+        rows[:, at:at + len(md)] = np.frombuffer(md, np.uint8)
+        assert at + len(md) == sz
+        dest = off[grp][:, None] + np.arange(sz)[None, :]
+        buf[dest] = rows
+    data = memoryview(whole)
+
+    def member(i):
+        raw = data[i:i + block_bytes]
+        comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cdata = comp.compress(raw) + comp.flush()
+        return (struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(cdata) + 25) + cdata +
+                struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw)))
+
+    with ThreadPoolExecutor(max(1, threads)) as pool, open(path, "wb") as fh:
+        for blk in pool.map(member, range(0, len(data), block_bytes)):
+            fh.write(blk)
+        fh.write(BGZF_EOF)
+    return len(data)

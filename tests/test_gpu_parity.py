@@ -836,3 +836,61 @@ def test_custom_filters_are_evaluated_like_the_reference(pa, oracle):
     ga.remove_filter("even")
     arrays, _ = oracle.count_segments(aln_dict([reads]), oracle.mapping_spec("fiveprime", 5), [3], [1000], [9000], [1])
     assert np.array_equal(ga[seg], arrays[0])
+
+
+def test_exact_grid_guard_and_cache_invalidation(pa, monkeypatch):
+    """Large plans launch exactly the work-item counts a previous count of the plan left.  (1) What invalidates
+    those counts -- other alignment files, re-read knobs -- must drop the cache: results stay right.  (2) Should a
+    count ever queue MORE items than the cached counts launched, the last kernel of the call notices and the read-back
+    reports it instead of returning incomplete vectors (PC_TEST_STALE_COUNTS makes the cache one item short)."""
+    from plastid_amd import synth
+    from plastid_amd.engine import Engine
+    from plastid_amd.exceptions import EngineError
+    genome, tx, reads, mapping = synth.make_config("C4", scale=0.004, tx_scale=0.25)
+    p = tx.plan_arrays(rows=1)
+    half = reads.slice(0, reads.n // 2)
+
+    def count_twice(eng, plan):
+        a = plan.count(np.int64)
+        eng.sync()
+        b = plan.count(np.int64)            # by now the work counts of the first count have arrived: exact grids
+        assert np.array_equal(a, b)
+        return b
+    eng = Engine(0)
+    eng.set_alignments([reads])
+    synth.mapping_factory(mapping)._configure(eng)
+    plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    assert plan.tiles >= 4096
+    full = count_twice(eng, plan)
+    eng.set_alignments([half])              # same plan, other records: the cached counts must not be used
+    part = count_twice(eng, plan)
+    eng.set_alignments([reads])
+    monkeypatch.setenv("PC_WORK_R", "2048")
+    eng.reload_knobs()                      # other work-item size: more items than before
+    assert np.array_equal(count_twice(eng, plan), full)
+    monkeypatch.delenv("PC_WORK_R")
+    eng.reload_knobs()
+    plan.close()
+    e2 = Engine(0)
+    e2.set_alignments([half])
+    synth.mapping_factory(mapping)._configure(e2)
+    plan2 = e2.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    assert np.array_equal(plan2.count(np.int64), part)
+    plan2.close()
+    e2.close()
+    eng.close()
+    # (2) the guard
+    monkeypatch.setenv("PC_TEST_STALE_COUNTS", "1")
+    e3 = Engine(0)
+    monkeypatch.delenv("PC_TEST_STALE_COUNTS")
+    e3.set_alignments([reads])
+    synth.mapping_factory(mapping)._configure(e3)
+    plan3 = e3.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    assert np.array_equal(plan3.count(np.int64), full)       # first count: the whole capacity is launched
+    e3.sync()
+    plan3.launch(np.int64)                                   # second: "cached" counts, one light item short
+    with pytest.raises(EngineError):
+        plan3.read()
+    assert np.array_equal(plan3.count(np.int64), full)       # the cache was dropped: whole capacity again
+    plan3.close()
+    e3.close()
