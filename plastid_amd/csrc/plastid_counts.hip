@@ -405,6 +405,9 @@ struct pc_plan {
     std::vector<CenterChunk> cchunks;
     std::vector<GatherSeg> gsegs;
     std::vector<GatherChunk> gchunks;
+    bool lazy_center = false;    // large plans: cchunks / gchunks (and the upload of gsegs) wait for the first center count or coordinate export
+    bool center_ready = false;
+    DevBuf<uint8_t> d_tables2;   // ... and live in this block
     // host copies for warn evaluation
     std::vector<int32_t> h_tid;
     std::vector<int64_t> h_start, h_end;
@@ -461,7 +464,7 @@ struct pc_plan {
         DevPool *pl = &eng->pool;
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
-        d_cranges.pool = pl; d_crec.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl;
+        d_cranges.pool = pl; d_crec.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl;
     }
 };
 
@@ -483,6 +486,55 @@ int refresh_file_views(pc_engine *e) {
     if (rc != PC_OK) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->files_dirty = false;
+    return PC_OK;
+}
+
+// The center-only tables of a large plan (see pc_plan_create): built on first use.
+int ensure_center_tables(pc_engine *e, pc_plan *p) {
+    if (!p->lazy_center || p->center_ready) return PC_OK;
+    const int PT = std::min(usable_cpus(), 32);
+    const size_t ntl = p->tiles.size();
+    // chunks per tile, in tile / piece order (what the eager path produces piece by piece)
+    std::vector<size_t> at(ntl + 1, 0);
+    for (size_t t = 0; t < ntl; ++t) {
+        size_t n = 0;
+        for (uint32_t i = p->tiles[t].piece_begin; i < p->tiles[t].piece_end; ++i) n += (size_t)(p->pieces[i].len + kWave - 1) / kWave;
+        at[t + 1] = at[t] + n;
+    }
+    p->cchunks.resize(at[ntl]);
+    parallel_chunks((int64_t)ntl, PT, [&](int, int64_t tb, int64_t te) {
+        for (int64_t t = tb; t < te; ++t) {
+            size_t k = at[(size_t)t];
+            for (uint32_t i = p->tiles[(size_t)t].piece_begin; i < p->tiles[(size_t)t].piece_end; ++i) {
+                const Piece &pc_ = p->pieces[i];
+                for (int32_t a = 0; a < pc_.len; a += kWave) {
+                    CenterChunk c;
+                    c.hist_off = pc_.hist_off + a; c.tid = p->tiles[(size_t)t].tid; c.start = pc_.start + a;
+                    c.len = std::min<int32_t>(kWave, pc_.len - a); c.mode = pc_.mode;
+                    p->cchunks[k++] = c;
+                }
+            }
+        }
+    });
+    std::vector<size_t> gat((size_t)p->nseg + 1, 0);
+    for (int64_t s = 0; s < p->nseg; ++s) gat[(size_t)s + 1] = gat[(size_t)s] + (size_t)((p->gsegs[(size_t)s].len + kGatherChunk - 1) / kGatherChunk);
+    p->gchunks.resize(gat[(size_t)p->nseg]);
+    parallel_chunks(p->nseg, PT, [&](int, int64_t sb, int64_t se) {
+        for (int64_t s = sb; s < se; ++s)
+            for (size_t c = 0; c < gat[(size_t)s + 1] - gat[(size_t)s]; ++c) p->gchunks[gat[(size_t)s] + c] = {(uint32_t)s, (uint32_t)c};
+    });
+    size_t bytes = 0;
+    auto place = [&bytes](size_t n) { const size_t a = bytes; bytes += (n + 255) & ~(size_t)255; return a; };
+    const size_t at_c = place(p->cchunks.size() * sizeof(CenterChunk)), at_s = place(p->gsegs.size() * sizeof(GatherSeg)),
+                 at_g = place(p->gchunks.size() * sizeof(GatherChunk));
+    int rc = p->d_tables2.reserve(std::max<size_t>(bytes, 256));
+    if (rc != PC_OK) return rc;
+    uint8_t *d = p->d_tables2.p;
+    if (!p->cchunks.empty()) HIP_TRY(hipMemcpyAsync(d + at_c, p->cchunks.data(), p->cchunks.size() * sizeof(CenterChunk), hipMemcpyHostToDevice, e->stream));
+    if (!p->gsegs.empty()) HIP_TRY(hipMemcpyAsync(d + at_s, p->gsegs.data(), p->gsegs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, e->stream));
+    if (!p->gchunks.empty()) HIP_TRY(hipMemcpyAsync(d + at_g, p->gchunks.data(), p->gchunks.size() * sizeof(GatherChunk), hipMemcpyHostToDevice, e->stream));
+    p->d_cchunks.p = (CenterChunk *)(d + at_c); p->d_gsegs.p = (GatherSeg *)(d + at_s); p->d_gchunks.p = (GatherChunk *)(d + at_g);
+    p->center_ready = true;
     return PC_OK;
 }
 
@@ -1393,32 +1445,53 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     p->h_strand.assign(strand, strand + nseg);
     const int64_t kMaxPos = 0x7fffffffLL;
     uint32_t modes = 0;
-    for (int64_t s = 0; s < nseg; ++s) {
-        const int64_t len = end[s] - start[s];
-        if (len < 0) { delete p; return fail(PC_ERR_ARG, "segment %lld: end < start", (long long)s); }
-        if (out_step[s] != 1 && out_step[s] != -1 && out_step[s] != 0) { delete p; return fail(PC_ERR_ARG, "segment %lld: out_step must be +1, -1 or 0 (sum)", (long long)s); }
-        if (out_step[s] == 0) p->has_sums = true;
-        // output bounds
-        if (len > 0) {
-            const int64_t first = out_off[s], last = out_off[s] + (int64_t)out_step[s] * (len - 1);
-            const int64_t lo = std::min(first, last), hi = std::max(first, last) + (int64_t)(rows - 1) * row_stride[s];
-            if (lo < 0 || hi >= out_elems || row_stride[s] < 0) {
-                delete p;
-                return fail(PC_ERR_ARG, "segment %lld: output slice [%lld,%lld] outside buffer of %lld elements", (long long)s, (long long)lo, (long long)hi, (long long)out_elems);
+    // (large annotations: the passes over the segments and the per-contig sorts run on a thread pool)
+    const int PT = nseg >= (1 << 16) ? std::min(usable_cpus(), 32) : 1;
+    {
+        struct SegPart { std::vector<Iv> ivs; uint32_t modes = 0; int64_t covered = 0; bool has_sums = false; int64_t bad = -1; int bad_kind = 0; int64_t b_lo = 0, b_hi = 0; };
+        std::vector<SegPart> parts((size_t)PT);
+        parallel_chunks(nseg, PT, [&](int th, int64_t sb, int64_t se) {
+            SegPart &sp = parts[(size_t)th];
+            sp.ivs.reserve((size_t)(se - sb));
+            for (int64_t s = sb; s < se; ++s) {
+                const int64_t len = end[s] - start[s];
+                if (len < 0) { sp.bad = s; sp.bad_kind = 1; return; }
+                if (out_step[s] != 1 && out_step[s] != -1 && out_step[s] != 0) { sp.bad = s; sp.bad_kind = 2; return; }
+                if (out_step[s] == 0) sp.has_sums = true;
+                // output bounds
+                if (len > 0) {
+                    const int64_t first = out_off[s], last = out_off[s] + (int64_t)out_step[s] * (len - 1);
+                    const int64_t lo = std::min(first, last), hi = std::max(first, last) + (int64_t)(rows - 1) * row_stride[s];
+                    if (lo < 0 || hi >= out_elems || row_stride[s] < 0) { sp.bad = s; sp.bad_kind = 3; sp.b_lo = lo; sp.b_hi = hi; return; }
+                }
+                GatherSeg &g = p->gsegs[(size_t)s];
+                g.out_off = out_off[s]; g.row_stride = row_stride[s]; g.len = len; g.step = out_step[s]; g.pad = 0;
+                g.hist_off = -1; g.clip_lo = 0; g.clip_hi = 0; g.start = start[s];
+                sp.covered += (out_step[s] == 0 ? (len > 0 ? 1 : 0) : len) * rows;
+                if (tid[s] < 0 || tid[s] >= ntid || len == 0) continue; // unknown chromosome: zeros (genome_array.py:795-798)
+                const int64_t cs = std::max<int64_t>(start[s], 0), ce = std::min<int64_t>(end[s], kMaxPos);
+                if (ce <= cs) continue;
+                g.clip_lo = cs - start[s];
+                g.clip_hi = ce - start[s];
+                const int m = mode_of(strand[s]);
+                sp.modes |= 1u << m;
+                sp.ivs.push_back({tid[s], m, cs, ce});
             }
+        });
+        for (const SegPart &sp : parts)   // the defect of the lowest segment index, as a serial pass reports it
+            if (sp.bad >= 0) {
+                const long long b = (long long)sp.bad;
+                delete p;
+                if (sp.bad_kind == 1) return fail(PC_ERR_ARG, "segment %lld: end < start", b);
+                if (sp.bad_kind == 2) return fail(PC_ERR_ARG, "segment %lld: out_step must be +1, -1 or 0 (sum)", b);
+                return fail(PC_ERR_ARG, "segment %lld: output slice [%lld,%lld] outside buffer of %lld elements", b, (long long)sp.b_lo, (long long)sp.b_hi, (long long)out_elems);
+            }
+        for (SegPart &sp : parts) {
+            modes |= sp.modes;
+            p->covered += sp.covered;
+            p->has_sums |= sp.has_sums;
+            ivs.insert(ivs.end(), sp.ivs.begin(), sp.ivs.end());
         }
-        GatherSeg &g = p->gsegs[(size_t)s];
-        g.out_off = out_off[s]; g.row_stride = row_stride[s]; g.len = len; g.step = out_step[s]; g.pad = 0;
-        g.hist_off = -1; g.clip_lo = 0; g.clip_hi = 0; g.start = start[s];
-        p->covered += (out_step[s] == 0 ? (len > 0 ? 1 : 0) : len) * rows;
-        if (tid[s] < 0 || tid[s] >= ntid || len == 0) continue; // unknown chromosome: zeros (genome_array.py:795-798)
-        const int64_t cs = std::max<int64_t>(start[s], 0), ce = std::min<int64_t>(end[s], kMaxPos);
-        if (ce <= cs) continue;
-        g.clip_lo = cs - start[s];
-        g.clip_hi = ce - start[s];
-        const int m = mode_of(strand[s]);
-        modes |= 1u << m;
-        ivs.push_back({tid[s], m, cs, ce});
     }
     p->modes = modes;
     int nmodes = 0;
@@ -1439,7 +1512,29 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
 
     pclk.lap("plan: segments");
     // ---- islands: union of the queried intervals per (tid, mode)
-    std::sort(ivs.begin(), ivs.end(), [](const Iv &a, const Iv &b) {
+    // sorted by (contig, mode, start, end): contigs first (a counting pass), then every contig's stretch on its own
+    // thread -- the contigs of an annotation are independent
+    auto by_contig = [ntid, PT](auto &v, auto tid_of, auto less) {
+        typedef typename std::remove_reference<decltype(v)>::type Vec;
+        if (PT <= 1 || v.size() < (size_t)(1 << 16)) { std::sort(v.begin(), v.end(), less); return; }
+        std::vector<size_t> at((size_t)ntid + 1, 0);
+        for (const auto &x : v) at[(size_t)tid_of(x) + 1] += 1;
+        for (int t = 0; t < ntid; ++t) at[(size_t)t + 1] += at[(size_t)t];
+        Vec tmp(v.size());
+        { std::vector<size_t> cur(at.begin(), at.end() - 1); for (const auto &x : v) tmp[cur[(size_t)tid_of(x)]++] = x; }
+        v.swap(tmp);
+        // heaviest contigs first, dealt round-robin
+        std::vector<int> order((size_t)ntid);
+        for (int t = 0; t < ntid; ++t) order[(size_t)t] = t;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return at[(size_t)a + 1] - at[(size_t)a] > at[(size_t)b + 1] - at[(size_t)b]; });
+        parallel_chunks((int64_t)PT, PT, [&](int th, int64_t, int64_t) {
+            for (size_t k = (size_t)th; k < order.size(); k += (size_t)PT) {
+                const int t = order[k];
+                std::sort(v.begin() + (std::ptrdiff_t)at[(size_t)t], v.begin() + (std::ptrdiff_t)at[(size_t)t + 1], less);
+            }
+        });
+    };
+    by_contig(ivs, [](const Iv &a) { return a.tid; }, [](const Iv &a, const Iv &b) {
         if (a.tid != b.tid) return a.tid < b.tid;
         if (a.mode != b.mode) return a.mode < b.mode;
         if (a.s != b.s) return a.s < b.s;
@@ -1459,7 +1554,6 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
 
     pclk.lap("plan: islands");
     // ---- every segment -> its island (binary search)
-    const int PT = nseg >= (1 << 16) ? std::min(usable_cpus(), 32) : 1;
     parallel_chunks(nseg, PT, [&](int, int64_t sb, int64_t se) {
     for (int64_t s = sb; s < se; ++s) {
         GatherSeg &g = p->gsegs[(size_t)s];
@@ -1492,14 +1586,18 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
             a = b;
         }
     }
-    std::sort(raw.begin(), raw.end(), [](const RawPiece &a, const RawPiece &b) {
+    by_contig(raw, [](const RawPiece &a) { return a.tid; }, [](const RawPiece &a, const RawPiece &b) {
         if (a.tid != b.tid) return a.tid < b.tid;
         if (a.win != b.win) return a.win < b.win;
         if (a.pc_.mode != b.pc_.mode) return a.pc_.mode < b.pc_.mode;
         return a.pc_.start < b.pc_.start;
     });
+    // The tables only the center rule and the coordinate export read -- the 64-position chunks, the per-segment gather
+    // list -- are built (and uploaded) when first needed for a large annotation: a point-rule plan of 479 k exons
+    // otherwise pays for 1.4 M chunk descriptors it never uses.  Small plans keep everything in their one upload.
+    p->lazy_center = nseg >= (1 << 16);
     p->pieces.reserve(raw.size());
-    p->cchunks.reserve((size_t)(npos / kWave) + raw.size());
+    if (!p->lazy_center) p->cchunks.reserve((size_t)(npos / kWave) + raw.size());
     int max_slots = 1;
     for (size_t i = 0; i < raw.size(); ++i) {
         if (p->tiles.empty() || p->tiles.back().tid != raw[i].tid || p->tiles.back().win_start != (int32_t)raw[i].win) {
@@ -1516,7 +1614,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         t.span_hi = std::max<uint16_t>(t.span_hi, (uint16_t)(raw[i].pc_.start - t.win_start + raw[i].pc_.len));
         p->pieces.push_back(raw[i].pc_);
         // 64-position chunks for the ordered center replay (one wave each)
-        for (int32_t a = 0; a < raw[i].pc_.len; a += kWave) {
+        for (int32_t a = 0; !p->lazy_center && a < raw[i].pc_.len; a += kWave) {
             CenterChunk c;
             c.hist_off = raw[i].pc_.hist_off + a; c.tid = raw[i].tid; c.start = raw[i].pc_.start + a;
             c.len = std::min<int32_t>(kWave, raw[i].pc_.len - a); c.mode = raw[i].pc_.mode;
@@ -1561,22 +1659,54 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
             }
         });
         for (uint8_t z : part_zero) if (z) p->out_needs_zero = true;
-        // stable counting sort by tile (the thread lists are in segment order, taken in thread order)
+        // stable counting sort by tile (the thread lists are in segment order, taken in thread order).  The tile
+        // index space is cut into one stretch per thread; every thread walks all the lists' tile indices (4 bytes per
+        // record) and counts, then places, the records of its stretch: no serial pass over the records.
         const size_t ntl = p->tiles.size();
+        std::vector<size_t> list_off(part.size() + 1, 0);
+        for (size_t k = 0; k < part.size(); ++k) list_off[k + 1] = list_off[k] + part[k].size();
+        std::vector<uint32_t> tile_of(list_off.back());
+        parallel_chunks((int64_t)part.size(), PT, [&](int, int64_t kb, int64_t ke) {
+            for (int64_t k = kb; k < ke; ++k)
+                for (size_t i = 0; i < part[(size_t)k].size(); ++i) tile_of[list_off[(size_t)k] + i] = part[(size_t)k][i].tile;
+        });
         std::vector<uint32_t> at(ntl + 1, 0);
-        for (const auto &v : part) for (const RawOut &r : v) at[(size_t)r.tile + 1] += 1;
-        for (size_t t = 0; t < ntl; ++t) {
-            p->tiles[t].op_begin = at[t];
-            at[t + 1] += at[t];
-            p->tiles[t].op_end = at[t + 1];
-        }
-        p->opieces.resize(at[ntl]);
-        for (const auto &v : part) for (const RawOut &r : v) p->opieces[at[r.tile]++] = r.o;
+        std::vector<size_t> stretch_total((size_t)PT + 1, 0);
+        auto stretch = [&](int th, size_t &t0, size_t &t1) { t0 = ntl * (size_t)th / (size_t)PT; t1 = ntl * ((size_t)th + 1) / (size_t)PT; };
+        parallel_chunks((int64_t)PT, PT, [&](int th, int64_t, int64_t) {   // records per tile of the stretch
+            size_t t0, t1;
+            stretch(th, t0, t1);
+            size_t n = 0;
+            for (const uint32_t t : tile_of)
+                if (t >= t0 && t < t1) { at[(size_t)t + 1] += 1; ++n; }
+            stretch_total[(size_t)th + 1] = n;
+        });
+        for (int th = 0; th < PT; ++th) stretch_total[(size_t)th + 1] += stretch_total[(size_t)th];
+        p->opieces.resize(list_off.back());
+        parallel_chunks((int64_t)PT, PT, [&](int th, int64_t, int64_t) {   // offsets of the stretch's tiles, then placement
+            size_t t0, t1;
+            stretch(th, t0, t1);
+            if (t0 == t1) return;
+            uint32_t run = (uint32_t)stretch_total[(size_t)th];
+            for (size_t t = t0; t < t1; ++t) {
+                const uint32_t c = at[t + 1];
+                p->tiles[t].op_begin = run;
+                at[t + 1] = run;            // cursor of tile t (at[] is indexed t + 1 within the stretch; at[t0] belongs to the stretch below)
+                run += c;
+                p->tiles[t].op_end = run;
+            }
+            for (size_t k = 0; k < part.size(); ++k) {
+                const uint32_t *tl = tile_of.data() + list_off[k];
+                const std::vector<RawOut> &v = part[k];
+                for (size_t i = 0; i < v.size(); ++i)
+                    if (tl[i] >= t0 && tl[i] < t1) p->opieces[at[(size_t)tl[i] + 1]++] = v[i].o;
+            }
+        });
     }
 
     pclk.lap("plan: output pieces");
     // ---- gather work list (center rule)
-    for (int64_t s = 0; s < nseg; ++s) {
+    for (int64_t s = 0; !p->lazy_center && s < nseg; ++s) {
         const int64_t len = p->gsegs[(size_t)s].len;
         for (int64_t c = 0; c * kGatherChunk < len; ++c) p->gchunks.push_back({(uint32_t)s, (uint32_t)c});
     }
@@ -1588,7 +1718,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     auto place = [&bytes](size_t n) { const size_t at = bytes; bytes += (n + 255) & ~(size_t)255; return at; };
     const size_t at_tiles = place(p->tiles.size() * sizeof(Tile)), at_pieces = place(p->pieces.size() * sizeof(Piece)),
                  at_opieces = place(p->opieces.size() * sizeof(OutPiece)), at_cchunks = place(p->cchunks.size() * sizeof(CenterChunk)),
-                 at_gsegs = place(p->gsegs.size() * sizeof(GatherSeg)), at_gchunks = place(p->gchunks.size() * sizeof(GatherChunk)),
+                 at_gsegs = place(p->lazy_center ? 0 : p->gsegs.size() * sizeof(GatherSeg)), at_gchunks = place(p->gchunks.size() * sizeof(GatherChunk)),
                  at_items = place((p->tiles.size() + 1) * sizeof(uint32_t)), at_total = place(64);
     // a short compact histogram rides along, already zeroed (one memset less on the first count)
     const size_t hist_full = (size_t)p->npos * (size_t)p->rows * sizeof(double);
@@ -1612,7 +1742,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         put(at_pieces, p->pieces.data(), p->pieces.size() * sizeof(Piece));
         put(at_opieces, p->opieces.data(), p->opieces.size() * sizeof(OutPiece));
         put(at_cchunks, p->cchunks.data(), p->cchunks.size() * sizeof(CenterChunk));
-        put(at_gsegs, p->gsegs.data(), p->gsegs.size() * sizeof(GatherSeg));
+        if (!p->lazy_center) put(at_gsegs, p->gsegs.data(), p->gsegs.size() * sizeof(GatherSeg));
         put(at_gchunks, p->gchunks.data(), p->gchunks.size() * sizeof(GatherChunk));
         if (through_pinned) memset(h + at_items, 0, bytes - at_items);
         else if (hipMemsetAsync(d + at_items, 0, bytes - at_items, e->stream) != hipSuccess) copy_failed = true;
@@ -1662,7 +1792,9 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         return fail(PC_ERR_ARG, "pc_count: center mapping / normalisation produce float64 (map_factories.pyx:230, genome_array.py:826-827)");
     HIP_TRY(hipSetDevice(e->device));
     int rc = PC_OK;
-    if (center) {   // the center streams of the strand selections this plan queries (built once per file and filter state)
+    if (center) {   // the center-only tables of a large plan; the center streams of the strand selections it queries
+        rc = ensure_center_tables(e, p);
+        if (rc != PC_OK) return rc;
         const bool need[3] = {(p->modes & 1u) != 0, (p->modes & 2u) != 0, (p->modes & 12u) != 0};
         for (auto *f : e->files)
             for (int k = 0; k < 3 && rc == PC_OK; ++k)
@@ -2041,6 +2173,7 @@ int pc_plan_coordinates(pc_engine *e, pc_plan *p, int64_t *host_out, int64_t out
     DevBuf<int64_t> d;
     d.pool = &e->pool;
     int rc = d.reserve((size_t)out_elems);
+    if (rc == PC_OK) rc = ensure_center_tables(e, p);   // the per-segment gather list of a large plan
     if (rc != PC_OK) return rc;
     hipStream_t st = e->stream;
     HIP_TRY(hipMemsetAsync(d.p, 0xff, (size_t)out_elems * 8, st));   // -1: elements no segment covers
