@@ -70,7 +70,7 @@ typedef struct pc_plan pc_plan;
 #define PC_OUT_FLOAT64 1
 
 #define PC_OFFSET_TABLE_LEN 10000 /* map_factories.pxd:10-12 */
-#define PC_MAX_ALIGNED_LEN 65535
+#define PC_MAX_ALIGNED_LEN 65535 /* of the packed 16-bit field; longer reads: pc_add_alignment_file_wide */
 
 const char *pc_last_error(void);
 int pc_abi_version(void);
@@ -105,6 +105,17 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                           const int32_t *pos, const uint16_t *alen, const uint8_t *flags,
                           const uint8_t *nblk, int64_t nrun, const int32_t *blk_start,
                           const int32_t *blk_len);
+/* The same with WIDE records: reads whose aligned length exceeds 65 535 or that have more than 255 aligned runs (long
+ * reads; the reference has no such limit -- read.positions is a Python list, map_factories.pyx:243, 349).  Such a
+ * record carries the markers alen = 65535 AND nblk = 255 in the packed arrays and its true values in the side arrays:
+ *   n_wide                 number of wide records
+ *   wide_idx               their record indices, ascending
+ *   wide_alen, wide_nblk   true L and run count (int32); runs in blk_* as for every record with >= 2 runs */
+int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
+                               const int32_t *pos, const uint16_t *alen, const uint8_t *flags,
+                               const uint8_t *nblk, int64_t nrun, const int32_t *blk_start,
+                               const int32_t *blk_len, int64_t n_wide, const int64_t *wide_idx,
+                               const int32_t *wide_alen, const int32_t *wide_nblk);
 /* replace the flags of one staged file (host-side filters changed) */
 int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags);
 int pc_num_files(pc_engine *e);

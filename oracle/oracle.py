@@ -56,6 +56,8 @@ def lib():
             i64, vp, vp, vp, vp, vp, vp, vp, vp]          # segments + outputs
         L.po_count_segments_mt.restype = ctypes.c_int
         L.po_count_segments_mt.argtypes = L.po_count_segments.argtypes + [i32]
+        L.po_count_segments_wide_mt.restype = ctypes.c_int
+        L.po_count_segments_wide_mt.argtypes = L.po_count_segments_mt.argtypes + [i64, vp, vp, vp]
         L.po_cigar_to_runs.restype = ctypes.c_int
         L.po_cigar_to_runs.argtypes = [ctypes.c_int32, i32, vp, vp, i32, vp, vp, vp]
         _lib = L
@@ -138,14 +140,18 @@ def count_segments(aln, spec, seg_tid, seg_start, seg_end, seg_strand, want_mapp
     assert a["alen"].dtype == np.uint16 and a["flags"].dtype == np.uint8 and a["nblk"].dtype == np.uint8
     assert a["blk_start"].dtype == np.int32 and a["blk_len"].dtype == np.int32
     sf = spec.get("size_filter")
-    rcode = L.po_count_segments_mt(
+    # wide records (reads beyond the 16-bit / 8-bit fields): true lengths / run counts in the side arrays
+    wi = np.ascontiguousarray(a["wide_idx"], np.int64) if "wide_idx" in a else np.zeros(0, np.int64)
+    wa = np.ascontiguousarray(a["wide_alen"], np.int32) if "wide_idx" in a else np.zeros(0, np.int32)
+    wn = np.ascontiguousarray(a["wide_nblk"], np.int32) if "wide_idx" in a else np.zeros(0, np.int32)
+    rcode = L.po_count_segments_wide_mt(
         n, _ptr(a["tid"]), _ptr(a["pos"]), _ptr(a["alen"]), _ptr(a["flags"]), _ptr(a["nblk"]),
         _ptr(a.get("file_id")), _ptr(a["blk_start"]), _ptr(a["blk_len"]),
         spec["kind"], spec["param"], _ptr(spec["fw"]), _ptr(spec["rc"]),
         spec["min_len"], spec["max_len"],
         0 if sf is None else 1, 0 if sf is None else int(sf[0]), 0 if sf is None else int(sf[1]),
         nseg, _ptr(seg_tid), _ptr(seg_start), _ptr(seg_end), _ptr(seg_strand),
-        _ptr(out_off), _ptr(out), _ptr(warn), _ptr(mapped), int(threads))
+        _ptr(out_off), _ptr(out), _ptr(warn), _ptr(mapped), int(threads), len(wi), _ptr(wi), _ptr(wa), _ptr(wn))
     if rcode != 0:
         raise RuntimeError("oracle: po_count_segments failed with code %d" % rcode)
     arrays = []

@@ -73,7 +73,22 @@ typedef struct {
     const int32_t *blk_start, *blk_len;
     int64_t *blk_off; /* derived: first run of record i in blk_* (valid if nblk>=2) */
     int64_t *ref_end; /* derived: htslib bam_endpos */
+    /* wide records (> 65 535 aligned positions or > 255 runs; include/plastid_counts.h): markers alen 65535 /
+     * nblk 255 in the packed arrays, true values here, record indices ascending */
+    int64_t n_wide;
+    const int64_t *wide_idx;
+    const int32_t *wide_alen, *wide_nblk;
 } po_aln;
+
+/* true aligned length / run count of record i */
+static int64_t po_wide_at(const po_aln *a, int64_t i) {
+    if (a->n_wide == 0 || a->alen[i] != 0xffffu || a->nblk[i] != 0xffu) return -1;
+    int64_t lo = 0, hi = a->n_wide;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (a->wide_idx[mid] < i) lo = mid + 1; else hi = mid; }
+    return (lo < a->n_wide && a->wide_idx[lo] == i) ? lo : -1;
+}
+static int32_t po_len(const po_aln *a, int64_t i) { int64_t w = po_wide_at(a, i); return w >= 0 ? a->wide_alen[w] : (int32_t)a->alen[i]; }
+static int32_t po_nb(const po_aln *a, int64_t i) { int64_t w = po_wide_at(a, i); return w >= 0 ? a->wide_nblk[w] : (int32_t)a->nblk[i]; }
 
 typedef struct {
     int kind;
@@ -91,12 +106,13 @@ static int po_prepare(po_aln *a) {
     int64_t off = 0;
     for (int64_t i = 0; i < a->n; ++i) {
         a->blk_off[i] = off;
-        if (a->nblk[i] >= 2) {
-            int64_t last = off + a->nblk[i] - 1;
+        const int32_t nb = po_nb(a, i), L = po_len(a, i);
+        if (nb >= 2) {
+            int64_t last = off + nb - 1;
             a->ref_end[i] = (int64_t)a->blk_start[last] + a->blk_len[last];
-            off += a->nblk[i];
-        } else if (a->alen[i] > 0) {
-            a->ref_end[i] = (int64_t)a->pos[i] + a->alen[i];
+            off += nb;
+        } else if (L > 0) {
+            a->ref_end[i] = (int64_t)a->pos[i] + L;
         } else {
             a->ref_end[i] = (int64_t)a->pos[i] + 1; /* htslib: no aligned bases */
         }
@@ -113,14 +129,15 @@ static void po_release(po_aln *a) {
 /* read.positions (pysam get_reference_positions): every aligned reference coordinate, ascending */
 static int po_positions(const po_aln *a, int64_t i, int32_t *P) {
     int L = 0;
-    if (a->nblk[i] >= 2) {
-        for (int b = 0; b < a->nblk[i]; ++b) {
+    const int32_t nb = po_nb(a, i);
+    if (nb >= 2) {
+        for (int b = 0; b < nb; ++b) {
             int32_t s = a->blk_start[a->blk_off[i] + b];
             int32_t n = a->blk_len[a->blk_off[i] + b];
             for (int32_t x = 0; x < n; ++x) P[L++] = s + x;
         }
     } else {
-        for (int32_t x = 0; x < (int32_t)a->alen[i]; ++x) P[L++] = a->pos[i] + x;
+        for (int32_t x = 0, n1 = po_len(a, i); x < n1; ++x) P[L++] = a->pos[i] + x;
     }
     return L;
 }
@@ -300,17 +317,19 @@ static void *po_worker(void *arg) {
     return NULL;
 }
 
-int po_count_segments_mt(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
-                         const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
-                         const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
-                         const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
-                         int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
-                         const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
-                         const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped, int nthreads) {
+int po_count_segments_wide_mt(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
+                              const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
+                              const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
+                              const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
+                              int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
+                              const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
+                              const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped, int nthreads,
+                              int64_t n_wide, const int64_t *wide_idx, const int32_t *wide_alen, const int32_t *wide_nblk) {
     po_aln a;
     memset(&a, 0, sizeof(a));
     a.n = n; a.tid = tid; a.pos = pos; a.alen = alen; a.flags = flags; a.nblk = nblk;
     a.file_id = file_id; a.blk_start = blk_start; a.blk_len = blk_len;
+    a.n_wide = n_wide; a.wide_idx = wide_idx; a.wide_alen = wide_alen; a.wide_nblk = wide_nblk;
     po_map m;
     memset(&m, 0, sizeof(m));
     m.kind = kind; m.param = param; m.fw = fw; m.rc = rc; m.min_len = min_len; m.max_len = max_len;
@@ -346,7 +365,7 @@ int po_count_segments_mt(int64_t n, const int32_t *tid, const int32_t *pos, cons
             return PO_ERR_ARG; /* not coordinate sorted: pysam.fetch would raise */
         }
         if (a.ref_end[i] - pos[i] > max_span) max_span = a.ref_end[i] - pos[i];
-        if (alen[i] > maxL) maxL = alen[i];
+        if (po_len(&a, i) > maxL) maxL = po_len(&a, i);
     }
     if (nrng > 0) rng_hi[nrng - 1] = n;
 
@@ -371,6 +390,18 @@ int po_count_segments_mt(int64_t n, const int32_t *tid, const int32_t *pos, cons
     free(rng_lo); free(rng_hi); free(rng_tid);
     po_release(&a);
     return rcode;
+}
+
+int po_count_segments_mt(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
+                         const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
+                         const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
+                         const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
+                         int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
+                         const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
+                         const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped, int nthreads) {
+    return po_count_segments_wide_mt(n, tid, pos, alen, flags, nblk, file_id, blk_start, blk_len, kind, param, fw, rc,
+                                     min_len, max_len, filt_on, filt_min, filt_max, nseg, seg_tid, seg_start, seg_end,
+                                     seg_strand, out_off, out, warn, mapped, nthreads, 0, NULL, NULL, NULL);
 }
 
 int po_count_segments(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,

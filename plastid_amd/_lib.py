@@ -38,6 +38,7 @@ SIGNATURES = {
     "pc_reload_knobs": (_int, [_vp]),
     "pc_clear_alignments": (_int, [_vp]),
     "pc_add_alignment_file": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "pc_add_alignment_file_wide": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "pc_update_flags": (_int, [_vp, _int, _i64, _vp]),
     "pc_num_files": (_int, [_vp]),
     "pc_num_records": (_i64, [_vp, _int]),

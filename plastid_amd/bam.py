@@ -37,6 +37,9 @@ def _load():
         L.pb_ref_length.argtypes = [vp, ctypes.c_int]
         L.pb_counts.argtypes = [vp, vp]
         L.pb_fill.argtypes = [vp] * 8
+        L.pb_wide_count.restype = ctypes.c_int64
+        L.pb_wide_count.argtypes = [vp]
+        L.pb_fill_wide.argtypes = [vp] * 4
         _lib = L
     return _lib
 
@@ -85,6 +88,12 @@ def read_bam(path, threads=0, regions=None):
         bl = np.empty(nrun, np.int32)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
         L.pb_fill(h, p(tid), p(pos), p(alen), p(flags), p(nblk), p(bs), p(bl))
+        wide = {}
+        nw = int(L.pb_wide_count(h))
+        if nw > 0:   # reads beyond the 16-bit / 8-bit columns: true lengths / run counts aside (packing.py)
+            wi, wa, wn = np.empty(nw, np.int64), np.empty(nw, np.int32), np.empty(nw, np.int32)
+            L.pb_fill_wide(h, p(wi), p(wa), p(wn))
+            wide = dict(wide_idx=wi, wide_alen=wa, wide_nblk=wn)
     finally:
         L.pb_close(h)
     if mapped < 0:   # an index without the per-reference counts samtools writes
@@ -92,6 +101,6 @@ def read_bam(path, threads=0, regions=None):
         warnings.warn("the BAI index of %s carries no mapped-read counts; using the number of alignments read" % path)
         mapped = n
     out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
-                           validate=False)   # the native reader has checked every invariant validate() checks
+                           validate=False, **wide)   # the native reader has checked every invariant validate() checks
     out.filename = path
     return out

@@ -55,6 +55,10 @@ struct Part {
     uint8_t *flags = nullptr, *nblk = nullptr;
     size_t n = 0, nrun = 0;
     int64_t mapped = 0, unplaced = 0, total = 0;
+    // wide records of the piece (more than 65 535 aligned positions or more than 255 aligned runs: markers 65535 / 255 in
+    // the packed columns, true values here): record index within the piece, aligned length, run count
+    std::vector<int64_t> wide_idx;
+    std::vector<int32_t> wide_alen, wide_nblk;
     // first defect found inside the piece: record index within the piece, message; `before_order` marks
     // the checks the serial walk makes before it looks at the sort order of a record
     int64_t err_rec = INT64_MAX;
@@ -436,8 +440,10 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         }
         if (unknown_op) { ret = bad(i, false, "unknown CIGAR operation in " + bam.path); break; }
         if (ref > 0x7fffffffLL) { ret = bad(i, false, "alignment ends beyond 2^31 - 1"); break; }   // run starts are int32
-        if (L > 65535) { ret = bad(i, false, "alignment with more than 65535 aligned positions is not supported"); break; }
-        if (runs.size() > 255) { ret = bad(i, false, "alignment with more than 255 aligned runs is not supported"); break; }
+        if (L > 0x7fffffffLL) { ret = bad(i, false, "alignment with more than 2^31 - 1 aligned positions"); break; }
+        // beyond the 16-bit / 8-bit columns (or equal to both markers): a wide record, its true values aside
+        const bool wide = L > 65535 || runs.size() > 255 || (L == 65535 && runs.size() == 255);
+        if (wide) { pt.wide_idx.push_back((int64_t)n); pt.wide_alen.push_back((int32_t)L); pt.wide_nblk.push_back((int32_t)runs.size()); }
         // the packed format keys a record on its first aligned position; a CIGAR that opens with
         // D/N (not produced by aligners) is accepted only if that keeps the file order
         const int32_t spos = runs.empty() ? pos : runs[0].first;
@@ -449,9 +455,9 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         last_tid = tid; last_pos = pos; last_spos = spos;
         c_tid[n] = tid;
         c_pos[n] = spos;
-        c_alen[n] = (uint16_t)L;
+        c_alen[n] = wide ? (uint16_t)65535 : (uint16_t)L;
         c_flags[n] = (flag & 0x10) ? 1 : 0;
-        c_nblk[n] = (uint8_t)runs.size();
+        c_nblk[n] = wide ? (uint8_t)255 : (uint8_t)runs.size();
         ++n;
         if (runs.size() >= 2)
             for (auto &x : runs) {
@@ -1054,22 +1060,27 @@ int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, c
         return lo < merged.size() && merged[lo].tid == tid && merged[lo].s < endpos;
     };
     for (Part &pt : bam.parts) {
-        size_t w = 0, rw = 0, rr = 0;
+        size_t w = 0, rw = 0, rr = 0, wk = 0, ww = 0;   // wk / ww: wide records seen / kept
         for (size_t i = 0; i < pt.n; ++i) {
-            const int nb = pt.nblk[i];
+            int64_t nb = pt.nblk[i], L = pt.alen[i];
+            const bool wide = wk < pt.wide_idx.size() && pt.wide_idx[wk] == (int64_t)i;   // true values aside
+            if (wide) { nb = pt.wide_nblk[wk]; L = pt.wide_alen[wk]; }
             const size_t runs = nb >= 2 ? (size_t)nb : 0;
             const int64_t endpos = nb >= 2 ? (int64_t)pt.blk_start[rr + runs - 1] + pt.blk_len[rr + runs - 1]
-                                           : (int64_t)pt.pos[i] + std::max<int64_t>(pt.alen[i], 1);
+                                           : (int64_t)pt.pos[i] + std::max<int64_t>(L, 1);
             if (overlaps(pt.tid[i], pt.pos[i], endpos)) {
                 pt.tid[w] = pt.tid[i]; pt.pos[w] = pt.pos[i]; pt.alen[w] = pt.alen[i]; pt.flags[w] = pt.flags[i]; pt.nblk[w] = pt.nblk[i];
                 for (size_t k = 0; k < runs; ++k) { pt.blk_start[rw + k] = pt.blk_start[rr + k]; pt.blk_len[rw + k] = pt.blk_len[rr + k]; }
+                if (wide) { pt.wide_idx[ww] = (int64_t)w; pt.wide_alen[ww] = pt.wide_alen[wk]; pt.wide_nblk[ww] = pt.wide_nblk[wk]; ++ww; }
                 ++w;
                 rw += runs;
             }
+            if (wide) ++wk;
             rr += runs;
         }
         pt.n = w;
         pt.nrun = rw;
+        pt.wide_idx.resize(ww); pt.wide_alen.resize(ww); pt.wide_nblk.resize(ww);
     }
     for (size_t k = 0; k < bam.parts.size(); ++k) {
         bam.rec_off[k + 1] = bam.rec_off[k] + bam.parts[k].n;
@@ -1167,6 +1178,30 @@ int pb_counts(void *h, int64_t *counts) {
     counts[1] = (int64_t)b->nrun;
     counts[2] = b->mapped;
     counts[3] = b->total;
+    return 0;
+}
+
+// wide records (see Part): how many, and their flat record indices / true aligned lengths / run counts
+int64_t pb_wide_count(void *h) {
+    Bam *b = static_cast<Bam *>(h);
+    if (!b || !b->loaded) return -1;
+    int64_t n = 0;
+    for (const Part &pt : b->parts) n += (int64_t)pt.wide_idx.size();
+    return n;
+}
+
+int pb_fill_wide(void *h, int64_t *idx, int32_t *alen, int32_t *nblk) {
+    Bam *b = static_cast<Bam *>(h);
+    if (!b || !b->loaded) return fail("pb_fill_wide: file not loaded");
+    size_t at = 0;
+    for (size_t k = 0; k < b->parts.size(); ++k) {
+        const Part &pt = b->parts[k];
+        for (size_t j = 0; j < pt.wide_idx.size(); ++j, ++at) {
+            idx[at] = (int64_t)b->rec_off[k] + pt.wide_idx[j];
+            alen[at] = pt.wide_alen[j];
+            nblk[at] = pt.wide_nblk[j];
+        }
+    }
     return 0;
 }
 

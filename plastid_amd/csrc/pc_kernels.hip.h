@@ -53,6 +53,7 @@ constexpr int kWG = 256;          // 4 waves of 64
 constexpr int kHistWG = PC_HIST_WG;
 constexpr int kWave = 64;
 constexpr uint32_t kFlagReverse = 0x01;
+constexpr uint32_t kFlagWide = 0x10;      // engine-internal: aligned length > 65 535 or > 255 runs -- the 16 / 8-bit fields read 65535 / 255, true values aside
 constexpr uint32_t kFlagRuns = 0x20;      // engine-internal: every aligned run of the record is in the run stream
 constexpr uint32_t kFlagLong = 0x40;      // engine-internal: span > W, handled by the long-read path
 constexpr uint32_t kFlagExcluded = 0x80;
@@ -119,6 +120,12 @@ struct FileView {
     const uint2 *cs_ent[3];
     const uint32_t *cs_soff[3];
     int32_t c_lbase;                // first aligned length of the center rule's SGPR value table
+    // wide records: true {aligned length, run count} per long-list entry (nullptr: the file has none) and by record index
+    const uint2 *long_wide;
+    const uint2 *xlong_wide;
+    const uint32_t *wide_rec;
+    const uint2 *wide_val;
+    int64_t nwide;
     int64_t n;
     int64_t nlong;
     int64_t ngap;
@@ -162,6 +169,11 @@ struct GFile {
     const uint32_t PC_GLOBAL *xllin_tab;
     const uint32_t PC_GLOBAL *xplin_tab;
     int32_t c_lbase;
+    const u32x2 PC_GLOBAL *long_wide;
+    const u32x2 PC_GLOBAL *xlong_wide;
+    const uint32_t PC_GLOBAL *wide_rec;
+    const u32x2 PC_GLOBAL *wide_val;
+    int64_t nwide;
     int64_t n;
     int64_t nlong;
     int64_t ngap;
@@ -197,6 +209,11 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.xllin_tab = (const uint32_t PC_GLOBAL *)v.xllin_tab;
     g.xplin_tab = (const uint32_t PC_GLOBAL *)v.xplin_tab;
     g.c_lbase = v.c_lbase;   // (the center streams are picked by a run-time index: read from the FileView in memory, cs_stream)
+    g.long_wide = (const u32x2 PC_GLOBAL *)v.long_wide;
+    g.xlong_wide = (const u32x2 PC_GLOBAL *)v.xlong_wide;
+    g.wide_rec = (const uint32_t PC_GLOBAL *)v.wide_rec;
+    g.wide_val = (const u32x2 PC_GLOBAL *)v.wide_val;
+    g.nwide = v.nwide;
     g.n = v.n;
     g.nlong = v.nlong;
     g.ngap = v.ngap;
@@ -370,6 +387,22 @@ __device__ __forceinline__ int map_kleft_dyn(const MapParams &mp, int L, bool re
     }
 }
 
+// true {aligned length, run count} of record i: the packed header, or -- for a wide record -- the side table
+__device__ __forceinline__ void rec_true(const GFile &fv, int64_t i, uint32_t meta, int &L, int &nb) {
+    L = rec_len(meta);
+    nb = rec_nblk(meta);
+    if (rec_flags(meta) & kFlagWide) {
+        int64_t lo = 0, hi = fv.nwide;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)fv.wide_rec[mid] < i) lo = mid + 1; else hi = mid;
+        }
+        const u32x2 v = fv.wide_val[lo];
+        L = (int)v.x;
+        nb = (int)v.y;
+    }
+}
+
 // read.positions[k] for a record with aligned runs
 __device__ __forceinline__ int32_t walk_runs(const GFile &fv, int64_t i, int nblk, int k) {
     const i32x2 PC_GLOBAL *b = fv.blk + fv.blk_off[i];
@@ -384,12 +417,12 @@ __device__ __forceinline__ int32_t walk_runs(const GFile &fv, int64_t i, int nbl
 
 __device__ __forceinline__ int32_t rec_end(const GFile &fv, int64_t i, int32_t pos, uint32_t meta) {
     // htslib bam_endpos
-    int nb = rec_nblk(meta);
+    int L, nb;
+    rec_true(fv, i, meta, L, nb);
     if (nb >= 2) {
         i32x2 r = fv.blk[fv.blk_off[i] + nb - 1];
         return r.x + r.y;
     }
-    int L = rec_len(meta);
     return pos + (L > 0 ? L : 1);
 }
 
@@ -948,7 +981,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVE
 #pragma unroll
     for (int m = 0; m < kModes; ++m) c.base[m] = ((w.mode_mask >> m) & 1u) ? (nslots++) * mp.rows * G : -1;
     c.fmin = mp.filt_on ? (uint32_t)mp.filt_min : 0u;
-    c.frange = (mp.filt_on && mp.filt_max != -1) ? (uint32_t)(mp.filt_max - mp.filt_min) : 0xffffu - c.fmin;
+    c.frange = (mp.filt_on && mp.filt_max != -1) ? (uint32_t)(mp.filt_max - mp.filt_min) : 0x7fffffffu - c.fmin;   // (no maximum: every length, wide reads included)
     c.tab_lo = tab_lo;
     c.tab_n = (uint32_t)tab_n;
     // LDS: [table-driven entries, indexed by aligned length from 0][packed offset tables][bins]
@@ -1054,7 +1087,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVE
         const u32x4 g = in ? fv.xlong_rec[j] : gnone;
         const i32x4 gr = in ? fv.xlong_runs[j] : i32x4{0, 1, 0, 0};
         const uint32_t meta = g.y, hi = meta >> 16;
-        const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
+        int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
+        if (hi & kFlagWide) { const u32x2 tv = fv.xlong_wide[j]; L = (int)tv.x; nb = (int)tv.y; }   // beyond the 16 / 8-bit fields
         const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
         const i32x2 b0 = {gr.x, gr.y}, b1 = {gr.z, gr.w};
         int kf, kr;
@@ -1409,11 +1443,11 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
 // One read replayed from its record header (wave-uniform arguments): reads that come from the long-span list, and
 // reads the 8-bit fields of a stream entry cannot describe.  CenterMapFactory.__call__, map_factories.pyx:242-256.
 __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp, const double PC_GLOBAL *inv, int32_t pos,
-                                            uint32_t meta, uint32_t boff, int32_t p, double &acc) {
-    const int nib = mp.param, L = rec_len(meta), nbk = rec_nblk(meta);
+                                            int L, int nbk, uint32_t boff, int32_t p, double &acc) {
+    const int nib = mp.param;
     const int m = L - 2 * nib;                               // map_length, :245
     if (m <= 0 || !size_ok(mp, L)) return;
-    const double val = inv[m];                               // 1.0 / map_length, :250
+    const double val = m < 65536 ? inv[m] : 1.0 / (double)m; // 1.0 / map_length, :250 (the table holds the common lengths)
     bool hit;
     if (nbk < 2) {
         hit = (uint32_t)(p - (pos + nib)) < (uint32_t)m;
@@ -1562,7 +1596,7 @@ __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) voi
                 // a batch with a length outside the table, or a read the entry cannot describe: entry by entry
                 const int mtot = L - 2 * nib;
                 double val = 0.0;
-                if (live && size_ok(mp, L)) val = inv[mtot];    // live implies mtot >= m > 0
+                if (live && size_ok(mp, L)) val = mtot < 65536 ? inv[mtot] : 1.0 / (double)mtot;    // live implies mtot >= m > 0
                 unsigned long long todo = __ballot(live || indirect);
                 while (todo) {
                     const int j = __builtin_ctzll(todo);
@@ -1570,7 +1604,9 @@ __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) voi
                     if (lane_u32((uint32_t)indirect, j)) {
                         const int64_t i = (int64_t)lane_u32(recidx, j);
                         const u32x2 rr = fv.rec[i];
-                        center_read(fv, mp, inv, (int32_t)rr.x, rr.y, rec_nblk(rr.y) >= 2 ? fv.blk_off[i] : 0u, p, acc);
+                        int Li, nbi;
+                        rec_true(fv, i, rr.y, Li, nbi);
+                        center_read(fv, mp, inv, (int32_t)rr.x, Li, nbi, nbi >= 2 ? fv.blk_off[i] : 0u, p, acc);
                     } else {
                         const int aj = (int)lane_u32((uint32_t)a0, j), mj = (int)lane_u32((uint32_t)m, j);
                         const double vj = lane_f64(val, j);
@@ -1608,10 +1644,12 @@ __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) voi
             if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_key) break; // sorted by start: the rest is met in the near window
             const i32x4 runs = in ? fv.long_runs[j] : i32x4{0, 0, 0, 0};
             const uint32_t fl = rec_flags(g.y);
-            const int nbk = rec_nblk(g.y), r = lane & 1;
+            int nbk = rec_nblk(g.y), Lg = rec_len(g.y);
+            if (in && (fl & kFlagWide)) { const u32x2 tv = fv.long_wide[j]; Lg = (int)tv.x; nbk = (int)tv.y; }   // beyond the 16 / 8-bit fields
+            const int r = lane & 1;
             const bool ok = in && (int64_t)(int32_t)g.x < near_key && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse);
             replay(ok && nbk <= 2 && (r == 0 || nbk == 2), ok && nbk > 2 && r == 0, r ? runs.z : runs.x, r ? runs.w : runs.y,
-                   r ? runs.y : 0, rec_len(g.y), g.w, 64);
+                   r ? runs.y : 0, Lg, g.w, 64);
         }
         // near window: the stream entries of the records that start in [start - W + 1, end).  Whole chunks take the
         // exact record range of the pre-pass; a sub-chunk narrows it to its own positions.
@@ -1810,12 +1848,24 @@ __global__ __launch_bounds__(kWG) void k_run_lin(const unsigned long long *__res
 
 // staging: the 4-byte stream word of every record, and (for the following prefix sum) the number of runs a
 // multi-run record keeps in blk -- both functions of the uploaded 8-byte record
-__global__ __launch_bounds__(kWG) void k_stream_from_rec(const uint2 *__restrict__ rec, int64_t n, uint32_t *stream, uint32_t *nruns) {
+__global__ __launch_bounds__(kWG) void k_stream_from_rec(const uint2 *__restrict__ rec, int64_t n, uint32_t *stream, uint32_t *nruns,
+                                                         const uint32_t *__restrict__ wide_rec, const uint2 *__restrict__ wide_val, int64_t nwide) {
     const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (i >= n) return;
     const uint2 r = rec[i];
     stream[i] = stream_word(r.x, r.y);
-    if (nruns) { const uint32_t nb = r.y >> 24; nruns[i] = nb >= 2u ? nb : 0u; }
+    if (nruns) {
+        uint32_t nb = r.y >> 24;
+        if ((r.y >> 16) & kFlagWide) {   // a wide record: its true run count is in the side table
+            int64_t lo = 0, hi = nwide;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)wide_rec[mid] < i) lo = mid + 1; else hi = mid;
+            }
+            nb = wide_val[lo].y;
+        }
+        nruns[i] = nb >= 2u ? nb : 0u;
+    }
 }
 
 __global__ __launch_bounds__(kWG) void k_update_side_flags(uint4 *list, int64_t n, const uint2 *__restrict__ rec) {
@@ -1944,8 +1994,8 @@ __global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fview, MapParams 
     const uint32_t meta = r.y;
     const uint32_t fl = rec_flags(meta);
     const int32_t pos = (int32_t)r.x;
-    const int L = rec_len(meta);
-    const int nb = rec_nblk(meta);
+    int L, nb;
+    rec_true(fv, i, meta, L, nb);
     const bool rev = fl & kFlagReverse;
     uint8_t out = 0;
     const bool fetched = (int64_t)pos < end && (int64_t)rec_end(fv, i, pos, meta) > start;
@@ -1975,7 +2025,8 @@ __global__ __launch_bounds__(kWG) void k_unmappable(FileView fview, MapParams mp
     const u32x2 r = fv.rec[i];
     const uint32_t meta = r.y;
     const uint32_t fl = rec_flags(meta);
-    const int L = rec_len(meta);
+    int L, nb_unused;
+    rec_true(fv, i, meta, L, nb_unused);
     if ((fl & kFlagExcluded) || !size_ok(mp, L)) return;
     bool bad;
     switch (mp.kind) {

@@ -260,6 +260,11 @@ struct StagedFile {
     DevBuf<uint4> xlong_rec;
     DevBuf<int4> xlong_runs;
     DevBuf<uint32_t> xllin_tab, xplin_tab;
+    // wide records (aligned length > 65 535 or > 255 aligned runs): their true {length, run count} next to every
+    // long-list entry, and by record index (ascending) for the kernels that start from a record
+    int64_t nwide = 0;
+    DevBuf<uint2> long_wide, xlong_wide, wide_val;
+    DevBuf<uint32_t> wide_rec;
     // center streams (built at the first center-rule count that needs them; dropped when the host-side filters change)
     DevBuf<uint2> cs_ent[3];
     DevBuf<uint32_t> cs_soff[3];
@@ -277,6 +282,8 @@ struct StagedFile {
         v.run_rec = run_rec.p; v.rlin_tab = rlin_tab.p; v.nrunrec = nrunrec;
         v.xlong_rec = xlong_rec.p; v.xlong_runs = xlong_runs.p; v.xllin_tab = xllin_tab.p; v.xplin_tab = xplin_tab.p; v.nxlong = nxlong;
         for (int k = 0; k < 3; ++k) { v.cs_ent[k] = cs_n[k] >= 0 ? cs_ent[k].p : nullptr; v.cs_soff[k] = cs_n[k] >= 0 ? cs_soff[k].p : nullptr; }
+        v.long_wide = nwide ? long_wide.p : nullptr; v.xlong_wide = nwide ? xlong_wide.p : nullptr;
+        v.wide_rec = wide_rec.p; v.wide_val = wide_val.p; v.nwide = nwide;
         v.c_lbase = c_lbase;
         return v;
     }
@@ -692,7 +699,30 @@ struct StageClock {
 int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
                           const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
                           const int32_t *blk_start, const int32_t *blk_len) {
+    return pc_add_alignment_file_wide(e, n, ntid, tid, pos, alen, flags, nblk, nrun, blk_start, blk_len, 0, nullptr, nullptr, nullptr);
+}
+
+int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
+                               const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
+                               const int32_t *blk_start, const int32_t *blk_len, int64_t n_wide, const int64_t *wide_idx,
+                               const int32_t *wide_alen, const int32_t *wide_nblk) {
     if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    if (n_wide < 0 || (n_wide > 0 && (!wide_idx || !wide_alen || !wide_nblk))) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad wide-record arrays");
+    for (int64_t k = 0; k < n_wide; ++k) {
+        const int64_t i = wide_idx[k];
+        if (i < 0 || i >= n || (k > 0 && i <= wide_idx[k - 1])) return fail(PC_ERR_ARG, "pc_add_alignment_file: wide_idx must be ascending record indices");
+        if (alen[i] != 0xffffu || nblk[i] != 0xffu) return fail(PC_ERR_ARG, "pc_add_alignment_file: record %lld is listed as wide but its alen / nblk are not 65535 / 255", (long long)i);
+        if (wide_alen[k] < 0 || wide_nblk[k] < 0 || (wide_nblk[k] == 0) != (wide_alen[k] == 0) || wide_nblk[k] > wide_alen[k])
+            return fail(PC_ERR_ARG, "pc_add_alignment_file: record %lld: bad wide alen / nblk", (long long)i);
+    }
+    // true aligned length / run count of record i (wide records keep them in the side arrays)
+    auto wide_at = [&](int64_t i) -> int64_t {
+        if (n_wide == 0 || alen[i] != 0xffffu || nblk[i] != 0xffu) return -1;
+        const int64_t *q = std::lower_bound(wide_idx, wide_idx + n_wide, i);
+        return (q != wide_idx + n_wide && *q == i) ? (int64_t)(q - wide_idx) : -1;
+    };
+    auto AL = [&](int64_t i) -> int64_t { const int64_t w = wide_at(i); return w >= 0 ? (int64_t)wide_alen[w] : (int64_t)alen[i]; };
+    auto NB = [&](int64_t i) -> int64_t { const int64_t w = wide_at(i); return w >= 0 ? (int64_t)wide_nblk[w] : (int64_t)nblk[i]; };
     if (n < 0 || ntid <= 0 || nrun < 0) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad sizes");
     if (n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL array");
     if (nrun > 0 && (!blk_start || !blk_len)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL run array");
@@ -719,7 +749,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     // where its first run sits
     parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
         int64_t r = 0;
-        for (int64_t i = b; i < en; ++i) r += nblk[i] >= 2 ? nblk[i] : 0;
+        for (int64_t i = b; i < en; ++i) r += nblk[i] >= 2 ? NB(i) >= 2 ? NB(i) : 0 : 0;
         c1[(size_t)t].runs = r;
     });
     {
@@ -773,11 +803,11 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 return;
             }
             c.tid_count[(size_t)tid[i] + 1] += 1;
-            const int L = alen[i];
+            const int64_t L = AL(i), nbi = NB(i);
             int64_t end;
-            if (nblk[i] >= 2) {
+            if (nbi >= 2) {
                 int64_t sum = 0, prev_end = -1;
-                for (int k = 0; k < nblk[i]; ++k) {
+                for (int64_t k = 0; k < nbi; ++k) {
                     const int64_t s0 = blk_start[run_cursor + k], ln = blk_len[run_cursor + k];
                     if (ln <= 0 || (k > 0 && s0 <= prev_end)) {
                         bad(i, PC_ERR_ARG, "record %lld: aligned runs must be non-empty, ascending and non-adjacent", i, 0);
@@ -789,16 +819,16 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 }
                 if (sum != L) { bad(i, PC_ERR_ARG, "record %lld: run lengths do not sum to alen", i, 0); return; }
                 end = prev_end;
-                run_cursor += nblk[i];
+                run_cursor += nbi;
             } else {
-                if ((nblk[i] == 0) != (L == 0)) { bad(i, PC_ERR_ARG, "record %lld: nblk/alen mismatch", i, 0); return; }
+                if ((nbi == 0) != (L == 0)) { bad(i, PC_ERR_ARG, "record %lld: nblk/alen mismatch", i, 0); return; }
                 end = (int64_t)pos[i] + (L > 0 ? L : 1);
             }
             if (end > 0x7fffffffLL) { bad(i, PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", i, 0); return; }
             const int64_t sp = end - pos[i];
             c.tid_end[(size_t)tid[i]] = std::max(c.tid_end[(size_t)tid[i]], end);
             c.span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
-            c.len_hist[(size_t)L] += 1;
+            c.len_hist[(size_t)std::min<int64_t>(L, 65535)] += 1;
         }
     });
     std::vector<int64_t> span_hist(1026, 0), len_hist(65536, 0), tid_end((size_t)ntid, 0);
@@ -855,6 +885,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     const int64_t nslices = (n + S - 1) / S;
     struct Unit { // one thread's share of one slice
         std::vector<uint4> long_rec, gap_rec, xlong_rec;
+        std::vector<uint2> long_wide, xlong_wide;     // true {aligned length, run count} of every long-list entry
         std::vector<int32_t> long_span, xlong_span;
         int W = 1, Wg = 1, Wr = 1, smin = 65536, smax = -1;
         int64_t max_span = 1, cursor = 0;
@@ -878,8 +909,9 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                         std::memcpy(&eight, nblk + i, 8);
                         if (((eight & 0xfefefefefefefefeull) == 0)) { i += 7; continue; }   // every count is 0 or 1
                     }
-                    r += nblk[i] >= 2 ? nblk[i] : 0;
-                    rs += (nblk[i] >= 2 && alen[i] <= kStreamMaxLen) ? nblk[i] : 0;   // runs that go to the run stream
+                    const int64_t nbi = nblk[i] >= 2 ? NB(i) : nblk[i];
+                    r += nbi >= 2 ? nbi : 0;
+                    rs += (nbi >= 2 && alen[i] <= kStreamMaxLen) ? nbi : 0;   // runs that go to the run stream (never wide: those carry alen 65535)
                 }
                 units[(size_t)u].cursor = r;
                 units[(size_t)u].run_at = rs;
@@ -953,7 +985,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                             continue;
                         }
                     }
-                    const int L = alen[i], nb = nblk[i];
+                    const int64_t wi = wide_at(i);           // a record beyond the 16-bit / 8-bit fields: true values aside
+                    const int L = wi >= 0 ? wide_alen[wi] : (int)alen[i], nb = wi >= 0 ? wide_nblk[wi] : (int)nblk[i];
                     uint32_t boff = 0u;
                     int64_t end;
                     if (nb >= 2) {
@@ -965,10 +998,11 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                     }
                     const int32_t sp = (int32_t)(end - pos[i]);
                     uint32_t meta = (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) | ((uint32_t)nb << 24);
+                    if (wi >= 0) meta = 0xffffu | ((uint32_t)((flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) | kFlagWide) << 16) | (0xffu << 24);
                     c.max_span = std::max<int64_t>(c.max_span, sp);
                     // multi-run reads of ordinary length: every aligned run goes to the run stream (what the
                     // point rules scan); only longer reads keep to the gapped / long-span side lists there
-                    const bool in_runs = nb >= 2 && L <= kStreamMaxLen;
+                    const bool in_runs = nb >= 2 && L <= kStreamMaxLen && wi < 0;
                     if (in_runs) {
                         meta |= (kFlagRuns << 16);
                         uint32_t cum = 0;
@@ -982,13 +1016,15 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                             cum += rl;
                         }
                     }
-                    if (sp > wcap) {
+                    if (sp > wcap || wi >= 0) {   // (wide records always take the long-span lists: those carry their true length / run count)
                         meta |= (kFlagLong << 16);
                         c.long_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
                         c.long_span.push_back(sp);
+                        c.long_wide.push_back(make_uint2((uint32_t)L, (uint32_t)nb));
                         if (!in_runs) {
                             c.xlong_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
                             c.xlong_span.push_back(sp);
+                            c.xlong_wide.push_back(make_uint2((uint32_t)L, (uint32_t)nb));
                         }
                     } else {
                         c.W = std::max(c.W, (int)sp);
@@ -1035,10 +1071,20 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
             return fail(PC_ERR_HIP, "pc_add_alignment_file: staging the sentinels failed");
         }
     }
+    if (n_wide > 0) {   // the wide records by record index: what k_stream_from_rec and the per-record kernels look up
+        std::vector<uint32_t> wr((size_t)n_wide);
+        std::vector<uint2> wv((size_t)n_wide);
+        for (int64_t k = 0; k < n_wide; ++k) { wr[(size_t)k] = (uint32_t)wide_idx[k]; wv[(size_t)k] = make_uint2((uint32_t)wide_alen[k], (uint32_t)wide_nblk[k]); }
+        rc = sf->wide_rec.upload(wr, e->stream);
+        if (rc == PC_OK) rc = sf->wide_val.upload(wv, e->stream);
+        if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
+        if (rc != PC_OK) { delete sf; return rc; }
+        sf->nwide = n_wide;
+    }
     if (n > 0) {   // the 4-byte stream, and the run offsets (exclusive sum of the run counts of the multi-run records)
         const unsigned grid = (unsigned)((n + kWG - 1) / kWG);
         hipLaunchKernelGGL(k_stream_from_rec, dim3(grid), dim3(kWG), 0, e->stream, sf->rec.p, n, sf->stream.p,
-                           nrun > 0 ? sf->blk_off.p : nullptr);
+                           nrun > 0 ? sf->blk_off.p : nullptr, sf->wide_rec.p, sf->wide_val.p, n_wide);
         hipError_t he = hipGetLastError();
         if (he == hipSuccess && nrun > 0) {
             size_t tmp_bytes = 0;
@@ -1079,6 +1125,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     HostBuf<uint32_t> long_idx(nlong);
     HostBuf<int32_t> long_tid(nlong), long_pmax(nlong), xlong_tid(nxlong), xlong_pmax(nxlong);
     HostBuf<int4> long_runs(nlong), gap_runs(ngap), xlong_runs(nxlong);
+    HostBuf<uint2> long_wide(n_wide ? nlong : 0), xlong_wide(n_wide ? nxlong : 0);   // only files with wide records carry these
     if (!long_rec.p || !gap_rec.p || !long_idx.p || !long_tid.p || !long_pmax.p || !long_runs.p || !gap_runs.p || !xlong_rec.p ||
         !xlong_tid.p || !xlong_pmax.p || !xlong_runs.p) {
         delete sf;
@@ -1086,10 +1133,11 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     }
     // the first two aligned runs of every side-list record travel next to its header: the kernels then
     // need the run array only for reads with three or more runs
-    auto first_two = [&](const uint4 &g) { // {pos, aligned length | flags << 16 | runs << 24, first run, record}
-        return (g.y >> 24) >= 2u ? make_int4(blk_start[g.z], blk_len[g.z], blk_start[g.z + 1], blk_len[g.z + 1])
-                                 : make_int4((int32_t)g.x, (int)(g.y & 0xffffu), 0, 0);
+    auto first_two = [&](const uint4 &g, const uint2 &tv) { // {pos, aligned length | flags << 16 | runs << 24, first run, record}; true {length, runs}
+        return tv.y >= 2u ? make_int4(blk_start[g.z], blk_len[g.z], blk_start[g.z + 1], blk_len[g.z + 1])
+                          : make_int4((int32_t)g.x, (int)tv.x, 0, 0);
     };
+    auto plain_tv = [](const uint4 &g) { return make_uint2(g.y & 0xffffu, g.y >> 24); };
     parallel_chunks((int64_t)units.size(), T, [&](int, int64_t ub, int64_t ue) {
         int t_of = 0;
         for (int64_t u = ub; u < ue; ++u) {
@@ -1104,12 +1152,13 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 long_idx[at] = g.w;
                 long_tid[at] = t_of;
                 long_pmax[at] = (int32_t)g.x + c.long_span[k];   // the read's own end; made a running maximum below
-                long_runs[at] = first_two(g);
+                long_runs[at] = first_two(g, c.long_wide[k]);
+                if (n_wide) long_wide[at] = c.long_wide[k];
             }
             at = go_of[(size_t)u];
             for (size_t k = 0; k < c.gap_rec.size(); ++k, ++at) {
                 gap_rec[at] = c.gap_rec[k];
-                gap_runs[at] = first_two(c.gap_rec[k]);
+                gap_runs[at] = first_two(c.gap_rec[k], plain_tv(c.gap_rec[k]));
             }
             at = xo_of[(size_t)u];
             int t_x = 0;
@@ -1119,7 +1168,8 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
                 xlong_rec[at] = g;
                 xlong_tid[at] = t_x;
                 xlong_pmax[at] = (int32_t)g.x + c.xlong_span[k];
-                xlong_runs[at] = first_two(g);
+                xlong_runs[at] = first_two(g, c.xlong_wide[k]);
+                if (n_wide) xlong_wide[at] = c.xlong_wide[k];
             }
         }
     });
@@ -1170,9 +1220,13 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
         const int32_t *h_lt = long_tid.p, *h_lp = long_pmax.p;
         const int4 *h_lru = long_runs.p, *h_gru = gap_runs.p, *h_xru = xlong_runs.p;
         const uint4 *h_xr = xlong_rec.p;
+        const uint2 *h_lw = long_wide.p, *h_xw = xlong_wide.p;
+        const size_t nlw = n_wide ? nlong : 0, nxw = n_wide ? nxlong : 0;
         side_up = std::async(std::launch::async, [=]() -> int {
             if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
             int r = f->long_idx.upload(h_li, nlong, up_stream);
+            if (r == PC_OK && nlw) r = f->long_wide.upload(h_lw, nlw, up_stream);
+            if (r == PC_OK && nxw) r = f->xlong_wide.upload(h_xw, nxw, up_stream);
             if (r == PC_OK) r = f->xlong_rec.upload(h_xr, nxlong, up_stream);
             if (r == PC_OK) r = f->xlong_runs.upload(h_xru, nxlong, up_stream);
             if (r == PC_OK) r = f->long_tid.upload(h_lt, nlong, up_stream);

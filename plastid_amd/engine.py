@@ -59,10 +59,18 @@ class Engine(object):
                 raise ValueError("alignment array '%s' has %d entries, expected %d" % (name, len(getattr(packed, name)), packed.n))
         if len(packed.blk_start) != len(packed.blk_len):
             raise ValueError("run arrays blk_start / blk_len differ in length")
-        check(self._lib.pc_add_alignment_file(
-            self._h, packed.n, ntid, _ptr(packed.tid), _ptr(packed.pos), _ptr(packed.alen),
-            _ptr(packed.flags), _ptr(packed.nblk), len(packed.blk_start), _ptr(packed.blk_start),
-            _ptr(packed.blk_len)))
+        if getattr(packed, "n_wide", 0):   # reads beyond the 16-bit / 8-bit fields: their true lengths / run counts aside
+            if len(packed.wide_alen) != packed.n_wide or len(packed.wide_nblk) != packed.n_wide:
+                raise ValueError("wide_idx / wide_alen / wide_nblk differ in length")
+            check(self._lib.pc_add_alignment_file_wide(
+                self._h, packed.n, ntid, _ptr(packed.tid), _ptr(packed.pos), _ptr(packed.alen),
+                _ptr(packed.flags), _ptr(packed.nblk), len(packed.blk_start), _ptr(packed.blk_start),
+                _ptr(packed.blk_len), packed.n_wide, _ptr(packed.wide_idx), _ptr(packed.wide_alen), _ptr(packed.wide_nblk)))
+        else:
+            check(self._lib.pc_add_alignment_file(
+                self._h, packed.n, ntid, _ptr(packed.tid), _ptr(packed.pos), _ptr(packed.alen),
+                _ptr(packed.flags), _ptr(packed.nblk), len(packed.blk_start), _ptr(packed.blk_start),
+                _ptr(packed.blk_len)))
         self.nfiles += 1
         self.ntid = ntid
 

@@ -23,6 +23,12 @@ what gets bulk-staged to HBM:
 
 Records must be in BAM order: sorted by ``(tid, pos)``, ties in file order.
 
+WIDE records -- more than 65 535 aligned positions or more than 255 aligned runs (long reads; the
+reference has no such limit: ``read.positions`` is a Python list) -- carry the markers ``alen = 65535`` and
+``nblk = 255`` in the packed arrays and their true values in three short side arrays: ``wide_idx`` (ascending
+record indices), ``wide_alen``, ``wide_nblk`` (int32).  :meth:`PackedAlignments.true_alen` /
+:meth:`true_nblk` give the true values of every record.
+
 A :class:`PackedAlignments` also duck-types the small part of
 ``pysam.AlignmentFile`` that ``BAMGenomeArray`` uses (``fetch``, ``references``,
 ``lengths``, ``mapped``, ``close`` -- genome_array.py:669, 679, 690, 802-807), so
@@ -147,7 +153,8 @@ class PackedAlignments(object):
     """One coordinate-sorted alignment file as flat arrays (see module doc)."""
 
     def __init__(self, tid, pos, alen, flags, nblk, blk_start=None, blk_len=None,
-                 references=None, lengths=None, mapped=None, read_objects=None, validate=True):
+                 references=None, lengths=None, mapped=None, read_objects=None, validate=True,
+                 wide_idx=None, wide_alen=None, wide_nblk=None):
         self.tid = np.ascontiguousarray(tid, dtype=np.int32)
         self.pos = np.ascontiguousarray(pos, dtype=np.int32)
         self.alen = np.ascontiguousarray(alen, dtype=np.uint16)
@@ -157,6 +164,9 @@ class PackedAlignments(object):
             np.zeros(0, np.int32) if blk_start is None else blk_start, dtype=np.int32)
         self.blk_len = np.ascontiguousarray(
             np.zeros(0, np.int32) if blk_len is None else blk_len, dtype=np.int32)
+        self.wide_idx = np.ascontiguousarray(np.zeros(0, np.int64) if wide_idx is None else wide_idx, dtype=np.int64)
+        self.wide_alen = np.ascontiguousarray(np.zeros(0, np.int32) if wide_alen is None else wide_alen, dtype=np.int32)
+        self.wide_nblk = np.ascontiguousarray(np.zeros(0, np.int32) if wide_nblk is None else wide_nblk, dtype=np.int32)
         n = len(self.tid)
         if references is None:
             ntid = int(self.tid.max()) + 1 if n else 1
@@ -181,11 +191,36 @@ class PackedAlignments(object):
     def n(self):
         return len(self.tid)
 
+    @property
+    def n_wide(self):
+        return len(self.wide_idx)
+
+    def true_alen(self):
+        """Aligned length of every record as int64 (the side arrays patched in for wide records)."""
+        a = self.alen.astype(np.int64)
+        if self.n_wide:
+            a[self.wide_idx] = self.wide_alen
+        return a
+
+    def true_nblk(self):
+        """Run count of every record as int64 (the side arrays patched in for wide records)."""
+        a = self.nblk.astype(np.int64)
+        if self.n_wide:
+            a[self.wide_idx] = self.wide_nblk
+        return a
+
     def validate(self):
         n = self.n
         for name in ("pos", "alen", "flags", "nblk"):
             if len(getattr(self, name)) != n:
                 raise ValueError("PackedAlignments: array '%s' has wrong length" % name)
+        if self.n_wide:
+            w = self.wide_idx
+            if len(self.wide_alen) != len(w) or len(self.wide_nblk) != len(w) or np.any(np.diff(w) <= 0) or w[0] < 0 or w[-1] >= n:
+                raise ValueError("PackedAlignments: wide_idx must be ascending record indices with one wide_alen / wide_nblk each")
+            if np.any(self.alen[w] != MAX_ALIGNED_LEN) or np.any(self.nblk[w] != MAX_RUNS):
+                raise ValueError("PackedAlignments: wide records carry alen 65535 and nblk 255 in the packed arrays")
+            return self._validate_general()
         if n:
             if self.tid.min() < 0 or self.tid.max() >= len(self.references):
                 raise ValueError("PackedAlignments: tid out of range of `references`")
@@ -220,11 +255,44 @@ class PackedAlignments(object):
             if np.any(self.blk_start[inner] <= ends[np.nonzero(inner)[0] - 1]):
                 raise ValueError("PackedAlignments: runs must be ascending and non-adjacent")
 
+    def _validate_general(self):
+        """validate() for a file with wide records: the same checks on the true lengths / run counts."""
+        n = self.n
+        L, nb = self.true_alen(), self.true_nblk()
+        if n:
+            if self.tid.min() < 0 or self.tid.max() >= len(self.references):
+                raise ValueError("PackedAlignments: tid out of range of `references`")
+            key = (self.tid.astype(np.int64) << 32) | self.pos.astype(np.int64)
+            if np.any(key[1:] < key[:-1]):
+                raise ValueError("PackedAlignments: records are not sorted by (tid, pos); alignment files must be coordinate sorted")
+            if self.pos.min() < 0:
+                raise ValueError("PackedAlignments: negative alignment start")
+        multi = nb >= 2
+        if int(nb[multi].sum()) != len(self.blk_start) or len(self.blk_start) != len(self.blk_len):
+            raise ValueError("PackedAlignments: run arrays do not match `nblk`")
+        if np.any(L[nb == 1] == 0) or np.any((nb == 0) != (L == 0)):
+            raise ValueError("PackedAlignments: nblk/alen mismatch")
+        if len(self.blk_start):
+            off = self.block_offsets()
+            idx = np.nonzero(multi)[0]
+            if np.any(self.blk_start[off[idx]] != self.pos[idx]):
+                raise ValueError("PackedAlignments: first run of a record must start at pos")
+            if np.any(self.blk_len <= 0):
+                raise ValueError("PackedAlignments: empty run")
+            if np.any(np.add.reduceat(self.blk_len.astype(np.int64), off[idx]) != L[idx]):
+                raise ValueError("PackedAlignments: run lengths do not sum to alen")
+            ends = self.blk_start.astype(np.int64) + self.blk_len
+            inner = np.ones(len(self.blk_start), bool)
+            inner[off[idx]] = False
+            if np.any(self.blk_start[inner] <= ends[np.nonzero(inner)[0] - 1]):
+                raise ValueError("PackedAlignments: runs must be ascending and non-adjacent")
+
     def block_offsets(self):
         """``off[i]`` = index of record ``i``'s first run in ``blk_*`` (meaningful
         for ``nblk >= 2`` records)."""
         if self._blk_off is None:
-            cnt = np.where(self.nblk >= 2, self.nblk, 0).astype(np.int64)
+            nb = self.true_nblk() if self.n_wide else self.nblk
+            cnt = np.where(nb >= 2, nb, 0).astype(np.int64)
             off = np.zeros(self.n + 1, np.int64)
             np.cumsum(cnt, out=off[1:])
             self._blk_off = off
@@ -240,22 +308,33 @@ class PackedAlignments(object):
     def ref_end(self):
         """htslib ``bam_endpos``: one past the last aligned reference position
         (``pos + 1`` for records without aligned bases)."""
-        end = self.pos.astype(np.int64) + np.maximum(self.alen.astype(np.int64), 1)
-        multi = np.nonzero(self.nblk >= 2)[0]
+        L = self.true_alen() if self.n_wide else self.alen.astype(np.int64)
+        nb = self.true_nblk() if self.n_wide else self.nblk
+        end = self.pos.astype(np.int64) + np.maximum(L, 1)
+        multi = np.nonzero(nb >= 2)[0]
         if len(multi):
             off = self.block_offsets()
-            last = off[multi] + self.nblk[multi] - 1
+            last = off[multi] + nb[multi] - 1
             end[multi] = self.blk_start[last].astype(np.int64) + self.blk_len[last]
         return end
 
+    def _true_of(self, i):
+        """``(aligned length, run count)`` of record `i`."""
+        if self.n_wide and self.alen[i] == MAX_ALIGNED_LEN and self.nblk[i] == MAX_RUNS:
+            k = int(np.searchsorted(self.wide_idx, i))
+            if k < self.n_wide and self.wide_idx[k] == i:
+                return int(self.wide_alen[k]), int(self.wide_nblk[k])
+        return int(self.alen[i]), int(self.nblk[i])
+
     def runs_of(self, i):
-        if self.nblk[i] >= 2:
+        L, nb = self._true_of(i)
+        if nb >= 2:
             o = int(self.block_offsets()[i])
             return [(int(self.blk_start[o + b]), int(self.blk_len[o + b]))
-                    for b in range(int(self.nblk[i]))]
-        if self.alen[i] == 0:
+                    for b in range(nb)]
+        if L == 0:
             return []
-        return [(int(self.pos[i]), int(self.alen[i]))]
+        return [(int(self.pos[i]), L)]
 
     def read(self, i):
         """Read object for record ``i`` (the original object if this file was
@@ -318,11 +397,8 @@ class PackedAlignments(object):
                 alen[i] = sum(r[1] for r in runs)
             elif positions is not None:
                 pos[i] = positions[i]
-        if alen.max(initial=0) > MAX_ALIGNED_LEN:
-            raise ValueError("alignments with more than %d aligned positions are not supported"
-                             % MAX_ALIGNED_LEN)
-        if nblk.max(initial=0) > MAX_RUNS:
-            raise ValueError("alignments with more than %d aligned runs are not supported" % MAX_RUNS)
+        if alen.max(initial=0) > 0x7fffffff:
+            raise ValueError("alignments with more than 2^31 - 1 aligned positions are not supported")
         if sort and n:
             key = (tid.astype(np.int64) << 32) | pos.astype(np.int64)
             order = np.argsort(key, kind="stable")
@@ -336,8 +412,14 @@ class PackedAlignments(object):
                 for s, ln in runs:
                     bs.append(s)
                     bl.append(ln)
-        out = cls(tid, pos, alen.astype(np.uint16), flags, nblk.astype(np.uint8), bs, bl,
-                  references=references, lengths=lengths, mapped=mapped, read_objects=read_objects)
+        # records beyond the 16-bit / 8-bit fields keep markers there and their true values aside (module doc)
+        wide = np.nonzero((alen > MAX_ALIGNED_LEN) | (nblk > MAX_RUNS) | ((alen == MAX_ALIGNED_LEN) & (nblk == MAX_RUNS)))[0]
+        a16, n8 = alen.copy(), nblk.copy()
+        a16[wide] = MAX_ALIGNED_LEN
+        n8[wide] = MAX_RUNS
+        out = cls(tid, pos, a16.astype(np.uint16), flags, n8.astype(np.uint8), bs, bl,
+                  references=references, lengths=lengths, mapped=mapped, read_objects=read_objects,
+                  wide_idx=wide, wide_alen=alen[wide], wide_nblk=nblk[wide])
         out.sort_order = order
         return out
 
@@ -387,16 +469,24 @@ class PackedAlignments(object):
         if idx.dtype == bool:
             idx = np.nonzero(idx)[0]
         off = self.block_offsets()
-        multi = idx[self.nblk[idx] >= 2]
+        nb = self.true_nblk() if self.n_wide else self.nblk
+        multi = idx[nb[idx] >= 2]
         if len(multi):
-            sel = np.concatenate([np.arange(off[i], off[i] + self.nblk[i]) for i in multi])
+            sel = np.concatenate([np.arange(off[i], off[i] + nb[i]) for i in multi])
         else:
             sel = np.zeros(0, np.int64)
         ro = None if self._read_objects is None else [self._read_objects[i] for i in idx]
+        wide = {}
+        if self.n_wide:   # the selected wide records, at their new indices
+            is_w = np.zeros(self.n, bool)
+            is_w[self.wide_idx] = True
+            new_w = np.nonzero(is_w[idx])[0]
+            src = np.searchsorted(self.wide_idx, idx[new_w])
+            wide = dict(wide_idx=new_w, wide_alen=self.wide_alen[src], wide_nblk=self.wide_nblk[src])
         return PackedAlignments(self.tid[idx], self.pos[idx], self.alen[idx], self.flags[idx],
                                 self.nblk[idx], self.blk_start[sel], self.blk_len[sel],
                                 references=self.references, lengths=self.lengths,
-                                mapped=len(idx), read_objects=ro)
+                                mapped=len(idx), read_objects=ro, **wide)
 
 
     def slice(self, i0, i1):
@@ -406,10 +496,14 @@ class PackedAlignments(object):
         off = self.block_offsets()
         b0, b1 = int(off[i0]), int(off[i1])
         ro = None if self._read_objects is None else self._read_objects[i0:i1]
+        wide = {}
+        if self.n_wide:
+            k0, k1 = np.searchsorted(self.wide_idx, [i0, i1])
+            wide = dict(wide_idx=self.wide_idx[k0:k1] - i0, wide_alen=self.wide_alen[k0:k1], wide_nblk=self.wide_nblk[k0:k1])
         return PackedAlignments(self.tid[i0:i1], self.pos[i0:i1], self.alen[i0:i1], self.flags[i0:i1],
                                 self.nblk[i0:i1], self.blk_start[b0:b1], self.blk_len[b0:b1],
                                 references=self.references, lengths=self.lengths, mapped=i1 - i0,
-                                read_objects=ro, validate=False)
+                                read_objects=ro, validate=False, **wide)
 
 
 def concat_file_major(files):
@@ -418,7 +512,12 @@ def concat_file_major(files):
     genome_array.py:800-809).  Returns a dict of arrays incl. ``file_id``."""
     if not files:
         raise ValueError("no alignment files")
-    return {
+    base = np.cumsum([0] + [f.n for f in files])
+    wide = {}
+    if any(getattr(f, "n_wide", 0) for f in files):   # the wide records of all files, at their indices in the concatenation
+        wide = {"wide_idx": np.concatenate([f.wide_idx + base[k] for k, f in enumerate(files)]),
+                "wide_alen": np.concatenate([f.wide_alen for f in files]), "wide_nblk": np.concatenate([f.wide_nblk for f in files])}
+    return dict(wide, **{
         "tid": np.concatenate([f.tid for f in files]),
         "pos": np.concatenate([f.pos for f in files]),
         "alen": np.concatenate([f.alen for f in files]),
@@ -427,4 +526,4 @@ def concat_file_major(files):
         "file_id": np.concatenate([np.full(f.n, k, np.uint8) for k, f in enumerate(files)]),
         "blk_start": np.concatenate([f.blk_start for f in files]),
         "blk_len": np.concatenate([f.blk_len for f in files]),
-    }
+    })

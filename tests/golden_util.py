@@ -19,7 +19,11 @@ class Group(object):
     def aln(self, case):
         pfx = case["aln"]["prefix"]
         keys = ("tid", "pos", "alen", "flags", "nblk", "file_id", "blk_start", "blk_len")
-        return {k: self.arrays["%s_%s" % (pfx, k)] for k in keys}
+        out = {k: self.arrays["%s_%s" % (pfx, k)] for k in keys}
+        for k in ("wide_idx", "wide_alen", "wide_nblk"):    # reads beyond the 16-bit / 8-bit fields (wide_reads.npz)
+            if "%s_%s" % (pfx, k) in self.arrays:
+                out[k] = self.arrays["%s_%s" % (pfx, k)]
+        return out
 
     def __getitem__(self, key):
         return self.arrays[key]

@@ -345,3 +345,35 @@ def test_chunk_chaining_under_random_geometry(tmp_path, monkeypatch, seed):
         for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
             assert np.array_equal(getattr(got, name), getattr(exp, name)), (name, seed, trial)
         assert got.mapped == len(placed)
+
+
+def test_wide_reads_are_staged_not_refused(tmp_path):
+    """Reads with more than 65 535 aligned positions or more than 255 aligned runs (the reference has no such limit:
+    read.positions is a Python list, map_factories.pyx:243, 349) come out of the native reader as WIDE records --
+    markers in the packed columns, true lengths / run counts aside -- for a whole file and for a region load; a read of
+    exactly 65 535 bases in one run stays an ordinary record."""
+    from plastid_amd.packing import PackedAlignments
+    runs = [[(100, 30)], [(150, 70000)], [(200 + 3 * k, 2) for k in range(300)], [(5000, 20), (5100, 10)], [(6000, 65535)],
+            [(90000, 25)]]
+    pa = PackedAlignments.from_runs([0] * 6, [False, True, False, True, False, True], runs, references=["c"], lengths=[200000])
+    assert list(pa.wide_idx) == [1, 2] and list(pa.wide_alen) == [70000, 600] and list(pa.wide_nblk) == [1, 300]
+    assert list(pa.alen[[1, 2, 4]]) == [65535, 65535, 65535] and list(pa.nblk[[1, 2, 4]]) == [255, 255, 1]
+    path = str(tmp_path / "w.bam")
+    bam_writer.write_bam(path, pa.references, pa.lengths, bam_writer.packed_to_records(pa), index=True)
+    for small in (False, True):
+        if small:
+            os.environ.update(PB_CHUNK="4096", PB_PIECE="2")
+        try:
+            back = read_bam(path)
+        finally:
+            os.environ.pop("PB_CHUNK", None); os.environ.pop("PB_PIECE", None)
+        for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "wide_idx", "wide_alen", "wide_nblk"):
+            assert np.array_equal(getattr(back, k), getattr(pa, k)), (k, small)
+        back.validate()
+    assert np.array_equal(back.ref_end(), [130, 70150, 1099, 5110, 71535, 90025])
+    # a region only the long read (and the 65 535-base one) reaches
+    reg = read_bam(path, regions=[("c", 60000, 60010)])
+    assert reg.n == 2 and list(reg.wide_idx) == [0] and list(reg.wide_alen) == [70000] and list(reg.alen) == [65535, 65535]
+    sub = pa.subset([0, 2, 5])
+    assert list(sub.wide_idx) == [1] and list(sub.wide_nblk) == [300] and len(sub.blk_start) == 300
+    assert list(pa.slice(1, 4).wide_idx) == [0, 1]
