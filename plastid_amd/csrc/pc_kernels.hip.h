@@ -283,6 +283,13 @@ struct WorkItem {
 
 
 
+// Several alignment files: one work item serves a window for ALL of them (joint window).  The item itself carries the
+// ranges of file 0; those of file f >= 1 sit in a side array at [slot * (nfiles - 1) + f - 1].
+struct FileRange {
+    int64_t lo, hi, glo, ghi, llo, lhi;
+    uint32_t rlo, rhi;
+};
+
 struct CenterChunk {
     int64_t hist_off;
     int32_t tid;
@@ -556,11 +563,15 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
                                                            int nfiles, int G, int W, int Ws, int Wr, int64_t R, int64_t pile,
                                                            WorkItem *work, uint32_t *nwork, uint32_t *tile_items,
                                                            uint32_t work_cap, WorkItem *work_small, int small_g,
-                                                           int64_t small_n, int diag) {
+                                                           int64_t small_n, int diag, FileRange *chain, FileRange *chain_small) {
     __shared__ unsigned long long s_wave64[kRangesWG / 64];
     __shared__ uint32_t s_base[3];
     const int64_t idx = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
-    const bool live = idx < (int64_t)ntiles * nfiles;
+    // several files: ONE thread per window looks at all of them, and the window's work items are joint (every file's
+    // records binned into the same LDS bins, the output written once) -- only a pile-up still merges through the
+    // compact histogram
+    const bool joint = nfiles > 1;
+    const bool live = idx < (joint ? (int64_t)ntiles : (int64_t)ntiles * nfiles);
     int t = 0, f = 0, S = 1;
     Tile tl = {};
     GFile fv = {};
@@ -568,7 +579,67 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     int64_t wlo = 0, whi = 0, wglo = 0, wghi = 0, llo = 0, lhi = 0, wrlo = 0, wrhi = 0;
     uint32_t n_heavy = 0, n_light = 0, n_small = 0;
     bool merge = false;
-    if (live) {
+    // ranges of file `ff` for the window part [a, e) (a, e: first queried position, end rounded up to an index bucket)
+    auto file_ranges = [&](int ff, int32_t tidx, int64_t a, int64_t e, int64_t s_lo, int64_t s_hi, FileRange &r) {
+        const GFile g = ff == 0 ? gfile(file0) : gfile(files[ff]);
+        const int64_t q0 = g.lin_off[tidx], qn = g.lin_off[tidx + 1] - q0 - 1;
+        r.lo = lin_floor(g.lin_tab, q0, qn, a - Ws + 1);
+        r.hi = lin_floor(g.lin_tab, q0, qn, e);
+        r.glo = g.ngap ? lin_floor(g.glin_tab, q0, qn, a - W + 1) : 0;
+        r.ghi = g.ngap ? lin_floor(g.glin_tab, q0, qn, e) : 0;
+        r.rlo = g.nrunrec ? (uint32_t)lin_floor(g.rlin_tab, q0, qn, a - Wr + 1) : 0u;
+        r.rhi = g.nrunrec ? (uint32_t)lin_floor(g.rlin_tab, q0, qn, e) : 0u;
+        r.llo = r.lhi = 0;
+        if (g.nxlong) {   // long-span candidates of the whole queried span (every sub-window checks them)
+            r.lhi = lin_floor(g.xllin_tab, q0, qn, s_hi);
+            r.llo = lin_floor(g.xplin_tab, q0, qn, s_lo);
+            if (r.llo > r.lhi) r.llo = r.lhi;
+        }
+    };
+    int64_t jn = 0;   // joint: records of all files in the window
+    if (live && joint) {
+        t = (int)idx;
+        tl = tiles[t];
+        ws = tl.win_start;
+        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1;
+        int64_t ng = 0, nl = 0, nr = 0;
+        for (int ff = 0; ff < nfiles; ++ff) {
+            FileRange r;
+            file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
+            jn += r.hi - r.lo; ng += r.ghi - r.glo; nl += r.lhi - r.llo; nr += (int64_t)r.rhi - (int64_t)r.rlo;
+        }
+        while (S < kMaxSub && G % (S * 2 << kLinShift) == 0 && jn > R * S) S <<= 1;
+        if (S == 1) {
+            const bool small = small_g > 0 && (int)tl.span_hi - (int)tl.span_lo <= small_g && jn <= small_n && ng <= small_n &&
+                               nl <= small_n && nr <= small_n;
+            if (small) n_small = 1; else if (jn > R) n_heavy = 1; else n_light = 1;
+        } else {
+            const int sub = G / S;
+            for (int k = 0; k < S; ++k) {
+                const int64_t a = ws + (int64_t)k * sub;
+                int64_t nk = 0;
+                for (int ff = 0; ff < nfiles; ++ff) {
+                    const GFile g = ff == 0 ? gfile(file0) : gfile(files[ff]);
+                    const int64_t q0 = g.lin_off[tl.tid], qn = g.lin_off[tl.tid + 1] - q0 - 1;
+                    nk += lin_floor(g.lin_tab, q0, qn, a + sub) - lin_floor(g.lin_tab, q0, qn, a - Ws + 1);
+                }
+                if (nk > pile) merge = true; // a pile-up inside one sub-window
+                if (nk > R) ++n_heavy; else ++n_light;
+            }
+        }
+        if (merge) {   // record slices of every file, merged through the compact histogram
+            S = 1;
+            n_heavy = 0;
+            n_light = 0;
+            for (int ff = 0; ff < nfiles; ++ff) {
+                FileRange r;
+                file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
+                const int64_t nf = r.hi - r.lo;
+                n_light += nf > 0 ? (uint32_t)((nf + R - 1) / R) : ((r.ghi > r.glo || r.lhi > r.llo || r.rhi > r.rlo || ff == 0) ? 1u : 0u);
+            }
+        }
+    }
+    if (live && !joint) {
         t = (int)(idx / nfiles);
         f = (int)(idx % nfiles);
         tl = tiles[t];
@@ -636,6 +707,79 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     }
     __syncthreads();
     if (!(n_heavy + n_light + n_small)) return;
+    if (joint) {
+        WorkItem w;
+        w.tile = (uint32_t)t;
+        w.file = 0u;
+        w.mode_mask = tl.mode_mask;
+        w.piece_begin = tl.piece_begin; w.piece_end = tl.piece_end;
+        w.op_begin = tl.op_begin; w.op_end = tl.op_end;
+        w.win_start = tl.win_start;
+        w.span_lo = tl.span_lo; w.span_hi = tl.span_hi;
+        w.merge = merge ? 1u : 0u;
+        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1;
+        auto head = [&](const FileRange &r) {
+            w.lo = r.lo; w.hi = r.hi; w.glo = r.glo; w.ghi = r.ghi; w.llo = r.llo; w.lhi = r.lhi; w.rlo = r.rlo; w.rhi = r.rhi;
+        };
+        if (n_small) {
+            const uint32_t slot = s_base[2] + off_s;
+            for (int ff = 0; ff < nfiles; ++ff) {
+                FileRange r;
+                file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
+                if (ff == 0) head(r); else chain_small[(size_t)slot * (size_t)(nfiles - 1) + (size_t)(ff - 1)] = r;
+            }
+            w.win_start = tl.win_start + (int32_t)tl.span_lo; // a small window that starts at the first queried position
+            w.sub_lo = 0; w.sub_hi = small_g;
+            w.span_lo = 0; w.span_hi = (uint16_t)(tl.span_hi - tl.span_lo);
+            work_small[slot] = w;
+            return;
+        }
+        uint32_t ih = s_base[0] + off_h, il = s_base[1] + off_l;
+        if (merge) {
+            atomicAdd(&tile_items[t], n_light); // > 0 marks the tile for k_gather_split
+            for (int ff = 0; ff < nfiles; ++ff) {
+                FileRange r;
+                file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
+                const int64_t nf = r.hi - r.lo;
+                const uint32_t cnt = nf > 0 ? (uint32_t)((nf + R - 1) / R) : ((r.ghi > r.glo || r.lhi > r.llo || r.rhi > r.rlo || ff == 0) ? 1u : 0u);
+                w.file = (uint32_t)ff;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    w.lo = r.lo + (int64_t)k * R;
+                    w.hi = (w.lo + R < r.hi) ? w.lo + R : r.hi;
+                    w.glo = k == 0 ? r.glo : 0; w.ghi = k == 0 ? r.ghi : 0;
+                    w.llo = k == 0 ? r.llo : 0; w.lhi = k == 0 ? r.lhi : 0;
+                    w.rlo = k == 0 ? r.rlo : 0u; w.rhi = k == 0 ? r.rhi : 0u;
+                    w.sub_lo = 0; w.sub_hi = G;
+                    const uint32_t slot = work_cap - 1u - (il++);
+                    if (slot < work_cap) work[slot] = w;
+                }
+            }
+            return;
+        }
+        const int sub = G / S;
+        for (int k = 0; k < S; ++k) {
+            const int64_t a = S == 1 ? s_lo : ws + (int64_t)k * sub;
+            const int64_t e = S == 1 ? s_hi : a + sub;
+            FileRange r0, r;
+            file_ranges(0, tl.tid, a, e, s_lo, s_hi, r0);
+            int64_t nk = r0.hi - r0.lo;
+            for (int ff = 1; ff < nfiles; ++ff) {   // (counted first: the class decides the slot the chain entries belong to)
+                file_ranges(ff, tl.tid, a, e, s_lo, s_hi, r);
+                nk += r.hi - r.lo;
+            }
+            const uint32_t slot = nk > R ? ih++ : work_cap - 1u - (il++);
+            if (slot >= work_cap) continue; // capacity is an upper bound; the test is defensive
+            for (int ff = 1; ff < nfiles; ++ff) {
+                file_ranges(ff, tl.tid, a, e, s_lo, s_hi, r);
+                chain[(size_t)slot * (size_t)(nfiles - 1) + (size_t)(ff - 1)] = r;
+            }
+            head(r0);
+            w.sub_lo = S == 1 ? 0 : k * sub;
+            w.sub_hi = S == 1 ? G : w.sub_lo + sub;
+            work[slot] = w;
+        }
+        return;
+    }
     WorkItem w;
     w.tile = (uint32_t)t;
     w.file = (uint32_t)f;
@@ -906,8 +1050,10 @@ __device__ __forceinline__ void out_add(typename OutT_<OUTMODE>::type *dst, unsi
     }
 }
 
-template <int KIND, int OUTMODE, int WG, bool SMALL>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVES(KIND), 8))) void k_hist_point(const Piece *__restrict__ pieces,
+// MULTI: several alignment files (joint windows: the item's chain of per-file ranges is walked) -- an instantiation of
+// its own, so that the single-file kernels keep their register budget (seven waves per SIMD for the variable rule)
+template <int KIND, int OUTMODE, int WG, bool SMALL, bool MULTI>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : PC_HIST_WAVES(KIND), 8))) void k_hist_point(const Piece *__restrict__ pieces,
                                                     const OutPiece *__restrict__ opieces, FileView file0,
                                                     FileView file1, const FileView *__restrict__ files,
                                                     const WorkItem *__restrict__ work,
@@ -916,7 +1062,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVE
                                                     int G, int max_slots, int tab_lo, int tab_n, int fast_lo,
                                                     int fast_hi, uint32_t *hist,
                                                     int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
-                                                    double norm_sum, uint32_t work_cap, uint32_t grid_front) {
+                                                    double norm_sum, uint32_t work_cap, uint32_t grid_front,
+                                                    const FileRange *__restrict__ chain, int nfiles) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // heavy items sit at the front of the list, light ones at the back (see k_tile_ranges);
     // the sparse-window list is a plain array of its own
@@ -965,7 +1112,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVE
     const u32x4 gnone = {0u, kFlagExcluded << 16, 0u, 0u};
     // first batch of the gapped-record list, requested with everything else -- where the register budget is that of
     // six waves anyway (eight registers held across the stream loop are what separates six waves from seven)
-    constexpr bool kGapPrefetch = PC_HIST_WAVES(KIND) <= 6;
+    constexpr bool kGapPrefetch = MULTI || PC_HIST_WAVES(KIND) <= 6;
     const int64_t gj0 = w.glo + threadIdx.x;
     u32x4 gfirst = gnone;
     i32x4 gfirst_runs = {0, 1, 0, 0};
@@ -1040,63 +1187,105 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PC_HIST_WAVE
         fast_bin<4>(ftab, w.mode_mask, c.G, dump, w4, smem);
     }
 
-    // ---- run stream: the aligned runs of gapped and spliced reads (aligned length <= kStreamMaxLen), one
-    // 8-byte record per run, sorted by run start.  A rule picks ONE index k of read.positions; the run
-    // whose read indices [cum, cum + len) contain k holds the mapped position start + (k - cum), and that
-    // run starts at most `len` before it -- so a window scans the runs that start up to Wr before its
-    // first queried position: no dependent loads, no introns to look across, every run read once.
-    for (uint32_t base = w.rlo; base < w.rhi; base += WG) {
-        const uint32_t j = base + threadIdx.x;
-        const bool in = j < w.rhi;
-        const u32x2 rr = base == w.rlo ? rfirst : (in ? fv.run_rec[j] : rnone);
-        const int len = (int)(rr.y & 0xffu), cum = (int)((rr.y >> 8) & 0xffu), L = (int)((rr.y >> 16) & 0xffu);
-        const uint32_t fl = rr.y >> 24;
-        const bool valid = in & ((fl & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-        int kf, kr;
-        uint32_t rowoff;
-        map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
-        const bool hf = (uint32_t)(kf - cum) < (uint32_t)len, hr = (uint32_t)(kr - cum) < (uint32_t)len; // the index lies in this run
-        const int32_t pf = (int32_t)rr.x + (kf - cum), pr = (int32_t)rr.x + (kr - cum);
-        hist_bin(c, valid, fl & kFlagReverse, hf ? kf : -1, hr ? kr : -1, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start),
-                 rowoff, bins);
-    }
+    // the side lists of one file (run stream, gapped records outside it, long-span reads); `first_`: the head file of
+    // the item, whose first batches were requested at kernel start
+    auto side_lists = [&](const GFile &fv, uint32_t rlo_, uint32_t rhi_, int64_t glo_, int64_t ghi_, int64_t llo_, int64_t lhi_, bool first_) {
+        // ---- run stream: the aligned runs of gapped and spliced reads (aligned length <= kStreamMaxLen), one
+        // 8-byte record per run, sorted by run start.  A rule picks ONE index k of read.positions; the run
+        // whose read indices [cum, cum + len) contain k holds the mapped position start + (k - cum), and that
+        // run starts at most `len` before it -- so a window scans the runs that start up to Wr before its
+        // first queried position: no dependent loads, no introns to look across, every run read once.
+        for (uint32_t base = rlo_; base < rhi_; base += WG) {
+            const uint32_t j = base + threadIdx.x;
+            const bool in = j < rhi_;
+            const u32x2 rr = (first_ && base == rlo_) ? rfirst : (in ? fv.run_rec[j] : rnone);
+            const int len = (int)(rr.y & 0xffu), cum = (int)((rr.y >> 8) & 0xffu), L = (int)((rr.y >> 16) & 0xffu);
+            const uint32_t fl = rr.y >> 24;
+            const bool valid = in & ((fl & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
+            int kf, kr;
+            uint32_t rowoff;
+            map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
+            const bool hf = (uint32_t)(kf - cum) < (uint32_t)len, hr = (uint32_t)(kr - cum) < (uint32_t)len; // the index lies in this run
+            const int32_t pf = (int32_t)rr.x + (kf - cum), pr = (int32_t)rr.x + (kr - cum);
+            hist_bin(c, valid, fl & kFlagReverse, hf ? kf : -1, hr ? kr : -1, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start),
+                     rowoff, bins);
+        }
 
-    // ---- gapped records outside the run stream (aligned length > kStreamMaxLen): their aligned runs live in a side
-    // array; consecutive list entries own consecutive runs, so these gathers stay coalesced.
-    for (int64_t base = w.glo; base < w.ghi; base += WG) {
-        const int64_t j = base + threadIdx.x;
-        const bool in = j < w.ghi;
-        const u32x4 g = (kGapPrefetch && base == w.glo) ? gfirst : (in ? fv.gap_rec[j] : gnone);
-        const i32x4 gr = (kGapPrefetch && base == w.glo) ? gfirst_runs : (in ? fv.gap_runs[j] : i32x4{0, 1, 0, 0});
-        const uint32_t meta = g.y, hi = meta >> 16;
-        const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
-        const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-        const i32x2 b0 = {gr.x, gr.y}, b1 = {gr.z, gr.w}; // first two runs travel with the list entry
-        int kf, kr;
-        uint32_t rowoff;
-        map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
-        const int32_t pf = (valid && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
-        const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
-        hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
-    }
+        // ---- gapped records outside the run stream (aligned length > kStreamMaxLen): their aligned runs live in a side
+        // array; consecutive list entries own consecutive runs, so these gathers stay coalesced.
+        for (int64_t base = glo_; base < ghi_; base += WG) {
+            const int64_t j = base + threadIdx.x;
+            const bool in = j < ghi_;
+            const u32x4 g = (kGapPrefetch && first_ && base == glo_) ? gfirst : (in ? fv.gap_rec[j] : gnone);
+            const i32x4 gr = (kGapPrefetch && first_ && base == glo_) ? gfirst_runs : (in ? fv.gap_runs[j] : i32x4{0, 1, 0, 0});
+            const uint32_t meta = g.y, hi = meta >> 16;
+            const int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
+            const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
+            const i32x2 b0 = {gr.x, gr.y}, b1 = {gr.z, gr.w}; // first two runs travel with the list entry
+            int kf, kr;
+            uint32_t rowoff;
+            map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
+            const int32_t pf = (valid && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
+            const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
+            hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
+        }
 
-    // ---- long-span (spliced) reads that can reach this window: same binning, every run walked
-    for (int64_t base = w.llo; base < w.lhi; base += WG) {
-        const int64_t j = base + threadIdx.x;
-        const bool in = j < w.lhi;
-        const u32x4 g = in ? fv.xlong_rec[j] : gnone;
-        const i32x4 gr = in ? fv.xlong_runs[j] : i32x4{0, 1, 0, 0};
-        const uint32_t meta = g.y, hi = meta >> 16;
-        int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
-        if (hi & kFlagWide) { const u32x2 tv = fv.xlong_wide[j]; L = (int)tv.x; nb = (int)tv.y; }   // beyond the 16 / 8-bit fields
-        const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-        const i32x2 b0 = {gr.x, gr.y}, b1 = {gr.z, gr.w};
-        int kf, kr;
-        uint32_t rowoff;
-        map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
-        const int32_t pf = (valid && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
-        const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
-        hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
+        // ---- long-span (spliced) reads that can reach this window: same binning, every run walked
+        for (int64_t base = llo_; base < lhi_; base += WG) {
+            const int64_t j = base + threadIdx.x;
+            const bool in = j < lhi_;
+            const u32x4 g = in ? fv.xlong_rec[j] : gnone;
+            const i32x4 gr = in ? fv.xlong_runs[j] : i32x4{0, 1, 0, 0};
+            const uint32_t meta = g.y, hi = meta >> 16;
+            int L = (int)(meta & 0xffffu), nb = (int)(meta >> 24);
+            if (hi & kFlagWide) { const u32x2 tv = fv.xlong_wide[j]; L = (int)tv.x; nb = (int)tv.y; }   // beyond the 16 / 8-bit fields
+            const bool valid = in & ((hi & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
+            const i32x2 b0 = {gr.x, gr.y}, b1 = {gr.z, gr.w};
+            int kf, kr;
+            uint32_t rowoff;
+            map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
+            const int32_t pf = (valid && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
+            const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
+            hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
+        }
+    };
+    side_lists(fv, w.rlo, w.rhi, w.glo, w.ghi, w.llo, w.lhi, true);
+    // ---- joint window (several alignment files): the records of the other files into the same bins
+    if (MULTI && !w.merge) {
+        for (int ff = 1; ff < nfiles; ++ff) {
+            const FileRange fr = chain[(size_t)slot * (size_t)(nfiles - 1) + (size_t)(ff - 1)];
+            const GFile fv2 = ff == 1 ? gfile(file1) : gfile(files[ff]);
+            const int64_t ql2 = fr.lo >> 2;
+            const int nq2 = (int)((fr.hi >> 2) - ql2);
+            const u32x4 PC_GLOBAL *src2 = fv2.stream4 + ql2;
+            u32x4 c2[U];
+            {
+                const int lane_j = (int)(threadIdx.x >> 6) * (64 * U) + (int)(threadIdx.x & 63);
+#pragma unroll
+                for (int u = 0; u < U; ++u) c2[u] = (lane_j + u * 64 < nq2) ? src2[lane_j + u * 64] : none;
+            }
+            u32x4 tail2 = none;
+            if ((fr.hi & 3) && threadIdx.x == 0) tail2 = fv2.stream4[fr.hi >> 2];
+            if (threadIdx.x == 0) {   // records of the first quad before `lo`, of the cut last quad outside [lo, hi)
+                const int lead = (int)(fr.lo & 3), keep = (int)(fr.hi & 3);
+                if (nq2 > 0) {
+                    if (lead > 0) c2[0].x = kStreamSkip;
+                    if (lead > 1) c2[0].y = kStreamSkip;
+                    if (lead > 2) c2[0].z = kStreamSkip;
+                }
+                const int tlead = nq2 == 0 ? lead : 0;
+                if (keep <= 0 || tlead > 0) tail2.x = kStreamSkip;
+                if (keep <= 1 || tlead > 1) tail2.y = kStreamSkip;
+                if (keep <= 2 || tlead > 2) tail2.z = kStreamSkip;
+                tail2.w = kStreamSkip;
+            }
+            stream_records<WG, U>(src2, nq2, c2, none, ftab, w.mode_mask, c.G, dump, smem);
+            if ((fr.hi & 3) && threadIdx.x < 64) {
+                const uint32_t w4[4] = {tail2.x, tail2.y, tail2.z, tail2.w};
+                fast_bin<4>(ftab, w.mode_mask, c.G, dump, w4, smem);
+            }
+            side_lists(fv2, fr.rlo, fr.rhi, fr.glo, fr.ghi, fr.llo, fr.lhi, false);
+        }
     }
     __syncthreads();
 

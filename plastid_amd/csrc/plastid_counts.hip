@@ -351,6 +351,7 @@ struct pc_engine {
     DevBuf<double> d_cval; // per file: the 1/m of the center kernel's SGPR table (k_center_vals)
     // scratch for counting
     DevBuf<WorkItem> d_work, d_work_small;
+    DevBuf<FileRange> d_chain, d_chain_small;   // several files: the ranges of files >= 1 of every (joint) work item
     DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
     DevBuf<uint8_t> d_flags;     // staging buffer of pc_update_flags
     bool pinned_busy = false;
@@ -1911,16 +1912,18 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const int64_t small_n = e->knobs.small_n;
             const int64_t cap_small = small_g ? (int64_t)ntiles * nfiles : 0;
             rc = e->d_work_small.reserve((size_t)std::max<int64_t>(cap_small, 1));
+            if (rc == PC_OK && nfiles > 1) rc = e->d_chain.reserve((size_t)cap64 * (size_t)(nfiles - 1));
+            if (rc == PC_OK && nfiles > 1) rc = e->d_chain_small.reserve((size_t)std::max<int64_t>(cap_small, 1) * (size_t)(nfiles - 1));
             if (rc != PC_OK) return rc;
             // both are left zeroed by k_gather_split, the last kernel of the previous call
             if (!e->counters_zero) HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
             if (!p->tile_items_zero) HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
             e->counters_zero = false;
             p->tile_items_zero = false;
-            const int64_t nthreads = (int64_t)ntiles * nfiles; // one thread per (tile, file)
+            const int64_t nthreads = nfiles > 1 ? (int64_t)ntiles : (int64_t)ntiles * nfiles; // one thread per window (several files: joint windows)
             hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
                                e->files[0]->view(), e->d_files.p, nfiles, G, e->Wg(), e->Ws(), e->Wr(), R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
-                               e->d_work_small.p, small_g, small_n, e->knobs.debug_work);
+                               e->d_work_small.p, small_g, small_n, e->knobs.debug_work, e->d_chain.p, e->d_chain_small.p);
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
             int lmin = 65536, lmax = -1;
@@ -1967,17 +1970,22 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const int outmode = e->norm_on ? 2 : (out_dtype == PC_OUT_FLOAT64 ? 1 : 0);
 #define PC_LAUNCH_HIST(K, O)                                                                                          \
     do {                                                                                                              \
-        hipLaunchKernelGGL((k_hist_point<K, O, kHistWG, false>), dim3(grid), dim3(kHistWG), lds, st, p->d_pieces.p,             \
+        if (nfiles > 1) PC_LAUNCH_HIST_M(K, O, true); else PC_LAUNCH_HIST_M(K, O, false);                             \
+    } while (0)
+#define PC_LAUNCH_HIST_M(K, O, M)                                                                                     \
+    do {                                                                                                              \
+        hipLaunchKernelGGL((k_hist_point<K, O, kHistWG, false, M>), dim3(grid), dim3(kHistWG), lds, st, p->d_pieces.p,             \
                            p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, \
                            G, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, (uint32_t *)p->d_hist.p, p->npos,                        \
                            (OutT_<O>::type *)p->d_out.p,                                                                \
-                           e->norm_sum, (uint32_t)cap64, grid_front);                                                   \
+                           e->norm_sum, (uint32_t)cap64, grid_front, e->d_chain.p, nfiles);                             \
         if (cap_small && grid_small)                                                                                  \
-            hipLaunchKernelGGL((k_hist_point<K, O, 64, true>), dim3(grid_small), dim3(64), lds_small, st_small, \
+            hipLaunchKernelGGL((k_hist_point<K, O, 64, true, M>), dim3(grid_small), dim3(64), lds_small, st_small, \
                                p->d_pieces.p, p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work_small.p,                \
                                e->d_counters.p, p->d_tile_items.p, mp, small_g, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, \
                                (uint32_t *)p->d_hist.p,                                                                 \
-                               p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small, grid_small);    \
+                               p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small, grid_small,      \
+                               e->d_chain_small.p, nfiles);                                                               \
     } while (0)
 #define PC_LAUNCH_HIST_O(K)                                                                                           \
     do {                                                                                                              \
@@ -2003,6 +2011,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             }
 #undef PC_LAUNCH_HIST_O
 #undef PC_LAUNCH_HIST
+#undef PC_LAUNCH_HIST_M
             if (cap_small) {
                 HIP_TRY(hipEventRecord(e->ev_join, st_small));
                 HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
@@ -2010,7 +2019,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
             if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
             // tiles that were split into several work items: lay out from the merged histogram
-            const int split_per_wg = nfiles > 1 ? 1 : kWG; // several files: every window is merged
+            const int split_per_wg = kWG; // merged windows are the exception (pile-ups), with several files too (joint windows)
 #define PC_LAUNCH_SPLIT(O)                                                                                            \
     hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)((ntiles + split_per_wg - 1) / split_per_wg)), dim3(kWG), 0, st, \
                        p->d_tiles.p, ntiles, split_per_wg, p->d_pieces.p,                                               \
