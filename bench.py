@@ -264,7 +264,7 @@ def run_workload(name, args, ctx, headline):
     rng = np.random.default_rng(7 + (rank if partition == "replicas" else 0))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # (beside every config: the other configs get ~10 s per figure so that the default run stays within minutes)
-        budget = args.cpu_budget if headline else min(args.cpu_budget, 10.0)
+        budget = args.cpu_budget if headline else min(args.cpu_budget, 6.0)
         cpu, check_sel, check_arrays, _ = cpu_baseline(oracle, aln, spec, p, tx, reads.n, budget, rng)
         cpu["all_cores"] = cpu_baseline_all_cores(oracle, aln, spec, p, tx, reads.n, min(budget, 10.0),
                                                   np.random.default_rng(8), cpu)
@@ -363,6 +363,35 @@ def run_workload(name, args, ctx, headline):
     sf_elapsed = multigpu.max_over_ranks(time.perf_counter() - t0, device=ctx["tdev"])
     eng.set_size_filter(None)
 
+    # ---------------------------------------------------------------- the same records dealt alternately into TWO files
+    # (BAMGenomeArray(*bamfiles), genome_array.py:657-660, 800-809: several files count as one; joint windows)
+    two_files = None
+    if headline and world == 1 and not args.no_two_files:
+        from plastid_amd.packing import PackedAlignments
+        multi = np.nonzero(my_reads.nblk >= 2)[0]
+        rec_of_run = np.repeat(multi, my_reads.nblk[multi])
+        halves = []
+        for k in (0, 1):
+            sel = np.arange(k, my_reads.n, 2)
+            runs = np.nonzero((rec_of_run & 1) == k)[0]
+            halves.append(PackedAlignments(my_reads.tid[sel], my_reads.pos[sel], my_reads.alen[sel], my_reads.flags[sel], my_reads.nblk[sel],
+                                           my_reads.blk_start[runs], my_reads.blk_len[runs], references=my_reads.references,
+                                           lengths=my_reads.lengths, validate=False))
+        eng.set_alignments(halves)
+        for _ in range(2):
+            plan.launch(out_dtype)
+        eng.sync()
+        gate(exp, "two files")                       # two files count as their sum: the one-file expectation
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            plan.launch(out_dtype)
+        eng.sync()
+        two_ms = (time.perf_counter() - t0) / steps * 1e3
+        two_files = {"what": "the same records dealt alternately into two files (joint windows), parity-gated against the same oracle sample",
+                     "ms_per_step": two_ms, "ratio_to_one_file": two_ms / (elapsed / steps * 1e3)}
+        eng.set_alignments([my_reads])
+        del halves
+
     # ---------------------------------------------------------------- collectives
     n_records_all, counts_all, positions_all = multigpu.allreduce_int_totals(
         [int(my_reads.n), int(total_counts) if not center else 0, int(lp["out_elems"])], device=ctx["tdev"])
@@ -416,6 +445,7 @@ def run_workload(name, args, ctx, headline):
                      "frac_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_ms > 0) else None,
                      "algorithmic_bytes_per_launch": int(kern_alg_bytes), "avg_launch_ms": kern_ms},
         "cpu_baseline": cpu,
+        "two_files": two_files,
     }
     ctx["last_engine_objects"] = (eng, plan, my_reads)
     return res
@@ -687,6 +717,7 @@ def main():
     ap.add_argument("--tx-scale", type=float, default=1.0)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-files", action="store_true", help="skip the two-file variant of the headline")
     ap.add_argument("--out-dtype", default="int64", choices=["int64", "float64"])
     ap.add_argument("--other-configs", default="auto",
                     help="comma list of further configs run after the headline (auto: C3,C4,C5 at N=1 with the default "
@@ -696,7 +727,7 @@ def main():
     ap.add_argument("--parity-chains", type=int, default=200, help="chains of the parity sample when no CPU baseline is timed")
     ap.add_argument("--time-budget", type=float, default=1200.0, help="seconds after which no further config is started")
     ap.add_argument("--e2e-records", type=float, default=1e8, help="records of the BAM file of the e2e scope, at most the whole configuration (0: skip)")
-    ap.add_argument("--e2e-realistic-records", type=float, default=5e6,
+    ap.add_argument("--e2e-realistic-records", type=float, default=3e6,
                     help="records of the second e2e sample, written as an aligner writes them (~120 bytes per record; 0: skip)")
     args = ap.parse_args()
     t_start = time.perf_counter()
@@ -817,7 +848,8 @@ def main():
             "workload", "records_per_gpu", "records_total", "chains", "segments", "output_positions_per_gpu", "island_positions",
             "tiles", "rows", "mapping", "read_seed", "transcript_seed", "positions_per_sec", "parity", "sum_of_counts_all_ranks",
             "host_generate_s", "host_stage_s", "host_read_outputs_s", "plan_build_ms_once_per_annotation",
-            "algorithmic_bytes_per_step", "step_GBps_algorithmic", "kernel_ms", "size_filter_variant")}
+            "algorithmic_bytes_per_step", "step_GBps_algorithmic", "kernel_ms", "size_filter_variant", "two_files")}
+        config["kernel_source_sha16"] = kernel_source_hash()   # what a PMC traffic figure of this run belongs to (profiles/traffic.json)
         config["staged_stream_bytes_per_record"] = 4  # what the tile kernel reads; the algorithmic record is 8 B
         config["scopes"] = scopes
         if "partition" in head:

@@ -10,7 +10,7 @@ uncalibrated, so both are calibrated on a known byte count in the kernel's own a
 streaming probes bench.py runs in the same process (pc_stream_probe: k_probe_read = 16-byte loads per
 lane, k_probe_write = 8-byte stores per lane, 1 GiB each).  traffic = FETCH x f_read + WRITE x f_write.
 
-usage: python scripts/collect_profile.py gpurun_out/prof_<tag> profiles/r02/<config> <config>"""
+usage: python scripts/collect_profile.py gpurun_out/prof_<tag> profiles/r03/<config> <config>"""
 import csv
 import glob
 import json
@@ -66,10 +66,12 @@ if kw:
     cal["f_write"] = probe_bytes / (means[(kw, "WRITE_SIZE")] * 1024.0)
     cal["probe_write_WRITE_SIZE_KB"] = means[(kw, "WRITE_SIZE")]
 dominant = "k_center" if config == "C3" else "k_hist_point"
-entry = {"config": config, "round": 2, "dominant_kernel": dominant, "calibration": cal,
+entry = {"config": config, "round": 3, "dominant_kernel": dominant, "calibration": cal,
          "source": "%s/pmc_fetch_per_kernel.csv, pmc_write_per_kernel.csv (separate rocprofv3 --pmc passes, scripts/profile.sh)" % dst}
 if line is not None:
     entry["n_records"] = line["config"]["records_per_gpu"]
+    # the kernel sources these counters were measured on: bench.py reports the traffic only while they are unchanged
+    entry["kernel_source_sha16"] = line["config"].get("kernel_source_sha16")
     entry["algorithmic_bytes_per_launch"] = line["roofline"]["algorithmic_bytes_per_launch"]
 fetch = write = 0.0
 per_kernel = {}
