@@ -1359,9 +1359,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
 
 // ---------------------------------------------------------------- k_gather_split
 // Split tiles only: lay out their segment slices from the merged histogram, then clear the
-// tile's histogram region so the next call starts from zeros again.  Last kernel of a call: it
-// also leaves the work-list counters and the per-tile item counts zeroed, so that the next call
-// needs no memset launches in front of k_tile_ranges.
+// tile's histogram region so the next call starts from zeros again.  Last kernel of a call.  The
+// work lists, their counters and the per-tile item counts belong to the plan and are left as they
+// are: the next count of the plan serves the same lists without running k_tile_ranges again.
 // `per_wg` tiles are looked at by one workgroup: 1 when every window is merged (several BAM
 // files), 256 otherwise -- merged windows are then the exception (pile-ups), and a sparse
 // annotation has hundreds of thousands of windows that would each cost an empty workgroup.
@@ -1398,7 +1398,7 @@ template <int OUTMODE>
 __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ tiles, int ntiles, int per_wg,
                                                       const Piece *__restrict__ pieces,
                                                       const OutPiece *__restrict__ opieces,
-                                                      uint32_t *tile_items, uint32_t *counters, int rows,
+                                                      const uint32_t *__restrict__ tile_items, const uint32_t *__restrict__ counters, int rows,
                                                       uint32_t *hist, int64_t hist_row_stride,
                                                       typename OutT_<OUTMODE>::type *out, double norm_sum,
                                                       uint32_t launched_heavy, uint32_t launched_light, uint32_t launched_small,
@@ -1410,22 +1410,16 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
         // this plan left (0xffffffff: the whole capacity was launched); if this count queued more, items went unserved
         const uint32_t launched = threadIdx.x == 0 ? launched_heavy : (threadIdx.x == 1 ? launched_light : (threadIdx.x == 2 ? launched_small : 0xffffffffu));
         if (launched != 0xffffffffu && counters[threadIdx.x] > launched) atomicOr(grid_error, 1u);
-        counters[4 + threadIdx.x] = counters[threadIdx.x]; // kept for diagnostics (PC_DEBUG_WORK)
-        counters[threadIdx.x] = 0u;
     }
     if (per_wg == 1) {
         if (tile_items[blockIdx.x] == 0u) return; // only windows that were merged through the histogram
         gather_tile<OUTMODE>(tiles[blockIdx.x], pieces, opieces, rows, hist, hist_row_stride, out, norm_sum);
-        if (threadIdx.x == 0) tile_items[blockIdx.x] = 0u;
         return;
     }
     const int t = (int)blockIdx.x * kWG + (int)threadIdx.x;
     if (threadIdx.x == 0) s_n = 0u;
     __syncthreads();
-    if (t < ntiles && tile_items[t] != 0u) {
-        s_list[atomicAdd(&s_n, 1u)] = (uint32_t)t;
-        tile_items[t] = 0u;
-    }
+    if (t < ntiles && tile_items[t] != 0u) s_list[atomicAdd(&s_n, 1u)] = (uint32_t)t;
     __syncthreads();
     const uint32_t n = s_n;
     for (uint32_t k = 0; k < n; ++k) { // rare; the whole workgroup lays each of them out in turn

@@ -350,13 +350,10 @@ struct pc_engine {
     DevBuf<double> d_inv; // 1.0/m, m = 0..65535 (host-computed IEEE quotients)
     DevBuf<double> d_cval; // per file: the 1/m of the center kernel's SGPR table (k_center_vals)
     // scratch for counting
-    DevBuf<WorkItem> d_work, d_work_small;
-    DevBuf<FileRange> d_chain, d_chain_small;   // several files: the ranges of files >= 1 of every (joint) work item
-    DevBuf<uint32_t> d_counters; // [0] nwork, [1] unmappable count
+    DevBuf<uint32_t> d_counters; // [1] unmappable count, [7] sink of the stream probe, [12] exact-grid guard (work counts: pc_plan::d_wcounters)
     DevBuf<uint8_t> d_flags;     // staging buffer of pc_update_flags
     bool pinned_busy = false;
     PinnedBuf pinned;            // host side of the plan-table upload (reused: ev_pinned is waited for before it is rewritten)
-    bool counters_zero = false; // left zeroed by the last kernel of a point-rule count
     uint64_t work_generation = 1; // bumped by whatever changes the work list of a plan (alignment files, knobs)
     size_t max_lds = 64 * 1024; // LDS a workgroup may use (160 KiB on gfx950)
     DevBuf<double> d_partial;
@@ -447,6 +444,24 @@ struct pc_plan {
     DevView<GatherChunk> d_gchunks;
     DevView<uint32_t> d_tile_items;
     bool tile_items_zero = false;
+    // Work lists of the point rules.  They depend on the plan's windows, the staged alignments and the halo of the
+    // mapping rule only -- not on the counts -- so they belong to the plan and k_tile_ranges runs once per
+    // (plan, WorkKey): a repeated count goes straight to the histogram kernels.
+    struct WorkKey {
+        uint64_t generation = 0;   // engine work_generation (alignments, host-side filters, knobs)
+        int nfiles = 0, G = 0, Wg = 0, Ws = 0, Wr = 0, small_g = 0;
+        int64_t R = 0, pile = 0, small_n = 0, cap = 0;
+        bool operator==(const WorkKey &o) const {
+            return generation == o.generation && nfiles == o.nfiles && G == o.G && Wg == o.Wg && Ws == o.Ws && Wr == o.Wr &&
+                   small_g == o.small_g && R == o.R && pile == o.pile && small_n == o.small_n && cap == o.cap;
+        }
+    };
+    WorkKey work_key;
+    bool work_valid = false;
+    DevBuf<WorkItem> d_work, d_work_small;
+    DevBuf<FileRange> d_chain, d_chain_small;   // several files: the ranges of files >= 1 of every (joint) work item
+    DevView<uint32_t> d_wcounters;              // [0..3] queued heavy, light, small items, long-span candidates
+    bool wcounters_zero = false;
     DevView<uint8_t> d_hist; // uint32 or double; inside d_tables when short, else d_hist_own
     DevBuf<uint8_t> d_hist_own;
     DevBuf<uint8_t> d_out;  // int64 or double
@@ -473,6 +488,7 @@ struct pc_plan {
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
         d_cranges.pool = pl; d_crec.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl;
+        d_work.pool = pl; d_work_small.pool = pl; d_chain.pool = pl; d_chain_small.pool = pl;
     }
 };
 
@@ -630,7 +646,7 @@ int pc_create(int device, pc_engine **out) {
     inv[0] = 0.0;
     for (int m = 1; m < 65536; ++m) inv[m] = 1.0 / (double)m; // the reference's `1.0 / map_length`
     int rc = e->d_inv.upload(inv, e->stream);
-    if (rc == PC_OK) rc = e->d_counters.reserve(16);   // [0..3] work counts, [4..7] their copy, [12] exact-grid guard
+    if (rc == PC_OK) rc = e->d_counters.reserve(16);
     if (rc == PC_OK && hipMemsetAsync(e->d_counters.p, 0, 16 * sizeof(uint32_t), e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: memset failed");
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: sync failed");
     if (rc != PC_OK) {
@@ -1774,7 +1790,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     const size_t at_tiles = place(p->tiles.size() * sizeof(Tile)), at_pieces = place(p->pieces.size() * sizeof(Piece)),
                  at_opieces = place(p->opieces.size() * sizeof(OutPiece)), at_cchunks = place(p->cchunks.size() * sizeof(CenterChunk)),
                  at_gsegs = place(p->lazy_center ? 0 : p->gsegs.size() * sizeof(GatherSeg)), at_gchunks = place(p->gchunks.size() * sizeof(GatherChunk)),
-                 at_items = place((p->tiles.size() + 1) * sizeof(uint32_t)), at_total = place(64);
+                 at_items = place((p->tiles.size() + 1) * sizeof(uint32_t)), at_wcounters = place(64), at_total = place(64);
     // a short compact histogram rides along, already zeroed (one memset less on the first count)
     const size_t hist_full = (size_t)p->npos * (size_t)p->rows * sizeof(double);
     const bool hist_here = hist_full > 0 && hist_full <= 64 * 1024;
@@ -1805,7 +1821,9 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         p->d_opieces.p = (OutPiece *)(d + at_opieces); p->d_cchunks.p = (CenterChunk *)(d + at_cchunks);
         p->d_gsegs.p = (GatherSeg *)(d + at_gsegs); p->d_gchunks.p = (GatherChunk *)(d + at_gchunks);
         p->d_tile_items.p = (uint32_t *)(d + at_items); p->d_total.p = d + at_total;
+        p->d_wcounters.p = (uint32_t *)(d + at_wcounters);
         p->tile_items_zero = true;
+        p->wcounters_zero = true;
         if (hist_here) { p->d_hist.p = d + at_hist; p->hist_kind = 0; p->hist_clean = true; }
         if (!through_pinned) {   // the copies read the plan's own vectors, which live as long as the plan
             if (copy_failed) rc = fail(PC_ERR_HIP, "pc_plan_create: upload failed");
@@ -1903,7 +1921,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const double windows_per_record = 1.0 + (double)(halo + 127) / (double)G;
             const int64_t cap64 = (int64_t)ntiles * nfiles + (int64_t)(2.0 * windows_per_record * (double)nrec / (double)R) + nfiles + 64;
             if (cap64 >= (int64_t)0xffffffffu) return fail(PC_ERR_ARG, "pc_count: work list too large");
-            rc = e->d_work.reserve((size_t)cap64);
+            rc = p->d_work.reserve((size_t)cap64);
             if (rc != PC_OK) return rc;
             // sparse windows: single-wave workgroups with a small LDS window (rows == 1 only)
             // (skipped for dense annotations, where queried positions fill most of every window)
@@ -1911,19 +1929,29 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const int small_g = (p->rows == 1 && sparse_plan && !e->knobs.no_small) ? std::min(e->knobs.small_g, G) : 0;
             const int64_t small_n = e->knobs.small_n;
             const int64_t cap_small = small_g ? (int64_t)ntiles * nfiles : 0;
-            rc = e->d_work_small.reserve((size_t)std::max<int64_t>(cap_small, 1));
-            if (rc == PC_OK && nfiles > 1) rc = e->d_chain.reserve((size_t)cap64 * (size_t)(nfiles - 1));
-            if (rc == PC_OK && nfiles > 1) rc = e->d_chain_small.reserve((size_t)std::max<int64_t>(cap_small, 1) * (size_t)(nfiles - 1));
+            rc = p->d_work_small.reserve((size_t)std::max<int64_t>(cap_small, 1));
+            if (rc == PC_OK && nfiles > 1) rc = p->d_chain.reserve((size_t)cap64 * (size_t)(nfiles - 1));
+            if (rc == PC_OK && nfiles > 1) rc = p->d_chain_small.reserve((size_t)std::max<int64_t>(cap_small, 1) * (size_t)(nfiles - 1));
             if (rc != PC_OK) return rc;
-            // both are left zeroed by k_gather_split, the last kernel of the previous call
-            if (!e->counters_zero) HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, 4 * sizeof(uint32_t), st));
-            if (!p->tile_items_zero) HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
-            e->counters_zero = false;
-            p->tile_items_zero = false;
-            const int64_t nthreads = nfiles > 1 ? (int64_t)ntiles : (int64_t)ntiles * nfiles; // one thread per window (several files: joint windows)
-            hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
-                               e->files[0]->view(), e->d_files.p, nfiles, G, e->Wg(), e->Ws(), e->Wr(), R, pile, e->d_work.p, e->d_counters.p, p->d_tile_items.p, (uint32_t)cap64,
-                               e->d_work_small.p, small_g, small_n, e->knobs.debug_work, e->d_chain.p, e->d_chain_small.p);
+            pc_plan::WorkKey key;
+            key.generation = e->work_generation; key.nfiles = nfiles; key.G = G; key.Wg = e->Wg(); key.Ws = e->Ws(); key.Wr = e->Wr();
+            key.small_g = small_g; key.R = R; key.pile = pile; key.small_n = small_n; key.cap = cap64;
+            if (!(p->work_valid && p->work_key == key) || e->knobs.debug_work) {
+                // the lists of this plan are (re)built: counters and per-tile item counts start from zero (they arrive
+                // zeroed with the plan's tables, so the first count of a plan needs no memset)
+                if (!p->wcounters_zero) HIP_TRY(hipMemsetAsync(p->d_wcounters.p, 0, 4 * sizeof(uint32_t), st));
+                if (!p->tile_items_zero) HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
+                p->wcounters_zero = false;
+                p->tile_items_zero = false;
+                const int64_t nthreads = nfiles > 1 ? (int64_t)ntiles : (int64_t)ntiles * nfiles; // one thread per window (several files: joint windows)
+                hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
+                                   e->files[0]->view(), e->d_files.p, nfiles, G, e->Wg(), e->Ws(), e->Wr(), R, pile, p->d_work.p, p->d_wcounters.p, p->d_tile_items.p, (uint32_t)cap64,
+                                   p->d_work_small.p, small_g, small_n, e->knobs.debug_work, p->d_chain.p, p->d_chain_small.p);
+                p->work_key = key;
+                p->work_valid = true;
+                p->work_counts_known = false;      // the counts of the lists just replaced size no grid
+                p->work_counts_generation = 0;
+            }
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
             int lmin = 65536, lmax = -1;
@@ -1975,17 +2003,17 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
 #define PC_LAUNCH_HIST_M(K, O, M)                                                                                     \
     do {                                                                                                              \
         hipLaunchKernelGGL((k_hist_point<K, O, kHistWG, false, M>), dim3(grid), dim3(kHistWG), lds, st, p->d_pieces.p,             \
-                           p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work.p, e->d_counters.p, p->d_tile_items.p, mp, \
+                           p->d_opieces.p, fv0, fv1, e->d_files.p, p->d_work.p, p->d_wcounters.p, p->d_tile_items.p, mp, \
                            G, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, (uint32_t *)p->d_hist.p, p->npos,                        \
                            (OutT_<O>::type *)p->d_out.p,                                                                \
-                           e->norm_sum, (uint32_t)cap64, grid_front, e->d_chain.p, nfiles);                             \
+                           e->norm_sum, (uint32_t)cap64, grid_front, p->d_chain.p, nfiles);                             \
         if (cap_small && grid_small)                                                                                  \
             hipLaunchKernelGGL((k_hist_point<K, O, 64, true, M>), dim3(grid_small), dim3(64), lds_small, st_small, \
-                               p->d_pieces.p, p->d_opieces.p, fv0, fv1, e->d_files.p, e->d_work_small.p,                \
-                               e->d_counters.p, p->d_tile_items.p, mp, small_g, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, \
+                               p->d_pieces.p, p->d_opieces.p, fv0, fv1, e->d_files.p, p->d_work_small.p,                \
+                               p->d_wcounters.p, p->d_tile_items.p, mp, small_g, p->max_slots, tab_lo, tab_n, fast_lo, fast_hi, \
                                (uint32_t *)p->d_hist.p,                                                                 \
                                p->npos, (OutT_<O>::type *)p->d_out.p, e->norm_sum, (uint32_t)cap_small, grid_small,      \
-                               e->d_chain_small.p, nfiles);                                                               \
+                               p->d_chain_small.p, nfiles);                                                               \
     } while (0)
 #define PC_LAUNCH_HIST_O(K)                                                                                           \
     do {                                                                                                              \
@@ -2023,14 +2051,12 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
 #define PC_LAUNCH_SPLIT(O)                                                                                            \
     hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)((ntiles + split_per_wg - 1) / split_per_wg)), dim3(kWG), 0, st, \
                        p->d_tiles.p, ntiles, split_per_wg, p->d_pieces.p,                                               \
-                       p->d_opieces.p, p->d_tile_items.p, e->d_counters.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,   \
+                       p->d_opieces.p, p->d_tile_items.p, p->d_wcounters.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,   \
                        (OutT_<O>::type *)p->d_out.p, e->norm_sum, launched[0], launched[1], launched[2], e->d_counters.p + 12)
             if (outmode == 0) PC_LAUNCH_SPLIT(0);
             else if (outmode == 1) PC_LAUNCH_SPLIT(1);
             else PC_LAUNCH_SPLIT(2);
 #undef PC_LAUNCH_SPLIT
-            e->counters_zero = true;
-            p->tile_items_zero = true;
             if (track_counts) {   // how many items each class queued (k_gather_split keeps a copy): sizes the next launch
                 if (!p->h_work_counts) {
                     HIP_TRY(hipHostMalloc((void **)&p->h_work_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
@@ -2038,14 +2064,14 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 }
                 if (p->work_counts_generation != e->work_generation) {   // one read-back per (plan, generation)
                     p->work_counts_known = false;
-                    HIP_TRY(hipMemcpyAsync(p->h_work_counts, e->d_counters.p + 4, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipMemcpyAsync(p->h_work_counts, p->d_wcounters.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipEventRecord(p->ev_work_counts, st));
                     p->work_counts_generation = e->work_generation;
                 }
             }
             if (e->knobs.debug_work) { // diagnostics: how many work items of each class this call queued
                 uint32_t c4[4] = {0, 0, 0, 0};
-                HIP_TRY(hipMemcpyAsync(c4, e->d_counters.p + 4, sizeof(c4), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(c4, p->d_wcounters.p, sizeof(c4), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 fprintf(stderr, "[work] tiles %d: heavy %u light %u small %u, long-span candidates %u (capacity %lld, G %d, R %lld)\n", ntiles,
                         c4[0], c4[1], c4[2], c4[3], (long long)cap64, G, (long long)R);
@@ -2416,7 +2442,6 @@ int pc_warn_details(pc_engine *e, pc_plan *p, uint8_t *flags, int32_t *last_len)
             rc = e->d_unmap.reserve(cap);
             if (rc != PC_OK) return rc;
             HIP_TRY(hipMemsetAsync(e->d_counters.p + 1, 0, sizeof(uint32_t), e->stream));
-            e->counters_zero = false;
             hipLaunchKernelGGL(k_unmappable, dim3((unsigned)((f->n + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, f->view(), mp, e->ntid,
                                e->d_unmap.p, cap, e->d_counters.p + 1);
             uint32_t cnt = 0;

@@ -877,6 +877,21 @@ def test_exact_grid_guard_and_cache_invalidation(pa, monkeypatch):
     assert np.array_equal(count_twice(eng, plan), full)
     monkeypatch.delenv("PC_WORK_R")
     eng.reload_knobs()
+    # the work lists live in the plan and are reused from count to count; another mapping rule on the same plan (another
+    # halo in front of the windows) must rebuild them, and going back must rebuild them again
+    from plastid_amd import map_factories as mf
+    e_ref = Engine(0)
+    e_ref.set_alignments([reads])
+    mf.ThreePrimeMapFactory(3)._configure(e_ref)
+    plan_ref = e_ref.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    three = plan_ref.count(np.int64)
+    plan_ref.close()
+    e_ref.close()
+    mf.ThreePrimeMapFactory(3)._configure(eng)
+    assert np.array_equal(count_twice(eng, plan), three)
+    synth.mapping_factory(mapping)._configure(eng)
+    assert np.array_equal(count_twice(eng, plan), full)
+    assert np.array_equal(count_twice(eng, plan), full)
     plan.close()
     e2 = Engine(0)
     e2.set_alignments([half])
