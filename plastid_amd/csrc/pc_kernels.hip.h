@@ -968,6 +968,26 @@ __device__ __forceinline__ void fast_bin(const uint32_t *ftab, uint32_t mode_mas
     }
 }
 
+// Bin one record of the run stream (one aligned run of a gapped / spliced read) through the entry table -- see the
+// run-stream loop of k_hist_point.  A lane without a record holds an excluded one.
+__device__ __forceinline__ void run_bin(const uint32_t *ftab, uint32_t mode_mask, uint32_t G, uint32_t dump, u32x2 rr,
+                                        uint32_t win_start, uint32_t *smem) {
+    const char *tab = (const char *)ftab;
+    const uint32_t len = rr.y & 0xffu, cum = (rr.y >> 8) & 0xffu, fl = rr.y >> 24;
+    const uint32_t lbyte = (rr.y >> 12) & 0xff0u;   // L * 16: byte offset of the length's four entries
+    const bool live = (fl & kFlagExcluded) == 0u;
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        if (!(mode_mask & (pass == 0 ? 3u : (pass == 1 ? 4u : 8u)))) continue;
+        const uint32_t e = *(const uint32_t *)(tab + lbyte + (pass == 0 ? (fl & kFlagReverse) << 2 : (pass == 1 ? 8u : 12u)));
+        const uint32_t koff = (e >> 16) - cum;                       // (k - cum - win_start) mod 2^16 in the low half
+        const uint32_t t = (koff + win_start) & 0xffffu;             // k - cum: inside this run when < len
+        const uint32_t d = (koff + rr.x) & 0xffffu;                  // window-relative position of read.positions[k]
+        const uint32_t addr = (live & (t < len) & (d < G)) ? ((e & 0xffffu) + d) << 2 : dump;
+        atomicAdd((uint32_t *)((char *)smem + addr), 1u);
+    }
+}
+
 // The record stream of one work item: 16-byte loads of four 4-byte records, every wave owns
 // 4 KiB per batch (U x 64 lanes x 16 B, the U loads of a lane 1 KiB apart -> one address register
 // and immediate offsets), register double buffer.  Batches that lie wholly inside the range are
@@ -1052,6 +1072,12 @@ __device__ __forceinline__ void out_add(typename OutT_<OUTMODE>::type *dst, unsi
 
 // MULTI: several alignment files (joint windows: the item's chain of per-file ranges is walked) -- an instantiation of
 // its own, so that the single-file kernels keep their register budget (seven waves per SIMD for the variable rule)
+// Experiment hook (scripts/exp_hist_sections.py; never set in the product build): a build with -DPC_HIST_SKIP=<mask>
+// leaves sections of the kernel out -- 1 record stream, 2 side lists, 4 epilogue, 8 entry table, 16 bin clear -- so
+// that their share of a launch can be timed (the counts are then wrong).
+#ifndef PC_HIST_SKIP
+#define PC_HIST_SKIP 0
+#endif
 template <int KIND, int OUTMODE, int WG, bool SMALL, bool MULTI>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : PC_HIST_WAVES(KIND), 8))) void k_hist_point(const Piece *__restrict__ pieces,
                                                     const OutPiece *__restrict__ opieces, FileView file0,
@@ -1139,7 +1165,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     OutPiece *s_op = (OutPiece *)(bins + (size_t)max_slots * mp.rows * G); // 16-byte aligned: every part is a multiple of 4 words
     const uint32_t dump = (uint32_t)((char *)(s_op + kOpStage) - (char *)smem) + (threadIdx.x & 63u) * 4u; // the lane's dump word
     if ((int)threadIdx.x < nstage * 3) ((u32x4 *)s_op)[threadIdx.x] = opq;
-    {   // only bins in [span_lo, span_hi) are ever read back: clear just those
+    if (!(PC_HIST_SKIP & 16)) {   // only bins in [span_lo, span_hi) are ever read back: clear just those
         // (16-byte stores over the span rounded out to 4 words; no per-element division)
         const int lo4 = (int)w.span_lo >> 2, hi4 = ((int)w.span_hi + 3) >> 2, nrow = nslots * mp.rows;
         const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -1163,7 +1189,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
             ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
     }
-    fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)(bins - smem), (int)threadIdx.x, WG, pre_f, pre_r);
+    if (!(PC_HIST_SKIP & 8)) fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)(bins - smem), (int)threadIdx.x, WG, pre_f, pre_r);
     if (threadIdx.x == 0) {
         // records of the first quad before `lo`, of the cut last quad outside [lo, hi)
         const int lead = (int)(w.lo & 3), keep = (int)(w.hi & 3);
@@ -1181,8 +1207,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     __syncthreads();
 
     // ---- the record stream: no dependent global loads in this loop
-    stream_records<WG, U>(src, nquads, cur, none, ftab, w.mode_mask, c.G, dump, smem);
-    if ((w.hi & 3) && threadIdx.x < 64) { // the cut last quad lives in lane 0 of the first wave
+    if (!(PC_HIST_SKIP & 1)) stream_records<WG, U>(src, nquads, cur, none, ftab, w.mode_mask, c.G, dump, smem);
+    else if (cur[0].x == 0x12345u) smem[0] = tail.x + opq.x + gfirst.x + rfirst.x + gfirst_runs.x;   // (keeps the loads of the prologue alive)
+    if (!(PC_HIST_SKIP & 1) && (w.hi & 3) && threadIdx.x < 64) { // the cut last quad lives in lane 0 of the first wave
         const uint32_t w4[4] = {tail.x, tail.y, tail.z, tail.w};
         fast_bin<4>(ftab, w.mode_mask, c.G, dump, w4, smem);
     }
@@ -1195,20 +1222,22 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
         // whose read indices [cum, cum + len) contain k holds the mapped position start + (k - cum), and that
         // run starts at most `len` before it -- so a window scans the runs that start up to Wr before its
         // first queried position: no dependent loads, no introns to look across, every run read once.
-        for (uint32_t base = rlo_; base < rhi_; base += WG) {
-            const uint32_t j = base + threadIdx.x;
-            const bool in = j < rhi_;
-            const u32x2 rr = (first_ && base == rlo_) ? rfirst : (in ? fv.run_rec[j] : rnone);
-            const int len = (int)(rr.y & 0xffu), cum = (int)((rr.y >> 8) & 0xffu), L = (int)((rr.y >> 16) & 0xffu);
-            const uint32_t fl = rr.y >> 24;
-            const bool valid = in & ((fl & kFlagExcluded) == 0) & ((uint32_t)(L - (int)c.fmin) <= c.frange);
-            int kf, kr;
-            uint32_t rowoff;
-            map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
-            const bool hf = (uint32_t)(kf - cum) < (uint32_t)len, hr = (uint32_t)(kr - cum) < (uint32_t)len; // the index lies in this run
-            const int32_t pf = (int32_t)rr.x + (kf - cum), pr = (int32_t)rr.x + (kr - cum);
-            hist_bin(c, valid, fl & kFlagReverse, hf ? kf : -1, hr ? kr : -1, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start),
-                     rowoff, bins);
+        // Binned through the same LDS entry table as the record stream: the entry of (L, strand mode) holds
+        // (k - win_start) mod 2^16 and the bins' word offset, so  k - cum  (is the index inside this run?) and the
+        // window-relative position  start + (k - cum) - win_start  are two adds each; size filter, rule, stratified
+        // row and "no bins for this mode" are already folded into the entry (an entry without a bin holds k = 32768,
+        // which lies in no run).
+        // (four loads per lane in flight: a window's runs usually fit one trip, and a trip costs one memory latency)
+        for (uint32_t base = rlo_; base < rhi_; base += 4 * WG) {
+            u32x2 rr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t j = base + u * WG + threadIdx.x;
+                rr[u] = (u == 0 && first_ && base == rlo_) ? rfirst : (j < rhi_ ? fv.run_rec[j] : rnone);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + u * WG < rhi_) run_bin(ftab, w.mode_mask, c.G, dump, rr[u], (uint32_t)c.win_start, smem);
         }
 
         // ---- gapped records outside the run stream (aligned length > kStreamMaxLen): their aligned runs live in a side
@@ -1249,7 +1278,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
             hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
         }
     };
-    side_lists(fv, w.rlo, w.rhi, w.glo, w.ghi, w.llo, w.lhi, true);
+    if (!(PC_HIST_SKIP & 2)) side_lists(fv, w.rlo, w.rhi, w.glo, w.ghi, w.llo, w.lhi, true);
     // ---- joint window (several alignment files): the records of the other files into the same bins
     if (MULTI && !w.merge) {
         for (int ff = 1; ff < nfiles; ++ff) {
@@ -1289,6 +1318,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     }
     __syncthreads();
 
+    if (PC_HIST_SKIP & 4) return;
     if (!w.merge) {
         // ---- this workgroup owns [sub_lo, sub_hi) of the window and its bins are complete:
         // write every queried segment slice straight into the caller's layout (chain offset,

@@ -247,6 +247,7 @@ struct StagedFile {
     std::vector<int64_t> len_hist; // records per aligned length (host), for cheap warn pre-checks
     int len_min = 65536, len_max = -1; // aligned lengths present
     int slen_min = 0, slen_max = 0;    // ... among the records the 4-byte stream carries
+    int tlen_min = 0, tlen_max = 0;    // ... among those and the reads of the run stream (range of the LDS entry table)
     DevBuf<uint32_t> stream;           // 4-byte record stream (pc::stream_word), padded with skip words
     // run stream (aligned runs of multi-run reads with L <= kStreamMaxLen, sorted by contig and run start)
     int64_t nrunrec = 0;
@@ -904,7 +905,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         std::vector<uint4> long_rec, gap_rec, xlong_rec;
         std::vector<uint2> long_wide, xlong_wide;     // true {aligned length, run count} of every long-list entry
         std::vector<int32_t> long_span, xlong_span;
-        int W = 1, Wg = 1, Wr = 1, smin = 65536, smax = -1;
+        int W = 1, Wg = 1, Wr = 1, smin = 65536, smax = -1, rmin = 65536, rmax = -1;
         int64_t max_span = 1, cursor = 0;
         int64_t run_at = 0;                        // where this unit's run-stream records go
     };
@@ -1022,6 +1023,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
                     const bool in_runs = nb >= 2 && L <= kStreamMaxLen && wi < 0;
                     if (in_runs) {
                         meta |= (kFlagRuns << 16);
+                        c.rmin = std::min(c.rmin, L); c.rmax = std::max(c.rmax, L);   // run-stream records index the same LDS entry table
                         uint32_t cum = 0;
                         for (int k = 0; k < nb; ++k) {
                             const uint32_t rs = (uint32_t)blk_start[boff + k], rl = (uint32_t)blk_len[boff + k];
@@ -1122,7 +1124,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     std::vector<size_t> lo_of(units.size() + 1, 0), go_of(units.size() + 1, 0), xo_of(units.size() + 1, 0);
     int Wg = 1, Wr = 1;
     {
-        int smin = 65536, smax = -1;
+        int smin = 65536, smax = -1, tmin = 65536, tmax = -1;
         for (size_t u = 0; u < units.size(); ++u) {
             const Unit &c = units[u];
             W = std::max(W, c.W);
@@ -1131,11 +1133,14 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
             xo_of[u + 1] = xo_of[u] + c.xlong_rec.size();
             max_span = std::max(max_span, c.max_span);
             smin = std::min(smin, c.smin); smax = std::max(smax, c.smax);
+            tmin = std::min(tmin, std::min(c.smin, c.rmin)); tmax = std::max(tmax, std::max(c.smax, c.rmax));
             lo_of[u + 1] = lo_of[u] + c.long_rec.size();
             go_of[u + 1] = go_of[u] + c.gap_rec.size();
         }
         sf->slen_min = smax >= smin ? smin : 0;
         sf->slen_max = smax >= smin ? smax : 0;
+        sf->tlen_min = tmax >= tmin ? tmin : 0;
+        sf->tlen_max = tmax >= tmin ? tmax : 0;
     }
     const size_t nlong = lo_of[units.size()], ngap = go_of[units.size()], nxlong = xo_of[units.size()], nrunrec = (size_t)nrunrec_total;
     HostBuf<uint4> long_rec(nlong), gap_rec(ngap), xlong_rec(nxlong);
@@ -1966,7 +1971,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             const size_t bins_words = (size_t)p->max_slots * p->rows * G + (size_t)((tab_n + 3) & ~3) + stage_words;
             // LDS entry table of the record stream: the aligned lengths the stream carries
             int fast_lo = kStreamMaxLen, fast_hi = 0;
-            for (auto *f : e->files) { fast_lo = std::min(fast_lo, f->slen_min); fast_hi = std::max(fast_hi, f->slen_max); }
+            for (auto *f : e->files) { fast_lo = std::min(fast_lo, f->tlen_min); fast_hi = std::max(fast_hi, f->tlen_max); }
             fast_lo = std::min(fast_lo, fast_hi);
             const size_t fwords = (size_t)(fast_hi + 1) * kModes + 64; // entry table + one dump word per lane (after the staged pieces)
             const size_t lds = (bins_words + fwords) * sizeof(uint32_t);
