@@ -2081,6 +2081,150 @@ __global__ __launch_bounds__(kWG) void k_stream_from_rec(const uint2 *__restrict
     }
 }
 
+// ---------------------------------------------------------------- side lists, built on the GPU
+// The gapped-record, long-span and long-span-outside-the-run-stream lists of a staged file are compactions of its
+// records (the class of a record is written in its header by the host pack pass), so they are made where the
+// records already are: the members are selected in record order (hipcub::DeviceSelect over a counting iterator with
+// the predicates below), k_side_fill writes their entries, an inclusive max-scan of (contig << 32 | end) gives the
+// running maximum of the ends per contig, k_list_bounds the per-contig ranges and k_lin_table the linear-index tables.
+struct SelectLong {      // span beyond the window halo (or a wide record): the long-span list
+    const uint2 *rec;
+    __device__ bool operator()(uint32_t i) const { return ((rec[i].y >> 16) & kFlagLong) != 0u; }
+};
+struct SelectXLong {     // ... whose runs are not in the run stream: what the point rules still walk
+    const uint2 *rec;
+    __device__ bool operator()(uint32_t i) const {
+        const uint32_t fl = rec[i].y >> 16;
+        return (fl & kFlagLong) != 0u && (fl & kFlagRuns) == 0u;
+    }
+};
+struct SelectGap {       // several runs or longer than the stream carries, inside the halo, not in the run stream
+    const uint2 *rec;
+    __device__ bool operator()(uint32_t i) const {
+        const uint32_t meta = rec[i].y, fl = meta >> 16;
+        return (fl & (kFlagLong | kFlagRuns)) == 0u && ((meta >> 24) >= 2u || (meta & 0xffffu) > (uint32_t)kStreamMaxLen);
+    }
+};
+
+// members of each list (long-span, gapped, long-span outside the run stream): sizes the lists before they are selected
+__global__ __launch_bounds__(kWG) void k_side_count(const uint2 *__restrict__ rec, int64_t n, uint32_t *counts) {
+    const SelectLong sl{rec};
+    const SelectGap sg{rec};
+    const SelectXLong sx{rec};
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    const int64_t base = (int64_t)blockIdx.x * kWG * 16;
+    for (int u = 0; u < 16; ++u) {
+        const int64_t i = base + (int64_t)u * kWG + threadIdx.x;
+        if (i < n) { c0 += sl((uint32_t)i); c1 += sg((uint32_t)i); c2 += sx((uint32_t)i); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_down(c0, o, 64); c1 += __shfl_down(c1, o, 64); c2 += __shfl_down(c2, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (c0) atomicAdd(&counts[0], c0);
+        if (c1) atomicAdd(&counts[1], c1);
+        if (c2) atomicAdd(&counts[2], c2);
+    }
+}
+
+// aligned runs of the multi-run records as {start, length} pairs, from the caller's two arrays
+__global__ __launch_bounds__(kWG) void k_zip_runs(const int32_t *__restrict__ start, const int32_t *__restrict__ len, int64_t n, int2 *blk) {
+    const int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (j < n) blk[j] = make_int2(start[j], len[j]);
+}
+
+// entry k of a side list = record idx[k]: {pos, header, first run, record}, its first two runs (a single-run record:
+// {pos, L}), its contig, (contig << 32 | end) for the running maximum, and -- files with wide records -- the true
+// {aligned length, run count}
+__global__ __launch_bounds__(kWG) void k_side_fill(const uint32_t *__restrict__ idx, int64_t m, const uint2 *__restrict__ rec,
+                                                   const uint32_t *__restrict__ blk_off, const int2 *__restrict__ blk,
+                                                   const int64_t *__restrict__ tid_bounds, int ntid,
+                                                   const uint32_t *__restrict__ wide_rec, const uint2 *__restrict__ wide_val, int64_t nwide,
+                                                   uint4 *out_rec, int4 *out_runs, int32_t *out_tid, unsigned long long *out_key,
+                                                   uint2 *out_wide) {
+    const int64_t k = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t i = idx[k];
+    const uint2 r = rec[i];
+    uint32_t L = r.y & 0xffffu, nb = r.y >> 24;
+    if ((r.y >> 16) & kFlagWide) {
+        int64_t lo = 0, hi = nwide;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (wide_rec[mid] < i) lo = mid + 1; else hi = mid;
+        }
+        L = wide_val[lo].x;
+        nb = wide_val[lo].y;
+    }
+    const uint32_t boff = nb >= 2u ? blk_off[i] : 0u;
+    int4 runs = make_int4((int32_t)r.x, (int32_t)L, 0, 0);
+    int64_t end = (int64_t)(int32_t)r.x + (L > 0u ? (int64_t)L : 1);
+    if (nb >= 2u) {
+        const int2 b0 = blk[boff], b1 = blk[boff + 1u], bl = blk[boff + nb - 1u];
+        runs = make_int4(b0.x, b0.y, b1.x, b1.y);
+        end = (int64_t)bl.x + bl.y;
+    }
+    out_rec[k] = make_uint4(r.x, r.y, boff, i);
+    out_runs[k] = runs;
+    if (out_tid || out_key) {
+        int lo = 0, hi = ntid;   // contig of record i: tid_bounds[t] <= i < tid_bounds[t + 1]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (tid_bounds[mid + 1] <= (int64_t)i) lo = mid + 1; else hi = mid;
+        }
+        if (out_tid) out_tid[k] = lo;
+        if (out_key) out_key[k] = ((unsigned long long)lo << 32) | (unsigned long long)(uint32_t)end;
+    }
+    if (out_wide) out_wide[k] = make_uint2(L, nb);
+}
+
+// the low half of the scanned keys: the running maximum of the ends inside the entry's contig
+__global__ __launch_bounds__(kWG) void k_unpack_pmax(const unsigned long long *__restrict__ key, int64_t m, int32_t *pmax) {
+    const int64_t k = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (k < m) pmax[k] = (int32_t)(uint32_t)key[k];
+}
+
+// bounds[t] = entries of the list that belong to contigs before t (the list is in record order)
+__global__ __launch_bounds__(kWG) void k_list_bounds(const uint32_t *__restrict__ idx, int64_t m, const int64_t *__restrict__ tid_bounds,
+                                                     int ntid, int64_t *bounds) {
+    const int t = (int)(blockIdx.x * kWG + threadIdx.x);
+    if (t > ntid) return;
+    const int64_t first = tid_bounds[t];
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)idx[mid] < first) lo = mid + 1; else hi = mid;
+    }
+    bounds[t] = lo;
+}
+
+// Linear index of a list: tab[g] = first entry of bucket g's contig whose key is not before the bucket's edge (the
+// last entry of a contig's table = the end of its range).  KEY 0: the start of a record (rec[].x); 1: the start of a
+// side-list entry (uint4 .x); 2: a running maximum of ends -- an entry counts as "before" while its maximum is <= edge.
+template <int KEY>
+__global__ __launch_bounds__(kWG) void k_lin_table(const void *__restrict__ keys, const int64_t *__restrict__ bounds,
+                                                   const int64_t *__restrict__ lin_off, int ntid, int64_t nlin, uint32_t *tab) {
+    const int64_t g = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (g >= nlin) return;
+    int lo_t = 0, hi_t = ntid;             // contig of table entry g
+    while (lo_t < hi_t) {
+        const int mid = (lo_t + hi_t) >> 1;
+        if (lin_off[mid + 1] <= g) lo_t = mid + 1; else hi_t = mid;
+    }
+    const int t = lo_t;
+    const int64_t k = g - lin_off[t], nb = lin_off[t + 1] - lin_off[t] - 1;
+    int64_t lo = bounds[t], hi = bounds[t + 1];
+    if (k >= nb) { tab[g] = (uint32_t)hi; return; }
+    const int64_t edge = k << kLinShift;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        bool before;
+        if (KEY == 0) before = (int64_t)(int32_t)((const uint2 *)keys)[mid].x < edge;
+        else if (KEY == 1) before = (int64_t)(int32_t)((const uint4 *)keys)[mid].x < edge;
+        else before = (int64_t)((const int32_t *)keys)[mid] <= edge;
+        if (before) lo = mid + 1; else hi = mid;
+    }
+    tab[g] = (uint32_t)lo;
+}
+
 __global__ __launch_bounds__(kWG) void k_update_side_flags(uint4 *list, int64_t n, const uint2 *__restrict__ rec) {
     const int64_t j = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (j >= n) return;

@@ -750,6 +750,22 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         return fail(PC_ERR_ARG, "pc_add_alignment_file: all files must use the same reference list (ntid %d vs %d)", ntid, e->ntid);
     HIP_TRY(hipSetDevice(e->device));
 
+    // the caller's run arrays go up on a thread of their own while the records are validated and packed (the GPU
+    // zips them into {start, length} pairs and builds the side lists from them)
+    DevBuf<int32_t> d_bs, d_bl;
+    struct Joined { std::future<int> f; ~Joined() { if (f.valid()) f.wait(); } } runs_up;   // (joined on every way out, before the buffers go)
+    if (nrun > 0) {
+        const int dev = e->device;
+        hipStream_t s = e->stream;
+        runs_up.f = std::async(std::launch::async, [&d_bs, &d_bl, blk_start, blk_len, nrun, dev, s]() -> int {
+            if (hipSetDevice(dev) != hipSuccess) return PC_ERR_HIP;
+            int r = d_bs.upload(blk_start, (size_t)nrun, s);
+            if (r == PC_OK) r = d_bl.upload(blk_len, (size_t)nrun, s);
+            if (r == PC_OK && hipStreamSynchronize(s) != hipSuccess) r = PC_ERR_HIP;
+            return r;
+        });
+    }
+
     StageClock clk;
     // ---- host pass: validation, per-tid bounds, spans, packed records.  Threaded over contiguous
     // record chunks; every per-chunk result is merged in chunk order, and the error reported is the
@@ -902,9 +918,6 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     if (const char *env = getenv("PC_STAGE_SLICE")) S = std::max<int64_t>(1, atoll(env)); // test knob: tiny slices
     const int64_t nslices = (n + S - 1) / S;
     struct Unit { // one thread's share of one slice
-        std::vector<uint4> long_rec, gap_rec, xlong_rec;
-        std::vector<uint2> long_wide, xlong_wide;     // true {aligned length, run count} of every long-list entry
-        std::vector<int32_t> long_span, xlong_span;
         int W = 1, Wg = 1, Wr = 1, smin = 65536, smax = -1, rmin = 65536, rmax = -1;
         int64_t max_span = 1, cursor = 0;
         int64_t run_at = 0;                        // where this unit's run-stream records go
@@ -976,7 +989,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         const int64_t s0 = sl * S, s1 = std::min(n, s0 + S);
         parallel_chunks((int64_t)T, T, [&](int, int64_t tb, int64_t te) {
             for (int64_t t = tb; t < te; ++t) {
-                Unit &c = units[(size_t)(sl * T + t)];
+                Unit c = units[(size_t)(sl * T + t)];   // a local copy, written back below: neighbouring units share cache lines
                 int64_t b, en;
                 unit_range(sl, (int)t, b, en);
                 int64_t cursor = c.cursor, run_at = c.run_at;
@@ -1035,22 +1048,13 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
                             cum += rl;
                         }
                     }
+                    // the class of the record goes into its header; the side lists themselves are compacted from the
+                    // headers on the GPU (SelectLong / SelectXLong / SelectGap in pc_kernels.hip.h)
                     if (sp > wcap || wi >= 0) {   // (wide records always take the long-span lists: those carry their true length / run count)
                         meta |= (kFlagLong << 16);
-                        c.long_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
-                        c.long_span.push_back(sp);
-                        c.long_wide.push_back(make_uint2((uint32_t)L, (uint32_t)nb));
-                        if (!in_runs) {
-                            c.xlong_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
-                            c.xlong_span.push_back(sp);
-                            c.xlong_wide.push_back(make_uint2((uint32_t)L, (uint32_t)nb));
-                        }
                     } else {
                         c.W = std::max(c.W, (int)sp);
-                        if ((nb >= 2 || L > kStreamMaxLen) && !in_runs) { // binned from the side list, not from a stream
-                            c.gap_rec.push_back(make_uint4((uint32_t)pos[i], meta, boff, (uint32_t)i));
-                            c.Wg = std::max(c.Wg, (int)sp);
-                        }
+                        if ((nb >= 2 || L > kStreamMaxLen) && !in_runs) c.Wg = std::max(c.Wg, (int)sp); // binned from the gapped-record list, not from a stream
                     }
                     const uint32_t wd = stream_word((uint32_t)pos[i], meta & ~((uint32_t)kFlagExcluded << 16));
                     if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
@@ -1065,6 +1069,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
                     c.W = std::max(c.W, pl_max);
                     c.smin = std::min(c.smin, pl_min); c.smax = std::max(c.smax, pl_max);
                 }
+                units[(size_t)(sl * T + t)] = c;
             }
         });
         uint2 *d_rec = sf->rec.p + s0;
@@ -1116,12 +1121,9 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         if (he != hipSuccess) { delete sf; return fail(PC_ERR_HIP, "pc_add_alignment_file: deriving the record stream failed: %s", hipGetErrorString(he)); }
     }
     clk.lap("pack + upload (pipelined)");
-    // side lists in record order (slice-major, then thread order inside a slice): every unit copies
-    // its entries to their final place; only the running maximum of the ends is a serial walk
-    std::vector<int64_t> long_bounds((size_t)ntid + 1, 0), gap_bounds((size_t)ntid + 1, 0), xlong_bounds((size_t)ntid + 1, 0);
+    // ---- statistics of the pack pass
     int W = 1;
     int64_t max_span = 1;
-    std::vector<size_t> lo_of(units.size() + 1, 0), go_of(units.size() + 1, 0), xo_of(units.size() + 1, 0);
     int Wg = 1, Wr = 1;
     {
         int smin = 65536, smax = -1, tmin = 65536, tmax = -1;
@@ -1130,223 +1132,178 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
             W = std::max(W, c.W);
             Wg = std::max(Wg, c.Wg);
             Wr = std::max(Wr, c.Wr);
-            xo_of[u + 1] = xo_of[u] + c.xlong_rec.size();
             max_span = std::max(max_span, c.max_span);
             smin = std::min(smin, c.smin); smax = std::max(smax, c.smax);
             tmin = std::min(tmin, std::min(c.smin, c.rmin)); tmax = std::max(tmax, std::max(c.smax, c.rmax));
-            lo_of[u + 1] = lo_of[u] + c.long_rec.size();
-            go_of[u + 1] = go_of[u] + c.gap_rec.size();
         }
         sf->slen_min = smax >= smin ? smin : 0;
         sf->slen_max = smax >= smin ? smax : 0;
         sf->tlen_min = tmax >= tmin ? tmin : 0;
         sf->tlen_max = tmax >= tmin ? tmax : 0;
     }
-    const size_t nlong = lo_of[units.size()], ngap = go_of[units.size()], nxlong = xo_of[units.size()], nrunrec = (size_t)nrunrec_total;
-    HostBuf<uint4> long_rec(nlong), gap_rec(ngap), xlong_rec(nxlong);
-    HostBuf<uint32_t> long_idx(nlong);
-    HostBuf<int32_t> long_tid(nlong), long_pmax(nlong), xlong_tid(nxlong), xlong_pmax(nxlong);
-    HostBuf<int4> long_runs(nlong), gap_runs(ngap), xlong_runs(nxlong);
-    HostBuf<uint2> long_wide(n_wide ? nlong : 0), xlong_wide(n_wide ? nxlong : 0);   // only files with wide records carry these
-    if (!long_rec.p || !gap_rec.p || !long_idx.p || !long_tid.p || !long_pmax.p || !long_runs.p || !gap_runs.p || !xlong_rec.p ||
-        !xlong_tid.p || !xlong_pmax.p || !xlong_runs.p) {
-        delete sf;
-        return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
-    }
-    // the first two aligned runs of every side-list record travel next to its header: the kernels then
-    // need the run array only for reads with three or more runs
-    auto first_two = [&](const uint4 &g, const uint2 &tv) { // {pos, aligned length | flags << 16 | runs << 24, first run, record}; true {length, runs}
-        return tv.y >= 2u ? make_int4(blk_start[g.z], blk_len[g.z], blk_start[g.z + 1], blk_len[g.z + 1])
-                          : make_int4((int32_t)g.x, (int)tv.x, 0, 0);
-    };
-    auto plain_tv = [](const uint4 &g) { return make_uint2(g.y & 0xffffu, g.y >> 24); };
-    parallel_chunks((int64_t)units.size(), T, [&](int, int64_t ub, int64_t ue) {
-        int t_of = 0;
-        for (int64_t u = ub; u < ue; ++u) {
-            const Unit &c = units[(size_t)u];
-            size_t at = lo_of[(size_t)u];
-            for (size_t k = 0; k < c.long_rec.size(); ++k, ++at) {
-                const uint4 g = c.long_rec[k];
-                // (the contig comes from tid_bounds, walked along with the list: a look-up in the
-                // caller's tid[] would miss the cache every time)
-                while ((int64_t)g.w >= tid_bounds[(size_t)t_of + 1]) ++t_of;
-                long_rec[at] = g;
-                long_idx[at] = g.w;
-                long_tid[at] = t_of;
-                long_pmax[at] = (int32_t)g.x + c.long_span[k];   // the read's own end; made a running maximum below
-                long_runs[at] = first_two(g, c.long_wide[k]);
-                if (n_wide) long_wide[at] = c.long_wide[k];
-            }
-            at = go_of[(size_t)u];
-            for (size_t k = 0; k < c.gap_rec.size(); ++k, ++at) {
-                gap_rec[at] = c.gap_rec[k];
-                gap_runs[at] = first_two(c.gap_rec[k], plain_tv(c.gap_rec[k]));
-            }
-            at = xo_of[(size_t)u];
-            int t_x = 0;
-            for (size_t k = 0; k < c.xlong_rec.size(); ++k, ++at) {
-                const uint4 g = c.xlong_rec[k];
-                while ((int64_t)g.w >= tid_bounds[(size_t)t_x + 1]) ++t_x;
-                xlong_rec[at] = g;
-                xlong_tid[at] = t_x;
-                xlong_pmax[at] = (int32_t)g.x + c.xlong_span[k];
-                xlong_runs[at] = first_two(g, c.xlong_wide[k]);
-                if (n_wide) xlong_wide[at] = c.xlong_wide[k];
-            }
-        }
-    });
-    {
-        int cur_tid = -1;
-        int32_t pm = 0;
-        for (size_t k = 0; k < nlong; ++k) { // running maximum of the ends, per contig
-            const int t_of = long_tid[k];
-            if (t_of != cur_tid) { cur_tid = t_of; pm = 0; }
-            pm = std::max(pm, long_pmax[k]);
-            long_pmax[k] = pm;
-            long_bounds[(size_t)t_of + 1] += 1;
-        }
-        int t_of = 0;
-        for (size_t k = 0; k < ngap; ++k) {
-            while ((int64_t)gap_rec[k].w >= tid_bounds[(size_t)t_of + 1]) ++t_of;
-            gap_bounds[(size_t)t_of + 1] += 1;
-        }
-        for (int t = 0; t < ntid; ++t) long_bounds[(size_t)t + 1] += long_bounds[(size_t)t];
-        for (int t = 0; t < ntid; ++t) gap_bounds[(size_t)t + 1] += gap_bounds[(size_t)t];
-        cur_tid = -1; pm = 0;
-        for (size_t k = 0; k < nxlong; ++k) { // the same for the long-span reads outside the run stream
-            const int t_x = xlong_tid[k];
-            if (t_x != cur_tid) { cur_tid = t_x; pm = 0; }
-            pm = std::max(pm, xlong_pmax[k]);
-            xlong_pmax[k] = pm;
-            xlong_bounds[(size_t)t_x + 1] += 1;
-        }
-        for (int t = 0; t < ntid; ++t) xlong_bounds[(size_t)t + 1] += xlong_bounds[(size_t)t];
-    }
     sf->W = W;
     sf->Wg = Wg;
     sf->Wr = Wr;
     sf->max_span = max_span;
-    sf->nlong = (int64_t)nlong;
-    sf->ngap = (int64_t)ngap;
-    sf->nxlong = (int64_t)nxlong;
+    const size_t nrunrec = (size_t)nrunrec_total;
     sf->nrunrec = (int64_t)nrunrec;
     units.clear();
     units.shrink_to_fit();
-    clk.lap("side lists");
-    // they go up while the index tables are built
-    std::future<int> side_up;
-    {
-        StagedFile *f = sf;
-        const uint4 *h_lr = long_rec.p, *h_gr = gap_rec.p;
-        const uint32_t *h_li = long_idx.p;
-        const int32_t *h_lt = long_tid.p, *h_lp = long_pmax.p;
-        const int4 *h_lru = long_runs.p, *h_gru = gap_runs.p, *h_xru = xlong_runs.p;
-        const uint4 *h_xr = xlong_rec.p;
-        const uint2 *h_lw = long_wide.p, *h_xw = xlong_wide.p;
-        const size_t nlw = n_wide ? nlong : 0, nxw = n_wide ? nxlong : 0;
-        side_up = std::async(std::launch::async, [=]() -> int {
-            if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
-            int r = f->long_idx.upload(h_li, nlong, up_stream);
-            if (r == PC_OK && nlw) r = f->long_wide.upload(h_lw, nlw, up_stream);
-            if (r == PC_OK && nxw) r = f->xlong_wide.upload(h_xw, nxw, up_stream);
-            if (r == PC_OK) r = f->xlong_rec.upload(h_xr, nxlong, up_stream);
-            if (r == PC_OK) r = f->xlong_runs.upload(h_xru, nxlong, up_stream);
-            if (r == PC_OK) r = f->long_tid.upload(h_lt, nlong, up_stream);
-            if (r == PC_OK) r = f->long_pmax.upload(h_lp, nlong, up_stream);
-            if (r == PC_OK) r = f->long_rec.upload(h_lr, nlong, up_stream);
-            if (r == PC_OK) r = f->gap_rec.upload(h_gr, ngap, up_stream);
-            if (r == PC_OK) r = f->gap_runs.upload(h_gru, ngap, up_stream);
-            if (r == PC_OK) r = f->long_runs.upload(h_lru, nlong, up_stream);
-            if (r == PC_OK && hipStreamSynchronize(up_stream) != hipSuccess) r = PC_ERR_HIP;
-            return r;
-        });
-    }
 
-    // ---- linear index: first record at/after every 2^kLinShift-position bucket of each contig
+    // ---- linear-index layout: one table entry per 2^kLinShift-position bucket of each contig, up to the last
+    // record start -- and up to the furthest end of a read of the contig (tid_end): a long-span read reaches
+    // windows beyond every record start, and the later runs of gapped reads start there
     std::vector<int64_t> lin_off((size_t)ntid + 1, 0);
     for (int t = 0; t < ntid; ++t) {
         const int64_t b = tid_bounds[(size_t)t], en = tid_bounds[(size_t)t + 1];
-        // buckets up to the last record start -- and up to the furthest end of a long-span read,
-        // which can reach windows that lie beyond every record start
         int64_t last = en > b ? (int64_t)pos[en - 1] : -1;
-        const int64_t lb = long_bounds[(size_t)t], le = long_bounds[(size_t)t + 1];
-        if (le > lb) last = std::max<int64_t>(last, (int64_t)long_pmax[(size_t)le - 1] - 1);
-        if (en > b) last = std::max<int64_t>(last, tid_end[(size_t)t] - 1);   // later runs of gapped reads start beyond every record start
+        if (en > b) last = std::max<int64_t>(last, tid_end[(size_t)t] - 1);
         const int64_t nb = last >= 0 ? (last >> kLinShift) + 1 : 0;
         lin_off[(size_t)t + 1] = lin_off[(size_t)t] + nb + 1;
     }
-    // (not value-initialised: a human-scale genome has 2.4e7 buckets per table, and the threads that
-    // fill them are the first to touch their part)
     const size_t nlin = (size_t)lin_off[(size_t)ntid];
-    HostBuf<uint32_t> lin_tab(nlin), glin_tab(nlin), llin_tab(nlin), plin_tab(nlin);
-    if (!lin_tab.p || !glin_tab.p || !llin_tab.p || !plin_tab.p) {
-        (void)side_up.get();
-        delete sf;
-        return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
-    }
-    // every table entry is "first list index whose key is not before the bucket edge": the entries are
-    // dealt to the threads in contiguous ranges; a thread finds its first index by bisection and
-    // walks on from there (the keys are monotone inside a contig)
-    auto fill_lin = [&](HostBuf<uint32_t> &tab, const std::vector<int64_t> &bounds, auto before) {
-        parallel_chunks(lin_off[(size_t)ntid], T, [&](int, int64_t g0, int64_t g1) {
-            if (g0 >= g1) return;
-            int t = (int)(std::upper_bound(lin_off.begin(), lin_off.end(), g0) - lin_off.begin()) - 1;
-            int64_t i = -1;
-            for (int64_t g = g0; g < g1; ++g) {
-                while (g >= lin_off[(size_t)t + 1]) { ++t; i = -1; }
-                const int64_t l0 = lin_off[(size_t)t], nb = lin_off[(size_t)t + 1] - l0 - 1, k = g - l0;
-                const int64_t b = bounds[(size_t)t], en = bounds[(size_t)t + 1];
-                if (k >= nb) { tab[(size_t)g] = (uint32_t)en; continue; }
-                const int64_t edge = k << kLinShift;
-                if (i < 0) {
-                    int64_t lo = b, hi = en;
-                    while (lo < hi) {
-                        const int64_t mid = (lo + hi) >> 1;
-                        if (before(mid, edge)) lo = mid + 1; else hi = mid;
-                    }
-                    i = lo;
-                } else {
-                    while (i < en && before(i, edge)) ++i;
-                }
-                tab[(size_t)g] = (uint32_t)i;
-            }
-        });
-    };
-    fill_lin(lin_tab, tid_bounds, [&](int64_t i, int64_t edge) { return (int64_t)pos[i] < edge; });
-    fill_lin(glin_tab, gap_bounds, [&](int64_t i, int64_t edge) { return (int64_t)(int32_t)gap_rec[(size_t)i].x < edge; });
-    // long-span list: by start, and by running maximum end (both monotone)
-    fill_lin(llin_tab, long_bounds, [&](int64_t i, int64_t edge) { return (int64_t)(int32_t)long_rec[(size_t)i].x < edge; });
-    fill_lin(plin_tab, long_bounds, [&](int64_t i, int64_t edge) { return (int64_t)long_pmax[(size_t)i] <= edge; });
-    HostBuf<uint32_t> xllin_tab(nxlong ? nlin : 0), xplin_tab(nxlong ? nlin : 0);
-    if (nxlong) {
-        if (!xllin_tab.p || !xplin_tab.p) { (void)side_up.get(); delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
-        fill_lin(xllin_tab, xlong_bounds, [&](int64_t i, int64_t edge) { return (int64_t)(int32_t)xlong_rec[(size_t)i].x < edge; });
-        fill_lin(xplin_tab, xlong_bounds, [&](int64_t i, int64_t edge) { return (int64_t)xlong_pmax[(size_t)i] <= edge; });
-    }
 
-    clk.lap("linear index");
-    // ---- the remaining tables
-    { const int r = side_up.get(); if (rc == PC_OK && r != PC_OK) rc = fail(r, "pc_add_alignment_file: staging the side lists failed"); }
+    // ---- side lists and linear-index tables, on the GPU (pc_kernels.hip.h, "side lists"): the records are there
+    // already; from the host come only the aligned runs of the multi-run records and the two small per-contig tables
+    hipStream_t st = e->stream;
+    rc = sf->tid_bounds.upload(tid_bounds, st);
+    if (rc == PC_OK) rc = sf->lin_off.upload(lin_off, st);
+    if (nrun > 0) { const int r = runs_up.f.get(); if (rc == PC_OK && r != PC_OK) rc = fail(r, "stage: uploading the aligned runs failed"); }
     if (rc == PC_OK && nrun > 0) {
-        HostBuf<int2> blk((size_t)nrun);
-        if (!blk.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
-        parallel_chunks(nrun, T, [&](int, int64_t jb, int64_t je) {
-            for (int64_t j = jb; j < je; ++j) blk[(size_t)j] = make_int2(blk_start[j], blk_len[j]);
-        });
-        rc = sf->blk.upload(blk.p, (size_t)nrun, e->stream);
-        if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
+        rc = sf->blk.reserve((size_t)nrun);
+        if (rc == PC_OK) {
+            hipLaunchKernelGGL(k_zip_runs, dim3((unsigned)((nrun + kWG - 1) / kWG)), dim3(kWG), 0, st, d_bs.p, d_bl.p, nrun, sf->blk.p);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: staging the aligned runs failed");
+            d_bs.release();
+            d_bl.release();
+        }
     }
-    if (rc == PC_OK) rc = sf->tid_bounds.upload(tid_bounds, e->stream);
-    if (rc == PC_OK) rc = sf->long_tid_bounds.upload(long_bounds, e->stream);
-    if (rc == PC_OK) rc = sf->gap_tid_bounds.upload(gap_bounds, e->stream);
-    if (rc == PC_OK) rc = sf->lin_tab.upload(lin_tab.p, nlin, e->stream);
-    if (rc == PC_OK) rc = sf->glin_tab.upload(glin_tab.p, nlin, e->stream);
-    if (rc == PC_OK) rc = sf->llin_tab.upload(llin_tab.p, nlin, e->stream);
-    if (rc == PC_OK) rc = sf->plin_tab.upload(plin_tab.p, nlin, e->stream);
-    if (rc == PC_OK && nxlong) rc = sf->xllin_tab.upload(xllin_tab.p, nlin, e->stream);
-    if (rc == PC_OK && nxlong) rc = sf->xplin_tab.upload(xplin_tab.p, nlin, e->stream);
-    if (rc == PC_OK) rc = sf->lin_off.upload(lin_off, e->stream);
-    if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
+    size_t nlong = 0, ngap = 0, nxlong = 0;
+    DevBuf<uint32_t> d_gap_idx, d_xlong_idx, d_nsel;
+    if (rc == PC_OK && n > 0) {
+        // members of the three lists, in record order (counted first: the lists are sized exactly)
+        rc = d_nsel.reserve(8);
+        uint32_t ncls[3] = {0, 0, 0};
+        if (rc == PC_OK) {
+            hipError_t he = hipMemsetAsync(d_nsel.p, 0, 8 * sizeof(uint32_t), st);
+            if (he == hipSuccess) {
+                const int64_t per_wg = (int64_t)kWG * 16;
+                hipLaunchKernelGGL(k_side_count, dim3((unsigned)((n + per_wg - 1) / per_wg)), dim3(kWG), 0, st, sf->rec.p, n, d_nsel.p + 4);
+                he = hipMemcpyAsync(ncls, d_nsel.p + 4, sizeof(ncls), hipMemcpyDeviceToHost, st);
+            }
+            if (he == hipSuccess) he = hipStreamSynchronize(st);
+            if (he != hipSuccess) rc = fail(PC_ERR_HIP, "stage: counting the side lists failed: %s", hipGetErrorString(he));
+        }
+        if (rc == PC_OK) rc = sf->long_idx.reserve(ncls[0]);
+        if (rc == PC_OK) rc = d_gap_idx.reserve(ncls[1]);
+        if (rc == PC_OK) rc = d_xlong_idx.reserve(ncls[2]);
+        if (rc == PC_OK) {
+            hipcub::CountingInputIterator<uint32_t> ids(0u);
+            size_t tmp_bytes = 0, need = 0;
+            hipError_t he = hipcub::DeviceSelect::If(nullptr, need, ids, sf->long_idx.p, d_nsel.p, (int)n, SelectLong{sf->rec.p}, st);
+            tmp_bytes = need;
+            if (he == hipSuccess) he = hipcub::DeviceSelect::If(nullptr, need, ids, d_gap_idx.p, d_nsel.p + 1, (int)n, SelectGap{sf->rec.p}, st);
+            tmp_bytes = std::max(tmp_bytes, need);
+            if (he == hipSuccess) he = hipcub::DeviceSelect::If(nullptr, need, ids, d_xlong_idx.p, d_nsel.p + 2, (int)n, SelectXLong{sf->rec.p}, st);
+            tmp_bytes = std::max(tmp_bytes, need);
+            DevBuf<uint8_t> d_tmp;
+            if (he == hipSuccess && d_tmp.reserve(std::max<size_t>(tmp_bytes, 16)) != PC_OK) he = hipErrorOutOfMemory;
+            size_t tb = tmp_bytes;
+            if (he == hipSuccess) he = hipcub::DeviceSelect::If(d_tmp.p, tb, ids, sf->long_idx.p, d_nsel.p, (int)n, SelectLong{sf->rec.p}, st);
+            tb = tmp_bytes;
+            if (he == hipSuccess) he = hipcub::DeviceSelect::If(d_tmp.p, tb, ids, d_gap_idx.p, d_nsel.p + 1, (int)n, SelectGap{sf->rec.p}, st);
+            tb = tmp_bytes;
+            if (he == hipSuccess) he = hipcub::DeviceSelect::If(d_tmp.p, tb, ids, d_xlong_idx.p, d_nsel.p + 2, (int)n, SelectXLong{sf->rec.p}, st);
+            uint32_t nsel[3] = {0, 0, 0};
+            if (he == hipSuccess) he = hipMemcpyAsync(nsel, d_nsel.p, sizeof(nsel), hipMemcpyDeviceToHost, st);
+            if (he == hipSuccess) he = hipStreamSynchronize(st);   // the counts size what follows; d_tmp goes out of scope
+            if (he != hipSuccess) rc = fail(PC_ERR_HIP, "stage: selecting the side lists failed: %s", hipGetErrorString(he));
+            nlong = nsel[0]; ngap = nsel[1]; nxlong = nsel[2];
+            if (rc == PC_OK && (nlong != ncls[0] || ngap != ncls[1] || nxlong != ncls[2])) rc = fail(PC_ERR_STATE, "stage: the side lists changed size while they were built");
+        }
+    }
+    sf->nlong = (int64_t)nlong;
+    sf->ngap = (int64_t)ngap;
+    sf->nxlong = (int64_t)nxlong;
+    DevBuf<int64_t> d_xlong_bounds;
+    DevBuf<int32_t> d_xlong_pmax;
+    if (rc == PC_OK) {
+        // entries, running maxima of the ends, per-contig ranges
+        DevBuf<unsigned long long> d_key, d_key_scanned;
+        DevBuf<uint8_t> d_tmp;
+        rc = sf->long_rec.reserve(nlong);
+        if (rc == PC_OK) rc = sf->long_runs.reserve(nlong);
+        if (rc == PC_OK) rc = sf->long_tid.reserve(nlong);
+        if (rc == PC_OK) rc = sf->long_pmax.reserve(nlong);
+        if (rc == PC_OK && n_wide) rc = sf->long_wide.reserve(nlong);
+        if (rc == PC_OK) rc = sf->gap_rec.reserve(ngap);
+        if (rc == PC_OK) rc = sf->gap_runs.reserve(ngap);
+        if (rc == PC_OK) rc = sf->xlong_rec.reserve(nxlong);
+        if (rc == PC_OK) rc = sf->xlong_runs.reserve(nxlong);
+        if (rc == PC_OK && n_wide) rc = sf->xlong_wide.reserve(nxlong);
+        if (rc == PC_OK) rc = d_xlong_pmax.reserve(nxlong);
+        if (rc == PC_OK) rc = d_key.reserve(std::max(nlong, nxlong));
+        if (rc == PC_OK) rc = d_key_scanned.reserve(std::max(nlong, nxlong));
+        if (rc == PC_OK) rc = sf->long_tid_bounds.reserve((size_t)ntid + 1);
+        if (rc == PC_OK) rc = sf->gap_tid_bounds.reserve((size_t)ntid + 1);
+        if (rc == PC_OK) rc = d_xlong_bounds.reserve((size_t)ntid + 1);
+        hipError_t he = hipSuccess;
+        if (rc == PC_OK) {
+            size_t need = 0;
+            he = hipcub::DeviceScan::InclusiveScan(nullptr, need, d_key.p, d_key_scanned.p, hipcub::Max(), (int)std::max(nlong, nxlong), st);
+            if (he == hipSuccess && d_tmp.reserve(std::max<size_t>(need, 16)) != PC_OK) he = hipErrorOutOfMemory;
+        }
+        auto grid_of = [](size_t m) { return dim3((unsigned)((m + kWG - 1) / kWG)); };
+        auto running_max = [&](size_t m, int32_t *pmax) {   // d_key -> pmax
+            size_t tb = d_tmp.cap;
+            if (he == hipSuccess) he = hipcub::DeviceScan::InclusiveScan(d_tmp.p, tb, d_key.p, d_key_scanned.p, hipcub::Max(), (int)m, st);
+            if (he == hipSuccess) hipLaunchKernelGGL(k_unpack_pmax, grid_of(m), dim3(kWG), 0, st, d_key_scanned.p, (int64_t)m, pmax);
+        };
+        if (rc == PC_OK && he == hipSuccess) {
+            if (nlong) {
+                hipLaunchKernelGGL(k_side_fill, grid_of(nlong), dim3(kWG), 0, st, sf->long_idx.p, (int64_t)nlong, sf->rec.p, sf->blk_off.p, sf->blk.p,
+                                   sf->tid_bounds.p, ntid, sf->wide_rec.p, sf->wide_val.p, n_wide, sf->long_rec.p, sf->long_runs.p, sf->long_tid.p,
+                                   d_key.p, n_wide ? sf->long_wide.p : nullptr);
+                running_max(nlong, sf->long_pmax.p);
+            }
+            if (ngap)
+                hipLaunchKernelGGL(k_side_fill, grid_of(ngap), dim3(kWG), 0, st, d_gap_idx.p, (int64_t)ngap, sf->rec.p, sf->blk_off.p, sf->blk.p,
+                                   sf->tid_bounds.p, ntid, sf->wide_rec.p, sf->wide_val.p, n_wide, sf->gap_rec.p, sf->gap_runs.p, (int32_t *)nullptr,
+                                   (unsigned long long *)nullptr, (uint2 *)nullptr);
+            if (nxlong) {
+                hipLaunchKernelGGL(k_side_fill, grid_of(nxlong), dim3(kWG), 0, st, d_xlong_idx.p, (int64_t)nxlong, sf->rec.p, sf->blk_off.p, sf->blk.p,
+                                   sf->tid_bounds.p, ntid, sf->wide_rec.p, sf->wide_val.p, n_wide, sf->xlong_rec.p, sf->xlong_runs.p, (int32_t *)nullptr,
+                                   d_key.p, n_wide ? sf->xlong_wide.p : nullptr);
+                running_max(nxlong, d_xlong_pmax.p);
+            }
+            const dim3 gt((unsigned)((ntid + 1 + kWG - 1) / kWG));
+            hipLaunchKernelGGL(k_list_bounds, gt, dim3(kWG), 0, st, sf->long_idx.p, (int64_t)nlong, sf->tid_bounds.p, ntid, sf->long_tid_bounds.p);
+            hipLaunchKernelGGL(k_list_bounds, gt, dim3(kWG), 0, st, d_gap_idx.p, (int64_t)ngap, sf->tid_bounds.p, ntid, sf->gap_tid_bounds.p);
+            hipLaunchKernelGGL(k_list_bounds, gt, dim3(kWG), 0, st, d_xlong_idx.p, (int64_t)nxlong, sf->tid_bounds.p, ntid, d_xlong_bounds.p);
+        }
+        // the linear-index tables: one bisection per table entry
+        if (rc == PC_OK) rc = sf->lin_tab.reserve(nlin);
+        if (rc == PC_OK) rc = sf->glin_tab.reserve(nlin);
+        if (rc == PC_OK) rc = sf->llin_tab.reserve(nlin);
+        if (rc == PC_OK) rc = sf->plin_tab.reserve(nlin);
+        if (rc == PC_OK && nxlong) rc = sf->xllin_tab.reserve(nlin);
+        if (rc == PC_OK && nxlong) rc = sf->xplin_tab.reserve(nlin);
+        if (rc == PC_OK && he == hipSuccess && nlin) {
+            const dim3 gl = grid_of(nlin);
+            hipLaunchKernelGGL((k_lin_table<0>), gl, dim3(kWG), 0, st, (const void *)sf->rec.p, sf->tid_bounds.p, sf->lin_off.p, ntid, (int64_t)nlin, sf->lin_tab.p);
+            hipLaunchKernelGGL((k_lin_table<1>), gl, dim3(kWG), 0, st, (const void *)sf->gap_rec.p, sf->gap_tid_bounds.p, sf->lin_off.p, ntid, (int64_t)nlin, sf->glin_tab.p);
+            hipLaunchKernelGGL((k_lin_table<1>), gl, dim3(kWG), 0, st, (const void *)sf->long_rec.p, sf->long_tid_bounds.p, sf->lin_off.p, ntid, (int64_t)nlin, sf->llin_tab.p);
+            hipLaunchKernelGGL((k_lin_table<2>), gl, dim3(kWG), 0, st, (const void *)sf->long_pmax.p, sf->long_tid_bounds.p, sf->lin_off.p, ntid, (int64_t)nlin, sf->plin_tab.p);
+            if (nxlong) {
+                hipLaunchKernelGGL((k_lin_table<1>), gl, dim3(kWG), 0, st, (const void *)sf->xlong_rec.p, d_xlong_bounds.p, sf->lin_off.p, ntid, (int64_t)nlin, sf->xllin_tab.p);
+                hipLaunchKernelGGL((k_lin_table<2>), gl, dim3(kWG), 0, st, (const void *)d_xlong_pmax.p, d_xlong_bounds.p, sf->lin_off.p, ntid, (int64_t)nlin, sf->xplin_tab.p);
+            }
+        }
+        if (rc == PC_OK && he == hipSuccess) he = hipGetLastError();
+        if (rc == PC_OK && he == hipSuccess) he = hipStreamSynchronize(st);   // the temporaries go out of scope
+        if (rc == PC_OK && he != hipSuccess) rc = fail(PC_ERR_HIP, "stage: building the side lists failed: %s", hipGetErrorString(he));
+    }
+    clk.lap("side lists + linear index (GPU)");
     // ---- run stream: sorted by (contig, run start) on the GPU (radix sort of the 64-bit keys, the 8-byte
     // records and their record indices permuted along), then its linear index by one bisection per bucket
     if (rc == PC_OK && nrunrec) {
