@@ -316,7 +316,7 @@ def run_workload(name, args, ctx, headline):
     # host side of the read-back: page-locked (what a caller that reads repeatedly would hand over), touched once
     # (above 1 GiB -- the sparse configurations -- ordinary pageable memory)
     out_pin = torch.zeros(int(lp["out_elems"]), dtype=torch.int64 if out_dtype == np.int64 else torch.float64,
-                          pin_memory=int(lp["out_elems"]) * 8 <= (1 << 30))
+                          pin_memory=int(lp["out_elems"]) * 8 <= (16 << 30))
     out_buf = out_pin.numpy()
 
     def gate(expected, what):

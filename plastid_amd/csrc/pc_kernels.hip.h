@@ -2059,26 +2059,48 @@ __global__ __launch_bounds__(kWG) void k_run_lin(const unsigned long long *__res
     rlin[g] = (uint32_t)lo;
 }
 
-// staging: the 4-byte stream word of every record, and (for the following prefix sum) the number of runs a
-// multi-run record keeps in blk -- both functions of the uploaded 8-byte record
-__global__ __launch_bounds__(kWG) void k_stream_from_rec(const uint2 *__restrict__ rec, int64_t n, uint32_t *stream, uint32_t *nruns,
-                                                         const uint32_t *__restrict__ wide_rec, const uint2 *__restrict__ wide_val, int64_t nwide) {
+// staging: the number of runs a multi-run record keeps in blk (for the prefix sum that gives every record its
+// first run) -- a function of the uploaded 8-byte record
+__global__ __launch_bounds__(kWG) void k_run_counts(const uint2 *__restrict__ rec, int64_t n, uint32_t *nruns,
+                                                    const uint32_t *__restrict__ wide_rec, const uint2 *__restrict__ wide_val, int64_t nwide) {
     const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (i >= n) return;
     const uint2 r = rec[i];
-    stream[i] = stream_word(r.x, r.y);
-    if (nruns) {
-        uint32_t nb = r.y >> 24;
-        if ((r.y >> 16) & kFlagWide) {   // a wide record: its true run count is in the side table
-            int64_t lo = 0, hi = nwide;
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) >> 1;
-                if ((int64_t)wide_rec[mid] < i) lo = mid + 1; else hi = mid;
-            }
-            nb = wide_val[lo].y;
+    uint32_t nb = r.y >> 24;
+    if ((r.y >> 16) & kFlagWide) {   // a wide record: its true run count is in the side table
+        int64_t lo = 0, hi = nwide;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)wide_rec[mid] < i) lo = mid + 1; else hi = mid;
         }
-        nruns[i] = nb >= 2u ? nb : 0u;
+        nb = wide_val[lo].y;
     }
+    nruns[i] = nb >= 2u ? nb : 0u;
+}
+
+// staging: the class of every record that depends on the statistics of the whole file -- kFlagLong when its span
+// (pos .. end of the last aligned run) is beyond the window halo `wcap`, always for a wide record -- written into the
+// header, and the 4-byte stream word that follows from the header
+__global__ __launch_bounds__(kWG) void k_classify(uint2 *rec, int64_t n, const uint32_t *__restrict__ blk_off, const int2 *__restrict__ blk,
+                                                  int wcap, uint32_t *stream) {
+    const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= n) return;
+    uint2 r = rec[i];
+    const uint32_t L = r.y & 0xffffu, fl = (r.y >> 16) & 0xffu, nb = r.y >> 24;
+    bool far = (fl & kFlagWide) != 0u;
+    if (!far) {
+        int64_t span = L > 0u ? (int64_t)L : 1;
+        if (nb >= 2u) {
+            const int2 last = blk[blk_off[i] + nb - 1u];
+            span = (int64_t)last.x + last.y - (int64_t)(int32_t)r.x;
+        }
+        far = span > (int64_t)wcap;
+    }
+    if (far) {
+        r.y |= kFlagLong << 16;
+        rec[i].y = r.y;
+    }
+    stream[i] = stream_word(r.x, r.y);
 }
 
 // ---------------------------------------------------------------- side lists, built on the GPU

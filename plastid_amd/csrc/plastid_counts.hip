@@ -180,6 +180,7 @@ template <typename T> struct HostBuf {
     }
     explicit HostBuf(size_t count) : p(grab(count)), n(count) {}
     ~HostBuf() { free(p); }
+    void release() { free(p); p = nullptr; n = 0; }
     HostBuf(const HostBuf &) = delete;
     HostBuf &operator=(const HostBuf &) = delete;
     T &operator[](size_t i) { return p[i]; }
@@ -739,7 +740,6 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         const int64_t *q = std::lower_bound(wide_idx, wide_idx + n_wide, i);
         return (q != wide_idx + n_wide && *q == i) ? (int64_t)(q - wide_idx) : -1;
     };
-    auto AL = [&](int64_t i) -> int64_t { const int64_t w = wide_at(i); return w >= 0 ? (int64_t)wide_alen[w] : (int64_t)alen[i]; };
     auto NB = [&](int64_t i) -> int64_t { const int64_t w = wide_at(i); return w >= 0 ? (int64_t)wide_nblk[w] : (int64_t)nblk[i]; };
     if (n < 0 || ntid <= 0 || nrun < 0) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad sizes");
     if (n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL array");
@@ -767,159 +767,38 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     }
 
     StageClock clk;
-    // ---- host pass: validation, per-tid bounds, spans, packed records.  Threaded over contiguous
-    // record chunks; every per-chunk result is merged in chunk order, and the error reported is the
-    // one of the lowest record index, so the outcome does not depend on the thread count.
+    // ---- ONE host pass over the caller's arrays: validation, statistics (per-contig bounds, span and length
+    // histograms) and the packed 8-byte records, slice by slice into two sets of reusable host buffers; a slice crosses
+    // PCIe (on a thread of its own) while the next one is packed, so the host never holds more than two slices.
+    // What depends on the statistics of the WHOLE file -- the window halo `wcap` (a span quantile) and with it the
+    // long-span class of a record and its stream word -- is derived on the GPU afterwards (k_classify).
+    // Every thread keeps its own running statistics; the error reported is the one of the lowest record index of the
+    // first slice that has one, so the outcome does not depend on the thread count.
     const int T = stage_threads(n);
     struct ChunkErr { int64_t idx = INT64_MAX; int code = PC_OK; char msg[200] = {0}; };
-    struct Chunk1 {
+    struct Acc {
         ChunkErr err;
-        std::vector<int64_t> tid_count, span_hist, len_hist, tid_end;
-        int64_t runs = 0, cursor = 0;
+        std::vector<int64_t> tid_count, span_hist, gap_span_hist, wide_span_hist, len_hist, len1_hist, tid_end;
+        int Wr = 1, rmin = 65536, rmax = -1;
+        int64_t max_span = 1;
     };
-    std::vector<Chunk1> c1((size_t)T);
+    std::vector<Acc> acc((size_t)T);
+    for (auto &a : acc) {
+        a.tid_count.assign((size_t)ntid + 1, 0);
+        a.span_hist.assign(1026, 0);      // spans 0..1024, [1025] = larger
+        a.gap_span_hist.assign(1026, 0);  // ... of the records longer than the stream carries (gapped-record list unless long-span)
+        a.wide_span_hist.assign(1026, 0); // ... of the wide records (long-span whatever their span)
+        a.len_hist.assign(65536, 0);
+        a.len1_hist.assign(256, 0);       // aligned lengths of the single-run records the 4-byte stream can carry
+        a.tid_end.assign((size_t)ntid, 0);
+    }
     std::vector<int64_t> tid_bounds((size_t)ntid + 1, 0);
-    // runs owned by each chunk (records with >= 2 runs keep theirs in blk_*), so that a chunk knows
-    // where its first run sits
-    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
-        int64_t r = 0;
-        for (int64_t i = b; i < en; ++i) r += nblk[i] >= 2 ? NB(i) >= 2 ? NB(i) : 0 : 0;
-        c1[(size_t)t].runs = r;
-    });
-    {
-        int64_t cur = 0;
-        for (auto &c : c1) { c.cursor = cur; cur += c.runs; }
-        if (cur != nrun)
-            return fail(PC_ERR_ARG, cur > nrun ? "run arrays shorter than sum of nblk" : "run arrays longer than sum of nblk (%lld vs %lld)",
-                        (long long)cur, (long long)nrun);
-    }
-    // pass A keeps nothing per record: it validates and gathers the statistics that decide the halo
-    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
-        Chunk1 &c = c1[(size_t)t];
-        c.tid_count.assign((size_t)ntid + 1, 0);
-        c.span_hist.assign(1026, 0); // spans 0..1024, [1025] = larger
-        c.len_hist.assign(65536, 0);
-        c.tid_end.assign((size_t)ntid, 0);
-        int64_t run_cursor = c.cursor;
-        auto bad = [&](int64_t i, int code, const char *fmt, long long a1, long long a2) {
-            c.err.idx = i; c.err.code = code;
-            snprintf(c.err.msg, sizeof(c.err.msg), fmt, a1, a2);
-        };
-        for (int64_t i = b; i < en; ++i) {
-            if (i + 8 <= en) {   // eight plain records of one contig, in order: nothing to report, fewer branches
-                const int32_t t0 = tid[i];
-                bool ok8 = t0 >= 0 && t0 < ntid && pos[i] >= 0 &&
-                           (i == 0 || tid[i - 1] < t0 || (tid[i - 1] == t0 && pos[i - 1] <= pos[i])) &&
-                           (int64_t)pos[i + 7] + 65535 <= 0x7fffffffLL;
-                int32_t prev = pos[i];
-                for (int k = 0; k < 8; ++k) {
-                    ok8 &= (tid[i + k] == t0) & (nblk[i + k] == 1) & (alen[i + k] > 0) & (pos[i + k] >= prev);
-                    prev = pos[i + k];
-                }
-                if (ok8) {
-                    int64_t emax = 0;
-                    for (int k = 0; k < 8; ++k) {
-                        const int L = alen[i + k];
-                        c.len_hist[(size_t)L] += 1;
-                        c.span_hist[(size_t)std::min(L, 1025)] += 1;
-                        emax = std::max(emax, (int64_t)pos[i + k] + L);
-                    }
-                    c.tid_count[(size_t)t0 + 1] += 8;
-                    c.tid_end[(size_t)t0] = std::max(c.tid_end[(size_t)t0], emax);
-                    i += 7;
-                    continue;
-                }
-            }
-            if (tid[i] < 0 || tid[i] >= ntid) { bad(i, PC_ERR_ARG, "record %lld: tid %lld out of range", i, tid[i]); return; }
-            if (pos[i] < 0) { bad(i, PC_ERR_ARG, "record %lld: negative position", i, 0); return; }
-            if (i > 0 && (tid[i] < tid[i - 1] || (tid[i] == tid[i - 1] && pos[i] < pos[i - 1]))) {
-                bad(i, PC_ERR_UNSORTED, "records are not sorted by (tid, pos) at record %lld; alignment files must be coordinate sorted", i, 0);
-                return;
-            }
-            c.tid_count[(size_t)tid[i] + 1] += 1;
-            const int64_t L = AL(i), nbi = NB(i);
-            int64_t end;
-            if (nbi >= 2) {
-                int64_t sum = 0, prev_end = -1;
-                for (int64_t k = 0; k < nbi; ++k) {
-                    const int64_t s0 = blk_start[run_cursor + k], ln = blk_len[run_cursor + k];
-                    if (ln <= 0 || (k > 0 && s0 <= prev_end)) {
-                        bad(i, PC_ERR_ARG, "record %lld: aligned runs must be non-empty, ascending and non-adjacent", i, 0);
-                        return;
-                    }
-                    if (k == 0 && s0 != pos[i]) { bad(i, PC_ERR_ARG, "record %lld: first run must start at pos", i, 0); return; }
-                    sum += ln;
-                    prev_end = s0 + ln;
-                }
-                if (sum != L) { bad(i, PC_ERR_ARG, "record %lld: run lengths do not sum to alen", i, 0); return; }
-                end = prev_end;
-                run_cursor += nbi;
-            } else {
-                if ((nbi == 0) != (L == 0)) { bad(i, PC_ERR_ARG, "record %lld: nblk/alen mismatch", i, 0); return; }
-                end = (int64_t)pos[i] + (L > 0 ? L : 1);
-            }
-            if (end > 0x7fffffffLL) { bad(i, PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", i, 0); return; }
-            const int64_t sp = end - pos[i];
-            c.tid_end[(size_t)tid[i]] = std::max(c.tid_end[(size_t)tid[i]], end);
-            c.span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
-            c.len_hist[(size_t)std::min<int64_t>(L, 65535)] += 1;
-        }
-    });
-    std::vector<int64_t> span_hist(1026, 0), len_hist(65536, 0), tid_end((size_t)ntid, 0);
-    {
-        const ChunkErr *first = nullptr;
-        for (const auto &c : c1)
-            if (c.err.code != PC_OK && (!first || c.err.idx < first->idx)) first = &c.err;
-        if (first) return fail(first->code, "%s", first->msg);
-        for (const auto &c : c1) {
-            if (c.tid_count.empty()) continue;
-            for (int t = 0; t <= ntid; ++t) tid_bounds[(size_t)t] += c.tid_count[(size_t)t];
-            for (int t = 0; t < ntid; ++t) tid_end[(size_t)t] = std::max(tid_end[(size_t)t], c.tid_end[(size_t)t]);
-            for (size_t k = 0; k < span_hist.size(); ++k) span_hist[k] += c.span_hist[k];
-            for (size_t k = 0; k < len_hist.size(); ++k) len_hist[k] += c.len_hist[k];
-        }
-    }
-    clk.lap("validate + statistics");
-    for (int t = 0; t < ntid; ++t) tid_bounds[(size_t)t + 1] += tid_bounds[(size_t)t];
 
-    // ---- choose the window halo W: the smallest span bound (>= 64, <= 1024) that covers
-    // >= 99.5% of the records; longer (spliced) reads go through the long-read path.
-    int wcap = 64;
-    {
-        int64_t cum = 0;
-        const int64_t need = n - n / 200;
-        int s0 = 0;
-        for (; s0 <= 1024; ++s0) {
-            cum += span_hist[(size_t)s0];
-            if (cum >= need) break;
-        }
-        wcap = std::max(64, std::min(s0, 1024));
-    }
-    StagedFile *sf = new StagedFile();
-    sf->n = n;
-    sf->nrun = nrun;
-    sf->len_hist.swap(len_hist);
-    for (int L = 0; L < 65536; ++L)
-        if (sf->len_hist[(size_t)L]) { sf->len_min = std::min(sf->len_min, L); sf->len_max = std::max(sf->len_max, L); }
-    {   // the kCTab consecutive aligned lengths (<= 255) that hold the most records: the center kernel's fast table
-        int64_t win = 0, best = -1;
-        for (int L = 1; L <= 255; ++L) {
-            win += sf->len_hist[(size_t)L];
-            if (L - kCTab >= 1) win -= sf->len_hist[(size_t)(L - kCTab)];
-            if (win > best) { best = win; sf->c_lbase = std::max(1, L - kCTab + 1); }
-        }
-    }
-
-    // ---- pass B: packed records (8 B), record stream (4 B), run offsets and the side lists, produced
-    // slice by slice into two sets of reusable host buffers; a slice crosses PCIe (on a thread of
-    // its own) while the next one is packed, so the host never holds more than two slices and there
-    // is no per-record scratch to fault in or to give back.
     int64_t S = (int64_t)8 << 20;
     if (const char *env = getenv("PC_STAGE_SLICE")) S = std::max<int64_t>(1, atoll(env)); // test knob: tiny slices
     const int64_t nslices = (n + S - 1) / S;
     struct Unit { // one thread's share of one slice
-        int W = 1, Wg = 1, Wr = 1, smin = 65536, smax = -1, rmin = 65536, rmax = -1;
-        int64_t max_span = 1, cursor = 0;
+        int64_t cursor = 0;                        // where this unit's first run sits in blk_*
         int64_t run_at = 0;                        // where this unit's run-stream records go
     };
     std::vector<Unit> units((size_t)(nslices * T));
@@ -929,7 +808,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         b = std::min(s1, s0 + (int64_t)t * q);
         en = std::min(s1, b + q);
     };
-    if (nrun > 0) { // where every unit's first run sits
+    {   // runs owned by each unit (records with >= 2 runs keep theirs in blk_*), so that a unit knows where its first run sits
         parallel_chunks(nslices * T, T, [&](int, int64_t ub, int64_t ue) {
             for (int64_t u = ub; u < ue; ++u) {
                 int64_t b, en, r = 0, rs = 0;
@@ -954,8 +833,14 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
             const int64_t q = u.run_at; u.run_at = rcur; rcur += q;
         }
         nrunrec_total = rcur;
+        if (cur != nrun)
+            return fail(PC_ERR_ARG, cur > nrun ? "run arrays shorter than sum of nblk" : "run arrays longer than sum of nblk (%lld vs %lld)",
+                        (long long)cur, (long long)nrun);
     }
-    if (nrunrec_total >= (int64_t)0x7fffffff) { delete sf; return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 aligned runs of multi-run reads per file are not supported"); }
+    if (nrunrec_total >= (int64_t)0x7fffffff) return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 aligned runs of multi-run reads per file are not supported");
+    StagedFile *sf = new StagedFile();
+    sf->n = n;
+    sf->nrun = nrun;
     HostBuf<uint2> run_val((size_t)nrunrec_total);      // {run start, len | cum << 8 | L << 16 | flags << 24}, record order
     HostBuf<uint32_t> run_idx((size_t)nrunrec_total);   // record of every run
     if (!run_val.p || !run_idx.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
@@ -982,6 +867,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     const int device = e->device;
     hipStream_t up_stream = e->stream;
     clk.lap("run layout + allocations");
+    const ChunkErr *first_err = nullptr;
     for (int64_t sl = 0; sl < nslices && rc == PC_OK; ++sl) {
         SliceBuf &sb = bufs[sl & 1];
         if (sb.up.valid()) rc = sb.up.get();               // the slice that used these buffers has gone up
@@ -989,89 +875,121 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         const int64_t s0 = sl * S, s1 = std::min(n, s0 + S);
         parallel_chunks((int64_t)T, T, [&](int, int64_t tb, int64_t te) {
             for (int64_t t = tb; t < te; ++t) {
-                Unit c = units[(size_t)(sl * T + t)];   // a local copy, written back below: neighbouring units share cache lines
+                Acc &a = acc[(size_t)t];
                 int64_t b, en;
                 unit_range(sl, (int)t, b, en);
-                int64_t cursor = c.cursor, run_at = c.run_at;
-                // Eight records at a time when all eight are plain (one aligned run, ordinary length, span within the
-                // halo): then span = L, nothing goes to a side list or the run stream, and the loop has no branches.
-                const int plain_max = std::min(wcap, kStreamMaxLen);
-                int pl_min = 65536, pl_max = 0;
+                int64_t cursor = units[(size_t)(sl * T + t)].cursor, run_at = units[(size_t)(sl * T + t)].run_at;
+                int Wr = a.Wr, rmin = a.rmin, rmax = a.rmax;   // (scalars in locals: neighbouring accumulators share cache lines)
+                int64_t max_span = a.max_span;
+                auto bad = [&](int64_t i, int code, const char *fmt, long long a1, long long a2) {
+                    a.err.idx = i; a.err.code = code;
+                    snprintf(a.err.msg, sizeof(a.err.msg), fmt, a1, a2);
+                };
                 for (int64_t i = b; i < en; ++i) {
+                    // Eight records at a time when all eight are plain (one contig, in order, one aligned run of a length
+                    // the stream carries): nothing to report, nothing for a side list or the run stream, no branches.
                     if (i + 8 <= en) {
-                        bool plain = true;
-                        int lo8 = 65536, hi8 = 0;
+                        const int32_t t0 = tid[i];
+                        bool ok8 = t0 >= 0 && t0 < ntid && pos[i] >= 0 &&
+                                   (i == 0 || tid[i - 1] < t0 || (tid[i - 1] == t0 && pos[i - 1] <= pos[i])) &&
+                                   (int64_t)pos[i + 7] + 65535 <= 0x7fffffffLL;
+                        int32_t prev = pos[i];
+                        int hi8 = 0;
                         for (int k = 0; k < 8; ++k) {
-                            const int Lk = alen[i + k];
-                            plain &= (nblk[i + k] == 1);
-                            lo8 = std::min(lo8, Lk); hi8 = std::max(hi8, Lk);
+                            ok8 &= (tid[i + k] == t0) & (nblk[i + k] == 1) & (alen[i + k] > 0) & (pos[i + k] >= prev);
+                            prev = pos[i + k];
+                            hi8 = std::max(hi8, (int)alen[i + k]);
                         }
-                        if (plain && lo8 > 0 && hi8 <= plain_max) {
+                        if (ok8 && hi8 <= kStreamMaxLen) {
+                            int64_t emax = 0;
                             const size_t j0 = (size_t)(i - s0);
-                            for (int k = 0; k < 8; ++k)
-                                sb.rec[j0 + k] = make_uint2((uint32_t)pos[i + k], (uint32_t)alen[i + k] | (1u << 24) |
+                            for (int k = 0; k < 8; ++k) {
+                                const int L = alen[i + k];
+                                a.len_hist[(size_t)L] += 1;
+                                a.len1_hist[(size_t)L] += 1;
+                                a.span_hist[(size_t)L] += 1;
+                                emax = std::max(emax, (int64_t)pos[i + k] + L);
+                                sb.rec[j0 + k] = make_uint2((uint32_t)pos[i + k], (uint32_t)L | (1u << 24) |
                                                             ((uint32_t)(flags[i + k] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16));
-                            pl_min = std::min(pl_min, lo8); pl_max = std::max(pl_max, hi8);
+                            }
+                            max_span = std::max<int64_t>(max_span, hi8);
+                            a.tid_count[(size_t)t0 + 1] += 8;
+                            a.tid_end[(size_t)t0] = std::max(a.tid_end[(size_t)t0], emax);
                             i += 7;
                             continue;
                         }
                     }
+                    if (tid[i] < 0 || tid[i] >= ntid) { bad(i, PC_ERR_ARG, "record %lld: tid %lld out of range", i, tid[i]); return; }
+                    if (pos[i] < 0) { bad(i, PC_ERR_ARG, "record %lld: negative position", i, 0); return; }
+                    if (i > 0 && (tid[i] < tid[i - 1] || (tid[i] == tid[i - 1] && pos[i] < pos[i - 1]))) {
+                        bad(i, PC_ERR_UNSORTED, "records are not sorted by (tid, pos) at record %lld; alignment files must be coordinate sorted", i, 0);
+                        return;
+                    }
                     const int64_t wi = wide_at(i);           // a record beyond the 16-bit / 8-bit fields: true values aside
-                    const int L = wi >= 0 ? wide_alen[wi] : (int)alen[i], nb = wi >= 0 ? wide_nblk[wi] : (int)nblk[i];
+                    const int64_t L = wi >= 0 ? (int64_t)wide_alen[wi] : (int64_t)alen[i], nb = wi >= 0 ? (int64_t)wide_nblk[wi] : (int64_t)nblk[i];
                     uint32_t boff = 0u;
                     int64_t end;
                     if (nb >= 2) {
+                        int64_t sum = 0, prev_end = -1;
+                        for (int64_t k = 0; k < nb; ++k) {
+                            const int64_t r0 = blk_start[cursor + k], ln = blk_len[cursor + k];
+                            if (ln <= 0 || (k > 0 && r0 <= prev_end)) {
+                                bad(i, PC_ERR_ARG, "record %lld: aligned runs must be non-empty, ascending and non-adjacent", i, 0);
+                                return;
+                            }
+                            if (k == 0 && r0 != pos[i]) { bad(i, PC_ERR_ARG, "record %lld: first run must start at pos", i, 0); return; }
+                            sum += ln;
+                            prev_end = r0 + ln;
+                        }
+                        if (sum != L) { bad(i, PC_ERR_ARG, "record %lld: run lengths do not sum to alen", i, 0); return; }
+                        end = prev_end;
                         boff = (uint32_t)cursor;
-                        end = (int64_t)blk_start[cursor + nb - 1] + blk_len[cursor + nb - 1];
-                        cursor += nb;
                     } else {
+                        if ((nb == 0) != (L == 0)) { bad(i, PC_ERR_ARG, "record %lld: nblk/alen mismatch", i, 0); return; }
                         end = (int64_t)pos[i] + (L > 0 ? L : 1);
                     }
-                    const int32_t sp = (int32_t)(end - pos[i]);
+                    if (end > 0x7fffffffLL) { bad(i, PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", i, 0); return; }
+                    const int64_t sp = end - pos[i];
+                    a.tid_count[(size_t)tid[i] + 1] += 1;
+                    a.tid_end[(size_t)tid[i]] = std::max(a.tid_end[(size_t)tid[i]], end);
+                    a.span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
+                    a.len_hist[(size_t)std::min<int64_t>(L, 65535)] += 1;
+                    max_span = std::max(max_span, sp);
                     uint32_t meta = (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) | ((uint32_t)nb << 24);
                     if (wi >= 0) meta = 0xffffu | ((uint32_t)((flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) | kFlagWide) << 16) | (0xffu << 24);
-                    c.max_span = std::max<int64_t>(c.max_span, sp);
                     // multi-run reads of ordinary length: every aligned run goes to the run stream (what the
                     // point rules scan); only longer reads keep to the gapped / long-span side lists there
                     const bool in_runs = nb >= 2 && L <= kStreamMaxLen && wi < 0;
                     if (in_runs) {
                         meta |= (kFlagRuns << 16);
-                        c.rmin = std::min(c.rmin, L); c.rmax = std::max(c.rmax, L);   // run-stream records index the same LDS entry table
+                        rmin = std::min(rmin, (int)L); rmax = std::max(rmax, (int)L);   // run-stream records index the same LDS entry table
                         uint32_t cum = 0;
-                        for (int k = 0; k < nb; ++k) {
+                        for (int64_t k = 0; k < nb; ++k) {
                             const uint32_t rs = (uint32_t)blk_start[boff + k], rl = (uint32_t)blk_len[boff + k];
                             run_val[(size_t)run_at] = make_uint2(rs, rl | (cum << 8) | ((uint32_t)L << 16) |
                                                                          ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 24));
                             run_idx[(size_t)run_at] = (uint32_t)i;
                             ++run_at;
-                            c.Wr = std::max(c.Wr, (int)rl);
+                            Wr = std::max(Wr, (int)rl);
                             cum += rl;
                         }
-                    }
-                    // the class of the record goes into its header; the side lists themselves are compacted from the
-                    // headers on the GPU (SelectLong / SelectXLong / SelectGap in pc_kernels.hip.h)
-                    if (sp > wcap || wi >= 0) {   // (wide records always take the long-span lists: those carry their true length / run count)
-                        meta |= (kFlagLong << 16);
+                    } else if (wi >= 0) {
+                        a.wide_span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
                     } else {
-                        c.W = std::max(c.W, (int)sp);
-                        if ((nb >= 2 || L > kStreamMaxLen) && !in_runs) c.Wg = std::max(c.Wg, (int)sp); // binned from the gapped-record list, not from a stream
+                        if (L > kStreamMaxLen) a.gap_span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;   // the gapped-record list, unless the span is beyond the halo
+                        else if (nb < 2) a.len1_hist[(size_t)L] += 1;                                      // carried by the stream, unless ...
                     }
-                    const uint32_t wd = stream_word((uint32_t)pos[i], meta & ~((uint32_t)kFlagExcluded << 16));
-                    if (!(wd & kStreamSkip)) { // carried by the stream (host-side exclusion may change later)
-                        const int Ls = (int)stream_len(wd);
-                        c.smin = std::min(c.smin, Ls); c.smax = std::max(c.smax, Ls);
-                    }
-                    const size_t j = (size_t)(i - s0);
-                    sb.rec[j] = make_uint2((uint32_t)pos[i], meta);
+                    if (nb >= 2) cursor += nb;
+                    // (whether the span is beyond the window halo -- the long-span class -- is written into the header on
+                    // the GPU, once the halo is known: k_classify)
+                    sb.rec[(size_t)(i - s0)] = make_uint2((uint32_t)pos[i], meta);
                 }
-                if (pl_max > 0) {   // what the plain blocks contribute to the unit's statistics
-                    c.max_span = std::max<int64_t>(c.max_span, pl_max);
-                    c.W = std::max(c.W, pl_max);
-                    c.smin = std::min(c.smin, pl_min); c.smax = std::max(c.smax, pl_max);
-                }
-                units[(size_t)(sl * T + t)] = c;
+                a.Wr = Wr; a.rmin = rmin; a.rmax = rmax; a.max_span = max_span;
             }
         });
+        for (const auto &a : acc)
+            if (a.err.code != PC_OK && (!first_err || a.err.idx < first_err->idx)) first_err = &a.err;
+        if (first_err) break;
         uint2 *d_rec = sf->rec.p + s0;
         const uint2 *h_rec = sb.rec;
         const size_t cnt = (size_t)(s1 - s0);
@@ -1083,7 +1001,69 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     }
     for (auto &sb : bufs)
         if (sb.up.valid()) { const int r = sb.up.get(); if (rc == PC_OK) rc = r; }
+    if (first_err) { delete sf; return fail(first_err->code, "%s", first_err->msg); }
     if (rc != PC_OK) { delete sf; return fail(rc, "pc_add_alignment_file: staging a slice failed"); }
+
+    // ---- statistics of the whole file
+    std::vector<int64_t> span_hist(1026, 0), gap_span_hist(1026, 0), wide_span_hist(1026, 0), len_hist(65536, 0), len1_hist(256, 0), tid_end((size_t)ntid, 0);
+    int Wr = 1, rmin = 65536, rmax = -1;
+    int64_t max_span = 1;
+    for (const auto &a : acc) {
+        for (int t = 0; t <= ntid; ++t) tid_bounds[(size_t)t] += a.tid_count[(size_t)t];
+        for (int t = 0; t < ntid; ++t) tid_end[(size_t)t] = std::max(tid_end[(size_t)t], a.tid_end[(size_t)t]);
+        for (size_t k = 0; k < span_hist.size(); ++k) { span_hist[k] += a.span_hist[k]; gap_span_hist[k] += a.gap_span_hist[k]; wide_span_hist[k] += a.wide_span_hist[k]; }
+        for (size_t k = 0; k < len_hist.size(); ++k) len_hist[k] += a.len_hist[k];
+        for (size_t k = 0; k < len1_hist.size(); ++k) len1_hist[k] += a.len1_hist[k];
+        Wr = std::max(Wr, a.Wr); rmin = std::min(rmin, a.rmin); rmax = std::max(rmax, a.rmax);
+        max_span = std::max(max_span, a.max_span);
+    }
+    acc.clear();
+    acc.shrink_to_fit();
+    for (int t = 0; t < ntid; ++t) tid_bounds[(size_t)t + 1] += tid_bounds[(size_t)t];
+    // the window halo W: the smallest span bound (>= 64, <= 1024) that covers >= 99.5% of the records; longer
+    // (spliced) reads go through the long-read path
+    int wcap = 64;
+    {
+        int64_t cum = 0;
+        const int64_t need = n - n / 200;
+        int s0 = 0;
+        for (; s0 <= 1024; ++s0) {
+            cum += span_hist[(size_t)s0];
+            if (cum >= need) break;
+        }
+        wcap = std::max(64, std::min(s0, 1024));
+    }
+    int W = 1, Wg = 1;   // the longest span inside the halo: of any record, of a record of the gapped-record list
+    for (int s0 = 1; s0 <= wcap; ++s0) {
+        if (span_hist[(size_t)s0] > wide_span_hist[(size_t)s0]) W = s0;
+        if (gap_span_hist[(size_t)s0]) Wg = s0;
+    }
+    {   // aligned lengths the 4-byte stream carries (single-run records inside the halo), and those of the run stream
+        int smin = 65536, smax = -1;
+        for (int L = 0; L <= std::min(wcap, kStreamMaxLen); ++L)
+            if (len1_hist[(size_t)L]) { smin = std::min(smin, L); smax = std::max(smax, L); }
+        const int tmin = std::min(smin, rmin), tmax = std::max(smax, rmax);
+        sf->slen_min = smax >= smin ? smin : 0;
+        sf->slen_max = smax >= smin ? smax : 0;
+        sf->tlen_min = tmax >= tmin ? tmin : 0;
+        sf->tlen_max = tmax >= tmin ? tmax : 0;
+    }
+    sf->W = W;
+    sf->Wg = Wg;
+    sf->Wr = Wr;
+    sf->max_span = max_span;
+    sf->len_hist.swap(len_hist);
+    for (int L = 0; L < 65536; ++L)
+        if (sf->len_hist[(size_t)L]) { sf->len_min = std::min(sf->len_min, L); sf->len_max = std::max(sf->len_max, L); }
+    {   // the kCTab consecutive aligned lengths (<= 255) that hold the most records: the center kernel's fast table
+        int64_t win = 0, best = -1;
+        for (int L = 1; L <= 255; ++L) {
+            win += sf->len_hist[(size_t)L];
+            if (L - kCTab >= 1) win -= sf->len_hist[(size_t)(L - kCTab)];
+            if (win > best) { best = win; sf->c_lbase = std::max(1, L - kCTab + 1); }
+        }
+    }
+
     {   // sentinels behind the last record: two excluded headers, eight skip words (whole quads can always be loaded)
         const uint2 tail_rec[2] = {make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16), make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16)};
         uint32_t tail_stream[8];
@@ -1095,7 +1075,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
             return fail(PC_ERR_HIP, "pc_add_alignment_file: staging the sentinels failed");
         }
     }
-    if (n_wide > 0) {   // the wide records by record index: what k_stream_from_rec and the per-record kernels look up
+    if (n_wide > 0) {   // the wide records by record index: what the per-record kernels look up
         std::vector<uint32_t> wr((size_t)n_wide);
         std::vector<uint2> wv((size_t)n_wide);
         for (int64_t k = 0; k < n_wide; ++k) { wr[(size_t)k] = (uint32_t)wide_idx[k]; wv[(size_t)k] = make_uint2((uint32_t)wide_alen[k], (uint32_t)wide_nblk[k]); }
@@ -1105,12 +1085,18 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         if (rc != PC_OK) { delete sf; return rc; }
         sf->nwide = n_wide;
     }
-    if (n > 0) {   // the 4-byte stream, and the run offsets (exclusive sum of the run counts of the multi-run records)
+    // the aligned runs as {start, length} pairs (they went up while the records were packed)
+    if (nrun > 0) { const int r = runs_up.f.get(); if (r != PC_OK) { delete sf; return fail(r, "stage: uploading the aligned runs failed"); } }
+    if (nrun > 0) {
+        rc = sf->blk.reserve((size_t)nrun);
+        if (rc != PC_OK) { delete sf; return rc; }
+        hipLaunchKernelGGL(k_zip_runs, dim3((unsigned)((nrun + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, d_bs.p, d_bl.p, nrun, sf->blk.p);
+    }
+    if (n > 0) {   // run offsets (exclusive sum of the run counts of the multi-run records), then the class and the 4-byte stream word of every record
         const unsigned grid = (unsigned)((n + kWG - 1) / kWG);
-        hipLaunchKernelGGL(k_stream_from_rec, dim3(grid), dim3(kWG), 0, e->stream, sf->rec.p, n, sf->stream.p,
-                           nrun > 0 ? sf->blk_off.p : nullptr, sf->wide_rec.p, sf->wide_val.p, n_wide);
-        hipError_t he = hipGetLastError();
-        if (he == hipSuccess && nrun > 0) {
+        hipError_t he = hipSuccess;
+        if (nrun > 0) {
+            hipLaunchKernelGGL(k_run_counts, dim3(grid), dim3(kWG), 0, e->stream, sf->rec.p, n, sf->blk_off.p, sf->wide_rec.p, sf->wide_val.p, n_wide);
             size_t tmp_bytes = 0;
             DevBuf<uint8_t> d_tmp;
             he = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, sf->blk_off.p, sf->blk_off.p, (int)n, e->stream);
@@ -1118,37 +1104,18 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
             if (he == hipSuccess) he = hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, sf->blk_off.p, sf->blk_off.p, (int)n, e->stream);
             if (he == hipSuccess) he = hipStreamSynchronize(e->stream);   // d_tmp goes out of scope
         }
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kWG), 0, e->stream, sf->rec.p, n, nrun > 0 ? sf->blk_off.p : nullptr, sf->blk.p, wcap, sf->stream.p);
+            he = hipGetLastError();
+            if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        }
         if (he != hipSuccess) { delete sf; return fail(PC_ERR_HIP, "pc_add_alignment_file: deriving the record stream failed: %s", hipGetErrorString(he)); }
     }
-    clk.lap("pack + upload (pipelined)");
-    // ---- statistics of the pack pass
-    int W = 1;
-    int64_t max_span = 1;
-    int Wg = 1, Wr = 1;
-    {
-        int smin = 65536, smax = -1, tmin = 65536, tmax = -1;
-        for (size_t u = 0; u < units.size(); ++u) {
-            const Unit &c = units[u];
-            W = std::max(W, c.W);
-            Wg = std::max(Wg, c.Wg);
-            Wr = std::max(Wr, c.Wr);
-            max_span = std::max(max_span, c.max_span);
-            smin = std::min(smin, c.smin); smax = std::max(smax, c.smax);
-            tmin = std::min(tmin, std::min(c.smin, c.rmin)); tmax = std::max(tmax, std::max(c.smax, c.rmax));
-        }
-        sf->slen_min = smax >= smin ? smin : 0;
-        sf->slen_max = smax >= smin ? smax : 0;
-        sf->tlen_min = tmax >= tmin ? tmin : 0;
-        sf->tlen_max = tmax >= tmin ? tmax : 0;
-    }
-    sf->W = W;
-    sf->Wg = Wg;
-    sf->Wr = Wr;
-    sf->max_span = max_span;
+    d_bs.release();
+    d_bl.release();
+    clk.lap("validate + pack + upload (pipelined)");
     const size_t nrunrec = (size_t)nrunrec_total;
     sf->nrunrec = (int64_t)nrunrec;
-    units.clear();
-    units.shrink_to_fit();
 
     // ---- linear-index layout: one table entry per 2^kLinShift-position bucket of each contig, up to the last
     // record start -- and up to the furthest end of a read of the contig (tid_end): a long-span read reaches
@@ -1168,16 +1135,6 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     hipStream_t st = e->stream;
     rc = sf->tid_bounds.upload(tid_bounds, st);
     if (rc == PC_OK) rc = sf->lin_off.upload(lin_off, st);
-    if (nrun > 0) { const int r = runs_up.f.get(); if (rc == PC_OK && r != PC_OK) rc = fail(r, "stage: uploading the aligned runs failed"); }
-    if (rc == PC_OK && nrun > 0) {
-        rc = sf->blk.reserve((size_t)nrun);
-        if (rc == PC_OK) {
-            hipLaunchKernelGGL(k_zip_runs, dim3((unsigned)((nrun + kWG - 1) / kWG)), dim3(kWG), 0, st, d_bs.p, d_bl.p, nrun, sf->blk.p);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: staging the aligned runs failed");
-            d_bs.release();
-            d_bl.release();
-        }
-    }
     size_t nlong = 0, ngap = 0, nxlong = 0;
     DevBuf<uint32_t> d_gap_idx, d_xlong_idx, d_nsel;
     if (rc == PC_OK && n > 0) {
@@ -1350,7 +1307,13 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         delete sf;
         return rc;
     }
-    clk.lap("upload of the side tables");
+    clk.lap("run stream (GPU sort)");
+    {   // giving a gigabyte of run records back to the system takes tens of milliseconds: not on the caller's time
+        void *p0 = run_val.p, *p1 = run_idx.p;
+        run_val.p = nullptr; run_idx.p = nullptr;
+        if (nrunrec_total > (int64_t)1 << 22) std::thread([p0, p1]() { free(p0); free(p1); }).detach();
+        else { free(p0); free(p1); }
+    }
     e->files.push_back(sf);
     e->ntid = ntid;
     e->files_dirty = true;
