@@ -189,6 +189,28 @@ def cpu_baseline_all_cores(oracle, aln, spec, p, tx, n_records, budget_s, rng, o
                       "(preparation + threaded counting time / sampled fraction)" % (nch, tx.n, cores, wall, prep)}
 
 
+def warm_runtime(ctx):
+    """Once per process, before anything is timed: a throwaway engine stages 100 k spliced records and counts them, so
+    that the HIP runtime's one-time costs (code-object load of every kernel, the page-locked bounce buffers of pageable
+    copies, hipcub's first temporary allocations) are not billed to the first config's `host_stage_s` / staged scope --
+    the warm-up steps of the timed loop do the same for the kernel scope.  Reported as `config.runtime_warmup_s`."""
+    Engine, rehearsal = engine_class()
+    if ctx.get("runtime_warmup_s") is not None or rehearsal:
+        return
+    t0 = time.perf_counter()
+    _g, tx, reads, mapping = synth.make_config("C4", scale=0.0002, tx_scale=0.002)
+    factory = synth.mapping_factory(mapping)
+    p = tx.plan_arrays(rows=1)
+    eng = Engine(ctx["dev_index"])
+    eng.set_alignments([reads])
+    factory._configure(eng)
+    plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    plan.count(np.int64)
+    plan.close()
+    eng.close()
+    ctx["runtime_warmup_s"] = round(time.perf_counter() - t0, 3)
+
+
 def first_count(eng, plan, out_dtype):
     """The first count of a plan also builds the plan's work lists (k_tile_ranges: which records every window scans --
     a function of the annotation, the staged alignments and the rule's halo, not of the counts); later counts of the
@@ -303,6 +325,7 @@ def run_workload(name, args, ctx, headline):
 
     # ---------------------------------------------------------------- GPU
     import torch
+    warm_runtime(ctx)
     eng = Engine(ctx["dev_index"])
     t0 = time.perf_counter()
     eng.set_alignments([my_reads])
@@ -458,7 +481,10 @@ def run_workload(name, args, ctx, headline):
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "frac_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_ms > 0) else None,
-                     "algorithmic_bytes_per_launch": int(kern_alg_bytes), "avg_launch_ms": kern_ms},
+                     "algorithmic_bytes_per_launch": int(kern_alg_bytes), "avg_launch_ms": kern_ms,
+                     "basis": "achieved / frac: ALGORITHMIC bytes of SURVEY 8(d) (8 B per record of the whole file + runs + "
+                              "segments + outputs) over the kernel's time -- not the bytes moved: the kernel streams 4 B per "
+                              "record, so this can exceed the measured stream rate; frac_traffic is the PMC-measured figure"},
         "cpu_baseline": cpu,
         "two_files": two_files,
     }
@@ -529,6 +555,7 @@ def run_partitioned(name, args, ctx, headline):
 
     # ---------------------------------------------------------------- GPU
     import torch
+    warm_runtime(ctx)
     eng = Engine(ctx["dev_index"])
     t0 = time.perf_counter()
     eng.set_alignments([my_reads])
@@ -876,6 +903,7 @@ def main():
             config["rehearsal"] = head["rehearsal"]
         if others:
             config["other_configs"] = others
+        config["runtime_warmup_s"] = ctx.get("runtime_warmup_s")   # see warm_runtime()
         config["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
         result = {
             "metric": "mapped_reads_per_sec",

@@ -15,7 +15,7 @@ eng = Engine(0)
 eng.set_alignments([reads])
 factory._configure(eng)
 plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
-dt = np.int64
+dt = np.float64 if mapping[0] == "center" else np.int64
 for _ in range(3):
     plan.launch(dt)
 eng.sync()
