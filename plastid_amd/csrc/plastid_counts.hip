@@ -841,10 +841,18 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     StagedFile *sf = new StagedFile();
     sf->n = n;
     sf->nrun = nrun;
-    HostBuf<uint2> run_val((size_t)nrunrec_total);      // {run start, len | cum << 8 | L << 16 | flags << 24}, record order
-    HostBuf<uint32_t> run_idx((size_t)nrunrec_total);   // record of every run
-    if (!run_val.p || !run_idx.p) { delete sf; return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory"); }
+    // run-stream records {run start, len | cum << 8 | L << 16 | flags << 24} and the record of every run, in record order:
+    // the units of a slice own one contiguous stretch of them, so they travel with the slice (no file-sized host array)
+    DevBuf<uint2> d_val_in;
+    DevBuf<uint32_t> d_idx_in;
+    size_t slice_runs = 1;
+    for (int64_t sl = 0; sl < nslices; ++sl) {
+        const int64_t r0 = units[(size_t)(sl * T)].run_at, r1 = sl + 1 < nslices ? units[(size_t)((sl + 1) * T)].run_at : nrunrec_total;
+        slice_runs = std::max(slice_runs, (size_t)(r1 - r0));
+    }
     int rc = sf->rec.reserve((size_t)n + 2);
+    if (rc == PC_OK && nrunrec_total > 0) rc = d_val_in.reserve((size_t)nrunrec_total);
+    if (rc == PC_OK && nrunrec_total > 0) rc = d_idx_in.reserve((size_t)nrunrec_total);
     if (rc == PC_OK) rc = sf->stream.reserve((size_t)n + 8);
     if (rc == PC_OK && nrun > 0) rc = sf->blk_off.reserve((size_t)n);
     if (rc != PC_OK) { delete sf; return rc; }
@@ -853,14 +861,15 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     // (Page-locked slices were measured and bought nothing: on the 16 CPUs a GPU box grants, packing a slice
     // takes as long as its pageable upload, 31-37 ms per 100 M records either way.)
     struct SliceBuf {
-        HostBuf<uint2> own;
+        HostBuf<uint2> own, run_val;
+        HostBuf<uint32_t> run_idx;
         uint2 *rec = nullptr;
         std::future<int> up;
-        explicit SliceBuf(size_t cap) : own(cap) { rec = own.p; }
+        SliceBuf(size_t cap, size_t runs) : own(cap), run_val(runs), run_idx(runs) { rec = own.p; }
     };
     const size_t slice_cap = (size_t)std::min<int64_t>(S, std::max<int64_t>(n, 1));
-    SliceBuf bufs[2] = {SliceBuf(slice_cap), SliceBuf(nslices > 1 ? slice_cap : 1)};
-    if (!bufs[0].rec || !bufs[1].rec) {
+    SliceBuf bufs[2] = {SliceBuf(slice_cap, slice_runs), SliceBuf(nslices > 1 ? slice_cap : 1, nslices > 1 ? slice_runs : 1)};
+    if (!bufs[0].rec || !bufs[1].rec || !bufs[0].run_val.p || !bufs[1].run_val.p || !bufs[0].run_idx.p || !bufs[1].run_idx.p) {
         delete sf;
         return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
     }
@@ -873,6 +882,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         if (sb.up.valid()) rc = sb.up.get();               // the slice that used these buffers has gone up
         if (rc != PC_OK) break;
         const int64_t s0 = sl * S, s1 = std::min(n, s0 + S);
+        const int64_t run0 = units[(size_t)(sl * T)].run_at, run1 = sl + 1 < nslices ? units[(size_t)((sl + 1) * T)].run_at : nrunrec_total;
         parallel_chunks((int64_t)T, T, [&](int, int64_t tb, int64_t te) {
             for (int64_t t = tb; t < te; ++t) {
                 Acc &a = acc[(size_t)t];
@@ -966,9 +976,9 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
                         uint32_t cum = 0;
                         for (int64_t k = 0; k < nb; ++k) {
                             const uint32_t rs = (uint32_t)blk_start[boff + k], rl = (uint32_t)blk_len[boff + k];
-                            run_val[(size_t)run_at] = make_uint2(rs, rl | (cum << 8) | ((uint32_t)L << 16) |
-                                                                         ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 24));
-                            run_idx[(size_t)run_at] = (uint32_t)i;
+                            sb.run_val[(size_t)(run_at - run0)] = make_uint2(rs, rl | (cum << 8) | ((uint32_t)L << 16) |
+                                                                                     ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 24));
+                            sb.run_idx[(size_t)(run_at - run0)] = (uint32_t)i;
                             ++run_at;
                             Wr = std::max(Wr, (int)rl);
                             cum += rl;
@@ -992,10 +1002,17 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         if (first_err) break;
         uint2 *d_rec = sf->rec.p + s0;
         const uint2 *h_rec = sb.rec;
-        const size_t cnt = (size_t)(s1 - s0);
+        const size_t cnt = (size_t)(s1 - s0), nruns_sl = (size_t)(run1 - run0);
+        uint2 *d_rv = d_val_in.p + run0;
+        uint32_t *d_ri = d_idx_in.p + run0;
+        const uint2 *h_rv = sb.run_val.p;
+        const uint32_t *h_ri = sb.run_idx.p;
         sb.up = std::async(std::launch::async, [=]() -> int {
             if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
             if (hipMemcpyAsync(d_rec, h_rec, cnt * sizeof(uint2), hipMemcpyHostToDevice, up_stream) != hipSuccess) return PC_ERR_HIP;
+            if (nruns_sl && (hipMemcpyAsync(d_rv, h_rv, nruns_sl * sizeof(uint2), hipMemcpyHostToDevice, up_stream) != hipSuccess ||
+                             hipMemcpyAsync(d_ri, h_ri, nruns_sl * sizeof(uint32_t), hipMemcpyHostToDevice, up_stream) != hipSuccess))
+                return PC_ERR_HIP;
             return hipStreamSynchronize(up_stream) == hipSuccess ? PC_OK : PC_ERR_HIP;
         });
     }
@@ -1265,13 +1282,10 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     // records and their record indices permuted along), then its linear index by one bisection per bucket
     if (rc == PC_OK && nrunrec) {
         DevBuf<unsigned long long> d_key, d_key_sorted;
-        DevBuf<uint32_t> d_ord, d_ord_sorted, d_idx_in;
-        DevBuf<uint2> d_val_in;
+        DevBuf<uint32_t> d_ord, d_ord_sorted;
         DevBuf<uint8_t> d_tmp;
         rc = d_key.reserve(nrunrec);
         if (rc == PC_OK) rc = d_ord.reserve(nrunrec);
-        if (rc == PC_OK) rc = d_val_in.upload(run_val.p, nrunrec, e->stream);
-        if (rc == PC_OK) rc = d_idx_in.upload(run_idx.p, nrunrec, e->stream);
         if (rc == PC_OK) rc = d_key_sorted.reserve(nrunrec);
         if (rc == PC_OK) rc = d_ord_sorted.reserve(nrunrec);
         if (rc == PC_OK) rc = sf->run_rec.reserve(nrunrec + 1);
@@ -1308,12 +1322,6 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         return rc;
     }
     clk.lap("run stream (GPU sort)");
-    {   // giving a gigabyte of run records back to the system takes tens of milliseconds: not on the caller's time
-        void *p0 = run_val.p, *p1 = run_idx.p;
-        run_val.p = nullptr; run_idx.p = nullptr;
-        if (nrunrec_total > (int64_t)1 << 22) std::thread([p0, p1]() { free(p0); free(p1); }).detach();
-        else { free(p0); free(p1); }
-    }
     e->files.push_back(sf);
     e->ntid = ntid;
     e->files_dirty = true;
