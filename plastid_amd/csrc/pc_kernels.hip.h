@@ -737,6 +737,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         uint32_t ih = s_base[0] + off_h, il = s_base[1] + off_l;
         if (merge) {
             atomicAdd(&tile_items[t], n_light); // > 0 marks the tile for k_gather_split
+            atomicAdd(&nwork[4], 1u);           // windows merged through the compact histogram (none: k_gather_split has nothing to do)
             for (int ff = 0; ff < nfiles; ++ff) {
                 FileRange r;
                 file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
@@ -801,6 +802,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     uint32_t ih = s_base[0] + off_h, il = s_base[1] + off_l;
     if (merge) {
         atomicAdd(&tile_items[t], n_light); // > 0 marks the tile for k_gather_split
+        atomicAdd(&nwork[4], 1u);
         for (uint32_t k = 0; k < n_light; ++k) {
             w.lo = wlo + (int64_t)k * R;
             w.hi = (w.lo + R < whi) ? w.lo + R : whi;

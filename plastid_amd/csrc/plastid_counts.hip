@@ -472,11 +472,12 @@ struct pc_plan {
     bool counted = false;
     // queued work items per class as the last count of this plan left them (a large plan launches exactly
     // that many workgroups next time instead of the whole list capacity)
-    uint32_t *h_work_counts = nullptr;   // page-locked [4]: heavy, light, small, -
+    uint32_t *h_work_counts = nullptr;   // page-locked [8]: heavy, light, small, (diagnostics), merged windows
     hipEvent_t ev_work_counts = nullptr;
     uint64_t work_counts_generation = 0; // engine work_generation the read-back belongs to (0: none in flight)
     bool work_counts_known = false;      // the read-back has arrived: work_counts holds it
     uint32_t work_counts[3] = {0, 0, 0};
+    uint32_t work_merged = 0;            // windows of the lists that are merged through the compact histogram (what k_gather_split lays out)
     bool exact_grid_used = false;        // some count of this plan launched exact grids: its results are read back with the guard word
     ~pc_plan() {
         if (ev_work_counts) (void)hipEventDestroy(ev_work_counts);
@@ -1872,7 +1873,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (!(p->work_valid && p->work_key == key) || e->knobs.debug_work) {
                 // the lists of this plan are (re)built: counters and per-tile item counts start from zero (they arrive
                 // zeroed with the plan's tables, so the first count of a plan needs no memset)
-                if (!p->wcounters_zero) HIP_TRY(hipMemsetAsync(p->d_wcounters.p, 0, 4 * sizeof(uint32_t), st));
+                if (!p->wcounters_zero) HIP_TRY(hipMemsetAsync(p->d_wcounters.p, 0, 8 * sizeof(uint32_t), st));
                 if (!p->tile_items_zero) HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
                 p->wcounters_zero = false;
                 p->tile_items_zero = false;
@@ -1916,6 +1917,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (track_counts && p->work_counts_generation == e->work_generation && p->h_work_counts && !p->work_counts_known &&
                 hipEventQuery(p->ev_work_counts) == hipSuccess) {
                 for (int k = 0; k < 3; ++k) p->work_counts[k] = p->h_work_counts[k];
+                p->work_merged = p->h_work_counts[4];
                 p->work_counts_known = true;   // deterministic for this plan while the generation stands: no further read-backs
             }
             if (track_counts && p->work_counts_known && p->work_counts_generation == e->work_generation) {
@@ -1986,18 +1988,22 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                        p->d_tiles.p, ntiles, split_per_wg, p->d_pieces.p,                                               \
                        p->d_opieces.p, p->d_tile_items.p, p->d_wcounters.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,   \
                        (OutT_<O>::type *)p->d_out.p, e->norm_sum, launched[0], launched[1], launched[2], e->d_counters.p + 12)
-            if (outmode == 0) PC_LAUNCH_SPLIT(0);
+            // (skipped once the plan's lists are known to hold no merged window: the lists are the plan's own and do not
+            // change from count to count, so neither does that -- and the exact grids it would check were read from them)
+            const bool nothing_to_merge = launched[0] != 0xffffffffu && p->work_merged == 0 && !e->knobs.test_stale_counts;
+            if (nothing_to_merge) {}
+            else if (outmode == 0) PC_LAUNCH_SPLIT(0);
             else if (outmode == 1) PC_LAUNCH_SPLIT(1);
             else PC_LAUNCH_SPLIT(2);
 #undef PC_LAUNCH_SPLIT
             if (track_counts) {   // how many items each class queued (k_gather_split keeps a copy): sizes the next launch
                 if (!p->h_work_counts) {
-                    HIP_TRY(hipHostMalloc((void **)&p->h_work_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
+                    HIP_TRY(hipHostMalloc((void **)&p->h_work_counts, 8 * sizeof(uint32_t), hipHostMallocDefault));
                     HIP_TRY(hipEventCreateWithFlags(&p->ev_work_counts, hipEventDisableTiming));
                 }
                 if (p->work_counts_generation != e->work_generation) {   // one read-back per (plan, generation)
                     p->work_counts_known = false;
-                    HIP_TRY(hipMemcpyAsync(p->h_work_counts, p->d_wcounters.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipMemcpyAsync(p->h_work_counts, p->d_wcounters.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipEventRecord(p->ev_work_counts, st));
                     p->work_counts_generation = e->work_generation;
                 }
