@@ -187,6 +187,36 @@ template <typename T> struct HostBuf {
     const T &operator[](size_t i) const { return p[i]; }
 };
 
+// First index in [0, n) for which `before(idx)` is false (before() is monotone: true ... true false ... false),
+// searched outward from `hint`: consecutive queries of a plan (the exons of a chain) land next to each other, and a
+// bisection over a few hundred thousand entries costs ~18 cache misses where the gallop costs two or three.
+template <typename F> static size_t gallop_lower_bound(size_t n, size_t hint, F before) {
+    if (n == 0) return 0;
+    if (hint >= n) hint = n - 1;
+    size_t lo, hi;   // the answer lies in [lo, hi]: before(lo - 1) holds (or lo == 0), before(hi) does not (or hi == n)
+    if (before(hint)) {
+        size_t step = 1;
+        lo = hint + 1;
+        hi = lo;
+        while (hi < n && before(hi)) { lo = hi + 1; hi += step; step <<= 1; }
+        if (hi > n) hi = n;
+    } else {
+        size_t step = 1;
+        lo = hi = hint;
+        while (lo > 0) {
+            const size_t probe = lo > step ? lo - step : 0;
+            if (before(probe)) { lo = probe + 1; break; }
+            lo = hi = probe;
+            step <<= 1;
+        }
+    }
+    while (lo < hi) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (before(mid)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 // fn(thread index, begin, end) over [0, n) cut into `nthreads` contiguous chunks
 template <typename F> static void parallel_chunks(int64_t n, int nthreads, F fn) {
     if (nthreads <= 1 || n <= 0) { fn(0, (int64_t)0, n); return; }
@@ -1560,18 +1590,19 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     pclk.lap("plan: islands");
     // ---- every segment -> its island (binary search)
     parallel_chunks(nseg, PT, [&](int, int64_t sb, int64_t se) {
+    size_t hint = 0;   // (the exons of a chain follow each other in the caller's arrays: the search starts where the last one ended)
     for (int64_t s = sb; s < se; ++s) {
         GatherSeg &g = p->gsegs[(size_t)s];
         if (g.clip_hi <= g.clip_lo) continue;
         const int64_t cs = start[s] + g.clip_lo;
         const int m = mode_of(strand[s]);
-        size_t lo = 0, hi = islands.size();
-        while (lo < hi) { // last island with (tid,mode,s) <= (tid,m,cs)
-            size_t mid = (lo + hi) / 2;
-            const Island &is = islands[mid];
-            bool le = is.tid < tid[s] || (is.tid == tid[s] && (is.mode < m || (is.mode == m && is.s <= cs)));
-            if (le) lo = mid + 1; else hi = mid;
-        }
+        const int32_t ts = tid[s];
+        // first island after the last one with (tid, mode, s) <= (tid, m, cs)
+        const size_t lo = gallop_lower_bound(islands.size(), hint, [&](size_t k) {
+            const Island &is = islands[k];
+            return is.tid < ts || (is.tid == ts && (is.mode < m || (is.mode == m && is.s <= cs)));
+        });
+        hint = lo;
         const Island &is = islands[lo - 1];
         g.hist_off = is.off + (cs - is.s);
     }
@@ -1581,49 +1612,113 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     // ---- pieces: islands cut at the fixed genome grid of G positions; tiles: grid windows
     struct RawPiece { int32_t tid; int64_t win; Piece pc_; };
     std::vector<RawPiece> raw;
-    for (const Island &is : islands) {
-        for (int64_t a = is.s; a < is.e;) {
-            const int64_t win = (a / G) * G;
-            const int64_t b = std::min<int64_t>(is.e, win + G);
-            Piece pc_;
-            pc_.hist_off = is.off + (a - is.s); pc_.start = (int32_t)a; pc_.len = (int32_t)(b - a); pc_.mode = is.mode; pc_.pad = 0;
-            raw.push_back({is.tid, win, pc_});
-            a = b;
-        }
-    }
-    by_contig(raw, [](const RawPiece &a) { return a.tid; }, [](const RawPiece &a, const RawPiece &b) {
-        if (a.tid != b.tid) return a.tid < b.tid;
-        if (a.win != b.win) return a.win < b.win;
-        if (a.pc_.mode != b.pc_.mode) return a.pc_.mode < b.pc_.mode;
-        return a.pc_.start < b.pc_.start;
-    });
     // The tables only the center rule and the coordinate export read -- the 64-position chunks, the per-segment gather
     // list -- are built (and uploaded) when first needed for a large annotation: a point-rule plan of 479 k exons
     // otherwise pays for 1.4 M chunk descriptors it never uses.  Small plans keep everything in their one upload.
     p->lazy_center = nseg >= (1 << 16);
-    p->pieces.reserve(raw.size());
-    if (!p->lazy_center) p->cchunks.reserve((size_t)(npos / kWave) + raw.size());
-    int max_slots = 1;
-    for (size_t i = 0; i < raw.size(); ++i) {
-        if (p->tiles.empty() || p->tiles.back().tid != raw[i].tid || p->tiles.back().win_start != (int32_t)raw[i].win) {
-            Tile t;
-            t.tid = raw[i].tid; t.win_start = (int32_t)raw[i].win; t.piece_begin = (uint32_t)i; t.piece_end = (uint32_t)i; t.mode_mask = 0;
-            t.op_begin = t.op_end = 0;
-            t.span_lo = 0xffff; t.span_hi = 0;
-            p->tiles.push_back(t);
+    auto cut_island = [G](const Island &is, RawPiece *dst) {   // the island's pieces, in order; returns their number
+        size_t k = 0;
+        for (int64_t a = is.s; a < is.e;) {
+            const int64_t win = (a / G) * G;
+            const int64_t b = std::min<int64_t>(is.e, win + G);
+            if (dst) {
+                Piece pc_;
+                pc_.hist_off = is.off + (a - is.s); pc_.start = (int32_t)a; pc_.len = (int32_t)(b - a); pc_.mode = is.mode; pc_.pad = 0;
+                dst[k] = {is.tid, win, pc_};
+            }
+            ++k;
+            a = b;
         }
-        Tile &t = p->tiles.back();
-        t.piece_end = (uint32_t)i + 1;
-        t.mode_mask |= 1u << raw[i].pc_.mode;
-        t.span_lo = std::min<uint16_t>(t.span_lo, (uint16_t)(raw[i].pc_.start - t.win_start));
-        t.span_hi = std::max<uint16_t>(t.span_hi, (uint16_t)(raw[i].pc_.start - t.win_start + raw[i].pc_.len));
-        p->pieces.push_back(raw[i].pc_);
-        // 64-position chunks for the ordered center replay (one wave each)
-        for (int32_t a = 0; !p->lazy_center && a < raw[i].pc_.len; a += kWave) {
-            CenterChunk c;
-            c.hist_off = raw[i].pc_.hist_off + a; c.tid = raw[i].tid; c.start = raw[i].pc_.start + a;
-            c.len = std::min<int32_t>(kWave, raw[i].pc_.len - a); c.mode = raw[i].pc_.mode;
-            p->cchunks.push_back(c);
+        return k;
+    };
+    {   // islands -> pieces: counted, placed by prefix sum, filled by all threads
+        std::vector<size_t> at(islands.size() + 1, 0);
+        parallel_chunks((int64_t)islands.size(), PT, [&](int, int64_t ib, int64_t ie) {
+            for (int64_t i = ib; i < ie; ++i) {
+                const Island &is = islands[(size_t)i];
+                at[(size_t)i + 1] = is.e > is.s ? (size_t)((is.e - 1) / G - is.s / G + 1) : 0;
+            }
+        });
+        for (size_t i = 0; i < islands.size(); ++i) at[i + 1] += at[i];
+        raw.resize(at.back());
+        parallel_chunks((int64_t)islands.size(), PT, [&](int, int64_t ib, int64_t ie) {
+            for (int64_t i = ib; i < ie; ++i) cut_island(islands[(size_t)i], raw.data() + at[(size_t)i]);
+        });
+        // sorted by (contig, window, mode, start).  The islands are in contig order, so the pieces of a contig are
+        // already one stretch of `raw`: every stretch is sorted in place on its own thread, heaviest contigs first
+        auto less = [](const RawPiece &a, const RawPiece &b) {
+            if (a.win != b.win) return a.win < b.win;
+            if (a.pc_.mode != b.pc_.mode) return a.pc_.mode < b.pc_.mode;
+            return a.pc_.start < b.pc_.start;
+        };
+        std::vector<std::pair<size_t, size_t>> stretch;   // [begin, end) of every contig that has pieces
+        for (size_t i = 0; i < islands.size();) {
+            size_t j = i + 1;
+            while (j < islands.size() && islands[j].tid == islands[i].tid) ++j;
+            if (at[j] > at[i]) stretch.push_back({at[i], at[j]});
+            i = j;
+        }
+        std::sort(stretch.begin(), stretch.end(), [](const std::pair<size_t, size_t> &a, const std::pair<size_t, size_t> &b) {
+            return a.second - a.first > b.second - b.first;
+        });
+        parallel_chunks((int64_t)PT, PT, [&](int th, int64_t, int64_t) {
+            for (size_t k = (size_t)th; k < stretch.size(); k += (size_t)PT)
+                std::sort(raw.begin() + (std::ptrdiff_t)stretch[k].first, raw.begin() + (std::ptrdiff_t)stretch[k].second, less);
+        });
+    }
+    int max_slots = 1;
+    auto new_tile = [&](size_t i) { return i == 0 || raw[i - 1].tid != raw[i].tid || raw[i - 1].win != raw[i].win; };
+    auto fill_tile = [&](Tile &t, size_t i0, size_t i1) {   // the tile of the sorted pieces [i0, i1)
+        t.tid = raw[i0].tid; t.win_start = (int32_t)raw[i0].win; t.piece_begin = (uint32_t)i0; t.piece_end = (uint32_t)i1;
+        t.mode_mask = 0; t.op_begin = t.op_end = 0; t.span_lo = 0xffff; t.span_hi = 0;
+        for (size_t i = i0; i < i1; ++i) {
+            t.mode_mask |= 1u << raw[i].pc_.mode;
+            t.span_lo = std::min<uint16_t>(t.span_lo, (uint16_t)(raw[i].pc_.start - t.win_start));
+            t.span_hi = std::max<uint16_t>(t.span_hi, (uint16_t)(raw[i].pc_.start - t.win_start + raw[i].pc_.len));
+        }
+    };
+    if (p->lazy_center && PT > 1) {
+        // large plans: every thread takes a stretch of the sorted pieces and owns the tiles that START in it
+        p->pieces.resize(raw.size());
+        std::vector<size_t> tcount((size_t)PT + 1, 0);
+        parallel_chunks((int64_t)raw.size(), PT, [&](int th, int64_t ib, int64_t ie) {
+            size_t n = 0;
+            for (int64_t i = ib; i < ie; ++i) {
+                p->pieces[(size_t)i] = raw[(size_t)i].pc_;
+                n += new_tile((size_t)i) ? 1 : 0;
+            }
+            tcount[(size_t)th + 1] = n;
+        });
+        for (int th = 0; th < PT; ++th) tcount[(size_t)th + 1] += tcount[(size_t)th];
+        p->tiles.resize(tcount[(size_t)PT]);
+        parallel_chunks((int64_t)raw.size(), PT, [&](int th, int64_t ib, int64_t ie) {
+            size_t k = tcount[(size_t)th];
+            for (int64_t i = ib; i < ie; ++i) {
+                if (!new_tile((size_t)i)) continue;
+                size_t j = (size_t)i + 1;
+                while (j < raw.size() && !new_tile(j)) ++j;   // (a tile may end in the next thread's stretch)
+                fill_tile(p->tiles[k++], (size_t)i, j);
+            }
+        });
+    } else {
+        p->pieces.reserve(raw.size());
+        if (!p->lazy_center) p->cchunks.reserve((size_t)(npos / kWave) + raw.size());
+        for (size_t i = 0; i < raw.size();) {
+            size_t j = i + 1;
+            while (j < raw.size() && !new_tile(j)) ++j;
+            Tile t;
+            fill_tile(t, i, j);
+            p->tiles.push_back(t);
+            for (; i < j; ++i) {
+                p->pieces.push_back(raw[i].pc_);
+                // 64-position chunks for the ordered center replay (one wave each)
+                for (int32_t a = 0; !p->lazy_center && a < raw[i].pc_.len; a += kWave) {
+                    CenterChunk c;
+                    c.hist_off = raw[i].pc_.hist_off + a; c.tid = raw[i].tid; c.start = raw[i].pc_.start + a;
+                    c.len = std::min<int32_t>(kWave, raw[i].pc_.len - a); c.mode = raw[i].pc_.mode;
+                    p->cchunks.push_back(c);
+                }
+            }
         }
     }
     for (const Tile &t : p->tiles) max_slots = std::max(max_slots, __builtin_popcount(t.mode_mask));
@@ -1637,22 +1732,29 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         std::vector<uint8_t> part_zero((size_t)PT, 0);
         parallel_chunks(nseg, PT, [&](int th, int64_t sb, int64_t se) {
             std::vector<RawOut> &mine = part[(size_t)th];
+            mine.reserve((size_t)(se - sb) + (size_t)(se - sb) / 2);
+            size_t seg_hint = 0;   // tile of the previous segment's last window: the next exon of the chain is close by
             for (int64_t s = sb; s < se; ++s) {
                 const GatherSeg &g = p->gsegs[(size_t)s];
                 if (g.len > 0 && (g.hist_off < 0 || g.clip_lo > 0 || g.clip_hi < g.len)) part_zero[(size_t)th] = 1;
                 if (g.hist_off < 0 || g.clip_hi <= g.clip_lo) continue;
                 const int m = mode_of(strand[s]);
                 const int64_t cs = start[s] + g.clip_lo, ce = start[s] + g.clip_hi;
+                size_t prev = (size_t)-1;   // tile of the segment's previous window: the next window's tile follows it
                 for (int64_t a = cs; a < ce;) {
                     const int64_t win = (a / G) * G;
                     const int64_t b = std::min<int64_t>(ce, win + G);
                     // tile of (tid, win)
-                    size_t lo = 0, hi = p->tiles.size();
-                    while (lo < hi) {
-                        size_t mid = (lo + hi) / 2;
-                        const Tile &t = p->tiles[mid];
-                        if (t.tid < tid[s] || (t.tid == tid[s] && (int64_t)t.win_start < win)) lo = mid + 1; else hi = mid;
+                    size_t lo = prev + 1;
+                    if (prev == (size_t)-1 || lo >= p->tiles.size() || p->tiles[lo].tid != tid[s] || (int64_t)p->tiles[lo].win_start != win) {
+                        const int32_t ts = tid[s];
+                        lo = gallop_lower_bound(p->tiles.size(), seg_hint, [&](size_t k) {
+                            const Tile &t = p->tiles[k];
+                            return t.tid < ts || (t.tid == ts && (int64_t)t.win_start < win);
+                        });
                     }
+                    prev = lo;
+                    seg_hint = lo;
                     OutPiece o;
                     o.out_off = g.out_off + (int64_t)g.step * (a - start[s]);
                     o.row_stride = g.row_stride;
