@@ -225,10 +225,11 @@ def first_count(eng, plan, out_dtype):
 
 
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) of the kernel sources: what a PMC-derived traffic figure belongs to."""
+    """sha256 (first 16 hex digits) of the device code (every kernel lives in pc_kernels.hip.h): what a PMC-derived
+    traffic figure belongs to.  (The host file -- staging, plan build, launches -- is not part of it.)"""
     import hashlib
     h = hashlib.sha256()
-    for rel in ("plastid_amd/csrc/pc_kernels.hip.h", "plastid_amd/csrc/plastid_counts.hip"):
+    for rel in ("plastid_amd/csrc/pc_kernels.hip.h",):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -187,6 +187,18 @@ template <typename T> struct HostBuf {
     const T &operator[](size_t i) const { return p[i]; }
 };
 
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the plan's tables are sized
+// once and then filled by all threads, and a serial zero-fill of tens of megabytes (plus the page faults it takes on
+// one thread) cost more than the fill itself.
+template <typename T> struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <typename U> void construct(U *q) { ::new ((void *)q) U; }
+    template <typename U, typename... A> void construct(U *q, A &&...a) { ::new ((void *)q) U(std::forward<A>(a)...); }
+};
+template <typename T> using PodVec = std::vector<T, NoInitAlloc<T>>;
+
 // First index in [0, n) for which `before(idx)` is false (before() is monotone: true ... true false ... false),
 // searched outward from `hint`: consecutive queries of a plan (the exons of a chain) land next to each other, and a
 // bisection over a few hundred thousand entries costs ~18 cache misses where the gallop costs two or three.
@@ -432,9 +444,9 @@ struct pc_plan {
     uint32_t modes = 0;
     int max_slots = 1;
     int64_t npos = 0; // island positions (hist row length)
-    std::vector<Tile> tiles;
-    std::vector<Piece> pieces;
-    std::vector<OutPiece> opieces;
+    PodVec<Tile> tiles;
+    PodVec<Piece> pieces;
+    PodVec<OutPiece> opieces;
     bool has_sums = false;       // some slices are summed (out_step 0): the output is an accumulator
     bool out_needs_zero = false; // some queried positions lie outside every tile (unknown contig, clipped)
     bool hist_clean = false;     // compact histogram known to be all zero (point-rule invariant)
@@ -1611,7 +1623,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     pclk.lap("plan: segment->island");
     // ---- pieces: islands cut at the fixed genome grid of G positions; tiles: grid windows
     struct RawPiece { int32_t tid; int64_t win; Piece pc_; };
-    std::vector<RawPiece> raw;
+    PodVec<RawPiece> raw;
     // The tables only the center rule and the coordinate export read -- the 64-position chunks, the per-segment gather
     // list -- are built (and uploaded) when first needed for a large annotation: a point-rule plan of 479 k exons
     // otherwise pays for 1.4 M chunk descriptors it never uses.  Small plans keep everything in their one upload.
@@ -1772,7 +1784,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         const size_t ntl = p->tiles.size();
         std::vector<size_t> list_off(part.size() + 1, 0);
         for (size_t k = 0; k < part.size(); ++k) list_off[k + 1] = list_off[k] + part[k].size();
-        std::vector<uint32_t> tile_of(list_off.back());
+        PodVec<uint32_t> tile_of(list_off.back());
         parallel_chunks((int64_t)part.size(), PT, [&](int, int64_t kb, int64_t ke) {
             for (int64_t k = kb; k < ke; ++k)
                 for (size_t i = 0; i < part[(size_t)k].size(); ++i) tile_of[list_off[(size_t)k] + i] = part[(size_t)k][i].tile;
