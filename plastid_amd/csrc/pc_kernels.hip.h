@@ -1105,10 +1105,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     const WorkItem w = work[slot];
     // offset-table values this thread needs for the LDS tables (variable / stratified rules): they
     // depend on kernel arguments only and travel together with the work item
-    int pre_f = -1, pre_r = -1, lt_f = -1, lt_r = -1;
+    int pre_f = -1, pre_r = -1;
     if (KIND >= 3) {
         const int32_t PC_GLOBAL *fw = (const int32_t PC_GLOBAL *)mp.fw, *rc = (const int32_t PC_GLOBAL *)mp.rc;
-        if ((int)threadIdx.x < tab_n) { lt_f = fw[tab_lo + threadIdx.x]; lt_r = rc[tab_lo + threadIdx.x]; }
         const int Lp = fast_lo + (int)(threadIdx.x >> 2);
         if (Lp <= fast_hi && Lp < mp.table_len) { pre_f = fw[Lp]; pre_r = rc[Lp]; }
     }
@@ -1183,11 +1182,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
             }
         }
     }
-    if (KIND >= 3) {
+    // (the packed offset table serves the gapped-record and long-span lists only: the record stream and the run stream
+    // go through the entry table -- a window without such records, the common case, does not build it)
+    if (KIND >= 3 && (MULTI || w.ghi > w.glo || w.lhi > w.llo)) {
         const int32_t PC_GLOBAL *fw = (const int32_t PC_GLOBAL *)mp.fw, *rc = (const int32_t PC_GLOBAL *)mp.rc;
         for (int i = threadIdx.x; i < tab_n; i += WG) {
-            const bool first = i == (int)threadIdx.x;
-            const int f = first ? lt_f : fw[tab_lo + i], r = first ? lt_r : rc[tab_lo + i];
+            const int f = fw[tab_lo + i], r = rc[tab_lo + i];
             ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
     }
