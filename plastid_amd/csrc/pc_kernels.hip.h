@@ -11,7 +11,7 @@
 //               first two aligned runs; blk_off[i], blk[j] int2 {start,len}: all runs of nblk>=2 records
 //   lin_tab, glin_tab, llin_tab, plin_tab   linear index (first record at/after every 128-nt bucket)
 //   hist        compact coverage over the *union* of queried intervals per strand mode
-//               ("islands"): uint32 (merged windows of the point rules) or float64 (center)
+//               ("islands"): uint32, what merged windows of the point rules go through
 //   out         the caller-visible int64/float64 vectors (every chain 5'->3')
 //
 // Kernels (reference = plastid/genomics/map_factories.pyx unless noted)
@@ -21,8 +21,7 @@
 //   k_gather_split  lays out windows that were split into several work items
 //   k_cs_count / k_cs_scatter   center streams: the aligned runs of the reads a strand selection keeps, record order
 //   k_center_vals / k_center_weigh / k_center_order / k_center   CenterMapFactory, ordered float64 replay (:200-265)
-//   k_gather        SegmentChain.get_counts layout + normalisation for the center rule
-//                                                                         (roitools.pyx:3259-3271, genome_array.py:826-830)
+//                   + SegmentChain.get_counts layout + normalisation    (roitools.pyx:3259-3271, genome_array.py:826-830)
 //   k_rle_*         run-length encoding of an output vector (export, genome_array.py:990-1111)
 //   k_total_*       sum of an output vector (multi-GPU summary totals)
 //   k_mapped_reads  reads_out of the map functions for one segment
@@ -296,6 +295,7 @@ struct CenterChunk {
     int32_t start;
     int32_t len;
     int32_t mode;
+    uint32_t op_begin, op_end;   // output pieces of the chunk's window (Tile::op_begin / op_end): where its sums go
 };
 
 struct GatherSeg {
@@ -1756,8 +1756,8 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) void k_center(
     const CenterChunk *__restrict__ chunks, int64_t nchunks, const FileView *__restrict__ files, int nfiles, MapParams mp, int W,
     const double *__restrict__ inv_, const double *__restrict__ cval, const uint32_t *__restrict__ order,
-    const uint32_t *__restrict__ counters, const u32x4 *__restrict__ ranges, const u32x2 *__restrict__ rec_ranges, double *hist,
-    unsigned long long *dbg) {
+    const uint32_t *__restrict__ counters, const u32x4 *__restrict__ ranges, const u32x2 *__restrict__ rec_ranges,
+    const OutPiece *__restrict__ opieces, double *out, double norm_sum, int norm_on, unsigned long long *dbg) {
     const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
     // the list holds the heavy entries at its front and the light ones at its back; workgroup b serves the b-th
     // entry of the two runs (the grid is their exact number once a count of the plan has shown it, else 2 x chunks,
@@ -1901,41 +1901,25 @@ __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) voi
             step(q1, base + 64);
         }
     }
-    if (lane < ck.len) hist[ck.hist_off + lane] = acc;
+    // The sums go straight into the caller's layout (SegmentChain.get_counts, roitools.pyx:3259-3271: chain offset,
+    // 5'->3' reversal of '-' chains; reads-per-million as count / sum * 1e6 in that order, genome_array.py:826-827):
+    // every queried segment slice of the chunk's window that holds this lane's position gets the lane's sum -- no
+    // intermediate histogram, no gather pass (round 2 and most of round 3: 0.1 ms of C3's 1.5).
+    {
+        const double val = norm_on ? acc / norm_sum * 1e6 : acc;
+        for (uint32_t oi = ck.op_begin; oi < ck.op_end; ++oi) {
+            const OutPiece o = opieces[oi];
+            if (o.mode != ck.mode) continue;                  // the window's slices of other strand modes
+            const uint32_t rel = (uint32_t)(p - o.start);
+            if (lane < ck.len && rel < (uint32_t)o.len) out[o.out_off + (int64_t)o.step * (int64_t)rel] = val;
+        }
+    }
     if (dbg && lane == 0) {   // PC_CENTER_DEBUG
         dbg[2 * (size_t)slot] = wall_clock64() - t_begin; dbg[2 * (size_t)slot + 1] = t_begin;
         dbg[2 * (size_t)cap + slot] = n_slots;
     }
 }
 #pragma clang diagnostic pop
-
-// ---------------------------------------------------------------- k_gather
-// Lays the per-segment slices out the way SegmentChain.get_counts does: chain
-// offset, 5'->3' reversal for '-' chains, int64 or float64, optional
-// reads-per-million normalisation (count / sum * 1e6, in that order).
-template <typename HistT, typename OutT, bool NORM>
-__global__ __launch_bounds__(kWG) void k_gather(const GatherSeg *__restrict__ segs,
-                                                const GatherChunk *__restrict__ chunks,
-                                                const HistT *__restrict__ hist, int64_t hist_row_stride,
-                                                int rows, double norm_sum, OutT *out) {
-    const GatherChunk gc = chunks[blockIdx.x];
-    const GatherSeg sg = segs[gc.seg];
-    const int64_t base = (int64_t)gc.chunk * kGatherChunk;
-    const int64_t n = (sg.len - base < kGatherChunk) ? sg.len - base : kGatherChunk;
-    for (int r = 0; r < rows; ++r) {
-        const HistT *src = hist + (size_t)r * hist_row_stride + sg.hist_off - sg.clip_lo;
-        OutT *dst = out + sg.out_off + (int64_t)r * sg.row_stride;
-        for (int64_t i = threadIdx.x; i < n; i += kWG) {
-            const int64_t idx = base + i;
-            HistT v = 0;
-            if (sg.hist_off >= 0 && idx >= sg.clip_lo && idx < sg.clip_hi) v = src[idx];
-            OutT o;
-            if (NORM) o = (OutT)((double)v / norm_sum * 1e6);
-            else o = (OutT)v;
-            dst[(int64_t)sg.step * idx] = o;
-        }
-    }
-}
 
 // ---------------------------------------------------------------- k_coordinates
 // SegmentChain._get_position_hash / get_position_list (roitools.pyx:1450-1484, 2059-2080) for a whole

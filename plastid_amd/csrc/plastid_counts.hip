@@ -645,6 +645,7 @@ int ensure_center_tables(pc_engine *e, pc_plan *p) {
                     CenterChunk c;
                     c.hist_off = pc_.hist_off + a; c.tid = p->tiles[(size_t)t].tid; c.start = pc_.start + a;
                     c.len = std::min<int32_t>(kWave, pc_.len - a); c.mode = pc_.mode;
+                    c.op_begin = p->tiles[(size_t)t].op_begin; c.op_end = p->tiles[(size_t)t].op_end;
                     p->cchunks[k++] = c;
                 }
             }
@@ -702,18 +703,6 @@ int build_center_stream(pc_engine *e, StagedFile *sf, int sel) {
 }
 
 // ------------------------------------------------------------------ counting
-template <typename HistT, typename OutT>
-void launch_gather(pc_engine *e, pc_plan *p, const HistT *hist, OutT *outp) {
-    const unsigned grid = (unsigned)p->gchunks.size();
-    if (!grid) return;
-    if (e->norm_on)
-        hipLaunchKernelGGL((k_gather<HistT, OutT, true>), dim3(grid), dim3(kWG), 0, e->stream, p->d_gsegs.p, p->d_gchunks.p,
-                           hist, p->npos, p->rows, e->norm_sum, outp);
-    else
-        hipLaunchKernelGGL((k_gather<HistT, OutT, false>), dim3(grid), dim3(kWG), 0, e->stream, p->d_gsegs.p, p->d_gchunks.p,
-                           hist, p->npos, p->rows, e->norm_sum, outp);
-}
-
 
 } // namespace
 
@@ -1793,6 +1782,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
                     CenterChunk c;
                     c.hist_off = raw[i].pc_.hist_off + a; c.tid = raw[i].tid; c.start = raw[i].pc_.start + a;
                     c.len = std::min<int32_t>(kWave, raw[i].pc_.len - a); c.mode = raw[i].pc_.mode;
+                    c.op_begin = (uint32_t)(p->tiles.size() - 1); c.op_end = 0;   // the tile, until its output pieces are known (below)
                     p->cchunks.push_back(c);
                 }
             }
@@ -1888,6 +1878,11 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         });
     }
 
+    for (CenterChunk &c : p->cchunks) {   // (eager tables of a small plan) the chunk's output pieces = those of its tile
+        const Tile &t = p->tiles[c.op_begin];
+        c.op_begin = t.op_begin;
+        c.op_end = t.op_end;
+    }
     pclk.lap("plan: output pieces");
     // ---- gather work list (center rule)
     for (int64_t s = 0; !p->lazy_center && s < nseg; ++s) {
@@ -1990,10 +1985,11 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     rc = refresh_file_views(e);
     if (rc != PC_OK) return rc;
 
-    const size_t hist_elem = center ? sizeof(double) : sizeof(uint32_t);
-    const size_t hist_bytes = (size_t)p->npos * p->rows * hist_elem;
-    if (!p->d_hist.p) {
-        rc = p->d_hist_own.reserve(std::max<size_t>((size_t)p->npos * p->rows * sizeof(double), 8));
+    // the compact histogram (uint32 per island position and row): what merged windows of the point rules go through;
+    // the center rule does not use it
+    const size_t hist_bytes = center ? 0 : (size_t)p->npos * p->rows * sizeof(uint32_t);
+    if (!center && !p->d_hist.p) {
+        rc = p->d_hist_own.reserve(std::max<size_t>((size_t)p->npos * p->rows * sizeof(uint32_t), 8));
         p->d_hist.p = p->d_hist_own.p;
     }
     if (rc == PC_OK) rc = p->d_out.reserve(std::max<size_t>((size_t)p->out_elems * 8, 8));
@@ -2200,9 +2196,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
         }
     } else {
-        p->hist_kind = 1;
-        p->hist_clean = false;
-        // the center gather writes whole slices, including zeros outside the tiles
+        // (k_center writes every queried position of the tiles straight into the output layout; the compact histogram
+        // is not touched)
         if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
         const int64_t nchunks = (int64_t)p->cchunks.size();
         if (nchunks > 0) {
@@ -2255,7 +2250,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             unsigned long long *dbg = dbg_on ? d_dbg.p : nullptr;
             hipLaunchKernelGGL(k_center, dim3((unsigned)((cgrid * 64 + kCenterWG - 1) / kCenterWG)), dim3(kCenterWG), (size_t)e->knobs.center_lds, st, p->d_cchunks.p, nchunks,
                                e->d_files.p, nfiles, mp, W, e->d_inv.p, e->d_cval.p, p->d_corder.p, p->d_ccounts.p, p->d_cranges.p,
-                               p->d_crec.p, (double *)p->d_hist.p, dbg);
+                               p->d_crec.p, p->d_opieces.p, (double *)p->d_out.p, e->norm_sum, e->norm_on ? 1 : 0, dbg);
             if (dbg_on) {
                 std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks)), h_slots((size_t)(kCenterCap * nchunks));
                 std::vector<uint32_t> h_order((size_t)(kCenterCap * nchunks)), h_cand((size_t)nchunks);
@@ -2310,7 +2305,6 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         }
         if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
         if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
-        launch_gather<double, double>(e, p, (const double *)p->d_hist.p, (double *)p->d_out.p);
     }
     if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[5], st));
     HIP_TRY(hipGetLastError());
