@@ -440,8 +440,9 @@ def run_workload(name, args, ctx, headline):
     n_extra_runs = int(len(my_reads.blk_start))
     n_seg_local = int(len(lp["tid"]))
     if center:
-        # k_center streams the candidate records and writes the float64 island histogram
-        kern_alg_bytes = my_reads.n * 8 + n_extra_runs * 8 + plan.positions * 8
+        # k_center (fused since round 3): streams the center stream of the records (8 B per aligned run), reads the
+        # segment table and writes every output position once -- the same B_alg as the point rules
+        kern_alg_bytes = my_reads.n * 8 + n_extra_runs * 8 + n_seg_local * 24 + int(lp["out_elems"]) * 8
         kernel_name = "k_center"
     else:
         # dominant kernel = k_hist_point (fused): streams every packed record once (8 B) + the runs of
@@ -655,7 +656,7 @@ def run_partitioned(name, args, ctx, headline):
         splan.close()
 
     n_extra_runs = int(len(my_reads.blk_start))
-    kern_alg_bytes = (my_reads.n * 8 + n_extra_runs * 8 + (plan.positions * 8 if center else len(lp["tid"]) * 24 + int(lp["out_elems"]) * 8))
+    kern_alg_bytes = my_reads.n * 8 + n_extra_runs * 8 + len(lp["tid"]) * 24 + int(lp["out_elems"]) * 8
     kern_ms = phases["hist"]
     achieved = kern_alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     ms_per_step = elapsed / steps * 1e3
