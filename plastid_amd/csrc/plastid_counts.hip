@@ -515,7 +515,7 @@ struct pc_plan {
     bool has_sums = false;       // some slices are summed (out_step 0): the output is an accumulator
     bool out_needs_zero = false; // some queried positions lie outside every tile (unknown contig, clipped)
     bool hist_clean = false;     // compact histogram known to be all zero (point-rule invariant)
-    int hist_kind = -1;          // 0 uint32 (point rules), 1 float64 (center)
+    int hist_kind = -1;          // 0: holds uint32 zeros / merged point-rule windows; -1: freshly allocated, not cleared yet
     std::vector<CenterChunk> cchunks;
     std::vector<GatherSeg> gsegs;
     std::vector<GatherChunk> gchunks;
