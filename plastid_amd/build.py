@@ -6,7 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "plastid_counts.hip")
-HDRS = [os.path.join(HERE, "csrc", "pc_kernels.hip.h"), os.path.join(ROOT, "include", "plastid_counts.h")]
+HDRS = [os.path.join(HERE, "csrc", "pc_kernels.hip.h"), os.path.join(HERE, "csrc", "host_util.h"),
+        os.path.join(ROOT, "include", "plastid_counts.h")]
 LIB = os.path.join(HERE, "libplastid_counts.so")
 
 HIPCC_FLAGS = [

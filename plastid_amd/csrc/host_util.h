@@ -1,0 +1,130 @@
+// host_util.h -- host-side helpers of the counting engine that do not touch HIP: the worker pool behind
+// parallel_chunks, the galloping lower bound of the plan build, a vector without zero-fill.  Plain C++17, so that
+// tests/test_host_logic.py can compile tests/host_util_test.cpp against it on a machine without a GPU.
+#pragma once
+#include <algorithm>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <utility>
+#include <vector>
+#include <unistd.h>
+
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the plan's tables are sized
+// once and then filled by all threads, and a serial zero-fill of tens of megabytes (plus the page faults it takes on
+// one thread) cost more than the fill itself.
+template <typename T> struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <typename U> void construct(U *q) { ::new ((void *)q) U; }
+    template <typename U, typename... A> void construct(U *q, A &&...a) { ::new ((void *)q) U(std::forward<A>(a)...); }
+};
+template <typename T> using PodVec = std::vector<T, NoInitAlloc<T>>;
+
+// First index in [0, n) for which `before(idx)` is false (before() is monotone: true ... true false ... false),
+// searched outward from `hint`: consecutive queries of a plan (the exons of a chain) land next to each other, and a
+// bisection over a few hundred thousand entries costs ~18 cache misses where the gallop costs two or three.
+template <typename F> static size_t gallop_lower_bound(size_t n, size_t hint, F before) {
+    if (n == 0) return 0;
+    if (hint >= n) hint = n - 1;
+    size_t lo, hi;   // the answer lies in [lo, hi]: before(lo - 1) holds (or lo == 0), before(hi) does not (or hi == n)
+    if (before(hint)) {
+        size_t step = 1;
+        lo = hint + 1;
+        hi = lo;
+        while (hi < n && before(hi)) { lo = hi + 1; hi += step; step <<= 1; }
+        if (hi > n) hi = n;
+    } else {
+        size_t step = 1;
+        lo = hi = hint;
+        while (lo > 0) {
+            const size_t probe = lo > step ? lo - step : 0;
+            if (before(probe)) { lo = probe + 1; break; }
+            lo = hi = probe;
+            step <<= 1;
+        }
+    }
+    while (lo < hi) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (before(mid)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// A process-wide pool of worker threads for the host passes (staging, plan build): a 16-thread region costs ~0.5 ms to
+// spawn and join, and one staging call runs some seventy of them.  One region at a time uses the pool (the caller is
+// worker 0); a region that finds it taken -- another engine staging on another host thread, a nested region -- spawns
+// its own threads as before.
+class WorkerPool {
+    std::mutex gate_;                       // held for the duration of a region
+    std::mutex m_;
+    std::condition_variable start_, done_;
+    std::vector<std::thread> workers_;      // worker k has index k + 1
+    const std::function<void(int)> *job_ = nullptr;
+    int njobs_ = 0;                         // indices [1, njobs_) take part in the current region
+    int pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+    const pid_t pid_ = getpid();
+    void loop(int idx) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            start_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            if (idx >= njobs_) continue;
+            const std::function<void(int)> *job = job_;
+            lk.unlock();
+            (*job)(idx);
+            lk.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+public:
+    // runs f(0) ... f(n - 1), f(0) on the calling thread; false (nothing done) when the pool is in use
+    bool run(int n, const std::function<void(int)> &f) {
+        if (getpid() != pid_) return false;   // a forked child has the pool's bookkeeping but not its threads
+        std::unique_lock<std::mutex> region(gate_, std::try_to_lock);
+        if (!region.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            while ((int)workers_.size() < n - 1) {
+                const int idx = (int)workers_.size() + 1;
+                workers_.emplace_back([this, idx] { loop(idx); });
+            }
+            job_ = &f;
+            njobs_ = n;
+            pending_ = n - 1;
+            ++generation_;
+        }
+        start_.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+        njobs_ = 0;
+        return true;
+    }
+};
+// (never destroyed: its threads sleep until the process ends -- no joins during static destruction)
+static WorkerPool &worker_pool() { static WorkerPool *p = new WorkerPool; return *p; }
+
+// fn(thread index, begin, end) over [0, n) cut into `nthreads` contiguous chunks
+template <typename F> static void parallel_chunks(int64_t n, int nthreads, F fn) {
+    if (nthreads <= 1 || n <= 0) { fn(0, (int64_t)0, n); return; }
+    const int64_t chunk = (n + nthreads - 1) / nthreads;
+    auto part = [&](int t) {
+        const int64_t b = std::min<int64_t>(n, (int64_t)t * chunk), e_ = std::min<int64_t>(n, b + chunk);
+        fn(t, b, e_);
+    };
+    if (worker_pool().run(nthreads, part)) return;
+    std::vector<std::thread> th;
+    th.reserve((size_t)nthreads);
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(part, t);
+    for (auto &x : th) x.join();
+}

@@ -1,0 +1,53 @@
+// CPU test of plastid_amd/csrc/host_util.h (compiled and run by tests/test_host_logic.py; test infrastructure).
+#include <atomic>
+#include <cstdio>
+#include <random>
+#include "host_util.h"
+
+int main() {
+    long bad = 0;
+    // gallop_lower_bound == std::lower_bound for every hint
+    std::mt19937_64 rng(5);
+    for (int it = 0; it < 100000; ++it) {
+        const size_t n = rng() % 40;
+        std::vector<int> v(n);
+        for (auto &x : v) x = (int)(rng() % 30);
+        std::sort(v.begin(), v.end());
+        const int key = (int)(rng() % 34) - 2;
+        const size_t hint = n ? rng() % (n + 3) : 0;
+        const size_t got = gallop_lower_bound(n, hint, [&](size_t i) { return v[i] < key; });
+        const size_t want = (size_t)(std::lower_bound(v.begin(), v.end(), key) - v.begin());
+        if (got != want) ++bad;
+    }
+    printf("gallop_lower_bound: bad %ld\n", bad);
+    // parallel_chunks covers [0, n) exactly once, whatever the width (regions served by the pool)
+    for (int r = 0; r < 4000; ++r) {
+        const int T = 1 + r % 17;
+        const int64_t n = r % 3 == 0 ? 5 : 1000 + r;
+        std::vector<int> hit((size_t)n, 0);
+        parallel_chunks(n, T, [&](int, int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) hit[(size_t)i] += 1; });
+        for (int v : hit) if (v != 1) ++bad;
+    }
+    // nested regions and concurrent callers (the pool is taken: those regions spawn their own threads)
+    std::atomic<long> total{0};
+    std::vector<std::thread> callers;
+    for (int c = 0; c < 4; ++c) callers.emplace_back([&] {
+        for (int r = 0; r < 500; ++r)
+            parallel_chunks(64, 8, [&](int, int64_t b, int64_t e) {
+                parallel_chunks(e - b, 3, [&](int, int64_t b2, int64_t e2) { total += e2 - b2; });
+            });
+    });
+    for (auto &t : callers) t.join();
+    if (total.load() != 4L * 500 * 64) ++bad;
+    printf("parallel_chunks: total %ld (want %ld)\n", total.load(), 4L * 500 * 64);
+    // PodVec: resize keeps what was written, push_back works
+    PodVec<int> pv;
+    pv.resize(1000);
+    for (int i = 0; i < 1000; ++i) pv[(size_t)i] = i;
+    pv.push_back(7);
+    pv.resize(2000);
+    for (int i = 0; i < 1000; ++i) if (pv[(size_t)i] != i) ++bad;
+    if (pv[1000] != 7) ++bad;
+    printf("host_util: %s\n", bad ? "FAILED" : "ok");
+    return bad != 0;
+}

@@ -389,3 +389,21 @@ def test_usable_cpus_respects_the_container_limits():
     assert 1 <= n <= (os.cpu_count() or 1)
     if hasattr(os, "sched_getaffinity"):
         assert n <= len(os.sched_getaffinity(0))
+
+
+def test_host_helpers_of_the_engine(tmp_path):
+    """plastid_amd/csrc/host_util.h is plain C++: the worker pool behind the host passes (regions of every width, nested
+    regions, concurrent callers), the galloping lower bound of the plan build against std::lower_bound for every hint,
+    and the vector without zero-fill -- compiled with the host compiler and run here."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        pytest.skip("no host C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_util_test")
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-pthread", "-I", os.path.join(root, "plastid_amd", "csrc"),
+                           os.path.join(root, "tests", "host_util_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stdout.decode()
+    assert b"host_util: ok" in out.stdout
