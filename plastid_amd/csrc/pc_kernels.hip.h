@@ -41,10 +41,12 @@ constexpr int kWG = 256;          // 4 waves of 64
 // fits six waves (76 - 77 VGPRs) and, without the first-batch prefetch of the gapped-record list, seven (66 - 69)
 // without scratch; eight spill.  Measured (scripts/exp_hist_occupancy.sh): C4 (variable offsets) 1.51 ms at five
 // waves, 1.36 at six, 1.22 at seven; C2 (dense, HBM-bound) 0.155 at six, 0.158 at seven; C5 (stratified: its
-// 11-row window allows six workgroups per CU by LDS alone) 5.0 at six, 5.1 at seven.  So: seven for the
-// variable-offset rule, six for the others.
+// 11-row window allowed six workgroups per CU by LDS alone then) 5.0 at six, 5.1 at seven.  Round 3: the run stream goes
+// through the entry table (every instantiation fits 66 - 69 VGPRs at seven waves, no scratch) and a multi-row plan gives
+// every strand mode of a window its own tile, i.e. half the LDS -- so seven for the variable-offset and the stratified
+// rule, six for the dense single-row rules.
 #ifndef PC_HIST_WAVES
-#define PC_HIST_WAVES(KIND) ((KIND) == 3 ? 7 : 6)
+#define PC_HIST_WAVES(KIND) ((KIND) >= 3 ? 7 : 6)
 #endif
 #ifndef PC_HIST_U
 #define PC_HIST_U(KIND) 4

@@ -1619,7 +1619,14 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         });
     }
     int max_slots = 1;
-    auto new_tile = [&](size_t i) { return i == 0 || raw[i - 1].tid != raw[i].tid || raw[i - 1].win != raw[i].win; };
+    // A multi-row plan (stratified rule: rows x G bins per strand mode) gives every strand mode of a window a tile of its
+    // own: the LDS window of the launch is then sized for ONE mode -- C5: 14 KB instead of 25, seven workgroups per CU
+    // instead of six -- and the two windows in a hundred that query both strands are scanned twice.  Single-row plans keep
+    // all modes of a window in one tile: one pass over the records serves both strands.
+    const bool split_modes = rows > 1;
+    auto new_tile = [&](size_t i) {
+        return i == 0 || raw[i - 1].tid != raw[i].tid || raw[i - 1].win != raw[i].win || (split_modes && raw[i - 1].pc_.mode != raw[i].pc_.mode);
+    };
     auto fill_tile = [&](Tile &t, size_t i0, size_t i1) {   // the tile of the sorted pieces [i0, i1)
         t.tid = raw[i0].tid; t.win_start = (int32_t)raw[i0].win; t.piece_begin = (uint32_t)i0; t.piece_end = (uint32_t)i1;
         t.mode_mask = 0; t.op_begin = t.op_end = 0; t.span_lo = 0xffff; t.span_hi = 0;
@@ -1698,12 +1705,18 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
                     const int64_t win = (a / G) * G;
                     const int64_t b = std::min<int64_t>(ce, win + G);
                     // tile of (tid, win)
+                    // (tiles are sorted by contig, window and -- when every mode has its own tile -- mode: a one-mode
+                    // tile's mask, 1 << mode, orders like the mode)
                     size_t lo = prev + 1;
-                    if (prev == (size_t)-1 || lo >= p->tiles.size() || p->tiles[lo].tid != tid[s] || (int64_t)p->tiles[lo].win_start != win) {
+                    const uint32_t want_mask = 1u << m;
+                    if (prev == (size_t)-1 || lo >= p->tiles.size() || p->tiles[lo].tid != tid[s] || (int64_t)p->tiles[lo].win_start != win ||
+                        (split_modes && p->tiles[lo].mode_mask != want_mask)) {
                         const int32_t ts = tid[s];
                         lo = gallop_lower_bound(p->tiles.size(), seg_hint, [&](size_t k) {
                             const Tile &t = p->tiles[k];
-                            return t.tid < ts || (t.tid == ts && (int64_t)t.win_start < win);
+                            if (t.tid != ts) return t.tid < ts;
+                            if ((int64_t)t.win_start != win) return (int64_t)t.win_start < win;
+                            return split_modes && t.mode_mask < want_mask;
                         });
                     }
                     prev = lo;
