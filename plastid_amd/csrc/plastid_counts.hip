@@ -406,8 +406,8 @@ struct pc_plan {
     std::vector<GatherSeg> gsegs;
     std::vector<GatherChunk> gchunks;
     bool lazy_center = false;    // large plans: cchunks / gchunks (and the upload of gsegs) wait for the first center count or coordinate export
-    bool center_ready = false;
-    DevBuf<uint8_t> d_tables2;   // ... and live in this block
+    bool center_ready = false, gather_ready = false;
+    DevBuf<uint8_t> d_tables2, d_tables3;   // ... and live in these blocks (chunks; gather list)
     // host copies for warn evaluation
     std::vector<int32_t> h_tid;
     std::vector<int64_t> h_start, h_end;
@@ -483,7 +483,7 @@ struct pc_plan {
         DevPool *pl = &eng->pool;
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
-        d_cranges.pool = pl; d_crec.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl;
+        d_cranges.pool = pl; d_crec.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
         d_work.pool = pl; d_work_small.pool = pl; d_chain.pool = pl; d_chain_small.pool = pl;
     }
 };
@@ -510,6 +510,8 @@ int refresh_file_views(pc_engine *e) {
 }
 
 // The center-only tables of a large plan (see pc_plan_create): built on first use.
+// The tables of a large plan that only the center rule (64-position chunks) or only the coordinate export (the
+// per-segment gather list) reads are built and uploaded when first asked for, each on its own.
 int ensure_center_tables(pc_engine *e, pc_plan *p) {
     if (!p->lazy_center || p->center_ready) return PC_OK;
     const int PT = std::min(usable_cpus(), 32);
@@ -537,6 +539,17 @@ int ensure_center_tables(pc_engine *e, pc_plan *p) {
             }
         }
     });
+    int rc = p->d_tables2.reserve(std::max<size_t>(p->cchunks.size() * sizeof(CenterChunk), 256));
+    if (rc != PC_OK) return rc;
+    if (!p->cchunks.empty()) HIP_TRY(hipMemcpyAsync(p->d_tables2.p, p->cchunks.data(), p->cchunks.size() * sizeof(CenterChunk), hipMemcpyHostToDevice, e->stream));
+    p->d_cchunks.p = (CenterChunk *)p->d_tables2.p;
+    p->center_ready = true;
+    return PC_OK;
+}
+
+int ensure_gather_tables(pc_engine *e, pc_plan *p) {
+    if (!p->lazy_center || p->gather_ready) return PC_OK;
+    const int PT = std::min(usable_cpus(), 32);
     std::vector<size_t> gat((size_t)p->nseg + 1, 0);
     for (int64_t s = 0; s < p->nseg; ++s) gat[(size_t)s + 1] = gat[(size_t)s] + (size_t)((p->gsegs[(size_t)s].len + kGatherChunk - 1) / kGatherChunk);
     p->gchunks.resize(gat[(size_t)p->nseg]);
@@ -546,16 +559,14 @@ int ensure_center_tables(pc_engine *e, pc_plan *p) {
     });
     size_t bytes = 0;
     auto place = [&bytes](size_t n) { const size_t a = bytes; bytes += (n + 255) & ~(size_t)255; return a; };
-    const size_t at_c = place(p->cchunks.size() * sizeof(CenterChunk)), at_s = place(p->gsegs.size() * sizeof(GatherSeg)),
-                 at_g = place(p->gchunks.size() * sizeof(GatherChunk));
-    int rc = p->d_tables2.reserve(std::max<size_t>(bytes, 256));
+    const size_t at_s = place(p->gsegs.size() * sizeof(GatherSeg)), at_g = place(p->gchunks.size() * sizeof(GatherChunk));
+    int rc = p->d_tables3.reserve(std::max<size_t>(bytes, 256));
     if (rc != PC_OK) return rc;
-    uint8_t *d = p->d_tables2.p;
-    if (!p->cchunks.empty()) HIP_TRY(hipMemcpyAsync(d + at_c, p->cchunks.data(), p->cchunks.size() * sizeof(CenterChunk), hipMemcpyHostToDevice, e->stream));
+    uint8_t *d = p->d_tables3.p;
     if (!p->gsegs.empty()) HIP_TRY(hipMemcpyAsync(d + at_s, p->gsegs.data(), p->gsegs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, e->stream));
     if (!p->gchunks.empty()) HIP_TRY(hipMemcpyAsync(d + at_g, p->gchunks.data(), p->gchunks.size() * sizeof(GatherChunk), hipMemcpyHostToDevice, e->stream));
-    p->d_cchunks.p = (CenterChunk *)(d + at_c); p->d_gsegs.p = (GatherSeg *)(d + at_s); p->d_gchunks.p = (GatherChunk *)(d + at_g);
-    p->center_ready = true;
+    p->d_gsegs.p = (GatherSeg *)(d + at_s); p->d_gchunks.p = (GatherChunk *)(d + at_g);
+    p->gather_ready = true;
     return PC_OK;
 }
 
@@ -2273,7 +2284,7 @@ int pc_plan_coordinates(pc_engine *e, pc_plan *p, int64_t *host_out, int64_t out
     DevBuf<int64_t> d;
     d.pool = &e->pool;
     int rc = d.reserve((size_t)out_elems);
-    if (rc == PC_OK) rc = ensure_center_tables(e, p);   // the per-segment gather list of a large plan
+    if (rc == PC_OK) rc = ensure_gather_tables(e, p);   // the per-segment gather list of a large plan
     if (rc != PC_OK) return rc;
     hipStream_t st = e->stream;
     HIP_TRY(hipMemsetAsync(d.p, 0xff, (size_t)out_elems * 8, st));   // -1: elements no segment covers

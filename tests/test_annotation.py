@@ -268,4 +268,11 @@ def test_position_arrays_device_kernel_equals_numpy():
         want = pos[off[c]:off[c + 1]]
         assert np.array_equal(co[off[c]:off[c + 1]], want[::-1] if tx.strand[c] == 2 else want)
     plan.close()
+    # a large annotation (>= 65 536 exons): the plan builds its per-segment gather list only now, when the coordinates
+    # are asked for -- on its own, without the center rule's chunk table
+    big = synth.make_transcripts(synth.HUMAN, 12000, 2004, "human")
+    assert big.n_segments >= (1 << 16)
+    bpos, boff = big.position_arrays()
+    bd, bo = big.position_arrays(eng)
+    assert np.array_equal(bd, bpos) and np.array_equal(bo, boff)
     eng.close()
