@@ -209,6 +209,11 @@ int pc_set_profiling(pc_engine *e, int level);
 int pc_last_timing(pc_engine *e, double *ms, int n);
 /* algorithmic bytes of the last pc_count (SURVEY.md section 8d formula) */
 int64_t pc_last_algorithmic_bytes(pc_engine *e);
+/* Measurement helper for the center rule (CenterMapFactory.__call__, map_factories.pyx:200-265): counts `plan` once
+ * more in a diagnostic launch and reports how many replay steps (one step = entry j of each 16-lane row applied to the
+ * row: 3 single-rate vector instructions + one v_fmac_f64) and how many waves the launch executed -- the numerator
+ * of the kernel's vector-issue bound that bench.py reports beside the HBM fraction.  No reference counterpart. */
+int pc_center_replay_steps(pc_engine *e, pc_plan *p, int64_t *steps, int64_t *waves);
 /* Measured streaming rates of this GPU (GB/s) for the access patterns of the tile kernel: 16-byte
  * contiguous loads per lane and 8-byte contiguous stores per lane over a buffer of `bytes` bytes
  * (>= 1 MiB; use several hundred MB to get past the 256 MiB Infinity Cache).  The second roofline

@@ -317,19 +317,77 @@ static void *po_worker(void *arg) {
     return NULL;
 }
 
-int po_count_segments_wide_mt(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
-                              const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
-                              const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
-                              const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
-                              int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
-                              const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
-                              const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped, int nthreads,
-                              int64_t n_wide, const int64_t *wide_idx, const int32_t *wide_alen, const int32_t *wide_nblk) {
+/*
+ * A prepared alignment set: what depends on the records only -- run offsets and end coordinates (po_prepare), the
+ * (file, tid) runs of the record array and the longest reference span for the fetch emulation -- derived ONCE and
+ * reused by any number of po_prepared_count calls (bench.py's CPU baseline times the preparation apart and then
+ * counts thousands of chains against it; the reference likewise opens and indexes a BAM file once).  The handle
+ * keeps the caller's pointers: the arrays must outlive it.
+ */
+typedef struct {
     po_aln a;
-    memset(&a, 0, sizeof(a));
-    a.n = n; a.tid = tid; a.pos = pos; a.alen = alen; a.flags = flags; a.nblk = nblk;
-    a.file_id = file_id; a.blk_start = blk_start; a.blk_len = blk_len;
-    a.n_wide = n_wide; a.wide_idx = wide_idx; a.wide_alen = wide_alen; a.wide_nblk = wide_nblk;
+    int64_t *rng_lo, *rng_hi;
+    int32_t *rng_tid;
+    int64_t nrng, max_span;
+    int maxL;
+} po_prepared;
+
+void po_close(po_prepared *h) {
+    if (!h) return;
+    free(h->rng_lo); free(h->rng_hi); free(h->rng_tid);
+    po_release(&h->a);
+    free(h);
+}
+
+po_prepared *po_open(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen, const uint8_t *flags,
+                     const uint8_t *nblk, const uint8_t *file_id, const int32_t *blk_start, const int32_t *blk_len,
+                     int64_t n_wide, const int64_t *wide_idx, const int32_t *wide_alen, const int32_t *wide_nblk,
+                     int *rcode_out) {
+    int rcode = PO_OK;
+    po_prepared *h = (po_prepared *)calloc(1, sizeof(po_prepared));
+    if (!h) { if (rcode_out) *rcode_out = PO_ERR_NOMEM; return NULL; }
+    po_aln *a = &h->a;
+    a->n = n; a->tid = tid; a->pos = pos; a->alen = alen; a->flags = flags; a->nblk = nblk;
+    a->file_id = file_id; a->blk_start = blk_start; a->blk_len = blk_len;
+    a->n_wide = n_wide; a->wide_idx = wide_idx; a->wide_alen = wide_alen; a->wide_nblk = wide_nblk;
+    rcode = po_prepare(a);
+    /* (file, tid) runs + the longest reference span, for the fetch emulation */
+    int64_t cap = 64;
+    h->rng_lo = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+    h->rng_hi = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+    h->rng_tid = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+    h->max_span = 1;
+    if (rcode == PO_OK && (!h->rng_lo || !h->rng_hi || !h->rng_tid)) rcode = PO_ERR_NOMEM;
+    for (int64_t i = 0; rcode == PO_OK && i < n; ++i) {
+        int newrun = (i == 0) || tid[i] != tid[i - 1] || (file_id && file_id[i] != file_id[i - 1]);
+        if (newrun) {
+            if (h->nrng == cap) {
+                cap *= 2;
+                h->rng_lo = (int64_t *)realloc(h->rng_lo, sizeof(int64_t) * (size_t)cap);
+                h->rng_hi = (int64_t *)realloc(h->rng_hi, sizeof(int64_t) * (size_t)cap);
+                h->rng_tid = (int32_t *)realloc(h->rng_tid, sizeof(int32_t) * (size_t)cap);
+                if (!h->rng_lo || !h->rng_hi || !h->rng_tid) { rcode = PO_ERR_NOMEM; break; }
+            }
+            if (h->nrng > 0) h->rng_hi[h->nrng - 1] = i;
+            h->rng_lo[h->nrng] = i; h->rng_tid[h->nrng] = tid[i]; ++h->nrng;
+        } else if (pos[i] < pos[i - 1]) {
+            rcode = PO_ERR_ARG; /* not coordinate sorted: pysam.fetch would raise */
+            break;
+        }
+        if (a->ref_end[i] - pos[i] > h->max_span) h->max_span = a->ref_end[i] - pos[i];
+        if (po_len(a, i) > h->maxL) h->maxL = po_len(a, i);
+    }
+    if (rcode == PO_OK && h->nrng > 0) h->rng_hi[h->nrng - 1] = n;
+    if (rcode_out) *rcode_out = rcode;
+    if (rcode != PO_OK) { po_close(h); return NULL; }
+    return h;
+}
+
+int po_prepared_count(const po_prepared *h, int kind, int param, const int32_t *fw, const int32_t *rc, int min_len,
+                      int max_len, int filt_on, int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
+                      const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
+                      const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped, int nthreads) {
+    if (!h) return PO_ERR_ARG;
     po_map m;
     memset(&m, 0, sizeof(m));
     m.kind = kind; m.param = param; m.fw = fw; m.rc = rc; m.min_len = min_len; m.max_len = max_len;
@@ -337,42 +395,10 @@ int po_count_segments_wide_mt(int64_t n, const int32_t *tid, const int32_t *pos,
     if (kind < PO_FIVE || kind > PO_STRAT5) return PO_ERR_ARG;
     if ((kind == PO_VAR5 || kind == PO_STRAT5) && (!fw || !rc)) return PO_ERR_ARG;
     if (kind == PO_STRAT5 && max_len < min_len) return PO_ERR_ARG;
-
-    int rcode = po_prepare(&a);
-    if (rcode != PO_OK) { po_release(&a); return rcode; }
-
-    /* (file, tid) runs + the longest reference span, for the fetch emulation */
-    int64_t nrng = 0, cap = 64;
-    int64_t *rng_lo = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
-    int64_t *rng_hi = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
-    int32_t *rng_tid = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
-    int64_t max_span = 1;
-    int maxL = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        int newrun = (i == 0) || tid[i] != tid[i - 1] ||
-                     (file_id && file_id[i] != file_id[i - 1]);
-        if (newrun) {
-            if (nrng == cap) {
-                cap *= 2;
-                rng_lo = (int64_t *)realloc(rng_lo, sizeof(int64_t) * (size_t)cap);
-                rng_hi = (int64_t *)realloc(rng_hi, sizeof(int64_t) * (size_t)cap);
-                rng_tid = (int32_t *)realloc(rng_tid, sizeof(int32_t) * (size_t)cap);
-            }
-            if (nrng > 0) rng_hi[nrng - 1] = i;
-            rng_lo[nrng] = i; rng_tid[nrng] = tid[i]; ++nrng;
-        } else if (pos[i] < pos[i - 1]) {
-            free(rng_lo); free(rng_hi); free(rng_tid); po_release(&a);
-            return PO_ERR_ARG; /* not coordinate sorted: pysam.fetch would raise */
-        }
-        if (a.ref_end[i] - pos[i] > max_span) max_span = a.ref_end[i] - pos[i];
-        if (po_len(&a, i) > maxL) maxL = po_len(&a, i);
-    }
-    if (nrng > 0) rng_hi[nrng - 1] = n;
-
     po_job job;
     memset(&job, 0, sizeof(job));
-    job.a = &a; job.m = &m; job.rng_lo = rng_lo; job.rng_hi = rng_hi; job.nrng = nrng; job.rng_tid = rng_tid;
-    job.max_span = max_span; job.maxL = maxL; job.nseg = nseg; job.seg_tid = seg_tid; job.seg_start = seg_start;
+    job.a = &h->a; job.m = &m; job.rng_lo = h->rng_lo; job.rng_hi = h->rng_hi; job.nrng = h->nrng; job.rng_tid = h->rng_tid;
+    job.max_span = h->max_span; job.maxL = h->maxL; job.nseg = nseg; job.seg_tid = seg_tid; job.seg_start = seg_start;
     job.seg_end = seg_end; job.seg_strand = seg_strand; job.out_off = out_off; job.out = out; job.warn = warn;
     job.mapped = mapped; job.next = 0; job.rcode = PO_OK;
     if (nthreads <= 1) {
@@ -386,9 +412,26 @@ int po_count_segments_wide_mt(int64_t n, const int32_t *tid, const int32_t *pos,
         for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
         free(th);
     }
-    rcode = job.rcode;
-    free(rng_lo); free(rng_hi); free(rng_tid);
-    po_release(&a);
+    return job.rcode;
+}
+
+int po_count_segments_wide_mt(int64_t n, const int32_t *tid, const int32_t *pos, const uint16_t *alen,
+                              const uint8_t *flags, const uint8_t *nblk, const uint8_t *file_id,
+                              const int32_t *blk_start, const int32_t *blk_len, int kind, int param,
+                              const int32_t *fw, const int32_t *rc, int min_len, int max_len, int filt_on,
+                              int filt_min, int filt_max, int64_t nseg, const int32_t *seg_tid,
+                              const int64_t *seg_start, const int64_t *seg_end, const uint8_t *seg_strand,
+                              const int64_t *out_off, void *out, uint8_t *warn, uint8_t *mapped, int nthreads,
+                              int64_t n_wide, const int64_t *wide_idx, const int32_t *wide_alen, const int32_t *wide_nblk) {
+    if (kind < PO_FIVE || kind > PO_STRAT5) return PO_ERR_ARG;
+    if ((kind == PO_VAR5 || kind == PO_STRAT5) && (!fw || !rc)) return PO_ERR_ARG;
+    if (kind == PO_STRAT5 && max_len < min_len) return PO_ERR_ARG;
+    int rcode = PO_OK;
+    po_prepared *h = po_open(n, tid, pos, alen, flags, nblk, file_id, blk_start, blk_len, n_wide, wide_idx, wide_alen, wide_nblk, &rcode);
+    if (!h) return rcode;
+    rcode = po_prepared_count(h, kind, param, fw, rc, min_len, max_len, filt_on, filt_min, filt_max, nseg, seg_tid, seg_start,
+                              seg_end, seg_strand, out_off, out, warn, mapped, nthreads);
+    po_close(h);
     return rcode;
 }
 

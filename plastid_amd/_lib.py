@@ -66,6 +66,7 @@ SIGNATURES = {
     "pc_set_profiling": (_int, [_vp, _int]),
     "pc_last_timing": (_int, [_vp, _vp, _int]),
     "pc_last_algorithmic_bytes": (_i64, [_vp]),
+    "pc_center_replay_steps": (_int, [_vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "pc_stream_probe": (_int, [_vp, _i64, _int, _vp, _vp]),
 }
 

@@ -1,0 +1,683 @@
+// bam_kernels.hip.h -- compressed BAM on the GPU (round 4; extends SURVEY 8(f1)).
+//
+// The reference reaches its reads through pysam / htslib: `AlignmentFile.fetch` over BGZF
+// (plastid/genomics/genome_array.py:800-809).  A BAM file is a series of BGZF members, each an independent raw DEFLATE
+// stream of at most 64 KiB of payload (RFC 1951 / 1952; read by the vendored kent/src/htslib/bgzf.c:292-340, 421-530),
+// whose concatenated payloads are the BAM stream: header, then records  {block_size:u32, refID:i32, pos:i32,
+// l_read_name:u8, mapq:u8, bin:u16, n_cigar_op:u16, flag:u16, l_seq:i32, next_refID, next_pos, tlen, read_name,
+// cigar[n_cigar_op]:u32 (op = v & 15, len = v >> 4; ops MIDNSHP=X, kent/src/htslib/htslib/sam.h:64-104), seq, qual,
+// tags}  (kent/src/htslib/sam.c bam_read1).  Host inflate (zlib / libdeflate on the 16 CPUs a GPU box grants) runs at
+// ~11 GB/s: 5.4e7 reads/s from a realistic file, against 6e11 at kernel scope.  Here the file image goes to HBM as it
+// is and
+//   k_bgzf_inflate    ONE WAVE PER MEMBER inflates it: Huffman tables and a 32 KiB window in LDS, the symbol decode
+//                     wave-uniform, match copies and the flushes of the window to HBM spread over the lanes;
+//   k_bam_chain       one wave per member finds where the first BAM record of the member starts (a guess: the first
+//                     offset from which a few records in a row look like records) and walks the chain of length prefixes
+//                     to the first record start of the NEXT member, noting every start; the host only confirms that
+//                     the guesses chain (and restarts the few members whose guess did not);
+//   k_bam_fields      one thread per record: fixed-offset fields, CIGAR -> aligned runs (sam.h:64-104), the checks of
+//                     the host decoder (bam_stager.cpp decode_span_cols) as an error code;
+//   k_bam_runs        the runs of the multi-run records at their scanned offsets.
+// The columns that come out (tid, pos, alen, flags, nblk, runs) are what pc_add_alignment_file takes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pcbam {
+
+constexpr int kInflWG = 64;                 // one wave per BGZF member
+constexpr int kWinBytes = 32768;            // DEFLATE window (RFC 1951: distances up to 32 768)
+constexpr int kLitRoot = 9, kDistRoot = 6;  // first-level table bits (zlib's choice: enough.c bounds 852 / 592 entries)
+constexpr int kLitEntries = 1024, kDistEntries = 640;
+constexpr int kInBytes = 1024;              // compressed input staged in LDS (two halves of 512 bytes)
+constexpr int kFlush = 8192;                // the window goes to HBM in pieces of this size
+
+struct Member {
+    uint64_t coff;     // offset of the raw DEFLATE stream in the file image (behind the gzip header)
+    uint32_t clen;     // its length (the 8-byte trailer excluded)
+    uint32_t ulen;     // ISIZE: bytes it inflates to
+    uint64_t uoff;     // where they go in the inflated stream
+    uint32_t crc;      // CRC-32 of the payload (gzip trailer)
+    uint32_t pad;
+};
+
+// error codes of k_bgzf_inflate (per member)
+enum { kInfOk = 0, kInfBadBlockType = 1, kInfBadStored = 2, kInfBadCodeLengths = 3, kInfOverSubscribed = 4, kInfBadSymbol = 5,
+       kInfBadDistance = 6, kInfOverrun = 7, kInfShort = 8, kInfInputOverrun = 9, kInfCrc = 10 };
+
+// ---- table entries (uint32):  bits 0-3 code bits to consume, 4-7 extra bits, 8-9 kind, 16-31 value
+//   kind 0: literal (value = byte) / distance base;  1: length base;  2: end of block;  3: pointer to a second-level
+//   table (value = its first entry, bits 4-7 = its index bits)
+__device__ __forceinline__ uint32_t mk_entry(uint32_t nbits, uint32_t extra, uint32_t kind, uint32_t value) {
+    return nbits | (extra << 4) | (kind << 8) | (value << 16);
+}
+
+// length / distance bases and extra bits (RFC 1951 3.2.5)
+__device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t c, int len) { return __brev(c) >> (32 - len); }
+
+// Canonical Huffman code of `n` symbols with code lengths `lens` (0: unused) -> two-level decode table with `root`
+// first-level bits.  Run by the whole wave (wave-uniform control flow; the fills are spread over the lanes).
+// LITLEN: symbols 0-255 literals, 256 end of block, 257-285 lengths; else distances.  Returns 0, or an error code
+// (over-subscribed or incomplete code -- a single distance code is allowed, as in zlib -- or a table that does not
+// fit `cap` entries).
+template <bool LITLEN>
+__device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table, int cap, uint16_t *scratch, int lane) {
+    // counts per length (uniform: every lane walks the lengths; n <= 288)
+    int count[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) count[i] = 0;
+    for (int s = 0; s < n; ++s) count[lens[s]] += 1;
+    count[0] = 0;
+    int left = 1, maxlen = 0, nsym = 0;
+    for (int len = 1; len <= 15; ++len) {
+        left = (left << 1) - count[len];
+        if (left < 0) return kInfOverSubscribed;
+        if (count[len]) maxlen = len;
+        nsym += count[len];
+    }
+    if (left > 0 && (LITLEN || nsym > 1)) return kInfOverSubscribed;   // incomplete code (zlib: inflate_table returns -1)
+    // clear the first level (an incomplete distance code leaves holes: they decode as "bad symbol")
+    for (int i = lane; i < (1 << root); i += 64) table[i] = 0u;
+    if (nsym == 0) return kInfOk;
+    int next_code[16];
+    {
+        int code = 0;
+        next_code[0] = 0;
+        for (int len = 1; len <= 15; ++len) { code = (code + count[len - 1]) << 1; next_code[len] = code; }
+    }
+    // second-level tables: index bits per first-level prefix = longest code with that prefix - root
+    uint8_t *subbits = (uint8_t *)scratch;            // [1 << root]
+    if (maxlen > root) {
+        for (int i = lane; i < (1 << root); i += 64) subbits[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // pass over the symbols in order (canonical codes are assigned in symbol order within a length): every lane
+    // computes the codes of all symbols (cheap, uniform) and fills its share of the replicated entries
+    int nc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) nc[i] = next_code[i];
+    if (maxlen > root) {
+        for (int s = 0; s < n; ++s) {
+            const int len = lens[s];
+            if (!len) continue;
+            const uint32_t rc = bitrev((uint32_t)nc[len]++, len);
+            if (len > root && lane == 0) {
+                const uint32_t pre = rc & ((1u << root) - 1u);
+                if (subbits[pre] < len - root) subbits[pre] = (uint8_t)(len - root);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // allocate (serial over the prefixes; uniform)
+        int used = 1 << root;
+        for (int pre = 0; pre < (1 << root); ++pre) {
+            const int sb = subbits[pre];
+            if (!sb) continue;
+            if (used + (1 << sb) > cap) return kInfBadCodeLengths;
+            if (lane == 0) table[pre] = mk_entry((uint32_t)root, (uint32_t)sb, 3u, (uint32_t)used);
+            for (int i = lane; i < (1 << sb); i += 64) table[used + i] = 0u;
+            used += 1 << sb;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nc[i] = next_code[i];
+    }
+    for (int s = 0; s < n; ++s) {
+        const int len = lens[s];
+        if (!len) continue;
+        const uint32_t rc = bitrev((uint32_t)nc[len]++, len);
+        uint32_t e;
+        if (LITLEN) {
+            if (s < 256) e = mk_entry(0u, 0u, 0u, (uint32_t)s);
+            else if (s == 256) e = mk_entry(0u, 0u, 2u, 0u);
+            else if (s <= 285) e = mk_entry(0u, kLenExtra[s - 257], 1u, kLenBase[s - 257]);
+            else e = mk_entry(0u, 0u, 2u, 1u);                           // 286 / 287: never valid (kind 2, value 1 = bad)
+        } else {
+            e = s < 30 ? mk_entry(0u, kDistExtra[s], 0u, kDistBase[s]) : mk_entry(0u, 0u, 2u, 1u);
+        }
+        if (len <= root) {
+            e |= (uint32_t)len;
+            for (uint32_t i = rc + ((uint32_t)lane << len); i < (1u << root); i += 64u << len) table[i] = e;
+        } else {
+            const uint32_t pre = rc & ((1u << root) - 1u);
+            const uint32_t pe = table[pre];
+            const uint32_t base = pe >> 16, sb = (pe >> 4) & 15u;
+            const int sl = len - root;
+            e |= (uint32_t)sl;
+            for (uint32_t i = (rc >> root) + ((uint32_t)lane << sl); i < (1u << sb); i += 64u << sl) table[base + i] = e;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return kInfOk;
+}
+
+// CRC-32 (RFC 1952) of `n` window bytes starting at window offset `at`: 64 lanes x contiguous slices with a 256-entry
+// table in LDS, combined in lane order.  (What htslib checks per member, bgzf.c:421-530.)
+__device__ __forceinline__ uint32_t crc_byte(const uint32_t *tab, uint32_t crc, uint32_t b) { return tab[(crc ^ b) & 0xffu] ^ (crc >> 8); }
+
+struct InflateShared {
+    uint32_t lit[kLitEntries];
+    uint32_t dist[kDistEntries];
+    uint32_t in[kInBytes / 4];
+    uint8_t win[kWinBytes];
+};
+
+// One wave inflates one BGZF member.  Everything but the copies is wave-uniform (every lane holds the same bit
+// buffer and positions): no divergence, table reads are LDS broadcasts.
+__global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restrict__ image, const Member *__restrict__ members, int nmembers,
+                                                          uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
+    __shared__ InflateShared sh;
+    __shared__ uint8_t s_lens[320];
+    __shared__ uint16_t s_scratch[512];
+    const int m = blockIdx.x;
+    if (m >= nmembers) return;
+    const Member mb = members[m];
+    const int lane = threadIdx.x & 63;
+    const uint8_t *src = image + mb.coff;
+    uint8_t *dst = out + mb.uoff;
+    const uint32_t clen = mb.clen, ulen = mb.ulen;
+    int err = kInfOk;
+
+    // ---- input: `in` holds the 1 KiB of the stream around the read position as 256 dwords (ring); refilled a half
+    // (512 bytes) at a time by the wave when the reader has crossed into the other half
+    uint32_t in_pos = 0;          // next byte of the stream to pull into the bit buffer (always a multiple of 4)
+    uint32_t in_loaded = 0;       // bytes of the stream staged so far (multiple of 512)
+    auto stage_half = [&]() {     // stage stream bytes [in_loaded, in_loaded + 512)
+        const uint32_t base = in_loaded;
+        // 128 dwords by 64 lanes, byte-wise assembled (the stream starts at an arbitrary byte of the image)
+        for (int k = lane; k < 128; k += 64) {
+            const uint32_t b = base + 4u * (uint32_t)k;
+            uint32_t w = 0;
+            if (b + 3u < clen) w = (uint32_t)src[b] | ((uint32_t)src[b + 1] << 8) | ((uint32_t)src[b + 2] << 16) | ((uint32_t)src[b + 3] << 24);
+            else {
+                if (b < clen) w |= (uint32_t)src[b];
+                if (b + 1u < clen) w |= (uint32_t)src[b + 1] << 8;
+                if (b + 2u < clen) w |= (uint32_t)src[b + 2] << 16;
+            }
+            sh.in[((base >> 2) + (uint32_t)k) & (kInBytes / 4 - 1)] = w;
+        }
+        in_loaded += 512u;
+        __builtin_amdgcn_wave_barrier();
+    };
+    stage_half();
+    stage_half();
+    unsigned long long bb = 0;    // bit buffer
+    int nb = 0;                   // valid bits in it
+    auto refill = [&]() {         // at least 32 valid bits afterwards (zeros behind the end of the stream)
+        if (nb <= 32) {
+            if (in_pos + 512u + 4u > in_loaded && in_loaded < clen + 512u) stage_half();   // the reader entered the last staged half: fetch the next
+            const uint32_t w = sh.in[(in_pos >> 2) & (kInBytes / 4 - 1)];
+            bb |= (unsigned long long)w << nb;
+            nb += 32;
+            in_pos += 4u;
+        }
+    };
+    auto take = [&](int n) -> uint32_t {   // n <= 16
+        const uint32_t v = (uint32_t)bb & ((1u << n) - 1u);
+        bb >>= n;
+        nb -= n;
+        return v;
+    };
+
+    uint32_t pos = 0;             // bytes produced
+    uint32_t flushed = 0;         // bytes written to HBM
+    auto flush_to = [&](uint32_t upto) {   // window bytes [flushed, upto) -> HBM; both multiples of 16 except at the very end
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t b = flushed + 16u * (uint32_t)lane; b < upto; b += 16u * 64u) {
+            if (b + 16u <= upto && ((mb.uoff + b) & 15u) == 0u) {
+                const uint4 v = *(const uint4 *)&sh.win[b & (kWinBytes - 1)];
+                *(uint4 *)(dst + b) = v;
+            } else {
+                for (uint32_t k = b; k < upto && k < b + 16u; ++k) dst[k] = sh.win[k & (kWinBytes - 1)];
+            }
+        }
+        flushed = upto;
+    };
+
+    bool last = false;
+    while (!last && err == kInfOk) {
+        refill();
+        last = take(1) != 0u;
+        const uint32_t type = take(2);
+        if (type == 0u) {
+            // stored block: skip to the byte boundary, LEN / NLEN, raw bytes
+            take(nb & 7);
+            refill();
+            const uint32_t len = take(16);
+            refill();
+            const uint32_t nlen = take(16);
+            if ((len ^ 0xffffu) != nlen) { err = kInfBadStored; break; }
+            if (pos + len > ulen) { err = kInfOverrun; break; }
+            // the bit buffer holds whole bytes now: give them back to the stream position
+            uint32_t sp = in_pos - (uint32_t)(nb >> 3);
+            bb = 0; nb = 0;
+            if (sp + len > clen) { err = kInfInputOverrun; break; }
+            for (uint32_t k = lane; k < len; k += 64) sh.win[(pos + k) & (kWinBytes - 1)] = src[sp + k];
+            __builtin_amdgcn_wave_barrier();
+            // (a stored block can be longer than the flush piece: flush as we go)
+            pos += len;
+            while (pos - flushed >= (uint32_t)kFlush + 16u) flush_to((flushed + kFlush) & ~15u);
+            sp += len;
+            // restart the staged input at the new position (dword aligned below it; the odd bytes are dropped from the bit buffer)
+            in_pos = sp & ~3u;
+            in_loaded = in_pos & ~511u;
+            stage_half();
+            stage_half();
+            refill();
+            take((int)((sp & 3u) * 8u));
+            continue;
+        }
+        if (type == 3u) { err = kInfBadBlockType; break; }
+        if (type == 1u) {
+            // fixed Huffman codes (RFC 1951 3.2.6)
+            for (int s = lane; s < 288; s += 64) s_lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
+            __builtin_amdgcn_wave_barrier();
+            err = build_table<true>(s_lens, 288, kLitRoot, sh.lit, kLitEntries, s_scratch, lane);
+            if (err) break;
+            for (int s = lane; s < 32; s += 64) s_lens[s] = 5;
+            __builtin_amdgcn_wave_barrier();
+            err = build_table<false>(s_lens, 30, kDistRoot, sh.dist, kDistEntries, s_scratch, lane);
+            if (err) break;
+        } else {
+            // dynamic codes: HLIT, HDIST, HCLEN, the code-length code, then the two length lists (RFC 1951 3.2.7)
+            refill();
+            const int hlit = (int)take(5) + 257, hdist = (int)take(5) + 1, hclen = (int)take(4) + 4;
+            if (hlit > 286 || hdist > 30) { err = kInfBadCodeLengths; break; }
+            if (lane < 19) s_lens[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < hclen; ++i) {
+                refill();
+                const uint32_t v = take(3);
+                if (lane == 0) s_lens[kClOrder[i]] = (uint8_t)v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the code-length code decodes through the distance table's space (7 root bits would do; 6 + a second level is fine)
+            err = build_table<false>(s_lens, 19, kDistRoot, sh.dist, kDistEntries, s_scratch, lane);
+            if (err) break;
+            // (build_table<false> stores symbol s < 30 as a distance entry: read the SYMBOL back from its base table index --
+            // simpler: decode lengths with an own loop over the canonical code)
+            // -> re-derive: a compact canonical decode for the 19-symbol code (lengths <= 7)
+            int cl_count[8], cl_first[8], cl_off[8];
+            uint8_t cl_sorted[19];
+            {
+                for (int i = 0; i < 8; ++i) cl_count[i] = 0;
+                for (int s = 0; s < 19; ++s) cl_count[s_lens[s]] += 1;
+                cl_count[0] = 0;
+                int code = 0, off = 0;
+                for (int len = 1; len <= 7; ++len) {
+                    code = (code + cl_count[len - 1]) << 1;
+                    cl_first[len] = code;
+                    cl_off[len] = off;
+                    off += cl_count[len];
+                }
+                int fill[8];
+                for (int i = 0; i < 8; ++i) fill[i] = cl_off[i];
+                for (int s = 0; s < 19; ++s) if (s_lens[s]) cl_sorted[fill[s_lens[s]]++] = (uint8_t)s;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int got = 0, prev = 0;
+            const int want = hlit + hdist;
+            while (got < want && err == kInfOk) {
+                refill();
+                // bit-serial canonical decode (at most 7 bits; ~300 symbols per block)
+                int code = 0, len = 0, sym = -1;
+                for (len = 1; len <= 7; ++len) {
+                    code = (code << 1) | (int)((bb >> (len - 1)) & 1ull);
+                    const int idx = code - cl_first[len];
+                    if (idx >= 0 && idx < cl_count[len]) { sym = cl_sorted[cl_off[len] + idx]; break; }
+                }
+                if (sym < 0) { err = kInfBadCodeLengths; break; }
+                take(len);
+                int rep = 1, val = sym;
+                if (sym == 16) { if (got == 0) { err = kInfBadCodeLengths; break; } rep = 3 + (int)take(2); val = prev; }
+                else if (sym == 17) { rep = 3 + (int)take(3); val = 0; }
+                else if (sym == 18) { rep = 11 + (int)take(7); val = 0; }
+                if (got + rep > want) { err = kInfBadCodeLengths; break; }
+                if (lane == 0) for (int k = 0; k < rep; ++k) s_lens[32 + got + k] = (uint8_t)val;   // (kept clear of the 19 code-length lengths)
+                got += rep;
+                prev = val;
+            }
+            if (err) break;
+            __builtin_amdgcn_wave_barrier();
+            if (s_lens[32 + 256] == 0) { err = kInfBadCodeLengths; break; }     // no end-of-block code
+            err = build_table<true>(s_lens + 32, hlit, kLitRoot, sh.lit, kLitEntries, s_scratch, lane);
+            if (err) break;
+            // the distance lengths follow the literal/length ones: move them to a 4-byte aligned place of their own
+            uint8_t dl = (lane < hdist) ? s_lens[32 + hlit + lane] : 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) s_lens[lane] = dl;
+            __builtin_amdgcn_wave_barrier();
+            err = build_table<false>(s_lens, hdist, kDistRoot, sh.dist, kDistEntries, s_scratch, lane);
+            if (err) break;
+        }
+        // ---- the symbols of the block
+        for (;;) {
+            refill();
+            uint32_t e = sh.lit[(uint32_t)bb & ((1u << kLitRoot) - 1u)];
+            if (((e >> 8) & 3u) == 3u) {
+                const uint32_t sb = (e >> 4) & 15u;
+                e = sh.lit[(e >> 16) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))];
+                bb >>= kLitRoot; nb -= kLitRoot;
+            }
+            const uint32_t nbits = e & 15u;
+            if (nbits == 0u) { err = kInfBadSymbol; break; }
+            bb >>= nbits; nb -= (int)nbits;
+            const uint32_t kind = (e >> 8) & 3u;
+            if (kind == 0u) {                         // literal
+                if (pos >= ulen) { err = kInfOverrun; break; }
+                if (lane == 0) sh.win[pos & (kWinBytes - 1)] = (uint8_t)(e >> 16);
+                pos += 1u;
+            } else if (kind == 2u) {                  // end of block
+                if (e >> 16) err = kInfBadSymbol;
+                break;
+            } else {                                  // length + distance
+                refill();
+                const uint32_t len = (e >> 16) + take((int)((e >> 4) & 15u));
+                refill();
+                uint32_t d = sh.dist[(uint32_t)bb & ((1u << kDistRoot) - 1u)];
+                if (((d >> 8) & 3u) == 3u) {
+                    const uint32_t sb = (d >> 4) & 15u;
+                    d = sh.dist[(d >> 16) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))];
+                    bb >>= kDistRoot; nb -= kDistRoot;
+                }
+                const uint32_t dbits = d & 15u;
+                if (dbits == 0u || ((d >> 8) & 3u) != 0u) { err = kInfBadSymbol; break; }
+                bb >>= dbits; nb -= (int)dbits;
+                refill();
+                const uint32_t dist = (d >> 16) + take((int)((d >> 4) & 15u));
+                if (dist > pos) { err = kInfBadDistance; break; }
+                if (pos + len > ulen) { err = kInfOverrun; break; }
+                __builtin_amdgcn_wave_barrier();
+                // copy: byte k comes from `dist` back; where the match overlaps itself the pattern repeats
+                for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
+                    const uint32_t from = dist >= len ? pos - dist + k : pos - dist + (k % dist);
+                    sh.win[(pos + k) & (kWinBytes - 1)] = sh.win[from & (kWinBytes - 1)];
+                }
+                __builtin_amdgcn_wave_barrier();
+                pos += len;
+            }
+            if (pos - flushed >= (uint32_t)kFlush + 272u) flush_to((flushed + kFlush) & ~15u);   // (keeps 32 KiB - 8 KiB - slack of history)
+        }
+    }
+    if (err == kInfOk && pos != ulen) err = kInfShort;
+    if (err == kInfOk) flush_to(ulen);
+    // CRC-32 of the member is checked by k_bgzf_crc (below) on the inflated bytes in HBM
+    if (lane == 0) status[m] = (uint32_t)err;
+}
+
+// CRC-32 of every member's payload (what bgzf.c verifies, kent/src/htslib/bgzf.c:421-530): one wave per member,
+// 64 contiguous slices, combined in order.  crc(A || B) = shift(crc(A), |B|) ^ crc(B) with the shift by a fixed slice
+// length applied through four 256-entry tables (computed by the host: `shift_tab[4][256]` for slices of kCrcSlice bytes).
+constexpr int kCrcSlice = 1024;
+__global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out, const Member *__restrict__ members, int nmembers,
+                                                 const uint32_t *__restrict__ crc_tab, const uint32_t *__restrict__ shift_tab,
+                                                 uint32_t *__restrict__ status) {
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t part[64];
+    const int m = blockIdx.x;
+    if (m >= nmembers) return;
+    const Member mb = members[m];
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < 256; i += 64) tab[i] = crc_tab[i];
+    __builtin_amdgcn_wave_barrier();
+    // slice 0 takes the odd head, slices 1.. are kCrcSlice bytes each
+    const uint32_t n = mb.ulen;
+    const uint32_t nfull = n / kCrcSlice, head = n - nfull * kCrcSlice;
+    const uint8_t *p = out + mb.uoff;
+    uint32_t crc = 0u;
+    // lane l handles slice l: slice 0 = [0, head) (starts from the all-ones register), slice k >= 1 = [head + (k-1) S, head + k S)
+    // (from a zero register: the CRC of a message part under the linear part of the recurrence)
+    if (lane == 0) {
+        crc = 0xffffffffu;
+        for (uint32_t i = 0; i < head; ++i) crc = crc_byte(tab, crc, p[i]);
+    } else if ((uint32_t)lane <= nfull) {
+        const uint8_t *q = p + head + (size_t)(lane - 1) * kCrcSlice;
+        for (int i = 0; i < kCrcSlice; ++i) crc = crc_byte(tab, crc, q[i]);
+    }
+    part[lane] = crc;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        uint32_t c = part[0];
+        for (uint32_t k = 1; k <= nfull && k < 64; ++k) {
+            // advance c over kCrcSlice zero bytes, then add the slice's own remainder
+            c = shift_tab[c & 0xffu] ^ shift_tab[256 + ((c >> 8) & 0xffu)] ^ shift_tab[512 + ((c >> 16) & 0xffu)] ^ shift_tab[768 + (c >> 24)];
+            c ^= part[k];
+        }
+        c ^= 0xffffffffu;
+        if (status[m] == 0u && c != mb.crc) status[m] = (uint32_t)kInfCrc;
+    }
+}
+
+// ---------------------------------------------------------------- BAM records
+// Does a BAM record plausibly start at `q` (bytes available: avail)?  The checks the host's guess makes
+// (bam_stager.cpp guess_record_start): a length prefix that holds the fixed fields, name, CIGAR, sequence and
+// qualities; a reference id in range; a position that is a position.
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+__device__ __forceinline__ bool plausible_record(const uint8_t *q, uint64_t avail, uint32_t n_ref) {
+    if (avail < 36) return false;
+    const uint32_t bs = ld32(q);
+    if (bs < 32 || bs > (1u << 26)) return false;
+    const int32_t tid = (int32_t)ld32(q + 4), pos = (int32_t)ld32(q + 8);
+    if (tid < -1 || tid >= (int32_t)n_ref || pos < -1) return false;
+    const uint32_t l_name = q[12], n_cig = ld16(q + 16), l_seq = ld32(q + 20);
+    if (l_name == 0 || l_seq > (1u << 26)) return false;
+    const int32_t ntid = (int32_t)ld32(q + 24), npos = (int32_t)ld32(q + 28);
+    if (ntid < -1 || ntid >= (int32_t)n_ref || npos < -1) return false;
+    return (uint64_t)32 + l_name + 4ull * n_cig + (l_seq + 1) / 2 + l_seq <= bs;
+}
+
+constexpr int kMaxRecPerMember = 1824;   // 65536 / 36 + 3: a record takes at least 36 bytes of the stream
+constexpr int kGuessChain = 3;           // records in a row that have to look like records
+
+struct MemberChain {
+    uint64_t first;      // stream offset of the first record start at or behind the member's begin (guessed or given)
+    uint64_t next;       // where the chain from `first` leaves the member: the first record start at or behind its end
+    uint32_t nrec;       // record starts in [first, member end)
+    uint32_t flags;      // 1: no plausible start found, 2: a length prefix below the fixed fields met on the way
+};
+
+// One wave per member.  forced[m] != ~0: start there instead of guessing (the host found that the preceding member's
+// chain ends there).  rec_off[m * kMaxRecPerMember + k] = offset of record k relative to the member's begin.
+__global__ __launch_bounds__(64) void k_bam_chain(const uint8_t *__restrict__ stream, uint64_t stream_len, const Member *__restrict__ members,
+                                                  int nmembers, uint32_t n_ref, uint64_t first_record, const uint64_t *__restrict__ forced,
+                                                  MemberChain *chain, uint32_t *rec_off) {
+    const int m = blockIdx.x;
+    if (m >= nmembers) return;
+    const int lane = threadIdx.x & 63;
+    const Member mb = members[m];
+    const uint64_t begin = mb.uoff, end = mb.uoff + mb.ulen;
+    MemberChain mc;
+    mc.first = ~0ull; mc.next = ~0ull; mc.nrec = 0; mc.flags = 0;
+    uint64_t start = forced[m];
+    if (start == ~0ull && first_record >= begin && first_record < end) start = first_record;   // the member that holds the end of the header
+    if (start == ~0ull && end <= first_record) {   // header only: nothing starts here
+        if (lane == 0) { mc.first = first_record; mc.next = first_record; chain[m] = mc; }
+        return;
+    }
+    if (start == ~0ull) {
+        // guess: lanes try consecutive offsets, 64 at a time; the first offset from which kGuessChain records chain
+        for (uint64_t base = begin; base < end && start == ~0ull; base += 64) {
+            const uint64_t o = base + (uint64_t)lane;
+            bool ok = o < end;
+            uint64_t q = o;
+            for (int k = 0; k < kGuessChain && ok; ++k) {
+                if (q >= stream_len) break;                      // chained to the end of the stream: fine
+                ok = plausible_record(stream + q, stream_len - q, n_ref) && q + 4 + ld32(stream + q) <= stream_len;
+                if (ok) q += 4 + (uint64_t)ld32(stream + q);
+            }
+            const unsigned long long hit = __ballot(ok);
+            if (hit) start = base + (uint64_t)__builtin_ctzll(hit);
+        }
+        if (start == ~0ull) {   // no record starts in this member (one record spans it)
+            if (lane == 0) { mc.flags = 1u; chain[m] = mc; }
+            return;
+        }
+    }
+    // walk the chain (uniform)
+    uint64_t q = start;
+    uint32_t n = 0;
+    while (q < end) {
+        if (q + 4 > stream_len) { mc.flags |= 2u; break; }   // a length prefix cut by the end of the stream
+        const uint32_t bs = ld32(stream + q);
+        if (n < (uint32_t)kMaxRecPerMember && lane == 0) rec_off[(size_t)m * kMaxRecPerMember + n] = (uint32_t)(q - begin);
+        ++n;
+        if (bs < 32) { mc.flags |= 2u; break; }              // (the record decode reports it)
+        q += 4 + (uint64_t)bs;
+    }
+    if (lane == 0) { mc.first = start; mc.next = q; mc.nrec = n; chain[m] = mc; }
+}
+
+// error codes of the record decode, in the order the host's serial walk checks them (bam_stager.cpp decode_span_cols)
+enum { kRecOk = 0, kRecTruncated = 1, kRecBadSize = 2, kRecTidRange = 3, kRecNegPos = 4, kRecUnsorted = 5, kRecCigarOverrun = 6,
+       kRecUnknownOp = 7, kRecEndBeyond = 8, kRecTooLong = 9, kRecDeletionOrder = 10 };
+
+struct RecOut {
+    int32_t tid, spos, pos;     // reference id, first aligned position (the sort key of the packed format), POS field
+    uint32_t L;                 // aligned positions
+    uint32_t nruns;             // maximal runs of aligned positions
+    uint16_t flag;
+    uint8_t err;
+    uint8_t placed;
+};
+
+// One thread per record start (member-major, k_bam_chain's order): fields and CIGAR -> RecOut.
+__global__ __launch_bounds__(256) void k_bam_fields(const uint8_t *__restrict__ stream, uint64_t stream_len, const Member *__restrict__ members,
+                                                    const uint64_t *__restrict__ rec_base, const MemberChain *__restrict__ chain,
+                                                    const uint32_t *__restrict__ rec_off, int nmembers, int64_t nrec, uint32_t n_ref,
+                                                    const uint32_t *__restrict__ rec_member, RecOut *recs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrec) return;
+    // member of record i: rec_member holds it for every 256-record group start; walk forward from there
+    int m = (int)rec_member[i >> 8];
+    while (m + 1 < nmembers && (int64_t)rec_base[m + 1] <= i) ++m;
+    const uint64_t q = members[m].uoff + rec_off[(size_t)m * kMaxRecPerMember + (size_t)(i - (int64_t)rec_base[m])];
+    RecOut o;
+    o.tid = -1; o.spos = 0; o.pos = 0; o.L = 0; o.nruns = 0; o.flag = 0; o.err = kRecOk; o.placed = 0;
+    if (q + 4 > stream_len) { o.err = kRecTruncated; recs[i] = o; return; }
+    const uint32_t bs = ld32(stream + q);
+    if (bs < 32) { o.err = kRecBadSize; recs[i] = o; return; }
+    if (q + 4 + (uint64_t)bs > stream_len) { o.err = kRecTruncated; recs[i] = o; return; }
+    const uint8_t *r = stream + q + 4;
+    const int32_t tid = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
+    const uint32_t l_name = r[8], n_cig = ld16(r + 12);
+    o.flag = (uint16_t)ld16(r + 14);
+    o.tid = tid; o.pos = pos; o.spos = pos;
+    if (tid < 0) { recs[i] = o; return; }                   // unplaced: counted, not staged
+    o.placed = 1;
+    if (tid >= (int32_t)n_ref) { o.err = kRecTidRange; recs[i] = o; return; }
+    if (pos < 0) { o.err = kRecNegPos; recs[i] = o; return; }
+    if ((uint64_t)32 + l_name + 4ull * n_cig > bs) { o.err = kRecCigarOverrun; recs[i] = o; return; }
+    const uint8_t *cig = r + 32 + l_name;
+    int64_t ref = pos, L = 0, run_end = -1;
+    int32_t first_run = -1;
+    uint32_t nruns = 0;
+    for (uint32_t c = 0; c < n_cig; ++c) {
+        const uint32_t v = ld32(cig + 4 * c), op = v & 15u, len = v >> 4;
+        if (op == 0u || op == 7u || op == 8u) {             // M = X: aligned positions
+            if (len) {
+                if (run_end != ref) { ++nruns; if (first_run < 0) first_run = (int32_t)ref; }
+                ref += len; L += len; run_end = ref;
+            }
+        } else if (op == 2u || op == 3u) ref += len;        // D N: reference only
+        else if (op == 1u || op == 4u || op == 5u || op == 6u) {}   // I S H P
+        else { o.err = kRecUnknownOp; break; }
+    }
+    if (o.err == kRecOk && ref > 0x7fffffffLL) o.err = kRecEndBeyond;
+    if (o.err == kRecOk && L > 0x7fffffffLL) o.err = kRecTooLong;
+    o.L = (uint32_t)L; o.nruns = nruns;
+    if (nruns) o.spos = first_run;
+    recs[i] = o;
+}
+
+// order checks between neighbours (the host's serial walk: sorted by (tid, POS), unplaced reads last, and the first
+// aligned positions in order too) + the lowest record index with a defect
+__global__ __launch_bounds__(256) void k_bam_order(const RecOut *__restrict__ recs, int64_t nrec, const uint32_t *__restrict__ placed_before,
+                                                   unsigned long long *first_err) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrec) return;
+    const RecOut o = recs[i];
+    uint32_t err = o.err;
+    if (o.placed && (err == kRecOk || err >= kRecCigarOverrun)) {
+        // previous PLACED record (placed records are contiguous in a valid file: an unplaced one in between is the defect)
+        if (i > 0) {
+            const RecOut pr = recs[i - 1];
+            uint32_t oerr = 0;
+            if (!pr.placed) oerr = kRecUnsorted;                               // a placed record behind an unplaced one
+            else if (o.tid < pr.tid || (o.tid == pr.tid && o.pos < pr.pos)) oerr = kRecUnsorted;
+            else if (pr.err == kRecOk && o.tid == pr.tid && pr.spos > o.spos && err == kRecOk) oerr = kRecDeletionOrder;
+            if (oerr == kRecUnsorted) err = kRecUnsorted;                      // checked before the record's own CIGAR
+            else if (oerr && err == kRecOk) err = oerr;
+        }
+    }
+    if (err) atomicMin(first_err, ((unsigned long long)i << 8) | (unsigned long long)err);
+}
+
+// columns of the staged (placed) records at their scanned indices; runs of the multi-run records at theirs
+__global__ __launch_bounds__(256) void k_bam_columns(const uint8_t *__restrict__ stream, const Member *__restrict__ members,
+                                                     const uint64_t *__restrict__ rec_base, const uint32_t *__restrict__ rec_off, int nmembers,
+                                                     const uint32_t *__restrict__ rec_member, const RecOut *__restrict__ recs, int64_t nrec,
+                                                     const uint32_t *__restrict__ staged_at, const uint32_t *__restrict__ run_at,
+                                                     int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags, uint8_t *nblk,
+                                                     int32_t *blk_start, int32_t *blk_len, uint32_t *wide_flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrec) return;
+    const RecOut o = recs[i];
+    if (!o.placed) return;
+    const uint32_t k = staged_at[i];
+    const bool wide = o.L > 65535u || o.nruns > 255u || (o.L == 65535u && o.nruns == 255u);
+    tid[k] = o.tid;
+    pos[k] = o.spos;
+    alen[k] = wide ? (uint16_t)65535 : (uint16_t)o.L;
+    flags[k] = (o.flag & 0x10) ? 1 : 0;
+    nblk[k] = wide ? (uint8_t)255 : (uint8_t)o.nruns;
+    if (wide) wide_flag[k] = 1u;
+    if (o.nruns < 2u) return;
+    int m = (int)rec_member[i >> 8];
+    while (m + 1 < nmembers && (int64_t)rec_base[m + 1] <= i) ++m;
+    const uint8_t *r = stream + members[m].uoff + rec_off[(size_t)m * kMaxRecPerMember + (size_t)(i - (int64_t)rec_base[m])] + 4;
+    const uint32_t l_name = r[8], n_cig = ld16(r + 12);
+    const uint8_t *cig = r + 32 + l_name;
+    int64_t ref = o.pos, run_end = -1;
+    int64_t w = (int64_t)run_at[i] - 1;
+    for (uint32_t c = 0; c < n_cig; ++c) {
+        const uint32_t v = ld32(cig + 4 * c), op = v & 15u, len = v >> 4;
+        if (op == 0u || op == 7u || op == 8u) {
+            if (len) {
+                if (run_end != ref) { ++w; blk_start[w] = (int32_t)ref; blk_len[w] = 0; }
+                blk_len[w] += (int32_t)len;
+                ref += len; run_end = ref;
+            }
+        } else if (op == 2u || op == 3u) ref += len;
+    }
+}
+
+// per-record scan inputs: staged (placed) flag and the runs a multi-run record keeps
+__global__ __launch_bounds__(256) void k_bam_scan_inputs(const RecOut *__restrict__ recs, int64_t nrec, uint32_t *placed, uint32_t *runs,
+                                                         unsigned long long *counts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t pl = 0, rn = 0, mapped = 0;
+    if (i < nrec) {
+        const RecOut o = recs[i];
+        pl = o.placed;
+        rn = (o.placed && o.nruns >= 2u) ? o.nruns : 0u;
+        mapped = (o.flag & 0x4) ? 0u : 1u;
+        placed[i] = pl;
+        runs[i] = rn;
+    }
+    // counts[0] mapped (flag 0x4 unset), counts[1] unplaced
+    unsigned long long a = mapped, b = (i < nrec && !pl) ? 1ull : 0ull;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) { a += __shfl_down(a, o2, 64); b += __shfl_down(b, o2, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&counts[0], a);
+        if (b) atomicAdd(&counts[1], b);
+    }
+}
+
+} // namespace pcbam

@@ -89,8 +89,13 @@ public:
     // runs f(0) ... f(n - 1), f(0) on the calling thread; false (nothing done) when the pool is in use
     bool run(int n, const std::function<void(int)> &f) {
         if (getpid() != pid_) return false;   // a forked child has the pool's bookkeeping but not its threads
+        // a region nested inside a job of this pool: worker 0 of the outer region is the thread that owns gate_, and
+        // try_lock on a mutex the caller already owns is undefined -- every thread that runs a job says so itself
+        static thread_local bool in_region = false;
+        if (in_region) return false;
         std::unique_lock<std::mutex> region(gate_, std::try_to_lock);
         if (!region.owns_lock()) return false;
+        struct Mark { bool &f; explicit Mark(bool &x) : f(x) { f = true; } ~Mark() { f = false; } } mark(in_region);
         {
             std::lock_guard<std::mutex> lk(m_);
             while ((int)workers_.size() < n - 1) {

@@ -20,7 +20,7 @@
 //                                                                         (:308-367,:407-466,:585-650,:724-780)
 //   k_gather_split  lays out windows that were split into several work items
 //   k_cs_count / k_cs_scatter   center streams: the aligned runs of the reads a strand selection keeps, record order
-//   k_center_vals / k_center_weigh / k_center_order / k_center   CenterMapFactory, ordered float64 replay (:200-265)
+//   k_center_weigh / k_center_order / k_center   CenterMapFactory, ordered float64 replay (:200-265)
 //                   + SegmentChain.get_counts layout + normalisation    (roitools.pyx:3259-3271, genome_array.py:826-830)
 //   k_rle_*         run-length encoding of an output vector (export, genome_array.py:990-1111)
 //   k_total_*       sum of an output vector (multi-GPU summary totals)
@@ -120,7 +120,6 @@ struct FileView {
     // center streams (see k_center): entries and entries-before-record per strand selection (forward / reverse / all reads)
     const uint2 *cs_ent[3];
     const uint32_t *cs_soff[3];
-    int32_t c_lbase;                // first aligned length of the center rule's SGPR value table
     // wide records: true {aligned length, run count} per long-list entry (nullptr: the file has none) and by record index
     const uint2 *long_wide;
     const uint2 *xlong_wide;
@@ -169,7 +168,6 @@ struct GFile {
     const i32x4 PC_GLOBAL *xlong_runs;
     const uint32_t PC_GLOBAL *xllin_tab;
     const uint32_t PC_GLOBAL *xplin_tab;
-    int32_t c_lbase;
     const u32x2 PC_GLOBAL *long_wide;
     const u32x2 PC_GLOBAL *xlong_wide;
     const uint32_t PC_GLOBAL *wide_rec;
@@ -209,7 +207,7 @@ __device__ __forceinline__ GFile gfile(const FileView &v) {
     g.xlong_runs = (const i32x4 PC_GLOBAL *)v.xlong_runs;
     g.xllin_tab = (const uint32_t PC_GLOBAL *)v.xllin_tab;
     g.xplin_tab = (const uint32_t PC_GLOBAL *)v.xplin_tab;
-    g.c_lbase = v.c_lbase;   // (the center streams are picked by a run-time index: read from the FileView in memory, cs_stream)
+    // (the center streams are picked by a run-time index: read from the FileView in memory, cs_stream)
     g.long_wide = (const u32x2 PC_GLOBAL *)v.long_wide;
     g.xlong_wide = (const u32x2 PC_GLOBAL *)v.xlong_wide;
     g.wide_rec = (const uint32_t PC_GLOBAL *)v.wide_rec;
@@ -1436,7 +1434,7 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
                                                       uint32_t *hist, int64_t hist_row_stride,
                                                       typename OutT_<OUTMODE>::type *out, double norm_sum,
                                                       uint32_t launched_heavy, uint32_t launched_light, uint32_t launched_small,
-                                                      uint32_t *grid_error) {
+                                                      uint32_t work_cap, uint32_t *grid_error) {
     __shared__ uint32_t s_list[kWG];
     __shared__ uint32_t s_n;
     if (blockIdx.x == 0 && threadIdx.x < 4) {
@@ -1444,6 +1442,9 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
         // this plan left (0xffffffff: the whole capacity was launched); if this count queued more, items went unserved
         const uint32_t launched = threadIdx.x == 0 ? launched_heavy : (threadIdx.x == 1 ? launched_light : (threadIdx.x == 2 ? launched_small : 0xffffffffu));
         if (launched != 0xffffffffu && counters[threadIdx.x] > launched) atomicOr(grid_error, 1u);
+        // guard of the list capacity: heavy items fill the list from the front, light ones from the back; more of them
+        // than slots means the two ends overwrote each other (k_tile_ranges only keeps its writes inside the list)
+        if (threadIdx.x == 0 && (uint64_t)counters[0] + (uint64_t)counters[1] > (uint64_t)work_cap) atomicOr(grid_error, 2u);
     }
     if (per_wg == 1) {
         if (tile_items[blockIdx.x] == 0u) return; // only windows that were merged through the histogram
@@ -1466,18 +1467,29 @@ __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ t
 // CenterMapFactory: count[p] is the left-to-right float64 sum, in read order, of
 // 1/(L-2*nibble) over the reads whose trimmed positions contain p.  The order is
 // part of the contract (the reference's own test demands exact equality), so
-// there are no atomics: one lane owns one output position and replays, in record
-// order, every read that can cover it.  One wave per chunk of <= 64 positions.
+// there are no atomics and no re-association: one lane owns one output position and
+// replays, in record order, every read that can cover it.
 //
-// Round 3: the candidates come from a CENTER STREAM (below) -- one 8-byte entry per aligned run of every read a
-// strand mode keeps, in record order, host-excluded reads left out -- so a wave never filters or compacts: a batch of
-// 64 entries arrives with one coalesced load (lane j holds entry j), every lane derives the covered interval of its
-// entry, and entry j is then broadcast with two v_readlane.  1/m comes from a 16-entry table held in SGPRs
-// (s_movrels_b64), the covering test of four entries is computed ahead into SGPR pairs (v_cmp), and the ordered
-// accumulation is  s_mov_b64 exec, mask ; v_add_f64 acc, acc, 1/m  -- lanes outside the mask keep their sum, which is
-// the reference's conditional add bit for bit.  No LDS at all (round 2's kernel spent 80 % of the launch on one
-// 16-byte LDS broadcast read per entry and wave), 5 vector + 3 scalar instructions per entry (scripts/ubench/
-// scalar_stream_probe.hip: 23 SIMD-cycles per entry at full occupancy, 45 for a wave that runs alone).
+// Round 4: FOUR ordered replays per wave, one per 16-lane row.  A wave still owns a chunk of <= 64 positions, but every
+// row of 16 lanes owns 16 of them and walks ITS OWN stretch of the center stream (below): the entries of the records
+// that start in [row start - W + 1, row end).  A row of 16 positions has to look at (16 + W - 1) positions' worth of
+// reads, a wave of 64 at (64 + W - 1) -- with 30-nt reads that is 50 against 98 -- and the four rows advance together:
+// one step applies entry j of every row to that row's lanes.  Every lane prepares ONE entry per batch of 16 steps:
+// its 16-bit coverage mask of the row (bit i: position i of the row is counted) and half its value, 0.5 / (L - 2 nibble).
+// The entry is then broadcast INSIDE its row by DPP (row_newbcast:j -- lane j of each row to all 16 lanes of the
+// row), fused into the instructions that use it, so a step is three vector instructions and nothing else:
+//     v_and_b32_dpp   x, cm, lbit          x      = cm[j] & (1 << lane)        covered: 1 << lane, else 0
+//     v_lshlrev_b32   one.hi, 30 - lane, x   one = covered ? 2.0 : 0.0           (0x40000000 is the high word of 2.0)
+//     v_fmac_f64_dpp  acc, valh, one       acc    = fma(valh[j], one, acc)
+// fma(val / 2, 2.0, acc) rounds val + acc once -- the reference's `count[c] += val` bit for bit (halving and doubling
+// are exact) -- and fma(val / 2, 0.0, acc) is acc: the conditional add without touching exec.  No scalar
+// instruction, no LDS, no v_readlane in the loop.  Why this form (scripts/ubench/valu_cost_probe.hip, center_dpp_probe.hip,
+// cycles per instruction and SIMD at eight waves): only plain 32-bit VOP1/VOP2 instructions issue at 2 cycles; DPP,
+// SDWA, VOP3 encodings, an SGPR or carry operand cost 4 (a DPP on an f64 instruction is free), the CU's ONE scalar
+// unit serves each SIMD every 4 cycles -- round 3's replay (3 SALU + 3.25 VALU + the add per entry) ran at 19.5 cycles
+// per entry, a compare-and-select step (sub, borrow, cndmask, fmac) at 21, this one at 12.  (A DPP *rev* opcode
+// broadcasts its SECOND source on gfx950 -- v_subrev_u32_dpp d, a, b = dpp(b) - a, dpp_semantics.hip -- the AND is
+// commutative.)
 
 // wave-uniform value of lane `j` of a per-lane register (j uniform)
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
@@ -1496,14 +1508,16 @@ constexpr int kCenterWG = PC_CENTER_WG;
 
 // Center stream of a staged file and a strand selection (0: forward reads, 1: reverse reads, 2: all reads), built
 // on the GPU at the first center-rule count of the file and again when the host-side filters change:
-//   cs_ent[k] = {x, y}: x = first position of an aligned run; y = run length | read index of the run's first base << 8
-//               | aligned length L of the read << 16 | flags << 24.  A read contributes its runs consecutively, reads in
-//               record order; reads the selection drops, host-excluded reads and reads without aligned bases have no
-//               entry.  flags bit 0 (kCsIndirect): the read does not fit the 8-bit fields (L > 255) -- one entry,
-//               x = its record index.
+//   cs_ent[k] = {x, y}: one entry per aligned run of a read, ALREADY TRIMMED by the rule's nibble: x = first counted
+//               position of the run, y = counted positions m (0: the nibble leaves nothing of this run) | aligned length
+//               L of the read << 16 | flags << 24.  (CenterMapFactory counts read indices [nibble, L - nibble),
+//               map_factories.pyx:250-254; a run whose first base is read index `cum` keeps [max(cum, nibble),
+//               min(cum + len, L - nibble)).)  A read contributes its runs consecutively, reads in record order; reads the
+//               selection drops, host-excluded reads and reads without aligned bases have no entry.  flags bit 0
+//               (kCsIndirect): the read does not fit the 8-bit fields (L > 255) -- one entry, x = its record index.
+//               The entries depend on the nibble: a change of the rule's parameter re-runs k_cs_scatter (not the scan).
 //   cs_soff[i] = entries before record i (cs_soff[n] = all): turns a record range into an entry range.
 constexpr uint32_t kCsIndirect = 1u;
-constexpr int kCTab = 16;   // aligned lengths [c_lbase, c_lbase + kCTab) have their 1/m in the SGPR table; others take a slower path
 
 __device__ __forceinline__ uint32_t cs_entries_of(uint32_t meta, int sel) {
     const uint32_t fl = rec_flags(meta);
@@ -1519,7 +1533,7 @@ __global__ __launch_bounds__(kWG) void k_cs_count(const uint2 *__restrict__ rec,
 }
 
 __global__ __launch_bounds__(kWG) void k_cs_scatter(const uint2 *__restrict__ rec, const uint32_t *__restrict__ blk_off,
-                                                    const int2 *__restrict__ blk, int64_t n, int sel,
+                                                    const int2 *__restrict__ blk, int64_t n, int sel, int nib,
                                                     const uint32_t *__restrict__ soff, uint2 *ent) {
     const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (i >= n) {   // padding behind the last entry: entries that cover nothing (whole batches can always be loaded)
@@ -1532,31 +1546,35 @@ __global__ __launch_bounds__(kWG) void k_cs_scatter(const uint2 *__restrict__ re
     uint2 *dst = ent + soff[i];
     const uint32_t L = (uint32_t)rec_len(r.y);
     if (L > 255u) { dst[0] = make_uint2((uint32_t)i, kCsIndirect << 24); return; }
-    if (rec_nblk(r.y) < 2) { dst[0] = make_uint2(r.x, L | (L << 16)); return; }
+    // run [start, start + len) holding read indices [cum, cum + len): what the nibble leaves of it
+    auto entry = [&](int32_t start, int len, int cum) {
+        const int lo_i = cum > nib ? cum : nib, hi_i = cum + len < (int)L - nib ? cum + len : (int)L - nib;
+        const int m = hi_i > lo_i ? hi_i - lo_i : 0;
+        return make_uint2((uint32_t)(start + (lo_i - cum)), (uint32_t)m | (L << 16));
+    };
+    if (rec_nblk(r.y) < 2) { dst[0] = entry((int32_t)r.x, (int)L, 0); return; }
     const int2 *b = blk + blk_off[i];
-    uint32_t cum = 0;
+    int cum = 0;
     for (uint32_t q = 0; q < k; ++q) {
         const int2 run = b[q];
-        dst[q] = make_uint2((uint32_t)run.x, (uint32_t)run.y | (cum << 8) | (L << 16));
-        cum += (uint32_t)run.y;
+        dst[q] = entry(run.x, run.y, cum);
+        cum += run.y;
     }
 }
 
-// 1.0 / map_length for the lengths of every file's SGPR table (0.0 where the read is not counted: size filter,
-// map length <= 0 -- adding +0.0 never changes a sum that starts at +0.0 and only grows)
-__global__ void k_center_vals(const FileView *__restrict__ files, int nfiles, MapParams mp, const double *__restrict__ inv, double *cval) {
-    const int t = (int)threadIdx.x;
-    if (t >= nfiles * kCTab) return;
-    const int L = files[t / kCTab].c_lbase + t % kCTab, m = L - 2 * mp.param;
-    cval[t] = (m > 0 && m < 65536 && size_ok(mp, L)) ? inv[m] : 0.0;
+// half the value of a read by aligned length, for the lengths a stream entry can carry: 0.5 / (L - 2 nibble), or 0.0
+// where the read is not counted (size filter, nothing left by the nibble: adding +0.0 never changes a sum)
+__global__ void k_center_vals(MapParams mp, const double *__restrict__ invh, double *cvalh) {
+    const int L = (int)threadIdx.x, m = L - 2 * mp.param;
+    if (L < 256) cvalh[L] = (m > 0 && size_ok(mp, L)) ? invh[m] : 0.0;
 }
 
 // Dispatch list of the center kernel.  A chunk's replay is sequential in the reads that overlap
 // it (the order is the contract), so its time is proportional to that count, and expression is
 // heavy-tailed: the kernel would wait for the chunks over the deepest pile-up.  Two measures:
 //   * chunks with many candidates are CUT into 4 or 8 sub-chunks of 16 / 8 positions, one wave
-//     each: a wave then replays the reads over (8 + L) instead of (64 + L) positions -- the
-//     critical path shrinks 2-2.5x for idle lanes in a few waves;
+//     each, whose rows own 4 / 2 positions: a row then replays the reads over (4 + W) or (2 + W) instead of
+//     (16 + W) positions -- the critical path shrinks for idle lanes in a few waves;
 //   * those entries are queued first (longest-first in two classes, as for the histogram work
 //     list): list[0 .. nheavy) heavy, list[cap-1 .. cap-nlight] light, cap = kCenterCap * nchunks.
 // Thresholds are relative to the mean candidate count (pass 1 sums it), so by Markov's
@@ -1572,7 +1590,8 @@ __device__ __forceinline__ const uint32_t PC_GLOBAL *cs_offsets(const FileView *
 
 // pass 1 (one THREAD per chunk): per file the EXACT record range of the chunk's near window -- first record that
 // starts at or after start - W + 1, first record that starts at or after the chunk's end (index bucket, then a
-// bisection inside it) -- and the candidate range of the long-span list; all the dependent index lookups happen
+// bisection inside it) -- the entry ranges of its four rows of 16 positions (bisections inside that record range),
+// and the candidate range of the long-span list; all the dependent index lookups happen
 // here, once, instead of at the head of every wave of k_center.  The candidate count (stream entries of the near
 // window) and its sum (counters[2..3] as one 64-bit value) feed the dispatch order.
 __device__ __forceinline__ int64_t bucket_lower_bound(const GFile &fv, int64_t q0, int64_t nb, int64_t key) {
@@ -1582,9 +1601,10 @@ __device__ __forceinline__ int64_t bucket_lower_bound(const GFile &fv, int64_t q
     return lower_bound_pos(fv.rec, fv.lin_tab[q0 + b], fv.lin_tab[q0 + b1], key);
 }
 
+constexpr int kCenterRows = 4;        // 16-lane rows of a wave: independent replays
 __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                             const FileView *__restrict__ files, int nfiles, int W,
-                                                            uint32_t *cand_out, u32x4 *ranges, u32x2 *rec_ranges,
+                                                            uint32_t *cand_out, u32x4 *ranges, u32x2 *rec_ranges, uint32_t *row_ranges,
                                                             unsigned long long *total) {
     const int64_t c = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
     unsigned long long cand = 0;
@@ -1611,6 +1631,22 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
             }
             ranges[c * nfiles + f] = rg;
             rec_ranges[c * nfiles + f] = rr;
+            // rows: [first entry of the records that start at or after row start - W + 1, ... at or after row end)
+            uint32_t *rt = row_ranges + (size_t)(c * nfiles + f) * (2 * kCenterRows);
+            int64_t from = rr.x;
+            for (int r = 0; r < kCenterRows; ++r) {
+                const int64_t rs = (int64_t)ck.start + 16 * r;
+                if (rs >= cend) { rt[r] = rg.y; continue; }
+                from = r == 0 ? (int64_t)rr.x : lower_bound_pos(fv.rec, from, rr.y, rs - W + 1);
+                rt[r] = soff[from];
+            }
+            from = rr.x;
+            for (int r = 0; r < kCenterRows; ++r) {
+                const int64_t rs = (int64_t)ck.start + 16 * r, re = rs + 16 < cend ? rs + 16 : cend;
+                if (rs >= cend) { rt[kCenterRows + r] = rg.y; continue; }
+                from = re >= cend ? (int64_t)rr.y : lower_bound_pos(fv.rec, from, rr.y, re);
+                rt[kCenterRows + r] = soff[from];
+            }
             cand += rg.y - rg.x;
         }
         cand_out[c] = (uint32_t)(cand > 0xffffffffull ? 0xffffffffull : cand);
@@ -1633,8 +1669,8 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
     const int64_t th_whole = 8 * mean > floor_whole ? 8 * mean : floor_whole;       // starts early, but stays whole
     const int64_t cand = live ? (int64_t)cand_in[c] : 0;
     // entries a chunk puts at the FRONT of the list: 8 / 4 sub-chunks, 1 = the whole chunk (heavy but
-    // below the cut threshold: cutting multiplies the work -- eight sub-chunks scan 8 x (8 + L)
-    // positions' worth of reads instead of 64 + L -- so only the deepest pile-ups, whose sequential
+    // below the cut threshold: cutting multiplies the work -- eight sub-chunks scan 8 x 4 x (2 + W)
+    // positions' worth of reads instead of 4 x (16 + W) -- so only the deepest pile-ups, whose sequential
     // replay would otherwise outlast the rest of the launch, are cut); 0 = light, queued from the back
     const uint32_t nsub = !live ? 0u : (cand > t2 ? 8u : (cand > t1 ? 4u : (cand > th_whole ? 1u : 0u)));
     uint32_t th, tl;
@@ -1657,8 +1693,9 @@ __global__ __launch_bounds__(kRangesWG) void k_center_order(const uint32_t *__re
     }
 }
 
-// One read replayed from its record header (wave-uniform arguments): reads that come from the long-span list, and
-// reads the 8-bit fields of a stream entry cannot describe.  CenterMapFactory.__call__, map_factories.pyx:242-256.
+// One read replayed from its record header (wave-uniform arguments): reads that come from the long-span list with more
+// than two runs, and reads the 8-bit fields of a stream entry cannot describe.  CenterMapFactory.__call__,
+// map_factories.pyx:242-256.
 __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp, const double PC_GLOBAL *inv, int32_t pos,
                                             int L, int nbk, uint32_t boff, int32_t p, double &acc) {
     const int nib = mp.param;
@@ -1681,239 +1718,223 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
     acc += hit ? val : 0.0;                                  // :254, one IEEE add per covering read, in order
 }
 
-// Replay of a batch.  Lanes j of vlo / vhi / vix hold entry j's 64-bit mask of covered lanes and its table index x 2.
-// Per entry: v_readlane of the two mask halves (and, once per four entries, of their packed table indices), s_bfe m0 +
-// s_movrels_b64 (1/m out of the SGPR table), then  s_mov_b64 exec, mask ; v_add_f64 acc, acc, 1/m  -- 3.25 vector + 3
-// scalar instructions.  Entries go in
-// groups of four, software-pipelined: the twelve v_readlane of group g+1 are issued before the adds of group g and
-// its table look-ups between them, so that a wave that runs alone (the deepest pile-up is the launch's critical
-// path) does not wait for a VALU-written SGPR at every step (scripts/ubench/scalar_stream_probe.hip, forms Ma / Mb /
-// Mc: 57 / 42 / 38 cycles per entry for one wave alone, 19 at full occupancy).
-// Fixed registers: the value table in s[42:73], two sets of four masks in s[74:89] -- k_center is compiled for 48
-// SGPRs (s0 - s41 + the six special ones), so the compiler never allocates them, and the kernel as a whole stays
-// within 96: eight waves per SIMD.
-#define PC_C_RL_IDX(S, J0, J1, J2, J3) "v_readlane_b32 %[si" #S "], %[vix], " #J0 "\n\t"
-#define PC_C_MASKS_A(J0, J1, J2, J3)                                                                                   \
-    "v_readlane_b32 s74, %[vlo], " #J0 "\n\tv_readlane_b32 s75, %[vhi], " #J0 "\n\t"                                    \
-    "v_readlane_b32 s76, %[vlo], " #J1 "\n\tv_readlane_b32 s77, %[vhi], " #J1 "\n\t"                                    \
-    "v_readlane_b32 s78, %[vlo], " #J2 "\n\tv_readlane_b32 s79, %[vhi], " #J2 "\n\t"                                    \
-    "v_readlane_b32 s80, %[vlo], " #J3 "\n\tv_readlane_b32 s81, %[vhi], " #J3 "\n\t"
-#define PC_C_MASKS_B(J0, J1, J2, J3)                                                                                   \
-    "v_readlane_b32 s82, %[vlo], " #J0 "\n\tv_readlane_b32 s83, %[vhi], " #J0 "\n\t"                                    \
-    "v_readlane_b32 s84, %[vlo], " #J1 "\n\tv_readlane_b32 s85, %[vhi], " #J1 "\n\t"                                    \
-    "v_readlane_b32 s86, %[vlo], " #J2 "\n\tv_readlane_b32 s87, %[vhi], " #J2 "\n\t"                                    \
-    "v_readlane_b32 s88, %[vlo], " #J3 "\n\tv_readlane_b32 s89, %[vhi], " #J3 "\n\t"
-// (an instruction has to sit between a scalar write of m0 and s_movrels)
-#define PC_C_M0(S, K) "s_bfe_u32 m0, %[si" #S "], 0x80000 + 8 * " #K "\n\t"   /* byte K of the group's index word: offset 8 K, width 8 */
-#define PC_C_LOOKUP(S, K) PC_C_M0(S, K) "s_nop 0\n\ts_movrels_b64 %[val" #S #K "], s[42:43]\n\t"
-#define PC_C_ADD(S, K, M) "s_mov_b64 exec, s[" #M "]\n\tv_add_f64 %[acc], %[acc], %[val" #S #K "]\n\t"
-// first group of a block into set A
-#define PC_C_PRO(J0, J1, J2, J3)                                                                                       \
-    PC_C_RL_IDX(a, J0, J1, J2, J3) PC_C_MASKS_A(J0, J1, J2, J3) PC_C_LOOKUP(a, 0) PC_C_LOOKUP(a, 1) PC_C_LOOKUP(a, 2) PC_C_LOOKUP(a, 3)
-// the adds of the group in set A, with group J0..J3 read into set B and looked up in between; and the mirror image
-#define PC_C_STEP_AB(J0, J1, J2, J3)                                                                                   \
-    PC_C_RL_IDX(b, J0, J1, J2, J3) PC_C_MASKS_B(J0, J1, J2, J3)                                                         \
-    "s_mov_b64 exec, s[74:75]\n\tv_add_f64 %[acc], %[acc], %[vala0]\n\t" PC_C_M0(b, 0) ""                        \
-    "s_mov_b64 exec, s[76:77]\n\ts_movrels_b64 %[valb0], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala1]\n\t" PC_C_M0(b, 1) "" \
-    "s_mov_b64 exec, s[78:79]\n\ts_movrels_b64 %[valb1], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala2]\n\t" PC_C_M0(b, 2) "" \
-    "s_mov_b64 exec, s[80:81]\n\ts_movrels_b64 %[valb2], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[vala3]\n\t" PC_C_M0(b, 3) "" \
-    "s_mov_b64 exec, -1\n\ts_movrels_b64 %[valb3], s[42:43]\n\t"
-#define PC_C_STEP_BA(J0, J1, J2, J3)                                                                                   \
-    PC_C_RL_IDX(a, J0, J1, J2, J3) PC_C_MASKS_A(J0, J1, J2, J3)                                                         \
-    "s_mov_b64 exec, s[82:83]\n\tv_add_f64 %[acc], %[acc], %[valb0]\n\t" PC_C_M0(a, 0) ""                        \
-    "s_mov_b64 exec, s[84:85]\n\ts_movrels_b64 %[vala0], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb1]\n\t" PC_C_M0(a, 1) "" \
-    "s_mov_b64 exec, s[86:87]\n\ts_movrels_b64 %[vala1], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb2]\n\t" PC_C_M0(a, 2) "" \
-    "s_mov_b64 exec, s[88:89]\n\ts_movrels_b64 %[vala2], s[42:43]\n\tv_add_f64 %[acc], %[acc], %[valb3]\n\t" PC_C_M0(a, 3) "" \
-    "s_mov_b64 exec, -1\n\ts_movrels_b64 %[vala3], s[42:43]\n\t"
-#define PC_C_EPI_A PC_C_ADD(a, 0, 74:75) PC_C_ADD(a, 1, 76:77) PC_C_ADD(a, 2, 78:79) PC_C_ADD(a, 3, 80:81) "s_mov_b64 exec, -1\n\t"
-#define PC_C_EPI_B PC_C_ADD(b, 0, 82:83) PC_C_ADD(b, 1, 84:85) PC_C_ADD(b, 2, 86:87) PC_C_ADD(b, 3, 88:89) "s_mov_b64 exec, -1\n\t"
-#define PC_C_PAIR(B) PC_C_STEP_AB(B + 4, B + 5, B + 6, B + 7) PC_C_STEP_BA(B + 8, B + 9, B + 10, B + 11)
-// sixteen entries (lanes B .. B+15) and a whole batch of 64
-#define PC_C_16(B) PC_C_PRO(B + 0, B + 1, B + 2, B + 3) PC_C_PAIR(B) PC_C_STEP_AB(B + 12, B + 13, B + 14, B + 15) PC_C_EPI_B
-#define PC_C_64                                                                                                        \
-    PC_C_PRO(0, 1, 2, 3) PC_C_PAIR(0) PC_C_PAIR(8) PC_C_PAIR(16) PC_C_PAIR(24) PC_C_PAIR(32) PC_C_PAIR(40) PC_C_PAIR(48)  \
-    PC_C_STEP_AB(60, 61, 62, 63) PC_C_EPI_B
-#define PC_CENTER_TABLE_REGS                                                                                           \
-    "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57",    \
-        "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73"
-#define PC_CENTER_MASK_REGS "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89"
+// The replay steps.  Operands: acc (the lane's sum), cm / valh (the entry this lane prepared: entry `lane & 15` of its
+// row's batch), lbit = 1 << (lane & 15), sh = 30 - (lane & 15).  Temporaries are fixed registers (the high half of `one`
+// has to be named on its own): v8, v9 = x of two steps in flight, v[10:11], v[12:13] = their `one` (low halves zero).
+// The DPP operands (cm, valh) are never written inside a block; the two v_mov and the s_nop at its head keep the
+// producer of an operand two instructions away from its first DPP read (the hazard the compiler cannot see through
+// inline asm).
+#define PC_CS_AND(J, T) "v_and_b32_dpp " T ", %[cm], %[lbit] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+#define PC_CS_SHL(OH, T) "v_lshlrev_b32 " OH ", %[sh], " T "\n\t"
+#define PC_CS_FMA(J, PAIR) "v_fmac_f64_dpp %[acc], %[val], " PAIR " row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+#define PC_CS_2(J0, J1)                                                                                                \
+    PC_CS_AND(J0, "v8") PC_CS_AND(J1, "v9") PC_CS_SHL("v11", "v8") PC_CS_SHL("v13", "v9")                               \
+    PC_CS_FMA(J0, "v[10:11]") PC_CS_FMA(J1, "v[12:13]")
+#define PC_CS_HEAD "v_mov_b32 v10, 0\n\tv_mov_b32 v12, 0\n\ts_nop 1\n\t"
+#define PC_CS_Q0 PC_CS_2(0, 1) PC_CS_2(2, 3)
+#define PC_CS_Q1 PC_CS_2(4, 5) PC_CS_2(6, 7)
+#define PC_CS_Q2 PC_CS_2(8, 9) PC_CS_2(10, 11)
+#define PC_CS_Q3 PC_CS_2(12, 13) PC_CS_2(14, 15)
+#define PC_CENTER_STEPS(CODE)                                                                                          \
+    asm volatile(PC_CS_HEAD CODE                                                                                       \
+                 : [acc] "+v"(acc)                                                                                     \
+                 : [cm] "v"(cm_), [val] "v"(valh_), [lbit] "v"(lane_bit), [sh] "v"(lane_sh)                            \
+                 : "v8", "v9", "v10", "v11", "v12", "v13")
 
-// CODE = PC_C_64 or PC_C_16(B); exec all ones on entry and on exit
-#define PC_CENTER_REPLAY(CODE)                                                                                         \
-    do {                                                                                                               \
-        int sia_, sib_, m0_;                                                                                           \
-        double vala0_, vala1_, vala2_, vala3_, valb0_, valb1_, valb2_, valb3_;                                         \
-        asm volatile("s_mov_b32 %[m0s], m0\n\t" CODE "s_mov_b32 m0, %[m0s]\n\t"                                        \
-                     : [acc] "+v"(acc), [sia] "=&s"(sia_), [sib] "=&s"(sib_),                                          \
-                       [vala0] "=&s"(vala0_), [vala1] "=&s"(vala1_), [vala2] "=&s"(vala2_),                            \
-                       [vala3] "=&s"(vala3_), [valb0] "=&s"(valb0_), [valb1] "=&s"(valb1_), [valb2] "=&s"(valb2_),     \
-                       [valb3] "=&s"(valb3_), [m0s] "=&s"(m0_)                                                         \
-                     : [vlo] "v"(mlo), [vhi] "v"(mhi), [vix] "v"(vix)                                                  \
-                     : PC_CENTER_MASK_REGS, "scc");                                                                    \
-    } while (0)
-
-// (the table registers are reserved -- that is the point -- so naming them as clobbered draws a warning)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) void k_center(
+__global__ __launch_bounds__(kCenterWG) void k_center(
     const CenterChunk *__restrict__ chunks, int64_t nchunks, const FileView *__restrict__ files, int nfiles, MapParams mp, int W,
-    const double *__restrict__ inv_, const double *__restrict__ cval, const uint32_t *__restrict__ order,
+    const double *__restrict__ inv_, const double *__restrict__ invh_, const double *__restrict__ cvalh_, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ counters, const u32x4 *__restrict__ ranges, const u32x2 *__restrict__ rec_ranges,
-    const OutPiece *__restrict__ opieces, double *out, double norm_sum, int norm_on, unsigned long long *dbg) {
-    const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;
+    const uint32_t *__restrict__ row_ranges, const OutPiece *__restrict__ opieces, double *out, double norm_sum, int norm_on,
+    unsigned long long *dbg) {
+    const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;      // 1.0 / m
+    const double PC_GLOBAL *invh = (const double PC_GLOBAL *)invh_;    // 0.5 / m = (1.0 / m) / 2, exactly
+    const char PC_GLOBAL *cvalh = (const char PC_GLOBAL *)cvalh_;      // 0.5 / (L - 2 nibble) by aligned length L < 256 (0.0: not counted)
     // the list holds the heavy entries at its front and the light ones at its back; workgroup b serves the b-th
     // entry of the two runs (the grid is their exact number once a count of the plan has shown it, else 2 x chunks,
     // which bounds it).  One wave per entry: persistent waves that take entries off the list (heavy first, light
     // ones a few at a time) were measured at 2.3 - 2.4 ms against 1.6 on C3, whatever the grab size.
+    // Light entries are dealt so that the workgroups of one XCD (workgroup b runs on XCD b mod 8) walk ONE contiguous
+    // eighth of the list: neighbouring chunks re-read each other's halo, and that then hits the XCD's own L2.
     const uint32_t cap = kCenterCap * (uint32_t)nchunks;
     const uint32_t n_heavy = counters[0], n_light = counters[1];
     const uint32_t bidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (uint32_t)kCenterWG + threadIdx.x) >> 6));
-    if (bidx >= n_heavy + n_light) return;
-    const int lane = threadIdx.x & 63;
+    uint32_t slot;
+    if (bidx < n_heavy) {
+        slot = bidx;
+    } else {
+        const uint32_t k = bidx - n_heavy, n8 = (n_light + 7u) >> 3;
+        if (k >= 8u * n8) return;
+        const uint32_t kk = (bidx & 7u) * n8 + (k >> 3);
+        if (kk >= n_light) return;
+        slot = cap - 1u - kk;
+    }
+    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
     const int nib = mp.param;
-    const uint32_t slot = bidx < n_heavy ? bidx : cap - 1u - (bidx - n_heavy);
     const uint32_t entry = order[slot];
     const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
-    CenterChunk ck = chunks[cidx];
-    {   // a sub-chunk is a chunk of its own: narrow the descriptor
-        const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
-        const int sub_len = code == 0u ? 64 : (code <= 4u ? 16 : 8);
-        if (sub_off >= ck.len) return;
-        ck.len = ck.len - sub_off < sub_len ? ck.len - sub_off : sub_len;
-        ck.start += sub_off;
-        ck.hist_off += sub_off;
-    }
-    const int32_t p = ck.start + lane;
-    const int32_t cend = ck.start + ck.len;
+    const CenterChunk ck = chunks[cidx];
+    // a sub-chunk is a chunk of its own: 16 (8) positions, rows of 4 (2)
+    const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
+    const int roww = code == 0u ? 16 : (code <= 4u ? 4 : 2);
+    if (sub_off >= ck.len) return;
+    const int32_t s0 = ck.start + sub_off;
+    const int32_t cend = ck.start + (ck.len < sub_off + kCenterRows * roww ? ck.len : sub_off + kCenterRows * roww);
+    const int32_t rs = s0 + row * roww;                              // this lane's row: positions [rs, re)
+    const int32_t re = rs + roww < cend ? rs + roww : cend;
+    const bool row_live = rs < cend;
+    const int32_t p = rs + li;
+    const bool owns = li < roww && p < cend;
     const int sel = center_sel(ck.mode);
+    const int lane_bit = 1 << li, lane_sh = 30 - li;
     double acc = 0.0;
     const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
-    unsigned long long n_slots = 0;   // PC_CENTER_DEBUG: entry slots this wave replayed
+    unsigned long long n_slots = 0;   // PC_CENTER_DEBUG: replay steps of this wave
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
-        {   // this file's value table into the reserved registers
-            const unsigned long long tp = (unsigned long long)(cval + (size_t)f * kCTab);
-            asm volatile("s_load_dwordx2 s[42:43], %0, 0x0\n\ts_load_dwordx4 s[44:47], %0, 0x8\n\ts_load_dwordx16 s[48:63], %0, 0x18\n\t"
-                         "s_load_dwordx8 s[64:71], %0, 0x58\n\ts_load_dwordx2 s[72:73], %0, 0x78\n\ts_waitcnt lgkmcnt(0)"
-                         :: "s"(tp) : PC_CENTER_TABLE_REGS, "memory");
-        }
-        const int lbase = fv.c_lbase;
-        const int64_t near_key = (int64_t)ck.start - W + 1;
         const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[(int64_t)cidx * nfiles + f]; // from k_center_weigh
-        // One batch: lane j describes entry j -- aligned run [x, x + len) of a read of aligned length L, the run's
-        // first base being read index `cum` (or `indirect`: a read the 8-bit fields cannot describe, record `recidx`).
-        // Every lane derives what its entry covers after the nibble; then the entries are replayed in lane order.
-        auto replay = [&](bool valid, bool indirect, int32_t x, int len, int cum, int L, uint32_t recidx, int nvalid) {
-            // read indices [nib, L - nib) are counted: the part of this run inside that, as genome positions
-            const int lo_i = cum > nib ? cum : nib, hi_i = cum + len < L - nib ? cum + len : L - nib;
-            const int a0 = x + (lo_i - cum), m = hi_i - lo_i;
-            const bool live = valid && !indirect && m > 0 && a0 < cend && a0 + m > ck.start;
-            const uint32_t tix = (uint32_t)(L - lbase);
-            if (__any(indirect || (live && tix >= (uint32_t)kCTab))) {
-                // a batch with a length outside the table, or a read the entry cannot describe: entry by entry
-                const int mtot = L - 2 * nib;
-                double val = 0.0;
-                if (live && size_ok(mp, L)) val = mtot < 65536 ? inv[mtot] : 1.0 / (double)mtot;    // live implies mtot >= m > 0
-                unsigned long long todo = __ballot(live || indirect);
-                while (todo) {
-                    const int j = __builtin_ctzll(todo);
-                    todo &= todo - 1ull;
-                    if (lane_u32((uint32_t)indirect, j)) {
-                        const int64_t i = (int64_t)lane_u32(recidx, j);
-                        const u32x2 rr = fv.rec[i];
-                        int Li, nbi;
-                        rec_true(fv, i, rr.y, Li, nbi);
-                        center_read(fv, mp, inv, (int32_t)rr.x, Li, nbi, nbi >= 2 ? fv.blk_off[i] : 0u, p, acc);
-                    } else {
-                        const int aj = (int)lane_u32((uint32_t)a0, j), mj = (int)lane_u32((uint32_t)m, j);
-                        const double vj = lane_f64(val, j);
-                        acc += ((uint32_t)(p - aj) < (uint32_t)mj) ? vj : 0.0;
+        // One entry, already trimmed by the nibble: counted positions [a0, a0 + m) of a read of aligned length L.  What
+        // the replay needs of it: the coverage mask of this lane's ROW and half the read's value.
+        auto row_mask = [&](bool valid, int a0, int m) {
+            const int first = a0 - rs, b0 = first > 0 ? first : 0, b1 = first + m < 16 ? first + m : 16;   // row-relative [b0, b1)
+            return (valid && b1 > b0) ? (int)((1u << b1) - (1u << b0)) : 0;
+        };
+        // one batch: entry `li` of every row in (cm_, valh_); `indirect`: a read the entry cannot describe (record `recidx`)
+        auto replay = [&](int a0_, int mm_, int cm_, double valh_, bool indirect, uint32_t recidx, int nsteps) {   // (a0_, mm_: the slow path's)
+            n_slots += (unsigned long long)nsteps;
+            if (__any(indirect)) {
+                // entry by entry, row by row (what matters is the order inside a row)
+                for (int j = 0; j < 16; ++j) {
+                    for (int r = 0; r < kCenterRows; ++r) {
+                        const int src = r * 16 + j;
+                        if (lane_u32((uint32_t)indirect, src)) {
+                            const int64_t i = (int64_t)lane_u32(recidx, src);
+                            const u32x2 rr = fv.rec[i];
+                            int Li, nbi;
+                            rec_true(fv, i, rr.y, Li, nbi);
+                            double t = acc;
+                            center_read(fv, mp, inv, (int32_t)rr.x, Li, nbi, nbi >= 2 ? fv.blk_off[i] : 0u, p, t);
+                            acc = row == r ? t : acc;
+                        } else {
+                            const int aj = (int)lane_u32((uint32_t)a0_, src), mj = (int)lane_u32((uint32_t)(cm_ ? mm_ : 0), src);
+                            if (mj == 0) continue;
+                            const double vj = lane_f64(valh_, src) * 2.0;      // (exact; 0.0 where the row is not covered at all)
+                            acc += (row == r && (uint32_t)(p - aj) < (uint32_t)mj) ? vj : 0.0;
+                        }
                     }
                 }
                 return;
             }
-            // the lanes entry j covers, as a 64-bit mask (chunk-relative positions [rlo, rhi))
-            const int rel = a0 - ck.start, rlo = rel > 0 ? rel : 0, rhi = rel + m < 64 ? rel + m : 64, nlanes = rhi - rlo;
-            const unsigned long long mask = (live && nlanes > 0) ? ((nlanes >= 64 ? ~0ull : ((1ull << nlanes) - 1ull)) << rlo) : 0ull;
-            const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-            // table index x 2 of the entry, and in every fourth lane those of the three entries after it (one byte each)
-            const int ix1 = (int)(live ? tix * 2u : 0u);
-            const uint32_t vix = (uint32_t)ix1 | ((uint32_t)__builtin_amdgcn_update_dpp(0, ix1, 0x101, 0xf, 0xf, true) << 8) |
-                                 ((uint32_t)__builtin_amdgcn_update_dpp(0, ix1, 0x102, 0xf, 0xf, true) << 16) |
-                                 ((uint32_t)__builtin_amdgcn_update_dpp(0, ix1, 0x103, 0xf, 0xf, true) << 24);
-            if (nvalid > 32) {
-                n_slots += 64ull;
-                PC_CENTER_REPLAY(PC_C_64);
+            if (nsteps > 12) {
+                PC_CENTER_STEPS(PC_CS_Q0 PC_CS_Q1 PC_CS_Q2 PC_CS_Q3);
             } else {
-                n_slots += (unsigned long long)((nvalid + 15) & ~15);
-                PC_CENTER_REPLAY(PC_C_16(0));
-                if (nvalid > 16) PC_CENTER_REPLAY(PC_C_16(16));
+                PC_CENTER_STEPS(PC_CS_Q0);
+                if (nsteps > 4) PC_CENTER_STEPS(PC_CS_Q1);
+                if (nsteps > 8) PC_CENTER_STEPS(PC_CS_Q2);
             }
         };
-        // long-span reads that start before the near window but may reach into it: they precede every
-        // near-window record in the file, so they are replayed first -- 32 reads per batch, the first two aligned
-        // runs of read j (they travel next to its header) as entries 2j and 2j + 1; reads with more runs go through
-        // their record
-        for (int64_t base = rg.z; base < (int64_t)rg.w; base += 32) {
-            const int64_t j = base + (lane >> 1);
-            const bool in = j < (int64_t)rg.w;
-            const u32x4 g = in ? fv.long_rec[j] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
-            if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_key) break; // sorted by start: the rest is met in the near window
-            const i32x4 runs = in ? fv.long_runs[j] : i32x4{0, 0, 0, 0};
-            const uint32_t fl = rec_flags(g.y);
-            int nbk = rec_nblk(g.y), Lg = rec_len(g.y);
-            if (in && (fl & kFlagWide)) { const u32x2 tv = fv.long_wide[j]; Lg = (int)tv.x; nbk = (int)tv.y; }   // beyond the 16 / 8-bit fields
-            const int r = lane & 1;
-            const bool ok = in && (int64_t)(int32_t)g.x < near_key && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse);
-            replay(ok && nbk <= 2 && (r == 0 || nbk == 2), ok && nbk > 2 && r == 0, r ? runs.z : runs.x, r ? runs.w : runs.y,
-                   r ? runs.y : 0, Lg, g.w, 64);
+        // long-span reads that start before the near window of a row but may reach into it: they precede every
+        // near-window record in the file, so they are replayed first -- 8 reads per batch, the first two aligned
+        // runs of read j (they travel next to its header) as entries 2j and 2j + 1 of EVERY row; a row only counts
+        // those that start before its own near window (the others it meets in its stream); reads with more runs go
+        // through their record
+        if (rg.w > rg.z) {
+            const int64_t near_row = (int64_t)rs - W + 1;
+            const int64_t near_last = (int64_t)s0 + (kCenterRows - 1) * roww - W + 1;   // the last row's: the furthest any row looks
+            for (int64_t base = rg.z; base < (int64_t)rg.w; base += 8) {
+                const int64_t j = base + (li >> 1);
+                const bool in = j < (int64_t)rg.w;
+                const u32x4 g = in ? fv.long_rec[j] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
+                if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_last) break; // sorted by start: the rest is met in the near windows
+                const i32x4 runs = in ? fv.long_runs[j] : i32x4{0, 0, 0, 0};
+                const uint32_t fl = rec_flags(g.y);
+                int nbk = rec_nblk(g.y), Lg = rec_len(g.y);
+                if (in && (fl & kFlagWide)) { const u32x2 tv = fv.long_wide[j]; Lg = (int)tv.x; nbk = (int)tv.y; }   // beyond the 16 / 8-bit fields
+                const int r = li & 1;
+                const bool ok = in && row_live && (int64_t)(int32_t)g.x < near_row && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse);
+                // (these entries come with their read's header, not from the stream: trimmed by the nibble here)
+                const int x = r ? runs.z : runs.x, len = r ? runs.w : runs.y, cum = r ? runs.y : 0;
+                const int lo_i = cum > nib ? cum : nib, hi_i = cum + len < Lg - nib ? cum + len : Lg - nib;
+                const int a0_ = x + (lo_i - cum), mm_ = hi_i > lo_i ? hi_i - lo_i : 0, mtot = Lg - 2 * nib;
+                const int cm_ = row_mask(ok && nbk <= 2 && (r == 0 || nbk == 2) && size_ok(mp, Lg), a0_, mm_);
+                double valh_ = 0.0;
+                if (cm_) valh_ = mtot < 65536 ? invh[mtot] : (1.0 / (double)mtot) * 0.5;   // cm != 0 implies mtot >= m > 0
+                replay(a0_, mm_, cm_, valh_, ok && nbk > 2 && r == 0, g.w, 16);
+            }
         }
-        // near window: the stream entries of the records that start in [start - W + 1, end).  Whole chunks take the
-        // exact record range of the pre-pass; a sub-chunk narrows it to its own positions.
-        int64_t lo = rg.x, hi = rg.y;
-        if (code != 0u) {
+        // near windows: row r replays the stream entries of the records that start in [rs - W + 1, re).  Whole chunks
+        // take the rows' entry ranges from the pre-pass; a sub-chunk finds those of its narrower rows itself.
+        uint32_t lo, hi;
+        if (code == 0u) {
+            const uint32_t PC_GLOBAL *rt = (const uint32_t PC_GLOBAL *)row_ranges + ((size_t)cidx * nfiles + f) * (2 * kCenterRows);
+            lo = rt[row];
+            hi = rt[kCenterRows + row];
+        } else {
             const u32x2 rr = ((const u32x2 PC_GLOBAL *)rec_ranges)[(int64_t)cidx * nfiles + f];
-            const int64_t r0 = wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, rr.x, rr.y, near_key, lane);
-            const int64_t r1 = wave_lower_bound<2>((const uint32_t PC_GLOBAL *)fv.rec, r0, rr.y, (int64_t)cend, lane);
+            const int64_t key_lo = row_live ? (int64_t)rs - W + 1 : (int64_t)cend, key_hi = row_live ? (int64_t)re : (int64_t)cend;
+            const int64_t r0 = lower_bound_pos(fv.rec, rr.x, rr.y, key_lo);
+            const int64_t r1 = lower_bound_pos(fv.rec, r0, rr.y, key_hi);
             const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, sel);
             lo = soff[r0];
             hi = soff[r1];
         }
-        const u32x2 PC_GLOBAL *ent = cs_stream(files + f, sel);
-        // (the loads are unconditional, with the index clamped into the range: the padding behind the last
-        // entry makes every clamped batch readable)
-        const int64_t last = hi - 1;
-        u32x2 q0 = {0u, 0u}, q1 = q0;
-        if (hi > lo) {
-            q0 = ent[lo + lane < last ? lo + lane : last];
-            q1 = ent[lo + 64 + lane < last ? lo + 64 + lane : last];
+        if (hi < lo) hi = lo;
+        uint32_t nmax = hi - lo;
+        {
+            const uint32_t n1 = lane_u32(nmax, 16), n2 = lane_u32(nmax, 32), n3 = lane_u32(nmax, 48), n0 = lane_u32(nmax, 0);
+            nmax = n0 > n1 ? n0 : n1;
+            nmax = nmax > n2 ? nmax : n2;
+            nmax = nmax > n3 ? nmax : n3;
         }
-        // one batch of the stream: its entries out of register `q`, `q` refilled with the batch two ahead
-        auto step = [&](u32x2 &q, int64_t base) {
-            const u32x2 r = q;
-            q = ent[base + 128 + lane < last ? base + 128 + lane : last];
-            const int nvalid = hi - base < 64 ? (int)(hi - base) : 64;
-            const bool valid = lane < nvalid;
-            replay(valid, valid && ((r.y >> 24) & kCsIndirect), (int32_t)r.x, (int)(r.y & 0xffu), (int)((r.y >> 8) & 0xffu),
-                   (int)((r.y >> 16) & 0xffu), r.x, nvalid);
+        if (nmax == 0u) continue;
+        const u32x2 PC_GLOBAL *ent = cs_stream(files + f, sel);
+        // (the loads are unconditional, with the index clamped to the row's end: entry `hi` is readable -- another
+        // row's, or the padding behind the last entry -- and a lane past its row's end treats it as covering nothing;
+        // 32-bit offsets from the chunk's first entry: one scalar base, no 64-bit address arithmetic per lane)
+        const char PC_GLOBAL *eb = (const char PC_GLOBAL *)(ent + rg.x);
+        const uint32_t rlo = lo - rg.x + (uint32_t)li, rhi = hi - rg.x;
+        auto fetch = [&](uint32_t base) {
+            const uint32_t idx = rlo + base;
+            return *(const u32x2 PC_GLOBAL *)(eb + ((idx < rhi ? idx : rhi) << 3));
         };
-        for (int64_t base = lo; base < hi; base += 128) {
-            step(q0, base);
-            if (base + 64 >= hi) break;
-            step(q1, base + 64);
+        // three batches in flight: entries two ahead; coverage mask and half value -- a gather by aligned length -- one ahead
+        auto unpack = [&](const u32x2 q, uint32_t base, int &cm, double &valh, bool &ind) {
+            const bool valid = rlo + base < rhi;
+            ind = valid && ((q.y >> 24) & kCsIndirect);
+            cm = row_mask(valid && !ind, (int32_t)q.x, (int)(q.y & 0xffu));
+            valh = *(const double PC_GLOBAL *)(cvalh + ((q.y >> 13) & 0x7f8u));   // cvalh[L], L = bits 16-23 (an indirect entry reads [0])
+        };
+        u32x2 q1 = fetch(0u), q2 = fetch(16u);
+        int cmn;
+        double valn;
+        bool indn;
+        u32x2 qn = q1;
+        unpack(q1, 0u, cmn, valn, indn);
+        q1 = q2;
+        for (uint32_t base = 0; base < nmax; base += 16u) {
+            const int cmc = cmn;
+            const double valc = valn;
+            const bool indc = indn;
+            const u32x2 qc = qn;
+            q2 = fetch(base + 32u);
+            qn = q1;
+            unpack(q1, base + 16u, cmn, valn, indn);
+            q1 = q2;
+            const uint32_t left = nmax - base;
+            replay((int32_t)qc.x, (int)(qc.y & 0xffu), cmc, valc, indc, qc.x, left >= 16u ? 16 : (int)((left + 3u) & ~3u));
         }
     }
     // The sums go straight into the caller's layout (SegmentChain.get_counts, roitools.pyx:3259-3271: chain offset,
     // 5'->3' reversal of '-' chains; reads-per-million as count / sum * 1e6 in that order, genome_array.py:826-827):
     // every queried segment slice of the chunk's window that holds this lane's position gets the lane's sum -- no
-    // intermediate histogram, no gather pass (round 2 and most of round 3: 0.1 ms of C3's 1.5).
+    // intermediate histogram, no gather pass.
     {
         const double val = norm_on ? acc / norm_sum * 1e6 : acc;
         for (uint32_t oi = ck.op_begin; oi < ck.op_end; ++oi) {
             const OutPiece o = opieces[oi];
             if (o.mode != ck.mode) continue;                  // the window's slices of other strand modes
             const uint32_t rel = (uint32_t)(p - o.start);
-            if (lane < ck.len && rel < (uint32_t)o.len) out[o.out_off + (int64_t)o.step * (int64_t)rel] = val;
+            if (owns && rel < (uint32_t)o.len) out[o.out_off + (int64_t)o.step * (int64_t)rel] = val;
         }
     }
     if (dbg && lane == 0) {   // PC_CENTER_DEBUG
@@ -1921,7 +1942,6 @@ __global__ __attribute__((amdgpu_num_sgpr(48))) __launch_bounds__(kCenterWG) voi
         dbg[2 * (size_t)cap + slot] = n_slots;
     }
 }
-#pragma clang diagnostic pop
 
 // ---------------------------------------------------------------- k_coordinates
 // SegmentChain._get_position_hash / get_position_list (roitools.pyx:1450-1484, 2059-2080) for a whole

@@ -264,7 +264,7 @@ struct StagedFile {
     DevBuf<uint2> cs_ent[3];
     DevBuf<uint32_t> cs_soff[3];
     int64_t cs_n[3] = {-1, -1, -1};    // entries, -1: not built
-    int c_lbase = 0;                   // the 16 aligned lengths from here on have their 1/m in the center kernel's SGPR table
+    int cs_nib[3] = {-1, -1, -1};      // the nibble the entries were trimmed with
     FileView view() const {
         FileView v;
         v.rec = rec.p; v.blk_off = blk_off.p; v.blk = blk.p; v.tid_bounds = tid_bounds.p;
@@ -279,7 +279,6 @@ struct StagedFile {
         for (int k = 0; k < 3; ++k) { v.cs_ent[k] = cs_n[k] >= 0 ? cs_ent[k].p : nullptr; v.cs_soff[k] = cs_n[k] >= 0 ? cs_soff[k].p : nullptr; }
         v.long_wide = nwide ? long_wide.p : nullptr; v.xlong_wide = nwide ? xlong_wide.p : nullptr;
         v.wide_rec = wide_rec.p; v.wide_val = wide_val.p; v.nwide = nwide;
-        v.c_lbase = c_lbase;
         return v;
     }
 };
@@ -343,7 +342,8 @@ struct pc_engine {
     int norm_on = 0;
     double norm_sum = 1.0;
     DevBuf<double> d_inv; // 1.0/m, m = 0..65535 (host-computed IEEE quotients)
-    DevBuf<double> d_cval; // per file: the 1/m of the center kernel's SGPR table (k_center_vals)
+    DevBuf<double> d_invh; // the same halved (exact): what the center kernel's fma doubles again
+    DevBuf<double> d_cvalh; // [256] half the value of a read by aligned length under the current rule and size filter (k_center_vals)
     // scratch for counting
     DevBuf<uint32_t> d_counters; // [1] unmappable count, [7] sink of the stream probe, [12] exact-grid guard (work counts: pc_plan::d_wcounters)
     DevBuf<uint8_t> d_flags;     // staging buffer of pc_update_flags
@@ -358,6 +358,8 @@ struct pc_engine {
     int prof_level = 0;      // pc_set_profiling: 0 no events, 1 whole call + histogram/center kernel, 2 every phase
     int timed_level = 0;     // level the last pc_count was recorded with
     int64_t last_alg_bytes = 0;
+    bool want_center_steps = false;      // pc_center_replay_steps: the next center count reports the replay steps it executed
+    int64_t center_steps = 0, center_waves = 0;
 
     MapParams params() const {
         MapParams mp;
@@ -426,6 +428,7 @@ struct pc_plan {
     int64_t rle_runs = -1;
     DevBuf<u32x4> d_cranges;    // per (chunk, file): entry range of the near window and candidate range of the long-span list
     DevBuf<u32x2> d_crec;       // per (chunk, file): the near window as a record range (sub-chunks narrow it)
+    DevBuf<uint32_t> d_crows;   // per (chunk, file): entry ranges of the chunk's four rows of 16 positions (4 x lo, 4 x hi)
     DevBuf<uint32_t> d_ccounts; // [0] heavy, [1] light entries of the dispatch list, [2..3] sum of the candidate counts
     // the center pre-passes (ranges, candidate counts, dispatch order) depend on the plan, the staged files and the
     // knobs only -- not on the mapping rule: kept from count to count while the engine's work generation stands
@@ -472,6 +475,7 @@ struct pc_plan {
     uint32_t work_counts[3] = {0, 0, 0};
     uint32_t work_merged = 0;            // windows of the lists that are merged through the compact histogram (what k_gather_split lays out)
     bool exact_grid_used = false;        // some count of this plan launched exact grids: its results are read back with the guard word
+    bool guard_pending = false;          // the work lists were rebuilt since the guard word was last read (capacity check)
     ~pc_plan() {
         if (ev_work_counts) (void)hipEventDestroy(ev_work_counts);
         if (h_work_counts) (void)hipHostFree(h_work_counts);
@@ -483,7 +487,7 @@ struct pc_plan {
         DevPool *pl = &eng->pool;
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
-        d_cranges.pool = pl; d_crec.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
+        d_cranges.pool = pl; d_crec.pool = pl; d_crows.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
         d_work.pool = pl; d_work_small.pool = pl; d_chain.pool = pl; d_chain_small.pool = pl;
     }
 };
@@ -572,30 +576,39 @@ int ensure_gather_tables(pc_engine *e, pc_plan *p) {
 
 // Center stream `sel` (0 forward reads, 1 reverse reads, 2 all reads) of one staged file: entries per record,
 // exclusive sum, scatter -- three passes over the 8-byte records in HBM (see k_center in pc_kernels.hip.h).
-int build_center_stream(pc_engine *e, StagedFile *sf, int sel) {
+int build_center_stream(pc_engine *e, StagedFile *sf, int sel, int nib) {
     hipStream_t st = e->stream;
     const int64_t n = sf->n;
-    int rc = sf->cs_soff[sel].reserve((size_t)n + 1);
-    if (rc != PC_OK) return rc;
-    hipLaunchKernelGGL(k_cs_count, dim3((unsigned)((n + 1 + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, n, sel, sf->cs_soff[sel].p);
-    {
-        size_t tmp_bytes = 0;
-        DevBuf<uint8_t> d_tmp;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, sf->cs_soff[sel].p, sf->cs_soff[sel].p, (int)(n + 1), st));
-        rc = d_tmp.reserve(tmp_bytes);
+    if (sf->cs_n[sel] >= 0 && sf->cs_nib[sel] == nib) return PC_OK;
+    // (one entry per aligned run, counted and scanned in 32 bits: n records + the extra runs of the multi-run ones bounds them)
+    if (n + sf->nrun >= (int64_t)0xffffffffu)
+        return fail(PC_ERR_ARG, "pc_count: the center rule takes at most 2^32-2 aligned runs per file (%lld records, %lld runs of multi-run reads); split the file",
+                    (long long)n, (long long)sf->nrun);
+    int rc = PC_OK;
+    if (sf->cs_n[sel] < 0) {   // entries per record and their exclusive sum: independent of the nibble
+        rc = sf->cs_soff[sel].reserve((size_t)n + 1);
         if (rc != PC_OK) return rc;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, sf->cs_soff[sel].p, sf->cs_soff[sel].p, (int)(n + 1), st));
-        HIP_TRY(hipStreamSynchronize(st));   // d_tmp goes out of scope
+        hipLaunchKernelGGL(k_cs_count, dim3((unsigned)((n + 1 + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, n, sel, sf->cs_soff[sel].p);
+        {
+            size_t tmp_bytes = 0;
+            DevBuf<uint8_t> d_tmp;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, sf->cs_soff[sel].p, sf->cs_soff[sel].p, (int)(n + 1), st));
+            rc = d_tmp.reserve(tmp_bytes);
+            if (rc != PC_OK) return rc;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, sf->cs_soff[sel].p, sf->cs_soff[sel].p, (int)(n + 1), st));
+            HIP_TRY(hipStreamSynchronize(st));   // d_tmp goes out of scope
+        }
+        uint32_t total = 0;
+        HIP_TRY(hipMemcpy(&total, sf->cs_soff[sel].p + n, sizeof(total), hipMemcpyDeviceToHost));
+        rc = sf->cs_ent[sel].reserve((size_t)total + 64);
+        if (rc != PC_OK) return rc;
+        sf->cs_n[sel] = (int64_t)total;
+        e->files_dirty = true;
     }
-    uint32_t total = 0;
-    HIP_TRY(hipMemcpy(&total, sf->cs_soff[sel].p + n, sizeof(total), hipMemcpyDeviceToHost));
-    rc = sf->cs_ent[sel].reserve((size_t)total + 64);
-    if (rc != PC_OK) return rc;
     hipLaunchKernelGGL(k_cs_scatter, dim3((unsigned)((n + 64 + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, sf->blk_off.p, sf->blk.p, n,
-                       sel, sf->cs_soff[sel].p, sf->cs_ent[sel].p);
+                       sel, nib, sf->cs_soff[sel].p, sf->cs_ent[sel].p);
     HIP_TRY(hipGetLastError());
-    sf->cs_n[sel] = (int64_t)total;
-    e->files_dirty = true;
+    sf->cs_nib[sel] = nib;
     return PC_OK;
 }
 
@@ -642,6 +655,9 @@ int pc_create(int device, pc_engine **out) {
     inv[0] = 0.0;
     for (int m = 1; m < 65536; ++m) inv[m] = 1.0 / (double)m; // the reference's `1.0 / map_length`
     int rc = e->d_inv.upload(inv, e->stream);
+    std::vector<double> invh(65536);
+    for (int m = 0; m < 65536; ++m) invh[m] = inv[m] * 0.5;   // exact: a power-of-two scaling of a normal number
+    if (rc == PC_OK) rc = e->d_invh.upload(invh, e->stream);
     if (rc == PC_OK) rc = e->d_counters.reserve(16);
     if (rc == PC_OK && hipMemsetAsync(e->d_counters.p, 0, 16 * sizeof(uint32_t), e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: memset failed");
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: sync failed");
@@ -720,6 +736,9 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
                                const int32_t *blk_start, const int32_t *blk_len, int64_t n_wide, const int64_t *wide_idx,
                                const int32_t *wide_alen, const int32_t *wide_nblk) {
     if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    if (n < 0 || ntid <= 0 || nrun < 0) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad sizes");
+    if (n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL array");
+    if (nrun > 0 && (!blk_start || !blk_len)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL run array");
     if (n_wide < 0 || (n_wide > 0 && (!wide_idx || !wide_alen || !wide_nblk))) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad wide-record arrays");
     for (int64_t k = 0; k < n_wide; ++k) {
         const int64_t i = wide_idx[k];
@@ -735,9 +754,6 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         return (q != wide_idx + n_wide && *q == i) ? (int64_t)(q - wide_idx) : -1;
     };
     auto NB = [&](int64_t i) -> int64_t { const int64_t w = wide_at(i); return w >= 0 ? (int64_t)wide_nblk[w] : (int64_t)nblk[i]; };
-    if (n < 0 || ntid <= 0 || nrun < 0) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad sizes");
-    if (n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL array");
-    if (nrun > 0 && (!blk_start || !blk_len)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL run array");
     if (n >= (int64_t)0x7fffffff || nrun >= (int64_t)0xffffffffu)
         return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 records per file are not supported");
     if (!e->files.empty() && ntid != e->ntid)
@@ -1066,14 +1082,6 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     sf->len_hist.swap(len_hist);
     for (int L = 0; L < 65536; ++L)
         if (sf->len_hist[(size_t)L]) { sf->len_min = std::min(sf->len_min, L); sf->len_max = std::max(sf->len_max, L); }
-    {   // the kCTab consecutive aligned lengths (<= 255) that hold the most records: the center kernel's fast table
-        int64_t win = 0, best = -1;
-        for (int L = 1; L <= 255; ++L) {
-            win += sf->len_hist[(size_t)L];
-            if (L - kCTab >= 1) win -= sf->len_hist[(size_t)(L - kCTab)];
-            if (win > best) { best = win; sf->c_lbase = std::max(1, L - kCTab + 1); }
-        }
-    }
 
     {   // sentinels behind the last record: two excluded headers, eight skip words (whole quads can always be loaded)
         const uint2 tail_rec[2] = {make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16), make_uint2(0u, (uint32_t)PC_FLAG_EXCLUDED << 16)};
@@ -1889,7 +1897,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         const bool need[3] = {(p->modes & 1u) != 0, (p->modes & 2u) != 0, (p->modes & 12u) != 0};
         for (auto *f : e->files)
             for (int k = 0; k < 3 && rc == PC_OK; ++k)
-                if (need[k] && f->cs_n[k] < 0) rc = build_center_stream(e, f, k);
+                if (need[k]) rc = build_center_stream(e, f, k, e->param);   // (no-op when built for this nibble)
         if (rc != PC_OK) return rc;
     }
     rc = refresh_file_views(e);
@@ -1937,7 +1945,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // work-list capacity (an upper bound): a window scanning n records yields at most
             // max(1, 2n/R) items, and every record is scanned by at most 1 + (W+127)/G windows
             const int halo = std::max(std::max(W, e->Ws()), std::max(e->Wg(), e->Wr()));
-            const double windows_per_record = 1.0 + (double)(halo + 127) / (double)G;
+            // (a multi-row plan gives every strand mode of a window a tile of its own -- pc_plan_create, split_modes --
+            // so a record is scanned by up to popcount(modes) tiles per window)
+            const int tiles_per_window = p->rows > 1 ? std::max(1, __builtin_popcount(p->modes)) : 1;
+            const double windows_per_record = (1.0 + (double)(halo + 127) / (double)G) * (double)tiles_per_window;
             const int64_t cap64 = (int64_t)ntiles * nfiles + (int64_t)(2.0 * windows_per_record * (double)nrec / (double)R) + nfiles + 64;
             if (cap64 >= (int64_t)0xffffffffu) return fail(PC_ERR_ARG, "pc_count: work list too large");
             rc = p->d_work.reserve((size_t)cap64);
@@ -1969,6 +1980,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 p->work_key = key;
                 p->work_valid = true;
                 p->work_counts_known = false;      // the counts of the lists just replaced size no grid
+                p->guard_pending = true;           // k_gather_split checks the new lists against the capacity: read with the results
                 p->work_counts_generation = 0;
             }
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
@@ -2072,7 +2084,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     hipLaunchKernelGGL((k_gather_split<O>), dim3((unsigned)((ntiles + split_per_wg - 1) / split_per_wg)), dim3(kWG), 0, st, \
                        p->d_tiles.p, ntiles, split_per_wg, p->d_pieces.p,                                               \
                        p->d_opieces.p, p->d_tile_items.p, p->d_wcounters.p, p->rows, (uint32_t *)p->d_hist.p, p->npos,   \
-                       (OutT_<O>::type *)p->d_out.p, e->norm_sum, launched[0], launched[1], launched[2], e->d_counters.p + 12)
+                       (OutT_<O>::type *)p->d_out.p, e->norm_sum, launched[0], launched[1], launched[2], (uint32_t)cap64, e->d_counters.p + 12)
             // (skipped once the plan's lists are known to hold no merged window: the lists are the plan's own and do not
             // change from count to count, so neither does that -- and the exact grids it would check were read from them)
             const bool nothing_to_merge = launched[0] != 0xffffffffu && p->work_merged == 0 && !e->knobs.test_stale_counts;
@@ -2116,18 +2128,17 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (rc == PC_OK) rc = p->d_ccand.reserve((size_t)nchunks);
             if (rc == PC_OK) rc = p->d_cranges.reserve((size_t)nchunks * (size_t)nfiles);
             if (rc == PC_OK) rc = p->d_crec.reserve((size_t)nchunks * (size_t)nfiles);
+            if (rc == PC_OK) rc = p->d_crows.reserve((size_t)nchunks * (size_t)nfiles * (size_t)(2 * kCenterRows));
             if (rc == PC_OK) rc = p->d_ccounts.reserve(8);
+            if (rc == PC_OK) rc = e->d_cvalh.reserve(256);
             if (rc != PC_OK) return rc;
-            if (nfiles * kCTab > 1024) return fail(PC_ERR_ARG, "pc_count: the center rule takes at most %d alignment files", 1024 / kCTab);
-            rc = e->d_cval.reserve((size_t)nfiles * kCTab);
-            if (rc != PC_OK) return rc;
-            hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(1024), 0, st, e->d_files.p, nfiles, mp, e->d_inv.p, e->d_cval.p);
+            hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(256), 0, st, mp, e->d_invh.p, e->d_cvalh.p);
             if (p->center_generation != e->work_generation || p->center_W != W) {
                 HIP_TRY(hipMemsetAsync(p->d_ccounts.p, 0, 4 * sizeof(uint32_t), st));
                 unsigned long long *total = (unsigned long long *)(p->d_ccounts.p + 2);
                 const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
                 hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
-                                   p->d_ccand.p, p->d_cranges.p, p->d_crec.p, total);
+                                   p->d_ccand.p, p->d_cranges.p, p->d_crec.p, p->d_crows.p, total);
                 // cut thresholds, in multiples of the mean candidate count
                 const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2;
                 hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, e->knobs.center_floor,
@@ -2149,9 +2160,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             }
             uint64_t cgrid = 2 * (uint64_t)nchunks;   // bounds heavy + light entries (fewer than an eighth of the chunks are cut, into at most eight)
             if (p->center_counts_known) cgrid = std::max<uint64_t>(1, (uint64_t)p->center_counts[0] + p->center_counts[1]);
+            cgrid += 8;   // (the light entries are dealt to the XCDs in eighths, rounded up)
             // PC_CENTER_DEBUG: how long every dispatched wave ran (wall clock ticks), printed after the launch
             DevBuf<unsigned long long> d_dbg;
-            const bool dbg_on = e->knobs.center_debug != 0;
+            const bool dbg_on = e->knobs.center_debug != 0 || e->want_center_steps;
             if (dbg_on) {
                 rc = d_dbg.reserve((size_t)(2 * kCenterCap * nchunks) + (size_t)kCenterCap * nchunks);
                 if (rc != PC_OK) return rc;
@@ -2159,9 +2171,18 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             }
             unsigned long long *dbg = dbg_on ? d_dbg.p : nullptr;
             hipLaunchKernelGGL(k_center, dim3((unsigned)((cgrid * 64 + kCenterWG - 1) / kCenterWG)), dim3(kCenterWG), (size_t)e->knobs.center_lds, st, p->d_cchunks.p, nchunks,
-                               e->d_files.p, nfiles, mp, W, e->d_inv.p, e->d_cval.p, p->d_corder.p, p->d_ccounts.p, p->d_cranges.p,
-                               p->d_crec.p, p->d_opieces.p, (double *)p->d_out.p, e->norm_sum, e->norm_on ? 1 : 0, dbg);
-            if (dbg_on) {
+                               e->d_files.p, nfiles, mp, W, e->d_inv.p, e->d_invh.p, e->d_cvalh.p, p->d_corder.p, p->d_ccounts.p, p->d_cranges.p,
+                               p->d_crec.p, p->d_crows.p, p->d_opieces.p, (double *)p->d_out.p, e->norm_sum, e->norm_on ? 1 : 0, dbg);
+            if (e->want_center_steps) {   // diagnostic launch: replay steps and dispatched waves, summed on the host
+                std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks)), h_slots((size_t)(kCenterCap * nchunks));
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(h.data(), d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(h_slots.data(), d_dbg.p + h.size(), h_slots.size() * 8, hipMemcpyDeviceToHost));
+                e->center_steps = 0; e->center_waves = 0;
+                for (size_t i = 0; i < h_slots.size(); ++i)
+                    if (h[2 * i]) { e->center_steps += (int64_t)h_slots[i]; e->center_waves += 1; }
+            }
+            if (e->knobs.center_debug != 0) {
                 std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks)), h_slots((size_t)(kCenterCap * nchunks));
                 std::vector<uint32_t> h_order((size_t)(kCenterCap * nchunks)), h_cand((size_t)nchunks);
                 HIP_TRY(hipStreamSynchronize(st));
@@ -2239,15 +2260,20 @@ int pc_sync(pc_engine *e) {
 // Exact grids (pc_count) rest on the work counts of a plan being a function of (plan, work generation).  The last
 // kernel of a count compares what was queued with what was launched; a mismatch means work items went unserved.
 static int check_grid_guard(pc_engine *e, pc_plan *p) {
-    if (!p->exact_grid_used) return PC_OK;
+    if (!p->exact_grid_used && !p->guard_pending) return PC_OK;
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(&err, e->d_counters.p + 12, sizeof(err), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    p->guard_pending = false;
     if (!err) return PC_OK;
     HIP_TRY(hipMemsetAsync(e->d_counters.p + 12, 0, sizeof(uint32_t), e->stream));
     p->work_counts_known = false;
     p->work_counts_generation = 0;
     p->exact_grid_used = false;
+    p->work_valid = false;
+    if (err & 2u)
+        return fail(PC_ERR_STATE, "the work lists of this plan overflowed their capacity (results incomplete): an engine defect -- please report "
+                                  "the annotation / alignment shape; PC_WORK_R changes the item size");
     return fail(PC_ERR_STATE, "a count of this plan queued more work items than the cached work counts launched (results incomplete); "
                               "the cache has been dropped -- count again");
 }
@@ -2396,6 +2422,18 @@ int pc_last_timing(pc_engine *e, double *ms, int n) {
 }
 
 int64_t pc_last_algorithmic_bytes(pc_engine *e) { return e ? e->last_alg_bytes : -1; }
+
+int pc_center_replay_steps(pc_engine *e, pc_plan *p, int64_t *steps, int64_t *waves) {
+    if (!e || !p || p->e != e || !steps || !waves) return fail(PC_ERR_ARG, "pc_center_replay_steps: bad arguments");
+    if (e->kind != PC_MAP_CENTER) return fail(PC_ERR_STATE, "pc_center_replay_steps: the mapping rule is not the center rule");
+    e->want_center_steps = true;
+    const int rc = pc_count(e, p, PC_OUT_FLOAT64);
+    e->want_center_steps = false;
+    if (rc != PC_OK) return rc;
+    *steps = e->center_steps;
+    *waves = e->center_waves;
+    return PC_OK;
+}
 
 int pc_stream_probe(pc_engine *e, int64_t bytes, int iters, double *read_gbps, double *write_gbps) {
     if (!e || bytes < (1 << 20) || iters < 1) return fail(PC_ERR_ARG, "pc_stream_probe: bad arguments");

@@ -162,6 +162,12 @@ class Engine(object):
     def last_algorithmic_bytes(self):
         return int(self._lib.pc_last_algorithmic_bytes(self._h))
 
+    def center_replay_steps(self, plan):
+        """``(steps, waves)`` of one center-rule count of `plan` (a diagnostic launch; see ``pc_center_replay_steps``)."""
+        steps, waves = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.pc_center_replay_steps(self._h, plan._h, ctypes.byref(steps), ctypes.byref(waves)))
+        return steps.value, waves.value
+
     @property
     def stream(self):
         return self._lib.pc_stream(self._h)

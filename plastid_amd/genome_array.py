@@ -56,13 +56,14 @@ def _pack_source(src, chroms, chrom_index):
         tid = remap[src.tid] if src.n else src.tid
         if src.n and np.any(np.diff(tid) < 0):
             order = np.argsort(tid, kind="stable")  # keep BAM order within a contig
-            sub = src.subset(order)
+            sub = src.subset(order, validate=False)   # (the source's own contig order is not this array's)
             tid = tid[order]
         else:
             sub = src
         return PackedAlignments(tid, sub.pos, sub.alen, sub.flags, sub.nblk, sub.blk_start, sub.blk_len,
                                 references=chroms, lengths=[0] * len(chroms), mapped=src.mapped,
-                                read_objects=sub._read_objects)
+                                read_objects=sub._read_objects, wide_idx=sub.wide_idx, wide_alen=sub.wide_alen,
+                                wide_nblk=sub.wide_nblk)
     # duck-typed pysam.AlignmentFile: walk every contig in coordinate order
     reads, tids = [], []
     for ref, length in zip(src.references, src.lengths):

@@ -463,8 +463,9 @@ class PackedAlignments(object):
         nblk = (alen > 0).astype(np.uint8)
         return cls(tid, pos, alen.astype(np.uint16), flags, nblk, **kwargs)
 
-    def subset(self, mask_or_index):
-        """New :class:`PackedAlignments` with the selected records (order kept)."""
+    def subset(self, mask_or_index, validate=True):
+        """New :class:`PackedAlignments` with the selected records, in the order given (``validate=False``: the
+        caller re-orders the records and re-labels the contigs itself)."""
         idx = np.asarray(mask_or_index)
         if idx.dtype == bool:
             idx = np.nonzero(idx)[0]
@@ -486,7 +487,7 @@ class PackedAlignments(object):
         return PackedAlignments(self.tid[idx], self.pos[idx], self.alen[idx], self.flags[idx],
                                 self.nblk[idx], self.blk_start[sel], self.blk_len[sel],
                                 references=self.references, lengths=self.lengths,
-                                mapped=len(idx), read_objects=ro, **wide)
+                                mapped=len(idx), read_objects=ro, validate=validate, **wide)
 
 
     def slice(self, i0, i1):

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE -- a stand-in for ``plastid_amd.engine.Engine`` that counts with the oracle, so that the
 multi-rank CONTROL FLOW of ``bench.py --gpus N`` (self-spawn, per-rank generation, partition, parity gates,
-all-reduces, the JSON line) can be rehearsed in a container without GPUs (``PC_BENCH_ENGINE=tests.oracle_engine``,
+all-reduces, the JSON line) can be rehearsed in a container without GPUs (``tests/bench_rehearsal.py``,
 ``PC_BENCH_BACKEND=gloo``).  It is never imported by the product or by a measuring run; a line produced with it says
 "rehearsal" and carries no value."""
 import numpy as np

@@ -256,28 +256,39 @@ def test_range_addressable_generator_rank_slices_are_the_job():
 
 def test_bench_spawns_its_ranks_and_runs_the_one_job_mode(tmp_path):
     """``python bench.py --gpus 2`` without a torchrun environment: the parent spawns the two ranks and relays ONE JSON
-    line.  Rehearsed here without GPUs (gloo; the oracle-backed stand-in engine of tests/oracle_engine.py counts): every
-    rank generates only its range, passes its parity gates, the chain sums agree after the all-reduce, the records owned
-    by the ranks add up to the job, and C4 / C5 follow the headline as partitioned jobs."""
+    line.  Rehearsed here without GPUs through tests/bench_rehearsal.py (the same main(), with the oracle-backed stand-in
+    engine of tests/oracle_engine.py patched in from the test side; gloo): every rank generates only its range, passes
+    its parity gates, the chain sums agree after the all-reduce, the records owned by the ranks add up to the job, C4 /
+    C5 follow the headline as partitioned jobs, and the one stdout line stays within 4 KB with every config in it."""
     import json
     import subprocess
-    env = dict(os.environ, PC_BENCH_BACKEND="gloo", PC_BENCH_ENGINE="tests.oracle_engine", PYTHONPATH=ROOT)
+    env = dict(os.environ, PC_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.002", "--tx-scale", "0.01", "--steps", "2",
-           "--warmup", "1", "--other-configs", "C4,C5", "--parity-chains", "60"]
+    detail = str(tmp_path / "detail.json")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", "2", "--scale", "0.002", "--tx-scale", "0.01",
+           "--steps", "2", "--warmup", "1", "--other-configs", "C4,C5", "--parity-chains", "60", "--detail-out", detail]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert proc.returncode == 0, proc.stderr.decode()[-3000:]
     lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(lines[0]) <= 4096
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["metric"] == "mapped_reads_per_sec"
-    assert "rehearsal" in d["config"] and d["value"] is None
-    part = d["config"]["partition"]
-    assert sum(part["records_per_rank"]) == d["config"]["records_total"] == 200000
+    assert "rehearsal" in d["config"] and d["value"] is None and d["value_first_count"] is None
+    assert sum(d["config"]["partition"]["records_per_rank"]) == d["config"]["records"] == 200000
+    assert set(d["configs"]) == {"C4", "C5"}
+    for c in ("C4", "C5"):
+        assert d["configs"][c]["parity_positions"] > 0 and d["configs"][c]["ms_per_step"] > 0
+    # the prose and the full figures live in the side file
+    full = json.load(open(detail))
+    part = full["headline"]["partition"]
+    assert sum(part["records_per_rank"]) == full["headline"]["records_total"] == 200000
     assert all(s >= o for s, o in zip(part["records_staged_per_rank"], part["records_per_rank"]))
     assert len(part["peak_host_rss_MB_per_rank"]) == 2 and part["allreduce"]["chains_checked_vs_oracle"] == 60
     for c in ("C4", "C5"):
-        oc = d["config"]["other_configs"][c]
-        assert sum(oc["partition"]["records_per_rank"]) == oc["records"]
+        oc = full["other_configs"][c]
+        assert sum(oc["partition"]["records_per_rank"]) == oc["records_total"]
         assert oc["partition"]["halo_positions"] > 1000 and "bit-exact" in oc["parity"]
+    # bench.py has no switch that routes it around the HIP engine
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "PC_BENCH_ENGINE" not in src and "oracle_engine" not in src

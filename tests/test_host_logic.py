@@ -13,6 +13,7 @@ import pytest
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import plastid_amd as pa  # noqa: E402
 from plastid_amd import _lib, map_factories as mf, packing, synth  # noqa: E402
+from plastid_amd.packing import PackedAlignments  # noqa: E402
 from plastid_amd.build import build_library  # noqa: E402
 from tests import golden_util as gu  # noqa: E402
 
@@ -235,6 +236,32 @@ def test_packed_alignments_roundtrip_and_fetch():
         assert np.array_equal(getattr(from_reads, k), getattr(p, k)), k
 
 
+def test_wide_reads_survive_a_reference_remap():
+    """A source whose reference list differs from the array's chromosome list (extra contigs, another order) is
+    re-labelled by ``_pack_source``; the side arrays of over-wide reads (> 65 535 aligned bases, > 255 runs) and
+    a header order that is not the array's sorted one must both survive that."""
+    from plastid_amd.genome_array import _pack_source
+    # references in an order that is not lexicographic: chr2 before chr10
+    refs = ["chr2", "chr10"]
+    tid = np.array([0, 0, 1], np.int32)
+    pos = np.array([5, 100, 7], np.int32)
+    alen = np.array([30, 65535, 28], np.uint16)
+    nblk = np.array([1, 255, 1], np.uint8)
+    src = PackedAlignments(tid, pos, alen, np.zeros(3, np.uint8), nblk, references=refs, lengths=[200000, 1000],
+                           wide_idx=[1], wide_alen=[70000], wide_nblk=[1])
+    chroms = sorted(refs + ["chr3"])             # chr10, chr2, chr3
+    index = {c: i for i, c in enumerate(chroms)}
+    out = _pack_source(src, chroms, index)
+    assert list(out.tid) == [0, 1, 1] and list(out.pos) == [7, 5, 100]
+    assert list(out.wide_idx) == [2] and list(out.wide_alen) == [70000] and list(out.wide_nblk) == [1]
+    assert out.true_alen()[2] == 70000
+    # same order, one extra contig in the array: no re-ordering, wide arrays kept
+    out2 = _pack_source(PackedAlignments(tid, pos, alen, np.zeros(3, np.uint8), nblk, references=["a", "c"],
+                                         wide_idx=[1], wide_alen=[70000], wide_nblk=[1]), ["a", "b", "c"],
+                        {"a": 0, "b": 1, "c": 2})
+    assert list(out2.tid) == [0, 0, 2] and list(out2.wide_idx) == [1] and out2.true_alen()[1] == 70000
+
+
 def test_synthetic_configs_are_seeded_and_valid():
     for name, scale, txs in (("C1", 0.01, 0.5), ("C2", 0.0002, 0.005), ("C4", 0.00004, 0.002), ("C5", 0.00002, 0.002)):
         g, tx, reads, mapping = synth.make_config(name, scale=scale, tx_scale=txs)
@@ -335,12 +362,11 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
     assert not bad, "kernels using scratch memory: %s" % bad
 
 
-def test_center_kernel_keeps_its_reserved_registers(tmp_path):
-    """k_center keeps the 1/m table in s[42:73] and the lane masks of two entry groups in s[74:89] across its inline
-    assembly blocks; it is compiled for 48 SGPRs so that the compiler never allocates those.  Checked on the built code
-    object: the kernel stays within 96 SGPRs (eight waves per SIMD), and in its disassembly the table registers are only
-    ever written by the s_load that fills them and read by s_movrels, the mask registers only written by v_readlane
-    and read by s_mov_b64 exec."""
+def test_center_kernel_replays_through_dpp_rows(tmp_path):
+    """k_center's replay step is three vector instructions -- v_and_b32_dpp (coverage mask of the entry & the lane's bit),
+    v_lshlrev_b32 (-> the high word of 2.0 or 0.0), v_fmac_f64_dpp -- with the entry broadcast inside a 16-lane row by DPP
+    (row_newbcast), and nothing scalar: checked on the built code object.  The kernel must fit eight waves per SIMD by
+    its vector registers (<= 64) and use neither LDS nor scratch."""
     import re
     import shutil
     import subprocess
@@ -358,27 +384,23 @@ def test_center_kernel_keeps_its_reserved_registers(tmp_path):
     notes = subprocess.check_output([readelf, "--notes", obj]).decode()
     block = [b for b in notes.split("- .agpr_count")[1:] if re.search(r"\.name:\s+_ZN2pc8k_centerE", b)]
     assert len(block) == 1
-    assert int(re.search(r"\.sgpr_count:\s+(\d+)", block[0]).group(1)) <= 96
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", block[0]).group(1)) <= 64
+    assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block[0]).group(1)) == 0
     symbol = re.search(r"\.name:\s+(_ZN2pc8k_centerE\S+)", block[0]).group(1)
     dis = subprocess.check_output([objdump, "-d", "--disassemble-symbols=" + symbol, obj]).decode()
     lines = [ln.split("//")[0].strip() for ln in dis.splitlines() if "\t" in ln]
     assert len(lines) > 500, "k_center not found in the disassembly"
-    sreg = re.compile(r"\bs\[?(\d+)(?::(\d+))?\]?")
-    seen_table = seen_mask = 0
-    for ln in lines:
-        parts = ln.split(None, 1)
-        if len(parts) < 2:
-            continue
-        op, args = parts[0], parts[1]
-        for m in sreg.finditer(args):
-            lo, hi = int(m.group(1)), int(m.group(2) or m.group(1))
-            if hi >= 42 and lo <= 73:
-                assert op.startswith("s_load_dword") or op == "s_movrels_b64", ln
-                seen_table += 1
-            elif hi >= 74 and lo <= 89:
-                assert op == "v_readlane_b32" or (op == "s_mov_b64" and args.startswith("exec")), ln
-                seen_mask += 1
-    assert seen_table > 100 and seen_mask > 100
+    ops = [ln.split(None, 1)[0] for ln in lines if ln]
+    n_fma = sum(1 for ln in lines if ln.startswith("v_fmac_f64_dpp") and "row_newbcast" in ln)
+    assert n_fma >= 16 and n_fma % 4 == 0
+    assert sum(1 for ln in lines if ln.startswith("v_and_b32_dpp") and "row_newbcast" in ln) == n_fma
+    assert not any(op.startswith("ds_") for op in ops), "k_center uses no LDS"
+    # a 16-step block is 48 instructions of exactly these three kinds: nothing scalar, no lane crossing but the DPP
+    idx = [i for i, ln in enumerate(lines) if ln.startswith("v_fmac_f64_dpp") and "row_newbcast:15" in ln]
+    assert idx
+    for last in idx:
+        blockops = ops[last - 47:last + 1]
+        assert all(o.startswith(("v_and_b32_dpp", "v_lshlrev_b32", "v_fmac_f64_dpp")) for o in blockops), blockops
 
 
 def test_usable_cpus_respects_the_container_limits():
