@@ -120,6 +120,8 @@ struct FileView {
     // center streams (see k_center): entries and entries-before-record per strand selection (forward / reverse / all reads)
     const uint2 *cs_ent[3];
     const uint32_t *cs_soff[3];
+    uint32_t cs_total[3];           // entries of each stream (64 entries that cover nothing follow them)
+    uint32_t cs_indirect[3];        // 1: the stream holds indirect entries (reads beyond the 8-bit fields)
     // wide records: true {aligned length, run count} per long-list entry (nullptr: the file has none) and by record index
     const uint2 *long_wide;
     const uint2 *xlong_wide;
@@ -1602,6 +1604,7 @@ __device__ __forceinline__ int64_t bucket_lower_bound(const GFile &fv, int64_t q
 }
 
 constexpr int kCenterRows = 4;        // 16-lane rows of a wave: independent replays
+
 __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *__restrict__ chunks, int64_t nchunks,
                                                             const FileView *__restrict__ files, int nfiles, int W,
                                                             uint32_t *cand_out, u32x4 *ranges, u32x2 *rec_ranges, uint32_t *row_ranges,
@@ -1650,6 +1653,7 @@ __global__ __launch_bounds__(kRangesWG) void k_center_weigh(const CenterChunk *_
             cand += rg.y - rg.x;
         }
         cand_out[c] = (uint32_t)(cand > 0xffffffffull ? 0xffffffffull : cand);
+
     }
     for (int o = 32; o > 0; o >>= 1) cand += __shfl_down(cand, o, 64);
     if ((threadIdx.x & 63) == 0 && cand) atomicAdd(total, cand);
@@ -1735,45 +1739,55 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 #define PC_CS_Q1 PC_CS_2(4, 5) PC_CS_2(6, 7)
 #define PC_CS_Q2 PC_CS_2(8, 9) PC_CS_2(10, 11)
 #define PC_CS_Q3 PC_CS_2(12, 13) PC_CS_2(14, 15)
+#ifndef PC_CENTER_RING
+#define PC_CENTER_RING 2   // batches of entries in flight per wave (2 / 3 / 4 measured on one box: 1.29 / 1.50 - 1.58 / 1.31 ms on C3)
+#endif
 #define PC_CENTER_STEPS(CODE)                                                                                          \
     asm volatile(PC_CS_HEAD CODE                                                                                       \
                  : [acc] "+v"(acc)                                                                                     \
                  : [cm] "v"(cm_), [val] "v"(valh_), [lbit] "v"(lane_bit), [sh] "v"(lane_sh)                            \
                  : "v8", "v9", "v10", "v11", "v12", "v13")
 
-__global__ __launch_bounds__(kCenterWG) void k_center(
-    const CenterChunk *__restrict__ chunks, int64_t nchunks, const FileView *__restrict__ files, int nfiles, MapParams mp, int W,
-    const double *__restrict__ inv_, const double *__restrict__ invh_, const double *__restrict__ cvalh_, const uint32_t *__restrict__ order,
-    const uint32_t *__restrict__ counters, const u32x4 *__restrict__ ranges, const u32x2 *__restrict__ rec_ranges,
-    const uint32_t *__restrict__ row_ranges, const OutPiece *__restrict__ opieces, double *out, double norm_sum, int norm_on,
-    unsigned long long *dbg) {
-    const double PC_GLOBAL *inv = (const double PC_GLOBAL *)inv_;      // 1.0 / m
-    const double PC_GLOBAL *invh = (const double PC_GLOBAL *)invh_;    // 0.5 / m = (1.0 / m) / 2, exactly
-    const char PC_GLOBAL *cvalh = (const char PC_GLOBAL *)cvalh_;      // 0.5 / (L - 2 nibble) by aligned length L < 256 (0.0: not counted)
-    // the list holds the heavy entries at its front and the light ones at its back; workgroup b serves the b-th
-    // entry of the two runs (the grid is their exact number once a count of the plan has shown it, else 2 x chunks,
-    // which bounds it).  One wave per entry: persistent waves that take entries off the list (heavy first, light
-    // ones a few at a time) were measured at 2.3 - 2.4 ms against 1.6 on C3, whatever the grab size.
-    // Light entries are dealt so that the workgroups of one XCD (workgroup b runs on XCD b mod 8) walk ONE contiguous
-    // eighth of the list: neighbouring chunks re-read each other's halo, and that then hits the XCD's own L2.
-    const uint32_t cap = kCenterCap * (uint32_t)nchunks;
-    const uint32_t n_heavy = counters[0], n_light = counters[1];
-    const uint32_t bidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (uint32_t)kCenterWG + threadIdx.x) >> 6));
-    uint32_t slot;
-    if (bidx < n_heavy) {
-        slot = bidx;
-    } else {
-        const uint32_t k = bidx - n_heavy, n8 = (n_light + 7u) >> 3;
-        if (k >= 8u * n8) return;
-        const uint32_t kk = (bidx & 7u) * n8 + (k >> 3);
-        if (kk >= n_light) return;
-        slot = cap - 1u - kk;
-    }
-    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+struct CenterCtx {
+    const CenterChunk *chunks;
+    int64_t nchunks;
+    const FileView *files;
+    int nfiles;
+    MapParams mp;
+    int W;
+    const double *inv, *invh, *cvalh;
+    const uint32_t *order, *counters;
+    const u32x4 *ranges;
+    const u32x2 *rec_ranges;
+    const uint32_t *row_ranges;
+    const OutPiece *opieces;
+    double *out;
+    double norm_sum;
+    int norm_on;
+    unsigned long long *dbg;
+};
+
+// One dispatch entry -- a whole chunk (code 0) or a sub-chunk of a cut one -- replayed by one wave.
+// DBG: count the replay steps (PC_CENTER_DEBUG, pc_center_replay_steps).  GENERAL: some staged file holds reads a stream
+// entry cannot describe (aligned length > 255: indirect entries) or a stream too long for 32-bit byte offsets -- the
+// stream loop then tests every batch for them; short-read files run the instantiation that does not.
+template <bool DBG, bool GENERAL>
+__device__ __forceinline__ void center_chunk(const CenterCtx &cx, const uint32_t cidx, const uint32_t code, const CenterChunk ck, const int lane,
+                                             const double *s_valh, unsigned long long &n_slots) {
+    const double PC_GLOBAL *inv = (const double PC_GLOBAL *)cx.inv;      // 1.0 / m
+    const double PC_GLOBAL *invh = (const double PC_GLOBAL *)cx.invh;    // 0.5 / m = (1.0 / m) / 2, exactly
+    const MapParams &mp = cx.mp;
+    const FileView *files = cx.files;
+    const int nfiles = cx.nfiles, W = cx.W;
+    const u32x4 *ranges = cx.ranges;
+    const u32x2 *rec_ranges = cx.rec_ranges;
+    const uint32_t *row_ranges = cx.row_ranges;
+    const OutPiece *opieces = cx.opieces;
+    double *out = cx.out;
+    const double norm_sum = cx.norm_sum;
+    const int norm_on = cx.norm_on;
+    const int row = lane >> 4, li = lane & 15;
     const int nib = mp.param;
-    const uint32_t entry = order[slot];
-    const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
-    const CenterChunk ck = chunks[cidx];
     // a sub-chunk is a chunk of its own: 16 (8) positions, rows of 4 (2)
     const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
     const int roww = code == 0u ? 16 : (code <= 4u ? 4 : 2);
@@ -1788,21 +1802,19 @@ __global__ __launch_bounds__(kCenterWG) void k_center(
     const int sel = center_sel(ck.mode);
     const int lane_bit = 1 << li, lane_sh = 30 - li;
     double acc = 0.0;
-    const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
-    unsigned long long n_slots = 0;   // PC_CENTER_DEBUG: replay steps of this wave
     for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
         const GFile fv = gfile(files[f]);
         const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[(int64_t)cidx * nfiles + f]; // from k_center_weigh
         // One entry, already trimmed by the nibble: counted positions [a0, a0 + m) of a read of aligned length L.  What
         // the replay needs of it: the coverage mask of this lane's ROW and half the read's value.
-        auto row_mask = [&](bool valid, int a0, int m) {
+        auto row_mask = [&](int a0, int m) {   // (m = 0: nothing)
             const int first = a0 - rs, b0 = first > 0 ? first : 0, b1 = first + m < 16 ? first + m : 16;   // row-relative [b0, b1)
-            return (valid && b1 > b0) ? (int)((1u << b1) - (1u << b0)) : 0;
+            return b1 > b0 ? (int)((1u << b1) - (1u << b0)) : 0;
         };
         // one batch: entry `li` of every row in (cm_, valh_); `indirect`: a read the entry cannot describe (record `recidx`)
-        auto replay = [&](int a0_, int mm_, int cm_, double valh_, bool indirect, uint32_t recidx, int nsteps) {   // (a0_, mm_: the slow path's)
-            n_slots += (unsigned long long)nsteps;
-            if (__any(indirect)) {
+        auto replay = [&](int a0_, int mm_, int cm_, double valh_, bool indirect, uint32_t recidx, int nsteps, bool may_be_indirect) {   // (a0_, mm_: the slow path's)
+            if (DBG) n_slots += (unsigned long long)nsteps;
+            if (may_be_indirect && __any(indirect)) {
                 // entry by entry, row by row (what matters is the order inside a row)
                 for (int j = 0; j < 16; ++j) {
                     for (int r = 0; r < kCenterRows; ++r) {
@@ -1856,10 +1868,10 @@ __global__ __launch_bounds__(kCenterWG) void k_center(
                 const int x = r ? runs.z : runs.x, len = r ? runs.w : runs.y, cum = r ? runs.y : 0;
                 const int lo_i = cum > nib ? cum : nib, hi_i = cum + len < Lg - nib ? cum + len : Lg - nib;
                 const int a0_ = x + (lo_i - cum), mm_ = hi_i > lo_i ? hi_i - lo_i : 0, mtot = Lg - 2 * nib;
-                const int cm_ = row_mask(ok && nbk <= 2 && (r == 0 || nbk == 2) && size_ok(mp, Lg), a0_, mm_);
+                const int cm_ = (ok && nbk <= 2 && (r == 0 || nbk == 2) && size_ok(mp, Lg)) ? row_mask(a0_, mm_) : 0;
                 double valh_ = 0.0;
                 if (cm_) valh_ = mtot < 65536 ? invh[mtot] : (1.0 / (double)mtot) * 0.5;   // cm != 0 implies mtot >= m > 0
-                replay(a0_, mm_, cm_, valh_, ok && nbk > 2 && r == 0, g.w, 16);
+                replay(a0_, mm_, cm_, valh_, ok && nbk > 2 && r == 0, g.w, 16, true);
             }
         }
         // near windows: row r replays the stream entries of the records that start in [rs - W + 1, re).  Whole chunks
@@ -1888,40 +1900,52 @@ __global__ __launch_bounds__(kCenterWG) void k_center(
         }
         if (nmax == 0u) continue;
         const u32x2 PC_GLOBAL *ent = cs_stream(files + f, sel);
-        // (the loads are unconditional, with the index clamped to the row's end: entry `hi` is readable -- another
-        // row's, or the padding behind the last entry -- and a lane past its row's end treats it as covering nothing;
-        // 32-bit offsets from the chunk's first entry: one scalar base, no 64-bit address arithmetic per lane)
+        // (the loads are unconditional: a lane past its row's end reads one of the 64 entries behind the stream's last,
+        // which cover nothing -- no validity test per entry; 32-bit offsets from the chunk's first entry: one scalar base,
+        // no 64-bit address arithmetic per lane)
         const char PC_GLOBAL *eb = (const char PC_GLOBAL *)(ent + rg.x);
-        const uint32_t rlo = lo - rg.x + (uint32_t)li, rhi = hi - rg.x;
+        // (a stream so long that its end is beyond a 32-bit byte offset from here -- > 5e8 entries -- clamps to the row's
+        // end instead and tests every entry's index)
+        const uint32_t to_end = files[f].cs_total[sel] - rg.x;
+        const bool far = GENERAL && to_end >= (1u << 28);
+        const uint32_t rlo = lo - rg.x + (uint32_t)li, rhi = hi - rg.x, dead = far ? rhi : to_end + (uint32_t)li;
         auto fetch = [&](uint32_t base) {
             const uint32_t idx = rlo + base;
-            return *(const u32x2 PC_GLOBAL *)(eb + ((idx < rhi ? idx : rhi) << 3));
+            return *(const u32x2 PC_GLOBAL *)(eb + ((idx < rhi ? idx : dead) << 3));
         };
-        // three batches in flight: entries two ahead; coverage mask and half value -- a gather by aligned length -- one ahead
-        auto unpack = [&](const u32x2 q, uint32_t base, int &cm, double &valh, bool &ind) {
-            const bool valid = rlo + base < rhi;
-            ind = valid && ((q.y >> 24) & kCsIndirect);
-            cm = row_mask(valid && !ind, (int32_t)q.x, (int)(q.y & 0xffu));
-            valh = *(const double PC_GLOBAL *)(cvalh + ((q.y >> 13) & 0x7f8u));   // cvalh[L], L = bits 16-23 (an indirect entry reads [0])
+        const bool any_indirect = GENERAL && files[f].cs_indirect[sel] != 0u;   // (uniform: short-read files have none, and never look)
+        // PC_CENTER_RING batches of entries in flight, each in a register pair of its own (a copy of a register with a load
+        // outstanding waits for that load: the loop body is unrolled over the ring instead).  The batch after the one
+        // being replayed is already unpacked -- coverage mask, and half the read's value out of the LDS copy of the
+        // by-length table (a global gather would be the youngest load in flight, and waiting for the youngest waits for
+        // all of them) -- so that neither the entry load nor the LDS read is waited for right before its steps.
+        struct Prepared { int cm; double valh; bool ind; u32x2 r; };
+        auto unpack = [&](const u32x2 r, uint32_t base) {
+            Prepared pr;
+            pr.r = r;
+            pr.ind = any_indirect && ((r.y >> 24) & kCsIndirect);     // (an indirect entry carries m = 0)
+            pr.cm = row_mask((int32_t)r.x, (int)(r.y & 0xffu));
+            if (far && !(rlo + base < rhi)) pr.cm = 0;
+            pr.valh = s_valh[(r.y >> 16) & 0xffu];   // by aligned length (an indirect entry reads [0])
+            return pr;
         };
-        u32x2 q1 = fetch(0u), q2 = fetch(16u);
-        int cmn;
-        double valn;
-        bool indn;
-        u32x2 qn = q1;
-        unpack(q1, 0u, cmn, valn, indn);
-        q1 = q2;
-        for (uint32_t base = 0; base < nmax; base += 16u) {
-            const int cmc = cmn;
-            const double valc = valn;
-            const bool indc = indn;
-            const u32x2 qc = qn;
-            q2 = fetch(base + 32u);
-            qn = q1;
-            unpack(q1, base + 16u, cmn, valn, indn);
-            q1 = q2;
-            const uint32_t left = nmax - base;
-            replay((int32_t)qc.x, (int)(qc.y & 0xffu), cmc, valc, indc, qc.x, left >= 16u ? 16 : (int)((left + 3u) & ~3u));
+        u32x2 q[PC_CENTER_RING];
+#pragma unroll
+        for (int k = 0; k < PC_CENTER_RING; ++k) q[k] = fetch(16u * (uint32_t)k);
+        Prepared nxt = unpack(q[0], 0u);
+        q[0] = fetch(16u * PC_CENTER_RING);
+        for (uint32_t base = 0; base < nmax;) {
+#pragma unroll
+            for (int k = 0; k < PC_CENTER_RING; ++k) {
+                const Prepared cur = nxt;
+                const int kn = (k + 1) % PC_CENTER_RING;   // (a constant once the loop is unrolled: q stays in registers)
+                nxt = unpack(q[kn], base + 16u);
+                q[kn] = fetch(base + 16u + 16u * PC_CENTER_RING);
+                const uint32_t left = nmax - base;
+                replay((int32_t)cur.r.x, (int)(cur.r.y & 0xffu), cur.cm, cur.valh, cur.ind, cur.r.x, left >= 16u ? 16 : (int)((left + 3u) & ~3u), GENERAL);
+                base += 16u;
+                if (base >= nmax) break;
+            }
         }
     }
     // The sums go straight into the caller's layout (SegmentChain.get_counts, roitools.pyx:3259-3271: chain offset,
@@ -1936,6 +1960,46 @@ __global__ __launch_bounds__(kCenterWG) void k_center(
             const uint32_t rel = (uint32_t)(p - o.start);
             if (owns && rel < (uint32_t)o.len) out[o.out_off + (int64_t)o.step * (int64_t)rel] = val;
         }
+    }
+}
+
+// Dispatch: one wave per entry of the list.  The HEAVY entries -- chunks far above the mean, the deepest cut into
+// sub-chunks (k_center_order) -- sit at the front of the list and start at t = 0, the light ones follow from the back.
+// Light entries are dealt so that the workgroups of one XCD (workgroup b runs on XCD b mod 8) walk ONE contiguous
+// eighth of the list: neighbouring chunks re-read each other's halo, and that then hits the XCD's own L2.
+// (Persistent waves were measured twice and dropped twice: pulling chunks from a queue, round 3, 2.3 - 2.4 ms against
+// 1.6; walking equal-work stretches of the chunk list -- the replay steps of every chunk are known exactly from the
+// pre-pass -- with the next descriptor requested ahead, round 4, 1.27 - 1.32 ms against 1.13: the per-chunk fixed cost is
+// instructions, not dispatch, and the stretches finish unevenly.)
+template <bool DBG, bool GENERAL>
+__global__ __launch_bounds__(kCenterWG) void k_center(CenterCtx cx) {
+    const uint32_t cap = kCenterCap * (uint32_t)cx.nchunks;
+    const uint32_t n_heavy = cx.counters[0];
+    const uint32_t bidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (uint32_t)kCenterWG + threadIdx.x) >> 6));
+    const int lane = threadIdx.x & 63;
+    unsigned long long *dbg = DBG ? cx.dbg : nullptr;
+    const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
+    unsigned long long n_slots = 0;   // PC_CENTER_DEBUG / pc_center_replay_steps: replay steps of this wave
+    // half the value of a read by aligned length (k_center_vals), in LDS: one copy per wave
+    __shared__ double s_valh[256];
+    for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
+    __builtin_amdgcn_wave_barrier();
+    uint32_t slot;
+    if (bidx < n_heavy) {
+        slot = bidx;
+        const uint32_t entry = cx.order[slot];
+        const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
+        center_chunk<DBG, GENERAL>(cx, cidx, code, cx.chunks[cidx], lane, s_valh, n_slots);
+    } else {
+        // one wave per light entry of the list, dealt so that the workgroups of one XCD (workgroup b runs on XCD b mod 8)
+        // walk ONE contiguous eighth of it: neighbouring chunks re-read each other's halo, and that then hits the XCD's own L2
+        const uint32_t n_light = cx.counters[1], k = bidx - n_heavy, n8 = (n_light + 7u) >> 3;
+        if (k >= 8u * n8) return;
+        const uint32_t kk = (bidx & 7u) * n8 + (k >> 3);
+        if (kk >= n_light) return;
+        slot = cap - 1u - kk;
+        const uint32_t cidx = cx.order[slot];
+        center_chunk<DBG, GENERAL>(cx, cidx, 0u, cx.chunks[cidx], lane, s_valh, n_slots);
     }
     if (dbg && lane == 0) {   // PC_CENTER_DEBUG
         dbg[2 * (size_t)slot] = wall_clock64() - t_begin; dbg[2 * (size_t)slot + 1] = t_begin;

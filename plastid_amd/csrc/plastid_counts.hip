@@ -276,7 +276,11 @@ struct StagedFile {
         v.lin_tab = lin_tab.p; v.glin_tab = glin_tab.p; v.llin_tab = llin_tab.p; v.plin_tab = plin_tab.p; v.lin_off = lin_off.p;
         v.run_rec = run_rec.p; v.rlin_tab = rlin_tab.p; v.nrunrec = nrunrec;
         v.xlong_rec = xlong_rec.p; v.xlong_runs = xlong_runs.p; v.xllin_tab = xllin_tab.p; v.xplin_tab = xplin_tab.p; v.nxlong = nxlong;
-        for (int k = 0; k < 3; ++k) { v.cs_ent[k] = cs_n[k] >= 0 ? cs_ent[k].p : nullptr; v.cs_soff[k] = cs_n[k] >= 0 ? cs_soff[k].p : nullptr; }
+        for (int k = 0; k < 3; ++k) {
+            v.cs_ent[k] = cs_n[k] >= 0 ? cs_ent[k].p : nullptr; v.cs_soff[k] = cs_n[k] >= 0 ? cs_soff[k].p : nullptr;
+            v.cs_total[k] = cs_n[k] >= 0 ? (uint32_t)cs_n[k] : 0u;
+            v.cs_indirect[k] = len_max > 255 ? 1u : 0u;   // (reads beyond the 8-bit fields of a stream entry)
+        }
         v.long_wide = nwide ? long_wide.p : nullptr; v.xlong_wide = nwide ? xlong_wide.p : nullptr;
         v.wide_rec = wide_rec.p; v.wide_val = wide_val.p; v.nwide = nwide;
         return v;
@@ -2158,66 +2162,66 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 p->center_counts[1] = p->h_center_counts[1];
                 p->center_counts_known = true;
             }
-            uint64_t cgrid = 2 * (uint64_t)nchunks;   // bounds heavy + light entries (fewer than an eighth of the chunks are cut, into at most eight)
-            if (p->center_counts_known) cgrid = std::max<uint64_t>(1, (uint64_t)p->center_counts[0] + p->center_counts[1]);
-            cgrid += 8;   // (the light entries are dealt to the XCDs in eighths, rounded up)
+            // grid: one wave per entry of the list -- their exact number once a count of the plan has shown it, else twice the
+            // chunks, which bounds it (fewer than an eighth of the chunks are cut, into at most eight); + 8: the light entries
+            // are dealt to the XCDs in eighths, rounded up
+            uint64_t cgrid = (p->center_counts_known ? (uint64_t)p->center_counts[0] + p->center_counts[1] : 2 * (uint64_t)nchunks) + 8;
             // PC_CENTER_DEBUG: how long every dispatched wave ran (wall clock ticks), printed after the launch
             DevBuf<unsigned long long> d_dbg;
             const bool dbg_on = e->knobs.center_debug != 0 || e->want_center_steps;
+            const size_t dbg_slots = (size_t)(kCenterCap * nchunks);   // heavy entries from the front, light ones from the back
             if (dbg_on) {
-                rc = d_dbg.reserve((size_t)(2 * kCenterCap * nchunks) + (size_t)kCenterCap * nchunks);
+                rc = d_dbg.reserve(3 * dbg_slots);
                 if (rc != PC_OK) return rc;
-                HIP_TRY(hipMemsetAsync(d_dbg.p, 0, (size_t)(3 * kCenterCap * nchunks) * 8, st));
+                HIP_TRY(hipMemsetAsync(d_dbg.p, 0, 3 * dbg_slots * 8, st));
             }
             unsigned long long *dbg = dbg_on ? d_dbg.p : nullptr;
-            hipLaunchKernelGGL(k_center, dim3((unsigned)((cgrid * 64 + kCenterWG - 1) / kCenterWG)), dim3(kCenterWG), (size_t)e->knobs.center_lds, st, p->d_cchunks.p, nchunks,
-                               e->d_files.p, nfiles, mp, W, e->d_inv.p, e->d_invh.p, e->d_cvalh.p, p->d_corder.p, p->d_ccounts.p, p->d_cranges.p,
-                               p->d_crec.p, p->d_crows.p, p->d_opieces.p, (double *)p->d_out.p, e->norm_sum, e->norm_on ? 1 : 0, dbg);
-            if (e->want_center_steps) {   // diagnostic launch: replay steps and dispatched waves, summed on the host
-                std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks)), h_slots((size_t)(kCenterCap * nchunks));
+            CenterCtx cx;
+            cx.chunks = p->d_cchunks.p; cx.nchunks = nchunks; cx.files = e->d_files.p; cx.nfiles = nfiles; cx.mp = mp; cx.W = W;
+            cx.inv = e->d_inv.p; cx.invh = e->d_invh.p; cx.cvalh = e->d_cvalh.p; cx.order = p->d_corder.p; cx.counters = p->d_ccounts.p;
+            cx.ranges = p->d_cranges.p; cx.rec_ranges = p->d_crec.p; cx.row_ranges = p->d_crows.p; cx.opieces = p->d_opieces.p;
+            cx.out = (double *)p->d_out.p; cx.norm_sum = e->norm_sum; cx.norm_on = e->norm_on ? 1 : 0;
+            cx.dbg = dbg;
+            // (files with reads beyond a stream entry's 8-bit fields, or a stream too long for 32-bit byte offsets, take the
+            // instantiation that tests every batch for them)
+            bool general = false;
+            for (auto *f : e->files) general |= f->len_max > 255 || f->n + f->nrun >= ((int64_t)1 << 28);
+            const dim3 cg((unsigned)((cgrid * 64 + kCenterWG - 1) / kCenterWG));
+            if (dbg_on) {
+                if (general) hipLaunchKernelGGL((k_center<true, true>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
+                else hipLaunchKernelGGL((k_center<true, false>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
+            } else {
+                if (general) hipLaunchKernelGGL((k_center<false, true>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
+                else hipLaunchKernelGGL((k_center<false, false>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
+            }
+            if (dbg_on) {   // diagnostic launch: replay steps and dispatched waves, summed on the host; PC_CENTER_DEBUG prints them
+                std::vector<unsigned long long> h(2 * dbg_slots), h_slots(dbg_slots);
                 HIP_TRY(hipStreamSynchronize(st));
                 HIP_TRY(hipMemcpy(h.data(), d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
                 HIP_TRY(hipMemcpy(h_slots.data(), d_dbg.p + h.size(), h_slots.size() * 8, hipMemcpyDeviceToHost));
                 e->center_steps = 0; e->center_waves = 0;
-                for (size_t i = 0; i < h_slots.size(); ++i)
-                    if (h[2 * i]) { e->center_steps += (int64_t)h_slots[i]; e->center_waves += 1; }
-            }
-            if (e->knobs.center_debug != 0) {
-                std::vector<unsigned long long> h((size_t)(2 * kCenterCap * nchunks)), h_slots((size_t)(kCenterCap * nchunks));
-                std::vector<uint32_t> h_order((size_t)(kCenterCap * nchunks)), h_cand((size_t)nchunks);
-                HIP_TRY(hipStreamSynchronize(st));
-                HIP_TRY(hipMemcpy(h.data(), d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(h_slots.data(), d_dbg.p + h.size(), h_slots.size() * 8, hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(h_order.data(), p->d_corder.p, h_order.size() * 4, hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(h_cand.data(), p->d_ccand.p, h_cand.size() * 4, hipMemcpyDeviceToHost));
-                {   // replayed entry slots per class of dispatch entry (whole chunk / quarter / eighth)
-                    unsigned long long cls[3] = {0, 0, 0}, ncl[3] = {0, 0, 0};
-                    for (size_t i = 0; i < h_slots.size(); ++i)
-                        if (h[2 * i]) {
-                            const uint32_t code = h_order[i] >> kSubShift;
-                            const int k = code == 0u ? 0 : (code <= 4u ? 1 : 2);
-                            cls[k] += h_slots[i]; ncl[k] += 1;
-                        }
-                    fprintf(stderr, "[center] replayed entry slots: whole chunks %llu in %llu waves, quarters %llu in %llu, eighths %llu in %llu\n", cls[0], ncl[0],
-                            cls[1], ncl[1], cls[2], ncl[2]);
-                }
-                unsigned long long t0 = ~0ull, t1 = 0, sum = 0;
-                size_t nw = 0;
+                unsigned long long t0 = ~0ull, t1 = 0, sum = 0, steps_heavy = 0, steps_pers = 0, n_heavy_w = 0, n_pers_w = 0;
+                const size_t n_front = (size_t)nchunks;   // (heavy entries occupy the front of the list: fewer than the chunk count)
                 std::vector<std::pair<unsigned long long, size_t>> byd;
-                for (size_t i = 0; i < h.size() / 2; ++i)
+                for (size_t i = 0; i < dbg_slots; ++i)
                     if (h[2 * i]) {
+                        e->center_steps += (int64_t)h_slots[i]; e->center_waves += 1;
+                        const bool pers = i >= n_front;
+                        (pers ? steps_pers : steps_heavy) += h_slots[i];
+                        (pers ? n_pers_w : n_heavy_w) += 1;
                         t0 = std::min(t0, h[2 * i + 1]); t1 = std::max(t1, h[2 * i + 1] + h[2 * i]);
-                        sum += h[2 * i]; ++nw;
+                        sum += h[2 * i];
                         byd.emplace_back(h[2 * i], i);
                     }
-                std::sort(byd.rbegin(), byd.rend());
-                fprintf(stderr, "[center] W %d: %zu waves, launch span %llu ticks (100 MHz: %.3f ms), summed wave time %llu ticks = %.1f x the span\n", W, nw, t1 - t0,
-                        (t1 - t0) / 1e5, sum, (double)sum / (double)std::max<unsigned long long>(t1 - t0, 1));
-                {   // resident waves over the launch, in twenty slices of its span
+                if (e->knobs.center_debug != 0) {
+                    fprintf(stderr, "[center] replay steps: %llu in %llu waves of the heavy entries, %llu in %llu waves of the light ones\n", steps_heavy, n_heavy_w,
+                            steps_pers, n_pers_w);
+                    fprintf(stderr, "[center] W %d: launch span %llu ticks (100 MHz: %.3f ms), summed wave time %llu ticks = %.1f x the span\n", W, t1 - t0,
+                            (t1 - t0) / 1e5, sum, (double)sum / (double)std::max<unsigned long long>(t1 - t0, 1));
                     const int nb = 20;
                     std::vector<double> occ(nb, 0.0);
                     const double span = (double)std::max<unsigned long long>(t1 - t0, 1);
-                    for (size_t i = 0; i < h.size() / 2; ++i)
+                    for (size_t i = 0; i < dbg_slots; ++i)
                         if (h[2 * i]) {
                             const double a = (double)(h[2 * i + 1] - t0) / span * nb, b = (double)(h[2 * i + 1] + h[2 * i] - t0) / span * nb;
                             for (int k = std::max(0, (int)a); k < nb && k < b; ++k) occ[(size_t)k] += std::min(b, k + 1.0) - std::max(a, (double)k);
@@ -2225,12 +2229,16 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                     fprintf(stderr, "[center] resident waves per twentieth of the launch:");
                     for (int k = 0; k < nb; ++k) fprintf(stderr, " %.0f", occ[(size_t)k]);
                     fprintf(stderr, "\n");
-                }
-                for (size_t k = 0; k < std::min<size_t>(byd.size(), 12); ++k) {
-                    const size_t i = byd[k].second;
-                    const uint32_t en = h_order[i], ci = en & ((1u << kSubShift) - 1u);
-                    fprintf(stderr, "[center]   slot %zu: %.3f ms, started at %.3f ms, chunk %u code %u, candidates %u\n", i, byd[k].first / 1e5,
-                            (h[2 * i + 1] - t0) / 1e5, ci, en >> kSubShift, h_cand[ci]);
+                    std::sort(byd.rbegin(), byd.rend());
+                    for (size_t k = 0; k < std::min<size_t>(byd.size(), 8); ++k) {
+                        const size_t i = byd[k].second;
+                        fprintf(stderr, "[center]   slot %zu (%s): %.3f ms, started at %.3f ms, %llu steps\n", i,
+                                i >= n_front ? "light" : "heavy", byd[k].first / 1e5, (h[2 * i + 1] - t0) / 1e5, h_slots[i]);
+                    }
+                    if (!byd.empty()) {
+                        const size_t i = byd.back().second;
+                        fprintf(stderr, "[center]   shortest: slot %zu: %.3f ms, %llu steps\n", i, byd.back().first / 1e5, h_slots[i]);
+                    }
                 }
             }
         }
