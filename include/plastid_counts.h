@@ -220,6 +220,34 @@ int pc_center_replay_steps(pc_engine *e, pc_plan *p, int64_t *steps, int64_t *wa
  * denominator of SURVEY.md 8(d); no reference counterpart. */
 int pc_stream_probe(pc_engine *e, int64_t bytes, int iters, double *read_gbps, double *write_gbps);
 
+/* ---- compressed BAM on the GPU (extends SURVEY.md 8(f1)).
+ * Replaces, for a whole coordinate-sorted file, what the reference gets from pysam / htslib: `pysam.AlignmentFile(X, "rb")`
+ * + `fetch` + `read.positions` / `read.is_reverse` / `.mapped` (plastid/genomics/genome_array.py:660, 669, 690, 800-815),
+ * i.e. htslib's BGZF reader (kent/src/htslib/bgzf.c:292-340 block header, :421-530 inflate + CRC check), bam_read1
+ * (kent/src/htslib/sam.c) and the CIGAR operation table (kent/src/htslib/htslib/sam.h:64-104).
+ * `image` = the bytes of the .bam file (host memory; e.g. an mmap).  The BGZF members are inflated on the GPU (one wave
+ * per member), the BAM records found and decoded there; what comes back are the packed columns pc_add_alignment_file
+ * takes -- bit-identical to those of the host decoder (plastid_amd/csrc/bam_stager.cpp), same checks, same messages.
+ * Errors: PC_ERR_ARG (not a BGZF / BAM file, damaged member, CRC mismatch, corrupt record), PC_ERR_UNSORTED (not
+ * coordinate sorted -- pysam raises ValueError at fetch, genome_array.py:784-787). */
+typedef struct pc_bam pc_bam;
+int pc_bam_open(pc_engine *e, const void *image, int64_t size, const char *name /* for messages; may be NULL */, pc_bam **out);
+/* counts[0] staged (placed) records, [1] runs of the multi-run ones, [2] mapped (flag 0x4 unset: pysam's .mapped),
+ * [3] all records, [4] wide records, [5] BGZF members, [6] inflated bytes, [7] members whose first-record guess was redone */
+int pc_bam_counts(pc_bam *b, int64_t *counts8);
+/* milliseconds on the engine's stream: [0] upload of the image, [1] inflate + CRC, [2] record chain, [3] fields + columns */
+int pc_bam_timing(pc_bam *b, double *ms4);
+int pc_bam_nref(pc_bam *b);
+const char *pc_bam_ref_name(pc_bam *b, int i);
+int32_t pc_bam_ref_length(pc_bam *b, int i);
+/* the columns, to caller-owned arrays of counts[0] / counts[1] / counts[4] elements (see pc_add_alignment_file_wide) */
+int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags, uint8_t *nblk, int32_t *blk_start,
+                int32_t *blk_len, int64_t *wide_idx, int32_t *wide_alen, int32_t *wide_nblk);
+int pc_bam_close(pc_bam *b);
+/* decode `image` and stage it as one more alignment file of the engine (reference ids = the file's own reference
+ * list, which must be that of the files staged before it); *mapped (optional) = the file's mapped-read count */
+int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped);
+
 #ifdef __cplusplus
 }
 #endif

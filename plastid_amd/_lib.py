@@ -68,6 +68,15 @@ SIGNATURES = {
     "pc_last_algorithmic_bytes": (_i64, [_vp]),
     "pc_center_replay_steps": (_int, [_vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "pc_stream_probe": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "pc_bam_open": (_int, [_vp, _vp, _i64, ctypes.c_char_p, _pp]),
+    "pc_bam_counts": (_int, [_vp, _vp]),
+    "pc_bam_timing": (_int, [_vp, _vp]),
+    "pc_bam_nref": (_int, [_vp]),
+    "pc_bam_ref_name": (ctypes.c_char_p, [_vp, _int]),
+    "pc_bam_ref_length": (_i32, [_vp, _int]),
+    "pc_bam_read": (_int, [_vp] * 11),
+    "pc_bam_close": (_int, [_vp]),
+    "pc_add_alignment_bam": (_int, [_vp, _vp, _i64, ctypes.c_char_p, ctypes.POINTER(_i64)]),
 }
 
 _lib = None

@@ -44,6 +44,58 @@ def _load():
     return _lib
 
 
+def read_bam_gpu(path, engine, timing=None):
+    """The same :class:`PackedAlignments` as :func:`read_bam` gives for a whole file, decoded ON THE GPU: the file image
+    goes to HBM as it is, the BGZF members are inflated there (one wave per member) and the BAM records decoded
+    (``pc_bam_open``, ``csrc/bam_kernels.hip.h``); only the packed columns -- 13 bytes per record instead of the ~120 of
+    an aligner's record -- come back.  `engine`: a :class:`plastid_amd.engine.Engine` (its device and stream are used).
+    `timing`: optional dict that receives the phase times in ms and the member / byte counts."""
+    import mmap
+    from . import _lib as clib
+    L = clib.load()
+    with open(path, "rb") as fh:
+        size = os.fstat(fh.fileno()).st_size
+        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) if size else None
+        try:
+            h = ctypes.c_void_p()
+            if size:
+                view = np.frombuffer(mm, dtype=np.uint8)
+                rc = L.pc_bam_open(engine._h, view.ctypes.data_as(ctypes.c_void_p), size, os.fsencode(path), ctypes.byref(h))
+                del view
+            else:
+                rc = L.pc_bam_open(engine._h, None, 0, os.fsencode(path), ctypes.byref(h))
+        finally:
+            if mm is not None:
+                mm.close()
+    clib.check(rc)
+    try:
+        counts = np.zeros(8, np.int64)
+        clib.check(L.pc_bam_counts(h, counts.ctypes.data_as(ctypes.c_void_p)))
+        n, nrun, mapped, nw = int(counts[0]), int(counts[1]), int(counts[2]), int(counts[4])
+        nref = L.pc_bam_nref(h)
+        refs = [L.pc_bam_ref_name(h, i).decode() for i in range(nref)]
+        lens = [int(L.pc_bam_ref_length(h, i)) for i in range(nref)]
+        tid, pos = np.empty(n, np.int32), np.empty(n, np.int32)
+        alen, flags, nblk = np.empty(n, np.uint16), np.empty(n, np.uint8), np.empty(n, np.uint8)
+        bs, bl = np.empty(nrun, np.int32), np.empty(nrun, np.int32)
+        wi, wa, wn = np.empty(nw, np.int64), np.empty(nw, np.int32), np.empty(nw, np.int32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        clib.check(L.pc_bam_read(h, p(tid), p(pos), p(alen), p(flags), p(nblk), p(bs), p(bl), p(wi), p(wa), p(wn)))
+        if timing is not None:
+            ms = np.zeros(4, np.float64)
+            clib.check(L.pc_bam_timing(h, p(ms)))
+            timing.update(upload_ms=float(ms[0]), inflate_ms=float(ms[1]), chain_ms=float(ms[2]), decode_ms=float(ms[3]),
+                          members=int(counts[5]), inflated_bytes=int(counts[6]), compressed_bytes=size, chain_restarts=int(counts[7]),
+                          records=int(counts[3]))
+    finally:
+        L.pc_bam_close(h)
+    wide = dict(wide_idx=wi, wide_alen=wa, wide_nblk=wn) if nw else {}
+    out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
+                           validate=False, **wide)   # the device decoder has checked every invariant validate() checks
+    out.filename = path
+    return out
+
+
 def read_bam(path, threads=0, regions=None):
     """Read a coordinate-sorted BAM file into a :class:`PackedAlignments`.
 

@@ -63,82 +63,83 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t c, int len) { return __brev(
 
 // Canonical Huffman code of `n` symbols with code lengths `lens` (0: unused) -> two-level decode table with `root`
 // first-level bits.  Run by the whole wave (wave-uniform control flow; the fills are spread over the lanes).
-// LITLEN: symbols 0-255 literals, 256 end of block, 257-285 lengths; else distances.  Returns 0, or an error code
-// (over-subscribed or incomplete code -- a single distance code is allowed, as in zlib -- or a table that does not
-// fit `cap` entries).
-template <bool LITLEN>
-__device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table, int cap, uint16_t *scratch, int lane) {
-    // counts per length (uniform: every lane walks the lengths; n <= 288)
+// KIND 0: literal/length alphabet (symbols 0-255 literals, 256 end of block, 257-285 lengths); 1: distances; 2: the
+// code-length alphabet (every symbol a "literal").  Returns 0, or an error code (over-subscribed or incomplete code --
+// a single one-bit code is allowed, as in zlib -- or a table that does not fit `cap` entries).
+// Small arrays live in LDS (`ws`): run-time indices into private arrays would put them into scratch memory.
+struct TableScratch {
     int count[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) count[i] = 0;
-    for (int s = 0; s < n; ++s) count[lens[s]] += 1;
-    count[0] = 0;
-    int left = 1, maxlen = 0, nsym = 0;
-    for (int len = 1; len <= 15; ++len) {
-        left = (left << 1) - count[len];
+    int next[16];
+    uint16_t code[320];
+    uint8_t subbits[512];
+};
+
+template <int KIND>
+__device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table, int cap, TableScratch *ws, int lane) {
+    // symbols per code length: lane L (1..15) counts the symbols of length L
+    if (lane < 16) {
+        int c = 0;
+        if (lane >= 1) for (int s = 0; s < n; ++s) c += lens[s] == lane ? 1 : 0;
+        ws->count[lane] = c;
+    }
+    __syncthreads();
+    int left = 1, maxlen = 0, nsym = 0, code = 0;
+    for (int len = 1; len <= 15; ++len) {          // (uniform: LDS broadcasts)
+        const int c = ws->count[len];
+        left = (left << 1) - c;
         if (left < 0) return kInfOverSubscribed;
-        if (count[len]) maxlen = len;
-        nsym += count[len];
+        if (c) maxlen = len;
+        nsym += c;
+        code = (code + ws->count[len - 1]) << 1;   // first code of this length
+        if (lane == 0) ws->next[len] = code;
     }
-    if (left > 0 && (LITLEN || nsym > 1)) return kInfOverSubscribed;   // incomplete code (zlib: inflate_table returns -1)
+    if (left > 0 && (KIND == 2 || maxlen != 1)) return kInfOverSubscribed;   // incomplete code: only a single one-bit code may be (zlib inftrees.c: `left > 0 && (type == CODES || max != 1)`)
     // clear the first level (an incomplete distance code leaves holes: they decode as "bad symbol")
-    for (int i = lane; i < (1 << root); i += 64) table[i] = 0u;
+    for (int i = lane; i < (1 << root); i += 64) { table[i] = 0u; if (i < 512) ws->subbits[i] = 0; }
+    __syncthreads();
     if (nsym == 0) return kInfOk;
-    int next_code[16];
-    {
-        int code = 0;
-        next_code[0] = 0;
-        for (int len = 1; len <= 15; ++len) { code = (code + count[len - 1]) << 1; next_code[len] = code; }
-    }
-    // second-level tables: index bits per first-level prefix = longest code with that prefix - root
-    uint8_t *subbits = (uint8_t *)scratch;            // [1 << root]
-    if (maxlen > root) {
-        for (int i = lane; i < (1 << root); i += 64) subbits[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-    }
-    // pass over the symbols in order (canonical codes are assigned in symbol order within a length): every lane
-    // computes the codes of all symbols (cheap, uniform) and fills its share of the replicated entries
-    int nc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) nc[i] = next_code[i];
-    if (maxlen > root) {
+    // codes in symbol order within a length (lane 0, serial: a few hundred symbols per block); the longest code of
+    // every first-level prefix sizes its second-level table
+    if (lane == 0) {
         for (int s = 0; s < n; ++s) {
             const int len = lens[s];
             if (!len) continue;
-            const uint32_t rc = bitrev((uint32_t)nc[len]++, len);
-            if (len > root && lane == 0) {
-                const uint32_t pre = rc & ((1u << root) - 1u);
-                if (subbits[pre] < len - root) subbits[pre] = (uint8_t)(len - root);
+            const int c = ws->next[len];
+            ws->next[len] = c + 1;
+            ws->code[s] = (uint16_t)c;
+            if (len > root) {
+                const uint32_t pre = bitrev((uint32_t)c, len) & ((1u << root) - 1u);
+                if (ws->subbits[pre] < len - root) ws->subbits[pre] = (uint8_t)(len - root);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        // allocate (serial over the prefixes; uniform)
+    }
+    __syncthreads();
+    if (maxlen > root) {   // allocate the second-level tables (serial over the prefixes; uniform)
         int used = 1 << root;
         for (int pre = 0; pre < (1 << root); ++pre) {
-            const int sb = subbits[pre];
+            const int sb = ws->subbits[pre];
             if (!sb) continue;
             if (used + (1 << sb) > cap) return kInfBadCodeLengths;
             if (lane == 0) table[pre] = mk_entry((uint32_t)root, (uint32_t)sb, 3u, (uint32_t)used);
             for (int i = lane; i < (1 << sb); i += 64) table[used + i] = 0u;
             used += 1 << sb;
         }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) nc[i] = next_code[i];
+        __syncthreads();
     }
     for (int s = 0; s < n; ++s) {
         const int len = lens[s];
         if (!len) continue;
-        const uint32_t rc = bitrev((uint32_t)nc[len]++, len);
+        const uint32_t rc = bitrev((uint32_t)ws->code[s], len);
         uint32_t e;
-        if (LITLEN) {
+        if (KIND == 0) {
             if (s < 256) e = mk_entry(0u, 0u, 0u, (uint32_t)s);
             else if (s == 256) e = mk_entry(0u, 0u, 2u, 0u);
             else if (s <= 285) e = mk_entry(0u, kLenExtra[s - 257], 1u, kLenBase[s - 257]);
             else e = mk_entry(0u, 0u, 2u, 1u);                           // 286 / 287: never valid (kind 2, value 1 = bad)
-        } else {
+        } else if (KIND == 1) {
             e = s < 30 ? mk_entry(0u, kDistExtra[s], 0u, kDistBase[s]) : mk_entry(0u, 0u, 2u, 1u);
+        } else {
+            e = mk_entry(0u, 0u, 0u, (uint32_t)s);
         }
         if (len <= root) {
             e |= (uint32_t)len;
@@ -152,7 +153,7 @@ __device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table
             for (uint32_t i = (rc >> root) + ((uint32_t)lane << sl); i < (1u << sb); i += 64u << sl) table[base + i] = e;
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     return kInfOk;
 }
 
@@ -168,12 +169,13 @@ struct InflateShared {
 };
 
 // One wave inflates one BGZF member.  Everything but the copies is wave-uniform (every lane holds the same bit
-// buffer and positions): no divergence, table reads are LDS broadcasts.
+// buffer and positions): no divergence, table reads are LDS broadcasts.  (The workgroup IS the wave: __syncthreads()
+// orders the LDS traffic of its lanes and costs no cross-wave barrier.)
 __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restrict__ image, const Member *__restrict__ members, int nmembers,
                                                           uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
-    __shared__ InflateShared sh;
-    __shared__ uint8_t s_lens[320];
-    __shared__ uint16_t s_scratch[512];
+    __shared__ __attribute__((aligned(16))) InflateShared sh;
+    __shared__ uint8_t s_lens[352];
+    __shared__ TableScratch s_ws;
     const int m = blockIdx.x;
     if (m >= nmembers) return;
     const Member mb = members[m];
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             sh.in[((base >> 2) + (uint32_t)k) & (kInBytes / 4 - 1)] = w;
         }
         in_loaded += 512u;
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     };
     stage_half();
     stage_half();
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     int nb = 0;                   // valid bits in it
     auto refill = [&]() {         // at least 32 valid bits afterwards (zeros behind the end of the stream)
         if (nb <= 32) {
-            if (in_pos + 512u + 4u > in_loaded && in_loaded < clen + 512u) stage_half();   // the reader entered the last staged half: fetch the next
+            if (in_pos + 512u + 4u > in_loaded) stage_half();   // the reader entered the last staged half: fetch the next (zeros behind the end)
             const uint32_t w = sh.in[(in_pos >> 2) & (kInBytes / 4 - 1)];
             bb |= (unsigned long long)w << nb;
             nb += 32;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     uint32_t pos = 0;             // bytes produced
     uint32_t flushed = 0;         // bytes written to HBM
     auto flush_to = [&](uint32_t upto) {   // window bytes [flushed, upto) -> HBM; both multiples of 16 except at the very end
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         for (uint32_t b = flushed + 16u * (uint32_t)lane; b < upto; b += 16u * 64u) {
             if (b + 16u <= upto && ((mb.uoff + b) & 15u) == 0u) {
                 const uint4 v = *(const uint4 *)&sh.win[b & (kWinBytes - 1)];
@@ -257,11 +259,15 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             uint32_t sp = in_pos - (uint32_t)(nb >> 3);
             bb = 0; nb = 0;
             if (sp + len > clen) { err = kInfInputOverrun; break; }
-            for (uint32_t k = lane; k < len; k += 64) sh.win[(pos + k) & (kWinBytes - 1)] = src[sp + k];
-            __builtin_amdgcn_wave_barrier();
-            // (a stored block can be longer than the flush piece: flush as we go)
-            pos += len;
-            while (pos - flushed >= (uint32_t)kFlush + 16u) flush_to((flushed + kFlush) & ~15u);
+            // (a stored block can be twice the window: copied and flushed piece by piece)
+            for (uint32_t done = 0; done < len;) {
+                const uint32_t piece = len - done < (uint32_t)kFlush ? len - done : (uint32_t)kFlush;
+                for (uint32_t k = lane; k < piece; k += 64) sh.win[(pos + k) & (kWinBytes - 1)] = src[sp + done + k];
+                __syncthreads();
+                pos += piece;
+                done += piece;
+                while (pos - flushed >= (uint32_t)kFlush + 16u) flush_to((flushed + kFlush) & ~15u);
+            }
             sp += len;
             // restart the staged input at the new position (dword aligned below it; the odd bytes are dropped from the bit buffer)
             in_pos = sp & ~3u;
@@ -276,12 +282,12 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
         if (type == 1u) {
             // fixed Huffman codes (RFC 1951 3.2.6)
             for (int s = lane; s < 288; s += 64) s_lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
-            __builtin_amdgcn_wave_barrier();
-            err = build_table<true>(s_lens, 288, kLitRoot, sh.lit, kLitEntries, s_scratch, lane);
+            __syncthreads();
+            err = build_table<0>(s_lens, 288, kLitRoot, sh.lit, kLitEntries, &s_ws, lane);
             if (err) break;
             for (int s = lane; s < 32; s += 64) s_lens[s] = 5;
-            __builtin_amdgcn_wave_barrier();
-            err = build_table<false>(s_lens, 30, kDistRoot, sh.dist, kDistEntries, s_scratch, lane);
+            __syncthreads();
+            err = build_table<1>(s_lens, 32, kDistRoot, sh.dist, kDistEntries, &s_ws, lane);   // (32 five-bit codes: 30 and 31 never valid)
             if (err) break;
         } else {
             // dynamic codes: HLIT, HDIST, HCLEN, the code-length code, then the two length lists (RFC 1951 3.2.7)
@@ -289,49 +295,23 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             const int hlit = (int)take(5) + 257, hdist = (int)take(5) + 1, hclen = (int)take(4) + 4;
             if (hlit > 286 || hdist > 30) { err = kInfBadCodeLengths; break; }
             if (lane < 19) s_lens[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
             for (int i = 0; i < hclen; ++i) {
                 refill();
                 const uint32_t v = take(3);
                 if (lane == 0) s_lens[kClOrder[i]] = (uint8_t)v;
             }
-            __builtin_amdgcn_wave_barrier();
-            // the code-length code decodes through the distance table's space (7 root bits would do; 6 + a second level is fine)
-            err = build_table<false>(s_lens, 19, kDistRoot, sh.dist, kDistEntries, s_scratch, lane);
+            __syncthreads();
+            // the code-length code (19 symbols, lengths <= 7) decodes through a 7-bit table in the distance table's space
+            err = build_table<2>(s_lens, 19, 7, sh.dist, kDistEntries, &s_ws, lane);
             if (err) break;
-            // (build_table<false> stores symbol s < 30 as a distance entry: read the SYMBOL back from its base table index --
-            // simpler: decode lengths with an own loop over the canonical code)
-            // -> re-derive: a compact canonical decode for the 19-symbol code (lengths <= 7)
-            int cl_count[8], cl_first[8], cl_off[8];
-            uint8_t cl_sorted[19];
-            {
-                for (int i = 0; i < 8; ++i) cl_count[i] = 0;
-                for (int s = 0; s < 19; ++s) cl_count[s_lens[s]] += 1;
-                cl_count[0] = 0;
-                int code = 0, off = 0;
-                for (int len = 1; len <= 7; ++len) {
-                    code = (code + cl_count[len - 1]) << 1;
-                    cl_first[len] = code;
-                    cl_off[len] = off;
-                    off += cl_count[len];
-                }
-                int fill[8];
-                for (int i = 0; i < 8; ++i) fill[i] = cl_off[i];
-                for (int s = 0; s < 19; ++s) if (s_lens[s]) cl_sorted[fill[s_lens[s]]++] = (uint8_t)s;
-            }
-            __builtin_amdgcn_wave_barrier();
             int got = 0, prev = 0;
             const int want = hlit + hdist;
             while (got < want && err == kInfOk) {
                 refill();
-                // bit-serial canonical decode (at most 7 bits; ~300 symbols per block)
-                int code = 0, len = 0, sym = -1;
-                for (len = 1; len <= 7; ++len) {
-                    code = (code << 1) | (int)((bb >> (len - 1)) & 1ull);
-                    const int idx = code - cl_first[len];
-                    if (idx >= 0 && idx < cl_count[len]) { sym = cl_sorted[cl_off[len] + idx]; break; }
-                }
-                if (sym < 0) { err = kInfBadCodeLengths; break; }
+                const uint32_t ce = sh.dist[(uint32_t)bb & 127u];
+                const int len = (int)(ce & 15u), sym = (int)(ce >> 16);
+                if (len == 0) { err = kInfBadCodeLengths; break; }
                 take(len);
                 int rep = 1, val = sym;
                 if (sym == 16) { if (got == 0) { err = kInfBadCodeLengths; break; } rep = 3 + (int)take(2); val = prev; }
@@ -343,16 +323,16 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                 prev = val;
             }
             if (err) break;
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
             if (s_lens[32 + 256] == 0) { err = kInfBadCodeLengths; break; }     // no end-of-block code
-            err = build_table<true>(s_lens + 32, hlit, kLitRoot, sh.lit, kLitEntries, s_scratch, lane);
+            err = build_table<0>(s_lens + 32, hlit, kLitRoot, sh.lit, kLitEntries, &s_ws, lane);
             if (err) break;
             // the distance lengths follow the literal/length ones: move them to a 4-byte aligned place of their own
             uint8_t dl = (lane < hdist) ? s_lens[32 + hlit + lane] : 0;
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();
             if (lane < 32) s_lens[lane] = dl;
-            __builtin_amdgcn_wave_barrier();
-            err = build_table<false>(s_lens, hdist, kDistRoot, sh.dist, kDistEntries, s_scratch, lane);
+            __syncthreads();
+            err = build_table<1>(s_lens, hdist, kDistRoot, sh.dist, kDistEntries, &s_ws, lane);
             if (err) break;
         }
         // ---- the symbols of the block
@@ -392,13 +372,13 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                 const uint32_t dist = (d >> 16) + take((int)((d >> 4) & 15u));
                 if (dist > pos) { err = kInfBadDistance; break; }
                 if (pos + len > ulen) { err = kInfOverrun; break; }
-                __builtin_amdgcn_wave_barrier();
+                __syncthreads();
                 // copy: byte k comes from `dist` back; where the match overlaps itself the pattern repeats
                 for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
                     const uint32_t from = dist >= len ? pos - dist + k : pos - dist + (k % dist);
                     sh.win[(pos + k) & (kWinBytes - 1)] = sh.win[from & (kWinBytes - 1)];
                 }
-                __builtin_amdgcn_wave_barrier();
+                __syncthreads();
                 pos += len;
             }
             if (pos - flushed >= (uint32_t)kFlush + 272u) flush_to((flushed + kFlush) & ~15u);   // (keeps 32 KiB - 8 KiB - slack of history)
@@ -413,7 +393,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
 // CRC-32 of every member's payload (what bgzf.c verifies, kent/src/htslib/bgzf.c:421-530): one wave per member,
 // 64 contiguous slices, combined in order.  crc(A || B) = shift(crc(A), |B|) ^ crc(B) with the shift by a fixed slice
 // length applied through four 256-entry tables (computed by the host: `shift_tab[4][256]` for slices of kCrcSlice bytes).
-constexpr int kCrcSlice = 1024;
+constexpr int kCrcSlice = 1056;   // 63 slices + a head cover the 64 KiB a member can hold
 __global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out, const Member *__restrict__ members, int nmembers,
                                                  const uint32_t *__restrict__ crc_tab, const uint32_t *__restrict__ shift_tab,
                                                  uint32_t *__restrict__ status) {
@@ -424,7 +404,7 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out
     const Member mb = members[m];
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < 256; i += 64) tab[i] = crc_tab[i];
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     // slice 0 takes the odd head, slices 1.. are kCrcSlice bytes each
     const uint32_t n = mb.ulen;
     const uint32_t nfull = n / kCrcSlice, head = n - nfull * kCrcSlice;
@@ -440,7 +420,7 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out
         for (int i = 0; i < kCrcSlice; ++i) crc = crc_byte(tab, crc, q[i]);
     }
     part[lane] = crc;
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     if (lane == 0) {
         uint32_t c = part[0];
         for (uint32_t k = 1; k <= nfull && k < 64; ++k) {
@@ -486,9 +466,9 @@ struct MemberChain {
 // One wave per member.  forced[m] != ~0: start there instead of guessing (the host found that the preceding member's
 // chain ends there).  rec_off[m * kMaxRecPerMember + k] = offset of record k relative to the member's begin.
 __global__ __launch_bounds__(64) void k_bam_chain(const uint8_t *__restrict__ stream, uint64_t stream_len, const Member *__restrict__ members,
-                                                  int nmembers, uint32_t n_ref, uint64_t first_record, const uint64_t *__restrict__ forced,
+                                                  int nmembers, int member_lo, uint32_t n_ref, uint64_t first_record, const uint64_t *__restrict__ forced,
                                                   MemberChain *chain, uint32_t *rec_off) {
-    const int m = blockIdx.x;
+    const int m = member_lo + (int)blockIdx.x;
     if (m >= nmembers) return;
     const int lane = threadIdx.x & 63;
     const Member mb = members[m];

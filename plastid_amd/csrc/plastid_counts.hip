@@ -2605,3 +2605,412 @@ int pc_mapped_reads(pc_engine *e, int file, int64_t rec_lo, int64_t rec_hi, int3
 }
 
 } // extern "C"
+
+// ================================================================== compressed BAM on the GPU (bam_kernels.hip.h)
+#include "bam_kernels.hip.h"
+
+struct pc_bam {
+    pc_engine *e = nullptr;
+    std::string name;
+    int64_t n = 0, nrun = 0, mapped = 0, unplaced = 0, total = 0;
+    std::vector<std::string> ref_names;
+    std::vector<int32_t> ref_lengths;
+    DevBuf<int32_t> tid, pos, blk_start, blk_len;
+    DevBuf<uint16_t> alen;
+    DevBuf<uint8_t> flags, nblk;
+    std::vector<int64_t> wide_idx;
+    std::vector<int32_t> wide_alen, wide_nblk;
+    double ms[4] = {0, 0, 0, 0};     // upload, inflate (+ CRC), record chain, fields + columns
+    int64_t members = 0, inflated_bytes = 0, compressed_bytes = 0;
+    int chain_restarts = 0;
+};
+
+namespace {
+
+uint16_t brd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+uint32_t brd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// CRC-32 tables (RFC 1952): the byte table, and the operator that advances the register over kCrcSlice zero bytes
+// split by register byte (k_bgzf_crc combines 64 slice remainders with it)
+struct CrcTables {
+    uint32_t tab[256];
+    uint32_t shift[4 * 256];
+    CrcTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            tab[i] = c;
+        }
+        for (int b = 0; b < 4; ++b)
+            for (uint32_t v = 0; v < 256; ++v) {
+                uint32_t c = v << (8 * b);
+                for (int k = 0; k < pcbam::kCrcSlice; ++k) c = tab[c & 0xffu] ^ (c >> 8);
+                shift[b * 256 + v] = c;
+            }
+    }
+};
+const CrcTables &crc_tables() { static const CrcTables t; return t; }
+
+double ms_between(hipEvent_t a, hipEvent_t b) { float t = 0.f; return hipEventElapsedTime(&t, a, b) == hipSuccess ? (double)t : 0.0; }
+
+} // namespace
+
+extern "C" {
+
+int pc_bam_close(pc_bam *b) {
+    if (!b) return PC_OK;
+    if (b->e) { (void)hipSetDevice(b->e->device); (void)hipStreamSynchronize(b->e->stream); }
+    delete b;
+    return PC_OK;
+}
+
+int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out) {
+    using namespace pcbam;
+    if (!e || !out || size < 0 || (size > 0 && !image_)) return fail(PC_ERR_ARG, "pc_bam_open: bad arguments");
+    *out = nullptr;
+    const uint8_t *image = (const uint8_t *)image_;
+    const std::string path = name ? name : "<memory>";
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    // ---- member boundaries (host: a walk over the gzip headers; 18 + bytes per 64 KiB of payload)
+    std::vector<Member> members;
+    uint64_t total_u = 0;
+    for (int64_t off = 0; off < size;) {
+        if (off + 18 > size) return fail(PC_ERR_ARG, "truncated BGZF header");
+        const uint8_t *h = image + off;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return fail(PC_ERR_ARG, "not a BGZF file (bad gzip member header)");
+        const uint16_t xlen = brd16(h + 10);
+        if (off + 12 + xlen > size) return fail(PC_ERR_ARG, "truncated BGZF extra field");
+        int bsize = -1;
+        for (size_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *sf = h + 12 + x;
+            const uint16_t slen = brd16(sf + 2);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = brd16(sf + 4);
+            x += 4 + slen;
+        }
+        if (bsize < 0) return fail(PC_ERR_ARG, "BGZF member without BC subfield");
+        const int64_t clen = (int64_t)bsize + 1;
+        if (off + clen > size) return fail(PC_ERR_ARG, "truncated BGZF member");
+        const uint32_t isize = brd32(image + off + clen - 4);
+        if (isize > (1u << 16)) return fail(PC_ERR_ARG, "corrupt BGZF member (more than 64 KiB of payload)");
+        const int64_t hdr = 12 + xlen;
+        if (clen < hdr + 8) return fail(PC_ERR_ARG, "BGZF inflate failed in %s", path.c_str());
+        Member mb;
+        mb.coff = (uint64_t)(off + hdr); mb.clen = (uint32_t)(clen - hdr - 8); mb.ulen = isize; mb.uoff = total_u;
+        mb.crc = brd32(image + off + clen - 8); mb.pad = 0;
+        if (isize) members.push_back(mb);      // (empty members -- the end-of-file marker -- hold nothing)
+        total_u += isize;
+        off += clen;
+    }
+    pc_bam *b = new pc_bam();
+    b->e = e; b->name = path; b->members = (int64_t)members.size(); b->inflated_bytes = (int64_t)total_u; b->compressed_bytes = size;
+    struct Guard { pc_bam *b; ~Guard() { if (b) pc_bam_close(b); } } guard{b};
+    const int nm = (int)members.size();
+    hipEvent_t ev[5];
+    for (auto &x : ev) HIP_TRY(hipEventCreate(&x));
+    struct EvGuard { hipEvent_t *ev; ~EvGuard() { for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]); } } evg{ev};
+    DevBuf<uint8_t> d_image, d_stream;
+    DevBuf<Member> d_members;
+    DevBuf<uint32_t> d_status, d_crc;
+    int rc = d_image.reserve((size_t)std::max<int64_t>(size, 16) + 16);
+    if (rc == PC_OK) rc = d_stream.reserve((size_t)total_u + 64);
+    if (rc == PC_OK) rc = d_members.reserve((size_t)std::max(nm, 1));
+    if (rc == PC_OK) rc = d_status.reserve((size_t)std::max(nm, 1));
+    if (rc == PC_OK) rc = d_crc.reserve(5 * 256);
+    if (rc != PC_OK) return rc;
+    HIP_TRY(hipEventRecord(ev[0], st));
+    if (size) HIP_TRY(hipMemcpyAsync(d_image.p, image, (size_t)size, hipMemcpyHostToDevice, st));
+    if (nm) HIP_TRY(hipMemcpyAsync(d_members.p, members.data(), (size_t)nm * sizeof(Member), hipMemcpyHostToDevice, st));
+    const CrcTables &ct = crc_tables();
+    HIP_TRY(hipMemcpyAsync(d_crc.p, ct.tab, sizeof(ct.tab), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_crc.p + 256, ct.shift, sizeof(ct.shift), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_stream.p + total_u, 0, 64, st));
+    HIP_TRY(hipEventRecord(ev[1], st));
+    // ---- inflate + CRC: one wave per member
+    std::vector<uint32_t> status((size_t)nm, 0u);
+    if (nm) {
+        hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)nm), dim3(kInflWG), 0, st, d_image.p, d_members.p, nm, d_stream.p, d_status.p);
+        hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)nm), dim3(64), 0, st, d_stream.p, d_members.p, nm, d_crc.p, d_crc.p + 256, d_status.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(status.data(), d_status.p, (size_t)nm * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(ev[2], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int m = 0; m < nm; ++m)
+        if (status[(size_t)m]) {
+            if (getenv("PC_BAM_DEBUG")) fprintf(stderr, "[bam] member %d of %d (%u compressed -> %u bytes at %llu): inflate status %u\n", m, nm,
+                                                members[(size_t)m].clen, members[(size_t)m].ulen, (unsigned long long)members[(size_t)m].uoff, status[(size_t)m]);
+            return fail(PC_ERR_ARG, "%s%s", status[(size_t)m] == (uint32_t)kInfCrc ? "BGZF CRC mismatch in " : "BGZF inflate failed in ", path.c_str());
+        }
+    d_image.release();
+    // ---- BAM header (host, from the head of the inflated stream)
+    uint64_t first_record = 0;
+    uint32_t n_ref = 0;
+    {
+        std::vector<uint8_t> head;
+        size_t want = std::min<size_t>((size_t)total_u, (size_t)1 << 16);
+        for (;;) {
+            head.resize(want);
+            if (want) HIP_TRY(hipMemcpy(head.data(), d_stream.p, want, hipMemcpyDeviceToHost));
+            const uint8_t *p = head.data(), *end = p + want;
+            bool more = false;
+            auto need = [&](size_t k) { if ((size_t)(end - p) < k) { more = true; return false; } return true; };
+            bool ok = true;
+            if (!need(12)) ok = false;
+            if (ok && std::memcmp(p, "BAM\1", 4) != 0) return fail(PC_ERR_ARG, "not a BAM file (bad magic)");
+            uint32_t l_text = 0;
+            if (ok) { l_text = brd32(p + 4); p += 8; if (!need((size_t)l_text + 4)) ok = false; }
+            if (ok) { p += l_text; n_ref = brd32(p); p += 4; }
+            b->ref_names.clear(); b->ref_lengths.clear();
+            for (uint32_t r = 0; ok && r < n_ref; ++r) {
+                if (!need(4)) { ok = false; break; }
+                const uint32_t l_name = brd32(p);
+                p += 4;
+                if (!need((size_t)l_name + 4)) { ok = false; break; }
+                b->ref_names.emplace_back((const char *)p, l_name ? l_name - 1 : 0);
+                p += l_name;
+                b->ref_lengths.push_back((int32_t)brd32(p));
+                p += 4;
+            }
+            if (ok) { first_record = (uint64_t)(p - head.data()); break; }
+            if (!more || want >= (size_t)total_u)
+                return fail(PC_ERR_ARG, want < 12 ? "not a BAM file (bad magic)" : (b->ref_names.empty() && n_ref == 0 ? "truncated BAM header" : "truncated BAM reference list"));
+            want = std::min<size_t>((size_t)total_u, want * 4);
+        }
+    }
+    // ---- record starts: every member guesses its first record start and walks the chain of length prefixes; the
+    // host confirms that the walks chain, and restarts the members whose guess did not
+    DevBuf<MemberChain> d_chain;
+    DevBuf<uint32_t> d_rec_off;
+    DevBuf<uint64_t> d_forced;
+    rc = d_chain.reserve((size_t)std::max(nm, 1));
+    if (rc == PC_OK) rc = d_rec_off.reserve((size_t)std::max(nm, 1) * kMaxRecPerMember);
+    if (rc == PC_OK) rc = d_forced.reserve((size_t)std::max(nm, 1));
+    if (rc != PC_OK) return rc;
+    std::vector<MemberChain> chain((size_t)nm);
+    std::vector<uint64_t> forced((size_t)nm, ~0ull), rec_base((size_t)nm + 1, 0);
+    std::vector<uint32_t> nrec_of((size_t)nm, 0u);
+    bool truncated = false;
+    int64_t nrec = 0;
+    if (nm) {
+        HIP_TRY(hipMemsetAsync(d_forced.p, 0xff, (size_t)nm * 8, st));
+        int from = 0;
+        uint64_t expected = first_record;
+        for (int round = 0;; ++round) {
+            hipLaunchKernelGGL(k_bam_chain, dim3((unsigned)(nm - from)), dim3(64), 0, st, d_stream.p, total_u, d_members.p, nm, from, n_ref, first_record,
+                               d_forced.p, d_chain.p, d_rec_off.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(chain.data() + from, d_chain.p + from, (size_t)(nm - from) * sizeof(MemberChain), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            int redo = -1;
+            for (int m = from; m < nm; ++m) {
+                const uint64_t begin = members[(size_t)m].uoff, end = begin + members[(size_t)m].ulen;
+                nrec_of[(size_t)m] = 0;
+                if (expected >= end) continue;                      // no record starts in this member
+                const MemberChain &mc = chain[(size_t)m];
+                if (mc.first != expected) {                         // the guess was off (or there was none): walk again from the right place
+                    forced[(size_t)m] = expected;
+                    redo = m;
+                    break;
+                }
+                nrec_of[(size_t)m] = mc.nrec;
+                if (mc.flags & 2u) { truncated = true; from = nm; break; }   // a length prefix that cannot be: the walk ends here
+                expected = mc.next;
+            }
+            if (redo < 0) break;
+            b->chain_restarts += 1;
+            HIP_TRY(hipMemcpyAsync(d_forced.p + redo, &forced[(size_t)redo], 8, hipMemcpyHostToDevice, st));
+            from = redo;
+            if (round > nm + 8) return fail(PC_ERR_STATE, "pc_bam_open: the record chain of %s did not settle", path.c_str());
+        }
+        if (!truncated && expected != total_u) truncated = expected > total_u || true;   // the last record runs past (or stops short of) the end of the stream
+        if (!truncated) {}
+        for (int m = 0; m < nm; ++m) rec_base[(size_t)m + 1] = rec_base[(size_t)m] + nrec_of[(size_t)m];
+        nrec = (int64_t)rec_base[(size_t)nm];
+    } else if (total_u != first_record) truncated = true;
+    HIP_TRY(hipEventRecord(ev[3], st));
+    b->total = nrec;
+    if (nrec >= (int64_t)0x7fffffff) return fail(PC_ERR_ARG, "pc_bam_open: more than 2^31-2 records per file are not supported");
+    // ---- fields, order checks, columns
+    DevBuf<uint64_t> d_rec_base;
+    DevBuf<uint32_t> d_rec_member, d_placed, d_runs, d_staged_at, d_run_at, d_wide;
+    DevBuf<RecOut> d_recs;
+    DevBuf<unsigned long long> d_misc;   // [0] first error (index << 8 | code), [1] mapped, [2] unplaced
+    rc = d_misc.reserve(4);
+    if (rc != PC_OK) return rc;
+    const unsigned long long misc0[4] = {~0ull, 0ull, 0ull, 0ull};
+    HIP_TRY(hipMemcpyAsync(d_misc.p, misc0, sizeof(misc0), hipMemcpyHostToDevice, st));
+    int64_t n_staged = 0, n_runs = 0;
+    if (nrec > 0) {
+        std::vector<uint32_t> rec_member((size_t)((nrec + 255) >> 8));
+        {
+            int m = 0;
+            for (size_t g = 0; g < rec_member.size(); ++g) {
+                const uint64_t i = (uint64_t)g << 8;
+                while (m + 1 < nm && rec_base[(size_t)m + 1] <= i) ++m;
+                rec_member[g] = (uint32_t)m;
+            }
+        }
+        rc = d_rec_base.upload(rec_base, st);
+        if (rc == PC_OK) rc = d_rec_member.upload(rec_member, st);
+        if (rc == PC_OK) rc = d_recs.reserve((size_t)nrec);
+        if (rc == PC_OK) rc = d_placed.reserve((size_t)nrec + 1);
+        if (rc == PC_OK) rc = d_runs.reserve((size_t)nrec + 1);
+        if (rc == PC_OK) rc = d_staged_at.reserve((size_t)nrec + 1);
+        if (rc == PC_OK) rc = d_run_at.reserve((size_t)nrec + 1);
+        if (rc != PC_OK) return rc;
+        const unsigned g256 = (unsigned)((nrec + 255) / 256);
+        hipLaunchKernelGGL(k_bam_fields, dim3(g256), dim3(256), 0, st, d_stream.p, total_u, d_members.p, d_rec_base.p, d_chain.p, d_rec_off.p, nm, nrec,
+                           n_ref, d_rec_member.p, d_recs.p);
+        hipLaunchKernelGGL(k_bam_order, dim3(g256), dim3(256), 0, st, d_recs.p, nrec, d_placed.p, d_misc.p);
+        HIP_TRY(hipMemsetAsync(d_placed.p + nrec, 0, 4, st));
+        HIP_TRY(hipMemsetAsync(d_runs.p + nrec, 0, 4, st));
+        hipLaunchKernelGGL(k_bam_scan_inputs, dim3(g256), dim3(256), 0, st, d_recs.p, nrec, d_placed.p, d_runs.p, d_misc.p + 1);
+        {
+            size_t tmp_bytes = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_placed.p, d_staged_at.p, (int)(nrec + 1), st));
+            DevBuf<uint8_t> d_tmp;
+            rc = d_tmp.reserve(std::max<size_t>(tmp_bytes, 16));
+            if (rc != PC_OK) return rc;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, d_placed.p, d_staged_at.p, (int)(nrec + 1), st));
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, d_runs.p, d_run_at.p, (int)(nrec + 1), st));
+            uint32_t tot[2] = {0, 0};
+            unsigned long long misc[3] = {0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(&tot[0], d_staged_at.p + nrec, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&tot[1], d_run_at.p + nrec, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(misc, d_misc.p, sizeof(misc), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));   // (d_tmp goes out of scope)
+            n_staged = tot[0]; n_runs = tot[1];
+            b->mapped = (int64_t)misc[1]; b->unplaced = (int64_t)misc[2];
+            if (misc[0] != ~0ull) {
+                switch ((int)(misc[0] & 0xffu)) {
+                case kRecTidRange: return fail(PC_ERR_ARG, "BAM record with reference id out of range");
+                case kRecNegPos: return fail(PC_ERR_ARG, "placed BAM record with a negative position");
+                case kRecUnsorted: return fail(PC_ERR_UNSORTED, "BAM file is not coordinate sorted: %s", path.c_str());
+                case kRecCigarOverrun: return fail(PC_ERR_ARG, "corrupt BAM record (cigar overruns block)");
+                case kRecUnknownOp: return fail(PC_ERR_ARG, "unknown CIGAR operation in %s", path.c_str());
+                case kRecEndBeyond: return fail(PC_ERR_ARG, "alignment ends beyond 2^31 - 1");
+                case kRecTooLong: return fail(PC_ERR_ARG, "alignment with more than 2^31 - 1 aligned positions");
+                case kRecDeletionOrder: return fail(PC_ERR_ARG, "alignment starting with a deletion breaks coordinate order; not supported");
+                default: truncated = true; break;   // kRecTruncated / kRecBadSize: reported below, after every other defect
+                }
+            }
+        }
+        if (truncated) return fail(PC_ERR_ARG, "truncated BAM record");
+        rc = b->tid.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->pos.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->alen.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->flags.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->nblk.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->blk_start.reserve((size_t)std::max<int64_t>(n_runs, 1));
+        if (rc == PC_OK) rc = b->blk_len.reserve((size_t)std::max<int64_t>(n_runs, 1));
+        if (rc == PC_OK) rc = d_wide.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc != PC_OK) return rc;
+        HIP_TRY(hipMemsetAsync(d_wide.p, 0, (size_t)std::max<int64_t>(n_staged, 1) * 4, st));
+        hipLaunchKernelGGL(k_bam_columns, dim3(g256), dim3(256), 0, st, d_stream.p, d_members.p, d_rec_base.p, d_rec_off.p, nm, d_rec_member.p, d_recs.p,
+                           nrec, d_staged_at.p, d_run_at.p, b->tid.p, b->pos.p, b->alen.p, b->flags.p, b->nblk.p, b->blk_start.p, b->blk_len.p, d_wide.p);
+        HIP_TRY(hipGetLastError());
+        // wide records (beyond the 16-bit / 8-bit columns): rare -- their staged indices are found from the markers on
+        // the host side of pc_bam_read; the true values are read back here, record by record
+        {
+            // count the flagged records (a sum reduction through the scan buffers would do; a plain read-back of the
+            // flags is only paid when the file has any: probe with a device-side total first)
+            DevBuf<uint32_t> d_wsum;
+            rc = d_wsum.reserve((size_t)n_staged + 1);
+            if (rc != PC_OK) return rc;
+            size_t tmp_bytes = 0;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_wide.p, d_wsum.p, (int)std::max<int64_t>(n_staged, 1), st));
+            DevBuf<uint8_t> d_tmp;
+            rc = d_tmp.reserve(std::max<size_t>(tmp_bytes, 16));
+            if (rc != PC_OK) return rc;
+            uint32_t last_sum = 0, last_flag = 0;
+            if (n_staged > 0) {
+                HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, d_wide.p, d_wsum.p, (int)n_staged, st));
+                HIP_TRY(hipMemcpyAsync(&last_sum, d_wsum.p + (n_staged - 1), 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&last_flag, d_wide.p + (n_staged - 1), 4, hipMemcpyDeviceToHost, st));
+            }
+            HIP_TRY(hipStreamSynchronize(st));
+            const uint32_t nwide = last_sum + last_flag;
+            if (nwide) {
+                std::vector<uint32_t> wf((size_t)n_staged), sa((size_t)nrec);
+                std::vector<RecOut> recs((size_t)nrec);
+                HIP_TRY(hipMemcpy(wf.data(), d_wide.p, (size_t)n_staged * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(sa.data(), d_staged_at.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(recs.data(), d_recs.p, (size_t)nrec * sizeof(RecOut), hipMemcpyDeviceToHost));
+                for (int64_t i = 0; i < nrec; ++i)
+                    if (recs[(size_t)i].placed && wf[sa[(size_t)i]]) {
+                        b->wide_idx.push_back((int64_t)sa[(size_t)i]);
+                        b->wide_alen.push_back((int32_t)recs[(size_t)i].L);
+                        b->wide_nblk.push_back((int32_t)recs[(size_t)i].nruns);
+                    }
+            }
+        }
+    } else if (truncated) return fail(PC_ERR_ARG, "truncated BAM record");
+    HIP_TRY(hipEventRecord(ev[4], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->n = n_staged; b->nrun = n_runs;
+    for (int k = 0; k < 4; ++k) b->ms[k] = ms_between(ev[k], ev[k + 1]);
+    guard.b = nullptr;
+    *out = b;
+    return PC_OK;
+}
+
+int pc_bam_counts(pc_bam *b, int64_t *counts) {
+    if (!b || !counts) return fail(PC_ERR_ARG, "pc_bam_counts: bad arguments");
+    counts[0] = b->n; counts[1] = b->nrun; counts[2] = b->mapped; counts[3] = b->total; counts[4] = (int64_t)b->wide_idx.size();
+    counts[5] = b->members; counts[6] = b->inflated_bytes; counts[7] = b->chain_restarts;
+    return PC_OK;
+}
+int pc_bam_timing(pc_bam *b, double *ms4) {
+    if (!b || !ms4) return fail(PC_ERR_ARG, "pc_bam_timing: bad arguments");
+    for (int k = 0; k < 4; ++k) ms4[k] = b->ms[k];
+    return PC_OK;
+}
+int pc_bam_nref(pc_bam *b) { return b ? (int)b->ref_names.size() : -1; }
+const char *pc_bam_ref_name(pc_bam *b, int i) { return (b && i >= 0 && i < (int)b->ref_names.size()) ? b->ref_names[(size_t)i].c_str() : nullptr; }
+int32_t pc_bam_ref_length(pc_bam *b, int i) { return (b && i >= 0 && i < (int)b->ref_lengths.size()) ? b->ref_lengths[(size_t)i] : -1; }
+
+int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags, uint8_t *nblk, int32_t *blk_start, int32_t *blk_len,
+                int64_t *wide_idx, int32_t *wide_alen, int32_t *wide_nblk) {
+    if (!b) return fail(PC_ERR_ARG, "pc_bam_read: NULL handle");
+    if (b->n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_bam_read: NULL array");
+    if (b->nrun > 0 && (!blk_start || !blk_len)) return fail(PC_ERR_ARG, "pc_bam_read: NULL run array");
+    if (!b->wide_idx.empty() && (!wide_idx || !wide_alen || !wide_nblk)) return fail(PC_ERR_ARG, "pc_bam_read: NULL wide array");
+    HIP_TRY(hipSetDevice(b->e->device));
+    hipStream_t st = b->e->stream;
+    const size_t n = (size_t)b->n, m = (size_t)b->nrun;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(tid, b->tid.p, n * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(pos, b->pos.p, n * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(alen, b->alen.p, n * 2, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(flags, b->flags.p, n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(nblk, b->nblk.p, n, hipMemcpyDeviceToHost, st));
+    }
+    if (m) {
+        HIP_TRY(hipMemcpyAsync(blk_start, b->blk_start.p, m * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(blk_len, b->blk_len.p, m * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t k = 0; k < b->wide_idx.size(); ++k) { wide_idx[k] = b->wide_idx[k]; wide_alen[k] = b->wide_alen[k]; wide_nblk[k] = b->wide_nblk[k]; }
+    return PC_OK;
+}
+
+int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped) {
+    pc_bam *b = nullptr;
+    int rc = pc_bam_open(e, image, size, name, &b);
+    if (rc != PC_OK) return rc;
+    const size_t n = (size_t)b->n, m = (size_t)b->nrun, nw = b->wide_idx.size();
+    std::vector<int32_t> tid(n), pos(n), bs(m), bl(m), wa(nw), wn(nw);
+    std::vector<uint16_t> alen(n);
+    std::vector<uint8_t> flags(n), nblk(n);
+    std::vector<int64_t> wi(nw);
+    rc = pc_bam_read(b, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), bs.data(), bl.data(), wi.data(), wa.data(), wn.data());
+    const int ntid = std::max(1, (int)b->ref_names.size());
+    if (mapped) *mapped = b->mapped;
+    pc_bam_close(b);
+    if (rc != PC_OK) return rc;
+    return pc_add_alignment_file_wide(e, (int64_t)n, ntid, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), (int64_t)m, bs.data(), bl.data(),
+                                      (int64_t)nw, wi.data(), wa.data(), wn.data());
+}
+
+} // extern "C"

@@ -1,0 +1,232 @@
+"""Compressed BAM on the GPU (``pc_bam_open``: BGZF inflate + BAM record decode as HIP kernels, csrc/bam_kernels.hip.h)
+against the host decoder (csrc/bam_stager.cpp, itself pinned to htslib by tests/test_hts_golden.py) and against the
+bytes htslib itself wrote (tests/golden/hts_fixture.npz): the packed columns must be bit-identical, the errors the
+same exceptions with the same messages."""
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import plastid_amd as pa  # noqa: E402
+from plastid_amd import synth  # noqa: E402
+from plastid_amd.bam import read_bam, read_bam_gpu  # noqa: E402
+from plastid_amd.engine import Engine  # noqa: E402
+from tests import bam_writer  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hts_fixture.npz")
+COLS = ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "wide_idx", "wide_alen", "wide_nblk")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def same(a, b):
+    for k in COLS:
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert a.references == b.references and a.lengths == b.lengths and a.mapped == b.mapped and a.n == b.n
+
+
+def member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    cdata = comp.compress(data) + comp.flush()
+    header = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(cdata) + 25)
+    return header + cdata + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+def bam_stream(refs, lens, recs, names=True):
+    text = b"@HD\tVN:1.6\tSO:coordinate\n"
+    out = b"BAM\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(refs))
+    for nm, ln in zip(refs, lens):
+        nmb = nm.encode() + b"\x00"
+        out += struct.pack("<I", len(nmb)) + nmb + struct.pack("<I", ln)
+    return out + b"".join(bam_writer.encode_record(t, p, c, f, name=(("read%07d" % i).encode() if names else b"r"))
+                          for i, (t, p, c, f) in enumerate(recs))
+
+
+def write_members(path, data, block_bytes, **kw):
+    with open(path, "wb") as fh:
+        for off in range(0, len(data), block_bytes):
+            fh.write(member(data[off:off + block_bytes], **kw))
+        fh.write(bam_writer.BGZF_EOF)
+
+
+def test_the_htslib_written_bam(eng, tmp_path):
+    hts = np.load(FIX)
+    path = str(tmp_path / "htslib.bam")
+    open(path, "wb").write(hts["bam"].tobytes())
+    timing = {}
+    got = read_bam_gpu(path, eng, timing=timing)
+    same(got, read_bam(path))
+    keep = np.nonzero(hts["tid"] >= 0)[0]
+    assert got.n == len(keep) and np.array_equal(got.pos, hts["pos"][keep])
+    assert got.mapped == int(hts["index_stat"][:, 1].sum())
+    assert np.array_equal(got.ref_end(), hts["endpos"][keep])          # htslib's bam_endpos
+    assert timing["members"] >= 1 and timing["records"] == len(hts["tid"])
+
+
+@pytest.mark.parametrize("kw,block", [({"level": 6}, 20000), ({"level": 1}, 65280), ({"level": 9}, 3000), ({"level": 0}, 40000),
+                                      ({"level": 6, "strategy": zlib.Z_FIXED}, 20000), ({"level": 6, "strategy": zlib.Z_HUFFMAN_ONLY}, 9000),
+                                      ({"level": 6}, 300), ({"level": 0}, 65000)])
+def test_deflate_block_types_and_member_geometry(eng, tmp_path, kw, block):
+    """Dynamic, fixed and stored DEFLATE blocks; members of 64 KiB down to 300 bytes (records then span several
+    members and most members hold no record start); unmapped-but-placed and unplaced records."""
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00004, tx_scale=0.002)
+    recs = bam_writer.packed_to_records(reads)
+    recs.insert(10, (recs[10][0], recs[10][1], [], 4))
+    recs += [(-1, -1, [], 4)] * 3
+    data = bam_stream(list(reads.references), list(reads.lengths), recs)
+    path = str(tmp_path / "x.bam")
+    write_members(path, data, block, **kw)
+    timing = {}
+    got = read_bam_gpu(path, eng, timing=timing)
+    same(got, read_bam(path))
+    assert got.n == reads.n + 1 and got.mapped == reads.n and timing["records"] == len(recs)
+
+
+def test_a_record_longer_than_many_members(eng, tmp_path):
+    """One read with thousands of CIGAR operations and a long sequence (a record of > 200 kB): whole members lie
+    inside it, and it is a wide record (> 255 aligned runs)."""
+    cig = []
+    for k in range(3000):
+        cig += [(0, 20), (3, 50)]
+    cig += [(0, 30)]
+    recs = [(0, 10, [(0, 30)], 0), (0, 40, cig, 16), (0, 50, [(0, 28)], 0), (0, 300000, [(0, 25), (2, 3), (0, 5)], 0)]
+    data = bam_stream(["c"], [1000000], recs)
+    path = str(tmp_path / "long.bam")
+    write_members(path, data, 20000, level=6)
+    got = read_bam_gpu(path, eng)
+    same(got, read_bam(path))
+    assert got.n == 4 and len(got.wide_idx) == 1 and got.true_nblk()[1] == 3001
+
+
+def test_realistic_records_and_the_counts_that_follow(eng, tmp_path):
+    """Records as an aligner writes them (names, sequences, qualities, tags); the staged GPU-decoded file counts
+    like the host-decoded one under a point rule and the center rule."""
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.0005, tx_scale=0.01)
+    path = str(tmp_path / "real.bam")
+    bam_writer.write_bam_realistic(path, reads, threads=4)
+    got = read_bam_gpu(path, eng)
+    ref = read_bam(path)
+    same(got, ref)
+    assert got.n == reads.n
+    outs = []
+    for aln in (got, ref):
+        eng.set_alignments([aln])
+        res = []
+        for mapping in (("fiveprime", 12), ("center", 0)):
+            synth.mapping_factory(mapping)._configure(eng)
+            p = tx.plan_arrays(rows=1)
+            plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+            res.append(plan.count(np.float64).copy())
+            plan.close()
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_errors_are_the_host_decoders(eng, tmp_path):
+    """Unsorted input, a damaged payload (CRC), a damaged DEFLATE stream, truncation, a foreign file: the same exception
+    class and message as the host decoder raises."""
+    def both(path):
+        out = []
+        for fn in (lambda: read_bam(path), lambda: read_bam_gpu(path, eng)):
+            try:
+                fn()
+                out.append(None)
+            except Exception as e:   # noqa: BLE001 -- compared below
+                out.append((type(e).__name__ if not isinstance(e, (ValueError, OSError)) else "ValueError/IOError", str(e)))
+        return out
+    path = str(tmp_path / "e.bam")
+    bam_writer.write_bam(path, ["c"], [1000], [(0, 50, [(0, 30)], 0), (0, 10, [(0, 30)], 0)])
+    a, b = both(path)
+    assert a is not None and "sorted" in a[1] and b is not None and b[1] == a[1]
+    with pytest.raises(ValueError):
+        read_bam_gpu(path, eng)
+    # a placed record behind an unplaced one
+    bam_writer.write_bam(path, ["c"], [1000], [(0, 5, [(0, 30)], 0), (-1, -1, [], 4), (0, 50, [(0, 30)], 0)])
+    a, b = both(path)
+    assert a is not None and b is not None and a[1] == b[1] and "sorted" in a[1]
+    # reference id out of range, unknown CIGAR operation
+    bam_writer.write_bam(path, ["c"], [1000], [(0, 5, [(0, 30)], 0), (3, 50, [(0, 30)], 0)])
+    a, b = both(path)
+    assert a is not None and b is not None and a[1] == b[1]
+    bam_writer.write_bam(path, ["c"], [1000], [(0, 5, [(0, 30)], 0), (0, 50, [(0, 10), (11, 4), (0, 5)], 0)])
+    a, b = both(path)
+    assert a is not None and b is not None and a[1] == b[1] and "CIGAR" in a[1]
+    # payload damaged, CRC and ISIZE kept: the inflated bytes differ from what the trailer promises
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.0002, tx_scale=0.01)
+    data = bam_stream(list(reads.references), list(reads.lengths), bam_writer.packed_to_records(reads))
+    good = b"".join(member(data[o:o + 30000]) for o in range(0, len(data), 30000)) + bam_writer.BGZF_EOF
+    m0 = member(data[:30000], level=0)      # stored: flipping a payload byte leaves a valid DEFLATE stream with a wrong CRC
+    bad = bytearray(m0 + good[len(member(data[:30000])):])
+    bad[18 + 5 + 1000] ^= 0x40
+    open(path, "wb").write(bytes(bad))
+    a, b = both(path)
+    assert a is not None and b is not None and "CRC" in a[1] and a[1] == b[1]
+    # a damaged DEFLATE stream
+    bad = bytearray(good)
+    for k in range(40, 80):
+        bad[k] ^= 0xa5
+    open(path, "wb").write(bytes(bad))
+    a, b = both(path)
+    assert a is not None and b is not None and "BGZF" in a[1] and "BGZF" in b[1]   # (which of the two checks trips first is the inflater's business)
+    # truncated inside the last record; not a BAM; not BGZF at all
+    cut = data[:len(data) - 17]
+    open(path, "wb").write(b"".join(member(cut[o:o + 30000]) for o in range(0, len(cut), 30000)) + bam_writer.BGZF_EOF)
+    a, b = both(path)
+    assert a is not None and b is not None and a[1] == b[1] and "truncated" in a[1]
+    open(path, "wb").write(member(b"SAM\x01" + data[4:2000]) + bam_writer.BGZF_EOF)
+    a, b = both(path)
+    assert a is not None and b is not None and a[1] == b[1]
+    open(path, "wb").write(b"this is not a BGZF file at all, just text " * 10)
+    a, b = both(path)
+    assert a is not None and b is not None and a[1] == b[1]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_damaged_files_are_rejected_not_crashed(eng, tmp_path, seed):
+    """Random damage inside well-formed BGZF blocks and to the container: the GPU decoder either loads exactly what
+    the host decoder loads or rejects the file; it never hangs or takes the process down."""
+    from plastid_amd.exceptions import EngineError, MalformedFileError
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00001, tx_scale=0.001)
+    good = bam_stream(list(reads.references), list(reads.lengths), bam_writer.packed_to_records(reads), names=False)
+    head_len = good.index(b"r\x00") - 36
+    rng = np.random.default_rng(100 + seed)
+    path = str(tmp_path / "damaged.bam")
+    for it in range(25):
+        b = bytearray(good)
+        mode = int(rng.integers(0, 4))
+        lo = 0 if rng.random() < 0.2 else head_len
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(lo, len(b)))] = int(rng.integers(0, 256))
+        elif mode == 1:
+            b = b[:int(rng.integers(lo, len(b)))]
+        else:
+            i = int(rng.integers(lo, len(b) - 4))
+            b[i:i + 4] = struct.pack("<I", int(rng.choice([0, 1, 0x7fffffff, 0xffffffff, 0x80000000, 65536])))
+        blob = b"".join(member(bytes(b[o:o + 3000])) for o in range(0, len(b), 3000)) + bam_writer.BGZF_EOF
+        if mode == 3:
+            blob = bytearray(blob)
+            blob[int(rng.integers(0, len(blob)))] ^= 0x5a
+            blob = bytes(blob[:int(rng.integers(len(blob) // 2, len(blob) + 1))])
+        open(path, "wb").write(blob)
+        res = []
+        for fn in (lambda: read_bam(path, threads=2), lambda: read_bam_gpu(path, eng)):
+            try:
+                res.append(fn())
+            except (ValueError, MalformedFileError, OSError, EngineError) as e:
+                res.append(str(e))
+        if isinstance(res[0], str) or isinstance(res[1], str):
+            assert isinstance(res[0], str) and isinstance(res[1], str), (it, mode, res)
+        else:
+            same(res[1], res[0])
