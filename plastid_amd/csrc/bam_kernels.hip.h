@@ -9,8 +9,11 @@
 // tags}  (kent/src/htslib/sam.c bam_read1).  Host inflate (zlib / libdeflate on the 16 CPUs a GPU box grants) runs at
 // ~11 GB/s: 5.4e7 reads/s from a realistic file, against 6e11 at kernel scope.  Here the file image goes to HBM as it
 // is and
-//   k_bgzf_inflate    ONE WAVE PER MEMBER inflates it: Huffman tables and a 32 KiB window in LDS, the symbol decode
-//                     wave-uniform, match copies and the flushes of the window to HBM spread over the lanes;
+//   k_bgzf_inflate    ONE WAVE PER MEMBER inflates it: Huffman tables and the last 4 KiB of output in LDS, the symbol
+//                     decode wave-uniform, match copies and the flushes to HBM spread over the lanes; a match that reaches
+//                     further back than the LDS window reads its source from the member's output in HBM.  (The decode is a
+//                     chain of dependent LDS reads: what sets the rate is how many members a CU has in flight, i.e. LDS
+//                     per wave: the whole 32 KiB window = 41 KiB, 3 waves per CU, 11 GB/s on records as an aligner writes them; 8 KiB: 24 GB/s; 4 KiB: 27; 2 KiB: 30.)
 //   k_bam_chain       one wave per member finds where the first BAM record of the member starts (a guess: the first
 //                     offset from which a few records in a row look like records) and walks the chain of length prefixes
 //                     to the first record start of the NEXT member, noting every start; the host only confirms that
@@ -26,11 +29,14 @@
 namespace pcbam {
 
 constexpr int kInflWG = 64;                 // one wave per BGZF member
-constexpr int kWinBytes = 32768;            // DEFLATE window (RFC 1951: distances up to 32 768)
+#ifndef PC_BGZF_WINDOW
+#define PC_BGZF_WINDOW 4096
+#endif
+constexpr int kWinBytes = PC_BGZF_WINDOW;   // the part of the DEFLATE window (RFC 1951: distances up to 32 768) kept in LDS; further back: HBM
 constexpr int kLitRoot = 9, kDistRoot = 6;  // first-level table bits (zlib's choice: enough.c bounds 852 / 592 entries)
 constexpr int kLitEntries = 1024, kDistEntries = 640;
 constexpr int kInBytes = 1024;              // compressed input staged in LDS (two halves of 512 bytes)
-constexpr int kFlush = 8192;                // the window goes to HBM in pieces of this size
+constexpr int kFlush = kWinBytes / 4;       // the window goes to HBM in pieces of this size
 
 struct Member {
     uint64_t coff;     // offset of the raw DEFLATE stream in the file image (behind the gzip header)
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     __shared__ TableScratch s_ws;
     const int m = blockIdx.x;
     if (m >= nmembers) return;
-    const Member mb = members[m];
+    const Member mb = members[m];   // (uniform: scalar loads)
     const int lane = threadIdx.x & 63;
     const uint8_t *src = image + mb.coff;
     uint8_t *dst = out + mb.uoff;
@@ -213,7 +219,8 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     auto refill = [&]() {         // at least 32 valid bits afterwards (zeros behind the end of the stream)
         if (nb <= 32) {
             if (in_pos + 512u + 4u > in_loaded) stage_half();   // the reader entered the last staged half: fetch the next (zeros behind the end)
-            const uint32_t w = sh.in[(in_pos >> 2) & (kInBytes / 4 - 1)];
+            // (every lane reads the same word: readfirstlane tells the compiler so, and what follows stays on the scalar unit)
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.in[(in_pos >> 2) & (kInBytes / 4 - 1)]);
             bb |= (unsigned long long)w << nb;
             nb += 32;
             in_pos += 4u;
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             const int want = hlit + hdist;
             while (got < want && err == kInfOk) {
                 refill();
-                const uint32_t ce = sh.dist[(uint32_t)bb & 127u];
+                const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(uint32_t)bb & 127u]);
                 const int len = (int)(ce & 15u), sym = (int)(ce >> 16);
                 if (len == 0) { err = kInfBadCodeLengths; break; }
                 take(len);
@@ -338,10 +345,10 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
         // ---- the symbols of the block
         for (;;) {
             refill();
-            uint32_t e = sh.lit[(uint32_t)bb & ((1u << kLitRoot) - 1u)];
+            uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(uint32_t)bb & ((1u << kLitRoot) - 1u)]);
             if (((e >> 8) & 3u) == 3u) {
                 const uint32_t sb = (e >> 4) & 15u;
-                e = sh.lit[(e >> 16) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))];
+                e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(e >> 16) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))]);
                 bb >>= kLitRoot; nb -= kLitRoot;
             }
             const uint32_t nbits = e & 15u;
@@ -359,10 +366,10 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                 refill();
                 const uint32_t len = (e >> 16) + take((int)((e >> 4) & 15u));
                 refill();
-                uint32_t d = sh.dist[(uint32_t)bb & ((1u << kDistRoot) - 1u)];
+                uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(uint32_t)bb & ((1u << kDistRoot) - 1u)]);
                 if (((d >> 8) & 3u) == 3u) {
                     const uint32_t sb = (d >> 4) & 15u;
-                    d = sh.dist[(d >> 16) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))];
+                    d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(d >> 16) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))]);
                     bb >>= kDistRoot; nb -= kDistRoot;
                 }
                 const uint32_t dbits = d & 15u;
@@ -373,15 +380,24 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                 if (dist > pos) { err = kInfBadDistance; break; }
                 if (pos + len > ulen) { err = kInfOverrun; break; }
                 __syncthreads();
-                // copy: byte k comes from `dist` back; where the match overlaps itself the pattern repeats
-                for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
-                    const uint32_t from = dist >= len ? pos - dist + k : pos - dist + (k % dist);
-                    sh.win[(pos + k) & (kWinBytes - 1)] = sh.win[from & (kWinBytes - 1)];
+                if (dist <= (uint32_t)kWinBytes - 258u) {
+                    // copy inside the LDS window: byte k comes from `dist` back; where the match overlaps itself the pattern repeats
+                    for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
+                        const uint32_t from = dist >= len ? pos - dist + k : pos - dist + (k % dist);
+                        sh.win[(pos + k) & (kWinBytes - 1)] = sh.win[from & (kWinBytes - 1)];
+                    }
+                } else {
+                    // the source lies behind the LDS window: it has been flushed (whatever is older than the window minus a
+                    // flush piece has), so read it back from the member's output -- once the stores have landed, and past
+                    // this CU's L1, which may hold an older state of the line (dist > len here: no self-overlap)
+                    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
+                    for (uint32_t k = (uint32_t)lane; k < len; k += 64u)
+                        sh.win[(pos + k) & (kWinBytes - 1)] = __hip_atomic_load(dst + (pos - dist + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
                 pos += len;
             }
-            if (pos - flushed >= (uint32_t)kFlush + 272u) flush_to((flushed + kFlush) & ~15u);   // (keeps 32 KiB - 8 KiB - slack of history)
+            if (pos - flushed >= (uint32_t)kFlush + 272u) flush_to((flushed + kFlush) & ~15u);   // (unflushed < a piece + two matches: the window keeps the rest as history)
         }
     }
     if (err == kInfOk && pos != ulen) err = kInfShort;
