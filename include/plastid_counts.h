@@ -199,6 +199,15 @@ void *pc_total_device_ptr(pc_plan *p);
 int pc_mapped_reads(pc_engine *e, int file, int64_t rec_lo, int64_t rec_hi, int32_t tid,
                     int64_t start, int64_t end, uint8_t strand, uint8_t *mask);
 
+/* reads_out for EVERY segment of a plan in one pass: which reads the reference's map function appends for each
+ * segment (genome_array.py:800-823 fetch -> strand -> filters -> map_fn; `get_reads` :834-859; bin/psite.py:182 and
+ * bin/phase_by_size.py:187 ask per region).  A CSR over (segment, file) pairs, pair index = segment * n_files + file:
+ * offsets[n_segments * n_files + 1]; the reads of a pair are listed in file order, so a segment's reads come out in
+ * the reference's fetch order (file-major).  pc_mapped_reads_batch computes the lists on the device and returns the
+ * offsets and *total = offsets[last]; pc_read_mapped_reads copies the record indices (within their file) out. */
+int pc_mapped_reads_batch(pc_engine *e, pc_plan *p, int64_t *offsets, int64_t *total);
+int pc_read_mapped_reads(pc_engine *e, pc_plan *p, uint32_t *rec, int64_t total);
+
 /* HIP-event timing of pc_count on the engine's stream.  level 0 (default): no events are
  * recorded; 1: the whole call and the histogram / center kernel; 2: every phase.  Each
  * recorded event costs a few microseconds of stream time, which is why it is opt-in. */

@@ -63,6 +63,8 @@ SIGNATURES = {
     "pc_total": (_int, [_vp, _vp, _vp]),
     "pc_total_device_ptr": (_vp, [_vp]),
     "pc_mapped_reads": (_int, [_vp, _int, _i64, _i64, _i32, _i64, _i64, ctypes.c_uint8, _vp]),
+    "pc_mapped_reads_batch": (_int, [_vp, _vp, _vp, ctypes.POINTER(_i64)]),
+    "pc_read_mapped_reads": (_int, [_vp, _vp, _vp, _i64]),
     "pc_set_profiling": (_int, [_vp, _int]),
     "pc_last_timing": (_int, [_vp, _vp, _int]),
     "pc_last_algorithmic_bytes": (_i64, [_vp]),

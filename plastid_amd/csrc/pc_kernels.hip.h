@@ -2434,13 +2434,12 @@ __global__ __launch_bounds__(kWG) void k_probe_write(unsigned long long *dst, in
 }
 
 // ---------------------------------------------------------------- k_mapped_reads
-// reads_out of the map functions for ONE segment (genome_array.py:800-823).
-__global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fview, MapParams mp, int64_t rec_lo, int64_t rec_hi,
-                                                      int64_t start, int64_t end, int mode, bool strand_filter,
-                                                      uint8_t *mask) {
-    const GFile fv = gfile(fview);
-    int64_t i = rec_lo + (int64_t)blockIdx.x * kWG + threadIdx.x;
-    if (i >= rec_hi) return;
+// reads_out of the map functions (genome_array.py:800-823): is record i of the file among the reads the reference's
+// map function appends for the segment [start, end) -- fetched (htslib overlap: pos < end, endpos > start), on the
+// segment's strand, past the filters, and mapped by the rule to a position inside the segment (center rule: every
+// fetched read with a positive map length, map_factories.pyx:249-256: appended even if nothing landed)?
+__device__ __forceinline__ bool read_is_mapped(const GFile &fv, const MapParams &mp, int64_t i, int64_t start, int64_t end, int mode,
+                                               bool strand_filter) {
     const u32x2 r = fv.rec[i];
     const uint32_t meta = r.y;
     const uint32_t fl = rec_flags(meta);
@@ -2448,21 +2447,90 @@ __global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fview, MapParams 
     int L, nb;
     rec_true(fv, i, meta, L, nb);
     const bool rev = fl & kFlagReverse;
-    uint8_t out = 0;
     const bool fetched = (int64_t)pos < end && (int64_t)rec_end(fv, i, pos, meta) > start;
-    if (fetched && !(fl & kFlagExcluded) && (!strand_filter || strand_ok(mode, rev)) && size_ok(mp, L)) {
-        if (mp.kind == 2) {
-            out = (L - 2 * mp.param) > 0; // CenterMapFactory :249-256: appended even if nothing landed
+    if (!(fetched && !(fl & kFlagExcluded) && (!strand_filter || strand_ok(mode, rev)) && size_ok(mp, L))) return false;
+    if (mp.kind == 2) return (L - 2 * mp.param) > 0;
+    int row;
+    const int k = map_kleft_dyn(mp, L, mode == 1 || mode == 3, row);
+    if (k < 0) return false;
+    const int64_t p = nb >= 2 ? walk_runs(fv, i, nb, k) : pos + k;
+    return p >= start && p < end;
+}
+
+// ONE segment: a mask over the record range [rec_lo, rec_hi)
+__global__ __launch_bounds__(kWG) void k_mapped_reads(FileView fview, MapParams mp, int64_t rec_lo, int64_t rec_hi,
+                                                      int64_t start, int64_t end, int mode, bool strand_filter,
+                                                      uint8_t *mask) {
+    const GFile fv = gfile(fview);
+    int64_t i = rec_lo + (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= rec_hi) return;
+    mask[i - rec_lo] = read_is_mapped(fv, mp, i, start, end, mode, strand_filter) ? 1 : 0;
+}
+
+// EVERY segment of a batch at once (get_reads for thousands of regions: bin/psite.py:182, bin/phase_by_size.py:187
+// loop over it): one workgroup per (segment, file) walks the records that can overlap the segment -- those that start
+// in [start - longest span of the file, end) -- in file order.  FILL = false counts the mapped ones, FILL = true
+// writes their record indices at the scanned offsets, in order (a CSR over (segment, file)).
+struct BatchSeg {
+    int64_t start, end;
+    int32_t tid;
+    int32_t mode;       // strand mode (bit 8: no strand filter)
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(kWG) void k_mapped_reads_batch(const BatchSeg *__restrict__ segs, int64_t nseg, const FileView *__restrict__ files,
+                                                            int nfiles, const int64_t *__restrict__ max_span, MapParams mp,
+                                                            unsigned long long *counts, const unsigned long long *__restrict__ offsets,
+                                                            uint32_t *rec_out) {
+    __shared__ uint32_t s_wave[kWG / 64];
+    const int64_t sf = blockIdx.x;
+    const int64_t s = sf / nfiles;
+    const int f = (int)(sf % nfiles);
+    if (s >= nseg) return;
+    const BatchSeg sg = segs[s];
+    const GFile fv = gfile(files[f]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long n = 0;
+    if (sg.tid >= 0 && sg.end >= sg.start) {   // (an empty segment still fetches the reads that span it: pos < end, endpos > start)
+        const int64_t q0 = fv.lin_off[sg.tid], nb = fv.lin_off[sg.tid + 1] - q0 - 1;
+        const int64_t t0 = fv.tid_bounds[sg.tid], t1 = fv.tid_bounds[sg.tid + 1];
+        int64_t lo = t0, hi = t1;
+        if (nb > 0) {
+            lo = bucket_lower_bound(fv, q0, nb, sg.start - max_span[f] + 1);
+            hi = bucket_lower_bound(fv, q0, nb, sg.end);
         } else {
-            int row;
-            const int k = map_kleft_dyn(mp, L, mode == 1 || mode == 3, row);
-            if (k >= 0) {
-                const int64_t p = nb >= 2 ? walk_runs(fv, i, nb, k) : pos + k;
-                out = p >= start && p < end;
+            lo = hi = t0;
+        }
+        const int mode = sg.mode & 3;
+        const bool strand_filter = !(sg.mode & 0x100);
+        unsigned long long out = FILL ? offsets[sf] : 0ull;
+        for (int64_t base = lo; base < hi; base += kWG) {
+            const int64_t i = base + threadIdx.x;
+            const bool hit = i < hi && read_is_mapped(fv, mp, i, sg.start, sg.end, mode, strand_filter);
+            const unsigned long long m = __ballot(hit);
+            if (!FILL) {
+                n += (lane == 0) ? (unsigned long long)__popcll(m) : 0ull;
+            } else {
+                if (lane == 0) s_wave[wv] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t before = 0, tot = 0;
+                for (int w = 0; w < kWG / 64; ++w) { const uint32_t t = s_wave[w]; if (w < wv) before += t; tot += t; }
+                if (hit) rec_out[out + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+                out += tot;
+                __syncthreads();
             }
         }
     }
-    mask[i - rec_lo] = out;
+    if (!FILL) {
+        // sum over the workgroup's four waves (lane 0 of each holds its wave's count)
+        if (lane == 0) s_wave[wv] = (uint32_t)n;    // (a (segment, file) pair holds fewer than 2^32 records)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < kWG / 64; ++w) t += s_wave[w];
+            counts[sf] = t;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- k_unmappable

@@ -467,6 +467,9 @@ struct pc_plan {
     DevView<uint8_t> d_hist; // uint32 or double; inside d_tables when short, else d_hist_own
     DevBuf<uint8_t> d_hist_own;
     DevBuf<uint8_t> d_out;  // int64 or double
+    DevBuf<unsigned long long> d_mr_off;   // pc_mapped_reads_batch: mapped reads before every (segment, file) pair
+    DevBuf<uint32_t> d_mr_rec;             // ... and their record indices
+    int64_t mr_total = -1;
     DevView<uint8_t> d_total;
     int last_dtype = -1;
     bool counted = false;
@@ -2600,6 +2603,77 @@ int pc_mapped_reads(pc_engine *e, int file, int64_t rec_lo, int64_t rec_hi, int3
     hipLaunchKernelGGL(k_mapped_reads, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, f->view(), e->params(), rec_lo, rec_hi,
                        start, end, mode_of(strand), !(strand & PC_STRAND_NOFILTER), d_mask.p);
     HIP_TRY(hipMemcpyAsync(mask, d_mask.p, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return PC_OK;
+}
+
+int pc_mapped_reads_batch(pc_engine *e, pc_plan *p, int64_t *offsets, int64_t *total) {
+    if (!e || !p || p->e != e || !offsets || !total) return fail(PC_ERR_ARG, "pc_mapped_reads_batch: bad arguments");
+    if (!e->have_map) return fail(PC_ERR_STATE, "pc_mapped_reads_batch: no mapping rule set");
+    if (e->files.empty()) return fail(PC_ERR_STATE, "pc_mapped_reads_batch: no alignments staged");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = refresh_file_views(e);
+    if (rc != PC_OK) return rc;
+    const int nfiles = (int)e->files.size();
+    const int64_t nseg = p->nseg, npair = nseg * nfiles;
+    *total = 0;
+    offsets[0] = 0;
+    p->mr_total = 0;
+    if (npair == 0) return PC_OK;
+    if (npair >= (int64_t)0x7fffffff) return fail(PC_ERR_ARG, "pc_mapped_reads_batch: too many (segment, file) pairs");
+    std::vector<BatchSeg> segs((size_t)nseg);
+    for (int64_t s = 0; s < nseg; ++s) {
+        BatchSeg &g = segs[(size_t)s];
+        const int32_t t = p->h_tid[(size_t)s];
+        g.tid = (t >= 0 && t < e->ntid) ? t : -1;
+        g.start = std::max<int64_t>(p->h_start[(size_t)s], 0);
+        g.end = std::min<int64_t>(p->h_end[(size_t)s], 0x7fffffffLL);
+        g.mode = mode_of(p->h_strand[(size_t)s]) | ((p->h_strand[(size_t)s] & PC_STRAND_NOFILTER) ? 0x100 : 0);
+    }
+    std::vector<int64_t> spans;
+    for (auto *f : e->files) spans.push_back(f->max_span);
+    DevBuf<BatchSeg> d_segs;
+    DevBuf<int64_t> d_spans;
+    d_segs.pool = &e->pool; d_spans.pool = &e->pool; p->d_mr_off.pool = &e->pool; p->d_mr_rec.pool = &e->pool;
+    hipStream_t st = e->stream;
+    rc = d_segs.upload(segs, st);
+    if (rc == PC_OK) rc = d_spans.upload(spans, st);
+    if (rc == PC_OK) rc = p->d_mr_off.reserve((size_t)npair + 1);
+    if (rc != PC_OK) return rc;
+    const MapParams mp = e->params();
+    HIP_TRY(hipMemsetAsync(p->d_mr_off.p + npair, 0, 8, st));
+    hipLaunchKernelGGL((k_mapped_reads_batch<false>), dim3((unsigned)npair), dim3(kWG), 0, st, d_segs.p, nseg, e->d_files.p, nfiles, d_spans.p, mp,
+                       p->d_mr_off.p, (const unsigned long long *)nullptr, (uint32_t *)nullptr);
+    {
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, p->d_mr_off.p, p->d_mr_off.p, (int)(npair + 1), st));
+        DevBuf<uint8_t> d_tmp;
+        d_tmp.pool = &e->pool;
+        rc = d_tmp.reserve(std::max<size_t>(tmp_bytes, 16));
+        if (rc != PC_OK) return rc;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, p->d_mr_off.p, p->d_mr_off.p, (int)(npair + 1), st));
+        static_assert(sizeof(unsigned long long) == sizeof(int64_t), "offsets are copied as they are");
+        HIP_TRY(hipMemcpyAsync(offsets, p->d_mr_off.p, (size_t)(npair + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    const int64_t tot = offsets[npair];
+    if (tot >= (int64_t)0xffffffffu) return fail(PC_ERR_ARG, "pc_mapped_reads_batch: more than 2^32-2 mapped reads in one batch; split the segments");
+    rc = p->d_mr_rec.reserve((size_t)std::max<int64_t>(tot, 1));
+    if (rc != PC_OK) return rc;
+    hipLaunchKernelGGL((k_mapped_reads_batch<true>), dim3((unsigned)npair), dim3(kWG), 0, st, d_segs.p, nseg, e->d_files.p, nfiles, d_spans.p, mp,
+                       (unsigned long long *)nullptr, p->d_mr_off.p, p->d_mr_rec.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // (the segment table and the spans return to the pool)
+    p->mr_total = tot;
+    *total = tot;
+    return PC_OK;
+}
+
+int pc_read_mapped_reads(pc_engine *e, pc_plan *p, uint32_t *rec, int64_t total) {
+    if (!e || !p || p->e != e) return fail(PC_ERR_ARG, "pc_read_mapped_reads: bad arguments");
+    if (total != p->mr_total || (total > 0 && !rec)) return fail(PC_ERR_ARG, "pc_read_mapped_reads: expected %lld records (pc_mapped_reads_batch)", (long long)p->mr_total);
+    HIP_TRY(hipSetDevice(e->device));
+    if (total > 0) HIP_TRY(hipMemcpyAsync(rec, p->d_mr_rec.p, (size_t)total * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return PC_OK;
 }

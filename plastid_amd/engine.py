@@ -252,6 +252,18 @@ class Plan(object):
         check(self._lib.pc_warn_details(self.engine._h, self._h, _ptr(flags), _ptr(lens)))
         return flags, lens
 
+    def mapped_reads(self):
+        """``reads_out`` of the current mapping rule for every segment of the plan, in ONE pass: ``(offsets, rec)`` --
+        a CSR over (segment, file) pairs (pair ``s * n_files + f``); ``rec[offsets[k]:offsets[k + 1]]`` are the record
+        indices, within file ``f``, of the reads the reference's map function would append for segment ``s``."""
+        nfiles = int(self._lib.pc_num_files(self.engine._h))
+        offsets = np.zeros(self.nseg * max(nfiles, 0) + 1, np.int64)
+        total = ctypes.c_int64(0)
+        check(self._lib.pc_mapped_reads_batch(self.engine._h, self._h, _ptr(offsets), ctypes.byref(total)))
+        rec = np.zeros(total.value, np.uint32)
+        check(self._lib.pc_read_mapped_reads(self.engine._h, self._h, _ptr(rec), total.value))
+        return offsets, rec
+
     def rle(self, period=0):
         """Run-length encode the last count on the GPU: ``(starts, values)``; run k covers
         ``[starts[k], starts[k+1])`` (the last one ends at ``out_elems``).  Runs are also cut at

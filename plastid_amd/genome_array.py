@@ -341,6 +341,33 @@ class BAMGenomeArray(object):
         reads, _ = self.get_reads_and_counts(roi)
         return reads
 
+    def get_reads_batch(self, segments, as_indices=False):
+        """``[self.get_reads(seg) for seg in segments]`` in ONE pass over the staged alignments
+        (``pc_mapped_reads_batch``): what ``bin/psite.py:182`` / ``bin/phase_by_size.py:187`` ask region by
+        region.  `as_indices`: lists of ``(file index, record index)`` arrays instead of read objects (no Python
+        object per read).  Segments on unknown chromosomes give empty lists (genome_array.py:795-798)."""
+        segs = list(segments)
+        if not self._native():
+            return [self.get_reads(s) for s in segs]
+        self._sync_engine([(s.chrom, s.start, s.end, s.strand) for s in segs])
+        n = len(segs)
+        tid = [self._chrom_index.get(s.chrom, -1) for s in segs]
+        plan = self._engine.plan(tid, [s.start for s in segs], [s.end for s in segs], [s.c_strand for s in segs],
+                                 np.zeros(n, np.int64), np.zeros(n, np.int8), np.ones(n, np.int64), max(self._engine.rows, 1), self._engine.rows)
+        try:
+            offsets, rec = plan.mapped_reads()
+        finally:
+            plan.close()
+        nfiles = len(self._packed)
+        out = []
+        for s in range(n):
+            parts = [(f, rec[offsets[s * nfiles + f]:offsets[s * nfiles + f + 1]]) for f in range(nfiles)]
+            if as_indices:
+                out.append([(f, idx.astype(np.int64)) for f, idx in parts if len(idx)])
+            else:
+                out.append([self._packed[f].read(int(i)) for f, idx in parts for i in idx])
+        return out
+
     def __getitem__(self, roi):
         return self.get(roi, roi_order=True)
 

@@ -306,12 +306,13 @@ def device_tensor(ptr, n, dtype="int64"):
     return torch.as_tensor(_DevicePointer(ptr, n, typestr), device="cuda")
 
 
-def allreduce_device_sums(ptr, n, dtype="int64"):
+def allreduce_device_sums(ptr, n, dtype="int64", force=False):
     """In-place all-reduce (RCCL ``ncclSum`` over xGMI) of `n` int64 / float64 values at device
     address `ptr`.  The caller synchronises the engine's stream first: RCCL runs on torch's stream.
-    Returns the tensor view."""
+    Returns the tensor view.  `force`: run the collective in a world of one too (the hardware test of
+    this path on a one-GPU box, tests/test_gpu_rccl.py)."""
     import torch.distributed as dist
     t = device_tensor(ptr, n, dtype)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t

@@ -916,3 +916,70 @@ def test_exact_grid_guard_and_cache_invalidation(pa, monkeypatch):
     assert np.array_equal(plan3.count(np.int64), full)       # the cache was dropped: whole capacity again
     plan3.close()
     e3.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", ["quirks", "random_reads", "wide_reads"])
+def test_golden_reads_out_through_the_batch_call(pa, group):
+    """`reads_out` of every golden segment query (the reference's own lists), reproduced by ONE pass per case over all
+    its segments: `BAMGenomeArray.get_reads_batch` -> `pc_mapped_reads_batch` (a CSR over (segment, file) pairs)."""
+    g = gu.load(group)
+    nq = 0
+    for case in g.cases:
+        if case["kind"] != "ga":
+            continue
+        files = files_of(pa, g, case)
+        ga = pa.BAMGenomeArray(files, mapping=factory_of(pa, case["spec"]))
+        if case.get("size_filter"):
+            ga.add_filter("size", pa.SizeFilterFactory(min=case["size_filter"][0], max=case["size_filter"][1]))
+        offs = np.cumsum([0] + [f.n for f in files])
+        qs = [q for q in case["queries"] if q["type"] == "segment"]
+        segs = [pa.GenomicSegment(q["chrom"], q["start"], q["end"], q["strand"]) for q in qs]
+        if not segs:
+            continue
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lists = ga.get_reads_batch(segs)
+            idx_lists = ga.get_reads_batch(segs, as_indices=True)
+        assert len(lists) == len(segs)
+        for q, reads, parts in zip(qs, lists, idx_lists):
+            nq += 1
+            got = [offs[files.index(r.source)] + r.index for r in reads]
+            assert got == list(g[q["reads_out"]]), (case["spec"], q)
+            flat = [int(offs[f] + i) for f, idx in parts for i in idx]
+            assert flat == got
+    assert nq >= 60
+
+
+@pytest.mark.gpu
+def test_reads_out_of_twenty_thousand_segments_in_one_pass(pa, oracle):
+    """20 000 exon-sized segments over a spliced, two-file data set: the batch lists equal the oracle's `mapped`
+    masks (fetch order, file-major) for a sample of segments and the per-segment engine path for another."""
+    from plastid_amd import synth
+    from plastid_amd.packing import concat_file_major
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0004, tx_scale=0.05)
+    halves = [reads.subset(np.arange(k, reads.n, 2)) for k in (0, 1)]
+    ga = pa.BAMGenomeArray(halves, mapping=pa.FivePrimeMapFactory(12))
+    p = tx.plan_arrays(rows=1)
+    nseg = min(20000, len(p["tid"]))
+    names = list(reads.references)
+    strand = {1: "+", 2: "-", 3: "."}
+    segs = [pa.GenomicSegment(names[int(p["tid"][s])], int(p["start"][s]), int(p["end"][s]), strand[int(p["strand"][s]) & 3]) for s in range(nseg)]
+    parts = ga.get_reads_batch(segs, as_indices=True)
+    assert len(parts) == nseg
+    aln = concat_file_major(ga._packed)
+    spec = oracle.mapping_spec("fiveprime", 12)
+    rng = np.random.default_rng(3)
+    pick = rng.choice(nseg, 60, replace=False)
+    offs = np.cumsum([0] + [f.n for f in ga._packed])
+    _, _, mapped = oracle.count_segments(aln, spec, p["tid"][pick], p["start"][pick], p["end"][pick], p["strand"][pick], want_mapped=True)
+    nonempty = 0
+    for k, s in enumerate(pick):
+        got = [int(offs[f] + i) for f, idx in parts[s] for i in idx]
+        assert got == list(np.nonzero(mapped[k])[0]), s
+        nonempty += bool(got)
+    assert nonempty > 10
+    for s in rng.choice(nseg, 15, replace=False):          # the per-segment path of the mirror
+        reads_one = ga.get_reads(segs[int(s)])
+        got = [(ga._packed.index(r.source), r.index) for r in reads_one]
+        assert got == [(f, int(i)) for f, idx in parts[int(s)] for i in idx]
