@@ -694,11 +694,13 @@ def run_partitioned(name, args, ctx, headline):
 
 
 def e2e_scope(args, ctx, name, realistic=False):
-    """SURVEY 8(d) t_e2e on a bounded sample: a BAM file written once (untimed) is decoded by the
-    native reader, staged, counted and read back.  Two files: the SKELETON records of round 1 / 2 (42 bytes each:
-    name ``r``, no sequence -- a best case by 3x in inflate bytes) and, `realistic`, records as an aligner writes them
-    (read name, sequence, qualities, NH / MD tags: ~120 bytes per 30-nt read)."""
-    from plastid_amd.bam import read_bam
+    """SURVEY 8(d) t_e2e on a bounded sample: a BAM file written once (untimed) is decoded, staged, counted and read
+    back.  Two files: the SKELETON records of round 1 / 2 (42 bytes each: name ``r``, no sequence -- a best case by 3x in
+    inflate bytes) and, `realistic`, records as an aligner writes them (read name, sequence, qualities, NH / MD tags:
+    ~120 bytes per 30-nt read).  Two decoders per file: the native host reader (zlib / libdeflate on the CPUs the box
+    grants) and, `*_gpu_decode`, the file image sent to HBM as it is with BGZF inflate and record decode as HIP kernels
+    (pc_bam_open)."""
+    from plastid_amd.bam import read_bam, read_bam_gpu
     from tests import bam_writer
     Engine, _ = engine_class()
     want = args.e2e_realistic_records if realistic else args.e2e_records
@@ -714,39 +716,51 @@ def e2e_scope(args, ctx, name, realistic=False):
     fsize = os.path.getsize(path)
     eng = Engine(ctx["dev_index"])
     factory._configure(eng)
-    read_bam(path)                                   # page cache + library warm-up
-    runs = []
-    for _ in range(3):                               # the host cores are shared with other tenants: three whole passes
-        t0 = time.perf_counter()
-        packed = read_bam(path)
-        t_decode = time.perf_counter() - t0
-        eng.set_alignments([packed])
-        t_stage = time.perf_counter() - t0 - t_decode
-        plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
-        got = plan.count(np.float64 if mapping[0] == "center" else np.int64)
-        t_all = time.perf_counter() - t0
-        runs.append((t_all, t_decode, t_stage))
-        plan.close()
-        ok = all(np.array_equal(getattr(packed, k), getattr(reads, k)) for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"))
-        del packed, got                              # released outside the timed pass
-    t_all, t_decode, t_stage = min(runs)
-    t_median = sorted(r[0] for r in runs)[1]
+    out = {}
+    for gpu_decode in (False, True):
+        key = ("e2e_realistic" if realistic else "e2e") + ("_gpu_decode" if gpu_decode else "")
+        decode = (lambda: read_bam_gpu(path, eng)) if gpu_decode else (lambda: read_bam(path))
+        try:
+            decode()                                     # page cache + library warm-up
+            runs = []
+            for _ in range(3):                           # the host cores are shared with other tenants: three whole passes
+                t0 = time.perf_counter()
+                packed = decode()
+                t_decode = time.perf_counter() - t0
+                eng.set_alignments([packed])
+                t_stage = time.perf_counter() - t0 - t_decode
+                plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
+                got = plan.count(np.float64 if mapping[0] == "center" else np.int64)
+                t_all = time.perf_counter() - t0
+                runs.append((t_all, t_decode, t_stage))
+                plan.close()
+                ok = all(np.array_equal(getattr(packed, k), getattr(reads, k)) for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"))
+                del packed, got                          # released outside the timed pass
+                if not ok:
+                    raise SystemExit("e2e scope: the decoded BAM differs from the records it was written from")
+        except SystemExit:
+            raise
+        except Exception as e:   # a scope that fails must not cost the bench line
+            out[key + "_error"] = str(e)
+            continue
+        t_all, t_decode, t_stage = min(runs)
+        t_median = sorted(r[0] for r in runs)[1]
+        out[key + "_reads_per_s"] = reads.n / t_all
+        out[key + "_reads_per_s_median"] = reads.n / t_median
+        out[key + "_sample"] = ("%d records of %s written once (untimed) as a BGZF-compressed BAM of %.0f MB (%.0f MB inflated, %.0f bytes per "
+                                "record%s); timed: three whole passes (%s s; value = best, median beside it): %s decode %.3f s + staging "
+                                "%.3f s + plan, count and read-back %.3f s" %
+                                (reads.n, name, fsize / 1e6, nbytes / 1e6, nbytes / float(reads.n),
+                                 ": read name, sequence, qualities, NH and MD tags" if realistic else ": name 'r', no sequence",
+                                 "/".join("%.3f" % r[0] for r in runs), "GPU (BGZF inflate + record decode as HIP kernels)" if gpu_decode else "native host",
+                                 t_decode, t_stage, t_all - t_decode - t_stage))
     eng.close()
     try:
         os.remove(path)
         os.rmdir(tmp)
     except OSError:
         pass
-    if not ok:
-        raise SystemExit("e2e scope: the decoded BAM differs from the records it was written from")
-    key = "e2e_realistic" if realistic else "e2e"
-    return {key + "_reads_per_s": reads.n / t_all, key + "_reads_per_s_median": reads.n / t_median,
-            key + "_sample": "%d records of %s written once (untimed) as a BGZF-compressed BAM of %.0f MB (%.0f MB inflated, %.0f bytes per "
-                             "record%s); timed: three whole passes (%s s; value = best, median beside it): native decode %.3f s + staging "
-                             "%.3f s + plan, count and read-back %.3f s" %
-                             (reads.n, name, fsize / 1e6, nbytes / 1e6, nbytes / float(reads.n),
-                              ": read name, sequence, qualities, NH and MD tags" if realistic else ": name 'r', no sequence",
-                              "/".join("%.3f" % r[0] for r in runs), t_decode, t_stage, t_all - t_decode - t_stage)}
+    return out
 
 
 def sig(x, digits=4):
@@ -986,7 +1000,7 @@ def main():
                           (cpu.get("chains_sampled", 0), head["chains"], head["records_total"], config["detail"]),
                 "all_cores": None if not cpu.get("all_cores") else {"value": sig(cpu["all_cores"]["value"]), "cores": cpu["all_cores"]["cores"]},
                 "cpu_model": cpu.get("cpu_model"), "usable_cores": cpu.get("usable_cores")},
-            "scopes": {k: sig(v) for k, v in scopes.items() if isinstance(v, (int, float))},
+            "scopes": {k: sig(v) for k, v in scopes.items() if isinstance(v, (int, float)) and not k.endswith("_median")},
             "configs": {c: brief_config(r) for c, r in others.items()},
         }
         if roof.get("stream_peak_measured"):

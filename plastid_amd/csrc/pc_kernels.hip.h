@@ -1082,7 +1082,11 @@ __device__ __forceinline__ void out_add(typename OutT_<OUTMODE>::type *dst, unsi
 #ifndef PC_HIST_SKIP
 #define PC_HIST_SKIP 0
 #endif
-template <int KIND, int OUTMODE, int WG, bool SMALL, bool MULTI>
+// SINGLE: a plan of ONE window over one file (`ga[segment]`, the reference's scripts ask region by region,
+// genome_array.py:861-928): the workgroup looks its record ranges up itself (what k_tile_ranges does for a window that is
+// not cut: a handful of linear-index reads) -- the whole count is this one launch, no work list, no second class, no
+// merge pass.  `work` then points at the plan's tile, `chain` carries the halos {Ws, Wg, Wr}.
+template <int KIND, int OUTMODE, int WG, bool SMALL, bool MULTI, bool SINGLE = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : PC_HIST_WAVES(KIND), 8))) void k_hist_point(const Piece *__restrict__ pieces,
                                                     const OutPiece *__restrict__ opieces, FileView file0,
                                                     FileView file1, const FileView *__restrict__ files,
@@ -1102,9 +1106,34 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     // the counters instead of after them: one dependent round trip less per workgroup.
     // (the first `grid_front` blocks serve the front of the list, the others its back: the host launches
     // the whole capacity the first time and exactly the queued counts once it has seen them)
-    const uint32_t slot = blockIdx.x < grid_front ? blockIdx.x : work_cap - (gridDim.x - blockIdx.x);
-    const uint32_t n_heavy = SMALL ? nwork[2] : nwork[0], n_light = SMALL ? 0u : nwork[1];
-    const WorkItem w = work[slot];
+    const uint32_t slot = SINGLE ? 0u : (blockIdx.x < grid_front ? blockIdx.x : work_cap - (gridDim.x - blockIdx.x));
+    const uint32_t n_heavy = SINGLE ? 1u : (SMALL ? nwork[2] : nwork[0]), n_light = (SMALL || SINGLE) ? 0u : nwork[1];
+    WorkItem w_;
+    if (SINGLE) {
+        const Tile tl = *(const Tile *)work;
+        const GFile g0 = gfile(file0);
+        const int Ws = (int)hist_row_stride, Wg = (int)work_cap, Wr = (int)grid_front;   // (the halos travel in arguments a single window has no use for)
+        const int64_t q0 = g0.lin_off[tl.tid], qn = g0.lin_off[tl.tid + 1] - q0 - 1;
+        const int64_t a = (int64_t)tl.win_start + tl.span_lo, e = (int64_t)tl.win_start + tl.span_hi + (1 << kLinShift) - 1;
+        w_.lo = lin_floor(g0.lin_tab, q0, qn, a - Ws + 1);
+        w_.hi = lin_floor(g0.lin_tab, q0, qn, e);
+        w_.glo = g0.ngap ? lin_floor(g0.glin_tab, q0, qn, a - Wg + 1) : 0;
+        w_.ghi = g0.ngap ? lin_floor(g0.glin_tab, q0, qn, e) : 0;
+        w_.rlo = g0.nrunrec ? (uint32_t)lin_floor(g0.rlin_tab, q0, qn, a - Wr + 1) : 0u;
+        w_.rhi = g0.nrunrec ? (uint32_t)lin_floor(g0.rlin_tab, q0, qn, e) : 0u;
+        w_.llo = w_.lhi = 0;
+        if (g0.nxlong) {
+            w_.lhi = lin_floor(g0.xllin_tab, q0, qn, e);
+            w_.llo = lin_floor(g0.xplin_tab, q0, qn, a);
+            if (w_.llo > w_.lhi) w_.llo = w_.lhi;
+        }
+        w_.tile = 0u; w_.file = 0u; w_.win_start = tl.win_start; w_.mode_mask = tl.mode_mask;
+        w_.piece_begin = tl.piece_begin; w_.piece_end = tl.piece_end; w_.op_begin = tl.op_begin; w_.op_end = tl.op_end;
+        w_.sub_lo = 0; w_.sub_hi = G; w_.merge = 0u; w_.span_lo = tl.span_lo; w_.span_hi = tl.span_hi;
+    } else {
+        w_ = work[slot];
+    }
+    const WorkItem w = w_;
     // offset-table values this thread needs for the LDS tables (variable / stratified rules): they
     // depend on kernel arguments only and travel together with the work item
     int pre_f = -1, pre_r = -1;

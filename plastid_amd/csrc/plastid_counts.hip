@@ -297,6 +297,8 @@ struct Knobs {
     int64_t work_r = 49152;    // PC_WORK_R: records per work item (192 KiB of the 4-byte stream)
     int64_t pile = 0;          // PC_PILE: records of a 128-nt sub-window beyond which it is merged through the histogram (0: 12 R)
     int no_small = 0;          // PC_NO_SMALL: no single-wave class for sparse windows
+    int small_rows = 0;        // PC_SMALL_ROWS: 1 = multi-row plans (stratified rule) may use the single-wave class too
+    int no_single = 0;         // PC_NO_SINGLE: one-window plans go through the work lists like any other (tests compare the two paths)
     int small_g = 512;         // PC_SMALL_G: queried span a single-wave window may have
     int64_t small_n = 8192;    // PC_SMALL_N: records a single-wave window may scan (C4: 1.25 ms at 2048, 1.22 at 8192, 1.21 at 32768)
     int debug_work = 0;        // PC_DEBUG_WORK: print the queued work items per class (stderr; synchronises)
@@ -312,6 +314,8 @@ struct Knobs {
         if (const char *env = getenv("PC_WORK_R")) work_r = std::max(1024, atoi(env));
         if (const char *env = getenv("PC_PILE")) pile = std::max<int64_t>(work_r, atoll(env));
         no_small = getenv("PC_NO_SMALL") ? 1 : 0;
+        if (const char *env = getenv("PC_SMALL_ROWS")) small_rows = atoi(env);
+        no_single = getenv("PC_NO_SINGLE") ? 1 : 0;
         if (const char *env = getenv("PC_SMALL_G")) small_g = std::max(64, atoi(env) / 64 * 64);
         if (const char *env = getenv("PC_SMALL_N")) small_n = std::max(64, atoi(env));
         debug_work = getenv("PC_DEBUG_WORK") ? 1 : 0;
@@ -1947,7 +1951,49 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     if (!center) {
         p->hist_kind = 0;
         p->hist_clean = true; // k_gather_split clears what the split tiles merged
-        if (ntiles > 0) {
+        // ---- a plan of ONE window over one file (`ga[segment]`): the whole count is one launch -- the workgroup looks its
+        // record ranges up itself; no work list, no second window class, no merge pass, no events
+        const bool single = ntiles == 1 && nfiles == 1 && !e->knobs.debug_work && !e->knobs.no_single;
+        if (single) {
+            int lmin = 65536, lmax = -1;
+            for (auto *f : e->files) { lmin = std::min(lmin, f->len_min); lmax = std::max(lmax, f->len_max); }
+            int tab_lo = 0, tab_n = 0;
+            if ((e->kind == PC_MAP_VAR5 || e->kind == PC_MAP_STRAT5) && lmax >= lmin) {
+                tab_lo = lmin;
+                tab_n = std::max(0, std::min(std::min(lmax, e->table_len - 1) - lmin + 1, 1024));
+            }
+            int fast_lo = kStreamMaxLen, fast_hi = 0;
+            for (auto *f : e->files) { fast_lo = std::min(fast_lo, f->tlen_min); fast_hi = std::max(fast_hi, f->tlen_max); }
+            fast_lo = std::min(fast_lo, fast_hi);
+            const size_t stage_words = (size_t)kOpStage * sizeof(OutPiece) / sizeof(uint32_t);
+            const size_t lds = ((size_t)p->max_slots * p->rows * G + (size_t)((tab_n + 3) & ~3) + stage_words + (size_t)(fast_hi + 1) * kModes + 64) * sizeof(uint32_t);
+            if (lds > e->max_lds)
+                return fail(PC_ERR_ARG, "pc_count: the window needs %zu bytes of LDS, the device offers %zu per workgroup (too many rows)", lds, e->max_lds);
+            const FileView fv0 = e->files[0]->view();
+            const int outmode = e->norm_on ? 2 : (out_dtype == PC_OUT_FLOAT64 ? 1 : 0);
+            if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
+#define PC_LAUNCH_SINGLE(K, O)                                                                                        \
+    hipLaunchKernelGGL((k_hist_point<K, O, kHistWG, false, false, true>), dim3(1), dim3(kHistWG), lds, st, p->d_pieces.p, p->d_opieces.p, \
+                       fv0, fv0, e->d_files.p, (const WorkItem *)p->d_tiles.p, p->d_wcounters.p, p->d_tile_items.p, mp, G, p->max_slots,    \
+                       tab_lo, tab_n, fast_lo, fast_hi, (uint32_t *)p->d_hist.p, (int64_t)e->Ws(), (OutT_<O>::type *)p->d_out.p,           \
+                       e->norm_sum, (uint32_t)e->Wg(), (uint32_t)e->Wr(), (const FileRange *)nullptr, nfiles)
+#define PC_LAUNCH_SINGLE_O(K)                                                                                         \
+    do {                                                                                                              \
+        if (outmode == 0) PC_LAUNCH_SINGLE(K, 0);                                                                     \
+        else if (outmode == 1) PC_LAUNCH_SINGLE(K, 1);                                                                \
+        else PC_LAUNCH_SINGLE(K, 2);                                                                                  \
+    } while (0)
+            switch (e->kind) {
+            case PC_MAP_FIVE: PC_LAUNCH_SINGLE_O(0); break;
+            case PC_MAP_THREE: PC_LAUNCH_SINGLE_O(1); break;
+            case PC_MAP_VAR5: PC_LAUNCH_SINGLE_O(3); break;
+            default: PC_LAUNCH_SINGLE_O(4); break;
+            }
+#undef PC_LAUNCH_SINGLE_O
+#undef PC_LAUNCH_SINGLE
+            if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[3], st));
+            if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[4], st));
+        } else if (ntiles > 0) {
             // work list capacity: every record lies in at most 1 + ceil(W/G) scan windows
             // work-list capacity (an upper bound): a window scanning n records yields at most
             // max(1, 2n/R) items, and every record is scanned by at most 1 + (W+127)/G windows
@@ -1963,7 +2009,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // sparse windows: single-wave workgroups with a small LDS window (rows == 1 only)
             // (skipped for dense annotations, where queried positions fill most of every window)
             const bool sparse_plan = (double)p->npos < 0.25 * (double)ntiles * (double)G;
-            const int small_g = (p->rows == 1 && sparse_plan && !e->knobs.no_small) ? std::min(e->knobs.small_g, G) : 0;
+            const int small_g = ((p->rows == 1 || e->knobs.small_rows) && sparse_plan && !e->knobs.no_small) ? std::min(e->knobs.small_g, G) : 0;
             const int64_t small_n = e->knobs.small_n;
             const int64_t cap_small = small_g ? (int64_t)ntiles * nfiles : 0;
             rc = p->d_work_small.reserve((size_t)std::max<int64_t>(cap_small, 1));

@@ -983,3 +983,77 @@ def test_reads_out_of_twenty_thousand_segments_in_one_pass(pa, oracle):
         reads_one = ga.get_reads(segs[int(s)])
         got = [(ga._packed.index(r.source), r.index) for r in reads_one]
         assert got == [(f, int(i)) for f, idx in parts[int(s)] for i in idx]
+
+
+@pytest.mark.gpu
+def test_one_window_plans_count_in_a_single_launch(pa, oracle):
+    """A plan of one window over one file (`ga[segment]`) takes the fused path: the tile kernel looks its record ranges
+    up itself.  Its counts equal the oracle's and those of the general path (work lists, window classes, merge pass;
+    forced with PC_NO_SINGLE) -- for every rule, forward / reversed / summed layouts, a spliced data set, a pile-up of
+    more records than one work item of the general path takes, an empty window and a window beyond the last record."""
+    from plastid_amd import synth
+    from plastid_amd.packing import PackedAlignments
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0005, tx_scale=0.01)
+    # a pile-up: 120 000 extra reads of mixed lengths at a handful of positions of the first contig
+    rng = np.random.default_rng(11)
+    npile = 120000
+    ppos = np.sort(rng.choice(np.arange(5000, 5040), npile)).astype(np.int32)
+    plen = rng.integers(25, 35, npile).astype(np.uint16)
+    extra = PackedAlignments(np.zeros(npile, np.int32), ppos, plen, rng.integers(0, 2, npile).astype(np.uint8), np.ones(npile, np.uint8),
+                             references=reads.references, lengths=reads.lengths)
+    first = reads.slice(0, int(np.searchsorted(reads.tid, 1)))
+    # (the pile-up file holds the first contig's single-run reads + the pile, in coordinate order)
+    order = np.argsort(np.concatenate([first.pos, extra.pos]), kind="stable")
+    cat = lambda k: np.concatenate([getattr(first, k), getattr(extra, k)])[order]   # noqa: E731
+    keep = cat("nblk") == 1
+    dense = PackedAlignments(cat("tid")[keep], cat("pos")[keep], cat("alen")[keep], cat("flags")[keep], cat("nblk")[keep],
+                             references=reads.references, lengths=reads.lengths)
+    names = list(reads.references)
+    cases = []
+    p = tx.plan_arrays(rows=1)
+    for s in rng.choice(len(p["tid"]), 12, replace=False):
+        cases.append((reads, int(p["tid"][s]), int(p["start"][s]), int(p["end"][s]), int(p["strand"][s])))
+    cases += [(dense, 0, 4900, 5200, 1), (dense, 0, 4990, 5100, 2), (dense, 0, 5000, 5001, 3),
+              (reads, 0, 10, 10, 1), (reads, len(names) - 1, int(reads.lengths[-1]) + 5000, int(reads.lengths[-1]) + 5300, 3)]
+    mappings = [("fiveprime", 12), ("threeprime", 3), ("variable", synth.VARIABLE_OFFSETS), ("stratified", synth.VARIABLE_OFFSETS, 27, 31)]
+    saved = os.environ.pop("PC_NO_SINGLE", None)
+    try:
+        for files in (reads, dense):
+            for mapping in mappings:
+                eng = engine_for(pa, [files], mapping)
+                rows = eng.rows
+                spec = spec_for(oracle, mapping)
+                aln = aln_dict([files])
+                for (fl, tid, start, end, strand) in cases:
+                    if fl is not files:
+                        continue
+                    n = end - start
+                    for step in (1, -1, 0):
+                        off = [0] if step >= 0 else [max(n - 1, 0)]
+                        stride = [max(n, 1)] if step else [1]
+                        elems = max(rows * n, 1) if step else rows
+                        got = {}
+                        for path in ("single", "general"):
+                            if path == "general":
+                                os.environ["PC_NO_SINGLE"] = "1"
+                            else:
+                                os.environ.pop("PC_NO_SINGLE", None)
+                            eng.reload_knobs()
+                            plan = eng.plan([tid], [start], [end], [strand], off, [step], stride, elems, rows)
+                            got[path] = plan.count(np.int64).copy()
+                            plan.close()
+                        assert np.array_equal(got["single"], got["general"]), (mapping, tid, start, end, strand, step)
+                        arrays, _ = oracle.count_segments(aln, spec, [tid], [start], [end], [strand])
+                        a2 = arrays[0].reshape(rows, n)
+                        if step == 0:
+                            exp = a2.sum(axis=1)
+                        else:
+                            exp = np.zeros(elems, np.int64)
+                            for r in range(rows):
+                                exp[off[0] + r * stride[0] + step * np.arange(n)] = a2[r]
+                        assert np.array_equal(got["single"][:len(exp)], exp), (mapping, tid, start, end, strand, step)
+                eng.close()
+    finally:
+        os.environ.pop("PC_NO_SINGLE", None)
+        if saved is not None:
+            os.environ["PC_NO_SINGLE"] = saved
