@@ -834,7 +834,7 @@ def main():
     ap.add_argument("--time-budget", type=float, default=1200.0, help="seconds after which no further config is started")
     ap.add_argument("--e2e-records", type=float, default=1e8, help="records of the BAM file of the e2e scope, at most the whole configuration (0: skip)")
     ap.add_argument("--detail-out", default=None, help="where the full result (prose included) goes; default bench_detail.json beside bench.py")
-    ap.add_argument("--e2e-realistic-records", type=float, default=3e6,
+    ap.add_argument("--e2e-realistic-records", type=float, default=2e7,
                     help="records of the second e2e sample, written as an aligner writes them (~120 bytes per record; 0: skip)")
     args = ap.parse_args()
     t_start = time.perf_counter()

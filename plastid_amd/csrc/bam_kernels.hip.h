@@ -30,7 +30,7 @@ namespace pcbam {
 
 constexpr int kInflWG = 64;                 // one wave per BGZF member
 #ifndef PC_BGZF_WINDOW
-#define PC_BGZF_WINDOW 4096
+#define PC_BGZF_WINDOW 2048
 #endif
 constexpr int kWinBytes = PC_BGZF_WINDOW;   // the part of the DEFLATE window (RFC 1951: distances up to 32 768) kept in LDS; further back: HBM
 constexpr int kLitRoot = 9, kDistRoot = 6;  // first-level table bits (zlib's choice: enough.c bounds 852 / 592 entries)
@@ -174,15 +174,102 @@ struct InflateShared {
     uint8_t win[kWinBytes];
 };
 
-// One wave inflates one BGZF member.  Everything but the copies is wave-uniform (every lane holds the same bit
-// buffer and positions): no divergence, table reads are LDS broadcasts.  (The workgroup IS the wave: __syncthreads()
-// orders the LDS traffic of its lanes and costs no cross-wave barrier.)
-__global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restrict__ image, const Member *__restrict__ members, int nmembers,
+// ---- the symbols of a block, a BATCH of bit offsets at a time (k_bgzf_inflate<true>)
+// A wave-uniform decode spends ~45 scalar instructions per symbol, and the CU's one scalar unit is shared by every
+// resident wave: more waves per CU stopped paying at ~30 GB/s.  What a symbol at bit offset `i` is -- and where the
+// next one starts -- depends only on the bits from `i` on and on the block's tables, so all of it can be looked up
+// for EVERY bit offset of the next kBatchBits at once, one lane per 8 consecutive offsets, without a branch:
+// sym[i] = {bits consumed, kind, literal byte | match length and distance}.  Which offsets are real symbol starts is
+// then a walk over sym[] from offset 0 (one LDS read and a dozen instructions per symbol, nothing else on the
+// dependent chain), and everything after it is per SYMBOL, one lane each: output positions by a prefix sum,
+// literals stored in parallel, matches whose source lies before the chunk copied in parallel (one per lane), the few
+// whose source is inside the chunk in stream order, each by the whole wave.
+// (Measured on the way: reachability by pointer doubling over all 512 offsets instead of the walk, with the
+// post-processing per offset -- correct, and at ~3 700 vector instructions per batch only 13 % faster than the uniform
+// decode.)
+constexpr int kBatchBits = 512;             // bit offsets per batch: 64 lanes x 8
+constexpr uint32_t kSymLit = 0u, kSymMatch = 1u, kSymEob = 2u, kSymBad = 3u;   // sym: bits 0-5 consumed, 6-7 kind, 8-15 byte | length - 3, 16-30 distance - 1
+
+struct BatchShared {
+    uint32_t sym[kBatchBits];               // what starts at bit offset i, were it a symbol start
+    uint32_t chain[kBatchBits];             // the symbols that are real, in stream order (a symbol is at least one bit)
+};
+
+struct HeaderShared {
+    uint8_t lens[352];
+    TableScratch ws;
+};
+
+// What the symbols at the lane's 8 bit offsets are, by the block's tables ({A, B, C}: the 96 bits from the first of
+// them on).  Straight-line -- the lanes of a wave look at different offsets, so every path would be walked anyway;
+// second-level lookups that do not apply read entry 0 -- and in stages, each stage's 8 table reads in flight
+// together (the empty asm statements pin the stage boundaries: left alone, the compiler sinks the distance lookups
+// into a branch and waits for every read on its own).
+#define PC_PIN8(x) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]))
+__device__ __forceinline__ void symbols_at8(const uint32_t *lit, const uint32_t *dist, uint32_t A, uint32_t B, uint32_t C, uint32_t (&out)[8]) {
+    uint32_t lo[8], w2[8], e[8], x[8], tot2[8], val[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        lo[t] = (uint32_t)((((unsigned long long)B << 32) | A) >> t);
+        e[t] = lit[lo[t] & ((1u << kLitRoot) - 1u)];
+    }
+    PC_PIN8(e);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool two = ((e[t] >> 8) & 3u) == 3u;
+        x[t] = lit[two ? (e[t] >> 16) + __builtin_amdgcn_ubfe(lo[t], (uint32_t)kLitRoot, (e[t] >> 4) & 15u) : 0u];
+    }
+    PC_PIN8(x);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool two = ((e[t] >> 8) & 3u) == 3u;
+        const uint32_t tot = (two ? (uint32_t)kLitRoot : 0u) + ((two ? x[t] : e[t]) & 15u);          // <= 15
+        e[t] = two ? x[t] : e[t];
+        const uint32_t xb = (e[t] >> 4) & 15u;                                                       // (literals: 0)
+        val[t] = (e[t] >> 16) + __builtin_amdgcn_ubfe(lo[t], tot, xb);                               // the byte | the match length
+        tot2[t] = tot + xb;                                                                          // <= 20
+        const uint32_t hi = (uint32_t)((((unsigned long long)C << 32) | B) >> t);
+        w2[t] = (uint32_t)((((unsigned long long)hi << 32) | lo[t]) >> tot2[t]);                     // (one v_alignbit: tot2 < 32)
+        x[t] = dist[w2[t] & ((1u << kDistRoot) - 1u)];
+    }
+    PC_PIN8(x);
+    uint32_t y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool dtwo = ((x[t] >> 8) & 3u) == 3u;
+        y[t] = dist[dtwo ? (x[t] >> 16) + __builtin_amdgcn_ubfe(w2[t], (uint32_t)kDistRoot, (x[t] >> 4) & 15u) : 0u];
+    }
+    PC_PIN8(y);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool dtwo = ((x[t] >> 8) & 3u) == 3u;
+        const uint32_t d = dtwo ? y[t] : x[t];
+        const uint32_t dt = (dtwo ? (uint32_t)kDistRoot : 0u) + (d & 15u);                           // <= 15
+        const uint32_t dxb = (d >> 4) & 15u;                                                         // <= 13
+        const uint32_t dd = (d >> 16) + __builtin_amdgcn_ubfe(w2[t], dt, dxb);
+        const bool dok = (d & 15u) != 0u && ((d >> 8) & 3u) == 0u;
+        const uint32_t kind = (e[t] >> 8) & 3u;
+        const uint32_t bad = 1u | (kSymBad << 6);
+        uint32_t r = (tot2[t]) | (kSymLit << 6) | (val[t] << 8);                                       // kind 0 (xb = 0: tot2 = tot)
+        r = kind == 1u ? (dok ? (tot2[t] + dt + dxb) | (kSymMatch << 6) | ((val[t] - 3u) << 8) | ((dd - 1u) << 16) : bad) : r;
+        r = kind == 2u ? ((e[t] >> 16) ? bad : tot2[t] | (kSymEob << 6)) : r;
+        out[t] = (e[t] & 15u) == 0u ? bad : r;
+    }
+}
+
+// One wave inflates one BGZF member.  Block headers, code lengths and stored blocks are read wave-uniform (every lane
+// holds the same bit buffer and positions: no divergence, table reads are LDS broadcasts); the symbols of a block go
+// batch-wise through the lanes (BATCH, above) or, BATCH = false, one by one through the same uniform reader (round 4's
+// first kernel, kept for comparison: PC_BGZF_SERIAL=1).  (The workgroup IS the wave: __syncthreads() orders the LDS
+// traffic of its lanes and costs no cross-wave barrier.)
+template <bool BATCH>
+__global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restrict__ image, const Member *__restrict__ members, int first_member, int nmembers,
                                                           uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
     __shared__ __attribute__((aligned(16))) InflateShared sh;
-    __shared__ uint8_t s_lens[352];
-    __shared__ TableScratch s_ws;
-    const int m = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) union { HeaderShared hdr; BatchShared bat; } su;
+    uint8_t *const s_lens = su.hdr.lens;
+    TableScratch &s_ws = su.hdr.ws;
+    const int m = first_member + (int)blockIdx.x;   // (the members of one upload piece: pc_bam_open)
     if (m >= nmembers) return;
     const Member mb = members[m];   // (uniform: scalar loads)
     const int lane = threadIdx.x & 63;
@@ -343,61 +430,216 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             if (err) break;
         }
         // ---- the symbols of the block
-        for (;;) {
-            refill();
-            uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(uint32_t)bb & ((1u << kLitRoot) - 1u)]);
-            if (((e >> 8) & 3u) == 3u) {
-                const uint32_t sb = (e >> 4) & 15u;
-                e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(e >> 16) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))]);
-                bb >>= kLitRoot; nb -= kLitRoot;
-            }
-            const uint32_t nbits = e & 15u;
-            if (nbits == 0u) { err = kInfBadSymbol; break; }
-            bb >>= nbits; nb -= (int)nbits;
-            const uint32_t kind = (e >> 8) & 3u;
-            if (kind == 0u) {                         // literal
-                if (pos >= ulen) { err = kInfOverrun; break; }
-                if (lane == 0) sh.win[pos & (kWinBytes - 1)] = (uint8_t)(e >> 16);
-                pos += 1u;
-            } else if (kind == 2u) {                  // end of block
-                if (e >> 16) err = kInfBadSymbol;
-                break;
-            } else {                                  // length + distance
-                refill();
-                const uint32_t len = (e >> 16) + take((int)((e >> 4) & 15u));
-                refill();
-                uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(uint32_t)bb & ((1u << kDistRoot) - 1u)]);
-                if (((d >> 8) & 3u) == 3u) {
-                    const uint32_t sb = (d >> 4) & 15u;
-                    d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(d >> 16) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))]);
-                    bb >>= kDistRoot; nb -= kDistRoot;
-                }
-                const uint32_t dbits = d & 15u;
-                if (dbits == 0u || ((d >> 8) & 3u) != 0u) { err = kInfBadSymbol; break; }
-                bb >>= dbits; nb -= (int)dbits;
-                refill();
-                const uint32_t dist = (d >> 16) + take((int)((d >> 4) & 15u));
-                if (dist > pos) { err = kInfBadDistance; break; }
-                if (pos + len > ulen) { err = kInfOverrun; break; }
+        if constexpr (BATCH) {
+            BatchShared &bs = su.bat;
+            uint32_t p = in_pos * 8u - (uint32_t)nb;       // bit position of the next symbol in the stream
+            bool eob = false;
+            while (!eob) {
+                if (pos - flushed >= (uint32_t)kFlush) flush_to(pos & ~15u);
+                // what the batch may produce: everything unflushed plus a maximal match stays inside the LDS window, so that
+                // a match source is either whole in the window or whole in what has been flushed
+                const uint32_t cap = flushed + (uint32_t)kWinBytes - 258u;
+                const uint32_t limit = cap < ulen ? cap : ulen;
+                if ((p >> 3) > clen + 8u) { err = kInfInputOverrun; break; }
+                while (in_loaded < (p >> 3) + 84u) stage_half();
                 __syncthreads();
-                if (dist <= (uint32_t)kWinBytes - 258u) {
-                    // copy inside the LDS window: byte k comes from `dist` back; where the match overlaps itself the pattern repeats
-                    for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
-                        const uint32_t from = dist >= len ? pos - dist + k : pos - dist + (k % dist);
-                        sh.win[(pos + k) & (kWinBytes - 1)] = sh.win[from & (kWinBytes - 1)];
+                // ---- every bit offset's symbol: lane l looks at offsets 8 l .. 8 l + 7
+                {
+                    const uint32_t a = p + 8u * (uint32_t)lane;
+                    const uint32_t di = a >> 5, s0 = a & 31u;
+                    const uint32_t d0 = sh.in[di & (kInBytes / 4 - 1)], d1 = sh.in[(di + 1u) & (kInBytes / 4 - 1)];
+                    const uint32_t d2 = sh.in[(di + 2u) & (kInBytes / 4 - 1)], d3 = sh.in[(di + 3u) & (kInBytes / 4 - 1)];
+                    // the 96 bits from the lane's first offset on
+                    const uint32_t A = (uint32_t)((((unsigned long long)d1 << 32) | d0) >> s0), B = (uint32_t)((((unsigned long long)d2 << 32) | d1) >> s0);
+                    const uint32_t C = (uint32_t)((((unsigned long long)d3 << 32) | d2) >> s0);
+                    uint32_t sy[8];
+                    symbols_at8(sh.lit, sh.dist, A, B, C, sy);
+                    *(uint4 *)&bs.sym[8 * lane] = make_uint4(sy[0], sy[1], sy[2], sy[3]);
+                    *(uint4 *)&bs.sym[8 * lane + 4] = make_uint4(sy[4], sy[5], sy[6], sy[7]);
+                }
+                __syncthreads();
+                // ---- which offsets are symbol starts: the walk from offset 0 (it stops behind an end-of-block code or a
+                // symbol that is none -- what follows would be read with the wrong tables)
+                uint32_t walk, nsym;
+                {
+                    // a dozen instructions per symbol and one LDS read on the dependent chain; every lane stores the same
+                    // value to the same place (no mask to set up)
+                    uint32_t va = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)bs.sym;
+                    const uint32_t vn0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)bs.chain;
+                    uint32_t vn = vn0, vs, sv;
+                    asm volatile("s_mov_b32 %[walk], 0\n\t"
+                                 "1:\n\t"
+                                 "ds_read_b32 %[vs], %[va]\n\t"
+                                 "s_waitcnt lgkmcnt(0)\n\t"
+                                 "ds_write_b32 %[vn], %[vs]\n\t"
+                                 "v_add_u32 %[vn], 4, %[vn]\n\t"
+                                 "v_readfirstlane_b32 %[sv], %[vs]\n\t"
+                                 "s_bitcmp1_b32 %[sv], 7\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_and_b32 %[sv], %[sv], 63\n\t"
+                                 "s_add_u32 %[walk], %[walk], %[sv]\n\t"
+                                 "v_lshl_add_u32 %[va], %[sv], 2, %[va]\n\t"
+                                 "s_cmpk_lt_u32 %[walk], 512\n\t"
+                                 "s_cbranch_scc1 1b\n\t"
+                                 "2:\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : [walk] "=&s"(walk), [va] "+v"(va), [vn] "+v"(vn), [vs] "=&v"(vs), [sv] "=&s"(sv)
+                                 :
+                                 : "scc", "memory");
+                    nsym = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vn - vn0)) >> 2;
+                }
+                __syncthreads();
+                // ---- per symbol, 64 at a time
+                uint32_t done = 0;            // bytes produced by the chunks before
+                uint32_t p_next = walk;       // where the next batch starts (bits from p), unless a symbol stops this one
+                bool stopped = false;
+                uint32_t bits = 0;            // bits consumed by the chunks before
+                for (uint32_t c0 = 0; c0 < nsym && !stopped; c0 += 64) {
+                    const uint32_t idx = c0 + (uint32_t)lane;
+                    const bool have = idx < nsym;
+                    const uint32_t sv = have ? bs.chain[idx] : 0u;
+                    const uint32_t kind = (sv >> 6) & 3u;
+                    const uint32_t ol = !have ? 0u : (kind == kSymLit ? 1u : (kind == kSymMatch ? ((sv >> 8) & 255u) + 3u : 0u));
+                    // one prefix sum for both: bytes produced (bits 0-15; <= 64 x 258) and bits consumed (16-31; <= 64 x 48)
+                    const uint32_t mine = ol | (have ? (sv & 63u) << 16 : 0u);
+                    uint32_t incl2 = mine;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t y = (uint32_t)__shfl_up((int)incl2, d, 64);
+                        if (lane >= d) incl2 += y;
                     }
-                } else {
-                    // the source lies behind the LDS window: it has been flushed (whatever is older than the window minus a
-                    // flush piece has), so read it back from the member's output -- once the stores have landed, and past
-                    // this CU's L1, which may hold an older state of the line (dist > len here: no self-overlap)
-                    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
-                    for (uint32_t k = (uint32_t)lane; k < len; k += 64u)
-                        sh.win[(pos + k) & (kWinBytes - 1)] = __hip_atomic_load(dst + (pos - dist + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t incl = incl2 & 0xffffu;
+                    const uint32_t off = bits + ((incl2 - mine) >> 16);
+                    const uint32_t chunk_start = pos + done;
+                    const uint32_t q = chunk_start + incl - ol, end = chunk_start + incl;
+                    const unsigned long long stopm = __ballot(have && (kind >= kSymEob || end > limit));
+                    const int first = stopm ? __builtin_ctzll(stopm) : 64;
+                    const uint32_t chunk_bytes = first < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)(incl - ol), first) : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    const uint32_t chunk_end = chunk_start + chunk_bytes;
+                    const bool emit = have && lane < first;
+                    if (emit && kind == kSymLit) sh.win[q & (kWinBytes - 1)] = (uint8_t)(sv >> 8);
+                    // ---- matches: those whose source lies before the chunk are independent of one another (one per lane);
+                    // those that read what this chunk writes follow in stream order, each copied by the whole wave
+                    const bool ism = emit && kind == kSymMatch;
+                    const uint32_t len = ol, dd = (sv >> 16) + 1u;
+                    if (__ballot(ism && dd > q) != 0ull) { err = kInfBadDistance; break; }
+                    const uint32_t src = q - dd;
+                    const bool dep = ism && src + len > chunk_start;
+                    const bool far = ism && chunk_end - src > (uint32_t)kWinBytes;     // (whole in what has been flushed: see `cap`)
+                    if (__ballot(far) != 0ull) __builtin_amdgcn_s_waitcnt(0);         // the flush stores have landed
+                    __syncthreads();
+#ifndef PC_BGZF_EXP_NOINDEP
+                    if (ism && !dep) {
+                        if (!far) {
+                            for (uint32_t k = 0; k < len; k += 4u) {     // four reads in flight (a read past the match's end is dropped)
+                                const uint8_t b0 = sh.win[(src + k) & (kWinBytes - 1)], b1 = sh.win[(src + k + 1u) & (kWinBytes - 1)];
+                                const uint8_t b2 = sh.win[(src + k + 2u) & (kWinBytes - 1)], b3 = sh.win[(src + k + 3u) & (kWinBytes - 1)];
+                                sh.win[(q + k) & (kWinBytes - 1)] = b0;
+                                if (k + 1u < len) sh.win[(q + k + 1u) & (kWinBytes - 1)] = b1;
+                                if (k + 2u < len) sh.win[(q + k + 2u) & (kWinBytes - 1)] = b2;
+                                if (k + 3u < len) sh.win[(q + k + 3u) & (kWinBytes - 1)] = b3;
+                            }
+                        } else for (uint32_t k = 0; k < len; ++k) sh.win[(q + k) & (kWinBytes - 1)] = __hip_atomic_load(dst + (src + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past this CU's L1, which may hold an older state of the line)
+                    }
+#endif
+                    __syncthreads();
+#ifdef PC_BGZF_EXP_NODEP
+                    unsigned long long dm = 0ull;
+#else
+                    unsigned long long dm = __ballot(dep);
+#endif
+                    while (dm) {
+                        const int l = __builtin_ctzll(dm);
+                        dm &= dm - 1ull;
+                        const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)q, l), len1 = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+                        const uint32_t dd1 = (uint32_t)__builtin_amdgcn_readlane((int)dd, l);
+                        // byte k comes from `dd1` back; where the match overlaps itself the pattern repeats
+                        for (uint32_t k = (uint32_t)lane; k < len1; k += 64u) {
+                            const uint32_t from = dd1 >= len1 ? q1 - dd1 + k : q1 - dd1 + (k % dd1);
+                            sh.win[(q1 + k) & (kWinBytes - 1)] = sh.win[from & (kWinBytes - 1)];
+                        }
+                        __syncthreads();
+                    }
+                    done += chunk_bytes;
+                    bits += (uint32_t)__builtin_amdgcn_readlane((int)incl2, 63) >> 16;
+                    if (first < 64) {         // the symbol that ends the batch: end of block, none at all, or one that does not fit
+                        const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)kind, first), o1 = (uint32_t)__builtin_amdgcn_readlane((int)off, first);
+                        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)end, first), s1 = (uint32_t)__builtin_amdgcn_readlane((int)sv, first);
+                        stopped = true;
+                        if (k1 == kSymBad) err = kInfBadSymbol;
+                        else if (k1 == kSymEob) { eob = true; p_next = o1 + (s1 & 63u); }
+                        else if (e1 > ulen) err = kInfOverrun;
+                        else p_next = o1;
+                    }
                 }
-                __syncthreads();
-                pos += len;
+                if (err) break;
+                pos += done;
+                p += p_next;
             }
-            if (pos - flushed >= (uint32_t)kFlush + 272u) flush_to((flushed + kFlush) & ~15u);   // (unflushed < a piece + two matches: the window keeps the rest as history)
+            if (err) break;
+            // hand the stream position back to the uniform reader (block headers, stored blocks)
+            __syncthreads();
+            in_pos = (p >> 5) << 2;
+            bb = 0; nb = 0;
+            refill();
+            { const int r = (int)(p & 31u); bb >>= r; nb -= r; }
+        } else {
+            for (;;) {
+                refill();
+                uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(uint32_t)bb & ((1u << kLitRoot) - 1u)]);
+                if (((e >> 8) & 3u) == 3u) {
+                    const uint32_t sb = (e >> 4) & 15u;
+                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(e >> 16) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))]);
+                    bb >>= kLitRoot; nb -= kLitRoot;
+                }
+                const uint32_t nbits = e & 15u;
+                if (nbits == 0u) { err = kInfBadSymbol; break; }
+                bb >>= nbits; nb -= (int)nbits;
+                const uint32_t kind = (e >> 8) & 3u;
+                if (kind == 0u) {                         // literal
+                    if (pos >= ulen) { err = kInfOverrun; break; }
+                    if (lane == 0) sh.win[pos & (kWinBytes - 1)] = (uint8_t)(e >> 16);
+                    pos += 1u;
+                } else if (kind == 2u) {                  // end of block
+                    if (e >> 16) err = kInfBadSymbol;
+                    break;
+                } else {                                  // length + distance
+                    refill();
+                    const uint32_t len = (e >> 16) + take((int)((e >> 4) & 15u));
+                    refill();
+                    uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(uint32_t)bb & ((1u << kDistRoot) - 1u)]);
+                    if (((d >> 8) & 3u) == 3u) {
+                        const uint32_t sb = (d >> 4) & 15u;
+                        d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(d >> 16) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))]);
+                        bb >>= kDistRoot; nb -= kDistRoot;
+                    }
+                    const uint32_t dbits = d & 15u;
+                    if (dbits == 0u || ((d >> 8) & 3u) != 0u) { err = kInfBadSymbol; break; }
+                    bb >>= dbits; nb -= (int)dbits;
+                    refill();
+                    const uint32_t dist = (d >> 16) + take((int)((d >> 4) & 15u));
+                    if (dist > pos) { err = kInfBadDistance; break; }
+                    if (pos + len > ulen) { err = kInfOverrun; break; }
+                    __syncthreads();
+                    if (dist <= (uint32_t)kWinBytes - 258u) {
+                        // copy inside the LDS window: byte k comes from `dist` back; where the match overlaps itself the pattern repeats
+                        for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
+                            const uint32_t from = dist >= len ? pos - dist + k : pos - dist + (k % dist);
+                            sh.win[(pos + k) & (kWinBytes - 1)] = sh.win[from & (kWinBytes - 1)];
+                        }
+                    } else {
+                        // the source lies behind the LDS window: it has been flushed (whatever is older than the window minus a
+                        // flush piece has), so read it back from the member's output -- once the stores have landed, and past
+                        // this CU's L1, which may hold an older state of the line (dist > len here: no self-overlap)
+                        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
+                        for (uint32_t k = (uint32_t)lane; k < len; k += 64u)
+                            sh.win[(pos + k) & (kWinBytes - 1)] = __hip_atomic_load(dst + (pos - dist + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __syncthreads();
+                    pos += len;
+                }
+                if (pos - flushed >= (uint32_t)kFlush + 272u) flush_to((flushed + kFlush) & ~15u);   // (unflushed < a piece + two matches: the window keeps the rest as history)
+            }
         }
     }
     if (err == kInfOk && pos != ulen) err = kInfShort;

@@ -2784,6 +2784,19 @@ int pc_bam_close(pc_bam *b) {
     return PC_OK;
 }
 
+namespace {
+struct BamClock {   // PC_BAM_TIMING=1: wall-clock laps of the host side of the GPU decoder
+    bool on = getenv("PC_BAM_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bam] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+} // namespace
+
 int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out) {
     using namespace pcbam;
     if (!e || !out || size < 0 || (size > 0 && !image_)) return fail(PC_ERR_ARG, "pc_bam_open: bad arguments");
@@ -2792,6 +2805,7 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
     const std::string path = name ? name : "<memory>";
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = e->stream;
+    BamClock clk;
     // ---- member boundaries (host: a walk over the gzip headers; 18 + bytes per 64 KiB of payload)
     std::vector<Member> members;
     uint64_t total_u = 0;
@@ -2823,6 +2837,7 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
         off += clen;
     }
     pc_bam *b = new pc_bam();
+    clk.lap("member walk");
     b->e = e; b->name = path; b->members = (int64_t)members.size(); b->inflated_bytes = (int64_t)total_u; b->compressed_bytes = size;
     struct Guard { pc_bam *b; ~Guard() { if (b) pc_bam_close(b); } } guard{b};
     const int nm = (int)members.size();
@@ -2838,24 +2853,61 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
     if (rc == PC_OK) rc = d_status.reserve((size_t)std::max(nm, 1));
     if (rc == PC_OK) rc = d_crc.reserve(5 * 256);
     if (rc != PC_OK) return rc;
+    clk.lap("allocations (image, stream)");
     HIP_TRY(hipEventRecord(ev[0], st));
-    if (size) HIP_TRY(hipMemcpyAsync(d_image.p, image, (size_t)size, hipMemcpyHostToDevice, st));
     if (nm) HIP_TRY(hipMemcpyAsync(d_members.p, members.data(), (size_t)nm * sizeof(Member), hipMemcpyHostToDevice, st));
     const CrcTables &ct = crc_tables();
     HIP_TRY(hipMemcpyAsync(d_crc.p, ct.tab, sizeof(ct.tab), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_crc.p + 256, ct.shift, sizeof(ct.shift), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_stream.p + total_u, 0, 64, st));
     HIP_TRY(hipEventRecord(ev[1], st));
-    // ---- inflate + CRC: one wave per member
+    // ---- upload + inflate, piece by piece: the file image crosses PCIe on the side stream in pieces of ~128 MiB of
+    // whole members while the members of the pieces before are inflated on the main one (one wave per member).  (Every
+    // launch ends in a tail of half-empty CUs -- a member takes ~4 ms and ~3 000 are in flight -- so the pieces are
+    // large: 20 M aligner-like records, 578 MB: one piece 87 ms, 48 MiB pieces 67 ms, 128 MiB 58 ms, 256 MiB 61 ms.)
     std::vector<uint32_t> status((size_t)nm, 0u);
     if (nm) {
-        hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)nm), dim3(kInflWG), 0, st, d_image.p, d_members.p, nm, d_stream.p, d_status.p);
+        const bool serial_symbols = getenv("PC_BGZF_SERIAL") != nullptr && atoi(getenv("PC_BGZF_SERIAL")) != 0;   // (round 4's first kernel, for comparison)
+        const int64_t piece_bytes = getenv("PC_BAM_PIECE") ? std::max<int64_t>(1, atoll(getenv("PC_BAM_PIECE"))) : ((int64_t)128 << 20);
+        hipStream_t up = e->side_stream ? e->side_stream : st;
+        std::vector<hipEvent_t> landed;
+        struct EvList { std::vector<hipEvent_t> &v; ~EvList() { for (auto x : v) (void)hipEventDestroy(x); } } landed_guard{landed};
+        if (up != st) {   // the side stream starts behind what the main one has queued so far (the buffers' previous users)
+            hipEvent_t x;
+            HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+            landed.push_back(x);
+            HIP_TRY(hipEventRecord(x, st));
+            HIP_TRY(hipStreamWaitEvent(up, x, 0));
+        }
+        int64_t byte0 = 0;          // the image is uploaded from here on (gzip headers and trailers ride along)
+        for (int m0 = 0; m0 < nm;) {
+            int m1 = m0;
+            int64_t byte1 = byte0;
+            while (m1 < nm && (byte1 - byte0 < piece_bytes || m1 == m0)) {
+                byte1 = (int64_t)(members[(size_t)m1].coff + members[(size_t)m1].clen);
+                ++m1;
+            }
+            if (m1 == nm) byte1 = size;
+            HIP_TRY(hipMemcpyAsync(d_image.p + byte0, image + byte0, (size_t)(byte1 - byte0), hipMemcpyHostToDevice, up));
+            if (up != st) {
+                hipEvent_t x;
+                HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+                landed.push_back(x);
+                HIP_TRY(hipEventRecord(x, up));
+                HIP_TRY(hipStreamWaitEvent(st, x, 0));
+            }
+            if (serial_symbols) hipLaunchKernelGGL(k_bgzf_inflate<false>, dim3((unsigned)(m1 - m0)), dim3(kInflWG), 0, st, d_image.p, d_members.p, m0, m1, d_stream.p, d_status.p);
+            else hipLaunchKernelGGL(k_bgzf_inflate<true>, dim3((unsigned)(m1 - m0)), dim3(kInflWG), 0, st, d_image.p, d_members.p, m0, m1, d_stream.p, d_status.p);
+            byte0 = byte1;
+            m0 = m1;
+        }
         hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)nm), dim3(64), 0, st, d_stream.p, d_members.p, nm, d_crc.p, d_crc.p + 256, d_status.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(status.data(), d_status.p, (size_t)nm * 4, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipStreamSynchronize(st));
+    clk.lap("upload + inflate + crc (sync)");
     for (int m = 0; m < nm; ++m)
         if (status[(size_t)m]) {
             if (getenv("PC_BAM_DEBUG")) fprintf(stderr, "[bam] member %d of %d (%u compressed -> %u bytes at %llu): inflate status %u\n", m, nm,
@@ -2863,6 +2915,7 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
             return fail(PC_ERR_ARG, "%s%s", status[(size_t)m] == (uint32_t)kInfCrc ? "BGZF CRC mismatch in " : "BGZF inflate failed in ", path.c_str());
         }
     d_image.release();
+    clk.lap("status check + image release");
     // ---- BAM header (host, from the head of the inflated stream)
     uint64_t first_record = 0;
     uint32_t n_ref = 0;
@@ -2949,6 +3002,7 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
         nrec = (int64_t)rec_base[(size_t)nm];
     } else if (total_u != first_record) truncated = true;
     HIP_TRY(hipEventRecord(ev[3], st));
+    clk.lap("header + record chain");
     b->total = nrec;
     if (nrec >= (int64_t)0x7fffffff) return fail(PC_ERR_ARG, "pc_bam_open: more than 2^31-2 records per file are not supported");
     // ---- fields, order checks, columns
@@ -3068,6 +3122,7 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
     } else if (truncated) return fail(PC_ERR_ARG, "truncated BAM record");
     HIP_TRY(hipEventRecord(ev[4], st));
     HIP_TRY(hipStreamSynchronize(st));
+    clk.lap("fields + scans + columns");
     b->n = n_staged; b->nrun = n_runs;
     for (int k = 0; k < 4; ++k) b->ms[k] = ms_between(ev[k], ev[k + 1]);
     guard.b = nullptr;
@@ -3098,6 +3153,7 @@ int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *
     if (!b->wide_idx.empty() && (!wide_idx || !wide_alen || !wide_nblk)) return fail(PC_ERR_ARG, "pc_bam_read: NULL wide array");
     HIP_TRY(hipSetDevice(b->e->device));
     hipStream_t st = b->e->stream;
+    BamClock rclk;
     const size_t n = (size_t)b->n, m = (size_t)b->nrun;
     if (n) {
         HIP_TRY(hipMemcpyAsync(tid, b->tid.p, n * 4, hipMemcpyDeviceToHost, st));
@@ -3111,6 +3167,7 @@ int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *
         HIP_TRY(hipMemcpyAsync(blk_len, b->blk_len.p, m * 4, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    rclk.lap("columns to the host");
     for (size_t k = 0; k < b->wide_idx.size(); ++k) { wide_idx[k] = b->wide_idx[k]; wide_alen[k] = b->wide_alen[k]; wide_nblk[k] = b->wide_nblk[k]; }
     return PC_OK;
 }

@@ -3,7 +3,7 @@
 usage: python scripts/kernel_resources.py [substring]"""
 import os, re, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = os.path.join(ROOT, "plastid_amd", "libplastid_counts.so")
+lib = os.environ.get("PLASTID_AMD_LIB") or os.path.join(ROOT, "plastid_amd", "libplastid_counts.so")
 work = tempfile.mkdtemp(prefix="kobj_")
 shutil.copy(lib, os.path.join(work, "l.so"))
 subprocess.call(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", "l.so"], cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

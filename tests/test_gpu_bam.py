@@ -133,6 +133,49 @@ def test_realistic_records_and_the_counts_that_follow(eng, tmp_path):
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
 
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_symbol_decoders_and_upload_pieces_agree(eng, tmp_path, monkeypatch, level):
+    """The batch decoder of the block symbols (every bit offset looked up by the lanes, then a walk), the wave-uniform
+    one (PC_BGZF_SERIAL=1) and an upload cut into pieces of a few members each (PC_BAM_PIECE) give the same columns
+    on records as an aligner writes them."""
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.01)      # (spliced reads: multi-run records)
+    path = str(tmp_path / "real.bam")
+    bam_writer.write_bam_realistic(path, reads, threads=4, level=level)
+    ref = read_bam(path)
+    same(read_bam_gpu(path, eng), ref)
+    monkeypatch.setenv("PC_BGZF_SERIAL", "1")
+    same(read_bam_gpu(path, eng), ref)
+    monkeypatch.setenv("PC_BAM_PIECE", "70000")
+    same(read_bam_gpu(path, eng), ref)
+    monkeypatch.delenv("PC_BGZF_SERIAL")
+    same(read_bam_gpu(path, eng), ref)
+
+
+def test_long_matches_and_long_distances(eng, tmp_path):
+    """Streams the record tests do not make: runs of one byte (matches of 258 that overlap themselves), a period just
+    short of the 32 KiB window (sources far behind the part of the window kept in LDS), incompressible bytes, and
+    blocks that end in the middle of a batch of bit offsets -- as the payload of unplaced reads' names."""
+    rng = np.random.default_rng(11)
+    period = rng.integers(0, 256, 32000, dtype=np.uint8).tobytes()
+    blobs = [b"\x00" * 70000, b"ab" * 40000, period * 3, rng.integers(0, 256, 50000, dtype=np.uint8).tobytes(),
+             (b"ACGT" * 50 + rng.integers(65, 70, 37, dtype=np.uint8).tobytes()) * 600]
+    refs, lens = ["chrA"], [100000]
+    head = bam_stream(refs, lens, [])
+    for level in (1, 6, 9):
+        for block in (65000, 9000):
+            data = head
+            for i, blob in enumerate(blobs):
+                # a placed record whose (long) read name carries the blob: l_read_name is one byte, so the blob rides in the sequence / quality fields
+                l_seq = len(blob) // 2
+                seq = blob[:(l_seq + 1) // 2]
+                qual = blob[(l_seq + 1) // 2:(l_seq + 1) // 2 + l_seq]
+                body = struct.pack("<iiBBHHHIiii", 0, 100 + i, 2, 30, 4680, 1, 0, l_seq, -1, -1, 0) + b"r\x00" + struct.pack("<I", (l_seq << 4) | 0) + seq + qual
+                data += struct.pack("<I", len(body)) + body
+            path = str(tmp_path / ("m%d_%d.bam" % (level, block)))
+            write_members(path, data, block, level=level)
+            same(read_bam_gpu(path, eng), read_bam(path))
+
+
 def test_errors_are_the_host_decoders(eng, tmp_path):
     """Unsorted input, a damaged payload (CRC), a damaged DEFLATE stream, truncation, a foreign file: the same exception
     class and message as the host decoder raises."""
