@@ -159,6 +159,12 @@ int pc_plan_destroy(pc_plan *p);
 int pc_plan_coordinates(pc_engine *e, pc_plan *p, int64_t *host_out, int64_t out_elems);
 int64_t pc_plan_positions(pc_plan *p); /* distinct (strand-mode, position) pairs counted */
 int64_t pc_plan_tiles(pc_plan *p);
+/* The plan's tables as pc_plan_create built them (tests compare the GPU builder of large annotations with the host
+ * builder, table by table).  which: 0 tiles (32-byte records), 1 island pieces (24), 2 output pieces (40), 3 per-segment
+ * gather records (64), 4 scalars as int64[12] = {window size, strand-mode mask, modes per window (max), histogram
+ * positions, covered output elements, has summed slices, output needs zeroing, tiles, pieces, output pieces, built on
+ * the GPU, segments}.  Copies min(cap_bytes, table bytes) to `buf`; *bytes = table bytes. */
+int pc_plan_table(pc_plan *p, int which, void *buf, int64_t cap_bytes, int64_t *bytes);
 
 /* ---- counting: map_fn(list(reads), roi) for every segment of the plan
  * (genome_array.py:823), then normalisation/strand layout.  pc_count launches

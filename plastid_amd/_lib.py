@@ -51,6 +51,7 @@ SIGNATURES = {
     "pc_plan_positions": (_i64, [_vp]),
     "pc_plan_coordinates": (_int, [_vp, _vp, _vp, _i64]),
     "pc_plan_tiles": (_i64, [_vp]),
+    "pc_plan_table": (_int, [_vp, _int, _vp, _i64, ctypes.POINTER(_i64)]),
     "pc_count": (_int, [_vp, _vp, _int]),
     "pc_sync": (_int, [_vp]),
     "pc_read_counts": (_int, [_vp, _vp, _vp, _i64]),

@@ -17,6 +17,7 @@
 //                                  k_gather_split, or the three center kernels + k_gather
 //   pc_rle / pc_total / pc_mapped_reads / pc_warn_flags   consumers of a finished count
 #include "pc_kernels.hip.h"
+#include "plan_kernels.hip.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -299,6 +300,7 @@ struct Knobs {
     int no_small = 0;          // PC_NO_SMALL: no single-wave class for sparse windows
     int small_rows = 0;        // PC_SMALL_ROWS: 1 = multi-row plans (stratified rule) may use the single-wave class too
     int no_single = 0;         // PC_NO_SINGLE: one-window plans go through the work lists like any other (tests compare the two paths)
+    int plan_build = 0;        // PC_PLAN_BUILD=host|gpu: where pc_plan_create builds the tables (default: on the GPU from 65 536 segments)
     int small_g = 512;         // PC_SMALL_G: queried span a single-wave window may have
     int64_t small_n = 8192;    // PC_SMALL_N: records a single-wave window may scan (C4: 1.25 ms at 2048, 1.22 at 8192, 1.21 at 32768)
     int debug_work = 0;        // PC_DEBUG_WORK: print the queued work items per class (stderr; synchronises)
@@ -316,6 +318,7 @@ struct Knobs {
         no_small = getenv("PC_NO_SMALL") ? 1 : 0;
         if (const char *env = getenv("PC_SMALL_ROWS")) small_rows = atoi(env);
         no_single = getenv("PC_NO_SINGLE") ? 1 : 0;
+        if (const char *env = getenv("PC_PLAN_BUILD")) plan_build = std::strcmp(env, "host") == 0 ? 1 : (std::strcmp(env, "gpu") == 0 ? 2 : 0);
         if (const char *env = getenv("PC_SMALL_G")) small_g = std::max(64, atoi(env) / 64 * 64);
         if (const char *env = getenv("PC_SMALL_N")) small_n = std::max(64, atoi(env));
         debug_work = getenv("PC_DEBUG_WORK") ? 1 : 0;
@@ -330,6 +333,7 @@ struct Knobs {
 
 struct pc_engine {
     DevPool pool;   // first member: outlives every buffer of the engine
+    DevBuf<uint8_t> plan_scratch[3];   // working arrays of the GPU plan builder (per segment, per piece, per output piece): grown, never shrunk
     Knobs knobs;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -408,6 +412,11 @@ struct pc_plan {
     PodVec<Tile> tiles;
     PodVec<Piece> pieces;
     PodVec<OutPiece> opieces;
+    size_t n_tiles = 0, n_pieces = 0, n_opieces = 0;   // table sizes (a GPU-built plan keeps its tables in HBM only)
+    bool gpu_built = false;      // pc_plan_create built the tables on the GPU (large annotations): the host vectors are fetched when a host pass needs them
+    bool host_tables = true, host_inputs = true;
+    DevBuf<uint8_t> d_inputs;    // the caller's segment arrays as uploaded (GPU-built plans)
+    DevBuf<GatherSeg> d_gsegs_own;
     bool has_sums = false;       // some slices are summed (out_step 0): the output is an accumulator
     bool out_needs_zero = false; // some queried positions lie outside every tile (unknown contig, clipped)
     bool hist_clean = false;     // compact histogram known to be all zero (point-rule invariant)
@@ -500,6 +509,7 @@ struct pc_plan {
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
         d_cranges.pool = pl; d_crec.pool = pl; d_crows.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
         d_work.pool = pl; d_work_small.pool = pl; d_chain.pool = pl; d_chain_small.pool = pl;
+        d_inputs.pool = pl; d_gsegs_own.pool = pl;
     }
 };
 
@@ -524,11 +534,289 @@ int refresh_file_views(pc_engine *e) {
     return PC_OK;
 }
 
+struct StageClock {
+    bool on = getenv("PC_STAGE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[stage] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
+// ---- plans built on the GPU (plan_kernels.hip.h): the host copies of their tables / inputs, when a host pass needs them
+int fetch_host_tables(pc_plan *p) {
+    if (p->host_tables) return PC_OK;
+    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    p->tiles.resize(p->n_tiles);
+    p->pieces.resize(p->n_pieces);
+    p->gsegs.resize((size_t)p->nseg);
+    if (p->n_tiles) HIP_TRY(hipMemcpy(p->tiles.data(), p->d_tiles.p, p->n_tiles * sizeof(Tile), hipMemcpyDeviceToHost));
+    if (p->n_pieces) HIP_TRY(hipMemcpy(p->pieces.data(), p->d_pieces.p, p->n_pieces * sizeof(Piece), hipMemcpyDeviceToHost));
+    if (p->nseg) HIP_TRY(hipMemcpy(p->gsegs.data(), p->d_gsegs_own.p, (size_t)p->nseg * sizeof(GatherSeg), hipMemcpyDeviceToHost));
+    p->host_tables = true;
+    return PC_OK;
+}
+
+struct PlanInputLayout {   // the caller's seven segment arrays in one block
+    size_t at_tid, at_start, at_end, at_strand, at_off, at_step, at_stride, bytes;
+    explicit PlanInputLayout(size_t n) {
+        size_t b = 0;
+        auto place = [&b](size_t k) { const size_t at = b; b += (k + 255) & ~(size_t)255; return at; };
+        at_tid = place(n * 4); at_start = place(n * 8); at_end = place(n * 8); at_strand = place(n);
+        at_off = place(n * 8); at_step = place(n); at_stride = place(n * 8);
+        bytes = b;
+    }
+};
+
+int fetch_host_inputs(pc_plan *p) {
+    if (p->host_inputs) return PC_OK;
+    const size_t n = (size_t)p->nseg;
+    const PlanInputLayout L(n);
+    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    p->h_tid.resize(n); p->h_start.resize(n); p->h_end.resize(n); p->h_strand.resize(n);
+    if (n) {
+        HIP_TRY(hipMemcpy(p->h_tid.data(), p->d_inputs.p + L.at_tid, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(p->h_start.data(), p->d_inputs.p + L.at_start, n * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(p->h_end.data(), p->d_inputs.p + L.at_end, n * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(p->h_strand.data(), p->d_inputs.p + L.at_strand, n, hipMemcpyDeviceToHost));
+    }
+    p->host_inputs = true;
+    return PC_OK;
+}
+
+struct Bump {   // carves the working arrays of one stage out of one block
+    uint8_t *base = nullptr;
+    size_t used = 0;
+    template <typename T> T *take(size_t n) {
+        used = (used + 255) & ~(size_t)255;
+        T *q = base ? (T *)(base + used) : nullptr;
+        used += n * sizeof(T);
+        return q;
+    }
+};
+
+inline int bits_for(uint64_t v) { int b = 0; while (b < 64 && (v >> b)) ++b; return std::max(b, 1); }
+
+// The tables of a plan, built on the GPU.  `p` arrives with nseg / out_elems / rows set; on PC_OK it has its tables in
+// HBM (d_tables and the views into it), the sizes and flags the host builder sets, and no host copies.
+int plan_build_gpu(pc_engine *e, pc_plan *p, int64_t nseg, const int32_t *tid, const int64_t *start, const int64_t *end, const uint8_t *strand,
+                   const int64_t *out_off, const int8_t *out_step, const int64_t *row_stride, int64_t out_elems, int rows) {
+    using namespace pcplan;
+    hipStream_t st = e->stream;
+    const int ntid = e->ntid;
+    const size_t n = (size_t)nseg;
+    StageClock pclk;
+    // ---- the caller's arrays
+    const PlanInputLayout L(n);
+    int rc = p->d_inputs.reserve(std::max<size_t>(L.bytes, 256));
+    if (rc == PC_OK) rc = p->d_gsegs_own.reserve(std::max<size_t>(n, 1));
+    if (rc != PC_OK) return rc;
+    uint8_t *di = p->d_inputs.p;
+    HIP_TRY(hipMemcpyAsync(di + L.at_tid, tid, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(di + L.at_start, start, n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(di + L.at_end, end, n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(di + L.at_strand, strand, n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(di + L.at_off, out_off, n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(di + L.at_step, out_step, n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(di + L.at_stride, row_stride, n * 8, hipMemcpyHostToDevice, st));
+    SegIn in;
+    in.tid = (const int32_t *)(di + L.at_tid); in.start = (const int64_t *)(di + L.at_start); in.end = (const int64_t *)(di + L.at_end);
+    in.strand = di + L.at_strand; in.out_off = (const int64_t *)(di + L.at_off); in.out_step = (const int8_t *)(di + L.at_step);
+    in.row_stride = (const int64_t *)(di + L.at_stride);
+    pclk.lap("plan(gpu): upload");
+    // ---- stage A: per segment
+    typedef unsigned long long u64;
+    size_t cub_a = 0;
+    {
+        size_t b = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const u64 *)nullptr, (u64 *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 64, st); cub_a = std::max(cub_a, b);
+        (void)hipcub::DeviceScan::InclusiveScan(nullptr, b, (const u64 *)nullptr, (u64 *)nullptr, GroupMax(), (int)n, st); cub_a = std::max(cub_a, b);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int64_t *)nullptr, (int64_t *)nullptr, (int)n + 1, st); cub_a = std::max(cub_a, b);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n + 1, st); cub_a = std::max(cub_a, b);
+    }
+    Bump A;
+    u64 *keys = nullptr, *keys2 = nullptr, *ge = nullptr, *pm = nullptr, *island_keys = nullptr;
+    uint32_t *ends = nullptr, *ends2 = nullptr, *flags = nullptr, *before = nullptr, *npieces = nullptr, *piece_at = nullptr, *nout = nullptr, *out_at = nullptr;
+    Island *islands = nullptr;
+    int64_t *lens = nullptr, *offs = nullptr;
+    Misc *misc = nullptr;
+    uint8_t *cub_tmp = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {   // (first pass: sizes)
+        A.used = 0;
+        misc = A.take<Misc>(1);
+        keys = A.take<u64>(n); keys2 = A.take<u64>(n); ends = A.take<uint32_t>(n); ends2 = A.take<uint32_t>(n);
+        ge = A.take<u64>(n); pm = A.take<u64>(n); flags = A.take<uint32_t>(n + 1); before = A.take<uint32_t>(n + 1);
+        islands = A.take<Island>(n); island_keys = A.take<u64>(n); lens = A.take<int64_t>(n + 1); offs = A.take<int64_t>(n + 1);
+        npieces = A.take<uint32_t>(n + 1); piece_at = A.take<uint32_t>(n + 1); nout = A.take<uint32_t>(n + 1); out_at = A.take<uint32_t>(n + 1);
+        cub_tmp = A.take<uint8_t>(cub_a + 256);
+        if (pass == 0) {
+            rc = e->plan_scratch[0].reserve(A.used + 256);
+            if (rc != PC_OK) return rc;
+            A.base = e->plan_scratch[0].p;
+        }
+    }
+    const unsigned gseg = (unsigned)((n + 255) / 256);
+    Misc h;
+    std::memset(&h, 0, sizeof(h));
+    h.first_bad = ~0ull;
+    h.max_slots = 1;
+    HIP_TRY(hipMemcpyAsync(misc, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_plan_segs, dim3(gseg), dim3(256), 0, st, in, nseg, ntid, rows, out_elems, p->d_gsegs_own.p, keys, ends, misc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h, misc, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h.first_bad != ~0ull) {   // the defect of the lowest segment index, as a serial pass reports it
+        const long long b = (long long)(h.first_bad >> 8);
+        const int kind = (int)(h.first_bad & 0xffu);
+        if (kind == 1) return fail(PC_ERR_ARG, "segment %lld: end < start", b);
+        if (kind == 2) return fail(PC_ERR_ARG, "segment %lld: out_step must be +1, -1 or 0 (sum)", b);
+        const int64_t len = end[b] - start[b], first = out_off[b], last = out_off[b] + (int64_t)out_step[b] * (len - 1);
+        const int64_t lo = std::min(first, last), hi = std::max(first, last) + (int64_t)(rows - 1) * row_stride[b];
+        return fail(PC_ERR_ARG, "segment %lld: output slice [%lld,%lld] outside buffer of %lld elements", b, (long long)lo, (long long)hi, (long long)out_elems);
+    }
+    p->modes = h.modes;
+    p->covered = (int64_t)h.covered;
+    p->has_sums = h.has_sums != 0;
+    int nmodes = 0;
+    for (int m = 0; m < kModes; ++m) nmodes += (h.modes >> m) & 1;
+    if (nmodes == 0) nmodes = 1;
+    {   // window size: as the host builder
+        int64_t g = (24 * 1024) / (4LL * nmodes * rows);
+        int G = 256;
+        int gmax = 4096;
+        while (G * 2 <= g && G * 2 <= gmax) G *= 2;
+        if (e->knobs.tile_g && e->knobs.tile_g <= 2 * g) G = e->knobs.tile_g;
+        if ((int64_t)4 * nmodes * rows * G > 150 * 1024) return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows);
+        p->G = G;
+    }
+    const int G = p->G;
+    const int split_modes = rows > 1 ? 1 : 0;
+    const size_t n_iv = (size_t)h.n_iv;
+    pclk.lap("plan(gpu): segments");
+    if (n_iv) {
+        const unsigned giv = (unsigned)((n_iv + 255) / 256);
+        size_t b = cub_a;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub_tmp, b, keys, keys2, ends, ends2, (int)n, 0, std::min(64, 33 + bits_for((uint64_t)ntid)), st));
+        hipLaunchKernelGGL(k_group_ends, dim3(giv), dim3(256), 0, st, keys2, ends2, misc, ge);
+        b = cub_a;
+        HIP_TRY(hipcub::DeviceScan::InclusiveScan(cub_tmp, b, ge, pm, GroupMax(), (int)n_iv, st));
+        hipLaunchKernelGGL(k_island_flags, dim3(giv), dim3(256), 0, st, keys2, pm, misc, flags, (int64_t)n_iv);
+        b = cub_a;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, flags, before, (int)n_iv, st));
+        hipLaunchKernelGGL(k_island_fill, dim3(giv), dim3(256), 0, st, keys2, pm, flags, before, misc, islands, island_keys);
+        hipLaunchKernelGGL(k_island_lens, dim3(giv), dim3(256), 0, st, misc, islands, lens, npieces, G, (int64_t)n_iv);
+        b = cub_a;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, lens, offs, (int)n_iv, st));
+        b = cub_a;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, npieces, piece_at, (int)n_iv, st));
+        hipLaunchKernelGGL(k_island_offsets, dim3(giv), dim3(256), 0, st, misc, islands, offs, lens, piece_at, npieces);
+    }
+    if (n) {
+        hipLaunchKernelGGL(k_seg_island, dim3(gseg), dim3(256), 0, st, in, nseg, p->d_gsegs_own.p, misc, islands, island_keys, nout, G);
+        size_t b = cub_a;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, nout, out_at, (int)n, st));
+        hipLaunchKernelGGL(k_out_total, dim3(1), dim3(64), 0, st, misc, out_at, nout, nseg);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h, misc, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    p->npos = (int64_t)h.npos;
+    p->out_needs_zero = h.needs_zero != 0;
+    const size_t n_pieces = h.n_pieces, n_op = h.n_opieces;
+    if (n_pieces >= 0x7fffffffu || n_op >= 0x7fffffffu) return fail(PC_ERR_ARG, "pc_plan_create: too many window pieces");
+    pclk.lap("plan(gpu): islands");
+    // ---- stage B: per piece; stage C: per output piece
+    size_t cub_b = 0, cub_c = 0;
+    {
+        size_t b = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const u64 *)nullptr, (u64 *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_pieces, 0, 64, st); cub_b = std::max(cub_b, b);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_pieces + 1, st); cub_b = std::max(cub_b, b);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_op, 0, 32, st); cub_c = std::max(cub_c, b);
+    }
+    Bump B, C;
+    u64 *pkeys = nullptr, *pkeys2 = nullptr, *tile_keys = nullptr;
+    uint32_t *pidx = nullptr, *pidx2 = nullptr, *new_tile = nullptr, *tbefore = nullptr, *otile = nullptr, *otile2 = nullptr, *oidx = nullptr, *oidx2 = nullptr;
+    Piece *praw = nullptr, *psorted = nullptr;
+    Tile *tiles_tmp = nullptr;
+    OutPiece *oraw = nullptr;
+    uint8_t *cub_tmp_b = nullptr, *cub_tmp_c = nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+        B.used = 0; C.used = 0;
+        pkeys = B.take<u64>(n_pieces); pkeys2 = B.take<u64>(n_pieces); pidx = B.take<uint32_t>(n_pieces); pidx2 = B.take<uint32_t>(n_pieces);
+        praw = B.take<Piece>(n_pieces); psorted = B.take<Piece>(n_pieces); new_tile = B.take<uint32_t>(n_pieces + 1); tbefore = B.take<uint32_t>(n_pieces + 1);
+        tiles_tmp = B.take<Tile>(n_pieces); tile_keys = B.take<u64>(n_pieces); cub_tmp_b = B.take<uint8_t>(cub_b + 256);
+        oraw = C.take<OutPiece>(n_op); otile = C.take<uint32_t>(n_op); otile2 = C.take<uint32_t>(n_op); oidx = C.take<uint32_t>(n_op); oidx2 = C.take<uint32_t>(n_op);
+        cub_tmp_c = C.take<uint8_t>(cub_c + 256);
+        if (pass == 0) {
+            rc = e->plan_scratch[1].reserve(B.used + 256);
+            if (rc == PC_OK) rc = e->plan_scratch[2].reserve(C.used + 256);
+            if (rc != PC_OK) return rc;
+            B.base = e->plan_scratch[1].p; C.base = e->plan_scratch[2].p;
+        }
+    }
+    if (n_pieces) {
+        const unsigned gp = (unsigned)((n_pieces + 255) / 256);
+        hipLaunchKernelGGL(k_pieces_raw, dim3(gp), dim3(256), 0, st, misc, islands, piece_at, G, pkeys, pidx, praw);
+        size_t b = cub_b;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub_tmp_b, b, pkeys, pkeys2, pidx, pidx2, (int)n_pieces, 0, std::min(64, 37 + bits_for((uint64_t)ntid)), st));
+        hipLaunchKernelGGL(k_pieces_sorted, dim3(gp), dim3(256), 0, st, misc, pkeys2, pidx2, praw, psorted, new_tile, split_modes, (int64_t)n_pieces);
+        b = cub_b;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp_b, b, new_tile, tbefore, (int)n_pieces, st));
+        hipLaunchKernelGGL(k_tile_fill, dim3(gp), dim3(256), 0, st, misc, pkeys2, psorted, new_tile, tbefore, G, split_modes, tiles_tmp, tile_keys);
+    }
+    if (n_op) {
+        hipLaunchKernelGGL(k_out_raw, dim3(gseg), dim3(256), 0, st, in, nseg, p->d_gsegs_own.p, misc, tile_keys, out_at, nout, G, split_modes, oraw, otile, oidx);
+        size_t b = cub_c;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub_tmp_c, b, otile, otile2, oidx, oidx2, (int)n_op, 0, std::min(32, bits_for((uint64_t)n_pieces)), st));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h, misc, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t n_tiles = h.n_tiles;
+    p->max_slots = (int)h.max_slots;
+    p->n_tiles = n_tiles; p->n_pieces = n_pieces; p->n_opieces = n_op;
+    pclk.lap("plan(gpu): pieces + tiles + output pieces");
+    // ---- the plan's block, laid out as the host builder lays it out
+    size_t bytes = 0;
+    auto place = [&bytes](size_t k) { const size_t at = bytes; bytes += (k + 255) & ~(size_t)255; return at; };
+    const size_t at_tiles = place(n_tiles * sizeof(Tile)), at_pieces = place(n_pieces * sizeof(Piece)), at_opieces = place(n_op * sizeof(OutPiece)),
+                 at_cchunks = place(0), at_gsegs = place(0), at_gchunks = place(0),
+                 at_items = place((n_tiles + 1) * sizeof(uint32_t)), at_wcounters = place(64), at_total = place(64);
+    const size_t hist_full = (size_t)p->npos * (size_t)p->rows * sizeof(double);
+    const bool hist_here = hist_full > 0 && hist_full <= 64 * 1024;
+    const size_t at_hist = hist_here ? place(hist_full) : 0;
+    rc = p->d_tables.reserve(bytes);
+    if (rc != PC_OK) return rc;
+    uint8_t *d = p->d_tables.p;
+    if (n_tiles) HIP_TRY(hipMemcpyAsync(d + at_tiles, tiles_tmp, n_tiles * sizeof(Tile), hipMemcpyDeviceToDevice, st));
+    if (n_pieces) HIP_TRY(hipMemcpyAsync(d + at_pieces, psorted, n_pieces * sizeof(Piece), hipMemcpyDeviceToDevice, st));
+    if (n_op) hipLaunchKernelGGL(k_out_sorted, dim3((unsigned)((n_op + 255) / 256)), dim3(256), 0, st, misc, otile2, oidx2, oraw, (OutPiece *)(d + at_opieces), (Tile *)(d + at_tiles));
+    HIP_TRY(hipMemsetAsync(d + at_items, 0, bytes - at_items, st));
+    HIP_TRY(hipGetLastError());
+    p->d_tiles.p = (Tile *)(d + at_tiles); p->d_pieces.p = (Piece *)(d + at_pieces);
+    p->d_opieces.p = (OutPiece *)(d + at_opieces); p->d_cchunks.p = (CenterChunk *)(d + at_cchunks);
+    p->d_gsegs.p = (GatherSeg *)(d + at_gsegs); p->d_gchunks.p = (GatherChunk *)(d + at_gchunks);
+    p->d_tile_items.p = (uint32_t *)(d + at_items); p->d_total.p = d + at_total;
+    p->d_wcounters.p = (uint32_t *)(d + at_wcounters);
+    p->tile_items_zero = true;
+    p->wcounters_zero = true;
+    if (hist_here) { p->d_hist.p = d + at_hist; p->hist_kind = 0; p->hist_clean = true; }
+    p->lazy_center = true;
+    p->gpu_built = true;
+    p->host_tables = false;
+    p->host_inputs = false;
+    pclk.lap("plan(gpu): tables");
+    return PC_OK;
+}
+
 // The center-only tables of a large plan (see pc_plan_create): built on first use.
 // The tables of a large plan that only the center rule (64-position chunks) or only the coordinate export (the
 // per-segment gather list) reads are built and uploaded when first asked for, each on its own.
 int ensure_center_tables(pc_engine *e, pc_plan *p) {
     if (!p->lazy_center || p->center_ready) return PC_OK;
+    { const int frc = fetch_host_tables(p); if (frc != PC_OK) return frc; }
     const int PT = std::min(usable_cpus(), 32);
     const size_t ntl = p->tiles.size();
     // chunks per tile, in tile / piece order (what the eager path produces piece by piece)
@@ -564,6 +852,7 @@ int ensure_center_tables(pc_engine *e, pc_plan *p) {
 
 int ensure_gather_tables(pc_engine *e, pc_plan *p) {
     if (!p->lazy_center || p->gather_ready) return PC_OK;
+    { const int frc = fetch_host_tables(p); if (frc != PC_OK) return frc; }
     const int PT = std::min(usable_cpus(), 32);
     std::vector<size_t> gat((size_t)p->nseg + 1, 0);
     for (int64_t s = 0; s < p->nseg; ++s) gat[(size_t)s + 1] = gat[(size_t)s] + (size_t)((p->gsegs[(size_t)s].len + kGatherChunk - 1) / kGatherChunk);
@@ -724,16 +1013,6 @@ int64_t pc_num_records(pc_engine *e, int file) {
 
 namespace {
 // PC_STAGE_TIMING=1: print where pc_add_alignment_file spends its time (stderr)
-struct StageClock {
-    bool on = getenv("PC_STAGE_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void lap(const char *what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[stage] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-        t = now;
-    }
-};
 } // namespace
 
 int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
@@ -1447,6 +1726,23 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     HIP_TRY(hipSetDevice(e->device));
     const int ntid = e->ntid;
 
+    // large annotations: every pass of the builder as a kernel, a radix sort or a scan (plan_kernels.hip.h); the host
+    // builder below is what small plans -- and PC_PLAN_BUILD=host -- take, and what the GPU tables are tested against
+    if (nseg > 0 && (int64_t)ntid < ((int64_t)1 << pcplan::kTidBits) && (e->knobs.plan_build == 2 || (e->knobs.plan_build == 0 && nseg >= (1 << 16)))) {
+        pc_plan *gp = new pc_plan(e);
+        gp->nseg = nseg;
+        gp->out_elems = out_elems;
+        gp->rows = rows;
+        const int grc = plan_build_gpu(e, gp, nseg, tid, start, end, strand, out_off, out_step, row_stride, out_elems, rows);
+        if (grc != PC_OK) {
+            (void)hipStreamSynchronize(e->stream);
+            delete gp;
+            return grc;
+        }
+        *out = gp;
+        return PC_OK;
+    }
+
     StageClock pclk;
     struct Iv { int32_t tid; int32_t mode; int64_t s, e; };
     std::vector<Iv> ivs;
@@ -1869,6 +2165,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
         else e->pinned_busy = true;
     }
     pclk.lap("plan: upload");
+    p->n_tiles = p->tiles.size(); p->n_pieces = p->pieces.size(); p->n_opieces = p->opieces.size();
     if (rc != PC_OK) {
         (void)hipStreamSynchronize(e->stream);   // copies out of the plan's vectors may be in flight
         delete p;
@@ -1889,7 +2186,35 @@ int pc_plan_destroy(pc_plan *p) {
 }
 
 int64_t pc_plan_positions(pc_plan *p) { return p ? p->npos : -1; }
-int64_t pc_plan_tiles(pc_plan *p) { return p ? (int64_t)p->tiles.size() : -1; }
+int64_t pc_plan_tiles(pc_plan *p) { return p ? (int64_t)p->n_tiles : -1; }
+
+int pc_plan_table(pc_plan *p, int which, void *buf, int64_t cap_bytes, int64_t *bytes) {
+    if (!p || !bytes || which < 0 || which > 4 || cap_bytes < 0 || (cap_bytes > 0 && !buf)) return fail(PC_ERR_ARG, "pc_plan_table: bad arguments");
+    HIP_TRY(hipSetDevice(p->e->device));
+    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    if (which == 4) {
+        const int64_t v[12] = {p->G, (int64_t)p->modes, p->max_slots, p->npos, p->covered, p->has_sums ? 1 : 0, p->out_needs_zero ? 1 : 0,
+                               (int64_t)p->n_tiles, (int64_t)p->n_pieces, (int64_t)p->n_opieces, p->gpu_built ? 1 : 0, p->nseg};
+        *bytes = (int64_t)sizeof(v);
+        std::memcpy(buf, v, (size_t)std::min<int64_t>(cap_bytes, *bytes));
+        return PC_OK;
+    }
+    const void *src = nullptr;
+    size_t n = 0;
+    bool on_host = false;
+    if (which == 0) { src = p->d_tiles.p; n = p->n_tiles * sizeof(Tile); }
+    else if (which == 1) { src = p->d_pieces.p; n = p->n_pieces * sizeof(Piece); }
+    else if (which == 2) { src = p->d_opieces.p; n = p->n_opieces * sizeof(OutPiece); }
+    else if (p->gpu_built) { src = p->d_gsegs_own.p; n = (size_t)p->nseg * sizeof(GatherSeg); }
+    else { src = p->gsegs.data(); n = p->gsegs.size() * sizeof(GatherSeg); on_host = true; }
+    *bytes = (int64_t)n;
+    const size_t take = (size_t)std::min<int64_t>(cap_bytes, (int64_t)n);
+    if (take) {
+        if (on_host) std::memcpy(buf, src, take);
+        else HIP_TRY(hipMemcpy(buf, src, take, hipMemcpyDeviceToHost));
+    }
+    return PC_OK;
+}
 
 int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     if (!e || !p || p->e != e) return fail(PC_ERR_ARG, "pc_count: bad engine/plan");
@@ -1930,7 +2255,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     const int64_t R = e->knobs.work_r;                             // records per work item
     const int64_t pile = e->knobs.pile ? e->knobs.pile : 12 * R;   // a 128-nt sub-window with more records than this is merged through the histogram
     const MapParams mp = e->params();
-    const int ntiles = (int)p->tiles.size();
+    const int ntiles = (int)p->n_tiles;
     hipStream_t st = e->stream;
     int64_t nrec = 0, nextra = 0;
     for (auto *f : e->files) { nrec += f->n; nextra += f->nrun; }
@@ -2598,6 +2923,7 @@ int pc_warn_details(pc_engine *e, pc_plan *p, uint8_t *flags, int32_t *last_len)
         pmax_f[i] = pf;
         pmax_r[i] = pr;
     }
+    { const int frc = fetch_host_inputs(p); if (frc != PC_OK) return frc; }
     for (int64_t s = 0; s < p->nseg; ++s) {
         const int32_t t = p->h_tid[(size_t)s];
         if (t < 0 || t >= e->ntid) continue;
@@ -2667,6 +2993,7 @@ int pc_mapped_reads_batch(pc_engine *e, pc_plan *p, int64_t *offsets, int64_t *t
     p->mr_total = 0;
     if (npair == 0) return PC_OK;
     if (npair >= (int64_t)0x7fffffff) return fail(PC_ERR_ARG, "pc_mapped_reads_batch: too many (segment, file) pairs");
+    { const int frc = fetch_host_inputs(p); if (frc != PC_OK) return frc; }
     std::vector<BatchSeg> segs((size_t)nseg);
     for (int64_t s = 0; s < nseg; ++s) {
         BatchSeg &g = segs[(size_t)s];

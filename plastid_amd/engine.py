@@ -216,6 +216,22 @@ class Plan(object):
     def tiles(self):
         return int(self._lib.pc_plan_tiles(self._h))
 
+    def tables(self):
+        """The plan's tables as ``pc_plan_create`` built them (tests compare the GPU builder with the host builder):
+        dict of raw ``uint8`` arrays ``tiles`` (32 bytes per record), ``pieces`` (24), ``opieces`` (40), ``gsegs`` (64)
+        and ``scalars`` (int64[12]: window size, strand-mode mask, most modes in a window, histogram positions, covered
+        output elements, has summed slices, output needs zeroing, tiles, pieces, output pieces, built on the GPU,
+        segments)."""
+        import ctypes
+        out = {}
+        for which, name in enumerate(("tiles", "pieces", "opieces", "gsegs", "scalars")):
+            n = ctypes.c_int64(0)
+            check(self._lib.pc_plan_table(self._h, which, None, 0, ctypes.byref(n)))
+            buf = np.zeros(max(int(n.value), 1), np.uint8)
+            check(self._lib.pc_plan_table(self._h, which, _ptr(buf), int(n.value), ctypes.byref(n)))
+            out[name] = buf[:int(n.value)].view(np.int64) if name == "scalars" else buf[:int(n.value)]
+        return out
+
     def coordinates(self):
         """Genomic coordinate of every output element of the plan's layout (``-1``: not covered)."""
         out = np.empty(self.out_elems, np.int64)
