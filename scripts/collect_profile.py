@@ -66,17 +66,19 @@ if kw:
     cal["f_write"] = probe_bytes / (means[(kw, "WRITE_SIZE")] * 1024.0)
     cal["probe_write_WRITE_SIZE_KB"] = means[(kw, "WRITE_SIZE")]
 dominant = "k_center" if config == "C3" else "k_hist_point"
-entry = {"config": config, "round": 3, "dominant_kernel": dominant, "calibration": cal,
+entry = {"config": config, "round": int(os.environ.get("PC_PROFILE_ROUND", "4")), "dominant_kernel": dominant, "calibration": cal,
          "source": "%s/pmc_fetch_per_kernel.csv, pmc_write_per_kernel.csv (separate rocprofv3 --pmc passes, scripts/profile.sh)" % dst}
 if line is not None:
-    entry["n_records"] = line["config"]["records_per_gpu"]
+    entry["n_records"] = line["config"].get("records_per_gpu", line["config"].get("records"))
     # the kernel sources these counters were measured on: bench.py reports the traffic only while they are unchanged
     entry["kernel_source_sha16"] = line["config"].get("kernel_source_sha16")
-    entry["algorithmic_bytes_per_launch"] = line["roofline"]["algorithmic_bytes_per_launch"]
+    roof = line["roofline"]   # (the short stdout line of round 4 carries the rate and the launch time, not the byte count)
+    entry["algorithmic_bytes_per_launch"] = roof.get("algorithmic_bytes_per_launch", int(round(roof["achieved"] * 1e9 * roof["avg_launch_ms"] * 1e-3)))
 fetch = write = 0.0
 per_kernel = {}
 for (k, c), v in means.items():
-    if dominant in k and "weigh" not in k and "order" not in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+    # (k_center<true, ...> is the diagnostic launch that counts the replay steps for bench.py's issue bound: not a step)
+    if dominant in k and "weigh" not in k and "order" not in k and "k_center<true" not in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
         per_kernel.setdefault(k, {})[c] = v
         if c == "FETCH_SIZE":
             fetch += v
