@@ -60,6 +60,7 @@ def read_bam_gpu(path, engine, timing=None):
         # (MAP_POPULATE: the page-cache pages are mapped in one go instead of one soft fault per 4 KiB during the walk
         # over the member headers and the upload)
         mm = mmap.mmap(fh.fileno(), 0, flags=mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0), prot=mmap.PROT_READ) if size else None
+        t_map = time.perf_counter()
         try:
             h = ctypes.c_void_p()
             if size:
@@ -68,11 +69,14 @@ def read_bam_gpu(path, engine, timing=None):
                 del view
             else:
                 rc = L.pc_bam_open(engine._h, None, 0, os.fsencode(path), ctypes.byref(h))
+            t_call = time.perf_counter()
         finally:
             if mm is not None:
                 mm.close()
     clib.check(rc)
     t_open = time.perf_counter()
+    if timing is not None:
+        timing.update(map_ms=(t_map - t_0) * 1e3, open_call_ms=(t_call - t_map) * 1e3, unmap_ms=(t_open - t_call) * 1e3)
     try:
         counts = np.zeros(8, np.int64)
         clib.check(L.pc_bam_counts(h, counts.ctypes.data_as(ctypes.c_void_p)))
@@ -94,7 +98,10 @@ def read_bam_gpu(path, engine, timing=None):
                           members=int(counts[5]), inflated_bytes=int(counts[6]), compressed_bytes=size, chain_restarts=int(counts[7]),
                           records=int(counts[3]))
     finally:
+        t_c = time.perf_counter()
         L.pc_bam_close(h)
+        if timing is not None:
+            timing["close_ms"] = (time.perf_counter() - t_c) * 1e3
     wide = dict(wide_idx=wi, wide_alen=wa, wide_nblk=wn) if nw else {}
     out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
                            validate=False, **wide)   # the device decoder has checked every invariant validate() checks

@@ -28,6 +28,8 @@
 
 namespace pcplan {
 
+using pc::CenterChunk;
+using pc::GatherChunk;
 using pc::GatherSeg;
 using pc::OutPiece;
 using pc::Piece;
@@ -348,6 +350,47 @@ __global__ __launch_bounds__(256) void k_out_sorted(const Misc *__restrict__ mis
     const uint32_t t = tile_of[i];
     if (i == 0 || tile_of[i - 1] != t) tiles[t].op_begin = i;
     if (i + 1 == n || tile_of[i + 1] != t) tiles[t].op_end = i + 1u;
+}
+
+// ---- the tables only the center rule / the coordinate export read, from a GPU-built plan's tables in HBM
+// (ensure_center_tables / ensure_gather_tables): 64-position chunks in tile / piece order; (segment, chunk) pairs
+__global__ __launch_bounds__(256) void k_cchunk_count(const Tile *__restrict__ tiles, const Piece *__restrict__ pieces, uint32_t ntiles, uint32_t *__restrict__ n) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    uint32_t k = 0;
+    for (uint32_t i = tiles[t].piece_begin; i < tiles[t].piece_end; ++i) k += (uint32_t)(pieces[i].len + pc::kWave - 1) / pc::kWave;
+    n[t] = k;
+}
+
+__global__ __launch_bounds__(256) void k_cchunk_fill(const Tile *__restrict__ tiles, const Piece *__restrict__ pieces, uint32_t ntiles, const uint32_t *__restrict__ at,
+                                                     CenterChunk *__restrict__ chunks) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    const Tile tl = tiles[t];
+    uint32_t k = at[t];
+    for (uint32_t i = tl.piece_begin; i < tl.piece_end; ++i) {
+        const Piece pc_ = pieces[i];
+        for (int32_t a = 0; a < pc_.len; a += pc::kWave) {
+            CenterChunk c;
+            c.hist_off = pc_.hist_off + a; c.tid = tl.tid; c.start = pc_.start + a;
+            c.len = pc_.len - a < pc::kWave ? pc_.len - a : pc::kWave; c.mode = pc_.mode;
+            c.op_begin = tl.op_begin; c.op_end = tl.op_end;
+            chunks[k++] = c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gchunk_count(const GatherSeg *__restrict__ gsegs, int64_t nseg, uint32_t *__restrict__ n) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    n[s] = (uint32_t)((gsegs[s].len + pc::kGatherChunk - 1) / pc::kGatherChunk);
+}
+
+__global__ __launch_bounds__(256) void k_gchunk_fill(int64_t nseg, const uint32_t *__restrict__ n, const uint32_t *__restrict__ at, GatherChunk *__restrict__ chunks) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    const uint32_t base = at[s];
+    for (uint32_t c = 0; c < n[s]; ++c) { chunks[base + c].seg = (uint32_t)s; chunks[base + c].chunk = c; }
 }
 
 } // namespace pcplan

@@ -300,7 +300,7 @@ struct Knobs {
     int no_small = 0;          // PC_NO_SMALL: no single-wave class for sparse windows
     int small_rows = 0;        // PC_SMALL_ROWS: 1 = multi-row plans (stratified rule) may use the single-wave class too
     int no_single = 0;         // PC_NO_SINGLE: one-window plans go through the work lists like any other (tests compare the two paths)
-    int plan_build = 0;        // PC_PLAN_BUILD=host|gpu: where pc_plan_create builds the tables (default: on the GPU from 65 536 segments)
+    int plan_build = 0;        // PC_PLAN_BUILD=host|gpu: where pc_plan_create builds the tables (default: on the GPU from 8 192 segments)
     int small_g = 512;         // PC_SMALL_G: queried span a single-wave window may have
     int64_t small_n = 8192;    // PC_SMALL_N: records a single-wave window may scan (C4: 1.25 ms at 2048, 1.22 at 8192, 1.21 at 32768)
     int debug_work = 0;        // PC_DEBUG_WORK: print the queued work items per class (stderr; synchronises)
@@ -413,6 +413,7 @@ struct pc_plan {
     PodVec<Piece> pieces;
     PodVec<OutPiece> opieces;
     size_t n_tiles = 0, n_pieces = 0, n_opieces = 0;   // table sizes (a GPU-built plan keeps its tables in HBM only)
+    size_t n_cchunks = 0, n_gchunks = 0;               // ... of the center chunk list and of the gather list, once built
     bool gpu_built = false;      // pc_plan_create built the tables on the GPU (large annotations): the host vectors are fetched when a host pass needs them
     bool host_tables = true, host_inputs = true;
     DevBuf<uint8_t> d_inputs;    // the caller's segment arrays as uploaded (GPU-built plans)
@@ -816,7 +817,45 @@ int plan_build_gpu(pc_engine *e, pc_plan *p, int64_t nseg, const int32_t *tid, c
 // per-segment gather list) reads are built and uploaded when first asked for, each on its own.
 int ensure_center_tables(pc_engine *e, pc_plan *p) {
     if (!p->lazy_center || p->center_ready) return PC_OK;
-    { const int frc = fetch_host_tables(p); if (frc != PC_OK) return frc; }
+    if (p->gpu_built) {   // from the tables in HBM: chunks per tile, exclusive sum, fill
+        using namespace pcplan;
+        hipStream_t st = e->stream;
+        const size_t ntl = p->n_tiles;
+        size_t tb = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)ntl + 1, st);
+        Bump A;
+        uint32_t *cnt = nullptr, *at = nullptr;
+        uint8_t *tmp = nullptr;
+        for (int pass = 0; pass < 2; ++pass) {
+            A.used = 0;
+            cnt = A.take<uint32_t>(ntl + 1); at = A.take<uint32_t>(ntl + 1); tmp = A.take<uint8_t>(tb + 256);
+            if (pass == 0) {
+                const int rc0 = e->plan_scratch[0].reserve(A.used + 256);
+                if (rc0 != PC_OK) return rc0;
+                A.base = e->plan_scratch[0].p;
+            }
+        }
+        uint32_t total = 0;
+        if (ntl) {
+            const unsigned g = (unsigned)((ntl + 255) / 256);
+            HIP_TRY(hipMemsetAsync(cnt + ntl, 0, 4, st));
+            hipLaunchKernelGGL(k_cchunk_count, dim3(g), dim3(256), 0, st, p->d_tiles.p, p->d_pieces.p, (uint32_t)ntl, cnt);
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, at, (int)ntl + 1, st));
+            HIP_TRY(hipMemcpyAsync(&total, at + ntl, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const int rc1 = p->d_tables2.reserve(std::max<size_t>((size_t)total * sizeof(CenterChunk), 256));
+            if (rc1 != PC_OK) return rc1;
+            if (total) hipLaunchKernelGGL(k_cchunk_fill, dim3(g), dim3(256), 0, st, p->d_tiles.p, p->d_pieces.p, (uint32_t)ntl, at, (CenterChunk *)p->d_tables2.p);
+            HIP_TRY(hipGetLastError());
+        } else {
+            const int rc1 = p->d_tables2.reserve(256);
+            if (rc1 != PC_OK) return rc1;
+        }
+        p->d_cchunks.p = (CenterChunk *)p->d_tables2.p;
+        p->n_cchunks = total;
+        p->center_ready = true;
+        return PC_OK;
+    }
     const int PT = std::min(usable_cpus(), 32);
     const size_t ntl = p->tiles.size();
     // chunks per tile, in tile / piece order (what the eager path produces piece by piece)
@@ -846,13 +885,49 @@ int ensure_center_tables(pc_engine *e, pc_plan *p) {
     if (rc != PC_OK) return rc;
     if (!p->cchunks.empty()) HIP_TRY(hipMemcpyAsync(p->d_tables2.p, p->cchunks.data(), p->cchunks.size() * sizeof(CenterChunk), hipMemcpyHostToDevice, e->stream));
     p->d_cchunks.p = (CenterChunk *)p->d_tables2.p;
+    p->n_cchunks = p->cchunks.size();
     p->center_ready = true;
     return PC_OK;
 }
 
 int ensure_gather_tables(pc_engine *e, pc_plan *p) {
     if (!p->lazy_center || p->gather_ready) return PC_OK;
-    { const int frc = fetch_host_tables(p); if (frc != PC_OK) return frc; }
+    if (p->gpu_built) {   // the per-segment records are in HBM already: (segment, chunk) pairs by count, exclusive sum, fill
+        using namespace pcplan;
+        hipStream_t st = e->stream;
+        const size_t n = (size_t)p->nseg;
+        size_t tb = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n + 1, st);
+        Bump A;
+        uint32_t *cnt = nullptr, *at = nullptr;
+        uint8_t *tmp = nullptr;
+        for (int pass = 0; pass < 2; ++pass) {
+            A.used = 0;
+            cnt = A.take<uint32_t>(n + 1); at = A.take<uint32_t>(n + 1); tmp = A.take<uint8_t>(tb + 256);
+            if (pass == 0) {
+                const int rc0 = e->plan_scratch[0].reserve(A.used + 256);
+                if (rc0 != PC_OK) return rc0;
+                A.base = e->plan_scratch[0].p;
+            }
+        }
+        uint32_t total = 0;
+        const unsigned g = (unsigned)((n + 255) / 256);
+        HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, st));
+        if (n) hipLaunchKernelGGL(k_gchunk_count, dim3(g), dim3(256), 0, st, p->d_gsegs_own.p, p->nseg, cnt);
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, at, (int)n + 1, st));
+        HIP_TRY(hipMemcpyAsync(&total, at + n, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int rc1 = p->d_tables3.reserve(std::max<size_t>((size_t)total * sizeof(GatherChunk), 256));
+        if (rc1 != PC_OK) return rc1;
+        if (total) hipLaunchKernelGGL(k_gchunk_fill, dim3(g), dim3(256), 0, st, p->nseg, cnt, at, (GatherChunk *)p->d_tables3.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));   // (the scratch block may be reused by the next builder call)
+        p->d_gsegs.p = p->d_gsegs_own.p;
+        p->d_gchunks.p = (GatherChunk *)p->d_tables3.p;
+        p->n_gchunks = total;
+        p->gather_ready = true;
+        return PC_OK;
+    }
     const int PT = std::min(usable_cpus(), 32);
     std::vector<size_t> gat((size_t)p->nseg + 1, 0);
     for (int64_t s = 0; s < p->nseg; ++s) gat[(size_t)s + 1] = gat[(size_t)s] + (size_t)((p->gsegs[(size_t)s].len + kGatherChunk - 1) / kGatherChunk);
@@ -870,6 +945,7 @@ int ensure_gather_tables(pc_engine *e, pc_plan *p) {
     if (!p->gsegs.empty()) HIP_TRY(hipMemcpyAsync(d + at_s, p->gsegs.data(), p->gsegs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, e->stream));
     if (!p->gchunks.empty()) HIP_TRY(hipMemcpyAsync(d + at_g, p->gchunks.data(), p->gchunks.size() * sizeof(GatherChunk), hipMemcpyHostToDevice, e->stream));
     p->d_gsegs.p = (GatherSeg *)(d + at_s); p->d_gchunks.p = (GatherChunk *)(d + at_g);
+    p->n_gchunks = p->gchunks.size();
     p->gather_ready = true;
     return PC_OK;
 }
@@ -1728,7 +1804,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
 
     // large annotations: every pass of the builder as a kernel, a radix sort or a scan (plan_kernels.hip.h); the host
     // builder below is what small plans -- and PC_PLAN_BUILD=host -- take, and what the GPU tables are tested against
-    if (nseg > 0 && (int64_t)ntid < ((int64_t)1 << pcplan::kTidBits) && (e->knobs.plan_build == 2 || (e->knobs.plan_build == 0 && nseg >= (1 << 16)))) {
+    if (nseg > 0 && (int64_t)ntid < ((int64_t)1 << pcplan::kTidBits) && (e->knobs.plan_build == 2 || (e->knobs.plan_build == 0 && nseg >= (1 << 13)))) {
         pc_plan *gp = new pc_plan(e);
         gp->nseg = nseg;
         gp->out_elems = out_elems;
@@ -2166,6 +2242,7 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     }
     pclk.lap("plan: upload");
     p->n_tiles = p->tiles.size(); p->n_pieces = p->pieces.size(); p->n_opieces = p->opieces.size();
+    p->n_cchunks = p->cchunks.size(); p->n_gchunks = p->gchunks.size();
     if (rc != PC_OK) {
         (void)hipStreamSynchronize(e->stream);   // copies out of the plan's vectors may be in flight
         delete p;
@@ -2499,7 +2576,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         // (k_center writes every queried position of the tiles straight into the output layout; the compact histogram
         // is not touched)
         if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
-        const int64_t nchunks = (int64_t)p->cchunks.size();
+        const int64_t nchunks = (int64_t)p->n_cchunks;
         if (nchunks > 0) {
             if (kCenterCap * nchunks >= (int64_t)1 << kSubShift) return fail(PC_ERR_ARG, "pc_count: too many positions for the center rule");
             rc = p->d_corder.reserve((size_t)(kCenterCap * nchunks));   // dispatch list: heavy entries front, light back
@@ -2696,7 +2773,7 @@ int pc_plan_coordinates(pc_engine *e, pc_plan *p, int64_t *host_out, int64_t out
     if (rc != PC_OK) return rc;
     hipStream_t st = e->stream;
     HIP_TRY(hipMemsetAsync(d.p, 0xff, (size_t)out_elems * 8, st));   // -1: elements no segment covers
-    const unsigned grid = (unsigned)p->gchunks.size();
+    const unsigned grid = (unsigned)p->n_gchunks;
     if (grid) hipLaunchKernelGGL(k_coordinates, dim3(grid), dim3(kWG), 0, st, p->d_gsegs.p, p->d_gchunks.p, p->rows, d.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_out, d.p, (size_t)out_elems * 8, hipMemcpyDeviceToHost, st));
