@@ -2000,8 +2000,11 @@ __device__ __forceinline__ void center_chunk(const CenterCtx &cx, const uint32_t
 // 1.6; walking equal-work stretches of the chunk list -- the replay steps of every chunk are known exactly from the
 // pre-pass -- with the next descriptor requested ahead, round 4, 1.27 - 1.32 ms against 1.13: the per-chunk fixed cost is
 // instructions, not dispatch, and the stretches finish unevenly.)
+// (Compiled for eight waves per SIMD: left alone the kernel takes 102 SGPRs -- seven waves; with the target it fits 78
+// SGPRs and 63 VGPRs without scratch.  A/B on one box, three rounds of 40 steps: 1.34 / 1.32 / 1.42 ms without,
+// 1.07 / 1.25 / 1.30 with.  Round 4's earlier amdgpu_num_sgpr(80) spilled; (96) gains less.)
 template <bool DBG, bool GENERAL>
-__global__ __launch_bounds__(kCenterWG) void k_center(CenterCtx cx) {
+__global__ __launch_bounds__(kCenterWG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_center(CenterCtx cx) {
     const uint32_t cap = kCenterCap * (uint32_t)cx.nchunks;
     const uint32_t n_heavy = cx.counters[0];
     const uint32_t bidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (uint32_t)kCenterWG + threadIdx.x) >> 6));

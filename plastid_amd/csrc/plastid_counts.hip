@@ -414,8 +414,8 @@ struct pc_plan {
     PodVec<OutPiece> opieces;
     size_t n_tiles = 0, n_pieces = 0, n_opieces = 0;   // table sizes (a GPU-built plan keeps its tables in HBM only)
     size_t n_cchunks = 0, n_gchunks = 0;               // ... of the center chunk list and of the gather list, once built
-    bool gpu_built = false;      // pc_plan_create built the tables on the GPU (large annotations): the host vectors are fetched when a host pass needs them
-    bool host_tables = true, host_inputs = true;
+    bool gpu_built = false;      // pc_plan_create built the tables on the GPU (large annotations): they live in HBM only
+    bool host_inputs = true;
     DevBuf<uint8_t> d_inputs;    // the caller's segment arrays as uploaded (GPU-built plans)
     DevBuf<GatherSeg> d_gsegs_own;
     bool has_sums = false;       // some slices are summed (out_step 0): the output is an accumulator
@@ -546,20 +546,7 @@ struct StageClock {
     }
 };
 
-// ---- plans built on the GPU (plan_kernels.hip.h): the host copies of their tables / inputs, when a host pass needs them
-int fetch_host_tables(pc_plan *p) {
-    if (p->host_tables) return PC_OK;
-    HIP_TRY(hipStreamSynchronize(p->e->stream));
-    p->tiles.resize(p->n_tiles);
-    p->pieces.resize(p->n_pieces);
-    p->gsegs.resize((size_t)p->nseg);
-    if (p->n_tiles) HIP_TRY(hipMemcpy(p->tiles.data(), p->d_tiles.p, p->n_tiles * sizeof(Tile), hipMemcpyDeviceToHost));
-    if (p->n_pieces) HIP_TRY(hipMemcpy(p->pieces.data(), p->d_pieces.p, p->n_pieces * sizeof(Piece), hipMemcpyDeviceToHost));
-    if (p->nseg) HIP_TRY(hipMemcpy(p->gsegs.data(), p->d_gsegs_own.p, (size_t)p->nseg * sizeof(GatherSeg), hipMemcpyDeviceToHost));
-    p->host_tables = true;
-    return PC_OK;
-}
-
+// ---- plans built on the GPU (plan_kernels.hip.h): the host copies of the caller's segment arrays, when a host pass needs them
 struct PlanInputLayout {   // the caller's seven segment arrays in one block
     size_t at_tid, at_start, at_end, at_strand, at_off, at_step, at_stride, bytes;
     explicit PlanInputLayout(size_t n) {
@@ -806,7 +793,6 @@ int plan_build_gpu(pc_engine *e, pc_plan *p, int64_t nseg, const int32_t *tid, c
     if (hist_here) { p->d_hist.p = d + at_hist; p->hist_kind = 0; p->hist_clean = true; }
     p->lazy_center = true;
     p->gpu_built = true;
-    p->host_tables = false;
     p->host_inputs = false;
     pclk.lap("plan(gpu): tables");
     return PC_OK;
