@@ -9,18 +9,21 @@
 // tags}  (kent/src/htslib/sam.c bam_read1).  Host inflate (zlib / libdeflate on the 16 CPUs a GPU box grants) runs at
 // ~11 GB/s: 5.4e7 reads/s from a realistic file, against 6e11 at kernel scope.  Here the file image goes to HBM as it
 // is and
-//   k_bgzf_inflate    ONE WAVE PER MEMBER inflates it: Huffman tables and the last 4 KiB of output in LDS, the symbol
-//                     decode wave-uniform, match copies and the flushes to HBM spread over the lanes; a match that reaches
-//                     further back than the LDS window reads its source from the member's output in HBM.  (The decode is a
-//                     chain of dependent LDS reads: what sets the rate is how many members a CU has in flight, i.e. LDS
-//                     per wave: the whole 32 KiB window = 41 KiB, 3 waves per CU, 11 GB/s on records as an aligner writes them; 8 KiB: 24 GB/s; 4 KiB: 27; 2 KiB: 30.)
+//   k_bgzf_inflate    ONE WAVE PER MEMBER inflates it: Huffman tables and the last 2 KiB of output in LDS; block headers
+//                     and code lengths read wave-uniform, the symbols of a block a batch of 512 bit offsets at a time
+//                     (every lane looks the symbol up at 8 offsets, a walk finds the real starts, positions / literals /
+//                     matches per symbol in parallel: see "the symbols of a block" below); a match that reaches further
+//                     back than the LDS window reads its source from the member's output in HBM.  43 GB/s on records
+//                     as an aligner writes them (the wave-uniform symbol decoder it replaced, PC_BGZF_SERIAL=1: ~27);
+//   k_bgzf_crc        CRC-32 of every member's payload, 64 slices per member combined by a shift operator;
 //   k_bam_chain       one wave per member finds where the first BAM record of the member starts (a guess: the first
 //                     offset from which a few records in a row look like records) and walks the chain of length prefixes
 //                     to the first record start of the NEXT member, noting every start; the host only confirms that
 //                     the guesses chain (and restarts the few members whose guess did not);
 //   k_bam_fields      one thread per record: fixed-offset fields, CIGAR -> aligned runs (sam.h:64-104), the checks of
 //                     the host decoder (bam_stager.cpp decode_span_cols) as an error code;
-//   k_bam_runs        the runs of the multi-run records at their scanned offsets.
+//   k_bam_order / k_bam_scan_inputs / k_bam_columns   sort order and unplaced reads, the inputs of the two exclusive sums
+//                     (staged index, run offset), and the packed columns with the runs of the multi-run records.
 // The columns that come out (tid, pos, alen, flags, nblk, runs) are what pc_add_alignment_file takes.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -528,7 +531,6 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                     const bool far = ism && chunk_end - src > (uint32_t)kWinBytes;     // (whole in what has been flushed: see `cap`)
                     if (__ballot(far) != 0ull) __builtin_amdgcn_s_waitcnt(0);         // the flush stores have landed
                     __syncthreads();
-#ifndef PC_BGZF_EXP_NOINDEP
                     if (ism && !dep) {
                         if (!far) {
                             for (uint32_t k = 0; k < len; k += 4u) {     // four reads in flight (a read past the match's end is dropped)
@@ -541,13 +543,8 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                             }
                         } else for (uint32_t k = 0; k < len; ++k) sh.win[(q + k) & (kWinBytes - 1)] = __hip_atomic_load(dst + (src + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past this CU's L1, which may hold an older state of the line)
                     }
-#endif
                     __syncthreads();
-#ifdef PC_BGZF_EXP_NODEP
-                    unsigned long long dm = 0ull;
-#else
                     unsigned long long dm = __ballot(dep);
-#endif
                     while (dm) {
                         const int l = __builtin_ctzll(dm);
                         dm &= dm - 1ull;
