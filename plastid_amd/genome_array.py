@@ -22,6 +22,7 @@ the HIP kernels honour it.  Only the five built-in factories and
 there (no CPU fallback).
 """
 import itertools
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -34,14 +35,26 @@ from .packing import FLAG_EXCLUDED, PackedAlignments
 from .roitools import GenomicSegment, SegmentChain
 
 
-def _open_alignment_source(src, regions=None):
-    """Filenames are read with the package's own BAM reader; objects are used as
+#: files of at least this many bytes are decoded on the GPU when ``decode="auto"`` (BGZF inflate + record decode as
+#: HIP kernels, bam.read_bam_gpu): below it the host reader's latency wins
+GPU_DECODE_MIN_BYTES = 32 << 20
+
+
+def _open_alignment_source(src, regions=None, engine=None, decode="auto"):
+    """Filenames are read with the package's own BAM readers; objects are used as
     given (``multiopen`` passes non-str objects through, util/io/openers.py:90-94).
-    `regions`: stage only the alignments that overlap them (through the BAI index)."""
+    `regions`: stage only the alignments that overlap them (through the BAI index).
+    `decode`: ``"host"`` (threads + zlib / libdeflate), ``"gpu"`` (the file image goes to HBM, pc_bam_open) or
+    ``"auto"`` (the GPU for whole files of GPU_DECODE_MIN_BYTES and more); both give the same arrays."""
     if isinstance(src, PackedAlignments):
         return src
     if isinstance(src, str):
-        from .bam import read_bam
+        from .bam import read_bam, read_bam_gpu
+        if decode not in ("auto", "host", "gpu"):
+            raise ValueError("decode must be 'auto', 'host' or 'gpu', got %r" % (decode,))
+        on_gpu = decode == "gpu" or (decode == "auto" and os.path.exists(src) and os.path.getsize(src) >= GPU_DECODE_MIN_BYTES)
+        if on_gpu and regions is None and engine is not None:
+            return read_bam_gpu(src, engine)
         return read_bam(src, regions=regions)
     return src
 
@@ -92,7 +105,9 @@ class BAMGenomeArray(object):
             bamfiles = bamfiles[0]
         # (extension) regions=[(chrom, start, end) | GenomicSegment, ...]: files named by path are staged
         # only where they overlap the regions, via their BAI index -- for a few loci of a large file
-        self.bamfiles = [_open_alignment_source(x, kwargs.get("regions")) for x in bamfiles]
+        # (the engine exists before the files are opened: large BAM files are inflated and decoded on its GPU)
+        self._engine = Engine(kwargs.get("device", 0))
+        self.bamfiles = [_open_alignment_source(x, kwargs.get("regions"), self._engine, kwargs.get("decode", "auto")) for x in bamfiles]
         self._strands = ("+", "-", ".")
         self._normalize = False
         self._sum = None
@@ -110,7 +125,6 @@ class BAMGenomeArray(object):
             self._tid_names = list(self._chroms)
         self._chrom_index = {c: i for i, c in enumerate(self._tid_names)}
         self._filters = OrderedDict()
-        self._engine = Engine(kwargs.get("device", 0))
         self._packed = [_pack_source(x, self._tid_names, self._chrom_index) for x in self.bamfiles]
         self._engine.set_alignments(self._packed, ntid=max(len(self._tid_names), 1))
         self._base_flags = [p.flags.copy() for p in self._packed]

@@ -273,3 +273,25 @@ def test_damaged_files_are_rejected_not_crashed(eng, tmp_path, seed):
             assert isinstance(res[0], str) and isinstance(res[1], str), (it, mode, res)
         else:
             same(res[1], res[0])
+
+
+def test_bam_genome_array_decodes_on_the_gpu(tmp_path):
+    """``BAMGenomeArray("x.bam", decode="gpu")`` -- what ``decode="auto"`` does for large files -- equals the host-decoded
+    array: references, sum, counts of a chain under two rules."""
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.0005, tx_scale=0.01)
+    path = str(tmp_path / "ga.bam")
+    bam_writer.write_bam_realistic(path, reads, threads=4, level=6)
+    a = pa.BAMGenomeArray(path, decode="host", mapping=pa.FivePrimeMapFactory(12))
+    b = pa.BAMGenomeArray(path, decode="gpu", mapping=pa.FivePrimeMapFactory(12))
+    assert a.chroms() == b.chroms() and a.sum() == b.sum() == reads.n
+    chains = tx.chains(limit=40)
+    for ga in (a, b):
+        ga.set_mapping(pa.FivePrimeMapFactory(12))
+    for x, y in zip(a.get_counts_batch(chains), b.get_counts_batch(chains)):
+        assert np.array_equal(x, y)
+    for ga in (a, b):
+        ga.set_mapping(pa.CenterMapFactory(3))
+    for x, y in zip(a.get_counts_batch(chains), b.get_counts_batch(chains)):
+        assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+    with pytest.raises(ValueError):
+        pa.BAMGenomeArray(path, decode="fpga")

@@ -386,6 +386,7 @@ def test_center_kernel_replays_through_dpp_rows(tmp_path):
     block = [b for b in notes.split("- .agpr_count")[1:] if re.search(r"\.name:\s+_ZN2pc8k_centerILb0ELb0EE", b)]
     assert len(block) == 1
     assert int(re.search(r"\.vgpr_count:\s+(\d+)", block[0]).group(1)) <= 64
+    assert int(re.search(r"\.sgpr_count:\s+(\d+)", block[0]).group(1)) <= 96, "eight waves per SIMD need <= 96 SGPRs (amdgpu_waves_per_eu(8, 8))"
     assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block[0]).group(1)) == 0
     symbol = re.search(r"\.name:\s+(_ZN2pc8k_centerILb0ELb0EE\S+)", block[0]).group(1)
     dis = subprocess.check_output([objdump, "-d", "--disassemble-symbols=" + symbol, obj]).decode()
@@ -431,3 +432,44 @@ def test_host_helpers_of_the_engine(tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, out.stdout.decode()
     assert b"host_util: ok" in out.stdout
+
+
+def test_inflate_and_plan_kernels_are_in_the_code_object(tmp_path):
+    """Round 4's device code beside the counting kernels: the BGZF inflate kernel in both forms (batch decoder of the
+    block symbols, wave-uniform decoder), without scratch memory and with an LDS footprint that leaves eleven waves per
+    CU; the walk over the symbol table is the hand-written loop (one LDS read, one LDS write, a readfirstlane per
+    symbol); every kernel of the GPU plan builder is there."""
+    import re
+    import shutil
+    import subprocess
+    from plastid_amd import build
+    lib = build.build_library()
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not available")
+    work = tmp_path / "co"
+    work.mkdir()
+    copy = str(work / "lib.so")
+    shutil.copy(lib, copy)
+    subprocess.check_call([objdump, "--offloading", copy], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(work))
+    obj = str(work / [f for f in os.listdir(str(work)) if "gfx950" in f][0])
+    notes = subprocess.check_output([readelf, "--notes", obj]).decode()
+    blocks = {re.search(r"\.name:\s+(\S+)", b).group(1): b for b in notes.split("- .agpr_count")[1:] if re.search(r"\.name:\s+(\S+)", b)}
+    for form in ("ILb1E", "ILb0E"):
+        name = [k for k in blocks if k.startswith("_ZN5pcbam14k_bgzf_inflate" + form)]
+        assert len(name) == 1, form
+        b = blocks[name[0]]
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", b).group(1)) == 0
+        assert int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", b).group(1)) <= 160 * 1024 // 11
+    batch = [k for k in blocks if k.startswith("_ZN5pcbam14k_bgzf_inflateILb1E")][0]
+    dis = subprocess.check_output([objdump, "-d", "--disassemble-symbols=" + batch, obj]).decode()
+    lines = [ln.split("//")[0].strip() for ln in dis.splitlines() if "\t" in ln]
+    at = [i for i, ln in enumerate(lines) if ln.startswith("s_bitcmp1_b32")]
+    assert at, "the walk over the symbol table was not found"
+    loop = [ln.split(None, 1)[0] for ln in lines[at[0] - 5:at[0] + 7]]
+    assert loop[:5] == ["ds_read_b32", "s_waitcnt", "ds_write_b32", "v_add_u32_e32", "v_readfirstlane_b32"], loop
+    assert loop[-1] == "s_cbranch_scc1" and len(loop) == 12
+    for k in ("k_plan_segs", "k_group_ends", "k_island_flags", "k_island_fill", "k_island_lens", "k_island_offsets", "k_seg_island", "k_pieces_raw",
+              "k_pieces_sorted", "k_tile_fill", "k_out_total", "k_out_raw", "k_out_sorted", "k_cchunk_count", "k_cchunk_fill", "k_gchunk_count",
+              "k_gchunk_fill"):
+        assert any(("pcplan" in name and k in name) for name in blocks), k
