@@ -894,22 +894,29 @@ __global__ __launch_bounds__(256) void k_bam_columns(const uint8_t *__restrict__
 }
 
 // per-record scan inputs: staged (placed) flag and the runs a multi-run record keeps
+constexpr int kScanInputsPerThread = 8;   // records per thread of k_bam_scan_inputs (one atomic per counter and workgroup: a single hot address takes ~90 atomics per us)
 __global__ __launch_bounds__(256) void k_bam_scan_inputs(const RecOut *__restrict__ recs, int64_t nrec, uint32_t *placed, uint32_t *runs,
                                                          unsigned long long *counts) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t pl = 0, rn = 0, mapped = 0;
-    if (i < nrec) {
-        const RecOut o = recs[i];
-        pl = o.placed;
-        rn = (o.placed && o.nruns >= 2u) ? o.nruns : 0u;
-        mapped = (o.flag & 0x4) ? 0u : 1u;
-        placed[i] = pl;
-        runs[i] = rn;
-    }
     // counts[0] mapped (flag 0x4 unset), counts[1] unplaced
-    unsigned long long a = mapped, b = (i < nrec && !pl) ? 1ull : 0ull;
+    unsigned long long a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < kScanInputsPerThread; ++k) {
+        const int64_t i = ((int64_t)blockIdx.x * kScanInputsPerThread + k) * 256 + threadIdx.x;
+        if (i < nrec) {
+            const RecOut o = recs[i];
+            placed[i] = o.placed;
+            runs[i] = (o.placed && o.nruns >= 2u) ? o.nruns : 0u;
+            a += (o.flag & 0x4) ? 0u : 1u;
+            b += o.placed ? 0u : 1u;
+        }
+    }
     for (int o2 = 32; o2 > 0; o2 >>= 1) { a += __shfl_down(a, o2, 64); b += __shfl_down(b, o2, 64); }
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ unsigned long long s_a[4], s_b[4];
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        b = s_b[0] + s_b[1] + s_b[2] + s_b[3];
         if (a) atomicAdd(&counts[0], a);
         if (b) atomicAdd(&counts[1], b);
     }

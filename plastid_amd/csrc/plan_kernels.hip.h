@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_tile_fill(Misc *__restrict__ misc, cons
     tiles[id] = t;
     // what an output piece looks its tile up by: (contig, window) and -- when every mode has a tile of its own -- the mode
     tile_keys[id] = split_modes ? keys[i] >> 12 : (keys[i] >> 14) << 2;
-    atomicMax(&misc->max_slots, (uint32_t)__popc(t.mode_mask));
+    if (__popc(t.mode_mask) > 1) atomicMax(&misc->max_slots, (uint32_t)__popc(t.mode_mask));   // (starts at 1: most windows query one strand mode)
 }
 
 __global__ __launch_bounds__(256) void k_out_total(Misc *__restrict__ misc, const uint32_t *__restrict__ out_at, const uint32_t *__restrict__ nout, int64_t nseg) {

@@ -3429,7 +3429,7 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
         hipLaunchKernelGGL(k_bam_order, dim3(g256), dim3(256), 0, st, d_recs.p, nrec, d_placed.p, d_misc.p);
         HIP_TRY(hipMemsetAsync(d_placed.p + nrec, 0, 4, st));
         HIP_TRY(hipMemsetAsync(d_runs.p + nrec, 0, 4, st));
-        hipLaunchKernelGGL(k_bam_scan_inputs, dim3(g256), dim3(256), 0, st, d_recs.p, nrec, d_placed.p, d_runs.p, d_misc.p + 1);
+        hipLaunchKernelGGL(k_bam_scan_inputs, dim3((unsigned)((nrec + 256 * kScanInputsPerThread - 1) / (256 * kScanInputsPerThread))), dim3(256), 0, st, d_recs.p, nrec, d_placed.p, d_runs.p, d_misc.p + 1);
         {
             size_t tmp_bytes = 0;
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_placed.p, d_staged_at.p, (int)(nrec + 1), st));
