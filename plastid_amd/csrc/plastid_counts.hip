@@ -18,6 +18,7 @@
 //   pc_rle / pc_total / pc_mapped_reads / pc_warn_flags   consumers of a finished count
 #include "pc_kernels.hip.h"
 #include "plan_kernels.hip.h"
+#include "stage_kernels.hip.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -1083,16 +1084,31 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
     return pc_add_alignment_file_wide(e, n, ntid, tid, pos, alen, flags, nblk, nrun, blk_start, blk_len, 0, nullptr, nullptr, nullptr);
 }
 
+// `dev`: the columns are in HBM already (a BAM file decoded on the GPU, pc_add_alignment_bam): the host pointers of the
+// columns and runs are then NULL and the one host pass below is replaced by kernels (stage_kernels.hip.h); the wide
+// side arrays come from the host either way.
+static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
+                      const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
+                      const int32_t *blk_start, const int32_t *blk_len, int64_t n_wide, const int64_t *wide_idx,
+                      const int32_t *wide_alen, const int32_t *wide_nblk, const pcstage::DevCols *dev);
+
 int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
                                const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
                                const int32_t *blk_start, const int32_t *blk_len, int64_t n_wide, const int64_t *wide_idx,
                                const int32_t *wide_alen, const int32_t *wide_nblk) {
+    return stage_file(e, n, ntid, tid, pos, alen, flags, nblk, nrun, blk_start, blk_len, n_wide, wide_idx, wide_alen, wide_nblk, nullptr);
+}
+
+static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
+                      const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
+                      const int32_t *blk_start, const int32_t *blk_len, int64_t n_wide, const int64_t *wide_idx,
+                      const int32_t *wide_alen, const int32_t *wide_nblk, const pcstage::DevCols *dev) {
     if (!e) return fail(PC_ERR_ARG, "engine is NULL");
     if (n < 0 || ntid <= 0 || nrun < 0) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad sizes");
-    if (n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL array");
-    if (nrun > 0 && (!blk_start || !blk_len)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL run array");
+    if (!dev && n > 0 && (!tid || !pos || !alen || !flags || !nblk)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL array");
+    if (!dev && nrun > 0 && (!blk_start || !blk_len)) return fail(PC_ERR_ARG, "pc_add_alignment_file: NULL run array");
     if (n_wide < 0 || (n_wide > 0 && (!wide_idx || !wide_alen || !wide_nblk))) return fail(PC_ERR_ARG, "pc_add_alignment_file: bad wide-record arrays");
-    for (int64_t k = 0; k < n_wide; ++k) {
+    for (int64_t k = 0; k < n_wide && !dev; ++k) {
         const int64_t i = wide_idx[k];
         if (i < 0 || i >= n || (k > 0 && i <= wide_idx[k - 1])) return fail(PC_ERR_ARG, "pc_add_alignment_file: wide_idx must be ascending record indices");
         if (alen[i] != 0xffffu || nblk[i] != 0xffu) return fail(PC_ERR_ARG, "pc_add_alignment_file: record %lld is listed as wide but its alen / nblk are not 65535 / 255", (long long)i);
@@ -1116,11 +1132,17 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     // zips them into {start, length} pairs and builds the side lists from them)
     DevBuf<int32_t> d_bs, d_bl;
     struct Joined { std::future<int> f; ~Joined() { if (f.valid()) f.wait(); } } runs_up;   // (joined on every way out, before the buffers go)
-    if (nrun > 0) {
-        const int dev = e->device;
+    if (nrun > 0 && dev) {
+        int r = d_bs.reserve((size_t)nrun);
+        if (r == PC_OK) r = d_bl.reserve((size_t)nrun);
+        if (r != PC_OK) return r;
+        HIP_TRY(hipMemcpyAsync(d_bs.p, dev->blk_start, (size_t)nrun * 4, hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d_bl.p, dev->blk_len, (size_t)nrun * 4, hipMemcpyDeviceToDevice, e->stream));
+    } else if (nrun > 0) {
+        const int devno = e->device;
         hipStream_t s = e->stream;
-        runs_up.f = std::async(std::launch::async, [&d_bs, &d_bl, blk_start, blk_len, nrun, dev, s]() -> int {
-            if (hipSetDevice(dev) != hipSuccess) return PC_ERR_HIP;
+        runs_up.f = std::async(std::launch::async, [&d_bs, &d_bl, blk_start, blk_len, nrun, devno, s]() -> int {
+            if (hipSetDevice(devno) != hipSuccess) return PC_ERR_HIP;
             int r = d_bs.upload(blk_start, (size_t)nrun, s);
             if (r == PC_OK) r = d_bl.upload(blk_len, (size_t)nrun, s);
             if (r == PC_OK && hipStreamSynchronize(s) != hipSuccess) r = PC_ERR_HIP;
@@ -1170,7 +1192,31 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         b = std::min(s1, s0 + (int64_t)t * q);
         en = std::min(s1, b + q);
     };
-    {   // runs owned by each unit (records with >= 2 runs keep theirs in blk_*), so that a unit knows where its first run sits
+    DevBuf<uint32_t> d_cursor, d_run_at;   // (device columns) where the runs of every record sit in the run arrays / go in the run stream
+    if (dev) {
+        using namespace pcstage;
+        hipStream_t st = e->stream;
+        DevBuf<uint8_t> d_tmp;
+        int r = d_cursor.reserve((size_t)n + 1);
+        if (r == PC_OK) r = d_run_at.reserve((size_t)n + 1);
+        size_t tb = 0;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_cursor.p, d_cursor.p, (int)n + 1, st));
+        if (r == PC_OK) r = d_tmp.reserve(std::max<size_t>(tb, 16));
+        if (r != PC_OK) return r;
+        hipLaunchKernelGGL(k_cols_runs, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, *dev, n, d_cursor.p, d_run_at.p);
+        size_t b2 = tb;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, b2, d_cursor.p, d_cursor.p, (int)n + 1, st));
+        b2 = tb;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, b2, d_run_at.p, d_run_at.p, (int)n + 1, st));
+        uint32_t tot[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(&tot[0], d_cursor.p + n, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&tot[1], d_run_at.p + n, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));   // (d_tmp goes out of scope)
+        nrunrec_total = tot[1];
+        if ((int64_t)tot[0] != nrun)
+            return fail(PC_ERR_ARG, (int64_t)tot[0] > nrun ? "run arrays shorter than sum of nblk" : "run arrays longer than sum of nblk (%lld vs %lld)",
+                        (long long)tot[0], (long long)nrun);
+    } else {   // runs owned by each unit (records with >= 2 runs keep theirs in blk_*), so that a unit knows where its first run sits
         parallel_chunks(nslices * T, T, [&](int, int64_t ub, int64_t ue) {
             for (int64_t u = ub; u < ue; ++u) {
                 int64_t b, en, r = 0, rs = 0;
@@ -1208,7 +1254,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     DevBuf<uint2> d_val_in;
     DevBuf<uint32_t> d_idx_in;
     size_t slice_runs = 1;
-    for (int64_t sl = 0; sl < nslices; ++sl) {
+    for (int64_t sl = 0; sl < nslices && !dev; ++sl) {
         const int64_t r0 = units[(size_t)(sl * T)].run_at, r1 = sl + 1 < nslices ? units[(size_t)((sl + 1) * T)].run_at : nrunrec_total;
         slice_runs = std::max(slice_runs, (size_t)(r1 - r0));
     }
@@ -1229,8 +1275,8 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         std::future<int> up;
         SliceBuf(size_t cap, size_t runs) : own(cap), run_val(runs), run_idx(runs) { rec = own.p; }
     };
-    const size_t slice_cap = (size_t)std::min<int64_t>(S, std::max<int64_t>(n, 1));
-    SliceBuf bufs[2] = {SliceBuf(slice_cap, slice_runs), SliceBuf(nslices > 1 ? slice_cap : 1, nslices > 1 ? slice_runs : 1)};
+    const size_t slice_cap = dev ? 1 : (size_t)std::min<int64_t>(S, std::max<int64_t>(n, 1));
+    SliceBuf bufs[2] = {SliceBuf(slice_cap, slice_runs), SliceBuf(nslices > 1 && !dev ? slice_cap : 1, nslices > 1 && !dev ? slice_runs : 1)};
     if (!bufs[0].rec || !bufs[1].rec || !bufs[0].run_val.p || !bufs[1].run_val.p || !bufs[0].run_idx.p || !bufs[1].run_idx.p) {
         delete sf;
         return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
@@ -1239,7 +1285,61 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     hipStream_t up_stream = e->stream;
     clk.lap("run layout + allocations");
     const ChunkErr *first_err = nullptr;
-    for (int64_t sl = 0; sl < nslices && rc == PC_OK; ++sl) {
+    std::vector<int32_t> dev_last_pos;   // (device columns) start of the last record of every contig
+    if (dev && n > 0) {
+        // ---- the same pass as kernels: records, run-stream records, ends, statistics (stage_kernels.hip.h)
+        using namespace pcstage;
+        hipStream_t st = e->stream;
+        DevBuf<unsigned long long> d_stats;
+        DevBuf<int32_t> d_ends, d_last_pos, d_tid_end;
+        DevBuf<int64_t> d_bounds;
+        DevBuf<uint8_t> d_tmp;
+        rc = d_stats.reserve(kStatWords);
+        if (rc == PC_OK) rc = d_ends.reserve((size_t)n);
+        if (rc == PC_OK) rc = d_last_pos.reserve((size_t)ntid);
+        if (rc == PC_OK) rc = d_tid_end.reserve((size_t)ntid);
+        if (rc == PC_OK) rc = d_bounds.reserve((size_t)ntid + 1);
+        size_t tb = 0;
+        if (rc == PC_OK && hipcub::DeviceSegmentedReduce::Max(nullptr, tb, d_ends.p, d_tid_end.p, ntid, d_bounds.p, d_bounds.p + 1, st) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: segmented max failed");
+        if (rc == PC_OK) rc = d_tmp.reserve(std::max<size_t>(tb, 16));
+        if (rc != PC_OK) { delete sf; return rc; }
+        std::vector<unsigned long long> hstats((size_t)kStatWords, 0ull);
+        hstats[(size_t)kAtMisc + 1] = 65536ull;   // rmin
+        std::vector<int64_t> hbounds((size_t)ntid + 1);
+        std::vector<int32_t> htid_end((size_t)ntid);
+        dev_last_pos.resize((size_t)ntid);
+        hipError_t he = hipMemcpyAsync(d_stats.p, hstats.data(), (size_t)kStatWords * 8, hipMemcpyHostToDevice, st);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_cols_pack, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, st, *dev, n, d_cursor.p, d_run_at.p,
+                               sf->rec.p, d_val_in.p, d_idx_in.p, d_ends.p, d_stats.p);
+            hipLaunchKernelGGL(k_cols_bounds, dim3((unsigned)((ntid + 256) / 256)), dim3(256), 0, st, dev->tid, dev->pos, n, ntid, d_bounds.p, d_last_pos.p);
+            he = hipcub::DeviceSegmentedReduce::Max(d_tmp.p, tb, d_ends.p, d_tid_end.p, ntid, d_bounds.p, d_bounds.p + 1, st);
+        }
+        if (he == hipSuccess) he = hipMemcpyAsync(hstats.data(), d_stats.p, (size_t)kStatWords * 8, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipMemcpyAsync(hbounds.data(), d_bounds.p, ((size_t)ntid + 1) * 8, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipMemcpyAsync(htid_end.data(), d_tid_end.p, (size_t)ntid * 4, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipMemcpyAsync(dev_last_pos.data(), d_last_pos.p, (size_t)ntid * 4, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipGetLastError();
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        if (he != hipSuccess) { delete sf; return fail(PC_ERR_HIP, "stage: packing the device columns failed: %s", hipGetErrorString(he)); }
+        Acc &a = acc[0];   // (what the threads of the host pass accumulate, from the device's one block)
+        for (int t = 0; t < ntid; ++t) {
+            a.tid_count[(size_t)t + 1] = hbounds[(size_t)t + 1] - hbounds[(size_t)t];
+            a.tid_end[(size_t)t] = hbounds[(size_t)t + 1] > hbounds[(size_t)t] ? (int64_t)htid_end[(size_t)t] : 0;
+        }
+        for (int k = 0; k < kSpanBins; ++k) {
+            a.span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtSpan + k)];
+            a.gap_span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtGap + k)];
+            a.wide_span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtWide + k)];
+        }
+        for (int k = 0; k < kLenBins; ++k) a.len_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtLen + k)];
+        for (int k = 0; k < kLen1Bins; ++k) a.len1_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtLen1 + k)];
+        a.Wr = std::max(1, (int)hstats[(size_t)kAtMisc + 0]);
+        a.rmin = (int)hstats[(size_t)kAtMisc + 1];
+        a.rmax = a.rmin >= 65536 ? -1 : (int)hstats[(size_t)kAtMisc + 2];
+        a.max_span = std::max<int64_t>(1, (int64_t)hstats[(size_t)kAtMisc + 3]);
+    }
+    for (int64_t sl = 0; sl < nslices && rc == PC_OK && !dev; ++sl) {
         SliceBuf &sb = bufs[sl & 1];
         if (sb.up.valid()) rc = sb.up.get();               // the slice that used these buffers has gone up
         if (rc != PC_OK) break;
@@ -1457,7 +1557,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
         sf->nwide = n_wide;
     }
     // the aligned runs as {start, length} pairs (they went up while the records were packed)
-    if (nrun > 0) { const int r = runs_up.f.get(); if (r != PC_OK) { delete sf; return fail(r, "stage: uploading the aligned runs failed"); } }
+    if (nrun > 0 && runs_up.f.valid()) { const int r = runs_up.f.get(); if (r != PC_OK) { delete sf; return fail(r, "stage: uploading the aligned runs failed"); } }
     if (nrun > 0) {
         rc = sf->blk.reserve((size_t)nrun);
         if (rc != PC_OK) { delete sf; return rc; }
@@ -1494,7 +1594,7 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
     std::vector<int64_t> lin_off((size_t)ntid + 1, 0);
     for (int t = 0; t < ntid; ++t) {
         const int64_t b = tid_bounds[(size_t)t], en = tid_bounds[(size_t)t + 1];
-        int64_t last = en > b ? (int64_t)pos[en - 1] : -1;
+        int64_t last = en > b ? (int64_t)(dev ? dev_last_pos[(size_t)t] : pos[en - 1]) : -1;
         if (en > b) last = std::max<int64_t>(last, tid_end[(size_t)t] - 1);
         const int64_t nb = last >= 0 ? (last >> kLinShift) + 1 : 0;
         lin_off[(size_t)t + 1] = lin_off[(size_t)t] + nb + 1;
@@ -3566,18 +3666,39 @@ int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const ch
     pc_bam *b = nullptr;
     int rc = pc_bam_open(e, image, size, name, &b);
     if (rc != PC_OK) return rc;
-    const size_t n = (size_t)b->n, m = (size_t)b->nrun, nw = b->wide_idx.size();
-    std::vector<int32_t> tid(n), pos(n), bs(m), bl(m), wa(nw), wn(nw);
-    std::vector<uint16_t> alen(n);
-    std::vector<uint8_t> flags(n), nblk(n);
-    std::vector<int64_t> wi(nw);
-    rc = pc_bam_read(b, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), bs.data(), bl.data(), wi.data(), wa.data(), wn.data());
+    struct Closer { pc_bam *b; ~Closer() { pc_bam_close(b); } } closer{b};
+    const int64_t n = b->n, m = b->nrun, nw = (int64_t)b->wide_idx.size();
     const int ntid = std::max(1, (int)b->ref_names.size());
     if (mapped) *mapped = b->mapped;
-    pc_bam_close(b);
+    // the decoder's columns never leave HBM: staged by kernels (stage_kernels.hip.h) instead of the host pass
+    // (PC_BAM_STAGE_HOST=1: read them back and take the host pass, as a caller of pc_bam_read + pc_add_alignment_file does)
+    if (!getenv("PC_BAM_STAGE_HOST")) {
+        DevBuf<uint32_t> d_wr;
+        DevBuf<uint2> d_wv;
+        if (nw) {
+            std::vector<uint32_t> wr((size_t)nw);
+            std::vector<uint2> wv((size_t)nw);
+            for (int64_t k = 0; k < nw; ++k) { wr[(size_t)k] = (uint32_t)b->wide_idx[(size_t)k]; wv[(size_t)k] = make_uint2((uint32_t)b->wide_alen[(size_t)k], (uint32_t)b->wide_nblk[(size_t)k]); }
+            rc = d_wr.upload(wr, e->stream);
+            if (rc == PC_OK) rc = d_wv.upload(wv, e->stream);
+            if (rc != PC_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(e->stream));   // (the host vectors go out of scope)
+        }
+        pcstage::DevCols dc;
+        dc.tid = b->tid.p; dc.pos = b->pos.p; dc.alen = b->alen.p; dc.flags = b->flags.p; dc.nblk = b->nblk.p;
+        dc.blk_start = b->blk_start.p; dc.blk_len = b->blk_len.p;
+        dc.wide_rec = d_wr.p; dc.wide_val = d_wv.p; dc.n_wide = nw;
+        return stage_file(e, n, ntid, nullptr, nullptr, nullptr, nullptr, nullptr, m, nullptr, nullptr, nw, b->wide_idx.data(), b->wide_alen.data(),
+                          b->wide_nblk.data(), &dc);
+    }
+    std::vector<int32_t> tid((size_t)n), pos((size_t)n), bs((size_t)m), bl((size_t)m), wa((size_t)nw), wn((size_t)nw);
+    std::vector<uint16_t> alen((size_t)n);
+    std::vector<uint8_t> flags((size_t)n), nblk((size_t)n);
+    std::vector<int64_t> wi((size_t)nw);
+    rc = pc_bam_read(b, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), bs.data(), bl.data(), wi.data(), wa.data(), wn.data());
     if (rc != PC_OK) return rc;
-    return pc_add_alignment_file_wide(e, (int64_t)n, ntid, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), (int64_t)m, bs.data(), bl.data(),
-                                      (int64_t)nw, wi.data(), wa.data(), wn.data());
+    return pc_add_alignment_file_wide(e, n, ntid, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), m, bs.data(), bl.data(),
+                                      nw, wi.data(), wa.data(), wn.data());
 }
 
 } // extern "C"

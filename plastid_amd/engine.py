@@ -79,6 +79,32 @@ class Engine(object):
         for f in files:
             self.add_alignment_file(f, ntid)
 
+    def add_bam(self, path):
+        """Stage a coordinate-sorted BAM file WITHOUT its records ever visiting the host (``pc_add_alignment_bam``): the
+        file image goes to HBM, the BGZF members are inflated and the records decoded there, and the packed columns are
+        staged by kernels.  Returns the number of mapped reads (pysam's ``AlignmentFile.mapped``).  The engine then
+        counts exactly as after ``add_alignment_file(read_bam(path))``; callers that also want the reads themselves
+        (``reads_out`` as objects, host-side filters) use :func:`plastid_amd.bam.read_bam_gpu` instead."""
+        import mmap
+        import os
+        with open(path, "rb") as fh:
+            size = os.fstat(fh.fileno()).st_size
+            mapped = ctypes.c_int64(0)
+            if size == 0:
+                check(self._lib.pc_add_alignment_bam(self._h, None, 0, os.fsencode(path), ctypes.byref(mapped)))
+                self.nfiles += 1
+                return 0
+            mm = mmap.mmap(fh.fileno(), 0, flags=mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0), prot=mmap.PROT_READ)
+            try:
+                view = np.frombuffer(mm, dtype=np.uint8)
+                rc = self._lib.pc_add_alignment_bam(self._h, view.ctypes.data_as(ctypes.c_void_p), size, os.fsencode(path), ctypes.byref(mapped))
+                del view
+            finally:
+                mm.close()
+        check(rc)
+        self.nfiles += 1
+        return int(mapped.value)
+
     def update_flags(self, file_index, flags):
         flags = _c(flags, np.uint8)
         check(self._lib.pc_update_flags(self._h, int(file_index), len(flags), _ptr(flags)))

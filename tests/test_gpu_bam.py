@@ -295,3 +295,88 @@ def test_bam_genome_array_decodes_on_the_gpu(tmp_path):
         assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
     with pytest.raises(ValueError):
         pa.BAMGenomeArray(path, decode="fpga")
+
+
+def _count_all_rules(eng, tx):
+    out = []
+    for mapping, dtype in ((("fiveprime", 12), np.int64), (("threeprime", 0), np.int64), (("center", 2), np.float64),
+                           (("variable", synth.VARIABLE_OFFSETS), np.int64), (("stratified", synth.VARIABLE_OFFSETS, 25, 35), np.int64)):
+        f = synth.mapping_factory(mapping)
+        f._configure(eng)
+        rows = getattr(f, "_numlengths", 1)
+        p = tx.plan_arrays(rows=rows)
+        plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
+        out.append(plan.count(dtype).copy().view(np.uint64))
+        plan.close()
+    return out
+
+
+@pytest.mark.parametrize("config,scale", [("C2", 0.0005), ("C4", 0.0003), ("C5", 0.0002)])
+def test_a_bam_file_staged_without_leaving_the_device(tmp_path, monkeypatch, config, scale):
+    """``Engine.add_bam`` (pc_add_alignment_bam): decode on the GPU, staging by kernels on the columns in HBM -- the counts
+    under all five rules equal those of the host-decoded, host-staged file, for single-end reads, spliced reads
+    (multi-run records, run stream) and mate pairs; the read-back-and-host-pass form of the same call
+    (PC_BAM_STAGE_HOST=1) agrees too; a second file on top (one staged each way) counts like two host-staged files."""
+    genome, tx, reads, _ = synth.make_config(config, scale=scale, tx_scale=0.01)
+    path = str(tmp_path / "dev.bam")
+    bam_writer.write_bam_realistic(path, reads, threads=4, level=6)
+    host = read_bam(path)
+    a = Engine(0)
+    a.set_alignments([host])
+    want = _count_all_rules(a, tx)
+    b = Engine(0)
+    assert b.add_bam(path) == host.mapped
+    for x, y in zip(want, _count_all_rules(b, tx)):
+        assert np.array_equal(x, y)
+    monkeypatch.setenv("PC_BAM_STAGE_HOST", "1")
+    c = Engine(0)
+    assert c.add_bam(path) == host.mapped
+    for x, y in zip(want, _count_all_rules(c, tx)):
+        assert np.array_equal(x, y)
+    monkeypatch.delenv("PC_BAM_STAGE_HOST")
+    a.add_alignment_file(host, None)
+    b.add_alignment_file(host, None)
+    for x, y in zip(_count_all_rules(a, tx), _count_all_rules(b, tx)):
+        assert np.array_equal(x, y)
+    for e in (a, b, c):
+        e.close()
+
+
+def test_wide_and_long_reads_staged_on_the_device(eng, tmp_path):
+    """A read beyond the 16-bit / 8-bit columns (3 001 aligned runs), long-span reads and unplaced reads, through
+    ``add_bam``: counts equal the host path's."""
+    refs, lens = ["chrA", "chrB"], [5000000, 200000]
+    cig_wide = []
+    for k in range(3000):
+        cig_wide += [(0, 20), (3, 30)]
+    cig_wide += [(0, 20)]
+    recs = [(0, 100, [(0, 30)], 0), (0, 120, cig_wide, 16), (0, 150, [(0, 10), (3, 5000), (0, 25)], 0), (0, 90000, [(0, 300)], 0),
+            (1, 5, [(0, 40)], 16), (1, 50, [(0, 10), (2, 1), (0, 10)], 0), (-1, -1, [], 4)]
+    data = bam_stream(refs, lens, recs)
+    path = str(tmp_path / "wide.bam")
+    write_members(path, data, 20000, level=6)
+    host = read_bam(path)
+    tid = np.array([0, 0, 0, 1], np.int32)
+    start = np.array([0, 80000, 150000, 0], np.int64)
+    end = np.array([70000, 95000, 160000, 300], np.int64)
+    strand = np.array([1, 2, 3, 3], np.uint8)
+    L = end - start
+    off = np.zeros(4, np.int64)
+    np.cumsum(L[:-1], out=off[1:])
+    outs = []
+    for how in ("host", "dev"):
+        e = Engine(0)
+        if how == "host":
+            e.set_alignments([host])
+        else:
+            assert e.add_bam(path) == host.mapped
+        res = []
+        for mapping, dtype in ((("fiveprime", 0), np.int64), (("threeprime", 3), np.int64), (("center", 0), np.float64)):
+            synth.mapping_factory(mapping)._configure(e)
+            plan = e.plan(tid, start, end, strand, off, np.ones(4, np.int8), L, int(L.sum()), 1)
+            res.append(plan.count(dtype).copy().view(np.uint64))
+            plan.close()
+        outs.append(res)
+        e.close()
+    for x, y in zip(*outs):
+        assert x.sum() > 0 and np.array_equal(x, y)
