@@ -262,6 +262,11 @@ int pc_bam_close(pc_bam *b);
 /* decode `image` and stage it as one more alignment file of the engine (reference ids = the file's own reference
  * list, which must be that of the files staged before it); *mapped (optional) = the file's mapped-read count */
 int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped);
+/* The same two calls for a file named by path (what `pysam.AlignmentFile(path, "rb")` takes, genome_array.py:660): the
+ * library maps the file itself -- the pages are touched by all host threads at once instead of one soft fault after the
+ * other, and the mapping is taken down on a thread of its own after the call has returned. */
+int pc_bam_open_path(pc_engine *e, const char *path, pc_bam **out);
+int pc_add_alignment_bam_path(pc_engine *e, const char *path, int64_t *mapped);
 
 #ifdef __cplusplus
 }

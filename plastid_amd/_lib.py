@@ -80,6 +80,8 @@ SIGNATURES = {
     "pc_bam_read": (_int, [_vp] * 11),
     "pc_bam_close": (_int, [_vp]),
     "pc_add_alignment_bam": (_int, [_vp, _vp, _i64, ctypes.c_char_p, ctypes.POINTER(_i64)]),
+    "pc_bam_open_path": (_int, [_vp, ctypes.c_char_p, _pp]),
+    "pc_add_alignment_bam_path": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_i64)]),
 }
 
 _lib = None

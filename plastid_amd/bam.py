@@ -50,33 +50,17 @@ def read_bam_gpu(path, engine, timing=None):
     (``pc_bam_open``, ``csrc/bam_kernels.hip.h``); only the packed columns -- 13 bytes per record instead of the ~120 of
     an aligner's record -- come back.  `engine`: a :class:`plastid_amd.engine.Engine` (its device and stream are used).
     `timing`: optional dict that receives the phase times in ms and the member / byte counts."""
-    import mmap
     import time
     from . import _lib as clib
     L = clib.load()
+    if not os.path.isfile(path):
+        raise IOError("No such file: %r" % (path,))
     t_0 = time.perf_counter()
-    with open(path, "rb") as fh:
-        size = os.fstat(fh.fileno()).st_size
-        # (MAP_POPULATE: the page-cache pages are mapped in one go instead of one soft fault per 4 KiB during the walk
-        # over the member headers and the upload)
-        mm = mmap.mmap(fh.fileno(), 0, flags=mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0), prot=mmap.PROT_READ) if size else None
-        t_map = time.perf_counter()
-        try:
-            h = ctypes.c_void_p()
-            if size:
-                view = np.frombuffer(mm, dtype=np.uint8)
-                rc = L.pc_bam_open(engine._h, view.ctypes.data_as(ctypes.c_void_p), size, os.fsencode(path), ctypes.byref(h))
-                del view
-            else:
-                rc = L.pc_bam_open(engine._h, None, 0, os.fsencode(path), ctypes.byref(h))
-            t_call = time.perf_counter()
-        finally:
-            if mm is not None:
-                mm.close()
-    clib.check(rc)
+    h = ctypes.c_void_p()
+    # (the library maps the file itself: pages touched by all host threads at once, unmapped on a thread of its own)
+    clib.check(L.pc_bam_open_path(engine._h, os.fsencode(path), ctypes.byref(h)))
     t_open = time.perf_counter()
-    if timing is not None:
-        timing.update(map_ms=(t_map - t_0) * 1e3, open_call_ms=(t_call - t_map) * 1e3, unmap_ms=(t_open - t_call) * 1e3)
+    size = os.path.getsize(path)
     try:
         counts = np.zeros(8, np.int64)
         clib.check(L.pc_bam_counts(h, counts.ctypes.data_as(ctypes.c_void_p)))

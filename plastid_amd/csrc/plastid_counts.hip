@@ -32,11 +32,15 @@
 #include <future>
 #include <functional>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <unistd.h>
 #include <mutex>
 #include <sched.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <cerrno>
 #include <thread>
 #include <vector>
 
@@ -74,15 +78,27 @@ int fail(int code, const char *fmt, ...) {
 struct DevPool {
     static constexpr int kMinShift = 8, kClasses = 18;   // 256 B .. 32 MiB
     static constexpr size_t kMaxCached = (size_t)512 << 20;
+    // Large blocks (> 32 MiB: the arrays of a staged file, the scratch of the BAM decoder) are kept too, by size rounded
+    // up to a quarter of a power of two, up to kBigLimit in all: on some hosts a hipMalloc / hipFree pair of a few
+    // hundred MB takes tens of milliseconds (measured: 60 ms per call on one box of the pool, < 1 ms on others), which a
+    // caller that stages file after file -- or the same file again -- would pay every time.
+    static constexpr size_t kBigLimit = (size_t)64 << 30;
     std::mutex m;
     std::vector<void *> bins[kClasses];
     size_t cached = 0;
+    std::map<size_t, std::vector<void *>> big;
+    size_t big_cached = 0;
     static int size_class(size_t bytes) {
         int c = 0;
         while (c < kClasses && ((size_t)1 << (kMinShift + c)) < bytes) ++c;
         return c;   // kClasses: too large to pool
     }
     static size_t class_bytes(int c) { return (size_t)1 << (kMinShift + c); }
+    static size_t big_round(size_t bytes) {
+        const int k = 63 - __builtin_clzll((unsigned long long)bytes);
+        const size_t step = (size_t)1 << (k - 2);
+        return (bytes + step - 1) / step * step;
+    }
     void *take(int c) {
         std::lock_guard<std::mutex> g(m);
         if (bins[c].empty()) return nullptr;
@@ -98,6 +114,22 @@ struct DevPool {
         cached += class_bytes(c);
         return true;
     }
+    void *big_take(size_t rounded) {
+        std::lock_guard<std::mutex> g(m);
+        auto it = big.find(rounded);
+        if (it == big.end() || it->second.empty()) return nullptr;
+        void *p = it->second.back();
+        it->second.pop_back();
+        big_cached -= rounded;
+        return p;
+    }
+    bool big_give(void *p, size_t rounded) {
+        std::lock_guard<std::mutex> g(m);
+        if (big_cached + rounded > kBigLimit) return false;
+        big[rounded].push_back(p);
+        big_cached += rounded;
+        return true;
+    }
     void drain() {
         std::lock_guard<std::mutex> g(m);
         for (auto &b : bins) {
@@ -105,26 +137,49 @@ struct DevPool {
             b.clear();
         }
         cached = 0;
+        for (auto &kv : big)
+            for (void *p : kv.second) (void)hipFree(p);
+        big.clear();
+        big_cached = 0;
     }
     ~DevPool() { drain(); }
+};
+
+// The pool a DevBuf without one of its own takes its blocks from: set for the duration of an entry point that
+// allocates on behalf of an engine (staging, the BAM decoder), so that every buffer made there -- temporaries and the
+// arrays a staged file keeps -- is recycled through that engine's pool.  (All users of one pool enqueue on its engine's
+// streams in an order the entry points fix with events, so a recycled block is ordered after its last use.)
+static thread_local DevPool *tls_pool = nullptr;
+struct PoolScope {
+    DevPool *prev;
+    explicit PoolScope(DevPool *p) : prev(tls_pool) { tls_pool = p; }
+    ~PoolScope() { tls_pool = prev; }
 };
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
     DevPool *pool = nullptr;   // set: blocks come from / return to this pool
-    int pool_class = -1;       // size class of the current block, -1: plain hipMalloc
+    int pool_class = -1;       // size class of the current block, -1: plain hipMalloc, -2: a large block of `big_bytes`
+    size_t big_bytes = 0;
     ~DevBuf() { release(); }
     void release() {
-        if (p && !(pool_class >= 0 && pool && pool->give(p, pool_class))) (void)hipFree(p);
+        if (p) {
+            bool kept = false;
+            if (pool && pool_class >= 0) kept = pool->give(p, pool_class);
+            else if (pool && pool_class == -2) kept = pool->big_give(p, big_bytes);
+            if (!kept) (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
         pool_class = -1;
+        big_bytes = 0;
     }
     int reserve(size_t n) {
         if (n <= cap) return PC_OK;
         release();
         if (n == 0) return PC_OK;
+        if (!pool) pool = tls_pool;
         if (pool) {
             const int c = DevPool::size_class(n * sizeof(T));
             if (c < DevPool::kClasses) {
@@ -135,6 +190,18 @@ template <typename T> struct DevBuf {
                 pool_class = c;
                 return PC_OK;
             }
+            const size_t rounded = DevPool::big_round(n * sizeof(T));
+            void *q = pool->big_take(rounded);
+            if (!q && hipMalloc(&q, rounded) != hipSuccess) {
+                (void)hipGetLastError();
+                pool->drain();   // (what the pool holds may be what is missing)
+                HIP_TRY(hipMalloc(&q, rounded));
+            }
+            p = (T *)q;
+            cap = rounded / sizeof(T);
+            pool_class = -2;
+            big_bytes = rounded;
+            return PC_OK;
         }
         HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
         cap = n;
@@ -1127,6 +1194,7 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
     if (!e->files.empty() && ntid != e->ntid)
         return fail(PC_ERR_ARG, "pc_add_alignment_file: all files must use the same reference list (ntid %d vs %d)", ntid, e->ntid);
     HIP_TRY(hipSetDevice(e->device));
+    PoolScope pool_scope(&e->pool);   // the file's arrays and the temporaries of staging are recycled through the engine's pool
 
     // the caller's run arrays go up on a thread of their own while the records are validated and packed (the GPU
     // zips them into {start, length} pairs and builds the side lists from them)
@@ -3294,6 +3362,7 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
     const uint8_t *image = (const uint8_t *)image_;
     const std::string path = name ? name : "<memory>";
     HIP_TRY(hipSetDevice(e->device));
+    PoolScope pool_scope(&e->pool);   // (the decoder's scratch -- image, inflated stream, record table -- is recycled through the engine's pool)
     hipStream_t st = e->stream;
     BamClock clk;
     // ---- member boundaries (host: a walk over the gzip headers; 18 + bytes per 64 KiB of payload)
@@ -3667,6 +3736,7 @@ int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const ch
     int rc = pc_bam_open(e, image, size, name, &b);
     if (rc != PC_OK) return rc;
     struct Closer { pc_bam *b; ~Closer() { pc_bam_close(b); } } closer{b};
+    PoolScope pool_scope(&e->pool);
     const int64_t n = b->n, m = b->nrun, nw = (int64_t)b->wide_idx.size();
     const int ntid = std::max(1, (int)b->ref_names.size());
     if (mapped) *mapped = b->mapped;
@@ -3699,6 +3769,59 @@ int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const ch
     if (rc != PC_OK) return rc;
     return pc_add_alignment_file_wide(e, n, ntid, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), m, bs.data(), bl.data(),
                                       nw, wi.data(), wa.data(), wn.data());
+}
+
+namespace {
+// A file mapped for one call: every host thread touches its share of the pages (soft faults in parallel: 578 MB in ~2 ms
+// instead of the 15 of MAP_POPULATE's one thread), and the mapping is taken down on a thread of its own (12 ms that
+// nobody waits for).
+struct MappedFile {
+    void *p = nullptr;
+    size_t size = 0;
+    int open(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return fail(PC_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) { ::close(fd); return fail(PC_ERR_ARG, "cannot stat %s: %s", path, strerror(errno)); }
+        size = (size_t)sb.st_size;
+        if (size) {
+            p = mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0);
+            if (p == MAP_FAILED) { p = nullptr; ::close(fd); return fail(PC_ERR_NOMEM, "cannot map %s: %s", path, strerror(errno)); }
+            (void)madvise(p, size, MADV_WILLNEED);
+            const int64_t pages = (int64_t)((size + 4095) / 4096);
+            const volatile uint8_t *q = (const volatile uint8_t *)p;
+            parallel_chunks(pages, std::min(usable_cpus(), 32), [&](int, int64_t b, int64_t en) {
+                uint8_t acc = 0;
+                for (int64_t k = b; k < en; ++k) acc ^= q[(size_t)k * 4096];
+                (void)acc;
+            });
+        }
+        ::close(fd);
+        return PC_OK;
+    }
+    ~MappedFile() {
+        if (!p) return;
+        void *q = p;
+        const size_t n = size;
+        try { std::thread([q, n]() { (void)munmap(q, n); }).detach(); } catch (...) { (void)munmap(q, n); }
+    }
+};
+} // namespace
+
+int pc_bam_open_path(pc_engine *e, const char *path, pc_bam **out) {
+    if (!e || !path || !out) return fail(PC_ERR_ARG, "pc_bam_open_path: bad arguments");
+    MappedFile mf;
+    const int rc = mf.open(path);
+    if (rc != PC_OK) return rc;
+    return pc_bam_open(e, mf.p, (int64_t)mf.size, path, out);
+}
+
+int pc_add_alignment_bam_path(pc_engine *e, const char *path, int64_t *mapped) {
+    if (!e || !path) return fail(PC_ERR_ARG, "pc_add_alignment_bam_path: bad arguments");
+    MappedFile mf;
+    const int rc = mf.open(path);
+    if (rc != PC_OK) return rc;
+    return pc_add_alignment_bam(e, mf.p, (int64_t)mf.size, path, mapped);
 }
 
 } // extern "C"

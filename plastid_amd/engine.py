@@ -85,22 +85,11 @@ class Engine(object):
         staged by kernels.  Returns the number of mapped reads (pysam's ``AlignmentFile.mapped``).  The engine then
         counts exactly as after ``add_alignment_file(read_bam(path))``; callers that also want the reads themselves
         (``reads_out`` as objects, host-side filters) use :func:`plastid_amd.bam.read_bam_gpu` instead."""
-        import mmap
         import os
-        with open(path, "rb") as fh:
-            size = os.fstat(fh.fileno()).st_size
-            mapped = ctypes.c_int64(0)
-            if size == 0:
-                check(self._lib.pc_add_alignment_bam(self._h, None, 0, os.fsencode(path), ctypes.byref(mapped)))
-                self.nfiles += 1
-                return 0
-            mm = mmap.mmap(fh.fileno(), 0, flags=mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0), prot=mmap.PROT_READ)
-            try:
-                view = np.frombuffer(mm, dtype=np.uint8)
-                rc = self._lib.pc_add_alignment_bam(self._h, view.ctypes.data_as(ctypes.c_void_p), size, os.fsencode(path), ctypes.byref(mapped))
-                del view
-            finally:
-                mm.close()
+        if not os.path.isfile(path):
+            raise IOError("No such file: %r" % (path,))
+        mapped = ctypes.c_int64(0)
+        rc = self._lib.pc_add_alignment_bam_path(self._h, os.fsencode(path), ctypes.byref(mapped))
         check(rc)
         self.nfiles += 1
         return int(mapped.value)
