@@ -3355,7 +3355,17 @@ struct BamClock {   // PC_BAM_TIMING=1: wall-clock laps of the host side of the 
 };
 } // namespace
 
-int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out) {
+// `uploaded` (optional): called once, with the stream the image is uploaded on, when the last piece has been queued -- once
+// that stream has drained the host copy of the file is not read again (pc_bam_open_path takes its mapping down while the
+// GPU is still inflating).
+typedef std::function<void(hipStream_t)> UploadedHook;
+static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out, const UploadedHook *uploaded);
+
+int pc_bam_open(pc_engine *e, const void *image, int64_t size, const char *name, pc_bam **out) {
+    return bam_open_impl(e, image, size, name, out, nullptr);
+}
+
+static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out, const UploadedHook *uploaded) {
     using namespace pcbam;
     if (!e || !out || size < 0 || (size > 0 && !image_)) return fail(PC_ERR_ARG, "pc_bam_open: bad arguments");
     *out = nullptr;
@@ -3460,6 +3470,7 @@ int pc_bam_open(pc_engine *e, const void *image_, int64_t size, const char *name
             byte0 = byte1;
             m0 = m1;
         }
+        if (uploaded) (*uploaded)(up);
         hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)nm), dim3(64), 0, st, d_stream.p, d_members.p, nm, d_crc.p, d_crc.p + 256, d_status.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(status.data(), d_status.p, (size_t)nm * 4, hipMemcpyDeviceToHost, st));
@@ -3731,9 +3742,15 @@ int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *
     return PC_OK;
 }
 
+static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded);
+
 int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped) {
+    return add_alignment_bam_impl(e, image, size, name, mapped, nullptr);
+}
+
+static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded) {
     pc_bam *b = nullptr;
-    int rc = pc_bam_open(e, image, size, name, &b);
+    int rc = bam_open_impl(e, image, size, name, &b, uploaded);
     if (rc != PC_OK) return rc;
     struct Closer { pc_bam *b; ~Closer() { pc_bam_close(b); } } closer{b};
     PoolScope pool_scope(&e->pool);
@@ -3773,8 +3790,8 @@ int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const ch
 
 namespace {
 // A file mapped for one call: every host thread touches its share of the pages (soft faults in parallel: 578 MB in ~2 ms
-// instead of the 15 of MAP_POPULATE's one thread), and the mapping is taken down on a thread of its own (12 ms that
-// nobody waits for).
+// instead of the 15 of MAP_POPULATE's one thread), and the mapping is taken down by a helper thread as soon as the
+// image has been uploaded -- while the caller's thread waits for the GPU.
 struct MappedFile {
     void *p = nullptr;
     size_t size = 0;
@@ -3799,11 +3816,24 @@ struct MappedFile {
         ::close(fd);
         return PC_OK;
     }
-    ~MappedFile() {
-        if (!p) return;
+    // the mapping goes as soon as the image has crossed PCIe -- on a helper thread, while the caller's thread waits for
+    // the GPU (munmap holds the address-space lock of the process: done later, it would stall the caller's next page faults)
+    std::thread helper;
+    void release_behind(hipStream_t up, int device) {
+        if (!p || helper.joinable()) return;
         void *q = p;
         const size_t n = size;
-        try { std::thread([q, n]() { (void)munmap(q, n); }).detach(); } catch (...) { (void)munmap(q, n); }
+        p = nullptr;
+        try {
+            helper = std::thread([q, n, up, device]() {
+                if (hipSetDevice(device) == hipSuccess) (void)hipStreamSynchronize(up);
+                (void)munmap(q, n);
+            });
+        } catch (...) { p = q; }
+    }
+    ~MappedFile() {
+        if (helper.joinable()) helper.join();
+        if (p) (void)munmap(p, size);
     }
 };
 } // namespace
@@ -3813,7 +3843,9 @@ int pc_bam_open_path(pc_engine *e, const char *path, pc_bam **out) {
     MappedFile mf;
     const int rc = mf.open(path);
     if (rc != PC_OK) return rc;
-    return pc_bam_open(e, mf.p, (int64_t)mf.size, path, out);
+    const int device = e->device;
+    const UploadedHook hook = [&mf, device](hipStream_t up) { mf.release_behind(up, device); };
+    return bam_open_impl(e, mf.p, (int64_t)mf.size, path, out, &hook);
 }
 
 int pc_add_alignment_bam_path(pc_engine *e, const char *path, int64_t *mapped) {
@@ -3821,7 +3853,9 @@ int pc_add_alignment_bam_path(pc_engine *e, const char *path, int64_t *mapped) {
     MappedFile mf;
     const int rc = mf.open(path);
     if (rc != PC_OK) return rc;
-    return pc_add_alignment_bam(e, mf.p, (int64_t)mf.size, path, mapped);
+    const int device = e->device;
+    const UploadedHook hook = [&mf, device](hipStream_t up) { mf.release_behind(up, device); };
+    return add_alignment_bam_impl(e, mf.p, (int64_t)mf.size, path, mapped, &hook);
 }
 
 } // extern "C"
