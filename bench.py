@@ -722,10 +722,16 @@ def e2e_scope(args, ctx, name, realistic=False):
     out = {}
     out_dtype = np.float64 if mapping[0] == "center" else np.int64
 
+    # host side of the read-back: page-locked, as in the staged scope (what a caller that reads repeatedly hands over)
+    import torch
+    out_pin = torch.zeros(int(p["out_elems"]), dtype=torch.int64 if out_dtype == np.int64 else torch.float64,
+                          pin_memory=int(p["out_elems"]) * 8 <= (16 << 30))
+    out_buf = out_pin.numpy()
+
     def counted():
         plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
         try:
-            return plan.count(out_dtype)
+            return plan.count(out_dtype, out=out_buf)
         finally:
             plan.close()
 
@@ -753,7 +759,7 @@ def e2e_scope(args, ctx, name, realistic=False):
         out[key + "_reads_per_s"] = reads.n / t_all
         out[key + "_reads_per_s_median"] = reads.n / sorted(r[0] for r in runs)[1]
         out[key + "_sample"] = ("the same file, decoded AND staged on the GPU (pc_add_alignment_bam: the columns never leave HBM); three whole "
-                                "passes (%s s): file -> staged %.3f s + plan, count and read-back %.3f s; counts gated on those of the "
+                                "passes (%s s): file -> staged %.3f s + plan, count and read-back into page-locked memory %.3f s; counts gated on those of the "
                                 "records the file was written from" % ("/".join("%.3f" % r[0] for r in runs), t_stage, t_all - t_stage))
         del want
     except SystemExit:
@@ -772,11 +778,9 @@ def e2e_scope(args, ctx, name, realistic=False):
                 t_decode = time.perf_counter() - t0
                 eng.set_alignments([packed])
                 t_stage = time.perf_counter() - t0 - t_decode
-                plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
-                got = plan.count(np.float64 if mapping[0] == "center" else np.int64)
+                got = counted()
                 t_all = time.perf_counter() - t0
                 runs.append((t_all, t_decode, t_stage))
-                plan.close()
                 ok = all(np.array_equal(getattr(packed, k), getattr(reads, k)) for k in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"))
                 del packed, got                          # released outside the timed pass
                 if not ok:
@@ -792,7 +796,7 @@ def e2e_scope(args, ctx, name, realistic=False):
         out[key + "_reads_per_s_median"] = reads.n / t_median
         out[key + "_sample"] = ("%d records of %s written once (untimed) as a BGZF-compressed BAM of %.0f MB (%.0f MB inflated, %.0f bytes per "
                                 "record%s); timed: three whole passes (%s s; value = best, median beside it): %s decode %.3f s + staging "
-                                "%.3f s + plan, count and read-back %.3f s" %
+                                "%.3f s + plan, count and read-back into page-locked memory %.3f s" %
                                 (reads.n, name, fsize / 1e6, nbytes / 1e6, nbytes / float(reads.n),
                                  ": read name, sequence, qualities, NH and MD tags" if realistic else ": name 'r', no sequence",
                                  "/".join("%.3f" % r[0] for r in runs), "GPU (BGZF inflate + record decode as HIP kernels)" if gpu_decode else "native host",

@@ -406,6 +406,8 @@ struct pc_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // the single-wave kernel of sparse windows runs beside the main one
+    static constexpr int kAux = 3;
+    hipStream_t aux_stream[kAux] = {nullptr, nullptr, nullptr};   // the upload pieces of the BAM decoder are inflated on these and the main stream in turn, so that one launch fills the tail of the launches before it
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_pinned = nullptr;      // end of the last copy out of `pinned`
     hipEvent_t ev[8] = {};
@@ -429,6 +431,8 @@ struct pc_engine {
     DevBuf<uint8_t> d_flags;     // staging buffer of pc_update_flags
     bool pinned_busy = false;
     PinnedBuf pinned;            // host side of the plan-table upload (reused: ev_pinned is waited for before it is rewritten)
+    PinnedBuf bam_ring[2];       // page-locked halves the image of a large BAM file crosses PCIe through (filled by all host threads)
+    hipEvent_t ev_ring[2] = {nullptr, nullptr};
     uint64_t work_generation = 1; // bumped by whatever changes the work list of a plan (alignment files, knobs)
     size_t max_lds = 64 * 1024; // LDS a workgroup may use (160 KiB on gfx950)
     DevBuf<double> d_partial;
@@ -1072,6 +1076,7 @@ int pc_create(int device, pc_engine **out) {
     e->knobs.load();
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    for (auto &a : e->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_pinned, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
@@ -1108,8 +1113,10 @@ int pc_destroy(pc_engine *e) {
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
+    for (auto &a : e->aux_stream) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_pinned) (void)hipEventDestroy(e->ev_pinned);
+    for (auto &x : e->ev_ring) if (x) (void)hipEventDestroy(x);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -3437,7 +3444,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
     std::vector<uint32_t> status((size_t)nm, 0u);
     if (nm) {
         const bool serial_symbols = getenv("PC_BGZF_SERIAL") != nullptr && atoi(getenv("PC_BGZF_SERIAL")) != 0;   // (round 4's first kernel, for comparison)
-        const int64_t piece_bytes = getenv("PC_BAM_PIECE") ? std::max<int64_t>(1, atoll(getenv("PC_BAM_PIECE"))) : ((int64_t)128 << 20);
+        const int64_t piece_bytes = getenv("PC_BAM_PIECE") ? std::max<int64_t>(1, atoll(getenv("PC_BAM_PIECE"))) : ((int64_t)64 << 20);
         hipStream_t up = e->side_stream ? e->side_stream : st;
         std::vector<hipEvent_t> landed;
         struct EvList { std::vector<hipEvent_t> &v; ~EvList() { for (auto x : v) (void)hipEventDestroy(x); } } landed_guard{landed};
@@ -3448,8 +3455,29 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             HIP_TRY(hipEventRecord(x, st));
             HIP_TRY(hipStreamWaitEvent(up, x, 0));
         }
+        // The inflate launches alternate between the main stream and an auxiliary one: a launch ends in a tail of
+        // half-empty CUs (a member takes ~4 ms, ~3 000 are in flight), which the launch of the next piece fills.
+        // (two streams in turn: measured on two boxes, 64 MiB pieces, 20 M aligner-like records: one stream 56 - 58 ms, two
+        // 46.6 - 53.5, four 48.6; PC_BAM_STREAMS = 1 .. 4 for experiments)
+        int naux = up != st ? 1 : 0;
+        if (const char *env = getenv("PC_BAM_STREAMS")) naux = up != st ? std::max(0, std::min(pc_engine::kAux, atoi(env) - 1)) : 0;
+        for (int k = 0; k < naux; ++k)   // (behind what the main stream has queued: the members table, the previous users of the buffers)
+            HIP_TRY(hipStreamWaitEvent(e->aux_stream[k], landed[0], 0));
+        // large files cross PCIe through two page-locked halves of one piece each (made once per engine)
+        bool ring = up != st && size >= 2 * piece_bytes && !getenv("PC_BAM_NO_RING");
+        bool ring_busy[2] = {false, false};
+        const int ring_threads = std::max(1, std::min(usable_cpus(), 16));
+        if (ring) {
+            // (a piece ends with a whole member: up to 64 KiB beyond piece_bytes)
+            for (int k = 0; k < 2 && ring; ++k) {
+                if (e->bam_ring[k].reserve((size_t)piece_bytes + ((size_t)1 << 17)) != PC_OK) ring = false;
+                if (ring && !e->ev_ring[k] && hipEventCreateWithFlags(&e->ev_ring[k], hipEventDisableTiming) != hipSuccess) ring = false;
+            }
+            (void)hipGetLastError();
+        }
+        int piece_no = 0;
         int64_t byte0 = 0;          // the image is uploaded from here on (gzip headers and trailers ride along)
-        for (int m0 = 0; m0 < nm;) {
+        for (int m0 = 0; m0 < nm; ++piece_no) {
             int m1 = m0;
             int64_t byte1 = byte0;
             while (m1 < nm && (byte1 - byte0 < piece_bytes || m1 == m0)) {
@@ -3457,18 +3485,42 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
                 ++m1;
             }
             if (m1 == nm) byte1 = size;
-            HIP_TRY(hipMemcpyAsync(d_image.p + byte0, image + byte0, (size_t)(byte1 - byte0), hipMemcpyHostToDevice, up));
+            if (ring) {
+                // through a page-locked half: the runtime's own staging of a pageable copy runs on one thread (12 - 20 GB/s);
+                // here every host thread copies its share, and the DMA of one half overlaps the filling of the other
+                const int slot = piece_no & 1;
+                if (ring_busy[slot]) HIP_TRY(hipEventSynchronize(e->ev_ring[slot]));
+                uint8_t *dstp = e->bam_ring[slot].p;
+                const uint8_t *srcp = image + byte0;
+                const int64_t len = byte1 - byte0, blk = (int64_t)1 << 20;
+                parallel_chunks((len + blk - 1) / blk, ring_threads, [&](int, int64_t b, int64_t en) {
+                    const int64_t lo = b * blk, hi = std::min(len, en * blk);
+                    if (hi > lo) std::memcpy(dstp + lo, srcp + lo, (size_t)(hi - lo));
+                });
+                HIP_TRY(hipMemcpyAsync(d_image.p + byte0, dstp, (size_t)len, hipMemcpyHostToDevice, up));
+                HIP_TRY(hipEventRecord(e->ev_ring[slot], up));
+                ring_busy[slot] = true;
+            } else
+                HIP_TRY(hipMemcpyAsync(d_image.p + byte0, image + byte0, (size_t)(byte1 - byte0), hipMemcpyHostToDevice, up));
             if (up != st) {
                 hipEvent_t x;
                 HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
                 landed.push_back(x);
                 HIP_TRY(hipEventRecord(x, up));
-                HIP_TRY(hipStreamWaitEvent(st, x, 0));
             }
-            if (serial_symbols) hipLaunchKernelGGL(k_bgzf_inflate<false>, dim3((unsigned)(m1 - m0)), dim3(kInflWG), 0, st, d_image.p, d_members.p, m0, m1, d_stream.p, d_status.p);
-            else hipLaunchKernelGGL(k_bgzf_inflate<true>, dim3((unsigned)(m1 - m0)), dim3(kInflWG), 0, st, d_image.p, d_members.p, m0, m1, d_stream.p, d_status.p);
+            hipStream_t ks = (piece_no % (naux + 1)) ? e->aux_stream[piece_no % (naux + 1) - 1] : st;
+            if (up != st) HIP_TRY(hipStreamWaitEvent(ks, landed.back(), 0));
+            if (serial_symbols) hipLaunchKernelGGL(k_bgzf_inflate<false>, dim3((unsigned)(m1 - m0)), dim3(kInflWG), 0, ks, d_image.p, d_members.p, m0, m1, d_stream.p, d_status.p);
+            else hipLaunchKernelGGL(k_bgzf_inflate<true>, dim3((unsigned)(m1 - m0)), dim3(kInflWG), 0, ks, d_image.p, d_members.p, m0, m1, d_stream.p, d_status.p);
             byte0 = byte1;
             m0 = m1;
+        }
+        for (int k = 0; k < naux; ++k) {   // the main stream goes on behind all of them
+            hipEvent_t x;
+            HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+            landed.push_back(x);
+            HIP_TRY(hipEventRecord(x, e->aux_stream[k]));
+            HIP_TRY(hipStreamWaitEvent(st, x, 0));
         }
         if (uploaded) (*uploaded)(up);
         hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)nm), dim3(64), 0, st, d_stream.p, d_members.p, nm, d_crc.p, d_crc.p + 256, d_status.p);
