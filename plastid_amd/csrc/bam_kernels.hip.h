@@ -38,7 +38,11 @@ constexpr int kInflWG = 64;                 // one wave per BGZF member
 constexpr int kWinBytes = PC_BGZF_WINDOW;   // the part of the DEFLATE window (RFC 1951: distances up to 32 768) kept in LDS; further back: HBM
 constexpr int kLitRoot = 9, kDistRoot = 6;  // first-level table bits (zlib's choice: enough.c bounds 852 / 592 entries)
 constexpr int kLitEntries = 1024, kDistEntries = 640;
-constexpr int kInBytes = 1024;              // compressed input staged in LDS (two halves of 512 bytes)
+#ifndef PC_BGZF_IN
+#define PC_BGZF_IN 512
+#endif
+constexpr int kInBytes = PC_BGZF_IN;       // compressed input staged in LDS (two halves)
+constexpr uint32_t kInHalf = kInBytes / 2;
 constexpr int kFlush = kWinBytes / 4;       // the window goes to HBM in pieces of this size
 
 struct Member {
@@ -281,14 +285,15 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     const uint32_t clen = mb.clen, ulen = mb.ulen;
     int err = kInfOk;
 
-    // ---- input: `in` holds the 1 KiB of the stream around the read position as 256 dwords (ring); refilled a half
-    // (512 bytes) at a time by the wave when the reader has crossed into the other half
+    // ---- input: `in` holds the kInBytes of the stream around the read position (ring); refilled a half at a time by
+    // the wave when the reader has crossed into the other half (512 bytes: a batch looks 84 bytes ahead; with 1 KiB a
+    // wave's LDS is 13.5 KiB -- eleven waves per CU -- with 512 bytes 13.0: twelve)
     uint32_t in_pos = 0;          // next byte of the stream to pull into the bit buffer (always a multiple of 4)
-    uint32_t in_loaded = 0;       // bytes of the stream staged so far (multiple of 512)
-    auto stage_half = [&]() {     // stage stream bytes [in_loaded, in_loaded + 512)
+    uint32_t in_loaded = 0;       // bytes of the stream staged so far (multiple of kInHalf)
+    auto stage_half = [&]() {     // stage stream bytes [in_loaded, in_loaded + kInHalf)
         const uint32_t base = in_loaded;
-        // 128 dwords by 64 lanes, byte-wise assembled (the stream starts at an arbitrary byte of the image)
-        for (int k = lane; k < 128; k += 64) {
+        // dwords assembled byte-wise (the stream starts at an arbitrary byte of the image)
+        for (int k = lane; k < (int)kInHalf / 4; k += 64) {
             const uint32_t b = base + 4u * (uint32_t)k;
             uint32_t w = 0;
             if (b + 3u < clen) w = (uint32_t)src[b] | ((uint32_t)src[b + 1] << 8) | ((uint32_t)src[b + 2] << 16) | ((uint32_t)src[b + 3] << 24);
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             }
             sh.in[((base >> 2) + (uint32_t)k) & (kInBytes / 4 - 1)] = w;
         }
-        in_loaded += 512u;
+        in_loaded += kInHalf;
         __syncthreads();
     };
     stage_half();
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     int nb = 0;                   // valid bits in it
     auto refill = [&]() {         // at least 32 valid bits afterwards (zeros behind the end of the stream)
         if (nb <= 32) {
-            if (in_pos + 512u + 4u > in_loaded) stage_half();   // the reader entered the last staged half: fetch the next (zeros behind the end)
+            if (in_pos + kInHalf + 4u > in_loaded) stage_half();   // the reader entered the last staged half: fetch the next (zeros behind the end)
             // (every lane reads the same word: readfirstlane tells the compiler so, and what follows stays on the scalar unit)
             const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.in[(in_pos >> 2) & (kInBytes / 4 - 1)]);
             bb |= (unsigned long long)w << nb;
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             sp += len;
             // restart the staged input at the new position (dword aligned below it; the odd bytes are dropped from the bit buffer)
             in_pos = sp & ~3u;
-            in_loaded = in_pos & ~511u;
+            in_loaded = in_pos & ~(kInHalf - 1u);
             stage_half();
             stage_half();
             refill();

@@ -3383,14 +3383,13 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
     hipStream_t st = e->stream;
     BamClock clk;
     // ---- member boundaries (host: a walk over the gzip headers; 18 + bytes per 64 KiB of payload)
-    std::vector<Member> members;
-    uint64_t total_u = 0;
-    for (int64_t off = 0; off < size;) {
-        if (off + 18 > size) return fail(PC_ERR_ARG, "truncated BGZF header");
+    // one member at `off`: 0, or which defect (the messages below)
+    auto parse_member = [&](int64_t off, Member &mb, int64_t &clen_out) -> int {
+        if (off + 18 > size) return 1;
         const uint8_t *h = image + off;
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return fail(PC_ERR_ARG, "not a BGZF file (bad gzip member header)");
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return 2;
         const uint16_t xlen = brd16(h + 10);
-        if (off + 12 + xlen > size) return fail(PC_ERR_ARG, "truncated BGZF extra field");
+        if (off + 12 + xlen > size) return 3;
         int bsize = -1;
         for (size_t x = 0; x + 4 <= xlen;) {
             const uint8_t *sf = h + 12 + x;
@@ -3398,20 +3397,90 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = brd16(sf + 4);
             x += 4 + slen;
         }
-        if (bsize < 0) return fail(PC_ERR_ARG, "BGZF member without BC subfield");
+        if (bsize < 0) return 4;
         const int64_t clen = (int64_t)bsize + 1;
-        if (off + clen > size) return fail(PC_ERR_ARG, "truncated BGZF member");
+        if (off + clen > size) return 5;
         const uint32_t isize = brd32(image + off + clen - 4);
-        if (isize > (1u << 16)) return fail(PC_ERR_ARG, "corrupt BGZF member (more than 64 KiB of payload)");
+        if (isize > (1u << 16)) return 6;
         const int64_t hdr = 12 + xlen;
-        if (clen < hdr + 8) return fail(PC_ERR_ARG, "BGZF inflate failed in %s", path.c_str());
-        Member mb;
-        mb.coff = (uint64_t)(off + hdr); mb.clen = (uint32_t)(clen - hdr - 8); mb.ulen = isize; mb.uoff = total_u;
+        if (clen < hdr + 8) return 7;
+        mb.coff = (uint64_t)(off + hdr); mb.clen = (uint32_t)(clen - hdr - 8); mb.ulen = isize; mb.uoff = 0;
         mb.crc = brd32(image + off + clen - 8); mb.pad = 0;
-        if (isize) members.push_back(mb);      // (empty members -- the end-of-file marker -- hold nothing)
-        total_u += isize;
+        clen_out = clen;
+        return 0;
+    };
+    auto walk_error = [&](int code) -> int {
+        switch (code) {
+        case 1: return fail(PC_ERR_ARG, "truncated BGZF header");
+        case 2: return fail(PC_ERR_ARG, "not a BGZF file (bad gzip member header)");
+        case 3: return fail(PC_ERR_ARG, "truncated BGZF extra field");
+        case 4: return fail(PC_ERR_ARG, "BGZF member without BC subfield");
+        case 5: return fail(PC_ERR_ARG, "truncated BGZF member");
+        case 6: return fail(PC_ERR_ARG, "corrupt BGZF member (more than 64 KiB of payload)");
+        default: return fail(PC_ERR_ARG, "BGZF inflate failed in %s", path.c_str());
+        }
+    };
+    std::vector<Member> members;
+    int64_t walked_to = 0;
+    // Large files: the walk is a chain of dependent cache misses (40 k members: 5.6 ms), so every host thread walks its
+    // own stretch of the file from the first offset in it where three members in a row parse; a stretch counts only if
+    // the walk of the stretch before it LANDS on its first member -- whatever does not chain is walked again, serially.
+    const int64_t walk_min = getenv("PC_BAM_WALK_MIN") ? atoll(getenv("PC_BAM_WALK_MIN")) : ((int64_t)32 << 20);   // (tests: the parallel walk on small files)
+    const int WT = size >= walk_min && size >= 64 ? std::max(1, std::min(usable_cpus(), 16)) : 1;
+    if (WT > 1) {
+        struct Stretch { int64_t first = -1, landing = -1; std::vector<Member> mem; };
+        std::vector<Stretch> str((size_t)WT);
+        parallel_chunks((int64_t)WT, WT, [&](int, int64_t kb, int64_t ke) {
+            for (int64_t k = kb; k < ke; ++k) {
+                Stretch &sx = str[(size_t)k];
+                const int64_t lo = size * k / WT, hi = size * (k + 1) / WT;
+                int64_t off = lo;
+                if (k > 0) {   // the first offset from which three members parse
+                    off = -1;
+                    for (int64_t c = lo; c < hi && c + 18 <= size; ++c) {
+                        if (image[c] != 31 || image[c + 1] != 139) continue;
+                        int64_t q = c;
+                        bool ok = true;
+                        for (int r = 0; r < 3 && ok && q < size; ++r) {
+                            Member mb;
+                            int64_t cl = 0;
+                            ok = parse_member(q, mb, cl) == 0;
+                            q += cl;
+                        }
+                        if (ok) { off = c; break; }
+                    }
+                    if (off < 0) continue;
+                }
+                sx.first = off;
+                while (off < hi && off < size) {
+                    Member mb;
+                    int64_t cl = 0;
+                    if (parse_member(off, mb, cl) != 0) { sx.first = -1; break; }   // (a defect: the serial walk below reports it)
+                    if (mb.ulen) sx.mem.push_back(mb);
+                    off += cl;
+                }
+                sx.landing = off;
+            }
+        });
+        int64_t expected = 0;
+        for (int k = 0; k < WT; ++k) {
+            const Stretch &sx = str[(size_t)k];
+            if (sx.first < 0 || sx.first != expected) break;
+            members.insert(members.end(), sx.mem.begin(), sx.mem.end());
+            expected = sx.landing;
+        }
+        walked_to = expected;
+    }
+    for (int64_t off = walked_to; off < size;) {
+        Member mb;
+        int64_t clen = 0;
+        const int code = parse_member(off, mb, clen);
+        if (code) return walk_error(code);
+        if (mb.ulen) members.push_back(mb);      // (empty members -- the end-of-file marker -- hold nothing)
         off += clen;
     }
+    uint64_t total_u = 0;
+    for (Member &mb : members) { mb.uoff = total_u; total_u += mb.ulen; }
     pc_bam *b = new pc_bam();
     clk.lap("member walk");
     b->e = e; b->name = path; b->members = (int64_t)members.size(); b->inflated_bytes = (int64_t)total_u; b->compressed_bytes = size;

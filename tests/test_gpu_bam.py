@@ -380,3 +380,39 @@ def test_wide_and_long_reads_staged_on_the_device(eng, tmp_path):
         e.close()
     for x, y in zip(*outs):
         assert x.sum() > 0 and np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_member_walk_by_all_host_threads(eng, tmp_path, monkeypatch, seed):
+    """Large files have their BGZF member boundaries walked by every host thread from a guessed start (chained by
+    where each stretch lands): forced here for small files -- same columns, and damaged files are rejected with the
+    same messages as by the serial walk."""
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0002, tx_scale=0.01, seed_shift=seed)
+    path = str(tmp_path / "walk.bam")
+    bam_writer.write_bam_realistic(path, reads, threads=4, level=6, block_bytes=3000 + 700 * seed)
+    ref = read_bam(path)
+    monkeypatch.setenv("PC_BAM_WALK_MIN", "1")
+    same(read_bam_gpu(path, eng), ref)
+    raw = bytearray(open(path, "rb").read())
+    rng = np.random.default_rng(seed)
+    for trial in range(12):
+        bad = bytearray(raw)
+        kind = trial % 3
+        at = int(rng.integers(100, len(bad) - 100))
+        if kind == 0:
+            bad[at] ^= 0xff                                   # a flipped byte (header or payload)
+        elif kind == 1:
+            del bad[at:]                                      # truncated
+        else:
+            bad[at:at] = b"\x1f\x8b\x08\x04" + bytes(rng.integers(0, 256, 40, dtype=np.uint8))   # a false member start inside
+        p2 = str(tmp_path / ("bad%d.bam" % trial))
+        open(p2, "wb").write(bytes(bad))
+        outcomes = []
+        for walk_min in ("1", "1000000000"):
+            monkeypatch.setenv("PC_BAM_WALK_MIN", walk_min)
+            try:
+                got = read_bam_gpu(p2, eng)
+                outcomes.append(("ok", got.n, int(got.pos.sum()) if got.n else 0))
+            except (ValueError, IOError) as e:
+                outcomes.append(("error", str(e)))
+        assert outcomes[0] == outcomes[1], outcomes
