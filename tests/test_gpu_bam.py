@@ -416,3 +416,38 @@ def test_member_walk_by_all_host_threads(eng, tmp_path, monkeypatch, seed):
             except (ValueError, IOError) as e:
                 outcomes.append(("error", str(e)))
         assert outcomes[0] == outcomes[1], outcomes
+
+
+def test_files_without_placed_reads_staged_on_the_device(tmp_path):
+    """A BAM file with a header only, and one with unplaced reads only, through ``add_bam``: staged as files of zero
+    records, counted as zeros; a file with records staged after it counts as if alone."""
+    refs, lens = ["chrA", "chrB"], [100000, 50000]
+    tid = np.array([0, 1], np.int32)
+    start = np.array([0, 0], np.int64)
+    end = np.array([2000, 1000], np.int64)
+    strand = np.array([3, 3], np.uint8)
+    L = end - start
+    off = np.array([0, 2000], np.int64)
+    for name, recs, mapped in (("empty", [], 0), ("unplaced", [(-1, -1, [], 4), (-1, -1, [], 4)], 0)):
+        path = str(tmp_path / (name + ".bam"))
+        write_members(path, bam_stream(refs, lens, recs), 20000, level=6)
+        e = Engine(0)
+        assert e.add_bam(path) == mapped
+        synth.mapping_factory(("fiveprime", 0))._configure(e)
+        plan = e.plan(tid, start, end, strand, off, np.ones(2, np.int8), L, int(L.sum()), 1)
+        assert plan.count(np.int64).sum() == 0
+        plan.close()
+        more = str(tmp_path / (name + "_more.bam"))
+        write_members(more, bam_stream(refs, lens, [(0, 100, [(0, 30)], 0), (1, 7, [(0, 25)], 16)]), 20000, level=6)
+        assert e.add_bam(more) == 2
+        plan = e.plan(tid, start, end, strand, off, np.ones(2, np.int8), L, int(L.sum()), 1)
+        got = plan.count(np.int64).copy()
+        plan.close()
+        h = Engine(0)
+        h.set_alignments([read_bam(path), read_bam(more)])
+        synth.mapping_factory(("fiveprime", 0))._configure(h)
+        plan = h.plan(tid, start, end, strand, off, np.ones(2, np.int8), L, int(L.sum()), 1)
+        assert got.sum() == 2 and np.array_equal(got, plan.count(np.int64))
+        plan.close()
+        e.close()
+        h.close()
