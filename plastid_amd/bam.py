@@ -44,6 +44,60 @@ def _load():
     return _lib
 
 
+def bam_header(path):
+    """``(references, lengths)`` of a BAM file from its header alone: the leading BGZF members are inflated (zlib) until
+    the reference list is complete -- what ``pysam.AlignmentFile(path).references / .lengths`` give
+    (genome_array.py:667-670)."""
+    import struct
+    import zlib
+    buf = b""
+    with open(path, "rb") as fh:
+        def more():
+            head = fh.read(12)
+            if len(head) < 12:
+                return False
+            if head[0] != 31 or head[1] != 139 or head[2] != 8 or not (head[3] & 4):
+                raise ValueError("not a BGZF file (bad gzip member header)")
+            xlen = struct.unpack("<H", head[10:12])[0]
+            extra = fh.read(xlen)
+            bsize, x = -1, 0
+            while x + 4 <= len(extra):
+                slen = struct.unpack("<H", extra[x + 2:x + 4])[0]
+                if extra[x:x + 2] == b"BC" and slen == 2:
+                    bsize = struct.unpack("<H", extra[x + 4:x + 6])[0]
+                x += 4 + slen
+            if bsize < 0:
+                raise ValueError("BGZF member without BC subfield")
+            payload = fh.read(bsize + 1 - 12 - xlen)
+            if len(payload) < bsize + 1 - 12 - xlen:
+                raise ValueError("truncated BGZF member")
+            nonlocal buf
+            buf += zlib.decompressobj(-15).decompress(payload[:-8])
+            return True
+
+        def need(n):
+            while len(buf) < n:
+                if not more():
+                    raise ValueError("truncated BAM header")
+
+        need(12)
+        if buf[:4] != b"BAM\x01":
+            raise ValueError("not a BAM file (bad magic)")
+        l_text = struct.unpack("<i", buf[4:8])[0]
+        need(12 + l_text)
+        n_ref = struct.unpack("<i", buf[8 + l_text:12 + l_text])[0]
+        at = 12 + l_text
+        refs, lens = [], []
+        for _ in range(n_ref):
+            need(at + 4)
+            l_name = struct.unpack("<i", buf[at:at + 4])[0]
+            need(at + 4 + l_name + 4)
+            refs.append(buf[at + 4:at + 4 + l_name - 1].decode())
+            lens.append(struct.unpack("<i", buf[at + 4 + l_name:at + 8 + l_name])[0])
+            at += 8 + l_name
+    return refs, lens
+
+
 def read_bam_gpu(path, engine, timing=None):
     """The same :class:`PackedAlignments` as :func:`read_bam` gives for a whole file, decoded ON THE GPU: the file image
     goes to HBM as it is, the BGZF members are inflated there (one wave per member) and the BAM records decoded

@@ -94,6 +94,10 @@ class Engine(object):
         self.nfiles += 1
         return int(mapped.value)
 
+    def num_records(self, file_index):
+        """Records staged for file `file_index`."""
+        return int(self._lib.pc_num_records(self._h, int(file_index)))
+
     def update_flags(self, file_index, flags):
         flags = _c(flags, np.uint8)
         check(self._lib.pc_update_flags(self._h, int(file_index), len(flags), _ptr(flags)))

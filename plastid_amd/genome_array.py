@@ -59,6 +59,29 @@ def _open_alignment_source(src, regions=None, engine=None, decode="auto"):
     return src
 
 
+class _DeviceAlignments(object):
+    """Stand-in for a BAM file whose records live in HBM only (``BAMGenomeArray(path, keep_reads=False)``): it knows
+    the header, the record and mapped-read counts -- not the reads."""
+
+    def __init__(self, path, references, lengths):
+        self.filename = path
+        self.references = list(references)
+        self.lengths = list(lengths)
+        self.mapped = 0
+        self.n = 0
+
+    def close(self):
+        pass
+
+    def _host_only(self, *args, **kwargs):
+        raise NotImplementedError(
+            "this BAMGenomeArray was opened with keep_reads=False: its reads live on the GPU only (count vectors, "
+            "get_reads_batch(as_indices=True), size filters); open it with keep_reads=True for read objects, "
+            "reads_out and arbitrary filter functions")
+
+    fetch = read = fetch_indices = _host_only
+
+
 def _pack_source(src, chroms, chrom_index):
     """Pack any alignment source into a :class:`PackedAlignments` whose ``tid``
     indexes `chroms` (the array's sorted chromosome list)."""
@@ -107,7 +130,19 @@ class BAMGenomeArray(object):
         # only where they overlap the regions, via their BAI index -- for a few loci of a large file
         # (the engine exists before the files are opened: large BAM files are inflated and decoded on its GPU)
         self._engine = Engine(kwargs.get("device", 0))
-        self.bamfiles = [_open_alignment_source(x, kwargs.get("regions"), self._engine, kwargs.get("decode", "auto")) for x in bamfiles]
+        # (extension) keep_reads=False: files named by path go from their bytes to staged alignments entirely on the GPU
+        # (Engine.add_bam: inflate, record decode and staging as kernels) -- the fastest way to count vectors; the reads
+        # themselves (reads_out as objects, arbitrary filter callables) then stay out of reach
+        self._device_only = kwargs.get("keep_reads", True) is False
+        if self._device_only:
+            from .bam import bam_header
+            if not bamfiles or not all(isinstance(x, str) for x in bamfiles) or kwargs.get("regions") is not None:
+                raise ValueError("keep_reads=False takes BAM files named by path, whole (no regions)")
+            self.bamfiles = [_DeviceAlignments(x, *bam_header(x)) for x in bamfiles]
+            if any(b.references != self.bamfiles[0].references for b in self.bamfiles):
+                raise ValueError("keep_reads=False needs the same reference list in every file")
+        else:
+            self.bamfiles = [_open_alignment_source(x, kwargs.get("regions"), self._engine, kwargs.get("decode", "auto")) for x in bamfiles]
         self._strands = ("+", "-", ".")
         self._normalize = False
         self._sum = None
@@ -125,9 +160,17 @@ class BAMGenomeArray(object):
             self._tid_names = list(self._chroms)
         self._chrom_index = {c: i for i, c in enumerate(self._tid_names)}
         self._filters = OrderedDict()
-        self._packed = [_pack_source(x, self._tid_names, self._chrom_index) for x in self.bamfiles]
-        self._engine.set_alignments(self._packed, ntid=max(len(self._tid_names), 1))
-        self._base_flags = [p.flags.copy() for p in self._packed]
+        if self._device_only:
+            self._packed = self.bamfiles
+            self._engine.clear_alignments()
+            for fi, b in enumerate(self.bamfiles):
+                b.mapped = self._engine.add_bam(b.filename)
+                b.n = self._engine.num_records(fi)
+            self._base_flags = None
+        else:
+            self._packed = [_pack_source(x, self._tid_names, self._chrom_index) for x in self.bamfiles]
+            self._engine.set_alignments(self._packed, ntid=max(len(self._tid_names), 1))
+            self._base_flags = [p.flags.copy() for p in self._packed]
         self._filters_dirty = False
         self._file_offsets = np.cumsum([0] + [p.n for p in self._packed])
         self.map_fn = None
@@ -220,13 +263,16 @@ class BAMGenomeArray(object):
                     size = f
                 else:
                     custom.append(f)
+            if custom and self._device_only:
+                self.bamfiles[0]._host_only()   # (arbitrary callables are evaluated on read objects the host does not have)
             self._custom_filters = custom
-            # verdicts of the callables per record: -1 not asked yet, 0 dropped, 1 kept
-            self._verdict = [np.full(packed.n, -1, np.int8) for packed in self._packed]
-            for fi, packed in enumerate(self._packed):
-                if not np.array_equal(self._base_flags[fi], packed.flags):
-                    packed.flags = self._base_flags[fi].copy()
-                    self._engine.update_flags(fi, packed.flags)
+            if not self._device_only:
+                # verdicts of the callables per record: -1 not asked yet, 0 dropped, 1 kept
+                self._verdict = [np.full(packed.n, -1, np.int8) for packed in self._packed]
+                for fi, packed in enumerate(self._packed):
+                    if not np.array_equal(self._base_flags[fi], packed.flags):
+                        packed.flags = self._base_flags[fi].copy()
+                        self._engine.update_flags(fi, packed.flags)
             self._size_filter_state = size
             self._filters_dirty = False
         if self._custom_filters:

@@ -451,3 +451,39 @@ def test_files_without_placed_reads_staged_on_the_device(tmp_path):
         plan.close()
         e.close()
         h.close()
+
+
+def test_bam_genome_array_without_host_reads(tmp_path):
+    """``BAMGenomeArray(path, keep_reads=False)``: the files go from bytes to staged alignments on the GPU; count
+    vectors, chains, normalisation, size filters and read indices equal those of the ordinary array; what needs read
+    objects says so."""
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.0003, tx_scale=0.01)
+    path = str(tmp_path / "dev.bam")
+    bam_writer.write_bam_realistic(path, reads, threads=4, level=6)
+    a = pa.BAMGenomeArray(path, mapping=pa.FivePrimeMapFactory(12))
+    b = pa.BAMGenomeArray(path, keep_reads=False, mapping=pa.FivePrimeMapFactory(12))
+    assert a.chroms() == b.chroms() and a.sum() == b.sum() == reads.n
+    chains = tx.chains(limit=30)
+    segs = [c[0] for c in chains[:10]]
+    for factory in (pa.FivePrimeMapFactory(12), pa.CenterMapFactory(0), pa.VariableFivePrimeMapFactory(synth.VARIABLE_OFFSETS)):
+        for ga in (a, b):
+            ga.set_mapping(factory)
+        for x, y in zip(a.get_counts_batch(chains), b.get_counts_batch(chains)):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+        for s_ in segs:
+            assert np.array_equal(np.asarray(a[s_]).view(np.uint64), np.asarray(b[s_]).view(np.uint64))
+    for ga in (a, b):
+        ga.set_mapping(pa.FivePrimeMapFactory(0))
+        ga.add_filter("size", pa.SizeFilterFactory(27, 31))
+        ga.set_normalize(True)
+    for x, y in zip(a.get_counts_batch(chains), b.get_counts_batch(chains)):
+        assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+    ia, ib = a.get_reads_batch(segs, as_indices=True), b.get_reads_batch(segs, as_indices=True)
+    assert len(ia) == len(ib) and all(len(p) == len(q) and all(np.array_equal(u[1], v[1]) for u, v in zip(p, q)) for p, q in zip(ia, ib))
+    with pytest.raises(NotImplementedError):
+        b.get_reads(segs[0])
+    with pytest.raises(NotImplementedError):
+        b.add_filter("mine", lambda read: True)
+        b[segs[0]]
+    with pytest.raises(ValueError):
+        pa.BAMGenomeArray(reads, keep_reads=False)
