@@ -654,12 +654,12 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
 // 64 contiguous slices, combined in order.  crc(A || B) = shift(crc(A), |B|) ^ crc(B) with the shift by a fixed slice
 // length applied through four 256-entry tables (computed by the host: `shift_tab[4][256]` for slices of kCrcSlice bytes).
 constexpr int kCrcSlice = 1056;   // 63 slices + a head cover the 64 KiB a member can hold
-__global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out, const Member *__restrict__ members, int nmembers,
+__global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ out, const Member *__restrict__ members, int first_member, int nmembers,
                                                  const uint32_t *__restrict__ crc_tab, const uint32_t *__restrict__ shift_tab,
                                                  uint32_t *__restrict__ status) {
     __shared__ uint32_t tab[256];
     __shared__ uint32_t part[64];
-    const int m = blockIdx.x;
+    const int m = first_member + (int)blockIdx.x;   // (the members of one upload piece, behind their inflate launch on the same stream)
     if (m >= nmembers) return;
     const Member mb = members[m];
     const int lane = threadIdx.x & 63;

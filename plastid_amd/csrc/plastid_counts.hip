@@ -3581,6 +3581,8 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             if (up != st) HIP_TRY(hipStreamWaitEvent(ks, landed.back(), 0));
             if (serial_symbols) hipLaunchKernelGGL(k_bgzf_inflate<false>, dim3((unsigned)(m1 - m0)), dim3(kInflWG), 0, ks, d_image.p, d_members.p, m0, m1, d_stream.p, d_status.p);
             else hipLaunchKernelGGL(k_bgzf_inflate<true>, dim3((unsigned)(m1 - m0)), dim3(kInflWG), 0, ks, d_image.p, d_members.p, m0, m1, d_stream.p, d_status.p);
+            // (the piece's CRC check right behind it, on the same stream: it runs while other pieces are still inflated)
+            hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)(m1 - m0)), dim3(64), 0, ks, d_stream.p, d_members.p, m0, m1, d_crc.p, d_crc.p + 256, d_status.p);
             byte0 = byte1;
             m0 = m1;
         }
@@ -3592,7 +3594,6 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             HIP_TRY(hipStreamWaitEvent(st, x, 0));
         }
         if (uploaded) (*uploaded)(up);
-        hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)nm), dim3(64), 0, st, d_stream.p, d_members.p, nm, d_crc.p, d_crc.p + 256, d_status.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(status.data(), d_status.p, (size_t)nm * 4, hipMemcpyDeviceToHost, st));
     }
