@@ -121,6 +121,21 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags);
 int pc_num_files(pc_engine *e);
 int64_t pc_num_records(pc_engine *e, int file);
 
+/* ---- read filters on the SAM FLAG word and MAPQ.  The reference's filter contract is "a function of the
+ * pysam.AlignedSegment" (BAMGenomeArray.add_filter, plastid/genomics/genome_array.py:697-722; every filter is called on
+ * every fetched read, :819-820).  Filters of the common kind -- `not read.is_secondary`, `not read.is_duplicate`,
+ * `read.mapping_quality >= 10`, `read.is_proper_pair` -- depend on two fields of the BAM record only (FLAG: u16 at
+ * byte 14, MAPQ: u8 at byte 9 of the record body, kent/src/htslib/sam.c bam_read1; bit names htslib/sam.h:110-132):
+ *   pc_set_alignment_sam   hands the engine those two columns of one staged file (3 bytes per record; files staged by
+ *                          pc_add_alignment_bam[_path] carry them already);
+ *   pc_set_flag_filter     a record is kept iff (flag & require) == require && (flag & exclude) == 0 && mapq >= min_mapq.
+ *                          Evaluated on the GPU in one pass per file and folded into the exclusion bit the counting
+ *                          kernels honour, on top of the caller's own PC_FLAG_EXCLUDED verdicts; enabled = 0 lifts it.
+ *                          PC_ERR_STATE if a staged file has records but no FLAG / MAPQ columns (also from pc_count,
+ *                          for a file staged after the filter was set). */
+int pc_set_alignment_sam(pc_engine *e, int file, int64_t n, const uint16_t *flag, const uint8_t *mapq);
+int pc_set_flag_filter(pc_engine *e, int enabled, uint32_t require, uint32_t exclude, int min_mapq);
+
 /* ---- mapping rule: replaces BAMGenomeArray.set_mapping (genome_array.py:935-963)
  * with one of the five factories.  `param` = offset (FIVE/THREE) or nibble
  * (CENTER).  fw/rc = forward_offsets/reverse_offsets[table_len] built on the
@@ -258,6 +273,9 @@ int32_t pc_bam_ref_length(pc_bam *b, int i);
 /* the columns, to caller-owned arrays of counts[0] / counts[1] / counts[4] elements (see pc_add_alignment_file_wide) */
 int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags, uint8_t *nblk, int32_t *blk_start,
                 int32_t *blk_len, int64_t *wide_idx, int32_t *wide_alen, int32_t *wide_nblk);
+/* the SAM FLAG word, MAPQ and l_seq of the same records (pysam: read.flag, .mapping_quality, .query_length -- what a
+ * filter function may look at, genome_array.py:697-722); any pointer may be NULL */
+int pc_bam_read_sam(pc_bam *b, uint16_t *flag, uint8_t *mapq, int32_t *lseq);
 int pc_bam_close(pc_bam *b);
 /* decode `image` and stage it as one more alignment file of the engine (reference ids = the file's own reference
  * list, which must be that of the files staged before it); *mapped (optional) = the file's mapped-read count */

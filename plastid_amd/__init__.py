@@ -8,7 +8,7 @@ ABI in ``include/plastid_counts.h``.  There is no CPU counting fallback.
 from .exceptions import DataWarning, EngineError, MalformedFileError  # noqa: F401
 from .packing import PackedAlignments  # noqa: F401
 from .roitools import GenomicSegment, SegmentChain  # noqa: F401
-from .map_factories import (CenterMapFactory, FivePrimeMapFactory, SizeFilterFactory,  # noqa: F401
+from .map_factories import (CenterMapFactory, FivePrimeMapFactory, FlagFilterFactory, SizeFilterFactory,  # noqa: F401
                             StratifiedVariableFivePrimeMapFactory, ThreePrimeMapFactory,
                             VariableFivePrimeMapFactory)
 from .genome_array import BAMGenomeArray, DenseGenomeArray  # noqa: F401

@@ -40,6 +40,8 @@ SIGNATURES = {
     "pc_add_alignment_file": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "pc_add_alignment_file_wide": (_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "pc_update_flags": (_int, [_vp, _int, _i64, _vp]),
+    "pc_set_alignment_sam": (_int, [_vp, _int, _i64, _vp, _vp]),
+    "pc_set_flag_filter": (_int, [_vp, _int, ctypes.c_uint32, ctypes.c_uint32, _int]),
     "pc_num_files": (_int, [_vp]),
     "pc_num_records": (_i64, [_vp, _int]),
     "pc_set_mapping": (_int, [_vp, _int, _int, _vp, _vp, _int, _int, _int]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "pc_bam_ref_name": (ctypes.c_char_p, [_vp, _int]),
     "pc_bam_ref_length": (_i32, [_vp, _int]),
     "pc_bam_read": (_int, [_vp] * 11),
+    "pc_bam_read_sam": (_int, [_vp, _vp, _vp, _vp]),
     "pc_bam_close": (_int, [_vp]),
     "pc_add_alignment_bam": (_int, [_vp, _vp, _i64, ctypes.c_char_p, ctypes.POINTER(_i64)]),
     "pc_bam_open_path": (_int, [_vp, ctypes.c_char_p, _pp]),

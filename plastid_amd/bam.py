@@ -40,6 +40,7 @@ def _load():
         L.pb_wide_count.restype = ctypes.c_int64
         L.pb_wide_count.argtypes = [vp]
         L.pb_fill_wide.argtypes = [vp] * 4
+        L.pb_fill_sam.argtypes = [vp] * 4
         _lib = L
     return _lib
 
@@ -128,6 +129,8 @@ def read_bam_gpu(path, engine, timing=None):
         wi, wa, wn = np.empty(nw, np.int64), np.empty(nw, np.int32), np.empty(nw, np.int32)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
         clib.check(L.pc_bam_read(h, p(tid), p(pos), p(alen), p(flags), p(nblk), p(bs), p(bl), p(wi), p(wa), p(wn)))
+        flag16, mapq, qlen = np.empty(n, np.uint16), np.empty(n, np.uint8), np.empty(n, np.int32)
+        clib.check(L.pc_bam_read_sam(h, p(flag16), p(mapq), p(qlen)))
         if timing is not None:
             timing.update(open_wall_ms=(t_open - t_0) * 1e3, read_wall_ms=(time.perf_counter() - t_open) * 1e3)
             ms = np.zeros(4, np.float64)
@@ -142,7 +145,7 @@ def read_bam_gpu(path, engine, timing=None):
             timing["close_ms"] = (time.perf_counter() - t_c) * 1e3
     wide = dict(wide_idx=wi, wide_alen=wa, wide_nblk=wn) if nw else {}
     out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
-                           validate=False, **wide)   # the device decoder has checked every invariant validate() checks
+                           validate=False, flag16=flag16, mapq=mapq, qlen=qlen, **wide)   # the device decoder has checked every invariant validate() checks
     out.filename = path
     return out
 
@@ -197,6 +200,9 @@ def read_bam(path, threads=0, regions=None):
             wi, wa, wn = np.empty(nw, np.int64), np.empty(nw, np.int32), np.empty(nw, np.int32)
             L.pb_fill_wide(h, p(wi), p(wa), p(wn))
             wide = dict(wide_idx=wi, wide_alen=wa, wide_nblk=wn)
+        # the SAM FLAG word, MAPQ and l_seq of every record: what read filters may look at (genome_array.py:697-722)
+        flag16, mapq, qlen = np.empty(n, np.uint16), np.empty(n, np.uint8), np.empty(n, np.int32)
+        L.pb_fill_sam(h, p(flag16), p(mapq), p(qlen))
     finally:
         L.pb_close(h)
     if mapped < 0:   # an index without the per-reference counts samtools writes
@@ -204,6 +210,6 @@ def read_bam(path, threads=0, regions=None):
         warnings.warn("the BAI index of %s carries no mapped-read counts; using the number of alignments read" % path)
         mapped = n
     out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
-                           validate=False, **wide)   # the native reader has checked every invariant validate() checks
+                           validate=False, flag16=flag16, mapq=mapq, qlen=qlen, **wide)   # the native reader has checked every invariant validate() checks
     out.filename = path
     return out

@@ -6,8 +6,14 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "plastid_counts.hip")
-HDRS = [os.path.join(HERE, "csrc", "pc_kernels.hip.h"), os.path.join(HERE, "csrc", "host_util.h"),
+def _headers():
+    """Every header the library is compiled from: all of ``csrc/*.h`` plus the public header."""
+    csrc = os.path.join(HERE, "csrc")
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")) + [
         os.path.join(ROOT, "include", "plastid_counts.h")]
+
+
+HDRS = _headers()
 LIB = os.path.join(HERE, "libplastid_counts.so")
 
 HIPCC_FLAGS = [
@@ -45,7 +51,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in [SRC] + HDRS)
+    return any(os.path.getmtime(f) > t for f in [SRC] + _headers())
 
 
 def build_library(force=False, verbose=False, extra_flags=(), out=None):

@@ -106,7 +106,9 @@ __device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table
         code = (code + ws->count[len - 1]) << 1;   // first code of this length
         if (lane == 0) ws->next[len] = code;
     }
-    if (left > 0 && (KIND == 2 || maxlen != 1)) return kInfOverSubscribed;   // incomplete code: only a single one-bit code may be (zlib inftrees.c: `left > 0 && (type == CODES || max != 1)`)
+    // no symbols at all (zlib inftrees.c: `if (max == 0)` -> a table of invalid-code markers, no error): a literal-only
+    // dynamic block may declare one distance code of length zero; any lookup in the cleared table is a "bad symbol"
+    if (maxlen != 0 && left > 0 && (KIND == 2 || maxlen != 1)) return kInfOverSubscribed;   // incomplete code: only a single one-bit code may be (zlib inftrees.c: `left > 0 && (type == CODES || max != 1)`)
     // clear the first level (an incomplete distance code leaves holes: they decode as "bad symbol")
     for (int i = lane; i < (1 << root); i += 64) { table[i] = 0u; if (i < 512) ws->subbits[i] = 0; }
     __syncthreads();
@@ -313,7 +315,12 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     int nb = 0;                   // valid bits in it
     auto refill = [&]() {         // at least 32 valid bits afterwards (zeros behind the end of the stream)
         if (nb <= 32) {
-            if (in_pos + kInHalf + 4u > in_loaded) stage_half();   // the reader entered the last staged half: fetch the next (zeros behind the end)
+            // Stage the next half only when the reader is within kInHalf - 8 bytes of the staged end: staging overwrites the
+            // ring slots of [in_loaded - kInBytes, in_loaded - kInHalf), and the 8 bytes below in_pos must stay in the ring --
+            // the bit buffer may still hold up to 64 unread bits of them when the batch decoder takes over and re-reads the
+            // stream from its bit position p = 8 in_pos - nb (invariant: in_pos - 8 >= in_loaded - kInBytes whenever a
+            // block's symbols start).  (Zeros behind the end of the stream.)
+            if (in_pos + kInHalf - 8u >= in_loaded) stage_half();
             // (every lane reads the same word: readfirstlane tells the compiler so, and what follows stays on the scalar unit)
             const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.in[(in_pos >> 2) & (kInBytes / 4 - 1)]);
             bb |= (unsigned long long)w << nb;
@@ -785,6 +792,8 @@ struct RecOut {
     uint16_t flag;
     uint8_t err;
     uint8_t placed;
+    int32_t lseq;               // l_seq (pysam's query_length)
+    uint32_t mapq;
 };
 
 // One thread per record start (member-major, k_bam_chain's order): fields and CIGAR -> RecOut.
@@ -799,7 +808,7 @@ __global__ __launch_bounds__(256) void k_bam_fields(const uint8_t *__restrict__ 
     while (m + 1 < nmembers && (int64_t)rec_base[m + 1] <= i) ++m;
     const uint64_t q = members[m].uoff + rec_off[(size_t)m * kMaxRecPerMember + (size_t)(i - (int64_t)rec_base[m])];
     RecOut o;
-    o.tid = -1; o.spos = 0; o.pos = 0; o.L = 0; o.nruns = 0; o.flag = 0; o.err = kRecOk; o.placed = 0;
+    o.tid = -1; o.spos = 0; o.pos = 0; o.L = 0; o.nruns = 0; o.flag = 0; o.err = kRecOk; o.placed = 0; o.lseq = 0; o.mapq = 0;
     if (q + 4 > stream_len) { o.err = kRecTruncated; recs[i] = o; return; }
     const uint32_t bs = ld32(stream + q);
     if (bs < 32) { o.err = kRecBadSize; recs[i] = o; return; }
@@ -808,6 +817,8 @@ __global__ __launch_bounds__(256) void k_bam_fields(const uint8_t *__restrict__ 
     const int32_t tid = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
     const uint32_t l_name = r[8], n_cig = ld16(r + 12);
     o.flag = (uint16_t)ld16(r + 14);
+    o.mapq = r[9];
+    o.lseq = (int32_t)ld32(r + 16);
     o.tid = tid; o.pos = pos; o.spos = pos;
     if (tid < 0) { recs[i] = o; return; }                   // unplaced: counted, not staged
     o.placed = 1;
@@ -865,7 +876,8 @@ __global__ __launch_bounds__(256) void k_bam_columns(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ rec_member, const RecOut *__restrict__ recs, int64_t nrec,
                                                      const uint32_t *__restrict__ staged_at, const uint32_t *__restrict__ run_at,
                                                      int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags, uint8_t *nblk,
-                                                     int32_t *blk_start, int32_t *blk_len, uint32_t *wide_flag) {
+                                                     int32_t *blk_start, int32_t *blk_len, uint32_t *wide_flag,
+                                                     uint16_t *flag16, uint8_t *mapq, int32_t *lseq) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nrec) return;
     const RecOut o = recs[i];
@@ -877,6 +889,9 @@ __global__ __launch_bounds__(256) void k_bam_columns(const uint8_t *__restrict__
     alen[k] = wide ? (uint16_t)65535 : (uint16_t)o.L;
     flags[k] = (o.flag & 0x10) ? 1 : 0;
     nblk[k] = wide ? (uint8_t)255 : (uint8_t)o.nruns;
+    flag16[k] = o.flag;
+    mapq[k] = (uint8_t)o.mapq;
+    lseq[k] = o.lseq;
     if (wide) wide_flag[k] = 1u;
     if (o.nruns < 2u) return;
     int m = (int)rec_member[i >> 8];

@@ -53,6 +53,11 @@ struct Part {
     int32_t *tid = nullptr, *pos = nullptr, *blk_start = nullptr, *blk_len = nullptr;
     uint16_t *alen = nullptr;
     uint8_t *flags = nullptr, *nblk = nullptr;
+    // what a read filter may look at beyond strand and length (genome_array.py:697-722: filters take the pysam read):
+    // the SAM FLAG word, MAPQ and l_seq (pysam's query_length) of every staged record
+    uint16_t *flag16 = nullptr;
+    uint8_t *mapq = nullptr;
+    int32_t *lseq = nullptr;
     size_t n = 0, nrun = 0;
     int64_t mapped = 0, unplaced = 0, total = 0;
     // wide records of the piece (more than 65 535 aligned positions or more than 255 aligned runs: markers 65535 / 255 in
@@ -151,12 +156,14 @@ struct Arena {
 // finished columns are copied into the Arena at their exact size).
 struct Cols {
     std::vector<int32_t> tid, pos, blk_start, blk_len;
-    std::vector<uint16_t> alen;
-    std::vector<uint8_t> flags, nblk;
+    std::vector<uint16_t> alen, flag16;
+    std::vector<uint8_t> flags, nblk, mapq;
+    std::vector<int32_t> lseq;
     size_t n = 0;   // records held: the five per-record columns are sized for the piece up front and written by index
     void clear() { n = 0; blk_start.clear(); blk_len.clear(); }
     void room(size_t records) {
-        if (tid.size() < records) { tid.resize(records); pos.resize(records); alen.resize(records); flags.resize(records); nblk.resize(records); }
+        if (tid.size() < records) { tid.resize(records); pos.resize(records); alen.resize(records); flags.resize(records); nblk.resize(records);
+                                      flag16.resize(records); mapq.resize(records); lseq.resize(records); }
     }
 };
 
@@ -354,7 +361,9 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
     // the compiler has to assume that every store may change them) and is written back on the way out
     int32_t *const c_tid = cols.tid.data(), *const c_pos = cols.pos.data();
     uint16_t *const c_alen = cols.alen.data();
-    uint8_t *const c_flags = cols.flags.data(), *const c_nblk = cols.nblk.data();
+    uint8_t *const c_flags = cols.flags.data(), *const c_nblk = cols.nblk.data(), *const c_mapq = cols.mapq.data();
+    uint16_t *const c_flag16 = cols.flag16.data();
+    int32_t *const c_lseq = cols.lseq.data();
     size_t n = 0;
     int64_t total = pt.total, mapped = pt.mapped, unplaced = pt.unplaced;
     bool any_placed = pt.any_placed, saw_unplaced = pt.saw_unplaced;
@@ -372,8 +381,9 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         const uint8_t *r = q + 4;
         q = r + block_size;
         const int32_t tid = (int32_t)rd32(r), pos = (int32_t)rd32(r + 4);
-        const uint8_t l_read_name = r[8];
+        const uint8_t l_read_name = r[8], mapq = r[9];
         const uint16_t n_cigar = rd16(r + 12), flag = rd16(r + 14);
+        const int32_t l_seq = (int32_t)rd32(r + 16);
         total += 1;
         if (!(flag & 0x4)) mapped += 1;
         if (tid < 0) { // unplaced reads sit at the end of a sorted BAM; fetch() never returns them
@@ -409,6 +419,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
                 c_alen[n] = (uint16_t)len;
                 c_flags[n] = (flag & 0x10) ? 1 : 0;
                 c_nblk[n] = 1;
+                c_flag16[n] = flag; c_mapq[n] = mapq; c_lseq[n] = l_seq;
                 ++n;
                 continue;
             }
@@ -458,6 +469,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         c_alen[n] = wide ? (uint16_t)65535 : (uint16_t)L;
         c_flags[n] = (flag & 0x10) ? 1 : 0;
         c_nblk[n] = wide ? (uint8_t)255 : (uint8_t)runs.size();
+        c_flag16[n] = flag; c_mapq[n] = mapq; c_lseq[n] = l_seq;
         ++n;
         if (runs.size() >= 2)
             for (auto &x : runs) {
@@ -478,7 +490,7 @@ const uint8_t *decode_span(Bam &bam, Part &pt, const uint8_t *q, const uint8_t *
     // the finished columns, at their exact size, into the load's arena
     const size_t n = cols.n, m = cols.blk_start.size();
     if (n) {
-        uint8_t *mem = (uint8_t *)bam.arena.alloc(n * 12 + 64 * 5 + m * 8 + 64 * 2);
+        uint8_t *mem = (uint8_t *)bam.arena.alloc(n * 19 + 64 * 8 + m * 8 + 64 * 2);
         if (!mem) {
             if (pt.err_rec == INT64_MAX) { pt.err_rec = 0; pt.err_before_order = true; pt.err = "out of memory reading " + bam.path; }
             return stop;
@@ -488,6 +500,8 @@ const uint8_t *decode_span(Bam &bam, Part &pt, const uint8_t *q, const uint8_t *
         pt.flags = take(n); pt.nblk = take(n);
         std::memcpy(pt.tid, cols.tid.data(), n * 4); std::memcpy(pt.pos, cols.pos.data(), n * 4);
         std::memcpy(pt.alen, cols.alen.data(), n * 2); std::memcpy(pt.flags, cols.flags.data(), n); std::memcpy(pt.nblk, cols.nblk.data(), n);
+        pt.flag16 = (uint16_t *)take(n * 2); pt.mapq = take(n); pt.lseq = (int32_t *)take(n * 4);
+        std::memcpy(pt.flag16, cols.flag16.data(), n * 2); std::memcpy(pt.mapq, cols.mapq.data(), n); std::memcpy(pt.lseq, cols.lseq.data(), n * 4);
         if (m) {
             pt.blk_start = (int32_t *)take(m * 4); pt.blk_len = (int32_t *)take(m * 4);
             std::memcpy(pt.blk_start, cols.blk_start.data(), m * 4); std::memcpy(pt.blk_len, cols.blk_len.data(), m * 4);
@@ -1070,6 +1084,7 @@ int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, c
                                            : (int64_t)pt.pos[i] + std::max<int64_t>(L, 1);
             if (overlaps(pt.tid[i], pt.pos[i], endpos)) {
                 pt.tid[w] = pt.tid[i]; pt.pos[w] = pt.pos[i]; pt.alen[w] = pt.alen[i]; pt.flags[w] = pt.flags[i]; pt.nblk[w] = pt.nblk[i];
+                pt.flag16[w] = pt.flag16[i]; pt.mapq[w] = pt.mapq[i]; pt.lseq[w] = pt.lseq[i];
                 for (size_t k = 0; k < runs; ++k) { pt.blk_start[rw + k] = pt.blk_start[rr + k]; pt.blk_len[rw + k] = pt.blk_len[rr + k]; }
                 if (wide) { pt.wide_idx[ww] = (int64_t)w; pt.wide_alen[ww] = pt.wide_alen[wk]; pt.wide_nblk[ww] = pt.wide_nblk[wk]; ++ww; }
                 ++w;
@@ -1235,6 +1250,24 @@ int pb_fill(void *h, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags,
     for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
     worker();
     for (auto &t : pool) t.join();
+    return 0;
+}
+
+
+// The SAM FLAG word, MAPQ and l_seq of every staged record (same order as pb_fill's columns): what pysam exposes as
+// read.flag / .mapping_quality / .query_length (and the is_* properties derived from the flag bits) to the filter
+// functions of BAMGenomeArray.add_filter (genome_array.py:697-722).  Any pointer may be NULL.
+int pb_fill_sam(void *h, uint16_t *flag16, uint8_t *mapq, int32_t *lseq) {
+    Bam *b = static_cast<Bam *>(h);
+    if (!b || !b->loaded) return fail("pb_fill_sam: file not loaded");
+    for (size_t k = 0; k < b->parts.size(); ++k) {
+        const Part &pt = b->parts[k];
+        const size_t at = b->rec_off[k], n = pt.n;
+        if (!n) continue;
+        if (flag16) std::memcpy(flag16 + at, pt.flag16, n * 2);
+        if (mapq) std::memcpy(mapq + at, pt.mapq, n);
+        if (lseq) std::memcpy(lseq + at, pt.lseq, n * 4);
+    }
     return 0;
 }
 

@@ -30,6 +30,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The kernels use gfx950 encodings directly (64-bit DPP with row_newbcast in k_center's replay, fixed wave64 layouts):
+// any other offload architecture is rejected here rather than at assembly time.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "plastid_amd is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace pc {
 
 constexpr int kWG = 256;          // 4 waves of 64
@@ -54,10 +60,13 @@ constexpr int kWG = 256;          // 4 waves of 64
 constexpr int kHistWG = PC_HIST_WG;
 constexpr int kWave = 64;
 constexpr uint32_t kFlagReverse = 0x01;
+constexpr uint32_t kFlagUser = 0x08;      // engine-internal: excluded by the CALLER's own filters (the PC_FLAG_EXCLUDED it staged); kFlagExcluded = this OR the verdict of the FLAG / MAPQ filter (pc_set_flag_filter)
 constexpr uint32_t kFlagWide = 0x10;      // engine-internal: aligned length > 65 535 or > 255 runs -- the 16 / 8-bit fields read 65535 / 255, true values aside
 constexpr uint32_t kFlagRuns = 0x20;      // engine-internal: every aligned run of the record is in the run stream
 constexpr uint32_t kFlagLong = 0x40;      // engine-internal: span > W, handled by the long-read path
 constexpr uint32_t kFlagExcluded = 0x80;
+// the flag byte of a staged record from the caller's PC_FLAG_* bits
+__host__ __device__ inline uint32_t caller_flags(uint32_t f) { return (f & kFlagReverse) | ((f & kFlagExcluded) ? (kFlagExcluded | kFlagUser) : 0u); }
 constexpr int kGatherChunk = 1024;
 constexpr int kLinShift = 7;              // linear-index bucket = 128 genome positions
 constexpr int kStreamMaxLen = 255;        // aligned lengths the 4-byte record stream can carry
@@ -2097,9 +2106,32 @@ __global__ __launch_bounds__(kWG) void k_update_flags(uint2 *rec, uint32_t *stre
                                                       int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (i >= n) return;
-    const uint32_t keep = ~((kFlagReverse | kFlagExcluded) << 16);
+    const uint32_t keep = ~((kFlagReverse | kFlagExcluded | kFlagUser) << 16);
     uint2 r = rec[i];
-    r.y = (r.y & keep) | ((uint32_t)(flags[i] & (kFlagReverse | kFlagExcluded)) << 16);
+    r.y = (r.y & keep) | (caller_flags(flags[i]) << 16);
+    rec[i] = r;
+    stream[i] = stream_word(r.x, r.y);
+}
+
+// The vectorised read filter on the SAM FLAG word and MAPQ (pc_set_flag_filter): a record stays iff
+// (flag & require) == require, (flag & exclude) == 0 and mapq >= min_mapq -- what a filter function such as
+// `lambda read: not read.is_secondary and read.mapping_quality >= 10` decides per read on the host
+// (genome_array.py:697-722, applied :819-820), here one pass over 3 bytes per record in HBM.  The caller's own
+// exclusions (kFlagUser) stay; `enabled` = 0 restores them alone.
+__global__ __launch_bounds__(kWG) void k_flag_filter(uint2 *rec, uint32_t *stream, const uint16_t *__restrict__ sam_flag,
+                                                     const uint8_t *__restrict__ mapq, int64_t n, uint32_t enabled, uint32_t require,
+                                                     uint32_t exclude, uint32_t min_mapq) {
+    const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (i >= n) return;
+    uint2 r = rec[i];
+    bool out = ((r.y >> 16) & kFlagUser) != 0u;
+    if (enabled) {
+        const uint32_t f = sam_flag[i];
+        out = out || (f & require) != require || (f & exclude) != 0u || (uint32_t)mapq[i] < min_mapq;
+    }
+    const uint32_t y = (r.y & ~(kFlagExcluded << 16)) | (out ? kFlagExcluded << 16 : 0u);
+    if (y == r.y) return;
+    r.y = y;
     rec[i] = r;
     stream[i] = stream_word(r.x, r.y);
 }

@@ -214,6 +214,9 @@ template <typename T> struct DevBuf {
         return PC_OK;
     }
     int upload(const std::vector<T> &v, hipStream_t s) { return upload(v.data(), v.size(), s); }
+    void swap(DevBuf &o) {
+        std::swap(p, o.p); std::swap(cap, o.cap); std::swap(pool, o.pool); std::swap(pool_class, o.pool_class); std::swap(big_bytes, o.big_bytes);
+    }
 };
 
 // Page-locked host buffer that only grows.
@@ -329,6 +332,11 @@ struct StagedFile {
     int64_t nwide = 0;
     DevBuf<uint2> long_wide, xlong_wide, wide_val;
     DevBuf<uint32_t> wide_rec;
+    // SAM FLAG word and MAPQ of every record (pc_set_alignment_sam, or straight from the device decoder): what the
+    // vectorised FLAG / MAPQ filter reads
+    DevBuf<uint16_t> sam_flag;
+    DevBuf<uint8_t> sam_mapq;
+    bool have_sam = false;
     // center streams (built at the first center-rule count that needs them; dropped when the host-side filters change)
     DevBuf<uint2> cs_ent[3];
     DevBuf<uint32_t> cs_soff[3];
@@ -429,6 +437,8 @@ struct pc_engine {
     // scratch for counting
     DevBuf<uint32_t> d_counters; // [1] unmappable count, [7] sink of the stream probe, [12] exact-grid guard (work counts: pc_plan::d_wcounters)
     DevBuf<uint8_t> d_flags;     // staging buffer of pc_update_flags
+    bool ff_on = false;          // pc_set_flag_filter: keep (flag & require) == require && (flag & exclude) == 0 && mapq >= min_mapq
+    uint32_t ff_require = 0, ff_exclude = 0, ff_min_mapq = 0;
     bool pinned_busy = false;
     PinnedBuf pinned;            // host side of the plan-table upload (reused: ev_pinned is waited for before it is rewritten)
     PinnedBuf bam_ring[2];       // page-locked halves the image of a large BAM file crosses PCIe through (filled by all host threads)
@@ -1457,7 +1467,7 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
                                 a.span_hist[(size_t)L] += 1;
                                 emax = std::max(emax, (int64_t)pos[i + k] + L);
                                 sb.rec[j0 + k] = make_uint2((uint32_t)pos[i + k], (uint32_t)L | (1u << 24) |
-                                                            ((uint32_t)(flags[i + k] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16));
+                                                            (caller_flags(flags[i + k]) << 16));
                             }
                             max_span = std::max<int64_t>(max_span, hi8);
                             a.tid_count[(size_t)t0 + 1] += 8;
@@ -1502,8 +1512,8 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
                     a.span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
                     a.len_hist[(size_t)std::min<int64_t>(L, 65535)] += 1;
                     max_span = std::max(max_span, sp);
-                    uint32_t meta = (uint32_t)L | ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 16) | ((uint32_t)nb << 24);
-                    if (wi >= 0) meta = 0xffffu | ((uint32_t)((flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) | kFlagWide) << 16) | (0xffu << 24);
+                    uint32_t meta = (uint32_t)L | (caller_flags(flags[i]) << 16) | ((uint32_t)nb << 24);
+                    if (wi >= 0) meta = 0xffffu | ((caller_flags(flags[i]) | kFlagWide) << 16) | (0xffu << 24);
                     // multi-run reads of ordinary length: every aligned run goes to the run stream (what the
                     // point rules scan); only longer reads keep to the gapped / long-span side lists there
                     const bool in_runs = nb >= 2 && L <= kStreamMaxLen && wi < 0;
@@ -1514,7 +1524,7 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
                         for (int64_t k = 0; k < nb; ++k) {
                             const uint32_t rs = (uint32_t)blk_start[boff + k], rl = (uint32_t)blk_len[boff + k];
                             sb.run_val[(size_t)(run_at - run0)] = make_uint2(rs, rl | (cum << 8) | ((uint32_t)L << 16) |
-                                                                                     ((uint32_t)(flags[i] & (PC_FLAG_REVERSE | PC_FLAG_EXCLUDED)) << 24));
+                                                                                     (caller_flags(flags[i]) << 24));
                             sb.run_idx[(size_t)(run_at - run0)] = (uint32_t)i;
                             ++run_at;
                             Wr = std::max(Wr, (int)rl);
@@ -1858,6 +1868,8 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
     return PC_OK;
 }
 
+static int propagate_record_flags(pc_engine *e, StagedFile *sf);
+
 int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     if (!e || file < 0 || file >= (int)e->files.size()) return fail(PC_ERR_ARG, "pc_update_flags: bad file index");
     StagedFile *sf = e->files[file];
@@ -1871,6 +1883,19 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     HIP_TRY(hipMemcpyAsync(e->d_flags.p, flags, (size_t)n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_update_flags, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, sf->stream.p,
                        e->d_flags.p, n);
+    if (e->ff_on && sf->have_sam)   // the FLAG / MAPQ filter's verdicts on top of the caller's
+        hipLaunchKernelGGL(k_flag_filter, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, sf->stream.p, sf->sam_flag.p,
+                           sf->sam_mapq.p, n, 1u, e->ff_require, e->ff_exclude, e->ff_min_mapq);
+    const int prc = propagate_record_flags(e, sf);
+    if (prc != PC_OK) return prc;
+    HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
+    return PC_OK;
+}
+
+// The strand / excluded bits of the packed records have changed: copy them into every other staged form of the
+// headers (side lists, run stream), drop what was derived from them (center streams, work lists).  Asynchronous.
+static int propagate_record_flags(pc_engine *e, StagedFile *sf) {
+    hipStream_t st = e->stream;
     if (sf->nlong)
         hipLaunchKernelGGL(k_update_side_flags, dim3((unsigned)((sf->nlong + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->long_rec.p,
                            sf->nlong, sf->rec.p);
@@ -1884,10 +1909,65 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
         hipLaunchKernelGGL(k_update_run_flags, dim3((unsigned)((sf->nrunrec + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->run_rec.p,
                            sf->run_recidx.p, sf->nrunrec, sf->rec.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
     for (int k = 0; k < 3; ++k) sf->cs_n[k] = -1;   // the center streams leave excluded reads out: rebuilt at the next center count
     e->files_dirty = true;
     e->work_generation += 1;
+    return PC_OK;
+}
+
+// (re-)apply the engine's FLAG / MAPQ filter to one staged file
+static int apply_flag_filter(pc_engine *e, StagedFile *sf) {
+    if (sf->n == 0) return PC_OK;
+    if (e->ff_on && !sf->have_sam)
+        return fail(PC_ERR_STATE, "a FLAG / MAPQ filter is set but an alignment file was staged without its FLAG / MAPQ columns (pc_set_alignment_sam)");
+    if (!sf->have_sam && !e->ff_on) {
+        // nothing to read the verdicts from, and nothing to undo: a file without the columns never had the filter applied
+        return PC_OK;
+    }
+    hipLaunchKernelGGL(k_flag_filter, dim3((unsigned)((sf->n + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, sf->rec.p, sf->stream.p,
+                       sf->sam_flag.p, sf->sam_mapq.p, sf->n, e->ff_on ? 1u : 0u, e->ff_require, e->ff_exclude, e->ff_min_mapq);
+    return propagate_record_flags(e, sf);
+}
+
+int pc_set_alignment_sam(pc_engine *e, int file, int64_t n, const uint16_t *flag, const uint8_t *mapq) {
+    if (!e || file < 0 || file >= (int)e->files.size()) return fail(PC_ERR_ARG, "pc_set_alignment_sam: bad file index");
+    StagedFile *sf = e->files[file];
+    if (n != sf->n || (n > 0 && (!flag || !mapq))) return fail(PC_ERR_ARG, "pc_set_alignment_sam: wrong record count");
+    HIP_TRY(hipSetDevice(e->device));
+    if (n > 0) {
+        PoolScope pool_scope(&e->pool);
+        int rc = sf->sam_flag.reserve((size_t)n);
+        if (rc == PC_OK) rc = sf->sam_mapq.reserve((size_t)n);
+        if (rc != PC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(sf->sam_flag.p, flag, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(sf->sam_mapq.p, mapq, (size_t)n, hipMemcpyHostToDevice, e->stream));
+    }
+    sf->have_sam = true;
+    int rc = PC_OK;
+    if (e->ff_on) rc = apply_flag_filter(e, sf);
+    HIP_TRY(hipStreamSynchronize(e->stream));   // the caller's arrays may go away
+    return rc;
+}
+
+int pc_set_flag_filter(pc_engine *e, int enabled, uint32_t require, uint32_t exclude, int min_mapq) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    if (enabled && (require > 0xffffu || exclude > 0xffffu || min_mapq < 0 || min_mapq > 255))
+        return fail(PC_ERR_ARG, "pc_set_flag_filter: FLAG masks are 16-bit, MAPQ is 0 .. 255");
+    if (enabled)
+        for (size_t f = 0; f < e->files.size(); ++f)
+            if (e->files[f]->n > 0 && !e->files[f]->have_sam)
+                return fail(PC_ERR_STATE, "pc_set_flag_filter: alignment file %d was staged without its FLAG / MAPQ columns (pc_set_alignment_sam)", (int)f);
+    HIP_TRY(hipSetDevice(e->device));
+    const bool was_on = e->ff_on;
+    const bool same = was_on == (enabled != 0) && (!enabled || (e->ff_require == require && e->ff_exclude == exclude && e->ff_min_mapq == (uint32_t)min_mapq));
+    if (same) return PC_OK;
+    e->ff_on = enabled != 0;
+    e->ff_require = enabled ? require : 0u; e->ff_exclude = enabled ? exclude : 0u; e->ff_min_mapq = enabled ? (uint32_t)min_mapq : 0u;
+    for (StagedFile *sf : e->files) {
+        if (!sf->have_sam) continue;
+        const int rc = apply_flag_filter(e, sf);
+        if (rc != PC_OK) return rc;
+    }
     return PC_OK;
 }
 
@@ -2460,6 +2540,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     if (e->files.empty()) return fail(PC_ERR_STATE, "pc_count: no alignments staged (pc_add_alignment_file)");
     if (out_dtype != PC_OUT_INT64 && out_dtype != PC_OUT_FLOAT64) return fail(PC_ERR_ARG, "pc_count: bad out_dtype");
     if (p->rows != e->rows) return fail(PC_ERR_ARG, "pc_count: plan built for %d rows, mapping rule has %d", p->rows, e->rows);
+    if (e->ff_on)   // a file staged after pc_set_flag_filter gets its verdicts when its columns arrive: not counted without them
+        for (size_t f = 0; f < e->files.size(); ++f)
+            if (e->files[f]->n > 0 && !e->files[f]->have_sam)
+                return fail(PC_ERR_STATE, "pc_count: a FLAG / MAPQ filter is set but alignment file %d has no FLAG / MAPQ columns (pc_set_alignment_sam)", (int)f);
     const bool center = e->kind == PC_MAP_CENTER;
     if ((center || e->norm_on) && out_dtype != PC_OUT_FLOAT64)
         return fail(PC_ERR_ARG, "pc_count: center mapping / normalisation produce float64 (map_factories.pyx:230, genome_array.py:826-827)");
@@ -3303,6 +3387,9 @@ struct pc_bam {
     DevBuf<int32_t> tid, pos, blk_start, blk_len;
     DevBuf<uint16_t> alen;
     DevBuf<uint8_t> flags, nblk;
+    DevBuf<uint16_t> flag16;           // the SAM FLAG word, MAPQ and l_seq of every staged record (pc_bam_read_sam; the
+    DevBuf<uint8_t> mapq;              // first two stay with the staged file for the FLAG / MAPQ filter)
+    DevBuf<int32_t> lseq;
     std::vector<int64_t> wide_idx;
     std::vector<int32_t> wide_alen, wide_nblk;
     double ms[4] = {0, 0, 0, 0};     // upload, inflate (+ CRC), record chain, fields + columns
@@ -3498,6 +3585,18 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
     if (rc == PC_OK) rc = d_status.reserve((size_t)std::max(nm, 1));
     if (rc == PC_OK) rc = d_crc.reserve(5 * 256);
     if (rc != PC_OK) return rc;
+    // An early return between here and the synchronisation behind the inflate launches must not hand the image, the
+    // stream buffer or the page-locked ring back (nor let the caller unmap the file) while the side / auxiliary streams
+    // still use them: drain every stream the decoder queues on before the buffers above go out of scope.
+    struct Drain {
+        pc_engine *e; bool armed;
+        ~Drain() {
+            if (!armed) return;
+            if (e->side_stream) (void)hipStreamSynchronize(e->side_stream);
+            for (int k = 0; k < pc_engine::kAux; ++k) if (e->aux_stream[k]) (void)hipStreamSynchronize(e->aux_stream[k]);
+            (void)hipStreamSynchronize(e->stream);
+        }
+    } drain{e, true};
     clk.lap("allocations (image, stream)");
     HIP_TRY(hipEventRecord(ev[0], st));
     if (nm) HIP_TRY(hipMemcpyAsync(d_members.p, members.data(), (size_t)nm * sizeof(Member), hipMemcpyHostToDevice, st));
@@ -3599,6 +3698,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
     }
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipStreamSynchronize(st));
+    drain.armed = false;   // (the main stream went on behind the side and auxiliary ones: all of them have drained)
     clk.lap("upload + inflate + crc (sync)");
     for (int m = 0; m < nm; ++m)
         if (status[(size_t)m]) {
@@ -3688,8 +3788,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             from = redo;
             if (round > nm + 8) return fail(PC_ERR_STATE, "pc_bam_open: the record chain of %s did not settle", path.c_str());
         }
-        if (!truncated && expected != total_u) truncated = expected > total_u || true;   // the last record runs past (or stops short of) the end of the stream
-        if (!truncated) {}
+        if (expected != total_u) truncated = true;   // the last record runs past (or stops short of) the end of the stream
         for (int m = 0; m < nm; ++m) rec_base[(size_t)m + 1] = rec_base[(size_t)m] + nrec_of[(size_t)m];
         nrec = (int64_t)rec_base[(size_t)nm];
     } else if (total_u != first_record) truncated = true;
@@ -3768,13 +3867,17 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
         if (rc == PC_OK) rc = b->alen.reserve((size_t)std::max<int64_t>(n_staged, 1));
         if (rc == PC_OK) rc = b->flags.reserve((size_t)std::max<int64_t>(n_staged, 1));
         if (rc == PC_OK) rc = b->nblk.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->flag16.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->mapq.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->lseq.reserve((size_t)std::max<int64_t>(n_staged, 1));
         if (rc == PC_OK) rc = b->blk_start.reserve((size_t)std::max<int64_t>(n_runs, 1));
         if (rc == PC_OK) rc = b->blk_len.reserve((size_t)std::max<int64_t>(n_runs, 1));
         if (rc == PC_OK) rc = d_wide.reserve((size_t)std::max<int64_t>(n_staged, 1));
         if (rc != PC_OK) return rc;
         HIP_TRY(hipMemsetAsync(d_wide.p, 0, (size_t)std::max<int64_t>(n_staged, 1) * 4, st));
         hipLaunchKernelGGL(k_bam_columns, dim3(g256), dim3(256), 0, st, d_stream.p, d_members.p, d_rec_base.p, d_rec_off.p, nm, d_rec_member.p, d_recs.p,
-                           nrec, d_staged_at.p, d_run_at.p, b->tid.p, b->pos.p, b->alen.p, b->flags.p, b->nblk.p, b->blk_start.p, b->blk_len.p, d_wide.p);
+                           nrec, d_staged_at.p, d_run_at.p, b->tid.p, b->pos.p, b->alen.p, b->flags.p, b->nblk.p, b->blk_start.p, b->blk_len.p, d_wide.p,
+                           b->flag16.p, b->mapq.p, b->lseq.p);
         HIP_TRY(hipGetLastError());
         // wide records (beyond the 16-bit / 8-bit columns): rare -- their staged indices are found from the markers on
         // the host side of pc_bam_read; the true values are read back here, record by record
@@ -3864,6 +3967,20 @@ int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *
     return PC_OK;
 }
 
+int pc_bam_read_sam(pc_bam *b, uint16_t *flag, uint8_t *mapq, int32_t *lseq) {
+    if (!b) return fail(PC_ERR_ARG, "pc_bam_read_sam: NULL handle");
+    HIP_TRY(hipSetDevice(b->e->device));
+    hipStream_t st = b->e->stream;
+    const size_t n = (size_t)b->n;
+    if (n) {
+        if (flag) HIP_TRY(hipMemcpyAsync(flag, b->flag16.p, n * 2, hipMemcpyDeviceToHost, st));
+        if (mapq) HIP_TRY(hipMemcpyAsync(mapq, b->mapq.p, n, hipMemcpyDeviceToHost, st));
+        if (lseq) HIP_TRY(hipMemcpyAsync(lseq, b->lseq.p, n * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return PC_OK;
+}
+
 static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded);
 
 int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped) {
@@ -3897,8 +4014,15 @@ static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size,
         dc.tid = b->tid.p; dc.pos = b->pos.p; dc.alen = b->alen.p; dc.flags = b->flags.p; dc.nblk = b->nblk.p;
         dc.blk_start = b->blk_start.p; dc.blk_len = b->blk_len.p;
         dc.wide_rec = d_wr.p; dc.wide_val = d_wv.p; dc.n_wide = nw;
-        return stage_file(e, n, ntid, nullptr, nullptr, nullptr, nullptr, nullptr, m, nullptr, nullptr, nw, b->wide_idx.data(), b->wide_alen.data(),
-                          b->wide_nblk.data(), &dc);
+        rc = stage_file(e, n, ntid, nullptr, nullptr, nullptr, nullptr, nullptr, m, nullptr, nullptr, nw, b->wide_idx.data(), b->wide_alen.data(),
+                        b->wide_nblk.data(), &dc);
+        if (rc != PC_OK) return rc;
+        // the FLAG / MAPQ columns stay with the staged file (no copy: the decoder's blocks change hands)
+        StagedFile *sf = e->files.back();
+        sf->sam_flag.swap(b->flag16);
+        sf->sam_mapq.swap(b->mapq);
+        sf->have_sam = true;
+        return e->ff_on ? apply_flag_filter(e, sf) : PC_OK;
     }
     std::vector<int32_t> tid((size_t)n), pos((size_t)n), bs((size_t)m), bl((size_t)m), wa((size_t)nw), wn((size_t)nw);
     std::vector<uint16_t> alen((size_t)n);
@@ -3906,8 +4030,14 @@ static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size,
     std::vector<int64_t> wi((size_t)nw);
     rc = pc_bam_read(b, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), bs.data(), bl.data(), wi.data(), wa.data(), wn.data());
     if (rc != PC_OK) return rc;
-    return pc_add_alignment_file_wide(e, n, ntid, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), m, bs.data(), bl.data(),
-                                      nw, wi.data(), wa.data(), wn.data());
+    std::vector<uint16_t> f16((size_t)n);
+    std::vector<uint8_t> mq((size_t)n);
+    rc = pc_bam_read_sam(b, f16.data(), mq.data(), nullptr);
+    if (rc != PC_OK) return rc;
+    rc = pc_add_alignment_file_wide(e, n, ntid, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), m, bs.data(), bl.data(),
+                                    nw, wi.data(), wa.data(), wn.data());
+    if (rc != PC_OK) return rc;
+    return pc_set_alignment_sam(e, (int)e->files.size() - 1, n, f16.data(), mq.data());
 }
 
 namespace {

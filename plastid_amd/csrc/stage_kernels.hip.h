@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_cols_pack(DevCols c, int64_t n, const u
         int64_t L, nb;
         const bool wide = true_len(c, i, L, nb);
         const int64_t p = c.pos[i];
-        const uint32_t fl = c.flags[i] & (uint32_t)(PC_FLAG_REVERSE | PC_FLAG_EXCLUDED);
+        const uint32_t fl = pc::caller_flags(c.flags[i]);
         int64_t end;
         const uint32_t cur = cursor[i];
         if (nb >= 2) end = (int64_t)c.blk_start[cur + nb - 1] + c.blk_len[cur + nb - 1];

@@ -73,6 +73,26 @@ class Engine(object):
                 _ptr(packed.blk_len)))
         self.nfiles += 1
         self.ntid = ntid
+        if getattr(packed, "flag16", None) is not None and getattr(packed, "mapq", None) is not None:
+            # the SAM FLAG word and MAPQ of every record: what the vectorised FLAG / MAPQ filter reads (3 bytes per record)
+            self.set_alignment_sam(self.nfiles - 1, packed.flag16, packed.mapq)
+
+    def set_alignment_sam(self, file_index, flag16, mapq):
+        """Hand the engine the SAM FLAG words and MAPQ values of a staged file (``pc_set_alignment_sam``)."""
+        flag16, mapq = _c(flag16, np.uint16), _c(mapq, np.uint8)
+        if len(flag16) != len(mapq):
+            raise ValueError("flag16 / mapq differ in length")
+        check(self._lib.pc_set_alignment_sam(self._h, int(file_index), len(flag16), _ptr(flag16), _ptr(mapq)))
+
+    def set_flag_filter(self, require=0, exclude=0, min_mapq=0, enabled=True):
+        """Keep a read iff ``(flag & require) == require and (flag & exclude) == 0 and mapq >= min_mapq``
+        (``pc_set_flag_filter``: evaluated on the GPU, folded into the exclusion bit of every staged record);
+        ``enabled=False`` lifts the filter."""
+        key = (bool(enabled), int(require), int(exclude), int(min_mapq)) if enabled else (False, 0, 0, 0)
+        if self._state.get("flagfilter", (False, 0, 0, 0)) == key:
+            return
+        check(self._lib.pc_set_flag_filter(self._h, 1 if enabled else 0, int(require), int(exclude), int(min_mapq)))
+        self._state["flagfilter"] = key
 
     def set_alignments(self, files, ntid=None):
         self.clear_alignments()

@@ -30,7 +30,7 @@ import numpy as np
 from . import _lib
 from .engine import STRAND_CODE, Engine, chain_layout
 from .exceptions import DataWarning, warn
-from .map_factories import CenterMapFactory, SizeFilterFactory, _EngineMapFactory
+from .map_factories import CenterMapFactory, FlagFilterFactory, SizeFilterFactory, _EngineMapFactory
 from .packing import FLAG_EXCLUDED, PackedAlignments
 from .roitools import GenomicSegment, SegmentChain
 
@@ -54,8 +54,21 @@ def _open_alignment_source(src, regions=None, engine=None, decode="auto"):
             raise ValueError("decode must be 'auto', 'host' or 'gpu', got %r" % (decode,))
         on_gpu = decode == "gpu" or (decode == "auto" and os.path.exists(src) and os.path.getsize(src) >= GPU_DECODE_MIN_BYTES)
         if on_gpu and regions is None and engine is not None:
-            return read_bam_gpu(src, engine)
-        return read_bam(src, regions=regions)
+            if decode == "gpu":
+                aln = read_bam_gpu(src, engine)
+                aln.decoder = "gpu"
+                return aln
+            # "auto": a file the device decoder rejects gets a second opinion from the host decoder (whose verdict -- the
+            # arrays or the exception -- is the one the caller sees); ``decoder`` records which of the two read the file
+            try:
+                aln = read_bam_gpu(src, engine)
+                aln.decoder = "gpu"
+                return aln
+            except (ValueError, IOError, OSError, RuntimeError):
+                pass
+        aln = read_bam(src, regions=regions)
+        aln.decoder = "host"
+        return aln
     return src
 
 
@@ -99,7 +112,7 @@ def _pack_source(src, chroms, chrom_index):
         return PackedAlignments(tid, sub.pos, sub.alen, sub.flags, sub.nblk, sub.blk_start, sub.blk_len,
                                 references=chroms, lengths=[0] * len(chroms), mapped=src.mapped,
                                 read_objects=sub._read_objects, wide_idx=sub.wide_idx, wide_alen=sub.wide_alen,
-                                wide_nblk=sub.wide_nblk)
+                                wide_nblk=sub.wide_nblk, flag16=sub.flag16, mapq=sub.mapq, qlen=sub.qlen)
     # duck-typed pysam.AlignmentFile: walk every contig in coordinate order
     reads, tids = [], []
     for ref, length in zip(src.references, src.lengths):
@@ -258,11 +271,20 @@ class BAMGenomeArray(object):
         if self._filters_dirty or not hasattr(self, "_size_filter_state"):
             size = None
             custom = []
+            # filters on FLAG / MAPQ run on the GPU when every file carries the two columns (files read by the
+            # package's own BAM decoders do; device-only files always): combined, they are one mask test
+            sam_ok = self._device_only or all(p.flag16 is not None and p.mapq is not None for p in self._packed)
+            flagf = None
             for f in self._filters.values():
                 if isinstance(f, SizeFilterFactory) and size is None:
                     size = f
+                elif isinstance(f, FlagFilterFactory) and sam_ok and not (flagf is not None and
+                                                                         ((flagf[0] | f.require) & (flagf[1] | f.exclude))):
+                    flagf = (f.require, f.exclude, f.min_mapq) if flagf is None else \
+                        (flagf[0] | f.require, flagf[1] | f.exclude, max(flagf[2], f.min_mapq))
                 else:
                     custom.append(f)
+            self._flag_filter_state = flagf
             if custom and self._device_only:
                 self.bamfiles[0]._host_only()   # (arbitrary callables are evaluated on read objects the host does not have)
             self._custom_filters = custom
@@ -277,6 +299,10 @@ class BAMGenomeArray(object):
             self._filters_dirty = False
         if self._custom_filters:
             self._evaluate_custom_filters(queries)
+        if self._flag_filter_state is None:
+            self._engine.set_flag_filter(enabled=False)
+        else:
+            self._engine.set_flag_filter(*self._flag_filter_state)
         size = self._size_filter_state
         if size is None:
             self._engine.set_size_filter(None)

@@ -402,3 +402,56 @@ class SizeFilterFactory(object):
             raise TypeError("Argument 'read' must not be None")
         my_length = len(read.positions)
         return my_length >= self.min_ and (my_length <= self.max_ or self.max_ == -1)
+
+
+#: SAM FLAG bits by pysam's property names (kent/src/htslib/htslib/sam.h:110-132)
+FLAG_BITS = {"is_paired": 0x1, "is_proper_pair": 0x2, "is_unmapped": 0x4, "mate_is_unmapped": 0x8, "is_reverse": 0x10,
+             "mate_is_reverse": 0x20, "is_read1": 0x40, "is_read2": 0x80, "is_secondary": 0x100, "is_qcfail": 0x200,
+             "is_duplicate": 0x400, "is_supplementary": 0x800}
+
+
+class FlagFilterFactory(object):
+    """FlagFilterFactory(require=0, exclude=0, min_mapq=0)
+
+    Read filter on the SAM FLAG word and MAPQ for :meth:`BAMGenomeArray.add_filter`: a read is kept iff
+    ``(read.flag & require) == require and (read.flag & exclude) == 0 and read.mapping_quality >= min_mapq``.
+    `require` / `exclude` are bit masks or iterables of pysam property names (``"is_secondary"``,
+    ``"is_duplicate"``, ``"is_qcfail"``, ``"is_proper_pair"`` ...).
+
+    The reference has no such class: there one writes ``lambda read: not read.is_secondary and
+    read.mapping_quality >= 10`` and it is called on every fetched read (genome_array.py:697-722, 819-820).
+    That callable works here too (on the host, read by read); this class says the same thing in a form
+    :class:`~plastid_amd.genome_array.BAMGenomeArray` evaluates on the GPU (``pc_set_flag_filter``: one
+    pass over 3 bytes per record), also for files opened with ``keep_reads=False``.  As a plain callable
+    it answers for a single read."""
+
+    def __init__(self, require=0, exclude=0, min_mapq=0):
+        self.require = self._mask(require)
+        self.exclude = self._mask(exclude)
+        self.min_mapq = _as_c_int(min_mapq, "min_mapq")
+        if not 0 <= self.min_mapq <= 255:
+            raise ValueError("FlagFilterFactory: min_mapq must be in 0 .. 255. Got %s" % min_mapq)
+        if self.require & self.exclude:
+            raise ValueError("FlagFilterFactory: the same FLAG bit is both required and excluded")
+
+    @staticmethod
+    def _mask(spec):
+        if isinstance(spec, str):
+            spec = [spec]
+        if isinstance(spec, (list, tuple, set, frozenset)):
+            m = 0
+            for name in spec:
+                if name not in FLAG_BITS:
+                    raise ValueError("FlagFilterFactory: unknown FLAG property %r" % (name,))
+                m |= FLAG_BITS[name]
+            return m
+        m = _as_c_int(spec, "flag mask")
+        if not 0 <= m <= 0xffff:
+            raise ValueError("FlagFilterFactory: FLAG masks are 16-bit. Got %s" % spec)
+        return m
+
+    def __call__(self, read):
+        if read is None:
+            raise TypeError("Argument 'read' must not be None")
+        flag = int(read.flag)
+        return (flag & self.require) == self.require and (flag & self.exclude) == 0 and int(read.mapping_quality) >= self.min_mapq

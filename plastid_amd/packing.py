@@ -19,7 +19,15 @@ what gets bulk-staged to HBM:
 ``blk_start``   int32     runs of every record with ``nblk >= 2``, record after
 ``blk_len``     int32     record (a ``nblk == 1`` record has the single implicit
                           run ``[pos, pos + L)``)
+``flag16``      uint16    (optional) the SAM FLAG word of every record
+``mapq``        uint8     (optional) MAPQ
+``qlen``        int32     (optional) ``l_seq``, pysam's ``query_length``
 ==============  ========  ====================================================
+
+The three optional columns are what read *filters* may look at beyond strand and length (the reference's filters
+take the ``pysam.AlignedSegment``, genome_array.py:697-722): :class:`PackedRead` serves ``flag``,
+``mapping_quality``, ``query_length`` and the ``is_*`` properties from them, and the engine evaluates
+:class:`~plastid_amd.map_factories.FlagFilterFactory` on ``flag16`` / ``mapq`` in HBM.
 
 Records must be in BAM order: sorted by ``(tid, pos)``, ties in file order.
 
@@ -116,15 +124,35 @@ class PackedRead(object):
     """Minimal read object yielded by :meth:`PackedAlignments.fetch`: carries
     what the reference's mapping functions and filters consume."""
 
-    __slots__ = ("source", "index", "reference_id", "reference_start", "is_reverse", "_runs")
+    __slots__ = ("source", "index", "reference_id", "reference_start", "is_reverse", "_runs", "flag", "mapping_quality",
+                 "query_length")
 
-    def __init__(self, source, index, tid, pos, is_reverse, runs):
+    def __init__(self, source, index, tid, pos, is_reverse, runs, flag=None, mapq=None, qlen=None):
         self.source = source
         self.index = index
         self.reference_id = tid
         self.reference_start = pos
         self.is_reverse = is_reverse
         self._runs = runs
+        # a source without the SAM columns (synthetic arrays, stub reads): the strand bit is all the FLAG word is
+        # known to hold, MAPQ is 255 ("not available", SAM spec 1.4), the query is as long as its aligned part
+        self.flag = int(flag) if flag is not None else (0x10 if is_reverse else 0)
+        self.mapping_quality = int(mapq) if mapq is not None else 255
+        self.query_length = int(qlen) if qlen is not None else sum(n for _, n in runs)
+
+    # the FLAG bits by pysam's names (kent/src/htslib/htslib/sam.h:110-132)
+    is_paired = property(lambda self: bool(self.flag & 0x1))
+    is_proper_pair = property(lambda self: bool(self.flag & 0x2))
+    is_unmapped = property(lambda self: bool(self.flag & 0x4))
+    mate_is_unmapped = property(lambda self: bool(self.flag & 0x8))
+    mate_is_reverse = property(lambda self: bool(self.flag & 0x20))
+    is_read1 = property(lambda self: bool(self.flag & 0x40))
+    is_read2 = property(lambda self: bool(self.flag & 0x80))
+    is_secondary = property(lambda self: bool(self.flag & 0x100))
+    is_qcfail = property(lambda self: bool(self.flag & 0x200))
+    is_duplicate = property(lambda self: bool(self.flag & 0x400))
+    is_supplementary = property(lambda self: bool(self.flag & 0x800))
+    mapq = property(lambda self: self.mapping_quality)
 
     @property
     def positions(self):
@@ -154,7 +182,7 @@ class PackedAlignments(object):
 
     def __init__(self, tid, pos, alen, flags, nblk, blk_start=None, blk_len=None,
                  references=None, lengths=None, mapped=None, read_objects=None, validate=True,
-                 wide_idx=None, wide_alen=None, wide_nblk=None):
+                 wide_idx=None, wide_alen=None, wide_nblk=None, flag16=None, mapq=None, qlen=None):
         self.tid = np.ascontiguousarray(tid, dtype=np.int32)
         self.pos = np.ascontiguousarray(pos, dtype=np.int32)
         self.alen = np.ascontiguousarray(alen, dtype=np.uint16)
@@ -167,7 +195,14 @@ class PackedAlignments(object):
         self.wide_idx = np.ascontiguousarray(np.zeros(0, np.int64) if wide_idx is None else wide_idx, dtype=np.int64)
         self.wide_alen = np.ascontiguousarray(np.zeros(0, np.int32) if wide_alen is None else wide_alen, dtype=np.int32)
         self.wide_nblk = np.ascontiguousarray(np.zeros(0, np.int32) if wide_nblk is None else wide_nblk, dtype=np.int32)
+        self.flag16 = None if flag16 is None else np.ascontiguousarray(flag16, dtype=np.uint16)
+        self.mapq = None if mapq is None else np.ascontiguousarray(mapq, dtype=np.uint8)
+        self.qlen = None if qlen is None else np.ascontiguousarray(qlen, dtype=np.int32)
         n = len(self.tid)
+        for name in ("flag16", "mapq", "qlen"):
+            col = getattr(self, name)
+            if col is not None and len(col) != n:
+                raise ValueError("PackedAlignments: array '%s' has wrong length" % name)
         if references is None:
             ntid = int(self.tid.max()) + 1 if n else 1
             references = ["chr%d" % i for i in range(ntid)]
@@ -342,7 +377,13 @@ class PackedAlignments(object):
         if self._read_objects is not None:
             return self._read_objects[i]
         return PackedRead(self, int(i), int(self.tid[i]), int(self.pos[i]),
-                          bool(self.flags[i] & FLAG_REVERSE), self.runs_of(i))
+                          bool(self.flags[i] & FLAG_REVERSE), self.runs_of(i),
+                          None if self.flag16 is None else self.flag16[i], None if self.mapq is None else self.mapq[i],
+                          None if self.qlen is None else self.qlen[i])
+
+    def sam_columns(self, idx):
+        """The optional SAM columns of the records `idx` (index array or slice) as constructor keywords."""
+        return {name: None if getattr(self, name) is None else getattr(self, name)[idx] for name in ("flag16", "mapq", "qlen")}
 
     # ------------------------------------------- pysam.AlignmentFile duck type
     def fetch(self, reference=None, start=None, end=None, **kwargs):
@@ -379,7 +420,7 @@ class PackedAlignments(object):
     # ------------------------------------------------------------ constructors
     @classmethod
     def from_runs(cls, tids, is_reverse, runs_per_read, references=None, lengths=None,
-                  mapped=None, read_objects=None, sort=False, positions=None):
+                  mapped=None, read_objects=None, sort=False, positions=None, flag16=None, mapq=None, qlen=None):
         """Build from per-read lists of aligned runs ``[(start, len), ...]``.  `positions`
         (optional) places the records that have no aligned base at all."""
         n = len(runs_per_read)
@@ -417,9 +458,14 @@ class PackedAlignments(object):
         a16, n8 = alen.copy(), nblk.copy()
         a16[wide] = MAX_ALIGNED_LEN
         n8[wide] = MAX_RUNS
+        sam = {}
+        for name, col in (("flag16", flag16), ("mapq", mapq), ("qlen", qlen)):
+            if col is not None:
+                col = np.asarray(col)
+                sam[name] = col[order] if order is not None else col
         out = cls(tid, pos, a16.astype(np.uint16), flags, n8.astype(np.uint8), bs, bl,
                   references=references, lengths=lengths, mapped=mapped, read_objects=read_objects,
-                  wide_idx=wide, wide_alen=alen[wide], wide_nblk=nblk[wide])
+                  wide_idx=wide, wide_alen=alen[wide], wide_nblk=nblk[wide], **sam)
         out.sort_order = order
         return out
 
@@ -433,6 +479,12 @@ class PackedAlignments(object):
         if tids is None:
             tids = [int(getattr(r, "reference_id", 0)) for r in reads]
             tids = [t if t >= 0 else 0 for t in tids]
+        # reads that know their FLAG word / MAPQ / query length (pysam.AlignedSegment does) keep them
+        if reads and all(hasattr(r, "flag") and hasattr(r, "mapping_quality") for r in reads):
+            kwargs.setdefault("flag16", np.array([int(r.flag) & 0xffff for r in reads], np.uint16))
+            kwargs.setdefault("mapq", np.array([int(r.mapping_quality) & 0xff for r in reads], np.uint8))
+            if all(getattr(r, "query_length", None) is not None for r in reads):
+                kwargs.setdefault("qlen", np.array([int(r.query_length) for r in reads], np.int32))
         return cls.from_runs(tids, rev, runs, read_objects=reads, **kwargs)
 
     @classmethod
@@ -487,7 +539,7 @@ class PackedAlignments(object):
         return PackedAlignments(self.tid[idx], self.pos[idx], self.alen[idx], self.flags[idx],
                                 self.nblk[idx], self.blk_start[sel], self.blk_len[sel],
                                 references=self.references, lengths=self.lengths,
-                                mapped=len(idx), read_objects=ro, validate=validate, **wide)
+                                mapped=len(idx), read_objects=ro, validate=validate, **dict(wide, **self.sam_columns(idx)))
 
 
     def slice(self, i0, i1):
@@ -504,7 +556,7 @@ class PackedAlignments(object):
         return PackedAlignments(self.tid[i0:i1], self.pos[i0:i1], self.alen[i0:i1], self.flags[i0:i1],
                                 self.nblk[i0:i1], self.blk_start[b0:b1], self.blk_len[b0:b1],
                                 references=self.references, lengths=self.lengths, mapped=i1 - i0,
-                                read_objects=ro, validate=False, **wide)
+                                read_objects=ro, validate=False, **dict(wide, **self.sam_columns(slice(i0, i1))))
 
 
 def concat_file_major(files):
@@ -518,6 +570,9 @@ def concat_file_major(files):
     if any(getattr(f, "n_wide", 0) for f in files):   # the wide records of all files, at their indices in the concatenation
         wide = {"wide_idx": np.concatenate([f.wide_idx + base[k] for k, f in enumerate(files)]),
                 "wide_alen": np.concatenate([f.wide_alen for f in files]), "wide_nblk": np.concatenate([f.wide_nblk for f in files])}
+    if all(getattr(f, "flag16", None) is not None and getattr(f, "mapq", None) is not None for f in files):
+        wide["flag16"] = np.concatenate([f.flag16 for f in files])
+        wide["mapq"] = np.concatenate([f.mapq for f in files])
     return dict(wide, **{
         "tid": np.concatenate([f.tid for f in files]),
         "pos": np.concatenate([f.pos for f in files]),

@@ -321,10 +321,11 @@ def write_bam_realistic(path, packed, block_bytes=60000, level=1, threads=8, see
         col(4, 4, packed.tid[grp], "<i4")
         col(8, 4, packed.pos[grp], "<i4")
         rows[:, 12] = name_len
-        rows[:, 13] = 255 if False else 30
+        rows[:, 13] = 30 if getattr(packed, "mapq", None) is None else packed.mapq[grp]
         col(14, 2, bins[grp], "<u2")
         col(16, 2, np.full(k, 2 * nb - 1), "<u2")
-        col(18, 2, np.where(packed.flags[grp] & 1, 16, 0), "<u2")
+        # (a packed file that carries SAM FLAG words -- strand bit in step with `flags` -- and MAPQ values has them written)
+        col(18, 2, np.where(packed.flags[grp] & 1, 16, 0) if getattr(packed, "flag16", None) is None else packed.flag16[grp], "<u2")
         col(20, 4, np.full(k, Lg), "<i4")
         col(24, 4, np.full(k, -1), "<i4")
         col(28, 4, np.full(k, -1), "<i4")

@@ -9,7 +9,7 @@
  * po_cigar_to_runs restate from the SAM specification):
  *   - the BAM / BGZF / BAI bytes htslib itself writes for seeded records over all nine CIGAR
  *     operations (sam_write1, sam_index_build);
- *   - per record, as htslib reads it back: pos, flag, bam_endpos() (sam.c:329-341) and the aligned
+ *   - per record, as htslib reads it back: pos, flag, MAPQ, l_qseq, bam_endpos() (sam.c:329-341) and the aligned
  *     reference positions from a CIGAR walk driven by htslib's own bam_cigar_type() table
  *     (htslib/sam.h:64-104: an op that consumes query AND reference emits positions) -- pysam's
  *     AlignedSegment.positions;
@@ -20,6 +20,7 @@
  * Output (stdout), one line per item:
  *   REF name length
  *   REC index tid pos flag endpos npos p0 p1 ...
+ *   SAM index mapq l_qseq                      (core.qual / core.l_qseq as read back: pysam's mapping_quality / query_length)
  *   CIG index n op0 len0 op1 len1 ...          (BAM op codes 0..8 = MIDNSHP=X, as read back)
  *   REG tid beg end n i0 i1 ...
  *   STAT tid mapped unmapped
@@ -84,7 +85,9 @@ static void fill(bam1_t *b, int idx, int tid, int pos, int flag, const uint32_t 
     memcpy(b->data + l_qname, cig, 4u * (size_t)ncig);
     memset(b->data + l_qname + 4 * ncig, 0x11, (size_t)((lq + 1) / 2));
     memset(b->data + l_qname + 4 * ncig + (lq + 1) / 2, 30, (size_t)lq);
-    b->core.tid = tid; b->core.pos = pos; b->core.qual = 30; b->core.l_qname = (uint8_t)l_qname;
+    /* MAPQ varies with the record index (0 .. 60, every 17th record 255 = "not available"); no random draw, so every
+     * other field of the fixture is what it was before the column was added */
+    b->core.tid = tid; b->core.pos = pos; b->core.qual = (uint8_t)(idx % 17 == 16 ? 255 : (idx * 37 + 11) % 61); b->core.l_qname = (uint8_t)l_qname;
     b->core.flag = (uint16_t)flag; b->core.n_cigar = (uint16_t)ncig; b->core.l_qseq = lq;
     b->core.mtid = -1; b->core.mpos = -1; b->core.isize = 0;
     b->core.bin = hts_reg2bin(pos, bam_endpos(b), 14, 5);
@@ -170,6 +173,7 @@ int main(int argc, char **argv) {
             if (type & 2) rp += len;
         }
         printf("\n");
+        printf("SAM %d %d %d\n", i, (int)b->core.qual, (int)b->core.l_qseq);     /* pysam: mapping_quality, query_length */
         printf("CIG %d %d", i, b->core.n_cigar);
         for (int k = 0; k < b->core.n_cigar; ++k) printf(" %d %d", bam_cigar_op(cig[k]), bam_cigar_oplen(cig[k]));
         printf("\n");

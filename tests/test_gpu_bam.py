@@ -19,7 +19,7 @@ from tests import bam_writer  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hts_fixture.npz")
-COLS = ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "wide_idx", "wide_alen", "wide_nblk")
+COLS = ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "wide_idx", "wide_alen", "wide_nblk", "flag16", "mapq", "qlen")
 
 
 @pytest.fixture(scope="module")
@@ -68,6 +68,8 @@ def test_the_htslib_written_bam(eng, tmp_path):
     same(got, read_bam(path))
     keep = np.nonzero(hts["tid"] >= 0)[0]
     assert got.n == len(keep) and np.array_equal(got.pos, hts["pos"][keep])
+    assert np.array_equal(got.flag16, hts["flag"][keep]) and np.array_equal(got.mapq, hts["mapq"][keep])   # FLAG / MAPQ as htslib reads them back
+    assert np.array_equal(got.qlen, hts["l_qseq"][keep])
     assert got.mapped == int(hts["index_stat"][:, 1].sum())
     assert np.array_equal(got.ref_end(), hts["endpos"][keep])          # htslib's bam_endpos
     assert timing["members"] >= 1 and timing["records"] == len(hts["tid"])
@@ -149,6 +151,157 @@ def test_symbol_decoders_and_upload_pieces_agree(eng, tmp_path, monkeypatch, lev
     same(read_bam_gpu(path, eng), ref)
     monkeypatch.delenv("PC_BGZF_SERIAL")
     same(read_bam_gpu(path, eng), ref)
+
+
+def multi_block_member(data, level, rng):
+    """One BGZF member of SEVERAL dynamic DEFLATE blocks that start at arbitrary bit positions: the payload goes
+    through one compressor in random pieces with ``flush(Z_BLOCK)`` between them (the block is completed, nothing is
+    padded and no empty stored block is written -- as when zlib's symbol buffer fills up in the middle of a member)."""
+    comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+    cdata, o = [], 0
+    while o < len(data):
+        k = int(rng.integers(400, 6000))
+        cdata.append(comp.compress(data[o:o + k]))
+        o += k
+        if o < len(data):
+            cdata.append(comp.flush(zlib.Z_BLOCK))
+    cdata = b"".join(cdata) + comp.flush()
+    assert len(cdata) + 25 < 65536
+    header = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(cdata) + 25)
+    return header + cdata + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+@pytest.mark.parametrize("level", [6, 9])
+def test_thousands_of_multi_block_members(eng, tmp_path, level):
+    """Members of 64 KiB with a dozen or two DEFLATE blocks each, by the thousand: a block header that ends just behind
+    a ring refill of the wave-uniform reader (whose bit buffer then still holds bits of bytes the refill has
+    overwritten in LDS) hands the batch decoder a bit position inside those bytes -- about one block header in a
+    hundred.  The reader keeps eight bytes of history in the ring for exactly that (round 4's reader did not, and
+    failed this test on dozens of members)."""
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.011, tx_scale=0.01)
+    whole = str(tmp_path / "whole.bam")
+    bam_writer.write_bam_realistic(whole, reads, threads=8, level=1, block_bytes=65280)
+    data = b"".join(zlib.decompressobj(-15).decompress(m) for m in _member_payloads(whole))
+    rng = np.random.default_rng(level)
+    path = str(tmp_path / "many.bam")
+    with open(path, "wb") as fh:
+        for off in range(0, len(data), 65280):
+            fh.write(multi_block_member(data[off:off + 65280], level, rng))
+        fh.write(bam_writer.BGZF_EOF)
+    timing = {}
+    got = read_bam_gpu(path, eng, timing=timing)
+    assert timing["members"] >= 2000
+    same(got, read_bam(path))
+
+
+def _member_payloads(path):
+    """The raw DEFLATE streams of the BGZF members of a file."""
+    raw = open(path, "rb").read()
+    off = 0
+    while off < len(raw):
+        bsize = struct.unpack("<H", raw[off + 16:off + 18])[0] + 1
+        if bsize > 28:
+            yield raw[off + 18:off + bsize - 8]
+        off += bsize
+
+
+class _Bits(object):
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, value, nbits):            # LSB first (header fields, extra bits)
+        self.acc |= value << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, c, nbits):               # Huffman codes go MSB first
+        self.put(int(format(c, "0%db" % nbits)[::-1], 2), nbits)
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 255)
+        return bytes(self.out)
+
+
+def _code_lengths(freq, limit):
+    """Huffman code lengths (<= limit) for the symbols with freq > 0."""
+    import heapq
+    f = {s: c for s, c in enumerate(freq) if c}
+    while True:
+        heap = [(c, s, (s,)) for s, c in f.items()]
+        heapq.heapify(heap)
+        depth = dict.fromkeys(f, 0)
+        if len(heap) == 1:
+            depth[heap[0][1]] = 1
+        while len(heap) > 1:
+            a, b = heapq.heappop(heap), heapq.heappop(heap)
+            for s in a[2] + b[2]:
+                depth[s] += 1
+            heapq.heappush(heap, (a[0] + b[0], min(a[1], b[1]), a[2] + b[2]))
+        if max(depth.values()) <= limit:
+            return depth
+        f = {s: (c + 1) // 2 for s, c in f.items()}
+
+
+def _canonical(lengths):
+    codes, code = {}, 0
+    for ln in range(1, 16):
+        for s in sorted(s for s, l in lengths.items() if l == ln):
+            codes[s] = (code, ln)
+            code += 1
+        code <<= 1
+    return codes
+
+
+def literal_only_dynamic_member(data):
+    """One BGZF member whose payload is ONE dynamic DEFLATE block of literals only, declaring HDIST = 1 distance code
+    of length ZERO (what libdeflate before 1.15 wrote for such blocks; zlib's inflate_table accepts `max == 0`)."""
+    freq = [0] * 257
+    for b in data:
+        freq[b] += 1
+    freq[256] = 1
+    ll = _code_lengths(freq, 15)
+    lens = [ll.get(s, 0) for s in range(257)] + [0]          # 257 literal/length lengths + the one distance length
+    cl_freq = [0] * 19
+    for v in lens:
+        cl_freq[v] += 1
+    cl = _code_lengths(cl_freq, 7)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    hclen = max(i for i, s in enumerate(order) if cl.get(s, 0)) + 1
+    w = _Bits()
+    w.put(1, 1); w.put(2, 2)                                   # BFINAL, dynamic
+    w.put(0, 5); w.put(0, 5); w.put(max(hclen, 4) - 4, 4)      # HLIT = 257, HDIST = 1
+    for s in order[:max(hclen, 4)]:
+        w.put(cl.get(s, 0), 3)
+    clc = _canonical(cl)
+    for v in lens:
+        w.code(*clc[v])
+    llc = _canonical(ll)
+    for b in data:
+        w.code(*llc[b])
+    w.code(*llc[256])
+    cdata = w.done()
+    assert zlib.decompressobj(-15).decompress(cdata) == data   # zlib itself takes the stream
+    header = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(cdata) + 25)
+    return header + cdata + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+def test_a_literal_only_block_with_an_empty_distance_code(eng, tmp_path):
+    """zlib (inftrees.c: `max == 0`) and libdeflate accept a dynamic block whose one distance code has length zero;
+    so does the host decoder, and so must the kernel's table builder."""
+    recs = [(0, 10 + 3 * i, [(0, 30)], 16 * (i & 1)) for i in range(200)]
+    data = bam_stream(["chrA"], [100000], recs)
+    path = str(tmp_path / "litonly.bam")
+    with open(path, "wb") as fh:
+        for off in range(0, len(data), 3000):
+            fh.write(literal_only_dynamic_member(data[off:off + 3000]))
+        fh.write(bam_writer.BGZF_EOF)
+    got = read_bam_gpu(path, eng)
+    same(got, read_bam(path))
+    assert got.n == 200
 
 
 def test_long_matches_and_long_distances(eng, tmp_path):
@@ -487,3 +640,106 @@ def test_bam_genome_array_without_host_reads(tmp_path):
         b[segs[0]]
     with pytest.raises(ValueError):
         pa.BAMGenomeArray(reads, keep_reads=False)
+
+
+def _with_sam_columns(reads, seed=3):
+    rng = np.random.default_rng(seed)
+    flag = np.where(reads.flags & 1, 0x10, 0).astype(np.uint16)
+    for bit, frac in ((0x100, 0.2), (0x400, 0.15), (0x200, 0.1), (0x1, 0.5), (0x800, 0.05)):
+        flag[rng.random(reads.n) < frac] |= bit
+    flag[((flag & 1) != 0) & (rng.random(reads.n) < 0.6)] |= 0x2
+    reads.flag16 = flag
+    reads.mapq = rng.choice(np.array([0, 3, 10, 29, 30, 60, 255], np.uint8), reads.n).astype(np.uint8)
+    return reads
+
+
+@pytest.mark.parametrize("config,scale", [("C2", 0.0005), ("C4", 0.0003)])
+def test_flag_and_mapq_filters_on_decoded_files(tmp_path, config, scale):
+    """FLAG / MAPQ travel from the BAM records through both decoders to the engine: ``FlagFilterFactory`` on a file
+    staged entirely on the GPU (keep_reads=False), on a GPU-decoded and on a host-decoded array give the counts of the
+    reads the filter keeps (engine on the subset), under point, center and stratified rules; lifting the filter
+    restores the unfiltered counts; the same decision as a plain callable on read objects agrees."""
+    genome, tx, reads, _ = synth.make_config(config, scale=scale, tx_scale=0.01)
+    reads = _with_sam_columns(reads)
+    path = str(tmp_path / "flags.bam")
+    bam_writer.write_bam_realistic(path, reads, threads=4, level=6)
+    host = read_bam(path)
+    assert np.array_equal(host.flag16, reads.flag16) and np.array_equal(host.mapq, reads.mapq)
+    chains = tx.chains(limit=40)
+    filt = pa.FlagFilterFactory(exclude=["is_secondary", "is_duplicate"], min_mapq=10)
+    keep = ((reads.flag16 & 0x500) == 0) & (reads.mapq >= 10)
+    assert 0.2 < keep.mean() < 0.8
+    arrays = {"host": pa.BAMGenomeArray(path, decode="host"), "gpu": pa.BAMGenomeArray(path, decode="gpu"),
+              "device_only": pa.BAMGenomeArray(path, keep_reads=False), "subset": pa.BAMGenomeArray(reads.subset(keep)),
+              "callable": pa.BAMGenomeArray(path, decode="host")}
+    for name, ga in arrays.items():
+        if name == "callable":
+            ga.add_filter("mine", lambda r: not r.is_secondary and not r.is_duplicate and r.mapping_quality >= 10)
+        elif name != "subset":
+            ga.add_filter("flags", filt)
+    for factory in (pa.FivePrimeMapFactory(12), pa.CenterMapFactory(1), pa.VariableFivePrimeMapFactory(synth.VARIABLE_OFFSETS),
+                    pa.StratifiedVariableFivePrimeMapFactory(synth.VARIABLE_OFFSETS, 25, 35)):
+        outs = {}
+        for name, ga in arrays.items():
+            ga.set_mapping(factory)
+            outs[name] = [np.asarray(x).view(np.uint64) for x in ga.get_counts_batch(chains)]
+        assert sum(int((x != 0).sum()) for x in outs["subset"]) > 0
+        for name in ("host", "gpu", "device_only", "callable"):
+            assert all(np.array_equal(x, y) for x, y in zip(outs["subset"], outs[name])), (name, type(factory).__name__)
+    # a second FLAG filter combines with the first; removing both restores every read
+    arrays["device_only"].add_filter("pairs", pa.FlagFilterFactory(require="is_proper_pair"))
+    keep2 = keep & ((reads.flag16 & 0x2) != 0)
+    sub2 = pa.BAMGenomeArray(reads.subset(keep2), mapping=pa.FivePrimeMapFactory(12))
+    arrays["device_only"].set_mapping(pa.FivePrimeMapFactory(12))
+    assert all(np.array_equal(x, y) for x, y in zip(sub2.get_counts_batch(chains), arrays["device_only"].get_counts_batch(chains)))
+    arrays["device_only"].remove_filter("pairs")
+    arrays["device_only"].remove_filter("flags")
+    full = pa.BAMGenomeArray(reads, mapping=pa.FivePrimeMapFactory(12))
+    assert all(np.array_equal(x, y) for x, y in zip(full.get_counts_batch(chains), arrays["device_only"].get_counts_batch(chains)))
+
+
+def test_flag_filter_needs_the_columns(eng):
+    """A FLAG / MAPQ filter over a file staged without the two columns is refused (at the setter, or at the count when
+    the file arrives later) rather than silently ignored; the columns can follow the file."""
+    from plastid_amd.exceptions import EngineError
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.0002, tx_scale=0.01)
+    e = Engine(0)
+    e.set_alignments([reads])                       # synthetic arrays: no FLAG / MAPQ
+    with pytest.raises(EngineError):
+        e.set_flag_filter(exclude=0x100)
+    e.clear_alignments()
+    e.set_flag_filter(exclude=0x100, min_mapq=5)    # no file yet: accepted
+    e.add_alignment_file(reads)
+    synth.mapping_factory(("fiveprime", 0))._configure(e)
+    p = tx.plan_arrays(rows=1)
+    plan = e.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    with pytest.raises(EngineError):
+        plan.count(np.int64)
+    rng = np.random.default_rng(1)
+    flag = np.where(rng.random(reads.n) < 0.3, 0x100, 0).astype(np.uint16) | np.where(reads.flags & 1, 0x10, 0).astype(np.uint16)
+    mapq = rng.integers(0, 11, reads.n).astype(np.uint8)
+    e.set_alignment_sam(0, flag, mapq)
+    got = plan.count(np.int64).copy()
+    plan.close()
+    keep = ((flag & 0x100) == 0) & (mapq >= 5)
+    h = Engine(0)
+    h.set_alignments([reads.subset(keep)])
+    synth.mapping_factory(("fiveprime", 0))._configure(h)
+    plan = h.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    assert got.sum() > 0 and np.array_equal(got, plan.count(np.int64))
+    plan.close()
+    # the caller's own exclusions (pc_update_flags) and the FLAG filter's combine; lifting the filter leaves the caller's
+    mine = rng.random(reads.n) < 0.25
+    e.update_flags(0, np.where(mine, reads.flags | 0x80, reads.flags).astype(np.uint8))
+    plan = e.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+    both = plan.count(np.int64).copy()
+    e.set_flag_filter(enabled=False)
+    only_mine = plan.count(np.int64).copy()
+    plan.close()
+    for want, keepmask in ((both, keep & ~mine), (only_mine, ~mine)):
+        h.set_alignments([reads.subset(keepmask)])
+        plan = h.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], 1)
+        assert np.array_equal(want, plan.count(np.int64))
+        plan.close()
+    e.close()
+    h.close()

@@ -48,6 +48,8 @@ def files_of(pa, g, case):
         if "wide_idx" in aln:
             w = (aln["wide_idx"] >= lo) & (aln["wide_idx"] < hi)
             wide = dict(wide_idx=aln["wide_idx"][w] - lo, wide_alen=aln["wide_alen"][w], wide_nblk=aln["wide_nblk"][w])
+        if "flag16" in aln:                     # the SAM FLAG word and MAPQ of every read (flag_filters.npz)
+            wide.update(flag16=aln["flag16"][lo:hi], mapq=aln["mapq"][lo:hi])
         files.append(pa.PackedAlignments(
             aln["tid"][lo:hi], aln["pos"][lo:hi], aln["alen"][lo:hi], aln["flags"][lo:hi], aln["nblk"][lo:hi],
             aln["blk_start"][off[lo]:off[hi]], aln["blk_len"][off[lo]:off[hi]], references=refs, lengths=lens,
@@ -147,6 +149,49 @@ def test_golden_bamgenomearray(pa, group):
                 assert chain.get_position_list() == list(g[q["position_list"]])
                 assert sorted(chain.get_masked_position_set()) == list(g[q["masked_position_set"]])
     assert nq > (100 if group != "wide_reads" else 70)
+
+
+@pytest.mark.parametrize("how", ["device", "callable"])
+def test_golden_flag_and_mapq_filters(pa, how):
+    """Filters on the FLAG word and MAPQ against what the reference returned for plain callables on
+    ``read.is_secondary`` / ``.mapping_quality`` ... (tests/golden/make_flag_golden.py; genome_array.py:697-722,
+    819-820): as :class:`FlagFilterFactory` (evaluated on the GPU, pc_set_flag_filter) and as the same plain callable
+    on the mirror's read objects (evaluated on the host, staged as exclusion bits) -- vectors, reads_out, warnings,
+    for all five rules, one and two files, next to a size filter and normalised."""
+    from plastid_amd.map_factories import FLAG_BITS
+    g = gu.load("flag_filters")
+    nq = 0
+    for case in g.cases:
+        files = files_of(pa, g, case)
+        ga = pa.BAMGenomeArray(files, mapping=factory_of(pa, case["spec"]))
+        req, exc, mq = case["filter"]
+        if how == "device":
+            ga.add_filter("flags", pa.FlagFilterFactory(req, exc, mq))
+        else:
+            need = [k for k, b in FLAG_BITS.items() if req & b]
+            ban = [k for k, b in FLAG_BITS.items() if exc & b]
+            ga.add_filter("flags", lambda r, need=need, ban=ban, mq=mq: all(getattr(r, k) for k in need) and
+                          not any(getattr(r, k) for k in ban) and r.mapping_quality >= mq)
+        if case["size_filter"]:
+            ga.add_filter("size", pa.SizeFilterFactory(min=case["size_filter"][0], max=case["size_filter"][1]))
+        if case["normalize"]:
+            ga.set_normalize(True)
+        assert ga.sum() == case["sum"]
+        offs = np.cumsum([0] + [f.n for f in files])
+        for q in case["queries"]:
+            nq += 1
+            if q["type"] == "segment":
+                seg = pa.GenomicSegment(q["chrom"], q["start"], q["end"], q["strand"])
+                (reads, arr), warns = call_with_warnings(ga.get_reads_and_counts, seg)
+                assert same(arr, g[q["expected"]]), (case["spec"], case["filter_name"], q)
+                assert [offs[files.index(r.source)] + r.index for r in reads] == list(g[q["reads_out"]]), (case["spec"], q)
+                assert (len(warns) > 0) == q["warned"], (case["spec"], q)
+            else:
+                chain = pa.SegmentChain(*[pa.GenomicSegment(q["chrom"], s, e, q["strand"]) for s, e in q["segments"]])
+                assert same(chain.get_counts(ga), g[q["expected"]]), (case["spec"], case["filter_name"], q)
+        if how == "device":
+            assert ga._engine._state["flagfilter"] == (True, req, exc, mq)     # it ran on the GPU, not read by read
+    assert nq > 800
 
 
 # ------------------------------------------------------------------ oracle, seeded random, through the C ABI

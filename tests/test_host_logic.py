@@ -473,3 +473,98 @@ def test_inflate_and_plan_kernels_are_in_the_code_object(tmp_path):
               "k_pieces_sorted", "k_tile_fill", "k_out_total", "k_out_raw", "k_out_sorted", "k_cchunk_count", "k_cchunk_fill", "k_gchunk_count",
               "k_gchunk_fill"):
         assert any(("pcplan" in name and k in name) for name in blocks), k
+
+
+# -------------------------------------------------------------- FLAG / MAPQ (round 5)
+def test_packed_reads_expose_what_filters_look_at():
+    """Filters take the read (genome_array.py:697-722): a PackedRead answers for flag, mapping_quality, query_length
+    and pysam's is_* properties -- from the SAM columns when the file has them, else from the strand bit alone."""
+    p = PackedAlignments.from_cigars([0, 0, 0], [5, 9, 30], ["20M", "5S10M3N10M", "25M"], [False, True, False],
+                                     references=["c"], lengths=[1000], flag16=[0x1 | 0x2 | 0x40, 0x10 | 0x100, 0x400 | 0x200 | 0x800],
+                                     mapq=[60, 0, 255], qlen=[20, 25, 25])
+    r0, r1, r2 = (p.read(i) for i in range(3))
+    assert (r0.flag, r0.mapping_quality, r0.mapq, r0.query_length) == (0x43, 60, 60, 20)
+    assert r0.is_paired and r0.is_proper_pair and r0.is_read1 and not (r0.is_read2 or r0.is_secondary or r0.is_unmapped)
+    assert r1.is_reverse and r1.is_secondary and not r1.is_duplicate and r1.query_length == 25 and r1.positions[:2] == [9, 10]
+    assert r2.is_duplicate and r2.is_qcfail and r2.is_supplementary and r2.mapping_quality == 255
+    q = p.subset([2, 0], validate=False)
+    assert list(q.flag16) == [0xe00, 0x43] and list(q.mapq) == [255, 60] and list(p.slice(1, 3).qlen) == [25, 25]
+    bare = PackedAlignments.from_ungapped(0, [3, 7], [30, 31], [False, True], references=["c"], lengths=[100])
+    assert bare.flag16 is None and (bare.read(1).flag, bare.read(1).mapping_quality, bare.read(1).query_length) == (0x10, 255, 31)
+    assert not bare.read(0).is_secondary and bare.read(0).flag == 0
+    with pytest.raises(ValueError):
+        PackedAlignments.from_ungapped(0, [3, 7], [30, 31], [False, True], flag16=[0])
+    # reads that know their flag (pysam.AlignedSegment does) keep it through from_reads
+    class R(object):
+        def __init__(self, pos, flag, mq):
+            self.positions, self.is_reverse, self.flag, self.mapping_quality, self.query_length = list(range(pos, pos + 10)), bool(flag & 16), flag, mq, 12
+    q = PackedAlignments.from_reads([R(5, 0x100, 3), R(8, 0x10, 40)], tids=[0, 0], references=["c"], lengths=[100])
+    assert list(q.flag16) == [0x100, 0x10] and list(q.mapq) == [3, 40] and list(q.qlen) == [12, 12]
+    from plastid_amd.packing import concat_file_major
+    assert list(concat_file_major([q, q])["mapq"]) == [3, 40, 3, 40] and "mapq" not in concat_file_major([q, bare])
+
+
+def test_flag_filter_factory():
+    f = pa.FlagFilterFactory(exclude=["is_secondary", "is_duplicate"], min_mapq=10)
+    assert (f.require, f.exclude, f.min_mapq) == (0, 0x500, 10)
+    g = pa.FlagFilterFactory(require="is_proper_pair", exclude=0x200)
+    assert (g.require, g.exclude, g.min_mapq) == (0x2, 0x200, 0)
+
+    class R(object):
+        def __init__(self, flag, mq):
+            self.flag, self.mapping_quality = flag, mq
+    assert f(R(0x10, 10)) and not f(R(0x10, 9)) and not f(R(0x100, 60)) and not f(R(0x400 | 0x10, 60))
+    assert g(R(0x3, 0)) and not g(R(0x1, 0)) and not g(R(0x203, 0))
+    with pytest.raises(TypeError):
+        f(None)
+    for bad in (dict(require="is_nice"), dict(exclude=0x10000), dict(min_mapq=256), dict(min_mapq=-1), dict(require=0x100, exclude=0x100)):
+        with pytest.raises(ValueError):
+            pa.FlagFilterFactory(**bad)
+
+
+def test_auto_decode_falls_back_to_the_host_decoder(tmp_path, monkeypatch):
+    """``decode="auto"`` asks the GPU decoder for large files; a file it rejects gets the host decoder's verdict (its
+    arrays, or its exception); ``decode="gpu"`` keeps the hard failure.  Which decoder read the file is recorded."""
+    from plastid_amd import bam, genome_array
+    from tests import bam_writer
+    path = str(tmp_path / "x.bam")
+    bam_writer.write_bam(path, ["c"], [1000], [(0, 5, [(0, 30)], 0), (0, 50, [(0, 20)], 16)])
+    calls = []
+
+    def broken(p, engine, timing=None):
+        calls.append(p)
+        raise ValueError("BGZF inflate failed in %s" % p)
+    monkeypatch.setattr(bam, "read_bam_gpu", broken)
+    monkeypatch.setattr(genome_array, "GPU_DECODE_MIN_BYTES", 1)
+    aln = genome_array._open_alignment_source(path, engine=object(), decode="auto")
+    assert calls == [path] and aln.decoder == "host" and aln.n == 2
+    with pytest.raises(ValueError):
+        genome_array._open_alignment_source(path, engine=object(), decode="gpu")
+    monkeypatch.setattr(bam, "read_bam_gpu", lambda p, engine, timing=None: bam.read_bam(p))
+    assert genome_array._open_alignment_source(path, engine=object(), decode="auto").decoder == "gpu"
+    open(path, "wb").write(b"not a bam")
+    monkeypatch.setattr(bam, "read_bam_gpu", broken)
+    with pytest.raises((ValueError, IOError)):
+        genome_array._open_alignment_source(path, engine=object(), decode="auto")
+
+
+def test_every_kernel_header_triggers_a_rebuild(tmp_path, monkeypatch):
+    """``needs_build()`` looks at every header under csrc/ (a stale .so would travel to the GPU box with a newer
+    kernel source): touching any of them -- the round-4 ones included -- makes it true."""
+    from plastid_amd import build
+    csrc = os.path.join(ROOT, "plastid_amd", "csrc")
+    hdrs = [f for f in os.listdir(csrc) if f.endswith(".h")]
+    assert {"pc_kernels.hip.h", "bam_kernels.hip.h", "plan_kernels.hip.h", "stage_kernels.hip.h", "host_util.h"} <= set(hdrs)
+    assert set(os.path.basename(h) for h in build._headers()) >= set(hdrs)
+    lib = tmp_path / "lib.so"
+    lib.write_bytes(b"")
+    monkeypatch.setattr(build, "LIB", str(lib))
+    now = max(os.path.getmtime(h) for h in build._headers() + [build.SRC])
+    os.utime(str(lib), (now + 10, now + 10))
+    assert not build.needs_build()
+    for h in hdrs:
+        fake = tmp_path / h
+        fake.write_text("// touched\n")
+        os.utime(str(fake), (now + 20, now + 20))
+        monkeypatch.setattr(build, "_headers", lambda fake=fake: [str(fake)])
+        assert build.needs_build(), h

@@ -80,6 +80,15 @@ def test_native_reader_decodes_the_htslib_written_bam(hts, bam_path):
         assert np.array_equal(got.flags & 1, (hts["flag"][keep] >> 4) & 1)   # FLAG 0x10 -> is_reverse
         assert got.mapped == int(hts["index_stat"][:, 1].sum())             # pysam AlignmentFile.mapped
         assert got.mapped == int(((hts["flag"][keep] & 0x4) == 0).sum())
+        # what filter functions may look at (genome_array.py:697-722): the FLAG word, MAPQ and l_seq as htslib reads them back
+        assert np.array_equal(got.flag16, hts["flag"][keep]) and np.array_equal(got.mapq, hts["mapq"][keep])
+        assert np.array_equal(got.qlen, hts["l_qseq"][keep])
+        assert len(np.unique(hts["mapq"])) > 50 and (hts["mapq"] == 255).any()
+        for j in (0, 7, len(keep) - 1):
+            r, f = got.read(j), int(hts["flag"][keep[j]])
+            assert r.flag == f and r.mapping_quality == int(hts["mapq"][keep[j]]) and r.query_length == int(hts["l_qseq"][keep[j]])
+            assert (r.is_secondary, r.is_duplicate, r.is_qcfail, r.is_unmapped, r.is_paired, r.is_read2, r.mate_is_reverse, r.is_reverse) == \
+                tuple(bool(f & b) for b in (0x100, 0x400, 0x200, 0x4, 0x1, 0x80, 0x20, 0x10))
         for j, i in enumerate(keep):
             runs, L = _htslib_runs(hts, i)
             assert int(got.alen[j]) == L, i
@@ -98,7 +107,7 @@ def test_chunked_decoding_of_the_htslib_written_bam(hts, bam_path, monkeypatch, 
         monkeypatch.setenv(k, v)
     for threads in (1, 3):
         got = read_bam(bam_path, threads=threads)
-        for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len"):
+        for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "flag16", "mapq", "qlen"):
             assert np.array_equal(getattr(got, name), getattr(whole, name)), (name, knobs)
         assert got.mapped == whole.mapped
 
