@@ -492,6 +492,25 @@ __device__ __forceinline__ int64_t lin_floor(const uint32_t PC_GLOBAL *lin, int6
     return lin[lin0 + b];
 }
 
+// The same lookup made EXACT: first entry of the contig whose start is >= key -- the bucket of `key`, then a bisection
+// inside it.  `v`: the sorted starts as a stride-STRIDE dword array (packed records: 2, run stream: 2, side lists: 4).
+// Short windows use it (k_tile_ranges): a 256-position window whose lower record bound is rounded down to a 128-nt
+// bucket scans up to half again as many records as it bins (C5: 6.96 GB read for a 4.3 GB stream in round 4).
+template <int STRIDE>
+__device__ __forceinline__ int64_t lin_exact(const uint32_t PC_GLOBAL *v, const uint32_t PC_GLOBAL *lin, int64_t lin0, int64_t nb, int64_t key) {
+    int64_t b = key <= 0 ? 0 : (key >> kLinShift);
+    if (b > nb) b = nb;
+    const int64_t b1 = b + 1 > nb ? nb : b + 1;
+    int64_t lo = lin[lin0 + b], hi = lin[lin0 + b1];
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)(int32_t)v[mid * STRIDE] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// (spans of at most this many positions get exact bounds: beyond it the bucket rounding is a few percent of the scan)
+constexpr int kExactSpan = 1024;
+
 // exclusive prefix sum of one value per thread over a kRangesWG-thread block
 __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -590,16 +609,26 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     int64_t wlo = 0, whi = 0, wglo = 0, wghi = 0, llo = 0, lhi = 0, wrlo = 0, wrhi = 0;
     uint32_t n_heavy = 0, n_light = 0, n_small = 0;
     bool merge = false;
-    // ranges of file `ff` for the window part [a, e) (a, e: first queried position, end rounded up to an index bucket)
+    // ranges of file `ff` for the window part [a, e) (a: first queried position, e: behind the last one)
     auto file_ranges = [&](int ff, int32_t tidx, int64_t a, int64_t e, int64_t s_lo, int64_t s_hi, FileRange &r) {
         const GFile g = ff == 0 ? gfile(file0) : gfile(files[ff]);
         const int64_t q0 = g.lin_off[tidx], qn = g.lin_off[tidx + 1] - q0 - 1;
-        r.lo = lin_floor(g.lin_tab, q0, qn, a - Ws + 1);
-        r.hi = lin_floor(g.lin_tab, q0, qn, e);
+        const int64_t e_up = e + (1 << kLinShift) - 1;   // (a table lookup rounds down: an end inside a bucket takes the whole bucket)
+        if (e - a <= kExactSpan) {   // a short span: exact bounds
+            r.lo = lin_exact<2>((const uint32_t PC_GLOBAL *)g.rec, g.lin_tab, q0, qn, a - Ws + 1);
+            r.hi = lin_exact<2>((const uint32_t PC_GLOBAL *)g.rec, g.lin_tab, q0, qn, e);
+            if (r.hi < r.lo) r.hi = r.lo;
+            r.rlo = g.nrunrec ? (uint32_t)lin_exact<2>((const uint32_t PC_GLOBAL *)g.run_rec, g.rlin_tab, q0, qn, a - Wr + 1) : 0u;
+            r.rhi = g.nrunrec ? (uint32_t)lin_exact<2>((const uint32_t PC_GLOBAL *)g.run_rec, g.rlin_tab, q0, qn, e) : 0u;
+            if (r.rhi < r.rlo) r.rhi = r.rlo;
+        } else {
+            r.lo = lin_floor(g.lin_tab, q0, qn, a - Ws + 1);
+            r.hi = lin_floor(g.lin_tab, q0, qn, e_up);
+            r.rlo = g.nrunrec ? (uint32_t)lin_floor(g.rlin_tab, q0, qn, a - Wr + 1) : 0u;
+            r.rhi = g.nrunrec ? (uint32_t)lin_floor(g.rlin_tab, q0, qn, e_up) : 0u;
+        }
         r.glo = g.ngap ? lin_floor(g.glin_tab, q0, qn, a - W + 1) : 0;
-        r.ghi = g.ngap ? lin_floor(g.glin_tab, q0, qn, e) : 0;
-        r.rlo = g.nrunrec ? (uint32_t)lin_floor(g.rlin_tab, q0, qn, a - Wr + 1) : 0u;
-        r.rhi = g.nrunrec ? (uint32_t)lin_floor(g.rlin_tab, q0, qn, e) : 0u;
+        r.ghi = g.ngap ? lin_floor(g.glin_tab, q0, qn, e_up) : 0;
         r.llo = r.lhi = 0;
         if (g.nxlong) {   // long-span candidates of the whole queried span (every sub-window checks them)
             r.lhi = lin_floor(g.xllin_tab, q0, qn, s_hi);
@@ -612,11 +641,11 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         t = (int)idx;
         tl = tiles[t];
         ws = tl.win_start;
-        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1;
+        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1, s_end = ws + tl.span_hi;
         int64_t ng = 0, nl = 0, nr = 0;
         for (int ff = 0; ff < nfiles; ++ff) {
             FileRange r;
-            file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
+            file_ranges(ff, tl.tid, s_lo, s_end, s_lo, s_hi, r);
             jn += r.hi - r.lo; ng += r.ghi - r.glo; nl += r.lhi - r.llo; nr += (int64_t)r.rhi - (int64_t)r.rlo;
         }
         while (S < kMaxSub && G % (S * 2 << kLinShift) == 0 && jn > R * S) S <<= 1;
@@ -629,10 +658,10 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             for (int k = 0; k < S; ++k) {
                 const int64_t a = ws + (int64_t)k * sub;
                 int64_t nk = 0;
-                for (int ff = 0; ff < nfiles; ++ff) {
-                    const GFile g = ff == 0 ? gfile(file0) : gfile(files[ff]);
-                    const int64_t q0 = g.lin_off[tl.tid], qn = g.lin_off[tl.tid + 1] - q0 - 1;
-                    nk += lin_floor(g.lin_tab, q0, qn, a + sub) - lin_floor(g.lin_tab, q0, qn, a - Ws + 1);
+                for (int ff = 0; ff < nfiles; ++ff) {   // (the very ranges the items below get: the class counts must agree with them)
+                    FileRange r;
+                    file_ranges(ff, tl.tid, a, a + sub, s_lo, s_hi, r);
+                    nk += r.hi - r.lo;
                 }
                 if (nk > pile) merge = true; // a pile-up inside one sub-window
                 if (nk > R) ++n_heavy; else ++n_light;
@@ -644,7 +673,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             n_light = 0;
             for (int ff = 0; ff < nfiles; ++ff) {
                 FileRange r;
-                file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
+                file_ranges(ff, tl.tid, s_lo, s_end, s_lo, s_hi, r);
                 const int64_t nf = r.hi - r.lo;
                 n_light += nf > 0 ? (uint32_t)((nf + R - 1) / R) : ((r.ghi > r.glo || r.lhi > r.llo || r.rhi > r.rlo || ff == 0) ? 1u : 0u);
             }
@@ -660,16 +689,29 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         nb = fv.lin_off[tl.tid + 1] - l0 - 1;
         // only reads that can land on a queried position matter: a sparse annotation (one
         // 150-nt exon in a 4096-nt window) scans the exon's neighbourhood, not the whole window
-        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1;
-        wlo = lin_floor(fv.lin_tab, l0, nb, s_lo - Ws + 1);
-        whi = lin_floor(fv.lin_tab, l0, nb, s_hi);
+        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1, s_end = ws + tl.span_hi;
+        const bool exact = (int)tl.span_hi - (int)tl.span_lo <= kExactSpan;   // a short span: exact bounds instead of bucket edges
+        if (exact) {
+            wlo = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, l0, nb, s_lo - Ws + 1);
+            whi = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, l0, nb, s_end);
+            if (whi < wlo) whi = wlo;
+        } else {
+            wlo = lin_floor(fv.lin_tab, l0, nb, s_lo - Ws + 1);
+            whi = lin_floor(fv.lin_tab, l0, nb, s_hi);
+        }
         if (fv.ngap) {
             wglo = lin_floor(fv.glin_tab, l0, nb, s_lo - W + 1);
             wghi = lin_floor(fv.glin_tab, l0, nb, s_hi);
         }
         if (fv.nrunrec) { // aligned runs (of gapped and spliced reads) that start up to Wr before the span
-            wrlo = lin_floor(fv.rlin_tab, l0, nb, s_lo - Wr + 1);
-            wrhi = lin_floor(fv.rlin_tab, l0, nb, s_hi);
+            if (exact) {
+                wrlo = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.run_rec, fv.rlin_tab, l0, nb, s_lo - Wr + 1);
+                wrhi = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.run_rec, fv.rlin_tab, l0, nb, s_end);
+                if (wrhi < wrlo) wrhi = wrlo;
+            } else {
+                wrlo = lin_floor(fv.rlin_tab, l0, nb, s_lo - Wr + 1);
+                wrhi = lin_floor(fv.rlin_tab, l0, nb, s_hi);
+            }
         }
         if (fv.nxlong) {
             // long-span reads outside the run stream that can reach the queried span: they start before
@@ -691,7 +733,11 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
                 const int sub = G / S;
                 for (int k = 0; k < S; ++k) {
                     const int64_t a = ws + (int64_t)k * sub;
-                    const int64_t nk = lin_floor(fv.lin_tab, l0, nb, a + sub) - lin_floor(fv.lin_tab, l0, nb, a - Ws + 1);
+                    // (the very range the item below gets -- exact lower bound for short sub-windows: the class counts must agree with it)
+                    const int64_t lo_k = sub <= kExactSpan ? lin_exact<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, l0, nb, a - Ws + 1)
+                                                           : lin_floor(fv.lin_tab, l0, nb, a - Ws + 1);
+                    int64_t nk = lin_floor(fv.lin_tab, l0, nb, a + sub) - lo_k;
+                    if (nk < 0) nk = 0;
                     if (nk > pile) merge = true; // a pile-up inside one sub-window
                     if (nk > R) ++n_heavy; else ++n_light;
                 }
@@ -728,7 +774,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         w.win_start = tl.win_start;
         w.span_lo = tl.span_lo; w.span_hi = tl.span_hi;
         w.merge = merge ? 1u : 0u;
-        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1;
+        const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1, s_end = ws + tl.span_hi;
         auto head = [&](const FileRange &r) {
             w.lo = r.lo; w.hi = r.hi; w.glo = r.glo; w.ghi = r.ghi; w.llo = r.llo; w.lhi = r.lhi; w.rlo = r.rlo; w.rhi = r.rhi;
         };
@@ -736,7 +782,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             const uint32_t slot = s_base[2] + off_s;
             for (int ff = 0; ff < nfiles; ++ff) {
                 FileRange r;
-                file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
+                file_ranges(ff, tl.tid, s_lo, s_end, s_lo, s_hi, r);
                 if (ff == 0) head(r); else chain_small[(size_t)slot * (size_t)(nfiles - 1) + (size_t)(ff - 1)] = r;
             }
             w.win_start = tl.win_start + (int32_t)tl.span_lo; // a small window that starts at the first queried position
@@ -751,7 +797,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             atomicAdd(&nwork[4], 1u);           // windows merged through the compact histogram (none: k_gather_split has nothing to do)
             for (int ff = 0; ff < nfiles; ++ff) {
                 FileRange r;
-                file_ranges(ff, tl.tid, s_lo, s_hi, s_lo, s_hi, r);
+                file_ranges(ff, tl.tid, s_lo, s_end, s_lo, s_hi, r);
                 const int64_t nf = r.hi - r.lo;
                 const uint32_t cnt = nf > 0 ? (uint32_t)((nf + R - 1) / R) : ((r.ghi > r.glo || r.lhi > r.llo || r.rhi > r.rlo || ff == 0) ? 1u : 0u);
                 w.file = (uint32_t)ff;
@@ -771,7 +817,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         const int sub = G / S;
         for (int k = 0; k < S; ++k) {
             const int64_t a = S == 1 ? s_lo : ws + (int64_t)k * sub;
-            const int64_t e = S == 1 ? s_hi : a + sub;
+            const int64_t e = S == 1 ? s_end : a + sub;
             FileRange r0, r;
             file_ranges(0, tl.tid, a, e, s_lo, s_hi, r0);
             int64_t nk = r0.hi - r0.lo;
@@ -830,12 +876,23 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     for (int k = 0; k < S; ++k) {
         const int64_t a = S == 1 ? ws + tl.span_lo : ws + (int64_t)k * sub;
         const int64_t e = S == 1 ? ws + tl.span_hi + (1 << kLinShift) - 1 : a + sub;
-        w.lo = lin_floor(fv.lin_tab, l0, nb, a - Ws + 1);
-        w.hi = lin_floor(fv.lin_tab, l0, nb, e);
+        if (S == 1) {   // (the window's own bounds from above: exact for a short span)
+            w.lo = wlo; w.hi = whi; w.rlo = (uint32_t)wrlo; w.rhi = (uint32_t)wrhi;
+        } else if (sub <= kExactSpan) {   // (a sub-window ends on a bucket edge: only its lower bounds need the search)
+            w.lo = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, l0, nb, a - Ws + 1);
+            w.hi = lin_floor(fv.lin_tab, l0, nb, e);
+            w.rlo = fv.nrunrec ? (uint32_t)lin_exact<2>((const uint32_t PC_GLOBAL *)fv.run_rec, fv.rlin_tab, l0, nb, a - Wr + 1) : 0u;
+            w.rhi = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, e) : 0u;
+            if (w.hi < w.lo) w.hi = w.lo;
+            if (w.rhi < w.rlo) w.rhi = w.rlo;
+        } else {
+            w.lo = lin_floor(fv.lin_tab, l0, nb, a - Ws + 1);
+            w.hi = lin_floor(fv.lin_tab, l0, nb, e);
+            w.rlo = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, a - Wr + 1) : 0u;
+            w.rhi = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, e) : 0u;
+        }
         w.glo = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, a - W + 1) : 0;
         w.ghi = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, e) : 0;
-        w.rlo = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, a - Wr + 1) : 0u;
-        w.rhi = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, e) : 0u;
         w.llo = llo; w.lhi = lhi; // every sub-window checks the (few) long-span candidates
         w.sub_lo = S == 1 ? 0 : k * sub;
         w.sub_hi = S == 1 ? G : w.sub_lo + sub;
@@ -1786,6 +1843,14 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
                  : [cm] "v"(cm_), [val] "v"(valh_), [lbit] "v"(lane_bit), [sh] "v"(lane_sh)                            \
                  : "v8", "v9", "v10", "v11", "v12", "v13")
 
+// Experiment hook (scripts/exp_center_sections.py; never set in the product build): a build with -DPC_CENTER_SKIP=<mask>
+// leaves out 1 the replay steps (entries are still loaded and prepared), 2 the near-window stream loop altogether,
+// 4 the epilogue (output pieces, stores), 8 the per-wave LDS copy of the by-length table -- each section's share of
+// k_center is the difference in time (the results are then wrong).
+#ifndef PC_CENTER_SKIP
+#define PC_CENTER_SKIP 0
+#endif
+
 struct CenterCtx {
     const CenterChunk *chunks;
     int64_t nchunks;
@@ -1875,6 +1940,7 @@ __device__ __forceinline__ void center_chunk(const CenterCtx &cx, const uint32_t
                 }
                 return;
             }
+            if (PC_CENTER_SKIP & 1) { asm volatile("" : [acc] "+v"(acc) : [cm] "v"(cm_), [val] "v"(valh_)); return; }
             if (nsteps > 12) {
                 PC_CENTER_STEPS(PC_CS_Q0 PC_CS_Q1 PC_CS_Q2 PC_CS_Q3);
             } else {
@@ -1937,6 +2003,7 @@ __device__ __forceinline__ void center_chunk(const CenterCtx &cx, const uint32_t
             nmax = nmax > n3 ? nmax : n3;
         }
         if (nmax == 0u) continue;
+        if (PC_CENTER_SKIP & 2) continue;
         const u32x2 PC_GLOBAL *ent = cs_stream(files + f, sel);
         // (the loads are unconditional: a lane past its row's end reads one of the 64 entries behind the stream's last,
         // which cover nothing -- no validity test per entry; 32-bit offsets from the chunk's first entry: one scalar base,
@@ -1990,6 +2057,7 @@ __device__ __forceinline__ void center_chunk(const CenterCtx &cx, const uint32_t
     // 5'->3' reversal of '-' chains; reads-per-million as count / sum * 1e6 in that order, genome_array.py:826-827):
     // every queried segment slice of the chunk's window that holds this lane's position gets the lane's sum -- no
     // intermediate histogram, no gather pass.
+    if (PC_CENTER_SKIP & 4) { asm volatile("" : : "v"(acc)); return; }
     {
         const double val = norm_on ? acc / norm_sum * 1e6 : acc;
         for (uint32_t oi = ck.op_begin; oi < ck.op_end; ++oi) {
@@ -2023,7 +2091,7 @@ __global__ __launch_bounds__(kCenterWG) __attribute__((amdgpu_waves_per_eu(8, 8)
     unsigned long long n_slots = 0;   // PC_CENTER_DEBUG / pc_center_replay_steps: replay steps of this wave
     // half the value of a read by aligned length (k_center_vals), in LDS: one copy per wave
     __shared__ double s_valh[256];
-    for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
+    if (!(PC_CENTER_SKIP & 8)) for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
     __builtin_amdgcn_wave_barrier();
     uint32_t slot;
     if (bidx < n_heavy) {
@@ -2045,6 +2113,390 @@ __global__ __launch_bounds__(kCenterWG) __attribute__((amdgpu_waves_per_eu(8, 8)
     if (dbg && lane == 0) {   // PC_CENTER_DEBUG
         dbg[2 * (size_t)slot] = wall_clock64() - t_begin; dbg[2 * (size_t)slot + 1] = t_begin;
         dbg[2 * (size_t)cap + slot] = n_slots;
+    }
+}
+
+// ---------------------------------------------------------------- k_center_slots / k_center2 (round 5)
+// Where round 4's k_center spent its time (scripts/exp_center_sections.py, sections compiled out): of 1.20 ms on C3 the
+// replay steps themselves are 0.14 -- the rest is LATENCY: a wave's four dependent loads before its first entry
+// (counters -> order -> {chunk, ranges, row ranges} -> entries: 0.36 ms for 372 k waves with nothing else to do), the
+// entry loop at two batches in flight (0.42 ms without a single step), and the output pieces fetched after the last step
+// (0.2 - 0.3 ms).  A wave spent 14 of its 26 us outside the replay loop, so on average fewer than four of a SIMD's eight
+// waves had steps to issue.  Hence, for plans over ONE alignment file (every BASELINE config):
+//   * k_center_slots (cached with the dispatch list: once per plan, alignments and halo) resolves every dispatch entry
+//     into a 128-byte DESCRIPTOR: the (sub-)chunk's positions, its rows' entry ranges (those of a sub-chunk's narrower
+//     rows by the bisections the wave used to make), the long-span candidates, and -- when exactly one output piece
+//     takes the chunk's sums, the common case -- that piece inline;
+//   * k_center2: a wave loads a descriptor with ONE coalesced 128-byte request (lane l holds dword l; fields come out
+//     by v_readlane, the rows' ranges by a lane permute) and requests its entries right behind it: two dependent trips
+//     instead of four, none in the epilogue;
+//   * a wave serves PC_CENTER_PER_WAVE consecutive light entries (heavy ones -- long replays -- keep a wave each) and has
+//     the NEXT descriptor in flight while it replays: the launch has a quarter of the waves, and three of four chunks
+//     start with their descriptor already in registers;
+//   * PC_CENTER2_RING batches of entries in flight per wave, and no load is issued for a batch behind the longest row.
+struct CenterSlot {
+    int32_t start;             // first position of the (sub-)chunk
+    uint32_t shape;            // positions (0: nothing to do) | row width << 8 | strand mode << 16 | 1 << 24: `out_off` .. `ostep` hold THE output piece
+    uint32_t ent0;             // first stream entry of the chunk's near window: base of the 32-bit entry offsets below
+    uint32_t to_end;           // entries from there to the end of the stream (64 entries that cover nothing follow it)
+    uint32_t lo[kCenterRows], hi[kCenterRows];   // the rows' entry ranges, relative to ent0
+    uint32_t long_z, long_w;   // candidate range of the long-span list
+    uint32_t nmax;             // entries of the longest row
+    uint32_t chunk;            // chunk index | code << kSubShift (diagnostics)
+    uint32_t out_lo, out_hi;   // out_off of the inline output piece (two halves: the descriptor is read dword by dword)
+    int32_t ostart, olen, ostep;
+    uint32_t op_begin, op_end; // the window's output pieces: the general epilogue when no piece, or several, take the sums
+    int32_t tid;
+    uint32_t pad[8];
+};
+static_assert(sizeof(CenterSlot) == 128, "a descriptor is 32 dwords: one per lane of half a wave");
+enum { kCsStart = 0, kCsShape = 1, kCsEnt0 = 2, kCsToEnd = 3, kCsLo = 4, kCsHi = 8, kCsLongZ = 12, kCsLongW = 13, kCsNmax = 14,
+       kCsChunk = 15, kCsOutLo = 16, kCsOutHi = 17, kCsOStart = 18, kCsOLen = 19, kCsOStep = 20, kCsOpBegin = 21, kCsOpEnd = 22, kCsTid = 23 };
+
+#ifndef PC_CENTER_PER_WAVE
+#define PC_CENTER_PER_WAVE 1   // light entries per wave (4 / 8 measured on C3: the bulk of the launch ends no earlier, and a wave over 4 consecutive dense chunks becomes its tail: 1.85 / 2.71 ms against 1.18)
+#endif
+#ifndef PC_CENTER_HEAVY_PRIO
+#define PC_CENTER_HEAVY_PRIO 3  // s_setprio of the waves that serve heavy entries (0: none)
+#endif
+#ifndef PC_CENTER2_RING
+#define PC_CENTER2_RING 4
+#endif
+
+// steps the replay executes for a row range of `n` entries (batches of 16, the last one rounded up to whole quarters)
+__device__ __forceinline__ uint32_t center_steps_of(uint32_t n) { return (n & ~15u) + (((n & 15u) + 3u) & ~3u); }
+
+// One THREAD per dispatch entry (heavy entries first, then the light ones in list order): its descriptor.
+// fill[0] += entries of all rows, fill[1] += 4 x replay steps (the lock-step rows' capacity): their ratio is the row
+// fill the bench line reports.
+__global__ __launch_bounds__(kRangesWG) void k_center_slots(const CenterChunk *__restrict__ chunks, int64_t nchunks, const FileView *__restrict__ files,
+                                                            int W, const uint32_t *__restrict__ order, const uint32_t *__restrict__ counters,
+                                                            const u32x4 *__restrict__ ranges, const u32x2 *__restrict__ rec_ranges,
+                                                            const uint32_t *__restrict__ row_ranges, const OutPiece *__restrict__ opieces,
+                                                            CenterSlot *slots, unsigned long long *fill) {
+    const uint32_t n_heavy = counters[0], n_light = counters[1];
+    const uint32_t e = blockIdx.x * (uint32_t)kRangesWG + threadIdx.x;
+    unsigned long long f_ent = 0, f_cap = 0;
+    if (e < n_heavy + n_light) {
+        const uint32_t cap = kCenterCap * (uint32_t)nchunks;
+        const uint32_t entry = e < n_heavy ? order[e] : order[cap - 1u - (e - n_heavy)];
+        const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
+        const CenterChunk ck = chunks[cidx];
+        CenterSlot sl;
+        for (int k = 0; k < 8; ++k) sl.pad[k] = 0u;
+        const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
+        const int roww = code == 0u ? 16 : (code <= 4u ? 4 : 2);
+        const int32_t s0 = ck.start + sub_off;
+        const int32_t cend = ck.start + (ck.len < sub_off + kCenterRows * roww ? ck.len : sub_off + kCenterRows * roww);
+        const int npos = cend > s0 ? cend - s0 : 0;
+        const int sel = center_sel(ck.mode);
+        const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[cidx];
+        sl.start = s0;
+        sl.ent0 = rg.x;
+        sl.to_end = files[0].cs_total[sel] - rg.x;
+        sl.long_z = rg.z; sl.long_w = rg.w;
+        sl.chunk = entry;
+        sl.tid = ck.tid;
+        sl.op_begin = ck.op_begin; sl.op_end = ck.op_end;
+        sl.out_lo = sl.out_hi = 0u; sl.ostart = 0; sl.olen = 0; sl.ostep = 0;
+        uint32_t nmax = 0;
+        if (npos > 0) {
+            const GFile fv = gfile(files[0]);
+            const uint32_t PC_GLOBAL *soff = cs_offsets(files, sel);
+            const u32x2 rr = ((const u32x2 PC_GLOBAL *)rec_ranges)[cidx];
+            for (int r = 0; r < kCenterRows; ++r) {
+                uint32_t lo, hi;
+                if (code == 0u) {
+                    const uint32_t PC_GLOBAL *rt = (const uint32_t PC_GLOBAL *)row_ranges + (size_t)cidx * (2 * kCenterRows);
+                    lo = rt[r]; hi = rt[kCenterRows + r];
+                } else {   // the narrower rows of a sub-chunk: records that start in [row start - W + 1, row end)
+                    const int32_t rs = s0 + r * roww, re = rs + roww < cend ? rs + roww : cend;
+                    const bool row_live = rs < cend;
+                    const int64_t key_lo = row_live ? (int64_t)rs - W + 1 : (int64_t)cend, key_hi = row_live ? (int64_t)re : (int64_t)cend;
+                    const int64_t r0 = lower_bound_pos(fv.rec, rr.x, rr.y, key_lo);
+                    const int64_t r1 = lower_bound_pos(fv.rec, r0, rr.y, key_hi);
+                    lo = soff[r0]; hi = soff[r1];
+                }
+                if (hi < lo) hi = lo;
+                sl.lo[r] = lo - rg.x; sl.hi[r] = hi - rg.x;
+                nmax = hi - lo > nmax ? hi - lo : nmax;
+                f_ent += hi - lo;
+            }
+            f_cap = (unsigned long long)kCenterRows * center_steps_of(nmax);
+            // the output pieces that take this (sub-)chunk's sums: exactly one -- inline
+            uint32_t hits = 0, which = 0;
+            for (uint32_t oi = ck.op_begin; oi < ck.op_end; ++oi) {
+                const OutPiece o = opieces[oi];
+                if (o.mode == ck.mode && o.start < cend && o.start + o.len > s0) { ++hits; which = oi; }
+            }
+            if (hits == 1u) {
+                const OutPiece o = opieces[which];
+                sl.out_lo = (uint32_t)((unsigned long long)o.out_off); sl.out_hi = (uint32_t)((unsigned long long)o.out_off >> 32);
+                sl.ostart = o.start; sl.olen = o.len; sl.ostep = o.step;
+            }
+            sl.shape = (uint32_t)npos | ((uint32_t)roww << 8) | ((uint32_t)ck.mode << 16) | (hits == 1u ? 1u << 24 : 0u);
+            if (hits == 0u) sl.op_begin = sl.op_end = 0u;   // (nothing takes the sums: the positions are replayed for nobody -- cannot happen for a chunk cut from queried pieces, kept harmless)
+        } else {
+            for (int r = 0; r < kCenterRows; ++r) { sl.lo[r] = 0u; sl.hi[r] = 0u; }
+            sl.shape = 0u;
+        }
+        sl.nmax = nmax;
+        slots[e] = sl;
+    }
+    for (int o = 32; o > 0; o >>= 1) { f_ent += __shfl_down(f_ent, o, 64); f_cap += __shfl_down(f_cap, o, 64); }
+    if ((threadIdx.x & 63) == 0 && f_cap) { atomicAdd(&fill[0], f_ent); atomicAdd(&fill[1], f_cap); }
+}
+
+struct Center2Ctx {
+    const CenterSlot *slots;
+    const uint2 *ent[3];       // the file's center streams by strand selection (kernel arguments: no load between descriptor and entries)
+    uint32_t indirect;         // bit sel: that stream holds indirect entries (reads beyond the 8-bit fields)
+    const FileView *files;
+    MapParams mp;
+    int W;
+    const double *inv, *invh, *cvalh;
+    const uint32_t *counters;
+    uint32_t known, n_heavy, n_light;   // known: the host has read the list's counts back (else the kernel reads `counters`)
+    const OutPiece *opieces;
+    double *out;
+    double norm_sum;
+    int norm_on;
+    unsigned long long *dbg;
+    uint32_t dbg_cap;
+};
+
+// One (sub-)chunk from its descriptor `d` (lane l < 32 holds dword l; the upper half of the wave holds a copy).
+template <bool DBG, bool GENERAL>
+__device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t d, const int lane, const double *s_valh, unsigned long long &n_slots) {
+    const uint32_t shape = lane_u32(d, kCsShape);
+    const int npos = (int)(shape & 0xffu);
+    if (npos == 0) return;
+    const int roww = (int)((shape >> 8) & 0xffu), mode = (int)((shape >> 16) & 0xffu);
+    const double PC_GLOBAL *inv = (const double PC_GLOBAL *)cx.inv;      // 1.0 / m
+    const double PC_GLOBAL *invh = (const double PC_GLOBAL *)cx.invh;    // 0.5 / m = (1.0 / m) / 2, exactly
+    const MapParams &mp = cx.mp;
+    const int W = cx.W;
+    const int row = lane >> 4, li = lane & 15;
+    const int nib = mp.param;
+    const int32_t s0 = (int32_t)lane_u32(d, kCsStart), cend = s0 + npos;
+    const int32_t rs = s0 + row * roww;                              // this lane's row: positions [rs, re)
+    const bool row_live = rs < cend;
+    const int32_t p = rs + li;
+    const bool owns = li < roww && p < cend;
+    const int sel = center_sel(mode);
+    const int lane_bit = 1 << li, lane_sh = 30 - li;
+    double acc = 0.0;
+    const GFile fv = gfile(cx.files[0]);
+    auto row_mask = [&](int a0, int m) {   // (m = 0: nothing)
+        const int first = a0 - rs, b0 = first > 0 ? first : 0, b1 = first + m < 16 ? first + m : 16;   // row-relative [b0, b1)
+        return b1 > b0 ? (int)((1u << b1) - (1u << b0)) : 0;
+    };
+    // one batch: entry `li` of every row in (cm_, valh_); `indirect`: a read the entry cannot describe (record `recidx`)
+    auto replay = [&](int a0_, int mm_, int cm_, double valh_, bool indirect, uint32_t recidx, int nsteps, bool may_be_indirect) {
+        if (DBG) n_slots += (unsigned long long)nsteps;
+        if (may_be_indirect && __any(indirect)) {
+            for (int j = 0; j < 16; ++j) {   // entry by entry, row by row (what matters is the order inside a row)
+                for (int r = 0; r < kCenterRows; ++r) {
+                    const int src = r * 16 + j;
+                    if (lane_u32((uint32_t)indirect, src)) {
+                        const int64_t i = (int64_t)lane_u32(recidx, src);
+                        const u32x2 rr = fv.rec[i];
+                        int Li, nbi;
+                        rec_true(fv, i, rr.y, Li, nbi);
+                        double t = acc;
+                        center_read(fv, mp, inv, (int32_t)rr.x, Li, nbi, nbi >= 2 ? fv.blk_off[i] : 0u, p, t);
+                        acc = row == r ? t : acc;
+                    } else {
+                        const int aj = (int)lane_u32((uint32_t)a0_, src), mj = (int)lane_u32((uint32_t)(cm_ ? mm_ : 0), src);
+                        if (mj == 0) continue;
+                        const double vj = lane_f64(valh_, src) * 2.0;      // (exact; 0.0 where the row is not covered at all)
+                        acc += (row == r && (uint32_t)(p - aj) < (uint32_t)mj) ? vj : 0.0;
+                    }
+                }
+            }
+            return;
+        }
+        if (PC_CENTER_SKIP & 1) { asm volatile("" : [acc] "+v"(acc) : [cm] "v"(cm_), [val] "v"(valh_)); return; }
+        if (nsteps > 12) {
+            PC_CENTER_STEPS(PC_CS_Q0 PC_CS_Q1 PC_CS_Q2 PC_CS_Q3);
+        } else {
+            PC_CENTER_STEPS(PC_CS_Q0);
+            if (nsteps > 4) PC_CENTER_STEPS(PC_CS_Q1);
+            if (nsteps > 8) PC_CENTER_STEPS(PC_CS_Q2);
+        }
+    };
+    // Long-span reads that start before the near window of a row but may reach into it: they precede every near-window
+    // record in the file, so they are replayed first, in list order.  The candidates are the reads whose SPAN covers
+    // the chunk -- in a region under many introns nearly all of them put no aligned base on it.  Round 4 walked them 8
+    // at a time, one dependent load and 16 replay steps per batch whether or not anything was covered: the chunks under
+    // the deepest stacks of spliced reads (7 400 candidates: 930 batches, a microsecond each) WERE the tail of the
+    // launch.  Now 64 candidates per trip (one per lane), a vote on which of them can count at all, and only the
+    // eighths of the group that hold such a read are handed round (lane permutes) and replayed -- skipping a read that
+    // adds +0.0 to every sum leaves every bit as it was.
+    const uint32_t long_z = lane_u32(d, kCsLongZ), long_w = lane_u32(d, kCsLongW);
+    if (long_w > long_z) {
+        const int64_t near_row = (int64_t)rs - W + 1;
+        const int64_t near_last = (int64_t)s0 + (kCenterRows - 1) * roww - W + 1;   // the last row's: the furthest any row looks
+        for (int64_t base = long_z; base < (int64_t)long_w; base += 64) {
+            const int64_t jl = base + lane;
+            const bool inl = jl < (int64_t)long_w;
+            u32x4 gl = inl ? fv.long_rec[jl] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
+            if ((int64_t)(int32_t)lane_u32(gl.x, 0) >= near_last) break; // sorted by start: the rest is met in the near windows
+            const i32x4 rl = inl ? fv.long_runs[jl] : i32x4{0, 0, 0, 0};
+            const uint32_t fll = rec_flags(gl.y);
+            int nbl = rec_nblk(gl.y), Ll = rec_len(gl.y);
+            if (inl && (fll & kFlagWide)) { const u32x2 tv = fv.long_wide[jl]; Ll = (int)tv.x; nbl = (int)tv.y; }   // beyond the 16 / 8-bit fields
+            // can candidate `lane` count anywhere in [s0, cend)?  (reads with more than two runs go through their record: kept)
+            bool matters = inl && (int64_t)(int32_t)gl.x < near_last && !(fll & kFlagExcluded) && strand_ok(mode, fll & kFlagReverse) && size_ok(mp, Ll);
+            if (matters && nbl <= 2) {
+                const int lo0 = nib, hi0 = rl.y < Ll - nib ? rl.y : Ll - nib;                         // run 0: read indices [0, len0)
+                const int a0 = rl.x + lo0, m0 = hi0 > lo0 ? hi0 - lo0 : 0;
+                const int lo1 = rl.y > nib ? rl.y : nib, hi1 = rl.y + rl.w < Ll - nib ? rl.y + rl.w : Ll - nib;   // run 1: [len0, len0 + len1)
+                const int a1 = rl.z + (lo1 - rl.y), m1 = (nbl == 2 && hi1 > lo1) ? hi1 - lo1 : 0;
+                matters = (m0 > 0 && a0 < cend && a0 + m0 > s0) || (m1 > 0 && a1 < cend && a1 + m1 > s0);
+            }
+            const unsigned long long vote = __ballot(matters);
+            if (vote == 0ull) continue;
+#pragma unroll 1
+            for (int e8 = 0; e8 < 8; ++e8) {
+                if (((vote >> (8 * e8)) & 0xffull) == 0ull) continue;
+                // candidate 8 e8 + (li >> 1) of the group to lanes 2k, 2k + 1 of every row (its first / second aligned run)
+                const int src = 8 * e8 + (li >> 1);
+                u32x4 g;
+                g.x = (uint32_t)__shfl((int)gl.x, src, 64); g.y = (uint32_t)__shfl((int)gl.y, src, 64);
+                g.z = 0u; g.w = (uint32_t)__shfl((int)gl.w, src, 64);
+                i32x4 runs;
+                runs.x = __shfl(rl.x, src, 64); runs.y = __shfl(rl.y, src, 64); runs.z = __shfl(rl.z, src, 64); runs.w = __shfl(rl.w, src, 64);
+                const int Lg = __shfl(Ll, src, 64), nbk = __shfl(nbl, src, 64);
+                const bool in = base + src < (int64_t)long_w;
+                const uint32_t fl = rec_flags(g.y);
+                const int r = li & 1;
+                const bool ok = in && row_live && (int64_t)(int32_t)g.x < near_row && !(fl & kFlagExcluded) && strand_ok(mode, fl & kFlagReverse);
+                // (these entries come with their read's header, not from the stream: trimmed by the nibble here)
+                const int x = r ? runs.z : runs.x, len = r ? runs.w : runs.y, cum = r ? runs.y : 0;
+                const int lo_i = cum > nib ? cum : nib, hi_i = cum + len < Lg - nib ? cum + len : Lg - nib;
+                const int a0_ = x + (lo_i - cum), mm_ = hi_i > lo_i ? hi_i - lo_i : 0, mtot = Lg - 2 * nib;
+                const int cm_ = (ok && nbk <= 2 && (r == 0 || nbk == 2) && size_ok(mp, Lg)) ? row_mask(a0_, mm_) : 0;
+                double valh_ = 0.0;
+                if (cm_) valh_ = mtot < 65536 ? invh[mtot] : (1.0 / (double)mtot) * 0.5;   // cm != 0 implies mtot >= m > 0
+                replay(a0_, mm_, cm_, valh_, ok && nbk > 2 && r == 0, g.w, 16, true);
+            }
+        }
+    }
+    // near windows: row r replays the stream entries [lo, hi) the descriptor names for it
+    const uint32_t nmax = lane_u32(d, kCsNmax);
+    if (nmax != 0u && !(PC_CENTER_SKIP & 2)) {
+        const uint32_t ent0 = lane_u32(d, kCsEnt0), to_end = lane_u32(d, kCsToEnd);
+        const uint32_t lo = (uint32_t)__shfl((int)d, kCsLo + row, 64), hi = (uint32_t)__shfl((int)d, kCsHi + row, 64);
+        const uint2 *ent_sel = sel == 0 ? cx.ent[0] : (sel == 1 ? cx.ent[1] : cx.ent[2]);   // (selects, not an indexed copy: that would live in scratch)
+        const char PC_GLOBAL *eb = (const char PC_GLOBAL *)((const u32x2 PC_GLOBAL *)ent_sel + ent0);
+        // (loads past a row's end read one of the 64 entries behind the stream's last, which cover nothing; a stream whose
+        // end lies beyond a 32-bit byte offset from here clamps to the row's end instead and tests every entry's index)
+        const bool far = GENERAL && to_end >= (1u << 28);
+        const uint32_t rlo = lo + (uint32_t)li, rhi = hi, dead = far ? rhi : to_end + (uint32_t)li;
+        auto fetch = [&](uint32_t base) {
+            const uint32_t idx = rlo + base;
+            return *(const u32x2 PC_GLOBAL *)(eb + ((idx < rhi ? idx : dead) << 3));
+        };
+        const bool any_indirect = GENERAL && ((cx.indirect >> sel) & 1u) != 0u;   // (uniform: short-read files have none, and never look)
+        struct Prepared { int cm; double valh; bool ind; u32x2 r; };
+        auto unpack = [&](const u32x2 r, uint32_t base) {
+            Prepared pr;
+            pr.r = r;
+            pr.ind = any_indirect && ((r.y >> 24) & kCsIndirect);     // (an indirect entry carries m = 0)
+            pr.cm = row_mask((int32_t)r.x, (int)(r.y & 0xffu));
+            if (far && !(rlo + base < rhi)) pr.cm = 0;
+            pr.valh = s_valh[(r.y >> 16) & 0xffu];   // by aligned length (an indirect entry reads [0])
+            return pr;
+        };
+        // PC_CENTER2_RING batches in flight, each in a register pair of its own; the batch after the one being replayed is
+        // already unpacked.  A batch that starts behind the longest row is not requested at all (uniform test).
+        constexpr int RING = PC_CENTER2_RING;
+        const u32x2 none = {0x7fffffffu, 0u};
+        u32x2 q[RING];
+#pragma unroll
+        for (int k = 0; k < RING; ++k) q[k] = 16u * (uint32_t)k < nmax ? fetch(16u * (uint32_t)k) : none;
+        Prepared nxt = unpack(q[0], 0u);
+        q[0] = 16u * RING < nmax ? fetch(16u * RING) : none;
+        for (uint32_t base = 0; base < nmax;) {
+#pragma unroll
+            for (int k = 0; k < RING; ++k) {
+                const Prepared cur = nxt;
+                const int kn = (k + 1) % RING;   // (a constant once the loop is unrolled: q stays in registers)
+                nxt = unpack(q[kn], base + 16u);
+                q[kn] = base + 16u + 16u * RING < nmax ? fetch(base + 16u + 16u * RING) : none;
+                const uint32_t left = nmax - base;
+                replay((int32_t)cur.r.x, (int)(cur.r.y & 0xffu), cur.cm, cur.valh, cur.ind, cur.r.x, left >= 16u ? 16 : (int)((left + 3u) & ~3u), GENERAL);
+                base += 16u;
+                if (base >= nmax) break;
+            }
+        }
+    }
+    // the sums, straight into the caller's layout (SegmentChain.get_counts, roitools.pyx:3259-3271; reads-per-million as
+    // count / sum * 1e6 in that order, genome_array.py:826-827)
+    if (PC_CENTER_SKIP & 4) { asm volatile("" : : "v"(acc)); return; }
+    const double val = cx.norm_on ? acc / cx.norm_sum * 1e6 : acc;
+    if (shape >> 24) {   // THE output piece of this chunk, from the descriptor
+        const long long out_off = (long long)(((unsigned long long)lane_u32(d, kCsOutHi) << 32) | lane_u32(d, kCsOutLo));
+        const int32_t ostart = (int32_t)lane_u32(d, kCsOStart), olen = (int32_t)lane_u32(d, kCsOLen), ostep = (int32_t)lane_u32(d, kCsOStep);
+        const uint32_t rel = (uint32_t)(p - ostart);
+        if (owns && rel < (uint32_t)olen) cx.out[out_off + (long long)ostep * (long long)rel] = val;
+    } else {
+        const uint32_t op_begin = lane_u32(d, kCsOpBegin), op_end = lane_u32(d, kCsOpEnd);
+        for (uint32_t oi = op_begin; oi < op_end; ++oi) {
+            const OutPiece o = cx.opieces[oi];
+            if (o.mode != mode) continue;                     // the window's slices of other strand modes
+            const uint32_t rel = (uint32_t)(p - o.start);
+            if (owns && rel < (uint32_t)o.len) cx.out[o.out_off + (int64_t)o.step * (int64_t)rel] = val;
+        }
+    }
+}
+
+// Dispatch: wave b < n_heavy serves heavy entry b (they start at t = 0); the others serve PC_CENTER_PER_WAVE
+// consecutive light entries each, dealt so that the workgroups of one XCD (workgroup b runs on XCD b mod 8) walk ONE
+// contiguous eighth of the light list -- neighbouring chunks re-read each other's halo, which then hits the XCD's own L2.
+// (the diagnostic instantiations carry their clocks and step counters: compiled for seven waves, they keep out of scratch)
+template <bool DBG, bool GENERAL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBG ? 7 : 8, 8))) void k_center2(Center2Ctx cx) {
+    const uint32_t n_heavy = cx.known ? cx.n_heavy : cx.counters[0], n_light = cx.known ? cx.n_light : cx.counters[1];
+    const uint32_t bidx = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    constexpr uint32_t K = PC_CENTER_PER_WAVE;
+    uint32_t first, count;
+    if (bidx < n_heavy) {
+        // A heavy entry is ONE long dependent replay (the deepest pile-ups: 15 - 30 k steps), and the launch ends when the
+        // last of them does: sharing its SIMD round-robin with seven light waves it advances one step per ~150 cycles
+        // (0.95 ms for 15 k steps, the whole tail of the launch).  With a raised priority the arbiter issues it whenever it
+        // is ready; the light waves fill the gaps.
+        if (PC_CENTER_HEAVY_PRIO) __builtin_amdgcn_s_setprio(PC_CENTER_HEAVY_PRIO);
+        first = bidx; count = 1u;
+    } else {
+        const uint32_t k = bidx - n_heavy, n8 = (n_light + 7u) >> 3;           // entries per eighth of the light list
+        const uint32_t x = bidx & 7u, at = (k >> 3) * K;                         // this XCD's eighth, K entries from `at` on
+        const uint32_t lo8 = x * n8, hi8 = lo8 + n8 < n_light ? lo8 + n8 : n_light;
+        if (lo8 + at >= hi8) return;
+        first = n_heavy + lo8 + at;
+        count = hi8 - (lo8 + at) < K ? hi8 - (lo8 + at) : K;
+    }
+    const uint32_t PC_GLOBAL *sw = (const uint32_t PC_GLOBAL *)cx.slots;
+    uint32_t d = sw[(size_t)first * 32u + (uint32_t)(lane & 31)];
+    unsigned long long *dbg = DBG ? cx.dbg : nullptr;
+    const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
+    unsigned long long n_slots = 0;   // PC_CENTER_DEBUG / pc_center_replay_steps: replay steps of this wave
+    // half the value of a read by aligned length (k_center_vals), in LDS: one copy per wave
+    __shared__ double s_valh[256];
+    if (!(PC_CENTER_SKIP & 8)) for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t c = 0; c < count; ++c) {
+        uint32_t dn = 0u;
+        if (c + 1u < count) dn = sw[(size_t)(first + c + 1u) * 32u + (uint32_t)(lane & 31)];   // the next descriptor, in flight while this chunk replays
+        center_slot<DBG, GENERAL>(cx, d, lane, s_valh, n_slots);
+        d = dn;
+    }
+    if (dbg && lane == 0 && first < cx.dbg_cap) {   // PC_CENTER_DEBUG: heavy entries from the front of the table, light ones from its back (as k_center's list)
+        const size_t at = first < n_heavy ? (size_t)first : (size_t)cx.dbg_cap - 1u - (size_t)(first - n_heavy);
+        dbg[2 * at] = wall_clock64() - t_begin; dbg[2 * at + 1] = t_begin;
+        dbg[2 * (size_t)cx.dbg_cap + at] = n_slots;
     }
 }
 

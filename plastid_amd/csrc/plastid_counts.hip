@@ -385,6 +385,8 @@ struct Knobs {
     int center_t2 = 4;         //   count are cut into 4 (8) sub-chunks
     int64_t center_floor = 32768; // PC_CENTER_FLOOR: stream entries below which a chunk is never cut (a wave alone replays ~50 k per ms)
     int center_lds = 0;        // PC_CENTER_LDS: bytes of (unused) LDS per k_center workgroup -- an occupancy throttle for experiments
+    int center_legacy = 0;     // PC_CENTER_LEGACY: one-file plans through round 4's k_center too (A/B against k_center2)
+    int center_per_wave = 0;   // (reserved)
     int center_debug = 0;      // PC_CENTER_DEBUG: wall-clock span of every dispatched wave of k_center, printed after the launch (synchronises)
     void load() {
         *this = Knobs();
@@ -403,6 +405,7 @@ struct Knobs {
         if (const char *env = getenv("PC_CENTER_T2")) center_t2 = std::max(1, atoi(env));
         if (const char *env = getenv("PC_CENTER_FLOOR")) center_floor = std::max(64, atoi(env));
         center_debug = getenv("PC_CENTER_DEBUG") ? 1 : 0;
+        center_legacy = getenv("PC_CENTER_LEGACY") ? atoi(getenv("PC_CENTER_LEGACY")) : 0;
         if (const char *env = getenv("PC_CENTER_LDS")) center_lds = std::max(0, atoi(env));
     }
 };
@@ -529,11 +532,13 @@ struct pc_plan {
     DevBuf<u32x4> d_cranges;    // per (chunk, file): entry range of the near window and candidate range of the long-span list
     DevBuf<u32x2> d_crec;       // per (chunk, file): the near window as a record range (sub-chunks narrow it)
     DevBuf<uint32_t> d_crows;   // per (chunk, file): entry ranges of the chunk's four rows of 16 positions (4 x lo, 4 x hi)
-    DevBuf<uint32_t> d_ccounts; // [0] heavy, [1] light entries of the dispatch list, [2..3] sum of the candidate counts
+    DevBuf<uint32_t> d_ccounts; // [0] heavy, [1] light entries of the dispatch list, [2..3] sum of the candidate counts, [4..5] entries of all rows, [6..7] 4 x replay steps (row fill)
+    DevBuf<CenterSlot> d_cslots; // one descriptor per dispatch entry (plans over one alignment file: k_center2)
     // the center pre-passes (ranges, candidate counts, dispatch order) depend on the plan, the staged files and the
     // knobs only -- not on the mapping rule: kept from count to count while the engine's work generation stands
     uint64_t center_generation = 0;
     int center_W = -1;
+    bool center_slots = false;             // the dispatch list has been resolved into descriptors (d_cslots)
     uint32_t *h_center_counts = nullptr;   // page-locked [2]: heavy, light entries of the list (sizes the grid of later counts)
     hipEvent_t ev_center_counts = nullptr;
     bool center_counts_known = false;
@@ -590,7 +595,7 @@ struct pc_plan {
         DevPool *pl = &eng->pool;
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
-        d_cranges.pool = pl; d_crec.pool = pl; d_crows.pool = pl; d_ccounts.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
+        d_cranges.pool = pl; d_crec.pool = pl; d_crows.pool = pl; d_ccounts.pool = pl; d_cslots.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
         d_work.pool = pl; d_work_small.pool = pl; d_chain.pool = pl; d_chain_small.pool = pl;
         d_inputs.pool = pl; d_gsegs_own.pool = pl;
     }
@@ -2831,10 +2836,14 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (rc == PC_OK) rc = p->d_crows.reserve((size_t)nchunks * (size_t)nfiles * (size_t)(2 * kCenterRows));
             if (rc == PC_OK) rc = p->d_ccounts.reserve(8);
             if (rc == PC_OK) rc = e->d_cvalh.reserve(256);
+            // one alignment file (every BASELINE config): descriptors per dispatch entry, several entries per wave (k_center2);
+            // several files keep round 4's kernel, whose waves walk the files of a chunk one after the other
+            const bool slots_on = nfiles == 1 && !e->knobs.center_legacy;
+            if (rc == PC_OK && slots_on) rc = p->d_cslots.reserve((size_t)(2 * nchunks));   // (heavy entries < chunks, light entries <= chunks)
             if (rc != PC_OK) return rc;
             hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(256), 0, st, mp, e->d_invh.p, e->d_cvalh.p);
-            if (p->center_generation != e->work_generation || p->center_W != W) {
-                HIP_TRY(hipMemsetAsync(p->d_ccounts.p, 0, 4 * sizeof(uint32_t), st));
+            if (p->center_generation != e->work_generation || p->center_W != W || p->center_slots != slots_on) {
+                HIP_TRY(hipMemsetAsync(p->d_ccounts.p, 0, 8 * sizeof(uint32_t), st));
                 unsigned long long *total = (unsigned long long *)(p->d_ccounts.p + 2);
                 const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
                 hipLaunchKernelGGL(k_center_weigh, dim3(wgs), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks, e->d_files.p, nfiles, W,
@@ -2843,6 +2852,11 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2;
                 hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, e->knobs.center_floor,
                                    (int64_t)2048, ck1, ck2, p->d_corder.p, p->d_ccounts.p);
+                if (slots_on)
+                    hipLaunchKernelGGL(k_center_slots, dim3((unsigned)((2 * nchunks + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks,
+                                       e->d_files.p, W, p->d_corder.p, p->d_ccounts.p, p->d_cranges.p, p->d_crec.p, p->d_crows.p, p->d_opieces.p,
+                                       p->d_cslots.p, (unsigned long long *)(p->d_ccounts.p + 4));
+                p->center_slots = slots_on;
                 p->center_generation = e->work_generation;
                 p->center_W = W;
                 // how many entries the list got: sizes the grid of the later counts of this plan (read back once)
@@ -2883,7 +2897,35 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             bool general = false;
             for (auto *f : e->files) general |= f->len_max > 255 || f->n + f->nrun >= ((int64_t)1 << 28);
             const dim3 cg((unsigned)((cgrid * 64 + kCenterWG - 1) / kCenterWG));
-            if (dbg_on) {
+            if (slots_on) {
+                // descriptors: heavy entries one wave each, PC_CENTER_PER_WAVE light entries per wave (an eighth of the list per XCD)
+                Center2Ctx c2;
+                StagedFile *sf0 = e->files[0];
+                c2.slots = p->d_cslots.p;
+                c2.indirect = 0u;
+                for (int k = 0; k < 3; ++k) {
+                    c2.ent[k] = sf0->cs_n[k] >= 0 ? sf0->cs_ent[k].p : nullptr;
+                    if (sf0->len_max > 255) c2.indirect |= 1u << k;
+                }
+                c2.files = e->d_files.p; c2.mp = mp; c2.W = W; c2.inv = e->d_inv.p; c2.invh = e->d_invh.p; c2.cvalh = e->d_cvalh.p;
+                c2.counters = p->d_ccounts.p;
+                c2.known = p->center_counts_known ? 1u : 0u; c2.n_heavy = p->center_counts[0]; c2.n_light = p->center_counts[1];
+                c2.opieces = p->d_opieces.p; c2.out = (double *)p->d_out.p; c2.norm_sum = e->norm_sum; c2.norm_on = e->norm_on ? 1 : 0;
+                c2.dbg = dbg; c2.dbg_cap = (uint32_t)dbg_slots;
+                uint64_t g2;
+                if (p->center_counts_known) {
+                    const uint64_t n8 = ((uint64_t)p->center_counts[1] + 7) >> 3;
+                    g2 = (uint64_t)p->center_counts[0] + 8 * ((n8 + PC_CENTER_PER_WAVE - 1) / PC_CENTER_PER_WAVE);
+                } else g2 = 2 * (uint64_t)nchunks + 8;
+                const dim3 cg2((unsigned)std::max<uint64_t>(g2, 1));
+                if (dbg_on) {
+                    if (general) hipLaunchKernelGGL((k_center2<true, true>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
+                    else hipLaunchKernelGGL((k_center2<true, false>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
+                } else {
+                    if (general) hipLaunchKernelGGL((k_center2<false, true>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
+                    else hipLaunchKernelGGL((k_center2<false, false>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
+                }
+            } else if (dbg_on) {
                 if (general) hipLaunchKernelGGL((k_center<true, true>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
                 else hipLaunchKernelGGL((k_center<true, false>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
             } else {

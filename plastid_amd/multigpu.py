@@ -226,29 +226,48 @@ class GenomePartition(object):
                     out_step=np.ones(len(ln), np.int8), row_stride=ln.astype(np.int64), out_elems=int(off[-1]),
                     piece_index=sg["piece_index"])
 
+    def _element_maps(self, rank, rows, keep=None):
+        """Flat ``(local_index, global_index, piece_of_element)`` of every element of rank `rank`'s local output
+        (pieces `keep`: boolean over the rank's pieces) -- built with repeats and running offsets, no loop over
+        pieces (C4: 479 k exons x cuts)."""
+        lp = self.local_plan_arrays(rank, rows)
+        pi = lp["piece_index"]
+        n = (lp["end"] - lp["start"]).astype(np.int64)
+        sel = n > 0
+        if keep is not None:
+            sel &= keep
+        j = np.nonzero(sel)[0]
+        z = np.zeros(0, np.int64)
+        if not len(j):
+            return z, z, z, lp
+        nj = n[j]
+        cnt = nj * rows                                  # elements of every kept piece: rows x len, row-major
+        tot = int(cnt.sum())
+        first = np.zeros(len(j) + 1, np.int64)
+        np.cumsum(cnt, out=first[1:])
+        pj = np.repeat(np.arange(len(j)), cnt)           # kept piece of every element
+        e = np.arange(tot, dtype=np.int64) - first[:-1][pj]   # element index inside its piece
+        r, i = e // nj[pj], e % nj[pj]                   # row, position
+        pc = self.piece
+        g0 = pc["out_off"][pi[j]].astype(np.int64)
+        st = pc["out_step"][pi[j]].astype(np.int64)
+        rs = pc["row_stride"][pi[j]].astype(np.int64)
+        li = lp["out_off"][j][pj] + e
+        gi = g0[pj] + r * rs[pj] + st[pj] * i
+        return li, gi, j[pj], lp
+
     def owned_elements(self, rank, rows=1, segments=None):
         """Where rank `rank`'s local output (see :meth:`local_plan_arrays`) sits in the caller's global
         layout: ``(local_index, global_index)`` element arrays, optionally only for the pieces of the
         given segment indices.  Summed slices (``out_step`` 0) are not covered."""
-        lp = self.local_plan_arrays(rank, rows)
-        want = None
+        keep = None
         if segments is not None:
             want = np.zeros(len(self.seg["tid"]), bool)
             want[np.asarray(segments, np.int64)] = True
-        pc = self.piece
-        li, gi = [], []
-        for j, pi in enumerate(lp["piece_index"]):
-            if want is not None and not want[pc["owner"][pi]]:
-                continue
-            n = int(lp["end"][j] - lp["start"][j])
-            if n <= 0:
-                continue
-            g0, st, rs = int(pc["out_off"][pi]), int(pc["out_step"][pi]), int(pc["row_stride"][pi])
-            for r in range(rows):
-                li.append(lp["out_off"][j] + r * n + np.arange(n))
-                gi.append(g0 + r * rs + st * np.arange(n))
-        z = np.zeros(0, np.int64)
-        return (np.concatenate(li) if li else z, np.concatenate(gi) if gi else z)
+            pi = np.nonzero(self.piece["rank"] == rank)[0]
+            keep = want[self.piece["owner"][pi]]
+        li, gi, _, _ = self._element_maps(rank, rows, keep)
+        return li, gi
 
     def chain_sum_plan_arrays(self, rank, seg_chain, n_chains, rows=1):
         """``pc_plan_create`` arrays that make rank `rank` SUM each of its pieces into slot
@@ -265,18 +284,14 @@ class GenomePartition(object):
     def scatter_local(self, global_out, rank, local_out, rows=1):
         """Place a rank-local result (see :meth:`local_plan_arrays`) into the caller's global layout
         (host-side assembly of chains whose exons straddle a cut)."""
-        lp = self.local_plan_arrays(rank, rows)
-        for j, pi in enumerate(lp["piece_index"]):
-            n = int(lp["end"][j] - lp["start"][j])
-            if n <= 0:
-                continue
-            g0, st, rs = int(self.piece["out_off"][pi]), int(self.piece["out_step"][pi]), int(self.piece["row_stride"][pi])
-            src = local_out[lp["out_off"][j]:lp["out_off"][j] + n * rows].reshape(rows, n)
-            for r in range(rows):
-                if st == 0:
-                    global_out[g0 + r * rs] += src[r].sum()
-                else:
-                    global_out[g0 + r * rs + st * np.arange(n)] = src[r]
+        li, gi, pj, lp = self._element_maps(rank, rows)
+        if not len(li):
+            return global_out
+        st = self.piece["out_step"][lp["piece_index"][pj]]
+        laid = st != 0
+        global_out[gi[laid]] = np.asarray(local_out)[li[laid]]
+        if not laid.all():                               # summed slices: every element of a (piece, row) adds to ONE slot
+            np.add.at(global_out, gi[~laid], np.asarray(local_out)[li[~laid]])
         return global_out
 
 

@@ -292,3 +292,57 @@ def test_bench_spawns_its_ranks_and_runs_the_one_job_mode(tmp_path):
     # bench.py has no switch that routes it around the HIP engine
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "PC_BENCH_ENGINE" not in src and "oracle_engine" not in src
+
+
+def test_partition_element_maps_equal_the_piecewise_walk():
+    """``owned_elements`` / ``scatter_local`` build their index arrays with repeats and running offsets (479 k exons x
+    cuts at C4: no Python loop per piece); against the straightforward walk over pieces and rows, for laid-out
+    (forward / reversed) and summed slices, several rows, a segment subset."""
+    from plastid_amd import multigpu
+    rng = np.random.default_rng(5)
+    nseg, world, rows = 400, 3, 3
+    tid = rng.integers(0, 3, nseg).astype(np.int32)
+    start = rng.integers(0, 5000, nseg).astype(np.int64)
+    length = rng.integers(0, 300, nseg)
+    end = start + length
+    step = rng.choice(np.array([1, -1, 0], np.int8), nseg, p=[0.5, 0.3, 0.2])
+    off = np.zeros(nseg, np.int64)
+    stride = np.where(step == 0, 1, length).astype(np.int64)
+    at = 0
+    for s in range(nseg):
+        off[s] = at + (length[s] - 1 if step[s] < 0 else 0)
+        at += rows * (1 if step[s] == 0 else int(length[s]))
+    seg = dict(tid=tid, start=start, end=end, strand=np.ones(nseg, np.uint8), out_off=off, out_step=step, row_stride=stride)
+    tid_off = np.array([0, 6000, 12000, 18000], np.int64)
+    part = multigpu.GenomePartition.from_cuts(seg, world, tid_off, np.array([4100, 13050], np.int64), halo=40)
+    total = np.zeros(at, np.int64)
+    for rank in range(world):
+        lp = part.local_plan_arrays(rank, rows)
+        local = rng.integers(1, 1000, lp["out_elems"]).astype(np.int64)
+        # the walk over pieces and rows
+        want_li, want_gi = [], []
+        ref = np.zeros(at, np.int64)
+        for j, pi in enumerate(lp["piece_index"]):
+            n = int(lp["end"][j] - lp["start"][j])
+            if n <= 0:
+                continue
+            g0, st, rs = int(part.piece["out_off"][pi]), int(part.piece["out_step"][pi]), int(part.piece["row_stride"][pi])
+            for r in range(rows):
+                src = local[lp["out_off"][j] + r * n:lp["out_off"][j] + (r + 1) * n]
+                if st == 0:
+                    ref[g0 + r * rs] += src.sum()
+                else:
+                    ref[g0 + r * rs + st * np.arange(n)] = src
+                want_li.append(lp["out_off"][j] + r * n + np.arange(n))
+                want_gi.append(g0 + r * rs + st * np.arange(n))
+        li, gi = part.owned_elements(rank, rows)
+        assert np.array_equal(li, np.concatenate(want_li)) and np.array_equal(gi, np.concatenate(want_gi))
+        got = part.scatter_local(np.zeros(at, np.int64), rank, local, rows)
+        assert np.array_equal(got, ref)
+        total += got
+        some = rng.choice(nseg, 50, replace=False)
+        li2, gi2 = part.owned_elements(rank, rows, segments=some)
+        keep = np.isin(part.piece["owner"][lp["piece_index"]], some)
+        sel = np.concatenate([np.full(rows * max(int(lp["end"][j] - lp["start"][j]), 0), keep[j]) for j in range(len(keep))]) if len(keep) else np.zeros(0, bool)
+        assert np.array_equal(li2, li[sel]) and np.array_equal(gi2, gi[sel])
+    assert total.sum() > 0
