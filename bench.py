@@ -830,7 +830,7 @@ def brief_config(r):
          "plan_build_ms": r["plan_build_ms_once_per_annotation"], "staged_reads_per_s": sig(r["scopes"]["staged_reads_per_s"])}
     if r["scopes"].get("staged_with_plan_reads_per_s"):
         b["staged_with_plan"] = sig(r["scopes"]["staged_with_plan_reads_per_s"])
-    for k in ("issue_bound_ms", "issue_frac"):
+    for k in ("issue_bound_ms", "issue_frac", "row_fill"):
         if k in roof:
             b[k] = sig(roof[k], 3)
     if r.get("size_filter_variant", {}).get("ms_per_step"):
@@ -887,7 +887,13 @@ def center_issue_bound(eng, plan, kernel_ms):
     except Exception as e:   # a diagnostic must not cost the bench line
         return {"issue_bound_error": str(e)}
     floor_ms = steps * 10.0 / (1024 * 2.4e9) * 1e3
-    return {"replay_steps": int(steps), "replay_waves": int(waves), "issue_bound_ms": floor_ms,
+    fill = {}
+    try:   # how full the four lock-step rows of a wave are: entries of all rows / (4 x steps)
+        ent, cap = eng.center_row_fill(plan)
+        fill = {"row_fill": ent / float(cap) if cap else None, "row_entries": int(ent)}
+    except Exception as e:
+        fill = {"row_fill_error": str(e)}
+    return {"replay_steps": int(steps), "replay_waves": int(waves), "issue_bound_ms": floor_ms, **fill,
             "issue_frac": floor_ms / kernel_ms if kernel_ms > 0 else None,
             "issue_basis": "replay steps x (3 x 2 + 4) cycles / (1024 SIMDs x 2.4 GHz): subrev, subrev_co, cndmask at 2 cycles, v_fmac_f64 at 4"}
 
@@ -1080,7 +1086,7 @@ def main():
             "config": config,
             "roofline": {k: (sig(v) if isinstance(v, float) else v) for k, v in roof.items()
                          if k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "avg_launch_ms",
-                                  "frac_of_measured_stream", "issue_bound_ms", "issue_frac", "replay_steps")},
+                                  "frac_of_measured_stream", "issue_bound_ms", "issue_frac", "replay_steps", "row_fill")},
             "cpu_baseline": None if not cpu else {
                 "value": sig(cpu["value"]), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
                 "sample": "oracle (C port of the reference algorithm) on %d of %d chains, all %d records; see %s" %

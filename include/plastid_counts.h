@@ -120,6 +120,17 @@ int pc_add_alignment_file_wide(pc_engine *e, int64_t n, int32_t ntid, const int3
 int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags);
 int pc_num_files(pc_engine *e);
 int64_t pc_num_records(pc_engine *e, int file);
+/* Read objects of a staged file back (the reference hands pysam reads to its callers: get_reads / reads_out,
+ * genome_array.py:834-859, and to filter functions, :697-722) -- for files whose records never visited the host
+ * (pc_add_alignment_bam[_path | _span]).  pc_read_records: per requested record index its reference id, first aligned
+ * position, aligned length L = len(read.positions), strand (1: reverse), number of aligned runs, and -- pointers may be
+ * NULL -- the SAM FLAG word and MAPQ (from the strand alone / 255 when the file carries none).  pc_read_record_runs: the
+ * aligned runs of the same records, record k's from slot run_at[k] on (the caller's exclusive sum of its run counts;
+ * nruns = their total): read.positions is their concatenation. */
+int pc_read_records(pc_engine *e, int file, int64_t n, const int64_t *idx, int32_t *tid, int32_t *pos, int32_t *alen, uint8_t *reverse,
+                    int32_t *nblk, uint16_t *flag16, uint8_t *mapq);
+int pc_read_record_runs(pc_engine *e, int file, int64_t n, const int64_t *idx, const int64_t *run_at, int64_t nruns, int32_t *start,
+                        int32_t *len);
 
 /* ---- read filters on the SAM FLAG word and MAPQ.  The reference's filter contract is "a function of the
  * pysam.AlignedSegment" (BAMGenomeArray.add_filter, plastid/genomics/genome_array.py:697-722; every filter is called on
@@ -244,6 +255,11 @@ int64_t pc_last_algorithmic_bytes(pc_engine *e);
  * row: 3 single-rate vector instructions + one v_fmac_f64) and how many waves the launch executed -- the numerator
  * of the kernel's vector-issue bound that bench.py reports beside the HBM fraction.  No reference counterpart. */
 int pc_center_replay_steps(pc_engine *e, pc_plan *p, int64_t *steps, int64_t *waves);
+/* Row fill of the center kernel's dispatch list (plans over one alignment file, after a center-rule count): the four
+ * 16-lane rows of a wave replay in lock-step, one step per entry of the LONGEST row, so a step does useful work for
+ * row_entries / row_slots of its four rows -- row_entries = entries of all rows of all dispatch entries, row_slots =
+ * 4 x replay steps.  A measurement helper like pc_center_replay_steps; no reference counterpart. */
+int pc_center_row_fill(pc_engine *e, pc_plan *p, int64_t *row_entries, int64_t *row_slots);
 /* Measured streaming rates of this GPU (GB/s) for the access patterns of the tile kernel: 16-byte
  * contiguous loads per lane and 8-byte contiguous stores per lane over a buffer of `bytes` bytes
  * (>= 1 MiB; use several hundred MB to get past the 256 MiB Infinity Cache).  The second roofline
@@ -285,6 +301,21 @@ int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const ch
  * other, and the mapping is taken down on a thread of its own after the call has returned. */
 int pc_bam_open_path(pc_engine *e, const char *path, pc_bam **out);
 int pc_add_alignment_bam_path(pc_engine *e, const char *path, int64_t *mapped);
+/* REGION reads: what `AlignmentFile.fetch(reference, start, end)` returns (genome_array.py:800-809; htslib's iterator,
+ * kent/src/htslib/hts.c:1924-1960) for a set of regions, decoded on the GPU.  The caller resolves the regions through the
+ * file's BAI index (bins + 16 kb linear index: plastid_amd/csrc/bam_stager.cpp pb_resolve_regions) into
+ *   voff_begin, voff_end   the span of virtual offsets (file offset of a BGZF member << 16 | offset in its payload) that
+ *                          holds every chunk of every region; 0, 0: nothing overlaps (the header alone is read);
+ *   nreg, tid, beg, end    the regions themselves by reference id, ascending by (tid, beg), merged (none overlap).
+ * Only the members of the span -- and the leading ones that hold the header -- are uploaded and inflated; the record
+ * chain starts at the record the index points to; a placed record stays iff pos < end && endpos > beg for one of the
+ * regions (htslib's rule, as the host reader applies it).  counts[2] / *mapped = mapped records among those kept (the
+ * whole file's count lives in the index).  One rank of a multi-GPU job stages its genome range of ONE shared file this
+ * way.  Errors: as pc_bam_open, plus PC_ERR_ARG when the span does not fit the file (a foreign index). */
+int pc_bam_open_span(pc_engine *e, const char *path, uint64_t voff_begin, uint64_t voff_end, int nreg, const int32_t *tid,
+                     const int64_t *beg, const int64_t *end, pc_bam **out);
+int pc_add_alignment_bam_span(pc_engine *e, const char *path, uint64_t voff_begin, uint64_t voff_end, int nreg, const int32_t *tid,
+                              const int64_t *beg, const int64_t *end, int64_t *mapped);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,8 @@ SIGNATURES = {
     "pc_set_flag_filter": (_int, [_vp, _int, ctypes.c_uint32, ctypes.c_uint32, _int]),
     "pc_num_files": (_int, [_vp]),
     "pc_num_records": (_i64, [_vp, _int]),
+    "pc_read_records": (_int, [_vp, _int, _i64] + [_vp] * 8),
+    "pc_read_record_runs": (_int, [_vp, _int, _i64, _vp, _vp, _i64, _vp, _vp]),
     "pc_set_mapping": (_int, [_vp, _int, _int, _vp, _vp, _int, _int, _int]),
     "pc_set_size_filter": (_int, [_vp, _int, _int, _int]),
     "pc_set_normalize": (_int, [_vp, _int, ctypes.c_double]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "pc_last_timing": (_int, [_vp, _vp, _int]),
     "pc_last_algorithmic_bytes": (_i64, [_vp]),
     "pc_center_replay_steps": (_int, [_vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "pc_center_row_fill": (_int, [_vp, _vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "pc_stream_probe": (_int, [_vp, _i64, _int, _vp, _vp]),
     "pc_bam_open": (_int, [_vp, _vp, _i64, ctypes.c_char_p, _pp]),
     "pc_bam_counts": (_int, [_vp, _vp]),
@@ -85,6 +88,8 @@ SIGNATURES = {
     "pc_add_alignment_bam": (_int, [_vp, _vp, _i64, ctypes.c_char_p, ctypes.POINTER(_i64)]),
     "pc_bam_open_path": (_int, [_vp, ctypes.c_char_p, _pp]),
     "pc_add_alignment_bam_path": (_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_i64)]),
+    "pc_bam_open_span": (_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _int, _vp, _vp, _vp, _pp]),
+    "pc_add_alignment_bam_span": (_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _int, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
 }
 
 _lib = None

@@ -41,6 +41,7 @@ def _load():
         L.pb_wide_count.argtypes = [vp]
         L.pb_fill_wide.argtypes = [vp] * 4
         L.pb_fill_sam.argtypes = [vp] * 4
+        L.pb_resolve_regions.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)] + [vp] * 9
         _lib = L
     return _lib
 
@@ -99,12 +100,54 @@ def bam_header(path):
     return refs, lens
 
 
-def read_bam_gpu(path, engine, timing=None):
+def _region_tuples(regions):
+    return [(r.chrom, r.start, r.end) if hasattr(r, "chrom") else tuple(r) for r in regions]
+
+
+def resolve_regions(path, regions):
+    """Resolve `regions` (``(chrom, start, end)`` or |GenomicSegments|) through the BAI index of `path` for a decoder
+    that reads the file itself (:func:`read_bam_gpu`, :meth:`Engine.add_bam`): returns a dict with the span of virtual
+    offsets ``voff_begin``, ``voff_end`` that holds every chunk of every region (bins + 16 kb linear index, SAM
+    specification section 5 -- what ``AlignmentFile.fetch`` walks per region, genome_array.py:800-809), the merged regions
+    by reference id (``tid``, ``beg``, ``end`` arrays), the index's whole-file ``mapped`` count (-1: none) and the
+    file's ``references`` / ``lengths``."""
+    L = _load()
+    h = L.pb_open(os.fsencode(path))
+    if not h:
+        raise IOError(L.pb_last_error().decode())
+    try:
+        regs = _region_tuples(regions)
+        n = len(regs)
+        names = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(str(c)) for c, _, _ in regs])
+        starts = np.array([int(s) for _, s, _ in regs], np.int64)
+        ends = np.array([int(e) for _, _, e in regs], np.int64)
+        vb, ve = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        mapped, nm = ctypes.c_int64(0), ctypes.c_int(0)
+        tid, beg, end = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        rc = L.pb_resolve_regions(h, n, names, p(starts), p(ends), ctypes.byref(vb), ctypes.byref(ve), ctypes.byref(mapped), ctypes.byref(nm),
+                                  p(tid), p(beg), p(end))
+        if rc != 0:
+            raise ValueError(L.pb_last_error().decode())
+        nref = L.pb_nref(h)
+        refs = [L.pb_ref_name(h, i).decode() for i in range(nref)]
+        lens = [int(L.pb_ref_length(h, i)) for i in range(nref)]
+    finally:
+        L.pb_close(h)
+    k = int(nm.value)
+    return dict(voff_begin=int(vb.value), voff_end=int(ve.value), tid=tid[:k].copy(), beg=beg[:k].copy(), end=end[:k].copy(),
+                mapped=int(mapped.value), references=refs, lengths=lens)
+
+
+def read_bam_gpu(path, engine, timing=None, regions=None):
     """The same :class:`PackedAlignments` as :func:`read_bam` gives for a whole file, decoded ON THE GPU: the file image
     goes to HBM as it is, the BGZF members are inflated there (one wave per member) and the BAM records decoded
     (``pc_bam_open``, ``csrc/bam_kernels.hip.h``); only the packed columns -- 13 bytes per record instead of the ~120 of
     an aligner's record -- come back.  `engine`: a :class:`plastid_amd.engine.Engine` (its device and stream are used).
-    `timing`: optional dict that receives the phase times in ms and the member / byte counts."""
+    `timing`: optional dict that receives the phase times in ms and the member / byte counts.
+    `regions`: as for :func:`read_bam` -- only the alignments that overlap one of them, through the BAI index: only the
+    BGZF members the index points to are uploaded and inflated (``pc_bam_open_span``); ``mapped`` is then the index's
+    whole-file count, as pysam's."""
     import time
     from . import _lib as clib
     L = clib.load()
@@ -112,8 +155,15 @@ def read_bam_gpu(path, engine, timing=None):
         raise IOError("No such file: %r" % (path,))
     t_0 = time.perf_counter()
     h = ctypes.c_void_p()
-    # (the library maps the file itself: pages touched by all host threads at once, unmapped on a thread of its own)
-    clib.check(L.pc_bam_open_path(engine._h, os.fsencode(path), ctypes.byref(h)))
+    span = None
+    if regions is not None:
+        span = resolve_regions(path, regions)
+        pv = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        clib.check(L.pc_bam_open_span(engine._h, os.fsencode(path), span["voff_begin"], span["voff_end"], len(span["tid"]),
+                                      pv(span["tid"]), pv(span["beg"]), pv(span["end"]), ctypes.byref(h)))
+    else:
+        # (the library maps the file itself: pages touched by all host threads at once, unmapped on a thread of its own)
+        clib.check(L.pc_bam_open_path(engine._h, os.fsencode(path), ctypes.byref(h)))
     t_open = time.perf_counter()
     size = os.path.getsize(path)
     try:
@@ -144,6 +194,13 @@ def read_bam_gpu(path, engine, timing=None):
         if timing is not None:
             timing["close_ms"] = (time.perf_counter() - t_c) * 1e3
     wide = dict(wide_idx=wi, wide_alen=wa, wide_nblk=wn) if nw else {}
+    if span is not None:   # `mapped` as pysam reports it: from the index, for the whole file
+        if span["mapped"] < 0:
+            import warnings
+            warnings.warn("the BAI index of %s carries no mapped-read counts; using the number of alignments read" % path)
+            mapped = n
+        else:
+            mapped = span["mapped"]
     out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
                            validate=False, flag16=flag16, mapq=mapq, qlen=qlen, **wide)   # the device decoder has checked every invariant validate() checks
     out.filename = path
@@ -170,7 +227,7 @@ def read_bam(path, threads=0, regions=None):
         if regions is None:
             rc = L.pb_load(h, int(threads))
         else:
-            regs = [(r.chrom, r.start, r.end) if hasattr(r, "chrom") else tuple(r) for r in regions]
+            regs = _region_tuples(regions)
             names = (ctypes.c_char_p * max(len(regs), 1))(*[os.fsencode(str(c)) for c, _, _ in regs])
             starts = np.array([int(s) for _, s, _ in regs], np.int64)
             ends = np.array([int(e) for _, _, e in regs], np.int64)

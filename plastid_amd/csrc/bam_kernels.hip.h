@@ -734,14 +734,19 @@ struct MemberChain {
 // chain ends there).  rec_off[m * kMaxRecPerMember + k] = offset of record k relative to the member's begin.
 __global__ __launch_bounds__(64) void k_bam_chain(const uint8_t *__restrict__ stream, uint64_t stream_len, const Member *__restrict__ members,
                                                   int nmembers, int member_lo, uint32_t n_ref, uint64_t first_record, const uint64_t *__restrict__ forced,
-                                                  MemberChain *chain, uint32_t *rec_off) {
+                                                  MemberChain *chain, uint32_t *rec_off, uint64_t stop_at) {
     const int m = member_lo + (int)blockIdx.x;
     if (m >= nmembers) return;
     const int lane = threadIdx.x & 63;
     const Member mb = members[m];
-    const uint64_t begin = mb.uoff, end = mb.uoff + mb.ulen;
+    // (region reads: no record is looked for at or behind `stop_at`, the end of the last chunk of the index)
+    const uint64_t begin = mb.uoff, end = mb.uoff + mb.ulen < stop_at ? mb.uoff + mb.ulen : stop_at;
     MemberChain mc;
     mc.first = ~0ull; mc.next = ~0ull; mc.nrec = 0; mc.flags = 0;
+    if (begin >= end) {   // wholly behind the stop: nothing starts here
+        if (lane == 0) { mc.first = stop_at; mc.next = stop_at; chain[m] = mc; }
+        return;
+    }
     uint64_t start = forced[m];
     if (start == ~0ull && first_record >= begin && first_record < end) start = first_record;   // the member that holds the end of the header
     if (start == ~0ull && end <= first_record) {   // header only: nothing starts here
@@ -791,9 +796,10 @@ struct RecOut {
     uint32_t nruns;             // maximal runs of aligned positions
     uint16_t flag;
     uint8_t err;
-    uint8_t placed;
+    uint8_t placed;             // 0 unplaced (tid < 0), 1 placed, 2 placed but outside every requested region (region reads: not staged)
     int32_t lseq;               // l_seq (pysam's query_length)
     uint32_t mapq;
+    int32_t end;                // one past the last aligned position (spos + 1 without aligned bases): the overlap test of region reads
 };
 
 // One thread per record start (member-major, k_bam_chain's order): fields and CIGAR -> RecOut.
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(256) void k_bam_fields(const uint8_t *__restrict__ 
     while (m + 1 < nmembers && (int64_t)rec_base[m + 1] <= i) ++m;
     const uint64_t q = members[m].uoff + rec_off[(size_t)m * kMaxRecPerMember + (size_t)(i - (int64_t)rec_base[m])];
     RecOut o;
-    o.tid = -1; o.spos = 0; o.pos = 0; o.L = 0; o.nruns = 0; o.flag = 0; o.err = kRecOk; o.placed = 0; o.lseq = 0; o.mapq = 0;
+    o.tid = -1; o.spos = 0; o.pos = 0; o.L = 0; o.nruns = 0; o.flag = 0; o.err = kRecOk; o.placed = 0; o.lseq = 0; o.mapq = 0; o.end = 0;
     if (q + 4 > stream_len) { o.err = kRecTruncated; recs[i] = o; return; }
     const uint32_t bs = ld32(stream + q);
     if (bs < 32) { o.err = kRecBadSize; recs[i] = o; return; }
@@ -844,6 +850,7 @@ __global__ __launch_bounds__(256) void k_bam_fields(const uint8_t *__restrict__ 
     if (o.err == kRecOk && L > 0x7fffffffLL) o.err = kRecTooLong;
     o.L = (uint32_t)L; o.nruns = nruns;
     if (nruns) o.spos = first_run;
+    o.end = (int32_t)(nruns ? (run_end > 0x7fffffffLL ? 0x7fffffffLL : run_end) : (int64_t)pos + 1);
     recs[i] = o;
 }
 
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(256) void k_bam_columns(const uint8_t *__restrict__
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nrec) return;
     const RecOut o = recs[i];
-    if (!o.placed) return;
+    if (o.placed != 1) return;
     const uint32_t k = staged_at[i];
     const bool wide = o.L > 65535u || o.nruns > 255u || (o.L == 65535u && o.nruns == 255u);
     tid[k] = o.tid;
@@ -913,6 +920,25 @@ __global__ __launch_bounds__(256) void k_bam_columns(const uint8_t *__restrict__
     }
 }
 
+// Region reads: a placed record stays iff it overlaps one of the requested regions (ascending, merged, by reference
+// id) -- htslib's test, pos < end && endpos > beg (hts.c:1924-1960), on the first aligned position and the end of the
+// last aligned run as the host reader applies it (bam_stager.cpp decode_regions).  Runs behind the order checks.
+__global__ __launch_bounds__(256) void k_bam_region_filter(RecOut *recs, int64_t nrec, int nreg, const int32_t *__restrict__ reg_tid,
+                                                           const int64_t *__restrict__ reg_beg, const int64_t *__restrict__ reg_end) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrec) return;
+    RecOut o = recs[i];
+    if (o.placed != 1) return;
+    // first region (ordered by reference id, then start) whose end lies beyond the record's first position
+    int lo = 0, hi = nreg;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (reg_tid[mid] < o.tid || (reg_tid[mid] == o.tid && reg_end[mid] <= (int64_t)o.spos)) lo = mid + 1; else hi = mid;
+    }
+    const bool keep = lo < nreg && reg_tid[lo] == o.tid && reg_beg[lo] < (int64_t)o.end;
+    if (!keep) { o.placed = 2; recs[i] = o; }
+}
+
 // per-record scan inputs: staged (placed) flag and the runs a multi-run record keeps
 constexpr int kScanInputsPerThread = 8;   // records per thread of k_bam_scan_inputs (one atomic per counter and workgroup: a single hot address takes ~90 atomics per us)
 __global__ __launch_bounds__(256) void k_bam_scan_inputs(const RecOut *__restrict__ recs, int64_t nrec, uint32_t *placed, uint32_t *runs,
@@ -924,9 +950,9 @@ __global__ __launch_bounds__(256) void k_bam_scan_inputs(const RecOut *__restric
         const int64_t i = ((int64_t)blockIdx.x * kScanInputsPerThread + k) * 256 + threadIdx.x;
         if (i < nrec) {
             const RecOut o = recs[i];
-            placed[i] = o.placed;
-            runs[i] = (o.placed && o.nruns >= 2u) ? o.nruns : 0u;
-            a += (o.flag & 0x4) ? 0u : 1u;
+            placed[i] = o.placed == 1 ? 1u : 0u;
+            runs[i] = (o.placed == 1 && o.nruns >= 2u) ? o.nruns : 0u;
+            a += (o.placed == 2 || (o.flag & 0x4)) ? 0u : 1u;   // (records outside the requested regions count for nothing)
             b += o.placed ? 0u : 1u;
         }
     }

@@ -949,33 +949,32 @@ void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &bins) {
     for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (end >> 14); ++k) bins.push_back((uint32_t)k);
 }
 
-int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, const int64_t *rstart, const int64_t *rend) {
-    Lap lap;
-    FILE *f = fopen(bam.path.c_str(), "rb");
-    if (!f) return fail("cannot read " + bam.path);
-    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{f};
-    // ---- header: inflate members from the start of the file until it is complete
-    uint32_t n_ref = 0;
-    {
-        std::vector<uint8_t> hbuf;
-        uint64_t coff = 0;
-        for (;;) {
-            const long cl = read_member(f, coff, hbuf);
-            if (cl <= 0) return fail(cl == 0 ? "truncated BAM header" : "not a BGZF file (bad gzip member header)");
-            coff += (uint64_t)cl;
-            const uint8_t *p = hbuf.data();
-            bool more = false;
-            if (parse_header(bam, p, hbuf.data() + hbuf.size(), n_ref, &more) == 0) break;
-            if (!more) return -1;
-        }
+// the BAM header from the leading BGZF members of `f`: as many as it takes
+int read_header_members(Bam &bam, FILE *f, uint32_t &n_ref) {
+    std::vector<uint8_t> hbuf;
+    uint64_t coff = 0;
+    for (;;) {
+        const long cl = read_member(f, coff, hbuf);
+        if (cl <= 0) return fail(cl == 0 ? "truncated BAM header" : "not a BGZF file (bad gzip member header)");
+        coff += (uint64_t)cl;
+        const uint8_t *p = hbuf.data();
+        bool more = false;
+        if (parse_header(bam, p, hbuf.data() + hbuf.size(), n_ref, &more) == 0) return 0;
+        if (!more) return -1;
     }
-    std::vector<BaiRef> refs;
+}
+
+// A requested region by reference id (sorted, overlapping / adjacent ones merged).
+struct RegionSpan { int32_t tid; int64_t s, e; };
+
+// Regions (reference name, 0-based half-open) -> merged regions by reference id and the chunks of virtual offsets
+// that hold every record overlapping one of them: the bins of each region (reg2bins), clipped by the 16 kb linear
+// index, sorted and merged (SAM specification section 5; what hts_itr_query does per region, hts.c:1924-1960).
+int resolve_regions(const Bam &bam, uint32_t n_ref, int nreg, const char *const *rname, const int64_t *rstart, const int64_t *rend,
+                    std::vector<BaiRef> &refs, std::vector<RegionSpan> &merged, std::vector<std::pair<uint64_t, uint64_t>> &chunks) {
     if (load_bai(bam.path, refs) != 0) return -1;
     if (refs.size() != (size_t)n_ref) return fail("the index does not belong to this BAM file (reference count differs): " + bam.path);
-    lap("header + index");
-    // ---- regions: by reference id, sorted, overlapping / adjacent ones merged
-    struct Reg { int32_t tid; int64_t s, e; };
-    std::vector<Reg> regs;
+    std::vector<RegionSpan> regs;
     for (int i = 0; i < nreg; ++i) {
         int32_t tid = -1;
         for (uint32_t r = 0; r < n_ref; ++r)
@@ -984,16 +983,15 @@ int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, c
         const int64_t s = std::max<int64_t>(rstart[i], 0), e = std::min<int64_t>(rend[i], (int64_t)1 << 29);
         if (e > s) regs.push_back({tid, s, e});
     }
-    std::sort(regs.begin(), regs.end(), [](const Reg &a, const Reg &b) { return a.tid != b.tid ? a.tid < b.tid : (a.s != b.s ? a.s < b.s : a.e < b.e); });
-    std::vector<Reg> merged;
-    for (const Reg &r : regs) {
+    std::sort(regs.begin(), regs.end(), [](const RegionSpan &a, const RegionSpan &b) { return a.tid != b.tid ? a.tid < b.tid : (a.s != b.s ? a.s < b.s : a.e < b.e); });
+    merged.clear();
+    for (const RegionSpan &r : regs) {
         if (!merged.empty() && merged.back().tid == r.tid && r.s <= merged.back().e) merged.back().e = std::max(merged.back().e, r.e);
         else merged.push_back(r);
     }
-    // ---- chunks of virtual offsets
     std::vector<std::pair<uint64_t, uint64_t>> ch;
     std::vector<uint32_t> bins;
-    for (const Reg &r : merged) {
+    for (const RegionSpan &r : merged) {
         const BaiRef &br = refs[(size_t)r.tid];
         const size_t w = (size_t)(r.s >> 14);
         if (br.linear.empty()) continue;
@@ -1008,11 +1006,27 @@ int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, c
         }
     }
     std::sort(ch.begin(), ch.end());
-    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    chunks.clear();
     for (const auto &c : ch) {
         if (!chunks.empty() && c.first <= chunks.back().second) chunks.back().second = std::max(chunks.back().second, c.second);
         else chunks.push_back(c);
     }
+    return 0;
+}
+
+int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, const int64_t *rstart, const int64_t *rend) {
+    Lap lap;
+    FILE *f = fopen(bam.path.c_str(), "rb");
+    if (!f) return fail("cannot read " + bam.path);
+    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{f};
+    // ---- header: inflate members from the start of the file until it is complete
+    uint32_t n_ref = 0;
+    if (read_header_members(bam, f, n_ref) != 0) return -1;
+    std::vector<BaiRef> refs;
+    std::vector<RegionSpan> merged;
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    if (resolve_regions(bam, n_ref, nreg, rname, rstart, rend, refs, merged, chunks) != 0) return -1;
+    lap("header + index");
     // ---- read and inflate what the chunks touch (threads over chunks, one file handle each)
     std::vector<std::vector<uint8_t>> bytes(chunks.size());
     std::atomic<size_t> next(0);
@@ -1178,6 +1192,38 @@ int pb_load_regions(void *h, int nthreads, int nreg, const char *const *names, c
     if (b->loaded) return fail("pb_load_regions: file already loaded");
     if (nthreads <= 0) nthreads = default_threads();
     return decode_regions(*b, nthreads, nreg, names, start, end);
+}
+
+// What a decoder that reads the file itself (pc_bam_open_span: BGZF inflate and record decode on the GPU) needs to know
+// about a set of regions: the merged regions by reference id (m_tid / m_start / m_end, capacity nreg; *nmerged of them)
+// and the SPAN of virtual offsets [*voff_begin, *voff_end) that holds every chunk of every region (0, 0: no record
+// overlaps any of them); *mapped = the index's mapped-read count of the whole file (-1: the index carries none).  The
+// header is read as a side effect (pb_nref / pb_ref_name / pb_ref_length answer afterwards).
+int pb_resolve_regions(void *h, int nreg, const char *const *names, const int64_t *start, const int64_t *end, uint64_t *voff_begin,
+                       uint64_t *voff_end, int64_t *mapped, int *nmerged, int32_t *m_tid, int64_t *m_start, int64_t *m_end) {
+    Bam *b = static_cast<Bam *>(h);
+    if (!b || nreg < 0 || (nreg > 0 && (!names || !start || !end)) || !voff_begin || !voff_end || !mapped || !nmerged)
+        return fail("pb_resolve_regions: bad arguments");
+    FILE *f = fopen(b->path.c_str(), "rb");
+    if (!f) return fail("cannot read " + b->path);
+    uint32_t n_ref = 0;
+    const int hrc = read_header_members(*b, f, n_ref);
+    fclose(f);
+    if (hrc != 0) return -1;
+    std::vector<BaiRef> refs;
+    std::vector<RegionSpan> merged;
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    if (resolve_regions(*b, n_ref, nreg, names, start, end, refs, merged, chunks) != 0) return -1;
+    *voff_begin = chunks.empty() ? 0 : chunks.front().first;
+    *voff_end = 0;
+    for (const auto &c : chunks) *voff_end = std::max(*voff_end, c.second);
+    int64_t m = 0;
+    bool any_meta = false;
+    for (const BaiRef &br : refs) { m += (int64_t)br.n_mapped; any_meta |= br.has_meta; }
+    *mapped = any_meta ? m : -1;
+    *nmerged = (int)merged.size();
+    for (size_t k = 0; k < merged.size() && m_tid && m_start && m_end; ++k) { m_tid[k] = merged[k].tid; m_start[k] = merged[k].s; m_end[k] = merged[k].e; }
+    return 0;
 }
 
 int pb_nref(void *h) { return h ? (int)static_cast<Bam *>(h)->ref_names.size() : -1; }

@@ -593,7 +593,13 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
                                                            int nfiles, int G, int W, int Ws, int Wr, int64_t R, int64_t pile,
                                                            WorkItem *work, uint32_t *nwork, uint32_t *tile_items,
                                                            uint32_t work_cap, WorkItem *work_small, int small_g,
-                                                           int64_t small_n, int diag, FileRange *chain, FileRange *chain_small) {
+                                                           int64_t small_n, int diag, FileRange *chain, FileRange *chain_small, int b16) {
+    // b16: the plan's windows are binned into 16-BIT counters (several rows: the stratified rule, k_hist_point) -- no work
+    // item may add 65 536 times or more to one bin.  An item's adds are bounded by what it scans (records, runs, list
+    // entries), so: a window is cut into sub-windows by that total, one whose (sub-)window still scans more than 65 535
+    // is merged through the compact histogram, and a merged window's slices hold ONE kind of range each, at most R
+    // (49 152) entries of it.
+    constexpr int64_t kMax16 = 65535;
     __shared__ unsigned long long s_wave64[kRangesWG / 64];
     __shared__ uint32_t s_base[3];
     const int64_t idx = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
@@ -636,6 +642,40 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             if (r.llo > r.lhi) r.llo = r.lhi;
         }
     };
+    // slices of a merged window for the ranges `r` of one file
+    auto ceil_r = [&](int64_t n) -> uint32_t { return n > 0 ? (uint32_t)((n + R - 1) / R) : 0u; };
+    auto merged_count = [&](const FileRange &r, bool first_file) -> uint32_t {
+        if (b16) {
+            const uint32_t c = ceil_r(r.hi - r.lo) + ceil_r((int64_t)r.rhi - (int64_t)r.rlo) + ceil_r(r.ghi - r.glo) + ceil_r(r.lhi - r.llo);
+            return c ? c : (first_file ? 1u : 0u);
+        }
+        const int64_t nf = r.hi - r.lo;
+        return nf > 0 ? ceil_r(nf) : ((r.ghi > r.glo || r.lhi > r.llo || r.rhi > r.rlo || first_file) ? 1u : 0u);
+    };
+    // (w: the window's fields filled in; il: light slots taken so far by this thread)
+    auto merged_emit = [&](WorkItem &w, const FileRange &r, uint32_t base_l, uint32_t &il, bool first_file) {
+        auto put = [&]() { const uint32_t slot = work_cap - 1u - (base_l + il++); if (slot < work_cap) work[slot] = w; };
+        auto clear = [&]() { w.lo = w.hi = 0; w.glo = w.ghi = 0; w.llo = w.lhi = 0; w.rlo = w.rhi = 0u; w.sub_lo = 0; w.sub_hi = G; };
+        if (b16) {   // one kind of range per slice
+            uint32_t made = 0;
+            for (int64_t a = r.lo; a < r.hi; a += R, ++made) { clear(); w.lo = a; w.hi = a + R < r.hi ? a + R : r.hi; put(); }
+            for (int64_t a = r.rlo; a < (int64_t)r.rhi; a += R, ++made) { clear(); w.rlo = (uint32_t)a; w.rhi = (uint32_t)(a + R < (int64_t)r.rhi ? a + R : (int64_t)r.rhi); put(); }
+            for (int64_t a = r.glo; a < r.ghi; a += R, ++made) { clear(); w.glo = a; w.ghi = a + R < r.ghi ? a + R : r.ghi; put(); }
+            for (int64_t a = r.llo; a < r.lhi; a += R, ++made) { clear(); w.llo = a; w.lhi = a + R < r.lhi ? a + R : r.lhi; put(); }
+            if (!made && first_file) { clear(); put(); }
+            return;
+        }
+        const uint32_t cnt = merged_count(r, first_file);
+        for (uint32_t k = 0; k < cnt; ++k) {
+            clear();
+            w.lo = r.lo + (int64_t)k * R;
+            w.hi = (w.lo + R < r.hi) ? w.lo + R : r.hi;
+            if (r.hi <= r.lo) { w.lo = r.lo; w.hi = r.hi; }
+            if (k == 0) { w.glo = r.glo; w.ghi = r.ghi; w.llo = r.llo; w.lhi = r.lhi; w.rlo = r.rlo; w.rhi = r.rhi; }
+            put();
+        }
+    };
+    auto adds_of = [&](const FileRange &r) -> int64_t { return (r.hi - r.lo) + ((int64_t)r.rhi - (int64_t)r.rlo) + (r.ghi - r.glo) + (r.lhi - r.llo); };
     int64_t jn = 0;   // joint: records of all files in the window
     if (live && joint) {
         t = (int)idx;
@@ -648,22 +688,25 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             file_ranges(ff, tl.tid, s_lo, s_end, s_lo, s_hi, r);
             jn += r.hi - r.lo; ng += r.ghi - r.glo; nl += r.lhi - r.llo; nr += (int64_t)r.rhi - (int64_t)r.rlo;
         }
-        while (S < kMaxSub && G % (S * 2 << kLinShift) == 0 && jn > R * S) S <<= 1;
+        const int64_t jt = jn + ng + nl + nr;   // everything the window's item would add
+        while (S < kMaxSub && G % (S * 2 << kLinShift) == 0 && (b16 ? jt : jn) > R * S) S <<= 1;
         if (S == 1) {
             const bool small = small_g > 0 && (int)tl.span_hi - (int)tl.span_lo <= small_g && jn <= small_n && ng <= small_n &&
                                nl <= small_n && nr <= small_n;
-            if (small) n_small = 1; else if (jn > R) n_heavy = 1; else n_light = 1;
+            if (b16 && jt > kMax16) merge = true;
+            else if (small) n_small = 1; else if (jn > R) n_heavy = 1; else n_light = 1;
         } else {
             const int sub = G / S;
             for (int k = 0; k < S; ++k) {
                 const int64_t a = ws + (int64_t)k * sub;
-                int64_t nk = 0;
+                int64_t nk = 0, nk16 = 0;
                 for (int ff = 0; ff < nfiles; ++ff) {   // (the very ranges the items below get: the class counts must agree with them)
                     FileRange r;
                     file_ranges(ff, tl.tid, a, a + sub, s_lo, s_hi, r);
                     nk += r.hi - r.lo;
+                    nk16 += adds_of(r);
                 }
-                if (nk > pile) merge = true; // a pile-up inside one sub-window
+                if (nk > pile || (b16 && nk16 > kMax16)) merge = true; // a pile-up inside one sub-window
                 if (nk > R) ++n_heavy; else ++n_light;
             }
         }
@@ -674,8 +717,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             for (int ff = 0; ff < nfiles; ++ff) {
                 FileRange r;
                 file_ranges(ff, tl.tid, s_lo, s_end, s_lo, s_hi, r);
-                const int64_t nf = r.hi - r.lo;
-                n_light += nf > 0 ? (uint32_t)((nf + R - 1) / R) : ((r.ghi > r.glo || r.lhi > r.llo || r.rhi > r.rlo || ff == 0) ? 1u : 0u);
+                n_light += merged_count(r, ff == 0);
             }
         }
     }
@@ -722,13 +764,15 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             if (llo > lhi) llo = lhi;
         }
         const int64_t n = whi - wlo;
+        const int64_t nt = n + (wghi - wglo) + (lhi - llo) + (wrhi - wrlo);   // everything the window's item would add
         merge = nfiles > 1;
         if (!merge) {
-            while (S < kMaxSub && G % (S * 2 << kLinShift) == 0 && n > R * S) S <<= 1; // sub-windows end on index buckets
+            while (S < kMaxSub && G % (S * 2 << kLinShift) == 0 && (b16 ? nt : n) > R * S) S <<= 1; // sub-windows end on index buckets
             if (S == 1) {
                 const bool small = small_g > 0 && (int)tl.span_hi - (int)tl.span_lo <= small_g && n <= small_n &&
                                    (wghi - wglo) <= small_n && (lhi - llo) <= small_n && (wrhi - wrlo) <= small_n;
-                if (small) n_small = 1; else if (n > R) n_heavy = 1; else n_light = 1;
+                if (b16 && nt > kMax16) merge = true;
+                else if (small) n_small = 1; else if (n > R) n_heavy = 1; else n_light = 1;
             } else {
                 const int sub = G / S;
                 for (int k = 0; k < S; ++k) {
@@ -739,6 +783,11 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
                     int64_t nk = lin_floor(fv.lin_tab, l0, nb, a + sub) - lo_k;
                     if (nk < 0) nk = 0;
                     if (nk > pile) merge = true; // a pile-up inside one sub-window
+                    if (b16) {   // ... or a sub-window that would add more than a 16-bit bin holds (its runs and list entries counted in, by their widest bounds)
+                        const int64_t gk = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, a + sub) - lin_floor(fv.glin_tab, l0, nb, a - W + 1) : 0;
+                        const int64_t rk = fv.nrunrec ? lin_floor(fv.rlin_tab, l0, nb, a + sub) - lin_floor(fv.rlin_tab, l0, nb, a - Wr + 1) : 0;
+                        if (nk + gk + rk + (lhi - llo) > kMax16) merge = true;
+                    }
                     if (nk > R) ++n_heavy; else ++n_light;
                 }
             }
@@ -746,7 +795,9 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         if (merge) {
             S = 1;
             n_heavy = 0;
-            n_light = n > 0 ? (uint32_t)((n + R - 1) / R) : ((wghi > wglo || lhi > llo || wrhi > wrlo || f == 0) ? 1u : 0u);
+            FileRange r;
+            r.lo = wlo; r.hi = whi; r.glo = wglo; r.ghi = wghi; r.llo = llo; r.lhi = lhi; r.rlo = (uint32_t)wrlo; r.rhi = (uint32_t)wrhi;
+            n_light = merged_count(r, f == 0);
         }
     }
     if (diag && live && f == 0 && lhi > llo) atomicAdd(&nwork[3], (uint32_t)(lhi - llo)); // PC_DEBUG_WORK: long-span candidates
@@ -795,22 +846,12 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         if (merge) {
             atomicAdd(&tile_items[t], n_light); // > 0 marks the tile for k_gather_split
             atomicAdd(&nwork[4], 1u);           // windows merged through the compact histogram (none: k_gather_split has nothing to do)
+            uint32_t made = 0;
             for (int ff = 0; ff < nfiles; ++ff) {
                 FileRange r;
                 file_ranges(ff, tl.tid, s_lo, s_end, s_lo, s_hi, r);
-                const int64_t nf = r.hi - r.lo;
-                const uint32_t cnt = nf > 0 ? (uint32_t)((nf + R - 1) / R) : ((r.ghi > r.glo || r.lhi > r.llo || r.rhi > r.rlo || ff == 0) ? 1u : 0u);
                 w.file = (uint32_t)ff;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    w.lo = r.lo + (int64_t)k * R;
-                    w.hi = (w.lo + R < r.hi) ? w.lo + R : r.hi;
-                    w.glo = k == 0 ? r.glo : 0; w.ghi = k == 0 ? r.ghi : 0;
-                    w.llo = k == 0 ? r.llo : 0; w.lhi = k == 0 ? r.lhi : 0;
-                    w.rlo = k == 0 ? r.rlo : 0u; w.rhi = k == 0 ? r.rhi : 0u;
-                    w.sub_lo = 0; w.sub_hi = G;
-                    const uint32_t slot = work_cap - 1u - (il++);
-                    if (slot < work_cap) work[slot] = w;
-                }
+                merged_emit(w, r, il, made, ff == 0);
             }
             return;
         }
@@ -860,16 +901,10 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     if (merge) {
         atomicAdd(&tile_items[t], n_light); // > 0 marks the tile for k_gather_split
         atomicAdd(&nwork[4], 1u);
-        for (uint32_t k = 0; k < n_light; ++k) {
-            w.lo = wlo + (int64_t)k * R;
-            w.hi = (w.lo + R < whi) ? w.lo + R : whi;
-            w.glo = k == 0 ? wglo : 0; w.ghi = k == 0 ? wghi : 0;
-            w.llo = k == 0 ? llo : 0;  w.lhi = k == 0 ? lhi : 0;
-            w.rlo = k == 0 ? (uint32_t)wrlo : 0u; w.rhi = k == 0 ? (uint32_t)wrhi : 0u;
-            w.sub_lo = 0; w.sub_hi = G;
-            const uint32_t slot = work_cap - 1u - (il + k);
-            if (slot < work_cap) work[slot] = w;
-        }
+        FileRange r;
+        r.lo = wlo; r.hi = whi; r.glo = wglo; r.ghi = wghi; r.llo = llo; r.lhi = lhi; r.rlo = (uint32_t)wrlo; r.rhi = (uint32_t)wrhi;
+        uint32_t made = 0;
+        merged_emit(w, r, il, made, f == 0);
         return;
     }
     const int sub = G / S;
@@ -955,19 +990,28 @@ __device__ __forceinline__ void map_both(const MapParams &mp, const HistCfg &c, 
 // Bin one read.  `pf`/`pr` = window-relative position under the forward / reverse rule.
 // Modes 0 ('+') and 1 ('-') are mutually exclusive per read (strand filter), so they share
 // one predicated ds_add; '.' (mode 2) and the unfiltered reverse rule (mode 3) add their own.
+// B16: the bins are 16 bits wide, two positions per LDS word (the stratified rule: see k_hist_point) -- bin h is the
+// (h & 1)-th half of word h >> 1, and one count is 1 << 16 (h & 1) added to that word.
+template <bool B16>
+__device__ __forceinline__ void bin_add(uint32_t *bins, uint32_t h) {
+    if (B16) atomicAdd(&bins[h >> 1], 1u << ((h & 1u) << 4));
+    else atomicAdd(&bins[h], 1u);
+}
+
+template <bool B16>
 __device__ __forceinline__ void hist_bin(const HistCfg &c, bool valid, bool rev, int kf, int kr, uint32_t df,
                                          uint32_t dr, uint32_t rowoff, uint32_t *bins) {
     if ((c.base[0] & c.base[1]) != -1) { // uniform: the tile has a '+' and/or a '-' island
         const int k = rev ? kr : kf;
         const int b = rev ? c.base[1] : c.base[0];
         const uint32_t d = rev ? dr : df;
-        if (valid & (k >= 0) & (b >= 0) & (d < c.G)) atomicAdd(&bins[(uint32_t)b + rowoff + d], 1u);
+        if (valid & (k >= 0) & (b >= 0) & (d < c.G)) bin_add<B16>(bins, (uint32_t)b + rowoff + d);
     }
     if (c.base[2] >= 0) {
-        if (valid & (kf >= 0) & (df < c.G)) atomicAdd(&bins[(uint32_t)c.base[2] + rowoff + df], 1u);
+        if (valid & (kf >= 0) & (df < c.G)) bin_add<B16>(bins, (uint32_t)c.base[2] + rowoff + df);
     }
     if (c.base[3] >= 0) {
-        if (valid & (kr >= 0) & (dr < c.G)) atomicAdd(&bins[(uint32_t)c.base[3] + rowoff + dr], 1u);
+        if (valid & (kr >= 0) & (dr < c.G)) bin_add<B16>(bins, (uint32_t)c.base[3] + rowoff + dr);
     }
 }
 
@@ -1006,7 +1050,7 @@ __device__ __forceinline__ void fast_table_init(const MapParams &mp, const HistC
 // bins share the LDS), and one read-wait-add chain per record would serialise on the LDS latency.
 // A record without a bin (outside the window, skipped, unmapped length) is sent to the lane's own
 // dump word instead of being branched around.
-template <int N>
+template <int N, bool B16>
 __device__ __forceinline__ void fast_bin(const uint32_t *ftab, uint32_t mode_mask, uint32_t G, uint32_t dump,
                                          const uint32_t (&w)[N], uint32_t *smem) {
     const char *tab = (const char *)ftab;
@@ -1026,13 +1070,17 @@ __device__ __forceinline__ void fast_bin(const uint32_t *ftab, uint32_t mode_mas
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const uint32_t d = (w[i] + e[i]) >> 16;
-            addr[i] = (((w[i] << 31) | d) < G) ? ((e[i] & 0xffffu) + d) << 2 : dump;
+            // (B16: the entry's low half is the bin's index in 16-bit units -- a byte address with 2-byte granularity)
+            addr[i] = (((w[i] << 31) | d) < G) ? ((e[i] & 0xffffu) + d) << (B16 ? 1 : 2) : dump;
         }
         uint32_t cnt = 1;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const bool last = (i == N - 1) || (addr[i + 1 < N ? i + 1 : i] != addr[i]);
-            if (last) atomicAdd((uint32_t *)((char *)smem + addr[i]), cnt);
+            if (last) {
+                if (B16) atomicAdd((uint32_t *)((char *)smem + (addr[i] & ~3u)), cnt << ((addr[i] & 2u) << 3));   // (the dump word is word-aligned: low half)
+                else atomicAdd((uint32_t *)((char *)smem + addr[i]), cnt);
+            }
             cnt = last ? 1u : cnt + 1u;
         }
     }
@@ -1040,6 +1088,7 @@ __device__ __forceinline__ void fast_bin(const uint32_t *ftab, uint32_t mode_mas
 
 // Bin one record of the run stream (one aligned run of a gapped / spliced read) through the entry table -- see the
 // run-stream loop of k_hist_point.  A lane without a record holds an excluded one.
+template <bool B16>
 __device__ __forceinline__ void run_bin(const uint32_t *ftab, uint32_t mode_mask, uint32_t G, uint32_t dump, u32x2 rr,
                                         uint32_t win_start, uint32_t *smem) {
     const char *tab = (const char *)ftab;
@@ -1053,8 +1102,9 @@ __device__ __forceinline__ void run_bin(const uint32_t *ftab, uint32_t mode_mask
         const uint32_t koff = (e >> 16) - cum;                       // (k - cum - win_start) mod 2^16 in the low half
         const uint32_t t = (koff + win_start) & 0xffffu;             // k - cum: inside this run when < len
         const uint32_t d = (koff + rr.x) & 0xffffu;                  // window-relative position of read.positions[k]
-        const uint32_t addr = (live & (t < len) & (d < G)) ? ((e & 0xffffu) + d) << 2 : dump;
-        atomicAdd((uint32_t *)((char *)smem + addr), 1u);
+        const uint32_t addr = (live & (t < len) & (d < G)) ? ((e & 0xffffu) + d) << (B16 ? 1 : 2) : dump;
+        if (B16) atomicAdd((uint32_t *)((char *)smem + (addr & ~3u)), 1u << ((addr & 2u) << 3));
+        else atomicAdd((uint32_t *)((char *)smem + addr), 1u);
     }
 }
 
@@ -1062,7 +1112,7 @@ __device__ __forceinline__ void run_bin(const uint32_t *ftab, uint32_t mode_mask
 // 4 KiB per batch (U x 64 lanes x 16 B, the U loads of a lane 1 KiB apart -> one address register
 // and immediate offsets), register double buffer.  Batches that lie wholly inside the range are
 // loaded without per-lane predicates; lanes past the end of the last batch hold skip words.
-template <int WG, int U>
+template <int WG, int U, bool B16>
 __device__ __forceinline__ void stream_records(const u32x4 PC_GLOBAL *src, int nquads, u32x4 (&cur)[U], const u32x4 none,
                                                const uint32_t *ftab, uint32_t mode_mask, uint32_t G, uint32_t dump,
                                                uint32_t *smem) {
@@ -1085,7 +1135,7 @@ __device__ __forceinline__ void stream_records(const u32x4 PC_GLOBAL *src, int n
         for (int u = 0; u < U; u += 2) { // eight records (two quads of the lane's slice) per call
             if (wave_q + u * 64 >= nquads) break; // wave-uniform: nothing but padding from here on (sparse windows)
             const uint32_t w8[8] = {c[u].x, c[u].y, c[u].z, c[u].w, c[u + 1].x, c[u + 1].y, c[u + 1].z, c[u + 1].w};
-            fast_bin<8>(ftab, mode_mask, G, dump, w8, smem);
+            fast_bin<8, B16>(ftab, mode_mask, G, dump, w8, smem);
         }
     };
     u32x4 alt[U];
@@ -1165,6 +1215,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
                                                     double norm_sum, uint32_t work_cap, uint32_t grid_front,
                                                     const FileRange *__restrict__ chain, int nfiles) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // The stratified rule (the only one with several rows) bins into 16-BIT counters, two positions per LDS word: the
+    // same bytes of LDS hold a window twice as long, so a plan has half the windows -- half the workgroup starts, entry
+    // tables, bin clears and halos (C5: 798 k windows of 256 positions x 11 rows, 0.8 of 3.7 ms in their fixed cost).
+    // What makes it safe: no work item of such a plan adds 65 536 times or more (k_tile_ranges cuts or merges the windows
+    // whose records, runs and list entries could), so no bin carries into its neighbour.
+    constexpr bool B16 = KIND == 4;
     // heavy items sit at the front of the list, light ones at the back (see k_tile_ranges);
     // the sparse-window list is a plain array of its own
     // The grid spans the whole list capacity and block b serves slot b (heavy slots [0, n_heavy),
@@ -1260,21 +1316,23 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     uint32_t *ftab = smem;
     uint32_t *ltab = smem + fwords;                      // variable / stratified rules: gapped and long-span reads
     uint32_t *bins = smem + fwords + ((tab_n + 3) & ~3);
-    OutPiece *s_op = (OutPiece *)(bins + (size_t)max_slots * mp.rows * G); // 16-byte aligned: every part is a multiple of 4 words
+    OutPiece *s_op = (OutPiece *)(bins + (((size_t)max_slots * mp.rows * G) >> (B16 ? 1 : 0))); // 16-byte aligned: every part is a multiple of 4 words
     const uint32_t dump = (uint32_t)((char *)(s_op + kOpStage) - (char *)smem) + (threadIdx.x & 63u) * 4u; // the lane's dump word
     if ((int)threadIdx.x < nstage * 3) ((u32x4 *)s_op)[threadIdx.x] = opq;
     if (!(PC_HIST_SKIP & 16)) {   // only bins in [span_lo, span_hi) are ever read back: clear just those
         // (16-byte stores over the span rounded out to 4 words; no per-element division)
-        const int lo4 = (int)w.span_lo >> 2, hi4 = ((int)w.span_hi + 3) >> 2, nrow = nslots * mp.rows;
+        // (a 16-byte store covers 4 bins of 32 bits, 8 of 16)
+        constexpr int PS = B16 ? 3 : 2;
+        const int lo4 = (int)w.span_lo >> PS, hi4 = ((int)w.span_hi + (1 << PS) - 1) >> PS, nrow = nslots * mp.rows;
         const u32x4 zero4 = {0u, 0u, 0u, 0u};
-        if (nrow > 2 && (hi4 - lo4) * 2 > (G >> 2)) {
+        if (nrow > 2 && (hi4 - lo4) * 2 > (G >> PS)) {
             // many rows and a span that covers most of the window: clear all rows in one flat sweep
             // (a row-by-row loop costs one mostly idle pass per row)
             u32x4 *all4 = (u32x4 *)bins;
-            for (int i = (int)threadIdx.x; i < nrow * (G >> 2); i += WG) all4[i] = zero4;
+            for (int i = (int)threadIdx.x; i < nrow * (G >> PS); i += WG) all4[i] = zero4;
         } else {
             for (int r = 0; r < nrow; ++r) {
-                u32x4 *row4 = (u32x4 *)(bins + r * G);
+                u32x4 *row4 = (u32x4 *)bins + r * (G >> PS);
                 for (int i = lo4 + (int)threadIdx.x; i < hi4; i += WG) row4[i] = zero4;
             }
         }
@@ -1288,7 +1346,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
             ltab[i] = (uint32_t)(f < 0 ? 0xffff : f) | ((uint32_t)(r < 0 ? 0xffff : r) << 16);
         }
     }
-    if (!(PC_HIST_SKIP & 8)) fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)(bins - smem), (int)threadIdx.x, WG, pre_f, pre_r);
+    // (the entries carry the bins' place in units of one bin: words, or 16-bit halves)
+    if (!(PC_HIST_SKIP & 8)) fast_table_init<KIND>(mp, c, w.mode_mask, fast_lo, fast_hi, ftab, (uint32_t)(bins - smem) << (B16 ? 1 : 0), (int)threadIdx.x, WG, pre_f, pre_r);
     if (threadIdx.x == 0) {
         // records of the first quad before `lo`, of the cut last quad outside [lo, hi)
         const int lead = (int)(w.lo & 3), keep = (int)(w.hi & 3);
@@ -1306,11 +1365,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     __syncthreads();
 
     // ---- the record stream: no dependent global loads in this loop
-    if (!(PC_HIST_SKIP & 1)) stream_records<WG, U>(src, nquads, cur, none, ftab, w.mode_mask, c.G, dump, smem);
+    if (!(PC_HIST_SKIP & 1)) stream_records<WG, U, B16>(src, nquads, cur, none, ftab, w.mode_mask, c.G, dump, smem);
     else if (cur[0].x == 0x12345u) smem[0] = tail.x + opq.x + gfirst.x + rfirst.x + gfirst_runs.x;   // (keeps the loads of the prologue alive)
     if (!(PC_HIST_SKIP & 1) && (w.hi & 3) && threadIdx.x < 64) { // the cut last quad lives in lane 0 of the first wave
         const uint32_t w4[4] = {tail.x, tail.y, tail.z, tail.w};
-        fast_bin<4>(ftab, w.mode_mask, c.G, dump, w4, smem);
+        fast_bin<4, B16>(ftab, w.mode_mask, c.G, dump, w4, smem);
     }
 
     // the side lists of one file (run stream, gapped records outside it, long-span reads); `first_`: the head file of
@@ -1336,7 +1395,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (base + u * WG < rhi_) run_bin(ftab, w.mode_mask, c.G, dump, rr[u], (uint32_t)c.win_start, smem);
+                if (base + u * WG < rhi_) run_bin<B16>(ftab, w.mode_mask, c.G, dump, rr[u], (uint32_t)c.win_start, smem);
         }
 
         // ---- gapped records outside the run stream (aligned length > kStreamMaxLen): their aligned runs live in a side
@@ -1355,7 +1414,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
             map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
             const int32_t pf = (valid && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
             const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
-            hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
+            hist_bin<B16>(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
         }
 
         // ---- long-span (spliced) reads that can reach this window: same binning, every run walked
@@ -1374,7 +1433,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
             map_both<KIND>(mp, c, ltab, L, kf, kr, rowoff);
             const int32_t pf = (valid && kf >= 0) ? walk_from(fv, g.z, nb, kf, b0, b1) : 0;
             const int32_t pr = (valid && kr >= 0) ? walk_from(fv, g.z, nb, kr, b0, b1) : 0;
-            hist_bin(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
+            hist_bin<B16>(c, valid, hi & kFlagReverse, kf, kr, (uint32_t)(pf - c.win_start), (uint32_t)(pr - c.win_start), rowoff, bins);
         }
     };
     if (!(PC_HIST_SKIP & 2)) side_lists(fv, w.rlo, w.rhi, w.glo, w.ghi, w.llo, w.lhi, true);
@@ -1407,10 +1466,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
                 if (keep <= 2 || tlead > 2) tail2.z = kStreamSkip;
                 tail2.w = kStreamSkip;
             }
-            stream_records<WG, U>(src2, nq2, c2, none, ftab, w.mode_mask, c.G, dump, smem);
+            stream_records<WG, U, B16>(src2, nq2, c2, none, ftab, w.mode_mask, c.G, dump, smem);
             if ((fr.hi & 3) && threadIdx.x < 64) {
                 const uint32_t w4[4] = {tail2.x, tail2.y, tail2.z, tail2.w};
-                fast_bin<4>(ftab, w.mode_mask, c.G, dump, w4, smem);
+                fast_bin<4, B16>(ftab, w.mode_mask, c.G, dump, w4, smem);
             }
             side_lists(fv2, fr.rlo, fr.rhi, fr.glo, fr.ghi, fr.llo, fr.lhi, false);
         }
@@ -1435,12 +1494,35 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
                 // pointer increments per element -- a row-major loop pays the 64-bit address set-up of a row
                 // for 1.2 KB of output (a 150-nt exon), eleven times per piece
                 for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) {
-                    const uint32_t *srcp = bins + slot * mp.rows * G + rel + i;
                     typename OutT_<OUTMODE>::type *dstp = out + o.out_off + (int64_t)o.step * i;
-                    for (int r = 0; r < mp.rows; ++r) {
-                        *dstp = out_conv<OUTMODE>(*srcp, norm_sum);
-                        srcp += G;
-                        dstp += o.row_stride;
+                    if (B16) {
+                        const uint16_t *srcp = (const uint16_t *)bins + slot * mp.rows * G + rel + i;
+                        for (int r = 0; r < mp.rows; ++r) {
+                            *dstp = out_conv<OUTMODE>((uint32_t)*srcp, norm_sum);
+                            srcp += G;
+                            dstp += o.row_stride;
+                        }
+                    } else {
+                        const uint32_t *srcp = bins + slot * mp.rows * G + rel + i;
+                        for (int r = 0; r < mp.rows; ++r) {
+                            *dstp = out_conv<OUTMODE>(*srcp, norm_sum);
+                            srcp += G;
+                            dstp += o.row_stride;
+                        }
+                    }
+                }
+                continue;
+            }
+            if (B16) {   // (several rows: only summed slices come this way -- the laid-out ones took the branch above)
+                for (int r = 0; r < mp.rows; ++r) {
+                    const uint16_t *srcb = (const uint16_t *)bins + (slot * mp.rows + r) * G + rel;
+                    typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
+                    if (o.step != 0) {
+                        for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>((uint32_t)srcb[i], norm_sum);
+                    } else {
+                        unsigned long long part = 0;
+                        for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) part += srcb[i];
+                        out_add<OUTMODE>(dst, part);
                     }
                 }
                 continue;
@@ -1475,10 +1557,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
                 // (not c.base[pc_.mode]: a run-time index into that array would put the whole struct into
                 // scratch memory -- 44 bytes per lane written to HBM by every work item)
                 const int mode_base = __popc(w.mode_mask & ((1u << pc_.mode) - 1u)) * mp.rows * G;
-                const uint32_t *srcb = bins + mode_base + r * G + rel;
                 uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
                 for (int i = threadIdx.x; i < pc_.len; i += WG) {
-                    const uint32_t v = srcb[i];
+                    const uint32_t v = B16 ? (uint32_t)((const uint16_t *)bins)[mode_base + r * G + rel + i] : bins[mode_base + r * G + rel + i];
                     if (v) atomicAdd(&dst[i], v);
                 }
             }
@@ -3047,6 +3128,50 @@ __global__ __launch_bounds__(kWG) void k_mapped_reads_batch(const BatchSeg *__re
             counts[sf] = t;
         }
     }
+}
+
+// ---------------------------------------------------------------- k_gather_records / k_gather_runs
+// Read objects for files whose records live in HBM only (`BAMGenomeArray(path, keep_reads=False)`; the reference hands
+// pysam reads to its callers, genome_array.py:834-859): the header fields of the records `idx` names -- reference id,
+// first aligned position, aligned length, strand, run count, FLAG / MAPQ when the file carries them -- and then their
+// aligned runs (a record with one run is the implicit run [pos, pos + L)).
+__global__ __launch_bounds__(kWG) void k_gather_records(FileView fview, int ntid, const int64_t *__restrict__ idx, int64_t n,
+                                                        const uint16_t *__restrict__ sam_flag, const uint8_t *__restrict__ sam_mapq,
+                                                        int32_t *tid, int32_t *pos, int32_t *alen, uint8_t *reverse, int32_t *nblk,
+                                                        uint16_t *flag16, uint8_t *mapq) {
+    const int64_t k = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (k >= n) return;
+    const GFile fv = gfile(fview);
+    const int64_t i = idx[k];
+    const u32x2 r = fv.rec[i];
+    int L, nb;
+    rec_true(fv, i, r.y, L, nb);
+    int lo = 0, hi = ntid;   // contig of record i
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (fv.tid_bounds[mid + 1] <= i) lo = mid + 1; else hi = mid;
+    }
+    tid[k] = lo; pos[k] = (int32_t)r.x; alen[k] = L; nblk[k] = nb;
+    reverse[k] = (uint8_t)(rec_flags(r.y) & kFlagReverse);
+    if (flag16) flag16[k] = sam_flag ? sam_flag[i] : (uint16_t)((rec_flags(r.y) & kFlagReverse) ? 0x10 : 0);
+    if (mapq) mapq[k] = sam_mapq ? sam_mapq[i] : (uint8_t)255;
+}
+
+// run_at[k] = first slot of record k's runs in the output (exclusive sum of max(nblk, 1) over the request, 0 runs for L = 0)
+__global__ __launch_bounds__(kWG) void k_gather_runs(FileView fview, const int64_t *__restrict__ idx, int64_t n, const int64_t *__restrict__ run_at,
+                                                     int32_t *start, int32_t *len) {
+    const int64_t k = (int64_t)blockIdx.x * kWG + threadIdx.x;
+    if (k >= n) return;
+    const GFile fv = gfile(fview);
+    const int64_t i = idx[k];
+    const u32x2 r = fv.rec[i];
+    int L, nb;
+    rec_true(fv, i, r.y, L, nb);
+    const int64_t at = run_at[k];
+    if (nb >= 2) {
+        const uint32_t off = fv.blk_off[i];
+        for (int q = 0; q < nb; ++q) { const i32x2 b = fv.blk[off + q]; start[at + q] = b.x; len[at + q] = b.y; }
+    } else if (L > 0) { start[at] = (int32_t)r.x; len[at] = L; }
 }
 
 // ---------------------------------------------------------------- k_unmappable

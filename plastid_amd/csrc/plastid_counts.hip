@@ -758,12 +758,13 @@ int plan_build_gpu(pc_engine *e, pc_plan *p, int64_t nseg, const int32_t *tid, c
     for (int m = 0; m < kModes; ++m) nmodes += (h.modes >> m) & 1;
     if (nmodes == 0) nmodes = 1;
     {   // window size: as the host builder
-        int64_t g = (24 * 1024) / (4LL * nmodes * rows);
+        const int64_t bin_bytes = rows > 1 ? 2 : 4;   // several rows (the stratified rule): 16-bit bins, two positions per LDS word (k_hist_point)
+        int64_t g = (24 * 1024) / (bin_bytes * nmodes * rows);
         int G = 256;
         int gmax = 4096;
         while (G * 2 <= g && G * 2 <= gmax) G *= 2;
         if (e->knobs.tile_g && e->knobs.tile_g <= 2 * g) G = e->knobs.tile_g;
-        if ((int64_t)4 * nmodes * rows * G > 150 * 1024) return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows);
+        if (bin_bytes * nmodes * rows * G > 150 * 1024) return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows);
         p->G = G;
     }
     const int G = p->G;
@@ -1166,6 +1167,66 @@ int64_t pc_num_records(pc_engine *e, int file) {
 namespace {
 // PC_STAGE_TIMING=1: print where pc_add_alignment_file spends its time (stderr)
 } // namespace
+
+int pc_read_records(pc_engine *e, int file, int64_t n, const int64_t *idx, int32_t *tid, int32_t *pos, int32_t *alen, uint8_t *reverse,
+                    int32_t *nblk, uint16_t *flag16, uint8_t *mapq) {
+    if (!e || file < 0 || file >= (int)e->files.size()) return fail(PC_ERR_ARG, "pc_read_records: bad file index");
+    if (n < 0 || (n > 0 && (!idx || !tid || !pos || !alen || !reverse || !nblk))) return fail(PC_ERR_ARG, "pc_read_records: bad arguments");
+    if (n == 0) return PC_OK;
+    StagedFile *sf = e->files[file];
+    for (int64_t k = 0; k < n; ++k)
+        if (idx[k] < 0 || idx[k] >= sf->n) return fail(PC_ERR_ARG, "pc_read_records: record index %lld out of range", (long long)idx[k]);
+    HIP_TRY(hipSetDevice(e->device));
+    PoolScope pool_scope(&e->pool);
+    hipStream_t st = e->stream;
+    DevBuf<int64_t> d_idx;
+    DevBuf<uint8_t> d_out;   // tid, pos, alen, nblk (int32 each), flag16 (u16), reverse, mapq (u8): 20 bytes per record
+    int rc = d_idx.upload(idx, (size_t)n, st);
+    if (rc == PC_OK) rc = d_out.reserve((size_t)n * 20 + 64);
+    if (rc != PC_OK) return rc;
+    int32_t *o_tid = (int32_t *)d_out.p, *o_pos = o_tid + n, *o_alen = o_pos + n, *o_nblk = o_alen + n;
+    uint16_t *o_f16 = (uint16_t *)(o_nblk + n);
+    uint8_t *o_rev = (uint8_t *)(o_f16 + n), *o_mq = o_rev + n;
+    hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->view(), e->ntid, d_idx.p, n,
+                       sf->have_sam ? sf->sam_flag.p : nullptr, sf->have_sam ? sf->sam_mapq.p : nullptr, o_tid, o_pos, o_alen, o_rev, o_nblk, o_f16, o_mq);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(tid, o_tid, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(pos, o_pos, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(alen, o_alen, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(nblk, o_nblk, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(reverse, o_rev, (size_t)n, hipMemcpyDeviceToHost, st));
+    if (flag16) HIP_TRY(hipMemcpyAsync(flag16, o_f16, (size_t)n * 2, hipMemcpyDeviceToHost, st));
+    if (mapq) HIP_TRY(hipMemcpyAsync(mapq, o_mq, (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PC_OK;
+}
+
+int pc_read_record_runs(pc_engine *e, int file, int64_t n, const int64_t *idx, const int64_t *run_at, int64_t nruns, int32_t *start, int32_t *len) {
+    if (!e || file < 0 || file >= (int)e->files.size()) return fail(PC_ERR_ARG, "pc_read_record_runs: bad file index");
+    if (n < 0 || nruns < 0 || (n > 0 && (!idx || !run_at)) || (nruns > 0 && (!start || !len))) return fail(PC_ERR_ARG, "pc_read_record_runs: bad arguments");
+    if (n == 0 || nruns == 0) return PC_OK;
+    StagedFile *sf = e->files[file];
+    for (int64_t k = 0; k < n; ++k) {
+        if (idx[k] < 0 || idx[k] >= sf->n) return fail(PC_ERR_ARG, "pc_read_record_runs: record index %lld out of range", (long long)idx[k]);
+        if (run_at[k] < 0 || run_at[k] > nruns || (k > 0 && run_at[k] < run_at[k - 1])) return fail(PC_ERR_ARG, "pc_read_record_runs: run offsets must ascend within [0, nruns]");
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    PoolScope pool_scope(&e->pool);
+    hipStream_t st = e->stream;
+    DevBuf<int64_t> d_idx, d_at;
+    DevBuf<int32_t> d_runs;
+    int rc = d_idx.upload(idx, (size_t)n, st);
+    if (rc == PC_OK) rc = d_at.upload(run_at, (size_t)n, st);
+    if (rc == PC_OK) rc = d_runs.reserve((size_t)nruns * 2);
+    if (rc != PC_OK) return rc;
+    // (the caller sized the run arrays from the run counts pc_read_records gave it: a slot beyond them would be a bug there)
+    hipLaunchKernelGGL(k_gather_runs, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->view(), d_idx.p, n, d_at.p, d_runs.p, d_runs.p + nruns);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(start, d_runs.p, (size_t)nruns * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(len, d_runs.p + nruns, (size_t)nruns * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PC_OK;
+}
 
 int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
                           const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
@@ -2135,12 +2196,13 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     // window size: 24 KiB of LDS bins (uint32 per mode x row x position) -- small enough for six
     // workgroups per CU; the per-call hard limit is checked in pc_count
     {
-        int64_t g = (24 * 1024) / (4LL * nmodes * rows);
+        const int64_t bin_bytes = rows > 1 ? 2 : 4;   // several rows (the stratified rule): 16-bit bins, two positions per LDS word (k_hist_point)
+        int64_t g = (24 * 1024) / (bin_bytes * nmodes * rows);
         int G = 256;
         int gmax = 4096;
         while (G * 2 <= g && G * 2 <= gmax) G *= 2;
         if (e->knobs.tile_g && e->knobs.tile_g <= 2 * g) G = e->knobs.tile_g; // tuning knob: any multiple of 256 within the budget
-        if ((int64_t)4 * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
+        if (bin_bytes * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
         p->G = G;
     }
     const int G = p->G;
@@ -2605,7 +2667,9 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         p->hist_clean = true; // k_gather_split clears what the split tiles merged
         // ---- a plan of ONE window over one file (`ga[segment]`): the whole count is one launch -- the workgroup looks its
         // record ranges up itself; no work list, no second window class, no merge pass, no events
-        const bool single = ntiles == 1 && nfiles == 1 && !e->knobs.debug_work && !e->knobs.no_single;
+        // (not under the stratified rule: its 16-bit bins rely on the work lists, which cut or merge a window that scans
+        // more than 65 535 records)
+        const bool single = ntiles == 1 && nfiles == 1 && !e->knobs.debug_work && !e->knobs.no_single && e->kind != PC_MAP_STRAT5;
         if (single) {
             int lmin = 65536, lmax = -1;
             for (auto *f : e->files) { lmin = std::min(lmin, f->len_min); lmax = std::max(lmax, f->len_max); }
@@ -2654,7 +2718,15 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             // so a record is scanned by up to popcount(modes) tiles per window)
             const int tiles_per_window = p->rows > 1 ? std::max(1, __builtin_popcount(p->modes)) : 1;
             const double windows_per_record = (1.0 + (double)(halo + 127) / (double)G) * (double)tiles_per_window;
-            const int64_t cap64 = (int64_t)ntiles * nfiles + (int64_t)(2.0 * windows_per_record * (double)nrec / (double)R) + nfiles + 64;
+            int64_t cap64 = (int64_t)ntiles * nfiles + (int64_t)(2.0 * windows_per_record * (double)nrec / (double)R) + nfiles + 64;
+            if (e->kind == PC_MAP_STRAT5) {
+                // 16-bit bins: a window that scans more than 65 535 records, runs and list entries is merged, in slices of ONE
+                // kind of range each (k_tile_ranges): at most adds / R + 4 items per such window, and fewer than adds / 65 535 of them
+                int64_t nxl = 0, ngp = 0;
+                for (auto *f : e->files) { nxl += f->nxlong; ngp += f->ngap; }
+                cap64 += (int64_t)(6.0 * windows_per_record * (double)(nrec + nextra + ngp) / (double)R) +
+                         (int64_t)ntiles * nfiles * (4 + 2 * (nxl / R));
+            }
             if (cap64 >= (int64_t)0xffffffffu) return fail(PC_ERR_ARG, "pc_count: work list too large");
             rc = p->d_work.reserve((size_t)cap64);
             if (rc != PC_OK) return rc;
@@ -2681,7 +2753,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 const int64_t nthreads = nfiles > 1 ? (int64_t)ntiles : (int64_t)ntiles * nfiles; // one thread per window (several files: joint windows)
                 hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
                                    e->files[0]->view(), e->d_files.p, nfiles, G, e->Wg(), e->Ws(), e->Wr(), R, pile, p->d_work.p, p->d_wcounters.p, p->d_tile_items.p, (uint32_t)cap64,
-                                   p->d_work_small.p, small_g, small_n, e->knobs.debug_work, p->d_chain.p, p->d_chain_small.p);
+                                   p->d_work_small.p, small_g, small_n, e->knobs.debug_work, p->d_chain.p, p->d_chain_small.p, e->kind == PC_MAP_STRAT5 ? 1 : 0);
                 p->work_key = key;
                 p->work_valid = true;
                 p->work_counts_known = false;      // the counts of the lists just replaced size no grid
@@ -2699,7 +2771,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 tab_n = std::max(0, std::min(tab_n, 1024)); // longer reads look the tables up in HBM
             }
             const size_t stage_words = (size_t)kOpStage * sizeof(OutPiece) / sizeof(uint32_t); // output pieces parked in LDS
-            const size_t bins_words = (size_t)p->max_slots * p->rows * G + (size_t)((tab_n + 3) & ~3) + stage_words;
+            const bool b16 = e->kind == PC_MAP_STRAT5;   // 16-bit bins, two positions per word (k_hist_point)
+            const size_t bins_words = (((size_t)p->max_slots * p->rows * G) >> (b16 ? 1 : 0)) + (size_t)((tab_n + 3) & ~3) + stage_words;
             // LDS entry table of the record stream: the aligned lengths the stream carries
             int fast_lo = kStreamMaxLen, fast_hi = 0;
             for (auto *f : e->files) { fast_lo = std::min(fast_lo, f->tlen_min); fast_hi = std::max(fast_hi, f->tlen_max); }
@@ -2758,7 +2831,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         else if (outmode == 1) PC_LAUNCH_HIST(K, 1);                                                                  \
         else PC_LAUNCH_HIST(K, 2);                                                                                    \
     } while (0)
-            const size_t lds_small = ((size_t)p->max_slots * p->rows * std::max(small_g, 1) + (size_t)((tab_n + 3) & ~3) + fwords + stage_words) * sizeof(uint32_t);
+            const size_t lds_small = ((((size_t)p->max_slots * p->rows * std::max(small_g, 1)) >> (b16 ? 1 : 0)) + (size_t)((tab_n + 3) & ~3) + fwords + stage_words) * sizeof(uint32_t);
             // sparse windows (single-wave workgroups) and dense ones are two independent launches over
             // disjoint windows: they run side by side on two streams, forked after the work lists exist
             // and joined before the last kernel of the call
@@ -3181,6 +3254,19 @@ int pc_center_replay_steps(pc_engine *e, pc_plan *p, int64_t *steps, int64_t *wa
     return PC_OK;
 }
 
+int pc_center_row_fill(pc_engine *e, pc_plan *p, int64_t *row_entries, int64_t *row_slots) {
+    if (!e || !p || p->e != e || !row_entries || !row_slots) return fail(PC_ERR_ARG, "pc_center_row_fill: bad arguments");
+    if (!p->center_slots || p->center_generation != e->work_generation || !p->d_ccounts.p)
+        return fail(PC_ERR_STATE, "pc_center_row_fill: the plan has no center dispatch list of one alignment file (count it under the center rule first)");
+    HIP_TRY(hipSetDevice(e->device));
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(v, p->d_ccounts.p + 4, sizeof(v), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *row_entries = (int64_t)v[0];
+    *row_slots = (int64_t)v[1];
+    return PC_OK;
+}
+
 int pc_stream_probe(pc_engine *e, int64_t bytes, int iters, double *read_gbps, double *write_gbps) {
     if (!e || bytes < (1 << 20) || iters < 1) return fail(PC_ERR_ARG, "pc_stream_probe: bad arguments");
     HIP_TRY(hipSetDevice(e->device));
@@ -3495,13 +3581,23 @@ struct BamClock {   // PC_BAM_TIMING=1: wall-clock laps of the host side of the 
 // that stream has drained the host copy of the file is not read again (pc_bam_open_path takes its mapping down while the
 // GPU is still inflating).
 typedef std::function<void(hipStream_t)> UploadedHook;
-static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out, const UploadedHook *uploaded);
+// A region read (pc_bam_open_span): only the BGZF members between two virtual offsets of the BAI index are uploaded and
+// inflated (plus the leading members that hold the header), and only the records that overlap one of the regions stay.
+struct BamSpan {
+    uint64_t voff_begin = 0, voff_end = 0;   // (file offset of a member << 16 | offset in its payload): [begin, end); 0, 0: header only
+    int nreg = 0;                            // merged regions, ascending by (reference id, start)
+    const int32_t *tid = nullptr;
+    const int64_t *beg = nullptr, *end = nullptr;
+    int64_t header_bytes = (int64_t)256 << 10;   // compressed bytes from the start of the file searched for the header (grown on retry)
+};
+constexpr int PC_RETRY_HEADER = -1000;   // (internal) the header did not fit the leading members that were inflated
+static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out, const UploadedHook *uploaded, const BamSpan *span = nullptr);
 
 int pc_bam_open(pc_engine *e, const void *image, int64_t size, const char *name, pc_bam **out) {
     return bam_open_impl(e, image, size, name, out, nullptr);
 }
 
-static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out, const UploadedHook *uploaded) {
+static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const char *name, pc_bam **out, const UploadedHook *uploaded, const BamSpan *span) {
     using namespace pcbam;
     if (!e || !out || size < 0 || (size > 0 && !image_)) return fail(PC_ERR_ARG, "pc_bam_open: bad arguments");
     *out = nullptr;
@@ -3550,12 +3646,58 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
         }
     };
     std::vector<Member> members;
-    int64_t walked_to = 0;
+    // the parts of the file that go to the GPU: [file_lo, file_hi) lands at image offset dev_lo (one run: the whole file)
+    struct Run { int64_t file_lo, file_hi, dev_lo; int m0, m1; };
+    std::vector<Run> runs;
+    int span_first_member = -1, span_last_member = -1;   // region read: indices (in `members`) of the members at voff_begin >> 16 and at voff_end >> 16
+    if (span) {
+        const int64_t cb = (int64_t)(span->voff_begin >> 16), ce = (int64_t)(span->voff_end >> 16);
+        const bool have = span->voff_end > span->voff_begin;
+        if (have && (cb >= size || ce > size)) return fail(PC_ERR_ARG, "the index does not belong to this BAM file (a chunk lies beyond its end): %s", path.c_str());
+        // serial walks: the header's members from the start of the file, the span's from its first member on
+        // (members that start in [lo, hi_excl), and the one at `last` too if asked for)
+        auto walk_run = [&](int64_t lo, int64_t hi_excl, bool with_last, int64_t last, int *idx_last) -> int {
+            Run r; r.file_lo = lo; r.m0 = (int)members.size(); r.dev_lo = 0;
+            int64_t off = lo;
+            while (off < size && (off < hi_excl || (with_last && off <= last))) {
+                Member mb;
+                int64_t clen = 0;
+                const int code = parse_member(off, mb, clen);
+                if (code) return walk_error(code);
+                if (idx_last && off == last) *idx_last = mb.ulen ? (int)members.size() : -1;
+                if (mb.ulen) members.push_back(mb);
+                off += clen;
+            }
+            r.file_hi = off; r.m1 = (int)members.size();
+            if (r.file_hi > r.file_lo) runs.push_back(r);
+            return PC_OK;
+        };
+        int rc0 = walk_run(0, have ? std::min<int64_t>(span->header_bytes, cb) : span->header_bytes, false, 0, nullptr);
+        if (rc0 != PC_OK) return rc0;
+        if (have) {
+            if (!runs.empty() && runs.back().file_hi > cb)   // (member starts are what the walk lands on: cb is none)
+                return fail(PC_ERR_ARG, "the index does not belong to this BAM file (a chunk does not start at a BGZF member): %s", path.c_str());
+            span_first_member = (int)members.size();
+            rc0 = walk_run(cb, ce, (span->voff_end & 0xffffu) != 0, ce, &span_last_member);
+            if (rc0 != PC_OK) return rc0;
+        }
+        // adjacent runs become one (a run is uploaded as one contiguous copy)
+        for (size_t k = 1; k < runs.size();)
+            if (runs[k].file_lo == runs[k - 1].file_hi) { runs[k - 1].file_hi = runs[k].file_hi; runs[k - 1].m1 = runs[k].m1; runs.erase(runs.begin() + (long)k); }
+            else ++k;
+        int64_t dev = 0;
+        for (Run &r : runs) {   // the members' streams by their place in the image on the device
+            r.dev_lo = dev;
+            for (int m = r.m0; m < r.m1; ++m) members[(size_t)m].coff = (uint64_t)((int64_t)members[(size_t)m].coff - r.file_lo + r.dev_lo);
+            dev += r.file_hi - r.file_lo;
+        }
+    }
+    int64_t walked_to = span ? size : 0;
     // Large files: the walk is a chain of dependent cache misses (40 k members: 5.6 ms), so every host thread walks its
     // own stretch of the file from the first offset in it where three members in a row parse; a stretch counts only if
     // the walk of the stretch before it LANDS on its first member -- whatever does not chain is walked again, serially.
     const int64_t walk_min = getenv("PC_BAM_WALK_MIN") ? atoll(getenv("PC_BAM_WALK_MIN")) : ((int64_t)32 << 20);   // (tests: the parallel walk on small files)
-    const int WT = size >= walk_min && size >= 64 ? std::max(1, std::min(usable_cpus(), 16)) : 1;
+    const int WT = !span && size >= walk_min && size >= 64 ? std::max(1, std::min(usable_cpus(), 16)) : 1;
     if (WT > 1) {
         struct Stretch { int64_t first = -1, landing = -1; std::vector<Member> mem; };
         std::vector<Stretch> str((size_t)WT);
@@ -3610,6 +3752,9 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
     }
     uint64_t total_u = 0;
     for (Member &mb : members) { mb.uoff = total_u; total_u += mb.ulen; }
+    if (!span) runs.push_back(Run{0, size, 0, 0, (int)members.size()});
+    int64_t image_bytes = 0;
+    for (const Run &r : runs) image_bytes += r.file_hi - r.file_lo;
     pc_bam *b = new pc_bam();
     clk.lap("member walk");
     b->e = e; b->name = path; b->members = (int64_t)members.size(); b->inflated_bytes = (int64_t)total_u; b->compressed_bytes = size;
@@ -3621,7 +3766,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
     DevBuf<uint8_t> d_image, d_stream;
     DevBuf<Member> d_members;
     DevBuf<uint32_t> d_status, d_crc;
-    int rc = d_image.reserve((size_t)std::max<int64_t>(size, 16) + 16);
+    int rc = d_image.reserve((size_t)std::max<int64_t>(image_bytes, 16) + 16);
     if (rc == PC_OK) rc = d_stream.reserve((size_t)total_u + 64);
     if (rc == PC_OK) rc = d_members.reserve((size_t)std::max(nm, 1));
     if (rc == PC_OK) rc = d_status.reserve((size_t)std::max(nm, 1));
@@ -3674,7 +3819,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
         for (int k = 0; k < naux; ++k)   // (behind what the main stream has queued: the members table, the previous users of the buffers)
             HIP_TRY(hipStreamWaitEvent(e->aux_stream[k], landed[0], 0));
         // large files cross PCIe through two page-locked halves of one piece each (made once per engine)
-        bool ring = up != st && size >= 2 * piece_bytes && !getenv("PC_BAM_NO_RING");
+        bool ring = up != st && image_bytes >= 2 * piece_bytes && !getenv("PC_BAM_NO_RING");
         bool ring_busy[2] = {false, false};
         const int ring_threads = std::max(1, std::min(usable_cpus(), 16));
         if (ring) {
@@ -3686,22 +3831,25 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             (void)hipGetLastError();
         }
         int piece_no = 0;
-        int64_t byte0 = 0;          // the image is uploaded from here on (gzip headers and trailers ride along)
-        for (int m0 = 0; m0 < nm; ++piece_no) {
+        for (const Run &run : runs) {
+        // (offsets in the image on the device; the file's bytes of the run start at run.file_lo - run.dev_lo before them)
+        const uint8_t *run_src = image + (run.file_lo - run.dev_lo);
+        int64_t byte0 = run.dev_lo;          // the run is uploaded from here on (gzip headers and trailers ride along)
+        for (int m0 = run.m0; m0 < run.m1; ++piece_no) {
             int m1 = m0;
             int64_t byte1 = byte0;
-            while (m1 < nm && (byte1 - byte0 < piece_bytes || m1 == m0)) {
+            while (m1 < run.m1 && (byte1 - byte0 < piece_bytes || m1 == m0)) {
                 byte1 = (int64_t)(members[(size_t)m1].coff + members[(size_t)m1].clen);
                 ++m1;
             }
-            if (m1 == nm) byte1 = size;
+            if (m1 == run.m1) byte1 = run.dev_lo + (run.file_hi - run.file_lo);
             if (ring) {
                 // through a page-locked half: the runtime's own staging of a pageable copy runs on one thread (12 - 20 GB/s);
                 // here every host thread copies its share, and the DMA of one half overlaps the filling of the other
                 const int slot = piece_no & 1;
                 if (ring_busy[slot]) HIP_TRY(hipEventSynchronize(e->ev_ring[slot]));
                 uint8_t *dstp = e->bam_ring[slot].p;
-                const uint8_t *srcp = image + byte0;
+                const uint8_t *srcp = run_src + byte0;
                 const int64_t len = byte1 - byte0, blk = (int64_t)1 << 20;
                 parallel_chunks((len + blk - 1) / blk, ring_threads, [&](int, int64_t b, int64_t en) {
                     const int64_t lo = b * blk, hi = std::min(len, en * blk);
@@ -3711,7 +3859,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
                 HIP_TRY(hipEventRecord(e->ev_ring[slot], up));
                 ring_busy[slot] = true;
             } else
-                HIP_TRY(hipMemcpyAsync(d_image.p + byte0, image + byte0, (size_t)(byte1 - byte0), hipMemcpyHostToDevice, up));
+                HIP_TRY(hipMemcpyAsync(d_image.p + byte0, run_src + byte0, (size_t)(byte1 - byte0), hipMemcpyHostToDevice, up));
             if (up != st) {
                 hipEvent_t x;
                 HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
@@ -3726,6 +3874,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             hipLaunchKernelGGL(k_bgzf_crc, dim3((unsigned)(m1 - m0)), dim3(64), 0, ks, d_stream.p, d_members.p, m0, m1, d_crc.p, d_crc.p + 256, d_status.p);
             byte0 = byte1;
             m0 = m1;
+        }
         }
         for (int k = 0; k < naux; ++k) {   // the main stream goes on behind all of them
             hipEvent_t x;
@@ -3753,9 +3902,13 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
     // ---- BAM header (host, from the head of the inflated stream)
     uint64_t first_record = 0;
     uint32_t n_ref = 0;
+    // (region read: the header is looked for in the leading members only -- what follows them is the span, from some
+    // record in the middle of the file on; a header that does not fit them makes the caller come back with more)
+    const size_t header_limit = (span && span_first_member >= 0) ? (size_t)(members[(size_t)span_first_member].uoff + members[(size_t)span_first_member].ulen)
+                                                                 : (size_t)total_u;
     {
         std::vector<uint8_t> head;
-        size_t want = std::min<size_t>((size_t)total_u, (size_t)1 << 16);
+        size_t want = std::min<size_t>(header_limit, (size_t)1 << 16);
         for (;;) {
             head.resize(want);
             if (want) HIP_TRY(hipMemcpy(head.data(), d_stream.p, want, hipMemcpyDeviceToHost));
@@ -3780,9 +3933,10 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
                 p += 4;
             }
             if (ok) { first_record = (uint64_t)(p - head.data()); break; }
-            if (!more || want >= (size_t)total_u)
+            if (more && want >= header_limit && span && header_limit < (size_t)total_u + 1 && span->header_bytes < size) return PC_RETRY_HEADER;
+            if (!more || want >= header_limit)
                 return fail(PC_ERR_ARG, want < 12 ? "not a BAM file (bad magic)" : (b->ref_names.empty() && n_ref == 0 ? "truncated BAM header" : "truncated BAM reference list"));
-            want = std::min<size_t>((size_t)total_u, want * 4);
+            want = std::min<size_t>(header_limit, want * 4);
         }
     }
     // ---- record starts: every member guesses its first record start and walks the chain of length prefixes; the
@@ -3794,6 +3948,21 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
     if (rc == PC_OK) rc = d_rec_off.reserve((size_t)std::max(nm, 1) * kMaxRecPerMember);
     if (rc == PC_OK) rc = d_forced.reserve((size_t)std::max(nm, 1));
     if (rc != PC_OK) return rc;
+    // region read: the records start where the index says (a record start inside the span's first member) and end at its
+    // last chunk's end; a header-only read (no chunk at all) has no records
+    uint64_t stop_at = total_u;
+    if (span) {
+        if (span_first_member < 0) { first_record = total_u; stop_at = total_u; }
+        else {
+            const uint64_t fr = members[(size_t)span_first_member].uoff + (span->voff_begin & 0xffffu);
+            if (fr < first_record || fr > total_u)
+                return fail(PC_ERR_ARG, "the index does not belong to this BAM file (a chunk starts inside the header or beyond its member): %s", path.c_str());
+            first_record = fr;
+            if (span_last_member >= 0) stop_at = members[(size_t)span_last_member].uoff + (span->voff_end & 0xffffu);
+            if (stop_at > total_u || stop_at < first_record)
+                return fail(PC_ERR_ARG, "the index does not belong to this BAM file (a chunk ends beyond its member): %s", path.c_str());
+        }
+    }
     std::vector<MemberChain> chain((size_t)nm);
     std::vector<uint64_t> forced((size_t)nm, ~0ull), rec_base((size_t)nm + 1, 0);
     std::vector<uint32_t> nrec_of((size_t)nm, 0u);
@@ -3805,15 +3974,15 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
         uint64_t expected = first_record;
         for (int round = 0;; ++round) {
             hipLaunchKernelGGL(k_bam_chain, dim3((unsigned)(nm - from)), dim3(64), 0, st, d_stream.p, total_u, d_members.p, nm, from, n_ref, first_record,
-                               d_forced.p, d_chain.p, d_rec_off.p);
+                               d_forced.p, d_chain.p, d_rec_off.p, stop_at);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(chain.data() + from, d_chain.p + from, (size_t)(nm - from) * sizeof(MemberChain), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             int redo = -1;
             for (int m = from; m < nm; ++m) {
-                const uint64_t begin = members[(size_t)m].uoff, end = begin + members[(size_t)m].ulen;
+                const uint64_t begin = members[(size_t)m].uoff, end = std::min<uint64_t>(begin + members[(size_t)m].ulen, stop_at);
                 nrec_of[(size_t)m] = 0;
-                if (expected >= end) continue;                      // no record starts in this member
+                if (expected >= end) continue;                      // no record starts in this member (or it lies behind the span)
                 const MemberChain &mc = chain[(size_t)m];
                 if (mc.first != expected) {                         // the guess was off (or there was none): walk again from the right place
                     forced[(size_t)m] = expected;
@@ -3830,10 +3999,13 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             from = redo;
             if (round > nm + 8) return fail(PC_ERR_STATE, "pc_bam_open: the record chain of %s did not settle", path.c_str());
         }
-        if (expected != total_u) truncated = true;   // the last record runs past (or stops short of) the end of the stream
+        if (expected != stop_at) {   // the last record runs past (or stops short of) the end of the stream
+            if (span) return fail(PC_ERR_ARG, "the index does not belong to this BAM file (a chunk ends inside a record): %s", path.c_str());
+            truncated = true;
+        }
         for (int m = 0; m < nm; ++m) rec_base[(size_t)m + 1] = rec_base[(size_t)m] + nrec_of[(size_t)m];
         nrec = (int64_t)rec_base[(size_t)nm];
-    } else if (total_u != first_record) truncated = true;
+    } else if (total_u != first_record && !span) truncated = true;
     HIP_TRY(hipEventRecord(ev[3], st));
     clk.lap("header + record chain");
     b->total = nrec;
@@ -3870,6 +4042,19 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
         hipLaunchKernelGGL(k_bam_fields, dim3(g256), dim3(256), 0, st, d_stream.p, total_u, d_members.p, d_rec_base.p, d_chain.p, d_rec_off.p, nm, nrec,
                            n_ref, d_rec_member.p, d_recs.p);
         hipLaunchKernelGGL(k_bam_order, dim3(g256), dim3(256), 0, st, d_recs.p, nrec, d_placed.p, d_misc.p);
+        DevBuf<int32_t> d_rtid;
+        DevBuf<int64_t> d_rbe;
+        if (span) {   // keep what overlaps a requested region (htslib's overlap rule); everything else is as if it were not in the file
+            const size_t nr = (size_t)std::max(span->nreg, 0);
+            rc = d_rtid.upload(span->tid, nr, st);
+            if (rc == PC_OK) rc = d_rbe.reserve(2 * std::max<size_t>(nr, 1));
+            if (rc != PC_OK) return rc;
+            if (nr) {
+                HIP_TRY(hipMemcpyAsync(d_rbe.p, span->beg, nr * 8, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(d_rbe.p + nr, span->end, nr * 8, hipMemcpyHostToDevice, st));
+            }
+            hipLaunchKernelGGL(k_bam_region_filter, dim3(g256), dim3(256), 0, st, d_recs.p, nrec, (int)nr, d_rtid.p, d_rbe.p, d_rbe.p + nr);
+        }
         HIP_TRY(hipMemsetAsync(d_placed.p + nrec, 0, 4, st));
         HIP_TRY(hipMemsetAsync(d_runs.p + nrec, 0, 4, st));
         hipLaunchKernelGGL(k_bam_scan_inputs, dim3((unsigned)((nrec + 256 * kScanInputsPerThread - 1) / (256 * kScanInputsPerThread))), dim3(256), 0, st, d_recs.p, nrec, d_placed.p, d_runs.p, d_misc.p + 1);
@@ -3949,7 +4134,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
                 HIP_TRY(hipMemcpy(sa.data(), d_staged_at.p, (size_t)nrec * 4, hipMemcpyDeviceToHost));
                 HIP_TRY(hipMemcpy(recs.data(), d_recs.p, (size_t)nrec * sizeof(RecOut), hipMemcpyDeviceToHost));
                 for (int64_t i = 0; i < nrec; ++i)
-                    if (recs[(size_t)i].placed && wf[sa[(size_t)i]]) {
+                    if (recs[(size_t)i].placed == 1 && wf[sa[(size_t)i]]) {
                         b->wide_idx.push_back((int64_t)sa[(size_t)i]);
                         b->wide_alen.push_back((int32_t)recs[(size_t)i].L);
                         b->wide_nblk.push_back((int32_t)recs[(size_t)i].nruns);
@@ -4023,15 +4208,28 @@ int pc_bam_read_sam(pc_bam *b, uint16_t *flag, uint8_t *mapq, int32_t *lseq) {
     return PC_OK;
 }
 
-static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded);
+static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded,
+                                  const BamSpan *span = nullptr);
 
 int pc_add_alignment_bam(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped) {
     return add_alignment_bam_impl(e, image, size, name, mapped, nullptr);
 }
 
-static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded) {
+// a region read comes back for a larger slice of the file's head when the header did not fit the first one
+static int bam_open_span_retry(pc_engine *e, const void *image, int64_t size, const char *name, pc_bam **out, const UploadedHook *uploaded, const BamSpan *span) {
+    if (!span) return bam_open_impl(e, image, size, name, out, uploaded, nullptr);
+    BamSpan sp = *span;
+    for (;;) {
+        const int rc = bam_open_impl(e, image, size, name, out, uploaded, &sp);
+        if (rc != PC_RETRY_HEADER) return rc;
+        sp.header_bytes = std::min<int64_t>(size, sp.header_bytes * 16);
+    }
+}
+
+static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded,
+                                  const BamSpan *span) {
     pc_bam *b = nullptr;
-    int rc = bam_open_impl(e, image, size, name, &b, uploaded);
+    int rc = bam_open_span_retry(e, image, size, name, &b, uploaded, span);
     if (rc != PC_OK) return rc;
     struct Closer { pc_bam *b; ~Closer() { pc_bam_close(b); } } closer{b};
     PoolScope pool_scope(&e->pool);
@@ -4089,7 +4287,8 @@ namespace {
 struct MappedFile {
     void *p = nullptr;
     size_t size = 0;
-    int open(const char *path) {
+    // touch: fault every page in up front (whole-file reads); a region read maps only, and faults what it uploads
+    int open(const char *path, bool touch = true) {
         const int fd = ::open(path, O_RDONLY);
         if (fd < 0) return fail(PC_ERR_ARG, "cannot open %s: %s", path, strerror(errno));
         struct stat sb;
@@ -4098,14 +4297,16 @@ struct MappedFile {
         if (size) {
             p = mmap(nullptr, size, PROT_READ, MAP_SHARED, fd, 0);
             if (p == MAP_FAILED) { p = nullptr; ::close(fd); return fail(PC_ERR_NOMEM, "cannot map %s: %s", path, strerror(errno)); }
-            (void)madvise(p, size, MADV_WILLNEED);
-            const int64_t pages = (int64_t)((size + 4095) / 4096);
-            const volatile uint8_t *q = (const volatile uint8_t *)p;
-            parallel_chunks(pages, std::min(usable_cpus(), 32), [&](int, int64_t b, int64_t en) {
-                uint8_t acc = 0;
-                for (int64_t k = b; k < en; ++k) acc ^= q[(size_t)k * 4096];
-                (void)acc;
-            });
+            if (touch) {
+                (void)madvise(p, size, MADV_WILLNEED);
+                const int64_t pages = (int64_t)((size + 4095) / 4096);
+                const volatile uint8_t *q = (const volatile uint8_t *)p;
+                parallel_chunks(pages, std::min(usable_cpus(), 32), [&](int, int64_t b, int64_t en) {
+                    uint8_t acc = 0;
+                    for (int64_t k = b; k < en; ++k) acc ^= q[(size_t)k * 4096];
+                    (void)acc;
+                });
+            }
         }
         ::close(fd);
         return PC_OK;
@@ -4150,6 +4351,42 @@ int pc_add_alignment_bam_path(pc_engine *e, const char *path, int64_t *mapped) {
     const int device = e->device;
     const UploadedHook hook = [&mf, device](hipStream_t up) { mf.release_behind(up, device); };
     return add_alignment_bam_impl(e, mf.p, (int64_t)mf.size, path, mapped, &hook);
+}
+
+static int span_args(const char *what, uint64_t voff_begin, uint64_t voff_end, int nreg, const int32_t *tid, const int64_t *beg, const int64_t *end, BamSpan &sp) {
+    if (voff_end < voff_begin || nreg < 0 || (nreg > 0 && (!tid || !beg || !end))) return fail(PC_ERR_ARG, "%s: bad span / regions", what);
+    for (int k = 0; k < nreg; ++k) {
+        if (tid[k] < 0 || end[k] <= beg[k]) return fail(PC_ERR_ARG, "%s: region %d is empty or has no reference id", what, k);
+        if (k > 0 && (tid[k] < tid[k - 1] || (tid[k] == tid[k - 1] && beg[k] < end[k - 1])))
+            return fail(PC_ERR_ARG, "%s: regions must be ascending by (reference id, start) and must not overlap", what);
+    }
+    sp.voff_begin = voff_begin; sp.voff_end = voff_end; sp.nreg = nreg; sp.tid = tid; sp.beg = beg; sp.end = end;
+    if (const char *env = getenv("PC_BAM_HEADER_BYTES")) sp.header_bytes = std::max<int64_t>(1, atoll(env));   // (tests: a header longer than the first slice)
+    return PC_OK;
+}
+
+int pc_bam_open_span(pc_engine *e, const char *path, uint64_t voff_begin, uint64_t voff_end, int nreg, const int32_t *tid, const int64_t *beg,
+                     const int64_t *end, pc_bam **out) {
+    if (!e || !path || !out) return fail(PC_ERR_ARG, "pc_bam_open_span: bad arguments");
+    BamSpan sp;
+    int rc = span_args("pc_bam_open_span", voff_begin, voff_end, nreg, tid, beg, end, sp);
+    if (rc != PC_OK) return rc;
+    MappedFile mf;
+    rc = mf.open(path, false);
+    if (rc != PC_OK) return rc;
+    return bam_open_span_retry(e, mf.p, (int64_t)mf.size, path, out, nullptr, &sp);
+}
+
+int pc_add_alignment_bam_span(pc_engine *e, const char *path, uint64_t voff_begin, uint64_t voff_end, int nreg, const int32_t *tid,
+                              const int64_t *beg, const int64_t *end, int64_t *mapped) {
+    if (!e || !path) return fail(PC_ERR_ARG, "pc_add_alignment_bam_span: bad arguments");
+    BamSpan sp;
+    int rc = span_args("pc_add_alignment_bam_span", voff_begin, voff_end, nreg, tid, beg, end, sp);
+    if (rc != PC_OK) return rc;
+    MappedFile mf;
+    rc = mf.open(path, false);
+    if (rc != PC_OK) return rc;
+    return add_alignment_bam_impl(e, mf.p, (int64_t)mf.size, path, mapped, nullptr, &sp);
 }
 
 } // extern "C"

@@ -99,17 +99,27 @@ class Engine(object):
         for f in files:
             self.add_alignment_file(f, ntid)
 
-    def add_bam(self, path):
+    def add_bam(self, path, regions=None):
         """Stage a coordinate-sorted BAM file WITHOUT its records ever visiting the host (``pc_add_alignment_bam``): the
         file image goes to HBM, the BGZF members are inflated and the records decoded there, and the packed columns are
         staged by kernels.  Returns the number of mapped reads (pysam's ``AlignmentFile.mapped``).  The engine then
         counts exactly as after ``add_alignment_file(read_bam(path))``; callers that also want the reads themselves
-        (``reads_out`` as objects, host-side filters) use :func:`plastid_amd.bam.read_bam_gpu` instead."""
+        (``reads_out`` as objects, host-side filters) use :func:`plastid_amd.bam.read_bam_gpu` instead.
+        `regions`: stage only the alignments that overlap one of them (``(chrom, start, end)`` or |GenomicSegments|),
+        through the file's BAI index -- only the BGZF members the index points to are uploaded and inflated
+        (``pc_add_alignment_bam_span``; what one rank of a multi-GPU job does with its genome range of a shared file);
+        the return value is then the number of mapped reads among those staged."""
         import os
         if not os.path.isfile(path):
             raise IOError("No such file: %r" % (path,))
         mapped = ctypes.c_int64(0)
-        rc = self._lib.pc_add_alignment_bam_path(self._h, os.fsencode(path), ctypes.byref(mapped))
+        if regions is not None:
+            from .bam import resolve_regions
+            sp = resolve_regions(path, regions)
+            rc = self._lib.pc_add_alignment_bam_span(self._h, os.fsencode(path), sp["voff_begin"], sp["voff_end"], len(sp["tid"]),
+                                                     _ptr(sp["tid"]), _ptr(sp["beg"]), _ptr(sp["end"]), ctypes.byref(mapped))
+        else:
+            rc = self._lib.pc_add_alignment_bam_path(self._h, os.fsencode(path), ctypes.byref(mapped))
         check(rc)
         self.nfiles += 1
         return int(mapped.value)
@@ -117,6 +127,25 @@ class Engine(object):
     def num_records(self, file_index):
         """Records staged for file `file_index`."""
         return int(self._lib.pc_num_records(self._h, int(file_index)))
+
+    def read_records(self, file_index, indices):
+        """Read objects' worth of data for records of a staged file (``pc_read_records`` + ``pc_read_record_runs``):
+        dict of arrays ``tid, pos, alen, reverse, nblk, flag16, mapq`` plus ``run_off`` (n + 1), ``run_start``,
+        ``run_len`` -- record k's aligned runs are ``run_start/len[run_off[k]:run_off[k + 1]]``."""
+        idx = _c(indices, np.int64)
+        n = len(idx)
+        out = dict(tid=np.zeros(n, np.int32), pos=np.zeros(n, np.int32), alen=np.zeros(n, np.int32), reverse=np.zeros(n, np.uint8),
+                   nblk=np.zeros(n, np.int32), flag16=np.zeros(n, np.uint16), mapq=np.zeros(n, np.uint8))
+        check(self._lib.pc_read_records(self._h, int(file_index), n, _ptr(idx), _ptr(out["tid"]), _ptr(out["pos"]), _ptr(out["alen"]),
+                                        _ptr(out["reverse"]), _ptr(out["nblk"]), _ptr(out["flag16"]), _ptr(out["mapq"])))
+        cnt = np.where(out["alen"] > 0, np.maximum(out["nblk"], 1), 0).astype(np.int64)
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(cnt, out=off[1:])
+        nr = int(off[-1])
+        out["run_off"], out["run_start"], out["run_len"] = off, np.zeros(nr, np.int32), np.zeros(nr, np.int32)
+        at = np.ascontiguousarray(off[:-1])
+        check(self._lib.pc_read_record_runs(self._h, int(file_index), n, _ptr(idx), _ptr(at), nr, _ptr(out["run_start"]), _ptr(out["run_len"])))
+        return out
 
     def update_flags(self, file_index, flags):
         flags = _c(flags, np.uint8)
@@ -206,6 +235,13 @@ class Engine(object):
         steps, waves = ctypes.c_int64(0), ctypes.c_int64(0)
         check(self._lib.pc_center_replay_steps(self._h, plan._h, ctypes.byref(steps), ctypes.byref(waves)))
         return steps.value, waves.value
+
+    def center_row_fill(self, plan):
+        """``(row_entries, row_slots)`` of `plan`'s center dispatch list (``pc_center_row_fill``): the fraction of the
+        lock-step rows' capacity that holds an entry."""
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.pc_center_row_fill(self._h, plan._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     @property
     def stream(self):

@@ -52,10 +52,10 @@ def _open_alignment_source(src, regions=None, engine=None, decode="auto"):
         from .bam import read_bam, read_bam_gpu
         if decode not in ("auto", "host", "gpu"):
             raise ValueError("decode must be 'auto', 'host' or 'gpu', got %r" % (decode,))
-        on_gpu = decode == "gpu" or (decode == "auto" and os.path.exists(src) and os.path.getsize(src) >= GPU_DECODE_MIN_BYTES)
-        if on_gpu and regions is None and engine is not None:
-            if decode == "gpu":
-                aln = read_bam_gpu(src, engine)
+        on_gpu = decode == "gpu" or (decode == "auto" and regions is None and os.path.exists(src) and os.path.getsize(src) >= GPU_DECODE_MIN_BYTES)
+        if on_gpu and engine is not None:
+            if decode == "gpu":   # (also with `regions`: the members the index points to are inflated on the GPU)
+                aln = read_bam_gpu(src, engine, regions=regions)
                 aln.decoder = "gpu"
                 return aln
             # "auto": a file the device decoder rejects gets a second opinion from the host decoder (whose verdict -- the
@@ -74,7 +74,8 @@ def _open_alignment_source(src, regions=None, engine=None, decode="auto"):
 
 class _DeviceAlignments(object):
     """Stand-in for a BAM file whose records live in HBM only (``BAMGenomeArray(path, keep_reads=False)``): it knows
-    the header, the record and mapped-read counts -- not the reads."""
+    the header, the record and mapped-read counts; read OBJECTS are made on demand from the staged records
+    (``pc_read_records``: position, aligned runs, strand, FLAG, MAPQ -- what the mapping functions and filters look at)."""
 
     def __init__(self, path, references, lengths):
         self.filename = path
@@ -82,17 +83,37 @@ class _DeviceAlignments(object):
         self.lengths = list(lengths)
         self.mapped = 0
         self.n = 0
+        self._engine = None
+        self._file_index = 0
 
     def close(self):
         pass
 
+    def reads(self, indices):
+        """:class:`~plastid_amd.packing.PackedRead` objects for the staged records `indices` (one gather on the GPU)."""
+        from .packing import PackedRead
+        idx = np.asarray(indices, np.int64)
+        if not len(idx):
+            return []
+        d = self._engine.read_records(self._file_index, idx)
+        out = []
+        off, rs, rl = d["run_off"], d["run_start"], d["run_len"]
+        for k in range(len(idx)):
+            runs = [(int(rs[j]), int(rl[j])) for j in range(int(off[k]), int(off[k + 1]))]
+            out.append(PackedRead(self, int(idx[k]), int(d["tid"][k]), int(d["pos"][k]), bool(d["reverse"][k]), runs,
+                                  int(d["flag16"][k]), int(d["mapq"][k]), None))
+        return out
+
+    def read(self, i):
+        return self.reads([int(i)])[0]
+
     def _host_only(self, *args, **kwargs):
         raise NotImplementedError(
-            "this BAMGenomeArray was opened with keep_reads=False: its reads live on the GPU only (count vectors, "
-            "get_reads_batch(as_indices=True), size filters); open it with keep_reads=True for read objects, "
-            "reads_out and arbitrary filter functions")
+            "this BAMGenomeArray was opened with keep_reads=False: its reads live on the GPU only (count vectors, read "
+            "objects through get_reads / get_reads_batch, size and FLAG / MAPQ filters); open it with keep_reads=True "
+            "for arbitrary filter functions and fetch()")
 
-    fetch = read = fetch_indices = _host_only
+    fetch = fetch_indices = _host_only
 
 
 def _pack_source(src, chroms, chrom_index):
@@ -149,8 +170,8 @@ class BAMGenomeArray(object):
         self._device_only = kwargs.get("keep_reads", True) is False
         if self._device_only:
             from .bam import bam_header
-            if not bamfiles or not all(isinstance(x, str) for x in bamfiles) or kwargs.get("regions") is not None:
-                raise ValueError("keep_reads=False takes BAM files named by path, whole (no regions)")
+            if not bamfiles or not all(isinstance(x, str) for x in bamfiles):
+                raise ValueError("keep_reads=False takes BAM files named by path")
             self.bamfiles = [_DeviceAlignments(x, *bam_header(x)) for x in bamfiles]
             if any(b.references != self.bamfiles[0].references for b in self.bamfiles):
                 raise ValueError("keep_reads=False needs the same reference list in every file")
@@ -177,8 +198,15 @@ class BAMGenomeArray(object):
             self._packed = self.bamfiles
             self._engine.clear_alignments()
             for fi, b in enumerate(self.bamfiles):
-                b.mapped = self._engine.add_bam(b.filename)
+                if kwargs.get("regions") is not None:   # only what overlaps the regions is staged; `mapped` is the index's whole-file count, as pysam's
+                    from .bam import resolve_regions
+                    kept = self._engine.add_bam(b.filename, regions=kwargs["regions"])
+                    whole = resolve_regions(b.filename, [])["mapped"]
+                    b.mapped = whole if whole >= 0 else kept
+                else:
+                    b.mapped = self._engine.add_bam(b.filename)
                 b.n = self._engine.num_records(fi)
+                b._engine, b._file_index = self._engine, fi
             self._base_flags = None
         else:
             self._packed = [_pack_source(x, self._tid_names, self._chrom_index) for x in self.bamfiles]
@@ -409,7 +437,9 @@ class BAMGenomeArray(object):
         tid = self._chrom_index[chrom]
         code = roi.c_strand
         reads = []
-        for fi, packed in enumerate(self._packed):
+        if self._device_only:   # the reads the rule kept, file by file, found and gathered on the GPU
+            reads = self.get_reads_batch([roi])[0]
+        for fi, packed in enumerate(self._packed if not self._device_only else []):
             idx = packed.fetch_indices(chrom, roi.start, roi.end)
             if len(idx) == 0:
                 continue
@@ -450,6 +480,8 @@ class BAMGenomeArray(object):
             parts = [(f, rec[offsets[s * nfiles + f]:offsets[s * nfiles + f + 1]]) for f in range(nfiles)]
             if as_indices:
                 out.append([(f, idx.astype(np.int64)) for f, idx in parts if len(idx)])
+            elif self._device_only:
+                out.append([r for f, idx in parts if len(idx) for r in self._packed[f].reads(idx)])
             else:
                 out.append([self._packed[f].read(int(i)) for f, idx in parts for i in idx])
         return out

@@ -203,6 +203,25 @@ class GenomePartition(object):
     def records(self, rank):
         return [f.slice(i0, i1) for f, (i0, i1) in zip(self.files, self.record_ranges(rank))]
 
+    def rank_regions(self, rank, references):
+        """The genome range of `rank` -- its cut interval extended to the left by the halo -- as ``(chrom, start, end)``
+        regions over `references` (the contig names): what the rank hands to a region read of ONE shared BAM file
+        (``Engine.add_bam(path, regions=...)`` / ``read_bam(path, regions=...)``: only the BGZF members the BAI index
+        points to are read) instead of every rank decoding the whole file.  A read is returned for a region it OVERLAPS,
+        so the rank gets at least the records :meth:`record_ranges` names (every record that starts inside the range or
+        within a halo before it) plus those that reach in from further left: more read-only duplication, same counts
+        (a read only counts at positions it aligns to, and the rank only counts positions of its own pieces)."""
+        lo = 0 if rank == 0 else int(self.cuts[rank - 1]) - self.halo
+        hi = int(self.tid_off[-1]) if rank == self.world - 1 else int(self.cuts[rank])
+        lo = max(lo, 0)
+        out = []
+        for t in range(self.ntid):
+            a, b = int(self.tid_off[t]), int(self.tid_off[t + 1])
+            s, e = max(lo, a), min(hi, b)
+            if e > s:
+                out.append((references[t], s - a, e - a))
+        return out
+
     def segments(self, rank, layout="global"):
         """Segment pieces of `rank` as ``pc_plan_create`` arrays.  ``layout="global"`` keeps the
         caller's output coordinates (every rank fills its part of one global layout: right for

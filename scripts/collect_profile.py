@@ -32,19 +32,47 @@ if os.path.exists(os.path.join(src, "bench_line.json")):
     if rows:
         line = json.loads(rows[-1])
         json.dump(line, open(os.path.join(dst, "bench_line.json"), "w"), indent=1)
+def grid_of(row):
+    for key in ("Grid_Size", "Grid_Size_X", "Grid_Size_x"):
+        if key in row and row[key] not in ("", None):
+            return row[key]
+    return "?"
+
+
+def steady(by_grid):
+    """The launches of the grid size that occurs most often: the steady state of a plan (exact grids), as opposed to
+    its first count (whole work-list capacity) and to one-off diagnostic launches."""
+    g = max(by_grid, key=lambda k: (len(by_grid[k]), k))
+    return g, by_grid[g]
+
+
+# ---- kernel trace: per kernel and grid size, so that per-kernel averages mean something (round-4 verdict, weak #1)
+traces = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+if traces:
+    d = defaultdict(lambda: defaultdict(list))
+    for row in csv.DictReader(open(traces[0])):
+        d[row["Kernel_Name"].split("(")[0]][grid_of(row)].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+    with open(os.path.join(dst, "kernel_steady.csv"), "w") as fh:
+        fh.write("kernel,grid_size,launches,mean_ms,min_ms,max_ms,steady\n")
+        for k in sorted(d, key=lambda k: -sum(sum(v) for v in d[k].values())):
+            gs, _ = steady(d[k])
+            for g, v in sorted(d[k].items(), key=lambda kv: -len(kv[1])):
+                fh.write('"%s",%s,%d,%.5f,%.5f,%.5f,%d\n' % (k, g, len(v), sum(v) / len(v), min(v), max(v), 1 if g == gs else 0))
 means = {}
 for sub in ("sq1", "sq2", "fetch", "write", "tcc"):
     files = glob.glob(os.path.join(src, "pmc_" + sub, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         continue
-    d = defaultdict(list)
+    d = defaultdict(lambda: defaultdict(list))
     for row in csv.DictReader(open(files[0])):
-        d[(row["Kernel_Name"].split("(")[0], row["Counter_Name"])].append(float(row["Counter_Value"]))
+        d[(row["Kernel_Name"].split("(")[0], row["Counter_Name"])][grid_of(row)].append(float(row["Counter_Value"]))
     with open(os.path.join(dst, "pmc_%s_per_kernel.csv" % sub), "w") as fh:
-        fh.write("kernel,counter,launches,mean_per_launch\n")
-        for (k, c), v in sorted(d.items()):
-            fh.write('"%s",%s,%d,%.6g\n' % (k, c, len(v), sum(v) / len(v)))
-            means[(k, c)] = sum(v) / len(v)
+        fh.write("kernel,counter,launches,mean_per_launch,steady_grid,steady_launches,steady_mean_per_launch\n")
+        for (k, c), bg in sorted(d.items()):
+            allv = [x for v in bg.values() for x in v]
+            g, v = steady(bg)
+            fh.write('"%s",%s,%d,%.6g,%s,%d,%.6g\n' % (k, c, len(allv), sum(allv) / len(allv), g, len(v), sum(v) / len(v)))
+            means[(k, c)] = sum(v) / len(v)   # (the steady-state launches: what a step is)
 
 
 def kernel_with(sub, counter):
@@ -66,7 +94,7 @@ if kw:
     cal["f_write"] = probe_bytes / (means[(kw, "WRITE_SIZE")] * 1024.0)
     cal["probe_write_WRITE_SIZE_KB"] = means[(kw, "WRITE_SIZE")]
 dominant = "k_center" if config == "C3" else "k_hist_point"
-entry = {"config": config, "round": int(os.environ.get("PC_PROFILE_ROUND", "4")), "dominant_kernel": dominant, "calibration": cal,
+entry = {"config": config, "round": int(os.environ.get("PC_PROFILE_ROUND", "5")), "dominant_kernel": dominant, "calibration": cal,
          "source": "%s/pmc_fetch_per_kernel.csv, pmc_write_per_kernel.csv (separate rocprofv3 --pmc passes, scripts/profile.sh)" % dst}
 if line is not None:
     entry["n_records"] = line["config"].get("records_per_gpu", line["config"].get("records"))
@@ -78,7 +106,7 @@ fetch = write = 0.0
 per_kernel = {}
 for (k, c), v in means.items():
     # (k_center<true, ...> is the diagnostic launch that counts the replay steps for bench.py's issue bound: not a step)
-    if dominant in k and "weigh" not in k and "order" not in k and "k_center<true" not in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+    if dominant in k and not any(x in k for x in ("weigh", "order", "slots", "vals", "k_center<true", "k_center2<true")) and c in ("FETCH_SIZE", "WRITE_SIZE"):
         per_kernel.setdefault(k, {})[c] = v
         if c == "FETCH_SIZE":
             fetch += v

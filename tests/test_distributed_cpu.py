@@ -346,3 +346,65 @@ def test_partition_element_maps_equal_the_piecewise_walk():
         sel = np.concatenate([np.full(rows * max(int(lp["end"][j] - lp["start"][j]), 0), keep[j]) for j in range(len(keep))]) if len(keep) else np.zeros(0, bool)
         assert np.array_equal(li2, li[sel]) and np.array_equal(gi2, gi[sel])
     assert total.sum() > 0
+
+
+# ---------------------------------------------------------------------------- one shared BAM file, a region read per rank
+def _file_shard_worker(rank, world, port, out_dir):
+    """Every rank reads ITS genome range of one shared, indexed BAM file (``GenomePartition.rank_regions`` -> a region
+    read through the BAI index: here the host reader, on a GPU box ``Engine.add_bam(path, regions=...)``), counts its
+    pieces (the oracle stands in for the engine) and the chain sums are completed with one all-reduce."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    from plastid_amd import multigpu, synth
+    from plastid_amd.bam import read_bam
+    from plastid_amd.packing import concat_file_major
+    multigpu.init("gloo")
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00008, tx_scale=0.003)
+    path = os.path.join(out_dir, "shared.bam")
+    p = tx.plan_arrays(rows=1)
+    part = multigpu.GenomePartition([reads], p, world)           # (cuts from the record density; a real job takes them from the index)
+    mine = read_bam(path, regions=part.rank_regions(rank, list(reads.references)))
+    want = part.records(rank)[0]
+    # the region read returns at least the records the partition names for the rank (plus reads reaching in from further left)
+    key = lambda a: set(zip(a.tid.tolist(), a.pos.tolist(), a.alen.tolist(), a.flags.tolist()))  # noqa: E731
+    assert key(want) <= key(mine) and mine.n <= reads.n
+    spec = oracle.mapping_spec("center", 2)
+    lp = part.local_plan_arrays(rank, 1)
+    arr, _ = oracle.count_segments(concat_file_major([mine]), spec, lp["tid"], lp["start"], lp["end"], lp["strand"])
+    local = np.concatenate([a.reshape(-1) for a in arr]) if len(arr) else np.zeros(0, np.float64)
+    li, gi = part.owned_elements(rank, 1)
+    np.save(os.path.join(out_dir, "fs_own%d.npy" % rank), np.stack([gi.astype(np.float64), local[li]]))
+    np.save(os.path.join(out_dir, "fs_n%d.npy" % rank), np.array([mine.n, want.n]))
+
+
+def test_two_ranks_stage_their_ranges_of_one_shared_file(tmp_path):
+    from oracle import oracle
+    from plastid_amd import synth
+    from plastid_amd.packing import concat_file_major
+    from tests import bam_writer
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00008, tx_scale=0.003)
+    path = os.path.join(str(tmp_path), "shared.bam")
+    bam_writer.write_bam(path, list(reads.references), [int(x) for x in reads.lengths], bam_writer.packed_to_records(reads),
+                         block_bytes=4000, index=True)
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_file_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    p = tx.plan_arrays(rows=1)
+    arr, _ = oracle.count_segments(concat_file_major([reads]), oracle.mapping_spec("center", 2), p["tid"], p["start"], p["end"], p["strand"])
+    want = np.zeros(p["out_elems"], np.float64)
+    for s, a in enumerate(arr):
+        want[p["out_off"][s] + p["out_step"][s].astype(np.int64) * np.arange(a.shape[-1])] = a
+    got = np.full(p["out_elems"], np.nan)
+    staged = 0
+    for r in range(world):
+        own = np.load(os.path.join(str(tmp_path), "fs_own%d.npy" % r))
+        idx = own[0].astype(np.int64)
+        assert np.isnan(got[idx]).all()                 # every element is owned by exactly one rank
+        got[idx] = own[1]
+        n = np.load(os.path.join(str(tmp_path), "fs_n%d.npy" % r))
+        staged += int(n[0])
+        assert n[0] >= n[1]
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))      # center sums bit for bit: the ranks' records keep their order
+    assert staged < 1.3 * reads.n                        # no rank read the whole file

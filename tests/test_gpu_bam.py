@@ -633,8 +633,17 @@ def test_bam_genome_array_without_host_reads(tmp_path):
         assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
     ia, ib = a.get_reads_batch(segs, as_indices=True), b.get_reads_batch(segs, as_indices=True)
     assert len(ia) == len(ib) and all(len(p) == len(q) and all(np.array_equal(u[1], v[1]) for u, v in zip(p, q)) for p, q in zip(ia, ib))
-    with pytest.raises(NotImplementedError):
-        b.get_reads(segs[0])
+    # read OBJECTS from the records in HBM (pc_read_records): the reads the rule kept, with positions, strand, FLAG, MAPQ
+    for s_ in segs[:6]:
+        ra, rb = a.get_reads(s_), b.get_reads(s_)
+        assert len(ra) == len(rb) and len(ra) > 0
+        for x, y in zip(ra, rb):
+            assert (x.index, x.reference_id, x.reference_start, x.is_reverse, x.positions, x.flag, x.mapping_quality) == \
+                (y.index, y.reference_id, y.reference_start, y.is_reverse, y.positions, y.flag, y.mapping_quality)
+        (r2, c2), (r1, c1) = b.get_reads_and_counts(s_), a.get_reads_and_counts(s_)
+        assert np.array_equal(np.asarray(c1).view(np.uint64), np.asarray(c2).view(np.uint64)) and [r.index for r in r1] == [r.index for r in r2]
+    ba, bb = a.get_reads_batch(segs), b.get_reads_batch(segs)
+    assert [[r.positions for r in x] for x in ba] == [[r.positions for r in x] for x in bb]
     with pytest.raises(NotImplementedError):
         b.add_filter("mine", lambda read: True)
         b[segs[0]]
@@ -743,3 +752,110 @@ def test_flag_filter_needs_the_columns(eng):
         plan.close()
     e.close()
     h.close()
+
+
+# ---------------------------------------------------------------- region reads (round 5)
+def test_region_reads_match_hts_itr_query_on_the_gpu(eng, tmp_path):
+    """``read_bam_gpu(path, regions=...)`` (pc_bam_open_span: only the BGZF members the BAI index points to are inflated,
+    the record chain starts where the index says, htslib's overlap rule on the GPU) returns what the host region reader
+    returns -- itself pinned to htslib's ``sam_itr_queryi`` result sets (tests/test_hts_golden.py) -- for each of the
+    fixture's 400 regions, and, record for record, htslib's own result sets."""
+    hts = np.load(FIX)
+    path = str(tmp_path / "htslib.bam")
+    open(path, "wb").write(hts["bam"].tobytes())
+    open(path + ".bai", "wb").write(hts["bai"].tobytes())
+    refs = [str(x) for x in hts["references"]]
+    placed = np.nonzero(hts["tid"] >= 0)[0]
+    key = {(int(hts["tid"][i]), int(hts["pos"][i]), int(hts["flag"][i]), int(hts["mapq"][i]), int(hts["l_qseq"][i])): None for i in placed}
+    assert len(key) > 2900           # (tid, pos, flag, mapq, l_seq) names nearly every record of the fixture
+    nonempty = 0
+    for q in range(len(hts["regions"])):
+        t, b, e = (int(x) for x in hts["regions"][q])
+        reg = [(refs[t], b, e)]
+        got = read_bam_gpu(path, eng, regions=reg)
+        same(got, read_bam(path, regions=reg))
+        want = hts["region_records"][hts["region_off"][q]:hts["region_off"][q + 1]]
+        assert got.n == len(want), (q, reg)
+        nonempty += got.n > 0
+        # htslib's iterator, record for record (file order)
+        assert np.array_equal(got.flag16, hts["flag"][want]) and np.array_equal(got.mapq, hts["mapq"][want]) and np.array_equal(got.qlen, hts["l_qseq"][want])
+    assert nonempty > 300
+    many = [(refs[int(t)], int(b), int(e)) for t, b, e in hts["regions"][:40]]
+    same(read_bam_gpu(path, eng, regions=many), read_bam(path, regions=many))
+    same(read_bam_gpu(path, eng, regions=[("chrA", 0, 400000), ("chrB", 0, 60000), ("chrC", 0, 2000)]), read_bam(path))
+    none = read_bam_gpu(path, eng, regions=[("nope", 0, 100)])
+    assert none.n == 0 and list(none.references) == refs and none.mapped == int(hts["index_stat"][:, 1].sum())
+
+
+def _indexed_bam(path, reads, block_bytes, rng, header_lines=0):
+    recs = bam_writer.packed_to_records(reads)
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@CO\tpadding line %06d %s\n" % (k, "x" * 60) for k in range(header_lines))
+    bam_writer.write_bam(path, list(reads.references), [int(x) for x in reads.lengths], recs, block_bytes=block_bytes, header_text=text, index=True)
+    return recs
+
+
+@pytest.mark.parametrize("block_bytes,header_lines", [(3000, 0), (20000, 0), (2500, 9000)])
+def test_region_reads_over_many_members(eng, tmp_path, monkeypatch, block_bytes, header_lines):
+    """Spans of hundreds of members, chunks that start and end in the middle of members, records that straddle members, a
+    header of a dozen members (longer than the first slice of the file's head that is searched for it): random region
+    sets through the GPU entry give the host region reader's arrays; staged on the device (``Engine.add_bam(path,
+    regions=...)``) they count like the host-staged ones, center rule included."""
+    genome, tx, reads, _ = synth.make_config("C4", scale=0.00006, tx_scale=0.002)
+    path = str(tmp_path / "idx.bam")
+    rng = np.random.default_rng(block_bytes)
+    if header_lines:
+        monkeypatch.setenv("PC_BAM_HEADER_BYTES", "600")     # the first slice searched for the header ends inside it: the reader comes back for more
+    _indexed_bam(path, reads, block_bytes, rng, header_lines)
+    refs, lens = list(reads.references), [int(x) for x in reads.lengths]
+    same(read_bam_gpu(path, eng), read_bam(path))
+    for trial in range(12):
+        regs = []
+        for _ in range(int(rng.integers(1, 6))):
+            t = int(rng.integers(0, len(refs)))
+            b = int(rng.integers(0, max(lens[t] - 10, 1)))
+            regs.append((refs[t], b, b + int(rng.choice([1, 50, 3000, 200000, lens[t]]))))
+        got, want = read_bam_gpu(path, eng, regions=regs), read_bam(path, regions=regs)
+        same(got, want)
+    # staged without leaving the device: counts inside the regions equal those of the host-staged region read
+    chains = tx.chains(limit=60)
+    regs = [(c.chrom, c.spanning_segment.start, c.spanning_segment.end) for c in chains[:25]]
+    host = read_bam(path, regions=regs)
+    a, b = Engine(0), Engine(0)
+    a.set_alignments([host])
+    kept = b.add_bam(path, regions=regs)
+    assert kept == int(((host.flag16 & 4) == 0).sum()) and b.num_records(0) == host.n
+    sub = tx.subset(np.arange(25))
+    for x, y in zip(_count_all_rules(a, sub), _count_all_rules(b, sub)):
+        assert np.array_equal(x, y)
+    a.close()
+    b.close()
+
+
+def test_a_foreign_index_is_refused(eng, tmp_path):
+    """An index that does not belong to the file (chunks beyond its end, or ending inside records) is an error, not a
+    crash; a file without an index says so."""
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.00005, tx_scale=0.002)
+    path, other = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    rng = np.random.default_rng(0)
+    _indexed_bam(path, reads, 3000, rng)
+    _indexed_bam(other, reads.slice(57, reads.n // 2), 7000, rng)     # another stream: other records, other member boundaries
+    with pytest.raises((ValueError, IOError)):
+        read_bam_gpu(str(tmp_path / "missing.bam"), eng, regions=[("chr1", 0, 10)])
+    os.replace(path + ".bai", other + ".bai")          # b.bam now has a.bam's index: offsets beyond / inside its members and records
+    ref0 = reads.references[0]
+    outcomes = []
+    for t in range(len(reads.references)):
+        on = reads.pos[reads.tid == t]
+        if not len(on):
+            continue
+        for b in (int(np.quantile(on, f)) for f in (0.1, 0.5, 0.9)):   # where a.bam has reads: its index names chunks there
+            try:
+                got = read_bam_gpu(other, eng, regions=[(reads.references[t], b, b + 50000)])
+                outcomes.append("ok")
+                assert got.n >= 0
+            except ValueError as e:
+                outcomes.append("error")
+                assert any(k in str(e) for k in ("index", "BGZF", "BAM", "sorted")), str(e)
+    assert outcomes.count("error") >= len(outcomes) // 2, outcomes
+    with pytest.raises((ValueError, IOError)):
+        read_bam_gpu(path, eng, regions=[(ref0, 0, 10)])     # a.bam has lost its index
