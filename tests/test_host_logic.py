@@ -531,7 +531,7 @@ def test_auto_decode_falls_back_to_the_host_decoder(tmp_path, monkeypatch):
     bam_writer.write_bam(path, ["c"], [1000], [(0, 5, [(0, 30)], 0), (0, 50, [(0, 20)], 16)])
     calls = []
 
-    def broken(p, engine, timing=None):
+    def broken(p, engine, timing=None, regions=None):
         calls.append(p)
         raise ValueError("BGZF inflate failed in %s" % p)
     monkeypatch.setattr(bam, "read_bam_gpu", broken)
@@ -540,7 +540,7 @@ def test_auto_decode_falls_back_to_the_host_decoder(tmp_path, monkeypatch):
     assert calls == [path] and aln.decoder == "host" and aln.n == 2
     with pytest.raises(ValueError):
         genome_array._open_alignment_source(path, engine=object(), decode="gpu")
-    monkeypatch.setattr(bam, "read_bam_gpu", lambda p, engine, timing=None: bam.read_bam(p))
+    monkeypatch.setattr(bam, "read_bam_gpu", lambda p, engine, timing=None, regions=None: bam.read_bam(p))
     assert genome_array._open_alignment_source(path, engine=object(), decode="auto").decoder == "gpu"
     open(path, "wb").write(b"not a bam")
     monkeypatch.setattr(bam, "read_bam_gpu", broken)
