@@ -197,6 +197,15 @@ int pc_plan_table(pc_plan *p, int which, void *buf, int64_t cap_bytes, int64_t *
  * asynchronously on the engine's stream; results stay in HBM until read. */
 int pc_count(pc_engine *e, pc_plan *p, int out_dtype);
 int pc_sync(pc_engine *e);
+/* ONE segment in ONE call: `ga[segment]` / `BAMGenomeArray.get(segment, roi_order)` (genome_array.py:861-928) -- what the
+ * reference's scripts do region by region (bin/psite.py:181-192) -- without a plan object: the window travels in the
+ * kernel's arguments, the counts come back through page-locked memory the kernel writes itself.  host_out: end - start
+ * elements of int64 / float64 (reads per million when normalisation is on), reversed when `reverse_out` (roi_order on
+ * a '-' segment, :829-830).  PC_ERR_STATE when the query does not qualify -- several staged files, the center or the
+ * stratified rule, a segment longer than 4 096 positions -- and the caller takes pc_plan_create; the DataWarning of the
+ * map functions is not reported here (a caller that needs it asks pc_warn_flags through a plan). */
+int pc_query_segment(pc_engine *e, int32_t tid, int64_t start, int64_t end, uint8_t strand, int reverse_out, int out_dtype,
+                     void *host_out);
 int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems);
 /* device pointer/stream of the last pc_count output (for zero-copy consumers) */
 void *pc_counts_device_ptr(pc_plan *p);

@@ -196,6 +196,14 @@ struct InflateShared {
 // (Measured on the way: reachability by pointer doubling over all 512 offsets instead of the walk, with the
 // post-processing per offset -- correct, and at ~3 700 vector instructions per batch only 13 % faster than the uniform
 // decode.)
+// Experiment hook (never set in the product build): -DPC_BGZF_SKIP=<mask> leaves out 1 the copies of matches whose source
+// lies before the chunk, 2 the matches that read what their own chunk writes, 4 the literal stores, 8 the flushes to HBM,
+// 16 the symbol lookup of the batch (every offset reads as an 8-bit literal), 32 the whole kernel (the lap is then the
+// upload) -- the output is then wrong (the CRC check says so), the
+// control flow is not: it depends on the compressed stream alone.  PC_BAM_TIMING=1 prints the inflate lap before the check.
+#ifndef PC_BGZF_SKIP
+#define PC_BGZF_SKIP 0
+#endif
 constexpr int kBatchBits = 512;             // bit offsets per batch: 64 lanes x 8
 constexpr uint32_t kSymLit = 0u, kSymMatch = 1u, kSymEob = 2u, kSymBad = 3u;   // sym: bits 0-5 consumed, 6-7 kind, 8-15 byte | length - 3, 16-30 distance - 1
 
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     TableScratch &s_ws = su.hdr.ws;
     const int m = first_member + (int)blockIdx.x;   // (the members of one upload piece: pc_bam_open)
     if (m >= nmembers) return;
+    if (PC_BGZF_SKIP & 32) { if (threadIdx.x == 0) status[m] = 0u; return; }   // (experiment: the lap without the kernel = the upload)
     const Member mb = members[m];   // (uniform: scalar loads)
     const int lane = threadIdx.x & 63;
     const uint8_t *src = image + mb.coff;
@@ -339,6 +348,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     uint32_t flushed = 0;         // bytes written to HBM
     auto flush_to = [&](uint32_t upto) {   // window bytes [flushed, upto) -> HBM; both multiples of 16 except at the very end
         __syncthreads();
+        if (PC_BGZF_SKIP & 8) { flushed = upto; return; }
         for (uint32_t b = flushed + 16u * (uint32_t)lane; b < upto; b += 16u * 64u) {
             if (b + 16u <= upto && ((mb.uoff + b) & 15u) == 0u) {
                 const uint4 v = *(const uint4 *)&sh.win[b & (kWinBytes - 1)];
@@ -468,7 +478,8 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                     const uint32_t A = (uint32_t)((((unsigned long long)d1 << 32) | d0) >> s0), B = (uint32_t)((((unsigned long long)d2 << 32) | d1) >> s0);
                     const uint32_t C = (uint32_t)((((unsigned long long)d3 << 32) | d2) >> s0);
                     uint32_t sy[8];
-                    symbols_at8(sh.lit, sh.dist, A, B, C, sy);
+                    if (PC_BGZF_SKIP & 16) { for (int t = 0; t < 8; ++t) sy[t] = 8u | (kSymLit << 6) | ((A >> t) & 0xff00u); }   // (experiment: no lookup -- every offset an 8-bit literal)
+                    else symbols_at8(sh.lit, sh.dist, A, B, C, sy);
                     *(uint4 *)&bs.sym[8 * lane] = make_uint4(sy[0], sy[1], sy[2], sy[3]);
                     *(uint4 *)&bs.sym[8 * lane + 4] = make_uint4(sy[4], sy[5], sy[6], sy[7]);
                 }
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                     const uint32_t chunk_bytes = first < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)(incl - ol), first) : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     const uint32_t chunk_end = chunk_start + chunk_bytes;
                     const bool emit = have && lane < first;
-                    if (emit && kind == kSymLit) sh.win[q & (kWinBytes - 1)] = (uint8_t)(sv >> 8);
+                    if (!(PC_BGZF_SKIP & 4) && emit && kind == kSymLit) sh.win[q & (kWinBytes - 1)] = (uint8_t)(sv >> 8);
                     // ---- matches: those whose source lies before the chunk are independent of one another (one per lane);
                     // those that read what this chunk writes follow in stream order, each copied by the whole wave
                     const bool ism = emit && kind == kSymMatch;
@@ -543,20 +554,38 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                     const bool far = ism && chunk_end - src > (uint32_t)kWinBytes;     // (whole in what has been flushed: see `cap`)
                     if (__ballot(far) != 0ull) __builtin_amdgcn_s_waitcnt(0);         // the flush stores have landed
                     __syncthreads();
-                    if (ism && !dep) {
-                        if (!far) {
-                            for (uint32_t k = 0; k < len; k += 4u) {     // four reads in flight (a read past the match's end is dropped)
-                                const uint8_t b0 = sh.win[(src + k) & (kWinBytes - 1)], b1 = sh.win[(src + k + 1u) & (kWinBytes - 1)];
-                                const uint8_t b2 = sh.win[(src + k + 2u) & (kWinBytes - 1)], b3 = sh.win[(src + k + 3u) & (kWinBytes - 1)];
-                                sh.win[(q + k) & (kWinBytes - 1)] = b0;
-                                if (k + 1u < len) sh.win[(q + k + 1u) & (kWinBytes - 1)] = b1;
-                                if (k + 2u < len) sh.win[(q + k + 2u) & (kWinBytes - 1)] = b2;
-                                if (k + 3u < len) sh.win[(q + k + 3u) & (kWinBytes - 1)] = b3;
+                    // The independent matches of the chunk, by OUTPUT BYTE: a lane per byte, 64 bytes a round.  (One lane per
+                    // match, copying its own bytes, ran every lane for as long as the longest match of the chunk lasted -- with
+                    // read names, quality runs and tags that is often a hundred bytes and more: 16 of the kernel's 42 ms on records as
+                    // an aligner writes them, scripts/exp_bam_sections.py.)  Which symbol a byte belongs to: the symbols' first
+                    // bytes are marked in 64 flag bytes (the offset table of the batch is free by now), and a byte's owner is the
+                    // number of marks up to it -- a ballot and a population count; the owner's source and start come by lane permute.
+                    if (!(PC_BGZF_SKIP & 1) && __ballot(ism && !dep) != 0ull) {
+                        uint8_t *marks = (uint8_t *)bs.sym;
+                        const uint32_t startrel = emit ? q - chunk_start : 0xffffu;
+                        const uint32_t info = (startrel & 0xffffu) | ((ism && !dep) ? 1u << 16 : 0u) | (far ? 1u << 17 : 0u);
+                        for (uint32_t base = 0; base < chunk_bytes; base += 64u) {
+                            marks[lane] = 0;
+                            __syncthreads();
+                            if (emit && ol != 0u && startrel >= base && startrel < base + 64u) marks[startrel - base] = 1;
+                            __syncthreads();
+                            const unsigned long long mk = __ballot(marks[lane] != 0);
+                            const uint32_t before = (uint32_t)__popcll(__ballot(emit && ol != 0u && startrel < base));
+                            const uint32_t owner = before + (uint32_t)__popcll(mk & (~0ull >> (63 - lane))) - 1u;   // (the chunk's first symbol starts at its byte 0)
+                            const uint32_t o_src = (uint32_t)__shfl((int)src, (int)(owner & 63u), 64);
+                            const uint32_t o_info = (uint32_t)__shfl((int)info, (int)(owner & 63u), 64);
+                            const uint32_t x = base + (uint32_t)lane;
+                            if (x < chunk_bytes && ((o_info >> 16) & 1u)) {
+                                const uint32_t from = o_src + (x - (o_info & 0xffffu));
+                                const uint8_t b = ((o_info >> 17) & 1u) ? __hip_atomic_load(dst + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   // (past this CU's L1, which may hold an older state of the line)
+                                                                        : sh.win[from & (kWinBytes - 1)];
+                                sh.win[(chunk_start + x) & (kWinBytes - 1)] = b;
                             }
-                        } else for (uint32_t k = 0; k < len; ++k) sh.win[(q + k) & (kWinBytes - 1)] = __hip_atomic_load(dst + (src + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past this CU's L1, which may hold an older state of the line)
+                            __syncthreads();
+                        }
                     }
                     __syncthreads();
-                    unsigned long long dm = __ballot(dep);
+                    unsigned long long dm = (PC_BGZF_SKIP & 2) ? 0ull : __ballot(dep);
                     while (dm) {
                         const int l = __builtin_ctzll(dm);
                         dm &= dm - 1ull;

@@ -1213,7 +1213,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
                                                     int fast_hi, uint32_t *hist,
                                                     int64_t hist_row_stride, typename OutT_<OUTMODE>::type *out,
                                                     double norm_sum, uint32_t work_cap, uint32_t grid_front,
-                                                    const FileRange *__restrict__ chain, int nfiles) {
+                                                    const FileRange *__restrict__ chain, int nfiles,
+                                                    // SINGLE with work == nullptr (pc_query_segment: `ga[segment]` in ONE call, no plan object, no upload, no
+                                                    // read-back copy): the window and its one output piece travel in the kernel's arguments, `out` is page-locked
+                                                    // host memory the kernel writes itself, and `done` -- behind the counts -- tells the polling host they are there
+                                                    Tile q_tile, OutPiece q_op, uint32_t *done, uint32_t done_seq) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // The stratified rule (the only one with several rows) bins into 16-BIT counters, two positions per LDS word: the
     // same bytes of LDS hold a window twice as long, so a plan has half the windows -- half the workgroup starts, entry
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     const uint32_t n_heavy = SINGLE ? 1u : (SMALL ? nwork[2] : nwork[0]), n_light = (SMALL || SINGLE) ? 0u : nwork[1];
     WorkItem w_;
     if (SINGLE) {
-        const Tile tl = *(const Tile *)work;
+        const Tile tl = work ? *(const Tile *)work : q_tile;
         const GFile g0 = gfile(file0);
         const int Ws = (int)hist_row_stride, Wg = (int)work_cap, Wr = (int)grid_front;   // (the halos travel in arguments a single window has no use for)
         const int64_t q0 = g0.lin_off[tl.tid], qn = g0.lin_off[tl.tid + 1] - q0 - 1;
@@ -1288,7 +1292,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     // epilogue does not start with a chain of dependent global loads
     const int nstage = w.merge ? 0 : (int)min(w.op_end - w.op_begin, (uint32_t)kOpStage);
     u32x4 opq = {0u, 0u, 0u, 0u};
-    if ((int)threadIdx.x < nstage * 3) opq = ((const u32x4 PC_GLOBAL *)(opieces + w.op_begin))[threadIdx.x];
+    if ((!SINGLE || work) && (int)threadIdx.x < nstage * 3) opq = ((const u32x4 PC_GLOBAL *)(opieces + w.op_begin))[threadIdx.x];
     const u32x4 gnone = {0u, kFlagExcluded << 16, 0u, 0u};
     // first batch of the gapped-record list, requested with everything else -- where the register budget is that of
     // six waves anyway (eight registers held across the stream loop are what separates six waves from seven)
@@ -1318,7 +1322,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
     uint32_t *bins = smem + fwords + ((tab_n + 3) & ~3);
     OutPiece *s_op = (OutPiece *)(bins + (((size_t)max_slots * mp.rows * G) >> (B16 ? 1 : 0))); // 16-byte aligned: every part is a multiple of 4 words
     const uint32_t dump = (uint32_t)((char *)(s_op + kOpStage) - (char *)smem) + (threadIdx.x & 63u) * 4u; // the lane's dump word
-    if ((int)threadIdx.x < nstage * 3) ((u32x4 *)s_op)[threadIdx.x] = opq;
+    if (SINGLE && !work) { if (threadIdx.x == 0) s_op[0] = q_op; }   // (the one output piece of an argument-borne window)
+    else if ((int)threadIdx.x < nstage * 3) ((u32x4 *)s_op)[threadIdx.x] = opq;
     if (!(PC_HIST_SKIP & 16)) {   // only bins in [span_lo, span_hi) are ever read back: clear just those
         // (16-byte stores over the span rounded out to 4 words; no per-element division)
         // (a 16-byte store covers 4 bins of 32 bits, 8 of 16)
@@ -1564,6 +1569,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
                 }
             }
         }
+    }
+    if (SINGLE && done) {   // pc_query_segment: the counts are in the host's buffer -- say so, behind them
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

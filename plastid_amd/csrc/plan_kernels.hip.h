@@ -57,6 +57,7 @@ struct Misc {
     unsigned long long npos;        // positions of the compact histogram (sum of the island lengths)
     uint32_t modes, has_sums, needs_zero, max_slots;
     uint32_t n_islands, n_pieces, n_tiles, n_opieces;
+    unsigned long long iv_len;      // summed length of those intervals (a sparse annotation takes a smaller window)
 };
 
 constexpr int kTidBits = 27;        // contigs a piece key has room for (contig 27 | window 23 | mode 2 | offset 12 bits)
@@ -77,7 +78,7 @@ __device__ __forceinline__ unsigned long long iv_key(int32_t tid, int mode, int6
 __global__ __launch_bounds__(256) void k_plan_segs(SegIn in, int64_t nseg, int ntid, int rows, int64_t out_elems, GatherSeg *__restrict__ gsegs,
                                                    unsigned long long *__restrict__ keys, uint32_t *__restrict__ ends, Misc *__restrict__ misc) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned long long covered = 0, n_iv = 0;
+    unsigned long long covered = 0, n_iv = 0, iv_len = 0;
     uint32_t modes = 0, sums = 0;
     if (s < nseg) {
         const int64_t st = in.start[s], en = in.end[s], len = en - st;
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void k_plan_segs(SegIn in, int64_t nseg, int n
                     key = iv_key(t, m, cs);
                     e32 = (uint32_t)ce;
                     n_iv = 1;
+                    iv_len = (unsigned long long)(ce - cs);
                 }
             }
             gsegs[s] = g;
@@ -119,18 +121,18 @@ __global__ __launch_bounds__(256) void k_plan_segs(SegIn in, int64_t nseg, int n
         ends[s] = e32;
     }
     // block totals -> one atomic each
-    __shared__ unsigned long long s_cov, s_niv;
+    __shared__ unsigned long long s_cov, s_niv, s_len;
     __shared__ uint32_t s_modes, s_sums;
-    if (threadIdx.x == 0) { s_cov = 0; s_niv = 0; s_modes = 0; s_sums = 0; }
+    if (threadIdx.x == 0) { s_cov = 0; s_niv = 0; s_len = 0; s_modes = 0; s_sums = 0; }
     __syncthreads();
     if (covered) atomicAdd(&s_cov, covered);
-    if (n_iv) atomicAdd(&s_niv, n_iv);
+    if (n_iv) { atomicAdd(&s_niv, n_iv); atomicAdd(&s_len, iv_len); }
     if (modes) atomicOr(&s_modes, modes);
     if (sums) atomicOr(&s_sums, sums);
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_cov) atomicAdd(&misc->covered, s_cov);
-        if (s_niv) atomicAdd(&misc->n_iv, s_niv);
+        if (s_niv) { atomicAdd(&misc->n_iv, s_niv); atomicAdd(&misc->iv_len, s_len); }
         if (s_modes) atomicOr(&misc->modes, s_modes);
         if (s_sums) atomicOr(&misc->has_sums, s_sums);
     }

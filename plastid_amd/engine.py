@@ -201,6 +201,13 @@ class Engine(object):
                                             int(start), int(end), int(strand_code), _ptr(mask)))
         return mask
 
+    def query_segment(self, tid, start, end, strand_code, reverse, dtype):
+        """Counts over ONE segment in ONE call (``pc_query_segment``: no plan object, no upload, no read-back copy)."""
+        out = np.empty(int(end) - int(start), dtype)
+        check(self._lib.pc_query_segment(self._h, int(tid), int(start), int(end), int(strand_code), 1 if reverse else 0,
+                                         OUT_FLOAT64 if dtype == np.float64 else OUT_INT64, out.ctypes.data))
+        return out
+
     def sync(self):
         check(self._lib.pc_sync(self._h))
 

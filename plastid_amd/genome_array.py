@@ -23,6 +23,7 @@ there (no CPU fallback).
 """
 import itertools
 import os
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -496,12 +497,36 @@ class BAMGenomeArray(object):
         if not self._native() or roi.chrom not in self._chr_lengths:
             _, count_array = self.get_reads_and_counts(roi, roi_order=roi_order)
             return count_array
+        if self._one_call_query(roi):
+            # one segment, one call: the window travels in the kernel's arguments, the counts come back through page-locked
+            # memory (pc_query_segment) -- for arrays whose reads cannot make the map function warn (checked once per rule)
+            self._sync_engine([(roi.chrom, roi.start, roi.end, roi.strand)])
+            return self._engine.query_segment(self._chrom_index[roi.chrom], roi.start, roi.end, roi.c_strand,
+                                              roi_order is True and roi.strand == "-", self._out_dtype())
         count_array, plan = self._count_segments([roi], roi_order=roi_order, keep_plan=True)
         self._warn_if_unmappable(plan)
         plan.close()
         if self.map_fn._kind == _lib.MAP_STRAT5:
             count_array = count_array.reshape(self._engine.rows, len(roi))
         return count_array
+
+    #: segments up to this many positions are counted by ``pc_query_segment``
+    ONE_CALL_MAX = 4096
+
+    def _one_call_query(self, roi):
+        if (self._device_only or len(self._packed) != 1 or not 0 < len(roi) <= self.ONE_CALL_MAX or roi.start < 0 or
+                self.map_fn._kind not in (_lib.MAP_FIVE, _lib.MAP_THREE, _lib.MAP_VAR5) or os.environ.get("PC_NO_SINGLE")):
+            return False
+        args = self.map_fn._engine_args()
+        key = (id(self.map_fn), args.get("kind"), args.get("param"))
+        if getattr(self, "_no_warn_key", None) != key:
+            # can any read of the file make this rule emit its DataWarning (an offset beyond the read, a length without an
+            # offset)?  One pass over the aligned lengths, once per rule; if so, queries keep to the plan path, which reports it
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self._no_warn = self.map_fn._direct_warning(self._packed) is None
+            self._no_warn_key = key
+        return self._no_warn
 
     def _count_segments(self, segs, roi_order, keep_plan=False):
         """One launch over independent segments, each laid out like ``get(seg, roi_order)``."""

@@ -1097,7 +1097,62 @@ def test_one_window_plans_count_in_a_single_launch(pa, oracle):
                             for r in range(rows):
                                 exp[off[0] + r * stride[0] + step * np.arange(n)] = a2[r]
                         assert np.array_equal(got["single"][:len(exp)], exp), (mapping, tid, start, end, strand, step)
+                        # the same window in ONE call (pc_query_segment: argument-borne window, counts through page-locked memory)
+                        if step != 0 and mapping[0] != "stratified" and 0 < n <= 4096 and 0 <= start:
+                            for dt in (np.int64, np.float64):
+                                q = eng.query_segment(tid, start, end, strand, step < 0, dt)
+                                assert q.dtype == dt and np.array_equal(q, exp.astype(dt)), (mapping, tid, start, end, strand, step)
                 eng.close()
+    finally:
+        os.environ.pop("PC_NO_SINGLE", None)
+        if saved is not None:
+            os.environ["PC_NO_SINGLE"] = saved
+
+
+def test_single_segment_queries_in_one_call(pa, oracle):
+    """``ga[segment]`` through the mirror: segments of up to 4 096 positions over one file take ``pc_query_segment`` (no
+    plan object); the vectors equal those of the plan path (PC_NO_SINGLE) -- point rules, both strands and '.', roi_order,
+    a size filter, a FLAG / MAPQ filter, normalisation -- and a rule that can warn keeps to the plan path and warns."""
+    from plastid_amd import synth
+    genome, tx, reads, _ = synth.make_config("C2", scale=0.002, tx_scale=0.02)
+    rng = np.random.default_rng(3)
+    reads.flag16 = (np.where(reads.flags & 1, 0x10, 0) | np.where(rng.random(reads.n) < 0.3, 0x100, 0)).astype(np.uint16)
+    reads.mapq = rng.integers(0, 40, reads.n).astype(np.uint8)
+    ga = pa.BAMGenomeArray(reads, mapping=pa.FivePrimeMapFactory(12))
+    segs = [c[0] for c in tx.chains(limit=60)]
+    segs += [pa.GenomicSegment(s.chrom, s.start, s.end, ".") for s in segs[:10]]
+    saved = os.environ.pop("PC_NO_SINGLE", None)
+    try:
+        calls = []
+        real = ga._engine.query_segment
+        ga._engine.query_segment = lambda *a: (calls.append(1), real(*a))[1]
+        for step, setup in enumerate((lambda: None, lambda: ga.set_mapping(pa.ThreePrimeMapFactory(0)),
+                                      lambda: ga.add_filter("size", pa.SizeFilterFactory(27, 32)),
+                                      lambda: ga.add_filter("flags", pa.FlagFilterFactory(exclude="is_secondary", min_mapq=10)),
+                                      lambda: ga.set_normalize(True),
+                                      lambda: ga.set_mapping(pa.VariableFivePrimeMapFactory(synth.VARIABLE_OFFSETS)))):
+            setup()
+            for s_ in segs:
+                for ro in (True, False):
+                    os.environ.pop("PC_NO_SINGLE", None)
+                    n0 = len(calls)
+                    fast = ga.get(s_, roi_order=ro)
+                    assert len(calls) == n0 + 1 or len(s_) > 4096
+                    os.environ["PC_NO_SINGLE"] = "1"
+                    slow = ga.get(s_, roi_order=ro)
+                    assert fast.dtype == slow.dtype and np.array_equal(np.asarray(fast).view(np.uint64), np.asarray(slow).view(np.uint64)), (step, s_)
+        assert sum(int(np.asarray(ga[s_]).sum() > 0) for s_ in segs) > 20
+        # a rule that can warn (offset beyond the shortest reads) keeps to the plan path and warns as ever
+        os.environ.pop("PC_NO_SINGLE", None)
+        ga.set_normalize(False)
+        ga.set_mapping(pa.FivePrimeMapFactory(int(reads.alen.max())))
+        n0 = len(calls)
+        dense = max(segs, key=lambda s_: np.asarray(ga.get(s_)).size)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for s_ in segs:
+                ga[s_]
+        assert len(calls) == n0 and any(issubclass(x.category, UserWarning) for x in w) and dense is not None
     finally:
         os.environ.pop("PC_NO_SINGLE", None)
         if saved is not None:
