@@ -919,6 +919,7 @@ def main():
     ap.add_argument("--time-budget", type=float, default=1200.0, help="seconds after which no further config is started")
     ap.add_argument("--e2e-records", type=float, default=1e8, help="records of the BAM file of the e2e scope, at most the whole configuration (0: skip)")
     ap.add_argument("--detail-out", default=None, help="where the full result (prose included) goes; default bench_detail.json beside bench.py")
+    ap.add_argument("--no-single-query", action="store_true", help="skip the single-query latency loop (profiling passes: it launches the tile kernel hundreds of times)")
     ap.add_argument("--e2e-realistic-records", type=float, default=1e8,
                     help="records of the second e2e sample, written as an aligner writes them (~120 bytes per record; 0: skip)")
     args = ap.parse_args()
@@ -985,7 +986,7 @@ def main():
     plan.close()
     eng.close()
     single_query = None
-    if rank == 0 and world == 1 and not rehearsal:
+    if rank == 0 and world == 1 and not rehearsal and not args.no_single_query:
         try:   # (the headline's own records, staged once more by the mirror's own engine)
             single_query = single_query_latency(_reads, ctx["last_annotation"], dev_index)
         except Exception as e:   # a diagnostic must not cost the bench line

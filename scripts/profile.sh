@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 export PC_SYNTH_CACHE=/tmp/pc_synth_cache
 cd /tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --other-configs none --e2e-records 0 --e2e-realistic-records 0 $@"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --other-configs none --e2e-records 0 --e2e-realistic-records 0 --no-single-query $@"
 python3 $R/bench.py $ARGS > $OUT/bench_line.json 2> $OUT/bench.log     # un-profiled line of the same command (fills the cache)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $OUT/pmc_sq1 -o pmc --output-format csv -- python3 $R/bench.py $ARGS > $OUT/pmc_sq1.log 2>&1
