@@ -2738,93 +2738,12 @@ __global__ __launch_bounds__(kWG) void k_run_lin(const unsigned long long *__res
     rlin[g] = (uint32_t)lo;
 }
 
-// staging: the number of runs a multi-run record keeps in blk (for the prefix sum that gives every record its
-// first run) -- a function of the uploaded 8-byte record
-__global__ __launch_bounds__(kWG) void k_run_counts(const uint2 *__restrict__ rec, int64_t n, uint32_t *nruns,
-                                                    const uint32_t *__restrict__ wide_rec, const uint2 *__restrict__ wide_val, int64_t nwide) {
-    const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
-    if (i >= n) return;
-    const uint2 r = rec[i];
-    uint32_t nb = r.y >> 24;
-    if ((r.y >> 16) & kFlagWide) {   // a wide record: its true run count is in the side table
-        int64_t lo = 0, hi = nwide;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((int64_t)wide_rec[mid] < i) lo = mid + 1; else hi = mid;
-        }
-        nb = wide_val[lo].y;
-    }
-    nruns[i] = nb >= 2u ? nb : 0u;
-}
-
-// staging: the class of every record that depends on the statistics of the whole file -- kFlagLong when its span
-// (pos .. end of the last aligned run) is beyond the window halo `wcap`, always for a wide record -- written into the
-// header, and the 4-byte stream word that follows from the header
-__global__ __launch_bounds__(kWG) void k_classify(uint2 *rec, int64_t n, const uint32_t *__restrict__ blk_off, const int2 *__restrict__ blk,
-                                                  int wcap, uint32_t *stream) {
-    const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
-    if (i >= n) return;
-    uint2 r = rec[i];
-    const uint32_t L = r.y & 0xffffu, fl = (r.y >> 16) & 0xffu, nb = r.y >> 24;
-    bool far = (fl & kFlagWide) != 0u;
-    if (!far) {
-        int64_t span = L > 0u ? (int64_t)L : 1;
-        if (nb >= 2u) {
-            const int2 last = blk[blk_off[i] + nb - 1u];
-            span = (int64_t)last.x + last.y - (int64_t)(int32_t)r.x;
-        }
-        far = span > (int64_t)wcap;
-    }
-    if (far) {
-        r.y |= kFlagLong << 16;
-        rec[i].y = r.y;
-    }
-    stream[i] = stream_word(r.x, r.y);
-}
-
 // ---------------------------------------------------------------- side lists, built on the GPU
 // The gapped-record, long-span and long-span-outside-the-run-stream lists of a staged file are compactions of its
-// records (the class of a record is written in its header by the host pack pass), so they are made where the
-// records already are: the members are selected in record order (hipcub::DeviceSelect over a counting iterator with
-// the predicates below), k_side_fill writes their entries, an inclusive max-scan of (contig << 32 | end) gives the
-// running maximum of the ends per contig, k_list_bounds the per-contig ranges and k_lin_table the linear-index tables.
-struct SelectLong {      // span beyond the window halo (or a wide record): the long-span list
-    const uint2 *rec;
-    __device__ bool operator()(uint32_t i) const { return ((rec[i].y >> 16) & kFlagLong) != 0u; }
-};
-struct SelectXLong {     // ... whose runs are not in the run stream: what the point rules still walk
-    const uint2 *rec;
-    __device__ bool operator()(uint32_t i) const {
-        const uint32_t fl = rec[i].y >> 16;
-        return (fl & kFlagLong) != 0u && (fl & kFlagRuns) == 0u;
-    }
-};
-struct SelectGap {       // several runs or longer than the stream carries, inside the halo, not in the run stream
-    const uint2 *rec;
-    __device__ bool operator()(uint32_t i) const {
-        const uint32_t meta = rec[i].y, fl = meta >> 16;
-        return (fl & (kFlagLong | kFlagRuns)) == 0u && ((meta >> 24) >= 2u || (meta & 0xffffu) > (uint32_t)kStreamMaxLen);
-    }
-};
-
-// members of each list (long-span, gapped, long-span outside the run stream): sizes the lists before they are selected
-__global__ __launch_bounds__(kWG) void k_side_count(const uint2 *__restrict__ rec, int64_t n, uint32_t *counts) {
-    const SelectLong sl{rec};
-    const SelectGap sg{rec};
-    const SelectXLong sx{rec};
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
-    const int64_t base = (int64_t)blockIdx.x * kWG * 16;
-    for (int u = 0; u < 16; ++u) {
-        const int64_t i = base + (int64_t)u * kWG + threadIdx.x;
-        if (i < n) { c0 += sl((uint32_t)i); c1 += sg((uint32_t)i); c2 += sx((uint32_t)i); }
-    }
-    for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_down(c0, o, 64); c1 += __shfl_down(c1, o, 64); c2 += __shfl_down(c2, o, 64); }
-    if ((threadIdx.x & 63) == 0) {
-        if (c0) atomicAdd(&counts[0], c0);
-        if (c1) atomicAdd(&counts[1], c1);
-        if (c2) atomicAdd(&counts[2], c2);
-    }
-}
+// records (the class of a record is in its header), so they are made where the records already are: the members are
+// selected in record order (stage_kernels.hip.h: k_classify counts them per workgroup, k_side_select writes their record
+// indices), k_side_fill writes their entries, an inclusive max-scan of (contig << 32 | end) gives the running maximum
+// of the ends per contig, k_list_bounds the per-contig ranges and k_lin_table the linear-index tables.
 
 // aligned runs of the multi-run records as {start, length} pairs, from the caller's two arrays
 __global__ __launch_bounds__(kWG) void k_zip_runs(const int32_t *__restrict__ start, const int32_t *__restrict__ len, int64_t n, int2 *blk) {

@@ -8,9 +8,11 @@
 // Host-side structure, in file order:
 //   DevPool / DevBuf / PinnedBuf   device blocks recycled per engine, one page-locked buffer: a plan of
 //                                  one short segment costs API calls, not bytes
-//   pc_add_alignment_file          staging: pass A validates and fixes the halo W; pass B packs the
-//                                  records slice by slice while the previous slice crosses PCIe; side
-//                                  lists and linear-index tables on the same threads
+//   UploadRing / scan_contigs      the caller's columns cross PCIe through a ring of page-locked pieces; the
+//                                  contig column stays on the host and becomes ntid + 1 record bounds
+//   pc_add_alignment_file          staging: columns to HBM, then kernels only (stage_kernels.hip.h: validation,
+//                                  8-byte records, run stream, statistics; pc_kernels.hip.h: record stream,
+//                                  side lists, linear-index tables)
 //   pc_plan_create                 segments -> islands -> windows -> output pieces, all tables of a
 //                                  plan in one device block
 //   pc_count                       k_tile_ranges -> k_hist_point (two classes, two streams) ->
@@ -72,6 +74,46 @@ int fail(int code, const char *fmt, ...) {
                         #expr, hipGetErrorString(err__), __FILE__, __LINE__);                      \
     } while (0)
 
+// Large device blocks that outlive their engine: an engine that goes away hands the idle large blocks of its pool to
+// this process-wide reservoir (per device, by rounded size) instead of freeing them, and the pool of a later engine looks
+// here before it allocates.  Engines come and go -- one per BAMGenomeArray, one per config in bench.py -- and on some
+// boxes of the pool a hipMalloc that follows the hipFree of tens of GB takes SECONDS (measured round 5: 1.5 s and 2.1 s
+// for the first large buffer of a staging call right after an engine of the same size was destroyed; milliseconds when
+// nothing had been freed).  Only blocks of a destroyed engine get here -- its streams are drained by then, so nothing
+// is in flight on them.  PC_POOL_RESERVOIR_GB caps what is kept (default 96; 0: keep nothing).
+struct BigReservoir {
+    std::mutex m;
+    std::map<size_t, std::vector<void *>> big[16];
+    size_t cached[16] = {};
+    size_t limit = (size_t)96 << 30;
+    BigReservoir() { if (const char *env = getenv("PC_POOL_RESERVOIR_GB")) limit = (size_t)std::max(0ll, atoll(env)) << 30; }
+    static BigReservoir &get() { static BigReservoir *r = new BigReservoir; return *r; }   // (never destroyed: no hipFree during static destruction)
+    void *take(int device, size_t rounded) {
+        std::lock_guard<std::mutex> g(m);
+        auto &b = big[device & 15];
+        auto it = b.find(rounded);
+        if (it == b.end() || it->second.empty()) return nullptr;
+        void *p = it->second.back();
+        it->second.pop_back();
+        cached[device & 15] -= rounded;
+        return p;
+    }
+    bool give(int device, void *p, size_t rounded) {
+        std::lock_guard<std::mutex> g(m);
+        if (cached[device & 15] + rounded > limit) return false;
+        big[device & 15][rounded].push_back(p);
+        cached[device & 15] += rounded;
+        return true;
+    }
+    void free_all(int device) {   // (an allocation failed: what is kept here may be what is missing)
+        std::lock_guard<std::mutex> g(m);
+        for (auto &kv : big[device & 15])
+            for (void *p : kv.second) (void)hipFree(p);
+        big[device & 15].clear();
+        cached[device & 15] = 0;
+    }
+};
+
 // Per-engine cache of small device blocks.  A plan of one short segment is otherwise dominated by
 // hipMalloc / hipFree (the latter synchronises the device): blocks up to 32 MiB are kept by
 // power-of-two size class when a plan lets go of them and handed to the next one.  Every user of
@@ -89,6 +131,7 @@ struct DevPool {
     size_t cached = 0;
     std::map<size_t, std::vector<void *>> big;
     size_t big_cached = 0;
+    int device = 0;
     static int size_class(size_t bytes) {
         int c = 0;
         while (c < kClasses && ((size_t)1 << (kMinShift + c)) < bytes) ++c;
@@ -116,13 +159,17 @@ struct DevPool {
         return true;
     }
     void *big_take(size_t rounded) {
-        std::lock_guard<std::mutex> g(m);
-        auto it = big.find(rounded);
-        if (it == big.end() || it->second.empty()) return nullptr;
-        void *p = it->second.back();
-        it->second.pop_back();
-        big_cached -= rounded;
-        return p;
+        {
+            std::lock_guard<std::mutex> g(m);
+            auto it = big.find(rounded);
+            if (it != big.end() && !it->second.empty()) {
+                void *p = it->second.back();
+                it->second.pop_back();
+                big_cached -= rounded;
+                return p;
+            }
+        }
+        return BigReservoir::get().take(device, rounded);
     }
     bool big_give(void *p, size_t rounded) {
         std::lock_guard<std::mutex> g(m);
@@ -131,7 +178,8 @@ struct DevPool {
         big_cached += rounded;
         return true;
     }
-    void drain() {
+    // keep_big: the engine is going away with its streams drained -- the large blocks go to the process-wide reservoir
+    void drain(bool keep_big) {
         std::lock_guard<std::mutex> g(m);
         for (auto &b : bins) {
             for (void *p : b) (void)hipFree(p);
@@ -139,11 +187,13 @@ struct DevPool {
         }
         cached = 0;
         for (auto &kv : big)
-            for (void *p : kv.second) (void)hipFree(p);
+            for (void *p : kv.second)
+                if (!keep_big || !BigReservoir::get().give(device, p, kv.first)) (void)hipFree(p);
         big.clear();
         big_cached = 0;
+        if (!keep_big) BigReservoir::get().free_all(device);
     }
-    ~DevPool() { drain(); }
+    ~DevPool() { drain(true); }
 };
 
 // The pool a DevBuf without one of its own takes its blocks from: set for the duration of an entry point that
@@ -195,7 +245,7 @@ template <typename T> struct DevBuf {
             void *q = pool->big_take(rounded);
             if (!q && hipMalloc(&q, rounded) != hipSuccess) {
                 (void)hipGetLastError();
-                pool->drain();   // (what the pool holds may be what is missing)
+                pool->drain(false);   // (what the pool and the reservoir hold may be what is missing)
                 HIP_TRY(hipMalloc(&q, rounded));
             }
             p = (T *)q;
@@ -241,30 +291,143 @@ template <typename T> struct DevView {
     T *p = nullptr;
 };
 
-// Host staging buffer that is NOT value-initialised: the worker threads of the staging pass are the
-// first to touch their slice (page faults spread over the threads instead of one memset).
-template <typename T> struct HostBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    // Large buffers ask for transparent huge pages: 512x fewer first-touch faults in the worker
-    // threads and a free() that does not take longer than the staging pass itself.
-    static T *grab(size_t count) {
-        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T), huge = (size_t)2 << 20;
-        if (bytes < 4 * huge) return (T *)malloc(bytes);
-        void *q = nullptr;
-        if (posix_memalign(&q, huge, (bytes + huge - 1) / huge * huge) != 0) return nullptr;
-        (void)madvise(q, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
-        return (T *)q;
+// Caller-owned (pageable) host arrays <-> HBM at the rate of the PCIe link.  hipMemcpy to or from pageable memory pins
+// the pages on the fly, on one thread inside the driver: 25 GB/s for memory the runtime has not seen before, whatever
+// the number of calling threads or streams (scripts/ubench/upload_probe.hip; 57 GB/s from page-locked memory on the
+// same box).  Here a few host threads move pieces of the arrays through a ring of page-locked slots, each piece with a
+// DMA of its own: 53 - 55 GB/s.  Up: a thread takes the next piece, waits until its slot's previous piece has landed,
+// copies the piece into the slot and queues the DMA.  Down: it queues the DMA into the slot, waits for it and copies the
+// piece out.  Pieces are taken in order and there are more slots than threads, so nobody waits on a piece that has not
+// been taken.
+struct UploadJob { void *dst; const void *src; size_t bytes; };
+struct UploadRing {
+    static constexpr int kSlots = 8, kThreads = 6;
+    static constexpr size_t kPiece = (size_t)16 << 20;
+    uint8_t *slot[kSlots] = {};
+    hipEvent_t ev[kSlots] = {};
+    hipStream_t stream = nullptr;
+    std::mutex busy;   // one transfer at a time per device
+    // One ring per device for the life of the process: page-locking its 128 MB costs as much as staging ten million
+    // records, and engines come and go (one per BAMGenomeArray).
+    static UploadRing &of(int device) {
+        static UploadRing rings[16];
+        return rings[device & 15];
     }
-    explicit HostBuf(size_t count) : p(grab(count)), n(count) {}
-    ~HostBuf() { free(p); }
-    void release() { free(p); p = nullptr; n = 0; }
-    HostBuf(const HostBuf &) = delete;
-    HostBuf &operator=(const HostBuf &) = delete;
-    T &operator[](size_t i) { return p[i]; }
-    const T &operator[](size_t i) const { return p[i]; }
+    // every job has landed when this returns; `down`: dst is host memory, src device memory.
+    // Small transfers take the runtime's own path (`always`: the ring whatever the size)
+    int run(int device, const std::vector<UploadJob> &jobs, size_t piece, bool always, bool down = false) {
+        std::lock_guard<std::mutex> one(busy);
+        HIP_TRY(hipSetDevice(device));
+        if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        size_t total = 0;
+        for (const auto &j : jobs) total += j.bytes;
+        if (total == 0) return PC_OK;
+        const hipMemcpyKind kind = down ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+        if (total < 4 * kPiece && !always) {
+            for (const auto &j : jobs)
+                if (j.bytes) HIP_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, kind, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            return PC_OK;
+        }
+        piece = std::max<size_t>(1, std::min(piece, kPiece));
+        for (int k = 0; k < kSlots; ++k) {
+            if (!slot[k]) HIP_TRY(hipHostMalloc((void **)&slot[k], kPiece, hipHostMallocDefault));
+            if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        std::vector<UploadJob> pieces;
+        for (const auto &j : jobs)
+            for (size_t off = 0; off < j.bytes; off += piece)
+                pieces.push_back({(uint8_t *)j.dst + off, (const uint8_t *)j.src + off, std::min(piece, j.bytes - off)});
+        const size_t np = pieces.size();
+        std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[np]);   // up: DMA queued; down: copied out
+        for (size_t k = 0; k < np; ++k) done[k].store(0, std::memory_order_relaxed);
+        std::atomic<size_t> next{0};
+        std::atomic<int> failed{0};
+        std::mutex order;   // DMA and event of a piece are queued together
+        auto work = [&]() {
+            if (hipSetDevice(device) != hipSuccess) failed.store(1);
+            for (;;) {
+                const size_t p = next.fetch_add(1);
+                if (p >= np) return;
+                const int k = (int)(p % kSlots);
+                if (p >= (size_t)kSlots) {   // the slot's previous piece
+                    while (!done[p - kSlots].load(std::memory_order_acquire)) std::this_thread::yield();
+                    if (!down && !failed.load() && hipEventSynchronize(ev[k]) != hipSuccess) failed.store(1);
+                }
+                if (!failed.load()) {
+                    if (!down) std::memcpy(slot[k], pieces[p].src, pieces[p].bytes);
+                    {
+                        std::lock_guard<std::mutex> lk(order);
+                        if (hipMemcpyAsync(down ? (void *)slot[k] : pieces[p].dst, down ? pieces[p].src : (const void *)slot[k], pieces[p].bytes, kind, stream) != hipSuccess ||
+                            hipEventRecord(ev[k], stream) != hipSuccess)
+                            failed.store(1);
+                    }
+                    if (down && !failed.load()) {
+                        if (hipEventSynchronize(ev[k]) != hipSuccess) failed.store(1);
+                        else std::memcpy(pieces[p].dst, slot[k], pieces[p].bytes);
+                    }
+                }
+                done[p].store(1, std::memory_order_release);   // (also after a failure: whoever waits for this slot goes on and ends)
+            }
+        };
+        int T = kThreads;
+        if (const char *env = getenv("PC_STAGE_UPLOAD_THREADS")) T = std::max(1, std::min(kSlots - 1, atoi(env)));
+        T = (int)std::min<size_t>((size_t)T, np);
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+        const hipError_t he = hipStreamSynchronize(stream);
+        if (failed.load() || he != hipSuccess) { (void)hipGetLastError(); return fail(PC_ERR_HIP, "transfer ring: a copy failed"); }
+        return PC_OK;
+    }
 };
 
+// The contig column of caller-owned records, examined where it is: `bounds[t]` = first record of contig t (t = 0 ..
+// ntid) and, returned, the first record whose contig is out of range or lower than its predecessor's (n: none; the
+// bounds then describe the records before it).  Sorted, the column changes value at most ntid times: the pass is a
+// streaming comparison of neighbours, and only a block that holds a change is looked at record by record.
+static int64_t scan_contigs(const int32_t *tid, int64_t n, int32_t ntid, int threads, std::vector<int64_t> &bounds) {
+    bounds.assign((size_t)ntid + 1, 0);
+    if (n <= 0) return 0;
+    struct Part { std::vector<std::pair<int64_t, int32_t>> changes; int64_t bad = INT64_MAX; };
+    const int T = std::max(1, threads);
+    std::vector<Part> parts((size_t)T);
+    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
+        Part &pt = parts[(size_t)t];
+        int64_t i = b;
+        if (i == 0 && i < en) {
+            if ((uint32_t)tid[0] >= (uint32_t)ntid) { pt.bad = 0; return; }
+            pt.changes.emplace_back(0, tid[0]);
+            i = 1;
+        }
+        constexpr int64_t kBlock = 4096;
+        while (i < en) {
+            const int64_t e2 = std::min(en, i + kBlock);
+            uint32_t diff = 0;
+            for (int64_t j = i; j < e2; ++j) diff |= (uint32_t)(tid[j] ^ tid[j - 1]);
+            if (diff)
+                for (int64_t j = i; j < e2; ++j)
+                    if (tid[j] != tid[j - 1]) {
+                        if (tid[j] < tid[j - 1] || tid[j] < 0 || tid[j] >= ntid) { pt.bad = j; return; }
+                        pt.changes.emplace_back(j, tid[j]);
+                    }
+            i = e2;
+        }
+    });
+    int64_t bad = INT64_MAX;
+    for (const auto &pt : parts) bad = std::min(bad, pt.bad);
+    const int64_t n_ok = std::min(n, bad);
+    int32_t last = -1;   // bounds are written up to this contig
+    for (const auto &pt : parts)
+        for (const auto &c : pt.changes) {
+            if (c.first >= n_ok) break;
+            for (int32_t t = last + 1; t <= c.second; ++t) bounds[(size_t)t] = c.first;
+            last = c.second;
+        }
+    for (int32_t t = last + 1; t <= ntid; ++t) bounds[(size_t)t] = n_ok;
+    return n_ok;
+}
 
 // CPUs this process may actually use: the smaller of the hardware threads, the affinity mask and the
 // container's CFS quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  Pools sized beyond the quota only
@@ -1097,6 +1260,7 @@ int pc_create(int device, pc_engine **out) {
     HIP_TRY(hipSetDevice(device));
     pc_engine *e = new pc_engine();
     e->device = device;
+    e->pool.device = device;
     e->knobs.load();
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
@@ -1244,7 +1408,7 @@ int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *
 }
 
 // `dev`: the columns are in HBM already (a BAM file decoded on the GPU, pc_add_alignment_bam): the host pointers of the
-// columns and runs are then NULL and the one host pass below is replaced by kernels (stage_kernels.hip.h); the wide
+// columns and runs are then NULL and nothing is uploaded or validated (the decoder did that); the wide
 // side arrays come from the host either way.
 static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid, const int32_t *pos,
                       const uint16_t *alen, const uint8_t *flags, const uint8_t *nblk, int64_t nrun,
@@ -1274,13 +1438,6 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
         if (wide_alen[k] < 0 || wide_nblk[k] < 0 || (wide_nblk[k] == 0) != (wide_alen[k] == 0) || wide_nblk[k] > wide_alen[k])
             return fail(PC_ERR_ARG, "pc_add_alignment_file: record %lld: bad wide alen / nblk", (long long)i);
     }
-    // true aligned length / run count of record i (wide records keep them in the side arrays)
-    auto wide_at = [&](int64_t i) -> int64_t {
-        if (n_wide == 0 || alen[i] != 0xffffu || nblk[i] != 0xffu) return -1;
-        const int64_t *q = std::lower_bound(wide_idx, wide_idx + n_wide, i);
-        return (q != wide_idx + n_wide && *q == i) ? (int64_t)(q - wide_idx) : -1;
-    };
-    auto NB = [&](int64_t i) -> int64_t { const int64_t w = wide_at(i); return w >= 0 ? (int64_t)wide_nblk[w] : (int64_t)nblk[i]; };
     if (n >= (int64_t)0x7fffffff || nrun >= (int64_t)0xffffffffu)
         return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 records per file are not supported");
     if (!e->files.empty() && ntid != e->ntid)
@@ -1288,377 +1445,196 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
     HIP_TRY(hipSetDevice(e->device));
     PoolScope pool_scope(&e->pool);   // the file's arrays and the temporaries of staging are recycled through the engine's pool
 
-    // the caller's run arrays go up on a thread of their own while the records are validated and packed (the GPU
-    // zips them into {start, length} pairs and builds the side lists from them)
-    DevBuf<int32_t> d_bs, d_bl;
-    struct Joined { std::future<int> f; ~Joined() { if (f.valid()) f.wait(); } } runs_up;   // (joined on every way out, before the buffers go)
-    if (nrun > 0 && dev) {
-        int r = d_bs.reserve((size_t)nrun);
-        if (r == PC_OK) r = d_bl.reserve((size_t)nrun);
-        if (r != PC_OK) return r;
-        HIP_TRY(hipMemcpyAsync(d_bs.p, dev->blk_start, (size_t)nrun * 4, hipMemcpyDeviceToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(d_bl.p, dev->blk_len, (size_t)nrun * 4, hipMemcpyDeviceToDevice, e->stream));
-    } else if (nrun > 0) {
+    hipStream_t st = e->stream;
+    StageClock clk;
+
+    // ---- caller-owned columns: up to HBM as they are.  The host moves bytes and looks at ONE column, the contigs: sorted,
+    // that column is ntid + 1 record bounds, so it does not travel -- a streaming comparison finds the bounds (and the first
+    // record out of order or out of range) on the worker threads while the other columns cross PCIe through the ring.
+    const bool host_cols = dev == nullptr;
+    DevBuf<int32_t> d_pos, d_bs, d_bl;
+    DevBuf<uint16_t> d_alen;
+    DevBuf<uint8_t> d_flags8, d_nblk8;
+    DevBuf<uint32_t> d_wr;
+    DevBuf<uint2> d_wv;
+    pcstage::DevCols hc;
+    std::vector<int64_t> tid_bounds((size_t)ntid + 1, 0);
+    int64_t n_ok = n;   // records before the first defect of the contig column
+    if (host_cols) {
+        int rc = d_pos.reserve((size_t)n + 1);
+        if (rc == PC_OK) rc = d_alen.reserve((size_t)n + 1);
+        if (rc == PC_OK) rc = d_flags8.reserve((size_t)n + 1);
+        if (rc == PC_OK) rc = d_nblk8.reserve((size_t)n + 1);
+        if (rc == PC_OK) rc = d_bs.reserve((size_t)nrun + 1);
+        if (rc == PC_OK) rc = d_bl.reserve((size_t)nrun + 1);
+        if (rc != PC_OK) return rc;
+        size_t piece = UploadRing::kPiece;
+        if (const char *env = getenv("PC_STAGE_SLICE")) piece = (size_t)std::max<int64_t>(1, std::min<int64_t>(atoll(env), (int64_t)(UploadRing::kPiece / 4))) * 4; // test knob: tiny pieces
+        std::vector<UploadJob> jobs;   // (what the first kernel reads goes first)
+        jobs.push_back({d_nblk8.p, nblk, (size_t)n});
+        jobs.push_back({d_alen.p, alen, (size_t)n * 2});
+        jobs.push_back({d_pos.p, pos, (size_t)n * 4});
+        jobs.push_back({d_flags8.p, flags, (size_t)n});
+        jobs.push_back({d_bs.p, blk_start, (size_t)nrun * 4});
+        jobs.push_back({d_bl.p, blk_len, (size_t)nrun * 4});
+        struct Joined { std::future<int> f; ~Joined() { if (f.valid()) f.wait(); } } up;   // (joined on every way out, before the buffers go)
+        clk.lap("column buffers");
         const int devno = e->device;
-        hipStream_t s = e->stream;
-        runs_up.f = std::async(std::launch::async, [&d_bs, &d_bl, blk_start, blk_len, nrun, devno, s]() -> int {
-            if (hipSetDevice(devno) != hipSuccess) return PC_ERR_HIP;
-            int r = d_bs.upload(blk_start, (size_t)nrun, s);
-            if (r == PC_OK) r = d_bl.upload(blk_len, (size_t)nrun, s);
-            if (r == PC_OK && hipStreamSynchronize(s) != hipSuccess) r = PC_ERR_HIP;
+        up.f = std::async(std::launch::async, [devno, &jobs, piece]() -> int {
+            StageClock uclk;
+            const int r = UploadRing::of(devno).run(devno, jobs, piece, getenv("PC_STAGE_SLICE") != nullptr);
+            uclk.lap("  (upload thread: ring)");
             return r;
         });
+        n_ok = scan_contigs(tid, n, ntid, stage_threads(n), tid_bounds);
+        clk.lap("contig bounds");
+        if (n_wide > 0) {
+            std::vector<uint32_t> wr((size_t)n_wide);
+            std::vector<uint2> wv((size_t)n_wide);
+            for (int64_t k = 0; k < n_wide; ++k) { wr[(size_t)k] = (uint32_t)wide_idx[k]; wv[(size_t)k] = make_uint2((uint32_t)wide_alen[k], (uint32_t)wide_nblk[k]); }
+            rc = d_wr.upload(wr, st);
+            if (rc == PC_OK) rc = d_wv.upload(wv, st);
+            if (rc == PC_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: uploading the wide records failed");
+        }
+        const int urc = up.f.get();
+        if (rc != PC_OK) return rc;
+        if (urc != PC_OK) return fail(urc, "pc_add_alignment_file: uploading the columns failed");
+        hc.tid = nullptr; hc.pos = d_pos.p; hc.alen = d_alen.p; hc.flags = d_flags8.p; hc.nblk = d_nblk8.p;
+        hc.blk_start = d_bs.p; hc.blk_len = d_bl.p;
+        hc.wide_rec = d_wr.p; hc.wide_val = d_wv.p; hc.n_wide = n_wide;
+        dev = &hc;
+        clk.lap("columns to HBM");
     }
-
-    StageClock clk;
-    // ---- ONE host pass over the caller's arrays: validation, statistics (per-contig bounds, span and length
-    // histograms) and the packed 8-byte records, slice by slice into two sets of reusable host buffers; a slice crosses
-    // PCIe (on a thread of its own) while the next one is packed, so the host never holds more than two slices.
-    // What depends on the statistics of the WHOLE file -- the window halo `wcap` (a span quantile) and with it the
-    // long-span class of a record and its stream word -- is derived on the GPU afterwards (k_classify).
-    // Every thread keeps its own running statistics; the error reported is the one of the lowest record index of the
-    // first slice that has one, so the outcome does not depend on the thread count.
-    const int T = stage_threads(n);
-    struct ChunkErr { int64_t idx = INT64_MAX; int code = PC_OK; char msg[200] = {0}; };
-    struct Acc {
-        ChunkErr err;
-        std::vector<int64_t> tid_count, span_hist, gap_span_hist, wide_span_hist, len_hist, len1_hist, tid_end;
-        int Wr = 1, rmin = 65536, rmax = -1;
-        int64_t max_span = 1;
+    // the first defect of the contig column, as the message the caller sees (unless a record before it has one of its own)
+    auto contig_defect = [&]() -> int {
+        const int64_t i = n_ok;
+        if (tid[i] < 0 || tid[i] >= ntid) return fail(PC_ERR_ARG, "record %lld: tid %lld out of range", (long long)i, (long long)tid[i]);
+        if (pos[i] < 0) return fail(PC_ERR_ARG, "record %lld: negative position", (long long)i);
+        return fail(PC_ERR_UNSORTED, "records are not sorted by (tid, pos) at record %lld; alignment files must be coordinate sorted", (long long)i);
     };
-    std::vector<Acc> acc((size_t)T);
-    for (auto &a : acc) {
-        a.tid_count.assign((size_t)ntid + 1, 0);
-        a.span_hist.assign(1026, 0);      // spans 0..1024, [1025] = larger
-        a.gap_span_hist.assign(1026, 0);  // ... of the records longer than the stream carries (gapped-record list unless long-span)
-        a.wide_span_hist.assign(1026, 0); // ... of the wide records (long-span whatever their span)
-        a.len_hist.assign(65536, 0);
-        a.len1_hist.assign(256, 0);       // aligned lengths of the single-run records the 4-byte stream can carry
-        a.tid_end.assign((size_t)ntid, 0);
-    }
-    std::vector<int64_t> tid_bounds((size_t)ntid + 1, 0);
 
-    int64_t S = (int64_t)8 << 20;
-    if (const char *env = getenv("PC_STAGE_SLICE")) S = std::max<int64_t>(1, atoll(env)); // test knob: tiny slices
-    const int64_t nslices = (n + S - 1) / S;
-    struct Unit { // one thread's share of one slice
-        int64_t cursor = 0;                        // where this unit's first run sits in blk_*
-        int64_t run_at = 0;                        // where this unit's run-stream records go
-    };
-    std::vector<Unit> units((size_t)(nslices * T));
+    StagedFile *sf = new StagedFile();
+    struct Owner { StagedFile *p; ~Owner() { delete p; } } owner{sf};   // (until the file is the engine's)
+    sf->n = n;
+    sf->nrun = nrun;
+
+    // ---- where the runs of every record sit in the run arrays (blk_off, kept with the file) / go in the run stream: two
+    // exclusive sums
+    DevBuf<uint32_t> d_run_at;
     int64_t nrunrec_total = 0;
-    auto unit_range = [&](int64_t sl, int t, int64_t &b, int64_t &en) {
-        const int64_t s0 = sl * S, s1 = std::min(n, s0 + S), q = (s1 - s0 + T - 1) / T;
-        b = std::min(s1, s0 + (int64_t)t * q);
-        en = std::min(s1, b + q);
-    };
-    DevBuf<uint32_t> d_cursor, d_run_at;   // (device columns) where the runs of every record sit in the run arrays / go in the run stream
-    if (dev) {
+    {
         using namespace pcstage;
-        hipStream_t st = e->stream;
         DevBuf<uint8_t> d_tmp;
-        int r = d_cursor.reserve((size_t)n + 1);
+        DevBuf<unsigned long long> d_tot;
+        int r = sf->blk_off.reserve((size_t)n + 1);
         if (r == PC_OK) r = d_run_at.reserve((size_t)n + 1);
+        if (r == PC_OK) r = d_tot.reserve(2);
         size_t tb = 0;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_cursor.p, d_cursor.p, (int)n + 1, st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_run_at.p, d_run_at.p, (int)n + 1, st));
         if (r == PC_OK) r = d_tmp.reserve(std::max<size_t>(tb, 16));
         if (r != PC_OK) return r;
-        hipLaunchKernelGGL(k_cols_runs, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, *dev, n, d_cursor.p, d_run_at.p);
+        HIP_TRY(hipMemsetAsync(d_tot.p, 0, 16, st));
+        hipLaunchKernelGGL(k_cols_runs, dim3((unsigned)std::min<int64_t>((n + 256) / 256, 4096)), dim3(256), 0, st, *dev, n, sf->blk_off.p, d_run_at.p, d_tot.p);
         size_t b2 = tb;
-        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, b2, d_cursor.p, d_cursor.p, (int)n + 1, st));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, b2, sf->blk_off.p, sf->blk_off.p, (int)n + 1, st));
         b2 = tb;
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, b2, d_run_at.p, d_run_at.p, (int)n + 1, st));
-        uint32_t tot[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(&tot[0], d_cursor.p + n, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&tot[1], d_run_at.p + n, 4, hipMemcpyDeviceToHost, st));
+        unsigned long long tot[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(tot, d_tot.p, 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));   // (d_tmp goes out of scope)
-        nrunrec_total = tot[1];
         if ((int64_t)tot[0] != nrun)
             return fail(PC_ERR_ARG, (int64_t)tot[0] > nrun ? "run arrays shorter than sum of nblk" : "run arrays longer than sum of nblk (%lld vs %lld)",
                         (long long)tot[0], (long long)nrun);
-    } else {   // runs owned by each unit (records with >= 2 runs keep theirs in blk_*), so that a unit knows where its first run sits
-        parallel_chunks(nslices * T, T, [&](int, int64_t ub, int64_t ue) {
-            for (int64_t u = ub; u < ue; ++u) {
-                int64_t b, en, r = 0, rs = 0;
-                unit_range(u / T, (int)(u % T), b, en);
-                for (int64_t i = b; i < en; ++i) {
-                    if (i + 8 <= en) {   // eight single-run records hold no run to place
-                        uint64_t eight;
-                        std::memcpy(&eight, nblk + i, 8);
-                        if (((eight & 0xfefefefefefefefeull) == 0)) { i += 7; continue; }   // every count is 0 or 1
-                    }
-                    const int64_t nbi = nblk[i] >= 2 ? NB(i) : nblk[i];
-                    r += nbi >= 2 ? nbi : 0;
-                    rs += (nbi >= 2 && alen[i] <= kStreamMaxLen) ? nbi : 0;   // runs that go to the run stream (never wide: those carry alen 65535)
-                }
-                units[(size_t)u].cursor = r;
-                units[(size_t)u].run_at = rs;
-            }
-        });
-        int64_t cur = 0, rcur = 0;
-        for (auto &u : units) {
-            const int64_t r = u.cursor; u.cursor = cur; cur += r;
-            const int64_t q = u.run_at; u.run_at = rcur; rcur += q;
-        }
-        nrunrec_total = rcur;
-        if (cur != nrun)
-            return fail(PC_ERR_ARG, cur > nrun ? "run arrays shorter than sum of nblk" : "run arrays longer than sum of nblk (%lld vs %lld)",
-                        (long long)cur, (long long)nrun);
+        if (tot[1] >= 0x7fffffffull) return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 aligned runs of multi-run reads per file are not supported");
+        nrunrec_total = (int64_t)tot[1];
     }
-    if (nrunrec_total >= (int64_t)0x7fffffff) return fail(PC_ERR_ARG, "pc_add_alignment_file: more than 2^31-2 aligned runs of multi-run reads per file are not supported");
-    StagedFile *sf = new StagedFile();
-    sf->n = n;
-    sf->nrun = nrun;
-    // run-stream records {run start, len | cum << 8 | L << 16 | flags << 24} and the record of every run, in record order:
-    // the units of a slice own one contiguous stretch of them, so they travel with the slice (no file-sized host array)
+    clk.lap("run layout (GPU)");
+    // run-stream records {run start, len | cum << 8 | L << 16 | flags << 24} and the record of every run, in record order
     DevBuf<uint2> d_val_in;
     DevBuf<uint32_t> d_idx_in;
-    size_t slice_runs = 1;
-    for (int64_t sl = 0; sl < nslices && !dev; ++sl) {
-        const int64_t r0 = units[(size_t)(sl * T)].run_at, r1 = sl + 1 < nslices ? units[(size_t)((sl + 1) * T)].run_at : nrunrec_total;
-        slice_runs = std::max(slice_runs, (size_t)(r1 - r0));
-    }
     int rc = sf->rec.reserve((size_t)n + 2);
     if (rc == PC_OK && nrunrec_total > 0) rc = d_val_in.reserve((size_t)nrunrec_total);
     if (rc == PC_OK && nrunrec_total > 0) rc = d_idx_in.reserve((size_t)nrunrec_total);
     if (rc == PC_OK) rc = sf->stream.reserve((size_t)n + 8);
-    if (rc == PC_OK && nrun > 0) rc = sf->blk_off.reserve((size_t)n);
-    if (rc != PC_OK) { delete sf; return rc; }
-    // Only the 8-byte records cross PCIe: the 4-byte stream word and the run offset of every record are functions
-    // of the records (stream_word; a prefix sum of the run counts) and are derived on the GPU below.
-    // (Page-locked slices were measured and bought nothing: on the 16 CPUs a GPU box grants, packing a slice
-    // takes as long as its pageable upload, 31-37 ms per 100 M records either way.)
-    struct SliceBuf {
-        HostBuf<uint2> own, run_val;
-        HostBuf<uint32_t> run_idx;
-        uint2 *rec = nullptr;
-        std::future<int> up;
-        SliceBuf(size_t cap, size_t runs) : own(cap), run_val(runs), run_idx(runs) { rec = own.p; }
-    };
-    const size_t slice_cap = dev ? 1 : (size_t)std::min<int64_t>(S, std::max<int64_t>(n, 1));
-    SliceBuf bufs[2] = {SliceBuf(slice_cap, slice_runs), SliceBuf(nslices > 1 && !dev ? slice_cap : 1, nslices > 1 && !dev ? slice_runs : 1)};
-    if (!bufs[0].rec || !bufs[1].rec || !bufs[0].run_val.p || !bufs[1].run_val.p || !bufs[0].run_idx.p || !bufs[1].run_idx.p) {
-        delete sf;
-        return fail(PC_ERR_NOMEM, "pc_add_alignment_file: out of host memory");
-    }
-    const int device = e->device;
-    hipStream_t up_stream = e->stream;
-    clk.lap("run layout + allocations");
-    const ChunkErr *first_err = nullptr;
-    std::vector<int32_t> dev_last_pos;   // (device columns) start of the last record of every contig
-    if (dev && n > 0) {
-        // ---- the same pass as kernels: records, run-stream records, ends, statistics (stage_kernels.hip.h)
+    if (rc != PC_OK) return rc;
+    clk.lap("allocations");
+
+    // ---- one pass over the columns: validation (caller-owned columns), the 8-byte records, the run-stream records, the
+    // ends, the statistics of the file (span and length histograms, per-contig bounds) -- stage_kernels.hip.h.  What
+    // depends on the statistics of the WHOLE file -- the window halo `wcap` (a span quantile) and with it the long-span
+    // class of a record and its stream word -- is derived afterwards (k_classify).
+    std::vector<int64_t> span_hist(1026, 0), gap_span_hist(1026, 0), wide_span_hist(1026, 0), len_hist(65536, 0), len1_hist(256, 0), tid_end((size_t)ntid, 0);
+    std::vector<int32_t> last_pos((size_t)ntid, -1);   // start of the last record of every contig
+    int Wr = 1, rmin = 65536, rmax = -1;
+    int64_t max_span = 1;
+    if (n > 0) {
         using namespace pcstage;
-        hipStream_t st = e->stream;
-        DevBuf<unsigned long long> d_stats;
-        DevBuf<int32_t> d_ends, d_last_pos, d_tid_end;
+        DevBuf<unsigned long long> d_stats;   // the statistics block, then the error word of the validation
+        DevBuf<int32_t> d_last_pos, d_tid_end;
         DevBuf<int64_t> d_bounds;
-        DevBuf<uint8_t> d_tmp;
-        rc = d_stats.reserve(kStatWords);
-        if (rc == PC_OK) rc = d_ends.reserve((size_t)n);
+        rc = d_stats.reserve(kStatWords + 1);
         if (rc == PC_OK) rc = d_last_pos.reserve((size_t)ntid);
         if (rc == PC_OK) rc = d_tid_end.reserve((size_t)ntid);
         if (rc == PC_OK) rc = d_bounds.reserve((size_t)ntid + 1);
-        size_t tb = 0;
-        if (rc == PC_OK && hipcub::DeviceSegmentedReduce::Max(nullptr, tb, d_ends.p, d_tid_end.p, ntid, d_bounds.p, d_bounds.p + 1, st) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: segmented max failed");
-        if (rc == PC_OK) rc = d_tmp.reserve(std::max<size_t>(tb, 16));
-        if (rc != PC_OK) { delete sf; return rc; }
-        std::vector<unsigned long long> hstats((size_t)kStatWords, 0ull);
+        if (rc != PC_OK) return rc;
+        std::vector<unsigned long long> hstats((size_t)kStatWords + 1, 0ull);
         hstats[(size_t)kAtMisc + 1] = 65536ull;   // rmin
-        std::vector<int64_t> hbounds((size_t)ntid + 1);
+        hstats[(size_t)kStatWords] = ~0ull;       // no defect
         std::vector<int32_t> htid_end((size_t)ntid);
-        dev_last_pos.resize((size_t)ntid);
-        hipError_t he = hipMemcpyAsync(d_stats.p, hstats.data(), (size_t)kStatWords * 8, hipMemcpyHostToDevice, st);
-        if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_cols_pack, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, st, *dev, n, d_cursor.p, d_run_at.p,
-                               sf->rec.p, d_val_in.p, d_idx_in.p, d_ends.p, d_stats.p);
+        const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+        hipError_t he = hipMemcpyAsync(d_stats.p, hstats.data(), hstats.size() * 8, hipMemcpyHostToDevice, st);
+        if (he == hipSuccess) he = hipMemsetAsync(d_tid_end.p, 0, (size_t)ntid * 4, st);
+        if (he == hipSuccess && host_cols) {
+            he = hipMemcpyAsync(d_bounds.p, tid_bounds.data(), ((size_t)ntid + 1) * 8, hipMemcpyHostToDevice, st);
+            if (he == hipSuccess)
+                hipLaunchKernelGGL((k_cols_pack<true>), dim3(grid), dim3(256), 0, st, *dev, n_ok, sf->blk_off.p, d_run_at.p, sf->rec.p, d_val_in.p, d_idx_in.p, d_tid_end.p,
+                                   d_stats.p, d_bounds.p, ntid, d_stats.p + kStatWords);
+            // the verdict before anything is derived from the records
+            unsigned long long verdict = ~0ull;
+            if (he == hipSuccess) he = hipMemcpyAsync(&verdict, d_stats.p + kStatWords, 8, hipMemcpyDeviceToHost, st);
+            if (he == hipSuccess) he = hipStreamSynchronize(st);
+            if (he == hipSuccess && verdict != ~0ull) {
+                const long long i = (long long)(verdict >> 8);
+                switch ((int)(verdict & 0xffu)) {
+                case kBadNegPos: return fail(PC_ERR_ARG, "record %lld: negative position", i);
+                case kBadOrder: return fail(PC_ERR_UNSORTED, "records are not sorted by (tid, pos) at record %lld; alignment files must be coordinate sorted", i);
+                case kBadRuns: return fail(PC_ERR_ARG, "record %lld: aligned runs must be non-empty, ascending and non-adjacent", i);
+                case kBadFirstRun: return fail(PC_ERR_ARG, "record %lld: first run must start at pos", i);
+                case kBadRunSum: return fail(PC_ERR_ARG, "record %lld: run lengths do not sum to alen", i);
+                case kBadLenRuns: return fail(PC_ERR_ARG, "record %lld: nblk/alen mismatch", i);
+                default: return fail(PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", i);
+                }
+            }
+            if (he == hipSuccess && n_ok < n) return contig_defect();
+            for (int t = 0; t < ntid; ++t)
+                if (tid_bounds[(size_t)t + 1] > tid_bounds[(size_t)t]) last_pos[(size_t)t] = pos[tid_bounds[(size_t)t + 1] - 1];
+        } else if (he == hipSuccess) {
             hipLaunchKernelGGL(k_cols_bounds, dim3((unsigned)((ntid + 256) / 256)), dim3(256), 0, st, dev->tid, dev->pos, n, ntid, d_bounds.p, d_last_pos.p);
-            he = hipcub::DeviceSegmentedReduce::Max(d_tmp.p, tb, d_ends.p, d_tid_end.p, ntid, d_bounds.p, d_bounds.p + 1, st);
+            hipLaunchKernelGGL((k_cols_pack<false>), dim3(grid), dim3(256), 0, st, *dev, n, sf->blk_off.p, d_run_at.p, sf->rec.p, d_val_in.p, d_idx_in.p, d_tid_end.p,
+                               d_stats.p, d_bounds.p, ntid, (unsigned long long *)nullptr);
         }
         if (he == hipSuccess) he = hipMemcpyAsync(hstats.data(), d_stats.p, (size_t)kStatWords * 8, hipMemcpyDeviceToHost, st);
-        if (he == hipSuccess) he = hipMemcpyAsync(hbounds.data(), d_bounds.p, ((size_t)ntid + 1) * 8, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess && !host_cols) he = hipMemcpyAsync(tid_bounds.data(), d_bounds.p, ((size_t)ntid + 1) * 8, hipMemcpyDeviceToHost, st);
         if (he == hipSuccess) he = hipMemcpyAsync(htid_end.data(), d_tid_end.p, (size_t)ntid * 4, hipMemcpyDeviceToHost, st);
-        if (he == hipSuccess) he = hipMemcpyAsync(dev_last_pos.data(), d_last_pos.p, (size_t)ntid * 4, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess && !host_cols) he = hipMemcpyAsync(last_pos.data(), d_last_pos.p, (size_t)ntid * 4, hipMemcpyDeviceToHost, st);
         if (he == hipSuccess) he = hipGetLastError();
         if (he == hipSuccess) he = hipStreamSynchronize(st);
-        if (he != hipSuccess) { delete sf; return fail(PC_ERR_HIP, "stage: packing the device columns failed: %s", hipGetErrorString(he)); }
-        Acc &a = acc[0];   // (what the threads of the host pass accumulate, from the device's one block)
-        for (int t = 0; t < ntid; ++t) {
-            a.tid_count[(size_t)t + 1] = hbounds[(size_t)t + 1] - hbounds[(size_t)t];
-            a.tid_end[(size_t)t] = hbounds[(size_t)t + 1] > hbounds[(size_t)t] ? (int64_t)htid_end[(size_t)t] : 0;
-        }
+        if (he != hipSuccess) return fail(PC_ERR_HIP, "stage: packing the columns failed: %s", hipGetErrorString(he));
+        for (int t = 0; t < ntid; ++t)
+            tid_end[(size_t)t] = tid_bounds[(size_t)t + 1] > tid_bounds[(size_t)t] ? (int64_t)htid_end[(size_t)t] : 0;
         for (int k = 0; k < kSpanBins; ++k) {
-            a.span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtSpan + k)];
-            a.gap_span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtGap + k)];
-            a.wide_span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtWide + k)];
+            span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtSpan + k)];
+            gap_span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtGap + k)];
+            wide_span_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtWide + k)];
         }
-        for (int k = 0; k < kLenBins; ++k) a.len_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtLen + k)];
-        for (int k = 0; k < kLen1Bins; ++k) a.len1_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtLen1 + k)];
-        a.Wr = std::max(1, (int)hstats[(size_t)kAtMisc + 0]);
-        a.rmin = (int)hstats[(size_t)kAtMisc + 1];
-        a.rmax = a.rmin >= 65536 ? -1 : (int)hstats[(size_t)kAtMisc + 2];
-        a.max_span = std::max<int64_t>(1, (int64_t)hstats[(size_t)kAtMisc + 3]);
+        for (int k = 0; k < kLenBins; ++k) len_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtLen + k)];
+        for (int k = 0; k < kLen1Bins; ++k) len1_hist[(size_t)k] = (int64_t)hstats[(size_t)(kAtLen1 + k)];
+        Wr = std::max(1, (int)hstats[(size_t)kAtMisc + 0]);
+        rmin = (int)hstats[(size_t)kAtMisc + 1];
+        rmax = rmin >= 65536 ? -1 : (int)hstats[(size_t)kAtMisc + 2];
+        max_span = std::max<int64_t>(1, (int64_t)hstats[(size_t)kAtMisc + 3]);
     }
-    for (int64_t sl = 0; sl < nslices && rc == PC_OK && !dev; ++sl) {
-        SliceBuf &sb = bufs[sl & 1];
-        if (sb.up.valid()) rc = sb.up.get();               // the slice that used these buffers has gone up
-        if (rc != PC_OK) break;
-        const int64_t s0 = sl * S, s1 = std::min(n, s0 + S);
-        const int64_t run0 = units[(size_t)(sl * T)].run_at, run1 = sl + 1 < nslices ? units[(size_t)((sl + 1) * T)].run_at : nrunrec_total;
-        parallel_chunks((int64_t)T, T, [&](int, int64_t tb, int64_t te) {
-            for (int64_t t = tb; t < te; ++t) {
-                Acc &a = acc[(size_t)t];
-                int64_t b, en;
-                unit_range(sl, (int)t, b, en);
-                int64_t cursor = units[(size_t)(sl * T + t)].cursor, run_at = units[(size_t)(sl * T + t)].run_at;
-                int Wr = a.Wr, rmin = a.rmin, rmax = a.rmax;   // (scalars in locals: neighbouring accumulators share cache lines)
-                int64_t max_span = a.max_span;
-                auto bad = [&](int64_t i, int code, const char *fmt, long long a1, long long a2) {
-                    a.err.idx = i; a.err.code = code;
-                    snprintf(a.err.msg, sizeof(a.err.msg), fmt, a1, a2);
-                };
-                for (int64_t i = b; i < en; ++i) {
-                    // Eight records at a time when all eight are plain (one contig, in order, one aligned run of a length
-                    // the stream carries): nothing to report, nothing for a side list or the run stream, no branches.
-                    if (i + 8 <= en) {
-                        const int32_t t0 = tid[i];
-                        bool ok8 = t0 >= 0 && t0 < ntid && pos[i] >= 0 &&
-                                   (i == 0 || tid[i - 1] < t0 || (tid[i - 1] == t0 && pos[i - 1] <= pos[i])) &&
-                                   (int64_t)pos[i + 7] + 65535 <= 0x7fffffffLL;
-                        int32_t prev = pos[i];
-                        int hi8 = 0;
-                        for (int k = 0; k < 8; ++k) {
-                            ok8 &= (tid[i + k] == t0) & (nblk[i + k] == 1) & (alen[i + k] > 0) & (pos[i + k] >= prev);
-                            prev = pos[i + k];
-                            hi8 = std::max(hi8, (int)alen[i + k]);
-                        }
-                        if (ok8 && hi8 <= kStreamMaxLen) {
-                            int64_t emax = 0;
-                            const size_t j0 = (size_t)(i - s0);
-                            for (int k = 0; k < 8; ++k) {
-                                const int L = alen[i + k];
-                                a.len_hist[(size_t)L] += 1;
-                                a.len1_hist[(size_t)L] += 1;
-                                a.span_hist[(size_t)L] += 1;
-                                emax = std::max(emax, (int64_t)pos[i + k] + L);
-                                sb.rec[j0 + k] = make_uint2((uint32_t)pos[i + k], (uint32_t)L | (1u << 24) |
-                                                            (caller_flags(flags[i + k]) << 16));
-                            }
-                            max_span = std::max<int64_t>(max_span, hi8);
-                            a.tid_count[(size_t)t0 + 1] += 8;
-                            a.tid_end[(size_t)t0] = std::max(a.tid_end[(size_t)t0], emax);
-                            i += 7;
-                            continue;
-                        }
-                    }
-                    if (tid[i] < 0 || tid[i] >= ntid) { bad(i, PC_ERR_ARG, "record %lld: tid %lld out of range", i, tid[i]); return; }
-                    if (pos[i] < 0) { bad(i, PC_ERR_ARG, "record %lld: negative position", i, 0); return; }
-                    if (i > 0 && (tid[i] < tid[i - 1] || (tid[i] == tid[i - 1] && pos[i] < pos[i - 1]))) {
-                        bad(i, PC_ERR_UNSORTED, "records are not sorted by (tid, pos) at record %lld; alignment files must be coordinate sorted", i, 0);
-                        return;
-                    }
-                    const int64_t wi = wide_at(i);           // a record beyond the 16-bit / 8-bit fields: true values aside
-                    const int64_t L = wi >= 0 ? (int64_t)wide_alen[wi] : (int64_t)alen[i], nb = wi >= 0 ? (int64_t)wide_nblk[wi] : (int64_t)nblk[i];
-                    uint32_t boff = 0u;
-                    int64_t end;
-                    if (nb >= 2) {
-                        int64_t sum = 0, prev_end = -1;
-                        for (int64_t k = 0; k < nb; ++k) {
-                            const int64_t r0 = blk_start[cursor + k], ln = blk_len[cursor + k];
-                            if (ln <= 0 || (k > 0 && r0 <= prev_end)) {
-                                bad(i, PC_ERR_ARG, "record %lld: aligned runs must be non-empty, ascending and non-adjacent", i, 0);
-                                return;
-                            }
-                            if (k == 0 && r0 != pos[i]) { bad(i, PC_ERR_ARG, "record %lld: first run must start at pos", i, 0); return; }
-                            sum += ln;
-                            prev_end = r0 + ln;
-                        }
-                        if (sum != L) { bad(i, PC_ERR_ARG, "record %lld: run lengths do not sum to alen", i, 0); return; }
-                        end = prev_end;
-                        boff = (uint32_t)cursor;
-                    } else {
-                        if ((nb == 0) != (L == 0)) { bad(i, PC_ERR_ARG, "record %lld: nblk/alen mismatch", i, 0); return; }
-                        end = (int64_t)pos[i] + (L > 0 ? L : 1);
-                    }
-                    if (end > 0x7fffffffLL) { bad(i, PC_ERR_ARG, "record %lld: alignment end beyond 2^31-1", i, 0); return; }
-                    const int64_t sp = end - pos[i];
-                    a.tid_count[(size_t)tid[i] + 1] += 1;
-                    a.tid_end[(size_t)tid[i]] = std::max(a.tid_end[(size_t)tid[i]], end);
-                    a.span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
-                    a.len_hist[(size_t)std::min<int64_t>(L, 65535)] += 1;
-                    max_span = std::max(max_span, sp);
-                    uint32_t meta = (uint32_t)L | (caller_flags(flags[i]) << 16) | ((uint32_t)nb << 24);
-                    if (wi >= 0) meta = 0xffffu | ((caller_flags(flags[i]) | kFlagWide) << 16) | (0xffu << 24);
-                    // multi-run reads of ordinary length: every aligned run goes to the run stream (what the
-                    // point rules scan); only longer reads keep to the gapped / long-span side lists there
-                    const bool in_runs = nb >= 2 && L <= kStreamMaxLen && wi < 0;
-                    if (in_runs) {
-                        meta |= (kFlagRuns << 16);
-                        rmin = std::min(rmin, (int)L); rmax = std::max(rmax, (int)L);   // run-stream records index the same LDS entry table
-                        uint32_t cum = 0;
-                        for (int64_t k = 0; k < nb; ++k) {
-                            const uint32_t rs = (uint32_t)blk_start[boff + k], rl = (uint32_t)blk_len[boff + k];
-                            sb.run_val[(size_t)(run_at - run0)] = make_uint2(rs, rl | (cum << 8) | ((uint32_t)L << 16) |
-                                                                                     (caller_flags(flags[i]) << 24));
-                            sb.run_idx[(size_t)(run_at - run0)] = (uint32_t)i;
-                            ++run_at;
-                            Wr = std::max(Wr, (int)rl);
-                            cum += rl;
-                        }
-                    } else if (wi >= 0) {
-                        a.wide_span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;
-                    } else {
-                        if (L > kStreamMaxLen) a.gap_span_hist[(size_t)std::min<int64_t>(sp, 1025)] += 1;   // the gapped-record list, unless the span is beyond the halo
-                        else if (nb < 2) a.len1_hist[(size_t)L] += 1;                                      // carried by the stream, unless ...
-                    }
-                    if (nb >= 2) cursor += nb;
-                    // (whether the span is beyond the window halo -- the long-span class -- is written into the header on
-                    // the GPU, once the halo is known: k_classify)
-                    sb.rec[(size_t)(i - s0)] = make_uint2((uint32_t)pos[i], meta);
-                }
-                a.Wr = Wr; a.rmin = rmin; a.rmax = rmax; a.max_span = max_span;
-            }
-        });
-        for (const auto &a : acc)
-            if (a.err.code != PC_OK && (!first_err || a.err.idx < first_err->idx)) first_err = &a.err;
-        if (first_err) break;
-        uint2 *d_rec = sf->rec.p + s0;
-        const uint2 *h_rec = sb.rec;
-        const size_t cnt = (size_t)(s1 - s0), nruns_sl = (size_t)(run1 - run0);
-        uint2 *d_rv = d_val_in.p + run0;
-        uint32_t *d_ri = d_idx_in.p + run0;
-        const uint2 *h_rv = sb.run_val.p;
-        const uint32_t *h_ri = sb.run_idx.p;
-        sb.up = std::async(std::launch::async, [=]() -> int {
-            if (hipSetDevice(device) != hipSuccess) return PC_ERR_HIP;
-            if (hipMemcpyAsync(d_rec, h_rec, cnt * sizeof(uint2), hipMemcpyHostToDevice, up_stream) != hipSuccess) return PC_ERR_HIP;
-            if (nruns_sl && (hipMemcpyAsync(d_rv, h_rv, nruns_sl * sizeof(uint2), hipMemcpyHostToDevice, up_stream) != hipSuccess ||
-                             hipMemcpyAsync(d_ri, h_ri, nruns_sl * sizeof(uint32_t), hipMemcpyHostToDevice, up_stream) != hipSuccess))
-                return PC_ERR_HIP;
-            return hipStreamSynchronize(up_stream) == hipSuccess ? PC_OK : PC_ERR_HIP;
-        });
-    }
-    for (auto &sb : bufs)
-        if (sb.up.valid()) { const int r = sb.up.get(); if (rc == PC_OK) rc = r; }
-    if (first_err) { delete sf; return fail(first_err->code, "%s", first_err->msg); }
-    if (rc != PC_OK) { delete sf; return fail(rc, "pc_add_alignment_file: staging a slice failed"); }
-
-    // ---- statistics of the whole file
-    std::vector<int64_t> span_hist(1026, 0), gap_span_hist(1026, 0), wide_span_hist(1026, 0), len_hist(65536, 0), len1_hist(256, 0), tid_end((size_t)ntid, 0);
-    int Wr = 1, rmin = 65536, rmax = -1;
-    int64_t max_span = 1;
-    for (const auto &a : acc) {
-        for (int t = 0; t <= ntid; ++t) tid_bounds[(size_t)t] += a.tid_count[(size_t)t];
-        for (int t = 0; t < ntid; ++t) tid_end[(size_t)t] = std::max(tid_end[(size_t)t], a.tid_end[(size_t)t]);
-        for (size_t k = 0; k < span_hist.size(); ++k) { span_hist[k] += a.span_hist[k]; gap_span_hist[k] += a.gap_span_hist[k]; wide_span_hist[k] += a.wide_span_hist[k]; }
-        for (size_t k = 0; k < len_hist.size(); ++k) len_hist[k] += a.len_hist[k];
-        for (size_t k = 0; k < len1_hist.size(); ++k) len1_hist[k] += a.len1_hist[k];
-        Wr = std::max(Wr, a.Wr); rmin = std::min(rmin, a.rmin); rmax = std::max(rmax, a.rmax);
-        max_span = std::max(max_span, a.max_span);
-    }
-    acc.clear();
-    acc.shrink_to_fit();
-    for (int t = 0; t < ntid; ++t) tid_bounds[(size_t)t + 1] += tid_bounds[(size_t)t];
+    clk.lap("validate + pack (GPU)");
     // the window halo W: the smallest span bound (>= 64, <= 1024) that covers >= 99.5% of the records; longer
     // (spliced) reads go through the long-read path
     int wcap = 64;
@@ -1701,50 +1677,57 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
         for (int k = 0; k < 8; ++k) tail_stream[k] = kStreamSkip;
         if (hipMemcpyAsync(sf->rec.p + n, tail_rec, sizeof(tail_rec), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
             hipMemcpyAsync(sf->stream.p + n, tail_stream, sizeof(tail_stream), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-            hipStreamSynchronize(e->stream) != hipSuccess) {
-            delete sf;
+            hipStreamSynchronize(e->stream) != hipSuccess)
             return fail(PC_ERR_HIP, "pc_add_alignment_file: staging the sentinels failed");
-        }
     }
     if (n_wide > 0) {   // the wide records by record index: what the per-record kernels look up
-        std::vector<uint32_t> wr((size_t)n_wide);
-        std::vector<uint2> wv((size_t)n_wide);
-        for (int64_t k = 0; k < n_wide; ++k) { wr[(size_t)k] = (uint32_t)wide_idx[k]; wv[(size_t)k] = make_uint2((uint32_t)wide_alen[k], (uint32_t)wide_nblk[k]); }
-        rc = sf->wide_rec.upload(wr, e->stream);
-        if (rc == PC_OK) rc = sf->wide_val.upload(wv, e->stream);
-        if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
-        if (rc != PC_OK) { delete sf; return rc; }
+        if (host_cols) {   // (they went up with the columns)
+            sf->wide_rec.swap(d_wr);
+            sf->wide_val.swap(d_wv);
+        } else {
+            std::vector<uint32_t> wr((size_t)n_wide);
+            std::vector<uint2> wv((size_t)n_wide);
+            for (int64_t k = 0; k < n_wide; ++k) { wr[(size_t)k] = (uint32_t)wide_idx[k]; wv[(size_t)k] = make_uint2((uint32_t)wide_alen[k], (uint32_t)wide_nblk[k]); }
+            rc = sf->wide_rec.upload(wr, e->stream);
+            if (rc == PC_OK) rc = sf->wide_val.upload(wv, e->stream);
+            if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "stage: sync failed");
+            if (rc != PC_OK) return rc;
+        }
         sf->nwide = n_wide;
     }
-    // the aligned runs as {start, length} pairs (they went up while the records were packed)
-    if (nrun > 0 && runs_up.f.valid()) { const int r = runs_up.f.get(); if (r != PC_OK) { delete sf; return fail(r, "stage: uploading the aligned runs failed"); } }
+    // the aligned runs as {start, length} pairs
     if (nrun > 0) {
         rc = sf->blk.reserve((size_t)nrun);
-        if (rc != PC_OK) { delete sf; return rc; }
-        hipLaunchKernelGGL(k_zip_runs, dim3((unsigned)((nrun + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, d_bs.p, d_bl.p, nrun, sf->blk.p);
+        if (rc != PC_OK) return rc;
+        hipLaunchKernelGGL(k_zip_runs, dim3((unsigned)((nrun + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, dev->blk_start, dev->blk_len, nrun, sf->blk.p);
     }
-    if (n > 0) {   // run offsets (exclusive sum of the run counts of the multi-run records), then the class and the 4-byte stream word of every record
-        const unsigned grid = (unsigned)((n + kWG - 1) / kWG);
-        hipError_t he = hipSuccess;
-        if (nrun > 0) {
-            hipLaunchKernelGGL(k_run_counts, dim3(grid), dim3(kWG), 0, e->stream, sf->rec.p, n, sf->blk_off.p, sf->wide_rec.p, sf->wide_val.p, n_wide);
-            size_t tmp_bytes = 0;
-            DevBuf<uint8_t> d_tmp;
-            he = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, sf->blk_off.p, sf->blk_off.p, (int)n, e->stream);
-            if (he == hipSuccess && d_tmp.reserve(tmp_bytes) != PC_OK) he = hipErrorOutOfMemory;
-            if (he == hipSuccess) he = hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, sf->blk_off.p, sf->blk_off.p, (int)n, e->stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(e->stream);   // d_tmp goes out of scope
-        }
+    if (nrun == 0) sf->blk_off.release();   // (all zero: no record keeps runs in the run arrays)
+    // the class and the 4-byte stream word of every record; per workgroup, the members of the three side lists
+    const uint32_t nwg = (uint32_t)((n + 255) / 256);
+    DevBuf<uint32_t> d_side_at;   // [3 * nwg + 1]: counts, then their exclusive sum
+    uint32_t side_total[3] = {0, 0, 0};
+    if (n > 0) {
+        using namespace pcstage;
+        DevBuf<uint8_t> d_tmp;
+        const int nside = 3 * (int)nwg + 1;
+        rc = d_side_at.reserve((size_t)nside);
+        size_t tb = 0;
+        hipError_t he = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_side_at.p, d_side_at.p, nside, st);
+        if (rc == PC_OK && he == hipSuccess) rc = d_tmp.reserve(std::max<size_t>(tb, 16));
+        if (rc != PC_OK) return rc;
+        uint32_t at[4] = {0, 0, 0, 0};
+        if (he == hipSuccess) he = hipMemsetAsync(d_side_at.p + 3 * (size_t)nwg, 0, 4, st);
         if (he == hipSuccess) {
-            hipLaunchKernelGGL(k_classify, dim3(grid), dim3(kWG), 0, e->stream, sf->rec.p, n, nrun > 0 ? sf->blk_off.p : nullptr, sf->blk.p, wcap, sf->stream.p);
-            he = hipGetLastError();
-            if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+            hipLaunchKernelGGL(pcstage::k_classify, dim3(nwg), dim3(256), 0, st, sf->rec.p, n, sf->blk_off.p, sf->blk.p, wcap, sf->stream.p, d_side_at.p);
+            he = hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb, d_side_at.p, d_side_at.p, nside, st);
         }
-        if (he != hipSuccess) { delete sf; return fail(PC_ERR_HIP, "pc_add_alignment_file: deriving the record stream failed: %s", hipGetErrorString(he)); }
+        for (int k = 1; k <= 3 && he == hipSuccess; ++k) he = hipMemcpyAsync(&at[k], d_side_at.p + (size_t)k * nwg, 4, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipGetLastError();
+        if (he == hipSuccess) he = hipStreamSynchronize(st);   // (d_tmp goes out of scope)
+        if (he != hipSuccess) return fail(PC_ERR_HIP, "pc_add_alignment_file: deriving the record stream failed: %s", hipGetErrorString(he));
+        for (int k = 0; k < 3; ++k) side_total[k] = at[k + 1] - at[k];
     }
-    d_bs.release();
-    d_bl.release();
-    clk.lap("validate + pack + upload (pipelined)");
+    clk.lap("record stream (GPU)");
     const size_t nrunrec = (size_t)nrunrec_total;
     sf->nrunrec = (int64_t)nrunrec;
 
@@ -1754,7 +1737,7 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
     std::vector<int64_t> lin_off((size_t)ntid + 1, 0);
     for (int t = 0; t < ntid; ++t) {
         const int64_t b = tid_bounds[(size_t)t], en = tid_bounds[(size_t)t + 1];
-        int64_t last = en > b ? (int64_t)(dev ? dev_last_pos[(size_t)t] : pos[en - 1]) : -1;
+        int64_t last = en > b ? (int64_t)last_pos[(size_t)t] : -1;
         if (en > b) last = std::max<int64_t>(last, tid_end[(size_t)t] - 1);
         const int64_t nb = last >= 0 ? (last >> kLinShift) + 1 : 0;
         lin_off[(size_t)t + 1] = lin_off[(size_t)t] + nb + 1;
@@ -1762,53 +1745,17 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
     const size_t nlin = (size_t)lin_off[(size_t)ntid];
 
     // ---- side lists and linear-index tables, on the GPU (pc_kernels.hip.h, "side lists"): the records are there
-    // already; from the host come only the aligned runs of the multi-run records and the two small per-contig tables
-    hipStream_t st = e->stream;
+    // already; from the host come only the two small per-contig tables
     rc = sf->tid_bounds.upload(tid_bounds, st);
     if (rc == PC_OK) rc = sf->lin_off.upload(lin_off, st);
-    size_t nlong = 0, ngap = 0, nxlong = 0;
-    DevBuf<uint32_t> d_gap_idx, d_xlong_idx, d_nsel;
-    if (rc == PC_OK && n > 0) {
-        // members of the three lists, in record order (counted first: the lists are sized exactly)
-        rc = d_nsel.reserve(8);
-        uint32_t ncls[3] = {0, 0, 0};
-        if (rc == PC_OK) {
-            hipError_t he = hipMemsetAsync(d_nsel.p, 0, 8 * sizeof(uint32_t), st);
-            if (he == hipSuccess) {
-                const int64_t per_wg = (int64_t)kWG * 16;
-                hipLaunchKernelGGL(k_side_count, dim3((unsigned)((n + per_wg - 1) / per_wg)), dim3(kWG), 0, st, sf->rec.p, n, d_nsel.p + 4);
-                he = hipMemcpyAsync(ncls, d_nsel.p + 4, sizeof(ncls), hipMemcpyDeviceToHost, st);
-            }
-            if (he == hipSuccess) he = hipStreamSynchronize(st);
-            if (he != hipSuccess) rc = fail(PC_ERR_HIP, "stage: counting the side lists failed: %s", hipGetErrorString(he));
-        }
-        if (rc == PC_OK) rc = sf->long_idx.reserve(ncls[0]);
-        if (rc == PC_OK) rc = d_gap_idx.reserve(ncls[1]);
-        if (rc == PC_OK) rc = d_xlong_idx.reserve(ncls[2]);
-        if (rc == PC_OK) {
-            hipcub::CountingInputIterator<uint32_t> ids(0u);
-            size_t tmp_bytes = 0, need = 0;
-            hipError_t he = hipcub::DeviceSelect::If(nullptr, need, ids, sf->long_idx.p, d_nsel.p, (int)n, SelectLong{sf->rec.p}, st);
-            tmp_bytes = need;
-            if (he == hipSuccess) he = hipcub::DeviceSelect::If(nullptr, need, ids, d_gap_idx.p, d_nsel.p + 1, (int)n, SelectGap{sf->rec.p}, st);
-            tmp_bytes = std::max(tmp_bytes, need);
-            if (he == hipSuccess) he = hipcub::DeviceSelect::If(nullptr, need, ids, d_xlong_idx.p, d_nsel.p + 2, (int)n, SelectXLong{sf->rec.p}, st);
-            tmp_bytes = std::max(tmp_bytes, need);
-            DevBuf<uint8_t> d_tmp;
-            if (he == hipSuccess && d_tmp.reserve(std::max<size_t>(tmp_bytes, 16)) != PC_OK) he = hipErrorOutOfMemory;
-            size_t tb = tmp_bytes;
-            if (he == hipSuccess) he = hipcub::DeviceSelect::If(d_tmp.p, tb, ids, sf->long_idx.p, d_nsel.p, (int)n, SelectLong{sf->rec.p}, st);
-            tb = tmp_bytes;
-            if (he == hipSuccess) he = hipcub::DeviceSelect::If(d_tmp.p, tb, ids, d_gap_idx.p, d_nsel.p + 1, (int)n, SelectGap{sf->rec.p}, st);
-            tb = tmp_bytes;
-            if (he == hipSuccess) he = hipcub::DeviceSelect::If(d_tmp.p, tb, ids, d_xlong_idx.p, d_nsel.p + 2, (int)n, SelectXLong{sf->rec.p}, st);
-            uint32_t nsel[3] = {0, 0, 0};
-            if (he == hipSuccess) he = hipMemcpyAsync(nsel, d_nsel.p, sizeof(nsel), hipMemcpyDeviceToHost, st);
-            if (he == hipSuccess) he = hipStreamSynchronize(st);   // the counts size what follows; d_tmp goes out of scope
-            if (he != hipSuccess) rc = fail(PC_ERR_HIP, "stage: selecting the side lists failed: %s", hipGetErrorString(he));
-            nlong = nsel[0]; ngap = nsel[1]; nxlong = nsel[2];
-            if (rc == PC_OK && (nlong != ncls[0] || ngap != ncls[1] || nxlong != ncls[2])) rc = fail(PC_ERR_STATE, "stage: the side lists changed size while they were built");
-        }
+    const size_t nlong = side_total[0], ngap = side_total[1], nxlong = side_total[2];
+    DevBuf<uint32_t> d_gap_idx, d_xlong_idx;
+    if (rc == PC_OK && n > 0) {   // members of the three lists, in record order
+        rc = sf->long_idx.reserve(nlong);
+        if (rc == PC_OK) rc = d_gap_idx.reserve(ngap);
+        if (rc == PC_OK) rc = d_xlong_idx.reserve(nxlong);
+        if (rc == PC_OK && nlong + ngap + nxlong > 0)
+            hipLaunchKernelGGL(pcstage::k_side_select, dim3(nwg), dim3(256), 0, st, sf->rec.p, n, d_side_at.p, nwg, sf->long_idx.p, d_gap_idx.p, d_xlong_idx.p);
     }
     sf->nlong = (int64_t)nlong;
     sf->ngap = (int64_t)ngap;
@@ -1931,11 +1878,9 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
                 rc = fail(PC_ERR_HIP, "stage: building the run stream failed");
         }
     }
-    if (rc != PC_OK) {
-        delete sf;
-        return rc;
-    }
+    if (rc != PC_OK) return rc;
     clk.lap("run stream (GPU sort)");
+    owner.p = nullptr;
     e->files.push_back(sf);
     e->ntid = ntid;
     e->files_dirty = true;
@@ -3119,6 +3064,15 @@ int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems) 
     HIP_TRY(hipSetDevice(e->device));
     { const int grc = check_grid_guard(e, p); if (grc != PC_OK) return grc; }
     const size_t bytes = (size_t)out_elems * 8;
+    const char *knob = getenv("PC_STAGE_SLICE");   // (test knob: the ring for every size, in pieces of so many 4 KiB pages)
+    if (bytes >= 4 * UploadRing::kPiece || (bytes > 0 && knob)) {
+        // the counts of a whole annotation: through the ring of page-locked pieces (a pageable destination the runtime has
+        // not seen before is filled at 25 GB/s; see UploadRing)
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        const std::vector<UploadJob> job{{host_out, p->d_out.p, bytes}};
+        const size_t piece = knob ? (size_t)std::max<int64_t>(1, std::min<int64_t>(atoll(knob), 4096)) * 4096 : UploadRing::kPiece;
+        return UploadRing::of(e->device).run(e->device, job, piece, knob != nullptr, true);
+    }
     // (growing the buffer frees the old one: not while a plan upload may still be reading from it)
     if (bytes > e->pinned.cap && e->pinned_busy) { HIP_TRY(hipEventSynchronize(e->ev_pinned)); e->pinned_busy = false; }
     if (bytes > 0 && bytes <= kSmallRead && e->pinned.reserve(bytes) == PC_OK) {
@@ -4338,8 +4292,8 @@ static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size,
     const int64_t n = b->n, m = b->nrun, nw = (int64_t)b->wide_idx.size();
     const int ntid = std::max(1, (int)b->ref_names.size());
     if (mapped) *mapped = b->mapped;
-    // the decoder's columns never leave HBM: staged by kernels (stage_kernels.hip.h) instead of the host pass
-    // (PC_BAM_STAGE_HOST=1: read them back and take the host pass, as a caller of pc_bam_read + pc_add_alignment_file does)
+    // the decoder's columns never leave HBM
+    // (PC_BAM_STAGE_HOST=1: read them back and hand them over as host arrays, as a caller of pc_bam_read + pc_add_alignment_file does)
     if (!getenv("PC_BAM_STAGE_HOST")) {
         DevBuf<uint32_t> d_wr;
         DevBuf<uint2> d_wv;

@@ -412,8 +412,9 @@ def test_genome_partition_through_the_engine(pa, oracle):
 
 
 def test_threaded_staging_is_deterministic(pa, monkeypatch):
-    """pc_add_alignment_file runs its host pass on several threads for large files: the staged
-    result (hence every count) and the reported error must not depend on the thread count."""
+    """pc_add_alignment_file examines the contig column on several host threads and sends the other columns through a
+    ring of page-locked pieces: the staged result (hence every count) and the reported error must not depend on the
+    thread count or the piece size."""
     from plastid_amd import synth
     from plastid_amd.engine import Engine
     genome, tx, reads, _ = synth.make_config("C4", scale=0.005, tx_scale=0.01)      # 2.5 M reads, spliced
@@ -424,7 +425,7 @@ def test_threaded_staging_is_deterministic(pa, monkeypatch):
         if slice_records is None:
             monkeypatch.delenv("PC_STAGE_SLICE", raising=False)
         else:
-            monkeypatch.setenv("PC_STAGE_SLICE", slice_records)    # several slices through the two host buffers
+            monkeypatch.setenv("PC_STAGE_SLICE", slice_records)    # the columns in pieces through the page-locked ring
         eng = engine_for(pa, [reads], ("threeprime", 3))
         plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"],
                         p["out_elems"], 1)
@@ -452,6 +453,78 @@ def test_threaded_staging_is_deterministic(pa, monkeypatch):
             eng.set_alignments([broken])
         assert "record %d" % first in str(ei.value), str(ei.value)
         eng.close()
+
+
+@pytest.mark.parametrize("slice_records", [None, "3"])
+def test_staging_rejects_every_defect_of_the_columns(pa, monkeypatch, slice_records):
+    """The caller's columns are validated on the GPU (stage_kernels.hip.h: k_cols_pack<true>; the contig column on the
+    host, where it stays): every defect the packed-record contract names is reported with its record index and the
+    message of the host-side validator (packing.PackedAlignments), the defect of the LOWEST record first -- also when one
+    of two defects is in the contig column and the other is not.  With PC_STAGE_SLICE the columns cross PCIe through
+    the ring of page-locked pieces, twelve bytes at a time."""
+    from plastid_amd.engine import Engine
+    if slice_records:
+        monkeypatch.setenv("PC_STAGE_SLICE", slice_records)
+    refs, lens = ["a", "b", "c"], [5000, 5000, 5000]
+    tid = np.array([0, 0, 0, 1, 1, 1, 1, 2, 2], np.int32)
+    pos = np.array([10, 20, 20, 5, 30, 40, 41, 0, 7], np.int32)
+    alen = np.array([30, 25, 28, 30, 40, 30, 30, 30, 29], np.uint16)
+    nblk = np.array([1, 1, 2, 1, 3, 1, 1, 1, 1], np.uint8)
+    flags = np.zeros(9, np.uint8)
+    blk_start = np.array([20, 60, 30, 50, 90], np.int32)
+    blk_len = np.array([10, 18, 10, 20, 10], np.int32)
+    cols = dict(tid=tid, pos=pos, alen=alen, flags=flags, nblk=nblk, blk_start=blk_start, blk_len=blk_len)
+
+    def stage(**changed):
+        c = {k: v.copy() for k, v in cols.items()}
+        for k, (i, v) in changed.items():
+            if i is None:
+                c[k] = v
+            else:
+                c[k][i] = v
+        reads = pa.PackedAlignments(c["tid"], c["pos"], c["alen"], c["flags"], c["nblk"], c["blk_start"], c["blk_len"],
+                                    references=refs, lengths=lens, validate=False)
+        eng = Engine(0)
+        try:
+            eng.set_alignments([reads])
+            return None
+        except ValueError as err:
+            return str(err)
+        finally:
+            eng.close()
+
+    assert stage() is None
+    cases = [
+        (dict(pos=(1, -3)), "record 1: negative position"),
+        (dict(pos=(5, 29)), "not sorted by (tid, pos) at record 5"),
+        (dict(tid=(4, 7)), "record 4: tid 7 out of range"),
+        (dict(tid=(4, -1)), "record 4: tid -1 out of range"),
+        (dict(tid=(0, -2)), "record 0: tid -2 out of range"),
+        (dict(tid=(5, 0)), "not sorted by (tid, pos) at record 5"),
+        (dict(blk_start=(0, 21)), "record 2: first run must start at pos"),
+        (dict(blk_len=(1, 19)), "record 2: run lengths do not sum to alen"),
+        (dict(blk_start=(3, 40)), "record 4: aligned runs must be non-empty, ascending and non-adjacent"),
+        (dict(blk_len=(3, 0)), "record 4: aligned runs must be non-empty"),
+        (dict(nblk=(6, 0)), "record 6: nblk/alen mismatch"),
+        (dict(alen=(8, 0)), "record 8: nblk/alen mismatch"),
+        (dict(pos=(8, 2**31 - 20)), "record 8: alignment end beyond 2^31-1"),
+        (dict(nblk=(0, 2)), "run arrays shorter than sum of nblk"),
+        (dict(blk_start=(None, np.append(blk_start, 7).astype(np.int32)), blk_len=(None, np.append(blk_len, 7).astype(np.int32))),
+         "run arrays longer than sum of nblk"),
+        # two defects: the lower record is the one reported, whichever column it is in
+        (dict(tid=(6, 0), pos=(1, -3)), "record 1: negative position"),
+        (dict(tid=(3, 2), pos=(5, 29)), "not sorted by (tid, pos) at record 4"),
+        (dict(tid=(6, 0), pos=(5, 29)), "not sorted by (tid, pos) at record 5"),
+        (dict(tid=(5, 9), blk_len=(1, 19)), "record 2: run lengths do not sum to alen"),
+        # ... and of two checks that fail for one record, the first in the validator's order
+        (dict(tid=(5, 0), pos=(5, -1)), "record 5: negative position"),
+        (dict(pos=(4, -9)), "record 4: negative position"),
+    ]
+    for changed, want in cases:
+        got = stage(**changed)
+        assert got is not None and want in got, (changed, want, got)
+    # contig starts are not defects: positions start over where the contig changes, and only there
+    assert stage(pos=(3, 0)) is None and stage(pos=(7, 0)) is None
 
 
 def test_stratified_with_many_rows(pa, oracle):
