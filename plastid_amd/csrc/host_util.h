@@ -1,5 +1,6 @@
 // host_util.h -- host-side helpers of the counting engine that do not touch HIP: the worker pool behind
-// parallel_chunks, the galloping lower bound of the plan build, a vector without zero-fill.  Plain C++17, so that
+// parallel_chunks, the galloping lower bound of the plan build, a vector without zero-fill, the host's look at the
+// contig column of caller-owned records (scan_contigs).  Plain C++17, so that
 // tests/test_host_logic.py can compile tests/host_util_test.cpp against it on a machine without a GPU.
 #pragma once
 #include <algorithm>
@@ -132,4 +133,50 @@ template <typename F> static void parallel_chunks(int64_t n, int nthreads, F fn)
     th.reserve((size_t)nthreads);
     for (int t = 0; t < nthreads; ++t) th.emplace_back(part, t);
     for (auto &x : th) x.join();
+}
+
+// The contig column of caller-owned records, examined where it is: `bounds[t]` = first record of contig t (t = 0 ..
+// ntid) and, returned, the first record whose contig is out of range or lower than its predecessor's (n: none; the
+// bounds then describe the records before it).  Sorted, the column changes value at most ntid times: the pass is a
+// streaming comparison of neighbours, and only a block that holds a change is looked at record by record.
+static int64_t scan_contigs(const int32_t *tid, int64_t n, int32_t ntid, int threads, std::vector<int64_t> &bounds) {
+    bounds.assign((size_t)ntid + 1, 0);
+    if (n <= 0) return 0;
+    struct Part { std::vector<std::pair<int64_t, int32_t>> changes; int64_t bad = INT64_MAX; };
+    const int T = std::max(1, threads);
+    std::vector<Part> parts((size_t)T);
+    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
+        Part &pt = parts[(size_t)t];
+        int64_t i = b;
+        if (i == 0 && i < en) {
+            if ((uint32_t)tid[0] >= (uint32_t)ntid) { pt.bad = 0; return; }
+            pt.changes.emplace_back(0, tid[0]);
+            i = 1;
+        }
+        constexpr int64_t kBlock = 4096;
+        while (i < en) {
+            const int64_t e2 = std::min(en, i + kBlock);
+            uint32_t diff = 0;
+            for (int64_t j = i; j < e2; ++j) diff |= (uint32_t)(tid[j] ^ tid[j - 1]);
+            if (diff)
+                for (int64_t j = i; j < e2; ++j)
+                    if (tid[j] != tid[j - 1]) {
+                        if (tid[j] < tid[j - 1] || tid[j] < 0 || tid[j] >= ntid) { pt.bad = j; return; }
+                        pt.changes.emplace_back(j, tid[j]);
+                    }
+            i = e2;
+        }
+    });
+    int64_t bad = INT64_MAX;
+    for (const auto &pt : parts) bad = std::min(bad, pt.bad);
+    const int64_t n_ok = std::min(n, bad);
+    int32_t last = -1;   // bounds are written up to this contig
+    for (const auto &pt : parts)
+        for (const auto &c : pt.changes) {
+            if (c.first >= n_ok) break;
+            for (int32_t t = last + 1; t <= c.second; ++t) bounds[(size_t)t] = c.first;
+            last = c.second;
+        }
+    for (int32_t t = last + 1; t <= ntid; ++t) bounds[(size_t)t] = n_ok;
+    return n_ok;
 }

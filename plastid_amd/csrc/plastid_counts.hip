@@ -74,9 +74,9 @@ int fail(int code, const char *fmt, ...) {
                         #expr, hipGetErrorString(err__), __FILE__, __LINE__);                      \
     } while (0)
 
-// Large device blocks that outlive their engine: an engine that goes away hands the idle large blocks of its pool to
-// this process-wide reservoir (per device, by rounded size) instead of freeing them, and the pool of a later engine looks
-// here before it allocates.  Engines come and go -- one per BAMGenomeArray, one per config in bench.py -- and on some
+// Device blocks that outlive their engine: an engine that goes away hands the idle blocks of its pool to this
+// process-wide reservoir (per device, by size) instead of freeing them, and the pool of a later engine looks here
+// before it allocates.  Engines come and go -- one per BAMGenomeArray, one per config in bench.py -- and on some
 // boxes of the pool a hipMalloc that follows the hipFree of tens of GB takes SECONDS (measured round 5: 1.5 s and 2.1 s
 // for the first large buffer of a staging call right after an engine of the same size was destroyed; milliseconds when
 // nothing had been freed).  Only blocks of a destroyed engine get here -- its streams are drained by then, so nothing
@@ -144,12 +144,16 @@ struct DevPool {
         return (bytes + step - 1) / step * step;
     }
     void *take(int c) {
-        std::lock_guard<std::mutex> g(m);
-        if (bins[c].empty()) return nullptr;
-        void *p = bins[c].back();
-        bins[c].pop_back();
-        cached -= class_bytes(c);
-        return p;
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (!bins[c].empty()) {
+                void *p = bins[c].back();
+                bins[c].pop_back();
+                cached -= class_bytes(c);
+                return p;
+            }
+        }
+        return BigReservoir::get().take(device, class_bytes(c));
     }
     bool give(void *p, int c) {
         std::lock_guard<std::mutex> g(m);
@@ -178,12 +182,13 @@ struct DevPool {
         big_cached += rounded;
         return true;
     }
-    // keep_big: the engine is going away with its streams drained -- the large blocks go to the process-wide reservoir
+    // keep_big: the engine is going away with its streams drained -- its blocks go to the process-wide reservoir
     void drain(bool keep_big) {
         std::lock_guard<std::mutex> g(m);
-        for (auto &b : bins) {
-            for (void *p : b) (void)hipFree(p);
-            b.clear();
+        for (int c = 0; c < kClasses; ++c) {
+            for (void *p : bins[c])
+                if (!keep_big || !BigReservoir::get().give(device, p, class_bytes(c))) (void)hipFree(p);
+            bins[c].clear();
         }
         cached = 0;
         for (auto &kv : big)
@@ -301,13 +306,13 @@ template <typename T> struct DevView {
 // been taken.
 struct UploadJob { void *dst; const void *src; size_t bytes; };
 struct UploadRing {
-    static constexpr int kSlots = 8, kThreads = 6;
+    static constexpr int kSlots = 12, kThreadsUp = 6, kThreadsDown = 10;   // (down: the destination's pages are often touched for the first time)
     static constexpr size_t kPiece = (size_t)16 << 20;
     uint8_t *slot[kSlots] = {};
     hipEvent_t ev[kSlots] = {};
     hipStream_t stream = nullptr;
     std::mutex busy;   // one transfer at a time per device
-    // One ring per device for the life of the process: page-locking its 128 MB costs as much as staging ten million
+    // One ring per device for the life of the process: page-locking its 192 MB costs as much as staging ten million
     // records, and engines come and go (one per BAMGenomeArray).
     static UploadRing &of(int device) {
         static UploadRing rings[16];
@@ -330,15 +335,25 @@ struct UploadRing {
             return PC_OK;
         }
         piece = std::max<size_t>(1, std::min(piece, kPiece));
-        for (int k = 0; k < kSlots; ++k) {
+        std::vector<UploadJob> pieces;
+        for (const auto &j : jobs) {
+            if (j.bytes == 0) continue;
+            // host memory that is page-locked already (hipHostMalloc, hipHostRegister, a pinned torch tensor) needs no ring
+            hipPointerAttribute_t attr;
+            const void *host_side = down ? j.dst : j.src;
+            if (!always && hipPointerGetAttributes(&attr, host_side) == hipSuccess && attr.type == hipMemoryTypeHost) {
+                HIP_TRY(hipMemcpyAsync(j.dst, j.src, j.bytes, kind, stream));
+                continue;
+            }
+            (void)hipGetLastError();   // (an ordinary pointer: some runtimes report it as an error)
+            for (size_t off = 0; off < j.bytes; off += piece)
+                pieces.push_back({(uint8_t *)j.dst + off, (const uint8_t *)j.src + off, std::min(piece, j.bytes - off)});
+        }
+        const size_t np = pieces.size();
+        for (int k = 0; k < kSlots && np > 0; ++k) {
             if (!slot[k]) HIP_TRY(hipHostMalloc((void **)&slot[k], kPiece, hipHostMallocDefault));
             if (!ev[k]) HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
         }
-        std::vector<UploadJob> pieces;
-        for (const auto &j : jobs)
-            for (size_t off = 0; off < j.bytes; off += piece)
-                pieces.push_back({(uint8_t *)j.dst + off, (const uint8_t *)j.src + off, std::min(piece, j.bytes - off)});
-        const size_t np = pieces.size();
         std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[np]);   // up: DMA queued; down: copied out
         for (size_t k = 0; k < np; ++k) done[k].store(0, std::memory_order_relaxed);
         std::atomic<size_t> next{0};
@@ -370,64 +385,18 @@ struct UploadRing {
                 done[p].store(1, std::memory_order_release);   // (also after a failure: whoever waits for this slot goes on and ends)
             }
         };
-        int T = kThreads;
+        int T = down ? kThreadsDown : kThreadsUp;
         if (const char *env = getenv("PC_STAGE_UPLOAD_THREADS")) T = std::max(1, std::min(kSlots - 1, atoi(env)));
         T = (int)std::min<size_t>((size_t)T, np);
         std::vector<std::thread> th;
         for (int t = 1; t < T; ++t) th.emplace_back(work);
-        work();
+        if (np > 0) work();
         for (auto &x : th) x.join();
         const hipError_t he = hipStreamSynchronize(stream);
         if (failed.load() || he != hipSuccess) { (void)hipGetLastError(); return fail(PC_ERR_HIP, "transfer ring: a copy failed"); }
         return PC_OK;
     }
 };
-
-// The contig column of caller-owned records, examined where it is: `bounds[t]` = first record of contig t (t = 0 ..
-// ntid) and, returned, the first record whose contig is out of range or lower than its predecessor's (n: none; the
-// bounds then describe the records before it).  Sorted, the column changes value at most ntid times: the pass is a
-// streaming comparison of neighbours, and only a block that holds a change is looked at record by record.
-static int64_t scan_contigs(const int32_t *tid, int64_t n, int32_t ntid, int threads, std::vector<int64_t> &bounds) {
-    bounds.assign((size_t)ntid + 1, 0);
-    if (n <= 0) return 0;
-    struct Part { std::vector<std::pair<int64_t, int32_t>> changes; int64_t bad = INT64_MAX; };
-    const int T = std::max(1, threads);
-    std::vector<Part> parts((size_t)T);
-    parallel_chunks(n, T, [&](int t, int64_t b, int64_t en) {
-        Part &pt = parts[(size_t)t];
-        int64_t i = b;
-        if (i == 0 && i < en) {
-            if ((uint32_t)tid[0] >= (uint32_t)ntid) { pt.bad = 0; return; }
-            pt.changes.emplace_back(0, tid[0]);
-            i = 1;
-        }
-        constexpr int64_t kBlock = 4096;
-        while (i < en) {
-            const int64_t e2 = std::min(en, i + kBlock);
-            uint32_t diff = 0;
-            for (int64_t j = i; j < e2; ++j) diff |= (uint32_t)(tid[j] ^ tid[j - 1]);
-            if (diff)
-                for (int64_t j = i; j < e2; ++j)
-                    if (tid[j] != tid[j - 1]) {
-                        if (tid[j] < tid[j - 1] || tid[j] < 0 || tid[j] >= ntid) { pt.bad = j; return; }
-                        pt.changes.emplace_back(j, tid[j]);
-                    }
-            i = e2;
-        }
-    });
-    int64_t bad = INT64_MAX;
-    for (const auto &pt : parts) bad = std::min(bad, pt.bad);
-    const int64_t n_ok = std::min(n, bad);
-    int32_t last = -1;   // bounds are written up to this contig
-    for (const auto &pt : parts)
-        for (const auto &c : pt.changes) {
-            if (c.first >= n_ok) break;
-            for (int32_t t = last + 1; t <= c.second; ++t) bounds[(size_t)t] = c.first;
-            last = c.second;
-        }
-    for (int32_t t = last + 1; t <= ntid; ++t) bounds[(size_t)t] = n_ok;
-    return n_ok;
-}
 
 // CPUs this process may actually use: the smaller of the hardware threads, the affinity mask and the
 // container's CFS quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  Pools sized beyond the quota only

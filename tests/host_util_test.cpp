@@ -48,6 +48,26 @@ int main() {
     pv.resize(2000);
     for (int i = 0; i < 1000; ++i) if (pv[(size_t)i] != i) ++bad;
     if (pv[1000] != 7) ++bad;
+    // scan_contigs == a record-by-record walk: bounds of the sorted prefix, first record out of order / out of range
+    for (int it = 0; it < 3000; ++it) {
+        const int ntid = 1 + (int)(rng() % 9);
+        const int64_t n = (int64_t)(rng() % (it % 50 == 0 ? 30000 : 300));
+        std::vector<int32_t> tid((size_t)n);
+        int32_t cur = 0;
+        for (auto &x : tid) { if (rng() % 17 == 0) cur = std::min<int32_t>(ntid - 1, cur + (int32_t)(rng() % 3)); x = cur; }
+        for (int d = (int)(rng() % 3); d > 0 && n > 0; --d)   // defects: a contig out of range, a step back
+            tid[(size_t)(rng() % (uint64_t)n)] = (rng() & 1) ? (int32_t)(rng() % 5) - 2 : ntid + (int32_t)(rng() % 2);
+        int64_t want_ok = n;
+        for (int64_t i = 0; i < n; ++i)
+            if (tid[(size_t)i] < 0 || tid[(size_t)i] >= ntid || (i > 0 && tid[(size_t)i] < tid[(size_t)i - 1])) { want_ok = i; break; }
+        std::vector<int64_t> want((size_t)ntid + 1, want_ok), got;
+        for (int t = 0; t <= ntid; ++t)
+            for (int64_t i = 0; i < want_ok; ++i)
+                if (tid[(size_t)i] >= t) { want[(size_t)t] = i; break; }
+        const int64_t got_ok = scan_contigs(tid.data(), n, ntid, 1 + it % 7, got);
+        if (got_ok != want_ok || got != want) ++bad;
+    }
+    printf("scan_contigs: bad %ld\n", bad);
     printf("host_util: %s\n", bad ? "FAILED" : "ok");
     return bad != 0;
 }

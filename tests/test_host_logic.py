@@ -419,7 +419,9 @@ def test_usable_cpus_respects_the_container_limits():
 def test_host_helpers_of_the_engine(tmp_path):
     """plastid_amd/csrc/host_util.h is plain C++: the worker pool behind the host passes (regions of every width, nested
     regions, concurrent callers), the galloping lower bound of the plan build against std::lower_bound for every hint,
-    and the vector without zero-fill -- compiled with the host compiler and run here."""
+    the vector without zero-fill, and the host's look at the contig column of caller-owned records (scan_contigs: the
+    record bounds of every contig and the first record out of order or out of range, against a record-by-record walk,
+    for every thread count) -- compiled with the host compiler and run here."""
     import shutil
     import subprocess
     cxx = shutil.which("g++") or shutil.which("c++")
