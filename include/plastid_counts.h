@@ -99,6 +99,10 @@ int pc_reload_knobs(pc_engine *e);
  *   nblk       number of maximal runs of contiguous aligned positions (0 iff L==0)
  *   nrun,blk_* runs (start,len) of every record with nblk >= 2, record after
  *              record; a record with nblk == 1 is the implicit run [pos, pos+L)
+ *
+ * The arrays are the caller's (pageable or page-locked host memory) and are only read: they cross PCIe as they are
+ * and are validated on the GPU.  A file that breaks the contract is refused (PC_ERR_ARG; PC_ERR_UNSORTED for records
+ * out of (tid, pos) order) with the defect of the LOWEST record index in pc_last_error(), and nothing is staged.
  */
 int pc_clear_alignments(pc_engine *e);
 int pc_add_alignment_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,

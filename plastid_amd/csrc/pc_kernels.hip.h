@@ -1487,7 +1487,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
         // write every queried segment slice straight into the caller's layout (chain offset,
         // 5'->3' reversal, int64/float64, normalisation) -- SegmentChain.get_counts,
         // roitools.pyx:3259-3271
-        for (uint32_t oi = w.op_begin; oi < w.op_end; ++oi) {
+        // several rows: the slices are short (a 150-nt exon against 256 lanes) -- every wave takes slices of its own
+        // (C5: 3.45 -> 3.39 ms)
+        const bool per_wave = B16 && WG > 64;
+        const uint32_t op_first = per_wave ? w.op_begin + (threadIdx.x >> 6) : w.op_begin, op_step = per_wave ? WG / 64 : 1;
+        const int lane0 = per_wave ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lanes = per_wave ? 64 : WG;
+        for (uint32_t oi = op_first; oi < w.op_end; oi += op_step) {
             const uint32_t k = oi - w.op_begin;
             const OutPiece o = k < (uint32_t)kOpStage ? s_op[k] : opieces[oi];
             const int rel = o.start - w.win_start;
@@ -1498,7 +1503,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
                 // several rows (stratified rule): a lane keeps its position and walks down the rows with two
                 // pointer increments per element -- a row-major loop pays the 64-bit address set-up of a row
                 // for 1.2 KB of output (a 150-nt exon), eleven times per piece
-                for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) {
+                for (int i = i0 + lane0; i < i1; i += lanes) {
                     typename OutT_<OUTMODE>::type *dstp = out + o.out_off + (int64_t)o.step * i;
                     if (B16) {
                         const uint16_t *srcp = (const uint16_t *)bins + slot * mp.rows * G + rel + i;
@@ -1523,10 +1528,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MULTI ? 5 : 
                     const uint16_t *srcb = (const uint16_t *)bins + (slot * mp.rows + r) * G + rel;
                     typename OutT_<OUTMODE>::type *dst = out + o.out_off + (int64_t)r * o.row_stride;
                     if (o.step != 0) {
-                        for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) dst[(int64_t)o.step * i] = out_conv<OUTMODE>((uint32_t)srcb[i], norm_sum);
+                        for (int i = i0 + lane0; i < i1; i += lanes) dst[(int64_t)o.step * i] = out_conv<OUTMODE>((uint32_t)srcb[i], norm_sum);
                     } else {
                         unsigned long long part = 0;
-                        for (int i = i0 + (int)threadIdx.x; i < i1; i += WG) part += srcb[i];
+                        for (int i = i0 + lane0; i < i1; i += lanes) part += srcb[i];
                         out_add<OUTMODE>(dst, part);
                     }
                 }
