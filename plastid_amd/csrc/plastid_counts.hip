@@ -758,6 +758,29 @@ int refresh_file_views(pc_engine *e) {
     return PC_OK;
 }
 
+// Window size G of a plan: the positions a workgroup of k_hist_point bins in LDS (per strand mode and row).
+//   one row     32-bit bins, 24 KiB of them (six workgroups per CU), a power of two; a SPARSE annotation (queried intervals
+//               a quarter of a window long on average: exons of a human-scale genome) takes 3/8 of that -- fewer bins
+//               to clear and read per exon, windows that start closer to their records (C4: 2 048 -> 1.01, 1 024 -> 0.94,
+//               768 -> 0.90 - 0.92 ms; below 768 twice the time; the dense C2 is flat from 1 536 to 3 072 and keeps 2 048)
+//   more rows   (the stratified rule) 16-bit bins, 36 KiB of them, any multiple of 256: a plan of 11 rows gets 768 positions
+//               (C5: 512 -> 3.38, 640 -> 3.27, 768 -> 3.21, 896 -> 3.21 ms on one box: a third fewer windows outweigh the
+//               fifth workgroup per CU they cost)
+// `knob`: PC_TILE_G, any multiple of 256 up to twice the budget.
+static int choose_window(int rows, int nmodes, unsigned long long n_iv, unsigned long long iv_len, int knob, int64_t *budget) {
+    const int64_t bin_bytes = rows > 1 ? 2 : 4;
+    const int64_t g = ((rows > 1 ? 36 : 24) * 1024) / (bin_bytes * nmodes * rows);
+    int G = 256;
+    if (rows > 1) G = (int)std::max<int64_t>(256, std::min<int64_t>(4096, g / 256 * 256));
+    else {
+        while (G * 2 <= g && G * 2 <= 4096) G *= 2;
+        if (G >= 2048 && n_iv > 0 && iv_len * 4 < n_iv * (unsigned long long)G) G = G / 8 * 3;
+    }
+    if (knob && knob <= 2 * g) G = knob;
+    *budget = g;
+    return G;
+}
+
 struct StageClock {
     bool on = getenv("PC_STAGE_TIMING") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -894,17 +917,9 @@ int plan_build_gpu(pc_engine *e, pc_plan *p, int64_t nseg, const int32_t *tid, c
     for (int m = 0; m < kModes; ++m) nmodes += (h.modes >> m) & 1;
     if (nmodes == 0) nmodes = 1;
     {   // window size: as the host builder
-        const int64_t bin_bytes = rows > 1 ? 2 : 4;   // several rows (the stratified rule): 16-bit bins, two positions per LDS word (k_hist_point)
-        int64_t g = (24 * 1024) / (bin_bytes * nmodes * rows);
-        int G = 256;
-        int gmax = 4096;
-        while (G * 2 <= g && G * 2 <= gmax) G *= 2;
-        // a SPARSE annotation (queried intervals a quarter of a window long on average: exons of a human-scale genome) takes
-        // half the window: fewer bins to clear and read per exon, windows that start closer to their records (C4: 1.01 -> 0.96 ms;
-        // the dense C2 loses 5 % at the smaller window and keeps the large one)
-        if (rows == 1 && G >= 2048 && h.n_iv > 0 && h.iv_len * 4 < h.n_iv * (unsigned long long)G) G /= 2;
-        if (e->knobs.tile_g && e->knobs.tile_g <= 2 * g) G = e->knobs.tile_g;
-        if (bin_bytes * nmodes * rows * G > 150 * 1024) return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows);
+        int64_t budget = 0;
+        const int G = choose_window(rows, nmodes, h.n_iv, h.iv_len, e->knobs.tile_g, &budget);
+        if ((rows > 1 ? 2 : 4) * (int64_t)nmodes * rows * G > 150 * 1024) return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows);
         p->G = G;
     }
     const int G = p->G;
@@ -2116,21 +2131,12 @@ int pc_plan_create(pc_engine *e, int64_t nseg, const int32_t *tid, const int64_t
     int nmodes = 0;
     for (int m = 0; m < kModes; ++m) nmodes += (modes >> m) & 1;
     if (nmodes == 0) nmodes = 1;
-    // window size: 24 KiB of LDS bins (uint32 per mode x row x position) -- small enough for six
-    // workgroups per CU; the per-call hard limit is checked in pc_count
-    {
-        const int64_t bin_bytes = rows > 1 ? 2 : 4;   // several rows (the stratified rule): 16-bit bins, two positions per LDS word (k_hist_point)
-        int64_t g = (24 * 1024) / (bin_bytes * nmodes * rows);
-        int G = 256;
-        int gmax = 4096;
-        while (G * 2 <= g && G * 2 <= gmax) G *= 2;
-        {   // (as the GPU builder: a sparse annotation takes half the window)
-            unsigned long long iv_len = 0;
-            for (const Iv &iv : ivs) iv_len += (unsigned long long)(iv.e - iv.s);
-            if (rows == 1 && G >= 2048 && !ivs.empty() && iv_len * 4 < (unsigned long long)ivs.size() * (unsigned long long)G) G /= 2;
-        }
-        if (e->knobs.tile_g && e->knobs.tile_g <= 2 * g) G = e->knobs.tile_g; // tuning knob: any multiple of 256 within the budget
-        if (bin_bytes * nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
+    {   // window size (the per-call hard limit of LDS is checked in pc_count)
+        unsigned long long iv_len = 0;
+        for (const Iv &iv : ivs) iv_len += (unsigned long long)(iv.e - iv.s);
+        int64_t budget = 0;
+        const int G = choose_window(rows, nmodes, (unsigned long long)ivs.size(), iv_len, e->knobs.tile_g, &budget);
+        if ((rows > 1 ? 2 : 4) * (int64_t)nmodes * rows * G > 150 * 1024) { delete p; return fail(PC_ERR_ARG, "pc_plan_create: too many rows (%d) for the LDS window", rows); }
         p->G = G;
     }
     const int G = p->G;
