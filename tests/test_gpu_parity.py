@@ -527,6 +527,63 @@ def test_staging_rejects_every_defect_of_the_columns(pa, monkeypatch, slice_reco
     assert stage(pos=(3, 0)) is None and stage(pos=(7, 0)) is None
 
 
+def test_transfer_ring_large_files_pinned_memory_and_two_engines(pa, monkeypatch):
+    """Staging and read-back of a file large enough for the ring of page-locked pieces by itself (12 M records: 96 MB of
+    columns up, 100 MB of counts down), against the same file sent in 40-byte pieces; page-locked caller memory (a pinned
+    torch tensor as the output buffer) bypasses the ring; two engines staging and counting on two host threads at once --
+    one ring per device, one transfer at a time -- give what each gives alone; and an engine made after another was
+    destroyed (its device blocks come from the process-wide reservoir) counts the same."""
+    import threading
+    import torch
+    from plastid_amd.engine import Engine
+    from plastid_amd.packing import PackedAlignments
+    n = 12_000_000
+    rng = np.random.default_rng(5)
+    pos = np.sort(rng.integers(0, 12_500_000, n)).astype(np.int32)
+    alen = rng.integers(25, 36, n).astype(np.uint16)
+    rev = rng.random(n) < 0.5
+    tid = (pos >= 6_000_000).astype(np.int32)
+    pos = np.where(tid == 1, pos - 6_000_000, pos).astype(np.int32)
+    reads = PackedAlignments.from_ungapped(tid, pos, alen, rev, references=["a", "b"], lengths=[6_100_000, 6_600_000], validate=False)
+    seg = dict(tid=np.array([0, 1], np.int32), start=np.array([0, 0], np.int64), end=np.array([6_050_000, 6_550_000], np.int64),
+               strand=np.array([3, 3], np.uint8))     # PC_STRAND_UNS: reads of both strands
+    seg["out_off"] = np.array([0, 6_050_000], np.int64)
+    seg["out_step"] = np.array([1, 1], np.int8)
+    seg["row_stride"] = np.array([0, 0], np.int64)
+    out_elems = 12_600_000
+
+    def count(out=None):
+        eng = Engine(0)
+        eng.set_alignments([reads])
+        pa.FivePrimeMapFactory(3)._configure(eng)
+        plan = eng.plan(seg["tid"], seg["start"], seg["end"], seg["strand"], seg["out_off"], seg["out_step"], seg["row_stride"], out_elems, 1)
+        got = plan.count(np.int64, out=out)
+        res = got.copy()
+        plan.close()
+        eng.close()
+        return res
+
+    want = count()
+    # every read lands somewhere inside the two segments (5' end + 3 for forward reads, 3' end - 3 for reverse ones)
+    assert want.sum() == n
+    monkeypatch.setenv("PC_STAGE_SLICE", "10")            # 40-byte pieces up, 40 KiB pieces down
+    small = count()
+    monkeypatch.delenv("PC_STAGE_SLICE")
+    assert np.array_equal(small, want)
+    pinned = torch.zeros(out_elems, dtype=torch.int64, pin_memory=True)
+    assert np.array_equal(count(out=pinned.numpy()), want)
+    results = [None, None]
+    def worker(k):
+        results[k] = count()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert np.array_equal(results[0], want) and np.array_equal(results[1], want)
+    assert np.array_equal(count(), want)
+
+
 def test_stratified_with_many_rows(pa, oracle):
     """36 length rows x both strands need more than 64 KiB of LDS bins per window: gfx950 lets a
     workgroup have it."""
