@@ -4208,18 +4208,24 @@ int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *
     hipStream_t st = b->e->stream;
     BamClock rclk;
     const size_t n = (size_t)b->n, m = (size_t)b->nrun;
+    // (through the ring of page-locked pieces when the columns are large: the caller's arrays are pageable, see UploadRing)
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<UploadJob> jobs;
     if (n) {
-        HIP_TRY(hipMemcpyAsync(tid, b->tid.p, n * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(pos, b->pos.p, n * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(alen, b->alen.p, n * 2, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(flags, b->flags.p, n, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(nblk, b->nblk.p, n, hipMemcpyDeviceToHost, st));
+        jobs.push_back({tid, b->tid.p, n * 4});
+        jobs.push_back({pos, b->pos.p, n * 4});
+        jobs.push_back({alen, b->alen.p, n * 2});
+        jobs.push_back({flags, b->flags.p, n});
+        jobs.push_back({nblk, b->nblk.p, n});
     }
     if (m) {
-        HIP_TRY(hipMemcpyAsync(blk_start, b->blk_start.p, m * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(blk_len, b->blk_len.p, m * 4, hipMemcpyDeviceToHost, st));
+        jobs.push_back({blk_start, b->blk_start.p, m * 4});
+        jobs.push_back({blk_len, b->blk_len.p, m * 4});
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    {
+        const int rc = UploadRing::of(b->e->device).run(b->e->device, jobs, UploadRing::kPiece, false, true);
+        if (rc != PC_OK) return rc;
+    }
     rclk.lap("columns to the host");
     for (size_t k = 0; k < b->wide_idx.size(); ++k) { wide_idx[k] = b->wide_idx[k]; wide_alen[k] = b->wide_alen[k]; wide_nblk[k] = b->wide_nblk[k]; }
     return PC_OK;
@@ -4230,13 +4236,12 @@ int pc_bam_read_sam(pc_bam *b, uint16_t *flag, uint8_t *mapq, int32_t *lseq) {
     HIP_TRY(hipSetDevice(b->e->device));
     hipStream_t st = b->e->stream;
     const size_t n = (size_t)b->n;
-    if (n) {
-        if (flag) HIP_TRY(hipMemcpyAsync(flag, b->flag16.p, n * 2, hipMemcpyDeviceToHost, st));
-        if (mapq) HIP_TRY(hipMemcpyAsync(mapq, b->mapq.p, n, hipMemcpyDeviceToHost, st));
-        if (lseq) HIP_TRY(hipMemcpyAsync(lseq, b->lseq.p, n * 4, hipMemcpyDeviceToHost, st));
-    }
     HIP_TRY(hipStreamSynchronize(st));
-    return PC_OK;
+    std::vector<UploadJob> jobs;
+    if (n && flag) jobs.push_back({flag, b->flag16.p, n * 2});
+    if (n && mapq) jobs.push_back({mapq, b->mapq.p, n});
+    if (n && lseq) jobs.push_back({lseq, b->lseq.p, n * 4});
+    return UploadRing::of(b->e->device).run(b->e->device, jobs, UploadRing::kPiece, false, true);
 }
 
 static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded,
