@@ -81,6 +81,10 @@ int pc_device_count(void);
 int pc_create(int device, pc_engine **out);
 /* Every plan of the engine must have been destroyed first (plans return their device blocks to it). */
 int pc_destroy(pc_engine *e);
+/* A destroyed engine leaves its idle device blocks to the process (up to PC_POOL_RESERVOIR_GB, default 96) for the next
+ * engine on the same device -- BAMGenomeArray objects come and go, and allocating tens of GB again can take seconds.
+ * This returns them to the driver (no reference counterpart; for callers that share the GPU with other libraries). */
+int pc_release_cached_memory(int device);
 /* The PC_* tuning/diagnostic environment knobs are read once, by pc_create;
  * this re-reads them (tests and experiments only -- no reference counterpart). */
 int pc_reload_knobs(pc_engine *e);

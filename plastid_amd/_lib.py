@@ -59,6 +59,7 @@ SIGNATURES = {
     "pc_count": (_int, [_vp, _vp, _int]),
     "pc_sync": (_int, [_vp]),
     "pc_query_segment": (_int, [_vp, _i32, _i64, _i64, ctypes.c_uint8, _int, _int, _vp]),
+    "pc_release_cached_memory": (_int, [_int]),
     "pc_read_counts": (_int, [_vp, _vp, _vp, _i64]),
     "pc_counts_device_ptr": (_vp, [_vp]),
     "pc_stream": (_vp, [_vp]),

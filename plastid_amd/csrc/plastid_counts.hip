@@ -1296,6 +1296,14 @@ int pc_destroy(pc_engine *e) {
     return PC_OK;
 }
 
+int pc_release_cached_memory(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(PC_ERR_ARG, "pc_release_cached_memory: device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    BigReservoir::get().free_all(device);
+    return PC_OK;
+}
+
 int pc_reload_knobs(pc_engine *e) {
     if (!e) return fail(PC_ERR_ARG, "engine is NULL");
     e->knobs.load();

@@ -26,6 +26,12 @@ def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+def release_cached_memory(device=0):
+    """Return to the driver the device memory that closed engines left to the process for the next engine
+    (``pc_release_cached_memory``) -- for callers that share the GPU with other libraries."""
+    check(_lib.load().pc_release_cached_memory(int(device)), "pc_release_cached_memory")
+
+
 class Engine(object):
     """One GPU's counting engine (``pc_engine``)."""
 

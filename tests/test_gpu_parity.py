@@ -582,6 +582,13 @@ def test_transfer_ring_large_files_pinned_memory_and_two_engines(pa, monkeypatch
         t.join()
     assert np.array_equal(results[0], want) and np.array_equal(results[1], want)
     assert np.array_equal(count(), want)
+    # ... and after the process has given the kept blocks back to the driver
+    import torch.cuda
+    from plastid_amd.engine import release_cached_memory
+    free_before = torch.cuda.mem_get_info(0)[0]
+    release_cached_memory(0)
+    assert torch.cuda.mem_get_info(0)[0] > free_before + (200 << 20)       # the records alone were 96 MB + 48 MB + ...
+    assert np.array_equal(count(), want)
 
 
 def test_stratified_with_many_rows(pa, oracle):
