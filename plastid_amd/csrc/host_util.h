@@ -1,6 +1,6 @@
 // host_util.h -- host-side helpers of the counting engine that do not touch HIP: the worker pool behind
 // parallel_chunks, the galloping lower bound of the plan build, a vector without zero-fill, the host's look at the
-// contig column of caller-owned records (scan_contigs).  Plain C++17, so that
+// contig column of caller-owned records (scan_contigs), the window size of a plan (choose_window).  Plain C++17, so that
 // tests/test_host_logic.py can compile tests/host_util_test.cpp against it on a machine without a GPU.
 #pragma once
 #include <algorithm>
@@ -179,4 +179,27 @@ static int64_t scan_contigs(const int32_t *tid, int64_t n, int32_t ntid, int thr
         }
     for (int32_t t = last + 1; t <= ntid; ++t) bounds[(size_t)t] = n_ok;
     return n_ok;
+}
+
+// Window size G of a plan: the positions a workgroup of k_hist_point bins in LDS (per strand mode and row).
+//   one row     32-bit bins, 24 KiB of them (six workgroups per CU), a power of two; a SPARSE annotation (queried intervals
+//               a quarter of a window long on average: exons of a human-scale genome) takes 3/8 of that -- fewer bins
+//               to clear and read per exon, windows that start closer to their records (C4: 2 048 -> 1.01, 1 024 -> 0.94,
+//               768 -> 0.90 - 0.92 ms; below 768 twice the time; the dense C2 is flat from 1 536 to 3 072 and keeps 2 048)
+//   more rows   (the stratified rule) 16-bit bins, 36 KiB of them, any multiple of 256: a plan of 11 rows gets 768 positions
+//               (C5: 512 -> 3.38, 640 -> 3.27, 768 -> 3.21, 896 -> 3.21 ms on one box: a third fewer windows outweigh the
+//               fifth workgroup per CU they cost)
+// `knob`: PC_TILE_G, any multiple of 256 up to twice the budget.
+static int choose_window(int rows, int nmodes, unsigned long long n_iv, unsigned long long iv_len, int knob, int64_t *budget) {
+    const int64_t bin_bytes = rows > 1 ? 2 : 4;
+    const int64_t g = ((rows > 1 ? 36 : 24) * 1024) / (bin_bytes * nmodes * rows);
+    int G = 256;
+    if (rows > 1) G = (int)std::max<int64_t>(256, std::min<int64_t>(4096, g / 256 * 256));
+    else {
+        while (G * 2 <= g && G * 2 <= 4096) G *= 2;
+        if (G >= 2048 && n_iv > 0 && iv_len * 4 < n_iv * (unsigned long long)G) G = G / 8 * 3;
+    }
+    if (knob && knob <= 2 * g) G = knob;
+    *budget = g;
+    return G;
 }

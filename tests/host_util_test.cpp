@@ -68,6 +68,20 @@ int main() {
         if (got_ok != want_ok || got != want) ++bad;
     }
     printf("scan_contigs: bad %ld\n", bad);
+    // choose_window: the window sizes the published numbers were measured with, and the knob's limits
+    {
+        int64_t g = 0;
+        if (choose_window(1, 2, 21031, 33373947ull, 0, &g) != 2048 || g != 3072) ++bad;          // C2 / C3: dense, stranded
+        if (choose_window(1, 2, 479339, 91633228ull, 0, &g) != 768) ++bad;                       // C4: exons, a quarter of a window or less
+        if (choose_window(1, 1, 10, 100000ull, 0, &g) != 4096 || g != 6144) ++bad;               // one strand mode: capped at 4 096
+        if (choose_window(11, 2, 479339, 91633228ull, 0, &g) != 768 || g != 837) ++bad;          // C5: 16-bit bins, 36 KiB, multiples of 256
+        if (choose_window(36, 2, 100, 100000ull, 0, &g) != 256) ++bad;                           // many rows: never below 256
+        if (choose_window(3, 1, 100, 100000ull, 0, &g) != 4096) ++bad;
+        if (choose_window(11, 2, 100, 100000ull, 512, &g) != 512) ++bad;                         // PC_TILE_G within twice the budget
+        if (choose_window(11, 2, 100, 100000ull, 4096, &g) != 768) ++bad;                        // ... and beyond it: ignored
+        if (choose_window(1, 2, 0, 0ull, 0, &g) != 2048) ++bad;                                  // no intervals: not sparse
+    }
+    printf("choose_window: bad %ld\n", bad);
     printf("host_util: %s\n", bad ? "FAILED" : "ok");
     return bad != 0;
 }

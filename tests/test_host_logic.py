@@ -421,7 +421,8 @@ def test_host_helpers_of_the_engine(tmp_path):
     regions, concurrent callers), the galloping lower bound of the plan build against std::lower_bound for every hint,
     the vector without zero-fill, and the host's look at the contig column of caller-owned records (scan_contigs: the
     record bounds of every contig and the first record out of order or out of range, against a record-by-record walk,
-    for every thread count) -- compiled with the host compiler and run here."""
+    for every thread count) and the window size of a plan (choose_window: the sizes the published numbers were measured
+    with, the knob's limits) -- compiled with the host compiler and run here."""
     import shutil
     import subprocess
     cxx = shutil.which("g++") or shutil.which("c++")
