@@ -8,7 +8,7 @@
 // Host-side structure, in file order:
 //   DevPool / DevBuf / PinnedBuf   device blocks recycled per engine, one page-locked buffer: a plan of
 //                                  one short segment costs API calls, not bytes
-//   UploadRing / scan_contigs      the caller's columns cross PCIe through a ring of page-locked pieces; the
+//   TransferRing / scan_contigs      the caller's columns cross PCIe through a ring of page-locked pieces; the
 //                                  contig column stays on the host and becomes ntid + 1 record bounds
 //   pc_add_alignment_file          staging: columns to HBM, then kernels only (stage_kernels.hip.h: validation,
 //                                  8-byte records, run stream, statistics; pc_kernels.hip.h: record stream,
@@ -304,8 +304,8 @@ template <typename T> struct DevView {
 // copies the piece into the slot and queues the DMA.  Down: it queues the DMA into the slot, waits for it and copies the
 // piece out.  Pieces are taken in order and there are more slots than threads, so nobody waits on a piece that has not
 // been taken.
-struct UploadJob { void *dst; const void *src; size_t bytes; };
-struct UploadRing {
+struct TransferJob { void *dst; const void *src; size_t bytes; };
+struct TransferRing {
     static constexpr int kSlots = 12, kThreadsUp = 6, kThreadsDown = 10;   // (down: the destination's pages are often touched for the first time)
     static constexpr size_t kPiece = (size_t)16 << 20;
     uint8_t *slot[kSlots] = {};
@@ -314,13 +314,13 @@ struct UploadRing {
     std::mutex busy;   // one transfer at a time per device
     // One ring per device for the life of the process: page-locking its 192 MB costs as much as staging ten million
     // records, and engines come and go (one per BAMGenomeArray).
-    static UploadRing &of(int device) {
-        static UploadRing rings[16];
+    static TransferRing &of(int device) {
+        static TransferRing rings[16];
         return rings[device & 15];
     }
     // every job has landed when this returns; `down`: dst is host memory, src device memory.
     // Small transfers take the runtime's own path (`always`: the ring whatever the size)
-    int run(int device, const std::vector<UploadJob> &jobs, size_t piece, bool always, bool down = false) {
+    int run(int device, const std::vector<TransferJob> &jobs, size_t piece, bool always, bool down = false) {
         std::lock_guard<std::mutex> one(busy);
         HIP_TRY(hipSetDevice(device));
         if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -335,7 +335,7 @@ struct UploadRing {
             return PC_OK;
         }
         piece = std::max<size_t>(1, std::min(piece, kPiece));
-        std::vector<UploadJob> pieces;
+        std::vector<TransferJob> pieces;
         for (const auto &j : jobs) {
             if (j.bytes == 0) continue;
             // host memory that is page-locked already (hipHostMalloc, hipHostRegister, a pinned torch tensor) needs no ring
@@ -1437,9 +1437,9 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
         if (rc == PC_OK) rc = d_bs.reserve((size_t)nrun + 1);
         if (rc == PC_OK) rc = d_bl.reserve((size_t)nrun + 1);
         if (rc != PC_OK) return rc;
-        size_t piece = UploadRing::kPiece;
-        if (const char *env = getenv("PC_STAGE_SLICE")) piece = (size_t)std::max<int64_t>(1, std::min<int64_t>(atoll(env), (int64_t)(UploadRing::kPiece / 4))) * 4; // test knob: tiny pieces
-        std::vector<UploadJob> jobs;   // (what the first kernel reads goes first)
+        size_t piece = TransferRing::kPiece;
+        if (const char *env = getenv("PC_STAGE_SLICE")) piece = (size_t)std::max<int64_t>(1, std::min<int64_t>(atoll(env), (int64_t)(TransferRing::kPiece / 4))) * 4; // test knob: tiny pieces
+        std::vector<TransferJob> jobs;   // (what the first kernel reads goes first)
         jobs.push_back({d_nblk8.p, nblk, (size_t)n});
         jobs.push_back({d_alen.p, alen, (size_t)n * 2});
         jobs.push_back({d_pos.p, pos, (size_t)n * 4});
@@ -1451,7 +1451,7 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
         const int devno = e->device;
         up.f = std::async(std::launch::async, [devno, &jobs, piece]() -> int {
             StageClock uclk;
-            const int r = UploadRing::of(devno).run(devno, jobs, piece, getenv("PC_STAGE_SLICE") != nullptr);
+            const int r = TransferRing::of(devno).run(devno, jobs, piece, getenv("PC_STAGE_SLICE") != nullptr);
             uclk.lap("  (upload thread: ring)");
             return r;
         });
@@ -3025,13 +3025,13 @@ int pc_read_counts(pc_engine *e, pc_plan *p, void *host_out, int64_t out_elems) 
     { const int grc = check_grid_guard(e, p); if (grc != PC_OK) return grc; }
     const size_t bytes = (size_t)out_elems * 8;
     const char *knob = getenv("PC_STAGE_SLICE");   // (test knob: the ring for every size, in pieces of so many 4 KiB pages)
-    if (bytes >= 4 * UploadRing::kPiece || (bytes > 0 && knob)) {
+    if (bytes >= 4 * TransferRing::kPiece || (bytes > 0 && knob)) {
         // the counts of a whole annotation: through the ring of page-locked pieces (a pageable destination the runtime has
-        // not seen before is filled at 25 GB/s; see UploadRing)
+        // not seen before is filled at 25 GB/s; see TransferRing)
         HIP_TRY(hipStreamSynchronize(e->stream));
-        const std::vector<UploadJob> job{{host_out, p->d_out.p, bytes}};
-        const size_t piece = knob ? (size_t)std::max<int64_t>(1, std::min<int64_t>(atoll(knob), 4096)) * 4096 : UploadRing::kPiece;
-        return UploadRing::of(e->device).run(e->device, job, piece, knob != nullptr, true);
+        const std::vector<TransferJob> job{{host_out, p->d_out.p, bytes}};
+        const size_t piece = knob ? (size_t)std::max<int64_t>(1, std::min<int64_t>(atoll(knob), 4096)) * 4096 : TransferRing::kPiece;
+        return TransferRing::of(e->device).run(e->device, job, piece, knob != nullptr, true);
     }
     // (growing the buffer frees the old one: not while a plan upload may still be reading from it)
     if (bytes > e->pinned.cap && e->pinned_busy) { HIP_TRY(hipEventSynchronize(e->ev_pinned)); e->pinned_busy = false; }
@@ -4193,9 +4193,9 @@ int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *
     hipStream_t st = b->e->stream;
     BamClock rclk;
     const size_t n = (size_t)b->n, m = (size_t)b->nrun;
-    // (through the ring of page-locked pieces when the columns are large: the caller's arrays are pageable, see UploadRing)
+    // (through the ring of page-locked pieces when the columns are large: the caller's arrays are pageable, see TransferRing)
     HIP_TRY(hipStreamSynchronize(st));
-    std::vector<UploadJob> jobs;
+    std::vector<TransferJob> jobs;
     if (n) {
         jobs.push_back({tid, b->tid.p, n * 4});
         jobs.push_back({pos, b->pos.p, n * 4});
@@ -4208,7 +4208,7 @@ int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *
         jobs.push_back({blk_len, b->blk_len.p, m * 4});
     }
     {
-        const int rc = UploadRing::of(b->e->device).run(b->e->device, jobs, UploadRing::kPiece, false, true);
+        const int rc = TransferRing::of(b->e->device).run(b->e->device, jobs, TransferRing::kPiece, false, true);
         if (rc != PC_OK) return rc;
     }
     rclk.lap("columns to the host");
@@ -4222,11 +4222,11 @@ int pc_bam_read_sam(pc_bam *b, uint16_t *flag, uint8_t *mapq, int32_t *lseq) {
     hipStream_t st = b->e->stream;
     const size_t n = (size_t)b->n;
     HIP_TRY(hipStreamSynchronize(st));
-    std::vector<UploadJob> jobs;
+    std::vector<TransferJob> jobs;
     if (n && flag) jobs.push_back({flag, b->flag16.p, n * 2});
     if (n && mapq) jobs.push_back({mapq, b->mapq.p, n});
     if (n && lseq) jobs.push_back({lseq, b->lseq.p, n * 4});
-    return UploadRing::of(b->e->device).run(b->e->device, jobs, UploadRing::kPiece, false, true);
+    return TransferRing::of(b->e->device).run(b->e->device, jobs, TransferRing::kPiece, false, true);
 }
 
 static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded,

@@ -4,7 +4,7 @@
 // Until round 5 pc_add_alignment_file staged the caller's packed columns (tid, pos, alen, flags, nblk + the aligned runs
 // of multi-run reads) with one threaded host pass -- validation, statistics, the 8-byte records, the run-stream records
 // -- that no number of host threads brought near the rate of the PCIe link.  Now the host only moves bytes: the columns
-// cross PCIe as they are (through a ring of page-locked pieces, plastid_counts.hip "UploadRing"; the contig column does
+// cross PCIe as they are (through a ring of page-locked pieces, plastid_counts.hip "TransferRing"; the contig column does
 // not travel at all: sorted, it is ntid + 1 record bounds, found by a streaming comparison on the host while the other
 // columns are in flight), and everything the host pass did is done here, the validation included (k_cols_pack<true>).
 // The columns of a BAM file decoded on the GPU (bam_kernels.hip.h) are in HBM to begin with and were validated by the
