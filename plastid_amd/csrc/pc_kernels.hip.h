@@ -508,6 +508,11 @@ __device__ __forceinline__ int64_t lin_exact(const uint32_t PC_GLOBAL *v, const 
     }
     return lo;
 }
+// Test hook (never set in the product build): a variant compiled with -DPC_KMAX16=1000000000 has NO guard on the 16-bit
+// bins of the stratified rule -- tests/test_gpu_parity.py::test_sixteen_bit_bins_do_not_overflow must fail on it.
+#ifndef PC_KMAX16
+#define PC_KMAX16 65535
+#endif
 // (spans of at most this many positions get exact bounds: beyond it the bucket rounding is a few percent of the scan)
 constexpr int kExactSpan = 1024;
 
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     // entries), so: a window is cut into sub-windows by that total, one whose (sub-)window still scans more than 65 535
     // is merged through the compact histogram, and a merged window's slices hold ONE kind of range each, at most R
     // (49 152) entries of it.
-    constexpr int64_t kMax16 = 65535;
+    constexpr int64_t kMax16 = PC_KMAX16;
     __shared__ unsigned long long s_wave64[kRangesWG / 64];
     __shared__ uint32_t s_base[3];
     const int64_t idx = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;

@@ -1294,3 +1294,70 @@ def test_single_segment_queries_in_one_call(pa, oracle):
         os.environ.pop("PC_NO_SINGLE", None)
         if saved is not None:
             os.environ["PC_NO_SINGLE"] = saved
+
+
+def test_sixteen_bit_bins_do_not_overflow(pa, oracle):
+    """The stratified rule bins into 16-bit LDS counters, two positions per word (k_hist_point, B16); what keeps a bin
+    from carrying into its neighbour is k_tile_ranges cutting or merging every work item that could add 65 536 times.
+    200 000 reads of ONE length at ONE position (an rRNA pile-up), 70 000 at the neighbouring position that shares its
+    LDS word, 100 000 on the first position of the next window and 90 000 reverse reads of another length: every element
+    against the oracle -- one file, the same reads dealt into two files (joint windows), '+', '-', '.', segments that end
+    on and run across the window edge, forward / reversed / summed layouts.  A library compiled with
+    -DPC_KMAX16=1000000000 (no guard) fails this test."""
+    from plastid_amd import synth
+    names, lens = ["a", "b"], [60000, 20000]
+    G = 768                                  # window of a multi-row plan (choose_window)
+    edge = G * 10
+    off28 = synth.VARIABLE_OFFSETS[28]       # forward rule: read.positions[13] of a 28-mer
+    off30 = synth.VARIABLE_OFFSETS[30]
+    rng = np.random.default_rng(16)
+    parts = [
+        (np.full(200000, edge - 2 - off28), 28, False),          # -> position edge - 2 (even: low half of its word)
+        (np.full(70000, edge - 1 - off28), 28, False),           # -> edge - 1: the high half of the same word
+        (np.full(100000, edge - off28), 28, False),              # -> edge: first position of the next window
+        (np.full(90000, edge - 3 - (30 - 1 - off30)), 30, True),  # reverse rule -> edge - 3
+        (rng.integers(0, 50000, 30000), 28, False),              # background, both strands
+        (rng.integers(0, 50000, 30000), 31, True),
+    ]
+    pos = np.concatenate([p_[0] for p_ in parts]).astype(np.int64)
+    alen = np.concatenate([np.full(len(p_[0]), p_[1]) for p_ in parts])
+    rev = np.concatenate([np.full(len(p_[0]), p_[2]) for p_ in parts])
+    order = np.argsort(pos, kind="stable")
+    pos, alen, rev = pos[order], alen[order], rev[order]
+    whole = pa.PackedAlignments.from_ungapped(0, pos, alen, rev, references=names, lengths=lens)
+    even, odd = np.arange(0, len(pos), 2), np.arange(1, len(pos), 2)
+    halves = [pa.PackedAlignments.from_ungapped(0, pos[k], alen[k], rev[k], references=names, lengths=lens) for k in (even, odd)]
+    seg_start = np.array([edge - 80, edge - 2, edge - 300, 0, edge - 3, edge - 1, edge - 80], np.int64)
+    seg_end = np.array([edge + 70, edge, edge - 1, 50000, edge + 1, edge + 1, edge + 70], np.int64)
+    seg_tid = np.zeros(len(seg_start), np.int32)
+    seg_strand = np.array([1, 1, 1, 3, 2, 3, 2], np.uint8)      # PC_STRAND_FWD / REV / UNS
+    mapping = ("stratified", synth.VARIABLE_OFFSETS, 25, 35)
+    spec = spec_for(oracle, mapping)
+    n = seg_end - seg_start
+    for files in ([whole], halves):
+        eng = engine_for(pa, files, mapping)
+        rows = eng.rows
+        aln = aln_dict(files)
+        arrays, _ = oracle.count_segments(aln, spec, seg_tid, seg_start, seg_end, seg_strand)
+        assert max(int(a.max()) for a in arrays) >= 200000       # the pile really is deeper than a 16-bit bin
+        for step in (1, -1, 0):
+            if step:
+                base = np.concatenate([[0], np.cumsum(n * rows)[:-1]])
+                out_off = base if step > 0 else base + n - 1
+                stride, elems = n, int((n * rows).sum())
+            else:
+                out_off = np.arange(len(n), dtype=np.int64) * rows
+                stride, elems = np.ones(len(n), np.int64), len(n) * rows
+            plan = eng.plan(seg_tid, seg_start, seg_end, seg_strand, out_off, np.full(len(n), step, np.int8), stride, elems, rows)
+            got = plan.count(np.int64)
+            exp = np.zeros(elems, np.int64)
+            for s, arr in enumerate(arrays):
+                a2 = arr.reshape(rows, int(n[s]))
+                for r in range(rows):
+                    if step:
+                        exp[out_off[s] + r * stride[s] + step * np.arange(int(n[s]))] = a2[r]
+                    else:
+                        exp[out_off[s] + r] = a2[r].sum()
+            assert np.array_equal(got, exp), (len(files), step, np.nonzero(got != exp)[0][:8])
+            plan.close()
+        eng.close()
