@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define PC_ABI_VERSION 1
+/* Bumped whenever entry points are added or the meaning of an argument changes (6: round 6).  A binding checks it
+ * BEFORE it resolves any other symbol: a stale library then fails with a version message, not with a missing symbol. */
+#define PC_ABI_VERSION 6
 
 typedef struct pc_engine pc_engine;
 typedef struct pc_plan pc_plan;

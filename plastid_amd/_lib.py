@@ -97,6 +97,10 @@ SIGNATURES = {
 _lib = None
 
 
+#: PC_ABI_VERSION of include/plastid_counts.h this binding was written against
+ABI_VERSION = 6
+
+
 def load():
     """Load ``libplastid_counts.so`` (built in-tree by :mod:`plastid_amd.build`)."""
     global _lib
@@ -111,12 +115,19 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise EngineError("cannot load %s: %s" % (LIB_PATH, e))
+    # the revision first: a stale library (an older header's build) must fail HERE, not at a missing symbol below
+    try:
+        lib.pc_abi_version.restype = _int
+        have = lib.pc_abi_version()
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise EngineError("%s implements ABI revision %s, this package needs %d: rebuild it with `python -m plastid_amd.build --force`"
+                          % (LIB_PATH, have, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.pc_abi_version() != 1:
-        raise EngineError("ABI version mismatch in %s" % LIB_PATH)
     _lib = lib
     return lib
 

@@ -508,6 +508,84 @@ __device__ __forceinline__ int64_t lin_exact(const uint32_t PC_GLOBAL *v, const 
     }
     return lo;
 }
+// Up to four exact lookups at once (k_tile_ranges: both bounds of the record stream and of the run stream of one
+// window).  The bucket edges of all of them are requested together, and every round of the searches issues one load per
+// search before it looks at any of them -- a thread that ran them one after the other waited for ~40 dependent loads.
+// CG = 1: plain bisections, interleaved.  CG = 16: the sixteen lanes `sub` = 0..15 of an aligned group work on the SAME
+// window and every round probes sixteen evenly spaced entries (three rounds for a bucket of 4 096 entries instead of
+// twelve): what small plans use, whose few thousand windows would otherwise leave most of the chip idle.
+// key[k] / v[k] / lin[k]: the searches; n: how many of them are live.  Returns lower bounds as lin_exact does.
+template <int CG>
+__device__ __forceinline__ void lin_exact_multi(const uint32_t PC_GLOBAL *const (&v)[4], const uint32_t PC_GLOBAL *const (&lin)[4],
+                                                int64_t lin0, int64_t nb, const int64_t (&key)[4], int n, int sub, int64_t (&out)[4]) {
+    int64_t lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = hi[k] = 0;
+        if (k < n) {
+            int64_t b = key[k] <= 0 ? 0 : (key[k] >> kLinShift);
+            if (b > nb) b = nb;
+            const int64_t b1 = b + 1 > nb ? nb : b + 1;
+            lo[k] = lin[k][lin0 + b];
+            hi[k] = lin[k][lin0 + b1];
+        }
+    }
+    if (CG == 1) {
+        while ((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]) | (lo[3] < hi[3])) {
+            int64_t mid[4];
+            int32_t val[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mid[k] = lo[k] + ((hi[k] - lo[k]) >> 1);
+                val[k] = lo[k] < hi[k] ? (int32_t)v[k][mid[k] * 2] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lo[k] < hi[k]) { if ((int64_t)val[k] < key[k]) lo[k] = mid[k] + 1; else hi[k] = mid[k]; }
+        }
+    } else {
+        const int gbase = (int)(threadIdx.x & 63u) & ~(CG - 1);   // first lane of this group inside its wave
+        const unsigned long long gmask = CG >= 64 ? ~0ull : ((1ull << CG) - 1ull);
+        // (every lane of a group holds the same lo / hi: the loop conditions are uniform inside the group, and a ballot
+        // only ever looks at the group's own bits)
+        while ((hi[0] - lo[0] > CG) | (hi[1] - lo[1] > CG) | (hi[2] - lo[2] > CG) | (hi[3] - lo[3] > CG)) {
+            int64_t step[4];
+            int32_t val[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                step[k] = (hi[k] - lo[k] + CG - 1) / CG;
+                int64_t idx = lo[k] + (int64_t)(sub + 1) * step[k] - 1;
+                if (idx >= hi[k]) idx = hi[k] - 1;
+                val[k] = hi[k] - lo[k] > CG ? (int32_t)v[k][idx * 2] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool wide = hi[k] - lo[k] > CG;
+                const unsigned long long bal = (__ballot(wide && (int64_t)val[k] < key[k]) >> gbase) & gmask;
+                if (wide) {   // probes are monotone: the first c are < key
+                    const int c = __popcll(bal);
+                    const int64_t nlo = c == 0 ? lo[k] : lo[k] + (int64_t)c * step[k];            // one past probe c - 1
+                    const int64_t nhi = c == CG ? hi[k] : lo[k] + (int64_t)(c + 1) * step[k] - 1;  // probe c
+                    const int64_t h0 = hi[k];
+                    lo[k] = nlo < h0 ? nlo : h0;
+                    hi[k] = nhi < h0 ? nhi : h0;
+                    if (hi[k] < lo[k]) hi[k] = lo[k];
+                }
+            }
+        }
+        int32_t val[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) val[k] = lo[k] + sub < hi[k] ? (int32_t)v[k][(lo[k] + sub) * 2] : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long bal = (__ballot(lo[k] + sub < hi[k] && (int64_t)val[k] < key[k]) >> gbase) & gmask;
+            lo[k] += __popcll(bal);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = lo[k];
+}
+
 // Test hook (never set in the product build): a variant compiled with -DPC_KMAX16=1000000000 has NO guard on the 16-bit
 // bins of the stratified rule -- tests/test_gpu_parity.py::test_sixteen_bit_bins_do_not_overflow must fail on it.
 #ifndef PC_KMAX16
@@ -593,6 +671,7 @@ __device__ __forceinline__ int64_t lower_bound_i32(const uint32_t PC_GLOBAL *v, 
 //          served by single-wave workgroups with a small LDS footprint -- a sparse annotation is
 //          latency-bound, so what matters is how many windows are in flight per CU.
 // One returning atomic per class per workgroup: a single hot counter saturates near 90/us.
+template <int CG>
 __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restrict__ tiles, int ntiles,
                                                            FileView file0, const FileView *__restrict__ files,
                                                            int nfiles, int G, int W, int Ws, int Wr, int64_t R, int64_t pile,
@@ -607,7 +686,11 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     constexpr int64_t kMax16 = PC_KMAX16;
     __shared__ unsigned long long s_wave64[kRangesWG / 64];
     __shared__ uint32_t s_base[3];
-    const int64_t idx = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
+    // CG lanes per window (1, or 16 for small plans: the exact bounds are then searched by the group, lin_exact_multi);
+    // the lanes of a group do everything else alike, and lane 0 of the group queues and writes
+    const int64_t gtid = (int64_t)blockIdx.x * kRangesWG + threadIdx.x;
+    const int64_t idx = gtid / CG;
+    const int gsub = (int)(gtid % CG);
     // several files: ONE thread per window looks at all of them, and the window's work items are joint (every file's
     // records binned into the same LDS bins, the output written once) -- only a pile-up still merges through the
     // compact histogram
@@ -738,10 +821,16 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         // 150-nt exon in a 4096-nt window) scans the exon's neighbourhood, not the whole window
         const int64_t s_lo = ws + tl.span_lo, s_hi = ws + tl.span_hi + (1 << kLinShift) - 1, s_end = ws + tl.span_hi;
         const bool exact = (int)tl.span_hi - (int)tl.span_lo <= kExactSpan;   // a short span: exact bounds instead of bucket edges
-        if (exact) {
-            wlo = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, l0, nb, s_lo - Ws + 1);
-            whi = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, l0, nb, s_end);
+        if (exact) {   // both streams' bounds in one go
+            const uint32_t PC_GLOBAL *const vv[4] = {(const uint32_t PC_GLOBAL *)fv.rec, (const uint32_t PC_GLOBAL *)fv.rec,
+                                                     (const uint32_t PC_GLOBAL *)fv.run_rec, (const uint32_t PC_GLOBAL *)fv.run_rec};
+            const uint32_t PC_GLOBAL *const ll[4] = {fv.lin_tab, fv.lin_tab, fv.rlin_tab, fv.rlin_tab};
+            const int64_t kk[4] = {s_lo - Ws + 1, s_end, s_lo - Wr + 1, s_end};
+            int64_t bound[4];
+            lin_exact_multi<CG>(vv, ll, l0, nb, kk, fv.nrunrec ? 4 : 2, gsub, bound);
+            wlo = bound[0]; whi = bound[1];
             if (whi < wlo) whi = wlo;
+            if (fv.nrunrec) { wrlo = bound[2]; wrhi = bound[3]; if (wrhi < wrlo) wrhi = wrlo; }
         } else {
             wlo = lin_floor(fv.lin_tab, l0, nb, s_lo - Ws + 1);
             whi = lin_floor(fv.lin_tab, l0, nb, s_hi);
@@ -750,15 +839,9 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             wglo = lin_floor(fv.glin_tab, l0, nb, s_lo - W + 1);
             wghi = lin_floor(fv.glin_tab, l0, nb, s_hi);
         }
-        if (fv.nrunrec) { // aligned runs (of gapped and spliced reads) that start up to Wr before the span
-            if (exact) {
-                wrlo = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.run_rec, fv.rlin_tab, l0, nb, s_lo - Wr + 1);
-                wrhi = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.run_rec, fv.rlin_tab, l0, nb, s_end);
-                if (wrhi < wrlo) wrhi = wrlo;
-            } else {
-                wrlo = lin_floor(fv.rlin_tab, l0, nb, s_lo - Wr + 1);
-                wrhi = lin_floor(fv.rlin_tab, l0, nb, s_hi);
-            }
+        if (fv.nrunrec && !exact) { // aligned runs (of gapped and spliced reads) that start up to Wr before the span
+            wrlo = lin_floor(fv.rlin_tab, l0, nb, s_lo - Wr + 1);
+            wrhi = lin_floor(fv.rlin_tab, l0, nb, s_hi);
         }
         if (fv.nxlong) {
             // long-span reads outside the run stream that can reach the queried span: they start before
@@ -805,7 +888,8 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
             n_light = merged_count(r, f == 0);
         }
     }
-    if (diag && live && f == 0 && lhi > llo) atomicAdd(&nwork[3], (uint32_t)(lhi - llo)); // PC_DEBUG_WORK: long-span candidates
+    if (CG > 1 && gsub != 0) { n_heavy = 0; n_light = 0; n_small = 0; }   // (lane 0 of the group queues and writes)
+    if (diag && live && gsub == 0 && f == 0 && lhi > llo) atomicAdd(&nwork[3], (uint32_t)(lhi - llo)); // PC_DEBUG_WORK: long-span candidates
     // one scan for the three classes: 21 bits each (a block queues far fewer than 2 M items)
     unsigned long long tot3;
     const unsigned long long off3 = block_scan_excl64((unsigned long long)n_heavy | ((unsigned long long)n_light << 21) |
@@ -1762,9 +1846,12 @@ __global__ __launch_bounds__(kWG) void k_cs_scatter(const uint2 *__restrict__ re
 
 // half the value of a read by aligned length, for the lengths a stream entry can carry: 0.5 / (L - 2 nibble), or 0.0
 // where the read is not counted (size filter, nothing left by the nibble: adding +0.0 never changes a sum)
-__global__ void k_center_vals(MapParams mp, const double *__restrict__ invh, double *cvalh) {
+// (and the cursors of the persistent center kernel, k_center2p: they start behind the first entry of every wave -- grid_p
+// waves, grid_p / 8 per eighth)
+__global__ void k_center_vals(MapParams mp, const double *__restrict__ invh, double *cvalh, uint32_t *cursors, uint32_t grid_p) {
     const int L = (int)threadIdx.x, m = L - 2 * mp.param;
     if (L < 256) cvalh[L] = (m > 0 && size_ok(mp, L)) ? invh[m] : 0.0;
+    if (cursors && L < 8) cursors[16 * L] = (grid_p + 7u) >> 3;
 }
 
 // Dispatch list of the center kernel.  A chunk's replay is sequential in the reads that overlap
@@ -2353,6 +2440,7 @@ struct Center2Ctx {
     const uint2 *ent[3];       // the file's center streams by strand selection (kernel arguments: no load between descriptor and entries)
     uint32_t indirect;         // bit sel: that stream holds indirect entries (reads beyond the 8-bit fields)
     const FileView *files;
+    FileView file0;            // the one file's view, by value: its pointers come out of the argument segment (scalar loads at the point of use) instead of per-lane loads from memory
     MapParams mp;
     int W;
     const double *inv, *invh, *cvalh;
@@ -2364,11 +2452,18 @@ struct Center2Ctx {
     int norm_on;
     unsigned long long *dbg;
     uint32_t dbg_cap;
+    uint32_t *cursors;         // persistent form (k_center2p): [16 x] = next light entry of eighth x (one cursor per 64-byte line)
 };
 
 // One (sub-)chunk from its descriptor `d` (lane l < 32 holds dword l; the upper half of the wave holds a copy).
-template <bool DBG, bool GENERAL>
-__device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t d, const int lane, const double *s_valh, unsigned long long &n_slots) {
+// `dsel`: 0 / 32 -- which half of the wave holds the descriptor (a wave that claims two adjacent entries loads both with
+// one 256-byte request).  RING: batches of entries in flight.
+// EARLY: the fields the epilogue needs are taken out of the descriptor before the replay (the persistent kernel: the
+// register that held the descriptor is then free for the next one while the chunk replays).
+template <bool DBG, bool GENERAL, int RING, bool EARLY = false>
+__device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t d_, const int dsel, const int lane, const double *s_valh, unsigned long long &n_slots) {
+    // (the descriptor in both halves of the wave, as the field reads below expect it; dsel < 0: it already is)
+    const uint32_t d = dsel < 0 ? d_ : (uint32_t)__shfl((int)d_, dsel + (lane & 31), 64);
     const uint32_t shape = lane_u32(d, kCsShape);
     const int npos = (int)(shape & 0xffu);
     if (npos == 0) return;
@@ -2387,7 +2482,7 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
     const int sel = center_sel(mode);
     const int lane_bit = 1 << li, lane_sh = 30 - li;
     double acc = 0.0;
-    const GFile fv = gfile(cx.files[0]);
+    const GFile fv = gfile(cx.file0);
     auto row_mask = [&](int a0, int m) {   // (m = 0: nothing)
         const int first = a0 - rs, b0 = first > 0 ? first : 0, b1 = first + m < 16 ? first + m : 16;   // row-relative [b0, b1)
         return b1 > b0 ? (int)((1u << b1) - (1u << b0)) : 0;
@@ -2435,6 +2530,18 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
     // eighths of the group that hold such a read are handed round (lane permutes) and replayed -- skipping a read that
     // adds +0.0 to every sum leaves every bit as it was.
     const uint32_t long_z = lane_u32(d, kCsLongZ), long_w = lane_u32(d, kCsLongW);
+    uint32_t e_out_lo = 0u, e_out_hi = 0u, e_op_begin = 0u, e_op_end = 0u;
+    int32_t e_ostart = 0, e_olen = 0, e_ostep = 0;
+    if (EARLY) {
+        e_out_lo = lane_u32(d, kCsOutLo); e_out_hi = lane_u32(d, kCsOutHi);
+        e_ostart = (int32_t)lane_u32(d, kCsOStart); e_olen = (int32_t)lane_u32(d, kCsOLen); e_ostep = (int32_t)lane_u32(d, kCsOStep);
+        e_op_begin = lane_u32(d, kCsOpBegin); e_op_end = lane_u32(d, kCsOpEnd);
+    }
+    uint32_t nmax = 0u, ent0 = 0u, to_end = 0u, lo = 0u, hi = 0u;
+    if (EARLY) {
+        nmax = lane_u32(d, kCsNmax); ent0 = lane_u32(d, kCsEnt0); to_end = lane_u32(d, kCsToEnd);
+        lo = (uint32_t)__shfl((int)d, kCsLo + row, 64); hi = (uint32_t)__shfl((int)d, kCsHi + row, 64);
+    }
     if (long_w > long_z) {
         const int64_t near_row = (int64_t)rs - W + 1;
         const int64_t near_last = (int64_t)s0 + (kCenterRows - 1) * roww - W + 1;   // the last row's: the furthest any row looks
@@ -2485,10 +2592,12 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
         }
     }
     // near windows: row r replays the stream entries [lo, hi) the descriptor names for it
-    const uint32_t nmax = lane_u32(d, kCsNmax);
+    if (!EARLY) nmax = lane_u32(d, kCsNmax);
     if (nmax != 0u && !(PC_CENTER_SKIP & 2)) {
-        const uint32_t ent0 = lane_u32(d, kCsEnt0), to_end = lane_u32(d, kCsToEnd);
-        const uint32_t lo = (uint32_t)__shfl((int)d, kCsLo + row, 64), hi = (uint32_t)__shfl((int)d, kCsHi + row, 64);
+        if (!EARLY) {
+            ent0 = lane_u32(d, kCsEnt0); to_end = lane_u32(d, kCsToEnd);
+            lo = (uint32_t)__shfl((int)d, kCsLo + row, 64); hi = (uint32_t)__shfl((int)d, kCsHi + row, 64);
+        }
         const uint2 *ent_sel = sel == 0 ? cx.ent[0] : (sel == 1 ? cx.ent[1] : cx.ent[2]);   // (selects, not an indexed copy: that would live in scratch)
         const char PC_GLOBAL *eb = (const char PC_GLOBAL *)((const u32x2 PC_GLOBAL *)ent_sel + ent0);
         // (loads past a row's end read one of the 64 entries behind the stream's last, which cover nothing; a stream whose
@@ -2512,7 +2621,6 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
         };
         // PC_CENTER2_RING batches in flight, each in a register pair of its own; the batch after the one being replayed is
         // already unpacked.  A batch that starts behind the longest row is not requested at all (uniform test).
-        constexpr int RING = PC_CENTER2_RING;
         const u32x2 none = {0x7fffffffu, 0u};
         u32x2 q[RING];
 #pragma unroll
@@ -2537,14 +2645,18 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
     // count / sum * 1e6 in that order, genome_array.py:826-827)
     if (PC_CENTER_SKIP & 4) { asm volatile("" : : "v"(acc)); return; }
     const double val = cx.norm_on ? acc / cx.norm_sum * 1e6 : acc;
-    if (shape >> 24) {   // THE output piece of this chunk, from the descriptor
-        const long long out_off = (long long)(((unsigned long long)lane_u32(d, kCsOutHi) << 32) | lane_u32(d, kCsOutLo));
-        const int32_t ostart = (int32_t)lane_u32(d, kCsOStart), olen = (int32_t)lane_u32(d, kCsOLen), ostep = (int32_t)lane_u32(d, kCsOStep);
+    if ((shape >> 24) & 1u) {   // THE output piece of this chunk, from the descriptor
+        if (!EARLY) {
+            e_out_lo = lane_u32(d, kCsOutLo); e_out_hi = lane_u32(d, kCsOutHi);
+            e_ostart = (int32_t)lane_u32(d, kCsOStart); e_olen = (int32_t)lane_u32(d, kCsOLen); e_ostep = (int32_t)lane_u32(d, kCsOStep);
+        }
+        const long long out_off = (long long)(((unsigned long long)e_out_hi << 32) | e_out_lo);
+        const int32_t ostart = e_ostart, olen = e_olen, ostep = e_ostep;
         const uint32_t rel = (uint32_t)(p - ostart);
         if (owns && rel < (uint32_t)olen) cx.out[out_off + (long long)ostep * (long long)rel] = val;
     } else {
-        const uint32_t op_begin = lane_u32(d, kCsOpBegin), op_end = lane_u32(d, kCsOpEnd);
-        for (uint32_t oi = op_begin; oi < op_end; ++oi) {
+        if (!EARLY) { e_op_begin = lane_u32(d, kCsOpBegin); e_op_end = lane_u32(d, kCsOpEnd); }
+        for (uint32_t oi = e_op_begin; oi < e_op_end; ++oi) {
             const OutPiece o = cx.opieces[oi];
             if (o.mode != mode) continue;                     // the window's slices of other strand modes
             const uint32_t rel = (uint32_t)(p - o.start);
@@ -2591,13 +2703,103 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBG ? 7 : 8,
     for (uint32_t c = 0; c < count; ++c) {
         uint32_t dn = 0u;
         if (c + 1u < count) dn = sw[(size_t)(first + c + 1u) * 32u + (uint32_t)(lane & 31)];   // the next descriptor, in flight while this chunk replays
-        center_slot<DBG, GENERAL>(cx, d, lane, s_valh, n_slots);
+        center_slot<DBG, GENERAL, PC_CENTER2_RING>(cx, d, -1, lane, s_valh, n_slots);
         d = dn;
     }
     if (dbg && lane == 0 && first < cx.dbg_cap) {   // PC_CENTER_DEBUG: heavy entries from the front of the table, light ones from its back (as k_center's list)
         const size_t at = first < n_heavy ? (size_t)first : (size_t)cx.dbg_cap - 1u - (size_t)(first - n_heavy);
         dbg[2 * at] = wall_clock64() - t_begin; dbg[2 * at + 1] = t_begin;
         dbg[2 * (size_t)cx.dbg_cap + at] = n_slots;
+    }
+}
+
+// ---------------------------------------------------------------- k_center_heavy / k_center2p (round 6)
+// Where round 5's k_center2 stood (C3, PC_CENTER_DEBUG): the launch ends with its HEAVY entries -- 32 k dependent steps
+// at ~56 cycles each although the wave runs at raised priority -- and the bulk (one wave per light entry, ~300 steps)
+// keeps ~6 900 of 8 192 wave slots resident, each wave a third of its life in the two dependent trips at its head.
+//   * 56 cycles per step is the PREFETCH DEPTH, not the issue rate: four batches of sixteen entries per row in flight,
+//     one memory round trip (~3 600 cycles under load) per 64 steps.  k_center_heavy serves the heavy entries -- one wave
+//     each, raised priority, as before -- with PC_CENTER_HEAVY_RING (twelve) batches in flight, on a stream of its own
+//     beside the light entries' kernel (launched first: its waves are placed before that one fills the chip).
+//   * k_center2p: a PERSISTENT grid for the light entries -- as many one-wave workgroups as the chip holds, launched
+//     once.  A wave claims one entry at a time from the cursor of its XCD's eighth of the list (workgroup b runs on XCD
+//     b mod 8; neighbouring chunks re-read each other's halo, which then sits in that XCD's L2) and, when its eighth is
+//     exhausted, from the others'.  The next entry's descriptor and the claim after it are in flight while an entry
+//     replays, so a chunk starts with ONE dependent trip (its entries) instead of a wave launch, an LDS table fill and
+//     two trips.
+constexpr uint32_t kCursorStride = 16;   // dwords between cursors: one 64-byte line each
+#ifndef PC_CENTER_HEAVY_RING
+#define PC_CENTER_HEAVY_RING 12
+#endif
+
+template <bool GENERAL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_center_heavy(Center2Ctx cx) {
+    const int lane = threadIdx.x & 63;
+    if (PC_CENTER_HEAVY_PRIO) __builtin_amdgcn_s_setprio(PC_CENTER_HEAVY_PRIO);
+    const uint32_t PC_GLOBAL *sw = (const uint32_t PC_GLOBAL *)cx.slots;
+    const uint32_t d = sw[(size_t)blockIdx.x * 32u + (uint32_t)(lane & 31)];   // (grid = the heavy entries: the front of the table)
+    __shared__ double s_valh[256];
+    for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long n_slots = 0;
+    center_slot<false, GENERAL, PC_CENTER_HEAVY_RING>(cx, d, -1, lane, s_valh, n_slots);
+}
+
+template <bool GENERAL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_center2p(Center2Ctx cx) {
+    const uint32_t n_heavy = cx.n_heavy, n_light = cx.n_light;   // (the host knows the list's counts: the first count of a plan runs k_center2)
+    const int lane = threadIdx.x & 63;
+    const uint32_t PC_GLOBAL *sw = (const uint32_t PC_GLOBAL *)cx.slots;
+    uint32_t *cursors = cx.cursors;
+    __shared__ double s_valh[256];
+    for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long n_slots = 0;
+    const uint32_t n8 = (n_light + 7u) >> 3;                           // entries per eighth of the light list
+    auto eighth_len = [&](uint32_t xx) { const uint32_t lo8 = xx * n8; return lo8 < n_light ? (lo8 + n8 < n_light ? n8 : n_light - lo8) : 0u; };
+    uint32_t x = blockIdx.x & 7u;       // the eighth this wave claims from (its XCD's, until that is exhausted)
+    uint32_t spent = 0u;                // eighths seen exhausted (bit x)
+    // a claim: what the atomic returned (lane 0), made on eighth `on`
+    auto issue = [&](uint32_t on) { uint32_t r = 0u; if (lane == 0) r = atomicAdd(&cursors[kCursorStride * on], 1u); return r; };
+    // -> the claimed entry's index in the slot table, or 0xffffffff: nothing left anywhere
+    auto resolve = [&](uint32_t raw, uint32_t on) -> uint32_t {
+        uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw);
+        while (true) {
+            if (idx < eighth_len(on)) return n_heavy + on * n8 + idx;
+            spent |= 1u << on;
+            if (spent == 0xffu) return 0xffffffffu;
+            while ((spent >> x) & 1u) x = (x + 1u) & 7u;                 // (a claim made before x moved on is retried where x is now)
+            on = x;
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue(on));
+        }
+    };
+    // pipeline: entry e0 replays from its descriptor d0 (a register that is free again once the replay has taken its fields
+    // out), the NEXT entry's descriptor is in flight in lanes 0-31 of `pre`, and the claim after that in lane 32 of the
+    // same register (both are waited for only after the replay).
+    // A wave's first claim needs no atomic: entry number (b >> 3) of its eighth (k_center_vals starts the cursors behind those).
+    const uint32_t none = 0xffffffffu;
+    uint32_t e0 = resolve(blockIdx.x >> 3, x);
+    uint32_t d0 = e0 != none ? sw[(size_t)e0 * 32u + (uint32_t)(lane & 31)] : 0u;
+    uint32_t e1 = none;
+    if (e0 != none) { const uint32_t on1 = x; e1 = resolve(issue(on1), on1); }
+    uint32_t pre = (e1 != none && lane < 32) ? sw[(size_t)e1 * 32u + (uint32_t)lane] : 0u;
+    // (the kernel's arguments are read from the argument segment again for every entry: hoisted out of this loop they
+    // would be held in scalar registers across it -- a wave of this kernel has 80 -- and spill)
+    typedef const Center2Ctx __attribute__((address_space(4))) CtxK;
+    CtxK *cxk = (CtxK *)__builtin_amdgcn_kernarg_segment_ptr();
+    while (e0 != none) {
+        const uint32_t on2 = x;
+        if (e1 != none && lane == 32) pre = atomicAdd(&cursors[kCursorStride * on2], 1u);
+        // (likewise what depends on the lane alone -- permute indices, the lane's place in a descriptor -- is worked out
+        // again per entry, a dozen instructions, instead of living in vector registers across the loop: the kernel has 64)
+        int lane_i = lane;
+        asm volatile("" : "+s"(cxk), "+v"(lane_i));
+        center_slot<false, GENERAL, PC_CENTER2_RING>(*(const Center2Ctx *)cxk, d0, 0, lane_i, s_valh, n_slots);
+        const uint32_t e2 = e1 != none ? resolve(lane_u32(pre, 32), on2) : none;
+        e0 = e1; d0 = pre;
+        e1 = e2;
+        asm volatile("" : "+v"(lane_i));
+        pre = (e2 != none && lane_i < 32) ? sw[(size_t)e2 * 32u + (uint32_t)lane_i] : 0u;
     }
 }
 

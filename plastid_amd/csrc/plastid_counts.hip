@@ -80,44 +80,64 @@ int fail(int code, const char *fmt, ...) {
 // boxes of the pool a hipMalloc that follows the hipFree of tens of GB takes SECONDS (measured round 5: 1.5 s and 2.1 s
 // for the first large buffer of a staging call right after an engine of the same size was destroyed; milliseconds when
 // nothing had been freed).  Only blocks of a destroyed engine get here -- its streams are drained by then, so nothing
-// is in flight on them.  PC_POOL_RESERVOIR_GB caps what is kept (default 96; 0: keep nothing).
+// is in flight on them.
+// What is kept is bounded: PC_POOL_RESERVOIR_GB per device (default 4: the tables of a few plans and a small file; a
+// process that cycles through engines of tens of GB -- bench.py -- opts in to more), and when the LAST engine of a device
+// is destroyed everything above that default is freed, so that another library in the process (torch, cupy) finds the
+// HBM this one no longer uses.  pc_release_cached_memory frees all of it.
 struct BigReservoir {
+    static constexpr size_t kDefaultLimit = (size_t)4 << 30;
     std::mutex m;
-    std::map<size_t, std::vector<void *>> big[16];
-    size_t cached[16] = {};
-    size_t limit = (size_t)96 << 30;
+    struct PerDevice { std::map<size_t, std::vector<void *>> big; size_t cached = 0; int engines = 0; };
+    std::map<int, PerDevice> dev;   // keyed by the device id itself (no folding of ids onto a fixed table)
+    size_t limit = kDefaultLimit;
     BigReservoir() { if (const char *env = getenv("PC_POOL_RESERVOIR_GB")) limit = (size_t)std::max(0ll, atoll(env)) << 30; }
     static BigReservoir &get() { static BigReservoir *r = new BigReservoir; return *r; }   // (never destroyed: no hipFree during static destruction)
     void *take(int device, size_t rounded) {
         std::lock_guard<std::mutex> g(m);
-        auto &b = big[device & 15];
-        auto it = b.find(rounded);
-        if (it == b.end() || it->second.empty()) return nullptr;
+        PerDevice &d = dev[device];
+        auto it = d.big.find(rounded);
+        if (it == d.big.end() || it->second.empty()) return nullptr;
         void *p = it->second.back();
         it->second.pop_back();
-        cached[device & 15] -= rounded;
+        d.cached -= rounded;
         return p;
     }
     bool give(int device, void *p, size_t rounded) {
         std::lock_guard<std::mutex> g(m);
-        if (cached[device & 15] + rounded > limit) return false;
-        big[device & 15][rounded].push_back(p);
-        cached[device & 15] += rounded;
+        PerDevice &d = dev[device];
+        if (d.cached + rounded > limit) return false;
+        d.big[rounded].push_back(p);
+        d.cached += rounded;
         return true;
+    }
+    // largest blocks first until at most `keep` bytes are left
+    void trim_locked(PerDevice &d, size_t keep) {
+        for (auto it = d.big.rbegin(); it != d.big.rend() && d.cached > keep; ++it)
+            while (!it->second.empty() && d.cached > keep) {
+                (void)hipFree(it->second.back());
+                it->second.pop_back();
+                d.cached -= it->first;
+            }
     }
     void free_all(int device) {   // (an allocation failed: what is kept here may be what is missing)
         std::lock_guard<std::mutex> g(m);
-        for (auto &kv : big[device & 15])
-            for (void *p : kv.second) (void)hipFree(p);
-        big[device & 15].clear();
-        cached[device & 15] = 0;
+        trim_locked(dev[device], 0);
+        dev[device].big.clear();
+    }
+    void engine_created(int device) { std::lock_guard<std::mutex> g(m); dev[device].engines += 1; }
+    void engine_destroyed(int device) {   // the last one of the device: only the default amount stays
+        std::lock_guard<std::mutex> g(m);
+        PerDevice &d = dev[device];
+        if (--d.engines <= 0) { d.engines = 0; trim_locked(d, std::min(limit, kDefaultLimit)); }
     }
 };
 
 // Per-engine cache of small device blocks.  A plan of one short segment is otherwise dominated by
 // hipMalloc / hipFree (the latter synchronises the device): blocks up to 32 MiB are kept by
 // power-of-two size class when a plan lets go of them and handed to the next one.  Every user of
-// one pool enqueues on the same engine stream, so a recycled block is ordered after its last use.
+// one pool enqueues on the same engine stream, so a recycled block is ordered after its last use.  (The one exception,
+// the transfer ring's own stream, synchronises the engine stream before it touches pooled blocks: stage_file.)
 struct DevPool {
     static constexpr int kMinShift = 8, kClasses = 18;   // 256 B .. 32 MiB
     static constexpr size_t kMaxCached = (size_t)512 << 20;
@@ -240,7 +260,11 @@ template <typename T> struct DevBuf {
             const int c = DevPool::size_class(n * sizeof(T));
             if (c < DevPool::kClasses) {
                 void *q = pool->take(c);
-                if (!q) HIP_TRY(hipMalloc(&q, DevPool::class_bytes(c)));
+                if (!q && hipMalloc(&q, DevPool::class_bytes(c)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    pool->drain(false);   // (what the pool and the reservoir hold may be what is missing)
+                    HIP_TRY(hipMalloc(&q, DevPool::class_bytes(c)));
+                }
                 p = (T *)q;
                 cap = DevPool::class_bytes(c) / sizeof(T);
                 pool_class = c;
@@ -259,7 +283,13 @@ template <typename T> struct DevBuf {
             big_bytes = rounded;
             return PC_OK;
         }
-        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+        if (hipMalloc((void **)&p, n * sizeof(T)) != hipSuccess) {   // (no pool of its own: the reservoir of the current device may hold what is missing)
+            (void)hipGetLastError();
+            p = nullptr;
+            int dev_now = 0;
+            if (hipGetDevice(&dev_now) == hipSuccess) BigReservoir::get().free_all(dev_now);
+            HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+        }
         cap = n;
         return PC_OK;
     }
@@ -315,8 +345,12 @@ struct TransferRing {
     // One ring per device for the life of the process: page-locking its 192 MB costs as much as staging ten million
     // records, and engines come and go (one per BAMGenomeArray).
     static TransferRing &of(int device) {
-        static TransferRing rings[16];
-        return rings[device & 15];
+        static std::mutex m;
+        static std::map<int, TransferRing *> *rings = new std::map<int, TransferRing *>;   // (never destroyed: no HIP call during static destruction)
+        std::lock_guard<std::mutex> g(m);
+        TransferRing *&r = (*rings)[device];
+        if (!r) r = new TransferRing;
+        return *r;
     }
     // every job has landed when this returns; `down`: dst is host memory, src device memory.
     // Small transfers take the runtime's own path (`always`: the ring whatever the size)
@@ -508,6 +542,8 @@ struct Knobs {
     int64_t pile = 0;          // PC_PILE: records of a 128-nt sub-window beyond which it is merged through the histogram (0: 12 R)
     int no_small = 0;          // PC_NO_SMALL: no single-wave class for sparse windows
     int small_rows = 0;        // PC_SMALL_ROWS: 1 = multi-row plans (stratified rule) may use the single-wave class too
+    int ranges_cg1 = 0;        // PC_RANGES_CG1: one thread per window in k_tile_ranges whatever the plan's size (tests compare the two forms)
+    int64_t first_sync_spare = 65536;   // PC_FIRST_SYNC_SPARE: spare work-list slots from which the first count of a plan reads its item counts back before it launches
     int no_single = 0;         // PC_NO_SINGLE: one-window plans go through the work lists like any other (tests compare the two paths)
     int plan_build = 0;        // PC_PLAN_BUILD=host|gpu: where pc_plan_create builds the tables (default: on the GPU from 8 192 segments)
     int small_g = 512;         // PC_SMALL_G: queried span a single-wave window may have
@@ -518,6 +554,8 @@ struct Knobs {
     int center_t2 = 4;         //   count are cut into 4 (8) sub-chunks
     int64_t center_floor = 32768; // PC_CENTER_FLOOR: stream entries below which a chunk is never cut (a wave alone replays ~50 k per ms)
     int center_lds = 0;        // PC_CENTER_LDS: bytes of (unused) LDS per k_center workgroup -- an occupancy throttle for experiments
+    int center_mode = 2;       // PC_CENTER_MODE: 0 round 5's k_center2 (one wave per dispatch entry); 2 k_center_heavy (deep prefetch) beside k_center2p (persistent waves over the light entries)
+    int center_pwaves = 8;     // PC_CENTER_PWAVES: persistent waves per SIMD (the kernel is compiled for eight)
     int center_legacy = 0;     // PC_CENTER_LEGACY: one-file plans through round 4's k_center too (A/B against k_center2)
     int center_per_wave = 0;   // (reserved)
     int center_debug = 0;      // PC_CENTER_DEBUG: wall-clock span of every dispatched wave of k_center, printed after the launch (synchronises)
@@ -529,6 +567,8 @@ struct Knobs {
         no_small = getenv("PC_NO_SMALL") ? 1 : 0;
         if (const char *env = getenv("PC_SMALL_ROWS")) small_rows = atoi(env);
         no_single = getenv("PC_NO_SINGLE") ? 1 : 0;
+        ranges_cg1 = getenv("PC_RANGES_CG1") ? 1 : 0;
+        first_sync_spare = getenv("PC_FIRST_SYNC_SPARE") ? atoll(getenv("PC_FIRST_SYNC_SPARE")) : 65536;
         if (const char *env = getenv("PC_PLAN_BUILD")) plan_build = std::strcmp(env, "host") == 0 ? 1 : (std::strcmp(env, "gpu") == 0 ? 2 : 0);
         if (const char *env = getenv("PC_SMALL_G")) small_g = std::max(64, atoi(env) / 64 * 64);
         if (const char *env = getenv("PC_SMALL_N")) small_n = std::max(64, atoi(env));
@@ -539,6 +579,8 @@ struct Knobs {
         if (const char *env = getenv("PC_CENTER_FLOOR")) center_floor = std::max(64, atoi(env));
         center_debug = getenv("PC_CENTER_DEBUG") ? 1 : 0;
         center_legacy = getenv("PC_CENTER_LEGACY") ? atoi(getenv("PC_CENTER_LEGACY")) : 0;
+        center_mode = getenv("PC_CENTER_MODE") ? atoi(getenv("PC_CENTER_MODE")) : 2;
+        center_pwaves = getenv("PC_CENTER_PWAVES") ? std::max(1, std::min(8, atoi(getenv("PC_CENTER_PWAVES")))) : 8;
         if (const char *env = getenv("PC_CENTER_LDS")) center_lds = std::max(0, atoi(env));
     }
 };
@@ -675,7 +717,8 @@ struct pc_plan {
     uint64_t center_generation = 0;
     int center_W = -1;
     bool center_slots = false;             // the dispatch list has been resolved into descriptors (d_cslots)
-    uint32_t *h_center_counts = nullptr;   // page-locked [2]: heavy, light entries of the list (sizes the grid of later counts)
+    DevBuf<uint32_t> d_ccursors; // cursors of the persistent center kernel (reset by k_center_vals at every count)
+    uint32_t *h_center_counts = nullptr;   // page-locked [2]: heavy, light entries of the list (sizes the grids of later counts)
     hipEvent_t ev_center_counts = nullptr;
     bool center_counts_known = false;
     uint32_t center_counts[2] = {0, 0};
@@ -731,7 +774,7 @@ struct pc_plan {
         DevPool *pl = &eng->pool;
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
-        d_cranges.pool = pl; d_crec.pool = pl; d_crows.pool = pl; d_ccounts.pool = pl; d_cslots.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
+        d_cranges.pool = pl; d_crec.pool = pl; d_crows.pool = pl; d_ccounts.pool = pl; d_cslots.pool = pl; d_ccursors.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
         d_work.pool = pl; d_work_small.pool = pl; d_chain.pool = pl; d_chain_small.pool = pl;
         d_inputs.pool = pl; d_gsegs_own.pool = pl;
     }
@@ -1223,6 +1266,7 @@ int pc_create(int device, pc_engine **out) {
     e->device = device;
     e->pool.device = device;
     e->knobs.load();
+    BigReservoir::get().engine_created(device);
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
     for (auto &a : e->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
@@ -1269,7 +1313,9 @@ int pc_destroy(pc_engine *e) {
     for (auto &x : e->ev_ring) if (x) (void)hipEventDestroy(x);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->stream) (void)hipStreamDestroy(e->stream);
-    delete e;
+    const int device = e->device;
+    delete e;                                          // (its pool hands its idle blocks to the reservoir)
+    BigReservoir::get().engine_destroyed(device);      // the last engine of the device: the reservoir shrinks to its default size
     return PC_OK;
 }
 
@@ -1437,6 +1483,10 @@ static int stage_file(pc_engine *e, int64_t n, int32_t ntid, const int32_t *tid,
         if (rc == PC_OK) rc = d_bs.reserve((size_t)nrun + 1);
         if (rc == PC_OK) rc = d_bl.reserve((size_t)nrun + 1);
         if (rc != PC_OK) return rc;
+        // (the ring fills these blocks on ITS stream: a block the pool recycled may still be read or written by work
+        // queued on the engine's stream -- a plan buffer that grew inside an asynchronous pc_count -- and every other user of
+        // the pool is ordered on that stream; the ring is the exception, so it starts behind everything queued there)
+        HIP_TRY(hipStreamSynchronize(st));
         size_t piece = TransferRing::kPiece;
         if (const char *env = getenv("PC_STAGE_SLICE")) piece = (size_t)std::max<int64_t>(1, std::min<int64_t>(atoll(env), (int64_t)(TransferRing::kPiece / 4))) * 4; // test knob: tiny pieces
         std::vector<TransferJob> jobs;   // (what the first kernel reads goes first)
@@ -2669,15 +2719,41 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 if (!p->tile_items_zero) HIP_TRY(hipMemsetAsync(p->d_tile_items.p, 0, ((size_t)ntiles + 1) * sizeof(uint32_t), st));
                 p->wcounters_zero = false;
                 p->tile_items_zero = false;
-                const int64_t nthreads = nfiles > 1 ? (int64_t)ntiles : (int64_t)ntiles * nfiles; // one thread per window (several files: joint windows)
-                hipLaunchKernelGGL(k_tile_ranges, dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles,
-                                   e->files[0]->view(), e->d_files.p, nfiles, G, e->Wg(), e->Ws(), e->Wr(), R, pile, p->d_work.p, p->d_wcounters.p, p->d_tile_items.p, (uint32_t)cap64,
-                                   p->d_work_small.p, small_g, small_n, e->knobs.debug_work, p->d_chain.p, p->d_chain_small.p, e->kind == PC_MAP_STRAT5 ? 1 : 0);
+                const int64_t nwin = nfiles > 1 ? (int64_t)ntiles : (int64_t)ntiles * nfiles; // one thread per window (several files: joint windows)
+                // ... or sixteen lanes per window while that still fits the chip at once: the exact record bounds of a window are
+                // then searched by the group (three rounds of sixteen probes instead of a dozen dependent loads each) -- a plan of
+                // a few thousand windows (C2: 6 144) otherwise runs on two dozen CUs at the pace of one thread's load chain
+                const bool group16 = nwin * 16 <= ((int64_t)1 << 19) && !e->knobs.ranges_cg1;
+                const int64_t nthreads = group16 ? nwin * 16 : nwin;
+#define PC_LAUNCH_RANGES(CG)                                                                                           \
+    hipLaunchKernelGGL((k_tile_ranges<CG>), dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles, \
+                       e->files[0]->view(), e->d_files.p, nfiles, G, e->Wg(), e->Ws(), e->Wr(), R, pile, p->d_work.p, p->d_wcounters.p, p->d_tile_items.p, (uint32_t)cap64, \
+                       p->d_work_small.p, small_g, small_n, e->knobs.debug_work, p->d_chain.p, p->d_chain_small.p, e->kind == PC_MAP_STRAT5 ? 1 : 0)
+                if (group16) PC_LAUNCH_RANGES(16); else PC_LAUNCH_RANGES(1);
+#undef PC_LAUNCH_RANGES
                 p->work_key = key;
                 p->work_valid = true;
                 p->work_counts_known = false;      // the counts of the lists just replaced size no grid
                 p->guard_pending = true;           // k_gather_split checks the new lists against the capacity: read with the results
                 p->work_counts_generation = 0;
+                // The first count of a plan does not know how many items its lists hold, and used to launch the whole
+                // capacity: for a sparse annotation under a multi-row rule that is 3.6 M workgroups for 0.53 M items (C5:
+                // 3.88 ms against 3.24, and the merge pass on top).  Where the capacity is far above the window count, the
+                // queued counts are read back NOW -- one small copy and a stream synchronisation, ~20 us of idle GPU -- and
+                // this count already launches exact grids.
+                const int64_t spare = cap64 + cap_small - nwin;
+                if (ntiles >= 4096 && spare >= e->knobs.first_sync_spare && !e->knobs.test_stale_counts && !e->knobs.debug_work) {
+                    if (!p->h_work_counts) {
+                        HIP_TRY(hipHostMalloc((void **)&p->h_work_counts, 8 * sizeof(uint32_t), hipHostMallocDefault));
+                        HIP_TRY(hipEventCreateWithFlags(&p->ev_work_counts, hipEventDisableTiming));
+                    }
+                    HIP_TRY(hipMemcpyAsync(p->h_work_counts, p->d_wcounters.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    for (int k = 0; k < 3; ++k) p->work_counts[k] = p->h_work_counts[k];
+                    p->work_merged = p->h_work_counts[4];
+                    p->work_counts_known = true;
+                    p->work_counts_generation = e->work_generation;
+                }
             }
             if (e->prof_level >= 1) HIP_TRY(hipEventRecord(e->ev[2], st));
             // offset tables are staged in LDS for the aligned lengths that occur in the data
@@ -2827,13 +2903,21 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (rc == PC_OK) rc = p->d_crec.reserve((size_t)nchunks * (size_t)nfiles);
             if (rc == PC_OK) rc = p->d_crows.reserve((size_t)nchunks * (size_t)nfiles * (size_t)(2 * kCenterRows));
             if (rc == PC_OK) rc = p->d_ccounts.reserve(8);
+            if (rc == PC_OK) rc = p->d_ccursors.reserve(16 * 8);
             if (rc == PC_OK) rc = e->d_cvalh.reserve(256);
             // one alignment file (every BASELINE config): descriptors per dispatch entry, several entries per wave (k_center2);
             // several files keep round 4's kernel, whose waves walk the files of a chunk one after the other
             const bool slots_on = nfiles == 1 && !e->knobs.center_legacy;
             if (rc == PC_OK && slots_on) rc = p->d_cslots.reserve((size_t)(2 * nchunks));   // (heavy entries < chunks, light entries <= chunks)
             if (rc != PC_OK) return rc;
-            hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(256), 0, st, mp, e->d_invh.p, e->d_cvalh.p);
+            // the persistent form's grid: what the chip holds of its one-wave workgroups
+            int n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, e->device);
+            uint32_t grid_p = (uint32_t)std::max(8, n_cu * 4 * e->knobs.center_pwaves);
+            if (p->center_counts_known) grid_p = (uint32_t)std::min<uint64_t>(grid_p, ((uint64_t)p->center_counts[1] + 7) / 8 * 8);   // (no more waves than light entries)
+            grid_p = std::max(grid_p, 8u);
+            // (the cursors start behind the first entry of each of the grid_p waves: the very grid k_center2p is launched with)
+            hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(256), 0, st, mp, e->d_invh.p, e->d_cvalh.p, p->d_ccursors.p, grid_p);
             if (p->center_generation != e->work_generation || p->center_W != W || p->center_slots != slots_on) {
                 HIP_TRY(hipMemsetAsync(p->d_ccounts.p, 0, 8 * sizeof(uint32_t), st));
                 unsigned long long *total = (unsigned long long *)(p->d_ccounts.p + 2);
@@ -2899,7 +2983,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                     c2.ent[k] = sf0->cs_n[k] >= 0 ? sf0->cs_ent[k].p : nullptr;
                     if (sf0->len_max > 255) c2.indirect |= 1u << k;
                 }
-                c2.files = e->d_files.p; c2.mp = mp; c2.W = W; c2.inv = e->d_inv.p; c2.invh = e->d_invh.p; c2.cvalh = e->d_cvalh.p;
+                c2.files = e->d_files.p; c2.file0 = sf0->view(); c2.mp = mp; c2.W = W; c2.inv = e->d_inv.p; c2.invh = e->d_invh.p; c2.cvalh = e->d_cvalh.p;
                 c2.counters = p->d_ccounts.p;
                 c2.known = p->center_counts_known ? 1u : 0u; c2.n_heavy = p->center_counts[0]; c2.n_light = p->center_counts[1];
                 c2.opieces = p->d_opieces.p; c2.out = (double *)p->d_out.p; c2.norm_sum = e->norm_sum; c2.norm_on = e->norm_on ? 1 : 0;
@@ -2910,13 +2994,33 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                     g2 = (uint64_t)p->center_counts[0] + 8 * ((n8 + PC_CENTER_PER_WAVE - 1) / PC_CENTER_PER_WAVE);
                 } else g2 = 2 * (uint64_t)nchunks + 8;
                 const dim3 cg2((unsigned)std::max<uint64_t>(g2, 1));
-                if (dbg_on) {
+                c2.cursors = p->d_ccursors.p;
+                // round 6: once the list's counts are known -- k_center_heavy for the heavy entries on the side stream (launched
+                // first: its waves are placed before the other kernel fills the chip), beside it the persistent grid over the
+                // light entries.  The first count of a plan, the diagnostic launch and PC_CENTER_MODE=0 run round 5's kernel
+                // (one wave per entry) over everything.
+                const int cmode = (p->center_counts_known && !dbg_on) ? e->knobs.center_mode : 0;
+                const bool heavy_on = cmode == 2 && p->center_counts[0] > 0u;
+                if (heavy_on) {
+                    HIP_TRY(hipEventRecord(e->ev_fork, st));
+                    HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+                    if (general) hipLaunchKernelGGL((k_center_heavy<true>), dim3(p->center_counts[0]), dim3(64), 0, e->side_stream, c2);
+                    else hipLaunchKernelGGL((k_center_heavy<false>), dim3(p->center_counts[0]), dim3(64), 0, e->side_stream, c2);
+                    HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
+                }
+                if (cmode == 2) {
+                    if (p->center_counts[1] > 0u) {
+                        if (general) hipLaunchKernelGGL((k_center2p<true>), dim3(grid_p), dim3(64), 0, st, c2);
+                        else hipLaunchKernelGGL((k_center2p<false>), dim3(grid_p), dim3(64), 0, st, c2);
+                    }
+                } else if (dbg_on) {
                     if (general) hipLaunchKernelGGL((k_center2<true, true>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
                     else hipLaunchKernelGGL((k_center2<true, false>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
                 } else {
                     if (general) hipLaunchKernelGGL((k_center2<false, true>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
                     else hipLaunchKernelGGL((k_center2<false, false>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
                 }
+                if (heavy_on) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
             } else if (dbg_on) {
                 if (general) hipLaunchKernelGGL((k_center<true, true>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
                 else hipLaunchKernelGGL((k_center<true, false>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);

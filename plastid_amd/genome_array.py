@@ -518,8 +518,14 @@ class BAMGenomeArray(object):
                 self.map_fn._kind not in (_lib.MAP_FIVE, _lib.MAP_THREE, _lib.MAP_VAR5) or os.environ.get("PC_NO_SINGLE")):
             return False
         args = self.map_fn._engine_args()
-        key = (id(self.map_fn), args.get("kind"), args.get("param"))
-        if getattr(self, "_no_warn_key", None) != key:
+        # the verdict depends on the rule (an offset table can be mutated in place: its bytes are part of the key) and on
+        # the reads staged -- the key holds the objects themselves, so a freed map function's id cannot come back as another
+        fw = args.get("fw")
+        key = (self.map_fn, args.get("kind"), args.get("param"), None if fw is None else np.asarray(fw).tobytes(),
+               tuple(self._packed))
+        prev = getattr(self, "_no_warn_key", None)
+        if prev is None or len(prev) != len(key) or prev[0] is not key[0] or prev[1:4] != key[1:4] or \
+                len(prev[4]) != len(key[4]) or any(a is not b for a, b in zip(prev[4], key[4])):
             # can any read of the file make this rule emit its DataWarning (an offset beyond the read, a length without an
             # offset)?  One pass over the aligned lengths, once per rule; if so, queries keep to the plan path, which reports it
             with warnings.catch_warnings():

@@ -30,7 +30,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().pc_abi_version() == 1
+    assert _lib.load().pc_abi_version() == _lib.ABI_VERSION
+    assert re.search(r"#define PC_ABI_VERSION (\d+)", header).group(1) == str(_lib.ABI_VERSION)
 
 
 def test_engine_fails_loudly_without_gpu():
