@@ -339,11 +339,13 @@ def run_workload(name, args, ctx, headline):
                     lp["out_elems"], rows)
     plan_s = time.perf_counter() - t0
 
-    # host side of the read-back: page-locked (what a caller that reads repeatedly would hand over), touched once
-    # (above 1 GiB -- the sparse configurations -- ordinary pageable memory)
-    out_pin = torch.zeros(int(lp["out_elems"]), dtype=torch.int64 if out_dtype == np.int64 else torch.float64,
-                          pin_memory=int(lp["out_elems"]) * 8 <= (16 << 30))
-    out_buf = out_pin.numpy()
+    # host side of the read-back: page-locked memory from the engine itself (pc_host_alloc: what a caller that reads
+    # repeatedly hands over); above 16 GiB ordinary pageable memory, which goes down through the transfer ring
+    if int(lp["out_elems"]) * 8 <= (16 << 30) and hasattr(eng, "host_buffer"):
+        out_buf = eng.host_buffer(int(lp["out_elems"]), out_dtype)
+        out_buf[:] = 0
+    else:
+        out_buf = np.zeros(int(lp["out_elems"]), out_dtype)
 
     def gate(expected, what):
         """Bit-exact comparison of the sampled elements with the oracle."""
@@ -357,6 +359,9 @@ def run_workload(name, args, ctx, headline):
     for _ in range(warmup):
         plan.launch(out_dtype)
     eng.sync()
+    t0 = time.perf_counter()
+    plan.read(out_buf)
+    read_first_s = time.perf_counter() - t0   # the first copy into this buffer (whatever the runtime does once per buffer is in it)
     t0 = time.perf_counter()
     plan.read(out_buf)
     read_s = time.perf_counter() - t0   # D2H of every output position
@@ -471,6 +476,7 @@ def run_workload(name, args, ctx, headline):
         "parity_positions": int(n_checked),
         "sum_of_counts_all_ranks": counts_all,
         "host_generate_s": round(gen_s, 2), "host_stage_s": round(stage_s, 3), "host_read_outputs_s": round(read_s, 4),
+        "host_read_outputs_first_s": round(read_first_s, 4),
         "plan_build_ms_once_per_annotation": round(plan_s * 1e3, 2),
         "first_count_ms": first_count_ms,
         "algorithmic_bytes_per_step": int(alg_bytes_step),
@@ -562,20 +568,59 @@ def run_partitioned(name, args, ctx, headline):
             oracle_part[seg_chain[piece_owner[j]] * rows:(seg_chain[piece_owner[j]] + 1) * rows] += a.reshape(rows, -1).sum(axis=1)
     del aln, piece_arrays
 
+    # ---------------------------------------------------------------- --from-bam: ONE shared file, written once (untimed)
+    # What a user of the reference has is a BAM file, and the reference reads each region from it
+    # (genome_array.py:800-809).  Rank 0 writes the job's records as a coordinate-sorted, indexed BAM; every rank then
+    # stages ITS genome range of that file (GenomePartition.rank_regions -> the BAI index -> pc_add_alignment_bam_span:
+    # only the BGZF members of the range are uploaded, inflated and decoded, on the GPU).  The records the rank
+    # generated above stay the oracle's input.
+    bam_path = None
+    if getattr(args, "from_bam", False):
+        from tests import bam_writer
+        bam_path = os.path.join(tempfile.gettempdir(), "pc_bench_job_%s_%s.bam" % (name, os.environ.get("MASTER_PORT", str(os.getppid()))))
+        if rank == 0:
+            whole = my_reads if world == 1 else synth.make_reads_blocked(lay)
+            bam_writer.write_bam_packed(bam_path, whole, threads=min(16, usable_cpus()), index=True)
+            del whole
+        multigpu.barrier()
+
     # ---------------------------------------------------------------- GPU
     import torch
     warm_runtime(ctx)
     eng = Engine(ctx["dev_index"])
     time.sleep(0.3)   # the all-cores CPU baseline just burnt the cgroup's CPU quota (CFS, 100 ms periods): staging is a host pass
-    t0 = time.perf_counter()
-    eng.set_alignments([my_reads])
-    stage_s = time.perf_counter() - t0
+    staged_n = int(my_reads.n)
+    if bam_path:
+        regions = gp.rank_regions(rank, list(my_reads.references))
+        if hasattr(eng, "add_bam"):
+            eng.clear_alignments()
+            eng.add_bam(bam_path, regions=regions)             # page cache + library warm-up
+            t0 = time.perf_counter()
+            eng.clear_alignments()
+            eng.add_bam(bam_path, regions=regions)
+            stage_s = time.perf_counter() - t0
+            staged_n = int(eng.num_records(0))
+        else:                                                   # (the CPU rehearsal's stand-in engine: the host reader, same regions)
+            from plastid_amd.bam import read_bam
+            t0 = time.perf_counter()
+            from_file = read_bam(bam_path, regions=regions)
+            eng.set_alignments([from_file])
+            stage_s = time.perf_counter() - t0
+            staged_n = int(from_file.n)
+        if staged_n < my_reads.n:
+            raise SystemExit("--from-bam (%s, rank %d): the region read staged %d records, the rank's range holds %d" % (name, rank, staged_n, my_reads.n))
+    else:
+        t0 = time.perf_counter()
+        eng.set_alignments([my_reads])
+        stage_s = time.perf_counter() - t0
     factory._configure(eng)
     t0 = time.perf_counter()
     plan = eng.plan(lp["tid"], lp["start"], lp["end"], lp["strand"], lp["out_off"], lp["out_step"], lp["row_stride"],
                     lp["out_elems"], rows)
     plan_s = time.perf_counter() - t0
-    out_buf = np.zeros(int(lp["out_elems"]), out_dtype)
+    out_buf = (eng.host_buffer(int(lp["out_elems"]), out_dtype) if (hasattr(eng, "host_buffer") and int(lp["out_elems"]) * 8 <= (16 << 30))
+               else np.zeros(int(lp["out_elems"]), out_dtype))   # page-locked, as at N = 1
+    out_buf[:] = 0
 
     def gate(idx, val, what):
         got = plan.read(out_buf)
@@ -632,7 +677,16 @@ def run_partitioned(name, args, ctx, headline):
     if center:
         counts_all = multigpu.reduce_float_totals_ordered([float(total_counts)], device=ctx["tdev"])[0]
     per_rank = lambda v: multigpu.allreduce_int_totals([int(v) if r == rank else 0 for r in range(world)], device=ctx["tdev"])
-    balance, staged, rss = per_rank(owned), per_rank(my_reads.n), per_rank(peak_rss_mb())
+    balance, staged, rss = per_rank(owned), per_rank(staged_n), per_rank(peak_rss_mb())
+    stage_ms_all = per_rank(round(stage_s * 1e3))
+    if bam_path:
+        multigpu.barrier()
+        if rank == 0:
+            for f in (bam_path, bam_path + ".bai"):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
     gen_all = per_rank(round(gen_s * 1e3))
     allreduce = None
     if not center:
@@ -698,7 +752,11 @@ def run_partitioned(name, args, ctx, headline):
         "partition": {"mode": "genome ranges at quantiles of the expected record density (synth.JobLayout.cuts); every rank generates "
                               "and stages only its range (synth.make_reads_blocked)",
                       "records_per_rank": balance, "records_staged_per_rank": staged, "halo_positions": int(lay.halo),
-                      "host_generate_ms_per_rank": gen_all, "peak_host_rss_MB_per_rank": rss, "allreduce": allreduce},
+                      "host_generate_ms_per_rank": gen_all, "peak_host_rss_MB_per_rank": rss, "allreduce": allreduce,
+                      "stage_ms_per_rank": stage_ms_all, "stage_ms_max": max(stage_ms_all),
+                      "source": ("one shared BAM file (written once by rank 0, untimed): every rank stages its genome range of it through the "
+                                 "BAI index, decoded on the GPU (pc_add_alignment_bam_span); stage_ms = file -> staged") if bam_path
+                                else "records generated by every rank for its own range; stage_ms = host arrays -> staged"},
     }
     if rehearsal:
         res["rehearsal"] = "engine stand-in %s: control flow only, no measurement" % getattr(Engine, "__module__", "?")
@@ -734,10 +792,8 @@ def e2e_scope(args, ctx, name, realistic=False):
     out_dtype = np.float64 if mapping[0] == "center" else np.int64
 
     # host side of the read-back: page-locked, as in the staged scope (what a caller that reads repeatedly hands over)
-    import torch
-    out_pin = torch.zeros(int(p["out_elems"]), dtype=torch.int64 if out_dtype == np.int64 else torch.float64,
-                          pin_memory=int(p["out_elems"]) * 8 <= (16 << 30))
-    out_buf = out_pin.numpy()
+    out_buf = eng.host_buffer(int(p["out_elems"]), out_dtype) if int(p["out_elems"]) * 8 <= (16 << 30) else np.zeros(int(p["out_elems"]), out_dtype)
+    out_buf[:] = 0
 
     def counted():
         plan = eng.plan(p["tid"], p["start"], p["end"], p["strand"], p["out_off"], p["out_step"], p["row_stride"], p["out_elems"], rows)
@@ -811,6 +867,7 @@ def e2e_scope(args, ctx, name, realistic=False):
                                  ": read name, sequence, qualities, NH and MD tags" if realistic else ": name 'r', no sequence",
                                  "/".join("%.3f" % r[0] for r in runs), "GPU (BGZF inflate + record decode as HIP kernels)" if gpu_decode else "native host",
                                  t_decode, t_stage, t_all - t_decode - t_stage))
+    del out_buf          # (page-locked memory of the engine: released while the engine is still there)
     eng.close()
     try:
         os.remove(path)
@@ -836,7 +893,8 @@ def brief_config(r):
     b = {"ms_per_step": sig(r["ms_per_step"]), "reads_per_s": sig(r["value"]), "kernel_ms": sig(roof["avg_launch_ms"]),
          "frac": sig(roof["frac"], 3), "frac_traffic": sig(roof.get("frac_traffic"), 3),
          "first_count_ms": r["first_count_ms"]["total"], "parity_positions": r["parity_positions"],
-         "plan_build_ms": r["plan_build_ms_once_per_annotation"], "staged_reads_per_s": sig(r["scopes"]["staged_reads_per_s"])}
+         "plan_build_ms": r["plan_build_ms_once_per_annotation"], "staged_reads_per_s": sig(r["scopes"]["staged_reads_per_s"]),
+         "host_stage_s": r.get("host_stage_s"), "read_s": r.get("host_read_outputs_s")}
     if r["scopes"].get("staged_with_plan_reads_per_s"):
         b["staged_with_plan"] = sig(r["scopes"]["staged_with_plan_reads_per_s"])
     for k in ("issue_bound_ms", "issue_frac", "row_fill"):
@@ -852,6 +910,7 @@ def brief_config(r):
     if "partition" in r:
         pt = r["partition"]
         b["records_per_rank"] = pt["records_per_rank"]
+        b["stage_ms_per_rank"] = pt.get("stage_ms_per_rank")
         if pt.get("allreduce"):
             b["allreduce_ms"] = sig(pt["allreduce"]["ms"])
     return b
@@ -925,6 +984,11 @@ def main():
     ap.add_argument("--partition", default="auto", choices=["auto", "genome", "replicas"],
                     help="N > 1: one job cut into genome ranges (strong scaling, default) or independent replicas (weak)")
     ap.add_argument("--parity-chains", type=int, default=200, help="chains of the parity sample when no CPU baseline is timed")
+    ap.add_argument("--from-bam", action="store_true",
+                    help="one job (also at N = 1): rank 0 writes the config's records as ONE indexed BAM file (untimed) and every rank "
+                         "stages its genome range of it -- decoded on the GPU -- instead of generated arrays")
+    ap.add_argument("--one-job", action="store_true",
+                    help="N = 1 through the one-job path of N > 1 (the blocked generator, the partition code with a single range): what --from-bam is compared with")
     ap.add_argument("--time-budget", type=float, default=1200.0, help="seconds after which no further config is started")
     ap.add_argument("--e2e-records", type=float, default=1e8, help="records of the BAM file of the e2e scope, at most the whole configuration (0: skip)")
     ap.add_argument("--detail-out", default=None, help="where the full result (prose included) goes; default bench_detail.json beside bench.py")
@@ -976,7 +1040,7 @@ def main():
     if not rehearsal:
         torch.cuda.set_device(dev_index)
     multigpu.init(backend, device=None if rehearsal else torch.device("cuda", dev_index))  # "nccl" is RCCL on ROCm
-    one_job = world > 1 and partition == "genome"
+    one_job = (world > 1 or args.from_bam or args.one_job) and partition == "genome"
     run_config = run_partitioned if one_job else run_workload
 
     head = run_config(args.config, args, ctx, headline=True)
@@ -995,7 +1059,7 @@ def main():
     plan.close()
     eng.close()
     single_query = None
-    if rank == 0 and world == 1 and not rehearsal and not args.no_single_query:
+    if rank == 0 and world == 1 and not rehearsal and not args.no_single_query and not args.from_bam and not args.one_job:
         try:   # (the headline's own records, staged once more by the mirror's own engine)
             single_query = single_query_latency(_reads, ctx["last_annotation"], dev_index)
         except Exception as e:   # a diagnostic must not cost the bench line
@@ -1007,7 +1071,7 @@ def main():
     want = args.other_configs
     if want == "auto":
         # N = 1: the other single-GPU configs; N > 1: the two configs BASELINE.json labels 8 x MI355X, as one job each
-        want = ("C3,C4,C5" if world == 1 else ("C4,C5" if one_job else "none")) if (args.config == "C2" and args.scale == 1.0) else "none"
+        want = ("C3,C4,C5" if world == 1 else ("C4,C5" if one_job else "none")) if (args.config == "C2" and args.scale == 1.0 and not args.from_bam and not args.one_job) else "none"
     names = [c for c in want.split(",") if c and c != "none" and c != args.config]
     for c in names:
         if time.perf_counter() - t_start > args.time_budget:
@@ -1023,7 +1087,7 @@ def main():
         gc.collect()
         others[c] = r
     e2e = None
-    if rank == 0 and world == 1 and not rehearsal and time.perf_counter() - t_start <= args.time_budget:
+    if rank == 0 and world == 1 and not rehearsal and not args.from_bam and not args.one_job and time.perf_counter() - t_start <= args.time_budget:
         e2e = {}
         for realistic, want in ((False, args.e2e_records), (True, args.e2e_realistic_records)):
             if want <= 0:
@@ -1063,6 +1127,7 @@ def main():
                   "segments": head["segments"], "output_positions": head["output_positions_per_gpu"], "tiles": head["tiles"],
                   "mapping": head["mapping"], "parity_positions": head["parity_positions"],
                   "plan_build_ms": head["plan_build_ms_once_per_annotation"], "host_stage_s": head["host_stage_s"],
+                  "read_s": head.get("host_read_outputs_s"),
                   "kernel_source_sha16": kernel_source_hash(), "bench_wall_s": detail["bench_wall_s"],
                   "detail": os.path.basename(detail_path) if detail_path else None}
         if head.get("two_files"):
@@ -1072,6 +1137,7 @@ def main():
         if "partition" in head:
             pt = head["partition"]
             config["partition"] = {"records_per_rank": pt["records_per_rank"], "halo": pt["halo_positions"],
+                                   "stage_ms_per_rank": pt.get("stage_ms_per_rank"), "from_bam": bool(args.from_bam),
                                    "allreduce_ms": sig(pt["allreduce"]["ms"]) if pt.get("allreduce") else None}
         if "rehearsal" in head:
             config["rehearsal"] = head["rehearsal"]

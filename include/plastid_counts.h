@@ -83,10 +83,17 @@ int pc_device_count(void);
 int pc_create(int device, pc_engine **out);
 /* Every plan of the engine must have been destroyed first (plans return their device blocks to it). */
 int pc_destroy(pc_engine *e);
-/* A destroyed engine leaves its idle device blocks to the process (up to PC_POOL_RESERVOIR_GB, default 96) for the next
- * engine on the same device -- BAMGenomeArray objects come and go, and allocating tens of GB again can take seconds.
+/* A destroyed engine leaves its idle device blocks to the process (up to PC_POOL_RESERVOIR_GB per device, default 4; the
+ * last engine of a device to go trims what is kept to that default) for the next engine on the same device --
+ * BAMGenomeArray objects come and go, and allocating tens of GB again can take seconds.
  * This returns them to the driver (no reference counterpart; for callers that share the GPU with other libraries). */
 int pc_release_cached_memory(int device);
+/* Page-locked host memory for count vectors that are read back repeatedly (pc_read_counts into such a buffer is one DMA
+ * at the rate of the link, no staging through the transfer ring): `bytes` of it, touched by the calling thread's NUMA
+ * policy.  What the reference returns from get_counts is an ordinary numpy array (roitools.pyx:3259-3271); this is an
+ * allocator a caller MAY use for the array it hands to pc_read_counts -- no reference counterpart. */
+int pc_host_alloc(pc_engine *e, uint64_t bytes, void **out);
+int pc_host_free(pc_engine *e, void *p);
 /* The PC_* tuning/diagnostic environment knobs are read once, by pc_create;
  * this re-reads them (tests and experiments only -- no reference counterpart). */
 int pc_reload_knobs(pc_engine *e);
@@ -156,6 +163,14 @@ int pc_read_record_runs(pc_engine *e, int file, int64_t n, const int64_t *idx, c
  *                          for a file staged after the filter was set). */
 int pc_set_alignment_sam(pc_engine *e, int file, int64_t n, const uint16_t *flag, const uint8_t *mapq);
 int pc_set_flag_filter(pc_engine *e, int enabled, uint32_t require, uint32_t exclude, int min_mapq);
+/* The same for the NH:i tag (number of reported alignments of the query): `lambda read: read.get_tag("NH") == 1` is the
+ * usual unique-mapper filter of the reference's users (genome_array.py:697-722, applied :819-820).
+ *   pc_set_alignment_nh    hands the engine the tag's value per record of one staged file (uint16, clamped to 65 535;
+ *                          0: the record has no NH tag); files staged by pc_add_alignment_bam* carry it already.
+ *   pc_set_nh_filter       max_nh > 0: a record is kept iff it has the tag and its value is <= max_nh; 0 lifts the test.
+ *                          Combines with pc_set_flag_filter and the caller's own exclusions (all must keep the read). */
+int pc_set_alignment_nh(pc_engine *e, int file, int64_t n, const uint16_t *nh);
+int pc_set_nh_filter(pc_engine *e, int max_nh);
 
 /* ---- mapping rule: replaces BAMGenomeArray.set_mapping (genome_array.py:935-963)
  * with one of the five factories.  `param` = offset (FIVE/THREE) or nibble
@@ -311,6 +326,9 @@ int pc_bam_read(pc_bam *b, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *
 /* the SAM FLAG word, MAPQ and l_seq of the same records (pysam: read.flag, .mapping_quality, .query_length -- what a
  * filter function may look at, genome_array.py:697-722); any pointer may be NULL */
 int pc_bam_read_sam(pc_bam *b, uint16_t *flag, uint8_t *mapq, int32_t *lseq);
+/* ... and their NH:i tags (0: none), what read.get_tag("NH") / read.has_tag("NH") answer from (pysam AlignedSegment; the
+ * walk over the auxiliary fields is htslib's bam_aux_get, kent/src/htslib/sam.c). */
+int pc_bam_read_nh(pc_bam *b, uint16_t *nh);
 int pc_bam_close(pc_bam *b);
 /* decode `image` and stage it as one more alignment file of the engine (reference ids = the file's own reference
  * list, which must be that of the files staged before it); *mapped (optional) = the file's mapped-read count */

@@ -42,6 +42,8 @@ SIGNATURES = {
     "pc_update_flags": (_int, [_vp, _int, _i64, _vp]),
     "pc_set_alignment_sam": (_int, [_vp, _int, _i64, _vp, _vp]),
     "pc_set_flag_filter": (_int, [_vp, _int, ctypes.c_uint32, ctypes.c_uint32, _int]),
+    "pc_set_alignment_nh": (_int, [_vp, _int, _i64, _vp]),
+    "pc_set_nh_filter": (_int, [_vp, _int]),
     "pc_num_files": (_int, [_vp]),
     "pc_num_records": (_i64, [_vp, _int]),
     "pc_read_records": (_int, [_vp, _int, _i64] + [_vp] * 8),
@@ -60,6 +62,8 @@ SIGNATURES = {
     "pc_sync": (_int, [_vp]),
     "pc_query_segment": (_int, [_vp, _i32, _i64, _i64, ctypes.c_uint8, _int, _int, _vp]),
     "pc_release_cached_memory": (_int, [_int]),
+    "pc_host_alloc": (_int, [_vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
+    "pc_host_free": (_int, [_vp, _vp]),
     "pc_read_counts": (_int, [_vp, _vp, _vp, _i64]),
     "pc_counts_device_ptr": (_vp, [_vp]),
     "pc_stream": (_vp, [_vp]),
@@ -86,6 +90,7 @@ SIGNATURES = {
     "pc_bam_ref_length": (_i32, [_vp, _int]),
     "pc_bam_read": (_int, [_vp] * 11),
     "pc_bam_read_sam": (_int, [_vp, _vp, _vp, _vp]),
+    "pc_bam_read_nh": (_int, [_vp, _vp]),
     "pc_bam_close": (_int, [_vp]),
     "pc_add_alignment_bam": (_int, [_vp, _vp, _i64, ctypes.c_char_p, ctypes.POINTER(_i64)]),
     "pc_bam_open_path": (_int, [_vp, ctypes.c_char_p, _pp]),

@@ -41,6 +41,7 @@ def _load():
         L.pb_wide_count.argtypes = [vp]
         L.pb_fill_wide.argtypes = [vp] * 4
         L.pb_fill_sam.argtypes = [vp] * 4
+        L.pb_fill_nh.argtypes = [vp] * 2
         L.pb_resolve_regions.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)] + [vp] * 9
         _lib = L
     return _lib
@@ -181,6 +182,8 @@ def read_bam_gpu(path, engine, timing=None, regions=None):
         clib.check(L.pc_bam_read(h, p(tid), p(pos), p(alen), p(flags), p(nblk), p(bs), p(bl), p(wi), p(wa), p(wn)))
         flag16, mapq, qlen = np.empty(n, np.uint16), np.empty(n, np.uint8), np.empty(n, np.int32)
         clib.check(L.pc_bam_read_sam(h, p(flag16), p(mapq), p(qlen)))
+        nh = np.empty(n, np.uint16)
+        clib.check(L.pc_bam_read_nh(h, p(nh)))
         if timing is not None:
             timing.update(open_wall_ms=(t_open - t_0) * 1e3, read_wall_ms=(time.perf_counter() - t_open) * 1e3)
             ms = np.zeros(4, np.float64)
@@ -202,7 +205,7 @@ def read_bam_gpu(path, engine, timing=None, regions=None):
         else:
             mapped = span["mapped"]
     out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
-                           validate=False, flag16=flag16, mapq=mapq, qlen=qlen, **wide)   # the device decoder has checked every invariant validate() checks
+                           validate=False, flag16=flag16, mapq=mapq, qlen=qlen, nh=nh, **wide)   # the device decoder has checked every invariant validate() checks
     out.filename = path
     return out
 
@@ -260,6 +263,8 @@ def read_bam(path, threads=0, regions=None):
         # the SAM FLAG word, MAPQ and l_seq of every record: what read filters may look at (genome_array.py:697-722)
         flag16, mapq, qlen = np.empty(n, np.uint16), np.empty(n, np.uint8), np.empty(n, np.int32)
         L.pb_fill_sam(h, p(flag16), p(mapq), p(qlen))
+        nh = np.empty(n, np.uint16)   # ... and the NH:i tag (0: none): read.get_tag("NH") / has_tag("NH")
+        L.pb_fill_nh(h, p(nh))
     finally:
         L.pb_close(h)
     if mapped < 0:   # an index without the per-reference counts samtools writes
@@ -267,6 +272,6 @@ def read_bam(path, threads=0, regions=None):
         warnings.warn("the BAI index of %s carries no mapped-read counts; using the number of alignments read" % path)
         mapped = n
     out = PackedAlignments(tid, pos, alen, flags, nblk, bs, bl, references=refs, lengths=lens, mapped=mapped,
-                           validate=False, flag16=flag16, mapq=mapq, qlen=qlen, **wide)   # the native reader has checked every invariant validate() checks
+                           validate=False, flag16=flag16, mapq=mapq, qlen=qlen, nh=nh, **wide)   # the native reader has checked every invariant validate() checks
     out.filename = path
     return out

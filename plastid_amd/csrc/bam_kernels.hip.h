@@ -37,9 +37,14 @@ constexpr int kInflWG = 64;                 // one wave per BGZF member
 #endif
 constexpr int kWinBytes = PC_BGZF_WINDOW;   // the part of the DEFLATE window (RFC 1951: distances up to 32 768) kept in LDS; further back: HBM
 constexpr int kLitRoot = 9, kDistRoot = 6;  // first-level table bits (zlib's choice: enough.c bounds 852 / 592 entries)
-constexpr int kLitEntries = 1024, kDistEntries = 640;
+// table capacities: zlib's ENOUGH_LENS / ENOUGH_DISTS (inftrees.h: 286 symbols, root 9, 15 bits -> 852 entries; 30 symbols,
+// root 6 -> 592), first level included -- build_table sizes a second-level table by the longest code under its prefix,
+// as inflate_table does for a complete code, so no valid stream needs more.  (Round 6: 1024 / 640 before; with the
+// symbol chain compacted in place and 256 bytes of staged input a wave's LDS is 9.9 KiB instead of 13: sixteen waves
+// per CU instead of twelve.)
+constexpr int kLitEntries = 852, kDistEntries = 592;
 #ifndef PC_BGZF_IN
-#define PC_BGZF_IN 512
+#define PC_BGZF_IN 256
 #endif
 constexpr int kInBytes = PC_BGZF_IN;       // compressed input staged in LDS (two halves)
 constexpr uint32_t kInHalf = kInBytes / 2;
@@ -208,8 +213,10 @@ constexpr int kBatchBits = 512;             // bit offsets per batch: 64 lanes x
 constexpr uint32_t kSymLit = 0u, kSymMatch = 1u, kSymEob = 2u, kSymBad = 3u;   // sym: bits 0-5 consumed, 6-7 kind, 8-15 byte | length - 3, 16-30 distance - 1
 
 struct BatchShared {
-    uint32_t sym[kBatchBits];               // what starts at bit offset i, were it a symbol start
-    uint32_t chain[kBatchBits];             // the symbols that are real, in stream order (a symbol is at least one bit)
+    // what starts at bit offset i, were it a symbol start -- and, once the walk has passed, the symbols that ARE real, in
+    // stream order, compacted IN PLACE: the k-th real symbol starts at an offset >= k (a symbol is at least one bit), so
+    // the walk writes entry k behind its own read position and never over an offset it has yet to read
+    uint32_t sym[kBatchBits];
 };
 
 struct HeaderShared {
@@ -297,8 +304,8 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
     int err = kInfOk;
 
     // ---- input: `in` holds the kInBytes of the stream around the read position (ring); refilled a half at a time by
-    // the wave when the reader has crossed into the other half (512 bytes: a batch looks 84 bytes ahead; with 1 KiB a
-    // wave's LDS is 13.5 KiB -- eleven waves per CU -- with 512 bytes 13.0: twelve)
+    // the wave when the reader has crossed into the other half (256 bytes: a batch looks 84 bytes ahead of its first bit,
+    // and a half is staged before the reader comes within 8 bytes of the staged end -- both fit 128-byte halves)
     uint32_t in_pos = 0;          // next byte of the stream to pull into the bit buffer (always a multiple of 4)
     uint32_t in_loaded = 0;       // bytes of the stream staged so far (multiple of kInHalf)
     auto stage_half = [&]() {     // stage stream bytes [in_loaded, in_loaded + kInHalf)
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                     // a dozen instructions per symbol and one LDS read on the dependent chain; every lane stores the same
                     // value to the same place (no mask to set up)
                     uint32_t va = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)bs.sym;
-                    const uint32_t vn0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)bs.chain;
+                    const uint32_t vn0 = va;   // (the chain is written over the offset table: see BatchShared)
                     uint32_t vn = vn0, vs, sv;
                     asm volatile("s_mov_b32 %[walk], 0\n\t"
                                  "1:\n\t"
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                 for (uint32_t c0 = 0; c0 < nsym && !stopped; c0 += 64) {
                     const uint32_t idx = c0 + (uint32_t)lane;
                     const bool have = idx < nsym;
-                    const uint32_t sv = have ? bs.chain[idx] : 0u;
+                    const uint32_t sv = have ? bs.sym[idx] : 0u;
                     const uint32_t kind = (sv >> 6) & 3u;
                     const uint32_t ol = !have ? 0u : (kind == kSymLit ? 1u : (kind == kSymMatch ? ((sv >> 8) & 255u) + 3u : 0u));
                     // one prefix sum for both: bytes produced (bits 0-15; <= 64 x 258) and bits consumed (16-31; <= 64 x 48)
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
                     // bytes are marked in 64 flag bytes (the offset table of the batch is free by now), and a byte's owner is the
                     // number of marks up to it -- a ballot and a population count; the owner's source and start come by lane permute.
                     if (!(PC_BGZF_SKIP & 1) && __ballot(ism && !dep) != 0ull) {
-                        uint8_t *marks = (uint8_t *)bs.sym;
+                        uint8_t *marks = (uint8_t *)bs.sym;   // (entries 0 .. 15 of the chain: this chunk's symbols are in registers, later chunks read from entry 64 on)
                         const uint32_t startrel = emit ? q - chunk_start : 0xffffu;
                         const uint32_t info = (startrel & 0xffffu) | ((ism && !dep) ? 1u << 16 : 0u) | (far ? 1u << 17 : 0u);
                         for (uint32_t base = 0; base < chunk_bytes; base += 64u) {
@@ -827,9 +834,51 @@ struct RecOut {
     uint8_t err;
     uint8_t placed;             // 0 unplaced (tid < 0), 1 placed, 2 placed but outside every requested region (region reads: not staged)
     int32_t lseq;               // l_seq (pysam's query_length)
-    uint32_t mapq;
+    uint32_t mapq;              // bits 0-7 MAPQ; bits 16-31 the NH:i tag (clamped to 65 535; 0: the record has none)
     int32_t end;                // one past the last aligned position (spos + 1 without aligned bases): the overlap test of region reads
 };
+
+// NH:i of a record (bam_stager.cpp aux_nh, bit for bit): the auxiliary fields behind the qualities, {tag[2], type, value}
+// each (SAM spec 4.2.4; htslib bam_aux_get's walk); the value of an integer-typed NH clamped to [0, 65 535], 0 without one.
+__device__ __forceinline__ uint32_t aux_nh(const uint8_t *after_cigar, int32_t l_seq, const uint8_t *end) {
+    if (l_seq < 0) return 0u;
+    const uint8_t *a = after_cigar + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    while (a + 3 <= end && a >= after_cigar) {
+        const uint32_t t0 = a[0], t1 = a[1], type = a[2];
+        a += 3;
+        size_t sz;
+        if (type == 'A' || type == 'c' || type == 'C') sz = 1;
+        else if (type == 's' || type == 'S') sz = 2;
+        else if (type == 'i' || type == 'I' || type == 'f') sz = 4;
+        else if (type == 'Z' || type == 'H') {
+            const uint8_t *z = a;
+            while (z < end && *z) ++z;
+            if (z >= end) return 0u;
+            sz = (size_t)(z - a) + 1;
+        } else if (type == 'B') {
+            if (a + 5 > end) return 0u;
+            const uint32_t sub = a[0];
+            const uint32_t cnt = (uint32_t)a[1] | ((uint32_t)a[2] << 8) | ((uint32_t)a[3] << 16) | ((uint32_t)a[4] << 24);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : ((sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0));
+            if (!es) return 0u;
+            sz = 5 + (size_t)cnt * es;
+        } else return 0u;
+        if ((size_t)(end - a) < sz) return 0u;
+        if (t0 == 'N' && t1 == 'H') {
+            long long v;
+            if (type == 'c') v = (int8_t)a[0];
+            else if (type == 'C') v = a[0];
+            else if (type == 's') v = (int16_t)((uint32_t)a[0] | ((uint32_t)a[1] << 8));
+            else if (type == 'S') v = (uint32_t)a[0] | ((uint32_t)a[1] << 8);
+            else if (type == 'i') v = (int32_t)((uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)a[2] << 16) | ((uint32_t)a[3] << 24));
+            else if (type == 'I') v = (uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)a[2] << 16) | ((uint32_t)a[3] << 24);
+            else return 0u;
+            return (uint32_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+        }
+        a += sz;
+    }
+    return 0u;
+}
 
 // One thread per record start (member-major, k_bam_chain's order): fields and CIGAR -> RecOut.
 __global__ __launch_bounds__(256) void k_bam_fields(const uint8_t *__restrict__ stream, uint64_t stream_len, const Member *__restrict__ members,
@@ -861,6 +910,7 @@ __global__ __launch_bounds__(256) void k_bam_fields(const uint8_t *__restrict__ 
     if (pos < 0) { o.err = kRecNegPos; recs[i] = o; return; }
     if ((uint64_t)32 + l_name + 4ull * n_cig > bs) { o.err = kRecCigarOverrun; recs[i] = o; return; }
     const uint8_t *cig = r + 32 + l_name;
+    o.mapq |= aux_nh(cig + 4ull * n_cig, o.lseq, r + bs) << 16;
     int64_t ref = pos, L = 0, run_end = -1;
     int32_t first_run = -1;
     uint32_t nruns = 0;
@@ -913,7 +963,7 @@ __global__ __launch_bounds__(256) void k_bam_columns(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ staged_at, const uint32_t *__restrict__ run_at,
                                                      int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags, uint8_t *nblk,
                                                      int32_t *blk_start, int32_t *blk_len, uint32_t *wide_flag,
-                                                     uint16_t *flag16, uint8_t *mapq, int32_t *lseq) {
+                                                     uint16_t *flag16, uint8_t *mapq, int32_t *lseq, uint16_t *nh) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nrec) return;
     const RecOut o = recs[i];
@@ -927,6 +977,7 @@ __global__ __launch_bounds__(256) void k_bam_columns(const uint8_t *__restrict__
     nblk[k] = wide ? (uint8_t)255 : (uint8_t)o.nruns;
     flag16[k] = o.flag;
     mapq[k] = (uint8_t)o.mapq;
+    nh[k] = (uint16_t)(o.mapq >> 16);
     lseq[k] = o.lseq;
     if (wide) wide_flag[k] = 1u;
     if (o.nruns < 2u) return;

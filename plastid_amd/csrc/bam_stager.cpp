@@ -58,6 +58,9 @@ struct Part {
     uint16_t *flag16 = nullptr;
     uint8_t *mapq = nullptr;
     int32_t *lseq = nullptr;
+    // ... and the NH:i tag (number of reported alignments of the query; `read.get_tag("NH") == 1` is the usual unique-mapper
+    // filter): its value clamped to 65 535, 0 when the record carries none
+    uint16_t *nh = nullptr;
     size_t n = 0, nrun = 0;
     int64_t mapped = 0, unplaced = 0, total = 0;
     // wide records of the piece (more than 65 535 aligned positions or more than 255 aligned runs: markers 65535 / 255 in
@@ -156,14 +159,14 @@ struct Arena {
 // finished columns are copied into the Arena at their exact size).
 struct Cols {
     std::vector<int32_t> tid, pos, blk_start, blk_len;
-    std::vector<uint16_t> alen, flag16;
+    std::vector<uint16_t> alen, flag16, nh;
     std::vector<uint8_t> flags, nblk, mapq;
     std::vector<int32_t> lseq;
     size_t n = 0;   // records held: the five per-record columns are sized for the piece up front and written by index
     void clear() { n = 0; blk_start.clear(); blk_len.clear(); }
     void room(size_t records) {
         if (tid.size() < records) { tid.resize(records); pos.resize(records); alen.resize(records); flags.resize(records); nblk.resize(records);
-                                      flag16.resize(records); mapq.resize(records); lseq.resize(records); }
+                                      flag16.resize(records); mapq.resize(records); lseq.resize(records); nh.resize(records); }
     }
 };
 
@@ -353,6 +356,52 @@ int parse_header(Bam &bam, const uint8_t *&p, const uint8_t *end, uint32_t &n_re
 // `pt` with every per-record format check and the order checks inside the piece.  Returns where it
 // stopped: `limit`, the start of the first record that crosses `limit`, or the record whose length
 // prefix is impossible (pt.bad_size).  A defect ends the piece (pt.err, pt.err_rec).
+// NH:i of a record: the auxiliary fields follow the packed sequence ((l_seq + 1) / 2 bytes) and the qualities (l_seq bytes)
+// behind the CIGAR; each is {tag[2], type, value} (SAM spec 4.2.4; walked as htslib's bam_aux_get does, sam.c:915-965 in the
+// vendored tree: A c C one byte, s S two, i I f four, Z H NUL-terminated, B {subtype, count:u32, elements}).  The value of
+// an integer-typed NH, clamped to [0, 65 535]; 0 when the record has no such field (or the fields are malformed).
+static inline uint16_t aux_nh(const uint8_t *after_cigar, int32_t l_seq, const uint8_t *end) {
+    if (l_seq < 0) return 0;
+    const uint8_t *a = after_cigar + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    while (a + 3 <= end && a >= after_cigar) {
+        const uint8_t t0 = a[0], t1 = a[1], type = a[2];
+        a += 3;
+        size_t sz;
+        switch (type) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': { const uint8_t *z = a; while (z < end && *z) ++z; if (z >= end) return 0; sz = (size_t)(z - a) + 1; break; }
+        case 'B': {
+            if (a + 5 > end) return 0;
+            const uint8_t sub = a[0];
+            const uint32_t cnt = rd32(a + 1);
+            const size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : ((sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0));
+            if (!es) return 0;
+            sz = 5 + (size_t)cnt * es;
+            break;
+        }
+        default: return 0;
+        }
+        if ((size_t)(end - a) < sz) return 0;
+        if (t0 == 'N' && t1 == 'H') {
+            int64_t v;
+            switch (type) {
+            case 'c': v = (int8_t)a[0]; break;
+            case 'C': v = a[0]; break;
+            case 's': v = (int16_t)rd16(a); break;
+            case 'S': v = rd16(a); break;
+            case 'i': v = (int32_t)rd32(a); break;
+            case 'I': v = rd32(a); break;
+            default: return 0;
+            }
+            return (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+        }
+        a += sz;
+    }
+    return 0;
+}
+
 const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint8_t *q, const uint8_t *limit, uint32_t n_ref, int64_t max_rec) {
     std::vector<std::pair<int32_t, int32_t>> runs;
     cols.clear();
@@ -364,6 +413,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
     uint8_t *const c_flags = cols.flags.data(), *const c_nblk = cols.nblk.data(), *const c_mapq = cols.mapq.data();
     uint16_t *const c_flag16 = cols.flag16.data();
     int32_t *const c_lseq = cols.lseq.data();
+    uint16_t *const c_nh = cols.nh.data();
     size_t n = 0;
     int64_t total = pt.total, mapped = pt.mapped, unplaced = pt.unplaced;
     bool any_placed = pt.any_placed, saw_unplaced = pt.saw_unplaced;
@@ -405,6 +455,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         const bool first = n == 0;
         if ((size_t)32 + l_read_name + (size_t)n_cigar * 4 > block_size) { ret = bad(i, false, "corrupt BAM record (cigar overruns block)"); break; }
         const uint8_t *cig = r + 32 + l_read_name;
+        const uint16_t nh = aux_nh(cig + (size_t)n_cigar * 4, l_seq, q);
         if (n_cigar == 1) {   // the common record: one M / = / X operation (one aligned run starting at pos)
             const uint32_t v = rd32(cig), op = v & 0xf, len = v >> 4;
             if ((op == 0 || op == 7 || op == 8) && len > 0 && len <= 65535 && (int64_t)pos + len <= 0x7fffffffLL) {
@@ -419,7 +470,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
                 c_alen[n] = (uint16_t)len;
                 c_flags[n] = (flag & 0x10) ? 1 : 0;
                 c_nblk[n] = 1;
-                c_flag16[n] = flag; c_mapq[n] = mapq; c_lseq[n] = l_seq;
+                c_flag16[n] = flag; c_mapq[n] = mapq; c_lseq[n] = l_seq; c_nh[n] = nh;
                 ++n;
                 continue;
             }
@@ -469,7 +520,7 @@ const uint8_t *decode_span_cols(const Bam &bam, Part &pt, Cols &cols, const uint
         c_alen[n] = wide ? (uint16_t)65535 : (uint16_t)L;
         c_flags[n] = (flag & 0x10) ? 1 : 0;
         c_nblk[n] = wide ? (uint8_t)255 : (uint8_t)runs.size();
-        c_flag16[n] = flag; c_mapq[n] = mapq; c_lseq[n] = l_seq;
+        c_flag16[n] = flag; c_mapq[n] = mapq; c_lseq[n] = l_seq; c_nh[n] = nh;
         ++n;
         if (runs.size() >= 2)
             for (auto &x : runs) {
@@ -490,7 +541,7 @@ const uint8_t *decode_span(Bam &bam, Part &pt, const uint8_t *q, const uint8_t *
     // the finished columns, at their exact size, into the load's arena
     const size_t n = cols.n, m = cols.blk_start.size();
     if (n) {
-        uint8_t *mem = (uint8_t *)bam.arena.alloc(n * 19 + 64 * 8 + m * 8 + 64 * 2);
+        uint8_t *mem = (uint8_t *)bam.arena.alloc(n * 21 + 64 * 9 + m * 8 + 64 * 2);
         if (!mem) {
             if (pt.err_rec == INT64_MAX) { pt.err_rec = 0; pt.err_before_order = true; pt.err = "out of memory reading " + bam.path; }
             return stop;
@@ -502,6 +553,8 @@ const uint8_t *decode_span(Bam &bam, Part &pt, const uint8_t *q, const uint8_t *
         std::memcpy(pt.alen, cols.alen.data(), n * 2); std::memcpy(pt.flags, cols.flags.data(), n); std::memcpy(pt.nblk, cols.nblk.data(), n);
         pt.flag16 = (uint16_t *)take(n * 2); pt.mapq = take(n); pt.lseq = (int32_t *)take(n * 4);
         std::memcpy(pt.flag16, cols.flag16.data(), n * 2); std::memcpy(pt.mapq, cols.mapq.data(), n); std::memcpy(pt.lseq, cols.lseq.data(), n * 4);
+        pt.nh = (uint16_t *)take(n * 2);
+        std::memcpy(pt.nh, cols.nh.data(), n * 2);
         if (m) {
             pt.blk_start = (int32_t *)take(m * 4); pt.blk_len = (int32_t *)take(m * 4);
             std::memcpy(pt.blk_start, cols.blk_start.data(), m * 4); std::memcpy(pt.blk_len, cols.blk_len.data(), m * 4);
@@ -1098,7 +1151,7 @@ int decode_regions(Bam &bam, int nthreads, int nreg, const char *const *rname, c
                                            : (int64_t)pt.pos[i] + std::max<int64_t>(L, 1);
             if (overlaps(pt.tid[i], pt.pos[i], endpos)) {
                 pt.tid[w] = pt.tid[i]; pt.pos[w] = pt.pos[i]; pt.alen[w] = pt.alen[i]; pt.flags[w] = pt.flags[i]; pt.nblk[w] = pt.nblk[i];
-                pt.flag16[w] = pt.flag16[i]; pt.mapq[w] = pt.mapq[i]; pt.lseq[w] = pt.lseq[i];
+                pt.flag16[w] = pt.flag16[i]; pt.mapq[w] = pt.mapq[i]; pt.lseq[w] = pt.lseq[i]; pt.nh[w] = pt.nh[i];
                 for (size_t k = 0; k < runs; ++k) { pt.blk_start[rw + k] = pt.blk_start[rr + k]; pt.blk_len[rw + k] = pt.blk_len[rr + k]; }
                 if (wide) { pt.wide_idx[ww] = (int64_t)w; pt.wide_alen[ww] = pt.wide_alen[wk]; pt.wide_nblk[ww] = pt.wide_nblk[wk]; ++ww; }
                 ++w;
@@ -1303,6 +1356,18 @@ int pb_fill(void *h, int32_t *tid, int32_t *pos, uint16_t *alen, uint8_t *flags,
 // The SAM FLAG word, MAPQ and l_seq of every staged record (same order as pb_fill's columns): what pysam exposes as
 // read.flag / .mapping_quality / .query_length (and the is_* properties derived from the flag bits) to the filter
 // functions of BAMGenomeArray.add_filter (genome_array.py:697-722).  Any pointer may be NULL.
+// The NH:i tag of every staged record (same order): its value clamped to 65 535, 0 where a record has none -- what
+// `read.get_tag("NH")` / `read.has_tag("NH")` answer from in a filter function (genome_array.py:697-722, 819-820).
+int pb_fill_nh(void *h, uint16_t *nh) {
+    Bam *b = static_cast<Bam *>(h);
+    if (!b || !b->loaded) return fail("pb_fill_nh: file not loaded");
+    for (size_t k = 0; k < b->parts.size(); ++k) {
+        const Part &pt = b->parts[k];
+        if (pt.n && nh) std::memcpy(nh + b->rec_off[k], pt.nh, pt.n * 2);
+    }
+    return 0;
+}
+
 int pb_fill_sam(void *h, uint16_t *flag16, uint8_t *mapq, int32_t *lseq) {
     Bam *b = static_cast<Bam *>(h);
     if (!b || !b->loaded) return fail("pb_fill_sam: file not loaded");

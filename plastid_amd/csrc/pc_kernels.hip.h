@@ -1851,7 +1851,7 @@ __global__ __launch_bounds__(kWG) void k_cs_scatter(const uint2 *__restrict__ re
 __global__ void k_center_vals(MapParams mp, const double *__restrict__ invh, double *cvalh, uint32_t *cursors, uint32_t grid_p) {
     const int L = (int)threadIdx.x, m = L - 2 * mp.param;
     if (L < 256) cvalh[L] = (m > 0 && size_ok(mp, L)) ? invh[m] : 0.0;
-    if (cursors && L < 8) cursors[16 * L] = (grid_p + 7u) >> 3;
+    if (cursors && L < 33) cursors[16 * L] = L < 32 ? (grid_p + 31u) >> 5 : grid_p;   // ([32]: the heavy entries' cursor)
 }
 
 // Dispatch list of the center kernel.  A chunk's replay is sequential in the reads that overlap
@@ -2350,6 +2350,9 @@ enum { kCsStart = 0, kCsShape = 1, kCsEnt0 = 2, kCsToEnd = 3, kCsLo = 4, kCsHi =
 #ifndef PC_CENTER2_RING
 #define PC_CENTER2_RING 4
 #endif
+#ifndef PC_CENTER_HEAVY_RING
+#define PC_CENTER_HEAVY_RING 12   // batches in flight for a heavy entry
+#endif
 
 // steps the replay executes for a row range of `n` entries (batches of 16, the last one rounded up to whole quarters)
 __device__ __forceinline__ uint32_t center_steps_of(uint32_t n) { return (n & ~15u) + (((n & 15u) + 3u) & ~3u); }
@@ -2452,7 +2455,7 @@ struct Center2Ctx {
     int norm_on;
     unsigned long long *dbg;
     uint32_t dbg_cap;
-    uint32_t *cursors;         // persistent form (k_center2p): [16 x] = next light entry of eighth x (one cursor per 64-byte line)
+    uint32_t *cursors;         // persistent form (k_center2p): [16 p] = next light entry of part p (32 parts, four per XCD), [16 * 32] = next heavy entry (one cursor per 64-byte line)
 };
 
 // One (sub-)chunk from its descriptor `d` (lane l < 32 holds dword l; the upper half of the wave holds a copy).
@@ -2700,11 +2703,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBG ? 7 : 8,
     __shared__ double s_valh[256];
     if (!(PC_CENTER_SKIP & 8)) for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t c = 0; c < count; ++c) {
-        uint32_t dn = 0u;
-        if (c + 1u < count) dn = sw[(size_t)(first + c + 1u) * 32u + (uint32_t)(lane & 31)];   // the next descriptor, in flight while this chunk replays
-        center_slot<DBG, GENERAL, PC_CENTER2_RING>(cx, d, -1, lane, s_valh, n_slots);
-        d = dn;
+    if (!GENERAL && PC_CENTER_HEAVY_RING != PC_CENTER2_RING && bidx < n_heavy) {   // (the short-read instantiation: with the indirect-entry path unrolled into both rings the other one spills)
+        // a heavy entry: PC_CENTER_HEAVY_RING batches in flight (four bound a 32 k-step replay by the memory round trip --
+        // 64 steps per ~3 600 cycles -- not by the steps)
+        center_slot<DBG, GENERAL, PC_CENTER_HEAVY_RING>(cx, d, -1, lane, s_valh, n_slots);
+    } else {
+        for (uint32_t c = 0; c < count; ++c) {
+            uint32_t dn = 0u;
+            if (c + 1u < count) dn = sw[(size_t)(first + c + 1u) * 32u + (uint32_t)(lane & 31)];   // the next descriptor, in flight while this chunk replays
+            center_slot<DBG, GENERAL, PC_CENTER2_RING>(cx, d, -1, lane, s_valh, n_slots);
+            d = dn;
+        }
     }
     if (dbg && lane == 0 && first < cx.dbg_cap) {   // PC_CENTER_DEBUG: heavy entries from the front of the table, light ones from its back (as k_center's list)
         const size_t at = first < n_heavy ? (size_t)first : (size_t)cx.dbg_cap - 1u - (size_t)(first - n_heavy);
@@ -2713,38 +2722,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBG ? 7 : 8,
     }
 }
 
-// ---------------------------------------------------------------- k_center_heavy / k_center2p (round 6)
+// ---------------------------------------------------------------- k_center2p (round 6)
 // Where round 5's k_center2 stood (C3, PC_CENTER_DEBUG): the launch ends with its HEAVY entries -- 32 k dependent steps
 // at ~56 cycles each although the wave runs at raised priority -- and the bulk (one wave per light entry, ~300 steps)
-// keeps ~6 900 of 8 192 wave slots resident, each wave a third of its life in the two dependent trips at its head.
-//   * 56 cycles per step is the PREFETCH DEPTH, not the issue rate: four batches of sixteen entries per row in flight,
-//     one memory round trip (~3 600 cycles under load) per 64 steps.  k_center_heavy serves the heavy entries -- one wave
-//     each, raised priority, as before -- with PC_CENTER_HEAVY_RING (twelve) batches in flight, on a stream of its own
-//     beside the light entries' kernel (launched first: its waves are placed before that one fills the chip).
-//   * k_center2p: a PERSISTENT grid for the light entries -- as many one-wave workgroups as the chip holds, launched
-//     once.  A wave claims one entry at a time from the cursor of its XCD's eighth of the list (workgroup b runs on XCD
-//     b mod 8; neighbouring chunks re-read each other's halo, which then sits in that XCD's L2) and, when its eighth is
-//     exhausted, from the others'.  The next entry's descriptor and the claim after it are in flight while an entry
-//     replays, so a chunk starts with ONE dependent trip (its entries) instead of a wave launch, an LDS table fill and
-//     two trips.
+// keeps ~6 100 of 8 192 wave slots resident, each wave a third of its life in the two dependent trips at its head.
+//   * 56 cycles per step is partly the PREFETCH DEPTH: four batches of sixteen entries per row in flight, one memory
+//     round trip per 64 steps.  Heavy entries replay with PC_CENTER_HEAVY_RING (twelve) batches in flight, in k_center2
+//     and here: 0.70 -> 0.61 ms for the 32 k-step entries (a lone wave's dependent step chain is 17 cycles: 0.30 ms).
+//   * k_center2p: a PERSISTENT grid -- as many one-wave workgroups as the chip holds, launched once.  Wave b first serves
+//     heavy entry b (they all start at t = 0, as before), then claims light entries one at a time from the cursor of its
+//     part of the list and, when that is exhausted, from the others'.  The next entry's descriptor and the claim after
+//     it are in flight while an entry replays, so a chunk starts with ONE dependent trip (its entries) instead of a wave
+//     launch, an LDS table fill and two trips.
+//     (Also measured: the heavy entries in a kernel of their own on a second stream, launched first -- the device placed
+//     the light entries' persistent grid first all the same, and the heavy entries ran behind it: 1.53 ms.)
 constexpr uint32_t kCursorStride = 16;   // dwords between cursors: one 64-byte line each
-#ifndef PC_CENTER_HEAVY_RING
-#define PC_CENTER_HEAVY_RING 12
-#endif
-
-template <bool GENERAL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_center_heavy(Center2Ctx cx) {
-    const int lane = threadIdx.x & 63;
-    if (PC_CENTER_HEAVY_PRIO) __builtin_amdgcn_s_setprio(PC_CENTER_HEAVY_PRIO);
-    const uint32_t PC_GLOBAL *sw = (const uint32_t PC_GLOBAL *)cx.slots;
-    const uint32_t d = sw[(size_t)blockIdx.x * 32u + (uint32_t)(lane & 31)];   // (grid = the heavy entries: the front of the table)
-    __shared__ double s_valh[256];
-    for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long n_slots = 0;
-    center_slot<false, GENERAL, PC_CENTER_HEAVY_RING>(cx, d, -1, lane, s_valh, n_slots);
-}
-
 template <bool GENERAL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_center2p(Center2Ctx cx) {
     const uint32_t n_heavy = cx.n_heavy, n_light = cx.n_light;   // (the host knows the list's counts: the first count of a plan runs k_center2)
@@ -2755,11 +2747,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
     __builtin_amdgcn_wave_barrier();
     unsigned long long n_slots = 0;
-    const uint32_t n8 = (n_light + 7u) >> 3;                           // entries per eighth of the light list
+    // ---- heavy entries first: wave b serves heavy entry b (they all start at t = 0, as in k_center2), then whatever the
+    // heavy cursor hands out (a list with more heavy entries than the grid has waves), with PC_CENTER_HEAVY_RING batches
+    // in flight and at raised priority
+    // (the kernel's arguments are read from the argument segment again for every entry, and what depends on the lane alone
+    // -- permute indices, the lane's place in a descriptor -- is worked out again per entry: hoisted out of the loops below
+    // they would be held in registers across them -- a wave of this kernel has 80 scalar and 64 vector ones -- and spill)
+    typedef const Center2Ctx __attribute__((address_space(4))) CtxK;
+    CtxK *cxk = (CtxK *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (blockIdx.x < n_heavy) {
+        if (PC_CENTER_HEAVY_PRIO) __builtin_amdgcn_s_setprio(PC_CENTER_HEAVY_PRIO);
+        uint32_t h = blockIdx.x;
+        while (h < n_heavy) {
+            int lane_h = lane;
+            asm volatile("" : "+s"(cxk), "+v"(lane_h));
+            const uint32_t dh = sw[(size_t)h * 32u + (uint32_t)(lane_h & 31)];
+            uint32_t got = 0xffffffffu;
+            if (n_heavy > gridDim.x) { if (lane_h == 0) got = atomicAdd(&cursors[kCursorStride * 32u], 1u); }   // (uniform condition; in flight while this one replays)
+            center_slot<false, GENERAL, PC_CENTER_HEAVY_RING>(*(const Center2Ctx *)cxk, dh, -1, lane_h, s_valh, n_slots);
+            h = n_heavy > gridDim.x ? (uint32_t)__builtin_amdgcn_readfirstlane((int)got) : 0xffffffffu;
+        }
+        if (PC_CENTER_HEAVY_PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+    if (n_light == 0u) return;
+    // The light list in kParts contiguous parts, a cursor each: XCD x (workgroup b runs on XCD b mod 8) owns parts
+    // 4x .. 4x + 3 -- its eighth of the list -- and a wave claims from part 4 (b mod 8) + (b / 8) mod 4.  (One cursor per
+    // XCD was measured first: 284 k claims a launch on eight addresses is 55 atomics per microsecond and address, two
+    // thirds of what one address takes at all -- the claims queued up and the kernel ran at 1.13 ms against 0.85.)
+    constexpr uint32_t kParts = 32u;
+    const uint32_t n8 = (n_light + kParts - 1u) / kParts;              // entries per part
     auto eighth_len = [&](uint32_t xx) { const uint32_t lo8 = xx * n8; return lo8 < n_light ? (lo8 + n8 < n_light ? n8 : n_light - lo8) : 0u; };
-    uint32_t x = blockIdx.x & 7u;       // the eighth this wave claims from (its XCD's, until that is exhausted)
-    uint32_t spent = 0u;                // eighths seen exhausted (bit x)
-    // a claim: what the atomic returned (lane 0), made on eighth `on`
+    uint32_t x = (blockIdx.x & 7u) * 4u + ((blockIdx.x >> 3) & 3u);   // the part this wave claims from (until that is exhausted)
+    uint32_t spent = 0u;                // parts seen exhausted (bit x)
+    // a claim: what the atomic returned (lane 0), made on part `on`
     auto issue = [&](uint32_t on) { uint32_t r = 0u; if (lane == 0) r = atomicAdd(&cursors[kCursorStride * on], 1u); return r; };
     // -> the claimed entry's index in the slot table, or 0xffffffff: nothing left anywhere
     auto resolve = [&](uint32_t raw, uint32_t on) -> uint32_t {
@@ -2767,8 +2787,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         while (true) {
             if (idx < eighth_len(on)) return n_heavy + on * n8 + idx;
             spent |= 1u << on;
-            if (spent == 0xffu) return 0xffffffffu;
-            while ((spent >> x) & 1u) x = (x + 1u) & 7u;                 // (a claim made before x moved on is retried where x is now)
+            if (spent == 0xffffffffu) return 0xffffffffu;
+            while ((spent >> x) & 1u) x = (x + 1u) & (kParts - 1u);      // (a claim made before x moved on is retried where x is now; the next part is this XCD's own until its eighth is done)
             on = x;
             idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue(on));
         }
@@ -2776,26 +2796,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // pipeline: entry e0 replays from its descriptor d0 (a register that is free again once the replay has taken its fields
     // out), the NEXT entry's descriptor is in flight in lanes 0-31 of `pre`, and the claim after that in lane 32 of the
     // same register (both are waited for only after the replay).
-    // A wave's first claim needs no atomic: entry number (b >> 3) of its eighth (k_center_vals starts the cursors behind those).
+    // A wave's first claim needs no atomic: entry number (b >> 5) of its part (k_center_vals starts the cursors behind those).
     const uint32_t none = 0xffffffffu;
-    uint32_t e0 = resolve(blockIdx.x >> 3, x);
+    uint32_t e0 = resolve(blockIdx.x >> 5, x);
     uint32_t d0 = e0 != none ? sw[(size_t)e0 * 32u + (uint32_t)(lane & 31)] : 0u;
     uint32_t e1 = none;
     if (e0 != none) { const uint32_t on1 = x; e1 = resolve(issue(on1), on1); }
     uint32_t pre = (e1 != none && lane < 32) ? sw[(size_t)e1 * 32u + (uint32_t)lane] : 0u;
-    // (the kernel's arguments are read from the argument segment again for every entry: hoisted out of this loop they
-    // would be held in scalar registers across it -- a wave of this kernel has 80 -- and spill)
-    typedef const Center2Ctx __attribute__((address_space(4))) CtxK;
-    CtxK *cxk = (CtxK *)__builtin_amdgcn_kernarg_segment_ptr();
     while (e0 != none) {
         const uint32_t on2 = x;
+#ifdef PC_CENTER_P_SPLIT
+        uint32_t r2 = 0u;
+        if (e1 != none && lane == 32) r2 = atomicAdd(&cursors[kCursorStride * on2], 1u);
+#else
         if (e1 != none && lane == 32) pre = atomicAdd(&cursors[kCursorStride * on2], 1u);
+#endif
         // (likewise what depends on the lane alone -- permute indices, the lane's place in a descriptor -- is worked out
         // again per entry, a dozen instructions, instead of living in vector registers across the loop: the kernel has 64)
         int lane_i = lane;
         asm volatile("" : "+s"(cxk), "+v"(lane_i));
         center_slot<false, GENERAL, PC_CENTER2_RING>(*(const Center2Ctx *)cxk, d0, 0, lane_i, s_valh, n_slots);
+#ifdef PC_CENTER_P_SPLIT
+        const uint32_t e2 = e1 != none ? resolve(lane_u32(r2, 32), on2) : none;
+#else
         const uint32_t e2 = e1 != none ? resolve(lane_u32(pre, 32), on2) : none;
+#endif
         e0 = e1; d0 = pre;
         e1 = e2;
         asm volatile("" : "+v"(lane_i));
@@ -2873,16 +2898,22 @@ __global__ __launch_bounds__(kWG) void k_update_flags(uint2 *rec, uint32_t *stre
 // `lambda read: not read.is_secondary and read.mapping_quality >= 10` decides per read on the host
 // (genome_array.py:697-722, applied :819-820), here one pass over 3 bytes per record in HBM.  The caller's own
 // exclusions (kFlagUser) stay; `enabled` = 0 restores them alone.
+// `max_nh` (0: no such test; round 6): keep a read only if it carries an NH:i tag of at most `max_nh` reported alignments
+// -- `read.has_tag("NH") and read.get_tag("NH") <= max_nh`, the unique-mapper filter for max_nh = 1; `nh` = the tag's
+// value per record, 0 without one.
 __global__ __launch_bounds__(kWG) void k_flag_filter(uint2 *rec, uint32_t *stream, const uint16_t *__restrict__ sam_flag,
                                                      const uint8_t *__restrict__ mapq, int64_t n, uint32_t enabled, uint32_t require,
-                                                     uint32_t exclude, uint32_t min_mapq) {
+                                                     uint32_t exclude, uint32_t min_mapq, const uint16_t *__restrict__ nh, uint32_t max_nh) {
     const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
     if (i >= n) return;
     uint2 r = rec[i];
     bool out = ((r.y >> 16) & kFlagUser) != 0u;
     if (enabled) {
-        const uint32_t f = sam_flag[i];
-        out = out || (f & require) != require || (f & exclude) != 0u || (uint32_t)mapq[i] < min_mapq;
+        if (sam_flag) {   // (nullptr: an NH filter alone, on a file without the FLAG / MAPQ columns)
+            const uint32_t f = sam_flag[i];
+            out = out || (f & require) != require || (f & exclude) != 0u || (uint32_t)mapq[i] < min_mapq;
+        }
+        if (max_nh) { const uint32_t v = nh[i]; out = out || v == 0u || v > max_nh; }
     }
     const uint32_t y = (r.y & ~(kFlagExcluded << 16)) | (out ? kFlagExcluded << 16 : 0u);
     if (y == r.y) return;

@@ -504,6 +504,8 @@ struct StagedFile {
     DevBuf<uint16_t> sam_flag;
     DevBuf<uint8_t> sam_mapq;
     bool have_sam = false;
+    DevBuf<uint16_t> sam_nh;           // the NH:i tag of every record (0: none): pc_set_alignment_nh, or straight from the device decoder
+    bool have_nh = false;
     // center streams (built at the first center-rule count that needs them; dropped when the host-side filters change)
     DevBuf<uint2> cs_ent[3];
     DevBuf<uint32_t> cs_soff[3];
@@ -554,7 +556,7 @@ struct Knobs {
     int center_t2 = 4;         //   count are cut into 4 (8) sub-chunks
     int64_t center_floor = 32768; // PC_CENTER_FLOOR: stream entries below which a chunk is never cut (a wave alone replays ~50 k per ms)
     int center_lds = 0;        // PC_CENTER_LDS: bytes of (unused) LDS per k_center workgroup -- an occupancy throttle for experiments
-    int center_mode = 2;       // PC_CENTER_MODE: 0 round 5's k_center2 (one wave per dispatch entry); 2 k_center_heavy (deep prefetch) beside k_center2p (persistent waves over the light entries)
+    int center_mode = 2;       // PC_CENTER_MODE: 0 round 5's k_center2 (one wave per dispatch entry); 2 k_center2p (persistent waves: heavy entries first, then light entries claimed from 32 cursors)
     int center_pwaves = 8;     // PC_CENTER_PWAVES: persistent waves per SIMD (the kernel is compiled for eight)
     int center_legacy = 0;     // PC_CENTER_LEGACY: one-file plans through round 4's k_center too (A/B against k_center2)
     int center_per_wave = 0;   // (reserved)
@@ -620,6 +622,8 @@ struct pc_engine {
     uint32_t q_seq = 0;
     bool ff_on = false;          // pc_set_flag_filter: keep (flag & require) == require && (flag & exclude) == 0 && mapq >= min_mapq
     uint32_t ff_require = 0, ff_exclude = 0, ff_min_mapq = 0;
+    uint32_t ff_max_nh = 0;      // pc_set_nh_filter: keep only reads with an NH:i tag of at most this many reported alignments (0: no such test)
+    bool filter_on() const { return ff_on || ff_max_nh != 0u; }
     bool pinned_busy = false;
     PinnedBuf pinned;            // host side of the plan-table upload (reused: ev_pinned is waited for before it is rewritten)
     PinnedBuf bam_ring[2];       // page-locked halves the image of a large BAM file crosses PCIe through (filled by all host threads)
@@ -1327,6 +1331,25 @@ int pc_release_cached_memory(int device) {
     return PC_OK;
 }
 
+int pc_host_alloc(pc_engine *e, uint64_t bytes, void **out) {
+    if (!e || !out) return fail(PC_ERR_ARG, "pc_host_alloc: engine / out is NULL");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(e->device));
+    void *p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, std::max<uint64_t>(bytes, 8), hipHostMallocDefault));
+    *out = p;
+    return PC_OK;
+}
+
+int pc_host_free(pc_engine *e, void *p) {
+    if (!e) return fail(PC_ERR_ARG, "pc_host_free: engine is NULL");
+    if (!p) return PC_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));   // (a read-back into it may still be in flight)
+    HIP_TRY(hipHostFree(p));
+    return PC_OK;
+}
+
 int pc_reload_knobs(pc_engine *e) {
     if (!e) return fail(PC_ERR_ARG, "engine is NULL");
     e->knobs.load();
@@ -1922,9 +1945,10 @@ int pc_update_flags(pc_engine *e, int file, int64_t n, const uint8_t *flags) {
     HIP_TRY(hipMemcpyAsync(e->d_flags.p, flags, (size_t)n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_update_flags, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, sf->stream.p,
                        e->d_flags.p, n);
-    if (e->ff_on && sf->have_sam)   // the FLAG / MAPQ filter's verdicts on top of the caller's
-        hipLaunchKernelGGL(k_flag_filter, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, sf->stream.p, sf->sam_flag.p,
-                           sf->sam_mapq.p, n, 1u, e->ff_require, e->ff_exclude, e->ff_min_mapq);
+    if (e->filter_on() && (sf->have_sam || !e->ff_on) && (sf->have_nh || !e->ff_max_nh))   // the FLAG / MAPQ / NH filter's verdicts on top of the caller's
+        hipLaunchKernelGGL(k_flag_filter, dim3((unsigned)((n + kWG - 1) / kWG)), dim3(kWG), 0, st, sf->rec.p, sf->stream.p, sf->have_sam ? sf->sam_flag.p : nullptr,
+                           sf->have_sam ? sf->sam_mapq.p : nullptr, n, 1u, e->ff_on ? e->ff_require : 0u, e->ff_on ? e->ff_exclude : 0u, e->ff_on ? e->ff_min_mapq : 0u,
+                           sf->have_nh ? sf->sam_nh.p : nullptr, e->ff_max_nh);
     const int prc = propagate_record_flags(e, sf);
     if (prc != PC_OK) return prc;
     HIP_TRY(hipStreamSynchronize(st)); // the caller's flag buffer may go away
@@ -1959,12 +1983,16 @@ static int apply_flag_filter(pc_engine *e, StagedFile *sf) {
     if (sf->n == 0) return PC_OK;
     if (e->ff_on && !sf->have_sam)
         return fail(PC_ERR_STATE, "a FLAG / MAPQ filter is set but an alignment file was staged without its FLAG / MAPQ columns (pc_set_alignment_sam)");
-    if (!sf->have_sam && !e->ff_on) {
+    if (e->ff_max_nh && !sf->have_nh)
+        return fail(PC_ERR_STATE, "an NH filter is set but an alignment file was staged without its NH column (pc_set_alignment_nh)");
+    if (!sf->have_sam && !sf->have_nh && !e->filter_on()) {
         // nothing to read the verdicts from, and nothing to undo: a file without the columns never had the filter applied
         return PC_OK;
     }
     hipLaunchKernelGGL(k_flag_filter, dim3((unsigned)((sf->n + kWG - 1) / kWG)), dim3(kWG), 0, e->stream, sf->rec.p, sf->stream.p,
-                       sf->sam_flag.p, sf->sam_mapq.p, sf->n, e->ff_on ? 1u : 0u, e->ff_require, e->ff_exclude, e->ff_min_mapq);
+                       sf->have_sam ? sf->sam_flag.p : nullptr, sf->have_sam ? sf->sam_mapq.p : nullptr, sf->n, e->filter_on() ? 1u : 0u,
+                       e->ff_on ? e->ff_require : 0u, e->ff_on ? e->ff_exclude : 0u, e->ff_on ? e->ff_min_mapq : 0u,
+                       sf->have_nh ? sf->sam_nh.p : nullptr, e->ff_max_nh);
     return propagate_record_flags(e, sf);
 }
 
@@ -1983,9 +2011,46 @@ int pc_set_alignment_sam(pc_engine *e, int file, int64_t n, const uint16_t *flag
     }
     sf->have_sam = true;
     int rc = PC_OK;
-    if (e->ff_on) rc = apply_flag_filter(e, sf);
+    if (e->ff_on && (sf->have_nh || !e->ff_max_nh)) rc = apply_flag_filter(e, sf);
     HIP_TRY(hipStreamSynchronize(e->stream));   // the caller's arrays may go away
     return rc;
+}
+
+int pc_set_alignment_nh(pc_engine *e, int file, int64_t n, const uint16_t *nh) {
+    if (!e || file < 0 || file >= (int)e->files.size()) return fail(PC_ERR_ARG, "pc_set_alignment_nh: bad file index");
+    StagedFile *sf = e->files[file];
+    if (n != sf->n || (n > 0 && !nh)) return fail(PC_ERR_ARG, "pc_set_alignment_nh: wrong record count");
+    HIP_TRY(hipSetDevice(e->device));
+    if (n > 0) {
+        PoolScope pool_scope(&e->pool);
+        const int rc = sf->sam_nh.reserve((size_t)n);
+        if (rc != PC_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(sf->sam_nh.p, nh, (size_t)n * 2, hipMemcpyHostToDevice, e->stream));
+    }
+    sf->have_nh = true;
+    int rc = PC_OK;
+    if (e->ff_max_nh && (sf->have_sam || !e->ff_on)) rc = apply_flag_filter(e, sf);
+    HIP_TRY(hipStreamSynchronize(e->stream));   // the caller's array may go away
+    return rc;
+}
+
+int pc_set_nh_filter(pc_engine *e, int max_nh) {
+    if (!e) return fail(PC_ERR_ARG, "engine is NULL");
+    if (max_nh < 0 || max_nh > 65535) return fail(PC_ERR_ARG, "pc_set_nh_filter: max_nh is 0 (off) .. 65535");
+    if (max_nh)
+        for (size_t f = 0; f < e->files.size(); ++f)
+            if (e->files[f]->n > 0 && !e->files[f]->have_nh)
+                return fail(PC_ERR_STATE, "pc_set_nh_filter: alignment file %d was staged without its NH column (pc_set_alignment_nh)", (int)f);
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->ff_max_nh == (uint32_t)max_nh) return PC_OK;
+    e->ff_max_nh = (uint32_t)max_nh;
+    for (StagedFile *sf : e->files) {
+        if (!sf->have_nh && !sf->have_sam) continue;
+        if ((e->ff_on && !sf->have_sam)) continue;   // (pc_count refuses such a file until its columns arrive)
+        const int rc = apply_flag_filter(e, sf);
+        if (rc != PC_OK) return rc;
+    }
+    return PC_OK;
 }
 
 int pc_set_flag_filter(pc_engine *e, int enabled, uint32_t require, uint32_t exclude, int min_mapq) {
@@ -2004,6 +2069,7 @@ int pc_set_flag_filter(pc_engine *e, int enabled, uint32_t require, uint32_t exc
     e->ff_require = enabled ? require : 0u; e->ff_exclude = enabled ? exclude : 0u; e->ff_min_mapq = enabled ? (uint32_t)min_mapq : 0u;
     for (StagedFile *sf : e->files) {
         if (!sf->have_sam) continue;
+        if (e->ff_max_nh && !sf->have_nh) continue;   // (pc_count refuses such a file until its NH column arrives)
         const int rc = apply_flag_filter(e, sf);
         if (rc != PC_OK) return rc;
     }
@@ -2576,6 +2642,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
     if (e->files.empty()) return fail(PC_ERR_STATE, "pc_count: no alignments staged (pc_add_alignment_file)");
     if (out_dtype != PC_OUT_INT64 && out_dtype != PC_OUT_FLOAT64) return fail(PC_ERR_ARG, "pc_count: bad out_dtype");
     if (p->rows != e->rows) return fail(PC_ERR_ARG, "pc_count: plan built for %d rows, mapping rule has %d", p->rows, e->rows);
+    if (e->ff_max_nh)
+        for (size_t f = 0; f < e->files.size(); ++f)
+            if (e->files[f]->n > 0 && !e->files[f]->have_nh)
+                return fail(PC_ERR_STATE, "pc_count: an NH filter is set but alignment file %d has no NH column (pc_set_alignment_nh)", (int)f);
     if (e->ff_on)   // a file staged after pc_set_flag_filter gets its verdicts when its columns arrive: not counted without them
         for (size_t f = 0; f < e->files.size(); ++f)
             if (e->files[f]->n > 0 && !e->files[f]->have_sam)
@@ -2903,7 +2973,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (rc == PC_OK) rc = p->d_crec.reserve((size_t)nchunks * (size_t)nfiles);
             if (rc == PC_OK) rc = p->d_crows.reserve((size_t)nchunks * (size_t)nfiles * (size_t)(2 * kCenterRows));
             if (rc == PC_OK) rc = p->d_ccounts.reserve(8);
-            if (rc == PC_OK) rc = p->d_ccursors.reserve(16 * 8);
+            if (rc == PC_OK) rc = p->d_ccursors.reserve(16 * 33);
             if (rc == PC_OK) rc = e->d_cvalh.reserve(256);
             // one alignment file (every BASELINE config): descriptors per dispatch entry, several entries per wave (k_center2);
             // several files keep round 4's kernel, whose waves walk the files of a chunk one after the other
@@ -2914,8 +2984,9 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             int n_cu = 256;
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, e->device);
             uint32_t grid_p = (uint32_t)std::max(8, n_cu * 4 * e->knobs.center_pwaves);
-            if (p->center_counts_known) grid_p = (uint32_t)std::min<uint64_t>(grid_p, ((uint64_t)p->center_counts[1] + 7) / 8 * 8);   // (no more waves than light entries)
-            grid_p = std::max(grid_p, 8u);
+            if (p->center_counts_known)   // (no more waves than entries of either kind)
+                grid_p = (uint32_t)std::min<uint64_t>(grid_p, ((uint64_t)std::max(p->center_counts[0], p->center_counts[1]) + 31) / 32 * 32);
+            grid_p = std::max(grid_p, 32u);
             // (the cursors start behind the first entry of each of the grid_p waves: the very grid k_center2p is launched with)
             hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(256), 0, st, mp, e->d_invh.p, e->d_cvalh.p, p->d_ccursors.p, grid_p);
             if (p->center_generation != e->work_generation || p->center_W != W || p->center_slots != slots_on) {
@@ -2995,23 +3066,14 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 } else g2 = 2 * (uint64_t)nchunks + 8;
                 const dim3 cg2((unsigned)std::max<uint64_t>(g2, 1));
                 c2.cursors = p->d_ccursors.p;
-                // round 6: once the list's counts are known -- k_center_heavy for the heavy entries on the side stream (launched
-                // first: its waves are placed before the other kernel fills the chip), beside it the persistent grid over the
-                // light entries.  The first count of a plan, the diagnostic launch and PC_CENTER_MODE=0 run round 5's kernel
-                // (one wave per entry) over everything.
-                const int cmode = (p->center_counts_known && !dbg_on) ? e->knobs.center_mode : 0;
-                const bool heavy_on = cmode == 2 && p->center_counts[0] > 0u;
-                if (heavy_on) {
-                    HIP_TRY(hipEventRecord(e->ev_fork, st));
-                    HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-                    if (general) hipLaunchKernelGGL((k_center_heavy<true>), dim3(p->center_counts[0]), dim3(64), 0, e->side_stream, c2);
-                    else hipLaunchKernelGGL((k_center_heavy<false>), dim3(p->center_counts[0]), dim3(64), 0, e->side_stream, c2);
-                    HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
-                }
+                // round 6: once the list's counts are known, the persistent grid (PC_CENTER_MODE=2).  The first count of a plan,
+                // the diagnostic launch and PC_CENTER_MODE=0 run one wave per entry (k_center2).
+                // (files with reads beyond a stream entry's 8-bit fields -- `general`: every batch is tested for indirect entries --
+                // keep to round 5's kernel: with that path unrolled into both rings the persistent form does not fit its registers)
+                const int cmode = (p->center_counts_known && !dbg_on && !general) ? e->knobs.center_mode : 0;
                 if (cmode == 2) {
-                    if (p->center_counts[1] > 0u) {
-                        if (general) hipLaunchKernelGGL((k_center2p<true>), dim3(grid_p), dim3(64), 0, st, c2);
-                        else hipLaunchKernelGGL((k_center2p<false>), dim3(grid_p), dim3(64), 0, st, c2);
+                    if (p->center_counts[0] + p->center_counts[1] > 0u) {
+                        hipLaunchKernelGGL((k_center2p<false>), dim3(grid_p), dim3(64), 0, st, c2);
                     }
                 } else if (dbg_on) {
                     if (general) hipLaunchKernelGGL((k_center2<true, true>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
@@ -3020,7 +3082,6 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                     if (general) hipLaunchKernelGGL((k_center2<false, true>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
                     else hipLaunchKernelGGL((k_center2<false, false>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
                 }
-                if (heavy_on) HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
             } else if (dbg_on) {
                 if (general) hipLaunchKernelGGL((k_center<true, true>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
                 else hipLaunchKernelGGL((k_center<true, false>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
@@ -3307,6 +3368,7 @@ int pc_query_segment(pc_engine *e, int32_t tid, int64_t start, int64_t end, uint
     if (tid < 0 || tid >= e->ntid) return fail(PC_ERR_ARG, "pc_query_segment: reference id out of range");
     StagedFile *sf = e->files[0];
     if (e->ff_on && sf->n > 0 && !sf->have_sam) return fail(PC_ERR_STATE, "pc_query_segment: a FLAG / MAPQ filter is set but the alignment file has no FLAG / MAPQ columns");
+    if (e->ff_max_nh && sf->n > 0 && !sf->have_nh) return fail(PC_ERR_STATE, "pc_query_segment: an NH filter is set but the alignment file has no NH column");
     HIP_TRY(hipSetDevice(e->device));
     if (!e->q_host) {
         HIP_TRY(hipHostMalloc((void **)&e->q_host, (size_t)kQueryMax * 8 + 64, hipHostMallocMapped));
@@ -3638,6 +3700,7 @@ struct pc_bam {
     DevBuf<uint16_t> flag16;           // the SAM FLAG word, MAPQ and l_seq of every staged record (pc_bam_read_sam; the
     DevBuf<uint8_t> mapq;              // first two stay with the staged file for the FLAG / MAPQ filter)
     DevBuf<int32_t> lseq;
+    DevBuf<uint16_t> nh;               // the NH:i tag of every staged record, 0 without one (pc_bam_read_nh; stays with the staged file for the NH filter)
     std::vector<int64_t> wide_idx;
     std::vector<int32_t> wide_alen, wide_nblk;
     double ms[4] = {0, 0, 0, 0};     // upload, inflate (+ CRC), record chain, fields + columns
@@ -4217,6 +4280,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
         if (rc == PC_OK) rc = b->flag16.reserve((size_t)std::max<int64_t>(n_staged, 1));
         if (rc == PC_OK) rc = b->mapq.reserve((size_t)std::max<int64_t>(n_staged, 1));
         if (rc == PC_OK) rc = b->lseq.reserve((size_t)std::max<int64_t>(n_staged, 1));
+        if (rc == PC_OK) rc = b->nh.reserve((size_t)std::max<int64_t>(n_staged, 1));
         if (rc == PC_OK) rc = b->blk_start.reserve((size_t)std::max<int64_t>(n_runs, 1));
         if (rc == PC_OK) rc = b->blk_len.reserve((size_t)std::max<int64_t>(n_runs, 1));
         if (rc == PC_OK) rc = d_wide.reserve((size_t)std::max<int64_t>(n_staged, 1));
@@ -4224,7 +4288,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
         HIP_TRY(hipMemsetAsync(d_wide.p, 0, (size_t)std::max<int64_t>(n_staged, 1) * 4, st));
         hipLaunchKernelGGL(k_bam_columns, dim3(g256), dim3(256), 0, st, d_stream.p, d_members.p, d_rec_base.p, d_rec_off.p, nm, d_rec_member.p, d_recs.p,
                            nrec, d_staged_at.p, d_run_at.p, b->tid.p, b->pos.p, b->alen.p, b->flags.p, b->nblk.p, b->blk_start.p, b->blk_len.p, d_wide.p,
-                           b->flag16.p, b->mapq.p, b->lseq.p);
+                           b->flag16.p, b->mapq.p, b->lseq.p, b->nh.p);
         HIP_TRY(hipGetLastError());
         // wide records (beyond the 16-bit / 8-bit columns): rare -- their staged indices are found from the markers on
         // the host side of pc_bam_read; the true values are read back here, record by record
@@ -4333,6 +4397,15 @@ int pc_bam_read_sam(pc_bam *b, uint16_t *flag, uint8_t *mapq, int32_t *lseq) {
     return TransferRing::of(b->e->device).run(b->e->device, jobs, TransferRing::kPiece, false, true);
 }
 
+int pc_bam_read_nh(pc_bam *b, uint16_t *nh) {
+    if (!b) return fail(PC_ERR_ARG, "pc_bam_read_nh: NULL handle");
+    HIP_TRY(hipSetDevice(b->e->device));
+    HIP_TRY(hipStreamSynchronize(b->e->stream));
+    std::vector<TransferJob> jobs;
+    if (b->n && nh) jobs.push_back({nh, b->nh.p, (size_t)b->n * 2});
+    return TransferRing::of(b->e->device).run(b->e->device, jobs, TransferRing::kPiece, false, true);
+}
+
 static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size, const char *name, int64_t *mapped, const UploadedHook *uploaded,
                                   const BamSpan *span = nullptr);
 
@@ -4387,7 +4460,9 @@ static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size,
         sf->sam_flag.swap(b->flag16);
         sf->sam_mapq.swap(b->mapq);
         sf->have_sam = true;
-        return e->ff_on ? apply_flag_filter(e, sf) : PC_OK;
+        sf->sam_nh.swap(b->nh);
+        sf->have_nh = true;
+        return e->filter_on() ? apply_flag_filter(e, sf) : PC_OK;
     }
     std::vector<int32_t> tid((size_t)n), pos((size_t)n), bs((size_t)m), bl((size_t)m), wa((size_t)nw), wn((size_t)nw);
     std::vector<uint16_t> alen((size_t)n);
@@ -4402,7 +4477,12 @@ static int add_alignment_bam_impl(pc_engine *e, const void *image, int64_t size,
     rc = pc_add_alignment_file_wide(e, n, ntid, tid.data(), pos.data(), alen.data(), flags.data(), nblk.data(), m, bs.data(), bl.data(),
                                     nw, wi.data(), wa.data(), wn.data());
     if (rc != PC_OK) return rc;
-    return pc_set_alignment_sam(e, (int)e->files.size() - 1, n, f16.data(), mq.data());
+    rc = pc_set_alignment_sam(e, (int)e->files.size() - 1, n, f16.data(), mq.data());
+    if (rc != PC_OK) return rc;
+    std::vector<uint16_t> nhv((size_t)n);
+    rc = pc_bam_read_nh(b, nhv.data());
+    if (rc != PC_OK) return rc;
+    return pc_set_alignment_nh(e, (int)e->files.size() - 1, n, nhv.data());
 }
 
 namespace {

@@ -51,6 +51,25 @@ class Engine(object):
     def close(self):
         self._finalizer()
 
+    def host_buffer(self, n, dtype=np.int64):
+        """A page-locked numpy array of `n` elements (``pc_host_alloc``): what a caller that reads count vectors back
+        repeatedly hands to :meth:`Plan.read` / :meth:`Plan.count` -- the read-back is then one DMA at the rate of the
+        link.  The memory is released when the array (and every view of it) is gone; the engine must still be open then."""
+        dtype = np.dtype(dtype)
+        nbytes = max(int(n), 0) * dtype.itemsize
+        p = ctypes.c_void_p()
+        check(self._lib.pc_host_alloc(self._h, nbytes, ctypes.byref(p)), "pc_host_alloc")
+        raw = (ctypes.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(raw, dtype=np.uint8, count=nbytes).view(dtype)
+        lib, h, addr = self._lib, self._h, p.value
+        fin = self._finalizer
+
+        def release():
+            if fin.alive:                      # (an engine that is gone took its page-locked blocks with the process)
+                lib.pc_host_free(h, ctypes.c_void_p(addr))
+        weakref.finalize(raw, release)
+        return arr
+
     # ------------------------------------------------------------ alignments
     def clear_alignments(self):
         check(self._lib.pc_clear_alignments(self._h))
@@ -82,6 +101,10 @@ class Engine(object):
         if getattr(packed, "flag16", None) is not None and getattr(packed, "mapq", None) is not None:
             # the SAM FLAG word and MAPQ of every record: what the vectorised FLAG / MAPQ filter reads (3 bytes per record)
             self.set_alignment_sam(self.nfiles - 1, packed.flag16, packed.mapq)
+        if getattr(packed, "nh", None) is not None:
+            # the NH:i tag of every record (2 bytes each): what FlagFilterFactory(max_nh=...) tests on the GPU
+            nh = _c(packed.nh, np.uint16)
+            check(self._lib.pc_set_alignment_nh(self._h, self.nfiles - 1, len(nh), _ptr(nh)))
 
     def set_alignment_sam(self, file_index, flag16, mapq):
         """Hand the engine the SAM FLAG words and MAPQ values of a staged file (``pc_set_alignment_sam``)."""
@@ -89,6 +112,14 @@ class Engine(object):
         if len(flag16) != len(mapq):
             raise ValueError("flag16 / mapq differ in length")
         check(self._lib.pc_set_alignment_sam(self._h, int(file_index), len(flag16), _ptr(flag16), _ptr(mapq)))
+
+    def set_nh_filter(self, max_nh=0):
+        """Keep a read iff it carries an ``NH:i`` tag of at most `max_nh` reported alignments (``pc_set_nh_filter``;
+        1: unique mappers); 0 lifts the test."""
+        if self._state.get("nhfilter", 0) == int(max_nh):
+            return
+        check(self._lib.pc_set_nh_filter(self._h, int(max_nh)))
+        self._state["nhfilter"] = int(max_nh)
 
     def set_flag_filter(self, require=0, exclude=0, min_mapq=0, enabled=True):
         """Keep a read iff ``(flag & require) == require and (flag & exclude) == 0 and mapq >= min_mapq``

@@ -134,7 +134,7 @@ def _pack_source(src, chroms, chrom_index):
         return PackedAlignments(tid, sub.pos, sub.alen, sub.flags, sub.nblk, sub.blk_start, sub.blk_len,
                                 references=chroms, lengths=[0] * len(chroms), mapped=src.mapped,
                                 read_objects=sub._read_objects, wide_idx=sub.wide_idx, wide_alen=sub.wide_alen,
-                                wide_nblk=sub.wide_nblk, flag16=sub.flag16, mapq=sub.mapq, qlen=sub.qlen)
+                                wide_nblk=sub.wide_nblk, flag16=sub.flag16, mapq=sub.mapq, qlen=sub.qlen, nh=sub.nh)
     # duck-typed pysam.AlignmentFile: walk every contig in coordinate order
     reads, tids = [], []
     for ref, length in zip(src.references, src.lengths):
@@ -303,17 +303,22 @@ class BAMGenomeArray(object):
             # filters on FLAG / MAPQ run on the GPU when every file carries the two columns (files read by the
             # package's own BAM decoders do; device-only files always): combined, they are one mask test
             sam_ok = self._device_only or all(p.flag16 is not None and p.mapq is not None for p in self._packed)
+            nh_ok = self._device_only or all(getattr(p, "nh", None) is not None for p in self._packed)
             flagf = None
+            max_nh = 0
             for f in self._filters.values():
                 if isinstance(f, SizeFilterFactory) and size is None:
                     size = f
-                elif isinstance(f, FlagFilterFactory) and sam_ok and not (flagf is not None and
-                                                                         ((flagf[0] | f.require) & (flagf[1] | f.exclude))):
+                elif isinstance(f, FlagFilterFactory) and sam_ok and (nh_ok or not f.max_nh) and \
+                        not (flagf is not None and ((flagf[0] | f.require) & (flagf[1] | f.exclude))):
                     flagf = (f.require, f.exclude, f.min_mapq) if flagf is None else \
                         (flagf[0] | f.require, flagf[1] | f.exclude, max(flagf[2], f.min_mapq))
+                    if f.max_nh:   # several NH limits: the tightest
+                        max_nh = f.max_nh if not max_nh else min(max_nh, f.max_nh)
                 else:
                     custom.append(f)
             self._flag_filter_state = flagf
+            self._nh_filter_state = max_nh
             if custom and self._device_only:
                 self.bamfiles[0]._host_only()   # (arbitrary callables are evaluated on read objects the host does not have)
             self._custom_filters = custom
@@ -332,6 +337,7 @@ class BAMGenomeArray(object):
             self._engine.set_flag_filter(enabled=False)
         else:
             self._engine.set_flag_filter(*self._flag_filter_state)
+        self._engine.set_nh_filter(getattr(self, "_nh_filter_state", 0))
         size = self._size_filter_state
         if size is None:
             self._engine.set_size_filter(None)

@@ -411,10 +411,11 @@ FLAG_BITS = {"is_paired": 0x1, "is_proper_pair": 0x2, "is_unmapped": 0x4, "mate_
 
 
 class FlagFilterFactory(object):
-    """FlagFilterFactory(require=0, exclude=0, min_mapq=0)
+    """FlagFilterFactory(require=0, exclude=0, min_mapq=0, max_nh=0)
 
-    Read filter on the SAM FLAG word and MAPQ for :meth:`BAMGenomeArray.add_filter`: a read is kept iff
-    ``(read.flag & require) == require and (read.flag & exclude) == 0 and read.mapping_quality >= min_mapq``.
+    Read filter on the SAM FLAG word, MAPQ and the ``NH:i`` tag for :meth:`BAMGenomeArray.add_filter`: a read is kept iff
+    ``(read.flag & require) == require and (read.flag & exclude) == 0 and read.mapping_quality >= min_mapq`` and --
+    with `max_nh` > 0 -- ``read.has_tag("NH") and read.get_tag("NH") <= max_nh`` (``max_nh=1``: the unique mappers).
     `require` / `exclude` are bit masks or iterables of pysam property names (``"is_secondary"``,
     ``"is_duplicate"``, ``"is_qcfail"``, ``"is_proper_pair"`` ...).
 
@@ -425,12 +426,15 @@ class FlagFilterFactory(object):
     pass over 3 bytes per record), also for files opened with ``keep_reads=False``.  As a plain callable
     it answers for a single read."""
 
-    def __init__(self, require=0, exclude=0, min_mapq=0):
+    def __init__(self, require=0, exclude=0, min_mapq=0, max_nh=0):
         self.require = self._mask(require)
         self.exclude = self._mask(exclude)
         self.min_mapq = _as_c_int(min_mapq, "min_mapq")
         if not 0 <= self.min_mapq <= 255:
             raise ValueError("FlagFilterFactory: min_mapq must be in 0 .. 255. Got %s" % min_mapq)
+        self.max_nh = _as_c_int(max_nh, "max_nh")
+        if not 0 <= self.max_nh <= 65535:
+            raise ValueError("FlagFilterFactory: max_nh must be in 0 (no test) .. 65535. Got %s" % max_nh)
         if self.require & self.exclude:
             raise ValueError("FlagFilterFactory: the same FLAG bit is both required and excluded")
 
@@ -454,4 +458,6 @@ class FlagFilterFactory(object):
         if read is None:
             raise TypeError("Argument 'read' must not be None")
         flag = int(read.flag)
-        return (flag & self.require) == self.require and (flag & self.exclude) == 0 and int(read.mapping_quality) >= self.min_mapq
+        if not ((flag & self.require) == self.require and (flag & self.exclude) == 0 and int(read.mapping_quality) >= self.min_mapq):
+            return False
+        return not self.max_nh or (bool(read.has_tag("NH")) and int(read.get_tag("NH")) <= self.max_nh)

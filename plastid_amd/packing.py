@@ -22,6 +22,7 @@ what gets bulk-staged to HBM:
 ``flag16``      uint16    (optional) the SAM FLAG word of every record
 ``mapq``        uint8     (optional) MAPQ
 ``qlen``        int32     (optional) ``l_seq``, pysam's ``query_length``
+``nh``          uint16    (optional) the ``NH:i`` tag (reported alignments of the query), 0 where a record has none
 ==============  ========  ====================================================
 
 The three optional columns are what read *filters* may look at beyond strand and length (the reference's filters
@@ -125,9 +126,9 @@ class PackedRead(object):
     what the reference's mapping functions and filters consume."""
 
     __slots__ = ("source", "index", "reference_id", "reference_start", "is_reverse", "_runs", "flag", "mapping_quality",
-                 "query_length")
+                 "query_length", "_nh")
 
-    def __init__(self, source, index, tid, pos, is_reverse, runs, flag=None, mapq=None, qlen=None):
+    def __init__(self, source, index, tid, pos, is_reverse, runs, flag=None, mapq=None, qlen=None, nh=None):
         self.source = source
         self.index = index
         self.reference_id = tid
@@ -139,6 +140,7 @@ class PackedRead(object):
         self.flag = int(flag) if flag is not None else (0x10 if is_reverse else 0)
         self.mapping_quality = int(mapq) if mapq is not None else 255
         self.query_length = int(qlen) if qlen is not None else sum(n for _, n in runs)
+        self._nh = None if nh is None else int(nh)   # the NH:i tag (None: the source has no such column; 0: this record has no tag)
 
     # the FLAG bits by pysam's names (kent/src/htslib/htslib/sam.h:110-132)
     is_paired = property(lambda self: bool(self.flag & 0x1))
@@ -153,6 +155,36 @@ class PackedRead(object):
     is_duplicate = property(lambda self: bool(self.flag & 0x400))
     is_supplementary = property(lambda self: bool(self.flag & 0x800))
     mapq = property(lambda self: self.mapping_quality)
+
+    # the one auxiliary field the packed columns carry: NH:i, what the usual unique-mapper filter of the reference's users
+    # reads (`lambda read: read.get_tag("NH") == 1`, genome_array.py:697-722); pysam's semantics: KeyError without the tag
+    def has_tag(self, tag):
+        return tag == "NH" and bool(self._nh)
+
+    def get_tag(self, tag, with_value_type=False):
+        if tag != "NH" or not self._nh:
+            raise KeyError("tag '%s' not present" % tag)
+        return (self._nh, "i") if with_value_type else self._nh
+
+    def get_tags(self, with_value_type=False):
+        return [("NH",) + ((self._nh, "i") if with_value_type else (self._nh,))] if self._nh else []
+
+    tags = property(lambda self: self.get_tags())
+
+    @property
+    def cigartuples(self):
+        """``[(op, length), ...]`` in BAM op codes: the aligned runs as ``M`` (0) joined by ``N`` (3) -- or ``D`` (2) for a
+        gap of one position, as :func:`tests.bam_writer.write_bam_realistic` writes them; insertions, clips and the
+        distinction = / X are not kept by the packed columns."""
+        out, prev = [], None
+        for s, n in self._runs:
+            if prev is not None:
+                out.append((2 if s - prev == 1 else 3, s - prev))
+            out.append((0, n))
+            prev = s + n
+        return out
+
+    cigar = property(lambda self: self.cigartuples)
 
     @property
     def positions(self):
@@ -182,7 +214,7 @@ class PackedAlignments(object):
 
     def __init__(self, tid, pos, alen, flags, nblk, blk_start=None, blk_len=None,
                  references=None, lengths=None, mapped=None, read_objects=None, validate=True,
-                 wide_idx=None, wide_alen=None, wide_nblk=None, flag16=None, mapq=None, qlen=None):
+                 wide_idx=None, wide_alen=None, wide_nblk=None, flag16=None, mapq=None, qlen=None, nh=None):
         self.tid = np.ascontiguousarray(tid, dtype=np.int32)
         self.pos = np.ascontiguousarray(pos, dtype=np.int32)
         self.alen = np.ascontiguousarray(alen, dtype=np.uint16)
@@ -198,8 +230,9 @@ class PackedAlignments(object):
         self.flag16 = None if flag16 is None else np.ascontiguousarray(flag16, dtype=np.uint16)
         self.mapq = None if mapq is None else np.ascontiguousarray(mapq, dtype=np.uint8)
         self.qlen = None if qlen is None else np.ascontiguousarray(qlen, dtype=np.int32)
+        self.nh = None if nh is None else np.ascontiguousarray(nh, dtype=np.uint16)
         n = len(self.tid)
-        for name in ("flag16", "mapq", "qlen"):
+        for name in ("flag16", "mapq", "qlen", "nh"):
             col = getattr(self, name)
             if col is not None and len(col) != n:
                 raise ValueError("PackedAlignments: array '%s' has wrong length" % name)
@@ -379,11 +412,11 @@ class PackedAlignments(object):
         return PackedRead(self, int(i), int(self.tid[i]), int(self.pos[i]),
                           bool(self.flags[i] & FLAG_REVERSE), self.runs_of(i),
                           None if self.flag16 is None else self.flag16[i], None if self.mapq is None else self.mapq[i],
-                          None if self.qlen is None else self.qlen[i])
+                          None if self.qlen is None else self.qlen[i], None if self.nh is None else self.nh[i])
 
     def sam_columns(self, idx):
         """The optional SAM columns of the records `idx` (index array or slice) as constructor keywords."""
-        return {name: None if getattr(self, name) is None else getattr(self, name)[idx] for name in ("flag16", "mapq", "qlen")}
+        return {name: None if getattr(self, name) is None else getattr(self, name)[idx] for name in ("flag16", "mapq", "qlen", "nh")}
 
     # ------------------------------------------- pysam.AlignmentFile duck type
     def fetch(self, reference=None, start=None, end=None, **kwargs):
@@ -420,7 +453,7 @@ class PackedAlignments(object):
     # ------------------------------------------------------------ constructors
     @classmethod
     def from_runs(cls, tids, is_reverse, runs_per_read, references=None, lengths=None,
-                  mapped=None, read_objects=None, sort=False, positions=None, flag16=None, mapq=None, qlen=None):
+                  mapped=None, read_objects=None, sort=False, positions=None, flag16=None, mapq=None, qlen=None, nh=None):
         """Build from per-read lists of aligned runs ``[(start, len), ...]``.  `positions`
         (optional) places the records that have no aligned base at all."""
         n = len(runs_per_read)
@@ -459,7 +492,7 @@ class PackedAlignments(object):
         a16[wide] = MAX_ALIGNED_LEN
         n8[wide] = MAX_RUNS
         sam = {}
-        for name, col in (("flag16", flag16), ("mapq", mapq), ("qlen", qlen)):
+        for name, col in (("flag16", flag16), ("mapq", mapq), ("qlen", qlen), ("nh", nh)):
             if col is not None:
                 col = np.asarray(col)
                 sam[name] = col[order] if order is not None else col
@@ -485,6 +518,8 @@ class PackedAlignments(object):
             kwargs.setdefault("mapq", np.array([int(r.mapping_quality) & 0xff for r in reads], np.uint8))
             if all(getattr(r, "query_length", None) is not None for r in reads):
                 kwargs.setdefault("qlen", np.array([int(r.query_length) for r in reads], np.int32))
+        if reads and all(hasattr(r, "has_tag") and hasattr(r, "get_tag") for r in reads):   # (pysam reads: NH:i where present)
+            kwargs.setdefault("nh", np.array([min(max(int(r.get_tag("NH")), 0), 65535) if r.has_tag("NH") else 0 for r in reads], np.uint16))
         return cls.from_runs(tids, rev, runs, read_objects=reads, **kwargs)
 
     @classmethod
@@ -573,6 +608,8 @@ def concat_file_major(files):
     if all(getattr(f, "flag16", None) is not None and getattr(f, "mapq", None) is not None for f in files):
         wide["flag16"] = np.concatenate([f.flag16 for f in files])
         wide["mapq"] = np.concatenate([f.mapq for f in files])
+    if all(getattr(f, "nh", None) is not None for f in files):
+        wide["nh"] = np.concatenate([f.nh for f in files])
     return dict(wide, **{
         "tid": np.concatenate([f.tid for f in files]),
         "pos": np.concatenate([f.pos for f in files]),

@@ -147,10 +147,75 @@ def reg2bin_array(beg, end):
     return out
 
 
-def write_bam_packed(path, packed, block_bytes=60000, level=1, threads=8):
+def write_bai_packed(path, packed, rec_off, data_len, block_bytes, block_coff):
+    """``path + ".bai"`` for a file written by :func:`write_bam_packed` -- the index :func:`write_bam` writes (bins ->
+    chunks of virtual offsets, 16 kb linear index, the samtools pseudo-bin 37450 with the mapped / unmapped counts; SAM
+    spec 5.2), built from arrays.  rec_off[k]: byte offset of record k in the uncompressed stream (n + 1 entries: the
+    last one is the end of the data); block_coff: file offset of every BGZF member and of the EOF block."""
+    n = packed.n
+    coff = np.asarray(block_coff, np.int64)
+    u = np.asarray(rec_off, np.int64)
+    voff = np.where(u >= data_len, coff[-1] << 16, (coff[np.minimum(u // block_bytes, len(coff) - 1)] << 16) | (u % block_bytes)).astype(np.uint64)
+    beg, endv = voff[:-1], voff[1:]
+    tid = packed.tid.astype(np.int64)
+    pos = packed.pos.astype(np.int64)
+    end = np.maximum(packed.ref_end().astype(np.int64), pos + 1)
+    rbin = reg2bin_array(pos, end).astype(np.int64)
+    nref = len(packed.references)
+    key = tid * 65536 + rbin
+    first = np.nonzero(np.r_[True, key[1:] != key[:-1]])[0] if n else np.zeros(0, np.int64)   # a chunk: consecutive records of one (reference, bin)
+    last = np.r_[first[1:], n] - 1 if n else first
+    ckey, cbeg, cend = key[first], beg[first], endv[last]
+    order = np.argsort(ckey, kind="stable")
+    ckey, cbeg, cend = ckey[order], cbeg[order], cend[order]
+    tb = np.searchsorted(tid, np.arange(nref + 1))                  # records of every reference (coordinate sorted)
+    w0, w1 = pos >> 14, (end - 1) >> 14
+    with open(path + ".bai", "wb") as fh:
+        fh.write(b"BAI\x01" + struct.pack("<i", nref))
+        for t in range(nref):
+            a, b = int(tb[t]), int(tb[t + 1])
+            ca, cb = np.searchsorted(ckey, [t * 65536, (t + 1) * 65536])
+            bins_t, where, cnt = np.unique(ckey[ca:cb] - t * 65536, return_index=True, return_counts=True)
+            fh.write(struct.pack("<i", len(bins_t) + (1 if b > a else 0)))
+            for bn, at, k in zip(bins_t.tolist(), where.tolist(), cnt.tolist()):
+                fh.write(struct.pack("<Ii", bn, k))
+                pair = np.empty((k, 2), "<u8")
+                pair[:, 0] = cbeg[ca + at:ca + at + k]
+                pair[:, 1] = cend[ca + at:ca + at + k]
+                fh.write(pair.tobytes())
+            if b > a:
+                nm = int(np.count_nonzero((packed.flags[a:b] & 0) == 0))   # (packed records are all mapped)
+                fh.write(struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", int(beg[a]), int(endv[b - 1]), nm, 0))
+            if b > a:
+                nint = int(w1[a:b].max()) + 1
+                firstrec = np.full(nint, n, np.int64)               # first record (file order) that overlaps each 16 kb window
+                ww = w0[a:b]
+                at0 = np.nonzero(np.r_[True, ww[1:] != ww[:-1]])[0]
+                np.minimum.at(firstrec, ww[at0], a + at0)
+                wide = np.nonzero(w1[a:b] > ww)[0]
+                if len(wide):
+                    reps = (w1[a:b][wide] - ww[wide]).astype(np.int64)
+                    rec = np.repeat(a + wide, reps)
+                    win = np.repeat(ww[wide], reps) + 1 + (np.arange(int(reps.sum())) - np.repeat(np.cumsum(reps) - reps, reps))
+                    np.minimum.at(firstrec, win, rec)
+                lin = np.zeros(nint, "<u8")
+                have = firstrec < n
+                lin[have] = beg[firstrec[have]]
+                # empty windows repeat the previous offset, as samtools writes them (leading ones: 0)
+                idx = np.where(have, np.arange(nint), -1)
+                np.maximum.accumulate(idx, out=idx)
+                lin = np.where(idx >= 0, lin[np.maximum(idx, 0)], 0).astype("<u8")
+                fh.write(struct.pack("<i", nint) + lin.tobytes())
+            else:
+                fh.write(struct.pack("<i", 0))
+        fh.write(struct.pack("<Q", 0))
+
+
+def write_bam_packed(path, packed, block_bytes=60000, level=1, threads=8, index=False):
     """Vectorised writer for a whole :class:`PackedAlignments` (millions of records): every record
     becomes ``<run>M`` ops joined by ``N`` gaps, name ``r``, no sequence (``l_seq`` 0).  BGZF members
-    are deflated on a thread pool.  Same format as :func:`write_bam`, no index."""
+    are deflated on a thread pool.  Same format as :func:`write_bam`; `index`: also ``path + ".bai"``
+    (:func:`write_bai_packed`)."""
     from concurrent.futures import ThreadPoolExecutor
     n = packed.n
     text = b"@HD\tVN:1.6\tSO:coordinate\n"
@@ -267,10 +332,19 @@ def write_bam_packed(path, packed, block_bytes=60000, level=1, threads=8):
         return (struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(cdata) + 25) + cdata +
                 struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw)))
 
+    block_coff = []
+    coff = 0
     with ThreadPoolExecutor(max(1, threads)) as pool, open(path, "wb") as fh:
         for blk in pool.map(member, range(0, len(data), block_bytes)):
+            block_coff.append(coff)
+            coff += len(blk)
             fh.write(blk)
+        block_coff.append(coff)          # the EOF block: virtual offset of "end of data"
         fh.write(BGZF_EOF)
+    if index:
+        rec_off = np.zeros(n + 1, np.int64)
+        np.cumsum(size, out=rec_off[1:])
+        write_bai_packed(path, packed, rec_off + H, len(data), block_bytes, block_coff)
     return len(data)
 
 

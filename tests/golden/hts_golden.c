@@ -21,6 +21,9 @@
  *   REF name length
  *   REC index tid pos flag endpos npos p0 p1 ...
  *   SAM index mapq l_qseq                      (core.qual / core.l_qseq as read back: pysam's mapping_quality / query_length)
+ *   AUX index has nh                           (bam_aux_get(b, "NH") != NULL and bam_aux2i of it: pysam's has_tag / get_tag;
+ *                                               a third of the records carry the tag -- every integer type, behind other
+ *                                               fields of every kind -- and some an NH of a non-integer type)
  *   CIG index n op0 len0 op1 len1 ...          (BAM op codes 0..8 = MIDNSHP=X, as read back)
  *   REG tid beg end n i0 i1 ...
  *   STAT tid mapped unmapped
@@ -93,6 +96,37 @@ static void fill(bam1_t *b, int idx, int tid, int pos, int flag, const uint32_t 
     b->core.bin = hts_reg2bin(pos, bam_endpos(b), 14, 5);
 }
 
+/* auxiliary fields by record index alone (no random draw: every other field of the fixture stays what it was): an NH tag
+ * on every third record, in turn of every integer type and value range, in front of / behind / between other fields of
+ * every type (A c s i f Z H B); every 31st record an NH of type Z or f (not an integer: pysam's get_tag would hand back
+ * the string / float; bam_aux2i answers 0) */
+static void add_aux(bam1_t *b, int idx) {
+    if (idx % 3 != 0 && idx % 31 != 5) {
+        if (idx % 7 == 1) { int32_t nm = idx % 5; bam_aux_append(b, "NM", 'i', 4, (uint8_t *)&nm); }
+        return;
+    }
+    const int k = idx / 3;
+    if (k % 2 == 0) { char xs = (k & 2) ? '+' : '-'; bam_aux_append(b, "XS", 'A', 1, (uint8_t *)&xs); }
+    if (k % 3 == 0) { char md[16]; snprintf(md, sizeof(md), "%d", 10 + k % 30); bam_aux_append(b, "MD", 'Z', (int)strlen(md) + 1, (uint8_t *)md); }
+    if (k % 5 == 0) { uint8_t arr[5 + 3 * 2] = {'S', 3, 0, 0, 0, 1, 0, 2, 0, 3, 0}; bam_aux_append(b, "ZB", 'B', (int)sizeof(arr), arr); }
+    if (k % 4 == 1) { float f = 0.5f * (float)(k % 9); bam_aux_append(b, "XF", 'f', 4, (uint8_t *)&f); }
+    if (k % 6 == 2) { char hx[8] = "1AE3"; bam_aux_append(b, "XH", 'H', (int)strlen(hx) + 1, (uint8_t *)hx); }
+    if (idx % 31 == 5 && idx % 3 != 0) {      /* an NH that is no integer */
+        if (idx % 2) { char z[4] = "2"; bam_aux_append(b, "NH", 'Z', 2, (uint8_t *)z); }
+        else { float f = 3.0f; bam_aux_append(b, "NH", 'f', 4, (uint8_t *)&f); }
+    } else {
+        switch (k % 6) {
+        case 0: { uint8_t v = (uint8_t)(1 + k % 4); bam_aux_append(b, "NH", 'C', 1, &v); break; }
+        case 1: { int8_t v = (int8_t)((k % 8 == 1) ? -3 : 2); bam_aux_append(b, "NH", 'c', 1, (uint8_t *)&v); break; }
+        case 2: { uint16_t v = (uint16_t)(k % 10 == 2 ? 65535 : 300 + k % 50); bam_aux_append(b, "NH", 'S', 2, (uint8_t *)&v); break; }
+        case 3: { int16_t v = (int16_t)(k % 12 == 3 ? -1 : 1); bam_aux_append(b, "NH", 's', 2, (uint8_t *)&v); break; }
+        case 4: { int32_t v = (k % 10 == 4) ? 70000 : 1; bam_aux_append(b, "NH", 'i', 4, (uint8_t *)&v); break; }
+        default: { uint32_t v = (k % 18 == 5) ? 4000000000u : 5; bam_aux_append(b, "NH", 'I', 4, (uint8_t *)&v); break; }
+        }
+    }
+    if (k % 2 == 1) { int16_t as = (int16_t)(-k % 90); bam_aux_append(b, "AS", 's', 2, (uint8_t *)&as); }
+}
+
 int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: hts_golden out.bam nrecords [seed]\n"); return 2; }
     const char *fn = argv[1];
@@ -144,6 +178,7 @@ int main(int argc, char **argv) {
             fill(b, idx, t, pos, flag, cig, ncig);
             /* keep every alignment inside its contig */
             if (bam_endpos(b) > lens[t]) { const uint32_t one = bam_cigar_gen(rint_(1, 10), BAM_CMATCH); fill(b, idx, t, pos, flag & ~BAM_FUNMAP, &one, 1); }
+            add_aux(b, idx);
             if (sam_write1(out, h, b) < 0) { fprintf(stderr, "write failed\n"); return 1; }
         }
     }
@@ -174,6 +209,10 @@ int main(int argc, char **argv) {
         }
         printf("\n");
         printf("SAM %d %d %d\n", i, (int)b->core.qual, (int)b->core.l_qseq);     /* pysam: mapping_quality, query_length */
+        {
+            const uint8_t *a = bam_aux_get(b, "NH");
+            printf("AUX %d %d %lld\n", i, a ? 1 : 0, a ? (long long)bam_aux2i(a) : 0ll);
+        }
         printf("CIG %d %d", i, b->core.n_cigar);
         for (int k = 0; k < b->core.n_cigar; ++k) printf(" %d %d", bam_cigar_op(cig[k]), bam_cigar_oplen(cig[k]));
         printf("\n");

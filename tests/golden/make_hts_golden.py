@@ -37,6 +37,7 @@ def main():
     reg, reg_off, reg_val = [], [0], []
     stat, nocoor = [], 0
     sam = []
+    aux = []
     for line in text.splitlines():
         f = line.split()
         if f[0] == "REF":
@@ -51,6 +52,9 @@ def main():
         elif f[0] == "SAM":
             assert int(f[1]) == len(sam)
             sam.append((int(f[2]), int(f[3])))
+        elif f[0] == "AUX":
+            assert int(f[1]) == len(aux)
+            aux.append((int(f[2]), int(f[3])))
         elif f[0] == "CIG":
             n = int(f[2])
             v = [int(x) for x in f[3:]]
@@ -67,7 +71,8 @@ def main():
             nocoor = int(f[1])
     rec = np.array(rec, np.int64)
     sam = np.array(sam, np.int64)
-    assert len(sam) == len(rec)
+    aux = np.array(aux, np.int64)
+    assert len(sam) == len(rec) == len(aux)
     out = os.path.join(HERE, "hts_fixture.npz")
     np.savez_compressed(
         out,
@@ -76,6 +81,7 @@ def main():
         references=np.array(refs), lengths=np.array(lens, np.int64),
         tid=rec[:, 0].astype(np.int32), pos=rec[:, 1].astype(np.int32), flag=rec[:, 2].astype(np.int32),
         endpos=rec[:, 3].astype(np.int64), mapq=sam[:, 0].astype(np.uint8), l_qseq=sam[:, 1].astype(np.int32),
+        has_nh=aux[:, 0].astype(np.uint8), nh=aux[:, 1].astype(np.int64),     # bam_aux_get(b, "NH") != NULL, bam_aux2i of it
         positions_off=np.array(pos_off, np.int64), positions=np.array(pos_val, np.int32),
         cigar_off=np.array(cig_off, np.int64), cigar_op=np.array(cig_op, np.uint8), cigar_len=np.array(cig_len, np.int32),
         regions=np.array(reg, np.int64), region_off=np.array(reg_off, np.int64), region_records=np.array(reg_val, np.int32),

@@ -20,7 +20,7 @@ class Group(object):
         pfx = case["aln"]["prefix"]
         keys = ("tid", "pos", "alen", "flags", "nblk", "file_id", "blk_start", "blk_len")
         out = {k: self.arrays["%s_%s" % (pfx, k)] for k in keys}
-        for k in ("wide_idx", "wide_alen", "wide_nblk", "flag16", "mapq"):    # reads beyond the 16-bit / 8-bit fields (wide_reads.npz); FLAG / MAPQ (flag_filters.npz)
+        for k in ("wide_idx", "wide_alen", "wide_nblk", "flag16", "mapq", "nh"):    # reads beyond the 16-bit / 8-bit fields (wide_reads.npz); FLAG / MAPQ (flag_filters.npz); NH (nh_filters.npz)
             if "%s_%s" % (pfx, k) in self.arrays:
                 out[k] = self.arrays["%s_%s" % (pfx, k)]
         return out

@@ -294,6 +294,35 @@ def test_bench_spawns_its_ranks_and_runs_the_one_job_mode(tmp_path):
     assert "PC_BENCH_ENGINE" not in src and "oracle_engine" not in src
 
 
+def test_bench_one_job_from_one_shared_bam_file(tmp_path):
+    """``bench.py --gpus 2 --from-bam``: rank 0 writes the job's records as ONE indexed BAM file, every rank stages its
+    genome range of it (the BAI index; here the host reader feeds the stand-in engine, on a GPU box
+    pc_add_alignment_bam_span) and passes the same parity gates as with generated records -- C2 (point rule), C3 (center
+    rule: float64 sums in file order) and the spliced C4.  The line carries the per-rank file -> staged times."""
+    import json
+    import subprocess
+    env = dict(os.environ, PC_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for cfg, n in (("C2", 100000), ("C3", 100000), ("C4", 100000)):
+        detail = str(tmp_path / ("detail_%s.json" % cfg))
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--gpus", "2", "--from-bam", "--config", cfg,
+               "--scale", str(n / {"C2": 1e8, "C3": 1e8, "C4": 5e8}[cfg]), "--tx-scale", "0.01",
+               "--steps", "2", "--warmup", "1", "--parity-chains", "60", "--detail-out", detail]
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+        lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+        assert len(lines) == 1 and len(lines[0]) <= 4096
+        d = json.loads(lines[0])
+        pt = d["config"]["partition"]
+        assert d["n_gpus"] == 2 and pt["from_bam"] is True and len(pt["stage_ms_per_rank"]) == 2
+        assert sum(pt["records_per_rank"]) == d["config"]["records"] == n
+        full = json.load(open(detail))["headline"]
+        assert "one shared BAM file" in full["partition"]["source"] and full["parity_positions"] > 0
+        # every rank staged at least the records of its own range (reads reaching in from the left come on top)
+        assert all(s >= o for s, o in zip(full["partition"]["records_staged_per_rank"], full["partition"]["records_per_rank"]))
+
+
 def test_partition_element_maps_equal_the_piecewise_walk():
     """``owned_elements`` / ``scatter_local`` build their index arrays with repeats and running offsets (479 k exons x
     cuts at C4: no Python loop per piece); against the straightforward walk over pieces and rows, for laid-out

@@ -18,8 +18,9 @@ from plastid_amd.engine import Engine  # noqa: E402
 from tests import bam_writer  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hts_fixture.npz")
-COLS = ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "wide_idx", "wide_alen", "wide_nblk", "flag16", "mapq", "qlen")
+COLS = ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "wide_idx", "wide_alen", "wide_nblk", "flag16", "mapq", "qlen", "nh")
 
 
 @pytest.fixture(scope="module")
@@ -859,3 +860,29 @@ def test_a_foreign_index_is_refused(eng, tmp_path):
     assert outcomes.count("error") >= len(outcomes) // 2, outcomes
     with pytest.raises((ValueError, IOError)):
         read_bam_gpu(path, eng, regions=[(ref0, 0, 10)])     # a.bam has lost its index
+
+
+@pytest.mark.gpu
+def test_bench_one_job_from_one_bam_file_on_the_gpu(tmp_path):
+    """``bench.py --gpus 1 --from-bam``: the job's records are written once as ONE indexed BAM file, the rank stages its
+    genome range of it through the BAI index with the decode on the GPU (pc_add_alignment_bam_span) and passes the very
+    parity gates of the generated-records run -- point rule (C2), the spliced C4 and the center rule (C3: float64 sums in
+    file order, bit for bit); the sum of all counts equals that of the same job counted from generated arrays (--one-job)."""
+    import json
+    import subprocess
+    sums = {}
+    for cfg, scale in (("C2", 0.004), ("C3", 0.004), ("C4", 0.0008)):
+        for mode in ("--from-bam", "--one-job"):
+            detail = str(tmp_path / ("d_%s_%d.json" % (cfg, mode == "--from-bam")))
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", mode, "--config", cfg, "--scale", str(scale), "--tx-scale", "0.02",
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-two-files", "--no-single-query", "--other-configs", "none",
+                   "--e2e-records", "0", "--e2e-realistic-records", "0", "--parity-chains", "100", "--detail-out", detail]
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+            d = json.loads([ln for ln in proc.stdout.decode().splitlines() if ln.startswith("{")][-1])
+            full = json.load(open(detail))["headline"]
+            assert full["parity_positions"] > 0 and d["value"] > 0
+            sums[(cfg, mode)] = full["sum_of_counts_all_ranks"]
+            if mode == "--from-bam":
+                assert d["config"]["partition"]["from_bam"] is True and "one shared BAM file" in full["partition"]["source"]
+        assert sums[(cfg, "--from-bam")] == sums[(cfg, "--one-job")], cfg

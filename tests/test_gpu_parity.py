@@ -50,6 +50,8 @@ def files_of(pa, g, case):
             wide = dict(wide_idx=aln["wide_idx"][w] - lo, wide_alen=aln["wide_alen"][w], wide_nblk=aln["wide_nblk"][w])
         if "flag16" in aln:                     # the SAM FLAG word and MAPQ of every read (flag_filters.npz)
             wide.update(flag16=aln["flag16"][lo:hi], mapq=aln["mapq"][lo:hi])
+        if "nh" in aln:                         # the NH:i tag of every read (nh_filters.npz)
+            wide.update(nh=aln["nh"][lo:hi])
         files.append(pa.PackedAlignments(
             aln["tid"][lo:hi], aln["pos"][lo:hi], aln["alen"][lo:hi], aln["flags"][lo:hi], aln["nblk"][lo:hi],
             aln["blk_start"][off[lo]:off[hi]], aln["blk_len"][off[lo]:off[hi]], references=refs, lengths=lens,
@@ -192,6 +194,51 @@ def test_golden_flag_and_mapq_filters(pa, how):
         if how == "device":
             assert ga._engine._state["flagfilter"] == (True, req, exc, mq)     # it ran on the GPU, not read by read
     assert nq > 800
+
+
+@pytest.mark.parametrize("how", ["device", "callable"])
+def test_golden_nh_filters(pa, how):
+    """Filters on the NH:i tag -- the unique-mapper test of the reference's users -- against what the reference returned
+    for ``lambda read: read.has_tag("NH") and read.get_tag("NH") <= k`` next to FLAG / MAPQ tests
+    (tests/golden/make_nh_golden.py; genome_array.py:697-722, 819-820): as ``FlagFilterFactory(max_nh=k)`` (evaluated on
+    the GPU: pc_set_nh_filter) and as the same plain callable on the mirror's read objects (``PackedRead.get_tag``;
+    evaluated on the host, staged as exclusion bits) -- vectors, reads_out, warnings, all five rules, one and two files,
+    next to a size filter and normalised."""
+    from plastid_amd.map_factories import FLAG_BITS
+    g = gu.load("nh_filters")
+    nq = 0
+    for case in g.cases:
+        files = files_of(pa, g, case)
+        assert all(f.nh is not None for f in files)
+        ga = pa.BAMGenomeArray(files, mapping=factory_of(pa, case["spec"]))
+        req, exc, mq, max_nh = case["filter"]
+        if how == "device":
+            ga.add_filter("nh", pa.FlagFilterFactory(req, exc, mq, max_nh=max_nh))
+        else:
+            need = [k for k, b in FLAG_BITS.items() if req & b]
+            ban = [k for k, b in FLAG_BITS.items() if exc & b]
+            ga.add_filter("nh", lambda r, need=need, ban=ban, mq=mq, k=max_nh: all(getattr(r, x) for x in need) and
+                          not any(getattr(r, x) for x in ban) and r.mapping_quality >= mq and r.has_tag("NH") and r.get_tag("NH") <= k)
+        if case["size_filter"]:
+            ga.add_filter("size", pa.SizeFilterFactory(min=case["size_filter"][0], max=case["size_filter"][1]))
+        if case["normalize"]:
+            ga.set_normalize(True)
+        assert ga.sum() == case["sum"]
+        offs = np.cumsum([0] + [f.n for f in files])
+        for q in case["queries"]:
+            nq += 1
+            if q["type"] == "segment":
+                seg = pa.GenomicSegment(q["chrom"], q["start"], q["end"], q["strand"])
+                (reads, arr), warns = call_with_warnings(ga.get_reads_and_counts, seg)
+                assert same(arr, g[q["expected"]]), (case["spec"], case["filter_name"], q)
+                assert [offs[files.index(r.source)] + r.index for r in reads] == list(g[q["reads_out"]]), (case["spec"], q)
+                assert (len(warns) > 0) == q["warned"], (case["spec"], q)
+            else:
+                chain = pa.SegmentChain(*[pa.GenomicSegment(q["chrom"], s, e, q["strand"]) for s, e in q["segments"]])
+                assert same(chain.get_counts(ga), g[q["expected"]]), (case["spec"], case["filter_name"], q)
+        if how == "device":
+            assert ga._engine._state["nhfilter"] == max_nh     # it ran on the GPU, not read by read
+    assert nq > 600
 
 
 # ------------------------------------------------------------------ oracle, seeded random, through the C ABI

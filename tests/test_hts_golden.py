@@ -42,6 +42,14 @@ def _htslib_runs(hts, i):
     return packing.positions_to_runs(p), len(p)
 
 
+def _expected_nh(hts):
+    """The `nh` column both decoders must produce for the fixture: htslib's bam_aux2i value of the NH tag (version 1.3 hands
+    a uint32 back through an int32: 4 000 000 000 reads -294 967 296), clamped to 0 .. 65 535; 0 without an integer NH."""
+    v = hts["nh"].astype(np.int64).copy()
+    v[v < -(1 << 20)] += 1 << 32
+    return np.where(hts["has_nh"] == 1, np.clip(v, 0, 65535), 0).astype(np.uint16)
+
+
 def test_fixture_covers_every_cigar_operation(hts):
     assert set(np.unique(hts["cigar_op"])) == set(range(9))                 # M I D N S H P = X
     n_ops = np.diff(hts["cigar_off"])
@@ -84,6 +92,17 @@ def test_native_reader_decodes_the_htslib_written_bam(hts, bam_path):
         assert np.array_equal(got.flag16, hts["flag"][keep]) and np.array_equal(got.mapq, hts["mapq"][keep])
         assert np.array_equal(got.qlen, hts["l_qseq"][keep])
         assert len(np.unique(hts["mapq"])) > 50 and (hts["mapq"] == 255).any()
+        # the NH:i tag as htslib's bam_aux_get / bam_aux2i read it back (pysam's has_tag / get_tag), clamped to 0 .. 65 535; 0 for
+        # a record without one -- and for an NH of a non-integer type, which bam_aux2i answers with 0 too
+        want_nh = _expected_nh(hts)[keep]
+        assert np.array_equal(got.nh, want_nh)
+        assert (want_nh > 0).sum() > 800 and (want_nh == 65535).sum() > 10 and ((hts["has_nh"][keep] == 1) & (want_nh == 0)).sum() > 50
+        for j in np.nonzero(want_nh > 0)[0][:5].tolist() + np.nonzero(want_nh == 0)[0][:3].tolist():
+            r = got.read(j)
+            assert r.has_tag("NH") == bool(want_nh[j]) and (r.get_tag("NH") == int(want_nh[j]) if want_nh[j] else True)
+            if not want_nh[j]:
+                with pytest.raises(KeyError):
+                    r.get_tag("NH")
         for j in (0, 7, len(keep) - 1):
             r, f = got.read(j), int(hts["flag"][keep[j]])
             assert r.flag == f and r.mapping_quality == int(hts["mapq"][keep[j]]) and r.query_length == int(hts["l_qseq"][keep[j]])
@@ -107,7 +126,7 @@ def test_chunked_decoding_of_the_htslib_written_bam(hts, bam_path, monkeypatch, 
         monkeypatch.setenv(k, v)
     for threads in (1, 3):
         got = read_bam(bam_path, threads=threads)
-        for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "flag16", "mapq", "qlen"):
+        for name in ("tid", "pos", "alen", "flags", "nblk", "blk_start", "blk_len", "flag16", "mapq", "qlen", "nh"):
             assert np.array_equal(getattr(got, name), getattr(whole, name)), (name, knobs)
         assert got.mapped == whole.mapped
 

@@ -85,12 +85,14 @@ def test_ga_cases(group):
     assert nq > (100 if group != "wide_reads" else 70)
 
 
-def flag_excluded(aln, req, exc, mq):
+def flag_excluded(aln, req, exc, mq, max_nh=0):
     """The alignments WITHOUT the reads a FLAG / MAPQ filter drops -- (flag & require) == require, (flag & exclude) == 0
     and mapq >= min_mapq keeps -- as the reference's fetch loop leaves them (genome_array.py:819-820); also the mask of
     the dropped reads and the original index of every kept one."""
     f = aln["flag16"].astype(np.int64)
     drop = ((f & req) != req) | ((f & exc) != 0) | (aln["mapq"] < mq)
+    if max_nh:   # ... and read.has_tag("NH") and read.get_tag("NH") <= max_nh
+        drop |= (aln["nh"] == 0) | (aln["nh"] > max_nh)
     keep = np.nonzero(~drop)[0]
     nb = aln["nblk"].astype(np.int64)
     cnt = np.where(nb >= 2, nb, 0)
@@ -126,6 +128,33 @@ def test_flag_and_mapq_filters():
                 assert same(got, g[q["expected"]]), (case["spec"], case["filter_name"], q)
     assert nq > 800 and ndrop > 10000
     assert any(g[q["expected"]].sum() == 0 for c in g.cases for q in c["queries"])     # the filter nothing passes
+
+
+def test_nh_filters():
+    """Filters on the NH:i tag (``read.has_tag("NH") and read.get_tag("NH") <= k``, the unique-mapper test; run by the
+    reference as plain callables: tests/golden/make_nh_golden.py): the oracle on the reads the filter keeps gives the
+    reference's vectors and reads_out for all five rules, with a size filter and normalised."""
+    g = gu.load("nh_filters")
+    nq, ndrop = 0, 0
+    for case in g.cases:
+        aln, drop, keep = flag_excluded(g.aln(case), *case["filter"])
+        ndrop += int(drop.sum())
+        spec = spec_of(case)
+        norm = case["sum"] if case["normalize"] else None
+        for q in case["queries"]:
+            nq += 1
+            tid = gu.tid_of(case, q["chrom"])
+            if q["type"] == "segment":
+                got = oracle.get_segment(aln, spec, tid, q["start"], q["end"], q["strand"], roi_order=True, normalize_sum=norm)
+                assert same(got, g[q["expected"]]), (case["spec"], case["filter_name"], q)
+                _, warn, mapped = oracle.count_segments(aln, spec, [tid], [q["start"]], [q["end"]], [gu.STRAND_CODE[q["strand"]]],
+                                                        want_mapped=True)
+                assert np.array_equal(keep[np.nonzero(mapped[0])[0]], g[q["reads_out"]]), (case["spec"], q)
+                assert bool(warn[0]) == q["warned"]
+            else:
+                got = oracle.chain_get_counts(aln, spec, tid, [tuple(x) for x in q["segments"]], q["strand"], normalize_sum=norm)
+                assert same(got, g[q["expected"]]), (case["spec"], case["filter_name"], q)
+    assert nq > 600 and ndrop > 8000
 
 
 def test_offset_tables():
