@@ -1846,12 +1846,15 @@ __global__ __launch_bounds__(kWG) void k_cs_scatter(const uint2 *__restrict__ re
 
 // half the value of a read by aligned length, for the lengths a stream entry can carry: 0.5 / (L - 2 nibble), or 0.0
 // where the read is not counted (size filter, nothing left by the nibble: adding +0.0 never changes a sum)
+#ifndef PC_CENTER_CLAIM
+#define PC_CENTER_CLAIM 8         // consecutive light entries per claim of a persistent wave (k_center2p)
+#endif
 // (and the cursors of the persistent center kernel, k_center2p: they start behind the first entry of every wave -- grid_p
 // waves, grid_p / 8 per eighth)
 __global__ void k_center_vals(MapParams mp, const double *__restrict__ invh, double *cvalh, uint32_t *cursors, uint32_t grid_p) {
     const int L = (int)threadIdx.x, m = L - 2 * mp.param;
     if (L < 256) cvalh[L] = (m > 0 && size_ok(mp, L)) ? invh[m] : 0.0;
-    if (cursors && L < 33) cursors[16 * L] = L < 32 ? (grid_p + 31u) >> 5 : grid_p;   // ([32]: the heavy entries' cursor)
+    if (cursors && L < 33) cursors[16 * L] = L < 32 ? ((grid_p + 31u) >> 5) * PC_CENTER_CLAIM : grid_p;   // ([32]: the heavy entries' cursor)
 }
 
 // Dispatch list of the center kernel.  A chunk's replay is sequential in the reads that overlap
@@ -2022,9 +2025,6 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 #define PC_CS_Q1 PC_CS_2(4, 5) PC_CS_2(6, 7)
 #define PC_CS_Q2 PC_CS_2(8, 9) PC_CS_2(10, 11)
 #define PC_CS_Q3 PC_CS_2(12, 13) PC_CS_2(14, 15)
-#ifndef PC_CENTER_RING
-#define PC_CENTER_RING 2   // batches of entries in flight per wave (2 / 3 / 4 measured on one box: 1.29 / 1.50 - 1.58 / 1.31 ms on C3)
-#endif
 #define PC_CENTER_STEPS(CODE)                                                                                          \
     asm volatile(PC_CS_HEAD CODE                                                                                       \
                  : [acc] "+v"(acc)                                                                                     \
@@ -2039,278 +2039,14 @@ __device__ __forceinline__ void center_read(const GFile &fv, const MapParams &mp
 #define PC_CENTER_SKIP 0
 #endif
 
-struct CenterCtx {
-    const CenterChunk *chunks;
-    int64_t nchunks;
-    const FileView *files;
-    int nfiles;
-    MapParams mp;
-    int W;
-    const double *inv, *invh, *cvalh;
-    const uint32_t *order, *counters;
-    const u32x4 *ranges;
-    const u32x2 *rec_ranges;
-    const uint32_t *row_ranges;
-    const OutPiece *opieces;
-    double *out;
-    double norm_sum;
-    int norm_on;
-    unsigned long long *dbg;
-};
-
-// One dispatch entry -- a whole chunk (code 0) or a sub-chunk of a cut one -- replayed by one wave.
-// DBG: count the replay steps (PC_CENTER_DEBUG, pc_center_replay_steps).  GENERAL: some staged file holds reads a stream
-// entry cannot describe (aligned length > 255: indirect entries) or a stream too long for 32-bit byte offsets -- the
-// stream loop then tests every batch for them; short-read files run the instantiation that does not.
-template <bool DBG, bool GENERAL>
-__device__ __forceinline__ void center_chunk(const CenterCtx &cx, const uint32_t cidx, const uint32_t code, const CenterChunk ck, const int lane,
-                                             const double *s_valh, unsigned long long &n_slots) {
-    const double PC_GLOBAL *inv = (const double PC_GLOBAL *)cx.inv;      // 1.0 / m
-    const double PC_GLOBAL *invh = (const double PC_GLOBAL *)cx.invh;    // 0.5 / m = (1.0 / m) / 2, exactly
-    const MapParams &mp = cx.mp;
-    const FileView *files = cx.files;
-    const int nfiles = cx.nfiles, W = cx.W;
-    const u32x4 *ranges = cx.ranges;
-    const u32x2 *rec_ranges = cx.rec_ranges;
-    const uint32_t *row_ranges = cx.row_ranges;
-    const OutPiece *opieces = cx.opieces;
-    double *out = cx.out;
-    const double norm_sum = cx.norm_sum;
-    const int norm_on = cx.norm_on;
-    const int row = lane >> 4, li = lane & 15;
-    const int nib = mp.param;
-    // a sub-chunk is a chunk of its own: 16 (8) positions, rows of 4 (2)
-    const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
-    const int roww = code == 0u ? 16 : (code <= 4u ? 4 : 2);
-    if (sub_off >= ck.len) return;
-    const int32_t s0 = ck.start + sub_off;
-    const int32_t cend = ck.start + (ck.len < sub_off + kCenterRows * roww ? ck.len : sub_off + kCenterRows * roww);
-    const int32_t rs = s0 + row * roww;                              // this lane's row: positions [rs, re)
-    const int32_t re = rs + roww < cend ? rs + roww : cend;
-    const bool row_live = rs < cend;
-    const int32_t p = rs + li;
-    const bool owns = li < roww && p < cend;
-    const int sel = center_sel(ck.mode);
-    const int lane_bit = 1 << li, lane_sh = 30 - li;
-    double acc = 0.0;
-    for (int f = 0; f < nfiles; ++f) { // file-major, genome_array.py:800-809
-        const GFile fv = gfile(files[f]);
-        const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[(int64_t)cidx * nfiles + f]; // from k_center_weigh
-        // One entry, already trimmed by the nibble: counted positions [a0, a0 + m) of a read of aligned length L.  What
-        // the replay needs of it: the coverage mask of this lane's ROW and half the read's value.
-        auto row_mask = [&](int a0, int m) {   // (m = 0: nothing)
-            const int first = a0 - rs, b0 = first > 0 ? first : 0, b1 = first + m < 16 ? first + m : 16;   // row-relative [b0, b1)
-            return b1 > b0 ? (int)((1u << b1) - (1u << b0)) : 0;
-        };
-        // one batch: entry `li` of every row in (cm_, valh_); `indirect`: a read the entry cannot describe (record `recidx`)
-        auto replay = [&](int a0_, int mm_, int cm_, double valh_, bool indirect, uint32_t recidx, int nsteps, bool may_be_indirect) {   // (a0_, mm_: the slow path's)
-            if (DBG) n_slots += (unsigned long long)nsteps;
-            if (may_be_indirect && __any(indirect)) {
-                // entry by entry, row by row (what matters is the order inside a row)
-                for (int j = 0; j < 16; ++j) {
-                    for (int r = 0; r < kCenterRows; ++r) {
-                        const int src = r * 16 + j;
-                        if (lane_u32((uint32_t)indirect, src)) {
-                            const int64_t i = (int64_t)lane_u32(recidx, src);
-                            const u32x2 rr = fv.rec[i];
-                            int Li, nbi;
-                            rec_true(fv, i, rr.y, Li, nbi);
-                            double t = acc;
-                            center_read(fv, mp, inv, (int32_t)rr.x, Li, nbi, nbi >= 2 ? fv.blk_off[i] : 0u, p, t);
-                            acc = row == r ? t : acc;
-                        } else {
-                            const int aj = (int)lane_u32((uint32_t)a0_, src), mj = (int)lane_u32((uint32_t)(cm_ ? mm_ : 0), src);
-                            if (mj == 0) continue;
-                            const double vj = lane_f64(valh_, src) * 2.0;      // (exact; 0.0 where the row is not covered at all)
-                            acc += (row == r && (uint32_t)(p - aj) < (uint32_t)mj) ? vj : 0.0;
-                        }
-                    }
-                }
-                return;
-            }
-            if (PC_CENTER_SKIP & 1) { asm volatile("" : [acc] "+v"(acc) : [cm] "v"(cm_), [val] "v"(valh_)); return; }
-            if (nsteps > 12) {
-                PC_CENTER_STEPS(PC_CS_Q0 PC_CS_Q1 PC_CS_Q2 PC_CS_Q3);
-            } else {
-                PC_CENTER_STEPS(PC_CS_Q0);
-                if (nsteps > 4) PC_CENTER_STEPS(PC_CS_Q1);
-                if (nsteps > 8) PC_CENTER_STEPS(PC_CS_Q2);
-            }
-        };
-        // long-span reads that start before the near window of a row but may reach into it: they precede every
-        // near-window record in the file, so they are replayed first -- 8 reads per batch, the first two aligned
-        // runs of read j (they travel next to its header) as entries 2j and 2j + 1 of EVERY row; a row only counts
-        // those that start before its own near window (the others it meets in its stream); reads with more runs go
-        // through their record
-        if (rg.w > rg.z) {
-            const int64_t near_row = (int64_t)rs - W + 1;
-            const int64_t near_last = (int64_t)s0 + (kCenterRows - 1) * roww - W + 1;   // the last row's: the furthest any row looks
-            for (int64_t base = rg.z; base < (int64_t)rg.w; base += 8) {
-                const int64_t j = base + (li >> 1);
-                const bool in = j < (int64_t)rg.w;
-                const u32x4 g = in ? fv.long_rec[j] : u32x4{0x7fffffffu, kFlagExcluded << 16, 0u, 0u};
-                if ((int64_t)(int32_t)lane_u32(g.x, 0) >= near_last) break; // sorted by start: the rest is met in the near windows
-                const i32x4 runs = in ? fv.long_runs[j] : i32x4{0, 0, 0, 0};
-                const uint32_t fl = rec_flags(g.y);
-                int nbk = rec_nblk(g.y), Lg = rec_len(g.y);
-                if (in && (fl & kFlagWide)) { const u32x2 tv = fv.long_wide[j]; Lg = (int)tv.x; nbk = (int)tv.y; }   // beyond the 16 / 8-bit fields
-                const int r = li & 1;
-                const bool ok = in && row_live && (int64_t)(int32_t)g.x < near_row && !(fl & kFlagExcluded) && strand_ok(ck.mode, fl & kFlagReverse);
-                // (these entries come with their read's header, not from the stream: trimmed by the nibble here)
-                const int x = r ? runs.z : runs.x, len = r ? runs.w : runs.y, cum = r ? runs.y : 0;
-                const int lo_i = cum > nib ? cum : nib, hi_i = cum + len < Lg - nib ? cum + len : Lg - nib;
-                const int a0_ = x + (lo_i - cum), mm_ = hi_i > lo_i ? hi_i - lo_i : 0, mtot = Lg - 2 * nib;
-                const int cm_ = (ok && nbk <= 2 && (r == 0 || nbk == 2) && size_ok(mp, Lg)) ? row_mask(a0_, mm_) : 0;
-                double valh_ = 0.0;
-                if (cm_) valh_ = mtot < 65536 ? invh[mtot] : (1.0 / (double)mtot) * 0.5;   // cm != 0 implies mtot >= m > 0
-                replay(a0_, mm_, cm_, valh_, ok && nbk > 2 && r == 0, g.w, 16, true);
-            }
-        }
-        // near windows: row r replays the stream entries of the records that start in [rs - W + 1, re).  Whole chunks
-        // take the rows' entry ranges from the pre-pass; a sub-chunk finds those of its narrower rows itself.
-        uint32_t lo, hi;
-        if (code == 0u) {
-            const uint32_t PC_GLOBAL *rt = (const uint32_t PC_GLOBAL *)row_ranges + ((size_t)cidx * nfiles + f) * (2 * kCenterRows);
-            lo = rt[row];
-            hi = rt[kCenterRows + row];
-        } else {
-            const u32x2 rr = ((const u32x2 PC_GLOBAL *)rec_ranges)[(int64_t)cidx * nfiles + f];
-            const int64_t key_lo = row_live ? (int64_t)rs - W + 1 : (int64_t)cend, key_hi = row_live ? (int64_t)re : (int64_t)cend;
-            const int64_t r0 = lower_bound_pos(fv.rec, rr.x, rr.y, key_lo);
-            const int64_t r1 = lower_bound_pos(fv.rec, r0, rr.y, key_hi);
-            const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, sel);
-            lo = soff[r0];
-            hi = soff[r1];
-        }
-        if (hi < lo) hi = lo;
-        uint32_t nmax = hi - lo;
-        {
-            const uint32_t n1 = lane_u32(nmax, 16), n2 = lane_u32(nmax, 32), n3 = lane_u32(nmax, 48), n0 = lane_u32(nmax, 0);
-            nmax = n0 > n1 ? n0 : n1;
-            nmax = nmax > n2 ? nmax : n2;
-            nmax = nmax > n3 ? nmax : n3;
-        }
-        if (nmax == 0u) continue;
-        if (PC_CENTER_SKIP & 2) continue;
-        const u32x2 PC_GLOBAL *ent = cs_stream(files + f, sel);
-        // (the loads are unconditional: a lane past its row's end reads one of the 64 entries behind the stream's last,
-        // which cover nothing -- no validity test per entry; 32-bit offsets from the chunk's first entry: one scalar base,
-        // no 64-bit address arithmetic per lane)
-        const char PC_GLOBAL *eb = (const char PC_GLOBAL *)(ent + rg.x);
-        // (a stream so long that its end is beyond a 32-bit byte offset from here -- > 5e8 entries -- clamps to the row's
-        // end instead and tests every entry's index)
-        const uint32_t to_end = files[f].cs_total[sel] - rg.x;
-        const bool far = GENERAL && to_end >= (1u << 28);
-        const uint32_t rlo = lo - rg.x + (uint32_t)li, rhi = hi - rg.x, dead = far ? rhi : to_end + (uint32_t)li;
-        auto fetch = [&](uint32_t base) {
-            const uint32_t idx = rlo + base;
-            return *(const u32x2 PC_GLOBAL *)(eb + ((idx < rhi ? idx : dead) << 3));
-        };
-        const bool any_indirect = GENERAL && files[f].cs_indirect[sel] != 0u;   // (uniform: short-read files have none, and never look)
-        // PC_CENTER_RING batches of entries in flight, each in a register pair of its own (a copy of a register with a load
-        // outstanding waits for that load: the loop body is unrolled over the ring instead).  The batch after the one
-        // being replayed is already unpacked -- coverage mask, and half the read's value out of the LDS copy of the
-        // by-length table (a global gather would be the youngest load in flight, and waiting for the youngest waits for
-        // all of them) -- so that neither the entry load nor the LDS read is waited for right before its steps.
-        struct Prepared { int cm; double valh; bool ind; u32x2 r; };
-        auto unpack = [&](const u32x2 r, uint32_t base) {
-            Prepared pr;
-            pr.r = r;
-            pr.ind = any_indirect && ((r.y >> 24) & kCsIndirect);     // (an indirect entry carries m = 0)
-            pr.cm = row_mask((int32_t)r.x, (int)(r.y & 0xffu));
-            if (far && !(rlo + base < rhi)) pr.cm = 0;
-            pr.valh = s_valh[(r.y >> 16) & 0xffu];   // by aligned length (an indirect entry reads [0])
-            return pr;
-        };
-        u32x2 q[PC_CENTER_RING];
-#pragma unroll
-        for (int k = 0; k < PC_CENTER_RING; ++k) q[k] = fetch(16u * (uint32_t)k);
-        Prepared nxt = unpack(q[0], 0u);
-        q[0] = fetch(16u * PC_CENTER_RING);
-        for (uint32_t base = 0; base < nmax;) {
-#pragma unroll
-            for (int k = 0; k < PC_CENTER_RING; ++k) {
-                const Prepared cur = nxt;
-                const int kn = (k + 1) % PC_CENTER_RING;   // (a constant once the loop is unrolled: q stays in registers)
-                nxt = unpack(q[kn], base + 16u);
-                q[kn] = fetch(base + 16u + 16u * PC_CENTER_RING);
-                const uint32_t left = nmax - base;
-                replay((int32_t)cur.r.x, (int)(cur.r.y & 0xffu), cur.cm, cur.valh, cur.ind, cur.r.x, left >= 16u ? 16 : (int)((left + 3u) & ~3u), GENERAL);
-                base += 16u;
-                if (base >= nmax) break;
-            }
-        }
-    }
-    // The sums go straight into the caller's layout (SegmentChain.get_counts, roitools.pyx:3259-3271: chain offset,
-    // 5'->3' reversal of '-' chains; reads-per-million as count / sum * 1e6 in that order, genome_array.py:826-827):
-    // every queried segment slice of the chunk's window that holds this lane's position gets the lane's sum -- no
-    // intermediate histogram, no gather pass.
-    if (PC_CENTER_SKIP & 4) { asm volatile("" : : "v"(acc)); return; }
-    {
-        const double val = norm_on ? acc / norm_sum * 1e6 : acc;
-        for (uint32_t oi = ck.op_begin; oi < ck.op_end; ++oi) {
-            const OutPiece o = opieces[oi];
-            if (o.mode != ck.mode) continue;                  // the window's slices of other strand modes
-            const uint32_t rel = (uint32_t)(p - o.start);
-            if (owns && rel < (uint32_t)o.len) out[o.out_off + (int64_t)o.step * (int64_t)rel] = val;
-        }
-    }
-}
-
-// Dispatch: one wave per entry of the list.  The HEAVY entries -- chunks far above the mean, the deepest cut into
-// sub-chunks (k_center_order) -- sit at the front of the list and start at t = 0, the light ones follow from the back.
-// Light entries are dealt so that the workgroups of one XCD (workgroup b runs on XCD b mod 8) walk ONE contiguous
-// eighth of the list: neighbouring chunks re-read each other's halo, and that then hits the XCD's own L2.
-// (Persistent waves were measured twice and dropped twice: pulling chunks from a queue, round 3, 2.3 - 2.4 ms against
-// 1.6; walking equal-work stretches of the chunk list -- the replay steps of every chunk are known exactly from the
-// pre-pass -- with the next descriptor requested ahead, round 4, 1.27 - 1.32 ms against 1.13: the per-chunk fixed cost is
-// instructions, not dispatch, and the stretches finish unevenly.)
-// (Compiled for eight waves per SIMD: left alone the kernel takes 102 SGPRs -- seven waves; with the target it fits 78
-// SGPRs and 63 VGPRs without scratch.  A/B on one box, three rounds of 40 steps: 1.34 / 1.32 / 1.42 ms without,
-// 1.07 / 1.25 / 1.30 with.  Round 4's earlier amdgpu_num_sgpr(80) spilled; (96) gains less.)
-template <bool DBG, bool GENERAL>
-__global__ __launch_bounds__(kCenterWG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_center(CenterCtx cx) {
-    const uint32_t cap = kCenterCap * (uint32_t)cx.nchunks;
-    const uint32_t n_heavy = cx.counters[0];
-    const uint32_t bidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * (uint32_t)kCenterWG + threadIdx.x) >> 6));
-    const int lane = threadIdx.x & 63;
-    unsigned long long *dbg = DBG ? cx.dbg : nullptr;
-    const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
-    unsigned long long n_slots = 0;   // PC_CENTER_DEBUG / pc_center_replay_steps: replay steps of this wave
-    // half the value of a read by aligned length (k_center_vals), in LDS: one copy per wave
-    __shared__ double s_valh[256];
-    if (!(PC_CENTER_SKIP & 8)) for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
-    __builtin_amdgcn_wave_barrier();
-    uint32_t slot;
-    if (bidx < n_heavy) {
-        slot = bidx;
-        const uint32_t entry = cx.order[slot];
-        const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
-        center_chunk<DBG, GENERAL>(cx, cidx, code, cx.chunks[cidx], lane, s_valh, n_slots);
-    } else {
-        // one wave per light entry of the list, dealt so that the workgroups of one XCD (workgroup b runs on XCD b mod 8)
-        // walk ONE contiguous eighth of it: neighbouring chunks re-read each other's halo, and that then hits the XCD's own L2
-        const uint32_t n_light = cx.counters[1], k = bidx - n_heavy, n8 = (n_light + 7u) >> 3;
-        if (k >= 8u * n8) return;
-        const uint32_t kk = (bidx & 7u) * n8 + (k >> 3);
-        if (kk >= n_light) return;
-        slot = cap - 1u - kk;
-        const uint32_t cidx = cx.order[slot];
-        center_chunk<DBG, GENERAL>(cx, cidx, 0u, cx.chunks[cidx], lane, s_valh, n_slots);
-    }
-    if (dbg && lane == 0) {   // PC_CENTER_DEBUG
-        dbg[2 * (size_t)slot] = wall_clock64() - t_begin; dbg[2 * (size_t)slot + 1] = t_begin;
-        dbg[2 * (size_t)cap + slot] = n_slots;
-    }
-}
-
 // ---------------------------------------------------------------- k_center_slots / k_center2 (round 5)
 // Where round 4's k_center spent its time (scripts/exp_center_sections.py, sections compiled out): of 1.20 ms on C3 the
 // replay steps themselves are 0.14 -- the rest is LATENCY: a wave's four dependent loads before its first entry
 // (counters -> order -> {chunk, ranges, row ranges} -> entries: 0.36 ms for 372 k waves with nothing else to do), the
 // entry loop at two batches in flight (0.42 ms without a single step), and the output pieces fetched after the last step
 // (0.2 - 0.3 ms).  A wave spent 14 of its 26 us outside the replay loop, so on average fewer than four of a SIMD's eight
-// waves had steps to issue.  Hence, for plans over ONE alignment file (every BASELINE config):
+// waves had steps to issue.  Hence (round 5 for plans over ONE alignment file; since round 6 for every plan -- a plan
+// over several files has one descriptor per entry and FILE, consecutive, replayed into the same sums in file order):
 //   * k_center_slots (cached with the dispatch list: once per plan, alignments and halo) resolves every dispatch entry
 //     into a 128-byte DESCRIPTOR: the (sub-)chunk's positions, its rows' entry ranges (those of a sub-chunk's narrower
 //     rows by the bisections the wave used to make), the long-span candidates, and -- when exactly one output piece
@@ -2360,7 +2096,7 @@ __device__ __forceinline__ uint32_t center_steps_of(uint32_t n) { return (n & ~1
 // One THREAD per dispatch entry (heavy entries first, then the light ones in list order): its descriptor.
 // fill[0] += entries of all rows, fill[1] += 4 x replay steps (the lock-step rows' capacity): their ratio is the row
 // fill the bench line reports.
-__global__ __launch_bounds__(kRangesWG) void k_center_slots(const CenterChunk *__restrict__ chunks, int64_t nchunks, const FileView *__restrict__ files,
+__global__ __launch_bounds__(kRangesWG) void k_center_slots(const CenterChunk *__restrict__ chunks, int64_t nchunks, const FileView *__restrict__ files, int nfiles,
                                                             int W, const uint32_t *__restrict__ order, const uint32_t *__restrict__ counters,
                                                             const u32x4 *__restrict__ ranges, const u32x2 *__restrict__ rec_ranges,
                                                             const uint32_t *__restrict__ row_ranges, const OutPiece *__restrict__ opieces,
@@ -2373,6 +2109,9 @@ __global__ __launch_bounds__(kRangesWG) void k_center_slots(const CenterChunk *_
         const uint32_t entry = e < n_heavy ? order[e] : order[cap - 1u - (e - n_heavy)];
         const uint32_t cidx = entry & ((1u << kSubShift) - 1u), code = entry >> kSubShift;
         const CenterChunk ck = chunks[cidx];
+        // (several files: the descriptors of one entry are consecutive, file-major -- the order the reference's fetch
+        // chains the files in, genome_array.py:800-809 -- and every one carries the output piece)
+        for (int f = 0; f < nfiles; ++f) {
         CenterSlot sl;
         for (int k = 0; k < 8; ++k) sl.pad[k] = 0u;
         const int sub_off = code == 0u ? 0 : (code <= 4u ? 16 * (int)(code - 1u) : 8 * (int)(code - 5u));
@@ -2381,10 +2120,10 @@ __global__ __launch_bounds__(kRangesWG) void k_center_slots(const CenterChunk *_
         const int32_t cend = ck.start + (ck.len < sub_off + kCenterRows * roww ? ck.len : sub_off + kCenterRows * roww);
         const int npos = cend > s0 ? cend - s0 : 0;
         const int sel = center_sel(ck.mode);
-        const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[cidx];
+        const u32x4 rg = ((const u32x4 PC_GLOBAL *)ranges)[(size_t)cidx * nfiles + f];
         sl.start = s0;
         sl.ent0 = rg.x;
-        sl.to_end = files[0].cs_total[sel] - rg.x;
+        sl.to_end = files[f].cs_total[sel] - rg.x;
         sl.long_z = rg.z; sl.long_w = rg.w;
         sl.chunk = entry;
         sl.tid = ck.tid;
@@ -2392,13 +2131,13 @@ __global__ __launch_bounds__(kRangesWG) void k_center_slots(const CenterChunk *_
         sl.out_lo = sl.out_hi = 0u; sl.ostart = 0; sl.olen = 0; sl.ostep = 0;
         uint32_t nmax = 0;
         if (npos > 0) {
-            const GFile fv = gfile(files[0]);
-            const uint32_t PC_GLOBAL *soff = cs_offsets(files, sel);
-            const u32x2 rr = ((const u32x2 PC_GLOBAL *)rec_ranges)[cidx];
+            const GFile fv = gfile(files[f]);
+            const uint32_t PC_GLOBAL *soff = cs_offsets(files + f, sel);
+            const u32x2 rr = ((const u32x2 PC_GLOBAL *)rec_ranges)[(size_t)cidx * nfiles + f];
             for (int r = 0; r < kCenterRows; ++r) {
                 uint32_t lo, hi;
                 if (code == 0u) {
-                    const uint32_t PC_GLOBAL *rt = (const uint32_t PC_GLOBAL *)row_ranges + (size_t)cidx * (2 * kCenterRows);
+                    const uint32_t PC_GLOBAL *rt = (const uint32_t PC_GLOBAL *)row_ranges + ((size_t)cidx * nfiles + f) * (2 * kCenterRows);
                     lo = rt[r]; hi = rt[kCenterRows + r];
                 } else {   // the narrower rows of a sub-chunk: records that start in [row start - W + 1, row end)
                     const int32_t rs = s0 + r * roww, re = rs + roww < cend ? rs + roww : cend;
@@ -2413,7 +2152,7 @@ __global__ __launch_bounds__(kRangesWG) void k_center_slots(const CenterChunk *_
                 nmax = hi - lo > nmax ? hi - lo : nmax;
                 f_ent += hi - lo;
             }
-            f_cap = (unsigned long long)kCenterRows * center_steps_of(nmax);
+            f_cap += (unsigned long long)kCenterRows * center_steps_of(nmax);
             // the output pieces that take this (sub-)chunk's sums: exactly one -- inline
             uint32_t hits = 0, which = 0;
             for (uint32_t oi = ck.op_begin; oi < ck.op_end; ++oi) {
@@ -2432,7 +2171,8 @@ __global__ __launch_bounds__(kRangesWG) void k_center_slots(const CenterChunk *_
             sl.shape = 0u;
         }
         sl.nmax = nmax;
-        slots[e] = sl;
+        slots[(size_t)e * nfiles + f] = sl;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { f_ent += __shfl_down(f_ent, o, 64); f_cap += __shfl_down(f_cap, o, 64); }
     if ((threadIdx.x & 63) == 0 && f_cap) { atomicAdd(&fill[0], f_ent); atomicAdd(&fill[1], f_cap); }
@@ -2443,6 +2183,7 @@ struct Center2Ctx {
     const uint2 *ent[3];       // the file's center streams by strand selection (kernel arguments: no load between descriptor and entries)
     uint32_t indirect;         // bit sel: that stream holds indirect entries (reads beyond the 8-bit fields)
     const FileView *files;
+    int nfiles;                // files of the plan's engine: a dispatch entry has one descriptor per file (consecutive)
     FileView file0;            // the one file's view, by value: its pointers come out of the argument segment (scalar loads at the point of use) instead of per-lane loads from memory
     MapParams mp;
     int W;
@@ -2459,12 +2200,14 @@ struct Center2Ctx {
 };
 
 // One (sub-)chunk from its descriptor `d` (lane l < 32 holds dword l; the upper half of the wave holds a copy).
-// `dsel`: 0 / 32 -- which half of the wave holds the descriptor (a wave that claims two adjacent entries loads both with
-// one 256-byte request).  RING: batches of entries in flight.
-// EARLY: the fields the epilogue needs are taken out of the descriptor before the replay (the persistent kernel: the
-// register that held the descriptor is then free for the next one while the chunk replays).
-template <bool DBG, bool GENERAL, int RING, bool EARLY = false>
-__device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t d_, const int dsel, const int lane, const double *s_valh, unsigned long long &n_slots) {
+// `dsel`: 0 / 32 -- which half of the wave holds the descriptor (-1: both hold a copy).  RING: batches of entries in flight.
+// MULTI: a plan over several alignment files -- the wave calls this once per file, in file order, with the same `acc`
+// (the reads of file f + 1 follow those of file f in every position's sum: itertools.chain over the files' fetches,
+// genome_array.py:800-809); the sums are written after the last file (`last`).  The file's view and streams then come
+// from memory (cx.files[file]); a single file's travel in the kernel arguments.
+template <bool DBG, bool GENERAL, int RING, bool MULTI = false>
+__device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t d_, const int dsel, const int lane, const double *s_valh, unsigned long long &n_slots,
+                                            double &acc, const int file = 0, const bool last = true) {
     // (the descriptor in both halves of the wave, as the field reads below expect it; dsel < 0: it already is)
     const uint32_t d = dsel < 0 ? d_ : (uint32_t)__shfl((int)d_, dsel + (lane & 31), 64);
     const uint32_t shape = lane_u32(d, kCsShape);
@@ -2484,8 +2227,7 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
     const bool owns = li < roww && p < cend;
     const int sel = center_sel(mode);
     const int lane_bit = 1 << li, lane_sh = 30 - li;
-    double acc = 0.0;
-    const GFile fv = gfile(cx.file0);
+    const GFile fv = MULTI ? gfile(cx.files[file]) : gfile(cx.file0);
     auto row_mask = [&](int a0, int m) {   // (m = 0: nothing)
         const int first = a0 - rs, b0 = first > 0 ? first : 0, b1 = first + m < 16 ? first + m : 16;   // row-relative [b0, b1)
         return b1 > b0 ? (int)((1u << b1) - (1u << b0)) : 0;
@@ -2533,18 +2275,6 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
     // eighths of the group that hold such a read are handed round (lane permutes) and replayed -- skipping a read that
     // adds +0.0 to every sum leaves every bit as it was.
     const uint32_t long_z = lane_u32(d, kCsLongZ), long_w = lane_u32(d, kCsLongW);
-    uint32_t e_out_lo = 0u, e_out_hi = 0u, e_op_begin = 0u, e_op_end = 0u;
-    int32_t e_ostart = 0, e_olen = 0, e_ostep = 0;
-    if (EARLY) {
-        e_out_lo = lane_u32(d, kCsOutLo); e_out_hi = lane_u32(d, kCsOutHi);
-        e_ostart = (int32_t)lane_u32(d, kCsOStart); e_olen = (int32_t)lane_u32(d, kCsOLen); e_ostep = (int32_t)lane_u32(d, kCsOStep);
-        e_op_begin = lane_u32(d, kCsOpBegin); e_op_end = lane_u32(d, kCsOpEnd);
-    }
-    uint32_t nmax = 0u, ent0 = 0u, to_end = 0u, lo = 0u, hi = 0u;
-    if (EARLY) {
-        nmax = lane_u32(d, kCsNmax); ent0 = lane_u32(d, kCsEnt0); to_end = lane_u32(d, kCsToEnd);
-        lo = (uint32_t)__shfl((int)d, kCsLo + row, 64); hi = (uint32_t)__shfl((int)d, kCsHi + row, 64);
-    }
     if (long_w > long_z) {
         const int64_t near_row = (int64_t)rs - W + 1;
         const int64_t near_last = (int64_t)s0 + (kCenterRows - 1) * roww - W + 1;   // the last row's: the furthest any row looks
@@ -2595,14 +2325,13 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
         }
     }
     // near windows: row r replays the stream entries [lo, hi) the descriptor names for it
-    if (!EARLY) nmax = lane_u32(d, kCsNmax);
+    const uint32_t nmax = lane_u32(d, kCsNmax);
     if (nmax != 0u && !(PC_CENTER_SKIP & 2)) {
-        if (!EARLY) {
-            ent0 = lane_u32(d, kCsEnt0); to_end = lane_u32(d, kCsToEnd);
-            lo = (uint32_t)__shfl((int)d, kCsLo + row, 64); hi = (uint32_t)__shfl((int)d, kCsHi + row, 64);
-        }
+        const uint32_t ent0 = lane_u32(d, kCsEnt0), to_end = lane_u32(d, kCsToEnd);
+        const uint32_t lo = (uint32_t)__shfl((int)d, kCsLo + row, 64), hi = (uint32_t)__shfl((int)d, kCsHi + row, 64);
         const uint2 *ent_sel = sel == 0 ? cx.ent[0] : (sel == 1 ? cx.ent[1] : cx.ent[2]);   // (selects, not an indexed copy: that would live in scratch)
-        const char PC_GLOBAL *eb = (const char PC_GLOBAL *)((const u32x2 PC_GLOBAL *)ent_sel + ent0);
+        const char PC_GLOBAL *eb = MULTI ? (const char PC_GLOBAL *)(cs_stream(cx.files + file, sel) + ent0)
+                                         : (const char PC_GLOBAL *)((const u32x2 PC_GLOBAL *)ent_sel + ent0);
         // (loads past a row's end read one of the 64 entries behind the stream's last, which cover nothing; a stream whose
         // end lies beyond a 32-bit byte offset from here clamps to the row's end instead and tests every entry's index)
         const bool far = GENERAL && to_end >= (1u << 28);
@@ -2611,7 +2340,7 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
             const uint32_t idx = rlo + base;
             return *(const u32x2 PC_GLOBAL *)(eb + ((idx < rhi ? idx : dead) << 3));
         };
-        const bool any_indirect = GENERAL && ((cx.indirect >> sel) & 1u) != 0u;   // (uniform: short-read files have none, and never look)
+        const bool any_indirect = GENERAL && (MULTI ? cx.files[file].cs_indirect[sel] != 0u : ((cx.indirect >> sel) & 1u) != 0u);   // (uniform: short-read files have none, and never look)
         struct Prepared { int cm; double valh; bool ind; u32x2 r; };
         auto unpack = [&](const u32x2 r, uint32_t base) {
             Prepared pr;
@@ -2646,20 +2375,17 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
     }
     // the sums, straight into the caller's layout (SegmentChain.get_counts, roitools.pyx:3259-3271; reads-per-million as
     // count / sum * 1e6 in that order, genome_array.py:826-827)
+    if (MULTI && !last) return;   // (the next file's reads follow in the same sums)
     if (PC_CENTER_SKIP & 4) { asm volatile("" : : "v"(acc)); return; }
     const double val = cx.norm_on ? acc / cx.norm_sum * 1e6 : acc;
     if ((shape >> 24) & 1u) {   // THE output piece of this chunk, from the descriptor
-        if (!EARLY) {
-            e_out_lo = lane_u32(d, kCsOutLo); e_out_hi = lane_u32(d, kCsOutHi);
-            e_ostart = (int32_t)lane_u32(d, kCsOStart); e_olen = (int32_t)lane_u32(d, kCsOLen); e_ostep = (int32_t)lane_u32(d, kCsOStep);
-        }
-        const long long out_off = (long long)(((unsigned long long)e_out_hi << 32) | e_out_lo);
-        const int32_t ostart = e_ostart, olen = e_olen, ostep = e_ostep;
+        const long long out_off = (long long)(((unsigned long long)lane_u32(d, kCsOutHi) << 32) | lane_u32(d, kCsOutLo));
+        const int32_t ostart = (int32_t)lane_u32(d, kCsOStart), olen = (int32_t)lane_u32(d, kCsOLen), ostep = (int32_t)lane_u32(d, kCsOStep);
         const uint32_t rel = (uint32_t)(p - ostart);
         if (owns && rel < (uint32_t)olen) cx.out[out_off + (long long)ostep * (long long)rel] = val;
     } else {
-        if (!EARLY) { e_op_begin = lane_u32(d, kCsOpBegin); e_op_end = lane_u32(d, kCsOpEnd); }
-        for (uint32_t oi = e_op_begin; oi < e_op_end; ++oi) {
+        const uint32_t op_begin = lane_u32(d, kCsOpBegin), op_end = lane_u32(d, kCsOpEnd);
+        for (uint32_t oi = op_begin; oi < op_end; ++oi) {
             const OutPiece o = cx.opieces[oi];
             if (o.mode != mode) continue;                     // the window's slices of other strand modes
             const uint32_t rel = (uint32_t)(p - o.start);
@@ -2672,8 +2398,8 @@ __device__ __forceinline__ void center_slot(const Center2Ctx &cx, const uint32_t
 // consecutive light entries each, dealt so that the workgroups of one XCD (workgroup b runs on XCD b mod 8) walk ONE
 // contiguous eighth of the light list -- neighbouring chunks re-read each other's halo, which then hits the XCD's own L2.
 // (the diagnostic instantiations carry their clocks and step counters: compiled for seven waves, they keep out of scratch)
-template <bool DBG, bool GENERAL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBG ? 7 : 8, 8))) void k_center2(Center2Ctx cx) {
+template <bool DBG, bool GENERAL, bool MULTI = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MULTI ? 6 : (DBG ? 7 : 8), 8))) void k_center2(Center2Ctx cx) {
     const uint32_t n_heavy = cx.known ? cx.n_heavy : cx.counters[0], n_light = cx.known ? cx.n_light : cx.counters[1];
     const uint32_t bidx = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -2695,7 +2421,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBG ? 7 : 8,
         count = hi8 - (lo8 + at) < K ? hi8 - (lo8 + at) : K;
     }
     const uint32_t PC_GLOBAL *sw = (const uint32_t PC_GLOBAL *)cx.slots;
-    uint32_t d = sw[(size_t)first * 32u + (uint32_t)(lane & 31)];
+    const uint32_t nf = MULTI ? (uint32_t)cx.nfiles : 1u;   // descriptors per entry
+    uint32_t d = sw[(size_t)first * nf * 32u + (uint32_t)(lane & 31)];
     unsigned long long *dbg = DBG ? cx.dbg : nullptr;
     const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
     unsigned long long n_slots = 0;   // PC_CENTER_DEBUG / pc_center_replay_steps: replay steps of this wave
@@ -2703,15 +2430,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DBG ? 7 : 8,
     __shared__ double s_valh[256];
     if (!(PC_CENTER_SKIP & 8)) for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
     __builtin_amdgcn_wave_barrier();
-    if (!GENERAL && PC_CENTER_HEAVY_RING != PC_CENTER2_RING && bidx < n_heavy) {   // (the short-read instantiation: with the indirect-entry path unrolled into both rings the other one spills)
+    if (MULTI) {
+        // several files: the entry's descriptors one after the other into the same sums (file-major, genome_array.py:800-809)
+        for (uint32_t c = 0; c < count; ++c) {
+            double acc = 0.0;
+            for (uint32_t f = 0; f < nf; ++f) {
+                uint32_t dn = 0u;
+                if (f + 1u < nf) dn = sw[((size_t)(first + c) * nf + f + 1u) * 32u + (uint32_t)(lane & 31)];
+                else if (c + 1u < count) dn = sw[(size_t)(first + c + 1u) * nf * 32u + (uint32_t)(lane & 31)];
+                center_slot<DBG, GENERAL, PC_CENTER2_RING, true>(cx, d, -1, lane, s_valh, n_slots, acc, (int)f, f + 1u == nf);
+                d = dn;
+            }
+        }
+    } else if (!GENERAL && PC_CENTER_HEAVY_RING != PC_CENTER2_RING && bidx < n_heavy) {   // (the short-read instantiation: with the indirect-entry path unrolled into both rings the other one spills)
         // a heavy entry: PC_CENTER_HEAVY_RING batches in flight (four bound a 32 k-step replay by the memory round trip --
         // 64 steps per ~3 600 cycles -- not by the steps)
-        center_slot<DBG, GENERAL, PC_CENTER_HEAVY_RING>(cx, d, -1, lane, s_valh, n_slots);
+        double acc = 0.0;
+        center_slot<DBG, GENERAL, PC_CENTER_HEAVY_RING>(cx, d, -1, lane, s_valh, n_slots, acc);
     } else {
         for (uint32_t c = 0; c < count; ++c) {
             uint32_t dn = 0u;
             if (c + 1u < count) dn = sw[(size_t)(first + c + 1u) * 32u + (uint32_t)(lane & 31)];   // the next descriptor, in flight while this chunk replays
-            center_slot<DBG, GENERAL, PC_CENTER2_RING>(cx, d, -1, lane, s_valh, n_slots);
+            double acc = 0.0;
+            center_slot<DBG, GENERAL, PC_CENTER2_RING>(cx, d, -1, lane, s_valh, n_slots, acc);
             d = dn;
         }
     }
@@ -2764,7 +2505,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const uint32_t dh = sw[(size_t)h * 32u + (uint32_t)(lane_h & 31)];
             uint32_t got = 0xffffffffu;
             if (n_heavy > gridDim.x) { if (lane_h == 0) got = atomicAdd(&cursors[kCursorStride * 32u], 1u); }   // (uniform condition; in flight while this one replays)
-            center_slot<false, GENERAL, PC_CENTER_HEAVY_RING>(*(const Center2Ctx *)cxk, dh, -1, lane_h, s_valh, n_slots);
+            double acc_h = 0.0;
+            center_slot<false, GENERAL, PC_CENTER_HEAVY_RING>(*(const Center2Ctx *)cxk, dh, -1, lane_h, s_valh, n_slots, acc_h);
             h = n_heavy > gridDim.x ? (uint32_t)__builtin_amdgcn_readfirstlane((int)got) : 0xffffffffu;
         }
         if (PC_CENTER_HEAVY_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -2775,56 +2517,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // XCD was measured first: 284 k claims a launch on eight addresses is 55 atomics per microsecond and address, two
     // thirds of what one address takes at all -- the claims queued up and the kernel ran at 1.13 ms against 0.85.)
     constexpr uint32_t kParts = 32u;
+    // ... and a claim is PC_CENTER_CLAIM consecutive entries: the atomic's return is waited for in order with the entry
+    // loads behind it (vmcnt counts in order), so a claim in flight while an entry replays stalls that replay's own
+    // loads behind a contended atomic -- one claim per entry ran at 0.97 - 1.13 ms against 0.85 for one wave per entry.
+    // One blocking claim per eight entries costs a per cent.
+    constexpr uint32_t K = PC_CENTER_CLAIM;
     const uint32_t n8 = (n_light + kParts - 1u) / kParts;              // entries per part
-    auto eighth_len = [&](uint32_t xx) { const uint32_t lo8 = xx * n8; return lo8 < n_light ? (lo8 + n8 < n_light ? n8 : n_light - lo8) : 0u; };
+    auto part_len = [&](uint32_t xx) { const uint32_t lo8 = xx * n8; return lo8 < n_light ? (lo8 + n8 < n_light ? n8 : n_light - lo8) : 0u; };
     uint32_t x = (blockIdx.x & 7u) * 4u + ((blockIdx.x >> 3) & 3u);   // the part this wave claims from (until that is exhausted)
     uint32_t spent = 0u;                // parts seen exhausted (bit x)
-    // a claim: what the atomic returned (lane 0), made on part `on`
-    auto issue = [&](uint32_t on) { uint32_t r = 0u; if (lane == 0) r = atomicAdd(&cursors[kCursorStride * on], 1u); return r; };
-    // -> the claimed entry's index in the slot table, or 0xffffffff: nothing left anywhere
-    auto resolve = [&](uint32_t raw, uint32_t on) -> uint32_t {
-        uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw);
+    // -> entries [cur, end) of the slot table from a claim that returned `idx` on part `on`; false: nothing left anywhere
+    uint32_t cur = 0u, end = 0u;
+    auto take = [&](uint32_t idx, uint32_t on) -> bool {
         while (true) {
-            if (idx < eighth_len(on)) return n_heavy + on * n8 + idx;
+            const uint32_t len = part_len(on);
+            if (idx < len) { cur = n_heavy + on * n8 + idx; end = cur + (len - idx < K ? len - idx : K); return true; }
             spent |= 1u << on;
-            if (spent == 0xffffffffu) return 0xffffffffu;
-            while ((spent >> x) & 1u) x = (x + 1u) & (kParts - 1u);      // (a claim made before x moved on is retried where x is now; the next part is this XCD's own until its eighth is done)
+            if (spent == 0xffffffffu) return false;
+            while ((spent >> x) & 1u) x = (x + 1u) & (kParts - 1u);      // (the next part is this XCD's own until its eighth is done)
             on = x;
-            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue(on));
+            uint32_t r = 0u;
+            if (lane == 0) r = atomicAdd(&cursors[kCursorStride * on], K);
+            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
         }
     };
-    // pipeline: entry e0 replays from its descriptor d0 (a register that is free again once the replay has taken its fields
-    // out), the NEXT entry's descriptor is in flight in lanes 0-31 of `pre`, and the claim after that in lane 32 of the
-    // same register (both are waited for only after the replay).
-    // A wave's first claim needs no atomic: entry number (b >> 5) of its part (k_center_vals starts the cursors behind those).
-    const uint32_t none = 0xffffffffu;
-    uint32_t e0 = resolve(blockIdx.x >> 5, x);
-    uint32_t d0 = e0 != none ? sw[(size_t)e0 * 32u + (uint32_t)(lane & 31)] : 0u;
-    uint32_t e1 = none;
-    if (e0 != none) { const uint32_t on1 = x; e1 = resolve(issue(on1), on1); }
-    uint32_t pre = (e1 != none && lane < 32) ? sw[(size_t)e1 * 32u + (uint32_t)lane] : 0u;
-    while (e0 != none) {
-        const uint32_t on2 = x;
-#ifdef PC_CENTER_P_SPLIT
-        uint32_t r2 = 0u;
-        if (e1 != none && lane == 32) r2 = atomicAdd(&cursors[kCursorStride * on2], 1u);
-#else
-        if (e1 != none && lane == 32) pre = atomicAdd(&cursors[kCursorStride * on2], 1u);
-#endif
-        // (likewise what depends on the lane alone -- permute indices, the lane's place in a descriptor -- is worked out
-        // again per entry, a dozen instructions, instead of living in vector registers across the loop: the kernel has 64)
-        int lane_i = lane;
-        asm volatile("" : "+s"(cxk), "+v"(lane_i));
-        center_slot<false, GENERAL, PC_CENTER2_RING>(*(const Center2Ctx *)cxk, d0, 0, lane_i, s_valh, n_slots);
-#ifdef PC_CENTER_P_SPLIT
-        const uint32_t e2 = e1 != none ? resolve(lane_u32(r2, 32), on2) : none;
-#else
-        const uint32_t e2 = e1 != none ? resolve(lane_u32(pre, 32), on2) : none;
-#endif
-        e0 = e1; d0 = pre;
-        e1 = e2;
-        asm volatile("" : "+v"(lane_i));
-        pre = (e2 != none && lane_i < 32) ? sw[(size_t)e2 * 32u + (uint32_t)lane_i] : 0u;
+    // A wave's first claim needs no atomic: claim number (b >> 5) of its part (k_center_vals starts the cursors behind those).
+    bool more = take((blockIdx.x >> 5) * K, x);
+    while (more) {
+        uint32_t d0 = sw[(size_t)cur * 32u + (uint32_t)(lane & 31)];
+        while (cur < end) {
+            // (what depends on the lane alone -- permute indices, the lane's place in a descriptor -- is worked out again per
+            // entry, a dozen instructions, instead of living in vector registers across the loop: the kernel has 64)
+            int lane_i = lane;
+            asm volatile("" : "+s"(cxk), "+v"(lane_i));
+            uint32_t dn = 0u;
+            if (cur + 1u < end) dn = sw[(size_t)(cur + 1u) * 32u + (uint32_t)(lane_i & 31)];   // the next descriptor, in flight while this entry replays
+            double acc_l = 0.0;
+            center_slot<false, GENERAL, PC_CENTER2_RING>(*(const Center2Ctx *)cxk, d0, -1, lane_i, s_valh, n_slots, acc_l);
+            d0 = dn;
+            ++cur;
+        }
+        uint32_t r = 0u;
+        if (lane == 0) r = atomicAdd(&cursors[kCursorStride * x], K);
+        more = take((uint32_t)__builtin_amdgcn_readfirstlane((int)r), x);
     }
 }
 

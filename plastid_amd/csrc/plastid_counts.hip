@@ -558,7 +558,6 @@ struct Knobs {
     int center_lds = 0;        // PC_CENTER_LDS: bytes of (unused) LDS per k_center workgroup -- an occupancy throttle for experiments
     int center_mode = 2;       // PC_CENTER_MODE: 0 round 5's k_center2 (one wave per dispatch entry); 2 k_center2p (persistent waves: heavy entries first, then light entries claimed from 32 cursors)
     int center_pwaves = 8;     // PC_CENTER_PWAVES: persistent waves per SIMD (the kernel is compiled for eight)
-    int center_legacy = 0;     // PC_CENTER_LEGACY: one-file plans through round 4's k_center too (A/B against k_center2)
     int center_per_wave = 0;   // (reserved)
     int center_debug = 0;      // PC_CENTER_DEBUG: wall-clock span of every dispatched wave of k_center, printed after the launch (synchronises)
     void load() {
@@ -580,7 +579,6 @@ struct Knobs {
         if (const char *env = getenv("PC_CENTER_T2")) center_t2 = std::max(1, atoi(env));
         if (const char *env = getenv("PC_CENTER_FLOOR")) center_floor = std::max(64, atoi(env));
         center_debug = getenv("PC_CENTER_DEBUG") ? 1 : 0;
-        center_legacy = getenv("PC_CENTER_LEGACY") ? atoi(getenv("PC_CENTER_LEGACY")) : 0;
         center_mode = getenv("PC_CENTER_MODE") ? atoi(getenv("PC_CENTER_MODE")) : 2;
         center_pwaves = getenv("PC_CENTER_PWAVES") ? std::max(1, std::min(8, atoi(getenv("PC_CENTER_PWAVES")))) : 8;
         if (const char *env = getenv("PC_CENTER_LDS")) center_lds = std::max(0, atoi(env));
@@ -721,6 +719,7 @@ struct pc_plan {
     uint64_t center_generation = 0;
     int center_W = -1;
     bool center_slots = false;             // the dispatch list has been resolved into descriptors (d_cslots)
+    int center_nfiles = 0;                 // ... for this many alignment files (one descriptor per entry and file)
     DevBuf<uint32_t> d_ccursors; // cursors of the persistent center kernel (reset by k_center_vals at every count)
     uint32_t *h_center_counts = nullptr;   // page-locked [2]: heavy, light entries of the list (sizes the grids of later counts)
     hipEvent_t ev_center_counts = nullptr;
@@ -2977,8 +2976,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (rc == PC_OK) rc = e->d_cvalh.reserve(256);
             // one alignment file (every BASELINE config): descriptors per dispatch entry, several entries per wave (k_center2);
             // several files keep round 4's kernel, whose waves walk the files of a chunk one after the other
-            const bool slots_on = nfiles == 1 && !e->knobs.center_legacy;
-            if (rc == PC_OK && slots_on) rc = p->d_cslots.reserve((size_t)(2 * nchunks));   // (heavy entries < chunks, light entries <= chunks)
+            const bool slots_on = true;   // (round 6: descriptors for plans over several files too -- one per entry and file)
+            if (rc == PC_OK) rc = p->d_cslots.reserve((size_t)(2 * nchunks) * (size_t)nfiles);   // (heavy entries < chunks, light entries <= chunks)
             if (rc != PC_OK) return rc;
             // the persistent form's grid: what the chip holds of its one-wave workgroups
             int n_cu = 256;
@@ -2989,7 +2988,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             grid_p = std::max(grid_p, 32u);
             // (the cursors start behind the first entry of each of the grid_p waves: the very grid k_center2p is launched with)
             hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(256), 0, st, mp, e->d_invh.p, e->d_cvalh.p, p->d_ccursors.p, grid_p);
-            if (p->center_generation != e->work_generation || p->center_W != W || p->center_slots != slots_on) {
+            if (p->center_generation != e->work_generation || p->center_W != W || p->center_slots != slots_on || p->center_nfiles != nfiles) {
+                p->center_nfiles = nfiles;
                 HIP_TRY(hipMemsetAsync(p->d_ccounts.p, 0, 8 * sizeof(uint32_t), st));
                 unsigned long long *total = (unsigned long long *)(p->d_ccounts.p + 2);
                 const unsigned wgs = (unsigned)((nchunks + kRangesWG - 1) / kRangesWG);
@@ -2999,9 +2999,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 const int ck1 = e->knobs.center_t1, ck2 = e->knobs.center_t2;
                 hipLaunchKernelGGL(k_center_order, dim3(wgs), dim3(kRangesWG), 0, st, p->d_ccand.p, nchunks, total, e->knobs.center_floor,
                                    (int64_t)2048, ck1, ck2, p->d_corder.p, p->d_ccounts.p);
-                if (slots_on)
-                    hipLaunchKernelGGL(k_center_slots, dim3((unsigned)((2 * nchunks + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks,
-                                       e->d_files.p, W, p->d_corder.p, p->d_ccounts.p, p->d_cranges.p, p->d_crec.p, p->d_crows.p, p->d_opieces.p,
+                hipLaunchKernelGGL(k_center_slots, dim3((unsigned)((2 * nchunks + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_cchunks.p, nchunks,
+                                       e->d_files.p, nfiles, W, p->d_corder.p, p->d_ccounts.p, p->d_cranges.p, p->d_crec.p, p->d_crows.p, p->d_opieces.p,
                                        p->d_cslots.p, (unsigned long long *)(p->d_ccounts.p + 4));
                 p->center_slots = slots_on;
                 p->center_generation = e->work_generation;
@@ -3019,10 +3018,6 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 p->center_counts[1] = p->h_center_counts[1];
                 p->center_counts_known = true;
             }
-            // grid: one wave per entry of the list -- their exact number once a count of the plan has shown it, else twice the
-            // chunks, which bounds it (fewer than an eighth of the chunks are cut, into at most eight); + 8: the light entries
-            // are dealt to the XCDs in eighths, rounded up
-            uint64_t cgrid = (p->center_counts_known ? (uint64_t)p->center_counts[0] + p->center_counts[1] : 2 * (uint64_t)nchunks) + 8;
             // PC_CENTER_DEBUG: how long every dispatched wave ran (wall clock ticks), printed after the launch
             DevBuf<unsigned long long> d_dbg;
             const bool dbg_on = e->knobs.center_debug != 0 || e->want_center_steps;
@@ -3033,18 +3028,11 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 HIP_TRY(hipMemsetAsync(d_dbg.p, 0, 3 * dbg_slots * 8, st));
             }
             unsigned long long *dbg = dbg_on ? d_dbg.p : nullptr;
-            CenterCtx cx;
-            cx.chunks = p->d_cchunks.p; cx.nchunks = nchunks; cx.files = e->d_files.p; cx.nfiles = nfiles; cx.mp = mp; cx.W = W;
-            cx.inv = e->d_inv.p; cx.invh = e->d_invh.p; cx.cvalh = e->d_cvalh.p; cx.order = p->d_corder.p; cx.counters = p->d_ccounts.p;
-            cx.ranges = p->d_cranges.p; cx.rec_ranges = p->d_crec.p; cx.row_ranges = p->d_crows.p; cx.opieces = p->d_opieces.p;
-            cx.out = (double *)p->d_out.p; cx.norm_sum = e->norm_sum; cx.norm_on = e->norm_on ? 1 : 0;
-            cx.dbg = dbg;
             // (files with reads beyond a stream entry's 8-bit fields, or a stream too long for 32-bit byte offsets, take the
             // instantiation that tests every batch for them)
             bool general = false;
             for (auto *f : e->files) general |= f->len_max > 255 || f->n + f->nrun >= ((int64_t)1 << 28);
-            const dim3 cg((unsigned)((cgrid * 64 + kCenterWG - 1) / kCenterWG));
-            if (slots_on) {
+            {
                 // descriptors: heavy entries one wave each, PC_CENTER_PER_WAVE light entries per wave (an eighth of the list per XCD)
                 Center2Ctx c2;
                 StagedFile *sf0 = e->files[0];
@@ -3054,7 +3042,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                     c2.ent[k] = sf0->cs_n[k] >= 0 ? sf0->cs_ent[k].p : nullptr;
                     if (sf0->len_max > 255) c2.indirect |= 1u << k;
                 }
-                c2.files = e->d_files.p; c2.file0 = sf0->view(); c2.mp = mp; c2.W = W; c2.inv = e->d_inv.p; c2.invh = e->d_invh.p; c2.cvalh = e->d_cvalh.p;
+                c2.files = e->d_files.p; c2.nfiles = nfiles; c2.file0 = sf0->view(); c2.mp = mp; c2.W = W; c2.inv = e->d_inv.p; c2.invh = e->d_invh.p; c2.cvalh = e->d_cvalh.p;
                 c2.counters = p->d_ccounts.p;
                 c2.known = p->center_counts_known ? 1u : 0u; c2.n_heavy = p->center_counts[0]; c2.n_light = p->center_counts[1];
                 c2.opieces = p->d_opieces.p; c2.out = (double *)p->d_out.p; c2.norm_sum = e->norm_sum; c2.norm_on = e->norm_on ? 1 : 0;
@@ -3070,24 +3058,20 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 // the diagnostic launch and PC_CENTER_MODE=0 run one wave per entry (k_center2).
                 // (files with reads beyond a stream entry's 8-bit fields -- `general`: every batch is tested for indirect entries --
                 // keep to round 5's kernel: with that path unrolled into both rings the persistent form does not fit its registers)
-                const int cmode = (p->center_counts_known && !dbg_on && !general) ? e->knobs.center_mode : 0;
+                const int cmode = (p->center_counts_known && !dbg_on && !general && nfiles == 1) ? e->knobs.center_mode : 0;
+                const bool multi = nfiles > 1;   // one descriptor per entry and file, replayed into the same sums in file order
                 if (cmode == 2) {
                     if (p->center_counts[0] + p->center_counts[1] > 0u) {
                         hipLaunchKernelGGL((k_center2p<false>), dim3(grid_p), dim3(64), 0, st, c2);
                     }
-                } else if (dbg_on) {
-                    if (general) hipLaunchKernelGGL((k_center2<true, true>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
-                    else hipLaunchKernelGGL((k_center2<true, false>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
                 } else {
-                    if (general) hipLaunchKernelGGL((k_center2<false, true>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
-                    else hipLaunchKernelGGL((k_center2<false, false>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2);
+#define PC_LAUNCH_CENTER2(D, G, M) hipLaunchKernelGGL((k_center2<D, G, M>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2)
+#define PC_LAUNCH_CENTER2_M(D, G) do { if (multi) PC_LAUNCH_CENTER2(D, G, true); else PC_LAUNCH_CENTER2(D, G, false); } while (0)
+                    if (dbg_on) { if (general) PC_LAUNCH_CENTER2_M(true, true); else PC_LAUNCH_CENTER2_M(true, false); }
+                    else { if (general) PC_LAUNCH_CENTER2_M(false, true); else PC_LAUNCH_CENTER2_M(false, false); }
+#undef PC_LAUNCH_CENTER2_M
+#undef PC_LAUNCH_CENTER2
                 }
-            } else if (dbg_on) {
-                if (general) hipLaunchKernelGGL((k_center<true, true>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
-                else hipLaunchKernelGGL((k_center<true, false>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
-            } else {
-                if (general) hipLaunchKernelGGL((k_center<false, true>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
-                else hipLaunchKernelGGL((k_center<false, false>), cg, dim3(kCenterWG), (size_t)e->knobs.center_lds, st, cx);
             }
             if (dbg_on) {   // diagnostic launch: replay steps and dispatched waves, summed on the host; PC_CENTER_DEBUG prints them
                 std::vector<unsigned long long> h(2 * dbg_slots), h_slots(dbg_slots);
