@@ -411,7 +411,7 @@ def run_workload(name, args, ctx, headline):
     # ---------------------------------------------------------------- the same records dealt alternately into TWO files
     # (BAMGenomeArray(*bamfiles), genome_array.py:657-660, 800-809: several files count as one; joint windows)
     two_files = None
-    if headline and world == 1 and not args.no_two_files:
+    if (headline or center) and world == 1 and not args.no_two_files:   # (the center rule too: its several-files form is the same kernel, one descriptor per entry and file)
         from plastid_amd.packing import PackedAlignments
         multi = np.nonzero(my_reads.nblk >= 2)[0]
         rec_of_run = np.repeat(multi, my_reads.nblk[multi])
@@ -902,6 +902,8 @@ def brief_config(r):
             b[k] = sig(roof[k], 3)
     if r.get("size_filter_variant", {}).get("ms_per_step"):
         b["size_filter_ms"] = sig(r["size_filter_variant"]["ms_per_step"])
+    if r.get("two_files"):
+        b["two_files_ratio"] = sig(r["two_files"]["ratio_to_one_file"], 3)
     if cpu:
         b["cpu_1core"] = sig(cpu["value"])
         if cpu.get("all_cores"):

@@ -147,7 +147,7 @@ def read_bam_gpu(path, engine, timing=None, regions=None):
     an aligner's record -- come back.  `engine`: a :class:`plastid_amd.engine.Engine` (its device and stream are used).
     `timing`: optional dict that receives the phase times in ms and the member / byte counts.
     `regions`: as for :func:`read_bam` -- only the alignments that overlap one of them, through the BAI index: only the
-    BGZF members the index points to are uploaded and inflated (``pc_bam_open_span``); ``mapped`` is then the index's
+    BGZF members of ONE span of the file -- from the first to the last index chunk of the regions, whatever lies between two far-apart regions included -- are uploaded and inflated (``pc_bam_open_span``; the overlap test then drops what no region wants: regions that sit together, like one rank's genome range, read little else); ``mapped`` is then the index's
     whole-file count, as pysam's."""
     import time
     from . import _lib as clib

@@ -1846,15 +1846,9 @@ __global__ __launch_bounds__(kWG) void k_cs_scatter(const uint2 *__restrict__ re
 
 // half the value of a read by aligned length, for the lengths a stream entry can carry: 0.5 / (L - 2 nibble), or 0.0
 // where the read is not counted (size filter, nothing left by the nibble: adding +0.0 never changes a sum)
-#ifndef PC_CENTER_CLAIM
-#define PC_CENTER_CLAIM 8         // consecutive light entries per claim of a persistent wave (k_center2p)
-#endif
-// (and the cursors of the persistent center kernel, k_center2p: they start behind the first entry of every wave -- grid_p
-// waves, grid_p / 8 per eighth)
-__global__ void k_center_vals(MapParams mp, const double *__restrict__ invh, double *cvalh, uint32_t *cursors, uint32_t grid_p) {
+__global__ void k_center_vals(MapParams mp, const double *__restrict__ invh, double *cvalh) {
     const int L = (int)threadIdx.x, m = L - 2 * mp.param;
     if (L < 256) cvalh[L] = (m > 0 && size_ok(mp, L)) ? invh[m] : 0.0;
-    if (cursors && L < 33) cursors[16 * L] = L < 32 ? ((grid_p + 31u) >> 5) * PC_CENTER_CLAIM : grid_p;   // ([32]: the heavy entries' cursor)
 }
 
 // Dispatch list of the center kernel.  A chunk's replay is sequential in the reads that overlap
@@ -2196,7 +2190,6 @@ struct Center2Ctx {
     int norm_on;
     unsigned long long *dbg;
     uint32_t dbg_cap;
-    uint32_t *cursors;         // persistent form (k_center2p): [16 p] = next light entry of part p (32 parts, four per XCD), [16 * 32] = next heavy entry (one cursor per 64-byte line)
 };
 
 // One (sub-)chunk from its descriptor `d` (lane l < 32 holds dword l; the upper half of the wave holds a copy).
@@ -2460,106 +2453,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MULTI ? 6 : 
         const size_t at = first < n_heavy ? (size_t)first : (size_t)cx.dbg_cap - 1u - (size_t)(first - n_heavy);
         dbg[2 * at] = wall_clock64() - t_begin; dbg[2 * at + 1] = t_begin;
         dbg[2 * (size_t)cx.dbg_cap + at] = n_slots;
-    }
-}
-
-// ---------------------------------------------------------------- k_center2p (round 6)
-// Where round 5's k_center2 stood (C3, PC_CENTER_DEBUG): the launch ends with its HEAVY entries -- 32 k dependent steps
-// at ~56 cycles each although the wave runs at raised priority -- and the bulk (one wave per light entry, ~300 steps)
-// keeps ~6 100 of 8 192 wave slots resident, each wave a third of its life in the two dependent trips at its head.
-//   * 56 cycles per step is partly the PREFETCH DEPTH: four batches of sixteen entries per row in flight, one memory
-//     round trip per 64 steps.  Heavy entries replay with PC_CENTER_HEAVY_RING (twelve) batches in flight, in k_center2
-//     and here: 0.70 -> 0.61 ms for the 32 k-step entries (a lone wave's dependent step chain is 17 cycles: 0.30 ms).
-//   * k_center2p: a PERSISTENT grid -- as many one-wave workgroups as the chip holds, launched once.  Wave b first serves
-//     heavy entry b (they all start at t = 0, as before), then claims light entries one at a time from the cursor of its
-//     part of the list and, when that is exhausted, from the others'.  The next entry's descriptor and the claim after
-//     it are in flight while an entry replays, so a chunk starts with ONE dependent trip (its entries) instead of a wave
-//     launch, an LDS table fill and two trips.
-//     (Also measured: the heavy entries in a kernel of their own on a second stream, launched first -- the device placed
-//     the light entries' persistent grid first all the same, and the heavy entries ran behind it: 1.53 ms.)
-constexpr uint32_t kCursorStride = 16;   // dwords between cursors: one 64-byte line each
-template <bool GENERAL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_center2p(Center2Ctx cx) {
-    const uint32_t n_heavy = cx.n_heavy, n_light = cx.n_light;   // (the host knows the list's counts: the first count of a plan runs k_center2)
-    const int lane = threadIdx.x & 63;
-    const uint32_t PC_GLOBAL *sw = (const uint32_t PC_GLOBAL *)cx.slots;
-    uint32_t *cursors = cx.cursors;
-    __shared__ double s_valh[256];
-    for (int i = lane; i < 256; i += 64) s_valh[i] = ((const double PC_GLOBAL *)cx.cvalh)[i];
-    __builtin_amdgcn_wave_barrier();
-    unsigned long long n_slots = 0;
-    // ---- heavy entries first: wave b serves heavy entry b (they all start at t = 0, as in k_center2), then whatever the
-    // heavy cursor hands out (a list with more heavy entries than the grid has waves), with PC_CENTER_HEAVY_RING batches
-    // in flight and at raised priority
-    // (the kernel's arguments are read from the argument segment again for every entry, and what depends on the lane alone
-    // -- permute indices, the lane's place in a descriptor -- is worked out again per entry: hoisted out of the loops below
-    // they would be held in registers across them -- a wave of this kernel has 80 scalar and 64 vector ones -- and spill)
-    typedef const Center2Ctx __attribute__((address_space(4))) CtxK;
-    CtxK *cxk = (CtxK *)__builtin_amdgcn_kernarg_segment_ptr();
-    if (blockIdx.x < n_heavy) {
-        if (PC_CENTER_HEAVY_PRIO) __builtin_amdgcn_s_setprio(PC_CENTER_HEAVY_PRIO);
-        uint32_t h = blockIdx.x;
-        while (h < n_heavy) {
-            int lane_h = lane;
-            asm volatile("" : "+s"(cxk), "+v"(lane_h));
-            const uint32_t dh = sw[(size_t)h * 32u + (uint32_t)(lane_h & 31)];
-            uint32_t got = 0xffffffffu;
-            if (n_heavy > gridDim.x) { if (lane_h == 0) got = atomicAdd(&cursors[kCursorStride * 32u], 1u); }   // (uniform condition; in flight while this one replays)
-            double acc_h = 0.0;
-            center_slot<false, GENERAL, PC_CENTER_HEAVY_RING>(*(const Center2Ctx *)cxk, dh, -1, lane_h, s_valh, n_slots, acc_h);
-            h = n_heavy > gridDim.x ? (uint32_t)__builtin_amdgcn_readfirstlane((int)got) : 0xffffffffu;
-        }
-        if (PC_CENTER_HEAVY_PRIO) __builtin_amdgcn_s_setprio(0);
-    }
-    if (n_light == 0u) return;
-    // The light list in kParts contiguous parts, a cursor each: XCD x (workgroup b runs on XCD b mod 8) owns parts
-    // 4x .. 4x + 3 -- its eighth of the list -- and a wave claims from part 4 (b mod 8) + (b / 8) mod 4.  (One cursor per
-    // XCD was measured first: 284 k claims a launch on eight addresses is 55 atomics per microsecond and address, two
-    // thirds of what one address takes at all -- the claims queued up and the kernel ran at 1.13 ms against 0.85.)
-    constexpr uint32_t kParts = 32u;
-    // ... and a claim is PC_CENTER_CLAIM consecutive entries: the atomic's return is waited for in order with the entry
-    // loads behind it (vmcnt counts in order), so a claim in flight while an entry replays stalls that replay's own
-    // loads behind a contended atomic -- one claim per entry ran at 0.97 - 1.13 ms against 0.85 for one wave per entry.
-    // One blocking claim per eight entries costs a per cent.
-    constexpr uint32_t K = PC_CENTER_CLAIM;
-    const uint32_t n8 = (n_light + kParts - 1u) / kParts;              // entries per part
-    auto part_len = [&](uint32_t xx) { const uint32_t lo8 = xx * n8; return lo8 < n_light ? (lo8 + n8 < n_light ? n8 : n_light - lo8) : 0u; };
-    uint32_t x = (blockIdx.x & 7u) * 4u + ((blockIdx.x >> 3) & 3u);   // the part this wave claims from (until that is exhausted)
-    uint32_t spent = 0u;                // parts seen exhausted (bit x)
-    // -> entries [cur, end) of the slot table from a claim that returned `idx` on part `on`; false: nothing left anywhere
-    uint32_t cur = 0u, end = 0u;
-    auto take = [&](uint32_t idx, uint32_t on) -> bool {
-        while (true) {
-            const uint32_t len = part_len(on);
-            if (idx < len) { cur = n_heavy + on * n8 + idx; end = cur + (len - idx < K ? len - idx : K); return true; }
-            spent |= 1u << on;
-            if (spent == 0xffffffffu) return false;
-            while ((spent >> x) & 1u) x = (x + 1u) & (kParts - 1u);      // (the next part is this XCD's own until its eighth is done)
-            on = x;
-            uint32_t r = 0u;
-            if (lane == 0) r = atomicAdd(&cursors[kCursorStride * on], K);
-            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-        }
-    };
-    // A wave's first claim needs no atomic: claim number (b >> 5) of its part (k_center_vals starts the cursors behind those).
-    bool more = take((blockIdx.x >> 5) * K, x);
-    while (more) {
-        uint32_t d0 = sw[(size_t)cur * 32u + (uint32_t)(lane & 31)];
-        while (cur < end) {
-            // (what depends on the lane alone -- permute indices, the lane's place in a descriptor -- is worked out again per
-            // entry, a dozen instructions, instead of living in vector registers across the loop: the kernel has 64)
-            int lane_i = lane;
-            asm volatile("" : "+s"(cxk), "+v"(lane_i));
-            uint32_t dn = 0u;
-            if (cur + 1u < end) dn = sw[(size_t)(cur + 1u) * 32u + (uint32_t)(lane_i & 31)];   // the next descriptor, in flight while this entry replays
-            double acc_l = 0.0;
-            center_slot<false, GENERAL, PC_CENTER2_RING>(*(const Center2Ctx *)cxk, d0, -1, lane_i, s_valh, n_slots, acc_l);
-            d0 = dn;
-            ++cur;
-        }
-        uint32_t r = 0u;
-        if (lane == 0) r = atomicAdd(&cursors[kCursorStride * x], K);
-        more = take((uint32_t)__builtin_amdgcn_readfirstlane((int)r), x);
     }
 }
 

@@ -556,8 +556,6 @@ struct Knobs {
     int center_t2 = 4;         //   count are cut into 4 (8) sub-chunks
     int64_t center_floor = 32768; // PC_CENTER_FLOOR: stream entries below which a chunk is never cut (a wave alone replays ~50 k per ms)
     int center_lds = 0;        // PC_CENTER_LDS: bytes of (unused) LDS per k_center workgroup -- an occupancy throttle for experiments
-    int center_mode = 2;       // PC_CENTER_MODE: 0 round 5's k_center2 (one wave per dispatch entry); 2 k_center2p (persistent waves: heavy entries first, then light entries claimed from 32 cursors)
-    int center_pwaves = 8;     // PC_CENTER_PWAVES: persistent waves per SIMD (the kernel is compiled for eight)
     int center_per_wave = 0;   // (reserved)
     int center_debug = 0;      // PC_CENTER_DEBUG: wall-clock span of every dispatched wave of k_center, printed after the launch (synchronises)
     void load() {
@@ -579,8 +577,6 @@ struct Knobs {
         if (const char *env = getenv("PC_CENTER_T2")) center_t2 = std::max(1, atoi(env));
         if (const char *env = getenv("PC_CENTER_FLOOR")) center_floor = std::max(64, atoi(env));
         center_debug = getenv("PC_CENTER_DEBUG") ? 1 : 0;
-        center_mode = getenv("PC_CENTER_MODE") ? atoi(getenv("PC_CENTER_MODE")) : 2;
-        center_pwaves = getenv("PC_CENTER_PWAVES") ? std::max(1, std::min(8, atoi(getenv("PC_CENTER_PWAVES")))) : 8;
         if (const char *env = getenv("PC_CENTER_LDS")) center_lds = std::max(0, atoi(env));
     }
 };
@@ -720,7 +716,6 @@ struct pc_plan {
     int center_W = -1;
     bool center_slots = false;             // the dispatch list has been resolved into descriptors (d_cslots)
     int center_nfiles = 0;                 // ... for this many alignment files (one descriptor per entry and file)
-    DevBuf<uint32_t> d_ccursors; // cursors of the persistent center kernel (reset by k_center_vals at every count)
     uint32_t *h_center_counts = nullptr;   // page-locked [2]: heavy, light entries of the list (sizes the grids of later counts)
     hipEvent_t ev_center_counts = nullptr;
     bool center_counts_known = false;
@@ -777,7 +772,7 @@ struct pc_plan {
         DevPool *pl = &eng->pool;
         d_tables.pool = pl; d_corder.pool = pl;
         d_ccand.pool = pl; d_rle_cnt.pool = pl; d_rle_base.pool = pl; d_rle_starts.pool = pl; d_rle_values.pool = pl;
-        d_cranges.pool = pl; d_crec.pool = pl; d_crows.pool = pl; d_ccounts.pool = pl; d_cslots.pool = pl; d_ccursors.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
+        d_cranges.pool = pl; d_crec.pool = pl; d_crows.pool = pl; d_ccounts.pool = pl; d_cslots.pool = pl; d_hist_own.pool = pl; d_out.pool = pl; d_tables2.pool = pl; d_tables3.pool = pl;
         d_work.pool = pl; d_work_small.pool = pl; d_chain.pool = pl; d_chain_small.pool = pl;
         d_inputs.pool = pl; d_gsegs_own.pool = pl;
     }
@@ -2972,22 +2967,13 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
             if (rc == PC_OK) rc = p->d_crec.reserve((size_t)nchunks * (size_t)nfiles);
             if (rc == PC_OK) rc = p->d_crows.reserve((size_t)nchunks * (size_t)nfiles * (size_t)(2 * kCenterRows));
             if (rc == PC_OK) rc = p->d_ccounts.reserve(8);
-            if (rc == PC_OK) rc = p->d_ccursors.reserve(16 * 33);
             if (rc == PC_OK) rc = e->d_cvalh.reserve(256);
             // one alignment file (every BASELINE config): descriptors per dispatch entry, several entries per wave (k_center2);
             // several files keep round 4's kernel, whose waves walk the files of a chunk one after the other
             const bool slots_on = true;   // (round 6: descriptors for plans over several files too -- one per entry and file)
             if (rc == PC_OK) rc = p->d_cslots.reserve((size_t)(2 * nchunks) * (size_t)nfiles);   // (heavy entries < chunks, light entries <= chunks)
             if (rc != PC_OK) return rc;
-            // the persistent form's grid: what the chip holds of its one-wave workgroups
-            int n_cu = 256;
-            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, e->device);
-            uint32_t grid_p = (uint32_t)std::max(8, n_cu * 4 * e->knobs.center_pwaves);
-            if (p->center_counts_known)   // (no more waves than entries of either kind)
-                grid_p = (uint32_t)std::min<uint64_t>(grid_p, ((uint64_t)std::max(p->center_counts[0], p->center_counts[1]) + 31) / 32 * 32);
-            grid_p = std::max(grid_p, 32u);
-            // (the cursors start behind the first entry of each of the grid_p waves: the very grid k_center2p is launched with)
-            hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(256), 0, st, mp, e->d_invh.p, e->d_cvalh.p, p->d_ccursors.p, grid_p);
+            hipLaunchKernelGGL(k_center_vals, dim3(1), dim3(256), 0, st, mp, e->d_invh.p, e->d_cvalh.p);
             if (p->center_generation != e->work_generation || p->center_W != W || p->center_slots != slots_on || p->center_nfiles != nfiles) {
                 p->center_nfiles = nfiles;
                 HIP_TRY(hipMemsetAsync(p->d_ccounts.p, 0, 8 * sizeof(uint32_t), st));
@@ -3053,18 +3039,8 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                     g2 = (uint64_t)p->center_counts[0] + 8 * ((n8 + PC_CENTER_PER_WAVE - 1) / PC_CENTER_PER_WAVE);
                 } else g2 = 2 * (uint64_t)nchunks + 8;
                 const dim3 cg2((unsigned)std::max<uint64_t>(g2, 1));
-                c2.cursors = p->d_ccursors.p;
-                // round 6: once the list's counts are known, the persistent grid (PC_CENTER_MODE=2).  The first count of a plan,
-                // the diagnostic launch and PC_CENTER_MODE=0 run one wave per entry (k_center2).
-                // (files with reads beyond a stream entry's 8-bit fields -- `general`: every batch is tested for indirect entries --
-                // keep to round 5's kernel: with that path unrolled into both rings the persistent form does not fit its registers)
-                const int cmode = (p->center_counts_known && !dbg_on && !general && nfiles == 1) ? e->knobs.center_mode : 0;
                 const bool multi = nfiles > 1;   // one descriptor per entry and file, replayed into the same sums in file order
-                if (cmode == 2) {
-                    if (p->center_counts[0] + p->center_counts[1] > 0u) {
-                        hipLaunchKernelGGL((k_center2p<false>), dim3(grid_p), dim3(64), 0, st, c2);
-                    }
-                } else {
+                {
 #define PC_LAUNCH_CENTER2(D, G, M) hipLaunchKernelGGL((k_center2<D, G, M>), cg2, dim3(64), (size_t)e->knobs.center_lds, st, c2)
 #define PC_LAUNCH_CENTER2_M(D, G) do { if (multi) PC_LAUNCH_CENTER2(D, G, true); else PC_LAUNCH_CENTER2(D, G, false); } while (0)
                     if (dbg_on) { if (general) PC_LAUNCH_CENTER2_M(true, true); else PC_LAUNCH_CENTER2_M(true, false); }

@@ -143,7 +143,7 @@ class Engine(object):
         counts exactly as after ``add_alignment_file(read_bam(path))``; callers that also want the reads themselves
         (``reads_out`` as objects, host-side filters) use :func:`plastid_amd.bam.read_bam_gpu` instead.
         `regions`: stage only the alignments that overlap one of them (``(chrom, start, end)`` or |GenomicSegments|),
-        through the file's BAI index -- only the BGZF members the index points to are uploaded and inflated
+        through the file's BAI index -- the BGZF members of ONE span of the file, from the first to the last index chunk of the regions (what lies between far-apart regions included; the overlap test drops it), are uploaded and inflated
         (``pc_add_alignment_bam_span``; what one rank of a multi-GPU job does with its genome range of a shared file);
         the return value is then the number of mapped reads among those staged."""
         import os

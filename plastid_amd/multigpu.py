@@ -206,7 +206,7 @@ class GenomePartition(object):
     def rank_regions(self, rank, references):
         """The genome range of `rank` -- its cut interval extended to the left by the halo -- as ``(chrom, start, end)``
         regions over `references` (the contig names): what the rank hands to a region read of ONE shared BAM file
-        (``Engine.add_bam(path, regions=...)`` / ``read_bam(path, regions=...)``: only the BGZF members the BAI index
+        (``Engine.add_bam(path, regions=...)`` / ``read_bam(path, regions=...)``: only the BGZF members of the span the BAI index
         points to are read) instead of every rank decoding the whole file.  A read is returned for a region it OVERLAPS,
         so the rank gets at least the records :meth:`record_ranges` names (every record that starts inside the range or
         within a halo before it) plus those that reach in from further left: more read-only duplication, same counts
