@@ -426,13 +426,23 @@ def run_workload(name, args, ctx, headline):
         for _ in range(2):
             plan.launch(out_dtype)
         eng.sync()
-        gate(exp, "two files")                       # two files count as their sum: the one-file expectation
+        if center:
+            # float64 sums in FILE-MAJOR read order (itertools.chain over the files' fetches, genome_array.py:800-809): not
+            # the one-file order -- the expectation is the oracle's on the two files, for a sample of chains of its own
+            prep2 = oracle.Prepared(concat_file_major(halves))
+            sel2 = segments_of_chains(tx, np.random.default_rng(11).permutation(tx.n)[:min(tx.n, 300)])
+            arr2, _ = oracle.count_segments(prep2, spec, p["tid"][sel2], p["start"][sel2], p["end"][sel2], p["strand"][sel2], threads=usable_cpus())
+            prep2.close()
+            gate(sparse_expected(arr2, p, sel2, rows), "two files")
+            del prep2, arr2
+        else:
+            gate(exp, "two files")                   # two files count as their sum: the one-file expectation
         t0 = time.perf_counter()
         for _ in range(steps):
             plan.launch(out_dtype)
         eng.sync()
         two_ms = (time.perf_counter() - t0) / steps * 1e3
-        two_files = {"what": "the same records dealt alternately into two files (joint windows), parity-gated against the same oracle sample",
+        two_files = {"what": "the same records dealt alternately into two files (point rules: joint windows, gated on the one-file oracle sample; center rule: one descriptor per entry and file, gated on the oracle's file-major sums of 300 chains)",
                      "ms_per_step": two_ms, "ratio_to_one_file": two_ms / (elapsed / steps * 1e3)}
         eng.set_alignments([my_reads])
         del halves
@@ -999,6 +1009,10 @@ def main():
                     help="records of the second e2e sample, written as an aligner writes them (~120 bytes per record; 0: skip)")
     args = ap.parse_args()
     t_start = time.perf_counter()
+    # this process creates one engine per config, tens of GB each, one after the other: the idle device blocks of a closed
+    # engine are kept for the next one (on some boxes a hipMalloc behind the hipFree of tens of GB takes seconds); the
+    # library keeps 4 GB per device by default
+    os.environ.setdefault("PC_POOL_RESERVOIR_GB", "96")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N`: spawn the N ranks (one per GPU) as a child torch.distributed.run and relay its

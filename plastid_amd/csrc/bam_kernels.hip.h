@@ -40,8 +40,7 @@ constexpr int kLitRoot = 9, kDistRoot = 6;  // first-level table bits (zlib's ch
 // table capacities: zlib's ENOUGH_LENS / ENOUGH_DISTS (inftrees.h: 286 symbols, root 9, 15 bits -> 852 entries; 30 symbols,
 // root 6 -> 592), first level included -- build_table sizes a second-level table by the longest code under its prefix,
 // as inflate_table does for a complete code, so no valid stream needs more.  (Round 6: 1024 / 640 before; with the
-// symbol chain compacted in place and 256 bytes of staged input a wave's LDS is 9.9 KiB instead of 13: sixteen waves
-// per CU instead of twelve.)
+// symbol chain compacted in place, 16-bit entries and 256 bytes of staged input a wave's LDS is 7.1 KiB instead of 13.)
 constexpr int kLitEntries = 852, kDistEntries = 592;
 #ifndef PC_BGZF_IN
 #define PC_BGZF_IN 256
@@ -63,18 +62,29 @@ struct Member {
 enum { kInfOk = 0, kInfBadBlockType = 1, kInfBadStored = 2, kInfBadCodeLengths = 3, kInfOverSubscribed = 4, kInfBadSymbol = 5,
        kInfBadDistance = 6, kInfOverrun = 7, kInfShort = 8, kInfInputOverrun = 9, kInfCrc = 10 };
 
-// ---- table entries (uint32):  bits 0-3 code bits to consume, 4-7 extra bits, 8-9 kind, 16-31 value
-//   kind 0: literal (value = byte) / distance base;  1: length base;  2: end of block;  3: pointer to a second-level
-//   table (value = its first entry, bits 4-7 = its index bits)
-__device__ __forceinline__ uint32_t mk_entry(uint32_t nbits, uint32_t extra, uint32_t kind, uint32_t value) {
-    return nbits | (extra << 4) | (kind << 8) | (value << 16);
+// ---- table entries (uint16, round 6: half the LDS of the uint32 ones -- the bases and extra-bit counts a uint32 entry
+// carried are arithmetic in the symbol, len_of / dist_of below):  bits 0-3 code bits to consume (0: no such code),
+// 4-5 kind, 6-15 value
+//   kind 0: literal (value = byte) / distance symbol / code-length symbol;  1: length symbol (value = symbol - 257);
+//   2: end of block (value 0) or a symbol that is never valid (value 1);  3: pointer to a second-level table
+//   (value = its first entry, bits 0-3 = its index bits)
+typedef uint16_t tab_t;
+__device__ __forceinline__ uint32_t mk_entry(uint32_t nbits, uint32_t kind, uint32_t value) { return nbits | (kind << 4) | (value << 6); }
+__device__ __forceinline__ uint32_t ent_bits(uint32_t e) { return e & 15u; }
+__device__ __forceinline__ uint32_t ent_kind(uint32_t e) { return (e >> 4) & 3u; }
+__device__ __forceinline__ uint32_t ent_value(uint32_t e) { return e >> 6; }
+// RFC 1951 3.2.5 in closed form: length symbol 257 + i -> {base, extra bits}; distance symbol s -> {base, extra bits}
+__device__ __forceinline__ void len_of(uint32_t i, uint32_t &base, uint32_t &extra) {
+    const uint32_t e = i < 8u ? 0u : (i >> 2) - 1u;
+    base = i == 28u ? 258u : (i < 8u ? 3u + i : 3u + ((4u + (i & 3u)) << e));
+    extra = i == 28u ? 0u : e;
+}
+__device__ __forceinline__ void dist_of(uint32_t sy, uint32_t &base, uint32_t &extra) {
+    const uint32_t e = sy < 4u ? 0u : (sy >> 1) - 1u;
+    base = sy < 4u ? 1u + sy : 1u + ((2u + (sy & 1u)) << e);
+    extra = e;
 }
 
-// length / distance bases and extra bits (RFC 1951 3.2.5)
-__device__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t c, int len) { return __brev(c) >> (32 - len); }
@@ -93,7 +103,7 @@ struct TableScratch {
 };
 
 template <int KIND>
-__device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table, int cap, TableScratch *ws, int lane) {
+__device__ int build_table(const uint8_t *lens, int n, int root, tab_t *table, int cap, TableScratch *ws, int lane) {
     // symbols per code length: lane L (1..15) counts the symbols of length L
     if (lane < 16) {
         int c = 0;
@@ -115,7 +125,7 @@ __device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table
     // dynamic block may declare one distance code of length zero; any lookup in the cleared table is a "bad symbol"
     if (maxlen != 0 && left > 0 && (KIND == 2 || maxlen != 1)) return kInfOverSubscribed;   // incomplete code: only a single one-bit code may be (zlib inftrees.c: `left > 0 && (type == CODES || max != 1)`)
     // clear the first level (an incomplete distance code leaves holes: they decode as "bad symbol")
-    for (int i = lane; i < (1 << root); i += 64) { table[i] = 0u; if (i < 512) ws->subbits[i] = 0; }
+    for (int i = lane; i < (1 << root); i += 64) { table[i] = (tab_t)0; if (i < 512) ws->subbits[i] = 0; }
     __syncthreads();
     if (nsym == 0) return kInfOk;
     // codes in symbol order within a length (lane 0, serial: a few hundred symbols per block); the longest code of
@@ -140,8 +150,8 @@ __device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table
             const int sb = ws->subbits[pre];
             if (!sb) continue;
             if (used + (1 << sb) > cap) return kInfBadCodeLengths;
-            if (lane == 0) table[pre] = mk_entry((uint32_t)root, (uint32_t)sb, 3u, (uint32_t)used);
-            for (int i = lane; i < (1 << sb); i += 64) table[used + i] = 0u;
+            if (lane == 0) table[pre] = (tab_t)mk_entry((uint32_t)sb, 3u, (uint32_t)used);
+            for (int i = lane; i < (1 << sb); i += 64) table[used + i] = (tab_t)0;
             used += 1 << sb;
         }
         __syncthreads();
@@ -152,25 +162,25 @@ __device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table
         const uint32_t rc = bitrev((uint32_t)ws->code[s], len);
         uint32_t e;
         if (KIND == 0) {
-            if (s < 256) e = mk_entry(0u, 0u, 0u, (uint32_t)s);
-            else if (s == 256) e = mk_entry(0u, 0u, 2u, 0u);
-            else if (s <= 285) e = mk_entry(0u, kLenExtra[s - 257], 1u, kLenBase[s - 257]);
-            else e = mk_entry(0u, 0u, 2u, 1u);                           // 286 / 287: never valid (kind 2, value 1 = bad)
+            if (s < 256) e = mk_entry(0u, 0u, (uint32_t)s);
+            else if (s == 256) e = mk_entry(0u, 2u, 0u);
+            else if (s <= 285) e = mk_entry(0u, 1u, (uint32_t)(s - 257));
+            else e = mk_entry(0u, 2u, 1u);                               // 286 / 287: never valid (kind 2, value 1 = bad)
         } else if (KIND == 1) {
-            e = s < 30 ? mk_entry(0u, kDistExtra[s], 0u, kDistBase[s]) : mk_entry(0u, 0u, 2u, 1u);
+            e = s < 30 ? mk_entry(0u, 0u, (uint32_t)s) : mk_entry(0u, 2u, 1u);
         } else {
-            e = mk_entry(0u, 0u, 0u, (uint32_t)s);
+            e = mk_entry(0u, 0u, (uint32_t)s);
         }
         if (len <= root) {
             e |= (uint32_t)len;
-            for (uint32_t i = rc + ((uint32_t)lane << len); i < (1u << root); i += 64u << len) table[i] = e;
+            for (uint32_t i = rc + ((uint32_t)lane << len); i < (1u << root); i += 64u << len) table[i] = (tab_t)e;
         } else {
             const uint32_t pre = rc & ((1u << root) - 1u);
             const uint32_t pe = table[pre];
-            const uint32_t base = pe >> 16, sb = (pe >> 4) & 15u;
+            const uint32_t base = ent_value(pe), sb = ent_bits(pe);
             const int sl = len - root;
             e |= (uint32_t)sl;
-            for (uint32_t i = (rc >> root) + ((uint32_t)lane << sl); i < (1u << sb); i += 64u << sl) table[base + i] = e;
+            for (uint32_t i = (rc >> root) + ((uint32_t)lane << sl); i < (1u << sb); i += 64u << sl) table[base + i] = (tab_t)e;
         }
     }
     __syncthreads();
@@ -182,8 +192,8 @@ __device__ int build_table(const uint8_t *lens, int n, int root, uint32_t *table
 __device__ __forceinline__ uint32_t crc_byte(const uint32_t *tab, uint32_t crc, uint32_t b) { return tab[(crc ^ b) & 0xffu] ^ (crc >> 8); }
 
 struct InflateShared {
-    uint32_t lit[kLitEntries];
-    uint32_t dist[kDistEntries];
+    tab_t lit[kLitEntries];
+    tab_t dist[kDistEntries];
     uint32_t in[kInBytes / 4];
     uint8_t win[kWinBytes];
 };
@@ -230,55 +240,70 @@ struct HeaderShared {
 // together (the empty asm statements pin the stage boundaries: left alone, the compiler sinks the distance lookups
 // into a branch and waits for every read on its own).
 #define PC_PIN8(x) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]))
-__device__ __forceinline__ void symbols_at8(const uint32_t *lit, const uint32_t *dist, uint32_t A, uint32_t B, uint32_t C, uint32_t (&out)[8]) {
-    uint32_t lo[8], w2[8], e[8], x[8], tot2[8], val[8];
+#define PC_PING(x) do { if constexpr (G == 8) asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4 % G]), "+v"(x[5 % G]), "+v"(x[6 % G]), "+v"(x[7 % G])); \
+                        else asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])); } while (0)
+template <int G, int T0>
+__device__ __forceinline__ void symbols_at(const tab_t *lit, const tab_t *dist, uint32_t A, uint32_t B, uint32_t C, uint32_t (&out)[8]) {
+    uint32_t lo[G], w2[G], e[G], x[G], tot2[G], val[G];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        lo[t] = (uint32_t)((((unsigned long long)B << 32) | A) >> t);
+    for (int t = 0; t < G; ++t) {
+        lo[t] = (uint32_t)((((unsigned long long)B << 32) | A) >> (T0 + t));
         e[t] = lit[lo[t] & ((1u << kLitRoot) - 1u)];
     }
-    PC_PIN8(e);
+    PC_PING(e);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const bool two = ((e[t] >> 8) & 3u) == 3u;
-        x[t] = lit[two ? (e[t] >> 16) + __builtin_amdgcn_ubfe(lo[t], (uint32_t)kLitRoot, (e[t] >> 4) & 15u) : 0u];
+    for (int t = 0; t < G; ++t) {
+        const bool two = ent_kind(e[t]) == 3u;
+        x[t] = lit[two ? ent_value(e[t]) + __builtin_amdgcn_ubfe(lo[t], (uint32_t)kLitRoot, ent_bits(e[t])) : 0u];
     }
-    PC_PIN8(x);
+    PC_PING(x);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const bool two = ((e[t] >> 8) & 3u) == 3u;
-        const uint32_t tot = (two ? (uint32_t)kLitRoot : 0u) + ((two ? x[t] : e[t]) & 15u);          // <= 15
+    for (int t = 0; t < G; ++t) {
+        const bool two = ent_kind(e[t]) == 3u;
+        const uint32_t tot = (two ? (uint32_t)kLitRoot : 0u) + ent_bits(two ? x[t] : e[t]);          // <= 15
         e[t] = two ? x[t] : e[t];
-        const uint32_t xb = (e[t] >> 4) & 15u;                                                       // (literals: 0)
-        val[t] = (e[t] >> 16) + __builtin_amdgcn_ubfe(lo[t], tot, xb);                               // the byte | the match length
+        uint32_t lbase, lxb;
+        len_of(ent_value(e[t]), lbase, lxb);
+        const bool islen = ent_kind(e[t]) == 1u;
+        const uint32_t xb = islen ? lxb : 0u;                                                        // (literals: 0)
+        val[t] = (islen ? lbase : ent_value(e[t])) + __builtin_amdgcn_ubfe(lo[t], tot, xb);          // the byte | the match length
         tot2[t] = tot + xb;                                                                          // <= 20
-        const uint32_t hi = (uint32_t)((((unsigned long long)C << 32) | B) >> t);
+        const uint32_t hi = (uint32_t)((((unsigned long long)C << 32) | B) >> (T0 + t));
         w2[t] = (uint32_t)((((unsigned long long)hi << 32) | lo[t]) >> tot2[t]);                     // (one v_alignbit: tot2 < 32)
         x[t] = dist[w2[t] & ((1u << kDistRoot) - 1u)];
     }
-    PC_PIN8(x);
-    uint32_t y[8];
+    PC_PING(x);
+    uint32_t y[G];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const bool dtwo = ((x[t] >> 8) & 3u) == 3u;
-        y[t] = dist[dtwo ? (x[t] >> 16) + __builtin_amdgcn_ubfe(w2[t], (uint32_t)kDistRoot, (x[t] >> 4) & 15u) : 0u];
+    for (int t = 0; t < G; ++t) {
+        const bool dtwo = ent_kind(x[t]) == 3u;
+        y[t] = dist[dtwo ? ent_value(x[t]) + __builtin_amdgcn_ubfe(w2[t], (uint32_t)kDistRoot, ent_bits(x[t])) : 0u];
     }
-    PC_PIN8(y);
+    PC_PING(y);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const bool dtwo = ((x[t] >> 8) & 3u) == 3u;
+    for (int t = 0; t < G; ++t) {
+        const bool dtwo = ent_kind(x[t]) == 3u;
         const uint32_t d = dtwo ? y[t] : x[t];
-        const uint32_t dt = (dtwo ? (uint32_t)kDistRoot : 0u) + (d & 15u);                           // <= 15
-        const uint32_t dxb = (d >> 4) & 15u;                                                         // <= 13
-        const uint32_t dd = (d >> 16) + __builtin_amdgcn_ubfe(w2[t], dt, dxb);
-        const bool dok = (d & 15u) != 0u && ((d >> 8) & 3u) == 0u;
-        const uint32_t kind = (e[t] >> 8) & 3u;
+        const uint32_t dt = (dtwo ? (uint32_t)kDistRoot : 0u) + ent_bits(d);                         // <= 15
+        uint32_t dbase, dxb;                                                                         // dxb <= 13
+        dist_of(ent_value(d) & 31u, dbase, dxb);
+        const uint32_t dd = dbase + __builtin_amdgcn_ubfe(w2[t], dt, dxb);
+        const bool dok = ent_bits(d) != 0u && ent_kind(d) == 0u;
+        const uint32_t kind = ent_kind(e[t]);
         const uint32_t bad = 1u | (kSymBad << 6);
         uint32_t r = (tot2[t]) | (kSymLit << 6) | (val[t] << 8);                                       // kind 0 (xb = 0: tot2 = tot)
         r = kind == 1u ? (dok ? (tot2[t] + dt + dxb) | (kSymMatch << 6) | ((val[t] - 3u) << 8) | ((dd - 1u) << 16) : bad) : r;
-        r = kind == 2u ? ((e[t] >> 16) ? bad : tot2[t] | (kSymEob << 6)) : r;
-        out[t] = (e[t] & 15u) == 0u ? bad : r;
+        r = kind == 2u ? (ent_value(e[t]) ? bad : tot2[t] | (kSymEob << 6)) : r;
+        out[T0 + t] = ent_bits(e[t]) == 0u ? bad : r;
     }
+}
+
+#ifndef PC_BGZF_GROUP
+#define PC_BGZF_GROUP 4
+#endif
+__device__ __forceinline__ void symbols_at8(const tab_t *lit, const tab_t *dist, uint32_t A, uint32_t B, uint32_t C, uint32_t (&out)[8]) {
+    if constexpr (PC_BGZF_GROUP == 8) symbols_at<8, 0>(lit, dist, A, B, C, out);
+    else { symbols_at<4, 0>(lit, dist, A, B, C, out); symbols_at<4, 4>(lit, dist, A, B, C, out); }
 }
 
 // One wave inflates one BGZF member.  Block headers, code lengths and stored blocks are read wave-uniform (every lane
@@ -286,8 +311,17 @@ __device__ __forceinline__ void symbols_at8(const uint32_t *lit, const uint32_t 
 // batch-wise through the lanes (BATCH, above) or, BATCH = false, one by one through the same uniform reader (round 4's
 // first kernel, kept for comparison: PC_BGZF_SERIAL=1).  (The workgroup IS the wave: __syncthreads() orders the LDS
 // traffic of its lanes and costs no cross-wave barrier.)
+// Occupancy (round 6): the kernel is bound by the latency of its dependent LDS chains, so resident waves are what pays.
+// 7.1 KiB of LDS allow 22 waves per CU; the registers are held to 96 (five waves per SIMD) by looking the batch's
+// symbols up in two groups of four offsets instead of one of eight (PC_BGZF_GROUP).  20 M aligner-like records, 2.39 GB
+// inflated: 32-bit entries, four waves per SIMD 25.8 - 26.1 ms; 16-bit entries at four waves 27.2 - 27.8 (the bases and
+// extra-bit counts became arithmetic); at five waves 24.0 - 24.2; compiled for six (20 bytes of scratch, LDS admits 5.5)
+// 23.9.
+#ifndef PC_BGZF_WAVES
+#define PC_BGZF_WAVES 5
+#endif
 template <bool BATCH>
-__global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restrict__ image, const Member *__restrict__ members, int first_member, int nmembers,
+__global__ __launch_bounds__(kInflWG) __attribute__((amdgpu_waves_per_eu(PC_BGZF_WAVES, 8))) void k_bgzf_inflate(const uint8_t *__restrict__ image, const Member *__restrict__ members, int first_member, int nmembers,
                                                           uint8_t *__restrict__ out, uint32_t *__restrict__ status) {
     __shared__ __attribute__((aligned(16))) InflateShared sh;
     __shared__ __attribute__((aligned(16))) union { HeaderShared hdr; BatchShared bat; } su;
@@ -436,7 +470,7 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             while (got < want && err == kInfOk) {
                 refill();
                 const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(uint32_t)bb & 127u]);
-                const int len = (int)(ce & 15u), sym = (int)(ce >> 16);
+                const int len = (int)ent_bits(ce), sym = (int)ent_value(ce);
                 if (len == 0) { err = kInfBadCodeLengths; break; }
                 take(len);
                 int rep = 1, val = sym;
@@ -632,37 +666,41 @@ __global__ __launch_bounds__(kInflWG) void k_bgzf_inflate(const uint8_t *__restr
             for (;;) {
                 refill();
                 uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(uint32_t)bb & ((1u << kLitRoot) - 1u)]);
-                if (((e >> 8) & 3u) == 3u) {
-                    const uint32_t sb = (e >> 4) & 15u;
-                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(e >> 16) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))]);
+                if (ent_kind(e) == 3u) {
+                    const uint32_t sb = ent_bits(e);
+                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[ent_value(e) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))]);
                     bb >>= kLitRoot; nb -= kLitRoot;
                 }
-                const uint32_t nbits = e & 15u;
+                const uint32_t nbits = ent_bits(e);
                 if (nbits == 0u) { err = kInfBadSymbol; break; }
                 bb >>= nbits; nb -= (int)nbits;
-                const uint32_t kind = (e >> 8) & 3u;
+                const uint32_t kind = ent_kind(e);
                 if (kind == 0u) {                         // literal
                     if (pos >= ulen) { err = kInfOverrun; break; }
-                    if (lane == 0) sh.win[pos & (kWinBytes - 1)] = (uint8_t)(e >> 16);
+                    if (lane == 0) sh.win[pos & (kWinBytes - 1)] = (uint8_t)ent_value(e);
                     pos += 1u;
                 } else if (kind == 2u) {                  // end of block
-                    if (e >> 16) err = kInfBadSymbol;
+                    if (ent_value(e)) err = kInfBadSymbol;
                     break;
                 } else {                                  // length + distance
                     refill();
-                    const uint32_t len = (e >> 16) + take((int)((e >> 4) & 15u));
+                    uint32_t lbase, lxb;
+                    len_of(ent_value(e), lbase, lxb);
+                    const uint32_t len = lbase + take((int)lxb);
                     refill();
                     uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(uint32_t)bb & ((1u << kDistRoot) - 1u)]);
-                    if (((d >> 8) & 3u) == 3u) {
-                        const uint32_t sb = (d >> 4) & 15u;
-                        d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(d >> 16) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))]);
+                    if (ent_kind(d) == 3u) {
+                        const uint32_t sb = ent_bits(d);
+                        d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[ent_value(d) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))]);
                         bb >>= kDistRoot; nb -= kDistRoot;
                     }
-                    const uint32_t dbits = d & 15u;
-                    if (dbits == 0u || ((d >> 8) & 3u) != 0u) { err = kInfBadSymbol; break; }
+                    const uint32_t dbits = ent_bits(d);
+                    if (dbits == 0u || ent_kind(d) != 0u) { err = kInfBadSymbol; break; }
                     bb >>= dbits; nb -= (int)dbits;
                     refill();
-                    const uint32_t dist = (d >> 16) + take((int)((d >> 4) & 15u));
+                    uint32_t dbase, dxb;
+                    dist_of(ent_value(d), dbase, dxb);
+                    const uint32_t dist = dbase + take((int)dxb);
                     if (dist > pos) { err = kInfBadDistance; break; }
                     if (pos + len > ulen) { err = kInfOverrun; break; }
                     __syncthreads();
