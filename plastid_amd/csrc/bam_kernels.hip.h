@@ -62,27 +62,37 @@ struct Member {
 enum { kInfOk = 0, kInfBadBlockType = 1, kInfBadStored = 2, kInfBadCodeLengths = 3, kInfOverSubscribed = 4, kInfBadSymbol = 5,
        kInfBadDistance = 6, kInfOverrun = 7, kInfShort = 8, kInfInputOverrun = 9, kInfCrc = 10 };
 
-// ---- table entries (uint16, round 6: half the LDS of the uint32 ones -- the bases and extra-bit counts a uint32 entry
-// carried are arithmetic in the symbol, len_of / dist_of below):  bits 0-3 code bits to consume (0: no such code),
-// 4-5 kind, 6-15 value
-//   kind 0: literal (value = byte) / distance symbol / code-length symbol;  1: length symbol (value = symbol - 257);
-//   2: end of block (value 0) or a symbol that is never valid (value 1);  3: pointer to a second-level table
-//   (value = its first entry, bits 0-3 = its index bits)
+// ---- table entries (uint16, round 6: half the LDS of the uint32 ones).  Bits 0-3: code bits to consume (0: no such
+// code).  What a lookup needs next sits in the entry ready to use, so that the per-offset lookup of a batch does no
+// arithmetic on symbols (RFC 1951 3.2.5: length = 3 + v + extra bits, distance = 1 + (m << e) + e extra bits):
+//   literal / length table   bit 15: a length -- bits 4-11 v = base - 3, bits 12-14 its number of extra bits
+//                            else bit 14: pointer to a second-level table -- bits 4-13 its first entry, bits 0-3 its index bits
+//                            else bit 13: end of block (bit 4 = 0) or a symbol that is never valid (bit 4 = 1)
+//                            else a literal -- bits 4-11 the byte (12-14 zero: "no extra bits")
+//   distance table           bit 14: pointer, as above;  bit 13: a symbol that is never valid (30, 31);
+//                            else bits 4-7 e, bits 8-9 m  (symbols 0-3: m = symbol, e = 0; others m = 2 + (s & 1), e = (s >> 1) - 1)
+//   code-length table        bits 4-8 the symbol (0-18)
 typedef uint16_t tab_t;
-__device__ __forceinline__ uint32_t mk_entry(uint32_t nbits, uint32_t kind, uint32_t value) { return nbits | (kind << 4) | (value << 6); }
+constexpr uint32_t kEntLen = 0x8000u, kEntPtr = 0x4000u, kEntSpecial = 0x2000u, kEntBadBit = 0x10u;
 __device__ __forceinline__ uint32_t ent_bits(uint32_t e) { return e & 15u; }
-__device__ __forceinline__ uint32_t ent_kind(uint32_t e) { return (e >> 4) & 3u; }
-__device__ __forceinline__ uint32_t ent_value(uint32_t e) { return e >> 6; }
-// RFC 1951 3.2.5 in closed form: length symbol 257 + i -> {base, extra bits}; distance symbol s -> {base, extra bits}
-__device__ __forceinline__ void len_of(uint32_t i, uint32_t &base, uint32_t &extra) {
+__device__ __forceinline__ bool ent_is_ptr(uint32_t e) { return (e & (kEntLen | kEntPtr)) == kEntPtr; }
+__device__ __forceinline__ uint32_t ent_ptr_start(uint32_t e) { return (e >> 4) & 1023u; }
+__device__ __forceinline__ uint32_t ent_v8(uint32_t e) { return (e >> 4) & 255u; }
+__device__ __forceinline__ uint32_t mk_ptr(uint32_t index_bits, uint32_t start) { return index_bits | (start << 4) | kEntPtr; }
+// leaf entries without their bit count
+__device__ __forceinline__ uint32_t mk_lit_leaf(int s) {
+    if (s < 256) return (uint32_t)s << 4;
+    if (s == 256) return kEntSpecial;
+    if (s > 285) return kEntSpecial | kEntBadBit;                       // 286 / 287: never valid
+    const uint32_t i = (uint32_t)(s - 257);
     const uint32_t e = i < 8u ? 0u : (i >> 2) - 1u;
-    base = i == 28u ? 258u : (i < 8u ? 3u + i : 3u + ((4u + (i & 3u)) << e));
-    extra = i == 28u ? 0u : e;
+    const uint32_t v = i == 28u ? 255u : (i < 8u ? i : (4u + (i & 3u)) << e);      // base - 3
+    return kEntLen | (v << 4) | ((i == 28u ? 0u : e) << 12);
 }
-__device__ __forceinline__ void dist_of(uint32_t sy, uint32_t &base, uint32_t &extra) {
-    const uint32_t e = sy < 4u ? 0u : (sy >> 1) - 1u;
-    base = sy < 4u ? 1u + sy : 1u + ((2u + (sy & 1u)) << e);
-    extra = e;
+__device__ __forceinline__ uint32_t mk_dist_leaf(int s) {
+    if (s >= 30) return kEntSpecial | kEntBadBit;
+    const uint32_t e = s < 4 ? 0u : ((uint32_t)s >> 1) - 1u, m = s < 4 ? (uint32_t)s : 2u + ((uint32_t)s & 1u);
+    return (e << 4) | (m << 8);
 }
 
 __device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -150,7 +160,7 @@ __device__ int build_table(const uint8_t *lens, int n, int root, tab_t *table, i
             const int sb = ws->subbits[pre];
             if (!sb) continue;
             if (used + (1 << sb) > cap) return kInfBadCodeLengths;
-            if (lane == 0) table[pre] = (tab_t)mk_entry((uint32_t)sb, 3u, (uint32_t)used);
+            if (lane == 0) table[pre] = (tab_t)mk_ptr((uint32_t)sb, (uint32_t)used);
             for (int i = lane; i < (1 << sb); i += 64) table[used + i] = (tab_t)0;
             used += 1 << sb;
         }
@@ -161,23 +171,14 @@ __device__ int build_table(const uint8_t *lens, int n, int root, tab_t *table, i
         if (!len) continue;
         const uint32_t rc = bitrev((uint32_t)ws->code[s], len);
         uint32_t e;
-        if (KIND == 0) {
-            if (s < 256) e = mk_entry(0u, 0u, (uint32_t)s);
-            else if (s == 256) e = mk_entry(0u, 2u, 0u);
-            else if (s <= 285) e = mk_entry(0u, 1u, (uint32_t)(s - 257));
-            else e = mk_entry(0u, 2u, 1u);                               // 286 / 287: never valid (kind 2, value 1 = bad)
-        } else if (KIND == 1) {
-            e = s < 30 ? mk_entry(0u, 0u, (uint32_t)s) : mk_entry(0u, 2u, 1u);
-        } else {
-            e = mk_entry(0u, 0u, (uint32_t)s);
-        }
+        e = KIND == 0 ? mk_lit_leaf(s) : (KIND == 1 ? mk_dist_leaf(s) : (uint32_t)s << 4);
         if (len <= root) {
             e |= (uint32_t)len;
             for (uint32_t i = rc + ((uint32_t)lane << len); i < (1u << root); i += 64u << len) table[i] = (tab_t)e;
         } else {
             const uint32_t pre = rc & ((1u << root) - 1u);
             const uint32_t pe = table[pre];
-            const uint32_t base = ent_value(pe), sb = ent_bits(pe);
+            const uint32_t base = ent_ptr_start(pe), sb = ent_bits(pe);
             const int sl = len - root;
             e |= (uint32_t)sl;
             for (uint32_t i = (rc >> root) + ((uint32_t)lane << sl); i < (1u << sb); i += 64u << sl) table[base + i] = (tab_t)e;
@@ -252,21 +253,16 @@ __device__ __forceinline__ void symbols_at(const tab_t *lit, const tab_t *dist, 
     }
     PC_PING(e);
 #pragma unroll
-    for (int t = 0; t < G; ++t) {
-        const bool two = ent_kind(e[t]) == 3u;
-        x[t] = lit[two ? ent_value(e[t]) + __builtin_amdgcn_ubfe(lo[t], (uint32_t)kLitRoot, ent_bits(e[t])) : 0u];
-    }
+    for (int t = 0; t < G; ++t)
+        x[t] = lit[ent_is_ptr(e[t]) ? ent_ptr_start(e[t]) + __builtin_amdgcn_ubfe(lo[t], (uint32_t)kLitRoot, ent_bits(e[t])) : 0u];
     PC_PING(x);
 #pragma unroll
     for (int t = 0; t < G; ++t) {
-        const bool two = ent_kind(e[t]) == 3u;
-        const uint32_t tot = (two ? (uint32_t)kLitRoot : 0u) + ent_bits(two ? x[t] : e[t]);          // <= 15
+        const bool two = ent_is_ptr(e[t]);
         e[t] = two ? x[t] : e[t];
-        uint32_t lbase, lxb;
-        len_of(ent_value(e[t]), lbase, lxb);
-        const bool islen = ent_kind(e[t]) == 1u;
-        const uint32_t xb = islen ? lxb : 0u;                                                        // (literals: 0)
-        val[t] = (islen ? lbase : ent_value(e[t])) + __builtin_amdgcn_ubfe(lo[t], tot, xb);          // the byte | the match length
+        const uint32_t tot = (two ? (uint32_t)kLitRoot : 0u) + ent_bits(e[t]);                       // <= 15
+        const uint32_t xb = (e[t] & kEntLen) ? (e[t] >> 12) & 7u : 0u;                               // (literals: 0)
+        val[t] = ent_v8(e[t]) + __builtin_amdgcn_ubfe(lo[t], tot, xb);                               // the byte | the match length - 3
         tot2[t] = tot + xb;                                                                          // <= 20
         const uint32_t hi = (uint32_t)((((unsigned long long)C << 32) | B) >> (T0 + t));
         w2[t] = (uint32_t)((((unsigned long long)hi << 32) | lo[t]) >> tot2[t]);                     // (one v_alignbit: tot2 < 32)
@@ -275,25 +271,21 @@ __device__ __forceinline__ void symbols_at(const tab_t *lit, const tab_t *dist, 
     PC_PING(x);
     uint32_t y[G];
 #pragma unroll
-    for (int t = 0; t < G; ++t) {
-        const bool dtwo = ent_kind(x[t]) == 3u;
-        y[t] = dist[dtwo ? ent_value(x[t]) + __builtin_amdgcn_ubfe(w2[t], (uint32_t)kDistRoot, ent_bits(x[t])) : 0u];
-    }
+    for (int t = 0; t < G; ++t)
+        y[t] = dist[(x[t] & kEntPtr) ? ent_ptr_start(x[t]) + __builtin_amdgcn_ubfe(w2[t], (uint32_t)kDistRoot, ent_bits(x[t])) : 0u];
     PC_PING(y);
 #pragma unroll
     for (int t = 0; t < G; ++t) {
-        const bool dtwo = ent_kind(x[t]) == 3u;
+        const bool dtwo = (x[t] & kEntPtr) != 0u;
         const uint32_t d = dtwo ? y[t] : x[t];
         const uint32_t dt = (dtwo ? (uint32_t)kDistRoot : 0u) + ent_bits(d);                         // <= 15
-        uint32_t dbase, dxb;                                                                         // dxb <= 13
-        dist_of(ent_value(d) & 31u, dbase, dxb);
-        const uint32_t dd = dbase + __builtin_amdgcn_ubfe(w2[t], dt, dxb);
-        const bool dok = ent_bits(d) != 0u && ent_kind(d) == 0u;
-        const uint32_t kind = ent_kind(e[t]);
+        const uint32_t dxb = (d >> 4) & 15u;                                                         // <= 13
+        const uint32_t dd1 = (((d >> 8) & 3u) << dxb) + __builtin_amdgcn_ubfe(w2[t], dt, dxb);       // the distance - 1
+        const bool dok = ent_bits(d) != 0u && (d & (kEntPtr | kEntSpecial)) == 0u;
         const uint32_t bad = 1u | (kSymBad << 6);
-        uint32_t r = (tot2[t]) | (kSymLit << 6) | (val[t] << 8);                                       // kind 0 (xb = 0: tot2 = tot)
-        r = kind == 1u ? (dok ? (tot2[t] + dt + dxb) | (kSymMatch << 6) | ((val[t] - 3u) << 8) | ((dd - 1u) << 16) : bad) : r;
-        r = kind == 2u ? (ent_value(e[t]) ? bad : tot2[t] | (kSymEob << 6)) : r;
+        uint32_t r = tot2[t] | (kSymLit << 6) | (val[t] << 8);                                       // a literal (xb = 0: tot2 = tot)
+        r = (e[t] & kEntLen) ? (dok ? (tot2[t] + dt + dxb) | (kSymMatch << 6) | (val[t] << 8) | (dd1 << 16) : bad) : r;
+        r = (e[t] & (kEntLen | kEntSpecial)) == kEntSpecial ? ((e[t] & kEntBadBit) ? bad : tot2[t] | (kSymEob << 6)) : r;
         out[T0 + t] = ent_bits(e[t]) == 0u ? bad : r;
     }
 }
@@ -311,12 +303,13 @@ __device__ __forceinline__ void symbols_at8(const tab_t *lit, const tab_t *dist,
 // batch-wise through the lanes (BATCH, above) or, BATCH = false, one by one through the same uniform reader (round 4's
 // first kernel, kept for comparison: PC_BGZF_SERIAL=1).  (The workgroup IS the wave: __syncthreads() orders the LDS
 // traffic of its lanes and costs no cross-wave barrier.)
-// Occupancy (round 6): the kernel is bound by the latency of its dependent LDS chains, so resident waves are what pays.
-// 7.1 KiB of LDS allow 22 waves per CU; the registers are held to 96 (five waves per SIMD) by looking the batch's
-// symbols up in two groups of four offsets instead of one of eight (PC_BGZF_GROUP).  20 M aligner-like records, 2.39 GB
-// inflated: 32-bit entries, four waves per SIMD 25.8 - 26.1 ms; 16-bit entries at four waves 27.2 - 27.8 (the bases and
-// extra-bit counts became arithmetic); at five waves 24.0 - 24.2; compiled for six (20 bytes of scratch, LDS admits 5.5)
-// 23.9.
+// Occupancy (round 6): 7.1 KiB of LDS allow 22 waves per CU; the registers are held to 96 (five waves per SIMD) by looking
+// the batch's symbols up in two groups of four offsets instead of one of eight (PC_BGZF_GROUP).  20 M aligner-like
+// records, 2.39 GB inflated, lap `upload + inflate + crc`: 32-bit entries, four waves per SIMD 25.8 - 26.1 ms; 16-bit
+// entries holding the bare symbol (bases and extra-bit counts computed per offset) at four waves 27.2 - 27.8, at five
+// 24.0 - 24.2, compiled for six (20 bytes of scratch, LDS admits 5.5) 23.9; 16-bit entries holding v / m / e ready to
+// use (above), five waves: 22.9 - 23.1 (104 GB/s).  The vector units issue for about two thirds of the lap (6.3 - 7.2
+// wave-instructions per output byte): instructions per byte is what is left to cut, not waves.
 #ifndef PC_BGZF_WAVES
 #define PC_BGZF_WAVES 5
 #endif
@@ -470,7 +463,7 @@ __global__ __launch_bounds__(kInflWG) __attribute__((amdgpu_waves_per_eu(PC_BGZF
             while (got < want && err == kInfOk) {
                 refill();
                 const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(uint32_t)bb & 127u]);
-                const int len = (int)ent_bits(ce), sym = (int)ent_value(ce);
+                const int len = (int)ent_bits(ce), sym = (int)(ce >> 4);
                 if (len == 0) { err = kInfBadCodeLengths; break; }
                 take(len);
                 int rep = 1, val = sym;
@@ -666,41 +659,37 @@ __global__ __launch_bounds__(kInflWG) __attribute__((amdgpu_waves_per_eu(PC_BGZF
             for (;;) {
                 refill();
                 uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[(uint32_t)bb & ((1u << kLitRoot) - 1u)]);
-                if (ent_kind(e) == 3u) {
+                if (ent_is_ptr(e)) {
                     const uint32_t sb = ent_bits(e);
-                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[ent_value(e) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))]);
+                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.lit[ent_ptr_start(e) + (((uint32_t)(bb >> kLitRoot)) & ((1u << sb) - 1u))]);
                     bb >>= kLitRoot; nb -= kLitRoot;
                 }
                 const uint32_t nbits = ent_bits(e);
                 if (nbits == 0u) { err = kInfBadSymbol; break; }
                 bb >>= nbits; nb -= (int)nbits;
-                const uint32_t kind = ent_kind(e);
-                if (kind == 0u) {                         // literal
+                if (!(e & (kEntLen | kEntSpecial))) {     // literal
                     if (pos >= ulen) { err = kInfOverrun; break; }
-                    if (lane == 0) sh.win[pos & (kWinBytes - 1)] = (uint8_t)ent_value(e);
+                    if (lane == 0) sh.win[pos & (kWinBytes - 1)] = (uint8_t)ent_v8(e);
                     pos += 1u;
-                } else if (kind == 2u) {                  // end of block
-                    if (ent_value(e)) err = kInfBadSymbol;
+                } else if (!(e & kEntLen)) {              // end of block
+                    if (e & kEntBadBit) err = kInfBadSymbol;
                     break;
                 } else {                                  // length + distance
                     refill();
-                    uint32_t lbase, lxb;
-                    len_of(ent_value(e), lbase, lxb);
-                    const uint32_t len = lbase + take((int)lxb);
+                    const uint32_t len = 3u + ent_v8(e) + take((int)((e >> 12) & 7u));
                     refill();
                     uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[(uint32_t)bb & ((1u << kDistRoot) - 1u)]);
-                    if (ent_kind(d) == 3u) {
+                    if (d & kEntPtr) {
                         const uint32_t sb = ent_bits(d);
-                        d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[ent_value(d) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))]);
+                        d = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dist[ent_ptr_start(d) + (((uint32_t)(bb >> kDistRoot)) & ((1u << sb) - 1u))]);
                         bb >>= kDistRoot; nb -= kDistRoot;
                     }
                     const uint32_t dbits = ent_bits(d);
-                    if (dbits == 0u || ent_kind(d) != 0u) { err = kInfBadSymbol; break; }
+                    if (dbits == 0u || (d & (kEntPtr | kEntSpecial)) != 0u) { err = kInfBadSymbol; break; }
                     bb >>= dbits; nb -= (int)dbits;
                     refill();
-                    uint32_t dbase, dxb;
-                    dist_of(ent_value(d), dbase, dxb);
-                    const uint32_t dist = dbase + take((int)dxb);
+                    const uint32_t dxb = (d >> 4) & 15u;
+                    const uint32_t dist = 1u + (((d >> 8) & 3u) << dxb) + take((int)dxb);
                     if (dist > pos) { err = kInfBadDistance; break; }
                     if (pos + len > ulen) { err = kInfOverrun; break; }
                     __syncthreads();

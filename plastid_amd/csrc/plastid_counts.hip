@@ -544,6 +544,7 @@ struct Knobs {
     int64_t pile = 0;          // PC_PILE: records of a 128-nt sub-window beyond which it is merged through the histogram (0: 12 R)
     int no_small = 0;          // PC_NO_SMALL: no single-wave class for sparse windows
     int small_rows = 0;        // PC_SMALL_ROWS: 1 = multi-row plans (stratified rule) may use the single-wave class too
+    int64_t ranges_cg16_max = (int64_t)1 << 19;   // PC_RANGES_CG16_MAX: k_tile_ranges gives a window sixteen lanes while windows x 16 stays within this many threads
     int ranges_cg1 = 0;        // PC_RANGES_CG1: one thread per window in k_tile_ranges whatever the plan's size (tests compare the two forms)
     int64_t first_sync_spare = 65536;   // PC_FIRST_SYNC_SPARE: spare work-list slots from which the first count of a plan reads its item counts back before it launches
     int no_single = 0;         // PC_NO_SINGLE: one-window plans go through the work lists like any other (tests compare the two paths)
@@ -567,6 +568,7 @@ struct Knobs {
         if (const char *env = getenv("PC_SMALL_ROWS")) small_rows = atoi(env);
         no_single = getenv("PC_NO_SINGLE") ? 1 : 0;
         ranges_cg1 = getenv("PC_RANGES_CG1") ? 1 : 0;
+        ranges_cg16_max = getenv("PC_RANGES_CG16_MAX") ? atoll(getenv("PC_RANGES_CG16_MAX")) : ((int64_t)1 << 19);
         first_sync_spare = getenv("PC_FIRST_SYNC_SPARE") ? atoll(getenv("PC_FIRST_SYNC_SPARE")) : 65536;
         if (const char *env = getenv("PC_PLAN_BUILD")) plan_build = std::strcmp(env, "host") == 0 ? 1 : (std::strcmp(env, "gpu") == 0 ? 2 : 0);
         if (const char *env = getenv("PC_SMALL_G")) small_g = std::max(64, atoi(env) / 64 * 64);
@@ -2787,7 +2789,7 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                 // ... or sixteen lanes per window while that still fits the chip at once: the exact record bounds of a window are
                 // then searched by the group (three rounds of sixteen probes instead of a dozen dependent loads each) -- a plan of
                 // a few thousand windows (C2: 6 144) otherwise runs on two dozen CUs at the pace of one thread's load chain
-                const bool group16 = nwin * 16 <= ((int64_t)1 << 19) && !e->knobs.ranges_cg1;
+                const bool group16 = nwin * 16 <= e->knobs.ranges_cg16_max && !e->knobs.ranges_cg1;
                 const int64_t nthreads = group16 ? nwin * 16 : nwin;
 #define PC_LAUNCH_RANGES(CG)                                                                                           \
     hipLaunchKernelGGL((k_tile_ranges<CG>), dim3((unsigned)((nthreads + kRangesWG - 1) / kRangesWG)), dim3(kRangesWG), 0, st, p->d_tiles.p, ntiles, \

@@ -1407,4 +1407,12 @@ def test_sixteen_bit_bins_do_not_overflow(pa, oracle):
                         exp[out_off[s] + r] = a2[r].sum()
             assert np.array_equal(got, exp), (len(files), step, np.nonzero(got != exp)[0][:8])
             plan.close()
+        # plans of ONE window (what `ga[segment]` builds): the stratified rule never takes the one-launch path of
+        # pc_query_segment / SINGLE (pc_count: `single` excludes PC_MAP_STRAT5), so these go through the same guarded lists
+        for s in (1, 4, 5):
+            one = slice(s, s + 1)
+            plan = eng.plan(seg_tid[one], seg_start[one], seg_end[one], seg_strand[one], np.zeros(1, np.int64), np.ones(1, np.int8),
+                            n[one], int(n[s]) * rows, rows)
+            assert np.array_equal(plan.count(np.int64), arrays[s].reshape(-1)), (len(files), s)
+            plan.close()
         eng.close()
