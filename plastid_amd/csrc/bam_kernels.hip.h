@@ -221,7 +221,13 @@ struct InflateShared {
 #define PC_BGZF_SKIP 0
 #endif
 constexpr int kBatchBits = 512;             // bit offsets per batch: 64 lanes x 8
-constexpr uint32_t kSymLit = 0u, kSymMatch = 1u, kSymEob = 2u, kSymBad = 3u;   // sym: bits 0-5 consumed, 6-7 kind, 8-15 byte | length - 3, 16-30 distance - 1
+// sym: bits 0-7 FOUR TIMES the bits consumed (the walk adds the byte to its LDS address as it is), 8-15 byte | length - 3,
+// 16-30 distance - 1, bit 31 a match; no match: bit 30 end of block or no symbol at all (then bit 29), else a literal
+constexpr uint32_t kSymMatch = 1u << 31, kSymSpecial = 1u << 30, kSymBadBit = 1u << 29;
+__device__ __forceinline__ bool sym_is_match(uint32_t sv) { return (sv >> 31) != 0u; }
+__device__ __forceinline__ bool sym_is_special(uint32_t sv) { return (sv >> 30) == 1u; }
+__device__ __forceinline__ bool sym_is_lit(uint32_t sv) { return (sv >> 30) == 0u; }
+__device__ __forceinline__ uint32_t sym_bits(uint32_t sv) { return (sv & 0xffu) >> 2; }
 
 struct BatchShared {
     // what starts at bit offset i, were it a symbol start -- and, once the walk has passed, the symbols that ARE real, in
@@ -282,10 +288,10 @@ __device__ __forceinline__ void symbols_at(const tab_t *lit, const tab_t *dist, 
         const uint32_t dxb = (d >> 4) & 15u;                                                         // <= 13
         const uint32_t dd1 = (((d >> 8) & 3u) << dxb) + __builtin_amdgcn_ubfe(w2[t], dt, dxb);       // the distance - 1
         const bool dok = ent_bits(d) != 0u && (d & (kEntPtr | kEntSpecial)) == 0u;
-        const uint32_t bad = 1u | (kSymBad << 6);
-        uint32_t r = tot2[t] | (kSymLit << 6) | (val[t] << 8);                                       // a literal (xb = 0: tot2 = tot)
-        r = (e[t] & kEntLen) ? (dok ? (tot2[t] + dt + dxb) | (kSymMatch << 6) | (val[t] << 8) | (dd1 << 16) : bad) : r;
-        r = (e[t] & (kEntLen | kEntSpecial)) == kEntSpecial ? ((e[t] & kEntBadBit) ? bad : tot2[t] | (kSymEob << 6)) : r;
+        const uint32_t bad = (1u << 2) | kSymSpecial | kSymBadBit;
+        uint32_t r = (tot2[t] << 2) | (val[t] << 8);                                                 // a literal (xb = 0: tot2 = tot)
+        r = (e[t] & kEntLen) ? (dok ? ((tot2[t] + dt + dxb) << 2) | kSymMatch | (val[t] << 8) | (dd1 << 16) : bad) : r;
+        r = (e[t] & (kEntLen | kEntSpecial)) == kEntSpecial ? ((e[t] & kEntBadBit) ? bad : (tot2[t] << 2) | kSymSpecial) : r;
         out[T0 + t] = ent_bits(e[t]) == 0u ? bad : r;
     }
 }
@@ -308,8 +314,9 @@ __device__ __forceinline__ void symbols_at8(const tab_t *lit, const tab_t *dist,
 // records, 2.39 GB inflated, lap `upload + inflate + crc`: 32-bit entries, four waves per SIMD 25.8 - 26.1 ms; 16-bit
 // entries holding the bare symbol (bases and extra-bit counts computed per offset) at four waves 27.2 - 27.8, at five
 // 24.0 - 24.2, compiled for six (20 bytes of scratch, LDS admits 5.5) 23.9; 16-bit entries holding v / m / e ready to
-// use (above), five waves: 22.9 - 23.1 (104 GB/s).  The vector units issue for about two thirds of the lap (6.3 - 7.2
-// wave-instructions per output byte): instructions per byte is what is left to cut, not waves.
+// use (above), five waves: 22.9 - 23.1; with the seven-instruction walk 21.8 - 22.2 (108 GB/s).  Where the lap goes now
+// (-DPC_BGZF_SKIP builds, profiles/r06/bam/sections_final_kernel.txt): the upload alone 11.5 ms (PCIe, overlapped), every
+// offset an 8-bit literal and no matches 13.3, the real lookups and symbol counts + 3.8, the match copies + 4.7.
 #ifndef PC_BGZF_WAVES
 #define PC_BGZF_WAVES 5
 #endif
@@ -512,41 +519,36 @@ __global__ __launch_bounds__(kInflWG) __attribute__((amdgpu_waves_per_eu(PC_BGZF
                     const uint32_t A = (uint32_t)((((unsigned long long)d1 << 32) | d0) >> s0), B = (uint32_t)((((unsigned long long)d2 << 32) | d1) >> s0);
                     const uint32_t C = (uint32_t)((((unsigned long long)d3 << 32) | d2) >> s0);
                     uint32_t sy[8];
-                    if (PC_BGZF_SKIP & 16) { for (int t = 0; t < 8; ++t) sy[t] = 8u | (kSymLit << 6) | ((A >> t) & 0xff00u); }   // (experiment: no lookup -- every offset an 8-bit literal)
+                    if (PC_BGZF_SKIP & 16) { for (int t = 0; t < 8; ++t) sy[t] = (8u << 2) | ((A >> t) & 0xff00u); }   // (experiment: no lookup -- every offset an 8-bit literal)
                     else symbols_at8(sh.lit, sh.dist, A, B, C, sy);
                     *(uint4 *)&bs.sym[8 * lane] = make_uint4(sy[0], sy[1], sy[2], sy[3]);
                     *(uint4 *)&bs.sym[8 * lane + 4] = make_uint4(sy[4], sy[5], sy[6], sy[7]);
                 }
                 __syncthreads();
-                // ---- which offsets are symbol starts: the walk from offset 0 (it stops behind an end-of-block code or a
-                // symbol that is none -- what follows would be read with the wrong tables)
+                // ---- which offsets are symbol starts: the walk from offset 0.  It does not look at what it passes: behind an
+                // end-of-block code or a symbol that is none it walks on through entries read with the wrong tables (every
+                // entry consumes at least a bit, so it ends), and the stage below stops at the first such symbol.
                 uint32_t walk, nsym;
                 {
-                    // a dozen instructions per symbol and one LDS read on the dependent chain; every lane stores the same
-                    // value to the same place (no mask to set up)
+                    // seven instructions per symbol (twelve with a scalar bit count and a test for the stop symbols), one LDS
+                    // read on the dependent chain; every lane stores the same value to the same place (no mask to set up)
                     uint32_t va = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)bs.sym;
-                    const uint32_t vn0 = va;   // (the chain is written over the offset table: see BatchShared)
-                    uint32_t vn = vn0, vs, sv;
-                    asm volatile("s_mov_b32 %[walk], 0\n\t"
-                                 "1:\n\t"
+                    const uint32_t vn0 = va, vend = va + 4u * (uint32_t)kBatchBits;   // (the chain is written over the offset table: see BatchShared)
+                    uint32_t vn = vn0, vs;
+                    asm volatile("1:\n\t"
                                  "ds_read_b32 %[vs], %[va]\n\t"
                                  "s_waitcnt lgkmcnt(0)\n\t"
                                  "ds_write_b32 %[vn], %[vs]\n\t"
                                  "v_add_u32 %[vn], 4, %[vn]\n\t"
-                                 "v_readfirstlane_b32 %[sv], %[vs]\n\t"
-                                 "s_bitcmp1_b32 %[sv], 7\n\t"
-                                 "s_cbranch_scc1 2f\n\t"
-                                 "s_and_b32 %[sv], %[sv], 63\n\t"
-                                 "s_add_u32 %[walk], %[walk], %[sv]\n\t"
-                                 "v_lshl_add_u32 %[va], %[sv], 2, %[va]\n\t"
-                                 "s_cmpk_lt_u32 %[walk], 512\n\t"
-                                 "s_cbranch_scc1 1b\n\t"
-                                 "2:\n\t"
+                                 "v_add_u32_sdwa %[va], %[va], %[vs] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                                 "v_cmp_gt_u32 vcc, %[vend], %[va]\n\t"
+                                 "s_cbranch_vccnz 1b\n\t"
                                  "s_waitcnt lgkmcnt(0)"
-                                 : [walk] "=&s"(walk), [va] "+v"(va), [vn] "+v"(vn), [vs] "=&v"(vs), [sv] "=&s"(sv)
-                                 :
-                                 : "scc", "memory");
+                                 : [va] "+v"(va), [vn] "+v"(vn), [vs] "=&v"(vs)
+                                 : [vend] "v"(vend)
+                                 : "vcc", "memory");
                     nsym = (uint32_t)__builtin_amdgcn_readfirstlane((int)(vn - vn0)) >> 2;
+                    walk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(va - vn0)) >> 2;
                 }
                 __syncthreads();
                 // ---- per symbol, 64 at a time
@@ -558,10 +560,9 @@ __global__ __launch_bounds__(kInflWG) __attribute__((amdgpu_waves_per_eu(PC_BGZF
                     const uint32_t idx = c0 + (uint32_t)lane;
                     const bool have = idx < nsym;
                     const uint32_t sv = have ? bs.sym[idx] : 0u;
-                    const uint32_t kind = (sv >> 6) & 3u;
-                    const uint32_t ol = !have ? 0u : (kind == kSymLit ? 1u : (kind == kSymMatch ? ((sv >> 8) & 255u) + 3u : 0u));
+                    const uint32_t ol = !have ? 0u : (sym_is_lit(sv) ? 1u : (sym_is_match(sv) ? ((sv >> 8) & 255u) + 3u : 0u));
                     // one prefix sum for both: bytes produced (bits 0-15; <= 64 x 258) and bits consumed (16-31; <= 64 x 48)
-                    const uint32_t mine = ol | (have ? (sv & 63u) << 16 : 0u);
+                    const uint32_t mine = ol | ((sv & 0xfcu) << 14);   // (sv = 0 without a symbol)
                     uint32_t incl2 = mine;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) {
@@ -572,16 +573,16 @@ __global__ __launch_bounds__(kInflWG) __attribute__((amdgpu_waves_per_eu(PC_BGZF
                     const uint32_t off = bits + ((incl2 - mine) >> 16);
                     const uint32_t chunk_start = pos + done;
                     const uint32_t q = chunk_start + incl - ol, end = chunk_start + incl;
-                    const unsigned long long stopm = __ballot(have && (kind >= kSymEob || end > limit));
+                    const unsigned long long stopm = __ballot(have && (sym_is_special(sv) || end > limit));
                     const int first = stopm ? __builtin_ctzll(stopm) : 64;
                     const uint32_t chunk_bytes = first < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)(incl - ol), first) : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     const uint32_t chunk_end = chunk_start + chunk_bytes;
                     const bool emit = have && lane < first;
-                    if (!(PC_BGZF_SKIP & 4) && emit && kind == kSymLit) sh.win[q & (kWinBytes - 1)] = (uint8_t)(sv >> 8);
+                    if (!(PC_BGZF_SKIP & 4) && emit && sym_is_lit(sv)) sh.win[q & (kWinBytes - 1)] = (uint8_t)(sv >> 8);
                     // ---- matches: those whose source lies before the chunk are independent of one another (one per lane);
                     // those that read what this chunk writes follow in stream order, each copied by the whole wave
-                    const bool ism = emit && kind == kSymMatch;
-                    const uint32_t len = ol, dd = (sv >> 16) + 1u;
+                    const bool ism = emit && sym_is_match(sv);
+                    const uint32_t len = ol, dd = ((sv >> 16) & 0x7fffu) + 1u;
                     if (__ballot(ism && dd > q) != 0ull) { err = kInfBadDistance; break; }
                     const uint32_t src = q - dd;
                     const bool dep = ism && src + len > chunk_start;
@@ -635,11 +636,11 @@ __global__ __launch_bounds__(kInflWG) __attribute__((amdgpu_waves_per_eu(PC_BGZF
                     done += chunk_bytes;
                     bits += (uint32_t)__builtin_amdgcn_readlane((int)incl2, 63) >> 16;
                     if (first < 64) {         // the symbol that ends the batch: end of block, none at all, or one that does not fit
-                        const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)kind, first), o1 = (uint32_t)__builtin_amdgcn_readlane((int)off, first);
+                        const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)off, first);
                         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)end, first), s1 = (uint32_t)__builtin_amdgcn_readlane((int)sv, first);
                         stopped = true;
-                        if (k1 == kSymBad) err = kInfBadSymbol;
-                        else if (k1 == kSymEob) { eob = true; p_next = o1 + (s1 & 63u); }
+                        if (sym_is_special(s1) && (s1 & kSymBadBit)) err = kInfBadSymbol;
+                        else if (sym_is_special(s1)) { eob = true; p_next = o1 + sym_bits(s1); }
                         else if (e1 > ulen) err = kInfOverrun;
                         else p_next = o1;
                     }
