@@ -547,6 +547,7 @@ struct Knobs {
     int64_t ranges_cg16_max = (int64_t)1 << 19;   // PC_RANGES_CG16_MAX: k_tile_ranges gives a window sixteen lanes while windows x 16 stays within this many threads
     int ranges_cg1 = 0;        // PC_RANGES_CG1: one thread per window in k_tile_ranges whatever the plan's size (tests compare the two forms)
     int64_t first_sync_spare = 65536;   // PC_FIRST_SYNC_SPARE: spare work-list slots from which the first count of a plan reads its item counts back before it launches
+    int no_stream_probe = 0;   // PC_NO_STREAM_PROBE: keep the engine's streams as created (see settle_streams)
     int no_single = 0;         // PC_NO_SINGLE: one-window plans go through the work lists like any other (tests compare the two paths)
     int plan_build = 0;        // PC_PLAN_BUILD=host|gpu: where pc_plan_create builds the tables (default: on the GPU from 8 192 segments)
     int small_g = 512;         // PC_SMALL_G: queried span a single-wave window may have
@@ -567,6 +568,7 @@ struct Knobs {
         no_small = getenv("PC_NO_SMALL") ? 1 : 0;
         if (const char *env = getenv("PC_SMALL_ROWS")) small_rows = atoi(env);
         no_single = getenv("PC_NO_SINGLE") ? 1 : 0;
+        no_stream_probe = getenv("PC_NO_STREAM_PROBE") ? 1 : 0;
         ranges_cg1 = getenv("PC_RANGES_CG1") ? 1 : 0;
         ranges_cg16_max = getenv("PC_RANGES_CG16_MAX") ? atoll(getenv("PC_RANGES_CG16_MAX")) : ((int64_t)1 << 19);
         first_sync_spare = getenv("PC_FIRST_SYNC_SPARE") ? atoll(getenv("PC_FIRST_SYNC_SPARE")) : 65536;
@@ -593,6 +595,7 @@ struct pc_engine {
     static constexpr int kAux = 3;
     hipStream_t aux_stream[kAux] = {nullptr, nullptr, nullptr};   // the upload pieces of the BAM decoder are inflated on these and the main stream in turn, so that one launch fills the tail of the launches before it
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipStream_t> parked_streams;   // streams settle_streams traded away (they shared a hardware queue with the main one)
     hipEvent_t ev_pinned = nullptr;      // end of the last copy out of `pinned`
     hipEvent_t ev[8] = {};
     std::vector<StagedFile *> files;
@@ -1241,6 +1244,71 @@ int build_center_stream(pc_engine *e, StagedFile *sf, int sel, int nib) {
 
 } // namespace
 
+// ---- which of the engine's streams really run beside the main one
+// The runtime multiplexes a process's streams onto a few hardware queues (four by default), and two streams that share
+// one run their kernels one after the other.  Two places of the engine count on kernels running side by side -- the
+// sparse-window class of a point-rule count (`side_stream`) and the inflate launches of the BAM decoder, which alternate
+// between the main stream and `aux_stream[0]` so that one launch fills the tail of the other -- and which queue a new
+// stream lands on depends on every stream the process already holds (other engines, torch, RCCL).  Measured in
+// bench.py's process, where the headline engine is alive beside the one that decodes the BAM: the two inflate streams
+// shared a queue, 139 ms for the 2.9 GB file against 94.5 ms in a process of its own (and 94.5 with GPU_MAX_HW_QUEUES=8).
+// So the engine asks: a kernel that waits (at most half a millisecond) for a flag on the main stream, a kernel that sets
+// it on the candidate -- seen means the two ran at once.  Candidates that did not are replaced by new streams (the
+// runtime hands those to its least-used queue) a few times over; what cannot be had stays as it is: correct, serial.
+namespace {
+__global__ void k_stream_probe_wait(uint32_t *flag, unsigned long long budget) {
+    const unsigned long long t0 = wall_clock64();
+    uint32_t seen = 0;
+    while ((seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < budget)
+        __builtin_amdgcn_s_sleep(16);
+    flag[1] = seen;
+}
+__global__ void k_stream_probe_set(uint32_t *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 1: a kernel on `b` ran while one on `a` was running; 0: it did not; < 0: error
+int streams_run_side_by_side(pc_engine *e, hipStream_t a, hipStream_t b, uint32_t *flag) {
+    HIP_TRY(hipMemsetAsync(flag, 0, 2 * sizeof(uint32_t), a));
+    HIP_TRY(hipEventRecord(e->ev_fork, a));
+    HIP_TRY(hipStreamWaitEvent(b, e->ev_fork, 0));
+    hipLaunchKernelGGL(k_stream_probe_wait, dim3(1), dim3(1), 0, a, flag, 50000ull);   // wall_clock64 ticks at 100 MHz: 0.5 ms
+    hipLaunchKernelGGL(k_stream_probe_set, dim3(1), dim3(1), 0, b, flag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(a));
+    HIP_TRY(hipStreamSynchronize(b));
+    uint32_t seen[2] = {0, 0};
+    HIP_TRY(hipMemcpy(seen, flag, sizeof(seen), hipMemcpyDeviceToHost));
+    return seen[1] ? 1 : 0;
+}
+
+// `side_stream` is made a stream that runs beside `stream`, and `aux_stream[0]` one that runs beside both (the BAM
+// decoder uploads on the side stream while the main and the auxiliary one inflate), if the process can have such
+int settle_streams(pc_engine *e) {
+    if (e->knobs.no_stream_probe) return PC_OK;
+    DevBuf<uint32_t> flag;
+    flag.pool = &e->pool;
+    int rc = flag.reserve(2);
+    if (rc != PC_OK) return rc;
+    auto settle = [&](hipStream_t &cand, std::initializer_list<hipStream_t> beside) -> int {
+        for (int attempt = 0;; ++attempt) {
+            int ok = 1;
+            for (hipStream_t other : beside) {
+                ok = streams_run_side_by_side(e, other, cand, flag.p);
+                if (ok <= 0) break;
+            }
+            if (ok < 0) return ok;
+            if (ok || attempt == 7) return PC_OK;          // (attempt 7: stays as it is -- correct, serial)
+            hipStream_t fresh = nullptr;
+            HIP_TRY(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+            e->parked_streams.push_back(cand);             // (destroyed with the engine: destroying it now would hand its queue slot straight back)
+            cand = fresh;
+        }
+    };
+    rc = settle(e->side_stream, {e->stream});
+    if (rc == PC_OK) rc = settle(e->aux_stream[0], {e->stream, e->side_stream});
+    return rc;
+}
+} // namespace
+
 extern "C" {
 
 const char *pc_last_error(void) { return g_err.c_str(); }
@@ -1289,6 +1357,7 @@ int pc_create(int device, pc_engine **out) {
     if (rc == PC_OK) rc = e->d_counters.reserve(16);
     if (rc == PC_OK && hipMemsetAsync(e->d_counters.p, 0, 16 * sizeof(uint32_t), e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: memset failed");
     if (rc == PC_OK && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail(PC_ERR_HIP, "pc_create: sync failed");
+    if (rc == PC_OK) rc = settle_streams(e);
     if (rc != PC_OK) {
         pc_destroy(e);
         return rc;
@@ -1307,6 +1376,7 @@ int pc_destroy(pc_engine *e) {
         if (ev) (void)hipEventDestroy(ev);
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     for (auto &a : e->aux_stream) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+    for (auto a : e->parked_streams) if (a) (void)hipStreamDestroy(a);
     if (e->q_host) (void)hipHostFree(e->q_host);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_pinned) (void)hipEventDestroy(e->ev_pinned);
@@ -3719,6 +3789,10 @@ struct BamClock {   // PC_BAM_TIMING=1: wall-clock laps of the host side of the 
         fprintf(stderr, "[bam] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
         t = now;
     }
+    void note(const char *what) {   // time since the last lap, the lap goes on
+        if (!on) return;
+        fprintf(stderr, "[bam]   (%s: %.2f ms into the lap)\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count());
+    }
 };
 } // namespace
 
@@ -4021,6 +4095,7 @@ static int bam_open_impl(pc_engine *e, const void *image_, int64_t size, const c
             m0 = m1;
         }
         }
+        clk.note("every piece copied into the page-locked ring and queued");
         for (int k = 0; k < naux; ++k) {   // the main stream goes on behind all of them
             hipEvent_t x;
             HIP_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));

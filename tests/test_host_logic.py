@@ -442,7 +442,7 @@ def test_host_helpers_of_the_engine(tmp_path):
 def test_inflate_and_plan_kernels_are_in_the_code_object(tmp_path):
     """Round 4's device code beside the counting kernels: the BGZF inflate kernel in both forms (batch decoder of the
     block symbols, wave-uniform decoder), without scratch memory and with an LDS footprint that leaves eleven waves per
-    CU; the walk over the symbol table is the hand-written loop (one LDS read, one LDS write, a readfirstlane per
+    CU; the walk over the symbol table is the hand-written loop (one LDS read, one LDS write, seven instructions per
     symbol); every kernel of the GPU plan builder is there."""
     import re
     import shutil
@@ -469,11 +469,11 @@ def test_inflate_and_plan_kernels_are_in_the_code_object(tmp_path):
     batch = [k for k in blocks if k.startswith("_ZN5pcbam14k_bgzf_inflateILb1E")][0]
     dis = subprocess.check_output([objdump, "-d", "--disassemble-symbols=" + batch, obj]).decode()
     lines = [ln.split("//")[0].strip() for ln in dis.splitlines() if "\t" in ln]
-    at = [i for i, ln in enumerate(lines) if ln.startswith("s_bitcmp1_b32")]
+    # (round 6: seven instructions -- the symbol word's low byte, four times its bit count, is added to the LDS address by an SDWA add)
+    at = [i for i, ln in enumerate(lines) if ln.startswith("v_add_u32_sdwa") and "src1_sel:BYTE_0" in ln]
     assert at, "the walk over the symbol table was not found"
-    loop = [ln.split(None, 1)[0] for ln in lines[at[0] - 5:at[0] + 7]]
-    assert loop[:5] == ["ds_read_b32", "s_waitcnt", "ds_write_b32", "v_add_u32_e32", "v_readfirstlane_b32"], loop
-    assert loop[-1] == "s_cbranch_scc1" and len(loop) == 12
+    loop = [ln.split(None, 1)[0] for ln in lines[at[0] - 4:at[0] + 3]]
+    assert loop == ["ds_read_b32", "s_waitcnt", "ds_write_b32", "v_add_u32_e32", "v_add_u32_sdwa", "v_cmp_gt_u32_e32", "s_cbranch_vccnz"], loop
     for k in ("k_plan_segs", "k_group_ends", "k_island_flags", "k_island_fill", "k_island_lens", "k_island_offsets", "k_seg_island", "k_pieces_raw",
               "k_pieces_sorted", "k_tile_fill", "k_out_total", "k_out_raw", "k_out_sorted", "k_cchunk_count", "k_cchunk_fill", "k_gchunk_count",
               "k_gchunk_fill"):
