@@ -27,7 +27,7 @@ def reg2bin(beg, end):
     return 0
 
 
-def encode_record(tid, pos, cigartuples, flag, name=b"r", seq_len=None, mapq=30):
+def encode_record(tid, pos, cigartuples, flag, name=b"r", seq_len=None, mapq=30, aux=b""):
     qlen = sum(n for op, n in cigartuples if op in (0, 1, 4, 7, 8))
     if seq_len is None:
         seq_len = qlen
@@ -37,12 +37,13 @@ def encode_record(tid, pos, cigartuples, flag, name=b"r", seq_len=None, mapq=30)
     seq = bytes([0x11] * ((seq_len + 1) // 2))
     qual = bytes([0xff] * seq_len)
     body = struct.pack("<iiBBHHHIiii", tid, pos, len(name), mapq, reg2bin(pos, pos + max(ref_len, 1)), len(cigartuples),
-                       flag, seq_len, -1, -1, 0) + name + cig + seq + qual
+                       flag, seq_len, -1, -1, 0) + name + cig + seq + qual + aux
     return struct.pack("<I", len(body)) + body
 
 
 def write_bam(path, references, lengths, records, block_bytes=60000, header_text="@HD\tVN:1.6\tSO:coordinate\n", index=False):
-    """records: sequence of (tid, pos, cigartuples, flag); `index`: also write ``path + ".bai"``."""
+    """records: sequence of (tid, pos, cigartuples, flag) or (tid, pos, cigartuples, flag, aux bytes); `index`: also write
+    ``path + ".bai"``."""
     records = list(records)
     text = header_text.encode()
     out = b"BAM\x01" + struct.pack("<I", len(text)) + text + struct.pack("<I", len(references))
@@ -50,8 +51,9 @@ def write_bam(path, references, lengths, records, block_bytes=60000, header_text
         nmb = nm.encode() + b"\x00"
         out += struct.pack("<I", len(nmb)) + nmb + struct.pack("<I", ln)
     chunks = [out]
-    for i, (tid, pos, cig, flag) in enumerate(records):
-        chunks.append(encode_record(tid, pos, cig, flag, name=("r%d" % i).encode()))
+    for i, rec in enumerate(records):
+        tid, pos, cig, flag = rec[:4]
+        chunks.append(encode_record(tid, pos, cig, flag, name=("r%d" % i).encode(), aux=rec[4] if len(rec) > 4 else b""))
     data = b"".join(chunks)
     block_coff = []
     coff = 0
@@ -78,7 +80,7 @@ def write_bam(path, references, lengths, records, block_bytes=60000, header_text
     meta = [[None, None, 0, 0] for _ in range(nref)]
     n_no_coor = 0
     last = (None, None)
-    for (tid, pos, cig, flag), raw in zip(records, chunks[1:]):
+    for (tid, pos, cig, flag), raw in zip((r[:4] for r in records), chunks[1:]):
         beg, endv = voff(u), voff(u + len(raw))
         u += len(raw)
         if tid < 0:
@@ -450,3 +452,25 @@ def write_bam_realistic(path, packed, block_bytes=60000, level=1, threads=8, see
             fh.write(blk)
         fh.write(BGZF_EOF)
     return len(data)
+
+
+def odd_aux_records():
+    """Records whose auxiliary fields are unusual or damaged, and the NH value (0: none) a decoder must report for each:
+    what htslib's bam_aux_get walk does -- a field it cannot size ends the walk (bam_stager.cpp aux_nh, the same on the
+    device).  Returns (records for write_bam, expected nh)."""
+    nh_i = lambda v: b"NHi" + struct.pack("<i", v)
+    cases = [
+        (b"XZZno terminator" + nh_i(3), 0),                                    # a string that runs into the end of the record
+        (b"XBBs" + struct.pack("<I", 1 << 30) + b"\x01\x02" + nh_i(3), 0),        # an array longer than the record
+        (b"XQq\x01" + nh_i(3), 0),                                              # an unknown type
+        (b"XBBs" + struct.pack("<Ihhh", 3, -1, 2, 3) + b"XZZab\x00" + b"XFf" + struct.pack("<f", 1.5) + b"NHC\x02", 2),
+        (nh_i(-5), 0),                                                          # negative: none
+        (b"NHI" + struct.pack("<I", 4000000000), 65535),                        # clamped
+        (b"NHZ7\x00", 0),                                                       # not an integer
+        (b"XAAx" + b"NH", 0),                                                   # a tag cut off behind its name
+        (b"XHH1AFF\x00" + b"XBBC" + struct.pack("<I", 0) + b"NHs" + struct.pack("<h", 300), 300),   # hex string, empty array
+        (b"", 0),
+        (b"NHc\x7f", 127),
+    ]
+    recs = [(0, 100 + 10 * i, [(0, 30)], 16 if i % 2 else 0, aux) for i, (aux, _) in enumerate(cases)]
+    return recs, [nh for _, nh in cases]

@@ -290,6 +290,16 @@ def literal_only_dynamic_member(data):
     return header + cdata + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
 
 
+def test_odd_and_damaged_auxiliary_fields_on_the_device(eng, tmp_path):
+    """tests/bam_writer.odd_aux_records through the GPU decoder: the same NH column as the host decoder and as expected."""
+    recs, want = bam_writer.odd_aux_records()
+    path = str(tmp_path / "aux.bam")
+    bam_writer.write_bam(path, ["c"], [100000], recs)
+    got = read_bam_gpu(path, eng)
+    assert got.nh.tolist() == want
+    same(got, read_bam(path))
+
+
 def test_a_literal_only_block_with_an_empty_distance_code(eng, tmp_path):
     """zlib (inftrees.c: `max == 0`) and libdeflate accept a dynamic block whose one distance code has length zero;
     so does the host decoder, and so must the kernel's table builder."""

@@ -199,3 +199,17 @@ def test_htslib_bam_end_to_end_on_the_gpu(hts, bam_path):
         assert np.array_equal(got, exp), mapping
         plan.close()
     eng.close()
+
+
+def test_odd_and_damaged_auxiliary_fields_on_the_host(tmp_path):
+    """The NH walk over auxiliary fields it cannot size (an unterminated string, an array longer than the record, an unknown
+    type, a tag cut off) ends without a value instead of reading past the record; every integer type, negative and
+    oversized values, fields of every other kind before the tag (tests/bam_writer.odd_aux_records)."""
+    from tests import bam_writer
+    from plastid_amd.bam import read_bam
+    recs, want = bam_writer.odd_aux_records()
+    path = str(tmp_path / "aux.bam")
+    bam_writer.write_bam(path, ["c"], [100000], recs)
+    got = read_bam(path)
+    assert got.n == len(recs) and got.nh.tolist() == want
+    assert [got.read(i).has_tag("NH") for i in range(got.n)] == [bool(v) for v in want]
