@@ -1708,6 +1708,35 @@ __device__ __forceinline__ void gather_tile(const Tile &tl, const Piece *__restr
     }
 }
 
+// The compact histogram of a large plan is never cleared as a whole (C5: 4 GB, 0.6 ms of its first count): behind
+// k_tile_ranges -- whenever the lists of a plan were (re)built -- this kernel zeroes the slices of the windows the lists
+// merge (tile_items != 0); k_gather_split leaves them zero again after every count, and no other window's slice is ever
+// read.  Sixty-four windows per workgroup: merged windows are the exception.
+constexpr int kClearPerWG = 64;
+__global__ __launch_bounds__(kWG) void k_clear_split(const Tile *__restrict__ tiles, int ntiles, const Piece *__restrict__ pieces,
+                                                     const uint32_t *__restrict__ tile_items, const uint32_t *__restrict__ counters, int rows,
+                                                     uint32_t *hist, int64_t hist_row_stride) {
+    if (counters[4] == 0u) return;   // no window is merged
+    __shared__ uint32_t s_list[kClearPerWG];
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    const int t = (int)blockIdx.x * kClearPerWG + (int)threadIdx.x;
+    if ((int)threadIdx.x < kClearPerWG && t < ntiles && tile_items[t] != 0u) s_list[atomicAdd(&s_n, 1u)] = (uint32_t)t;
+    __syncthreads();
+    const uint32_t n = s_n;
+    for (uint32_t k = 0; k < n; ++k) {
+        const Tile tl = tiles[s_list[k]];
+        for (uint32_t pi = tl.piece_begin; pi < tl.piece_end; ++pi) {
+            const Piece pc_ = pieces[pi];
+            for (int r = 0; r < rows; ++r) {
+                uint32_t *dst = hist + (size_t)r * hist_row_stride + pc_.hist_off;
+                for (int i = threadIdx.x; i < pc_.len; i += kWG) dst[i] = 0u;
+            }
+        }
+    }
+}
+
 template <int OUTMODE>
 __global__ __launch_bounds__(kWG) void k_gather_split(const Tile *__restrict__ tiles, int ntiles, int per_wg,
                                                       const Piece *__restrict__ pieces,

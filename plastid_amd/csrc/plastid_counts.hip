@@ -547,6 +547,8 @@ struct Knobs {
     int64_t ranges_cg16_max = (int64_t)1 << 19;   // PC_RANGES_CG16_MAX: k_tile_ranges gives a window sixteen lanes while windows x 16 stays within this many threads
     int ranges_cg1 = 0;        // PC_RANGES_CG1: one thread per window in k_tile_ranges whatever the plan's size (tests compare the two forms)
     int64_t first_sync_spare = 65536;   // PC_FIRST_SYNC_SPARE: spare work-list slots from which the first count of a plan reads its item counts back before it launches
+    int hist_memset = 0;       // PC_HIST_MEMSET: the compact histogram of a large plan is cleared as a whole before its first count (round 5) instead of slice by slice
+    int64_t hist_lazy_bytes = (int64_t)64 << 20;   // PC_HIST_LAZY_BYTES: size from which it is cleared slice by slice (tests: 1)
     int no_stream_probe = 0;   // PC_NO_STREAM_PROBE: keep the engine's streams as created (see settle_streams)
     int no_single = 0;         // PC_NO_SINGLE: one-window plans go through the work lists like any other (tests compare the two paths)
     int plan_build = 0;        // PC_PLAN_BUILD=host|gpu: where pc_plan_create builds the tables (default: on the GPU from 8 192 segments)
@@ -569,6 +571,8 @@ struct Knobs {
         if (const char *env = getenv("PC_SMALL_ROWS")) small_rows = atoi(env);
         no_single = getenv("PC_NO_SINGLE") ? 1 : 0;
         no_stream_probe = getenv("PC_NO_STREAM_PROBE") ? 1 : 0;
+        hist_memset = getenv("PC_HIST_MEMSET") ? 1 : 0;
+        hist_lazy_bytes = getenv("PC_HIST_LAZY_BYTES") ? std::max<int64_t>(1, atoll(getenv("PC_HIST_LAZY_BYTES"))) : ((int64_t)64 << 20);
         ranges_cg1 = getenv("PC_RANGES_CG1") ? 1 : 0;
         ranges_cg16_max = getenv("PC_RANGES_CG16_MAX") ? atoll(getenv("PC_RANGES_CG16_MAX")) : ((int64_t)1 << 19);
         first_sync_spare = getenv("PC_FIRST_SYNC_SPARE") ? atoll(getenv("PC_FIRST_SYNC_SPARE")) : 65536;
@@ -686,7 +690,8 @@ struct pc_plan {
     DevBuf<GatherSeg> d_gsegs_own;
     bool has_sums = false;       // some slices are summed (out_step 0): the output is an accumulator
     bool out_needs_zero = false; // some queried positions lie outside every tile (unknown contig, clipped)
-    bool hist_clean = false;     // compact histogram known to be all zero (point-rule invariant)
+    bool hist_clean = false;     // compact histogram known to be all zero (point-rule invariant; `hist_lazy`: in the slices of the merged windows)
+    bool hist_lazy = false;      // the histogram is large: never cleared as a whole, k_clear_split runs behind every k_tile_ranges
     int hist_kind = -1;          // 0: holds uint32 zeros / merged point-rule windows; -1: freshly allocated, not cleared yet
     std::vector<CenterChunk> cchunks;
     std::vector<GatherSeg> gsegs;
@@ -2768,7 +2773,10 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
         return fail(PC_ERR_ARG, "pc_count: summed slices (out_step 0) need an integer mapping rule without normalisation");
     if ((p->has_sums || p->out_needs_zero || p->covered != p->out_elems) && p->out_elems)
         HIP_TRY(hipMemsetAsync(p->d_out.p, 0, (size_t)p->out_elems * 8, st));
-    if (!center && hist_bytes && !(p->hist_clean && p->hist_kind == 0)) {
+    // (a large histogram is not cleared as a whole: k_clear_split zeroes the slices of the merged windows behind every
+    // k_tile_ranges, which is all that is ever read of it)
+    p->hist_lazy = !center && (int64_t)hist_bytes >= e->knobs.hist_lazy_bytes && !e->knobs.hist_memset;
+    if (!center && hist_bytes && !(p->hist_clean && p->hist_kind == 0) && !p->hist_lazy) {
         HIP_TRY(hipMemsetAsync(p->d_hist.p, 0, hist_bytes, st));
     }
     if (e->prof_level >= 2) HIP_TRY(hipEventRecord(e->ev[1], st));
@@ -2873,6 +2881,9 @@ int pc_count(pc_engine *e, pc_plan *p, int out_dtype) {
                        p->d_work_small.p, small_g, small_n, e->knobs.debug_work, p->d_chain.p, p->d_chain_small.p, e->kind == PC_MAP_STRAT5 ? 1 : 0)
                 if (group16) PC_LAUNCH_RANGES(16); else PC_LAUNCH_RANGES(1);
 #undef PC_LAUNCH_RANGES
+                if (p->hist_lazy)
+                    hipLaunchKernelGGL(k_clear_split, dim3((unsigned)((ntiles + kClearPerWG - 1) / kClearPerWG)), dim3(kWG), 0, st, p->d_tiles.p, ntiles,
+                                       p->d_pieces.p, p->d_tile_items.p, p->d_wcounters.p, p->rows, (uint32_t *)p->d_hist.p, (int64_t)p->npos);
                 p->work_key = key;
                 p->work_valid = true;
                 p->work_counts_known = false;      // the counts of the lists just replaced size no grid

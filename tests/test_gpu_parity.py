@@ -358,6 +358,53 @@ def test_pileup_and_multifile(pa, oracle):
             eng.close()
 
 
+def test_compact_histogram_cleared_slice_by_slice(pa, oracle, monkeypatch):
+    """A large plan's compact histogram (what merged windows go through) is never cleared as a whole: k_clear_split zeroes
+    the slices of the merged windows behind every k_tile_ranges, k_gather_split leaves them zero after every count.  With
+    PC_HIST_LAZY_BYTES=1 a small plan takes that path: a plan whose device block comes back from the pool dirty (a plan of
+    the same size was counted and closed before), several counts of one plan, and the SAME plan after the engine's
+    alignments changed under it (the lists are rebuilt, other windows are merged) -- against the oracle every time."""
+    rng = np.random.default_rng(77)
+    names, lens = ["a"], [200000]
+
+    def piled(at, n=250000):
+        pos = np.sort(np.concatenate([rng.integers(at, at + 40, n - 50000), rng.integers(0, 190000, 50000)]))
+        return pa.PackedAlignments.from_ungapped(np.zeros(n, np.int32), pos, rng.integers(20, 40, n), rng.random(n) < 0.5,
+                                                 references=names, lengths=lens)
+    f_a, f_b = piled(5000), piled(90000)
+    seg_start = np.array([0, 4000, 89000, 5000, 90010], np.int64)
+    seg_end = np.array([200000, 7000, 92000, 5040, 90011], np.int64)
+    seg_tid = np.zeros(len(seg_start), np.int32)
+    seg_strand = np.array([1, 2, 3, 3, 1], np.uint8)
+    lens_ = seg_end - seg_start
+    out_off = np.concatenate([[0], np.cumsum(lens_)[:-1]])
+    monkeypatch.setenv("PC_WORK_R", "512")
+    monkeypatch.setenv("PC_PILE", "2048")
+    mapping = ("fiveprime", 3)
+    spec = spec_for(oracle, mapping, None)
+    expected = {}
+    for key, files in (("a", [f_a]), ("b", [f_b]), ("ab", [f_a, f_b])):
+        expected[key] = np.concatenate(oracle.count_segments(aln_dict(files), spec, seg_tid, seg_start, seg_end, seg_strand)[0])
+        assert expected[key].max() > 3000                         # (the piles are there)
+    for lazy in ("1", None):
+        if lazy: monkeypatch.setenv("PC_HIST_LAZY_BYTES", lazy)
+        else: monkeypatch.delenv("PC_HIST_LAZY_BYTES", raising=False)
+        eng = engine_for(pa, [f_a], mapping, None)
+
+        def mk():
+            return eng.plan(seg_tid, seg_start, seg_end, seg_strand, out_off, np.ones(len(lens_), np.int8), lens_, int(lens_.sum()), 1)
+        dirty = mk(); dirty.count(np.int64); dirty.close()        # its block goes back to the pool with whatever the count left
+        plan = mk()
+        for key, files in (("a", None), ("b", [f_b]), ("a", [f_a]), ("ab", [f_a, f_b]), ("b", [f_b])):
+            if files is not None:
+                eng.clear_alignments()
+                eng.set_alignments(files)                         # under the plan: its lists are rebuilt at the next count
+            for _ in range(2):
+                assert np.array_equal(plan.count(np.int64), expected[key]), (lazy, key)
+        plan.close()
+        eng.close()
+
+
 def test_long_aligned_lengths(pa, oracle):
     """Ungapped reads too long for the 4-byte record stream (L > 255) are binned from the side
     list, and those longer than the window halo through the long-span path; short-only data stays
