@@ -703,6 +703,13 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
     int64_t wlo = 0, whi = 0, wglo = 0, wghi = 0, llo = 0, lhi = 0, wrlo = 0, wrhi = 0;
     uint32_t n_heavy = 0, n_light = 0, n_small = 0;
     bool merge = false;
+    // CG == 16, one file, a window cut into sub-windows: the sixteen lanes of the group share the sub-windows (lane g looks
+    // at sub-windows g and g + 16: their bounds are a dozen dependent index reads each, which one lane would do one
+    // sub-window after the other -- C2's 5 922 dense windows: 79 of the first count's 270 us); `sub_heavy[j]`: which of the
+    // group's sub-windows g + 16 j are heavy items, bit g
+    bool shared_subs = false;
+    uint32_t sub_heavy[2] = {0u, 0u};
+    const int group_shift = (int)(threadIdx.x & 48u);   // the group's first lane in its wave
     // ranges of file `ff` for the window part [a, e) (a: first queried position, e: behind the last one)
     auto file_ranges = [&](int ff, int32_t tidx, int64_t a, int64_t e, int64_t s_lo, int64_t s_hi, FileRange &r) {
         const GFile g = ff == 0 ? gfile(file0) : gfile(files[ff]);
@@ -863,20 +870,38 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
                 else if (small) n_small = 1; else if (n > R) n_heavy = 1; else n_light = 1;
             } else {
                 const int sub = G / S;
-                for (int k = 0; k < S; ++k) {
+                // what sub-window k scans: `mrg` -- it has to be merged; returns whether it is a heavy item
+                auto sub_class = [&](int k, bool &mrg) -> bool {
                     const int64_t a = ws + (int64_t)k * sub;
                     // (the very range the item below gets -- exact lower bound for short sub-windows: the class counts must agree with it)
                     const int64_t lo_k = sub <= kExactSpan ? lin_exact<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, l0, nb, a - Ws + 1)
                                                            : lin_floor(fv.lin_tab, l0, nb, a - Ws + 1);
                     int64_t nk = lin_floor(fv.lin_tab, l0, nb, a + sub) - lo_k;
                     if (nk < 0) nk = 0;
-                    if (nk > pile) merge = true; // a pile-up inside one sub-window
+                    if (nk > pile) mrg = true; // a pile-up inside one sub-window
                     if (b16) {   // ... or a sub-window that would add more than a 16-bit bin holds (its runs and list entries counted in, by their widest bounds)
                         const int64_t gk = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, a + sub) - lin_floor(fv.glin_tab, l0, nb, a - W + 1) : 0;
                         const int64_t rk = fv.nrunrec ? lin_floor(fv.rlin_tab, l0, nb, a + sub) - lin_floor(fv.rlin_tab, l0, nb, a - Wr + 1) : 0;
-                        if (nk + gk + rk + (lhi - llo) > kMax16) merge = true;
+                        if (nk + gk + rk + (lhi - llo) > kMax16) mrg = true;
                     }
-                    if (nk > R) ++n_heavy; else ++n_light;
+                    return nk > R;
+                };
+                if (CG == 16) {
+                    bool mrg = false, hv[2] = {false, false};
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (gsub + 16 * j < S) hv[j] = sub_class(gsub + 16 * j, mrg);
+                    // (the sixteen lanes of a group are here together: same window, same S)
+                    merge = ((__ballot(mrg) >> group_shift) & 0xffffull) != 0ull;
+                    sub_heavy[0] = (uint32_t)((__ballot(hv[0]) >> group_shift) & 0xffffull);
+                    sub_heavy[1] = (uint32_t)((__ballot(hv[1]) >> group_shift) & 0xffffull);
+                    n_heavy = (uint32_t)__popc(sub_heavy[0]) + (uint32_t)__popc(sub_heavy[1]);
+                    n_light = (uint32_t)S - n_heavy;
+                    shared_subs = !merge;
+                } else {
+                    for (int k = 0; k < S; ++k) {
+                        if (sub_class(k, merge)) ++n_heavy; else ++n_light;
+                    }
                 }
             }
         }
@@ -903,7 +928,7 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         s_base[2] = tot_s ? atomicAdd(&nwork[2], tot_s) : 0u;
     }
     __syncthreads();
-    if (!(n_heavy + n_light + n_small)) return;
+    if (!(n_heavy + n_light + n_small) && !shared_subs) return;
     if (joint) {
         WorkItem w;
         w.tile = (uint32_t)t;
@@ -997,6 +1022,39 @@ __global__ __launch_bounds__(kRangesWG) void k_tile_ranges(const Tile *__restric
         return;
     }
     const int sub = G / S;
+    if (shared_subs) {   // the group's lanes write the items of their own sub-windows, in the slots the one-lane loop below would give them
+        const uint32_t ih0 = s_base[0] + (uint32_t)__shfl((int)off_h, group_shift, 64), il0 = s_base[1] + (uint32_t)__shfl((int)off_l, group_shift, 64);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = gsub + 16 * j;
+            if (k >= S) continue;
+            const int64_t a = ws + (int64_t)k * sub, e = a + sub;
+            if (sub <= kExactSpan) {
+                w.lo = lin_exact<2>((const uint32_t PC_GLOBAL *)fv.rec, fv.lin_tab, l0, nb, a - Ws + 1);
+                w.hi = lin_floor(fv.lin_tab, l0, nb, e);
+                w.rlo = fv.nrunrec ? (uint32_t)lin_exact<2>((const uint32_t PC_GLOBAL *)fv.run_rec, fv.rlin_tab, l0, nb, a - Wr + 1) : 0u;
+                w.rhi = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, e) : 0u;
+                if (w.hi < w.lo) w.hi = w.lo;
+                if (w.rhi < w.rlo) w.rhi = w.rlo;
+            } else {
+                w.lo = lin_floor(fv.lin_tab, l0, nb, a - Ws + 1);
+                w.hi = lin_floor(fv.lin_tab, l0, nb, e);
+                w.rlo = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, a - Wr + 1) : 0u;
+                w.rhi = fv.nrunrec ? (uint32_t)lin_floor(fv.rlin_tab, l0, nb, e) : 0u;
+            }
+            w.glo = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, a - W + 1) : 0;
+            w.ghi = fv.ngap ? lin_floor(fv.glin_tab, l0, nb, e) : 0;
+            w.llo = llo; w.lhi = lhi;
+            w.sub_lo = k * sub;
+            w.sub_hi = w.sub_lo + sub;
+            const uint32_t below = (1u << gsub) - 1u;
+            const uint32_t heavy_before = j == 0 ? (uint32_t)__popc(sub_heavy[0] & below) : (uint32_t)__popc(sub_heavy[0]) + (uint32_t)__popc(sub_heavy[1] & below);
+            const bool heavy = ((sub_heavy[j] >> gsub) & 1u) != 0u;
+            const uint32_t slot = heavy ? ih0 + heavy_before : work_cap - 1u - (il0 + ((uint32_t)k - heavy_before));
+            if (slot < work_cap) work[slot] = w; // capacity is an upper bound; the test is defensive
+        }
+        return;
+    }
     for (int k = 0; k < S; ++k) {
         const int64_t a = S == 1 ? ws + tl.span_lo : ws + (int64_t)k * sub;
         const int64_t e = S == 1 ? ws + tl.span_hi + (1 << kLinShift) - 1 : a + sub;

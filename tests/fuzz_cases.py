@@ -12,7 +12,7 @@ import warnings
 import numpy as np
 
 NOFILTER = 0x10
-KNOBS = ("PC_TILE_G", "PC_WORK_R", "PC_PILE", "PC_NO_SMALL", "PC_STAGE_SLICE", "PC_HIST_LAZY_BYTES")
+KNOBS = ("PC_TILE_G", "PC_WORK_R", "PC_PILE", "PC_NO_SMALL", "PC_STAGE_SLICE", "PC_HIST_LAZY_BYTES", "PC_RANGES_CG1")
 
 
 def random_file(rng, pa, names, lens, n, max_len, p_gapped, p_long_gap, pile):
@@ -146,6 +146,8 @@ def random_case(seed, pa, size="small"):
         knobs["PC_STAGE_SLICE"] = str((1, 2, 5, 64)[(seed // 2) % 4])   # the cases of earlier revisions stay the same)
     if seed % 3 == 1:   # the compact histogram cleared slice by slice (k_clear_split), as for plans of 64 MB and more (not drawn from rng)
         knobs["PC_HIST_LAZY_BYTES"] = "1"
+    if seed % 5 == 2:   # one lane per window in k_tile_ranges, as for large plans (small plans: sixteen, sharing a cut window's sub-windows)
+        knobs["PC_RANGES_CG1"] = "1"
     layout = str(rng.choice(["forward", "reversed", "mixed", "sums"]))
     if kind == "center" and layout == "sums":
         layout = "mixed"
